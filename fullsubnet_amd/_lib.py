@@ -1,0 +1,140 @@
+"""ctypes binding of libfsn_hip.so (include/fsn_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, the caller
+gets an exception.  PyTorch is used for device memory and streams only.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfsn_hip.so")
+
+NORM_TYPES = {"offline_laplace_norm": 0, "cumulative_laplace_norm": 1}
+
+_f32p = ctypes.c_void_p
+_lib = None
+
+
+class FsnError(RuntimeError):
+    pass
+
+
+class Cfg(ctypes.Structure):
+    _fields_ = [("num_freqs", ctypes.c_int), ("look_ahead", ctypes.c_int), ("sb_num_neighbors", ctypes.c_int),
+                ("fb_hidden", ctypes.c_int), ("sb_hidden", ctypes.c_int), ("norm_type", ctypes.c_int)]
+
+
+PARAM_FIELDS = [
+    "fb_w_ih_l0", "fb_w_hh_l0", "fb_b_ih_l0", "fb_b_hh_l0", "fb_w_ih_l1", "fb_w_hh_l1", "fb_b_ih_l1", "fb_b_hh_l1",
+    "fb_fc_w", "fb_fc_b",
+    "sb_w_ih_l0", "sb_w_hh_l0", "sb_b_ih_l0", "sb_b_hh_l0", "sb_w_ih_l1", "sb_w_hh_l1", "sb_b_ih_l1", "sb_b_hh_l1",
+    "sb_fc_w", "sb_fc_b",
+]
+# reference state_dict key of each field
+STATE_KEYS = [
+    "fb_model.sequence_model.weight_ih_l0", "fb_model.sequence_model.weight_hh_l0",
+    "fb_model.sequence_model.bias_ih_l0", "fb_model.sequence_model.bias_hh_l0",
+    "fb_model.sequence_model.weight_ih_l1", "fb_model.sequence_model.weight_hh_l1",
+    "fb_model.sequence_model.bias_ih_l1", "fb_model.sequence_model.bias_hh_l1",
+    "fb_model.fc_output_layer.weight", "fb_model.fc_output_layer.bias",
+    "sb_model.sequence_model.weight_ih_l0", "sb_model.sequence_model.weight_hh_l0",
+    "sb_model.sequence_model.bias_ih_l0", "sb_model.sequence_model.bias_hh_l0",
+    "sb_model.sequence_model.weight_ih_l1", "sb_model.sequence_model.weight_hh_l1",
+    "sb_model.sequence_model.bias_ih_l1", "sb_model.sequence_model.bias_hh_l1",
+    "sb_model.fc_output_layer.weight", "sb_model.fc_output_layer.bias",
+]
+
+
+class Params(ctypes.Structure):
+    _fields_ = [(n, _f32p) for n in PARAM_FIELDS]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/fsn_hip.h
+_c = ctypes
+SIGNATURES = {
+    "fsn_last_error": (_c.c_char_p, []),
+    "fsn_version": (_c.c_int, []),
+    "fsn_stft": (_c.c_int, [_f32p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _f32p, _f32p, _f32p, _f32p,
+                            _c.c_void_p]),
+    "fsn_istft_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
+    "fsn_istft": (_c.c_int, [_f32p, _f32p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_int, _f32p,
+                             _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "fsn_decompress_cirm": (_c.c_int, [_f32p, _f32p, _c.c_size_t, _c.c_void_p]),
+    "fsn_compress_cirm": (_c.c_int, [_f32p, _f32p, _c.c_size_t, _c.c_void_p]),
+    "fsn_build_cirm": (_c.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _c.c_size_t, _c.c_void_p]),
+    "fsn_fullsubnet_packed_bytes": (_c.c_size_t, [_c.POINTER(Cfg)]),
+    "fsn_fullsubnet_pack": (_c.c_int, [_c.POINTER(Cfg), _c.POINTER(Params), _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "fsn_fullsubnet_workspace_bytes": (_c.c_size_t, [_c.POINTER(Cfg), _c.c_int, _c.c_int]),
+    "fsn_fullsubnet_forward": (_c.c_int, [_c.POINTER(Cfg), _c.c_void_p, _f32p, _c.c_int, _c.c_int, _f32p, _c.c_void_p,
+                                          _c.c_size_t, _c.c_void_p]),
+    "fsn_enhance_workspace_bytes": (_c.c_size_t, [_c.POINTER(Cfg), _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "fsn_enhance": (_c.c_int, [_c.POINTER(Cfg), _c.c_void_p, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                               _f32p, _f32p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "fsn_profile_enable": (_c.c_int, [_c.c_int]),
+    "fsn_profile_num_stages": (_c.c_int, []),
+    "fsn_profile_stage_name": (_c.c_char_p, [_c.c_int]),
+    "fsn_profile_read": (_c.c_int, [_c.POINTER(_c.c_float), _c.c_int]),
+}
+
+
+def lib():
+    """Load (once) and return the HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FsnError(
+                f"{LIB_PATH} is missing: build it with `python -m fullsubnet_amd.build` (hipcc, gfx950). "
+                "There is no CPU / PyTorch fallback for this path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the ABI drifted from include/fsn_hip.h
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise FsnError(f"libfsn_hip error {rc}: {lib().fsn_last_error().decode()}")
+
+
+def dev_ptr(t, name="tensor", allow_none=False):
+    """Validated raw device pointer of a contiguous fp32 ROCm tensor."""
+    if t is None:
+        if allow_none:
+            return None
+        raise FsnError(f"{name} is None")
+    if not t.is_cuda:
+        raise FsnError(f"{name} must live on a ROCm device (got {t.device}); this path has no CPU implementation")
+    if t.dtype != torch.float32:
+        raise FsnError(f"{name} must be float32 (got {t.dtype})")
+    if not t.is_contiguous():
+        raise FsnError(f"{name} must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def workspace(nbytes, device):
+    """Workspace from PyTorch's caching allocator (the library never allocates)."""
+    if nbytes <= 0:
+        raise FsnError(f"workspace query failed: {lib().fsn_last_error().decode()}")
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def profile_stage_names():
+    L = lib()
+    return [L.fsn_profile_stage_name(i).decode() for i in range(L.fsn_profile_num_stages())]
+
+
+def profile_read():
+    L = lib()
+    n = L.fsn_profile_num_stages()
+    buf = (ctypes.c_float * n)()
+    check(L.fsn_profile_read(buf, n))
+    return dict(zip(profile_stage_names(), list(buf)))

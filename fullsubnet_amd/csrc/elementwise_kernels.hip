@@ -1,0 +1,210 @@
+// Streaming (HBM-bound) kernels of the path: cIRM algebra, layout changes at the API boundary and
+// the normalisation statistics.  All fp32 unless stated; written without fma contraction so that
+// the elementwise results follow the reference's operation order.
+#include "fsn_common.h"
+
+namespace {
+
+// ---- audio_zen/acoustics/mask.py ------------------------------------------------------------
+__device__ __forceinline__ float decompress1(float m) {  // mask.py:47-64, K = 10, limit = 9.9
+    const float lim = 9.9f;
+    m = m >= lim ? lim : (m <= -lim ? -lim : m);
+    return -10.0f * logf((10.0f - m) / (10.0f + m));
+}
+__device__ __forceinline__ float compress1(float m) {  // mask.py:32-44, K = 10, C = 0.1
+    m = m <= -100.0f ? -100.0f : m;
+    const float e = expf(-0.1f * m);
+    return 10.0f * (1.0f - e) / (1.0f + e);
+}
+
+__global__ void decompress_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = decompress1(in[i]);
+}
+__global__ void compress_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = compress1(in[i]);
+}
+// mask.py:7-29
+__global__ void build_cirm_kernel(const float* __restrict__ nr, const float* __restrict__ ni,
+                                  const float* __restrict__ cr, const float* __restrict__ ci,
+                                  float* __restrict__ out, size_t n) {
+    const float eps = 1.1920928955078125e-07f;  // audio_zen/constant.py:9
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float a = nr[i], b = ni[i], c = cr[i], d = ci[i];
+        const float den = a * a + b * b + eps;
+        const float mr = (a * c + b * d) / den;
+        const float mi = (a * d - b * c) / den;
+        f32x2 o = {compress1(mr), compress1(mi)};
+        *reinterpret_cast<f32x2*>(out + 2 * i) = o;
+    }
+}
+
+// ---- batched 2-D transpose with zero fill: out[b][c][r] = in[b][r][c] ----------------------
+// (r < R_valid, c < C_valid come from `in`, the rest of the R x C output tile is zero)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        int R, int C, long ld_in, long bs_in, long ld_out,
+                                                        long bs_out, int R_valid, int C_valid) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R_valid && c < C_valid) ? in[b * bs_in + r * ld_in + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) out[b * bs_out + c * ld_out + r] = tile[tx][i];
+    }
+}
+
+// ---- normalisation statistics ---------------------------------------------------------------
+// binsum[b][f] = sum_t mag[b][t][f], fp64 accumulation, fixed order (deterministic).
+__global__ __launch_bounds__(256) void binsum_kernel(const float* __restrict__ mag, double* __restrict__ binsum,
+                                                     int Tp, int FP) {
+    const int b = blockIdx.y;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= FP) return;
+    const float* p = mag + (long)b * Tp * FP + f;
+    double acc = 0.0;
+    for (int t = 0; t < Tp; ++t) acc += (double)p[(long)t * FP];
+    binsum[(long)b * FP + f] = acc;
+}
+
+// reflect(j) of F.pad(mode="reflect") for j in [-N, F+N)
+__device__ __forceinline__ int reflect_idx(int j, int F) {
+    j = j < 0 ? -j : j;
+    return j >= F ? 2 * (F - 1) - j : j;
+}
+
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += scratch[w];
+    return tot;
+}
+
+// offline_laplace_norm (base_model.py:204-218): one mean per utterance, eps 1e-5.
+//   which == 0: den_fb[b] = mean_{f,t}(mag) + 1e-5                        (fullsubnet/model.py:92)
+//   which == 1: den_sb[b] = mean over the concatenated [F, 2nb+2, Tp] sub-band tensor + 1e-5
+//               (model.py:110-111) = (sum_f m[f] binsum[f] + sum fb_out) / (F (2nb+2) Tp) with
+//               m[f] = number of (unit, row) pairs of freq_unfold (base_model.py:31-44) hitting bin f.
+__global__ __launch_bounds__(256) void offline_den_kernel(const double* __restrict__ binsum,
+                                                          const float* __restrict__ fb_out,
+                                                          float* __restrict__ den_fb, float* __restrict__ den_sb,
+                                                          int Tp, int F, int FP, int nb, int which) {
+    __shared__ double scratch[4];
+    const int b = blockIdx.x;
+    double acc = 0.0;
+    if (which == 0) {
+        for (int f = threadIdx.x; f < F; f += blockDim.x) acc += binsum[(long)b * FP + f];
+        const double tot = block_sum(acc, scratch);
+        if (threadIdx.x == 0) den_fb[b] = (float)(tot / ((double)F * Tp)) + 1e-5f;
+    } else {
+        for (int f = threadIdx.x; f < F; f += blockDim.x) {
+            int m = 0;
+            for (int u = max(0, f - 2 * nb); u <= min(F - 1, f + 2 * nb); ++u)
+                for (int k = -nb; k <= nb; ++k) m += (reflect_idx(u + k, F) == f) ? 1 : 0;
+            acc += (double)m * binsum[(long)b * FP + f];
+        }
+        const float* p = fb_out + (long)b * Tp * FP;
+        for (long i = threadIdx.x; i < (long)Tp * FP; i += blockDim.x) {
+            const int f = (int)(i % FP);
+            if (f < F) acc += (double)p[i];
+        }
+        const double tot = block_sum(acc, scratch);
+        if (threadIdx.x == 0) den_sb[b] = (float)(tot / ((double)F * (2 * nb + 2) * Tp)) + 1e-5f;
+    }
+}
+
+// cumulative_laplace_norm (base_model.py:221-251) for the full-band input [B,1,F,Tp]:
+// den[b][t] = (sum_{tau<=t} sum_f mag[b][tau][f]) / (F (t+1)) + EPSILON.  One block per utterance.
+__global__ __launch_bounds__(256) void cumulative_den_fb_kernel(const float* __restrict__ mag,
+                                                                float* __restrict__ den, int Tp, int F, int FP) {
+    __shared__ double scratch[4];
+    const int b = blockIdx.x;
+    double run = 0.0;
+    for (int t = 0; t < Tp; ++t) {
+        double acc = 0.0;
+        for (int f = threadIdx.x; f < F; f += blockDim.x) acc += (double)mag[((long)b * Tp + t) * FP + f];
+        run += block_sum(acc, scratch);
+        if (threadIdx.x == 0)
+            den[(long)b * Tp + t] = (float)(run / ((double)F * (t + 1))) + 1.1920928955078125e-07f;
+    }
+}
+
+// cumulative_laplace_norm on the 4-D sub-band tensor [B, F, 2nb+2, Tp] (quirk Q4): every unit
+// (b, f) is its own "batch" entry with 2nb+2 "frequencies":
+// den[t][n] = (sum_{tau<=t} (sum_k mag[b][tau][refl(f+k)] + fb_out[b][tau][f])) / ((2nb+2)(t+1)) + EPS
+// with n = b F + f; stored [Tp][Npad] to match the row order of the input projection.
+__global__ __launch_bounds__(256) void cumulative_den_sb_kernel(const float* __restrict__ mag,
+                                                                const float* __restrict__ fb_out,
+                                                                float* __restrict__ den, int B, int Tp, int F,
+                                                                int FP, int nb, int Npad) {
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= (long)B * F) return;
+    const int b = (int)(n / F), f = (int)(n % F);
+    double run = 0.0;
+    for (int t = 0; t < Tp; ++t) {
+        const float* row = mag + ((long)b * Tp + t) * FP;
+        double acc = (double)fb_out[((long)b * Tp + t) * FP + f];
+        for (int k = -nb; k <= nb; ++k) acc += (double)row[reflect_idx(f + k, F)];
+        run += acc;
+        den[(long)t * Npad + n] = (float)(run / ((double)(2 * nb + 2) * (t + 1))) + 1.1920928955078125e-07f;
+    }
+}
+
+}  // namespace
+
+static unsigned ew_grid(size_t n) {
+    size_t g = (n + 255) / 256;
+    return (unsigned)(g < 2048 ? (g ? g : 1) : 2048);
+}
+
+int fsn_launch_decompress(const float* in, float* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(decompress_kernel, dim3(ew_grid(n)), dim3(256), 0, s, in, out, n);
+    return fsn_check_launch("decompress_kernel");
+}
+int fsn_launch_compress(const float* in, float* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(compress_kernel, dim3(ew_grid(n)), dim3(256), 0, s, in, out, n);
+    return fsn_check_launch("compress_kernel");
+}
+int fsn_launch_build_cirm(const float* nr, const float* ni, const float* cr, const float* ci, float* out, size_t n,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(build_cirm_kernel, dim3(ew_grid(n)), dim3(256), 0, s, nr, ni, cr, ci, out, n);
+    return fsn_check_launch("build_cirm_kernel");
+}
+int fsn_launch_transpose(const float* in, float* out, int batch, int R, int C, long ld_in, long bs_in, long ld_out,
+                         long bs_out, int R_valid, int C_valid, hipStream_t s) {
+    dim3 grid((C + 31) / 32, (R + 31) / 32, batch);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, out, R, C, ld_in, bs_in, ld_out, bs_out, R_valid,
+                       C_valid);
+    return fsn_check_launch("transpose_kernel");
+}
+int fsn_launch_binsum(const float* mag, double* binsum, int B, int Tp, int FP, hipStream_t s) {
+    hipLaunchKernelGGL(binsum_kernel, dim3((FP + 255) / 256, B), dim3(256), 0, s, mag, binsum, Tp, FP);
+    return fsn_check_launch("binsum_kernel");
+}
+int fsn_launch_offline_den(const double* binsum, const float* fb_out, float* den_fb, float* den_sb, int B, int Tp,
+                           int F, int FP, int nb, int which, hipStream_t s) {
+    hipLaunchKernelGGL(offline_den_kernel, dim3(B), dim3(256), 0, s, binsum, fb_out, den_fb, den_sb, Tp, F, FP, nb,
+                       which);
+    return fsn_check_launch("offline_den_kernel");
+}
+int fsn_launch_cumulative_den_fb(const float* mag, float* den, int B, int Tp, int F, int FP, hipStream_t s) {
+    hipLaunchKernelGGL(cumulative_den_fb_kernel, dim3(B), dim3(256), 0, s, mag, den, Tp, F, FP);
+    return fsn_check_launch("cumulative_den_fb_kernel");
+}
+int fsn_launch_cumulative_den_sb(const float* mag, const float* fb_out, float* den, int B, int Tp, int F, int FP,
+                                 int nb, int Npad, hipStream_t s) {
+    const long n = (long)B * F;
+    hipLaunchKernelGGL(cumulative_den_sb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mag, fb_out, den,
+                       B, Tp, F, FP, nb, Npad);
+    return fsn_check_launch("cumulative_den_sb_kernel");
+}

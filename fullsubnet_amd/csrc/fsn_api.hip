@@ -1,0 +1,571 @@
+// C ABI of libfsn_hip.so (see include/fsn_hip.h): argument validation, workspace carving and the
+// kernel sequence of the FullSubNet enhancement path.  No allocation, no host synchronisation and
+// no global state on the hot path (the optional per-stage profiler owns a few hipEvents).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "fsn_common.h"
+
+// ---- errors ---------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void fsn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int fsn_check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        fsn_set_error("%s: %s", what, hipGetErrorString(e));
+        return FSN_ERR_LAUNCH;
+    }
+    return FSN_OK;
+}
+extern "C" const char* fsn_last_error(void) { return g_err; }
+extern "C" int fsn_version(void) { return 100; }
+
+#define FSN_TRY(x)                \
+    do {                          \
+        const int _rc = (x);      \
+        if (_rc != FSN_OK) return _rc; \
+    } while (0)
+
+// ---- per-stage profiler ----------------------------------------------------------------------
+enum Stage {
+    ST_STFT = 0,
+    ST_NORM,
+    ST_FB_GEMM,
+    ST_FB_REC,
+    ST_SB_GEMM_L0,
+    ST_SB_REC_L0,
+    ST_SB_GEMM_L1,
+    ST_SB_REC_L1,
+    ST_SB_FC,
+    ST_MASK_ISTFT,
+    ST_COUNT
+};
+static const char* kStageNames[ST_COUNT] = {"stft",       "norm",       "fb_gemm",    "fb_rec", "sb_gemm_l0",
+                                            "sb_rec_l0",  "sb_gemm_l1", "sb_rec_l1",  "sb_fc",  "mask_istft"};
+static int g_prof_on = 0;
+static hipEvent_t g_ev[2 * ST_COUNT];
+static bool g_ev_made = false;
+static bool g_ev_used[ST_COUNT];
+static float g_ms_acc[ST_COUNT];
+
+struct StageTimer {
+    int st;
+    hipStream_t s;
+    StageTimer(int stage, hipStream_t stream) : st(stage), s(stream) {
+        if (!g_prof_on) return;
+        if (!g_ev_made) {
+            for (int i = 0; i < 2 * ST_COUNT; ++i) hipEventCreate(&g_ev[i]);
+            g_ev_made = true;
+        }
+        if (g_ev_used[st]) {  // stage re-entered (fb_gemm / fb_rec run once per layer): fold the previous span
+            float ms = 0.f;
+            hipEventSynchronize(g_ev[2 * st + 1]);
+            hipEventElapsedTime(&ms, g_ev[2 * st], g_ev[2 * st + 1]);
+            g_ms_acc[st] += ms;
+        }
+        hipEventRecord(g_ev[2 * st], s);
+    }
+    ~StageTimer() {
+        if (!g_prof_on) return;
+        hipEventRecord(g_ev[2 * st + 1], s);
+        g_ev_used[st] = true;
+    }
+};
+static void prof_reset() {
+    for (int i = 0; i < ST_COUNT; ++i) {
+        g_ev_used[i] = false;
+        g_ms_acc[i] = 0.f;
+    }
+}
+extern "C" int fsn_profile_enable(int on) {
+    g_prof_on = on ? 1 : 0;
+    prof_reset();
+    return FSN_OK;
+}
+extern "C" int fsn_profile_num_stages(void) { return ST_COUNT; }
+extern "C" const char* fsn_profile_stage_name(int stage) {
+    return (stage >= 0 && stage < ST_COUNT) ? kStageNames[stage] : "";
+}
+extern "C" int fsn_profile_read(float* ms, int n) {
+    if (!ms || n < ST_COUNT) {
+        fsn_set_error("fsn_profile_read: need room for %d stages", (int)ST_COUNT);
+        return FSN_ERR_ARG;
+    }
+    for (int i = 0; i < ST_COUNT; ++i) {
+        float v = g_ms_acc[i];
+        if (g_prof_on && g_ev_used[i]) {
+            float e = 0.f;
+            hipEventSynchronize(g_ev[2 * i + 1]);
+            hipEventElapsedTime(&e, g_ev[2 * i], g_ev[2 * i + 1]);
+            v += e;
+        }
+        ms[i] = v;
+    }
+    return FSN_OK;
+}
+
+// ---- workspace carving -----------------------------------------------------------------------
+struct Carver {
+    char* base;
+    size_t off;
+    explicit Carver(void* p) : base(static_cast<char*>(p)), off(0) {}
+    template <class T>
+    T* take(size_t count) {
+        off = fsn_round_up_sz(off, 256);
+        T* r = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return r;
+    }
+};
+
+static int check_cfg(const fsn_fullsubnet_cfg* cfg) {
+    FSN_REQUIRE(cfg != nullptr, "cfg is NULL");
+    FSN_REQUIRE(cfg->num_freqs >= 17 && cfg->num_freqs <= 4096, "num_freqs %d out of range", cfg->num_freqs);
+    FSN_REQUIRE(cfg->look_ahead >= 0, "look_ahead %d < 0", cfg->look_ahead);
+    FSN_REQUIRE(cfg->sb_num_neighbors >= 0 && cfg->sb_num_neighbors < cfg->num_freqs,
+                "sb_num_neighbors %d must be in [0, num_freqs) (reflect padding)", cfg->sb_num_neighbors);
+    FSN_REQUIRE(cfg->fb_hidden > 0 && cfg->fb_hidden % 64 == 0, "fb_hidden %d must be a multiple of 64",
+                cfg->fb_hidden);
+    FSN_REQUIRE(cfg->sb_hidden == 384, "sb_hidden %d unsupported (the sub-band recurrent kernel is built for 384)",
+                cfg->sb_hidden);
+    FSN_REQUIRE(cfg->norm_type == FSN_NORM_OFFLINE_LAPLACE || cfg->norm_type == FSN_NORM_CUMULATIVE_LAPLACE,
+                "norm_type %d unsupported", cfg->norm_type);
+    return FSN_OK;
+}
+
+// ---- packed weights --------------------------------------------------------------------------
+struct Packed {  // float offsets into the packed blob
+    size_t fb_wih0, fb_whh0, fb_b0, fb_wih1, fb_whh1, fb_b1, fb_fc, fb_fcb;
+    size_t sb_wih0, sb_whh0, sb_b0, sb_wih1, sb_whh1, sb_b1, sb_fc, sb_fcb;
+    size_t total;
+    int FP, sb_kin_pad;
+};
+static Packed packed_layout(const fsn_fullsubnet_cfg* c) {
+    Packed p;
+    size_t o = 0;
+    auto take = [&](size_t n) {
+        o = fsn_round_up_sz(o, 64);
+        const size_t r = o;
+        o += n;
+        return r;
+    };
+    const size_t Hf = c->fb_hidden, Hs = c->sb_hidden;
+    p.FP = fsn_fpad(c->num_freqs);
+    p.sb_kin_pad = fsn_round_up(2 * c->sb_num_neighbors + 2, 16);
+    p.fb_wih0 = take(4 * Hf * p.FP);
+    p.fb_whh0 = take(4 * Hf * Hf);
+    p.fb_b0 = take(4 * Hf);
+    p.fb_wih1 = take(4 * Hf * Hf);
+    p.fb_whh1 = take(4 * Hf * Hf);
+    p.fb_b1 = take(4 * Hf);
+    p.fb_fc = take((size_t)p.FP * Hf);
+    p.fb_fcb = take(p.FP);
+    p.sb_wih0 = take(4 * Hs * p.sb_kin_pad);
+    p.sb_whh0 = take(4 * Hs * Hs);
+    p.sb_b0 = take(4 * Hs);
+    p.sb_wih1 = take(4 * Hs * Hs);
+    p.sb_whh1 = take(4 * Hs * Hs);
+    p.sb_b1 = take(4 * Hs);
+    p.sb_fc = take(16 * Hs);
+    p.sb_fcb = take(16);
+    p.total = fsn_round_up_sz(o, 64);
+    return p;
+}
+
+extern "C" size_t fsn_fullsubnet_packed_bytes(const fsn_fullsubnet_cfg* cfg) {
+    if (check_cfg(cfg) != FSN_OK) return 0;
+    return packed_layout(cfg).total * sizeof(float);
+}
+
+extern "C" int fsn_fullsubnet_pack(const fsn_fullsubnet_cfg* cfg, const fsn_fullsubnet_params* w, void* packed,
+                                   size_t packed_bytes, void* stream) {
+    FSN_TRY(check_cfg(cfg));
+    FSN_REQUIRE(w && packed, "params / packed is NULL");
+    const float* const* all = reinterpret_cast<const float* const*>(w);
+    for (size_t i = 0; i < sizeof(*w) / sizeof(float*); ++i) FSN_REQUIRE(all[i], "params tensor %zu is NULL", i);
+    const Packed p = packed_layout(cfg);
+    FSN_REQUIRE(packed_bytes >= p.total * sizeof(float), "packed buffer too small: %zu < %zu", packed_bytes,
+                p.total * sizeof(float));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* o = static_cast<float*>(packed);
+    const int F = cfg->num_freqs, Hf = cfg->fb_hidden, Hs = cfg->sb_hidden;
+    const int kin = 2 * cfg->sb_num_neighbors + 2;
+    FSN_TRY(fsn_launch_pack(w->fb_w_ih_l0, o + p.fb_wih0, 4 * Hf, F, 4 * Hf, p.FP, s));
+    FSN_TRY(fsn_launch_pack(w->fb_w_hh_l0, o + p.fb_whh0, 4 * Hf, Hf, 4 * Hf, Hf, s));
+    FSN_TRY(fsn_launch_bias_sum(w->fb_b_ih_l0, w->fb_b_hh_l0, o + p.fb_b0, 4 * Hf, 4 * Hf, s));
+    FSN_TRY(fsn_launch_pack(w->fb_w_ih_l1, o + p.fb_wih1, 4 * Hf, Hf, 4 * Hf, Hf, s));
+    FSN_TRY(fsn_launch_pack(w->fb_w_hh_l1, o + p.fb_whh1, 4 * Hf, Hf, 4 * Hf, Hf, s));
+    FSN_TRY(fsn_launch_bias_sum(w->fb_b_ih_l1, w->fb_b_hh_l1, o + p.fb_b1, 4 * Hf, 4 * Hf, s));
+    FSN_TRY(fsn_launch_pack(w->fb_fc_w, o + p.fb_fc, F, Hf, p.FP, Hf, s));
+    FSN_TRY(fsn_launch_bias_sum(w->fb_fc_b, nullptr, o + p.fb_fcb, F, p.FP, s));
+    FSN_TRY(fsn_launch_pack(w->sb_w_ih_l0, o + p.sb_wih0, 4 * Hs, kin, 4 * Hs, p.sb_kin_pad, s));
+    FSN_TRY(fsn_launch_pack(w->sb_w_hh_l0, o + p.sb_whh0, 4 * Hs, Hs, 4 * Hs, Hs, s));
+    FSN_TRY(fsn_launch_bias_sum(w->sb_b_ih_l0, w->sb_b_hh_l0, o + p.sb_b0, 4 * Hs, 4 * Hs, s));
+    FSN_TRY(fsn_launch_pack(w->sb_w_ih_l1, o + p.sb_wih1, 4 * Hs, Hs, 4 * Hs, Hs, s));
+    FSN_TRY(fsn_launch_pack(w->sb_w_hh_l1, o + p.sb_whh1, 4 * Hs, Hs, 4 * Hs, Hs, s));
+    FSN_TRY(fsn_launch_bias_sum(w->sb_b_ih_l1, w->sb_b_hh_l1, o + p.sb_b1, 4 * Hs, 4 * Hs, s));
+    FSN_TRY(fsn_launch_pack(w->sb_fc_w, o + p.sb_fc, 2, Hs, 16, Hs, s));
+    FSN_TRY(fsn_launch_bias_sum(w->sb_fc_b, nullptr, o + p.sb_fcb, 2, 16, s));
+    return FSN_OK;
+}
+
+// ---- model core: magT [B][Tp][FP] -> crm_r, crm_i [B][T][FP] ------------------------------------
+struct CoreDims {
+    int B, T, Tp, F, FP, Hf, Hs, nb, la;
+    int Npad_fb;       // full-band rows per step (batch, padded to 16)
+    int N, RT, Npad;   // sub-band rows per step, row tiles per workgroup, padded rows
+};
+static CoreDims core_dims(const fsn_fullsubnet_cfg* c, int B, int T) {
+    CoreDims d;
+    d.B = B;
+    d.T = T;
+    d.la = c->look_ahead;
+    d.Tp = T + c->look_ahead;
+    d.F = c->num_freqs;
+    d.FP = fsn_fpad(d.F);
+    d.Hf = c->fb_hidden;
+    d.Hs = c->sb_hidden;
+    d.nb = c->sb_num_neighbors;
+    d.Npad_fb = fsn_round_up(B, 16);
+    d.N = B * d.F;
+    d.RT = fsn_lstm_rec_row_tiles(d.N, d.Hs);
+    d.Npad = fsn_round_up(d.N, 16 * d.RT);
+    return d;
+}
+struct CoreWs {
+    float *gx_fb, *hseq_fb0, *hseq_fb1, *c_fb, *fb_out, *den_fb, *den_sb, *gx_sb, *hseq_sb0, *hseq_sb1;
+    double* binsum;
+};
+static CoreWs core_carve(Carver& cv, const CoreDims& d, int norm_type) {
+    CoreWs w;
+    const size_t rows_fb = (size_t)d.Tp * d.Npad_fb, rows_sb = (size_t)d.Tp * d.Npad;
+    w.gx_fb = cv.take<float>(rows_fb * 4 * d.Hf);
+    w.hseq_fb0 = cv.take<float>(rows_fb * d.Hf);
+    w.hseq_fb1 = cv.take<float>(rows_fb * d.Hf);
+    w.c_fb = cv.take<float>((size_t)d.Npad_fb * d.Hf);
+    w.fb_out = cv.take<float>((size_t)d.B * d.Tp * d.FP);
+    w.binsum = cv.take<double>((size_t)d.B * d.FP);
+    const bool cum = norm_type == FSN_NORM_CUMULATIVE_LAPLACE;
+    w.den_fb = cv.take<float>(cum ? (size_t)d.B * d.Tp : (size_t)d.B);
+    w.den_sb = cv.take<float>(cum ? rows_sb : (size_t)d.B);
+    w.gx_sb = cv.take<float>(rows_sb * 4 * d.Hs);
+    w.hseq_sb0 = cv.take<float>(rows_sb * d.Hs);
+    w.hseq_sb1 = cv.take<float>(rows_sb * d.Hs);
+    return w;
+}
+
+static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float* magT, const CoreDims& d,
+                    const CoreWs& w, float* crm_r, float* crm_i, hipStream_t s) {
+    const Packed p = packed_layout(cfg);
+    const bool cum = cfg->norm_type == FSN_NORM_CUMULATIVE_LAPLACE;
+
+    // full-band norm divisor (fullsubnet/model.py:92)
+    {
+        StageTimer st(ST_NORM, s);
+        if (cum) {
+            FSN_TRY(fsn_launch_cumulative_den_fb(magT, w.den_fb, d.B, d.Tp, d.F, d.FP, s));
+        } else {
+            FSN_TRY(fsn_launch_binsum(magT, w.binsum, d.B, d.Tp, d.FP, s));
+            FSN_TRY(fsn_launch_offline_den(w.binsum, nullptr, w.den_fb, nullptr, d.B, d.Tp, d.F, d.FP, d.nb, 0, s));
+        }
+    }
+    // full-band model (model.py:95): 2 LSTM layers + Linear + ReLU
+    const int fb_rt = d.Tp * d.Npad_fb / 16;
+    FsnGemmA a{};
+    FsnGemmC c{};
+    for (int layer = 0; layer < 2; ++layer) {
+        {
+            StageTimer st(ST_FB_GEMM, s);
+            a = FsnGemmA{};
+            c = FsnGemmC{};
+            if (layer == 0) {
+                a.kind = 1;
+                a.p0 = magT;
+                a.den = w.den_fb;
+                a.den_mode = cum ? 1 : 0;
+                a.B = d.B;
+                a.Tp = d.Tp;
+                a.F = d.F;
+                a.FP = d.FP;
+                a.Npad = d.Npad_fb;
+            } else {
+                a.kind = 0;
+                a.p0 = w.hseq_fb0;
+                a.ld = d.Hf;
+            }
+            c.kind = 0;
+            c.p0 = w.gx_fb;
+            c.bias = pk + (layer == 0 ? p.fb_b0 : p.fb_b1);
+            FSN_TRY(fsn_launch_gemm(a, pk + (layer == 0 ? p.fb_wih0 : p.fb_wih1), c, fb_rt, 4 * d.Hf / 16,
+                                    layer == 0 ? d.FP / 16 : d.Hf / 16, s));
+        }
+        {
+            StageTimer st(ST_FB_REC, s);
+            float* hseq = layer == 0 ? w.hseq_fb0 : w.hseq_fb1;
+            const float* whh = pk + (layer == 0 ? p.fb_whh0 : p.fb_whh1);
+            const size_t step = (size_t)d.Npad_fb * d.Hf;
+            for (int t = 0; t < d.Tp; ++t)
+                FSN_TRY(fsn_launch_lstm_step(w.gx_fb, whh, t ? hseq + (t - 1) * step : hseq, hseq + t * step,
+                                             w.c_fb, t, d.Npad_fb, d.Hf, s));
+        }
+    }
+    {
+        StageTimer st(ST_FB_GEMM, s);
+        a = FsnGemmA{};
+        c = FsnGemmC{};
+        a.kind = 0;
+        a.p0 = w.hseq_fb1;
+        a.ld = d.Hf;
+        c.kind = 1;
+        c.p0 = w.fb_out;
+        c.bias = pk + p.fb_fcb;
+        c.B = d.B;
+        c.Tp = d.Tp;
+        c.F = d.F;
+        c.FP = d.FP;
+        c.Npad = d.Npad_fb;
+        FSN_TRY(fsn_launch_gemm(a, pk + p.fb_fc, c, fb_rt, d.FP / 16, d.Hf / 16, s));
+    }
+    // sub-band norm divisor over the (virtual) concatenated sub-band input (model.py:110-111)
+    {
+        StageTimer st(ST_NORM, s);
+        if (cum) {
+            FSN_TRY(fsn_launch_cumulative_den_sb(magT, w.fb_out, w.den_sb, d.B, d.Tp, d.F, d.FP, d.nb, d.Npad, s));
+        } else {
+            FSN_TRY(fsn_launch_offline_den(w.binsum, w.fb_out, nullptr, w.den_sb, d.B, d.Tp, d.F, d.FP, d.nb, 1, s));
+        }
+    }
+    // sub-band model (model.py:121-128): N = B F sequences, 2 LSTM layers + Linear(2)
+    const int sb_rt = (int)((long)d.Tp * d.Npad / 16);
+    {
+        StageTimer st(ST_SB_GEMM_L0, s);
+        a = FsnGemmA{};
+        c = FsnGemmC{};
+        a.kind = 2;
+        a.p0 = magT;
+        a.p1 = w.fb_out;
+        a.den = w.den_sb;
+        a.den_mode = cum ? 1 : 0;
+        a.B = d.B;
+        a.Tp = d.Tp;
+        a.F = d.F;
+        a.FP = d.FP;
+        a.Npad = d.Npad;
+        a.N = d.N;
+        a.nb = d.nb;
+        c.kind = 0;
+        c.p0 = w.gx_sb;
+        c.bias = pk + p.sb_b0;
+        FSN_TRY(fsn_launch_gemm(a, pk + p.sb_wih0, c, sb_rt, 4 * d.Hs / 16, p.sb_kin_pad / 16, s));
+    }
+    {
+        StageTimer st(ST_SB_REC_L0, s);
+        FSN_TRY(fsn_launch_lstm_rec(w.gx_sb, pk + p.sb_whh0, w.hseq_sb0, d.Tp, d.Npad, d.Hs, d.RT, s));
+    }
+    {
+        StageTimer st(ST_SB_GEMM_L1, s);
+        a = FsnGemmA{};
+        c = FsnGemmC{};
+        a.kind = 0;
+        a.p0 = w.hseq_sb0;
+        a.ld = d.Hs;
+        c.kind = 0;
+        c.p0 = w.gx_sb;
+        c.bias = pk + p.sb_b1;
+        FSN_TRY(fsn_launch_gemm(a, pk + p.sb_wih1, c, sb_rt, 4 * d.Hs / 16, d.Hs / 16, s));
+    }
+    {
+        StageTimer st(ST_SB_REC_L1, s);
+        FSN_TRY(fsn_launch_lstm_rec(w.gx_sb, pk + p.sb_whh1, w.hseq_sb1, d.Tp, d.Npad, d.Hs, d.RT, s));
+    }
+    {
+        StageTimer st(ST_SB_FC, s);
+        a = FsnGemmA{};
+        c = FsnGemmC{};
+        a.kind = 0;
+        a.p0 = w.hseq_sb1;
+        a.ld = d.Hs;
+        c.kind = 2;
+        c.p0 = crm_r;
+        c.p1 = crm_i;
+        c.bias = pk + p.sb_fcb;
+        c.T = d.T;
+        c.F = d.F;
+        c.FP = d.FP;
+        c.Npad = d.Npad;
+        c.N = d.N;
+        c.la = d.la;
+        FSN_TRY(fsn_launch_gemm(a, pk + p.sb_fc, c, sb_rt, 1, d.Hs / 16, s));
+    }
+    return FSN_OK;
+}
+
+static int check_bt(int B, int T) {
+    FSN_REQUIRE(B >= 1 && B <= 4096, "batch %d out of range", B);
+    FSN_REQUIRE(T >= 1 && T <= 100000, "frames %d out of range", T);
+    return FSN_OK;
+}
+
+extern "C" size_t fsn_fullsubnet_workspace_bytes(const fsn_fullsubnet_cfg* cfg, int B, int T) {
+    if (check_cfg(cfg) != FSN_OK || check_bt(B, T) != FSN_OK) return 0;
+    const CoreDims d = core_dims(cfg, B, T);
+    Carver cv(nullptr);
+    cv.take<float>((size_t)B * d.Tp * d.FP);     // magT
+    cv.take<float>((size_t)B * d.T * d.FP);      // crm_r
+    cv.take<float>((size_t)B * d.T * d.FP);      // crm_i
+    core_carve(cv, d, cfg->norm_type);
+    return fsn_round_up_sz(cv.off, 256);
+}
+
+extern "C" int fsn_fullsubnet_forward(const fsn_fullsubnet_cfg* cfg, const void* packed, const float* noisy_mag,
+                                      int B, int T, float* crm_out, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    FSN_TRY(check_cfg(cfg));
+    FSN_TRY(check_bt(B, T));
+    FSN_REQUIRE(packed && noisy_mag && crm_out && workspace, "NULL pointer argument");
+    const size_t need = fsn_fullsubnet_workspace_bytes(cfg, B, T);
+    if (workspace_bytes < need) {
+        fsn_set_error("workspace too small: %zu < %zu bytes", workspace_bytes, need);
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const CoreDims d = core_dims(cfg, B, T);
+    Carver cv(workspace);
+    float* magT = cv.take<float>((size_t)B * d.Tp * d.FP);
+    float* crm_r = cv.take<float>((size_t)B * d.T * d.FP);
+    float* crm_i = cv.take<float>((size_t)B * d.T * d.FP);
+    const CoreWs w = core_carve(cv, d, cfg->norm_type);
+    prof_reset();
+    // [B,1,F,T] -> frame-major [B][Tp][FP]; look-ahead frames (model.py:85) and padded bins are zeros
+    FSN_TRY(fsn_launch_transpose(noisy_mag, magT, B, d.FP, d.Tp, T, (long)d.F * T, d.FP, (long)d.Tp * d.FP, d.F, T, s));
+    FSN_TRY(run_core(cfg, static_cast<const float*>(packed), magT, d, w, crm_r, crm_i, s));
+    // frame-major planes -> [B, 2, F, T] (model.py:129-135)
+    FSN_TRY(fsn_launch_transpose(crm_r, crm_out, B, T, d.F, d.FP, (long)T * d.FP, T, 2L * d.F * T, T, d.F, s));
+    FSN_TRY(fsn_launch_transpose(crm_i, crm_out + (size_t)d.F * T, B, T, d.F, d.FP, (long)T * d.FP, T, 2L * d.F * T,
+                                 T, d.F, s));
+    return FSN_OK;
+}
+
+// ---- STFT / iSTFT boundary -------------------------------------------------------------------
+static int check_fft(int n_fft, int hop, int win_length) {
+    FSN_REQUIRE(n_fft == 512 && hop == 256 && win_length == 512,
+                "only n_fft = win_length = 512, hop = 256 is built (got %d/%d/%d)", n_fft, win_length, hop);
+    return FSN_OK;
+}
+
+extern "C" int fsn_stft(const float* y, int B, int L, int n_fft, int hop, int win_length, const float* window,
+                        float* real, float* imag, float* mag, void* stream) {
+    FSN_TRY(check_fft(n_fft, hop, win_length));
+    FSN_REQUIRE(y && window, "NULL pointer argument");
+    FSN_REQUIRE(B >= 1 && L > n_fft / 2, "need B >= 1 and L > n_fft/2 (reflect padding), got B=%d L=%d", B, L);
+    const int T = 1 + L / hop, F = n_fft / 2 + 1;
+    return fsn_launch_stft(y, B, L, window, real, imag, mag, T, T, F, fsn_fpad(F), false,
+                           static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t fsn_istft_workspace_bytes(int B, int T, int n_fft) {
+    if (B < 1 || T < 1 || n_fft != 512) return 0;
+    return fsn_round_up_sz((size_t)B * T * n_fft * sizeof(float), 256);
+}
+
+extern "C" int fsn_istft(const float* real, const float* imag, int B, int T, int n_fft, int hop, int win_length,
+                         const float* window, int length, float* y, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+    FSN_TRY(check_fft(n_fft, hop, win_length));
+    FSN_TRY(check_bt(B, T));
+    FSN_REQUIRE(real && imag && window && y && workspace, "NULL pointer argument");
+    FSN_REQUIRE(length >= 1, "length %d < 1", length);
+    if (workspace_bytes < fsn_istft_workspace_bytes(B, T, n_fft)) {
+        fsn_set_error("workspace too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int F = n_fft / 2 + 1;
+    float* wf = static_cast<float*>(workspace);
+    FSN_TRY(fsn_launch_mask_irfft(real, imag, nullptr, nullptr, B, T, F, fsn_fpad(F), false, window, wf, s));
+    return fsn_launch_ola(wf, window, B, T, length, y, s);
+}
+
+// ---- elementwise boundary --------------------------------------------------------------------
+extern "C" int fsn_decompress_cirm(const float* mask, float* out, size_t n, void* stream) {
+    FSN_REQUIRE(mask && out, "NULL pointer argument");
+    return n ? fsn_launch_decompress(mask, out, n, static_cast<hipStream_t>(stream)) : FSN_OK;
+}
+extern "C" int fsn_compress_cirm(const float* mask, float* out, size_t n, void* stream) {
+    FSN_REQUIRE(mask && out, "NULL pointer argument");
+    return n ? fsn_launch_compress(mask, out, n, static_cast<hipStream_t>(stream)) : FSN_OK;
+}
+extern "C" int fsn_build_cirm(const float* nr, const float* ni, const float* cr, const float* ci, float* out,
+                              size_t n, void* stream) {
+    FSN_REQUIRE(nr && ni && cr && ci && out, "NULL pointer argument");
+    return n ? fsn_launch_build_cirm(nr, ni, cr, ci, out, n, static_cast<hipStream_t>(stream)) : FSN_OK;
+}
+
+// ---- the whole path: inferencer.py:130-145 ---------------------------------------------------
+extern "C" size_t fsn_enhance_workspace_bytes(const fsn_fullsubnet_cfg* cfg, int B, int L, int n_fft, int hop) {
+    if (check_cfg(cfg) != FSN_OK || check_fft(n_fft, hop, n_fft) != FSN_OK || B < 1 || L <= n_fft / 2) return 0;
+    const int T = 1 + L / hop;
+    if (check_bt(B, T) != FSN_OK || cfg->num_freqs != n_fft / 2 + 1) return 0;
+    const CoreDims d = core_dims(cfg, B, T);
+    Carver cv(nullptr);
+    cv.take<float>((size_t)B * d.Tp * d.FP);  // magT
+    cv.take<float>((size_t)B * d.T * d.FP);   // re
+    cv.take<float>((size_t)B * d.T * d.FP);   // im
+    cv.take<float>((size_t)B * d.T * d.FP);   // crm_r
+    cv.take<float>((size_t)B * d.T * d.FP);   // crm_i
+    cv.take<float>((size_t)B * d.T * n_fft);  // windowed frames
+    core_carve(cv, d, cfg->norm_type);
+    return fsn_round_up_sz(cv.off, 256);
+}
+
+extern "C" int fsn_enhance(const fsn_fullsubnet_cfg* cfg, const void* packed, const float* window,
+                           const float* noisy, int B, int L, int n_fft, int hop, float* enhanced, float* crm_out,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    FSN_TRY(check_cfg(cfg));
+    FSN_TRY(check_fft(n_fft, hop, n_fft));
+    FSN_REQUIRE(packed && window && noisy && enhanced && workspace, "NULL pointer argument");
+    FSN_REQUIRE(B >= 1 && L > n_fft / 2, "need B >= 1 and L > n_fft/2, got B=%d L=%d", B, L);
+    FSN_REQUIRE(cfg->num_freqs == n_fft / 2 + 1, "num_freqs %d != n_fft/2+1", cfg->num_freqs);
+    const int T = 1 + L / hop;
+    FSN_TRY(check_bt(B, T));
+    const size_t need = fsn_enhance_workspace_bytes(cfg, B, L, n_fft, hop);
+    if (workspace_bytes < need) {
+        fsn_set_error("workspace too small: %zu < %zu bytes", workspace_bytes, need);
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const CoreDims d = core_dims(cfg, B, T);
+    Carver cv(workspace);
+    float* magT = cv.take<float>((size_t)B * d.Tp * d.FP);
+    float* re = cv.take<float>((size_t)B * d.T * d.FP);
+    float* im = cv.take<float>((size_t)B * d.T * d.FP);
+    float* crm_r = cv.take<float>((size_t)B * d.T * d.FP);
+    float* crm_i = cv.take<float>((size_t)B * d.T * d.FP);
+    float* wf = cv.take<float>((size_t)B * d.T * n_fft);
+    const CoreWs w = core_carve(cv, d, cfg->norm_type);
+    prof_reset();
+    {
+        StageTimer st(ST_STFT, s);
+        FSN_TRY(fsn_launch_stft(noisy, B, L, window, re, im, magT, d.T, d.Tp, d.F, d.FP, true, s));
+    }
+    FSN_TRY(run_core(cfg, static_cast<const float*>(packed), magT, d, w, crm_r, crm_i, s));
+    {
+        StageTimer st(ST_MASK_ISTFT, s);
+        FSN_TRY(fsn_launch_mask_irfft(re, im, crm_r, crm_i, B, d.T, d.F, d.FP, true, window, wf, s));
+        FSN_TRY(fsn_launch_ola(wf, window, B, d.T, L, enhanced, s));
+    }
+    if (crm_out) {
+        FSN_TRY(fsn_launch_transpose(crm_r, crm_out, B, d.T, d.F, d.FP, (long)d.T * d.FP, d.T, 2L * d.F * d.T, d.T,
+                                     d.F, s));
+        FSN_TRY(fsn_launch_transpose(crm_i, crm_out + (size_t)d.F * d.T, B, d.T, d.F, d.FP, (long)d.T * d.FP, d.T,
+                                     2L * d.F * d.T, d.T, d.F, s));
+    }
+    return FSN_OK;
+}

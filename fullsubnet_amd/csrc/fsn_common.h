@@ -1,0 +1,103 @@
+// Shared device/host helpers for libfsn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fsn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define FSN_WAVE 64
+
+static inline int fsn_round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline size_t fsn_round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+// frequency axis padded to a multiple of 16 floats: rows stay 16-byte aligned for float4 operand
+// loads and the zero padding doubles as the K padding of the full-band input projection.
+static inline int fsn_fpad(int F) { return fsn_round_up(F, 16); }
+
+void fsn_set_error(const char* fmt, ...);
+int fsn_check_launch(const char* what);
+
+#define FSN_REQUIRE(cond, ...)          \
+    do {                                \
+        if (!(cond)) {                  \
+            fsn_set_error(__VA_ARGS__); \
+            return FSN_ERR_ARG;         \
+        }                               \
+    } while (0)
+
+// D = A(16x4) * B(4x16) + C, exact fp32 (k-ordered fmaf chain).  Lane l supplies A[l&15][l>>4]
+// and B[l>>4][l&15]; D/C: col = l&15, row = 4*(l>>4) + reg.
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Bijective XCD-aware block remap: block b runs on XCD b % 8 (observed, speed only); give each
+// XCD a contiguous chunk of the virtual grid so neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk >> 3, r = nblk & 7u;
+    const unsigned xcd = bid & 7u, slot = bid >> 3;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+// ---- kernels' host launchers (one per translation unit) -------------------------------------
+struct FsnStream {
+    hipStream_t s;
+};
+
+// fft_kernels.hip
+int fsn_launch_stft(const float* y, int B, int L, const float* window, float* re, float* im, float* mag,
+                    int T, int Tp, int F, int FP, bool frame_major, hipStream_t s);
+int fsn_launch_mask_irfft(const float* re, const float* im, const float* crm_r, const float* crm_i,
+                          int B, int T, int F, int FP, bool frame_major, const float* window,
+                          float* wframes, hipStream_t s);
+int fsn_launch_ola(const float* wframes, const float* window, int B, int T, int length, float* y,
+                   hipStream_t s);
+
+// elementwise_kernels.hip
+int fsn_launch_decompress(const float* in, float* out, size_t n, hipStream_t s);
+int fsn_launch_compress(const float* in, float* out, size_t n, hipStream_t s);
+int fsn_launch_build_cirm(const float* nr, const float* ni, const float* cr, const float* ci, float* out,
+                          size_t n, hipStream_t s);
+int fsn_launch_transpose(const float* in, float* out, int batch, int R, int C, long ld_in, long bs_in,
+                         long ld_out, long bs_out, int R_valid, int C_valid, hipStream_t s);
+int fsn_launch_binsum(const float* mag, double* binsum, int B, int Tp, int FP, hipStream_t s);
+int fsn_launch_offline_den(const double* binsum, const float* fb_out, float* den_fb, float* den_sb, int B,
+                           int Tp, int F, int FP, int nb, int which, hipStream_t s);
+int fsn_launch_cumulative_den_fb(const float* mag, float* den, int B, int Tp, int F, int FP, hipStream_t s);
+int fsn_launch_cumulative_den_sb(const float* mag, const float* fb_out, float* den, int B, int Tp, int F,
+                                 int FP, int nb, int Npad, hipStream_t s);
+
+// gemm_kernels.hip
+struct FsnGemmA {  // A operand description
+    int kind;      // 0 row-major, 1 full-band input, 2 sub-band input
+    const float* p0;  // row-major: matrix; fb/sb: mag [B][Tp][FP]
+    const float* p1;  // sb: fb_out [B][Tp][FP]
+    const float* den;  // fb/sb: divisor
+    int den_mode;      // 0: den[b]   1: den[b*Tp + t] (fb) / den[(t*Npad)+n] (sb)
+    long ld;           // row-major leading dimension
+    int B, Tp, F, FP, Npad, N, nb;
+};
+struct FsnGemmC {  // C store description
+    int kind;      // 0 fragment-order + bias, 1 fb_out rows (bias + relu), 2 crm planes
+    float* p0;
+    float* p1;
+    const float* bias;
+    int B, Tp, T, F, FP, Npad, N, la;
+};
+int fsn_launch_gemm(const FsnGemmA& a, const float* w_packed, const FsnGemmC& c, int row_tiles, int col_tiles,
+                    int k_chunks, hipStream_t s);
+int fsn_launch_pack(const float* w, float* wp, int n_out, int k, int n_out_pad, int k_pad, hipStream_t s);
+int fsn_launch_bias_sum(const float* a, const float* b, float* out, int n, int n_pad, hipStream_t s);
+
+// lstm_kernels.hip
+int fsn_launch_lstm_step(const float* gx, const float* whh_p, const float* h_prev, float* h_out, float* c,
+                         int t, int Npad, int H, hipStream_t s);
+int fsn_launch_lstm_rec(const float* gx, const float* whh_p, float* hseq, int Tp, int Npad, int H, int RT,
+                        hipStream_t s);
+int fsn_lstm_rec_row_tiles(int N, int H);

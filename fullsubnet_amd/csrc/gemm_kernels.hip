@@ -1,0 +1,252 @@
+// fp32 MFMA GEMM family: C[R, Nout] = A[R, K] * W[Nout, K]^T (+ bias, epilogue).
+//
+// Used for every non-recurrent contraction of the path (sequence_model.py:116-123):
+//   * LSTM input projections  W_ih x_t + (b_ih + b_hh)  for all (t, n) at once,
+//   * the nn.Linear output layers (+ReLU for the full-band model).
+//
+// v_mfma_f32_16x16x4_f32 is exact fp32 at 64 FLOP/clk/SIMD; it needs ONE A and ONE B dword per lane
+// per 32-cycle instruction, so operands are fed straight from global memory / L2 as 16-byte
+// fragments (lane (i, q) reads 4 consecutive k of row i) without an LDS stage: at a 64x64 wave
+// tile the kernel needs ~16 B/clk/CU from L1/L2, a quarter of what the vector memory path gives.
+// Both operands are K-contiguous, so nn.LSTM's own [4H, K] weight layout is already the B layout;
+// weights are re-tiled once ("packed") so that a wave's B fragment is one contiguous 1 KB line
+// group.  K order inside a 16-chunk is permuted identically for A and B (j-th MFMA of a chunk
+// contracts k = 16 kc + 4 q + j), which is free because fp32 addition order is ours to choose.
+//
+// The A operand is produced on the fly for the two model inputs, so the 387 MB freq_unfold tensor
+// and the 400 MB concatenated / normalised sub-band input of the reference
+// (base_model.py:31-44, fullsubnet/model.py:110-111) are never materialised.
+#include "fsn_common.h"
+
+namespace {
+
+__device__ __forceinline__ int reflect_idx(int j, int F) {
+    j = j < 0 ? -j : j;
+    return j >= F ? 2 * (F - 1) - j : j;
+}
+
+// ------------------------------------------------------------------------------------------
+// A-operand providers.  prepare() resolves the row once; load() returns 4 consecutive k.
+// ------------------------------------------------------------------------------------------
+template <int KIND>
+struct ARow;
+
+template <>
+struct ARow<0> {  // row-major matrix [R][ld]
+    const float* base;
+    __device__ __forceinline__ void prepare(const FsnGemmA& a, long row, long nrows) {
+        row = row < nrows ? row : nrows - 1;  // clamped rows are computed and discarded
+        base = a.p0 + row * a.ld;
+    }
+    __device__ __forceinline__ f32x4 load(const FsnGemmA&, int k0) const {
+        return *reinterpret_cast<const f32x4*>(base + k0);
+    }
+};
+
+template <>
+struct ARow<1> {  // full-band model input: row (t, b) = mag[b][t][:] / den   (fullsubnet/model.py:92-94)
+    const float* base;
+    float den;
+    bool valid;
+    __device__ __forceinline__ void prepare(const FsnGemmA& a, long row, long nrows) {
+        const int t = (int)(row / a.Npad), b = (int)(row % a.Npad);
+        valid = row < nrows && b < a.B;
+        const int bb = valid ? b : 0, tt = valid ? t : 0;
+        base = a.p0 + ((long)bb * a.Tp + tt) * a.FP;
+        den = a.den[a.den_mode ? (long)bb * a.Tp + tt : bb];
+    }
+    __device__ __forceinline__ f32x4 load(const FsnGemmA&, int k0) const {
+        f32x4 v = *reinterpret_cast<const f32x4*>(base + k0);  // columns >= F are stored as zeros
+        if (!valid) return f32x4{0.f, 0.f, 0.f, 0.f};
+        return f32x4{v[0] / den, v[1] / den, v[2] / den, v[3] / den};
+    }
+};
+
+template <>
+struct ARow<2> {  // sub-band model input: row (t, n = b F + f), 2 nb + 2 channels
+    // channel c < 2nb+1 : mag[b][t][reflect(f + c - nb)]      (base_model.py:31-44, N = nb)
+    // channel 2nb+1     : fb_out[b][t][f]                      (model.py:98-101,110)
+    // all divided by the sub-band norm divisor                 (model.py:111)
+    const float* mrow;
+    const float* frow;
+    float den;
+    int f;
+    bool valid;
+    __device__ __forceinline__ void prepare(const FsnGemmA& a, long row, long nrows) {
+        const int t = (int)(row / a.Npad), n = (int)(row % a.Npad);
+        valid = row < nrows && n < a.N;
+        const int nn = valid ? n : 0, tt = valid ? t : 0;
+        const int b = nn / a.F;
+        f = nn % a.F;
+        mrow = a.p0 + ((long)b * a.Tp + tt) * a.FP;
+        frow = a.p1 + ((long)b * a.Tp + tt) * a.FP;
+        den = a.den[a.den_mode ? (long)tt * a.Npad + nn : b];
+    }
+    __device__ __forceinline__ f32x4 load(const FsnGemmA& a, int k0) const {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = k0 + j;
+            float x = 0.f;
+            if (c <= 2 * a.nb) x = mrow[reflect_idx(f + c - a.nb, a.F)];
+            else if (c == 2 * a.nb + 1) x = frow[f];
+            v[j] = valid ? x / den : 0.f;
+        }
+        return v;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// C stores.  acc register i of lane l is C[16 rtile + 4 (l>>4) + i][16 ctile + (l&15)].
+// ------------------------------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ void store_tile(const FsnGemmC& c, f32x4 acc, long rtile, int ctile, int col_tiles,
+                                           int lane) {
+    const int col = ctile * 16 + (lane & 15);
+    const float bias = c.bias ? c.bias[col] : 0.f;
+    if (KIND == 0) {
+        // fragment order: tile (rtile, ctile) is one contiguous 1 KB block [lane][reg]; this is the
+        // accumulator-init layout of the recurrent kernels.
+        f32x4 v = {acc[0] + bias, acc[1] + bias, acc[2] + bias, acc[3] + bias};
+        *reinterpret_cast<f32x4*>(c.p0 + ((rtile * col_tiles + ctile) * 64 + lane) * 4) = v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long row = rtile * 16 + 4 * (lane >> 4) + i;
+            const int t = (int)(row / c.Npad), n = (int)(row % c.Npad);
+            if (KIND == 1) {  // full-band output layer: ReLU(h W^T + b) -> fb_out[b][t][f]
+                if (n < c.B && col < c.FP) {
+                    const float v = col < c.F ? fmaxf(acc[i] + bias, 0.f) : 0.f;
+                    c.p0[((long)n * c.Tp + t) * c.FP + col] = v;
+                }
+            } else {  // sub-band output layer: compressed cIRM planes, look-ahead frames dropped
+                      // (model.py:128-135): crm_{r,i}[b][t - la][f]
+                if (n < c.N && t >= c.la && col < 2) {
+                    const int b = n / c.F, f = n % c.F;
+                    float* dst = col == 0 ? c.p0 : c.p1;
+                    dst[((long)b * c.T + (t - c.la)) * c.FP + f] = acc[i] + bias;
+                }
+            }
+        }
+    }
+}
+
+template <int AKIND, int CKIND, int RTW, int CTW, int WR, int WC>
+__global__ __launch_bounds__(WR* WC * 64) void gemm_kernel(FsnGemmA a, const float* __restrict__ wp, FsnGemmC c,
+                                                           int row_tiles, int col_tiles, int k_chunks) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    const unsigned ncb = (col_tiles + WC * CTW - 1) / (WC * CTW);
+    const unsigned v = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned rb = v / ncb, cb = v % ncb;
+    const long rtile0 = ((long)rb * WR + wr) * RTW;
+    const int ctile0 = ((int)cb * WC + wc) * CTW;
+    const long nrows = (long)row_tiles * 16;
+    const int kq = 4 * (lane >> 4);
+
+    ARow<AKIND> arow[RTW];
+#pragma unroll
+    for (int rt = 0; rt < RTW; ++rt) arow[rt].prepare(a, (rtile0 + rt) * 16 + (lane & 15), nrows);
+    const float* bptr[CTW];
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct) {
+        int ctile = ctile0 + ct;
+        ctile = ctile < col_tiles ? ctile : col_tiles - 1;
+        bptr[ct] = wp + ((long)ctile * k_chunks * 64 + lane) * 4;
+    }
+
+    f32x4 acc[RTW][CTW];
+#pragma unroll
+    for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 an[RTW], bn[CTW];
+#pragma unroll
+    for (int rt = 0; rt < RTW; ++rt) an[rt] = arow[rt].load(a, kq);
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct) bn[ct] = *reinterpret_cast<const f32x4*>(bptr[ct]);
+
+    for (int kc = 0; kc < k_chunks; ++kc) {
+        f32x4 ac[RTW], bc[CTW];
+#pragma unroll
+        for (int rt = 0; rt < RTW; ++rt) ac[rt] = an[rt];
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) bc[ct] = bn[ct];
+        if (kc + 1 < k_chunks) {
+#pragma unroll
+            for (int rt = 0; rt < RTW; ++rt) an[rt] = arow[rt].load(a, (kc + 1) * 16 + kq);
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct)
+                bn[ct] = *reinterpret_cast<const f32x4*>(bptr[ct] + (long)(kc + 1) * 256);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CTW; ++ct) acc[rt][ct] = mfma16(ac[rt][j], bc[ct][j], acc[rt][ct]);
+    }
+
+#pragma unroll
+    for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct)
+            if (rtile0 + rt < row_tiles && ctile0 + ct < col_tiles)
+                store_tile<CKIND>(c, acc[rt][ct], rtile0 + rt, ctile0 + ct, col_tiles, lane);
+}
+
+// W [n_out][k] (nn.LSTM / nn.Linear layout) -> B-fragment order [n_out_pad/16][k_pad/16][64][4]
+__global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int n_out, int k, int ctiles,
+                            int kchunks) {
+    const long total = (long)ctiles * kchunks * 256;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
+        const long blk = i >> 8;
+        const int kc = (int)(blk % kchunks), ct = (int)(blk / kchunks);
+        const int row = ct * 16 + (lane & 15), col = kc * 16 + 4 * (lane >> 4) + j;
+        wp[i] = (row < n_out && col < k) ? w[(long)row * k + col] : 0.f;
+    }
+}
+
+__global__ void bias_sum_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                int n, int n_pad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pad) out[i] = i < n ? (b ? a[i] + b[i] : a[i]) : 0.f;
+}
+
+template <int AKIND, int CKIND, int RTW, int CTW, int WR, int WC>
+int launch(const FsnGemmA& a, const float* wp, const FsnGemmC& c, int row_tiles, int col_tiles, int k_chunks,
+           hipStream_t s) {
+    const long nrb = ((long)row_tiles + WR * RTW - 1) / (WR * RTW);
+    const long ncb = (col_tiles + WC * CTW - 1) / (WC * CTW);
+    hipLaunchKernelGGL((gemm_kernel<AKIND, CKIND, RTW, CTW, WR, WC>), dim3((unsigned)(nrb * ncb)),
+                       dim3(WR * WC * 64), 0, s, a, wp, c, row_tiles, col_tiles, k_chunks);
+    return fsn_check_launch("gemm_kernel");
+}
+
+}  // namespace
+
+int fsn_launch_gemm(const FsnGemmA& a, const float* wp, const FsnGemmC& c, int row_tiles, int col_tiles,
+                    int k_chunks, hipStream_t s) {
+    if (a.kind == 2 && c.kind == 0) return launch<2, 0, 4, 4, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
+    if (a.kind == 1 && c.kind == 0) return launch<1, 0, 4, 4, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
+    if (a.kind == 0 && c.kind == 0) return launch<0, 0, 4, 4, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
+    if (a.kind == 0 && c.kind == 1) return launch<0, 1, 4, 4, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
+    if (a.kind == 0 && c.kind == 2) return launch<0, 2, 4, 1, 4, 1>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
+    fsn_set_error("fsn_launch_gemm: unsupported operand kinds A=%d C=%d", a.kind, c.kind);
+    return FSN_ERR_ARG;
+}
+
+int fsn_launch_pack(const float* w, float* wp, int n_out, int k, int n_out_pad, int k_pad, hipStream_t s) {
+    const int ctiles = n_out_pad / 16, kchunks = k_pad / 16;
+    const long total = (long)ctiles * kchunks * 256;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, s, w, wp, n_out, k, ctiles, kchunks);
+    return fsn_check_launch("pack_kernel");
+}
+
+int fsn_launch_bias_sum(const float* a, const float* b, float* out, int n, int n_pad, hipStream_t s) {
+    hipLaunchKernelGGL(bias_sum_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, s, a, b, out, n, n_pad);
+    return fsn_check_launch("bias_sum_kernel");
+}

@@ -1,0 +1,246 @@
+// Recurrent half of nn.LSTM (audio_zen/model/module/sequence_model.py:52-58,116-117) for gfx950.
+//
+// The input half  W_ih x_t + b_ih + b_hh  of every time step is produced beforehand by
+// gemm_kernels.hip in accumulator-fragment order ("gx").  What is left is, per step,
+//     gates = gx[t] + h_{t-1} W_hh^T ;  c = sig(f) c + sig(i) tanh(g) ;  h = sig(o) tanh(c)
+// with PyTorch's gate order (i, f, g, o) along the 4H axis and h_0 = c_0 = 0.
+//
+// Two kernels, one per regime:
+//   lstm_rec_kernel  - MANY independent sequences (the sub-band model: N = B*F = 16 448 rows).
+//     A workgroup owns 16*RT rows for the whole utterance: h lives in LDS, c in registers, W_hh
+//     streams from L2 as pre-tiled B fragments (2.4 MB, re-read once per step by each workgroup,
+//     ~15 GB/s per CU at RT = 5).  Each wave owns 32 hidden units x all four gates, so the cell
+//     update is lane-local in MFMA accumulator layout; the four gates are accumulated one after
+//     the other to keep accumulators + c + one temporary inside the 168-VGPR budget of 3 waves
+//     per SIMD.  MFMA-bound: 16*RT x 384 x 1536 MAC per step per workgroup.
+//   lstm_step_kernel - FEW sequences (the full-band model: N = B rows), one launch per time step,
+//     work split over hidden units x row tiles x 4-way split-K so that 128+ workgroups share a
+//     64-row problem; h and c live in global memory (L2 resident).
+#include "fsn_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+template <int H, int RT, int UG>
+__global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const float* __restrict__ gx,
+                                                                        const float* __restrict__ whh_p,
+                                                                        float* __restrict__ hseq, int Tp, int Npad) {
+    constexpr int NW = H / (16 * UG);   // waves per workgroup
+    constexpr int KC = H / 16;          // k chunks == unit groups
+    constexpr int CT = 4 * KC;          // column tiles of the gate matrix
+    constexpr int HS = H + 4;           // LDS row stride (floats): 16 B aligned, breaks the 64-bank period
+    constexpr int ROWS = RT * 16;
+    constexpr int UNR = RT >= 3 ? 1 : (RT == 2 ? 2 : 4);  // K-loop unroll: bound the in-flight B fragments
+    extern __shared__ __attribute__((aligned(16))) float hl[];  // [ROWS][HS]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const long n0 = (long)blockIdx.x * ROWS;
+
+    f32x4 cst[RT][UG], tmp[RT][UG];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int u = 0; u < UG; ++u) cst[rt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < ROWS * HS; i += NW * 64) hl[i] = 0.f;
+    __syncthreads();
+
+    for (int t = 0; t < Tp; ++t) {
+        const long gx_rt0 = ((long)t * Npad + n0) >> 4;
+        // gate order of evaluation: f (1), i (0), g (2), o (3)
+#pragma unroll 1
+        for (int pass = 0; pass < 4; ++pass) {
+            const int g = pass == 0 ? 1 : (pass == 1 ? 0 : pass);
+            f32x4 acc[RT][UG];
+            const float* bp[UG];
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {
+                const int ug = wave * UG + u;
+                bp[u] = whh_p + ((long)(g * KC + ug) * KC * 64 + lane) * 4;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt][u] = *reinterpret_cast<const f32x4*>(
+                        gx + (((gx_rt0 + rt) * CT + g * KC + ug) * 64 + lane) * 4);
+            }
+            if (t > 0) {  // h_{-1} = 0
+                f32x4 bn[UG];
+#pragma unroll
+                for (int u = 0; u < UG; ++u) bn[u] = *reinterpret_cast<const f32x4*>(bp[u]);
+#pragma unroll UNR
+                for (int kc = 0; kc < KC; ++kc) {
+                    f32x4 bc[UG];
+#pragma unroll
+                    for (int u = 0; u < UG; ++u) bc[u] = bn[u];
+                    if (kc + 1 < KC) {
+#pragma unroll
+                        for (int u = 0; u < UG; ++u)
+                            bn[u] = *reinterpret_cast<const f32x4*>(bp[u] + (long)(kc + 1) * 256);
+                    }
+                    const float* ap = hl + lr * HS + kc * 16 + 4 * lq;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(ap + rt * 16 * HS);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(a[j], bc[u][j], acc[rt][u]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int u = 0; u < UG; ++u)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float x = acc[rt][u][i];
+                        if (pass == 0) cst[rt][u][i] = sigmoid_f(x) * cst[rt][u][i];
+                        else if (pass == 1) tmp[rt][u][i] = sigmoid_f(x);
+                        else if (pass == 2) cst[rt][u][i] = cst[rt][u][i] + tmp[rt][u][i] * tanhf(x);
+                        else tmp[rt][u][i] = sigmoid_f(x) * tanhf(cst[rt][u][i]);
+                    }
+        }
+        __syncthreads();  // every wave has finished reading h_{t-1}
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int u = 0; u < UG; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    hl[(rt * 16 + 4 * lq + i) * HS + (wave * UG + u) * 16 + lr] = tmp[rt][u][i];
+        __syncthreads();  // h_t complete in LDS
+        // stream h_t out as whole rows: hseq[t][n0 + row][0..H)
+        float* dst = hseq + ((long)t * Npad + n0) * H;
+        for (int i = threadIdx.x; i < ROWS * (H / 4); i += NW * 64) {
+            const int row = i / (H / 4), c4 = i % (H / 4);
+            *reinterpret_cast<f32x4*>(dst + (long)row * H + c4 * 4) =
+                *reinterpret_cast<const f32x4*>(hl + row * HS + c4 * 4);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One time step for a small batch.  grid = (H/16 unit groups, Npad/16 row tiles), 4 waves = 4-way
+// split-K, reduced through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict__ gx,
+                                                        const float* __restrict__ whh_p,
+                                                        const float* __restrict__ h_prev,
+                                                        float* __restrict__ h_out, float* __restrict__ c,
+                                                        long gx_rt0, int H, int first) {
+    __shared__ f32x4 red[3][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int ug = blockIdx.x, rtile = blockIdx.y;
+    const int KC = H >> 4, CT = 4 * KC;
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!first) {
+        const int kc0 = wave * (KC >> 2), kc1 = kc0 + (KC >> 2);
+        const float* ap = h_prev + ((long)rtile * 16 + lr) * H + 4 * lq;
+#pragma unroll 4
+        for (int kc = kc0; kc < kc1; ++kc) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kc * 16);
+            f32x4 b[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                b[g] = *reinterpret_cast<const f32x4*>(whh_p + (((long)(g * KC + ug) * KC + kc) * 64 + lane) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = mfma16(a[j], b[g][j], acc[g]);
+        }
+        if (wave > 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) red[wave - 1][g][lane] = acc[g];
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (!first) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                const f32x4 r = red[w][g][lane];
+                acc[g] = f32x4{acc[g][0] + r[0], acc[g][1] + r[1], acc[g][2] + r[2], acc[g][3] + r[3]};
+            }
+        }
+        const f32x4 x = *reinterpret_cast<const f32x4*>(gx + (((gx_rt0 + rtile) * CT + g * KC + ug) * 64 + lane) * 4);
+        acc[g] = f32x4{acc[g][0] + x[0], acc[g][1] + x[1], acc[g][2] + x[2], acc[g][3] + x[3]};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long idx = ((long)rtile * 16 + 4 * lq + i) * H + ug * 16 + lr;
+        const float c_old = first ? 0.f : c[idx];
+        const float ig = sigmoid_f(acc[0][i]), fg = sigmoid_f(acc[1][i]);
+        const float gg = tanhf(acc[2][i]), og = sigmoid_f(acc[3][i]);
+        const float cn = fg * c_old + ig * gg;
+        c[idx] = cn;
+        h_out[idx] = og * tanhf(cn);
+    }
+}
+
+template <int H, int RT>
+int launch_rec(const float* gx, const float* whh_p, float* hseq, int Tp, int Npad, hipStream_t s) {
+    constexpr int UG = 2;
+    constexpr int NW = H / (16 * UG);
+    const size_t lds = (size_t)RT * 16 * (H + 4) * sizeof(float);
+    auto kern = lstm_rec_kernel<H, RT, UG>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
+        fsn_set_error("lstm_rec: cannot reserve %zu bytes of LDS", lds);
+        return FSN_ERR_LAUNCH;
+    }
+    const unsigned grid = (unsigned)(Npad / (RT * 16));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, gx, whh_p, hseq, Tp, Npad);
+    return fsn_check_launch("lstm_rec_kernel");
+}
+
+}  // namespace
+
+// Rows per workgroup (in 16-row tiles) that minimises the makespan on 256 CUs with one workgroup
+// per CU: ceil(WGs / 256) rounds of RT tiles each.  N = 16 448 -> RT = 5 (206 workgroups, 1 round).
+int fsn_lstm_rec_row_tiles(int N, int H) {
+    (void)H;
+    const int rt_max = 5;  // LDS: 16 RT (H + 4) floats = 124 KB at H = 384
+    const int tiles = (N + 15) / 16;
+    int best = 1;
+    long best_cost = -1;
+    for (int rt = 1; rt <= rt_max; ++rt) {
+        const long wgs = (tiles + rt - 1) / rt;
+        const long rounds = (wgs + 255) / 256;
+        const long cost = rounds * rt * 64 + rounds;  // MFMA time ~ rt per round; tie -> fewer rounds
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && rt > best)) {
+            best = rt;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
+int fsn_launch_lstm_rec(const float* gx, const float* whh_p, float* hseq, int Tp, int Npad, int H, int RT,
+                        hipStream_t s) {
+#define FSN_REC_CASE(HH, R) \
+    if (H == HH && RT == R) return launch_rec<HH, R>(gx, whh_p, hseq, Tp, Npad, s);
+    FSN_REC_CASE(384, 1)
+    FSN_REC_CASE(384, 2)
+    FSN_REC_CASE(384, 3)
+    FSN_REC_CASE(384, 4)
+    FSN_REC_CASE(384, 5)
+#undef FSN_REC_CASE
+    fsn_set_error("lstm_rec: unsupported hidden size %d / row tiles %d (built for H = 384)", H, RT);
+    return FSN_ERR_ARG;
+}
+
+int fsn_launch_lstm_step(const float* gx, const float* whh_p, const float* h_prev, float* h_out, float* c, int t,
+                         int Npad, int H, hipStream_t s) {
+    if (H % 64 != 0) {
+        fsn_set_error("lstm_step: hidden size %d must be a multiple of 64", H);
+        return FSN_ERR_ARG;
+    }
+    const long gx_rt0 = (long)t * (Npad / 16);
+    hipLaunchKernelGGL(lstm_step_kernel, dim3(H / 16, Npad / 16), dim3(256), 0, s, gx, whh_p, h_prev, h_out, c,
+                       gx_rt0, H, t == 0 ? 1 : 0);
+    return fsn_check_launch("lstm_step_kernel");
+}

@@ -1,0 +1,144 @@
+"""Drop-in ``Model`` for ``recipes/dns_interspeech_2020/fullsubnet/model.py`` backed by libfsn_hip.so.
+
+Same constructor keywords, same ``state_dict()`` keys / shapes (released checkpoints load with
+``strict=True``, base_inferencer.py:158), same ``forward(noisy_mag [B,1,F,T]) -> [B,2,F,T]``.
+The PyTorch modules below only *hold* the parameters; no ATen LSTM / Linear / unfold kernel runs.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .acoustics.feature import drop_band
+
+
+class SequenceModel(nn.Module):
+    """Parameter container with the names of audio_zen/model/module/sequence_model.py:26-104
+    (``sequence_model.weight_ih_l0`` ..., ``fc_output_layer.weight``)."""
+
+    def __init__(self, input_size, output_size, hidden_size, num_layers, bidirectional,
+                 sequence_model="LSTM", output_activate_function="Tanh"):
+        super().__init__()
+        if sequence_model != "LSTM":
+            raise NotImplementedError("libfsn_hip implements the LSTM branch (sequence_model.py:51-58); GRU is next")
+        if bidirectional:
+            raise NotImplementedError("unidirectional only (every FullSubNet TOML)")
+        self.sequence_model = nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers,
+                                      batch_first=True, bidirectional=False)
+        self.fc_output_layer = nn.Linear(hidden_size, output_size)
+        self.output_activate_function = output_activate_function
+        self.output_size = output_size
+
+    def forward(self, x):  # pragma: no cover - the fused path in Model.forward is the product
+        raise RuntimeError("SequenceModel is a parameter container; call Model.forward")
+
+
+class Model(nn.Module):
+    def __init__(self, num_freqs, look_ahead, sequence_model, fb_num_neighbors, sb_num_neighbors,
+                 fb_output_activate_function, sb_output_activate_function, fb_model_hidden_size,
+                 sb_model_hidden_size, norm_type="offline_laplace_norm", num_groups_in_drop_band=2,
+                 weight_init=True):
+        """fullsubnet/model.py:10-70 (same arguments)."""
+        super().__init__()
+        assert sequence_model in ("GRU", "LSTM"), f"{self.__class__.__name__} only support GRU and LSTM."
+        if fb_num_neighbors != 0:
+            raise NotImplementedError("fb_num_neighbors must be 0 (every shipped TOML)")
+        if fb_output_activate_function != "ReLU" or sb_output_activate_function:
+            raise NotImplementedError("built for fb ReLU / sb linear output (fullsubnet/train.toml:77-78)")
+        if norm_type not in _lib.NORM_TYPES:
+            raise NotImplementedError(f"norm_type {norm_type!r}: built {sorted(_lib.NORM_TYPES)} (others are next)")
+        self.fb_model = SequenceModel(num_freqs, num_freqs, fb_model_hidden_size, 2, False, sequence_model,
+                                      fb_output_activate_function)
+        self.sb_model = SequenceModel((sb_num_neighbors * 2 + 1) + (fb_num_neighbors * 2 + 1), 2,
+                                      sb_model_hidden_size, 2, False, sequence_model, sb_output_activate_function)
+        self.num_freqs = num_freqs
+        self.sb_num_neighbors = sb_num_neighbors
+        self.fb_num_neighbors = fb_num_neighbors
+        self.look_ahead = look_ahead
+        self.norm_type = norm_type
+        self.num_groups_in_drop_band = num_groups_in_drop_band
+        self._cfg = _lib.Cfg(num_freqs, look_ahead, sb_num_neighbors, fb_model_hidden_size, sb_model_hidden_size,
+                             _lib.NORM_TYPES[norm_type])
+        self._packed = None
+        self._packed_key = None
+        if weight_init:
+            self.apply(self.weight_init)
+
+    # base_model.py:374-439 (pure initialisation, no kernels involved)
+    @staticmethod
+    def weight_init(m):
+        if isinstance(m, nn.Linear):
+            nn.init.xavier_normal_(m.weight.data)
+            nn.init.normal_(m.bias.data)
+        elif isinstance(m, nn.LSTM):
+            for param in m.parameters():
+                if len(param.shape) >= 2:
+                    nn.init.orthogonal_(param.data)
+                else:
+                    nn.init.normal_(param.data)
+
+    # ------------------------------------------------------------------------------------------
+    def _params_in_abi_order(self):
+        sd = dict(self.named_parameters())
+        return [sd[k] for k in _lib.STATE_KEYS]
+
+    def packed_weights(self):
+        """Weights re-tiled into MFMA fragment order; rebuilt whenever a parameter changed."""
+        ps = self._params_in_abi_order()
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+        if self._packed is None or key != self._packed_key:
+            L = _lib.lib()
+            dev = ps[0].device
+            tensors = [p.detach().contiguous() for p in ps]
+            prm = _lib.Params(*[_lib.dev_ptr(t, k) for t, k in zip(tensors, _lib.STATE_KEYS)])
+            nbytes = L.fsn_fullsubnet_packed_bytes(ctypes.byref(self._cfg))
+            packed = _lib.workspace(nbytes, dev)
+            _lib.check(L.fsn_fullsubnet_pack(ctypes.byref(self._cfg), ctypes.byref(prm), packed.data_ptr(),
+                                             packed.numel(), _lib.stream_ptr(dev)))
+            self._packed, self._packed_key = packed, key
+        return self._packed
+
+    def forward(self, noisy_mag):
+        """fullsubnet/model.py:72-136.  noisy_mag [B, 1, F, T] -> compressed cIRM [B, 2, F, T]
+        ([B, 2, F // g, T] when B > 1 and num_groups_in_drop_band = g > 1, quirk Q1)."""
+        assert noisy_mag.dim() == 4
+        batch_size, num_channels, num_freqs, num_frames = noisy_mag.size()
+        assert num_channels == 1, f"{self.__class__.__name__} takes the mag feature as inputs."
+        assert num_freqs == self.num_freqs
+        if torch.is_grad_enabled() and (self.training or noisy_mag.requires_grad):
+            raise NotImplementedError(
+                "the training step (BPTT kernels) is the next row of the scope table; run inference under "
+                "torch.no_grad() / model.eval()")
+        x = noisy_mag.contiguous()
+        L = _lib.lib()
+        out = torch.empty((batch_size, 2, num_freqs, num_frames), dtype=torch.float32, device=x.device)
+        ws = _lib.workspace(L.fsn_fullsubnet_workspace_bytes(ctypes.byref(self._cfg), batch_size, num_frames),
+                            x.device)
+        _lib.check(L.fsn_fullsubnet_forward(ctypes.byref(self._cfg), self.packed_weights().data_ptr(),
+                                            _lib.dev_ptr(x, "noisy_mag"), batch_size, num_frames,
+                                            _lib.dev_ptr(out), ws.data_ptr(), ws.numel(), _lib.stream_ptr(x.device)))
+        if batch_size > 1 and self.num_groups_in_drop_band > 1:
+            # model.py:114-119 drops bands for any B > 1; rows of the sub-band model are independent
+            # and the norm statistics are taken before the drop, so selecting afterwards is identical.
+            out = drop_band(out, num_groups=self.num_groups_in_drop_band)
+        return out
+
+    @torch.no_grad()
+    def enhance(self, noisy, n_fft=512, hop_length=256, return_crm=False):
+        """Whole path of inferencer.py:130-145 in one call: noisy [B, L] -> enhanced [B, L]
+        (full-band masks for every sample, i.e. B independent utterances)."""
+        from .acoustics.feature import hann_window
+        assert noisy.dim() == 2
+        y = noisy.contiguous()
+        B, Ls = y.shape
+        L = _lib.lib()
+        out = torch.empty_like(y)
+        T = 1 + Ls // hop_length
+        crm = torch.empty((B, 2, self.num_freqs, T), dtype=torch.float32, device=y.device) if return_crm else None
+        ws = _lib.workspace(L.fsn_enhance_workspace_bytes(ctypes.byref(self._cfg), B, Ls, n_fft, hop_length), y.device)
+        _lib.check(L.fsn_enhance(ctypes.byref(self._cfg), self.packed_weights().data_ptr(),
+                                 _lib.dev_ptr(hann_window(n_fft, y.device)), _lib.dev_ptr(y, "noisy"), B, Ls, n_fft,
+                                 hop_length, _lib.dev_ptr(out), _lib.dev_ptr(crm, allow_none=True), ws.data_ptr(),
+                                 ws.numel(), _lib.stream_ptr(y.device)))
+        return (out, crm) if return_crm else out

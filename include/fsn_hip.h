@@ -1,0 +1,118 @@
+/*
+ * fsn_hip.h - C ABI of libfsn_hip.so, the MI355X (gfx950) implementation of the FullSubNet
+ * enhancement path.  Every entry point replaces one call site of the reference (cited as
+ * path:line relative to the Audio-WestlakeU/FullSubNet checkout); INTEGRATION.md shows the
+ * ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to contiguous fp32 arrays owned by the caller (PyTorch's
+ *     caching allocator in practice); the library never allocates on the hot path and keeps no
+ *     global state besides its code objects;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued and the call returns at once;
+ *   - return value 0 = OK, < 0 = error; fsn_last_error() gives the thread-local message;
+ *   - tensor shapes use the reference's names: B batch, L samples, F = n_fft/2+1 bins,
+ *     T = 1 + L/hop frames, la = look_ahead.
+ */
+#ifndef FSN_HIP_H
+#define FSN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSN_OK 0
+#define FSN_ERR_ARG (-1)       /* bad shape / null pointer / unsupported configuration */
+#define FSN_ERR_WORKSPACE (-2) /* workspace too small                                  */
+#define FSN_ERR_LAUNCH (-3)    /* hipLaunch / hipMemsetAsync failed                    */
+
+#define FSN_NORM_OFFLINE_LAPLACE 0    /* audio_zen/model/base_model.py:204-218 */
+#define FSN_NORM_CUMULATIVE_LAPLACE 1 /* audio_zen/model/base_model.py:221-251 */
+
+const char* fsn_last_error(void);
+int fsn_version(void);
+
+/* ---- STFT / iSTFT : audio_zen/acoustics/feature.py ------------------------------------- */
+
+/* feature.py:9-50  stft(y, n_fft, hop, win) -> (mag, phase, real, imag); phase is never used on
+ * the path (inferencer.py:132 discards it) and is not produced.
+ * y [B, L];  window [n_fft] (torch.hann_window(n_fft), feature.py:38);  real/imag/mag [B, F, T],
+ * any of the three may be NULL.  Supported: n_fft == win_length == 512, hop == 256. */
+int fsn_stft(const float* y, int B, int L, int n_fft, int hop, int win_length, const float* window,
+             float* real, float* imag, float* mag, void* stream);
+
+/* feature.py:53-91  istft((real, imag), n_fft, hop, win, length, input_type="real_imag").
+ * real/imag [B, F, T] -> y [B, length].  workspace >= fsn_istft_workspace_bytes(B, T, n_fft). */
+size_t fsn_istft_workspace_bytes(int B, int T, int n_fft);
+int fsn_istft(const float* real, const float* imag, int B, int T, int n_fft, int hop, int win_length,
+              const float* window, int length, float* y, void* workspace, size_t workspace_bytes,
+              void* stream);
+
+/* ---- cIRM mask algebra : audio_zen/acoustics/mask.py ----------------------------------- */
+
+/* mask.py:47-64  decompress_cIRM(mask, K=10, limit=9.9), elementwise over n floats. */
+int fsn_decompress_cirm(const float* mask, float* out, size_t n, void* stream);
+/* mask.py:32-44  compress_cIRM(mask, K=10, C=0.1). */
+int fsn_compress_cirm(const float* mask, float* out, size_t n, void* stream);
+/* mask.py:7-29  build_complex_ideal_ratio_mask: four [n] planes -> out [n, 2] (compressed). */
+int fsn_build_cirm(const float* noisy_real, const float* noisy_imag, const float* clean_real,
+                   const float* clean_imag, float* out, size_t n, void* stream);
+
+/* ---- FullSubNet model : recipes/dns_interspeech_2020/fullsubnet/model.py --------------- */
+
+typedef struct fsn_fullsubnet_cfg {
+    int num_freqs;        /* model.py:12  (257)                                   */
+    int look_ahead;       /* model.py:13  (2)                                     */
+    int sb_num_neighbors; /* model.py:16  (15); fb_num_neighbors must be 0        */
+    int fb_hidden;        /* model.py:19  (512), multiple of 32                   */
+    int sb_hidden;        /* model.py:20  (384), multiple of 32                   */
+    int norm_type;        /* model.py:21  FSN_NORM_*                              */
+} fsn_fullsubnet_cfg;
+
+/* The 20 tensors of Model.state_dict() in the reference's layout (nn.LSTM: weight_ih [4H, I],
+ * weight_hh [4H, H], gate rows i,f,g,o; nn.Linear: weight [O, I]).  SURVEY §8a rows A5 / A9. */
+typedef struct fsn_fullsubnet_params {
+    const float *fb_w_ih_l0, *fb_w_hh_l0, *fb_b_ih_l0, *fb_b_hh_l0;
+    const float *fb_w_ih_l1, *fb_w_hh_l1, *fb_b_ih_l1, *fb_b_hh_l1;
+    const float *fb_fc_w, *fb_fc_b;
+    const float *sb_w_ih_l0, *sb_w_hh_l0, *sb_b_ih_l0, *sb_b_hh_l0;
+    const float *sb_w_ih_l1, *sb_w_hh_l1, *sb_b_ih_l1, *sb_b_hh_l1;
+    const float *sb_fc_w, *sb_fc_b;
+} fsn_fullsubnet_params;
+
+/* Re-tile the weights into MFMA B-fragment order (done once per checkpoint load, the analogue of
+ * nn.LSTM.flatten_parameters(), sequence_model.py:114). */
+size_t fsn_fullsubnet_packed_bytes(const fsn_fullsubnet_cfg* cfg);
+int fsn_fullsubnet_pack(const fsn_fullsubnet_cfg* cfg, const fsn_fullsubnet_params* params,
+                        void* packed, size_t packed_bytes, void* stream);
+
+/* model.py:72-136  Model.forward(noisy_mag [B,1,F,T]) -> compressed cIRM [B,2,F,T]
+ * (inference semantics: every sample keeps all F bins, i.e. num_groups_in_drop_band = 1, see
+ * SURVEY quirk Q1). */
+size_t fsn_fullsubnet_workspace_bytes(const fsn_fullsubnet_cfg* cfg, int B, int T);
+int fsn_fullsubnet_forward(const fsn_fullsubnet_cfg* cfg, const void* packed, const float* noisy_mag,
+                           int B, int T, float* crm_out, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
+/* recipes/dns_interspeech_2020/inferencer.py:130-145  Inferencer.full_band_crm_mask:
+ * noisy [B, L] -> enhanced [B, L] (stft -> model -> decompress -> complex mask -> istft), all
+ * intermediates kept in the frame-major device layout.  crm_out (optional, may be NULL) receives
+ * the compressed mask [B, 2, F, T] for parity checks. */
+size_t fsn_enhance_workspace_bytes(const fsn_fullsubnet_cfg* cfg, int B, int L, int n_fft, int hop);
+int fsn_enhance(const fsn_fullsubnet_cfg* cfg, const void* packed, const float* window,
+                const float* noisy, int B, int L, int n_fft, int hop, float* enhanced, float* crm_out,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* Per-stage kernel timing of the last fsn_enhance / fsn_fullsubnet_forward call made with
+ * profiling enabled (hipEvents on `stream`; forces a stream sync when read).  Stage ids are listed
+ * by fsn_profile_stage_name(); used by bench.py for the roofline line.  */
+int fsn_profile_enable(int on);
+int fsn_profile_num_stages(void);
+const char* fsn_profile_stage_name(int stage);
+int fsn_profile_read(float* ms_per_stage, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSN_HIP_H */

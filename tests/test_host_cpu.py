@@ -1,0 +1,102 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/fsn_hip.h declares,
+the ctypes table matches the header, and the host-side mirror keeps the reference's surface.
+No GPU compute is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "fsn_hip.h")
+
+
+def header_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fsn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_entry_points():
+    syms = header_symbols()
+    for must in ("fsn_stft", "fsn_istft", "fsn_fullsubnet_forward", "fsn_fullsubnet_pack", "fsn_enhance",
+                 "fsn_decompress_cirm", "fsn_last_error"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from fullsubnet_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.fail(f"{_lib.LIB_PATH} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for s in header_symbols():
+        assert hasattr(handle, s), f"{s} declared in include/fsn_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == header_symbols(), "ctypes table and header disagree"
+    L = _lib.lib()
+    assert L.fsn_version() >= 100
+    names = _lib.profile_stage_names()
+    assert "sb_rec_l1" in names and len(names) == L.fsn_profile_num_stages()
+
+
+def test_argument_validation_without_a_gpu():
+    from fullsubnet_amd import _lib
+    L = _lib.lib()
+    bad = _lib.Cfg(257, 2, 15, 512, 100, 0)  # unsupported sub-band hidden size
+    assert L.fsn_fullsubnet_packed_bytes(ctypes.byref(bad)) == 0
+    assert b"sb_hidden" in L.fsn_last_error()
+    ok = _lib.Cfg(257, 2, 15, 512, 384, 0)
+    nbytes = L.fsn_fullsubnet_packed_bytes(ctypes.byref(ok))
+    assert nbytes >= 5_637_635 * 4  # at least the parameter count of the model
+    ws2 = L.fsn_enhance_workspace_bytes(ctypes.byref(ok), 2, 16000, 512, 256)
+    ws64 = L.fsn_enhance_workspace_bytes(ctypes.byref(ok), 64, 48000, 512, 256)
+    assert 0 < ws2 < ws64 < 64 << 30
+    assert L.fsn_enhance_workspace_bytes(ctypes.byref(ok), 2, 16000, 400, 100) == 0  # unsupported FFT
+    with pytest.raises(_lib.FsnError):
+        _lib.dev_ptr(torch.zeros(4), "x")  # CPU tensor is rejected, no fallback
+
+
+def test_model_surface_matches_reference_state_dict():
+    from fullsubnet_amd import Model, _lib
+    from oracle.fullsubnet_oracle import make_params
+    m = Model(num_freqs=257, look_ahead=2, sequence_model="LSTM", fb_num_neighbors=0, sb_num_neighbors=15,
+              fb_output_activate_function="ReLU", sb_output_activate_function=False, fb_model_hidden_size=512,
+              sb_model_hidden_size=384, norm_type="offline_laplace_norm", num_groups_in_drop_band=2,
+              weight_init=True)
+    ref = make_params(seed=0)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.keys())  # same names, same order as the reference's Model
+    for k, v in ref.items():
+        assert tuple(sd[k].shape) == v.shape, k
+    assert sorted(_lib.STATE_KEYS) == sorted(ref.keys())
+    assert sum(p.numel() for p in m.parameters()) == 5_637_635
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in ref.items()}, strict=True)
+    # orthogonal init ran (base_model.py:416-421)
+    m2 = Model(num_freqs=257, look_ahead=2, sequence_model="LSTM", fb_num_neighbors=0, sb_num_neighbors=15,
+               fb_output_activate_function="ReLU", sb_output_activate_function=False, fb_model_hidden_size=512,
+               sb_model_hidden_size=384, weight_init=True)
+    w = m2.sb_model.sequence_model.weight_hh_l0.detach()
+    assert torch.allclose(w.T @ w, torch.eye(384), atol=1e-4)
+    with pytest.raises(Exception):
+        m(torch.zeros(1, 1, 257, 10))  # CPU tensor: there is no fallback path
+
+
+def test_drop_band_mirror_matches_golden(golden_dir):
+    from fullsubnet_amd import drop_band
+    z = np.load(os.path.join(golden_dir, "elementwise.npz"))
+    np.testing.assert_array_equal(drop_band(torch.from_numpy(z["x"]), 2).numpy(), z["drop2"])
+    np.testing.assert_array_equal(drop_band(torch.from_numpy(z["x"]), 3).numpy(), z["drop3"])
+
+
+def test_drop_band_after_the_model_equals_drop_band_before(golden_dir):
+    """Host logic of Model.forward for B > 1: selecting rows of the full mask afterwards is what the
+    reference computes by dropping bands before the sub-band model (quirk Q1)."""
+    import ast
+    from oracle import fullsubnet_oracle as O
+    z = np.load(os.path.join(golden_dir, "fsn_dropband_b4.npz"))
+    meta = ast.literal_eval(str(z["meta"]))
+    params = O.make_params(seed=meta["seed_w"], gain=meta["gain"], mask_gain=meta["mask_gain"])
+    full = O.fullsubnet_forward(z["mag"][:, None], params, num_groups_in_drop_band=1)
+    sel = O.drop_band(full, 2)
+    assert np.abs(sel - z["crm"]).max() <= 1e-4
