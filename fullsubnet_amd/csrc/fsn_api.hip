@@ -50,39 +50,36 @@ enum Stage {
 static const char* kStageNames[ST_COUNT] = {"stft",       "norm",       "fb_gemm",    "fb_rec", "sb_gemm_l0",
                                             "sb_rec_l0",  "sb_gemm_l1", "sb_rec_l1",  "sb_fc",  "mask_istft"};
 static int g_prof_on = 0;
-static hipEvent_t g_ev[2 * ST_COUNT];
+constexpr int kMaxSpans = 4;  // a stage may be entered several times per call (once per layer)
+static hipEvent_t g_ev[ST_COUNT][kMaxSpans][2];
 static bool g_ev_made = false;
-static bool g_ev_used[ST_COUNT];
-static float g_ms_acc[ST_COUNT];
+static int g_spans[ST_COUNT];
 
 struct StageTimer {
-    int st;
+    int st, span;
     hipStream_t s;
-    StageTimer(int stage, hipStream_t stream) : st(stage), s(stream) {
+    StageTimer(int stage, hipStream_t stream) : st(stage), span(-1), s(stream) {
         if (!g_prof_on) return;
         if (!g_ev_made) {
-            for (int i = 0; i < 2 * ST_COUNT; ++i) hipEventCreate(&g_ev[i]);
+            for (int i = 0; i < ST_COUNT; ++i)
+                for (int j = 0; j < kMaxSpans; ++j) {
+                    (void)hipEventCreate(&g_ev[i][j][0]);
+                    (void)hipEventCreate(&g_ev[i][j][1]);
+                }
             g_ev_made = true;
         }
-        if (g_ev_used[st]) {  // stage re-entered (fb_gemm / fb_rec run once per layer): fold the previous span
-            float ms = 0.f;
-            hipEventSynchronize(g_ev[2 * st + 1]);
-            hipEventElapsedTime(&ms, g_ev[2 * st], g_ev[2 * st + 1]);
-            g_ms_acc[st] += ms;
-        }
-        hipEventRecord(g_ev[2 * st], s);
+        if (g_spans[st] >= kMaxSpans) return;
+        span = g_spans[st];
+        (void)hipEventRecord(g_ev[st][span][0], s);
     }
     ~StageTimer() {
-        if (!g_prof_on) return;
-        hipEventRecord(g_ev[2 * st + 1], s);
-        g_ev_used[st] = true;
+        if (span < 0) return;
+        (void)hipEventRecord(g_ev[st][span][1], s);
+        g_spans[st] = span + 1;
     }
 };
 static void prof_reset() {
-    for (int i = 0; i < ST_COUNT; ++i) {
-        g_ev_used[i] = false;
-        g_ms_acc[i] = 0.f;
-    }
+    for (int i = 0; i < ST_COUNT; ++i) g_spans[i] = 0;
 }
 extern "C" int fsn_profile_enable(int on) {
     g_prof_on = on ? 1 : 0;
@@ -93,17 +90,21 @@ extern "C" int fsn_profile_num_stages(void) { return ST_COUNT; }
 extern "C" const char* fsn_profile_stage_name(int stage) {
     return (stage >= 0 && stage < ST_COUNT) ? kStageNames[stage] : "";
 }
+// Milliseconds per stage of the LAST profiled call; waits for that call's events only.
 extern "C" int fsn_profile_read(float* ms, int n) {
     if (!ms || n < ST_COUNT) {
         fsn_set_error("fsn_profile_read: need room for %d stages", (int)ST_COUNT);
         return FSN_ERR_ARG;
     }
     for (int i = 0; i < ST_COUNT; ++i) {
-        float v = g_ms_acc[i];
-        if (g_prof_on && g_ev_used[i]) {
+        float v = 0.f;
+        for (int j = 0; j < g_spans[i]; ++j) {
             float e = 0.f;
-            hipEventSynchronize(g_ev[2 * i + 1]);
-            hipEventElapsedTime(&e, g_ev[2 * i], g_ev[2 * i + 1]);
+            if (hipEventSynchronize(g_ev[i][j][1]) != hipSuccess ||
+                hipEventElapsedTime(&e, g_ev[i][j][0], g_ev[i][j][1]) != hipSuccess) {
+                fsn_set_error("fsn_profile_read: event query failed for stage %s", kStageNames[i]);
+                return FSN_ERR_LAUNCH;
+            }
             v += e;
         }
         ms[i] = v;

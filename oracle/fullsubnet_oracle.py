@@ -219,6 +219,17 @@ def _sigmoid(x):
     return 1.0 / (1.0 + np.exp(-x))
 
 
+try:  # BLAS backend for the two GEMMs of the LSTM cell: torch's CPU matmul (MKL, all host cores) is
+    # ~8x faster than this image's numpy/OpenBLAS build; everything else stays explicit numpy.
+    import torch as _torch
+
+    def _matmul(a, b):
+        return (_torch.from_numpy(np.ascontiguousarray(a)) @ _torch.from_numpy(np.ascontiguousarray(b))).numpy()
+except ImportError:  # pragma: no cover
+    def _matmul(a, b):
+        return a @ b
+
+
 def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, dtype=np.float32):
     """One unidirectional nn.LSTM layer, batch_first, h0 = c0 = 0.
 
@@ -232,23 +243,27 @@ def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, dtype=np.float32):
     w_ih = np.asarray(w_ih, dtype=dtype)
     w_hh = np.asarray(w_hh, dtype=dtype)
     bias = (np.asarray(b_ih, dtype=dtype) + np.asarray(b_hh, dtype=dtype)).astype(dtype)
-    N, T, _ = x.shape
+    N, T, I = x.shape
     H = w_hh.shape[1]
     h = np.zeros((N, H), dtype=dtype)
     c = np.zeros((N, H), dtype=dtype)
-    out = np.empty((N, T, H), dtype=dtype)
+    out = np.empty((T, N, H), dtype=dtype)  # time-major scratch: every per-step slice is contiguous
     w_ih_t = np.ascontiguousarray(w_ih.T)
     w_hh_t = np.ascontiguousarray(w_hh.T)
+    xw = _matmul(np.ascontiguousarray(x.transpose(1, 0, 2)).reshape(T * N, I), w_ih_t)
+    xw += bias
+    xw = xw.reshape(T, N, 4 * H)
     for t in range(T):
-        gates = (x[:, t] @ w_ih_t + h @ w_hh_t + bias).astype(dtype)
+        gates = xw[t]
+        gates += _matmul(h, w_hh_t)
         i = _sigmoid(gates[:, 0:H])
         f = _sigmoid(gates[:, H:2 * H])
         g = np.tanh(gates[:, 2 * H:3 * H])
         o = _sigmoid(gates[:, 3 * H:4 * H])
-        c = (f * c + i * g).astype(dtype)
-        h = (o * np.tanh(c)).astype(dtype)
-        out[:, t] = h
-    return out
+        c = f * c + i * g
+        h = o * np.tanh(c)
+        out[t] = h
+    return np.ascontiguousarray(out.transpose(1, 0, 2))
 
 
 def sequence_model(x, params, prefix, num_layers=2, activation=None, dtype=np.float32):
