@@ -36,6 +36,29 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Gate non-linearities of the MFMA-bound recurrent kernel on the hardware transcendentals
+// (v_exp_f32 / v_rcp_f32, ~1 ULP each): 4-5 VALU instructions per value instead of ~30 for the
+// libm-accurate forms.  Absolute error <= ~2e-7, the size of one fp32 rounding of the gate
+// pre-activation itself; the end-to-end effect on the compressed mask is measured by the parity
+// tests (tests/test_gpu_parity.py).  -DFSN_ACCURATE_ACT=1 switches back to expf / tanhf.
+#ifndef FSN_ACCURATE_ACT
+#define FSN_ACCURATE_ACT 0
+#endif
+__device__ __forceinline__ float sigmoid_fast(float x) {
+#if FSN_ACCURATE_ACT
+    return sigmoid_f(x);
+#else
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+#endif
+}
+__device__ __forceinline__ float tanh_fast(float x) {
+#if FSN_ACCURATE_ACT
+    return tanhf(x);
+#else
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+#endif
+}
+
 // Bijective XCD-aware block remap: block b runs on XCD b % 8 (observed, speed only); give each
 // XCD a contiguous chunk of the virtual grid so neighbouring tiles share that XCD's L2.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {

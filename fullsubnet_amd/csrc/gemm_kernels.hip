@@ -18,6 +18,10 @@
 // (base_model.py:31-44, fullsubnet/model.py:110-111) are never materialised.
 #include "fsn_common.h"
 
+#ifndef FSN_GEMM_ABLATE
+#define FSN_GEMM_ABLATE 0  // probe-only: 1 = no operand loads in the K loop, 2 = no MFMAs
+#endif
+
 namespace {
 
 __device__ __forceinline__ int reflect_idx(int j, int F) {
@@ -40,6 +44,20 @@ struct ARow<0> {  // row-major matrix [R][ld]
     }
     __device__ __forceinline__ f32x4 load(const FsnGemmA&, int k0) const {
         return *reinterpret_cast<const f32x4*>(base + k0);
+    }
+};
+
+template <>
+struct ARow<3> {  // A already in fragment order: [rtile][kchunk][lane][4] (what lstm_rec_kernel emits)
+    const float* base;
+    long kstride;
+    __device__ __forceinline__ void prepare(const FsnGemmA& a, long row, long nrows) {
+        row = row < nrows ? row : nrows - 1;
+        // a.ld = K (floats per row); tile = row / 16, lane-in-tile handled by the caller's lane id
+        base = a.p0 + (row >> 4) * (a.ld * 16) + (threadIdx.x & 63) * 4;
+    }
+    __device__ __forceinline__ f32x4 load(const FsnGemmA&, int k0) const {
+        return *reinterpret_cast<const f32x4*>(base + (long)(k0 >> 4) * 256);
     }
 };
 
@@ -100,10 +118,9 @@ struct ARow<2> {  // sub-band model input: row (t, n = b F + f), 2 nb + 2 channe
 // C stores.  acc register i of lane l is C[16 rtile + 4 (l>>4) + i][16 ctile + (l&15)].
 // ------------------------------------------------------------------------------------------
 template <int KIND>
-__device__ __forceinline__ void store_tile(const FsnGemmC& c, f32x4 acc, long rtile, int ctile, int col_tiles,
-                                           int lane) {
+__device__ __forceinline__ void store_tile(const FsnGemmC& c, f32x4 acc, float bias, long rtile, int ctile,
+                                           int col_tiles, int lane) {
     const int col = ctile * 16 + (lane & 15);
-    const float bias = c.bias ? c.bias[col] : 0.f;
     if (KIND == 0) {
         // fragment order: tile (rtile, ctile) is one contiguous 1 KB block [lane][reg]; this is the
         // accumulator-init layout of the recurrent kernels.
@@ -131,28 +148,48 @@ __device__ __forceinline__ void store_tile(const FsnGemmC& c, f32x4 acc, long rt
     }
 }
 
-template <int AKIND, int CKIND, int RTW, int CTW, int WR, int WC>
+template <int AKIND, int CKIND, int RTW, int CTW, int WR, int WC, int PF>
 __global__ __launch_bounds__(WR* WC * 64) void gemm_kernel(FsnGemmA a, const float* __restrict__ wp, FsnGemmC c,
                                                            int row_tiles, int col_tiles, int k_chunks) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave / WC, wc = wave % WC;
     const unsigned ncb = (col_tiles + WC * CTW - 1) / (WC * CTW);
-    const unsigned v = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned nrb = (unsigned)(((long)row_tiles + WR * RTW - 1) / (WR * RTW));
+    const unsigned ntiles = nrb * ncb;
+    const long nrows = (long)row_tiles * 16;
+    const int kq = 4 * (lane >> 4);
+    // Persistent workgroups: the grid is sized to fill the chip once (short-lived workgroups were
+    // measured at ~half the residency the register budget allows), each workgroup walks over
+    // output tiles.  XCD x (block b runs on XCD b % 8 - speed only) owns one contiguous range of
+    // the tile list, rows-major with the column blocks of a row block adjacent, so the workgroups
+    // of one XCD work on neighbouring tiles at the same time and share A rows / B panels in its L2.
+#ifdef FSN_GEMM_PLACEMENT
+    if (threadIdx.x == 0) {
+        FSN_GEMM_PLACEMENT[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
+        FSN_GEMM_PLACEMENT[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    }
+#endif
+    const unsigned xcd = blockIdx.x & 7u, lid = blockIdx.x >> 3, lstride = (gridDim.x + 7u - xcd) >> 3;
+    const unsigned tq = ntiles >> 3, tr = ntiles & 7u;
+    const unsigned tbeg = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const unsigned tcnt = tq + (xcd < tr ? 1u : 0u);
+    for (unsigned ti = lid; ti < tcnt; ti += lstride) {
+    const unsigned v = tbeg + ti;
     const unsigned rb = v / ncb, cb = v % ncb;
     const long rtile0 = ((long)rb * WR + wr) * RTW;
     const int ctile0 = ((int)cb * WC + wc) * CTW;
-    const long nrows = (long)row_tiles * 16;
-    const int kq = 4 * (lane >> 4);
 
     ARow<AKIND> arow[RTW];
 #pragma unroll
     for (int rt = 0; rt < RTW; ++rt) arow[rt].prepare(a, (rtile0 + rt) * 16 + (lane & 15), nrows);
     const float* bptr[CTW];
+    float biasv[CTW];
 #pragma unroll
     for (int ct = 0; ct < CTW; ++ct) {
         int ctile = ctile0 + ct;
         ctile = ctile < col_tiles ? ctile : col_tiles - 1;
         bptr[ct] = wp + ((long)ctile * k_chunks * 64 + lane) * 4;
+        biasv[ct] = c.bias ? c.bias[ctile * 16 + (lane & 15)] : 0.f;
     }
 
     f32x4 acc[RTW][CTW];
@@ -161,31 +198,64 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm_kernel(FsnGemmA a, const flo
 #pragma unroll
         for (int ct = 0; ct < CTW; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x4 an[RTW], bn[CTW];
+    // Register ring of PF operand chunks.  The steady-state loop is branch-free (tail loads are
+    // clamped to the last chunk and simply re-read it) so that the compiler can count its own
+    // outstanding loads: it then waits with vmcnt(8 (PF-1)) instead of draining the queue before
+    // every chunk.  Chunk kc + PF is requested right after chunk kc has been consumed.
+    f32x4 abuf[PF][RTW], bbuf[PF][CTW];
+    const int last = k_chunks - 1;
 #pragma unroll
-    for (int rt = 0; rt < RTW; ++rt) an[rt] = arow[rt].load(a, kq);
+    for (int p = 0; p < PF; ++p) {
+        const int kc = p < last ? p : last;
 #pragma unroll
-    for (int ct = 0; ct < CTW; ++ct) bn[ct] = *reinterpret_cast<const f32x4*>(bptr[ct]);
-
-    for (int kc = 0; kc < k_chunks; ++kc) {
-        f32x4 ac[RTW], bc[CTW];
+        for (int rt = 0; rt < RTW; ++rt) abuf[p][rt] = arow[rt].load(a, kc * 16 + kq);
 #pragma unroll
-        for (int rt = 0; rt < RTW; ++rt) ac[rt] = an[rt];
+        for (int ct = 0; ct < CTW; ++ct) bbuf[p][ct] = *reinterpret_cast<const f32x4*>(bptr[ct] + (long)kc * 256);
+    }
+    const int k_main = (k_chunks / PF) * PF;
+    for (int kc0 = 0; kc0 < k_main; kc0 += PF) {
 #pragma unroll
-        for (int ct = 0; ct < CTW; ++ct) bc[ct] = bn[ct];
-        if (kc + 1 < k_chunks) {
+        for (int p = 0; p < PF; ++p) {
+#if FSN_GEMM_ABLATE != 2
 #pragma unroll
-            for (int rt = 0; rt < RTW; ++rt) an[rt] = arow[rt].load(a, (kc + 1) * 16 + kq);
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int ct = 0; ct < CTW; ++ct)
-                bn[ct] = *reinterpret_cast<const f32x4*>(bptr[ct] + (long)(kc + 1) * 256);
+                for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < CTW; ++ct)
+                        acc[rt][ct] = mfma16(abuf[p][rt][j], bbuf[p][ct][j], acc[rt][ct]);
+#else
+#pragma unroll
+            for (int rt = 0; rt < RTW; ++rt) asm volatile("" ::"v"(abuf[p][rt]));
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct) asm volatile("" ::"v"(bbuf[p][ct]));
+#endif
+#if FSN_GEMM_ABLATE != 1
+            // pin the refill of slot p right here: hipcc otherwise sinks these loads down to their
+            // first use (one ring turn later), which turns the ring into load -> wait -> use
+            __builtin_amdgcn_sched_barrier(0);
+            int kn = kc0 + p + PF;
+            kn = kn < last ? kn : last;
+#pragma unroll
+            for (int rt = 0; rt < RTW; ++rt) abuf[p][rt] = arow[rt].load(a, kn * 16 + kq);
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct) bbuf[p][ct] = *reinterpret_cast<const f32x4*>(bptr[ct] + (long)kn * 256);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
+    }
+    // remainder chunks (k_chunks % PF of them) are already sitting in the ring, in order
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+    for (int p = 0; p < PF - 1; ++p) {
+        if (k_main + p < k_chunks) {
 #pragma unroll
-            for (int rt = 0; rt < RTW; ++rt)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int ct = 0; ct < CTW; ++ct) acc[rt][ct] = mfma16(ac[rt][j], bc[ct][j], acc[rt][ct]);
+                for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < CTW; ++ct)
+                        acc[rt][ct] = mfma16(abuf[p][rt][j], bbuf[p][ct][j], acc[rt][ct]);
+        }
     }
 
 #pragma unroll
@@ -193,7 +263,8 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm_kernel(FsnGemmA a, const flo
 #pragma unroll
         for (int ct = 0; ct < CTW; ++ct)
             if (rtile0 + rt < row_tiles && ctile0 + ct < col_tiles)
-                store_tile<CKIND>(c, acc[rt][ct], rtile0 + rt, ctile0 + ct, col_tiles, lane);
+                store_tile<CKIND>(c, acc[rt][ct], biasv[ct], rtile0 + rt, ctile0 + ct, col_tiles, lane);
+    }  // tile loop
 }
 
 // W [n_out][k] (nn.LSTM / nn.Linear layout) -> B-fragment order [n_out_pad/16][k_pad/16][64][4]
@@ -215,24 +286,55 @@ __global__ void bias_sum_kernel(const float* __restrict__ a, const float* __rest
     if (i < n_pad) out[i] = i < n ? (b ? a[i] + b[i] : a[i]) : 0.f;
 }
 
-template <int AKIND, int CKIND, int RTW, int CTW, int WR, int WC>
+// Launch geometry.  Measured on MI355X (tools/probe_gemm.hip, profiles/r01_gemm_probe.md): two waves
+// that both stream MFMAs on one SIMD alternate instruction by instruction and lose ~45 % of the
+// matrix pipe, while ONE wave per SIMD with a large register tile (4x8 tiles = 64x128 outputs, 128
+// accumulator VGPRs + a 2-deep operand ring) sustains ~140 TFLOP/s (90 % of the fp32 MFMA peak).
+// So the big GEMMs run as exactly one 4-wave workgroup per CU (enforced with an LDS reservation
+// the kernel never touches), persistent over the tile list.
+template <int AKIND, int CKIND, int RTW, int CTW, int WR, int WC, int PF = 2>
 int launch(const FsnGemmA& a, const float* wp, const FsnGemmC& c, int row_tiles, int col_tiles, int k_chunks,
-           hipStream_t s) {
+           hipStream_t s, int wg_per_cu = 0, size_t lds_reserve = 0) {
     const long nrb = ((long)row_tiles + WR * RTW - 1) / (WR * RTW);
     const long ncb = (col_tiles + WC * CTW - 1) / (WC * CTW);
-    hipLaunchKernelGGL((gemm_kernel<AKIND, CKIND, RTW, CTW, WR, WC>), dim3((unsigned)(nrb * ncb)),
-                       dim3(WR * WC * 64), 0, s, a, wp, c, row_tiles, col_tiles, k_chunks);
+    auto kern = gemm_kernel<AKIND, CKIND, RTW, CTW, WR, WC, PF>;
+    static int occ = 0;  // per instantiation
+    if (occ == 0) {
+        int n = 0;
+        if (lds_reserve > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_reserve) != hipSuccess) {
+            fsn_set_error("gemm: cannot reserve %zu bytes of LDS", lds_reserve);
+            return FSN_ERR_LAUNCH;
+        }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, WR * WC * 64, lds_reserve) != hipSuccess || n < 1)
+            n = 1;
+        occ = n;
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    long grid = (long)cus * (wg_per_cu > 0 ? wg_per_cu : occ);
+    if (grid > nrb * ncb) grid = nrb * ncb;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WR * WC * 64), lds_reserve, s, a, wp, c, row_tiles,
+                       col_tiles, k_chunks);
     return fsn_check_launch("gemm_kernel");
 }
+
+constexpr size_t kOnePerCu = 96 * 1024;  // > 160 KB / 2: at most one such workgroup fits a CU
 
 }  // namespace
 
 int fsn_launch_gemm(const FsnGemmA& a, const float* wp, const FsnGemmC& c, int row_tiles, int col_tiles,
                     int k_chunks, hipStream_t s) {
-    if (a.kind == 2 && c.kind == 0) return launch<2, 0, 4, 4, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
-    if (a.kind == 1 && c.kind == 0) return launch<1, 0, 4, 4, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
-    if (a.kind == 0 && c.kind == 0) return launch<0, 0, 4, 4, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
-    if (a.kind == 0 && c.kind == 1) return launch<0, 1, 4, 4, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
+    if (a.kind == 2 && c.kind == 0)
+        return launch<2, 0, 4, 8, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s, 1, kOnePerCu);
+    if (a.kind == 1 && c.kind == 0)
+        return launch<1, 0, 4, 8, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s, 1, kOnePerCu);
+    if (a.kind == 0 && c.kind == 0)
+        return launch<0, 0, 4, 8, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s, 1, kOnePerCu);
+    if (a.kind == 0 && c.kind == 1)
+        return launch<0, 1, 4, 8, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s, 1, kOnePerCu);
+    // 2-column output layer: HBM-bound on reading the hidden sequence -> many waves in flight
     if (a.kind == 0 && c.kind == 2) return launch<0, 2, 4, 1, 4, 1>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
     fsn_set_error("fsn_launch_gemm: unsupported operand kinds A=%d C=%d", a.kind, c.kind);
     return FSN_ERR_ARG;

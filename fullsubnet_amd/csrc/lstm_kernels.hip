@@ -94,10 +94,10 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const fl
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float x = acc[rt][u][i];
-                        if (pass == 0) cst[rt][u][i] = sigmoid_f(x) * cst[rt][u][i];
-                        else if (pass == 1) tmp[rt][u][i] = sigmoid_f(x);
-                        else if (pass == 2) cst[rt][u][i] = cst[rt][u][i] + tmp[rt][u][i] * tanhf(x);
-                        else tmp[rt][u][i] = sigmoid_f(x) * tanhf(cst[rt][u][i]);
+                        if (pass == 0) cst[rt][u][i] = sigmoid_fast(x) * cst[rt][u][i];
+                        else if (pass == 1) tmp[rt][u][i] = sigmoid_fast(x);
+                        else if (pass == 2) cst[rt][u][i] = cst[rt][u][i] + tmp[rt][u][i] * tanh_fast(x);
+                        else tmp[rt][u][i] = sigmoid_fast(x) * tanh_fast(cst[rt][u][i]);
                     }
         }
         __syncthreads();  // every wave has finished reading h_{t-1}
