@@ -221,7 +221,8 @@ extern "C" int fsn_fullsubnet_pack(const fsn_fullsubnet_cfg* cfg, const fsn_full
 struct CoreDims {
     int B, T, Tp, F, FP, Hf, Hs, nb, la;
     int Npad_fb;       // full-band rows per step (batch, padded to 16)
-    int N, RT, Npad;   // sub-band rows per step, row tiles per workgroup, padded rows
+    int N, Npad;       // sub-band rows per step, padded rows (row stride of the [t][n] buffers)
+    FsnRecPlan rec;    // how those rows are spread over the CUs
 };
 static CoreDims core_dims(const fsn_fullsubnet_cfg* c, int B, int T) {
     CoreDims d;
@@ -236,12 +237,12 @@ static CoreDims core_dims(const fsn_fullsubnet_cfg* c, int B, int T) {
     d.nb = c->sb_num_neighbors;
     d.Npad_fb = fsn_round_up(B, 16);
     d.N = B * d.F;
-    d.RT = fsn_lstm_rec_row_tiles(d.N, d.Hs);
-    d.Npad = fsn_round_up(d.N, 16 * d.RT);
+    d.rec = fsn_lstm_rec_plan(d.N, d.Hs);
+    d.Npad = d.rec.npad;
     return d;
 }
 struct CoreWs {
-    float *gx_fb, *hseq_fb0, *hseq_fb1, *c_fb, *fb_out, *den_fb, *den_sb, *gx_sb, *hseq_sb0, *hseq_sb1;
+    float *gx_fb, *hseq_fb0, *hseq_fb1, *c_fb, *fb_out, *den_fb, *den_sb, *gx_sb, *hseq_sb0, *hseq_sb1, *c_left;
     double* binsum;
 };
 static CoreWs core_carve(Carver& cv, const CoreDims& d, int norm_type) {
@@ -259,7 +260,54 @@ static CoreWs core_carve(Carver& cv, const CoreDims& d, int norm_type) {
     w.gx_sb = cv.take<float>(rows_sb * 4 * d.Hs);
     w.hseq_sb0 = cv.take<float>(rows_sb * d.Hs);
     w.hseq_sb1 = cv.take<float>(rows_sb * d.Hs);
+    w.c_left = cv.take<float>((size_t)(d.rec.left_tiles > 0 ? d.rec.left_tiles : 1) * 16 * d.Hs);
     return w;
+}
+
+// ---- auxiliary stream for the left-over sub-band rows (see fsn_lstm_rec_plan) -------------------
+// Created lazily, once per process; besides the profiler's events this is the only state the
+// library owns.  The fork/join below uses events only, so it is also legal under stream capture.
+static hipStream_t g_aux_stream = nullptr;
+static hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
+static int aux_init() {
+    if (g_aux_stream) return FSN_OK;
+    if (hipStreamCreateWithFlags(&g_aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming) != hipSuccess) {
+        fsn_set_error("cannot create the auxiliary stream / events");
+        g_aux_stream = nullptr;
+        return FSN_ERR_LAUNCH;
+    }
+    return FSN_OK;
+}
+
+// One sub-band LSTM layer over all Tp steps: the persistent kernel on `s` and, concurrently, the
+// few left-over row tiles as per-step launches on the auxiliary stream.
+static int run_sb_recurrence(const float* gx, const float* whh, float* hseq, float* c_left, const CoreDims& d,
+                             hipStream_t s) {
+    const FsnRecPlan& r = d.rec;
+    if (r.left_tiles > 0) {
+        FSN_TRY(aux_init());
+        if (hipEventRecord(g_ev_fork, s) != hipSuccess || hipStreamWaitEvent(g_aux_stream, g_ev_fork, 0) != hipSuccess) {
+            fsn_set_error("aux stream fork failed");
+            return FSN_ERR_LAUNCH;
+        }
+    }
+    FSN_TRY(fsn_launch_lstm_rec(gx, whh, hseq, d.Tp, d.Npad, d.Hs, r.rt, r.main_wgs, s));
+    if (r.left_tiles > 0) {
+        const long main_tiles = (long)r.main_wgs * r.rt, main_rows = main_tiles * 16;
+        for (int t = 0; t < d.Tp; ++t) {
+            float* h_out = hseq + ((size_t)t * d.Npad + main_rows) * d.Hs;
+            const float* h_prev = t ? hseq + ((size_t)(t - 1) * d.Npad + main_rows) * d.Hs : h_out;
+            FSN_TRY(fsn_launch_lstm_step(gx, whh, h_prev, h_out, c_left, (long)t * r.tiles + main_tiles,
+                                         r.left_tiles, d.Hs, t == 0, g_aux_stream));
+        }
+        if (hipEventRecord(g_ev_join, g_aux_stream) != hipSuccess || hipStreamWaitEvent(s, g_ev_join, 0) != hipSuccess) {
+            fsn_set_error("aux stream join failed");
+            return FSN_ERR_LAUNCH;
+        }
+    }
+    return FSN_OK;
 }
 
 static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float* magT, const CoreDims& d,
@@ -314,7 +362,7 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
             const size_t step = (size_t)d.Npad_fb * d.Hf;
             for (int t = 0; t < d.Tp; ++t)
                 FSN_TRY(fsn_launch_lstm_step(w.gx_fb, whh, t ? hseq + (t - 1) * step : hseq, hseq + t * step,
-                                             w.c_fb, t, d.Npad_fb, d.Hf, s));
+                                             w.c_fb, (long)t * (d.Npad_fb / 16), d.Npad_fb / 16, d.Hf, t == 0, s));
         }
     }
     {
@@ -368,7 +416,7 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
     }
     {
         StageTimer st(ST_SB_REC_L0, s);
-        FSN_TRY(fsn_launch_lstm_rec(w.gx_sb, pk + p.sb_whh0, w.hseq_sb0, d.Tp, d.Npad, d.Hs, d.RT, s));
+        FSN_TRY(run_sb_recurrence(w.gx_sb, pk + p.sb_whh0, w.hseq_sb0, w.c_left, d, s));
     }
     {
         StageTimer st(ST_SB_GEMM_L1, s);
@@ -384,7 +432,7 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
     }
     {
         StageTimer st(ST_SB_REC_L1, s);
-        FSN_TRY(fsn_launch_lstm_rec(w.gx_sb, pk + p.sb_whh1, w.hseq_sb1, d.Tp, d.Npad, d.Hs, d.RT, s));
+        FSN_TRY(run_sb_recurrence(w.gx_sb, pk + p.sb_whh1, w.hseq_sb1, w.c_left, d, s));
     }
     {
         StageTimer st(ST_SB_FC, s);

@@ -119,8 +119,15 @@ int fsn_launch_pack(const float* w, float* wp, int n_out, int k, int n_out_pad, 
 int fsn_launch_bias_sum(const float* a, const float* b, float* out, int n, int n_pad, hipStream_t s);
 
 // lstm_kernels.hip
+struct FsnRecPlan {
+    int rt;          // 16-row tiles per workgroup of the persistent recurrent kernel
+    int main_wgs;    // its grid: rows [0, main_wgs * rt * 16)
+    int left_tiles;  // trailing tiles handled step by step on the auxiliary stream
+    int tiles;       // all tiles = npad / 16
+    int npad;        // padded row count (row stride of every [t][n] buffer)
+};
+FsnRecPlan fsn_lstm_rec_plan(int N, int H);
 int fsn_launch_lstm_step(const float* gx, const float* whh_p, const float* h_prev, float* h_out, float* c,
-                         int t, int Npad, int H, hipStream_t s);
+                         long gx_rt0, int row_tiles, int H, int first, hipStream_t s);
 int fsn_launch_lstm_rec(const float* gx, const float* whh_p, float* hseq, int Tp, int Npad, int H, int RT,
-                        hipStream_t s);
-int fsn_lstm_rec_row_tiles(int N, int H);
+                        int main_wgs, hipStream_t s);

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
 }
 
 template <int H, int RT>
-int launch_rec(const float* gx, const float* whh_p, float* hseq, int Tp, int Npad, hipStream_t s) {
+int launch_rec(const float* gx, const float* whh_p, float* hseq, int Tp, int Npad, int main_wgs, hipStream_t s) {
     constexpr int UG = 2;
     constexpr int NW = H / (16 * UG);
     const size_t lds = (size_t)RT * 16 * (H + 4) * sizeof(float);
@@ -192,37 +192,67 @@ int launch_rec(const float* gx, const float* whh_p, float* hseq, int Tp, int Npa
         fsn_set_error("lstm_rec: cannot reserve %zu bytes of LDS", lds);
         return FSN_ERR_LAUNCH;
     }
-    const unsigned grid = (unsigned)(Npad / (RT * 16));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, gx, whh_p, hseq, Tp, Npad);
+    hipLaunchKernelGGL(kern, dim3((unsigned)main_wgs), dim3(NW * 64), lds, s, gx, whh_p, hseq, Tp, Npad);
     return fsn_check_launch("lstm_rec_kernel");
 }
 
 }  // namespace
 
-// Rows per workgroup (in 16-row tiles) that minimises the makespan on 256 CUs with one workgroup
-// per CU: ceil(WGs / 256) rounds of RT tiles each.  N = 16 448 -> RT = 5 (206 workgroups, 1 round).
-int fsn_lstm_rec_row_tiles(int N, int H) {
+// How the N sub-band sequences are laid out on the chip.  One workgroup per CU (LDS-bound), RT
+// 16-row tiles per workgroup, so a single launch is worth max-RT tile-times and
+// N = B F = 64 * 257 = 1028 tiles is the worst case for 256 CUs: 4.016 tiles per CU.  Instead of
+// paying a fifth tile on every CU (206 workgroups x 5 tiles, 50 CUs idle), the main kernel takes
+// floor(tiles / CUs) tiles per CU on all CUs and the few left-over tiles (4 of 1028) run
+// concurrently as per-step lstm_step_kernel launches on an auxiliary stream: those small workgroups
+// fit next to the resident main workgroup (40 VGPRs, 12 KB LDS) and add 0.4 % of MFMA work.
+FsnRecPlan fsn_lstm_rec_plan(int N, int H) {
     (void)H;
-    const int rt_max = 5;  // LDS: 16 RT (H + 4) floats = 124 KB at H = 384
-    const int tiles = (N + 15) / 16;
+    const int rt_max = 5;    // LDS: 16 RT (H + 4) floats = 124 KB at H = 384
+    const int left_max = 16;  // tiles worth handing to the step kernels
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus < 1) cus = 256;
+    FsnRecPlan p;
+    p.tiles = (N + 15) / 16;
+    p.npad = p.tiles * 16;
+    if (p.tiles <= cus) {
+        p.rt = 1;
+        p.main_wgs = p.tiles;
+        p.left_tiles = 0;
+        return p;
+    }
+    const int rt_floor = p.tiles / cus < rt_max ? p.tiles / cus : rt_max;
+    const int left = p.tiles - cus * rt_floor;
+    if (left <= left_max) {
+        p.rt = rt_floor;
+        p.main_wgs = cus;
+        p.left_tiles = left;
+        return p;
+    }
+    // general case: whole rounds, pick the RT with the smallest makespan (rounds x RT)
     int best = 1;
     long best_cost = -1;
     for (int rt = 1; rt <= rt_max; ++rt) {
-        const long wgs = (tiles + rt - 1) / rt;
-        const long rounds = (wgs + 255) / 256;
-        const long cost = rounds * rt * 64 + rounds;  // MFMA time ~ rt per round; tie -> fewer rounds
+        const long wgs = (p.tiles + rt - 1) / rt;
+        const long rounds = (wgs + cus - 1) / cus;
+        const long cost = rounds * rt * 64 + rounds;
         if (best_cost < 0 || cost < best_cost || (cost == best_cost && rt > best)) {
             best = rt;
             best_cost = cost;
         }
     }
-    return best;
+    p.rt = best;
+    p.main_wgs = (p.tiles + best - 1) / best;
+    p.left_tiles = 0;
+    p.npad = p.main_wgs * best * 16;
+    p.tiles = p.npad / 16;
+    return p;
 }
 
 int fsn_launch_lstm_rec(const float* gx, const float* whh_p, float* hseq, int Tp, int Npad, int H, int RT,
-                        hipStream_t s) {
+                        int main_wgs, hipStream_t s) {
 #define FSN_REC_CASE(HH, R) \
-    if (H == HH && RT == R) return launch_rec<HH, R>(gx, whh_p, hseq, Tp, Npad, s);
+    if (H == HH && RT == R) return launch_rec<HH, R>(gx, whh_p, hseq, Tp, Npad, main_wgs, s);
     FSN_REC_CASE(384, 1)
     FSN_REC_CASE(384, 2)
     FSN_REC_CASE(384, 3)
@@ -233,14 +263,15 @@ int fsn_launch_lstm_rec(const float* gx, const float* whh_p, float* hseq, int Tp
     return FSN_ERR_ARG;
 }
 
-int fsn_launch_lstm_step(const float* gx, const float* whh_p, const float* h_prev, float* h_out, float* c, int t,
-                         int Npad, int H, hipStream_t s) {
+// One step for `row_tiles` 16-row tiles: gx tiles gx_rt0 .. gx_rt0 + row_tiles - 1 of the fragment-
+// ordered projection, h_prev / h_out / c point at the first of those rows.
+int fsn_launch_lstm_step(const float* gx, const float* whh_p, const float* h_prev, float* h_out, float* c,
+                         long gx_rt0, int row_tiles, int H, int first, hipStream_t s) {
     if (H % 64 != 0) {
         fsn_set_error("lstm_step: hidden size %d must be a multiple of 64", H);
         return FSN_ERR_ARG;
     }
-    const long gx_rt0 = (long)t * (Npad / 16);
-    hipLaunchKernelGGL(lstm_step_kernel, dim3(H / 16, Npad / 16), dim3(256), 0, s, gx, whh_p, h_prev, h_out, c,
-                       gx_rt0, H, t == 0 ? 1 : 0);
+    hipLaunchKernelGGL(lstm_step_kernel, dim3(H / 16, row_tiles), dim3(256), 0, s, gx, whh_p, h_prev, h_out, c,
+                       gx_rt0, H, first);
     return fsn_check_launch("lstm_step_kernel");
 }

@@ -162,6 +162,21 @@ def test_oracle_parity_fresh_weights(fsn):
     assert np.abs(enh.cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("batch", [16, 33])
+def test_more_row_tiles_than_cus(fsn, batch):
+    """B*F/16 > 256 tiles: the persistent recurrent kernel takes floor(tiles/CUs) tiles per CU and
+    the left-over tiles run step by step on the auxiliary stream (B=16: 257 tiles -> 256 + 1;
+    B=33: 531 tiles -> 2 x 256 + 19 -> general multi-round plan).  Every row must still match."""
+    meta = dict(seed_w=5, gain=2.0, mask_gain=24.0, norm_type="offline_laplace_norm", groups=1)
+    model, params = build_model(fsn, meta)
+    noisy = O.make_noisy(batch, 1300, seed=31)
+    enh, crm = model.enhance(dev(noisy), return_crm=True)
+    ref, inter = O.full_band_crm_mask(noisy, params, window=torch.hann_window(512).numpy(), return_intermediates=True)
+    err = np.abs(crm.cpu().numpy() - inter["crm"])
+    assert err.max() <= 1e-4, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    assert np.abs(enh.cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
+
+
 def test_errors_are_loud(fsn):
     with pytest.raises(Exception):
         fsn.stft(torch.zeros(2, 4000), 512, 256, 512)  # CPU tensor: no fallback
