@@ -177,6 +177,30 @@ def test_more_row_tiles_than_cus(fsn, batch):
     assert np.abs(enh.cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
 
 
+def test_config2_full_size(fsn):
+    """BASELINE config 2 at full size (batch 64 x 3 s): the oracle checks two utterances (a few
+    seconds of CPU each); the rest is covered by size-independent properties - every utterance of
+    the batch equals its own solo run (batch independence), and two runs are bit-identical."""
+    meta = dict(seed_w=0, gain=2.0, mask_gain=24.0, norm_type="offline_laplace_norm", groups=1)
+    model, params = build_model(fsn, meta)
+    noisy = O.make_noisy(64, 48000, seed=1234)
+    x = dev(noisy)
+    enh, crm = model.enhance(x, return_crm=True)
+    enh2 = model.enhance(x)
+    assert torch.equal(enh, enh2)
+    assert crm.shape == (64, 2, 257, 188) and bool(torch.isfinite(enh).all())
+    win = torch.hann_window(512).numpy()
+    for b in (0, 63):
+        ref, inter = O.full_band_crm_mask(noisy[b:b + 1], params, window=win, return_intermediates=True)
+        err = np.abs(crm[b:b + 1].cpu().numpy() - inter["crm"])
+        assert err.max() <= 1e-4, (b, err.max())
+        assert np.abs(enh[b:b + 1].cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
+    for b in (17, 40):  # rows of utterance 63 / 17 / 40 live in different workgroups and the aux stream
+        solo, solo_crm = model.enhance(x[b:b + 1], return_crm=True)
+        assert (solo_crm[0] - crm[b]).abs().max().item() <= 5e-5
+        assert (solo[0] - enh[b]).abs().max().item() <= 1e-3 * enh.abs().max().item()
+
+
 def test_errors_are_loud(fsn):
     with pytest.raises(Exception):
         fsn.stft(torch.zeros(2, 4000), 512, 256, 512)  # CPU tensor: no fallback
