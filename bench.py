@@ -1,20 +1,23 @@
 #!/usr/bin/env python
 """bench.py - frames/s of the FullSubNet enhancement path (BASELINE.json configs[1]) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the whole hot path (STFT -> FullSubNet -> cIRM decompress/apply -> iSTFT,
-inferencer.py:130-145) over one batch of 64 synthetic 3 s / 16 kHz utterances already resident in
-HBM.  With N > 1 ranks the 64 utterances are sharded across ranks (batch x frequency rows are
-independent sequences), each rank runs the path on its shard and the enhanced waveforms are
-re-assembled with one RCCL all-gather: total work is fixed -> "scaling": "strong".
+inferencer.py:130-145) over a batch of synthetic 3 s / 16 kHz utterances already resident in HBM:
+64 utterances per GPU (BASELINE config 2).  Utterances (and with them the batch x frequency rows of
+the sub-band model) are independent, so with N ranks every rank runs the unchanged single-GPU path
+on its own 64 utterances with no data-path collective, and one RCCL all-gather re-assembles the
+enhanced node batch: per-GPU work is fixed -> "scaling": "weak" (the default).  `--scaling strong`
+instead shards ONE 64-utterance batch across the ranks (8 utterances per rank at N = 8).
 
 Prints ONE JSON line (rank 0) with the driver's contract keys plus
-  roofline     - fp32-MFMA roofline fraction of the dominant kernel (the sub-band recurrent kernel),
-                 from its algorithmic FLOPs / its HIP-event duration on the launch stream
-  cpu_baseline - the CPU oracle (numpy port of the reference path) timed on this box's host cores
-                 on a bounded sample of the same workload.
+  roofline     - fp32-MFMA roofline fraction of the dominant kernel (the sub-band recurrent kernel,
+                 two launches per step) from its algorithmic FLOPs / its HIP-event duration on the
+                 launch stream; `traffic` from the committed rocprofv3 PMC passes of this config
+  cpu_baseline - the CPU oracle (numpy/MKL port of the reference path) timed on this box's host
+                 cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -35,7 +38,10 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, de
 MAC_FB = 2048 * (257 + 512) + 2048 * (512 + 512) + 512 * 257
 MAC_SB_PER_BIN = 1536 * (32 + 384) + 1536 * (384 + 384) + 384 * 2
 MAC_PER_FRAME = MAC_FB + 257 * MAC_SB_PER_BIN
-MAC_REC_PER_ROW_STEP = 1536 * 384  # h_{t-1} W_hh^T of one sub-band LSTM layer
+# the recurrent kernel, per sub-band row and step: layer 0 = W_hh h + the fused W_ih x (K = 32),
+# layer 1 = W_hh h only (its K = 384 input projection is a separate GEMM)
+MAC_REC_L0 = 1536 * (384 + 32)
+MAC_REC_L1 = 1536 * 384
 
 
 def build_model(device):
@@ -52,8 +58,8 @@ def build_model(device):
 
 
 def cpu_baseline(params, length, budget_s=20.0):
-    """Reference path restated on the CPU (oracle/, numpy + OpenBLAS on all host cores), timed on
-    a bounded sample: whole utterances of the same shape, as many as fit ~budget_s."""
+    """Reference path restated on the CPU (oracle/), timed on a bounded sample: whole utterances of
+    the same shape in one batch, as many as fit ~budget_s."""
     from oracle import fullsubnet_oracle as O
     # the port scales to ~16 threads (MKL GEMMs of 257-row panels + numpy elementwise); more threads
     # only add contention on a 256-core host, so that is what is used and what `cores` reports
@@ -92,8 +98,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="utterances per step, whole job")
+    ap.add_argument("--batch", type=int, default=64, help="utterances per step: per GPU (weak) / whole job (strong)")
     ap.add_argument("--seconds", type=float, default=3.0)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -121,13 +128,17 @@ def main():
     length = int(round(args.seconds * SR))
     T = 1 + length // HOP
     Tp = T + LA
-    B = args.batch
-    lo, hi = shard_bounds(B, rank, world)
+    if args.scaling == "weak":
+        b_total, b_loc = args.batch * world, args.batch
+        noisy_np = make_noisy(b_loc, length, seed=1234 + rank)
+    else:
+        b_total = args.batch
+        lo, hi = shard_bounds(b_total, rank, world)
+        b_loc = hi - lo
+        noisy_np = make_noisy(b_total, length, seed=1234)[lo:hi]
+    b_max = shard_bounds(b_total, 0, world)[1]
     model, params = build_model(device)
-    noisy_all = make_noisy(B, length, seed=1234)
-    noisy = torch.from_numpy(noisy_all[lo:hi]).to(device)  # resident in HBM before the timed region
-    b_loc = hi - lo
-    b_max = shard_bounds(B, 0, world)[1]
+    noisy = torch.from_numpy(noisy_np).to(device)  # resident in HBM before the timed region
     gathered = torch.empty((world * b_max, length), dtype=torch.float32, device=device) if world > 1 else None
     send = torch.zeros((b_max, length), dtype=torch.float32, device=device) if world > 1 else None
 
@@ -135,7 +146,7 @@ def main():
         enh = model.enhance(noisy, n_fft=N_FFT, hop_length=HOP)
         if world > 1:
             send[:b_loc].copy_(enh)
-            dist.all_gather_into_tensor(gathered, send)  # RCCL over xGMI: re-assemble the batch
+            dist.all_gather_into_tensor(gathered, send)  # RCCL over xGMI: re-assemble the node batch
             return gathered
         return enh
 
@@ -166,33 +177,36 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
-        frames = B * T
-        value = frames * args.steps / dt
+        value = b_total * T * args.steps / dt
         stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
         # dominant kernel: lstm_rec_kernel, launched twice per step (sub-band layers 0 and 1)
-        rec_ms = 0.5 * (stage_ms["sb_rec_l0"] + stage_ms["sb_rec_l1"])
-        rec_flops = 2.0 * MAC_REC_PER_ROW_STEP * (b_loc * F) * Tp
+        rows_steps = float(b_loc * F) * Tp
+        rec_flops = 2.0 * (MAC_REC_L0 + MAC_REC_L1) * rows_steps  # both launches
+        rec_ms = stage_ms["sb_rec_l0"] + stage_ms["sb_rec_l1"]
         achieved = rec_flops / (rec_ms * 1e-3) / 1e12 if rec_ms > 0 else 0.0
         path_flops = 2.0 * MAC_PER_FRAME * b_loc * Tp
+        at_config2 = world == 1 and b_loc == 64 and length == 48000
         out = {
             "metric": "frames/sec (16 kHz, 512-FFT, hop 256), whole job", "value": round(value, 1),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"FullSubNet inference (full_band_crm_mask path), 16 kHz, n_fft 512, hop 256, "
-                                   f"n_neighbour 15, look_ahead 2, batch {B} x {args.seconds:g} s, "
-                                   f"offline_laplace_norm, full 257-bin mask per utterance",
-                       "batch": B, "samples": length, "frames_per_utterance": T,
-                       "parallelism": f"batch-shard x{world}" + (" + all-gather" if world > 1 else "")},
+                                   f"n_neighbour 15, look_ahead 2, batch {b_loc} x {args.seconds:g} s per GPU "
+                                   f"({b_total} utterances per step in total), offline_laplace_norm, full 257-bin "
+                                   f"mask per utterance",
+                       "batch_per_gpu": b_loc, "batch_total": b_total, "samples": length,
+                       "frames_per_utterance": T,
+                       "parallelism": f"utterance-shard x{world}" + (" + all-gather" if world > 1 else "")},
             "rtf_speedup_audio_s_per_s": round(value / (SR / HOP), 1),
             "rtf_classic": round((SR / HOP) / value, 6),
-            "roofline": {"bound": "mfma", "kernel": "lstm_rec_kernel<384,RT,2> (sub-band recurrent, per layer)",
+            "roofline": {"bound": "mfma", "kernel": "lstm_rec_kernel<384,RT,2,*> (sub-band recurrent; 2 launches/step)",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                         # PMC passes are separate rocprofv3 runs at this exact config (B = 64, 1 GPU)
-                         "traffic": measured_traffic() if (world == 1 and B == 64 and length == 48000) else None,
+                         # PMC passes are separate rocprofv3 runs at config 2 (B = 64, 1 GPU)
+                         "traffic": measured_traffic() if at_config2 else None,
                          "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc)",
-                         "flops_per_launch": rec_flops, "ms_per_launch": round(rec_ms, 3),
+                         "flops_per_launch": rec_flops / 2, "ms_per_launch": round(rec_ms / 2, 3),
                          "whole_path_frac": round(path_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         }

@@ -283,7 +283,10 @@ static int aux_init() {
 
 // One sub-band LSTM layer over all Tp steps: the persistent kernel on `s` and, concurrently, the
 // few left-over row tiles as per-step launches on the auxiliary stream.
-static int run_sb_recurrence(const float* gx, const float* whh, float* hseq, float* c_left, const CoreDims& d,
+// Main kernel: input projection either precomputed (`gx`, tile (t, i) at t * tiles + i) or built
+// in-kernel from `xin`.  Left-over tiles: projection tiles in `gx_left` at t * left_stride + left_off + i.
+static int run_sb_recurrence(const float* gx, const FsnSbInput* xin, const float* gx_left, long left_stride,
+                             long left_off, const float* whh, float* hseq, float* c_left, const CoreDims& d,
                              hipStream_t s) {
     const FsnRecPlan& r = d.rec;
     if (r.left_tiles > 0) {
@@ -293,13 +296,13 @@ static int run_sb_recurrence(const float* gx, const float* whh, float* hseq, flo
             return FSN_ERR_LAUNCH;
         }
     }
-    FSN_TRY(fsn_launch_lstm_rec(gx, whh, hseq, d.Tp, d.Npad, d.Hs, r.rt, r.main_wgs, s));
+    FSN_TRY(fsn_launch_lstm_rec(gx, xin, whh, hseq, d.Tp, d.Npad, d.Hs, r.rt, r.main_wgs, s));
     if (r.left_tiles > 0) {
-        const long main_tiles = (long)r.main_wgs * r.rt, main_rows = main_tiles * 16;
+        const long main_rows = (long)r.main_wgs * r.rt * 16;
         for (int t = 0; t < d.Tp; ++t) {
             float* h_out = hseq + ((size_t)t * d.Npad + main_rows) * d.Hs;
             const float* h_prev = t ? hseq + ((size_t)(t - 1) * d.Npad + main_rows) * d.Hs : h_out;
-            FSN_TRY(fsn_launch_lstm_step(gx, whh, h_prev, h_out, c_left, (long)t * r.tiles + main_tiles,
+            FSN_TRY(fsn_launch_lstm_step(gx_left, whh, h_prev, h_out, c_left, (long)t * left_stride + left_off,
                                          r.left_tiles, d.Hs, t == 0, g_aux_stream));
         }
         if (hipEventRecord(g_ev_join, g_aux_stream) != hipSuccess || hipStreamWaitEvent(s, g_ev_join, 0) != hipSuccess) {
@@ -393,7 +396,10 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
     }
     // sub-band model (model.py:121-128): N = B F sequences, 2 LSTM layers + Linear(2)
     const int sb_rt = (int)((long)d.Tp * d.Npad / 16);
-    {
+    // Layer 0: the K = 2nb+2 input projection is fused into the persistent recurrent kernel (no 19 GB
+    // gx round trip); only the few left-over tiles, which run step by step, get a precomputed gx.
+    const long main_rows = (long)d.rec.main_wgs * d.rec.rt * 16;
+    if (d.rec.left_tiles > 0) {
         StageTimer st(ST_SB_GEMM_L0, s);
         a = FsnGemmA{};
         c = FsnGemmC{};
@@ -402,21 +408,39 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         a.p1 = w.fb_out;
         a.den = w.den_sb;
         a.den_mode = cum ? 1 : 0;
+        a.den_stride = d.Npad;
         a.B = d.B;
         a.Tp = d.Tp;
         a.F = d.F;
         a.FP = d.FP;
-        a.Npad = d.Npad;
+        a.Npad = d.rec.left_tiles * 16;
+        a.n_offset = (int)main_rows;
         a.N = d.N;
         a.nb = d.nb;
         c.kind = 0;
         c.p0 = w.gx_sb;
         c.bias = pk + p.sb_b0;
-        FSN_TRY(fsn_launch_gemm(a, pk + p.sb_wih0, c, sb_rt, 4 * d.Hs / 16, p.sb_kin_pad / 16, s));
+        FSN_TRY(fsn_launch_gemm(a, pk + p.sb_wih0, c, d.Tp * d.rec.left_tiles, 4 * d.Hs / 16, p.sb_kin_pad / 16, s));
     }
     {
         StageTimer st(ST_SB_REC_L0, s);
-        FSN_TRY(run_sb_recurrence(w.gx_sb, pk + p.sb_whh0, w.hseq_sb0, w.c_left, d, s));
+        FsnSbInput xin{};
+        xin.mag = magT;
+        xin.fb_out = w.fb_out;
+        xin.den = w.den_sb;
+        xin.wih_p = pk + p.sb_wih0;
+        xin.bias = pk + p.sb_b0;
+        xin.den_mode = cum ? 1 : 0;
+        xin.den_stride = d.Npad;
+        xin.B = d.B;
+        xin.Tp = d.Tp;
+        xin.F = d.F;
+        xin.FP = d.FP;
+        xin.N = d.N;
+        xin.nb = d.nb;
+        xin.kin_chunks = p.sb_kin_pad / 16;
+        FSN_TRY(run_sb_recurrence(nullptr, &xin, w.gx_sb, d.rec.left_tiles, 0, pk + p.sb_whh0, w.hseq_sb0, w.c_left,
+                                  d, s));
     }
     {
         StageTimer st(ST_SB_GEMM_L1, s);
@@ -432,7 +456,8 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
     }
     {
         StageTimer st(ST_SB_REC_L1, s);
-        FSN_TRY(run_sb_recurrence(w.gx_sb, pk + p.sb_whh1, w.hseq_sb1, w.c_left, d, s));
+        FSN_TRY(run_sb_recurrence(w.gx_sb, nullptr, w.gx_sb, d.rec.tiles, main_rows / 16, pk + p.sb_whh1, w.hseq_sb1,
+                                  w.c_left, d, s));
     }
     {
         StageTimer st(ST_SB_FC, s);

@@ -102,9 +102,11 @@ struct FsnGemmA {  // A operand description
     const float* p0;  // row-major: matrix; fb/sb: mag [B][Tp][FP]
     const float* p1;  // sb: fb_out [B][Tp][FP]
     const float* den;  // fb/sb: divisor
-    int den_mode;      // 0: den[b]   1: den[b*Tp + t] (fb) / den[(t*Npad)+n] (sb)
+    int den_mode;      // 0: den[b]   1: den[b*Tp + t] (fb) / den[t*den_stride + n] (sb)
     long ld;           // row-major leading dimension
     int B, Tp, F, FP, Npad, N, nb;
+    int n_offset;      // sb: first unit of this launch (rows are n_offset .. n_offset + Npad - 1)
+    int den_stride;    // sb, den_mode 1: row stride of den
 };
 struct FsnGemmC {  // C store description
     int kind;      // 0 fragment-order + bias, 1 fb_out rows (bias + relu), 2 crm planes
@@ -119,6 +121,19 @@ int fsn_launch_pack(const float* w, float* wp, int n_out, int k, int n_out_pad, 
 int fsn_launch_bias_sum(const float* a, const float* b, float* out, int n, int n_pad, hipStream_t s);
 
 // lstm_kernels.hip
+// Sub-band model input (fullsubnet/model.py:98-111) for kernels that build it on the fly:
+// channel c < 2nb+1 of unit n = b F + f at frame t is mag[b][t][reflect(f + c - nb)], channel 2nb+1
+// is fb_out[b][t][f]; everything divided by den (den_mode 0: den[b], 1: den[t * den_stride + n]).
+struct FsnSbInput {
+    const float* mag;
+    const float* fb_out;
+    const float* den;
+    const float* wih_p;  // packed W_ih [4H/16][kin_pad/16][64][4]
+    const float* bias;   // b_ih + b_hh [4H]
+    int den_mode, den_stride;
+    int B, Tp, F, FP, N, nb, kin_chunks;
+};
+
 struct FsnRecPlan {
     int rt;          // 16-row tiles per workgroup of the persistent recurrent kernel
     int main_wgs;    // its grid: rows [0, main_wgs * rt * 16)
@@ -129,5 +144,7 @@ struct FsnRecPlan {
 FsnRecPlan fsn_lstm_rec_plan(int N, int H);
 int fsn_launch_lstm_step(const float* gx, const float* whh_p, const float* h_prev, float* h_out, float* c,
                          long gx_rt0, int row_tiles, int H, int first, hipStream_t s);
-int fsn_launch_lstm_rec(const float* gx, const float* whh_p, float* hseq, int Tp, int Npad, int H, int RT,
-                        int main_wgs, hipStream_t s);
+// xin == NULL: accumulators start from the precomputed projection gx; otherwise the (K = 2nb+2)
+// input projection of the sub-band model's first layer is computed inside the kernel from xin.
+int fsn_launch_lstm_rec(const float* gx, const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad,
+                        int H, int RT, int main_wgs, hipStream_t s);

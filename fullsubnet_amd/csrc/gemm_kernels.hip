@@ -91,14 +91,14 @@ struct ARow<2> {  // sub-band model input: row (t, n = b F + f), 2 nb + 2 channe
     int f;
     bool valid;
     __device__ __forceinline__ void prepare(const FsnGemmA& a, long row, long nrows) {
-        const int t = (int)(row / a.Npad), n = (int)(row % a.Npad);
+        const int t = (int)(row / a.Npad), n = a.n_offset + (int)(row % a.Npad);
         valid = row < nrows && n < a.N;
         const int nn = valid ? n : 0, tt = valid ? t : 0;
         const int b = nn / a.F;
         f = nn % a.F;
         mrow = a.p0 + ((long)b * a.Tp + tt) * a.FP;
         frow = a.p1 + ((long)b * a.Tp + tt) * a.FP;
-        den = a.den[a.den_mode ? (long)tt * a.Npad + nn : b];
+        den = a.den[a.den_mode ? (long)tt * a.den_stride + nn : b];
     }
     __device__ __forceinline__ f32x4 load(const FsnGemmA& a, int k0) const {
         f32x4 v;

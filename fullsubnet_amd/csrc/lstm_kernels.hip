@@ -26,8 +26,31 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------
-template <int H, int RT, int UG>
+// One frame of the sub-band model input for the rows of this workgroup, written to LDS as
+// xl[row][0 .. 16 kin_chunks) (zero padded): freq_unfold + cat + norm of fullsubnet/model.py:98-111.
+template <int NTHREADS>
+__device__ __forceinline__ void stage_sb_input(const FsnSbInput& x, float* xl, int xs, long n0, int rows, int t) {
+    const int kin = 16 * x.kin_chunks;
+    for (int i = threadIdx.x; i < rows * kin; i += NTHREADS) {
+        const int row = i / kin, c = i % kin;
+        const long n = n0 + row;
+        float v = 0.f;
+        if (n < x.N && c <= 2 * x.nb + 1) {
+            const int b = (int)(n / x.F), f = (int)(n % x.F);
+            const long fo = ((long)b * x.Tp + t) * x.FP;
+            int j = f + c - x.nb;
+            j = j < 0 ? -j : j;
+            j = j >= x.F ? 2 * (x.F - 1) - j : j;
+            const float raw = c <= 2 * x.nb ? x.mag[fo + j] : x.fb_out[fo + f];
+            v = raw / x.den[x.den_mode ? (long)t * x.den_stride + n : b];
+        }
+        xl[row * xs + c] = v;
+    }
+}
+
+template <int H, int RT, int UG, bool XIN>
 __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const float* __restrict__ gx,
+                                                                        const FsnSbInput xin,
                                                                         const float* __restrict__ whh_p,
                                                                         float* __restrict__ hseq, int Tp, int Npad) {
     constexpr int NW = H / (16 * UG);   // waves per workgroup
@@ -36,7 +59,12 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const fl
     constexpr int HS = H + 4;           // LDS row stride (floats): 16 B aligned, breaks the 64-bank period
     constexpr int ROWS = RT * 16;
     constexpr int UNR = RT >= 3 ? 1 : (RT == 2 ? 2 : 4);  // K-loop unroll: bound the in-flight B fragments
-    extern __shared__ __attribute__((aligned(16))) float hl[];  // [ROWS][HS]
+    extern __shared__ __attribute__((aligned(16))) float hl[];  // [ROWS][HS] (+ 2 x [ROWS][XS] when XIN)
+    // XIN: the first sub-band layer builds its input projection itself (K = 2nb+2 = 32: two more
+    // chunks per gate) from a double-buffered LDS tile of the unfolded, normalised input, instead of
+    // reading a 19.2 GB precomputed gx that an HBM-write-bound GEMM would have to produce first.
+    const int XS = XIN ? 16 * xin.kin_chunks + 4 : 0;
+    float* xl = hl + ROWS * HS;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
@@ -48,10 +76,15 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const fl
 #pragma unroll
         for (int u = 0; u < UG; ++u) cst[rt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i = threadIdx.x; i < ROWS * HS; i += NW * 64) hl[i] = 0.f;
+    if (XIN) stage_sb_input<NW * 64>(xin, xl, XS, n0, ROWS, 0);
     __syncthreads();
 
     for (int t = 0; t < Tp; ++t) {
         const long gx_rt0 = ((long)t * Npad + n0) >> 4;
+        // frame t+1 goes into the other x buffer; it was last read in step t-1, which ended with
+        // two barriers, and is first read after the two barriers that end this step
+        if (XIN && t + 1 < Tp) stage_sb_input<NW * 64>(xin, xl + ((t + 1) & 1) * ROWS * XS, XS, n0, ROWS, t + 1);
+        const float* xt = xl + (t & 1) * ROWS * XS;
         // gate order of evaluation: f (1), i (0), g (2), o (3)
 #pragma unroll 1
         for (int pass = 0; pass < 4; ++pass) {
@@ -62,10 +95,33 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const fl
             for (int u = 0; u < UG; ++u) {
                 const int ug = wave * UG + u;
                 bp[u] = whh_p + ((long)(g * KC + ug) * KC * 64 + lane) * 4;
+                if (!XIN) {
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][u] = *reinterpret_cast<const f32x4*>(
-                        gx + (((gx_rt0 + rt) * CT + g * KC + ug) * 64 + lane) * 4);
+                    for (int rt = 0; rt < RT; ++rt)
+                        acc[rt][u] = *reinterpret_cast<const f32x4*>(
+                            gx + (((gx_rt0 + rt) * CT + g * KC + ug) * 64 + lane) * 4);
+                } else {
+                    const float bias = xin.bias[(g * KC + ug) * 16 + lr];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][u] = f32x4{bias, bias, bias, bias};
+                }
+            }
+            if (XIN) {  // W_ih x_t: the same fragment scheme with A from the staged input tile
+                for (int kx = 0; kx < xin.kin_chunks; ++kx) {
+                    f32x4 bx[UG];
+#pragma unroll
+                    for (int u = 0; u < UG; ++u)
+                        bx[u] = *reinterpret_cast<const f32x4*>(
+                            xin.wih_p + (((long)(g * KC + wave * UG + u) * xin.kin_chunks + kx) * 64 + lane) * 4);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(xt + (rt * 16 + lr) * XS + kx * 16 + 4 * lq);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(a[j], bx[u][j], acc[rt][u]);
+                    }
+                }
             }
             if (t > 0) {  // h_{-1} = 0
                 f32x4 bn[UG];
@@ -350,18 +406,22 @@ int launch_rec1(const float* gx, const float* whh_p, float* hseq, int Tp, int Np
     return fsn_check_launch("lstm_rec1_kernel");
 }
 
-template <int H, int RT>
-int launch_rec(const float* gx, const float* whh_p, float* hseq, int Tp, int Npad, int main_wgs, hipStream_t s) {
+template <int H, int RT, bool XIN>
+int launch_rec(const float* gx, const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad,
+               int main_wgs, hipStream_t s) {
     constexpr int UG = 2;
     constexpr int NW = H / (16 * UG);
-    const size_t lds = (size_t)RT * 16 * (H + 4) * sizeof(float);
-    auto kern = lstm_rec_kernel<H, RT, UG>;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+    size_t lds = (size_t)RT * 16 * (H + 4) * sizeof(float);
+    if (XIN) lds += (size_t)2 * RT * 16 * (16 * xin->kin_chunks + 4) * sizeof(float);
+    auto kern = lstm_rec_kernel<H, RT, UG, XIN>;
+    if (lds > 160 * 1024 ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
         fsn_set_error("lstm_rec: cannot reserve %zu bytes of LDS", lds);
         return FSN_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)main_wgs), dim3(NW * 64), lds, s, gx, whh_p, hseq, Tp, Npad);
+    hipLaunchKernelGGL(kern, dim3((unsigned)main_wgs), dim3(NW * 64), lds, s, gx, XIN ? *xin : FsnSbInput{}, whh_p,
+                       hseq, Tp, Npad);
     return fsn_check_launch("lstm_rec_kernel");
 }
 
@@ -418,8 +478,8 @@ FsnRecPlan fsn_lstm_rec_plan(int N, int H) {
     return p;
 }
 
-int fsn_launch_lstm_rec(const float* gx, const float* whh_p, float* hseq, int Tp, int Npad, int H, int RT,
-                        int main_wgs, hipStream_t s) {
+int fsn_launch_lstm_rec(const float* gx, const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad,
+                        int H, int RT, int main_wgs, hipStream_t s) {
     // Default: the 3-waves-per-SIMD kernel (29.5 ms per layer at config 2).  FSN_REC_KERNEL=1 selects
     // the one-wave-per-SIMD variant, which is correct but not yet faster (30.2 ms; 27.5 ms with the
     // gate non-linearities removed, i.e. it needs them interleaved with the MFMAs) and whose 512
@@ -429,14 +489,16 @@ int fsn_launch_lstm_rec(const float* gx, const float* whh_p, float* hseq, int Tp
         return !(e && e[0] == '1');
     }();
 #define FSN_REC1_CASE(HH, R) \
-    if (!use_v3 && H == HH && RT == R) return launch_rec1<HH, R>(gx, whh_p, hseq, Tp, Npad, main_wgs, s);
+    if (!use_v3 && !xin && H == HH && RT == R) return launch_rec1<HH, R>(gx, whh_p, hseq, Tp, Npad, main_wgs, s);
     FSN_REC1_CASE(384, 1)
     FSN_REC1_CASE(384, 2)
     FSN_REC1_CASE(384, 3)
     FSN_REC1_CASE(384, 4)
 #undef FSN_REC1_CASE
-#define FSN_REC_CASE(HH, R) \
-    if (H == HH && RT == R) return launch_rec<HH, R>(gx, whh_p, hseq, Tp, Npad, main_wgs, s);
+#define FSN_REC_CASE(HH, R)                                                                              \
+    if (H == HH && RT == R)                                                                              \
+        return xin ? launch_rec<HH, R, true>(gx, xin, whh_p, hseq, Tp, Npad, main_wgs, s)                \
+                   : launch_rec<HH, R, false>(gx, xin, whh_p, hseq, Tp, Npad, main_wgs, s);
     FSN_REC_CASE(384, 1)
     FSN_REC_CASE(384, 2)
     FSN_REC_CASE(384, 3)

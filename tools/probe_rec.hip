@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
         for (int it = 0; it < 3; ++it) {
             hipEventRecord(e0, 0);
             if (ver == 0) launch_rec1<384, 4>(gx, w, hseq, Tp, Npad, 256, 0);
-            else launch_rec<384, 4>(gx, w, hseq, Tp, Npad, 256, 0);
+            else launch_rec<384, 4, false>(gx, nullptr, w, hseq, Tp, Npad, 256, 0);
             hipEventRecord(e1, 0); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); if (it > 0 && ms < best) best = ms;
         }
