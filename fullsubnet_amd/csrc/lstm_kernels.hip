@@ -181,6 +181,151 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// Small-N variant (RT <= 2, i.e. fewer row tiles than ~2 per CU: small batches, per-rank shards of a
+// strong-scaled batch, single utterances).  With 16-32 rows per workgroup a K chunk is only 8-16 MFMAs
+// per gate, far shorter than the L2 latency of its B fragments, and lstm_rec_kernel's four sequential
+// gate passes leave the step latency-bound (52 us per step at RT = 1, 10 us of MFMA).  Registers are
+// plentiful here, so all four gates accumulate in ONE pass: a quarter of the dependent chunk
+// iterations, four times the MFMA work between two waits, no temporaries in the cell update.
+template <int H, int RT, int UG, bool XIN>
+__global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_small_kernel(const float* __restrict__ gx,
+                                                                              const FsnSbInput xin,
+                                                                              const float* __restrict__ whh_p,
+                                                                              float* __restrict__ hseq, int Tp,
+                                                                              int Npad) {
+    constexpr int NW = H / (16 * UG);
+    constexpr int KC = H / 16;
+    constexpr int CT = 4 * KC;
+    constexpr int HS = H + 4;
+    constexpr int ROWS = RT * 16;
+    extern __shared__ __attribute__((aligned(16))) float hl[];
+    const int XS = XIN ? 16 * xin.kin_chunks + 4 : 0;
+    float* xl = hl + ROWS * HS;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const long n0 = (long)blockIdx.x * ROWS;
+
+    f32x4 cst[RT][UG];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int u = 0; u < UG; ++u) cst[rt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < ROWS * HS; i += NW * 64) hl[i] = 0.f;
+    if (XIN) stage_sb_input<NW * 64>(xin, xl, XS, n0, ROWS, 0);
+    __syncthreads();
+
+    const float* bp[4][UG];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int u = 0; u < UG; ++u) bp[g][u] = whh_p + ((long)(g * KC + wave * UG + u) * KC * 64 + lane) * 4;
+
+    for (int t = 0; t < Tp; ++t) {
+        const long gx_rt0 = ((long)t * Npad + n0) >> 4;
+        if (XIN && t + 1 < Tp) stage_sb_input<NW * 64>(xin, xl + ((t + 1) & 1) * ROWS * XS, XS, n0, ROWS, t + 1);
+        const float* xt = xl + (t & 1) * ROWS * XS;
+        f32x4 acc[4][RT][UG];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {
+                const int ug = wave * UG + u;
+                if (!XIN) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        acc[g][rt][u] = *reinterpret_cast<const f32x4*>(
+                            gx + (((gx_rt0 + rt) * CT + g * KC + ug) * 64 + lane) * 4);
+                } else {
+                    const float bias = xin.bias[(g * KC + ug) * 16 + lr];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[g][rt][u] = f32x4{bias, bias, bias, bias};
+                }
+            }
+        if (XIN) {
+            for (int kx = 0; kx < xin.kin_chunks; ++kx) {
+                f32x4 a[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    a[rt] = *reinterpret_cast<const f32x4*>(xt + (rt * 16 + lr) * XS + kx * 16 + 4 * lq);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int u = 0; u < UG; ++u) {
+                        const f32x4 bx = *reinterpret_cast<const f32x4*>(
+                            xin.wih_p + (((long)(g * KC + wave * UG + u) * xin.kin_chunks + kx) * 64 + lane) * 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt) acc[g][rt][u] = mfma16(a[rt][j], bx[j], acc[g][rt][u]);
+                    }
+            }
+        }
+        if (t > 0) {  // h_{-1} = 0
+            f32x4 bn[4][UG];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int u = 0; u < UG; ++u) bn[g][u] = *reinterpret_cast<const f32x4*>(bp[g][u]);
+#pragma unroll 1
+            for (int kc = 0; kc < KC; ++kc) {
+                f32x4 bc[4][UG], a[RT];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int u = 0; u < UG; ++u) bc[g][u] = bn[g][u];
+                const int kn = kc + 1 < KC ? kc + 1 : kc;  // clamped: branch-free, counted waits
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int u = 0; u < UG; ++u)
+                        bn[g][u] = *reinterpret_cast<const f32x4*>(bp[g][u] + (long)kn * 256);
+                const float* ap = hl + lr * HS + kc * 16 + 4 * lq;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(ap + rt * 16 * HS);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                            for (int u = 0; u < UG; ++u)
+                                acc[g][rt][u] = mfma16(a[rt][j], bc[g][u][j], acc[g][rt][u]);
+            }
+        }
+        f32x4 hv[RT][UG];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int u = 0; u < UG; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float ig = sigmoid_fast(acc[0][rt][u][i]), fg = sigmoid_fast(acc[1][rt][u][i]);
+                    const float gg = tanh_fast(acc[2][rt][u][i]), og = sigmoid_fast(acc[3][rt][u][i]);
+                    const float cn = fg * cst[rt][u][i] + ig * gg;
+                    cst[rt][u][i] = cn;
+                    hv[rt][u][i] = og * tanh_fast(cn);
+                }
+        __syncthreads();
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int u = 0; u < UG; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    hl[(rt * 16 + 4 * lq + i) * HS + (wave * UG + u) * 16 + lr] = hv[rt][u][i];
+        __syncthreads();
+        float* dst = hseq + ((long)t * Npad + n0) * H;
+        for (int i = threadIdx.x; i < ROWS * (H / 4); i += NW * 64) {
+            const int row = i / (H / 4), c4 = i % (H / 4);
+            *reinterpret_cast<f32x4*>(dst + (long)row * H + c4 * 4) =
+                *reinterpret_cast<const f32x4*>(hl + row * HS + c4 * 4);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // One time step for a small batch.  grid = (H/16 unit groups, Npad/16 row tiles), 4 waves = 4-way
 // split-K, reduced through LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict__ gx,
@@ -413,7 +558,18 @@ int launch_rec(const float* gx, const FsnSbInput* xin, const float* whh_p, float
     constexpr int NW = H / (16 * UG);
     size_t lds = (size_t)RT * 16 * (H + 4) * sizeof(float);
     if (XIN) lds += (size_t)2 * RT * 16 * (16 * xin->kin_chunks + 4) * sizeof(float);
-    auto kern = lstm_rec_kernel<H, RT, UG, XIN>;
+    // RT == 1 (fewer row tiles than CUs): the one-pass-all-gates variant, ~10 % faster there (8.8 vs
+    // 10.0 ms per layer; a 16-row workgroup still owes 9216 MFMAs = 31 us per step, so small batches
+    // stay bound by one tile per CU until the hidden units of a tile are split across CUs).  At
+    // RT = 2 it spills and loses.  FSN_REC_SMALL=0 keeps the 4-pass kernel.
+    static const bool use_small = [] {
+        const char* e = getenv("FSN_REC_SMALL");
+        return !(e && e[0] == '0');
+    }();
+    void (*kern)(const float*, const FsnSbInput, const float*, float*, int, int) = lstm_rec_kernel<H, RT, UG, XIN>;
+    if constexpr (RT <= 1) {
+        if (use_small) kern = lstm_rec_small_kernel<H, RT, UG, XIN>;
+    }
     if (lds > 160 * 1024 ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
