@@ -72,6 +72,15 @@ SIGNATURES = {
     "fsn_enhance_workspace_bytes": (_c.c_size_t, [_c.POINTER(Cfg), _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "fsn_enhance": (_c.c_int, [_c.POINTER(Cfg), _c.c_void_p, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                _f32p, _f32p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "fsn_lstm_layer_save_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
+    "fsn_lstm_layer_fwd_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "fsn_lstm_layer_forward": (_c.c_int, [_f32p, _c.c_long, _f32p, _f32p, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_int,
+                                          _c.c_int, _f32p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t,
+                                          _c.c_void_p]),
+    "fsn_lstm_layer_bwd_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "fsn_lstm_layer_backward": (_c.c_int, [_f32p, _f32p, _c.c_long, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_int,
+                                           _c.c_int, _f32p, _c.c_void_p, _f32p, _c.c_long, _f32p, _f32p, _f32p,
+                                           _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "fsn_profile_enable": (_c.c_int, [_c.c_int]),
     "fsn_profile_num_stages": (_c.c_int, []),
     "fsn_profile_stage_name": (_c.c_char_p, [_c.c_int]),

@@ -643,3 +643,154 @@ extern "C" int fsn_enhance(const fsn_fullsubnet_cfg* cfg, const void* packed, co
     }
     return FSN_OK;
 }
+
+// ---- training step: one nn.LSTM layer, forward with saved activations + BPTT ---------------------
+// (recipes/dns_interspeech_2020/fullsubnet/trainer.py:56-63 through sequence_model.py:52-58)
+static int check_lstm_layer(int T, int N, int I, int H, long ldx) {
+    FSN_REQUIRE(T >= 1 && N >= 16 && N % 16 == 0, "lstm layer: need T >= 1 and N a positive multiple of 16 (got %d, %d)", T, N);
+    FSN_REQUIRE(I >= 1 && H >= 64 && H % 64 == 0, "lstm layer: need I >= 1 and H a multiple of 64 (got %d, %d)", I, H);
+    FSN_REQUIRE(ldx >= fsn_round_up(I, 16) && ldx % 4 == 0, "lstm layer: x row stride %ld must be >= round_up(I,16) and 16-byte aligned", ldx);
+    return FSN_OK;
+}
+
+extern "C" size_t fsn_lstm_layer_save_bytes(int T, int N, int H) {
+    return fsn_round_up_sz(((size_t)T * N * 4 * H + (size_t)T * N * H) * sizeof(float), 256);
+}
+extern "C" size_t fsn_lstm_layer_fwd_workspace_bytes(int T, int N, int I, int H) {
+    Carver cv(nullptr);
+    cv.take<float>((size_t)4 * H * fsn_round_up(I, 16));
+    cv.take<float>((size_t)4 * H * H);
+    cv.take<float>((size_t)4 * H);
+    cv.take<float>((size_t)T * N * 4 * H);
+    return fsn_round_up_sz(cv.off, 256);
+}
+
+extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_ih, const float* w_hh,
+                                      const float* b_ih, const float* b_hh, int T, int N, int I, int H, float* hseq,
+                                      void* save, size_t save_bytes, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
+    FSN_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && hseq && save && workspace, "NULL pointer argument");
+    if (save_bytes < fsn_lstm_layer_save_bytes(T, N, H) ||
+        workspace_bytes < fsn_lstm_layer_fwd_workspace_bytes(T, N, I, H)) {
+        fsn_set_error("lstm layer forward: save / workspace buffer too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Ipad = fsn_round_up(I, 16);
+    Carver cv(workspace);
+    float* wih_p = cv.take<float>((size_t)4 * H * Ipad);
+    float* whh_p = cv.take<float>((size_t)4 * H * H);
+    float* bias = cv.take<float>((size_t)4 * H);
+    float* gx = cv.take<float>((size_t)T * N * 4 * H);
+    float* gates = static_cast<float*>(save);
+    float* cseq = gates + (size_t)T * N * 4 * H;
+    FSN_TRY(fsn_launch_pack(w_ih, wih_p, 4 * H, I, 4 * H, Ipad, s));
+    FSN_TRY(fsn_launch_pack(w_hh, whh_p, 4 * H, H, 4 * H, H, s));
+    FSN_TRY(fsn_launch_bias_sum(b_ih, b_hh, bias, 4 * H, 4 * H, s));
+    FsnGemmA a{};
+    a.kind = 0;
+    a.p0 = x;
+    a.ld = ldx;
+    FsnGemmC c{};
+    c.kind = 0;
+    c.p0 = gx;
+    c.bias = bias;
+    FSN_TRY(fsn_launch_gemm(a, wih_p, c, T * (N / 16), 4 * H / 16, Ipad / 16, s));
+    const size_t step = (size_t)N * H;
+    for (int t = 0; t < T; ++t)
+        FSN_TRY(fsn_launch_lstm_step_train(gx, whh_p, t ? hseq + (t - 1) * step : hseq, hseq + t * step,
+                                           t ? cseq + (t - 1) * step : cseq, cseq + t * step,
+                                           gates + (size_t)t * N * 4 * H, (long)t * (N / 16), N / 16, H, t == 0, s));
+    return FSN_OK;
+}
+
+extern "C" size_t fsn_lstm_layer_bwd_workspace_bytes(int T, int N, int I, int H) {
+    const int Ipad = fsn_round_up(I, 16);
+    Carver cv(nullptr);
+    cv.take<float>((size_t)H * 4 * H);          // W_hh^T fragments
+    cv.take<float>((size_t)Ipad * 4 * H);       // W_ih^T fragments
+    cv.take<float>((size_t)T * N * 4 * H);      // dgates
+    cv.take<float>((size_t)N * H);              // dh_rec
+    cv.take<float>((size_t)N * H);              // dc
+    size_t tn = fsn_gemm_tn_workspace_bytes(4 * H, I, (long)T * N);
+    const size_t tn2 = fsn_gemm_tn_workspace_bytes(4 * H, H, (long)T * N);
+    tn = tn > tn2 ? tn : tn2;
+    const size_t cs = fsn_colsum_workspace_bytes(4 * H, (long)T * N);
+    cv.take<char>(tn > cs ? tn : cs);
+    return fsn_round_up_sz(cv.off, 256);
+}
+
+extern "C" int fsn_lstm_layer_backward(const float* dh, const float* x, long ldx, const float* w_ih,
+                                       const float* w_hh, int T, int N, int I, int H, const float* hseq,
+                                       const void* save, float* dx, long lddx, float* dw_ih, float* dw_hh, float* db,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
+    FSN_REQUIRE(dh && x && w_ih && w_hh && hseq && save && dw_ih && dw_hh && db && workspace, "NULL pointer argument");
+    FSN_REQUIRE(!dx || lddx >= I, "dx row stride %ld < I", lddx);
+    if (workspace_bytes < fsn_lstm_layer_bwd_workspace_bytes(T, N, I, H)) {
+        fsn_set_error("lstm layer backward: workspace too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Ipad = fsn_round_up(I, 16), G = 4 * H;
+    Carver cv(workspace);
+    float* whhT_p = cv.take<float>((size_t)H * G);
+    float* wihT_p = cv.take<float>((size_t)Ipad * G);
+    float* dgates = cv.take<float>((size_t)T * N * G);
+    float* dh_rec = cv.take<float>((size_t)N * H);
+    float* dc = cv.take<float>((size_t)N * H);
+    size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
+    const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
+    tn = tn > tn2 ? tn : tn2;
+    const size_t cs = fsn_colsum_workspace_bytes(G, (long)T * N);
+    void* scratch = cv.take<char>(tn > cs ? tn : cs);
+    const float* gates = static_cast<const float*>(save);
+    const float* cseq = gates + (size_t)T * N * G;
+    // "weights" of dh_rec = dgates W_hh are W_hh^T: out = H columns, k = 4H; nn.LSTM stores exactly
+    // that transposed ([4H][H] = [k][out]).  Likewise W_ih^T for dX.
+    FSN_TRY(fsn_launch_pack(w_hh, whhT_p, H, G, H, G, s, 1, H));
+    FSN_TRY(fsn_launch_pack(w_ih, wihT_p, I, G, Ipad, G, s, 1, I));
+    const size_t step = (size_t)N * H;
+    FsnGemmA a{};
+    FsnGemmC c{};
+    for (int t = T - 1; t >= 0; --t) {
+        FSN_TRY(fsn_launch_bptt_elem(dh + t * step, dh_rec, dc, gates + (size_t)t * N * G, cseq + t * step,
+                                     t ? cseq + (t - 1) * step : cseq, dgates + (size_t)t * N * G, (long)step, H,
+                                     t == T - 1, t == 0, s));
+        if (t > 0) {
+            a = FsnGemmA{};
+            a.kind = 0;
+            a.p0 = dgates + (size_t)t * N * G;
+            a.ld = G;
+            c = FsnGemmC{};
+            c.kind = 3;
+            c.p0 = dh_rec;
+            c.ld = H;
+            c.rows = N;
+            c.cols = H;
+            FSN_TRY(fsn_launch_gemm(a, whhT_p, c, N / 16, H / 16, G / 16, s));
+        }
+    }
+    if (dx) {
+        a = FsnGemmA{};
+        a.kind = 0;
+        a.p0 = dgates;
+        a.ld = G;
+        c = FsnGemmC{};
+        c.kind = 3;
+        c.p0 = dx;
+        c.ld = lddx;
+        c.rows = T * N;
+        c.cols = I;
+        FSN_TRY(fsn_launch_gemm(a, wihT_p, c, T * (N / 16), Ipad / 16, G / 16, s));
+    }
+    FSN_TRY(fsn_launch_gemm_tn(dgates, G, x, ldx, dw_ih, I, G, I, (long)T * N, scratch, s));
+    if (T > 1) {
+        FSN_TRY(fsn_launch_gemm_tn(dgates + (size_t)N * G, G, hseq, H, dw_hh, H, G, H, (long)(T - 1) * N, scratch, s));
+    } else if (hipMemsetAsync(dw_hh, 0, (size_t)G * H * sizeof(float), s) != hipSuccess) {
+        fsn_set_error("memset failed");
+        return FSN_ERR_LAUNCH;
+    }
+    return fsn_launch_colsum(dgates, G, db, G, (long)T * N, scratch, s);
+}

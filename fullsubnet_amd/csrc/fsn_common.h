@@ -20,6 +20,12 @@ static inline int fsn_fpad(int F) { return fsn_round_up(F, 16); }
 void fsn_set_error(const char* fmt, ...);
 int fsn_check_launch(const char* what);
 
+#define FSN_TRY_LAUNCH(what)                        \
+    do {                                            \
+        const int _rc = fsn_check_launch(what);     \
+        if (_rc != FSN_OK) return _rc;              \
+    } while (0)
+
 #define FSN_REQUIRE(cond, ...)          \
     do {                                \
         if (!(cond)) {                  \
@@ -109,16 +115,30 @@ struct FsnGemmA {  // A operand description
     int den_stride;    // sb, den_mode 1: row stride of den
 };
 struct FsnGemmC {  // C store description
-    int kind;      // 0 fragment-order + bias, 1 fb_out rows (bias + relu), 2 crm planes
+    int kind;      // 0 fragment-order + bias, 1 fb_out rows (bias + relu), 2 crm planes, 3 plain row-major
     float* p0;
     float* p1;
     const float* bias;
     int B, Tp, T, F, FP, Npad, N, la;
+    long ld;       // kind 3: leading dimension of p0
+    int rows, cols;  // kind 3: valid extent
 };
 int fsn_launch_gemm(const FsnGemmA& a, const float* w_packed, const FsnGemmC& c, int row_tiles, int col_tiles,
                     int k_chunks, hipStream_t s);
-int fsn_launch_pack(const float* w, float* wp, int n_out, int k, int n_out_pad, int k_pad, hipStream_t s);
+// W [n_out][k] (transposed = 0) or W^T stored as [k][n_out] (transposed = 1, row stride ldw) -> B fragments
+int fsn_launch_pack(const float* w, float* wp, int n_out, int k, int n_out_pad, int k_pad, hipStream_t s,
+                    int transposed = 0, int ldw = 0);
 int fsn_launch_bias_sum(const float* a, const float* b, float* out, int n, int n_pad, hipStream_t s);
+
+// lstm_train_kernels.hip (training step: BPTT pieces)
+// C [M][Nc] = sum_k A[k][M]^T B[k][Nc]   (both operands row-major over k; split-K, deterministic 2-pass)
+size_t fsn_gemm_tn_workspace_bytes(int M, int Nc, long K);
+int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int Nc, long K,
+                       void* workspace, hipStream_t s);
+int fsn_launch_colsum(const float* A, long lda, float* out, int cols, long rows, void* workspace, hipStream_t s);
+size_t fsn_colsum_workspace_bytes(int cols, long rows);
+int fsn_launch_bptt_elem(const float* dh_out, const float* dh_rec, float* dc, const float* gates, const float* c_t,
+                         const float* c_prev, float* dgates, long n_elems, int H, int last, int first, hipStream_t s);
 
 // lstm_kernels.hip
 // Sub-band model input (fullsubnet/model.py:98-111) for kernels that build it on the fly:
@@ -144,6 +164,9 @@ struct FsnRecPlan {
 FsnRecPlan fsn_lstm_rec_plan(int N, int H);
 int fsn_launch_lstm_step(const float* gx, const float* whh_p, const float* h_prev, float* h_out, float* c,
                          long gx_rt0, int row_tiles, int H, int first, hipStream_t s);
+int fsn_launch_lstm_step_train(const float* gx, const float* whh_p, const float* h_prev, float* h_out,
+                               const float* c_prev, float* c_out, float* gates_out, long gx_rt0, int row_tiles, int H,
+                               int first, hipStream_t s);
 // xin == NULL: accumulators start from the precomputed projection gx; otherwise the (K = 2nb+2)
 // input projection of the sub-band model's first layer is computed inside the kernel from xin.
 int fsn_launch_lstm_rec(const float* gx, const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad,

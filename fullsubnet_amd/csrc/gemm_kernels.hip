@@ -126,6 +126,12 @@ __device__ __forceinline__ void store_tile(const FsnGemmC& c, f32x4 acc, float b
         // accumulator-init layout of the recurrent kernels.
         f32x4 v = {acc[0] + bias, acc[1] + bias, acc[2] + bias, acc[3] + bias};
         *reinterpret_cast<f32x4*>(c.p0 + ((rtile * col_tiles + ctile) * 64 + lane) * 4) = v;
+    } else if (KIND == 3) {  // plain row-major C (+ optional bias), used by the training-step GEMMs
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long row = rtile * 16 + 4 * (lane >> 4) + i;
+            if (row < c.rows && col < c.cols) c.p0[row * c.ld + col] = acc[i] + bias;
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -269,14 +275,15 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm_kernel(FsnGemmA a, const flo
 
 // W [n_out][k] (nn.LSTM / nn.Linear layout) -> B-fragment order [n_out_pad/16][k_pad/16][64][4]
 __global__ void pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int n_out, int k, int ctiles,
-                            int kchunks) {
+                            int kchunks, int transposed, int ldw) {
     const long total = (long)ctiles * kchunks * 256;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
         const long blk = i >> 8;
         const int kc = (int)(blk % kchunks), ct = (int)(blk / kchunks);
         const int row = ct * 16 + (lane & 15), col = kc * 16 + 4 * (lane >> 4) + j;
-        wp[i] = (row < n_out && col < k) ? w[(long)row * k + col] : 0.f;
+        // transposed: the source holds W^T, i.e. element (row, col) of W sits at w[col][row]
+        wp[i] = (row < n_out && col < k) ? (transposed ? w[(long)col * ldw + row] : w[(long)row * k + col]) : 0.f;
     }
 }
 
@@ -336,15 +343,18 @@ int fsn_launch_gemm(const FsnGemmA& a, const float* wp, const FsnGemmC& c, int r
         return launch<0, 1, 4, 8, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s, 1, kOnePerCu);
     // 2-column output layer: HBM-bound on reading the hidden sequence -> many waves in flight
     if (a.kind == 0 && c.kind == 2) return launch<0, 2, 4, 1, 4, 1>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
+    // training-step GEMMs (row-major C): few row tiles per launch -> small workgroup tiles, many of them
+    if (a.kind == 0 && c.kind == 3) return launch<0, 3, 2, 2, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
     fsn_set_error("fsn_launch_gemm: unsupported operand kinds A=%d C=%d", a.kind, c.kind);
     return FSN_ERR_ARG;
 }
 
-int fsn_launch_pack(const float* w, float* wp, int n_out, int k, int n_out_pad, int k_pad, hipStream_t s) {
+int fsn_launch_pack(const float* w, float* wp, int n_out, int k, int n_out_pad, int k_pad, hipStream_t s,
+                    int transposed, int ldw) {
     const int ctiles = n_out_pad / 16, kchunks = k_pad / 16;
     const long total = (long)ctiles * kchunks * 256;
     const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, s, w, wp, n_out, k, ctiles, kchunks);
+    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, s, w, wp, n_out, k, ctiles, kchunks, transposed, ldw);
     return fsn_check_launch("pack_kernel");
 }
 

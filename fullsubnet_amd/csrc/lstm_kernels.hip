@@ -331,8 +331,9 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_small_kernel(co
 __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict__ gx,
                                                         const float* __restrict__ whh_p,
                                                         const float* __restrict__ h_prev,
-                                                        float* __restrict__ h_out, float* __restrict__ c,
-                                                        long gx_rt0, int H, int first) {
+                                                        float* __restrict__ h_out, const float* c_prev,
+                                                        float* c, float* __restrict__ gates_out, long gx_rt0,
+                                                        int H, int first) {
     __shared__ f32x4 red[3][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
@@ -377,13 +378,21 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const long idx = ((long)rtile * 16 + 4 * lq + i) * H + ug * 16 + lr;
-        const float c_old = first ? 0.f : c[idx];
+        const long row = (long)rtile * 16 + 4 * lq + i;
+        const long idx = row * H + ug * 16 + lr;
+        const float c_old = first ? 0.f : c_prev[idx];
         const float ig = sigmoid_f(acc[0][i]), fg = sigmoid_f(acc[1][i]);
         const float gg = tanhf(acc[2][i]), og = sigmoid_f(acc[3][i]);
         const float cn = fg * c_old + ig * gg;
         c[idx] = cn;
         h_out[idx] = og * tanhf(cn);
+        if (gates_out) {  // training: keep the activated gates for the backward pass, [row][4H]
+            float* gp = gates_out + row * 4 * H + ug * 16 + lr;
+            gp[0] = ig;
+            gp[H] = fg;
+            gp[2 * H] = gg;
+            gp[3 * H] = og;
+        }
     }
 }
 
@@ -551,10 +560,9 @@ int launch_rec1(const float* gx, const float* whh_p, float* hseq, int Tp, int Np
     return fsn_check_launch("lstm_rec1_kernel");
 }
 
-template <int H, int RT, bool XIN>
+template <int H, int RT, bool XIN, int UG = 2>
 int launch_rec(const float* gx, const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad,
                int main_wgs, hipStream_t s) {
-    constexpr int UG = 2;
     constexpr int NW = H / (16 * UG);
     size_t lds = (size_t)RT * 16 * (H + 4) * sizeof(float);
     if (XIN) lds += (size_t)2 * RT * 16 * (16 * xin->kin_chunks + 4) * sizeof(float);
@@ -669,11 +677,19 @@ int fsn_launch_lstm_rec(const float* gx, const FsnSbInput* xin, const float* whh
 // ordered projection, h_prev / h_out / c point at the first of those rows.
 int fsn_launch_lstm_step(const float* gx, const float* whh_p, const float* h_prev, float* h_out, float* c,
                          long gx_rt0, int row_tiles, int H, int first, hipStream_t s) {
+    return fsn_launch_lstm_step_train(gx, whh_p, h_prev, h_out, c, c, nullptr, gx_rt0, row_tiles, H, first, s);
+}
+
+// Training form: c_{t-1} is read from c_prev, c_t written to c_out (the saved cell sequence) and the
+// activated gates i, f, g, o to gates_out [rows][4H].
+int fsn_launch_lstm_step_train(const float* gx, const float* whh_p, const float* h_prev, float* h_out,
+                               const float* c_prev, float* c_out, float* gates_out, long gx_rt0, int row_tiles, int H,
+                               int first, hipStream_t s) {
     if (H % 64 != 0) {
         fsn_set_error("lstm_step: hidden size %d must be a multiple of 64", H);
         return FSN_ERR_ARG;
     }
-    hipLaunchKernelGGL(lstm_step_kernel, dim3(H / 16, row_tiles), dim3(256), 0, s, gx, whh_p, h_prev, h_out, c,
-                       gx_rt0, H, first);
+    hipLaunchKernelGGL(lstm_step_kernel, dim3(H / 16, row_tiles), dim3(256), 0, s, gx, whh_p, h_prev, h_out, c_prev,
+                       c_out, gates_out, gx_rt0, H, first);
     return fsn_check_launch("lstm_step_kernel");
 }

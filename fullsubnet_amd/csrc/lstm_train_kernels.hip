@@ -1,0 +1,187 @@
+// Training-step pieces of nn.LSTM (recipes/dns_interspeech_2020/fullsubnet/trainer.py:56-63 ->
+// autograd through audio_zen/model/module/sequence_model.py:52-58): back-propagation through time.
+//
+// Per layer, with the activated gates i,f,g,o and the cell sequence c_t saved by the forward pass:
+//   for t = T-1 .. 0:
+//     dh      = dH_t (from the layer above) + dh_rec (from step t+1)
+//     do      = dh * tanh(c_t);  dc = dc_carry + dh * o * (1 - tanh(c_t)^2)
+//     di, dg, df = dc*g, dc*i, dc*c_{t-1};  dc_carry = dc * f
+//     dgates_t = [di i(1-i), df f(1-f), dg (1-g^2), do o(1-o)]          (bptt_elem_kernel)
+//     dh_rec  = dgates_t W_hh                                            (gemm_kernel, K = 4H)
+//   dX = dgates W_ih (one GEMM over all steps);  dW_ih = dgates^T X;  dW_hh = dgates_{1..}^T H_{0..T-2};
+//   db = column sums of dgates                                           (gemm_tn_kernel / colsum)
+// First, correctness-first version: one elementwise launch + one small GEMM per step.
+#include "fsn_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void bptt_elem_kernel(const float* __restrict__ dh_out,
+                                                        const float* __restrict__ dh_rec, float* __restrict__ dc,
+                                                        const float* __restrict__ gates,
+                                                        const float* __restrict__ c_t,
+                                                        const float* __restrict__ c_prev,
+                                                        float* __restrict__ dgates, long n_elems, int H, int last,
+                                                        int first) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_elems) return;
+    const long row = idx / H;
+    const int u = (int)(idx % H);
+    const float* gp = gates + row * 4 * H + u;
+    const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
+    const float dh = dh_out[idx] + (last ? 0.f : dh_rec[idx]);
+    const float tc = tanhf(c_t[idx]);
+    const float d_o = dh * tc;
+    const float dct = (last ? 0.f : dc[idx]) + dh * og * (1.f - tc * tc);
+    const float cp = first ? 0.f : c_prev[idx];
+    float* dg = dgates + row * 4 * H + u;
+    dg[0] = dct * gg * ig * (1.f - ig);
+    dg[H] = dct * cp * fg * (1.f - fg);
+    dg[2 * H] = dct * ig * (1.f - gg * gg);
+    dg[3 * H] = d_o * og * (1.f - og);
+    dc[idx] = dct * fg;
+}
+
+// C[M][Nc] (partial, per K split) = sum_k A[k][m] * B[k][n]; A, B row-major over k.
+// 4 waves = 2 (m) x 2 (n); wave tile 4 x 2 MFMA tiles; lane (r = l&15, q = l>>4) feeds
+// A[k0 + 4q + j][m0 + r] / B[k0 + 4q + j][n0 + r] as the j-th MFMA's operands (16 lanes read 64
+// contiguous bytes of one k row).
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, long lda,
+                                                      const float* __restrict__ B, long ldb,
+                                                      float* __restrict__ part, int M, int Nc, long K, long k_per_split,
+                                                      int m_blocks, int n_blocks) {
+    constexpr int RTW = 4, CTW = 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = blockIdx.x % (m_blocks * n_blocks), split = blockIdx.x / (m_blocks * n_blocks);
+    const int mb = tile / n_blocks, nb = tile % n_blocks;
+    const int m0 = (mb * 2 + wm) * RTW * 16, n0 = (nb * 2 + wn) * CTW * 16;
+    const long k_begin = (long)split * k_per_split;
+    long k_end = k_begin + k_per_split;
+    k_end = k_end < K ? k_end : K;
+
+    f32x4 acc[RTW][CTW];
+#pragma unroll
+    for (int i = 0; i < RTW; ++i)
+#pragma unroll
+        for (int j = 0; j < CTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long k0 = k_begin; k0 < k_end; k0 += 16) {
+        float a[RTW][4], b[CTW][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long k = k0 + 4 * lq + j;
+            const bool kv = k < k_end;
+#pragma unroll
+            for (int i = 0; i < RTW; ++i) {
+                const int m = m0 + i * 16 + lr;
+                a[i][j] = (kv && m < M) ? A[k * lda + m] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < CTW; ++i) {
+                const int n = n0 + i * 16 + lr;
+                b[i][j] = (kv && n < Nc) ? B[k * ldb + n] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < RTW; ++i)
+#pragma unroll
+                for (int jj = 0; jj < CTW; ++jj) acc[i][jj] = mfma16(a[i][j], b[jj][j], acc[i][jj]);
+    }
+    float* out = part + (long)split * M * Nc;
+#pragma unroll
+    for (int i = 0; i < RTW; ++i)
+#pragma unroll
+        for (int jj = 0; jj < CTW; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + i * 16 + 4 * lq + r, n = n0 + jj * 16 + lr;
+                if (m < M && n < Nc) out[(long)m * Nc + n] = acc[i][jj][r];
+            }
+}
+
+// out[i] = sum_s part[s][i] in a fixed order
+__global__ void reduce_splits_kernel(const float* __restrict__ part, float* __restrict__ C, long ldc, int M, int Nc,
+                                     int splits) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)M * Nc) return;
+    float acc = 0.f;
+    for (int s = 0; s < splits; ++s) acc += part[(long)s * M * Nc + i];
+    C[(i / Nc) * ldc + (i % Nc)] = acc;
+}
+
+// partial column sums over blocks of rows: part[rb][c] = sum_{r in block rb} A[r][c]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ A, long lda,
+                                                             float* __restrict__ part, int cols, long rows,
+                                                             long rows_per_block) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    r1 = r1 < rows ? r1 : rows;
+    float acc = 0.f;
+    for (long r = r0; r < r1; ++r) acc += A[r * lda + c];
+    part[(long)blockIdx.y * cols + c] = acc;
+}
+
+struct TnPlan {
+    int m_blocks, n_blocks, splits;
+    long k_per_split;
+};
+TnPlan tn_plan(int M, int Nc, long K) {
+    TnPlan p;
+    p.m_blocks = (M + 127) / 128;
+    p.n_blocks = (Nc + 63) / 64;
+    const long tiles = (long)p.m_blocks * p.n_blocks;
+    long s = (1024 + tiles - 1) / tiles;
+    const long max_s = (K + 255) / 256;
+    s = s < max_s ? s : max_s;
+    s = s < 1 ? 1 : s;
+    p.k_per_split = ((K + s - 1) / s + 15) / 16 * 16;
+    p.splits = (int)((K + p.k_per_split - 1) / p.k_per_split);
+    return p;
+}
+constexpr long kColsumRows = 2048;
+
+}  // namespace
+
+size_t fsn_gemm_tn_workspace_bytes(int M, int Nc, long K) {
+    const TnPlan p = tn_plan(M, Nc, K);
+    return (size_t)p.splits * M * Nc * sizeof(float);
+}
+
+int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int Nc, long K,
+                       void* workspace, hipStream_t s) {
+    const TnPlan p = tn_plan(M, Nc, K);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.m_blocks * p.n_blocks * p.splits)), dim3(256), 0, s, A, lda, B,
+                       ldb, part, M, Nc, K, p.k_per_split, p.m_blocks, p.n_blocks);
+    FSN_TRY_LAUNCH("gemm_tn_kernel");
+    const long n = (long)M * Nc;
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, C, ldc, M, Nc,
+                       p.splits);
+    return fsn_check_launch("reduce_splits_kernel");
+}
+
+size_t fsn_colsum_workspace_bytes(int cols, long rows) {
+    return (size_t)((rows + kColsumRows - 1) / kColsumRows) * cols * sizeof(float);
+}
+
+int fsn_launch_colsum(const float* A, long lda, float* out, int cols, long rows, void* workspace, hipStream_t s) {
+    const int rb = (int)((rows + kColsumRows - 1) / kColsumRows);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, rb), dim3(256), 0, s, A, lda, part, cols, rows,
+                       kColsumRows);
+    FSN_TRY_LAUNCH("colsum_partial_kernel");
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, part, out, (long)cols, 1, cols,
+                       rb);
+    return fsn_check_launch("reduce_splits_kernel");
+}
+
+int fsn_launch_bptt_elem(const float* dh_out, const float* dh_rec, float* dc, const float* gates, const float* c_t,
+                         const float* c_prev, float* dgates, long n_elems, int H, int last, int first, hipStream_t s) {
+    hipLaunchKernelGGL(bptt_elem_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, s, dh_out, dh_rec, dc,
+                       gates, c_t, c_prev, dgates, n_elems, H, last, first);
+    return fsn_check_launch("bptt_elem_kernel");
+}

@@ -107,9 +107,12 @@ class Model(nn.Module):
         assert num_channels == 1, f"{self.__class__.__name__} takes the mag feature as inputs."
         assert num_freqs == self.num_freqs
         if torch.is_grad_enabled() and (self.training or noisy_mag.requires_grad):
-            raise NotImplementedError(
-                "the training step (BPTT kernels) is the next row of the scope table; run inference under "
-                "torch.no_grad() / model.eval()")
+            # training step (fullsubnet/trainer.py:56-63): autograd graph with the LSTM layers
+            # (forward + BPTT) on the HIP kernels, see fullsubnet_amd/train.py
+            from .train import forward_train
+            if not noisy_mag.is_cuda:
+                raise _lib.FsnError("noisy_mag must live on a ROCm device; this path has no CPU implementation")
+            return forward_train(self, noisy_mag)
         x = noisy_mag.contiguous()
         L = _lib.lib()
         out = torch.empty((batch_size, 2, num_freqs, num_frames), dtype=torch.float32, device=x.device)

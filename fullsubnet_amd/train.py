@@ -1,0 +1,141 @@
+"""Training step of the FullSubNet recipe (recipes/dns_interspeech_2020/fullsubnet/trainer.py:33-76).
+
+First version of SURVEY §8 row A16: the four LSTM layers (99.9 % of the FLOPs of the step,
+forward and backward) run on libfsn_hip.so through ``LstmLayerFunction`` (forward with saved
+activations + back-propagation through time); the thin glue around them (look-ahead pad, Laplace
+norms, sub-band unfold, drop_band, the two output Linear layers, MSE) is expressed with autograd-
+tracked torch tensor ops, so every gradient of the reference's graph is produced.  Replacing that
+glue by fused HIP kernels is the next step of this row and does not change the interface.
+"""
+import torch
+import torch.nn.functional as functional
+
+from . import _lib
+from .acoustics.feature import drop_band, stft
+from .acoustics.mask import build_complex_ideal_ratio_mask
+
+
+class LstmLayerFunction(torch.autograd.Function):
+    """One nn.LSTM layer (unidirectional, h0 = c0 = 0) on time-major input x [T, N, I] -> [T, N, H]."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        L = _lib.lib()
+        T, N, I = x.shape
+        H = w_hh.shape[1]
+        Np, Ip = (N + 15) // 16 * 16, (I + 15) // 16 * 16
+        xp = x
+        if Np != N or Ip != I or not x.is_contiguous():
+            xp = torch.zeros((T, Np, Ip), dtype=torch.float32, device=x.device)
+            xp[:, :N, :I] = x
+        w_ih_c, w_hh_c = w_ih.detach().contiguous(), w_hh.detach().contiguous()
+        hseq = torch.empty((T, Np, H), dtype=torch.float32, device=x.device)
+        save = _lib.workspace(L.fsn_lstm_layer_save_bytes(T, Np, H), x.device)
+        ws = _lib.workspace(L.fsn_lstm_layer_fwd_workspace_bytes(T, Np, I, H), x.device)
+        _lib.check(L.fsn_lstm_layer_forward(
+            _lib.dev_ptr(xp, "x"), Ip, _lib.dev_ptr(w_ih_c, "w_ih"), _lib.dev_ptr(w_hh_c, "w_hh"),
+            _lib.dev_ptr(b_ih.detach().contiguous(), "b_ih"), _lib.dev_ptr(b_hh.detach().contiguous(), "b_hh"),
+            T, Np, I, H, _lib.dev_ptr(hseq), save.data_ptr(), save.numel(), ws.data_ptr(), ws.numel(),
+            _lib.stream_ptr(x.device)))
+        ctx.save_for_backward(xp, w_ih_c, w_hh_c, hseq, save)
+        ctx.dims = (T, N, I, H, Np, Ip)
+        return hseq[:, :N]
+
+    @staticmethod
+    def backward(ctx, dh):
+        L = _lib.lib()
+        xp, w_ih, w_hh, hseq, save = ctx.saved_tensors
+        T, N, I, H, Np, Ip = ctx.dims
+        dhp = dh
+        if Np != N or not dh.is_contiguous():
+            dhp = torch.zeros((T, Np, H), dtype=torch.float32, device=dh.device)
+            dhp[:, :N] = dh
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty((T, Np, Ip), dtype=torch.float32, device=dh.device) if need_dx else None
+        dw_ih = torch.empty_like(w_ih)
+        dw_hh = torch.empty_like(w_hh)
+        db = torch.empty((4 * H,), dtype=torch.float32, device=dh.device)
+        ws = _lib.workspace(L.fsn_lstm_layer_bwd_workspace_bytes(T, Np, I, H), dh.device)
+        _lib.check(L.fsn_lstm_layer_backward(
+            _lib.dev_ptr(dhp, "dh"), _lib.dev_ptr(xp), Ip, _lib.dev_ptr(w_ih), _lib.dev_ptr(w_hh), T, Np, I, H,
+            _lib.dev_ptr(hseq), save.data_ptr(), _lib.dev_ptr(dx, allow_none=True), Ip, _lib.dev_ptr(dw_ih),
+            _lib.dev_ptr(dw_hh), _lib.dev_ptr(db), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dh.device)))
+        return (dx[:, :N, :I] if need_dx else None), dw_ih, dw_hh, db, db.clone()
+
+
+def lstm_stack(x_tn, lstm):
+    """Two stacked layers of an nn.LSTM parameter container on time-major x [T, N, I]."""
+    h = x_tn
+    for k in range(lstm.num_layers):
+        h = LstmLayerFunction.apply(h, getattr(lstm, f"weight_ih_l{k}"), getattr(lstm, f"weight_hh_l{k}"),
+                                    getattr(lstm, f"bias_ih_l{k}"), getattr(lstm, f"bias_hh_l{k}"))
+    return h
+
+
+def _freq_unfold(x, n):
+    """audio_zen/model/base_model.py:14-46 (same ops)."""
+    B, C, F, T = x.shape
+    if n <= 0:
+        return x.permute(0, 2, 1, 3).reshape(B, F, C, 1, T)
+    out = x.reshape(B * C, 1, F, T)
+    out = functional.pad(out, [0, 0, n, n], mode="reflect")
+    out = functional.unfold(out, kernel_size=(2 * n + 1, T))
+    out = out.reshape(B, C, 2 * n + 1, T, F)
+    return out.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def _norm(x, norm_type):
+    """offline / cumulative Laplace norm, base_model.py:204-251."""
+    if norm_type == "offline_laplace_norm":
+        mu = torch.mean(x, dim=list(range(1, x.dim())), keepdim=True)
+        return x / (mu + 1e-5)
+    B, C, F, T = x.shape
+    xr = x.reshape(B * C, F, T)
+    cum = torch.cumsum(torch.sum(xr, dim=1), dim=-1)
+    count = torch.arange(F, F * T + 1, F, dtype=x.dtype, device=x.device).reshape(1, T)
+    mean = (cum / count).reshape(B * C, 1, T)
+    return (xr / (mean + torch.finfo(torch.float32).eps)).reshape(B, C, F, T)
+
+
+def forward_train(model, noisy_mag):
+    """fullsubnet/model.py:72-136 under autograd (drop_band included), LSTMs on the HIP kernels.
+    noisy_mag [B, 1, F, T] -> [B, 2, F // g, T]."""
+    x = functional.pad(noisy_mag, [0, model.look_ahead])
+    B, C, F, Tp = x.shape
+    fb_in = _norm(x, model.norm_type).reshape(B, F, Tp)
+    h = lstm_stack(fb_in.permute(2, 0, 1), model.fb_model.sequence_model)  # [Tp, B, Hf]
+    fb_out = functional.relu(model.fb_model.fc_output_layer(h))  # [Tp, B, F]
+    fb_out = fb_out.permute(1, 2, 0).reshape(B, 1, F, Tp)
+    n = model.sb_num_neighbors
+    sb_in = torch.cat([_freq_unfold(x, n).reshape(B, F, 2 * n + 1, Tp),
+                       _freq_unfold(fb_out, 0).reshape(B, F, 1, Tp)], dim=2)
+    sb_in = _norm(sb_in, model.norm_type)
+    Fs = F
+    if B > 1:
+        sb_in = drop_band(sb_in.permute(0, 2, 1, 3), num_groups=model.num_groups_in_drop_band)
+        Fs = sb_in.shape[2]
+        sb_in = sb_in.permute(0, 2, 1, 3)
+    sb_in = sb_in.reshape(B * Fs, 2 * n + 2, Tp)
+    h = lstm_stack(sb_in.permute(2, 0, 1), model.sb_model.sequence_model)  # [Tp, B Fs, Hs]
+    mask = model.sb_model.fc_output_layer(h)  # [Tp, B Fs, 2]
+    mask = mask.permute(1, 2, 0).reshape(B, Fs, 2, Tp).permute(0, 2, 1, 3).contiguous()
+    return mask[:, :, :, model.look_ahead:]
+
+
+def train_step(model, optimizer, noisy, clean, n_fft=512, hop_length=256, win_length=512, clip_grad_norm_value=10.0,
+               loss_function=None):
+    """One iteration of Trainer._train_epoch (fullsubnet/trainer.py:41-71), fp32 (use_amp = false).
+    Returns the loss tensor (call .item() to synchronise like the reference does)."""
+    loss_function = loss_function or torch.nn.MSELoss()
+    optimizer.zero_grad()
+    noisy_mag, _, noisy_real, noisy_imag = stft(noisy, n_fft, hop_length, win_length)
+    _, _, clean_real, clean_imag = stft(clean, n_fft, hop_length, win_length)
+    cirm = build_complex_ideal_ratio_mask(noisy_real, noisy_imag, clean_real, clean_imag)  # [B, F, T, 2]
+    inner = model.module if hasattr(model, "module") else model
+    cirm = drop_band(cirm.permute(0, 3, 1, 2), inner.num_groups_in_drop_band).permute(0, 2, 3, 1)
+    crm = model(noisy_mag.unsqueeze(1)).permute(0, 2, 3, 1)
+    loss = loss_function(cirm, crm)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), clip_grad_norm_value)
+    optimizer.step()
+    return loss

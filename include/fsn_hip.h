@@ -104,6 +104,26 @@ int fsn_enhance(const fsn_fullsubnet_cfg* cfg, const void* packed, const float* 
                 const float* noisy, int B, int L, int n_fft, int hop, float* enhanced, float* crm_out,
                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- training step: one nn.LSTM layer with back-propagation through time ----------------- */
+
+/* audio_zen/model/module/sequence_model.py:52-58 (nn.LSTM, one layer, batch_first, h0 = c0 = 0) as
+ * used under autograd by fullsubnet/trainer.py:56-63.  Time-major rows: x [T][N][ldx] (columns
+ * I..ldx-1 zero, ldx >= round_up(I,16)), hseq [T][N][H]; w_ih [4H][I], w_hh [4H][H], b_* [4H] in the
+ * reference's layout.  N % 16 == 0, H % 64 == 0.  `save` keeps the activated gates and the cell
+ * sequence for the backward pass. */
+size_t fsn_lstm_layer_save_bytes(int T, int N, int H);
+size_t fsn_lstm_layer_fwd_workspace_bytes(int T, int N, int I, int H);
+int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
+                           const float* b_hh, int T, int N, int I, int H, float* hseq, void* save,
+                           size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream);
+/* dh [T][N][H] = dLoss/dhseq.  Outputs: dx [T][N][lddx] (may be NULL), dw_ih [4H][I], dw_hh [4H][H],
+ * db [4H] (= d b_ih = d b_hh). */
+size_t fsn_lstm_layer_bwd_workspace_bytes(int T, int N, int I, int H);
+int fsn_lstm_layer_backward(const float* dh, const float* x, long ldx, const float* w_ih, const float* w_hh, int T,
+                            int N, int I, int H, const float* hseq, const void* save, float* dx, long lddx,
+                            float* dw_ih, float* dw_hh, float* db, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
 /* Per-stage kernel timing of the last fsn_enhance / fsn_fullsubnet_forward call made with
  * profiling enabled (hipEvents on `stream`; forces a stream sync when read).  Stage ids are listed
  * by fsn_profile_stage_name(); used by bench.py for the roofline line.  */

@@ -1,0 +1,67 @@
+"""Golden vectors of ONE TRAINING STEP produced by the REFERENCE itself (CPU, torch) - run in the
+authoring container:   python tests/golden/make_golden_train.py
+
+Follows recipes/dns_interspeech_2020/fullsubnet/trainer.py:41-71 with use_amp = false: reference
+stft / build_complex_ideal_ratio_mask / drop_band / Model (nn.LSTM) / MSELoss / clip_grad_norm_(10)
+/ Adam(lr 1e-3).  Stored: the loss, and for every parameter the clipped-gradient norm, a strided
+sample of the gradient and of the updated parameter (the full tensors are 22 MB each).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.modules.setdefault("librosa", types.ModuleType("librosa"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, "/root/reference/recipes/dns_interspeech_2020")
+
+from audio_zen.acoustics.feature import drop_band, stft  # noqa: E402
+from audio_zen.acoustics.mask import build_complex_ideal_ratio_mask  # noqa: E402
+from fullsubnet.model import Model  # noqa: E402
+
+from oracle.fullsubnet_oracle import make_noisy, make_params  # noqa: E402
+
+SAMPLE = 97  # stride of the per-parameter samples
+
+
+def main(batch=4, length=2560, groups=2):
+    params = make_params(seed=3)
+    noisy = make_noisy(batch, length, seed=41)
+    clean = 0.7 * make_noisy(batch, length, seed=42)
+    model = Model(num_freqs=257, look_ahead=2, sequence_model="LSTM", fb_num_neighbors=0, sb_num_neighbors=15,
+                  fb_output_activate_function="ReLU", sb_output_activate_function=False, fb_model_hidden_size=512,
+                  sb_model_hidden_size=384, norm_type="offline_laplace_norm", num_groups_in_drop_band=groups,
+                  weight_init=False).train()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    opt.zero_grad()
+    noisy_mag, _, nr, ni = stft(torch.from_numpy(noisy), 512, 256, 512)
+    _, _, cr, ci = stft(torch.from_numpy(clean), 512, 256, 512)
+    cirm = build_complex_ideal_ratio_mask(nr, ni, cr, ci)
+    cirm = drop_band(cirm.permute(0, 3, 1, 2), groups).permute(0, 2, 3, 1)
+    crm = model(noisy_mag.unsqueeze(1)).permute(0, 2, 3, 1)
+    loss = torch.nn.MSELoss()(cirm, crm)
+    loss.backward()
+    total_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+    out = dict(loss=np.float64(loss.item()), total_norm=np.float64(total_norm.item()))
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    opt.step()
+    for k, p in model.named_parameters():
+        out["gnorm/" + k] = np.float64(grads[k].norm().item())
+        out["g/" + k] = grads[k].reshape(-1)[::SAMPLE].numpy().copy()
+        out["p/" + k] = p.detach().reshape(-1)[::SAMPLE].numpy().copy()
+    out["meta"] = np.array(repr(dict(batch=batch, length=length, groups=groups, seed_w=3, seed_noisy=41, seed_clean=42,
+                                     clean_gain=0.7, sample=SAMPLE, torch=torch.__version__)))
+    path = os.path.join(HERE, "fsn_train_b4.npz")
+    np.savez_compressed(path, **out)
+    print(f"loss {loss.item():.6f} total grad norm {total_norm.item():.4f} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    main()

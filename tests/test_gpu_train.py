@@ -1,0 +1,79 @@
+"""Training step on the HIP path (LSTM layers forward + BPTT through the C ABI) against the training
+oracle and the reference's golden vectors.  Needs an MI355X:  python -m pytest tests -m gpu"""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fullsubnet_oracle as O
+from oracle import train_oracle as TO
+
+pytestmark = pytest.mark.gpu
+
+MODEL_KW = dict(num_freqs=257, look_ahead=2, sequence_model="LSTM", fb_num_neighbors=0, sb_num_neighbors=15,
+                fb_output_activate_function="ReLU", sb_output_activate_function=False, fb_model_hidden_size=512,
+                sb_model_hidden_size=384, weight_init=False)
+
+
+@pytest.fixture(scope="module")
+def fsn():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu tests need a ROCm device")
+    import fullsubnet_amd
+    fullsubnet_amd._lib.lib()
+    return fullsubnet_amd
+
+
+@pytest.mark.parametrize("T,N,I,H", [(7, 33, 32, 384), (5, 4, 257, 512), (6, 48, 384, 384), (1, 16, 32, 384)])
+def test_lstm_layer_forward_and_bptt(fsn, T, N, I, H):
+    from fullsubnet_amd.train import LstmLayerFunction
+    g = torch.Generator().manual_seed(T * 1000 + N)
+    k = 1.0 / np.sqrt(H)
+    x = torch.randn(T, N, I, generator=g)
+    w = [(torch.rand(s, generator=g) * 2 - 1) * k * 2 for s in ((4 * H, I), (4 * H, H), (4 * H,), (4 * H,))]
+    dy = torch.randn(T, N, H, generator=g)
+    # oracle: restated cell + autograd (batch_first there)
+    xo = x.clone().requires_grad_(True)
+    wo = [t.clone().requires_grad_(True) for t in w]
+    yo = TO.lstm_layer(xo.permute(1, 0, 2), *wo).permute(1, 0, 2)
+    (yo * dy).sum().backward()
+    # HIP
+    xd = x.cuda().requires_grad_(True)
+    wd = [t.cuda().requires_grad_(True) for t in w]
+    yd = LstmLayerFunction.apply(xd, *wd)
+    (yd * dy.cuda()).sum().backward()
+    assert (yd.detach().cpu() - yo.detach()).abs().max().item() <= 2e-6
+    for name, a, b in [("dx", xd.grad, xo.grad), ("dw_ih", wd[0].grad, wo[0].grad), ("dw_hh", wd[1].grad, wo[1].grad),
+                       ("db_ih", wd[2].grad, wo[2].grad), ("db_hh", wd[3].grad, wo[3].grad)]:
+        err = (a.cpu() - b).abs().max().item()
+        assert err <= 1e-4 * max(b.abs().max().item(), 1e-3), (name, err, b.abs().max().item())
+
+
+def test_train_step_vs_reference_and_oracle(fsn, golden_dir):
+    from fullsubnet_amd.train import train_step
+    z = np.load(os.path.join(golden_dir, "fsn_train_b4.npz"))
+    meta = ast.literal_eval(str(z["meta"]))
+    params = O.make_params(seed=meta["seed_w"])
+    noisy = O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_noisy"])
+    clean = (meta["clean_gain"] * O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_clean"])).astype(np.float32)
+    model = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=meta["groups"], **MODEL_KW)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    model = model.cuda().train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    loss = train_step(model, opt, torch.from_numpy(noisy).cuda(), torch.from_numpy(clean).cuda())
+    assert abs(loss.item() - float(z["loss"])) <= 1e-5 * float(z["loss"])
+    s = meta["sample"]
+    named = dict(model.named_parameters())
+    for k in params:
+        g = named[k].grad.detach().reshape(-1)[::s].cpu().numpy()
+        gn = float(z["gnorm/" + k])
+        assert abs(float(named[k].grad.norm()) - gn) <= 2e-3 * gn + 1e-9, k
+        assert np.abs(g - z["g/" + k]).max() <= 2e-3 * max(np.abs(z["g/" + k]).max(), 1e-3 * gn) + 1e-9, k
+        p = named[k].detach().reshape(-1)[::s].cpu().numpy()
+        assert np.abs(p - z["p/" + k]).max() <= 2.5e-3, k
+        assert np.mean(np.abs(p - z["p/" + k]) > 1e-5) <= 0.02, k
+    # a second step must lower the loss on the same batch (the optimiser really moved the weights)
+    loss2 = train_step(model, opt, torch.from_numpy(noisy).cuda(), torch.from_numpy(clean).cuda())
+    assert loss2.item() < loss.item()

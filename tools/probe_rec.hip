@@ -21,18 +21,23 @@ int main(int argc, char** argv) {
     fill_kernel<<<256, 256>>>(w, (size_t)4 * H * H, 2, 0.05f);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int ver = 0; ver < 2; ++ver) {
+    for (int ver = 0; ver < 5; ++ver) {
         float best = 1e30f;
         for (int it = 0; it < 3; ++it) {
             hipEventRecord(e0, 0);
             if (ver == 0) launch_rec1<384, 4>(gx, w, hseq, Tp, Npad, 256, 0);
-            else launch_rec<384, 4, false>(gx, nullptr, w, hseq, Tp, Npad, 256, 0);
+            else if (ver == 1) launch_rec<384, 4, false, 2>(gx, nullptr, w, hseq, Tp, Npad, 256, 0);
+            else if (ver == 2) launch_rec<384, 4, false, 3>(gx, nullptr, w, hseq, Tp, Npad, 256, 0);
+            else if (ver == 3) launch_rec<384, 4, false, 4>(gx, nullptr, w, hseq, Tp, Npad, 256, 0);
+            else launch_rec<384, 4, false, 6>(gx, nullptr, w, hseq, Tp, Npad, 256, 0);
             hipEventRecord(e1, 0); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); if (it > 0 && ms < best) best = ms;
         }
         const double flops = 2.0 * 256 * 64 * 384.0 * 1536 * Tp;
-        printf("%s ablate=%d: %.3f ms  %.1f TFLOP/s (ideal %.3f ms)\n", ver == 0 ? "rec1 (1 wave/SIMD)" : "rec  (3 waves/SIMD)",
-               FSN_REC1_ABLATE, best, flops / best / 1e9, flops / 156e9);
+        const char* names[5] = {"rec1 (1 wave/SIMD, pinned)", "rec UG=2 (12 waves)", "rec UG=3 (8 waves)", "rec UG=4 (6 waves)",
+                                "rec UG=6 (4 waves)"};
+        printf("%s ablate=%d: %.3f ms  %.1f TFLOP/s (ideal %.3f ms)\n", names[ver], FSN_REC1_ABLATE, best,
+               flops / best / 1e9, flops / 156e9);
     }
     return 0;
 }
