@@ -97,6 +97,63 @@ def _norm(x, norm_type):
     return (xr / (mean + torch.finfo(torch.float32).eps)).reshape(B, C, F, T)
 
 
+_INDEX_CACHE = {}
+
+
+def _sb_indices(B, F, n, groups, device):
+    """Row list of the sub-band model after drop_band (feature.py:327-345 order: group g holds samples
+    g::G at bins g:F':G), the reflect-padded window bins of every row (base_model.py:31-44) and the
+    number of (unit, window row) pairs that hit each bin (for the analytic mean of the unfolded tensor)."""
+    key = (B, F, n, groups, str(device))
+    if key not in _INDEX_CACHE:
+        f_all = torch.arange(F)
+        k = torch.arange(-n, n + 1)
+        src = (f_all[:, None] + k[None, :]).abs()
+        src = torch.where(src >= F, 2 * (F - 1) - src, src)  # [F, 2n+1]
+        mult = torch.bincount(src.reshape(-1), minlength=F).to(torch.float32)
+        if B > 1 and groups > 1:
+            Fd = F - F % groups
+            rb = torch.cat([torch.arange(g, B, groups).repeat_interleave(len(range(g, Fd, groups))) for g in range(groups)])
+            rf = torch.cat([torch.arange(g, Fd, groups).repeat(len(range(g, B, groups))) for g in range(groups)])
+            Fs = Fd // groups
+        else:
+            rb, rf, Fs = torch.arange(B).repeat_interleave(F), f_all.repeat(B), F
+        _INDEX_CACHE[key] = (rb.to(device), rf.to(device), src[rf].to(device), mult.to(device), Fs)
+    return _INDEX_CACHE[key]
+
+
+class SubbandInputOffline(torch.autograd.Function):
+    """fullsubnet/model.py:98-125 for norm_type = offline_laplace_norm without materialising the
+    unfolded tensor twice: freq_unfold(noisy, n) ++ fb_output, divided by the per-utterance mean of
+    the FULL [F, 2n+2, T'] tensor (computed analytically from per-bin sums), restricted to the rows
+    drop_band keeps.  Gradient flows to fb_output only (directly and through the mean)."""
+
+    @staticmethod
+    def forward(ctx, x, fb_out, n, groups):
+        B, _, F, Tp = x.shape
+        rb, rf, win_idx, mult, Fs = _sb_indices(B, F, n, groups, x.device)
+        raw = torch.cat([x[rb[:, None], 0, win_idx, :], fb_out[rb, 0, rf, :][:, None, :]], dim=1)  # [R, 2n+2, Tp]
+        count = float(F * (2 * n + 2) * Tp)
+        mu = ((x[:, 0].sum(dim=2) * mult[None, :]).sum(dim=1) + fb_out.sum(dim=(1, 2, 3))) / count  # [B]
+        den = (mu + 1e-5)[rb]  # [R]
+        ctx.save_for_backward(raw, den, rb, rf)
+        ctx.dims = (B, F, Tp, Fs, count)
+        return raw / den[:, None, None]
+
+    @staticmethod
+    def backward(ctx, dy):
+        raw, den, rb, rf = ctx.saved_tensors
+        B, F, Tp, Fs, count = ctx.dims
+        d_fb = torch.zeros((B, 1, F, Tp), dtype=dy.dtype, device=dy.device)
+        d_fb[rb, 0, rf, :] = dy[:, -1, :] / den[:, None]
+        # d mu_b = - sum_{rows of b} dy * raw / (mu + eps)^2 ; every fb_out element has weight 1/count in mu
+        per_row = (dy * raw).sum(dim=(1, 2)) / (den * den)
+        d_mu = torch.zeros((B,), dtype=dy.dtype, device=dy.device)
+        d_mu[rb[::Fs]] = -per_row.reshape(-1, Fs).sum(dim=1)  # a sample's rows are one contiguous block
+        d_fb += (d_mu / count)[:, None, None, None]
+        return None, d_fb, None, None
+
+
 def forward_train(model, noisy_mag):
     """fullsubnet/model.py:72-136 under autograd (drop_band included), LSTMs on the HIP kernels.
     noisy_mag [B, 1, F, T] -> [B, 2, F // g, T]."""
@@ -107,15 +164,19 @@ def forward_train(model, noisy_mag):
     fb_out = functional.relu(model.fb_model.fc_output_layer(h))  # [Tp, B, F]
     fb_out = fb_out.permute(1, 2, 0).reshape(B, 1, F, Tp)
     n = model.sb_num_neighbors
-    sb_in = torch.cat([_freq_unfold(x, n).reshape(B, F, 2 * n + 1, Tp),
-                       _freq_unfold(fb_out, 0).reshape(B, F, 1, Tp)], dim=2)
-    sb_in = _norm(sb_in, model.norm_type)
-    Fs = F
-    if B > 1:
-        sb_in = drop_band(sb_in.permute(0, 2, 1, 3), num_groups=model.num_groups_in_drop_band)
-        Fs = sb_in.shape[2]
-        sb_in = sb_in.permute(0, 2, 1, 3)
-    sb_in = sb_in.reshape(B * Fs, 2 * n + 2, Tp)
+    if model.norm_type == "offline_laplace_norm":
+        sb_in = SubbandInputOffline.apply(x, fb_out, n, model.num_groups_in_drop_band)
+        Fs = sb_in.shape[0] // B
+    else:
+        sb_in = torch.cat([_freq_unfold(x, n).reshape(B, F, 2 * n + 1, Tp),
+                           _freq_unfold(fb_out, 0).reshape(B, F, 1, Tp)], dim=2)
+        sb_in = _norm(sb_in, model.norm_type)
+        Fs = F
+        if B > 1:
+            sb_in = drop_band(sb_in.permute(0, 2, 1, 3), num_groups=model.num_groups_in_drop_band)
+            Fs = sb_in.shape[2]
+            sb_in = sb_in.permute(0, 2, 1, 3)
+        sb_in = sb_in.reshape(B * Fs, 2 * n + 2, Tp)
     h = lstm_stack(sb_in.permute(2, 0, 1), model.sb_model.sequence_model)  # [Tp, B Fs, Hs]
     mask = model.sb_model.fc_output_layer(h)  # [Tp, B Fs, 2]
     mask = mask.permute(1, 2, 0).reshape(B, Fs, 2, Tp).permute(0, 2, 1, 3).contiguous()
