@@ -81,6 +81,11 @@ SIGNATURES = {
     "fsn_lstm_layer_backward": (_c.c_int, [_f32p, _f32p, _c.c_long, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_int,
                                            _c.c_int, _f32p, _c.c_void_p, _f32p, _c.c_long, _f32p, _f32p, _f32p,
                                            _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "fsn_linear_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
+    "fsn_linear_forward": (_c.c_int, [_f32p, _c.c_long, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _f32p,
+                                      _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "fsn_linear_backward": (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_int, _c.c_int, _c.c_int, _f32p,
+                                       _c.c_long, _f32p, _f32p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "fsn_profile_enable": (_c.c_int, [_c.c_int]),
     "fsn_profile_num_stages": (_c.c_int, []),
     "fsn_profile_stage_name": (_c.c_char_p, [_c.c_int]),

@@ -794,3 +794,86 @@ extern "C" int fsn_lstm_layer_backward(const float* dh, const float* x, long ldx
     }
     return fsn_launch_colsum(dgates, G, db, G, (long)T * N, scratch, s);
 }
+
+// ---- training step: nn.Linear (sequence_model.py:82-84) forward / backward ------------------------
+// x [R][ldx] (columns I..ldx-1 zero, ldx = round_up(I,16)), w [O][I], b [O] -> y [R][O] (+ ReLU).
+extern "C" size_t fsn_linear_workspace_bytes(int R, int I, int O) {
+    const int Ip = fsn_round_up(I, 16), Op = fsn_round_up(O, 16);
+    Carver cv(nullptr);
+    cv.take<float>((size_t)Op * Ip);  // W (forward) or W^T (backward) fragments
+    cv.take<float>((size_t)Op);       // padded bias
+    size_t tn = fsn_gemm_tn_workspace_bytes(O, I, R);
+    const size_t cs = fsn_colsum_workspace_bytes(O, R);
+    cv.take<char>(tn > cs ? tn : cs);
+    return fsn_round_up_sz(cv.off, 256);
+}
+
+extern "C" int fsn_linear_forward(const float* x, long ldx, const float* w, const float* b, int R, int I, int O,
+                                  int relu, float* y, void* workspace, size_t workspace_bytes, void* stream) {
+    FSN_REQUIRE(x && w && b && y && workspace, "NULL pointer argument");
+    FSN_REQUIRE(R >= 1 && I >= 1 && O >= 1 && ldx >= fsn_round_up(I, 16) && ldx % 4 == 0, "linear: bad shape");
+    if (workspace_bytes < fsn_linear_workspace_bytes(R, I, O)) {
+        fsn_set_error("linear: workspace too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Ip = fsn_round_up(I, 16), Op = fsn_round_up(O, 16);
+    Carver cv(workspace);
+    float* wp = cv.take<float>((size_t)Op * Ip);
+    float* bp = cv.take<float>((size_t)Op);
+    FSN_TRY(fsn_launch_pack(w, wp, O, I, Op, Ip, s));
+    FSN_TRY(fsn_launch_bias_sum(b, nullptr, bp, O, Op, s));
+    FsnGemmA a{};
+    a.kind = 0;
+    a.p0 = x;
+    a.ld = ldx;
+    FsnGemmC c{};
+    c.kind = 3;
+    c.p0 = y;
+    c.bias = bp;
+    c.ld = O;
+    c.rows = R;
+    c.cols = O;
+    c.la = relu ? 1 : 0;  // kind 3: la doubles as the ReLU flag
+    a.N = R;
+    return fsn_launch_gemm(a, wp, c, (R + 15) / 16, Op / 16, Ip / 16, s);
+}
+
+// dy [R][lddy] (columns O..lddy-1 zero, lddy = round_up(O,16)) -> dx [R][lddx] (may be NULL), dw [O][I], db [O]
+extern "C" int fsn_linear_backward(const float* dy, long lddy, const float* x, long ldx, const float* w, int R, int I,
+                                   int O, float* dx, long lddx, float* dw, float* db, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    FSN_REQUIRE(dy && x && w && dw && db && workspace, "NULL pointer argument");
+    FSN_REQUIRE(R >= 1 && I >= 1 && O >= 1 && lddy >= fsn_round_up(O, 16) && lddy % 4 == 0 && ldx >= I,
+                "linear backward: bad shape");
+    if (workspace_bytes < fsn_linear_workspace_bytes(R, I, O)) {
+        fsn_set_error("linear: workspace too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Ip = fsn_round_up(I, 16), Op = fsn_round_up(O, 16);
+    Carver cv(workspace);
+    float* wtp = cv.take<float>((size_t)Op * Ip);
+    cv.take<float>((size_t)Op);
+    size_t tn = fsn_gemm_tn_workspace_bytes(O, I, R);
+    const size_t cs = fsn_colsum_workspace_bytes(O, R);
+    void* scratch = cv.take<char>(tn > cs ? tn : cs);
+    if (dx) {
+        // dX = dY W: "weights" W^T (out = I, k = O) = the stored [O][I] read transposed
+        FSN_TRY(fsn_launch_pack(w, wtp, I, O, Ip, Op, s, 1, I));
+        FsnGemmA a{};
+        a.kind = 0;
+        a.p0 = dy;
+        a.ld = lddy;
+        FsnGemmC c{};
+        c.kind = 3;
+        c.p0 = dx;
+        c.ld = lddx;
+        c.rows = R;
+        c.cols = I;
+        a.N = R;
+        FSN_TRY(fsn_launch_gemm(a, wtp, c, (R + 15) / 16, Ip / 16, Op / 16, s));
+    }
+    FSN_TRY(fsn_launch_gemm_tn(dy, lddy, x, ldx, dw, I, O, I, R, scratch, s));
+    return fsn_launch_colsum(dy, lddy, db, O, R, scratch, s);
+}

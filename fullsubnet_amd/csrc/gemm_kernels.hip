@@ -39,7 +39,8 @@ template <>
 struct ARow<0> {  // row-major matrix [R][ld]
     const float* base;
     __device__ __forceinline__ void prepare(const FsnGemmA& a, long row, long nrows) {
-        row = row < nrows ? row : nrows - 1;  // clamped rows are computed and discarded
+        const long lim = a.N > 0 ? (long)a.N : nrows;  // a.N: valid rows when not a multiple of 16
+        row = row < lim ? row : lim - 1;  // clamped rows are computed and discarded
         base = a.p0 + row * a.ld;
     }
     __device__ __forceinline__ f32x4 load(const FsnGemmA&, int k0) const {
@@ -130,7 +131,10 @@ __device__ __forceinline__ void store_tile(const FsnGemmC& c, f32x4 acc, float b
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long row = rtile * 16 + 4 * (lane >> 4) + i;
-            if (row < c.rows && col < c.cols) c.p0[row * c.ld + col] = acc[i] + bias;
+            if (row < c.rows && col < c.cols) {
+                const float v = acc[i] + bias;
+                c.p0[row * c.ld + col] = (c.la && v < 0.f) ? 0.f : v;  // la doubles as the ReLU flag here
+            }
         }
     } else {
 #pragma unroll

@@ -2,10 +2,11 @@
 
 First version of SURVEY §8 row A16: the four LSTM layers (99.9 % of the FLOPs of the step,
 forward and backward) run on libfsn_hip.so through ``LstmLayerFunction`` (forward with saved
-activations + back-propagation through time); the thin glue around them (look-ahead pad, Laplace
-norms, sub-band unfold, drop_band, the two output Linear layers, MSE) is expressed with autograd-
-tracked torch tensor ops, so every gradient of the reference's graph is produced.  Replacing that
-glue by fused HIP kernels is the next step of this row and does not change the interface.
+activations + back-propagation through time) and the two output layers through ``LinearFunction``;
+the thin glue around them (look-ahead pad, Laplace norms, sub-band input gather, MSE, gradient
+clipping, Adam) is autograd-tracked torch tensor algebra, so every gradient of the reference's graph
+is produced.  Fusing that glue into HIP kernels is the next step of this row and does not change the
+interface.
 """
 import torch
 import torch.nn.functional as functional
@@ -61,6 +62,53 @@ class LstmLayerFunction(torch.autograd.Function):
             _lib.dev_ptr(hseq), save.data_ptr(), _lib.dev_ptr(dx, allow_none=True), Ip, _lib.dev_ptr(dw_ih),
             _lib.dev_ptr(dw_hh), _lib.dev_ptr(db), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dh.device)))
         return (dx[:, :N, :I] if need_dx else None), dw_ih, dw_hh, db, db.clone()
+
+
+class LinearFunction(torch.autograd.Function):
+    """nn.Linear (+ optional ReLU) on x [..., I] -> [..., O] through fsn_linear_forward / _backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        L = _lib.lib()
+        lead, I, O = x.shape[:-1], x.shape[-1], w.shape[0]
+        R = x.numel() // I
+        Ip = (I + 15) // 16 * 16
+        x2 = x.reshape(R, I)
+        if Ip != I or not x2.is_contiguous():
+            xp = torch.zeros((R, Ip), dtype=torch.float32, device=x.device)
+            xp[:, :I] = x2
+        else:
+            xp = x2
+        wc = w.detach().contiguous()
+        y = torch.empty((R, O), dtype=torch.float32, device=x.device)
+        ws = _lib.workspace(L.fsn_linear_workspace_bytes(R, I, O), x.device)
+        _lib.check(L.fsn_linear_forward(_lib.dev_ptr(xp, "x"), Ip, _lib.dev_ptr(wc, "w"),
+                                        _lib.dev_ptr(b.detach().contiguous(), "b"), R, I, O, 1 if relu else 0,
+                                        _lib.dev_ptr(y), ws.data_ptr(), ws.numel(), _lib.stream_ptr(x.device)))
+        ctx.save_for_backward(xp, wc, y if relu else None)
+        ctx.dims = (lead, R, I, O, Ip, relu)
+        return y.reshape(*lead, O)
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        xp, w, y = ctx.saved_tensors
+        lead, R, I, O, Ip, relu = ctx.dims
+        Op = (O + 15) // 16 * 16
+        dy2 = dy.reshape(R, O)
+        if relu:
+            dy2 = dy2 * (y > 0)
+        dyp = torch.zeros((R, Op), dtype=torch.float32, device=dy.device)
+        dyp[:, :O] = dy2
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty((R, Ip), dtype=torch.float32, device=dy.device) if need_dx else None
+        dw = torch.empty_like(w)
+        db = torch.empty((O,), dtype=torch.float32, device=dy.device)
+        ws = _lib.workspace(L.fsn_linear_workspace_bytes(R, I, O), dy.device)
+        _lib.check(L.fsn_linear_backward(_lib.dev_ptr(dyp, "dy"), Op, _lib.dev_ptr(xp), Ip, _lib.dev_ptr(w), R, I, O,
+                                         _lib.dev_ptr(dx, allow_none=True), Ip, _lib.dev_ptr(dw), _lib.dev_ptr(db),
+                                         ws.data_ptr(), ws.numel(), _lib.stream_ptr(dy.device)))
+        return (dx[:, :I].reshape(*lead, I) if need_dx else None), dw, db, None
 
 
 def lstm_stack(x_tn, lstm):
@@ -161,7 +209,8 @@ def forward_train(model, noisy_mag):
     B, C, F, Tp = x.shape
     fb_in = _norm(x, model.norm_type).reshape(B, F, Tp)
     h = lstm_stack(fb_in.permute(2, 0, 1), model.fb_model.sequence_model)  # [Tp, B, Hf]
-    fb_out = functional.relu(model.fb_model.fc_output_layer(h))  # [Tp, B, F]
+    fc = model.fb_model.fc_output_layer
+    fb_out = LinearFunction.apply(h, fc.weight, fc.bias, True)  # ReLU(h W^T + b): [Tp, B, F]
     fb_out = fb_out.permute(1, 2, 0).reshape(B, 1, F, Tp)
     n = model.sb_num_neighbors
     if model.norm_type == "offline_laplace_norm":
@@ -178,7 +227,8 @@ def forward_train(model, noisy_mag):
             sb_in = sb_in.permute(0, 2, 1, 3)
         sb_in = sb_in.reshape(B * Fs, 2 * n + 2, Tp)
     h = lstm_stack(sb_in.permute(2, 0, 1), model.sb_model.sequence_model)  # [Tp, B Fs, Hs]
-    mask = model.sb_model.fc_output_layer(h)  # [Tp, B Fs, 2]
+    fc = model.sb_model.fc_output_layer
+    mask = LinearFunction.apply(h, fc.weight, fc.bias, False)  # [Tp, B Fs, 2]
     mask = mask.permute(1, 2, 0).reshape(B, Fs, 2, Tp).permute(0, 2, 1, 3).contiguous()
     return mask[:, :, :, model.look_ahead:]
 

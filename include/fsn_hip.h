@@ -124,6 +124,16 @@ int fsn_lstm_layer_backward(const float* dh, const float* x, long ldx, const flo
                             float* dw_ih, float* dw_hh, float* db, void* workspace, size_t workspace_bytes,
                             void* stream);
 
+/* nn.Linear (sequence_model.py:82-84) of the training step.  x [R][ldx] with ldx = round_up(I,16) and
+ * zero padding, w [O][I], b [O] -> y [R][O] (ReLU fused when relu != 0).  Backward: dy [R][lddy]
+ * (lddy = round_up(O,16), zero padded) -> dx [R][lddx] (may be NULL), dw [O][I], db [O]. */
+size_t fsn_linear_workspace_bytes(int R, int I, int O);
+int fsn_linear_forward(const float* x, long ldx, const float* w, const float* b, int R, int I, int O, int relu,
+                       float* y, void* workspace, size_t workspace_bytes, void* stream);
+int fsn_linear_backward(const float* dy, long lddy, const float* x, long ldx, const float* w, int R, int I, int O,
+                        float* dx, long lddx, float* dw, float* db, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
 /* Per-stage kernel timing of the last fsn_enhance / fsn_fullsubnet_forward call made with
  * profiling enabled (hipEvents on `stream`; forces a stream sync when read).  Stage ids are listed
  * by fsn_profile_stage_name(); used by bench.py for the roofline line.  */

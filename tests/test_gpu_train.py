@@ -77,3 +77,21 @@ def test_train_step_vs_reference_and_oracle(fsn, golden_dir):
     # a second step must lower the loss on the same batch (the optimiser really moved the weights)
     loss2 = train_step(model, opt, torch.from_numpy(noisy).cuda(), torch.from_numpy(clean).cuda())
     assert loss2.item() < loss.item()
+
+
+@pytest.mark.parametrize("R,I,O,relu", [(68, 512, 257, True), (33, 384, 2, False), (16, 32, 48, False)])
+def test_linear_forward_backward(fsn, R, I, O, relu):
+    from fullsubnet_amd.train import LinearFunction
+    g = torch.Generator().manual_seed(R + I + O)
+    x, w, b = torch.randn(R, I, generator=g), torch.randn(O, I, generator=g) * 0.1, torch.randn(O, generator=g)
+    dy = torch.randn(R, O, generator=g)
+    xo, wo, bo = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yo = torch.nn.functional.linear(xo, wo, bo)
+    yo = torch.relu(yo) if relu else yo
+    (yo * dy).sum().backward()
+    xd, wd, bd = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    yd = LinearFunction.apply(xd, wd, bd, relu)
+    (yd * dy.cuda()).sum().backward()
+    assert (yd.detach().cpu() - yo.detach()).abs().max().item() <= 1e-4
+    for a, r in ((xd.grad, xo.grad), (wd.grad, wo.grad), (bd.grad, bo.grad)):
+        assert (a.cpu() - r).abs().max().item() <= 1e-4 * max(r.abs().max().item(), 1.0)
