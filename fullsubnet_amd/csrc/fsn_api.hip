@@ -754,24 +754,12 @@ extern "C" int fsn_lstm_layer_backward(const float* dh, const float* x, long ldx
     const size_t step = (size_t)N * H;
     FsnGemmA a{};
     FsnGemmC c{};
-    for (int t = T - 1; t >= 0; --t) {
-        FSN_TRY(fsn_launch_bptt_elem(dh + t * step, dh_rec, dc, gates + (size_t)t * N * G, cseq + t * step,
-                                     t ? cseq + (t - 1) * step : cseq, dgates + (size_t)t * N * G, (long)step, H,
-                                     t == T - 1, t == 0, s));
-        if (t > 0) {
-            a = FsnGemmA{};
-            a.kind = 0;
-            a.p0 = dgates + (size_t)t * N * G;
-            a.ld = G;
-            c = FsnGemmC{};
-            c.kind = 3;
-            c.p0 = dh_rec;
-            c.ld = H;
-            c.rows = N;
-            c.cols = H;
-            FSN_TRY(fsn_launch_gemm(a, whhT_p, c, N / 16, H / 16, G / 16, s));
-        }
-    }
+    // one fused launch per step: dh_rec = dgates_{t+1} W_hh, then the cell derivative -> dgates_t
+    for (int t = T - 1; t >= 0; --t)
+        FSN_TRY(fsn_launch_bptt_step(dh + t * step, t + 1 < T ? dgates + (size_t)(t + 1) * N * G : dgates, whhT_p, dc,
+                                     gates + (size_t)t * N * G, cseq + t * step, t ? cseq + (t - 1) * step : cseq,
+                                     dgates + (size_t)t * N * G, N / 16, H, t == T - 1, t == 0, s));
+    (void)dh_rec;
     if (dx) {
         a = FsnGemmA{};
         a.kind = 0;

@@ -137,6 +137,9 @@ int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float
                        void* workspace, hipStream_t s);
 int fsn_launch_colsum(const float* A, long lda, float* out, int cols, long rows, void* workspace, hipStream_t s);
 size_t fsn_colsum_workspace_bytes(int cols, long rows);
+int fsn_launch_bptt_step(const float* dh_out, const float* dgates_next, const float* whhT_p, float* dc,
+                         const float* gates, const float* c_t, const float* c_prev, float* dgates, int row_tiles, int H,
+                         int last, int first, hipStream_t s);
 int fsn_launch_bptt_elem(const float* dh_out, const float* dh_rec, float* dc, const float* gates, const float* c_t,
                          const float* c_prev, float* dgates, long n_elems, int H, int last, int first, hipStream_t s);
 

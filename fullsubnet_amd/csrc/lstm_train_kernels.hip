@@ -41,6 +41,65 @@ __global__ __launch_bounds__(256) void bptt_elem_kernel(const float* __restrict_
     dc[idx] = dct * fg;
 }
 
+// One BPTT step, fused: dh_rec = dgates_{t+1} W_hh for a 16-row x 16-unit block (K = 4H, 4-way
+// split-K over the waves, reduced through LDS in a fixed order) followed by the cell derivative of
+// that block -> dgates_t.  The mirror image of lstm_step_kernel; grid = (H/16, N/16).
+__global__ __launch_bounds__(256) void bptt_step_kernel(const float* __restrict__ dh_out,
+                                                        const float* __restrict__ dgates_next,
+                                                        const float* __restrict__ whhT_p, float* __restrict__ dc,
+                                                        const float* __restrict__ gates,
+                                                        const float* __restrict__ c_t,
+                                                        const float* __restrict__ c_prev,
+                                                        float* __restrict__ dgates, int H, int last, int first) {
+    __shared__ f32x4 red[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int ug = blockIdx.x, rtile = blockIdx.y;
+    const int G = 4 * H, KC = G >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (!last) {
+        const int kc0 = wave * (KC >> 2), kc1 = kc0 + (KC >> 2);
+        const float* ap = dgates_next + ((long)rtile * 16 + lr) * G + 4 * lq;
+        const float* bp = whhT_p + ((long)ug * KC * 64 + lane) * 4;
+#pragma unroll 4
+        for (int kc = kc0; kc < kc1; ++kc) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kc * 16);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bp + (long)kc * 256);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = mfma16(a[j], b[j], acc);
+        }
+        if (wave > 0) red[wave - 1][lane] = acc;
+        __syncthreads();
+    }
+    if (wave != 0) return;
+    if (!last) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const f32x4 r = red[w][lane];
+            acc = f32x4{acc[0] + r[0], acc[1] + r[1], acc[2] + r[2], acc[3] + r[3]};
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long row = (long)rtile * 16 + 4 * lq + i;
+        const int u = ug * 16 + lr;
+        const long idx = row * H + u;
+        const float* gp = gates + row * G + u;
+        const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
+        const float dh = dh_out[idx] + acc[i];
+        const float tc = tanhf(c_t[idx]);
+        const float d_o = dh * tc;
+        const float dct = (last ? 0.f : dc[idx]) + dh * og * (1.f - tc * tc);
+        const float cp = first ? 0.f : c_prev[idx];
+        float* dg = dgates + row * G + u;
+        dg[0] = dct * gg * ig * (1.f - ig);
+        dg[H] = dct * cp * fg * (1.f - fg);
+        dg[2 * H] = dct * ig * (1.f - gg * gg);
+        dg[3 * H] = d_o * og * (1.f - og);
+        dc[idx] = dct * fg;
+    }
+}
+
 // C[M][Nc] (partial, per K split) = sum_k A[k][m] * B[k][n]; A, B row-major over k.
 // 4 waves = 2 (m) x 2 (n); wave tile 4 x 2 MFMA tiles; lane (r = l&15, q = l>>4) feeds
 // A[k0 + 4q + j][m0 + r] / B[k0 + 4q + j][n0 + r] as the j-th MFMA's operands (16 lanes read 64
@@ -177,6 +236,14 @@ int fsn_launch_colsum(const float* A, long lda, float* out, int cols, long rows,
     hipLaunchKernelGGL(reduce_splits_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, part, out, (long)cols, 1, cols,
                        rb);
     return fsn_check_launch("reduce_splits_kernel");
+}
+
+int fsn_launch_bptt_step(const float* dh_out, const float* dgates_next, const float* whhT_p, float* dc,
+                         const float* gates, const float* c_t, const float* c_prev, float* dgates, int row_tiles, int H,
+                         int last, int first, hipStream_t s) {
+    hipLaunchKernelGGL(bptt_step_kernel, dim3(H / 16, row_tiles), dim3(256), 0, s, dh_out, dgates_next, whhT_p, dc, gates,
+                       c_t, c_prev, dgates, H, last, first);
+    return fsn_check_launch("bptt_step_kernel");
 }
 
 int fsn_launch_bptt_elem(const float* dh_out, const float* dh_rec, float* dc, const float* gates, const float* c_t,
