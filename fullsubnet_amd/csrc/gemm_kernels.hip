@@ -347,8 +347,14 @@ int fsn_launch_gemm(const FsnGemmA& a, const float* wp, const FsnGemmC& c, int r
         return launch<0, 1, 4, 8, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s, 1, kOnePerCu);
     // 2-column output layer: HBM-bound on reading the hidden sequence -> many waves in flight
     if (a.kind == 0 && c.kind == 2) return launch<0, 2, 4, 1, 4, 1>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
-    // training-step GEMMs (row-major C): few row tiles per launch -> small workgroup tiles, many of them
-    if (a.kind == 0 && c.kind == 3) return launch<0, 3, 2, 2, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
+    // training-step GEMMs (row-major C).  All-steps GEMMs (dX, output layers): the one-workgroup-per-CU
+    // shape with a 256 x 128 tile (sb hidden 384 = 3 column blocks); per-step ones: few row tiles per
+    // launch -> small workgroup tiles, many of them.
+    if (a.kind == 0 && c.kind == 3) {
+        if (row_tiles >= 2048 && col_tiles >= 4)
+            return launch<0, 3, 8, 4, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s, 1, kOnePerCu);
+        return launch<0, 3, 2, 2, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
+    }
     fsn_set_error("fsn_launch_gemm: unsupported operand kinds A=%d C=%d", a.kind, c.kind);
     return FSN_ERR_ARG;
 }

@@ -100,54 +100,85 @@ __global__ __launch_bounds__(256) void bptt_step_kernel(const float* __restrict_
     }
 }
 
-// C[M][Nc] (partial, per K split) = sum_k A[k][m] * B[k][n]; A, B row-major over k.
-// 4 waves = 2 (m) x 2 (n); wave tile 4 x 2 MFMA tiles; lane (r = l&15, q = l>>4) feeds
-// A[k0 + 4q + j][m0 + r] / B[k0 + 4q + j][n0 + r] as the j-th MFMA's operands (16 lanes read 64
-// contiguous bytes of one k row).
+// C[M][Nc] (partial, per K split) = sum_k A[k][m] * B[k][n]; A, B row-major over k (K % 16 == 0).
+// Same execution shape as the forward GEMM (gemm_kernels.hip): ONE 4-wave workgroup per CU, one
+// wave per SIMD with a large accumulator tile (RTW x CTW MFMA tiles) and a 2-deep register ring of
+// operand chunks whose refills are pinned right behind the MFMAs that free them.  Lane (r = l&15,
+// q = l>>4) feeds A[k0 + 4q + j][m0 + r] / B[k0 + 4q + j][n0 + r] to the j-th MFMA of a 16-deep
+// chunk: 16 lanes read 64 contiguous bytes of one k row, the row base is wave-uniform (SGPR) and
+// the lane part a fixed 32-bit offset.  Out-of-range columns are clamped on load and never stored.
+template <int RTW, int CTW, int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, long lda,
                                                       const float* __restrict__ B, long ldb,
                                                       float* __restrict__ part, int M, int Nc, long K, long k_per_split,
                                                       int m_blocks, int n_blocks) {
-    constexpr int RTW = 4, CTW = 2;
+    constexpr int PF = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int tile = blockIdx.x % (m_blocks * n_blocks), split = blockIdx.x / (m_blocks * n_blocks);
     const int mb = tile / n_blocks, nb = tile % n_blocks;
-    const int m0 = (mb * 2 + wm) * RTW * 16, n0 = (nb * 2 + wn) * CTW * 16;
+    const int m0 = (mb * WM + wm) * RTW * 16, n0 = (nb * WN + wn) * CTW * 16;
     const long k_begin = (long)split * k_per_split;
     long k_end = k_begin + k_per_split;
     k_end = k_end < K ? k_end : K;
+    const int chunks = (int)((k_end - k_begin) >> 4), last = chunks - 1;
+
+    int aoff[RTW], boff[CTW];
+#pragma unroll
+    for (int i = 0; i < RTW; ++i) {
+        const int m = m0 + i * 16 + lr;
+        aoff[i] = 4 * lq * (int)lda + (m < M ? m : M - 1);
+    }
+#pragma unroll
+    for (int i = 0; i < CTW; ++i) {
+        const int n = n0 + i * 16 + lr;
+        boff[i] = 4 * lq * (int)ldb + (n < Nc ? n : Nc - 1);
+    }
+    const float* a0 = A + k_begin * lda;
+    const float* b0 = B + k_begin * ldb;
 
     f32x4 acc[RTW][CTW];
 #pragma unroll
     for (int i = 0; i < RTW; ++i)
 #pragma unroll
         for (int j = 0; j < CTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (long k0 = k_begin; k0 < k_end; k0 += 16) {
-        float a[RTW][4], b[CTW][4];
+
+    float abuf[PF][RTW][4], bbuf[PF][CTW][4];
+    auto fetch = [&](int p, int kc) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const long k = k0 + 4 * lq + j;
-            const bool kv = k < k_end;
+            const float* ar = a0 + ((long)kc * 16 + j) * lda;  // wave-uniform row bases
+            const float* br = b0 + ((long)kc * 16 + j) * ldb;
 #pragma unroll
-            for (int i = 0; i < RTW; ++i) {
-                const int m = m0 + i * 16 + lr;
-                a[i][j] = (kv && m < M) ? A[k * lda + m] : 0.f;
-            }
+            for (int i = 0; i < RTW; ++i) abuf[p][i][j] = ar[aoff[i]];
 #pragma unroll
-            for (int i = 0; i < CTW; ++i) {
-                const int n = n0 + i * 16 + lr;
-                b[i][j] = (kv && n < Nc) ? B[k * ldb + n] : 0.f;
-            }
+            for (int i = 0; i < CTW; ++i) bbuf[p][i][j] = br[boff[i]];
         }
+    };
+    auto consume = [&](int p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int i = 0; i < RTW; ++i)
 #pragma unroll
-                for (int jj = 0; jj < CTW; ++jj) acc[i][jj] = mfma16(a[i][j], b[jj][j], acc[i][jj]);
+                for (int jj = 0; jj < CTW; ++jj) acc[i][jj] = mfma16(abuf[p][i][j], bbuf[p][jj][j], acc[i][jj]);
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) fetch(p, p < last ? p : last);
+    const int k_main = (chunks / PF) * PF;
+    for (int kc0 = 0; kc0 < k_main; kc0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            consume(p);
+            __builtin_amdgcn_sched_barrier(0);
+            const int kn = kc0 + p + PF;
+            fetch(p, kn < last ? kn : last);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
+    if (k_main < chunks) consume(0);  // PF == 2: at most one left-over chunk, already in slot 0
+
     float* out = part + (long)split * M * Nc;
 #pragma unroll
     for (int i = 0; i < RTW; ++i)
@@ -170,6 +201,21 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __re
     C[(i / Nc) * ldc + (i % Nc)] = acc;
 }
 
+// gemm_tn epilogue: sum of the split partials (fixed order) + the K % 16 tail rows the MFMA kernel
+// does not cover; `transposed`: the partials hold C^T ([Nc][M], operands were swapped).
+__global__ void tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, long ldc, int M, int Nc,
+                                 int splits, int transposed, const float* __restrict__ A, long lda,
+                                 const float* __restrict__ B, long ldb, long k_tail0, long K) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)M * Nc) return;
+    const int m = (int)(i / Nc), n = (int)(i % Nc);
+    const long pi = transposed ? (long)n * M + m : i;
+    float acc = 0.f;
+    for (int s = 0; s < splits; ++s) acc += part[(long)s * M * Nc + pi];
+    for (long k = k_tail0; k < K; ++k) acc += A[k * lda + m] * B[k * ldb + n];
+    C[(long)m * ldc + n] = acc;
+}
+
 // partial column sums over blocks of rows: part[rb][c] = sum_{r in block rb} A[r][c]
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ A, long lda,
                                                              float* __restrict__ part, int cols, long rows,
@@ -185,42 +231,80 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 }
 
 struct TnPlan {
-    int m_blocks, n_blocks, splits;
+    int m_blocks, n_blocks, splits, narrow;
     long k_per_split;
 };
+// Workgroup tile 256 x 128 (wave tile 8 x 4, waves 2 x 2) or, for narrow outputs (the K = 2nb+2
+// input projection), 512 x 32 (wave tile 8 x 2, waves 4 x 1).  K is split so that the grid is one
+// workgroup per CU (or as close below it as the tile count allows).
 TnPlan tn_plan(int M, int Nc, long K) {
     TnPlan p;
-    p.m_blocks = (M + 127) / 128;
-    p.n_blocks = (Nc + 63) / 64;
+    p.narrow = Nc <= 32;
+    p.m_blocks = p.narrow ? (M + 511) / 512 : (M + 255) / 256;
+    p.n_blocks = p.narrow ? (Nc + 31) / 32 : (Nc + 127) / 128;
     const long tiles = (long)p.m_blocks * p.n_blocks;
-    long s = (1024 + tiles - 1) / tiles;
-    const long max_s = (K + 255) / 256;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    long s = cus / tiles;
+    const long max_s = (K + 127) / 128;  // at least 8 chunks per split
     s = s < max_s ? s : max_s;
     s = s < 1 ? 1 : s;
     p.k_per_split = ((K + s - 1) / s + 15) / 16 * 16;
     p.splits = (int)((K + p.k_per_split - 1) / p.k_per_split);
     return p;
 }
+constexpr size_t kTnOnePerCu = 96 * 1024;  // LDS reservation (never touched): one workgroup per CU
 constexpr long kColsumRows = 2048;
 
 }  // namespace
 
 size_t fsn_gemm_tn_workspace_bytes(int M, int Nc, long K) {
-    const TnPlan p = tn_plan(M, Nc, K);
-    return (size_t)p.splits * M * Nc * sizeof(float);
+    const bool swap = M <= 32 && Nc > 32;
+    if ((K & ~15L) <= 0) return (size_t)M * Nc * sizeof(float);
+    const TnPlan p = swap ? tn_plan(Nc, M, K & ~15L) : tn_plan(M, Nc, K & ~15L);
+    return (size_t)(p.splits > 0 ? p.splits : 1) * M * Nc * sizeof(float);
 }
 
 int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int Nc, long K,
                        void* workspace, hipStream_t s) {
-    const TnPlan p = tn_plan(M, Nc, K);
+    if (K <= 0 || lda * 16 > 0x7fffffffL || ldb * 16 > 0x7fffffffL) {
+        fsn_set_error("gemm_tn: bad K = %ld or leading dimension", K);
+        return FSN_ERR_ARG;
+    }
+    // a narrow M (the 2-row dW of the sub-band output layer) goes on the narrow side of the tile
+    const bool swap = M <= 32 && Nc > 32;
+    const long K16 = K & ~15L;
     float* part = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.m_blocks * p.n_blocks * p.splits)), dim3(256), 0, s, A, lda, B,
-                       ldb, part, M, Nc, K, p.k_per_split, p.m_blocks, p.n_blocks);
-    FSN_TRY_LAUNCH("gemm_tn_kernel");
+    int splits = 0;
+    if (K16 > 0) {
+        const TnPlan p = swap ? tn_plan(Nc, M, K16) : tn_plan(M, Nc, K16);
+        auto wide = gemm_tn_kernel<8, 4, 2, 2>;
+        auto narrow = gemm_tn_kernel<8, 2, 4, 1>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(wide), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kTnOnePerCu) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(narrow), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kTnOnePerCu) != hipSuccess) {
+                fsn_set_error("gemm_tn: cannot reserve %zu bytes of LDS", kTnOnePerCu);
+                return FSN_ERR_LAUNCH;
+            }
+            attr_set = true;
+        }
+        const dim3 grid((unsigned)(p.m_blocks * p.n_blocks * p.splits));
+        if (swap)
+            hipLaunchKernelGGL(p.narrow ? narrow : wide, grid, dim3(256), kTnOnePerCu, s, B, ldb, A, lda, part, Nc, M,
+                               K16, p.k_per_split, p.m_blocks, p.n_blocks);
+        else
+            hipLaunchKernelGGL(p.narrow ? narrow : wide, grid, dim3(256), kTnOnePerCu, s, A, lda, B, ldb, part, M, Nc,
+                               K16, p.k_per_split, p.m_blocks, p.n_blocks);
+        FSN_TRY_LAUNCH("gemm_tn_kernel");
+        splits = p.splits;
+    }
     const long n = (long)M * Nc;
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, C, ldc, M, Nc,
-                       p.splits);
-    return fsn_check_launch("reduce_splits_kernel");
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, C, ldc, M, Nc, splits,
+                       swap ? 1 : 0, A, lda, B, ldb, K16, K);
+    return fsn_check_launch("tn_reduce_kernel");
 }
 
 size_t fsn_colsum_workspace_bytes(int cols, long rows) {
