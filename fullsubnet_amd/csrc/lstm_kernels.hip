@@ -326,63 +326,82 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_small_kernel(co
 }
 
 // ---------------------------------------------------------------------------------------------
-// One time step for a small batch.  grid = (H/16 unit groups, Npad/16 row tiles), 4 waves = 4-way
-// split-K, reduced through LDS in a fixed order (deterministic).
+// One time step.  grid = (H/16 unit groups, ceil(row tiles / RTS)); a workgroup owns RTS 16-row
+// tiles x one 16-unit group x the four gates; its 4 waves split K four ways (each wave holds the
+// RTS x 4 partial tiles, so one W_hh fragment load feeds RTS MFMAs) and the partials are reduced
+// through LDS in a fixed order (deterministic); wave w < RTS then finishes row tile w.  RTS = 1 for
+// the few-row launches of inference (full-band model, left-over tiles), larger for the training step.
+template <int RTS>
 __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict__ gx,
                                                         const float* __restrict__ whh_p,
                                                         const float* __restrict__ h_prev,
                                                         float* __restrict__ h_out, const float* c_prev,
                                                         float* c, float* __restrict__ gates_out, long gx_rt0,
-                                                        int H, int first) {
-    __shared__ f32x4 red[3][4][64];
+                                                        int row_tiles, int H, int first) {
+    __shared__ f32x4 red[4][RTS][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    const int ug = blockIdx.x, rtile = blockIdx.y;
+    const int ug = blockIdx.x, rtile0 = blockIdx.y * RTS;
     const int KC = H >> 4, CT = 4 * KC;
-    f32x4 acc[4];
+    f32x4 acc[RTS][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < RTS; ++rt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[rt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!first) {
         const int kc0 = wave * (KC >> 2), kc1 = kc0 + (KC >> 2);
-        const float* ap = h_prev + ((long)rtile * 16 + lr) * H + 4 * lq;
-#pragma unroll 4
+        const float* ap[RTS];
+#pragma unroll
+        for (int rt = 0; rt < RTS; ++rt) {
+            int rtile = rtile0 + rt;
+            rtile = rtile < row_tiles ? rtile : row_tiles - 1;
+            ap[rt] = h_prev + ((long)rtile * 16 + lr) * H + 4 * lq;
+        }
+#pragma unroll 2
         for (int kc = kc0; kc < kc1; ++kc) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kc * 16);
-            f32x4 b[4];
+            f32x4 a[RTS], b[4];
+#pragma unroll
+            for (int rt = 0; rt < RTS; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(ap[rt] + kc * 16);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 b[g] = *reinterpret_cast<const f32x4*>(whh_p + (((long)(g * KC + ug) * KC + kc) * 64 + lane) * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = mfma16(a[j], b[g][j], acc[g]);
-        }
-        if (wave > 0) {
+                for (int rt = 0; rt < RTS; ++rt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) red[wave - 1][g][lane] = acc[g];
+                    for (int g = 0; g < 4; ++g) acc[rt][g] = mfma16(a[rt][j], b[g][j], acc[rt][g]);
         }
+#pragma unroll
+        for (int rt = 0; rt < RTS; ++rt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) red[wave][rt][g][lane] = acc[rt][g];
         __syncthreads();
     }
-    if (wave != 0) return;
+    const int rt = wave, rtile = rtile0 + rt;
+    if (rt >= RTS || rtile >= row_tiles) return;
+    f32x4 pre[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (!first) {
+            v = red[0][rt][g][lane];
 #pragma unroll
-            for (int w = 0; w < 3; ++w) {
-                const f32x4 r = red[w][g][lane];
-                acc[g] = f32x4{acc[g][0] + r[0], acc[g][1] + r[1], acc[g][2] + r[2], acc[g][3] + r[3]};
+            for (int w = 1; w < 4; ++w) {
+                const f32x4 r = red[w][rt][g][lane];
+                v = f32x4{v[0] + r[0], v[1] + r[1], v[2] + r[2], v[3] + r[3]};
             }
         }
         const f32x4 x = *reinterpret_cast<const f32x4*>(gx + (((gx_rt0 + rtile) * CT + g * KC + ug) * 64 + lane) * 4);
-        acc[g] = f32x4{acc[g][0] + x[0], acc[g][1] + x[1], acc[g][2] + x[2], acc[g][3] + x[3]};
+        pre[g] = f32x4{v[0] + x[0], v[1] + x[1], v[2] + x[2], v[3] + x[3]};
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const long row = (long)rtile * 16 + 4 * lq + i;
         const long idx = row * H + ug * 16 + lr;
         const float c_old = first ? 0.f : c_prev[idx];
-        const float ig = sigmoid_f(acc[0][i]), fg = sigmoid_f(acc[1][i]);
-        const float gg = tanhf(acc[2][i]), og = sigmoid_f(acc[3][i]);
+        const float ig = sigmoid_f(pre[0][i]), fg = sigmoid_f(pre[1][i]);
+        const float gg = tanhf(pre[2][i]), og = sigmoid_f(pre[3][i]);
         const float cn = fg * c_old + ig * gg;
         c[idx] = cn;
         h_out[idx] = og * tanhf(cn);
@@ -689,7 +708,14 @@ int fsn_launch_lstm_step_train(const float* gx, const float* whh_p, const float*
         fsn_set_error("lstm_step: hidden size %d must be a multiple of 64", H);
         return FSN_ERR_ARG;
     }
-    hipLaunchKernelGGL(lstm_step_kernel, dim3(H / 16, row_tiles), dim3(256), 0, s, gx, whh_p, h_prev, h_out, c_prev,
-                       c_out, gates_out, gx_rt0, H, first);
+    static const int force = getenv("FSN_STEP_RTS") ? atoi(getenv("FSN_STEP_RTS")) : 0;
+    const int rts = force ? force : (row_tiles >= 16 ? 2 : 1);  // measured: 2 is the best at 129 tiles, 4 no better
+#define FSN_STEP_CASE(R)                                                                                         \
+    hipLaunchKernelGGL(lstm_step_kernel<R>, dim3(H / 16, (row_tiles + R - 1) / R), dim3(256), 0, s, gx, whh_p, h_prev, \
+                       h_out, c_prev, c_out, gates_out, gx_rt0, row_tiles, H, first)
+    if (rts == 4) FSN_STEP_CASE(4);
+    else if (rts == 2) FSN_STEP_CASE(2);
+    else FSN_STEP_CASE(1);
+#undef FSN_STEP_CASE
     return fsn_check_launch("lstm_step_kernel");
 }

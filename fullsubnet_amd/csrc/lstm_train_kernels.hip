@@ -11,6 +11,8 @@
 //   dX = dgates W_ih (one GEMM over all steps);  dW_ih = dgates^T X;  dW_hh = dgates_{1..}^T H_{0..T-2};
 //   db = column sums of dgates                                           (gemm_tn_kernel / colsum)
 // First, correctness-first version: one elementwise launch + one small GEMM per step.
+#include <stdlib.h>
+
 #include "fsn_common.h"
 
 namespace {
@@ -41,62 +43,93 @@ __global__ __launch_bounds__(256) void bptt_elem_kernel(const float* __restrict_
     dc[idx] = dct * fg;
 }
 
-// One BPTT step, fused: dh_rec = dgates_{t+1} W_hh for a 16-row x 16-unit block (K = 4H, 4-way
-// split-K over the waves, reduced through LDS in a fixed order) followed by the cell derivative of
-// that block -> dgates_t.  The mirror image of lstm_step_kernel; grid = (H/16, N/16).
+// One BPTT step, fused: dh_rec = dgates_{t+1} W_hh for RTS 16-row tiles x CTS 16-unit groups (K = 4H,
+// 4-way split-K over the waves: one dgates fragment feeds CTS MFMAs, one W_hh^T fragment RTS of them;
+// partials reduced through LDS in a fixed order) followed by the cell derivative of those blocks ->
+// dgates_t.  The mirror image of lstm_step_kernel; grid = (H/16/CTS, ceil(row tiles / RTS)).
+template <int RTS, int CTS>
 __global__ __launch_bounds__(256) void bptt_step_kernel(const float* __restrict__ dh_out,
                                                         const float* __restrict__ dgates_next,
                                                         const float* __restrict__ whhT_p, float* __restrict__ dc,
                                                         const float* __restrict__ gates,
                                                         const float* __restrict__ c_t,
                                                         const float* __restrict__ c_prev,
-                                                        float* __restrict__ dgates, int H, int last, int first) {
-    __shared__ f32x4 red[3][64];
+                                                        float* __restrict__ dgates, int row_tiles, int H, int last,
+                                                        int first) {
+    __shared__ f32x4 red[4][RTS][CTS][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    const int ug = blockIdx.x, rtile = blockIdx.y;
+    const int ug0 = blockIdx.x * CTS, rtile0 = blockIdx.y * RTS;
     const int G = 4 * H, KC = G >> 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (!last) {
-        const int kc0 = wave * (KC >> 2), kc1 = kc0 + (KC >> 2);
-        const float* ap = dgates_next + ((long)rtile * 16 + lr) * G + 4 * lq;
-        const float* bp = whhT_p + ((long)ug * KC * 64 + lane) * 4;
-#pragma unroll 4
-        for (int kc = kc0; kc < kc1; ++kc) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kc * 16);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(bp + (long)kc * 256);
+        f32x4 acc[RTS][CTS];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = mfma16(a[j], b[j], acc);
+        for (int rt = 0; rt < RTS; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CTS; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int kc0 = wave * (KC >> 2), kc1 = kc0 + (KC >> 2);
+        const float* ap[RTS];
+        const float* bp[CTS];
+#pragma unroll
+        for (int rt = 0; rt < RTS; ++rt) {
+            int rtile = rtile0 + rt;
+            rtile = rtile < row_tiles ? rtile : row_tiles - 1;
+            ap[rt] = dgates_next + ((long)rtile * 16 + lr) * G + 4 * lq;
         }
-        if (wave > 0) red[wave - 1][lane] = acc;
+#pragma unroll
+        for (int ct = 0; ct < CTS; ++ct) bp[ct] = whhT_p + ((long)(ug0 + ct) * KC * 64 + lane) * 4;
+#pragma unroll 2
+        for (int kc = kc0; kc < kc1; ++kc) {
+            f32x4 a[RTS], b[CTS];
+#pragma unroll
+            for (int rt = 0; rt < RTS; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(ap[rt] + kc * 16);
+#pragma unroll
+            for (int ct = 0; ct < CTS; ++ct) b[ct] = *reinterpret_cast<const f32x4*>(bp[ct] + (long)kc * 256);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int rt = 0; rt < RTS; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < CTS; ++ct) acc[rt][ct] = mfma16(a[rt][j], b[ct][j], acc[rt][ct]);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RTS; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CTS; ++ct) red[wave][rt][ct][lane] = acc[rt][ct];
         __syncthreads();
     }
-    if (wave != 0) return;
-    if (!last) {
+    for (int tt = wave; tt < RTS * CTS; tt += 4) {
+        const int rt = tt / CTS, ct = tt % CTS;
+        const int rtile = rtile0 + rt;
+        if (rtile >= row_tiles) continue;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!last) {
+            v = red[0][rt][ct][lane];
 #pragma unroll
-        for (int w = 0; w < 3; ++w) {
-            const f32x4 r = red[w][lane];
-            acc = f32x4{acc[0] + r[0], acc[1] + r[1], acc[2] + r[2], acc[3] + r[3]};
+            for (int w = 1; w < 4; ++w) {
+                const f32x4 r = red[w][rt][ct][lane];
+                v = f32x4{v[0] + r[0], v[1] + r[1], v[2] + r[2], v[3] + r[3]};
+            }
         }
-    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const long row = (long)rtile * 16 + 4 * lq + i;
-        const int u = ug * 16 + lr;
-        const long idx = row * H + u;
-        const float* gp = gates + row * G + u;
-        const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
-        const float dh = dh_out[idx] + acc[i];
-        const float tc = tanhf(c_t[idx]);
-        const float d_o = dh * tc;
-        const float dct = (last ? 0.f : dc[idx]) + dh * og * (1.f - tc * tc);
-        const float cp = first ? 0.f : c_prev[idx];
-        float* dg = dgates + row * G + u;
-        dg[0] = dct * gg * ig * (1.f - ig);
-        dg[H] = dct * cp * fg * (1.f - fg);
-        dg[2 * H] = dct * ig * (1.f - gg * gg);
-        dg[3 * H] = d_o * og * (1.f - og);
-        dc[idx] = dct * fg;
+        for (int i = 0; i < 4; ++i) {
+            const long row = (long)rtile * 16 + 4 * lq + i;
+            const int u = (ug0 + ct) * 16 + lr;
+            const long idx = row * H + u;
+            const float* gp = gates + row * G + u;
+            const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
+            const float dh = dh_out[idx] + v[i];
+            const float tc = tanhf(c_t[idx]);
+            const float d_o = dh * tc;
+            const float dct = (last ? 0.f : dc[idx]) + dh * og * (1.f - tc * tc);
+            const float cp = first ? 0.f : c_prev[idx];
+            float* dg = dgates + row * G + u;
+            dg[0] = dct * gg * ig * (1.f - ig);
+            dg[H] = dct * cp * fg * (1.f - fg);
+            dg[2 * H] = dct * ig * (1.f - gg * gg);
+            dg[3 * H] = d_o * og * (1.f - og);
+            dc[idx] = dct * fg;
+        }
     }
 }
 
@@ -325,8 +358,19 @@ int fsn_launch_colsum(const float* A, long lda, float* out, int cols, long rows,
 int fsn_launch_bptt_step(const float* dh_out, const float* dgates_next, const float* whhT_p, float* dc,
                          const float* gates, const float* c_t, const float* c_prev, float* dgates, int row_tiles, int H,
                          int last, int first, hipStream_t s) {
-    hipLaunchKernelGGL(bptt_step_kernel, dim3(H / 16, row_tiles), dim3(256), 0, s, dh_out, dgates_next, whhT_p, dc, gates,
-                       c_t, c_prev, dgates, H, last, first);
+    static const int force = getenv("FSN_BPTT_TILE") ? atoi(getenv("FSN_BPTT_TILE")) : 0;  // e.g. 22 = 2 x 2
+    const int cfg = force ? force : (row_tiles >= 64 && H % 32 == 0 ? 22 : 11);
+#define FSN_BPTT_CASE(R, C)                                                                                        \
+    hipLaunchKernelGGL((bptt_step_kernel<R, C>), dim3(H / 16 / C, (row_tiles + R - 1) / R), dim3(256), 0, s, dh_out, \
+                       dgates_next, whhT_p, dc, gates, c_t, c_prev, dgates, row_tiles, H, last, first)
+    if (cfg == 22) FSN_BPTT_CASE(2, 2);
+    else if (cfg == 42) FSN_BPTT_CASE(4, 2);
+    else if (cfg == 24) FSN_BPTT_CASE(2, 4);
+    else if (cfg == 44) FSN_BPTT_CASE(4, 4);
+    else if (cfg == 21) FSN_BPTT_CASE(2, 1);
+    else if (cfg == 12) FSN_BPTT_CASE(1, 2);
+    else FSN_BPTT_CASE(1, 1);
+#undef FSN_BPTT_CASE
     return fsn_check_launch("bptt_step_kernel");
 }
 
