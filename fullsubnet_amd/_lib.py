@@ -47,6 +47,14 @@ STATE_KEYS = [
 ]
 
 
+class AdamCfg(ctypes.Structure):
+    _fields_ = [("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
+                ("max_norm", ctypes.c_float), ("step", ctypes.c_int)]
+
+
+ADAM_MAX_TENSORS = 32  # FSN_ADAM_MAX_TENSORS
+
+
 class Params(ctypes.Structure):
     _fields_ = [(n, _f32p) for n in PARAM_FIELDS]
 
@@ -86,6 +94,12 @@ SIGNATURES = {
                                       _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "fsn_linear_backward": (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _f32p, _c.c_int, _c.c_int, _c.c_int, _f32p,
                                        _c.c_long, _f32p, _f32p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "fsn_mse_loss_workspace_bytes": (_c.c_size_t, [_c.c_size_t]),
+    "fsn_mse_loss": (_c.c_int, [_f32p, _f32p, _c.c_size_t, _f32p, _f32p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "fsn_clip_adam_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.POINTER(_c.c_size_t)]),
+    "fsn_clip_adam_step": (_c.c_int, [_c.c_int, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_void_p),
+                                      _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
+                                      _c.c_void_p, _f32p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "fsn_profile_enable": (_c.c_int, [_c.c_int]),
     "fsn_profile_num_stages": (_c.c_int, []),
     "fsn_profile_stage_name": (_c.c_char_p, [_c.c_int]),

@@ -1,0 +1,64 @@
+"""Gradient clipping + Adam of the training step on the HIP library.
+
+Mirror of the two calls at recipes/dns_interspeech_2020/fullsubnet/trainer.py:65-69
+(`torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip_grad_norm_value)` then
+`self.optimizer.step()`, optimizer built at train.py:55-59 as `torch.optim.Adam(lr, betas=(beta1, 0.999))`):
+`ClipAdam.step()` runs both in two multi-tensor launches (`fsn_clip_adam_step`).  It subclasses
+`torch.optim.Optimizer`, keeps torch.optim.Adam's state layout (`step`, `exp_avg`, `exp_avg_sq`), so
+`state_dict()` / `load_state_dict()` interoperate with the reference's checkpoints
+(base_trainer.py:134,185 save / restore `optimizer.state_dict()`).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class ClipAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, clip_grad_norm_value=0.0):
+        if lr <= 0 or eps <= 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
+            raise ValueError("ClipAdam: invalid hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, clip_grad_norm_value=clip_grad_norm_value))
+        self.total_norm = None  # device scalar: gradient 2-norm before clipping (of the last group stepped)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _lib.lib()
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            if len(ps) > _lib.ADAM_MAX_TENSORS:
+                raise _lib.FsnError(f"ClipAdam: at most {_lib.ADAM_MAX_TENSORS} tensors per parameter group")
+            step = None
+            for p in ps:
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                k = int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"])
+                if step is not None and k != step:
+                    raise _lib.FsnError("ClipAdam: parameters of one group must share the step count")
+                step = k
+            n = len(ps)
+            arr = ctypes.c_void_p * n
+            P = arr(*[_lib.dev_ptr(p.data, "param").value for p in ps])
+            G = arr(*[_lib.dev_ptr(p.grad, "grad").value for p in ps])
+            M = arr(*[_lib.dev_ptr(self.state[p]["exp_avg"], "exp_avg").value for p in ps])
+            V = arr(*[_lib.dev_ptr(self.state[p]["exp_avg_sq"], "exp_avg_sq").value for p in ps])
+            numel = (ctypes.c_size_t * n)(*[p.numel() for p in ps])
+            dev = ps[0].device
+            cfg = _lib.AdamCfg(group["lr"], group["betas"][0], group["betas"][1], group["eps"],
+                               float(group["clip_grad_norm_value"] or 0.0), step)
+            ws = _lib.workspace(L.fsn_clip_adam_workspace_bytes(n, numel), dev)
+            self.total_norm = torch.empty(1, dtype=torch.float32, device=dev)
+            _lib.check(L.fsn_clip_adam_step(n, P, G, M, V, numel, ctypes.byref(cfg), _lib.dev_ptr(self.total_norm),
+                                            ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_ptr(dev)))
+        return loss

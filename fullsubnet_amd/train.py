@@ -1,12 +1,11 @@
 """Training step of the FullSubNet recipe (recipes/dns_interspeech_2020/fullsubnet/trainer.py:33-76).
 
-First version of SURVEY §8 row A16: the four LSTM layers (99.9 % of the FLOPs of the step,
-forward and backward) run on libfsn_hip.so through ``LstmLayerFunction`` (forward with saved
-activations + back-propagation through time) and the two output layers through ``LinearFunction``;
-the thin glue around them (look-ahead pad, Laplace norms, sub-band input gather, MSE, gradient
-clipping, Adam) is autograd-tracked torch tensor algebra, so every gradient of the reference's graph
-is produced.  Fusing that glue into HIP kernels is the next step of this row and does not change the
-interface.
+SURVEY §8 row A16: the four LSTM layers (99.9 % of the FLOPs of the step, forward and backward) run
+on libfsn_hip.so through ``LstmLayerFunction`` (forward with saved activations + back-propagation
+through time), the two output layers through ``LinearFunction``, the loss through ``mse_loss`` and
+gradient clipping + Adam through ``optim.ClipAdam``; the thin glue between them (look-ahead pad,
+Laplace norms, sub-band input gather) is autograd-tracked torch tensor algebra, so every gradient of
+the reference's graph is produced.
 """
 import torch
 import torch.nn.functional as functional
@@ -14,6 +13,7 @@ import torch.nn.functional as functional
 from . import _lib
 from .acoustics.feature import drop_band, stft
 from .acoustics.mask import build_complex_ideal_ratio_mask
+from .optim import ClipAdam
 
 
 class LstmLayerFunction(torch.autograd.Function):
@@ -233,11 +233,40 @@ def forward_train(model, noisy_mag):
     return mask[:, :, :, model.look_ahead:]
 
 
+class MseLossFunction(torch.autograd.Function):
+    """torch.nn.MSELoss() (audio_zen/loss.py:4) through fsn_mse_loss: the loss and d loss / d input in one pass."""
+
+    @staticmethod
+    def forward(ctx, input, target):
+        L = _lib.lib()
+        if input.shape != target.shape:
+            raise _lib.FsnError(f"mse_loss: shapes differ {tuple(input.shape)} vs {tuple(target.shape)}")
+        x, y = input.contiguous(), target.contiguous()
+        n = x.numel()
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ws = _lib.workspace(L.fsn_mse_loss_workspace_bytes(n), x.device)
+        _lib.check(L.fsn_mse_loss(_lib.dev_ptr(x, "input"), _lib.dev_ptr(y, "target"), n, _lib.dev_ptr(loss),
+                                  _lib.dev_ptr(grad, allow_none=True), ws.data_ptr(), ws.numel(),
+                                  _lib.stream_ptr(x.device)))
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (grad,) = ctx.saved_tensors
+        return grad * dloss, None
+
+
+def mse_loss(input, target):
+    return MseLossFunction.apply(input, target)
+
+
 def train_step(model, optimizer, noisy, clean, n_fft=512, hop_length=256, win_length=512, clip_grad_norm_value=10.0,
                loss_function=None):
     """One iteration of Trainer._train_epoch (fullsubnet/trainer.py:41-71), fp32 (use_amp = false).
     Returns the loss tensor (call .item() to synchronise like the reference does)."""
-    loss_function = loss_function or torch.nn.MSELoss()
+    loss_function = loss_function or (lambda target, pred: mse_loss(pred, target))
     optimizer.zero_grad()
     noisy_mag, _, noisy_real, noisy_imag = stft(noisy, n_fft, hop_length, win_length)
     _, _, clean_real, clean_imag = stft(clean, n_fft, hop_length, win_length)
@@ -247,6 +276,11 @@ def train_step(model, optimizer, noisy, clean, n_fft=512, hop_length=256, win_le
     crm = model(noisy_mag.unsqueeze(1)).permute(0, 2, 3, 1)
     loss = loss_function(cirm, crm)
     loss.backward()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), clip_grad_norm_value)
-    optimizer.step()
+    if isinstance(optimizer, ClipAdam):  # clip + Adam fused (two launches)
+        for group in optimizer.param_groups:
+            group["clip_grad_norm_value"] = clip_grad_norm_value
+        optimizer.step()
+    else:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), clip_grad_norm_value)
+        optimizer.step()
     return loss

@@ -134,6 +134,32 @@ int fsn_linear_backward(const float* dy, long lddy, const float* x, long ldx, co
                         float* dx, long lddx, float* dw, float* db, void* workspace, size_t workspace_bytes,
                         void* stream);
 
+/* ---- training step: loss, gradient clipping and the optimizer ------------------------------- */
+
+/* audio_zen/loss.py:4 (torch.nn.MSELoss(), reduction "mean") as used at fullsubnet/trainer.py:62:
+ * loss[0] = mean((input - target)^2); grad_input (may be NULL) = 2 (input - target) / n, i.e. the
+ * gradient for an upstream gradient of 1.  Deterministic two-pass reduction (fp64 partials). */
+size_t fsn_mse_loss_workspace_bytes(size_t n);
+int fsn_mse_loss(const float* input, const float* target, size_t n, float* loss, float* grad_input,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* fullsubnet/trainer.py:65-69: torch.nn.utils.clip_grad_norm_(parameters, max_norm) followed by
+ * torch.optim.Adam.step() (train.py:55-59: lr, betas, eps 1e-8, no weight decay / amsgrad), fused into
+ * two multi-tensor launches.  The arrays are HOST arrays of n_tensors device pointers / element
+ * counts.  grads are scaled in place by min(1, max_norm / (total_norm + 1e-6)) exactly like
+ * clip_grad_norm_ (max_norm <= 0 disables clipping); total_norm_out (device, may be NULL) receives
+ * the unclipped 2-norm.  `step` is the 1-based count of this update (bias corrections). */
+#define FSN_ADAM_MAX_TENSORS 32
+typedef struct fsn_adam_cfg {
+    float lr, beta1, beta2, eps;
+    float max_norm;
+    int step;
+} fsn_adam_cfg;
+size_t fsn_clip_adam_workspace_bytes(int n_tensors, const size_t* numel);
+int fsn_clip_adam_step(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const size_t* numel, const fsn_adam_cfg* cfg,
+                       float* total_norm_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Per-stage kernel timing of the last fsn_enhance / fsn_fullsubnet_forward call made with
  * profiling enabled (hipEvents on `stream`; forces a stream sync when read).  Stage ids are listed
  * by fsn_profile_stage_name(); used by bench.py for the roofline line.  */

@@ -61,7 +61,8 @@ def test_train_step_vs_reference_and_oracle(fsn, golden_dir):
     model = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=meta["groups"], **MODEL_KW)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
     model = model.cuda().train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    # clip_grad_norm_ + torch.optim.Adam of the reference -> the fused HIP optimizer
+    opt = fsn.ClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
     loss = train_step(model, opt, torch.from_numpy(noisy).cuda(), torch.from_numpy(clean).cuda())
     assert abs(loss.item() - float(z["loss"])) <= 1e-5 * float(z["loss"])
     s = meta["sample"]
@@ -95,3 +96,72 @@ def test_linear_forward_backward(fsn, R, I, O, relu):
     assert (yd.detach().cpu() - yo.detach()).abs().max().item() <= 1e-4
     for a, r in ((xd.grad, xo.grad), (wd.grad, wo.grad), (bd.grad, bo.grad)):
         assert (a.cpu() - r).abs().max().item() <= 1e-4 * max(r.abs().max().item(), 1.0)
+
+
+def test_train_step_torch_optimizer_path(fsn, golden_dir):
+    """The step also works with the reference's own optimizer objects (torch.optim.Adam + clip_grad_norm_)
+    and a user loss, and lands on the same parameters as the fused path."""
+    from fullsubnet_amd.train import train_step
+    params = O.make_params(seed=5)
+    noisy = torch.from_numpy(O.make_noisy(4, 8192, seed=1)).cuda()
+    clean = torch.from_numpy(0.7 * O.make_noisy(4, 8192, seed=2)).cuda()
+    out = []
+    for fused in (False, True):
+        model = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=2, **MODEL_KW)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        model = model.cuda().train()
+        opt = (fsn.ClipAdam if fused else torch.optim.Adam)(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
+        for _ in range(2):
+            loss = train_step(model, opt, noisy, clean, clip_grad_norm_value=0.05,
+                              loss_function=None if fused else torch.nn.MSELoss())
+        out.append((loss.item(), {k: v.detach().clone() for k, v in model.named_parameters()}))
+    assert abs(out[0][0] - out[1][0]) <= 1e-5 * abs(out[0][0])
+    for k in out[0][1]:
+        assert (out[0][1][k] - out[1][1][k]).abs().max().item() <= 2e-5, k
+
+
+@pytest.mark.parametrize("max_norm", [0.0, 0.5, 1e6])
+def test_clip_adam_vs_torch(fsn, max_norm):
+    g = torch.Generator().manual_seed(11)
+    shapes = [(2048, 257), (2048,), (3, 5), (1,), (1536, 384), (4097,)]
+    ref = [torch.randn(*s, generator=g).requires_grad_(True) for s in shapes]
+    dev = [p.detach().clone().cuda().requires_grad_(True) for p in ref]
+    o_ref = torch.optim.Adam(ref, lr=1e-3, betas=(0.9, 0.999))
+    o_dev = fsn.ClipAdam(dev, lr=1e-3, betas=(0.9, 0.999), clip_grad_norm_value=max_norm)
+    for it in range(3):
+        grads = [torch.randn(*s, generator=g) * (0.01 if it == 1 else 1.0) for s in shapes]
+        for p, d, gr in zip(ref, dev, grads):
+            p.grad = gr.clone()
+            d.grad = gr.clone().cuda()
+        norm = torch.nn.utils.clip_grad_norm_(ref, max_norm) if max_norm > 0 else None
+        o_ref.step()
+        o_dev.step()
+        if norm is not None:
+            assert abs(o_dev.total_norm.item() - norm.item()) <= 1e-5 * norm.item()
+        for p, d in zip(ref, dev):
+            assert (d.grad.cpu() - p.grad).abs().max().item() <= 1e-6 * max(p.grad.abs().max().item(), 1.0)
+            assert (d.detach().cpu() - p.detach()).abs().max().item() <= 2e-6
+            st_r, st_d = o_ref.state[p], o_dev.state[d]
+            assert (st_d["exp_avg"].cpu() - st_r["exp_avg"]).abs().max().item() <= 1e-6
+            assert (st_d["exp_avg_sq"].cpu() - st_r["exp_avg_sq"]).abs().max().item() <= 1e-5
+    # state_dict round trip with torch.optim.Adam's layout
+    sd = o_dev.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    o2 = fsn.ClipAdam(dev, lr=1e-3)
+    o2.load_state_dict(sd)
+    assert int(o2.state[dev[0]]["step"]) == 3
+
+
+@pytest.mark.parametrize("shape", [(4, 129, 195, 2), (7,), (3, 4097)])
+def test_mse_loss_vs_torch(fsn, shape):
+    from fullsubnet_amd.train import mse_loss
+    g = torch.Generator().manual_seed(len(shape))
+    x, y = torch.randn(*shape, generator=g), torch.randn(*shape, generator=g)
+    xr = x.clone().requires_grad_(True)
+    lr_ = torch.nn.functional.mse_loss(xr, y)
+    (3.0 * lr_).backward()
+    xd = x.cuda().requires_grad_(True)
+    ld = mse_loss(xd, y.cuda())
+    (3.0 * ld).backward()
+    assert abs(ld.item() - lr_.item()) <= 2e-6 * lr_.item()
+    assert (xd.grad.cpu() - xr.grad).abs().max().item() <= 1e-6 * xr.grad.abs().max().item() + 1e-12

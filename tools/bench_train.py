@@ -17,7 +17,7 @@ model = fullsubnet_amd.Model(num_freqs=257, look_ahead=2, sequence_model="LSTM",
                              norm_type="offline_laplace_norm", num_groups_in_drop_band=2, weight_init=False)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in make_params(seed=3).items()})
 model = model.cuda().train()
-opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+opt = fullsubnet_amd.ClipAdam(model.parameters(), lr=1e-3)
 noisy = torch.from_numpy(make_noisy(B, L, seed=1)).cuda()
 clean = torch.from_numpy(0.7 * make_noisy(B, L, seed=2)).cuda()
 for _ in range(2):
