@@ -285,32 +285,42 @@ static int aux_init() {
 // few left-over row tiles as per-step launches on the auxiliary stream.
 // Main kernel: input projection either precomputed (`gx`, tile (t, i) at t * tiles + i) or built
 // in-kernel from `xin`.  Left-over tiles: projection tiles in `gx_left` at t * left_stride + left_off + i.
-static int run_sb_recurrence(const float* gx, const FsnSbInput* xin, const float* gx_left, long left_stride,
-                             long left_off, const float* whh, float* hseq, float* c_left, const CoreDims& d,
-                             hipStream_t s) {
-    const FsnRecPlan& r = d.rec;
-    if (r.left_tiles > 0) {
+static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* gx_left, long left_stride,
+                          long left_off, const float* whh, float* hseq, float* c_left, int Tp, int Npad, int H,
+                          const FsnRecPlan& r, hipStream_t s) {
+    const bool fork = r.left_tiles > 0 && r.main_wgs > 0;  // no persistent part: the steps run on `s` itself
+    hipStream_t ls = s;
+    if (fork) {
         FSN_TRY(aux_init());
         if (hipEventRecord(g_ev_fork, s) != hipSuccess || hipStreamWaitEvent(g_aux_stream, g_ev_fork, 0) != hipSuccess) {
             fsn_set_error("aux stream fork failed");
             return FSN_ERR_LAUNCH;
         }
+        ls = g_aux_stream;
     }
-    FSN_TRY(fsn_launch_lstm_rec(gx, xin, whh, hseq, d.Tp, d.Npad, d.Hs, r.rt, r.main_wgs, s));
+    if (r.main_wgs > 0) FSN_TRY(fsn_launch_lstm_rec(gx, xin, whh, hseq, Tp, Npad, H, r.rt, r.main_wgs, s));
     if (r.left_tiles > 0) {
         const long main_rows = (long)r.main_wgs * r.rt * 16;
-        for (int t = 0; t < d.Tp; ++t) {
-            float* h_out = hseq + ((size_t)t * d.Npad + main_rows) * d.Hs;
-            const float* h_prev = t ? hseq + ((size_t)(t - 1) * d.Npad + main_rows) * d.Hs : h_out;
+        for (int t = 0; t < Tp; ++t) {
+            float* h_out = hseq + ((size_t)t * Npad + main_rows) * H;
+            const float* h_prev = t ? hseq + ((size_t)(t - 1) * Npad + main_rows) * H : h_out;
             FSN_TRY(fsn_launch_lstm_step(gx_left, whh, h_prev, h_out, c_left, (long)t * left_stride + left_off,
-                                         r.left_tiles, d.Hs, t == 0, g_aux_stream));
+                                         r.left_tiles, H, t == 0, ls));
         }
+    }
+    if (fork) {
         if (hipEventRecord(g_ev_join, g_aux_stream) != hipSuccess || hipStreamWaitEvent(s, g_ev_join, 0) != hipSuccess) {
             fsn_set_error("aux stream join failed");
             return FSN_ERR_LAUNCH;
         }
     }
     return FSN_OK;
+}
+
+static int run_sb_recurrence(const float* gx, const FsnSbInput* xin, const float* gx_left, long left_stride,
+                             long left_off, const float* whh, float* hseq, float* c_left, const CoreDims& d,
+                             hipStream_t s) {
+    return run_recurrence(gx, xin, gx_left, left_stride, left_off, whh, hseq, c_left, d.Tp, d.Npad, d.Hs, d.rec, s);
 }
 
 static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float* magT, const CoreDims& d,
@@ -662,7 +672,30 @@ extern "C" size_t fsn_lstm_layer_fwd_workspace_bytes(int T, int N, int I, int H)
     cv.take<float>((size_t)4 * H * H);
     cv.take<float>((size_t)4 * H);
     cv.take<float>((size_t)T * N * 4 * H);
+    cv.take<float>((size_t)N * H);  // cell state of the step kernels (inference mode)
     return fsn_round_up_sz(cv.off, 256);
+}
+
+// Row split of a stand-alone layer in inference mode: the persistent kernel (built for H = 384) takes
+// whole rounds of 16 RT-row tiles on all CUs, everything else goes step by step.
+static FsnRecPlan layer_plan(int N, int H) {
+    FsnRecPlan p{};
+    p.tiles = N / 16;
+    p.npad = N;
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus < 1) cus = 256;
+    if (H != 384 || p.tiles < cus / 4) {
+        p.left_tiles = p.tiles;
+    } else if (p.tiles <= cus) {
+        p.rt = 1;
+        p.main_wgs = p.tiles;
+    } else {
+        p.rt = p.tiles / cus < 5 ? p.tiles / cus : 5;
+        p.main_wgs = cus;
+        p.left_tiles = p.tiles - cus * p.rt;
+    }
+    return p;
 }
 
 extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_ih, const float* w_hh,
@@ -670,8 +703,8 @@ extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_i
                                       void* save, size_t save_bytes, void* workspace, size_t workspace_bytes,
                                       void* stream) {
     FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
-    FSN_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && hseq && save && workspace, "NULL pointer argument");
-    if (save_bytes < fsn_lstm_layer_save_bytes(T, N, H) ||
+    FSN_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && hseq && workspace, "NULL pointer argument");
+    if ((save && save_bytes < fsn_lstm_layer_save_bytes(T, N, H)) ||
         workspace_bytes < fsn_lstm_layer_fwd_workspace_bytes(T, N, I, H)) {
         fsn_set_error("lstm layer forward: save / workspace buffer too small");
         return FSN_ERR_WORKSPACE;
@@ -683,6 +716,7 @@ extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_i
     float* whh_p = cv.take<float>((size_t)4 * H * H);
     float* bias = cv.take<float>((size_t)4 * H);
     float* gx = cv.take<float>((size_t)T * N * 4 * H);
+    float* c_state = cv.take<float>((size_t)N * H);
     float* gates = static_cast<float*>(save);
     float* cseq = gates + (size_t)T * N * 4 * H;
     FSN_TRY(fsn_launch_pack(w_ih, wih_p, 4 * H, I, 4 * H, Ipad, s));
@@ -697,6 +731,12 @@ extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_i
     c.p0 = gx;
     c.bias = bias;
     FSN_TRY(fsn_launch_gemm(a, wih_p, c, T * (N / 16), 4 * H / 16, Ipad / 16, s));
+    if (!save) {  // inference: nothing kept but the hidden sequence
+        const FsnRecPlan plan = layer_plan(N, H);
+        const long main_tiles = (long)plan.main_wgs * plan.rt;
+        return run_recurrence(gx, nullptr, gx, plan.tiles, main_tiles, whh_p, hseq, c_state + main_tiles * 16 * H, T, N,
+                              H, plan, s);
+    }
     const size_t step = (size_t)N * H;
     for (int t = 0; t < T; ++t)
         FSN_TRY(fsn_launch_lstm_step_train(gx, whh_p, t ? hseq + (t - 1) * step : hseq, hseq + t * step,

@@ -11,27 +11,7 @@ import torch.nn as nn
 
 from . import _lib
 from .acoustics.feature import drop_band
-
-
-class SequenceModel(nn.Module):
-    """Parameter container with the names of audio_zen/model/module/sequence_model.py:26-104
-    (``sequence_model.weight_ih_l0`` ..., ``fc_output_layer.weight``)."""
-
-    def __init__(self, input_size, output_size, hidden_size, num_layers, bidirectional,
-                 sequence_model="LSTM", output_activate_function="Tanh"):
-        super().__init__()
-        if sequence_model != "LSTM":
-            raise NotImplementedError("libfsn_hip implements the LSTM branch (sequence_model.py:51-58); GRU is next")
-        if bidirectional:
-            raise NotImplementedError("unidirectional only (every FullSubNet TOML)")
-        self.sequence_model = nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers,
-                                      batch_first=True, bidirectional=False)
-        self.fc_output_layer = nn.Linear(hidden_size, output_size)
-        self.output_activate_function = output_activate_function
-        self.output_size = output_size
-
-    def forward(self, x):  # pragma: no cover - the fused path in Model.forward is the product
-        raise RuntimeError("SequenceModel is a parameter container; call Model.forward")
+from .sequence_model import SequenceModel
 
 
 class Model(nn.Module):

@@ -1,0 +1,166 @@
+"""``SequenceModel`` of audio_zen/model/module/sequence_model.py:26-125 on libfsn_hip.so.
+
+Same constructor, same parameter names (``sequence_model.weight_ih_l{k}`` ..., ``fc_output_layer.*``),
+same ``forward(x [B, F, T]) -> [B, O, T]``.  The ``nn.LSTM`` / ``nn.Linear`` members only hold the
+parameters; every layer runs through the C ABI:
+
+* inference (no autograd): ``fsn_lstm_layer_forward(save = NULL)`` per layer + ``fsn_linear_forward``;
+* training: ``LstmLayerFunction`` / ``LinearFunction`` (fullsubnet_amd/train.py: forward with saved
+  activations + back-propagation through time).
+
+Hidden sizes that are not a multiple of 64 (Fast FullSubNet's 257) are run zero-padded: a unit whose
+weights and biases are all zero keeps h = c = 0 at every step, so the padding is exact.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def pad_lstm_weights(w_ih, w_hh, b_ih, b_hh, in_pad):
+    """nn.LSTM layer tensors ([4H, I], [4H, H], [4H], [4H]) -> the same layer with H padded to a
+    multiple of 64 and I padded to ``in_pad`` columns (gate blocks stay contiguous).  Plain torch
+    ops, so gradients flow back to the unpadded parameters when autograd is recording."""
+    H, I = w_hh.shape[1], w_ih.shape[1]
+    Hp = _round_up(H, 64)
+    if Hp == H and in_pad == I:
+        return w_ih, w_hh, b_ih, b_hh
+    dev = w_ih.device
+    wi = torch.zeros((4, Hp, in_pad), dtype=torch.float32, device=dev)
+    wi[:, :H, :I] = w_ih.reshape(4, H, I)
+    wh = torch.zeros((4, Hp, Hp), dtype=torch.float32, device=dev)
+    wh[:, :H, :H] = w_hh.reshape(4, H, H)
+    bi = torch.zeros((4, Hp), dtype=torch.float32, device=dev)
+    bi[:, :H] = b_ih.reshape(4, H)
+    bh = torch.zeros((4, Hp), dtype=torch.float32, device=dev)
+    bh[:, :H] = b_hh.reshape(4, H)
+    return wi.reshape(4 * Hp, in_pad), wh.reshape(4 * Hp, Hp), bi.reshape(-1), bh.reshape(-1)
+
+
+def lstm_layer_infer(x, w_ih, w_hh, b_ih, b_hh):
+    """One LSTM layer, inference mode.  x [T, N, ldx] time-major, contiguous, N % 16 == 0, columns
+    beyond I = w_ih.shape[1] zero; H = w_hh.shape[1] a multiple of 64.  Returns hseq [T, N, H]."""
+    L = _lib.lib()
+    T, N, ldx = x.shape
+    I, H = w_ih.shape[1], w_hh.shape[1]
+    hseq = torch.empty((T, N, H), dtype=torch.float32, device=x.device)
+    ws = _lib.workspace(L.fsn_lstm_layer_fwd_workspace_bytes(T, N, I, H), x.device)
+    _lib.check(L.fsn_lstm_layer_forward(
+        _lib.dev_ptr(x, "x"), ldx, _lib.dev_ptr(w_ih, "w_ih"), _lib.dev_ptr(w_hh, "w_hh"), _lib.dev_ptr(b_ih, "b_ih"),
+        _lib.dev_ptr(b_hh, "b_hh"), T, N, I, H, _lib.dev_ptr(hseq), None, 0, ws.data_ptr(), ws.numel(),
+        _lib.stream_ptr(x.device)))
+    return hseq
+
+
+def linear_infer(x2, w, b, relu):
+    """x2 [R, ldx] (columns beyond I = w.shape[1] zero, ldx % 16 == 0) -> [R, O] (+ ReLU)."""
+    L = _lib.lib()
+    R, ldx = x2.shape
+    O, I = w.shape
+    y = torch.empty((R, O), dtype=torch.float32, device=x2.device)
+    ws = _lib.workspace(L.fsn_linear_workspace_bytes(R, I, O), x2.device)
+    _lib.check(L.fsn_linear_forward(_lib.dev_ptr(x2, "x"), ldx, _lib.dev_ptr(w, "w"), _lib.dev_ptr(b, "b"), R, I, O,
+                                    1 if relu else 0, _lib.dev_ptr(y), ws.data_ptr(), ws.numel(),
+                                    _lib.stream_ptr(x2.device)))
+    return y
+
+
+class SequenceModel(nn.Module):
+    def __init__(self, input_size, output_size, hidden_size, num_layers, bidirectional, sequence_model="GRU",
+                 output_activate_function="Tanh"):
+        super().__init__()
+        if sequence_model == "LSTM":
+            if bidirectional:
+                raise NotImplementedError("libfsn_hip: unidirectional only (every FullSubNet TOML)")
+            self.sequence_model = nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers,
+                                          batch_first=True, bidirectional=False)
+        elif sequence_model == "GRU":
+            raise NotImplementedError("libfsn_hip implements the LSTM branch (sequence_model.py:51-58); GRU is next")
+        else:
+            raise NotImplementedError(f"Not implemented {sequence_model}")
+        if int(output_size):
+            self.fc_output_layer = nn.Linear(hidden_size, output_size)
+        if output_activate_function:
+            acts = {"Tanh": nn.Tanh, "ReLU": nn.ReLU, "ReLU6": nn.ReLU6, "LeakyReLU": nn.LeakyReLU, "PReLU": nn.PReLU}
+            if output_activate_function not in acts:
+                raise NotImplementedError(f"Not implemented activation function {output_activate_function}")
+            self.activate_function = acts[output_activate_function]()
+        self.output_activate_function = output_activate_function
+        self.output_size = output_size
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.num_layers = num_layers
+        self._padded = None
+        self._padded_key = None
+
+    # ---- inference weights, padded once per parameter version --------------------------------
+    def _layer_tensors(self, k):
+        m = self.sequence_model
+        return (getattr(m, f"weight_ih_l{k}"), getattr(m, f"weight_hh_l{k}"), getattr(m, f"bias_ih_l{k}"),
+                getattr(m, f"bias_hh_l{k}"))
+
+    def _inference_weights(self):
+        ps = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+        if self._padded is None or key != self._padded_key:
+            Hp = _round_up(self.hidden_size, 64)
+            layers = []
+            with torch.no_grad():
+                for k in range(self.num_layers):
+                    in_pad = self.input_size if k == 0 else Hp
+                    layers.append(tuple(t.detach().contiguous()
+                                        for t in pad_lstm_weights(*self._layer_tensors(k), in_pad)))
+                fc = None
+                if self.output_size:
+                    w = torch.zeros((self.output_size, Hp), dtype=torch.float32, device=ps[0].device)
+                    w[:, :self.hidden_size] = self.fc_output_layer.weight.detach()
+                    fc = (w, self.fc_output_layer.bias.detach().contiguous())
+            self._padded, self._padded_key = (layers, fc), key
+        return self._padded
+
+    def forward(self, x):
+        """x [B, F, T] -> [B, O, T] (O = hidden_size when there is no output layer)."""
+        assert x.dim() == 3, f"The shape of input is {x.shape}."
+        if not x.is_cuda:
+            raise _lib.FsnError("SequenceModel: input must live on a ROCm device; this path has no CPU implementation")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self._forward_train(x)
+        B, F, T = x.shape
+        H, Hp = self.hidden_size, _round_up(self.hidden_size, 64)
+        Np, Ip = _round_up(B, 16), _round_up(F, 16)
+        layers, fc = self._inference_weights()
+        h = torch.zeros((T, Np, Ip), dtype=torch.float32, device=x.device)
+        h[:, :B, :F] = x.permute(2, 0, 1)
+        for w_ih, w_hh, b_ih, b_hh in layers:
+            h = lstm_layer_infer(h, w_ih, w_hh, b_ih, b_hh)
+        relu = self.output_activate_function == "ReLU"
+        if fc is not None:
+            o = linear_infer(h.reshape(T * Np, Hp), fc[0], fc[1], relu).reshape(T, Np, self.output_size)
+            o = o[:, :B]
+        else:
+            o = h[:, :B, :H]
+            relu = False
+        if self.output_activate_function and not relu:
+            o = self.activate_function(o)
+        return o.permute(1, 2, 0)
+
+    def _forward_train(self, x):
+        from .train import LinearFunction, LstmLayerFunction
+        H, Hp = self.hidden_size, _round_up(self.hidden_size, 64)
+        h = x.permute(2, 0, 1)  # [T, B, F]
+        for k in range(self.num_layers):
+            in_pad = self.input_size if k == 0 else Hp
+            h = LstmLayerFunction.apply(h, *pad_lstm_weights(*self._layer_tensors(k), in_pad))
+        h = h[..., :H]
+        relu = self.output_activate_function == "ReLU"
+        if self.output_size:
+            o = LinearFunction.apply(h, self.fc_output_layer.weight, self.fc_output_layer.bias, relu)
+        else:
+            o, relu = h, False
+        if self.output_activate_function and not relu:
+            o = self.activate_function(o)
+        return o.permute(1, 2, 0)

@@ -109,8 +109,11 @@ int fsn_enhance(const fsn_fullsubnet_cfg* cfg, const void* packed, const float* 
 /* audio_zen/model/module/sequence_model.py:52-58 (nn.LSTM, one layer, batch_first, h0 = c0 = 0) as
  * used under autograd by fullsubnet/trainer.py:56-63.  Time-major rows: x [T][N][ldx] (columns
  * I..ldx-1 zero, ldx >= round_up(I,16)), hseq [T][N][H]; w_ih [4H][I], w_hh [4H][H], b_* [4H] in the
- * reference's layout.  N % 16 == 0, H % 64 == 0.  `save` keeps the activated gates and the cell
- * sequence for the backward pass. */
+ * reference's layout.  N % 16 == 0, H % 64 == 0 (a smaller hidden size is run zero-padded: units
+ * with all-zero weights and biases stay at h = c = 0, exactly).  `save` keeps the activated gates and
+ * the cell sequence for the backward pass; save == NULL is inference mode (SequenceModel.forward under
+ * no_grad, sequence_model.py:106-125): nothing but hseq is kept and, for H = 384, the rows run on the
+ * persistent recurrent kernel of the sub-band model. */
 size_t fsn_lstm_layer_save_bytes(int T, int N, int H);
 size_t fsn_lstm_layer_fwd_workspace_bytes(int T, int N, int I, int H);
 int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,

@@ -1,0 +1,99 @@
+"""Golden vectors for the sibling model families, produced by running the REFERENCE models on CPU in
+the authoring container.  Run from the repo root:   python tests/golden/make_golden_family.py
+
+  recipes/dns_interspeech_2020/fast_fullsubnet/model.py:Model      (BASELINE config 4)
+  recipes/dns_interspeech_2020/fullband_baseline/model.py:Model    (BASELINE config 1)
+
+fast_fullsubnet/model.py imports torchaudio (:3) and torchinfo (:5), which are neither in the
+reference tree nor in this image.  torchinfo is only used by the module's __main__ block; of
+torchaudio only ``transforms.MelScale`` is used (:57-63).  Both are stubbed here; the MelScale stub
+applies the filterbank of oracle.model_family_oracle.melscale_fbanks (a restatement of torchaudio's
+documented HTK filterbank - parity unpinned at that boundary) and the filterbank itself is stored in
+the fixture, so that everything downstream of the mel matmul is pinned on the reference's own code.
+"""
+import os
+import sys
+import types
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import model_family_oracle as MF  # noqa: E402
+from oracle.fullsubnet_oracle import make_noisy  # noqa: E402
+
+
+class _MelScale(torch.nn.Module):
+    def __init__(self, n_mels, sample_rate, f_min, f_max, n_stft):
+        super().__init__()
+        fb = MF.melscale_fbanks(n_stft, f_min, f_max, n_mels, sample_rate).astype(np.float32)
+        self.register_buffer("fb", torch.from_numpy(fb))
+
+    def forward(self, specgram):
+        return torch.matmul(specgram.transpose(-1, -2), self.fb).transpose(-1, -2)
+
+
+ta = types.ModuleType("torchaudio")
+ta.transforms = types.ModuleType("torchaudio.transforms")
+ta.transforms.MelScale = _MelScale
+ti = types.ModuleType("torchinfo")
+ti.summary = lambda *a, **k: None
+sys.modules.update({"torchaudio": ta, "torchaudio.transforms": ta.transforms, "torchinfo": ti})
+sys.modules.setdefault("librosa", types.ModuleType("librosa"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, "/root/reference/recipes/dns_interspeech_2020")
+
+from audio_zen.acoustics.feature import stft  # noqa: E402
+from fast_fullsubnet.model import Model as FastModel  # noqa: E402
+from fullband_baseline.model import Model as FullbandModel  # noqa: E402
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes())
+
+
+def save(name, out, meta):
+    out["meta"] = np.array(repr(meta))
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    c = out["crm"]
+    print(f"{name}: crm {c.shape} range [{c.min():.3f}, {c.max():.3f}]")
+
+
+def fast_case(name, batch, length, seed_w=0, seed_x=77, gain=2.0):
+    params = MF.make_fast_params(seed=seed_w, gain=gain)
+    noisy = make_noisy(batch, length, seed=seed_x)
+    m = FastModel(look_ahead=2, shrink_size=2, sequence_model="LSTM", num_mels=64, encoder_input_size=257,
+                  bottleneck_hidden_size=384, bottleneck_num_layers=2, noisy_input_num_neighbors=5,
+                  encoder_output_num_neighbors=0, norm_type="offline_laplace_norm", weight_init=False).eval()
+    sd = {k: torch.from_numpy(v) for k, v in params.items()}
+    sd["mel_scale.fb"] = m.mel_scale.fb.clone()
+    m.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        mag, _, _, _ = stft(torch.from_numpy(noisy), 512, 256, 512)
+        crm = m(mag.unsqueeze(1))
+    meta = dict(batch=batch, length=length, seed_w=seed_w, seed_x=seed_x, gain=gain, torch=torch.__version__,
+                crc_noisy=crc(noisy), crc_w=crc(np.concatenate([v.ravel() for v in params.values()])))
+    save(name, dict(mag=mag.numpy(), crm=crm.numpy(), fb=m.mel_scale.fb.numpy()), meta)
+
+
+def fullband_case(name, batch, length, seed_w=0, seed_x=78, gain=1.5):
+    params = MF.make_fullband_params(seed=seed_w, gain=gain)
+    noisy = make_noisy(batch, length, seed=seed_x)
+    m = FullbandModel(num_freqs=257, hidden_size=512, sequence_model="LSTM", output_activate_function=None,
+                      look_ahead=2, norm_type="offline_laplace_norm", weight_init=False).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    with torch.no_grad():
+        mag, _, _, _ = stft(torch.from_numpy(noisy), 512, 256, 512)
+        crm = m(mag.unsqueeze(1))
+    meta = dict(batch=batch, length=length, seed_w=seed_w, seed_x=seed_x, gain=gain, torch=torch.__version__,
+                crc_noisy=crc(noisy), crc_w=crc(np.concatenate([v.ravel() for v in params.values()])))
+    save(name, dict(mag=mag.numpy(), crm=crm.numpy()), meta)
+
+
+if __name__ == "__main__":
+    fast_case("fast_b2_even", 2, 8192)          # T' = 35: 34 frames after the first -> all blocks full
+    fast_case("fast_b3_odd", 3, 8192 - 256, seed_w=1)  # T' = 34: 33 frames -> last block of 1
+    fullband_case("fullband_b2", 2, 8192)

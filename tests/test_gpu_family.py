@@ -1,0 +1,124 @@
+"""Parity of the SequenceModel block and the sibling model families (Fast FullSubNet, full-band
+baseline) on the HIP kernels against the reference's golden vectors and the CPU oracle.
+Needs a real MI355X:  python -m pytest tests -m gpu"""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_family_oracle as MF
+
+pytestmark = pytest.mark.gpu
+
+FAST_KW = dict(look_ahead=2, shrink_size=2, sequence_model="LSTM", num_mels=64, encoder_input_size=257,
+               bottleneck_hidden_size=384, bottleneck_num_layers=2, noisy_input_num_neighbors=5,
+               encoder_output_num_neighbors=0, norm_type="offline_laplace_norm", weight_init=False)
+
+
+@pytest.fixture(scope="module")
+def fsn():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu tests need a ROCm device")
+    import fullsubnet_amd
+    fullsubnet_amd._lib.lib()  # raises if libfsn_hip.so is missing: no fallback
+    return fullsubnet_amd
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    return z, ast.literal_eval(str(z["meta"]))
+
+
+@pytest.mark.parametrize("name", ["fast_b2_even", "fast_b3_odd"])
+def test_fast_fullsubnet_vs_reference(fsn, golden_dir, name):
+    from fullsubnet_amd.fast_fullsubnet import Model
+    z, meta = load(golden_dir, name)
+    params = MF.make_fast_params(seed=meta["seed_w"], gain=meta["gain"])
+    m = Model(**FAST_KW)
+    sd = {k: torch.from_numpy(v) for k, v in params.items()}
+    sd["mel_scale.fb"] = torch.from_numpy(z["fb"])
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        crm = m(torch.from_numpy(z["mag"]).cuda().unsqueeze(1)).cpu().numpy()
+    assert crm.shape == z["crm"].shape
+    assert np.abs(crm - z["crm"]).max() <= 1e-4  # north-star tolerance on the (compressed) mask
+
+
+def test_fast_fullsubnet_batch64_rows_on_persistent_kernel(fsn):
+    """B = 64 -> 4096 bottleneck rows = 256 tiles: the rows run on the persistent recurrent kernel
+    (not the step kernels of the small golden cases); checked against the oracle on 2 utterances."""
+    from fullsubnet_amd.fast_fullsubnet import Model
+    params = MF.make_fast_params(seed=5)
+    m = Model(**FAST_KW)
+    sd = {k: torch.from_numpy(v) for k, v in params.items()}
+    sd["mel_scale.fb"] = m.mel_scale.fb.clone()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    rng = np.random.default_rng(0)
+    mag = np.abs(rng.standard_normal((64, 1, 257, 21))).astype(np.float32)
+    mag[1] *= 3.0
+    with torch.no_grad():
+        crm = m(torch.from_numpy(mag).cuda()).cpu().numpy()
+    params["mel_scale.fb"] = m.mel_scale.fb.cpu().numpy()
+    want = MF.fast_fullsubnet_forward(mag[[1, 63]], params)
+    assert np.abs(crm[[1, 63]] - want).max() <= 1e-4
+
+
+def test_fullband_baseline_vs_reference(fsn, golden_dir):
+    from fullsubnet_amd.fullband_baseline import Model
+    z, meta = load(golden_dir, "fullband_b2")
+    params = MF.make_fullband_params(seed=meta["seed_w"], gain=meta["gain"])
+    m = Model(num_freqs=257, hidden_size=512, sequence_model="LSTM", output_activate_function=None, look_ahead=2,
+              norm_type="offline_laplace_norm", weight_init=False)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        crm = m(torch.from_numpy(z["mag"]).cuda().unsqueeze(1)).cpu().numpy()
+    assert np.abs(crm - z["crm"]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("I,H,O,layers,act,B,T", [
+    (64, 384, 0, 1, None, 3, 9),       # no output layer (Fast FullSubNet encoder.0)
+    (40, 257, 64, 1, "ReLU", 5, 7),    # hidden size padded 257 -> 320 (encoder.1)
+    (12, 384, 1, 2, "ReLU", 130, 6),   # bottleneck shape, rows not a multiple of 16
+    (20, 64, 8, 2, "Tanh", 2, 5),
+])
+def test_sequence_model_inference_and_training_vs_torch(fsn, I, H, O, layers, act, B, T):
+    """SequenceModel.forward under no_grad (inference kernels) and under autograd (forward with saves +
+    BPTT) against ATen's nn.LSTM / nn.Linear on CPU with the same parameters."""
+    from fullsubnet_amd.sequence_model import SequenceModel
+    torch.manual_seed(I + H)
+    m = SequenceModel(I, O, H, layers, False, "LSTM", act)
+    ref_lstm = torch.nn.LSTM(I, H, layers, batch_first=True)
+    ref_lstm.load_state_dict(m.sequence_model.state_dict())
+    x = torch.randn(B, I, T)
+    dy = torch.randn(B, O or H, T)
+
+    def ref_forward(xin):
+        o, _ = ref_lstm(xin.permute(0, 2, 1))
+        if O:
+            o = torch.nn.functional.linear(o, m.fc_output_layer.weight.detach().cpu(), m.fc_output_layer.bias.detach().cpu())
+        if act:
+            o = {"ReLU": torch.relu, "Tanh": torch.tanh}[act](o)
+        return o.permute(0, 2, 1)
+
+    xr = x.clone().requires_grad_(True)
+    yr = ref_forward(xr)
+    (yr * dy).sum().backward()
+    md = m.cuda()
+    with torch.no_grad():
+        yi = md(x.cuda())
+    assert (yi.cpu() - yr.detach()).abs().max().item() <= 2e-5
+    xd = x.cuda().requires_grad_(True)
+    yt = md(xd)
+    (yt * dy.cuda()).sum().backward()
+    assert (yt.detach().cpu() - yr.detach()).abs().max().item() <= 2e-5
+    assert (xd.grad.cpu() - xr.grad).abs().max().item() <= 1e-4 * max(xr.grad.abs().max().item(), 1.0)
+    for k in range(layers):
+        for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            g = getattr(md.sequence_model, f"{n}_l{k}").grad.cpu()
+            r = getattr(ref_lstm, f"{n}_l{k}").grad
+            assert (g - r).abs().max().item() <= 1e-4 * max(r.abs().max().item(), 1.0), (n, k)

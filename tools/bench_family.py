@@ -1,0 +1,57 @@
+"""Time the sibling model families on one MI355X (BASELINE configs 1 and 4):
+python tools/bench_family.py [fast|fullband] [batch]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fullsubnet_amd  # noqa: E402
+from fullsubnet_amd import decompress_cIRM, istft, stft  # noqa: E402
+from oracle.fullsubnet_oracle import make_noisy  # noqa: E402
+from oracle.model_family_oracle import make_fast_params, make_fullband_params  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "fast"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else (256 if which == "fast" else 1)
+L = 48000
+if which == "fast":
+    from fullsubnet_amd.fast_fullsubnet import Model
+    model = Model(look_ahead=2, shrink_size=2, sequence_model="LSTM", num_mels=64, encoder_input_size=257,
+                  bottleneck_hidden_size=384, bottleneck_num_layers=2, noisy_input_num_neighbors=5,
+                  encoder_output_num_neighbors=0)
+    sd = {k: torch.from_numpy(v) for k, v in make_fast_params(seed=3).items()}
+    sd["mel_scale.fb"] = model.mel_scale.fb.clone()
+    mmac = 62.9e6  # MAC / frame / utterance
+else:
+    from fullsubnet_amd.fullband_baseline import Model
+    model = Model(num_freqs=257, hidden_size=512, sequence_model="LSTM", output_activate_function=None, look_ahead=2,
+                  weight_init=False)
+    sd = {k: torch.from_numpy(v) for k, v in make_fullband_params(seed=3).items()}
+    mmac = 6.032384e6
+model.load_state_dict(sd, strict=True)
+model = model.cuda().eval()
+noisy = torch.from_numpy(make_noisy(min(B, 8), L, seed=1)).cuda().repeat((B + 7) // 8, 1)[:B].contiguous()
+
+
+@torch.no_grad()
+def enhance(y):
+    mag, _, re, im = stft(y, 512, 256, 512)
+    crm = decompress_cIRM(model(mag.unsqueeze(1)).permute(0, 2, 3, 1))
+    er = crm[..., 0] * re - crm[..., 1] * im
+    ei = crm[..., 1] * re + crm[..., 0] * im
+    return istft((er, ei), 512, 256, 512, length=y.size(-1), input_type="real_imag")
+
+
+for _ in range(2):
+    out = enhance(noisy)
+torch.cuda.synchronize()
+K = 5
+t0 = time.perf_counter()
+for _ in range(K):
+    out = enhance(noisy)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / K
+T = 1 + L // 256
+print(f"{which} B={B}: {dt * 1e3:.2f} ms / batch, {B * T / dt:.0f} frames/s ({B * T / dt / 62.5:.0f} x real time), "
+      f"~{2 * mmac * B * (T + 2) / dt / 1e12:.1f} TFLOP/s, finite={bool(torch.isfinite(out).all())}")
