@@ -538,31 +538,45 @@ extern "C" int fsn_fullsubnet_forward(const fsn_fullsubnet_cfg* cfg, const void*
 }
 
 // ---- STFT / iSTFT boundary -------------------------------------------------------------------
+static bool fast_fft(int n_fft, int hop) { return n_fft == 512 && hop == 256; }
+
+// fsn_enhance's fused path is built for the FullSubNet recipe's transform only
 static int check_fft(int n_fft, int hop, int win_length) {
     FSN_REQUIRE(n_fft == 512 && hop == 256 && win_length == 512,
-                "only n_fft = win_length = 512, hop = 256 is built (got %d/%d/%d)", n_fft, win_length, hop);
+                "fsn_enhance: only n_fft = win_length = 512, hop = 256 is built (got %d/%d/%d)", n_fft, win_length, hop);
+    return FSN_OK;
+}
+
+// fsn_stft / fsn_istft: 512 / 256 on the radix-8 kernels, any other even size / hop on the direct DFT
+static int check_fft_generic(int n_fft, int hop, int win_length) {
+    FSN_REQUIRE(win_length == n_fft, "win_length %d != n_fft %d is not built", win_length, n_fft);
+    FSN_REQUIRE(n_fft >= 16 && n_fft <= 4096 && n_fft % 2 == 0, "n_fft %d: need an even size in [16, 4096]", n_fft);
+    FSN_REQUIRE(hop >= 1 && hop <= n_fft, "hop %d out of range for n_fft %d", hop, n_fft);
     return FSN_OK;
 }
 
 extern "C" int fsn_stft(const float* y, int B, int L, int n_fft, int hop, int win_length, const float* window,
                         float* real, float* imag, float* mag, void* stream) {
-    FSN_TRY(check_fft(n_fft, hop, win_length));
+    FSN_TRY(check_fft_generic(n_fft, hop, win_length));
     FSN_REQUIRE(y && window, "NULL pointer argument");
     FSN_REQUIRE(B >= 1 && L > n_fft / 2, "need B >= 1 and L > n_fft/2 (reflect padding), got B=%d L=%d", B, L);
     const int T = 1 + L / hop, F = n_fft / 2 + 1;
+    FSN_REQUIRE((long)B * T <= 0x7fffffffL, "too many frames");
+    if (!fast_fft(n_fft, hop))
+        return fsn_launch_dft_stft(y, B, L, window, real, imag, mag, T, n_fft, hop, static_cast<hipStream_t>(stream));
     return fsn_launch_stft(y, B, L, window, real, imag, mag, T, T, F, fsn_fpad(F), false,
                            static_cast<hipStream_t>(stream));
 }
 
 extern "C" size_t fsn_istft_workspace_bytes(int B, int T, int n_fft) {
-    if (B < 1 || T < 1 || n_fft != 512) return 0;
+    if (B < 1 || T < 1 || n_fft < 16 || n_fft > 4096 || n_fft % 2) return 0;
     return fsn_round_up_sz((size_t)B * T * n_fft * sizeof(float), 256);
 }
 
 extern "C" int fsn_istft(const float* real, const float* imag, int B, int T, int n_fft, int hop, int win_length,
                          const float* window, int length, float* y, void* workspace, size_t workspace_bytes,
                          void* stream) {
-    FSN_TRY(check_fft(n_fft, hop, win_length));
+    FSN_TRY(check_fft_generic(n_fft, hop, win_length));
     FSN_TRY(check_bt(B, T));
     FSN_REQUIRE(real && imag && window && y && workspace, "NULL pointer argument");
     FSN_REQUIRE(length >= 1, "length %d < 1", length);
@@ -573,6 +587,7 @@ extern "C" int fsn_istft(const float* real, const float* imag, int B, int T, int
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int F = n_fft / 2 + 1;
     float* wf = static_cast<float*>(workspace);
+    if (!fast_fft(n_fft, hop)) return fsn_launch_dft_istft(real, imag, window, wf, y, B, T, n_fft, hop, length, s);
     FSN_TRY(fsn_launch_mask_irfft(real, imag, nullptr, nullptr, B, T, F, fsn_fpad(F), false, window, wf, s));
     return fsn_launch_ola(wf, window, B, T, length, y, s);
 }

@@ -88,6 +88,12 @@ int fsn_launch_mask_irfft(const float* re, const float* im, const float* crm_r, 
 int fsn_launch_ola(const float* wframes, const float* window, int B, int T, int length, float* y,
                    hipStream_t s);
 
+// dft_kernels.hip (any even n_fft / any hop: direct fp64 DFT; reference layout [B][F][T] only)
+int fsn_launch_dft_stft(const float* y, int B, int L, const float* window, float* re, float* im, float* mag, int T,
+                        int N, int hop, hipStream_t s);
+int fsn_launch_dft_istft(const float* re, const float* im, const float* window, float* wframes, float* y, int B, int T,
+                         int N, int hop, int length, hipStream_t s);
+
 // elementwise_kernels.hip
 int fsn_launch_decompress(const float* in, float* out, size_t n, hipStream_t s);
 int fsn_launch_compress(const float* in, float* out, size_t n, hipStream_t s);

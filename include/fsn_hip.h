@@ -38,7 +38,10 @@ int fsn_version(void);
 /* feature.py:9-50  stft(y, n_fft, hop, win) -> (mag, phase, real, imag); phase is never used on
  * the path (inferencer.py:132 discards it) and is not produced.
  * y [B, L];  window [n_fft] (torch.hann_window(n_fft), feature.py:38);  real/imag/mag [B, F, T],
- * any of the three may be NULL.  Supported: n_fft == win_length == 512, hop == 256. */
+ * any of the three may be NULL.  win_length == n_fft; n_fft = 512 / hop = 256 (every FullSubNet TOML)
+ * runs on the radix-8 kernels, any other even n_fft in [16, 4096] / hop in [1, n_fft] (e.g. 512 / 128
+ * and 960 / 480 of improved_fullsubnet/model.py:550-557) on a direct fp64 DFT.  Either way the
+ * result is the correctly rounded transform of the fp32 windowed frame. */
 int fsn_stft(const float* y, int B, int L, int n_fft, int hop, int win_length, const float* window,
              float* real, float* imag, float* mag, void* stream);
 

@@ -46,7 +46,7 @@ sys.modules.setdefault("librosa", types.ModuleType("librosa"))
 sys.path.insert(0, "/root/reference")
 sys.path.insert(0, "/root/reference/recipes/dns_interspeech_2020")
 
-from audio_zen.acoustics.feature import stft  # noqa: E402
+from audio_zen.acoustics.feature import istft, stft  # noqa: E402
 from fast_fullsubnet.model import Model as FastModel  # noqa: E402
 from fullband_baseline.model import Model as FullbandModel  # noqa: E402
 
@@ -93,7 +93,28 @@ def fullband_case(name, batch, length, seed_w=0, seed_x=78, gain=1.5):
     save(name, dict(mag=mag.numpy(), crm=crm.numpy()), meta)
 
 
+STFT_SHAPES = [(512, 128), (960, 480), (400, 100), (1536, 384)]  # (n_fft, hop); 512/256 is in make_golden.py
+
+
+def stft_generic_case(name, batch=2, length=5000, seed_x=79):
+    """audio_zen/acoustics/feature.py stft / istft (= torch.stft / torch.istft) at the transform shapes
+    of the other recipes (improved_fullsubnet/model.py:603-620) and two odd ones."""
+    noisy = make_noisy(batch, length, seed=seed_x)
+    out = {}
+    for n_fft, hop in STFT_SHAPES:
+        mag, _, re, im = stft(torch.from_numpy(noisy), n_fft, hop, n_fft)
+        back = istft((re * 0.5, im * 0.5 + re * 0.25), n_fft, hop, n_fft, length=length, input_type="real_imag")
+        k = f"{n_fft}_{hop}"
+        out.update({f"win/{k}": torch.hann_window(n_fft).numpy(), f"re/{k}": re.numpy(), f"im/{k}": im.numpy(),
+                    f"mag/{k}": mag.numpy(), f"back/{k}": back.numpy()})
+    out["meta"] = np.array(repr(dict(batch=batch, length=length, seed_x=seed_x, torch=torch.__version__,
+                                     crc_noisy=crc(noisy))))
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(name, {k: v.shape for k, v in out.items() if k.startswith("re/")})
+
+
 if __name__ == "__main__":
+    stft_generic_case("stft_generic")
     fast_case("fast_b2_even", 2, 8192)          # T' = 35: 34 frames after the first -> all blocks full
     fast_case("fast_b3_odd", 3, 8192 - 256, seed_w=1)  # T' = 34: 33 frames -> last block of 1
     fullband_case("fullband_b2", 2, 8192)

@@ -102,3 +102,25 @@ def test_family_state_dict_keys():
     assert set(fullband.state_dict().keys()) == set(MF.make_fullband_params().keys())
     with pytest.raises(Exception):
         fullband(torch.zeros(1, 1, 257, 8))  # CPU tensor: no CPU implementation of this path
+
+
+STFT_SHAPES = [(512, 128), (960, 480), (400, 100), (1536, 384)]
+
+
+@pytest.mark.parametrize("n_fft,hop", STFT_SHAPES)
+def test_oracle_stft_istft_other_transform_shapes(golden_dir, n_fft, hop):
+    """The oracle's STFT / iSTFT at the transform shapes of the sibling recipes, against torch.stft /
+    torch.istft as called by the reference's feature.py (golden stft_generic.npz)."""
+    z, meta = load(golden_dir, "stft_generic")
+    noisy = O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_x"])
+    assert crc(noisy) == meta["crc_noisy"]
+    k = f"{n_fft}_{hop}"
+    mag, _, re, im = O.stft(noisy, n_fft, hop, n_fft, window=z["win/" + k])
+    assert re.shape == z["re/" + k].shape
+    scale = np.abs(z["mag/" + k]).max()
+    assert np.abs(re - z["re/" + k]).max() <= 2e-6 * scale and np.abs(im - z["im/" + k]).max() <= 2e-6 * scale
+    assert np.abs(mag - z["mag/" + k]).max() <= 2e-6 * scale
+    r, i = z["re/" + k], z["im/" + k]
+    back = O.istft(r * np.float32(0.5), i * np.float32(0.5) + r * np.float32(0.25), n_fft, hop, n_fft,
+                   length=meta["length"], window=z["win/" + k])
+    assert np.abs(back - z["back/" + k]).max() <= 3e-6 * np.abs(z["back/" + k]).max()

@@ -122,3 +122,33 @@ def test_sequence_model_inference_and_training_vs_torch(fsn, I, H, O, layers, ac
             g = getattr(md.sequence_model, f"{n}_l{k}").grad.cpu()
             r = getattr(ref_lstm, f"{n}_l{k}").grad
             assert (g - r).abs().max().item() <= 1e-4 * max(r.abs().max().item(), 1.0), (n, k)
+
+
+@pytest.mark.parametrize("n_fft,hop", [(512, 128), (960, 480), (400, 100), (1536, 384)])
+def test_stft_istft_other_transform_shapes(fsn, golden_dir, n_fft, hop):
+    """fsn_stft / fsn_istft on the direct-DFT path (every shape but 512 / 256) against the oracle
+    (correctly rounded transform) and torch.stft / torch.istft as the reference calls them."""
+    from oracle import fullsubnet_oracle as O
+    z, meta = load(golden_dir, "stft_generic")
+    noisy = O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_x"])
+    k = f"{n_fft}_{hop}"
+    win = z["win/" + k]
+    mag, _, re, im = fsn.stft(torch.from_numpy(noisy).cuda(), n_fft, hop, n_fft)
+    re, im, mag = re.cpu().numpy(), im.cpu().numpy(), mag.cpu().numpy()
+    omag, _, ore, oim = O.stft(noisy, n_fft, hop, n_fft, window=win)
+    fmax = np.maximum(np.abs(ore), np.abs(oim)).max(axis=1, keepdims=True)
+    ulp = np.spacing(fmax.astype(np.float32))
+    assert (np.abs(re - ore) / ulp).max() <= 1.0 and (np.abs(im - oim) / ulp).max() <= 1.0
+    scale = np.abs(z["mag/" + k]).max()
+    assert np.abs(re - z["re/" + k]).max() <= 2e-6 * scale and np.abs(im - z["im/" + k]).max() <= 2e-6 * scale
+    assert np.abs(mag - z["mag/" + k]).max() <= 2e-6 * scale
+    r, i = z["re/" + k], z["im/" + k]
+    fr = torch.from_numpy(r * np.float32(0.5)).cuda()
+    fi = torch.from_numpy(i * np.float32(0.5) + r * np.float32(0.25)).cuda()
+    back = fsn.istft((fr, fi), n_fft, hop, n_fft, length=meta["length"], input_type="real_imag").cpu().numpy()
+    assert np.abs(back - z["back/" + k]).max() <= 3e-6 * np.abs(z["back/" + k]).max()
+    # round trip
+    y = torch.from_numpy(noisy).cuda()
+    _, _, re2, im2 = fsn.stft(y, n_fft, hop, n_fft)
+    rt = fsn.istft((re2, im2), n_fft, hop, n_fft, length=meta["length"], input_type="real_imag")
+    assert (rt - y).abs().max().item() <= 2e-6
