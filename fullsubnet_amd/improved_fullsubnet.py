@@ -1,0 +1,198 @@
+"""Drop-in ``Model`` for recipes/dns_interspeech_2020/improved_fullsubnet/model.py (BASELINE config 5):
+waveform in / waveform out, magnitude compression ``|X| ** fdrc``, a full-band LSTM on the first
+F - 1 bins and *banded* sub-band LSTMs (finer-to-coarser: section i moves over its band in steps of
+``num_center_freqs[i]`` bins and predicts that many complex mask bins per unit), the mask applied
+without decompression.
+
+STFT / iSTFT (any n_fft / hop: 512 / 128 at 16 kHz, 960 / 480 at 48 kHz) and every LSTM / Linear block
+run on libfsn_hip.so; power law, strided unfold, concat, norms and the complex product are
+tensor-algebra glue.  Parameter names follow the reference (``fb_model.*``, ``sb_model.sb_models.{i}.*``).
+"""
+import torch
+import torch.nn as nn
+from torch.nn import functional
+
+from .acoustics.feature import istft, stft
+from .sequence_model import SequenceModel as _SequenceModel
+
+EPSILON = float(torch.finfo(torch.float32).eps)
+
+
+class SequenceModel(_SequenceModel):
+    """improved_fullsubnet/model.py:25-121 (time-major nn.LSTM there; same parameters and results)."""
+
+    def __init__(self, input_size, output_size, hidden_size, num_layers, bidirectional, sequence_model="GRU",
+                 output_activate_function="Tanh", num_groups=4, mogrify_steps=5, dropout=0.0):
+        if dropout:
+            raise NotImplementedError("dropout between LSTM layers is not built (every use in the reference is 0)")
+        super().__init__(input_size, output_size, hidden_size, num_layers, bidirectional, sequence_model,
+                         output_activate_function)
+
+
+class BaseModel(nn.Module):
+    """improved_fullsubnet/model.py:124-216: note the eps of the offline norms is fp32 epsilon here."""
+
+    @staticmethod
+    def offline_laplace_norm(input, return_mu=False):
+        mu = torch.mean(input, dim=list(range(1, input.dim())), keepdim=True)
+        normed = input / (mu + EPSILON)
+        return (normed, mu) if return_mu else normed
+
+    @staticmethod
+    def cumulative_laplace_norm(input):
+        B, C, F, T = input.size()
+        x = input.reshape(B * C, F, T)
+        cum = torch.cumsum(torch.sum(x, dim=1), dim=-1)
+        count = torch.arange(F, F * T + 1, F, dtype=x.dtype, device=x.device).reshape(1, T)
+        mean = (cum / count).reshape(B * C, 1, T)
+        return (x / (mean + EPSILON)).reshape(B, C, F, T)
+
+    @staticmethod
+    def offline_gaussian_norm(input):
+        dims = list(range(1, input.dim()))
+        mu = torch.mean(input, dim=dims, keepdim=True)
+        std = torch.std(input, dim=dims, keepdim=True)
+        return (input - mu) / (std + EPSILON)
+
+    def norm_wrapper(self, norm_type: str):
+        norms = {"offline_laplace_norm": self.offline_laplace_norm,
+                 "cumulative_laplace_norm": self.cumulative_laplace_norm,
+                 "offline_gaussian_norm": self.offline_gaussian_norm}
+        if norm_type not in norms:
+            raise NotImplementedError("You must set up a type of Norm. "
+                                      "e.g. offline_laplace_norm, cumulative_laplace_norm, forgetting_norm, etc.")
+        return norms[norm_type]
+
+
+class SubBandSequenceWrapper(SequenceModel):
+    """model.py:219-245: [B, N, 1, F_sub, T] -> [B, 2, N * centre, T]."""
+
+    def forward(self, subband_input):
+        batch_size, num_subband_units, num_channels, num_subband_freqs, num_frames = subband_input.shape
+        assert num_channels == 1
+        output = subband_input.reshape(batch_size * num_subband_units, num_subband_freqs, num_frames)
+        output = super().forward(output)
+        output = output.reshape(batch_size, num_subband_units, 2, -1, num_frames)
+        output = output.permute(0, 2, 1, 3, 4).contiguous()
+        return output.reshape(batch_size, 2, -1, num_frames)
+
+
+class SubbandModel(BaseModel):
+    def __init__(self, freq_cutoffs, sb_num_center_freqs, sb_num_neighbor_freqs, fb_num_center_freqs,
+                 fb_num_neighbor_freqs, sequence_model, hidden_size, activate_function=False,
+                 norm_type="offline_laplace_norm"):
+        super().__init__()
+        if len(freq_cutoffs) < 1:
+            raise ValueError("the banded sub-band model needs at least two sections (one cut-off)")
+        self.sb_models = nn.ModuleList([
+            SubBandSequenceWrapper(input_size=(sc + sn * 2) + (fc + fn * 2), output_size=sc * 2,
+                                   hidden_size=hidden_size, num_layers=2, sequence_model=sequence_model,
+                                   bidirectional=False, output_activate_function=activate_function)
+            for sc, sn, fc, fn in zip(sb_num_center_freqs, sb_num_neighbor_freqs, fb_num_center_freqs,
+                                      fb_num_neighbor_freqs)])
+        self.freq_cutoffs = freq_cutoffs
+        self.sb_num_center_freqs = sb_num_center_freqs
+        self.sb_num_neighbor_freqs = sb_num_neighbor_freqs
+        self.fb_num_center_freqs = fb_num_center_freqs
+        self.fb_num_neighbor_freqs = fb_num_neighbor_freqs
+        self.norm = self.norm_wrapper(norm_type)
+
+    @staticmethod
+    def _freq_unfold(input, lower_cutoff_freq=0, upper_cutoff_freq=20, num_center_freqs=1, num_neighbor_freqs=15):
+        """model.py:315-400: unit u of the band [lower, upper) sees the bins
+        lower + u c - n ... lower + (u + 1) c + n - 1 (c centre bins, n neighbours on each side), reflected
+        at the two ends of the spectrum: [B, 1, F, T] -> [B, N = (upper - lower) / c, 1, c + 2 n, T]."""
+        batch_size, num_channels, num_freqs, num_frames = input.shape
+        assert num_channels == 1, "Only mono audio is supported."
+        if (upper_cutoff_freq - lower_cutoff_freq) % num_center_freqs != 0:
+            raise ValueError(
+                f"The number of center frequencies should be divisible by the subband freqency interval. "
+                f"Got {num_center_freqs=}, {upper_cutoff_freq=}, and {lower_cutoff_freq=}. "
+                f"The subband freqency interval is {upper_cutoff_freq-lower_cutoff_freq}.")
+        n, c = num_neighbor_freqs, num_center_freqs
+        if lower_cutoff_freq != 0 and lower_cutoff_freq - n < 0:
+            raise ValueError("an inner band needs num_neighbor_freqs bins below its lower cut-off")
+        if upper_cutoff_freq != num_freqs and lower_cutoff_freq != 0 and upper_cutoff_freq + n > num_freqs:
+            raise ValueError("an inner band needs num_neighbor_freqs bins above its upper cut-off")
+        units = (upper_cutoff_freq - lower_cutoff_freq) // c
+        dev = input.device
+        idx = (lower_cutoff_freq - n + c * torch.arange(units, device=dev).reshape(units, 1)
+               + torch.arange(c + 2 * n, device=dev).reshape(1, -1))
+        idx = idx.abs()
+        idx = torch.where(idx > num_freqs - 1, 2 * (num_freqs - 1) - idx, idx)
+        out = input[:, 0][:, idx, :]  # [B, N, c + 2n, T]
+        return out.unsqueeze(2).contiguous()
+
+    def forward(self, noisy_input, fb_output):
+        batch_size, num_channels, num_freqs, num_frames = noisy_input.size()
+        assert num_channels == 1, "Only mono audio is supported."
+        last = len(self.sb_models) - 1
+
+        def section(sb_idx):
+            lower = 0 if sb_idx == 0 else self.freq_cutoffs[sb_idx - 1]
+            upper = num_freqs if sb_idx == last else self.freq_cutoffs[sb_idx]
+            noisy_subband = self._freq_unfold(noisy_input, lower, upper, self.sb_num_center_freqs[sb_idx],
+                                              self.sb_num_neighbor_freqs[sb_idx])
+            fb_subband = self._freq_unfold(fb_output, lower, upper, self.fb_num_center_freqs[sb_idx],
+                                           self.fb_num_neighbor_freqs[sb_idx])
+            sb_model_input = self.norm(torch.cat([noisy_subband, fb_subband], dim=-2))
+            return self.sb_models[sb_idx](sb_model_input)
+
+        if torch.is_grad_enabled() or not noisy_input.is_cuda:
+            return torch.cat([section(i) for i in range(last + 1)], dim=-2)
+        # inference: the sections are independent and each one is a chain of small dependent launches
+        # (B x units rows only), so they run concurrently on one HIP stream each and join on the caller's
+        main = torch.cuda.current_stream(noisy_input.device)
+        if getattr(self, "_streams", None) is None or len(self._streams) != last + 1:
+            self._streams = [torch.cuda.Stream(noisy_input.device) for _ in range(last + 1)]
+        subband_output = []
+        for sb_idx, st in enumerate(self._streams):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                out = section(sb_idx)
+            out.record_stream(main)
+            subband_output.append(out)
+        for st in self._streams:
+            main.wait_stream(st)
+        return torch.cat(subband_output, dim=-2)
+
+
+class Model(BaseModel):
+    def __init__(self, n_fft=512, hop_length=128, win_length=512, fdrc=0.5, num_freqs=257, freq_cutoffs=[20, 80],
+                 sb_num_center_freqs=[1, 4, 8], sb_num_neighbor_freqs=[15, 15, 15], fb_num_center_freqs=[1, 4, 8],
+                 fb_num_neighbor_freqs=[15, 15, 15], fb_hidden_size=512, sb_hidden_size=384, sequence_model="LSTM",
+                 fb_output_activate_function=False, sb_output_activate_function=False,
+                 norm_type="offline_laplace_norm"):
+        super().__init__()
+        self.n_fft = n_fft
+        self.hop_length = hop_length
+        self.win_length = win_length
+        self.fdrc = fdrc
+        self.fb_model = SequenceModel(input_size=num_freqs - 1, output_size=num_freqs - 1, hidden_size=fb_hidden_size,
+                                      num_layers=2, bidirectional=False, sequence_model=sequence_model,
+                                      output_activate_function=fb_output_activate_function)
+        self.sb_model = SubbandModel(freq_cutoffs=freq_cutoffs, sb_num_center_freqs=sb_num_center_freqs,
+                                     sb_num_neighbor_freqs=sb_num_neighbor_freqs,
+                                     fb_num_center_freqs=fb_num_center_freqs,
+                                     fb_num_neighbor_freqs=fb_num_neighbor_freqs, hidden_size=sb_hidden_size,
+                                     sequence_model=sequence_model, activate_function=sb_output_activate_function)
+        self.norm = self.norm_wrapper(norm_type)
+
+    def forward(self, y):
+        """model.py:541-591: y [B, L] or [B, 1, L] -> enhanced [B, 1, L]."""
+        ndim = y.dim()
+        assert ndim in (2, 3), "Input must be 2D (B, T) or 3D tensor (B, 1, T)"
+        if ndim == 3:
+            assert y.size(1) == 1, "Input must be 2D (B, T) or 3D tensor (B, 1, T)"
+            y = y.squeeze(1)
+        mag, _, real, imag = stft(y, self.n_fft, self.hop_length, self.win_length)  # [B, F, T] each
+        noisy_mag = mag.unsqueeze(1) ** self.fdrc
+        noisy_mag = noisy_mag[..., :-1, :]  # the last bin is left out (model.py:566) and masked with 0 below
+        B, _, Fm, T = noisy_mag.shape
+        fb_output = self.fb_model(self.norm(noisy_mag).reshape(B, Fm, T)).reshape(B, 1, Fm, T)
+        cRM = self.sb_model(noisy_mag, fb_output)  # [B, 2, F - 1, T]
+        cRM = functional.pad(cRM, (0, 0, 0, 1), mode="constant", value=0.0)
+        # model.py:576-577: the mask multiplies real and imaginary parts separately (no complex product)
+        enhanced = istft((cRM[:, 0] * real, cRM[:, 1] * imag), self.n_fft, self.hop_length, self.win_length,
+                         length=y.size(-1), input_type="real_imag")
+        return enhanced.unsqueeze(1)

@@ -140,3 +140,83 @@ def make_fullband_params(seed=0, gain=2.0, out_gain=8.0, num_freqs=257, hidden=5
     for k in ("fullband_model.fc_output_layer.weight", "fullband_model.fc_output_layer.bias"):
         p[k] = p[k] * out_gain
     return {k: (v * gain).astype(dtype) for k, v in p.items()}
+
+
+# --------------------------------------------------------------------------- #
+# Improved FullSubNet     recipes/dns_interspeech_2020/improved_fullsubnet/model.py
+# --------------------------------------------------------------------------- #
+IMPROVED_16K = dict(n_fft=512, hop_length=128, win_length=512, fdrc=0.5, num_freqs=257, freq_cutoffs=[20, 80],
+                    sb_num_center_freqs=[1, 4, 8], sb_num_neighbor_freqs=[15, 15, 15], fb_num_center_freqs=[1, 4, 8],
+                    fb_num_neighbor_freqs=[15, 15, 15], fb_hidden_size=512, sb_hidden_size=384)
+# the reference's own 48 kHz example (model.py:603-620)
+IMPROVED_48K = dict(n_fft=960, hop_length=480, win_length=960, fdrc=0.5, num_freqs=481, freq_cutoffs=[20, 120, 240],
+                    sb_num_center_freqs=[1, 4, 20, 60], sb_num_neighbor_freqs=[15, 15, 15, 15],
+                    fb_num_center_freqs=[1, 4, 20, 60], fb_num_neighbor_freqs=[15, 15, 15, 15], fb_hidden_size=512,
+                    sb_hidden_size=384)
+
+
+def _norm_eps32(x, dtype=np.float32):
+    """improved_fullsubnet/model.py:128-150: utterance-level mean, eps = fp32 epsilon (not 1e-5)."""
+    x = np.asarray(x, dtype=dtype)
+    mu = x.mean(axis=tuple(range(1, x.ndim)), keepdims=True, dtype=np.float64).astype(dtype)
+    return (x / (mu + dtype(O.EPSILON))).astype(dtype)
+
+
+def banded_unfold(x, lower, upper, centers, neighbors):
+    """improved_fullsubnet/model.py:315-400.  x [B, 1, F, T] -> [B, N, 1, centers + 2 neighbors, T]: a window of
+    that width slides over the band in steps of ``centers`` bins; bins beyond either end of the spectrum are
+    mirrored (no edge repeat)."""
+    B, C, F, T = x.shape
+    assert C == 1 and (upper - lower) % centers == 0
+    units = (upper - lower) // centers
+    out = np.empty((B, units, 1, centers + 2 * neighbors, T), dtype=x.dtype)
+    for u in range(units):
+        for k in range(centers + 2 * neighbors):
+            j = lower + u * centers + k - neighbors
+            j = -j if j < 0 else j
+            j = 2 * (F - 1) - j if j > F - 1 else j
+            out[:, u, 0, k, :] = x[:, 0, j, :]
+    return out
+
+
+def improved_fullsubnet_forward(y, params, cfg, window, dtype=np.float32):
+    """improved_fullsubnet/model.py:541-591: y [B, L] -> enhanced [B, 1, L]."""
+    y = np.asarray(y, dtype=dtype)
+    n_fft, hop = cfg["n_fft"], cfg["hop_length"]
+    mag, _, re, im = O.stft(y, n_fft, hop, cfg["win_length"], window=window, dtype=dtype)
+    x = (mag[:, None].astype(dtype) ** dtype(cfg["fdrc"])).astype(dtype)[:, :, :-1, :]
+    B, _, F, T = x.shape
+    fb = sequence_block(_norm_eps32(x, dtype).reshape(B, F, T), params, "fb_model", 2, True, None, dtype)
+    fb = fb.reshape(B, 1, F, T)
+    cuts = list(cfg["freq_cutoffs"])
+    sections = []
+    for i in range(len(cuts) + 1):
+        lower = 0 if i == 0 else cuts[i - 1]
+        upper = F if i == len(cuts) else cuts[i]
+        a = banded_unfold(x, lower, upper, cfg["sb_num_center_freqs"][i], cfg["sb_num_neighbor_freqs"][i])
+        b = banded_unfold(fb, lower, upper, cfg["fb_num_center_freqs"][i], cfg["fb_num_neighbor_freqs"][i])
+        s = _norm_eps32(np.concatenate([a, b], axis=-2), dtype)
+        N, K = s.shape[1], s.shape[3]
+        o = sequence_block(s.reshape(B * N, K, T), params, f"sb_model.sb_models.{i}", 2, True, None, dtype)
+        o = o.reshape(B, N, 2, -1, T).transpose(0, 2, 1, 3, 4).reshape(B, 2, -1, T)
+        sections.append(o)
+    crm = np.concatenate(sections, axis=-2)
+    crm = np.pad(crm, [(0, 0), (0, 0), (0, 1), (0, 0)])
+    out = O.istft((crm[:, 0] * re).astype(dtype), (crm[:, 1] * im).astype(dtype), n_fft, hop, cfg["win_length"],
+                  length=y.shape[-1], window=window, dtype=dtype)
+    return out[:, None, :]
+
+
+def make_improved_params(cfg, seed=0, gain=1.5, mask_gain=6.0, dtype=np.float32):
+    """Random weights with the reference state_dict names of improved_fullsubnet.model.Model."""
+    rng = np.random.default_rng(seed)
+    p = {}
+    F = cfg["num_freqs"] - 1
+    _block_params(rng, p, "fb_model", F, cfg["fb_hidden_size"], F, 2)
+    for i, (sc, sn, fc, fn) in enumerate(zip(cfg["sb_num_center_freqs"], cfg["sb_num_neighbor_freqs"],
+                                             cfg["fb_num_center_freqs"], cfg["fb_num_neighbor_freqs"])):
+        pre = f"sb_model.sb_models.{i}"
+        _block_params(rng, p, pre, (sc + 2 * sn) + (fc + 2 * fn), cfg["sb_hidden_size"], 2 * sc, 2)
+        for k in (f"{pre}.fc_output_layer.weight", f"{pre}.fc_output_layer.bias"):
+            p[k] = p[k] * mask_gain
+    return {k: (v * gain).astype(dtype) for k, v in p.items()}

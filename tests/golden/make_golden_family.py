@@ -49,6 +49,7 @@ sys.path.insert(0, "/root/reference/recipes/dns_interspeech_2020")
 from audio_zen.acoustics.feature import istft, stft  # noqa: E402
 from fast_fullsubnet.model import Model as FastModel  # noqa: E402
 from fullband_baseline.model import Model as FullbandModel  # noqa: E402
+from improved_fullsubnet.model import Model as ImprovedModel  # noqa: E402
 
 
 def crc(a):
@@ -93,6 +94,22 @@ def fullband_case(name, batch, length, seed_w=0, seed_x=78, gain=1.5):
     save(name, dict(mag=mag.numpy(), crm=crm.numpy()), meta)
 
 
+def improved_case(name, cfg, batch, length, seed_w=0, seed_x=80):
+    """improved_fullsubnet/model.py:Model, waveform in -> waveform out."""
+    params = MF.make_improved_params(cfg, seed=seed_w)
+    noisy = make_noisy(batch, length, seed=seed_x)
+    m = ImprovedModel(**cfg).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    with torch.no_grad():
+        enh = m(torch.from_numpy(noisy))
+    meta = dict(batch=batch, length=length, seed_w=seed_w, seed_x=seed_x, torch=torch.__version__,
+                crc_noisy=crc(noisy), crc_w=crc(np.concatenate([v.ravel() for v in params.values()])))
+    out = dict(enhanced=enh.numpy(), window=torch.hann_window(cfg["win_length"]).numpy(), meta=np.array(repr(meta)))
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    e = out["enhanced"]
+    print(f"{name}: enhanced {e.shape} rms {np.sqrt((e ** 2).mean()):.4f} (input rms {np.sqrt((noisy ** 2).mean()):.4f})")
+
+
 STFT_SHAPES = [(512, 128), (960, 480), (400, 100), (1536, 384)]  # (n_fft, hop); 512/256 is in make_golden.py
 
 
@@ -115,6 +132,8 @@ def stft_generic_case(name, batch=2, length=5000, seed_x=79):
 
 if __name__ == "__main__":
     stft_generic_case("stft_generic")
+    improved_case("improved_16k_b2", MF.IMPROVED_16K, 2, 4000)
+    improved_case("improved_48k_b2", MF.IMPROVED_48K, 2, 9600, seed_w=1)
     fast_case("fast_b2_even", 2, 8192)          # T' = 35: 34 frames after the first -> all blocks full
     fast_case("fast_b3_odd", 3, 8192 - 256, seed_w=1)  # T' = 34: 33 frames -> last block of 1
     fullband_case("fullband_b2", 2, 8192)

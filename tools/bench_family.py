@@ -10,12 +10,28 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fullsubnet_amd  # noqa: E402
 from fullsubnet_amd import decompress_cIRM, istft, stft  # noqa: E402
 from oracle.fullsubnet_oracle import make_noisy  # noqa: E402
-from oracle.model_family_oracle import make_fast_params, make_fullband_params  # noqa: E402
+from oracle.model_family_oracle import (IMPROVED_16K, IMPROVED_48K, make_fast_params, make_fullband_params,  # noqa: E402
+                                        make_improved_params)
 
 which = sys.argv[1] if len(sys.argv) > 1 else "fast"
-B = int(sys.argv[2]) if len(sys.argv) > 2 else (256 if which == "fast" else 1)
+B = int(sys.argv[2]) if len(sys.argv) > 2 else {"fast": 256, "improved48": 32, "improved16": 32}.get(which, 1)
 L = 48000
-if which == "fast":
+hop = 256
+if which.startswith("improved"):
+    from fullsubnet_amd.improved_fullsubnet import Model
+    cfg = IMPROVED_48K if which == "improved48" else IMPROVED_16K
+    L = 144000 if which == "improved48" else 48000  # 3 s
+    hop = cfg["hop_length"]
+    model = Model(**cfg)
+    sd = {k: torch.from_numpy(v) for k, v in make_improved_params(cfg, seed=3).items()}
+    F = cfg["num_freqs"] - 1
+    mmac = 4 * 512 * (F + 512) + 4 * 512 * 1024 + 512 * F  # full-band model
+    cuts = [0] + list(cfg["freq_cutoffs"]) + [F]
+    for i, c in enumerate(cfg["sb_num_center_freqs"]):
+        units = (cuts[i + 1] - cuts[i]) // c
+        k_in = 2 * (c + 30)
+        mmac += units * (4 * 384 * (k_in + 384) + 4 * 384 * 768 + 384 * 2 * c)
+elif which == "fast":
     from fullsubnet_amd.fast_fullsubnet import Model
     model = Model(look_ahead=2, shrink_size=2, sequence_model="LSTM", num_mels=64, encoder_input_size=257,
                   bottleneck_hidden_size=384, bottleneck_num_layers=2, noisy_input_num_neighbors=5,
@@ -36,6 +52,8 @@ noisy = torch.from_numpy(make_noisy(min(B, 8), L, seed=1)).cuda().repeat((B + 7)
 
 @torch.no_grad()
 def enhance(y):
+    if which.startswith("improved"):
+        return model(y)  # waveform in, waveform out
     mag, _, re, im = stft(y, 512, 256, 512)
     crm = decompress_cIRM(model(mag.unsqueeze(1)).permute(0, 2, 3, 1))
     er = crm[..., 0] * re - crm[..., 1] * im
@@ -52,6 +70,8 @@ for _ in range(K):
     out = enhance(noisy)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
-T = 1 + L // 256
-print(f"{which} B={B}: {dt * 1e3:.2f} ms / batch, {B * T / dt:.0f} frames/s ({B * T / dt / 62.5:.0f} x real time), "
-      f"~{2 * mmac * B * (T + 2) / dt / 1e12:.1f} TFLOP/s, finite={bool(torch.isfinite(out).all())}")
+T = 1 + L // hop
+la = 0 if which.startswith("improved") else 2
+sr = 48000 if which == "improved48" else 16000
+print(f"{which} B={B}: {dt * 1e3:.2f} ms / batch, {B * T / dt:.0f} frames/s ({B * L / sr / dt:.0f} x real time), "
+      f"~{2 * mmac * B * (T + la) / dt / 1e12:.1f} TFLOP/s, finite={bool(torch.isfinite(out).all())}")
