@@ -838,6 +838,137 @@ extern "C" int fsn_lstm_layer_backward(const float* dh, const float* x, long ldx
     return fsn_launch_colsum(dgates, G, db, G, (long)T * N, scratch, s);
 }
 
+// ---- nn.GRU layer (sequence_model.py:59-66): forward (inference / training) + BPTT -----------------
+extern "C" size_t fsn_gru_layer_save_bytes(int T, int N, int H) {
+    return fsn_round_up_sz((size_t)T * N * 4 * H * sizeof(float), 256);  // r | z | n | hn
+}
+extern "C" size_t fsn_gru_layer_fwd_workspace_bytes(int T, int N, int I, int H) {
+    Carver cv(nullptr);
+    cv.take<float>((size_t)3 * H * fsn_round_up(I, 16));
+    cv.take<float>((size_t)3 * H * H);
+    cv.take<float>((size_t)3 * H);
+    cv.take<float>((size_t)T * N * 3 * H);
+    return fsn_round_up_sz(cv.off, 256);
+}
+
+extern "C" int fsn_gru_layer_forward(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
+                                     const float* b_hh, int T, int N, int I, int H, float* hseq, void* save,
+                                     size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+    FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
+    FSN_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && hseq && workspace, "NULL pointer argument");
+    if ((save && save_bytes < fsn_gru_layer_save_bytes(T, N, H)) ||
+        workspace_bytes < fsn_gru_layer_fwd_workspace_bytes(T, N, I, H)) {
+        fsn_set_error("gru layer forward: save / workspace buffer too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Ipad = fsn_round_up(I, 16), G = 3 * H;
+    Carver cv(workspace);
+    float* wih_p = cv.take<float>((size_t)G * Ipad);
+    float* whh_p = cv.take<float>((size_t)G * H);
+    float* bias = cv.take<float>((size_t)G);
+    float* gx = cv.take<float>((size_t)T * N * G);
+    FSN_TRY(fsn_launch_pack(w_ih, wih_p, G, I, G, Ipad, s));
+    FSN_TRY(fsn_launch_pack(w_hh, whh_p, G, H, G, H, s));
+    // bias of the projection: b_ih everywhere + b_hh for r and z (b_hn stays inside r * (W_hn h + b_hn))
+    FSN_TRY(fsn_launch_bias_sum(b_ih, nullptr, bias, G, G, s));
+    FSN_TRY(fsn_launch_bias_sum(b_ih, b_hh, bias, 2 * H, 2 * H, s));
+    FsnGemmA a{};
+    a.kind = 0;
+    a.p0 = x;
+    a.ld = ldx;
+    FsnGemmC c{};
+    c.kind = 0;
+    c.p0 = gx;
+    c.bias = bias;
+    FSN_TRY(fsn_launch_gemm(a, wih_p, c, T * (N / 16), G / 16, Ipad / 16, s));
+    const size_t step = (size_t)N * H;
+    float* sv = static_cast<float*>(save);
+    for (int t = 0; t < T; ++t)
+        FSN_TRY(fsn_launch_gru_step(gx, whh_p, b_hh + 2 * H, t ? hseq + (t - 1) * step : hseq, hseq + t * step,
+                                    sv ? sv + (size_t)t * N * 4 * H : nullptr, (long)t * (N / 16), N / 16, H, t == 0, s));
+    return FSN_OK;
+}
+
+extern "C" size_t fsn_gru_layer_bwd_workspace_bytes(int T, int N, int I, int H) {
+    const int Ipad = fsn_round_up(I, 16), G = 3 * H;
+    Carver cv(nullptr);
+    cv.take<float>((size_t)H * G);      // W_hh^T fragments
+    cv.take<float>((size_t)Ipad * G);   // W_ih^T fragments
+    cv.take<float>((size_t)T * N * G);  // dgx
+    cv.take<float>((size_t)T * N * H);  // dghn
+    cv.take<float>((size_t)N * H);      // carry
+    size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
+    const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
+    tn = tn > tn2 ? tn : tn2;
+    const size_t cs = fsn_colsum_workspace_bytes(G, (long)T * N);
+    cv.take<char>(tn > cs ? tn : cs);
+    return fsn_round_up_sz(cv.off, 256);
+}
+
+extern "C" int fsn_gru_layer_backward(const float* dh, const float* x, long ldx, const float* w_ih, const float* w_hh,
+                                      int T, int N, int I, int H, const float* hseq, const void* save, float* dx,
+                                      long lddx, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
+    FSN_REQUIRE(dh && x && w_ih && w_hh && hseq && save && dw_ih && dw_hh && db_ih && db_hh && workspace,
+                "NULL pointer argument");
+    FSN_REQUIRE(!dx || lddx >= I, "dx row stride %ld < I", lddx);
+    if (workspace_bytes < fsn_gru_layer_bwd_workspace_bytes(T, N, I, H)) {
+        fsn_set_error("gru layer backward: workspace too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Ipad = fsn_round_up(I, 16), G = 3 * H;
+    Carver cv(workspace);
+    float* whhT_p = cv.take<float>((size_t)H * G);
+    float* wihT_p = cv.take<float>((size_t)Ipad * G);
+    float* dgx = cv.take<float>((size_t)T * N * G);
+    float* dghn = cv.take<float>((size_t)T * N * H);
+    float* carry = cv.take<float>((size_t)N * H);
+    size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
+    const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
+    tn = tn > tn2 ? tn : tn2;
+    const size_t cs = fsn_colsum_workspace_bytes(G, (long)T * N);
+    void* scratch = cv.take<char>(tn > cs ? tn : cs);
+    const float* sv = static_cast<const float*>(save);
+    FSN_TRY(fsn_launch_pack(w_hh, whhT_p, H, G, H, G, s, 1, H));
+    FSN_TRY(fsn_launch_pack(w_ih, wihT_p, I, G, Ipad, G, s, 1, I));
+    const size_t step = (size_t)N * H;
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t tn1 = t + 1 < T ? (size_t)(t + 1) : 0;
+        FSN_TRY(fsn_launch_gru_bptt_step(dh + t * step, dgx + tn1 * N * G, dghn + tn1 * step, whhT_p, carry,
+                                         sv + (size_t)t * N * 4 * H, t ? hseq + (t - 1) * step : hseq,
+                                         dgx + (size_t)t * N * G, dghn + t * step, N / 16, H, t == T - 1, t == 0, s));
+    }
+    if (dx) {
+        FsnGemmA a{};
+        a.kind = 0;
+        a.p0 = dgx;
+        a.ld = G;
+        FsnGemmC c{};
+        c.kind = 3;
+        c.p0 = dx;
+        c.ld = lddx;
+        c.rows = T * N;
+        c.cols = I;
+        FSN_TRY(fsn_launch_gemm(a, wihT_p, c, T * (N / 16), Ipad / 16, G / 16, s));
+    }
+    FSN_TRY(fsn_launch_gemm_tn(dgx, G, x, ldx, dw_ih, I, G, I, (long)T * N, scratch, s));
+    if (T > 1) {
+        // dW_hh: rows r, z from the x-side derivatives (identical on the h side), rows n from dghn
+        FSN_TRY(fsn_launch_gemm_tn(dgx + (size_t)N * G, G, hseq, H, dw_hh, H, 2 * H, H, (long)(T - 1) * N, scratch, s));
+        FSN_TRY(fsn_launch_gemm_tn(dghn + step, H, hseq, H, dw_hh + (size_t)2 * H * H, H, H, H, (long)(T - 1) * N,
+                                   scratch, s));
+    } else if (hipMemsetAsync(dw_hh, 0, (size_t)G * H * sizeof(float), s) != hipSuccess) {
+        fsn_set_error("memset failed");
+        return FSN_ERR_LAUNCH;
+    }
+    FSN_TRY(fsn_launch_colsum(dgx, G, db_ih, G, (long)T * N, scratch, s));
+    FSN_TRY(fsn_launch_colsum(dgx, G, db_hh, 2 * H, (long)T * N, scratch, s));
+    return fsn_launch_colsum(dghn, H, db_hh + 2 * H, H, (long)T * N, scratch, s);
+}
+
 // ---- training step: nn.Linear (sequence_model.py:82-84) forward / backward ------------------------
 // x [R][ldx] (columns I..ldx-1 zero, ldx = round_up(I,16)), w [O][I], b [O] -> y [R][O] (+ ReLU).
 extern "C" size_t fsn_linear_workspace_bytes(int R, int I, int O) {

@@ -149,6 +149,13 @@ int fsn_launch_bptt_step(const float* dh_out, const float* dgates_next, const fl
 int fsn_launch_bptt_elem(const float* dh_out, const float* dh_rec, float* dc, const float* gates, const float* c_t,
                          const float* c_prev, float* dgates, long n_elems, int H, int last, int first, hipStream_t s);
 
+// gru_kernels.hip
+int fsn_launch_gru_step(const float* gx, const float* whh_p, const float* b_hn, const float* h_prev, float* h_out,
+                        float* save, long gx_rt0, int row_tiles, int H, int first, hipStream_t s);
+int fsn_launch_gru_bptt_step(const float* dh_out, const float* dgx_next, const float* dghn_next, const float* whhT_p,
+                             float* carry, const float* save, const float* h_prev, float* dgx, float* dghn,
+                             int row_tiles, int H, int last, int first, hipStream_t s);
+
 // lstm_kernels.hip
 // Sub-band model input (fullsubnet/model.py:98-111) for kernels that build it on the fly:
 // channel c < 2nb+1 of unit n = b F + f at frame t is mag[b][t][reflect(f + c - nb)], channel 2nb+1

@@ -22,12 +22,11 @@ class Model(nn.Module):
         """fullsubnet/model.py:10-70 (same arguments)."""
         super().__init__()
         assert sequence_model in ("GRU", "LSTM"), f"{self.__class__.__name__} only support GRU and LSTM."
-        if fb_num_neighbors != 0:
-            raise NotImplementedError("fb_num_neighbors must be 0 (every shipped TOML)")
-        if fb_output_activate_function != "ReLU" or sb_output_activate_function:
-            raise NotImplementedError("built for fb ReLU / sb linear output (fullsubnet/train.toml:77-78)")
-        if norm_type not in _lib.NORM_TYPES:
-            raise NotImplementedError(f"norm_type {norm_type!r}: built {sorted(_lib.NORM_TYPES)} (others are next)")
+        # configurations of the shipped TOMLs run fused in libfsn_hip (fsn_fullsubnet_forward / fsn_enhance);
+        # every other combination the reference constructor accepts (GRU, fb_num_neighbors > 0, other output
+        # activations, the three extra norms) runs composed from SequenceModel blocks (_forward_composed)
+        self._fused = (sequence_model == "LSTM" and fb_num_neighbors == 0 and fb_output_activate_function == "ReLU"
+                       and not sb_output_activate_function and norm_type in _lib.NORM_TYPES)
         self.fb_model = SequenceModel(num_freqs, num_freqs, fb_model_hidden_size, 2, False, sequence_model,
                                       fb_output_activate_function)
         self.sb_model = SequenceModel((sb_num_neighbors * 2 + 1) + (fb_num_neighbors * 2 + 1), 2,
@@ -39,7 +38,7 @@ class Model(nn.Module):
         self.norm_type = norm_type
         self.num_groups_in_drop_band = num_groups_in_drop_band
         self._cfg = _lib.Cfg(num_freqs, look_ahead, sb_num_neighbors, fb_model_hidden_size, sb_model_hidden_size,
-                             _lib.NORM_TYPES[norm_type])
+                             _lib.NORM_TYPES.get(norm_type, 0))
         self._packed = None
         self._packed_key = None
         if weight_init:
@@ -86,6 +85,8 @@ class Model(nn.Module):
         batch_size, num_channels, num_freqs, num_frames = noisy_mag.size()
         assert num_channels == 1, f"{self.__class__.__name__} takes the mag feature as inputs."
         assert num_freqs == self.num_freqs
+        if not self._fused:
+            return self._forward_composed(noisy_mag)
         if torch.is_grad_enabled() and (self.training or noisy_mag.requires_grad):
             # training step (fullsubnet/trainer.py:56-63): autograd graph with the LSTM layers
             # (forward + BPTT) on the HIP kernels, see fullsubnet_amd/train.py
@@ -107,6 +108,28 @@ class Model(nn.Module):
             out = drop_band(out, num_groups=self.num_groups_in_drop_band)
         return out
 
+    def _forward_composed(self, noisy_mag):
+        """fullsubnet/model.py:72-136 operation by operation, for the configurations the fused kernels
+        are not specialised for: the two SequenceModel blocks run on the HIP LSTM / GRU / GEMM kernels
+        (inference or autograd), norms / unfold / concat / drop_band are tensor algebra."""
+        from .base_model import BaseModel, look_ahead_pad
+        norm = BaseModel().norm_wrapper(self.norm_type)
+        x = look_ahead_pad(noisy_mag, self.look_ahead)
+        B, C, F, T = x.size()
+        fb_output = self.fb_model(norm(x).reshape(B, C * F, T)).reshape(B, 1, F, T)
+        fb_unfolded = BaseModel.freq_unfold(fb_output, self.fb_num_neighbors).reshape(
+            B, F, self.fb_num_neighbors * 2 + 1, T)
+        noisy_unfolded = BaseModel.freq_unfold(x, self.sb_num_neighbors).reshape(B, F, self.sb_num_neighbors * 2 + 1, T)
+        sb_input = norm(torch.cat([noisy_unfolded, fb_unfolded], dim=2))
+        if B > 1 and self.num_groups_in_drop_band > 1:  # model.py:114-119 (quirk Q1: also in eval mode)
+            sb_input = drop_band(sb_input.permute(0, 2, 1, 3), num_groups=self.num_groups_in_drop_band)
+            F = sb_input.shape[2]
+            sb_input = sb_input.permute(0, 2, 1, 3)
+        K = (self.sb_num_neighbors * 2 + 1) + (self.fb_num_neighbors * 2 + 1)
+        sb_mask = self.sb_model(sb_input.reshape(B * F, K, T))
+        output = sb_mask.reshape(B, F, 2, T).permute(0, 2, 1, 3).contiguous()
+        return output[:, :, :, self.look_ahead:]
+
     @torch.no_grad()
     def enhance(self, noisy, n_fft=512, hop_length=256, return_crm=False):
         """Whole path of inferencer.py:130-145 in one call: noisy [B, L] -> enhanced [B, L]
@@ -115,6 +138,19 @@ class Model(nn.Module):
         assert noisy.dim() == 2
         y = noisy.contiguous()
         B, Ls = y.shape
+        if not self._fused:  # composed configuration: the same stages as separate calls, no band dropping
+            from .acoustics.feature import istft, stft
+            from .acoustics.mask import decompress_cIRM
+            mag, _, re, im = stft(y, n_fft, hop_length, n_fft)
+            groups, self.num_groups_in_drop_band = self.num_groups_in_drop_band, 1
+            try:
+                crm = self._forward_composed(mag.unsqueeze(1))
+            finally:
+                self.num_groups_in_drop_band = groups
+            m = decompress_cIRM(crm.permute(0, 2, 3, 1))
+            out = istft((m[..., 0] * re - m[..., 1] * im, m[..., 1] * re + m[..., 0] * im), n_fft, hop_length, n_fft,
+                        length=Ls, input_type="real_imag")
+            return (out, crm) if return_crm else out
         L = _lib.lib()
         out = torch.empty_like(y)
         T = 1 + Ls // hop_length

@@ -4,9 +4,10 @@ Same constructor, same parameter names (``sequence_model.weight_ih_l{k}`` ..., `
 same ``forward(x [B, F, T]) -> [B, O, T]``.  The ``nn.LSTM`` / ``nn.Linear`` members only hold the
 parameters; every layer runs through the C ABI:
 
-* inference (no autograd): ``fsn_lstm_layer_forward(save = NULL)`` per layer + ``fsn_linear_forward``;
-* training: ``LstmLayerFunction`` / ``LinearFunction`` (fullsubnet_amd/train.py: forward with saved
-  activations + back-propagation through time).
+* inference (no autograd): ``fsn_lstm_layer_forward`` / ``fsn_gru_layer_forward`` (``save = NULL``) per
+  layer + ``fsn_linear_forward``;
+* training: ``LstmLayerFunction`` / ``GruLayerFunction`` / ``LinearFunction`` (fullsubnet_amd/train.py:
+  forward with saved activations + back-propagation through time).
 
 Hidden sizes that are not a multiple of 64 (Fast FullSubNet's 257) are run zero-padded: a unit whose
 weights and biases are all zero keeps h = c = 0 at every step, so the padding is exact.
@@ -22,23 +23,24 @@ def _round_up(x, m):
 
 
 def pad_lstm_weights(w_ih, w_hh, b_ih, b_hh, in_pad):
-    """nn.LSTM layer tensors ([4H, I], [4H, H], [4H], [4H]) -> the same layer with H padded to a
-    multiple of 64 and I padded to ``in_pad`` columns (gate blocks stay contiguous).  Plain torch
-    ops, so gradients flow back to the unpadded parameters when autograd is recording."""
+    """nn.LSTM / nn.GRU layer tensors ([gH, I], [gH, H], [gH], [gH], g = 4 / 3 gates) -> the same layer
+    with H padded to a multiple of 64 and I padded to ``in_pad`` columns (gate blocks stay contiguous).
+    Plain torch ops, so gradients flow back to the unpadded parameters when autograd is recording."""
     H, I = w_hh.shape[1], w_ih.shape[1]
+    g = w_hh.shape[0] // H
     Hp = _round_up(H, 64)
     if Hp == H and in_pad == I:
         return w_ih, w_hh, b_ih, b_hh
     dev = w_ih.device
-    wi = torch.zeros((4, Hp, in_pad), dtype=torch.float32, device=dev)
-    wi[:, :H, :I] = w_ih.reshape(4, H, I)
-    wh = torch.zeros((4, Hp, Hp), dtype=torch.float32, device=dev)
-    wh[:, :H, :H] = w_hh.reshape(4, H, H)
-    bi = torch.zeros((4, Hp), dtype=torch.float32, device=dev)
-    bi[:, :H] = b_ih.reshape(4, H)
-    bh = torch.zeros((4, Hp), dtype=torch.float32, device=dev)
-    bh[:, :H] = b_hh.reshape(4, H)
-    return wi.reshape(4 * Hp, in_pad), wh.reshape(4 * Hp, Hp), bi.reshape(-1), bh.reshape(-1)
+    wi = torch.zeros((g, Hp, in_pad), dtype=torch.float32, device=dev)
+    wi[:, :H, :I] = w_ih.reshape(g, H, I)
+    wh = torch.zeros((g, Hp, Hp), dtype=torch.float32, device=dev)
+    wh[:, :H, :H] = w_hh.reshape(g, H, H)
+    bi = torch.zeros((g, Hp), dtype=torch.float32, device=dev)
+    bi[:, :H] = b_ih.reshape(g, H)
+    bh = torch.zeros((g, Hp), dtype=torch.float32, device=dev)
+    bh[:, :H] = b_hh.reshape(g, H)
+    return wi.reshape(g * Hp, in_pad), wh.reshape(g * Hp, Hp), bi.reshape(-1), bh.reshape(-1)
 
 
 def lstm_layer_infer(x, w_ih, w_hh, b_ih, b_hh):
@@ -50,6 +52,20 @@ def lstm_layer_infer(x, w_ih, w_hh, b_ih, b_hh):
     hseq = torch.empty((T, N, H), dtype=torch.float32, device=x.device)
     ws = _lib.workspace(L.fsn_lstm_layer_fwd_workspace_bytes(T, N, I, H), x.device)
     _lib.check(L.fsn_lstm_layer_forward(
+        _lib.dev_ptr(x, "x"), ldx, _lib.dev_ptr(w_ih, "w_ih"), _lib.dev_ptr(w_hh, "w_hh"), _lib.dev_ptr(b_ih, "b_ih"),
+        _lib.dev_ptr(b_hh, "b_hh"), T, N, I, H, _lib.dev_ptr(hseq), None, 0, ws.data_ptr(), ws.numel(),
+        _lib.stream_ptr(x.device)))
+    return hseq
+
+
+def gru_layer_infer(x, w_ih, w_hh, b_ih, b_hh):
+    """One GRU layer, inference mode (same conventions as lstm_layer_infer, 3H gate rows r, z, n)."""
+    L = _lib.lib()
+    T, N, ldx = x.shape
+    I, H = w_ih.shape[1], w_hh.shape[1]
+    hseq = torch.empty((T, N, H), dtype=torch.float32, device=x.device)
+    ws = _lib.workspace(L.fsn_gru_layer_fwd_workspace_bytes(T, N, I, H), x.device)
+    _lib.check(L.fsn_gru_layer_forward(
         _lib.dev_ptr(x, "x"), ldx, _lib.dev_ptr(w_ih, "w_ih"), _lib.dev_ptr(w_hh, "w_hh"), _lib.dev_ptr(b_ih, "b_ih"),
         _lib.dev_ptr(b_hh, "b_hh"), T, N, I, H, _lib.dev_ptr(hseq), None, 0, ws.data_ptr(), ws.numel(),
         _lib.stream_ptr(x.device)))
@@ -73,15 +89,14 @@ class SequenceModel(nn.Module):
     def __init__(self, input_size, output_size, hidden_size, num_layers, bidirectional, sequence_model="GRU",
                  output_activate_function="Tanh"):
         super().__init__()
-        if sequence_model == "LSTM":
-            if bidirectional:
-                raise NotImplementedError("libfsn_hip: unidirectional only (every FullSubNet TOML)")
-            self.sequence_model = nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers,
-                                          batch_first=True, bidirectional=False)
-        elif sequence_model == "GRU":
-            raise NotImplementedError("libfsn_hip implements the LSTM branch (sequence_model.py:51-58); GRU is next")
-        else:
+        if sequence_model not in ("LSTM", "GRU"):
             raise NotImplementedError(f"Not implemented {sequence_model}")
+        if bidirectional:
+            raise NotImplementedError("libfsn_hip: unidirectional only (every FullSubNet TOML)")
+        rnn = nn.LSTM if sequence_model == "LSTM" else nn.GRU
+        self.sequence_model = rnn(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers,
+                                  batch_first=True, bidirectional=False)
+        self.cell = sequence_model
         if int(output_size):
             self.fc_output_layer = nn.Linear(hidden_size, output_size)
         if output_activate_function:
@@ -135,8 +150,9 @@ class SequenceModel(nn.Module):
         layers, fc = self._inference_weights()
         h = torch.zeros((T, Np, Ip), dtype=torch.float32, device=x.device)
         h[:, :B, :F] = x.permute(2, 0, 1)
+        layer_infer = lstm_layer_infer if self.cell == "LSTM" else gru_layer_infer
         for w_ih, w_hh, b_ih, b_hh in layers:
-            h = lstm_layer_infer(h, w_ih, w_hh, b_ih, b_hh)
+            h = layer_infer(h, w_ih, w_hh, b_ih, b_hh)
         relu = self.output_activate_function == "ReLU"
         if fc is not None:
             o = linear_infer(h.reshape(T * Np, Hp), fc[0], fc[1], relu).reshape(T, Np, self.output_size)
@@ -149,12 +165,13 @@ class SequenceModel(nn.Module):
         return o.permute(1, 2, 0)
 
     def _forward_train(self, x):
-        from .train import LinearFunction, LstmLayerFunction
+        from .train import GruLayerFunction, LinearFunction, LstmLayerFunction
         H, Hp = self.hidden_size, _round_up(self.hidden_size, 64)
+        layer = LstmLayerFunction if self.cell == "LSTM" else GruLayerFunction
         h = x.permute(2, 0, 1)  # [T, B, F]
         for k in range(self.num_layers):
             in_pad = self.input_size if k == 0 else Hp
-            h = LstmLayerFunction.apply(h, *pad_lstm_weights(*self._layer_tensors(k), in_pad))
+            h = layer.apply(h, *pad_lstm_weights(*self._layer_tensors(k), in_pad))
         h = h[..., :H]
         relu = self.output_activate_function == "ReLU"
         if self.output_size:

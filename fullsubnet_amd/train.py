@@ -64,6 +64,57 @@ class LstmLayerFunction(torch.autograd.Function):
         return (dx[:, :N, :I] if need_dx else None), dw_ih, dw_hh, db, db.clone()
 
 
+class GruLayerFunction(torch.autograd.Function):
+    """One nn.GRU layer (unidirectional, h0 = 0) on time-major input x [T, N, I] -> [T, N, H]
+    (fsn_gru_layer_forward with saved r, z, n, hn + fsn_gru_layer_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        L = _lib.lib()
+        T, N, I = x.shape
+        H = w_hh.shape[1]
+        Np, Ip = (N + 15) // 16 * 16, (I + 15) // 16 * 16
+        xp = x
+        if Np != N or Ip != I or not x.is_contiguous():
+            xp = torch.zeros((T, Np, Ip), dtype=torch.float32, device=x.device)
+            xp[:, :N, :I] = x
+        w_ih_c, w_hh_c = w_ih.detach().contiguous(), w_hh.detach().contiguous()
+        hseq = torch.empty((T, Np, H), dtype=torch.float32, device=x.device)
+        save = _lib.workspace(L.fsn_gru_layer_save_bytes(T, Np, H), x.device)
+        ws = _lib.workspace(L.fsn_gru_layer_fwd_workspace_bytes(T, Np, I, H), x.device)
+        _lib.check(L.fsn_gru_layer_forward(
+            _lib.dev_ptr(xp, "x"), Ip, _lib.dev_ptr(w_ih_c, "w_ih"), _lib.dev_ptr(w_hh_c, "w_hh"),
+            _lib.dev_ptr(b_ih.detach().contiguous(), "b_ih"), _lib.dev_ptr(b_hh.detach().contiguous(), "b_hh"),
+            T, Np, I, H, _lib.dev_ptr(hseq), save.data_ptr(), save.numel(), ws.data_ptr(), ws.numel(),
+            _lib.stream_ptr(x.device)))
+        ctx.save_for_backward(xp, w_ih_c, w_hh_c, hseq, save)
+        ctx.dims = (T, N, I, H, Np, Ip)
+        return hseq[:, :N]
+
+    @staticmethod
+    def backward(ctx, dh):
+        L = _lib.lib()
+        xp, w_ih, w_hh, hseq, save = ctx.saved_tensors
+        T, N, I, H, Np, Ip = ctx.dims
+        dhp = dh
+        if Np != N or not dh.is_contiguous():
+            dhp = torch.zeros((T, Np, H), dtype=torch.float32, device=dh.device)
+            dhp[:, :N] = dh
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty((T, Np, Ip), dtype=torch.float32, device=dh.device) if need_dx else None
+        dw_ih = torch.empty_like(w_ih)
+        dw_hh = torch.empty_like(w_hh)
+        db_ih = torch.empty((3 * H,), dtype=torch.float32, device=dh.device)
+        db_hh = torch.empty((3 * H,), dtype=torch.float32, device=dh.device)
+        ws = _lib.workspace(L.fsn_gru_layer_bwd_workspace_bytes(T, Np, I, H), dh.device)
+        _lib.check(L.fsn_gru_layer_backward(
+            _lib.dev_ptr(dhp, "dh"), _lib.dev_ptr(xp), Ip, _lib.dev_ptr(w_ih), _lib.dev_ptr(w_hh), T, Np, I, H,
+            _lib.dev_ptr(hseq), save.data_ptr(), _lib.dev_ptr(dx, allow_none=True), Ip, _lib.dev_ptr(dw_ih),
+            _lib.dev_ptr(dw_hh), _lib.dev_ptr(db_ih), _lib.dev_ptr(db_hh), ws.data_ptr(), ws.numel(),
+            _lib.stream_ptr(dh.device)))
+        return (dx[:, :N, :I] if need_dx else None), dw_ih, dw_hh, db_ih, db_hh
+
+
 class LinearFunction(torch.autograd.Function):
     """nn.Linear (+ optional ReLU) on x [..., I] -> [..., O] through fsn_linear_forward / _backward."""
 

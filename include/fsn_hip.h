@@ -130,6 +130,20 @@ int fsn_lstm_layer_backward(const float* dh, const float* x, long ldx, const flo
                             float* dw_ih, float* dw_hh, float* db, void* workspace, size_t workspace_bytes,
                             void* stream);
 
+/* nn.GRU branch of SequenceModel (sequence_model.py:59-66), one layer, unidirectional, h0 = 0; same
+ * conventions as the LSTM layer above with 3H gate rows (r, z, n).  save == NULL: inference.  The two
+ * bias gradients differ in the n block (b_hn sits inside r * (W_hn h + b_hn)), hence two outputs. */
+size_t fsn_gru_layer_save_bytes(int T, int N, int H);
+size_t fsn_gru_layer_fwd_workspace_bytes(int T, int N, int I, int H);
+int fsn_gru_layer_forward(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
+                          const float* b_hh, int T, int N, int I, int H, float* hseq, void* save, size_t save_bytes,
+                          void* workspace, size_t workspace_bytes, void* stream);
+size_t fsn_gru_layer_bwd_workspace_bytes(int T, int N, int I, int H);
+int fsn_gru_layer_backward(const float* dh, const float* x, long ldx, const float* w_ih, const float* w_hh, int T,
+                           int N, int I, int H, const float* hseq, const void* save, float* dx, long lddx,
+                           float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* nn.Linear (sequence_model.py:82-84) of the training step.  x [R][ldx] with ldx = round_up(I,16) and
  * zero padding, w [O][I], b [O] -> y [R][O] (ReLU fused when relu != 0).  Backward: dy [R][lddy]
  * (lddy = round_up(O,16), zero padded) -> dx [R][lddx] (may be NULL), dw [O][I], db [O]. */

@@ -192,6 +192,53 @@ def cumulative_laplace_norm(x, dtype=np.float32):
     return (xr / (mean + dtype(EPSILON))).astype(dtype).reshape(B, C, F, T)
 
 
+def offline_gaussian_norm(x, dtype=np.float32):
+    """base_model.py:295-310.  (x - mean) / (std + 1e-5), torch.std = unbiased (N - 1)."""
+    x = np.asarray(x, dtype=dtype)
+    ax = tuple(range(1, x.ndim))
+    mu = x.mean(axis=ax, keepdims=True, dtype=np.float64)
+    std = np.sqrt(((x.astype(np.float64) - mu) ** 2).sum(axis=ax, keepdims=True) / (x[0].size - 1))
+    return ((x - mu.astype(dtype)) / (std.astype(dtype) + dtype(1e-5))).astype(dtype)
+
+
+def cumulative_layer_norm(x, dtype=np.float32):
+    """base_model.py:312-354.  Running mean / variance over (F, frames <= t); dim 1 folded into batch."""
+    x = np.asarray(x, dtype=dtype)
+    B, C, F, T = x.shape
+    xr = x.reshape(B * C, F, T)
+    s1 = np.cumsum(xr.sum(axis=1, dtype=np.float64), axis=-1)
+    s2 = np.cumsum((xr.astype(np.float64) ** 2).sum(axis=1), axis=-1)
+    count = np.arange(F, F * T + 1, F, dtype=np.float64)[None, :]
+    mean = s1 / count
+    var = (s2 - 2 * mean * s1) / count + mean ** 2
+    std = np.sqrt(var + EPSILON)
+    out = (xr - mean.astype(dtype)[:, None, :]) / std.astype(dtype)[:, None, :]
+    return out.astype(dtype).reshape(B, C, F, T)
+
+
+def forgetting_norm(x, sample_length=192, dtype=np.float32):
+    """base_model.py:103-151.  mu_t = a_t mu_{t-1} + (1 - a_t) mean(x[:, :, t]) with
+    a_t = min((t - 1) / (t + 1), alpha) while t < sample_length (so a_0 = -1: the reference's own
+    start-up, mu_0 = 2 mean_0), alpha = (L - 1) / (L + 1) afterwards; x / (mu + 1e-10)."""
+    x = np.asarray(x, dtype=dtype)
+    B, C, F, T = x.shape
+    xr = x.reshape(B, C * F, T)
+    frame_mean = xr.mean(axis=1, dtype=np.float64).astype(dtype)  # [B, T]
+    alpha = (sample_length - 1) / (sample_length + 1)
+    mu = np.zeros((B,), dtype=dtype)
+    mus = np.empty((B, T), dtype=dtype)
+    for t in range(T):
+        a = dtype(min((t - 1) / (t + 1), alpha)) if t < sample_length else dtype(alpha)
+        mu = (a * mu + (dtype(1) - a) * frame_mean[:, t]).astype(dtype)
+        mus[:, t] = mu
+    return (xr / (mus[:, None, :] + dtype(1e-10))).astype(dtype).reshape(B, C, F, T)
+
+
+NORMS = {"offline_laplace_norm": offline_laplace_norm, "cumulative_laplace_norm": cumulative_laplace_norm,
+         "offline_gaussian_norm": offline_gaussian_norm, "cumulative_layer_norm": cumulative_layer_norm,
+         "forgetting_norm": forgetting_norm}
+
+
 def reflect_index(j: np.ndarray, F: int) -> np.ndarray:
     """F.pad(mode="reflect") source index (no edge repeat) for positions j in [-N, F+N)."""
     j = np.where(j < 0, -j, j)
@@ -266,7 +313,39 @@ def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, dtype=np.float32):
     return np.ascontiguousarray(out.transpose(1, 0, 2))
 
 
-def sequence_model(x, params, prefix, num_layers=2, activation=None, dtype=np.float32):
+def gru_layer(x, w_ih, w_hh, b_ih, b_hh, dtype=np.float32):
+    """One unidirectional nn.GRU layer, batch_first, h0 = 0 (sequence_model.py:59-66).
+
+    x: [N, T, I].  PyTorch gate order along the 3H axis is (r, z, n):
+        r = sigmoid(W_ir x + b_ir + W_hr h + b_hr)      z likewise
+        n = tanh(W_in x + b_in + r * (W_hn h + b_hn))
+        h = n + z * (h - n)
+    """
+    x = np.asarray(x, dtype=dtype)
+    w_ih = np.asarray(w_ih, dtype=dtype)
+    w_hh = np.asarray(w_hh, dtype=dtype)
+    b_ih = np.asarray(b_ih, dtype=dtype)
+    b_hh = np.asarray(b_hh, dtype=dtype)
+    N, T, I = x.shape
+    H = w_hh.shape[1]
+    h = np.zeros((N, H), dtype=dtype)
+    out = np.empty((T, N, H), dtype=dtype)
+    w_ih_t = np.ascontiguousarray(w_ih.T)
+    w_hh_t = np.ascontiguousarray(w_hh.T)
+    xw = _matmul(np.ascontiguousarray(x.transpose(1, 0, 2)).reshape(T * N, I), w_ih_t)
+    xw += b_ih
+    xw = xw.reshape(T, N, 3 * H)
+    for t in range(T):
+        hw = _matmul(h, w_hh_t) + b_hh
+        r = _sigmoid(xw[t][:, 0:H] + hw[:, 0:H])
+        z = _sigmoid(xw[t][:, H:2 * H] + hw[:, H:2 * H])
+        n = np.tanh(xw[t][:, 2 * H:] + r * hw[:, 2 * H:])
+        h = (n + z * (h - n)).astype(dtype)
+        out[t] = h
+    return np.ascontiguousarray(out.transpose(1, 0, 2))
+
+
+def sequence_model(x, params, prefix, num_layers=2, activation=None, dtype=np.float32, cell="LSTM"):
     """SequenceModel.forward (sequence_model.py:106-125): [B, F, T] -> [B, F', T].
 
     ``params`` holds reference state_dict names: ``{prefix}.sequence_model.weight_ih_l{k}`` ...
@@ -275,13 +354,16 @@ def sequence_model(x, params, prefix, num_layers=2, activation=None, dtype=np.fl
     o = np.ascontiguousarray(np.asarray(x, dtype=dtype).transpose(0, 2, 1))  # [B, T, F]
     for k in range(num_layers):
         p = f"{prefix}.sequence_model."
-        o = lstm_layer(o, params[p + f"weight_ih_l{k}"], params[p + f"weight_hh_l{k}"],
-                       params[p + f"bias_ih_l{k}"], params[p + f"bias_hh_l{k}"], dtype=dtype)
+        layer = lstm_layer if cell == "LSTM" else gru_layer
+        o = layer(o, params[p + f"weight_ih_l{k}"], params[p + f"weight_hh_l{k}"],
+                  params[p + f"bias_ih_l{k}"], params[p + f"bias_hh_l{k}"], dtype=dtype)
     w = np.asarray(params[f"{prefix}.fc_output_layer.weight"], dtype=dtype)
     b = np.asarray(params[f"{prefix}.fc_output_layer.bias"], dtype=dtype)
     o = (o @ w.T + b).astype(dtype)
     if activation == "ReLU":
         o = np.maximum(o, 0)
+    elif activation == "Tanh":
+        o = np.tanh(o)
     elif activation:
         raise NotImplementedError(activation)
     return np.ascontiguousarray(o.transpose(0, 2, 1))
@@ -292,18 +374,16 @@ def sequence_model(x, params, prefix, num_layers=2, activation=None, dtype=np.fl
 # --------------------------------------------------------------------------- #
 def fullsubnet_forward(noisy_mag, params, look_ahead=2, sb_num_neighbors=15, fb_num_neighbors=0,
                        norm_type="offline_laplace_norm", num_groups_in_drop_band=1,
-                       dtype=np.float32, return_intermediates=False):
+                       dtype=np.float32, return_intermediates=False, cell="LSTM", fb_activation="ReLU"):
     """noisy_mag [B, 1, F, T] -> compressed cIRM [B, 2, F, T] (or F//g under drop_band)."""
-    assert fb_num_neighbors == 0, "every shipped TOML uses fb_num_neighbors = 0"
-    norm = {"offline_laplace_norm": offline_laplace_norm,
-            "cumulative_laplace_norm": cumulative_laplace_norm}[norm_type]
+    norm = NORMS[norm_type]
     x = np.asarray(noisy_mag, dtype=dtype)
     assert x.ndim == 4 and x.shape[1] == 1
     x = np.pad(x, [(0, 0), (0, 0), (0, 0), (0, look_ahead)])  # model.py:85
     B, C, F, Tp = x.shape
 
     fb_input = norm(x, dtype=dtype).reshape(B, C * F, Tp)  # model.py:92-94
-    fb_output = sequence_model(fb_input, params, "fb_model", activation="ReLU", dtype=dtype)
+    fb_output = sequence_model(fb_input, params, "fb_model", activation=fb_activation, dtype=dtype, cell=cell)
     fb_output = fb_output.reshape(B, 1, F, Tp)  # model.py:95
 
     fb_unf = freq_unfold(fb_output, fb_num_neighbors).reshape(B, F, 2 * fb_num_neighbors + 1, Tp)
@@ -318,7 +398,7 @@ def fullsubnet_forward(noisy_mag, params, look_ahead=2, sb_num_neighbors=15, fb_
         sb_input = sb_input.transpose(0, 2, 1, 3)
     n_in = 2 * sb_num_neighbors + 1 + 2 * fb_num_neighbors + 1
     sb_in = np.ascontiguousarray(sb_input).reshape(B * Fs, n_in, Tp)  # model.py:121-125
-    sb_mask = sequence_model(sb_in, params, "sb_model", activation=None, dtype=dtype)
+    sb_mask = sequence_model(sb_in, params, "sb_model", activation=None, dtype=dtype, cell=cell)
     sb_mask = sb_mask.reshape(B, Fs, 2, Tp).transpose(0, 2, 1, 3)  # model.py:129-133
     out = np.ascontiguousarray(sb_mask[:, :, :, look_ahead:])  # model.py:135
     if return_intermediates:
@@ -349,7 +429,7 @@ FULLSUBNET_SHAPES = dict(num_freqs=257, fb_hidden=512, sb_hidden=384, sb_num_nei
 
 
 def make_params(seed=0, num_freqs=257, fb_hidden=512, sb_hidden=384, sb_num_neighbors=15,
-                gain=1.0, mask_gain=1.0, dtype=np.float32):
+                gain=1.0, mask_gain=1.0, dtype=np.float32, gates=4, fb_num_neighbors=0):
     """Random weights with the reference state_dict names/shapes.
 
     U(-1/sqrt(H), 1/sqrt(H)) like nn.LSTM / nn.Linear defaults, times ``gain``;
@@ -364,10 +444,10 @@ def make_params(seed=0, num_freqs=257, fb_hidden=512, sb_hidden=384, sb_num_neig
     def lstm(prefix, I, H):
         k = 1.0 / np.sqrt(H)
         for layer, isz in ((0, I), (1, H)):
-            p[f"{prefix}.sequence_model.weight_ih_l{layer}"] = rng.uniform(-k, k, (4 * H, isz))
-            p[f"{prefix}.sequence_model.weight_hh_l{layer}"] = rng.uniform(-k, k, (4 * H, H))
-            p[f"{prefix}.sequence_model.bias_ih_l{layer}"] = rng.uniform(-k, k, (4 * H,))
-            p[f"{prefix}.sequence_model.bias_hh_l{layer}"] = rng.uniform(-k, k, (4 * H,))
+            p[f"{prefix}.sequence_model.weight_ih_l{layer}"] = rng.uniform(-k, k, (gates * H, isz))
+            p[f"{prefix}.sequence_model.weight_hh_l{layer}"] = rng.uniform(-k, k, (gates * H, H))
+            p[f"{prefix}.sequence_model.bias_ih_l{layer}"] = rng.uniform(-k, k, (gates * H,))
+            p[f"{prefix}.sequence_model.bias_hh_l{layer}"] = rng.uniform(-k, k, (gates * H,))
 
     def fc(prefix, I, O):
         k = 1.0 / np.sqrt(I)
@@ -376,7 +456,7 @@ def make_params(seed=0, num_freqs=257, fb_hidden=512, sb_hidden=384, sb_num_neig
 
     lstm("fb_model", num_freqs, fb_hidden)
     fc("fb_model", fb_hidden, num_freqs)
-    lstm("sb_model", 2 * sb_num_neighbors + 1 + 1, sb_hidden)
+    lstm("sb_model", (2 * sb_num_neighbors + 1) + (2 * fb_num_neighbors + 1), sb_hidden)
     fc("sb_model", sb_hidden, 2)
     for k in ("sb_model.fc_output_layer.weight", "sb_model.fc_output_layer.bias"):
         p[k] = p[k] * mask_gain

@@ -80,19 +80,21 @@ def test_fullband_baseline_vs_reference(fsn, golden_dir):
     assert np.abs(crm - z["crm"]).max() <= 1e-4
 
 
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
 @pytest.mark.parametrize("I,H,O,layers,act,B,T", [
     (64, 384, 0, 1, None, 3, 9),       # no output layer (Fast FullSubNet encoder.0)
     (40, 257, 64, 1, "ReLU", 5, 7),    # hidden size padded 257 -> 320 (encoder.1)
     (12, 384, 1, 2, "ReLU", 130, 6),   # bottleneck shape, rows not a multiple of 16
     (20, 64, 8, 2, "Tanh", 2, 5),
+    (33, 128, 5, 1, None, 1100, 4),    # >= 64 row tiles: multi-tile step / BPTT kernels
 ])
-def test_sequence_model_inference_and_training_vs_torch(fsn, I, H, O, layers, act, B, T):
+def test_sequence_model_inference_and_training_vs_torch(fsn, cell, I, H, O, layers, act, B, T):
     """SequenceModel.forward under no_grad (inference kernels) and under autograd (forward with saves +
     BPTT) against ATen's nn.LSTM / nn.Linear on CPU with the same parameters."""
     from fullsubnet_amd.sequence_model import SequenceModel
     torch.manual_seed(I + H)
-    m = SequenceModel(I, O, H, layers, False, "LSTM", act)
-    ref_lstm = torch.nn.LSTM(I, H, layers, batch_first=True)
+    m = SequenceModel(I, O, H, layers, False, cell, act)
+    ref_lstm = (torch.nn.LSTM if cell == "LSTM" else torch.nn.GRU)(I, H, layers, batch_first=True)
     ref_lstm.load_state_dict(m.sequence_model.state_dict())
     x = torch.randn(B, I, T)
     dy = torch.randn(B, O or H, T)
@@ -169,3 +171,40 @@ def test_improved_fullsubnet_vs_reference(fsn, golden_dir, name, cfg):
         enh = m(torch.from_numpy(noisy).cuda().unsqueeze(1)).cpu().numpy()
     assert enh.shape == z["enhanced"].shape
     assert np.abs(enh - z["enhanced"]).max() <= 1e-4 * np.abs(z["enhanced"]).max()
+
+
+@pytest.mark.parametrize("name", ["var_gru_b2", "var_gaussian_b2", "var_cln_b2", "var_forgetting_b2",
+                                  "var_fbnn2_tanh_b3"])
+def test_fullsubnet_constructor_variants_vs_reference(fsn, golden_dir, name):
+    """FullSubNet with the constructor options outside the shipped TOMLs (GRU, extra norms, fb neighbours,
+    other activations): composed from SequenceModel blocks on the HIP kernels, against the reference model."""
+    from oracle import fullsubnet_oracle as O
+    z, meta = load(golden_dir, name)
+    kw = meta["kw"]
+    params = O.make_params(seed=meta["seed_w"], gain=meta["gain"], mask_gain=meta["mask_gain"], gates=meta["gates"],
+                           fb_num_neighbors=kw["fb_num_neighbors"])
+    m = fsn.Model(**kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        crm = m(torch.from_numpy(z["mag"]).cuda().unsqueeze(1)).cpu().numpy()
+    assert crm.shape == z["crm"].shape
+    assert np.abs(crm - z["crm"]).max() <= 1e-4 * max(1.0, np.abs(z["crm"]).max() / 10)
+
+
+def test_fullsubnet_gru_training_step_runs_and_learns(fsn):
+    """The composed path under autograd: GRU forward-with-saves + BPTT through both blocks."""
+    from oracle import fullsubnet_oracle as O
+    from fullsubnet_amd.train import train_step
+    kw = dict(num_freqs=257, look_ahead=2, sequence_model="GRU", fb_num_neighbors=0, sb_num_neighbors=15,
+              fb_output_activate_function="ReLU", sb_output_activate_function=False, fb_model_hidden_size=512,
+              sb_model_hidden_size=384, norm_type="offline_laplace_norm", num_groups_in_drop_band=2, weight_init=False)
+    m = fsn.Model(**kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in O.make_params(seed=4, gates=3).items()}, strict=True)
+    m = m.cuda().train()
+    opt = fsn.ClipAdam(m.parameters(), lr=1e-3)
+    noisy = torch.from_numpy(O.make_noisy(4, 4096, seed=1)).cuda()
+    clean = torch.from_numpy(0.7 * O.make_noisy(4, 4096, seed=2)).cuda()
+    losses = [train_step(m, opt, noisy, clean).item() for _ in range(3)]
+    assert all(np.isfinite(losses)) and losses[2] < losses[0]
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
