@@ -2,7 +2,8 @@
 signature, same ``_train_epoch(epoch)`` (fullsubnet/trainer.py:33-76) with the data-parallel strategy
 of audio_zen/trainer/base_trainer.py:32 (DistributedDataParallel over the "nccl" = RCCL backend; the
 custom autograd function of fullsubnet_amd/train.py is an ordinary graph node, so DDP's bucketed
-gradient all-reduce works unchanged).  fp32 only (``use_amp = false``); TensorBoard / PESQ / STOI
+gradient all-reduce works unchanged).  fp32 compute (``use_amp = true`` is accepted and runs in fp32,
+a precision superset of the reference's fp16 autocast); TensorBoard / PESQ / STOI
 validation of the reference is host-side tooling and not part of this path."""
 import torch
 
@@ -30,8 +31,13 @@ class Trainer:
         tc = config.get("trainer", {}).get("train", {})
         self.epochs = tc.get("epochs", 1)
         self.clip_grad_norm_value = tc.get("clip_grad_norm_value", 10.0)
-        if config.get("meta", {}).get("use_amp", False):
-            raise NotImplementedError("use_amp = true: the HIP training kernels are fp32 (set meta.use_amp = false)")
+        # meta.use_amp = true (every shipped train TOML) asks for fp16 autocast + GradScaler
+        # (fullsubnet/trainer.py:56,63-69).  The HIP training kernels compute in fp32 - at least the
+        # precision the flag asks for - so the flag is accepted and loss scaling becomes the identity.
+        self.use_amp = bool(config.get("meta", {}).get("use_amp", False))
+        if self.use_amp and rank == 0:
+            print("fullsubnet_amd.Trainer: meta.use_amp = true -> computing in fp32 (no 16-bit kernels yet); "
+                  "GradScaler is not needed")
         self.last_loss = None
 
     def _train_epoch(self, epoch):
