@@ -627,6 +627,17 @@ FsnRecPlan fsn_lstm_rec_plan(int N, int H) {
     FsnRecPlan p;
     p.tiles = (N + 15) / 16;
     p.npad = p.tiles * 16;
+    // Few rows: one 16-row tile per CU leaves most CUs idle and makes every busy one stream the whole
+    // W_hh (2.4 MB) from L2 per step (~31 us/step, measured); below this many tiles the per-step
+    // kernels, which spread a step over (H/16) x tiles workgroups, are faster (batch 1: 21.4 -> 8.4 ms
+    // for 3 s of audio; break-even at ~160 tiles = batch 10).
+    static const int step_below = getenv("FSN_REC_STEP_BELOW") ? atoi(getenv("FSN_REC_STEP_BELOW")) : 160;
+    if (p.tiles < step_below) {
+        p.rt = 1;
+        p.main_wgs = 0;
+        p.left_tiles = p.tiles;
+        return p;
+    }
     if (p.tiles <= cus) {
         p.rt = 1;
         p.main_wgs = p.tiles;

@@ -25,6 +25,8 @@ class Model(nn.Module):
         # configurations of the shipped TOMLs run fused in libfsn_hip (fsn_fullsubnet_forward / fsn_enhance);
         # every other combination the reference constructor accepts (GRU, fb_num_neighbors > 0, other output
         # activations, the three extra norms) runs composed from SequenceModel blocks (_forward_composed)
+        from .base_model import BaseModel
+        BaseModel().norm_wrapper(norm_type)  # unknown norm: NotImplementedError here, like model.py:62
         self._fused = (sequence_model == "LSTM" and fb_num_neighbors == 0 and fb_output_activate_function == "ReLU"
                        and not sb_output_activate_function and norm_type in _lib.NORM_TYPES)
         self.fb_model = SequenceModel(num_freqs, num_freqs, fb_model_hidden_size, 2, False, sequence_model,

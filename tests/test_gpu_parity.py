@@ -205,6 +205,11 @@ def test_errors_are_loud(fsn):
     with pytest.raises(Exception):
         fsn.stft(torch.zeros(2, 4000), 512, 256, 512)  # CPU tensor: no fallback
     with pytest.raises(fsn._lib.FsnError):
-        fsn.stft(torch.zeros(2, 4000).cuda(), 400, 100, 400)  # unsupported FFT size -> error code
+        fsn.stft(torch.zeros(2, 4000).cuda(), 401, 100, 401)  # odd FFT size -> error code from the C ABI
+    with pytest.raises(fsn._lib.FsnError):
+        fsn.stft(torch.zeros(2, 100).cuda(), 512, 256, 512)  # shorter than the reflect padding
     with pytest.raises(NotImplementedError):
-        fsn.Model(norm_type="forgetting_norm", num_groups_in_drop_band=1, **MODEL_KW)
+        fsn.Model(norm_type="no_such_norm", num_groups_in_drop_band=1, **MODEL_KW)
+    m = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=1, **MODEL_KW).cuda().eval()
+    with pytest.raises(fsn._lib.FsnError):
+        m.enhance(torch.zeros(1, 4000).cuda(), n_fft=1024, hop_length=512)  # the fused path is 512 / 256 only
