@@ -10,5 +10,6 @@ from .acoustics.mask import (build_complex_ideal_ratio_mask, complex_mul, compre
 from .inferencer import Inferencer  # noqa: F401
 from .model import Model  # noqa: F401
 from .optim import ClipAdam  # noqa: F401
+from .streaming import StreamingEnhancer  # noqa: F401
 
 __version__ = "0.1.0"

@@ -760,6 +760,49 @@ extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_i
     return FSN_OK;
 }
 
+// Streaming form (frame-by-frame / chunked inference with carried state): T more steps from the state
+// (h, c) [N][H], which is updated in place.  Always on the per-step kernels.
+extern "C" int fsn_lstm_layer_forward_state(const float* x, long ldx, const float* w_ih, const float* w_hh,
+                                            const float* b_ih, const float* b_hh, int T, int N, int I, int H,
+                                            float* hseq, float* h_state, float* c_state, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+    FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
+    FSN_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && hseq && h_state && c_state && workspace, "NULL pointer argument");
+    if (workspace_bytes < fsn_lstm_layer_fwd_workspace_bytes(T, N, I, H)) {
+        fsn_set_error("lstm layer forward: workspace too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Ipad = fsn_round_up(I, 16);
+    Carver cv(workspace);
+    float* wih_p = cv.take<float>((size_t)4 * H * Ipad);
+    float* whh_p = cv.take<float>((size_t)4 * H * H);
+    float* bias = cv.take<float>((size_t)4 * H);
+    float* gx = cv.take<float>((size_t)T * N * 4 * H);
+    FSN_TRY(fsn_launch_pack(w_ih, wih_p, 4 * H, I, 4 * H, Ipad, s));
+    FSN_TRY(fsn_launch_pack(w_hh, whh_p, 4 * H, H, 4 * H, H, s));
+    FSN_TRY(fsn_launch_bias_sum(b_ih, b_hh, bias, 4 * H, 4 * H, s));
+    FsnGemmA a{};
+    a.kind = 0;
+    a.p0 = x;
+    a.ld = ldx;
+    FsnGemmC c{};
+    c.kind = 0;
+    c.p0 = gx;
+    c.bias = bias;
+    FSN_TRY(fsn_launch_gemm(a, wih_p, c, T * (N / 16), 4 * H / 16, Ipad / 16, s));
+    const size_t step = (size_t)N * H;
+    for (int t = 0; t < T; ++t)
+        FSN_TRY(fsn_launch_lstm_step(gx, whh_p, t ? hseq + (t - 1) * step : h_state, hseq + t * step, c_state,
+                                     (long)t * (N / 16), N / 16, H, 0, s));
+    if (hipMemcpyAsync(h_state, hseq + (size_t)(T - 1) * step, step * sizeof(float), hipMemcpyDeviceToDevice, s) !=
+        hipSuccess) {
+        fsn_set_error("state copy failed");
+        return FSN_ERR_LAUNCH;
+    }
+    return FSN_OK;
+}
+
 extern "C" size_t fsn_lstm_layer_bwd_workspace_bytes(int T, int N, int I, int H) {
     const int Ipad = fsn_round_up(I, 16);
     Carver cv(nullptr);

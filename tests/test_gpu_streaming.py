@@ -1,0 +1,85 @@
+"""Streaming (chunked, stateful) enhancement == the offline path on the same utterance.
+Needs a real MI355X:  python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fullsubnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MODEL_KW = dict(num_freqs=257, look_ahead=2, sequence_model="LSTM", fb_num_neighbors=0, sb_num_neighbors=15,
+                fb_output_activate_function="ReLU", sb_output_activate_function=False, fb_model_hidden_size=512,
+                sb_model_hidden_size=384, weight_init=False)
+
+
+@pytest.fixture(scope="module")
+def setup():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu tests need a ROCm device")
+    import fullsubnet_amd as fsn
+    fsn._lib.lib()
+    params = O.make_params(seed=0, gain=2.0, mask_gain=24.0)
+    m = fsn.Model(norm_type="cumulative_laplace_norm", num_groups_in_drop_band=1, **MODEL_KW)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    return fsn, m.cuda().eval(), params
+
+
+def run_stream(fsn, model, noisy, sizes):
+    from fullsubnet_amd.streaming import StreamingEnhancer
+    enh = StreamingEnhancer(model, batch_size=noisy.shape[0])
+    out, pos, lat = [], 0, []
+    for n in sizes:
+        out.append(enh.process(noisy[:, pos:pos + n]))
+        pos += n
+        lat.append(pos - sum(o.shape[1] for o in out))
+    assert pos == noisy.shape[1]
+    out.append(enh.flush())
+    return torch.cat(out, dim=1), lat
+
+
+@pytest.mark.parametrize("L,chunking", [(5003, "hop"), (5003, "random"), (4096, "one"), (4096, "frame3"), (700, "tiny")])
+def test_streaming_equals_offline(setup, L, chunking):
+    fsn, model, params = setup
+    noisy = torch.from_numpy(O.make_noisy(2, L, seed=17)).cuda()
+    if chunking == "hop":
+        sizes = [256] * (L // 256) + ([L % 256] if L % 256 else [])
+    elif chunking == "random":
+        rng = np.random.default_rng(3)
+        sizes = []
+        while sum(sizes) < L:
+            sizes.append(int(min(rng.integers(1, 900), L - sum(sizes))))
+    elif chunking == "one":
+        sizes = [L]
+    elif chunking == "frame3":
+        sizes = [768] * (L // 768) + ([L % 768] if L % 768 else [])
+    else:
+        sizes = [100, 1, 155, 1, 443]
+    got, lat = run_stream(fsn, model, noisy, sizes)
+    assert got.shape == noisy.shape
+    offline = model.enhance(noisy)  # the fused single-call path (fsn_enhance)
+    scale = offline.abs().max().item()
+    assert (got - offline).abs().max().item() <= 2e-3 * scale
+    want = O.full_band_crm_mask(noisy.cpu().numpy(), params, norm_type="cumulative_laplace_norm")
+    assert np.abs(got.cpu().numpy() - want).max() <= 2e-3 * np.abs(want).max()
+    if chunking == "hop":
+        # algorithmic latency: look_ahead frames + the frame being completed + the overlap-add partner
+        assert max(lat) <= (2 + 2) * 256
+
+
+def test_streaming_is_chunking_invariant_and_resettable(setup):
+    fsn, model, _ = setup
+    from fullsubnet_amd.streaming import StreamingEnhancer
+    noisy = torch.from_numpy(O.make_noisy(1, 6000, seed=5)).cuda()
+    a, _ = run_stream(fsn, model, noisy, [256] * 23 + [112])
+    b, _ = run_stream(fsn, model, noisy, [1000, 2000, 3000])
+    assert (a - b).abs().max().item() <= 2e-5 * a.abs().max().item()
+    enh = StreamingEnhancer(model, batch_size=1)
+    enh.process(noisy[:, :3000])
+    enh.reset()
+    c = torch.cat([enh.process(noisy), enh.flush()], dim=1)
+    assert (c - b).abs().max().item() <= 2e-5 * a.abs().max().item()
+    with pytest.raises(RuntimeError):
+        enh.process(noisy)
+    with pytest.raises(ValueError):
+        StreamingEnhancer(fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=1, **MODEL_KW).cuda())
