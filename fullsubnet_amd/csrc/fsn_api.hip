@@ -305,7 +305,7 @@ static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* g
             float* h_out = hseq + ((size_t)t * Npad + main_rows) * H;
             const float* h_prev = t ? hseq + ((size_t)(t - 1) * Npad + main_rows) * H : h_out;
             FSN_TRY(fsn_launch_lstm_step(gx_left, whh, h_prev, h_out, c_left, (long)t * left_stride + left_off,
-                                         r.left_tiles, H, t == 0, ls));
+                                         r.left_tiles, H, t == 0, ls, fork ? 1 : 0));
         }
     }
     if (fork) {

@@ -178,8 +178,10 @@ struct FsnRecPlan {
     int npad;        // padded row count (row stride of every [t][n] buffer)
 };
 FsnRecPlan fsn_lstm_rec_plan(int N, int H);
+// beside_persistent: the launch runs concurrently with a resident lstm_rec_kernel (left-over tiles) and must
+// use the small-footprint single-tile kernel to get a slot next to it
 int fsn_launch_lstm_step(const float* gx, const float* whh_p, const float* h_prev, float* h_out, float* c,
-                         long gx_rt0, int row_tiles, int H, int first, hipStream_t s);
+                         long gx_rt0, int row_tiles, int H, int first, hipStream_t s, int beside_persistent = 0);
 int fsn_launch_lstm_step_train(const float* gx, const float* whh_p, const float* h_prev, float* h_out,
                                const float* c_prev, float* c_out, float* gates_out, long gx_rt0, int row_tiles, int H,
                                int first, hipStream_t s);

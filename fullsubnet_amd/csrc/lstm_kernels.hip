@@ -332,12 +332,10 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_small_kernel(co
 // through LDS in a fixed order (deterministic); wave w < RTS then finishes row tile w.  RTS = 1 for
 // the few-row launches of inference (full-band model, left-over tiles), larger for the training step.
 template <int RTS>
-__global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict__ gx,
-                                                        const float* __restrict__ whh_p,
-                                                        const float* __restrict__ h_prev,
-                                                        float* __restrict__ h_out, const float* c_prev,
-                                                        float* c, float* __restrict__ gates_out, long gx_rt0,
-                                                        int row_tiles, int H, int first) {
+__device__ __forceinline__ void lstm_step_body(const float* __restrict__ gx, const float* __restrict__ whh_p,
+                                               const float* __restrict__ h_prev, float* __restrict__ h_out,
+                                               const float* c_prev, float* c, float* __restrict__ gates_out,
+                                               long gx_rt0, int row_tiles, int H, int first) {
     __shared__ f32x4 red[4][RTS][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
@@ -384,7 +382,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (!first) {
+        if (!first) {  // partials summed in wave order 0, 1, 2, 3
             v = red[0][rt][g][lane];
 #pragma unroll
             for (int w = 1; w < 4; ++w) {
@@ -412,6 +410,83 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
             gp[2 * H] = gg;
             gp[3 * H] = og;
         }
+    }
+}
+
+template <int RTS>
+__global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict__ gx,
+                                                        const float* __restrict__ whh_p,
+                                                        const float* __restrict__ h_prev,
+                                                        float* __restrict__ h_out, const float* c_prev,
+                                                        float* c, float* __restrict__ gates_out, long gx_rt0,
+                                                        int row_tiles, int H, int first) {
+    lstm_step_body<RTS>(gx, whh_p, h_prev, h_out, c_prev, c, gates_out, gx_rt0, row_tiles, H, first);
+}
+
+// The single-tile form also runs the left-over tiles of the sub-band model NEXT TO the resident
+// persistent workgroups (12 waves x 152 registers = 456 of the 512 per SIMD lane for the layer-0
+// kernel): it only gets a slot there if it needs <= 56 registers and <= 12 KB of LDS - hence this
+// inference-only instance without the training outputs (40 + 16 registers; checked by
+// tests/test_host_cpu.py on the code object).  With more it silently waits for the 32 ms persistent
+// kernel to end (measured: +1.4 ms per batch).
+__global__ __launch_bounds__(256) void lstm_step1_kernel(const float* __restrict__ gx,
+                                                         const float* __restrict__ whh_p,
+                                                         const float* __restrict__ h_prev,
+                                                         float* __restrict__ h_out, float* __restrict__ c,
+                                                         long gx_rt0, int H, int first) {
+    __shared__ f32x4 red[3][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int ug = blockIdx.x, rtile = blockIdx.y;
+    const int KC = H >> 4, CT = 4 * KC;
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!first) {
+        const int kc0 = wave * (KC >> 2), kc1 = kc0 + (KC >> 2);
+        const float* ap = h_prev + ((long)rtile * 16 + lr) * H + 4 * lq;
+#pragma unroll 4
+        for (int kc = kc0; kc < kc1; ++kc) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kc * 16);
+            f32x4 b[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                b[g] = *reinterpret_cast<const f32x4*>(whh_p + (((long)(g * KC + ug) * KC + kc) * 64 + lane) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = mfma16(a[j], b[g][j], acc[g]);
+        }
+        if (wave > 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) red[wave - 1][g][lane] = acc[g];
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
+    // everything below accumulates in place: a second live copy of the 16 partial sums is what pushes the
+    // templated form over the register budget
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (!first) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                const f32x4 r = red[w][g][lane];
+                acc[g] = f32x4{acc[g][0] + r[0], acc[g][1] + r[1], acc[g][2] + r[2], acc[g][3] + r[3]};
+            }
+        }
+        const f32x4 x = *reinterpret_cast<const f32x4*>(gx + (((gx_rt0 + rtile) * CT + g * KC + ug) * 64 + lane) * 4);
+        acc[g] = f32x4{acc[g][0] + x[0], acc[g][1] + x[1], acc[g][2] + x[2], acc[g][3] + x[3]};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long idx = ((long)rtile * 16 + 4 * lq + i) * H + ug * 16 + lr;
+        const float c_old = first ? 0.f : c[idx];
+        const float ig = sigmoid_f(acc[0][i]), fg = sigmoid_f(acc[1][i]);
+        const float gg = tanhf(acc[2][i]), og = sigmoid_f(acc[3][i]);
+        const float cn = fg * c_old + ig * gg;
+        c[idx] = cn;
+        h_out[idx] = og * tanhf(cn);
     }
 }
 
@@ -706,7 +781,16 @@ int fsn_launch_lstm_rec(const float* gx, const FsnSbInput* xin, const float* whh
 // One step for `row_tiles` 16-row tiles: gx tiles gx_rt0 .. gx_rt0 + row_tiles - 1 of the fragment-
 // ordered projection, h_prev / h_out / c point at the first of those rows.
 int fsn_launch_lstm_step(const float* gx, const float* whh_p, const float* h_prev, float* h_out, float* c,
-                         long gx_rt0, int row_tiles, int H, int first, hipStream_t s) {
+                         long gx_rt0, int row_tiles, int H, int first, hipStream_t s, int beside_persistent) {
+    if (beside_persistent) {  // must fit next to a resident persistent workgroup, see lstm_step1_kernel
+        if (H % 64 != 0) {
+            fsn_set_error("lstm_step: hidden size %d must be a multiple of 64", H);
+            return FSN_ERR_ARG;
+        }
+        hipLaunchKernelGGL(lstm_step1_kernel, dim3(H / 16, row_tiles), dim3(256), 0, s, gx, whh_p, h_prev, h_out, c,
+                           gx_rt0, H, first);
+        return fsn_check_launch("lstm_step1_kernel");
+    }
     return fsn_launch_lstm_step_train(gx, whh_p, h_prev, h_out, c, c, nullptr, gx_rt0, row_tiles, H, first, s);
 }
 
@@ -726,7 +810,8 @@ int fsn_launch_lstm_step_train(const float* gx, const float* whh_p, const float*
                        h_out, c_prev, c_out, gates_out, gx_rt0, row_tiles, H, first)
     if (rts == 4) FSN_STEP_CASE(4);
     else if (rts == 2) FSN_STEP_CASE(2);
-    else FSN_STEP_CASE(1);
+    else
+        FSN_STEP_CASE(1);
 #undef FSN_STEP_CASE
     return fsn_check_launch("lstm_step_kernel");
 }

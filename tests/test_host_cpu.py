@@ -124,3 +124,38 @@ def test_subband_input_function_matches_unfold_cat_norm_dropband():
         (a * w).sum().backward()
         (ref * w).sum().backward()
         assert torch.allclose(fb.grad, fb2.grad, rtol=1e-4, atol=1e-6), (B, F)
+
+
+def test_leftover_step_kernel_fits_next_to_persistent_kernel(tmp_path):
+    """The left-over sub-band tiles run as lstm_step1_kernel launches CONCURRENTLY with the persistent
+    lstm_rec_kernel.  That only happens if both fit on a CU together: 12 persistent waves =
+    3 per SIMD x their register count, plus one step wave, within the 512-entry register file, and both
+    LDS allocations within 160 KB.  A compiler or source change that breaks this costs ~1.4 ms per batch
+    silently (the step kernels then queue behind the 32 ms kernel), so the budget is checked on the
+    compiled code object's metadata."""
+    import re
+    import shutil
+    import subprocess
+    from fullsubnet_amd import build as b
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "lstm.s"
+    flags = [f for f in b.FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", os.path.join(b.CSRC, "lstm_kernels.hip"), "-o", str(out)],
+                   check=True, capture_output=True)
+    meta = {}
+    for blk in out.read_text().split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        meta[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
+                      for k in ("vgpr_count", "group_segment_fixed_size", "vgpr_spill_count")}
+    step = next(v for k, v in meta.items() if "lstm_step1_kernel" in k)
+    recs = {k: v for k, v in meta.items() if "lstm_rec_kernelILi384ELi4ELi2E" in k}
+    assert len(recs) == 2 and step["vgpr_spill_count"] == 0
+    gran = lambda n: (n + 7) // 8 * 8  # VGPR allocation granule on gfx950
+    for name, rec in recs.items():
+        assert rec["vgpr_spill_count"] == 0, name
+        assert 3 * gran(rec["vgpr_count"]) + gran(step["vgpr_count"]) <= 512, (name, rec, step)
+    # dynamic LDS of the persistent kernel: 16 RT (H + 4) floats for h + the double-buffered layer-0 input tile
+    lds_rec = 4 * (64 * 388) + 4 * (2 * 64 * 36)
+    assert lds_rec + 3 * step["group_segment_fixed_size"] <= 160 * 1024
