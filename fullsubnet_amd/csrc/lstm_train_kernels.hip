@@ -358,17 +358,13 @@ int fsn_launch_colsum(const float* A, long lda, float* out, int cols, long rows,
 int fsn_launch_bptt_step(const float* dh_out, const float* dgates_next, const float* whhT_p, float* dc,
                          const float* gates, const float* c_t, const float* c_prev, float* dgates, int row_tiles, int H,
                          int last, int first, hipStream_t s) {
-    static const int force = getenv("FSN_BPTT_TILE") ? atoi(getenv("FSN_BPTT_TILE")) : 0;  // e.g. 22 = 2 x 2
-    const int cfg = force ? force : (row_tiles >= 64 && H % 32 == 0 ? 22 : 11);
+    // measured at 129 row tiles (tools/bench_train.py): 2 x 2 72.2 ms per training step, 1 x 2 73.0, 2 x 1 75.1,
+    // 1 x 1 76.3, 4 x 2 76.8, 2 x 4 77.8, 4 x 4 89.0
+    const int cfg = row_tiles >= 64 && H % 32 == 0 ? 22 : 11;
 #define FSN_BPTT_CASE(R, C)                                                                                        \
     hipLaunchKernelGGL((bptt_step_kernel<R, C>), dim3(H / 16 / C, (row_tiles + R - 1) / R), dim3(256), 0, s, dh_out, \
                        dgates_next, whhT_p, dc, gates, c_t, c_prev, dgates, row_tiles, H, last, first)
     if (cfg == 22) FSN_BPTT_CASE(2, 2);
-    else if (cfg == 42) FSN_BPTT_CASE(4, 2);
-    else if (cfg == 24) FSN_BPTT_CASE(2, 4);
-    else if (cfg == 44) FSN_BPTT_CASE(4, 4);
-    else if (cfg == 21) FSN_BPTT_CASE(2, 1);
-    else if (cfg == 12) FSN_BPTT_CASE(1, 2);
     else FSN_BPTT_CASE(1, 1);
 #undef FSN_BPTT_CASE
     return fsn_check_launch("bptt_step_kernel");

@@ -2,6 +2,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "../fullsubnet_amd/csrc/lstm_kernels.hip"
+#include "experimental_rec1.hip"
 void fsn_set_error(const char*, ...) {}
 int fsn_check_launch(const char*) { return hipGetLastError() == hipSuccess ? 0 : -3; }
 __global__ void fill_kernel(float* p, size_t n, unsigned seed, float scale) {
