@@ -113,13 +113,20 @@ def main():
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback for the product path)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()  # one rank per GPU when launched as the contract says
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)  # RCCL on ROCm
+        # "nccl" is RCCL on ROCm.  BENCH_DIST_BACKEND=gloo exists only to exercise the multi-rank control
+        # flow on a single-GPU box (ranks then share the device; RCCL refuses that).
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     from fullsubnet_amd import _lib
     from fullsubnet_amd.parallel import shard_bounds
