@@ -46,7 +46,7 @@ MAC_REC_L1 = 1536 * 384
 
 def build_model(device):
     import fullsubnet_amd
-    from oracle.fullsubnet_oracle import make_params  # seeded weights only (not a compute path)
+    from fsn_synthetic import make_params  # seeded weights
     params = make_params(seed=0, gain=2.0, mask_gain=24.0)
     model = fullsubnet_amd.Model(num_freqs=F, look_ahead=LA, sequence_model="LSTM", fb_num_neighbors=0,
                                  sb_num_neighbors=NB, fb_output_activate_function="ReLU",
@@ -130,7 +130,7 @@ def main():
 
     from fullsubnet_amd import _lib
     from fullsubnet_amd.parallel import shard_bounds
-    from oracle.fullsubnet_oracle import make_noisy  # seeded synthetic input generator
+    from fsn_synthetic import make_noisy  # seeded synthetic input
 
     length = int(round(args.seconds * SR))
     T = 1 + length // HOP

@@ -423,59 +423,7 @@ def full_band_crm_mask(noisy, params, n_fft=512, hop_length=256, win_length=512,
 
 
 # --------------------------------------------------------------------------- #
-# deterministic synthetic inputs / weights shared by tests, smoke and bench
+# deterministic synthetic inputs / weights: fsn_synthetic.py (shared with bench.py and tools/, which
+# may not import the oracle outside the cpu_baseline leg); re-exported here for the tests
 # --------------------------------------------------------------------------- #
-FULLSUBNET_SHAPES = dict(num_freqs=257, fb_hidden=512, sb_hidden=384, sb_num_neighbors=15)
-
-
-def make_params(seed=0, num_freqs=257, fb_hidden=512, sb_hidden=384, sb_num_neighbors=15,
-                gain=1.0, mask_gain=1.0, dtype=np.float32, gates=4, fb_num_neighbors=0):
-    """Random weights with the reference state_dict names/shapes.
-
-    U(-1/sqrt(H), 1/sqrt(H)) like nn.LSTM / nn.Linear defaults, times ``gain``;
-    the sub-band output layer (the compressed mask itself) is additionally
-    scaled by ``mask_gain`` so that the mask spans +-10 and crosses the +-9.9
-    clamp of decompress_cIRM - with default init it stays within +-0.07 and a
-    1e-4 absolute check would be vacuous.
-    """
-    rng = np.random.default_rng(seed)
-    p = {}
-
-    def lstm(prefix, I, H):
-        k = 1.0 / np.sqrt(H)
-        for layer, isz in ((0, I), (1, H)):
-            p[f"{prefix}.sequence_model.weight_ih_l{layer}"] = rng.uniform(-k, k, (gates * H, isz))
-            p[f"{prefix}.sequence_model.weight_hh_l{layer}"] = rng.uniform(-k, k, (gates * H, H))
-            p[f"{prefix}.sequence_model.bias_ih_l{layer}"] = rng.uniform(-k, k, (gates * H,))
-            p[f"{prefix}.sequence_model.bias_hh_l{layer}"] = rng.uniform(-k, k, (gates * H,))
-
-    def fc(prefix, I, O):
-        k = 1.0 / np.sqrt(I)
-        p[f"{prefix}.fc_output_layer.weight"] = rng.uniform(-k, k, (O, I))
-        p[f"{prefix}.fc_output_layer.bias"] = rng.uniform(-k, k, (O,))
-
-    lstm("fb_model", num_freqs, fb_hidden)
-    fc("fb_model", fb_hidden, num_freqs)
-    lstm("sb_model", (2 * sb_num_neighbors + 1) + (2 * fb_num_neighbors + 1), sb_hidden)
-    fc("sb_model", sb_hidden, 2)
-    for k in ("sb_model.fc_output_layer.weight", "sb_model.fc_output_layer.bias"):
-        p[k] = p[k] * mask_gain
-    return {k: (v * gain).astype(dtype) for k, v in p.items()}
-
-
-def make_noisy(batch, length, seed=1234, dtype=np.float32):
-    """Speech-like synthetic mix: 5 harmonics of f0 in U(100,300) Hz with
-    4 Hz AM, plus white noise at an SNR drawn from [-5, 20] dB, scaled to ~ -26 dBFS."""
-    rng = np.random.default_rng(seed)
-    t = np.arange(length) / 16000.0
-    out = np.empty((batch, length), dtype=np.float64)
-    for b in range(batch):
-        f0 = rng.uniform(100, 300)
-        clean = sum(np.sin(2 * np.pi * f0 * (h + 1) * t + rng.uniform(0, 6.28)) / (h + 1) for h in range(5))
-        clean *= 0.5 * (1 + np.sin(2 * np.pi * 4 * t + rng.uniform(0, 6.28)))
-        noise = rng.standard_normal(length)
-        snr = rng.uniform(-5, 20)
-        noise *= np.sqrt((clean ** 2).mean() / ((noise ** 2).mean() * 10 ** (snr / 10)))
-        mix = clean + noise
-        out[b] = 0.05 * mix / np.sqrt((mix ** 2).mean())
-    return out.astype(dtype)
+from fsn_synthetic import FULLSUBNET_SHAPES, make_noisy, make_params  # noqa: E402,F401

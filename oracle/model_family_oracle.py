@@ -17,6 +17,8 @@ from __future__ import annotations
 import numpy as np
 
 from . import fullsubnet_oracle as O
+from fsn_synthetic import (IMPROVED_16K, IMPROVED_48K, make_fast_params, make_fullband_params,  # noqa: F401
+                           make_improved_params)
 
 
 def melscale_fbanks(n_freqs=257, f_min=0.0, f_max=8000.0, n_mels=64, sample_rate=16000):
@@ -104,55 +106,9 @@ def fullband_baseline_forward(noisy_mag, params, look_ahead=2, dtype=np.float32)
     return np.ascontiguousarray(o.reshape(B, 2, F, T)[..., look_ahead:])
 
 
-def _block_params(rng, p, prefix, I, H, O_, num_layers):
-    k = 1.0 / np.sqrt(H)
-    for layer in range(num_layers):
-        isz = I if layer == 0 else H
-        p[f"{prefix}.sequence_model.weight_ih_l{layer}"] = rng.uniform(-k, k, (4 * H, isz))
-        p[f"{prefix}.sequence_model.weight_hh_l{layer}"] = rng.uniform(-k, k, (4 * H, H))
-        p[f"{prefix}.sequence_model.bias_ih_l{layer}"] = rng.uniform(-k, k, (4 * H,))
-        p[f"{prefix}.sequence_model.bias_hh_l{layer}"] = rng.uniform(-k, k, (4 * H,))
-    if O_:
-        p[f"{prefix}.fc_output_layer.weight"] = rng.uniform(-k, k, (O_, H))
-        p[f"{prefix}.fc_output_layer.bias"] = rng.uniform(-k, k, (O_,))
-
-
-def make_fast_params(seed=0, gain=2.0, out_gain=8.0, num_mels=64, num_freqs=257, bottleneck_hidden=384, bottleneck_layers=2,
-                     nn_noisy=5, nn_enc=0, dtype=np.float32):
-    """Random weights with the reference state_dict names of fast_fullsubnet.model.Model (without
-    ``mel_scale.fb``, which the tests take from the golden file / the product)."""
-    rng = np.random.default_rng(seed)
-    p = {}
-    _block_params(rng, p, "encoder.0", num_mels, 384, 0, 1)
-    _block_params(rng, p, "encoder.1", 384, 257, num_mels, 1)
-    _block_params(rng, p, "bottleneck", (2 * nn_noisy + 1) + (2 * nn_enc + 1), bottleneck_hidden, 1, bottleneck_layers)
-    _block_params(rng, p, "decoder_lstm.0", 2 * num_mels, 512, 0, 1)
-    _block_params(rng, p, "decoder_lstm.1", 512, 512, 2 * num_freqs, 1)
-    for k in ("decoder_lstm.1.fc_output_layer.weight", "decoder_lstm.1.fc_output_layer.bias"):
-        p[k] = p[k] * out_gain  # the mask itself: spread it over a few units so that 1e-4 absolute means something
-    return {k: (v * gain).astype(dtype) for k, v in p.items()}
-
-
-def make_fullband_params(seed=0, gain=2.0, out_gain=8.0, num_freqs=257, hidden=512, dtype=np.float32):
-    rng = np.random.default_rng(seed)
-    p = {}
-    _block_params(rng, p, "fullband_model", num_freqs, hidden, 2 * num_freqs, 3)
-    for k in ("fullband_model.fc_output_layer.weight", "fullband_model.fc_output_layer.bias"):
-        p[k] = p[k] * out_gain
-    return {k: (v * gain).astype(dtype) for k, v in p.items()}
-
-
 # --------------------------------------------------------------------------- #
 # Improved FullSubNet     recipes/dns_interspeech_2020/improved_fullsubnet/model.py
 # --------------------------------------------------------------------------- #
-IMPROVED_16K = dict(n_fft=512, hop_length=128, win_length=512, fdrc=0.5, num_freqs=257, freq_cutoffs=[20, 80],
-                    sb_num_center_freqs=[1, 4, 8], sb_num_neighbor_freqs=[15, 15, 15], fb_num_center_freqs=[1, 4, 8],
-                    fb_num_neighbor_freqs=[15, 15, 15], fb_hidden_size=512, sb_hidden_size=384)
-# the reference's own 48 kHz example (model.py:603-620)
-IMPROVED_48K = dict(n_fft=960, hop_length=480, win_length=960, fdrc=0.5, num_freqs=481, freq_cutoffs=[20, 120, 240],
-                    sb_num_center_freqs=[1, 4, 20, 60], sb_num_neighbor_freqs=[15, 15, 15, 15],
-                    fb_num_center_freqs=[1, 4, 20, 60], fb_num_neighbor_freqs=[15, 15, 15, 15], fb_hidden_size=512,
-                    sb_hidden_size=384)
 
 
 def _norm_eps32(x, dtype=np.float32):
@@ -205,18 +161,3 @@ def improved_fullsubnet_forward(y, params, cfg, window, dtype=np.float32):
     out = O.istft((crm[:, 0] * re).astype(dtype), (crm[:, 1] * im).astype(dtype), n_fft, hop, cfg["win_length"],
                   length=y.shape[-1], window=window, dtype=dtype)
     return out[:, None, :]
-
-
-def make_improved_params(cfg, seed=0, gain=1.5, mask_gain=6.0, dtype=np.float32):
-    """Random weights with the reference state_dict names of improved_fullsubnet.model.Model."""
-    rng = np.random.default_rng(seed)
-    p = {}
-    F = cfg["num_freqs"] - 1
-    _block_params(rng, p, "fb_model", F, cfg["fb_hidden_size"], F, 2)
-    for i, (sc, sn, fc, fn) in enumerate(zip(cfg["sb_num_center_freqs"], cfg["sb_num_neighbor_freqs"],
-                                             cfg["fb_num_center_freqs"], cfg["fb_num_neighbor_freqs"])):
-        pre = f"sb_model.sb_models.{i}"
-        _block_params(rng, p, pre, (sc + 2 * sn) + (fc + 2 * fn), cfg["sb_hidden_size"], 2 * sc, 2)
-        for k in (f"{pre}.fc_output_layer.weight", f"{pre}.fc_output_layer.bias"):
-            p[k] = p[k] * mask_gain
-    return {k: (v * gain).astype(dtype) for k, v in p.items()}

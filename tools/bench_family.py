@@ -9,9 +9,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fullsubnet_amd  # noqa: E402
 from fullsubnet_amd import decompress_cIRM, istft, stft  # noqa: E402
-from oracle.fullsubnet_oracle import make_noisy  # noqa: E402
-from oracle.model_family_oracle import (IMPROVED_16K, IMPROVED_48K, make_fast_params, make_fullband_params,  # noqa: E402
-                                        make_improved_params)
+from fsn_synthetic import (IMPROVED_16K, IMPROVED_48K, make_fast_params, make_fullband_params,  # noqa: E402
+                           make_improved_params, make_noisy)
 
 which = sys.argv[1] if len(sys.argv) > 1 else "fast"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else {"fast": 256, "improved48": 32, "improved16": 32}.get(which, 1)

@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fullsubnet_amd  # noqa: E402
 from fullsubnet_amd.streaming import StreamingEnhancer  # noqa: E402
-from oracle.fullsubnet_oracle import make_noisy, make_params  # noqa: E402
+from fsn_synthetic import make_noisy, make_params  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 1

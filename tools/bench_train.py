@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fullsubnet_amd  # noqa: E402
 from fullsubnet_amd.train import train_step  # noqa: E402
-from oracle.fullsubnet_oracle import make_noisy, make_params  # noqa: E402
+from fsn_synthetic import make_noisy, make_params  # noqa: E402
 
 B, L = int(sys.argv[1]) if len(sys.argv) > 1 else 16, 49152
 model = fullsubnet_amd.Model(num_freqs=257, look_ahead=2, sequence_model="LSTM", fb_num_neighbors=0,
