@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include "fsn_common.h"
 
 // ---- errors ---------------------------------------------------------------------------------
@@ -251,7 +253,7 @@ static CoreWs core_carve(Carver& cv, const CoreDims& d, int norm_type) {
     w.gx_fb = cv.take<float>(rows_fb * 4 * d.Hf);
     w.hseq_fb0 = cv.take<float>(rows_fb * d.Hf);
     w.hseq_fb1 = cv.take<float>(rows_fb * d.Hf);
-    w.c_fb = cv.take<float>((size_t)d.Npad_fb * d.Hf);
+    w.c_fb = cv.take<float>((size_t)2 * d.Npad_fb * d.Hf);  // one cell state per layer (wavefront)
     w.fb_out = cv.take<float>((size_t)d.B * d.Tp * d.FP);
     w.binsum = cv.take<double>((size_t)d.B * d.FP);
     const bool cum = norm_type == FSN_NORM_CUMULATIVE_LAPLACE;
@@ -260,7 +262,7 @@ static CoreWs core_carve(Carver& cv, const CoreDims& d, int norm_type) {
     w.gx_sb = cv.take<float>(rows_sb * 4 * d.Hs);
     w.hseq_sb0 = cv.take<float>(rows_sb * d.Hs);
     w.hseq_sb1 = cv.take<float>(rows_sb * d.Hs);
-    w.c_left = cv.take<float>((size_t)(d.rec.left_tiles > 0 ? d.rec.left_tiles : 1) * 16 * d.Hs);
+    w.c_left = cv.take<float>((size_t)2 * (d.rec.left_tiles > 0 ? d.rec.left_tiles : 1) * 16 * d.Hs);
     return w;
 }
 
@@ -323,6 +325,11 @@ static int run_sb_recurrence(const float* gx, const FsnSbInput* xin, const float
     return run_recurrence(gx, xin, gx_left, left_stride, left_off, whh, hseq, c_left, d.Tp, d.Npad, d.Hs, d.rec, s);
 }
 
+// below this many sub-band row tiles (batch <= 5) the two layers of the small-batch step path also run as
+// a wavefront; measured: batch 4 14.4 -> 13.5 ms, batch 8 (129 tiles) 22.4 -> 22.1, batch 1 unchanged
+// (host-launch bound there)
+constexpr int kWavefrontBelowTiles = 96;
+
 static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float* magT, const CoreDims& d,
                     const CoreWs& w, float* crm_r, float* crm_i, hipStream_t s) {
     const Packed p = packed_layout(cfg);
@@ -342,41 +349,31 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
     const int fb_rt = d.Tp * d.Npad_fb / 16;
     FsnGemmA a{};
     FsnGemmC c{};
-    for (int layer = 0; layer < 2; ++layer) {
-        {
-            StageTimer st(ST_FB_GEMM, s);
-            a = FsnGemmA{};
-            c = FsnGemmC{};
-            if (layer == 0) {
-                a.kind = 1;
-                a.p0 = magT;
-                a.den = w.den_fb;
-                a.den_mode = cum ? 1 : 0;
-                a.B = d.B;
-                a.Tp = d.Tp;
-                a.F = d.F;
-                a.FP = d.FP;
-                a.Npad = d.Npad_fb;
-            } else {
-                a.kind = 0;
-                a.p0 = w.hseq_fb0;
-                a.ld = d.Hf;
-            }
-            c.kind = 0;
-            c.p0 = w.gx_fb;
-            c.bias = pk + (layer == 0 ? p.fb_b0 : p.fb_b1);
-            FSN_TRY(fsn_launch_gemm(a, pk + (layer == 0 ? p.fb_wih0 : p.fb_wih1), c, fb_rt, 4 * d.Hf / 16,
-                                    layer == 0 ? d.FP / 16 : d.Hf / 16, s));
-        }
-        {
-            StageTimer st(ST_FB_REC, s);
-            float* hseq = layer == 0 ? w.hseq_fb0 : w.hseq_fb1;
-            const float* whh = pk + (layer == 0 ? p.fb_whh0 : p.fb_whh1);
-            const size_t step = (size_t)d.Npad_fb * d.Hf;
-            for (int t = 0; t < d.Tp; ++t)
-                FSN_TRY(fsn_launch_lstm_step(w.gx_fb, whh, t ? hseq + (t - 1) * step : hseq, hseq + t * step,
-                                             w.c_fb, (long)t * (d.Npad_fb / 16), d.Npad_fb / 16, d.Hf, t == 0, s));
-        }
+    {
+        StageTimer st(ST_FB_GEMM, s);
+        a = FsnGemmA{};
+        c = FsnGemmC{};
+        a.kind = 1;
+        a.p0 = magT;
+        a.den = w.den_fb;
+        a.den_mode = cum ? 1 : 0;
+        a.B = d.B;
+        a.Tp = d.Tp;
+        a.F = d.F;
+        a.FP = d.FP;
+        a.Npad = d.Npad_fb;
+        c.kind = 0;
+        c.p0 = w.gx_fb;
+        c.bias = pk + p.fb_b0;
+        FSN_TRY(fsn_launch_gemm(a, pk + p.fb_wih0, c, fb_rt, 4 * d.Hf / 16, d.FP / 16, s));
+    }
+    {
+        // N = B rows only: a chain of tiny dependent launches, so the two layers advance as a wavefront
+        // (layer 1 at step t next to layer 0 at step t + 1): T' + 1 launches instead of 2 T'
+        StageTimer st(ST_FB_REC, s);
+        FSN_TRY(fsn_launch_lstm_wavefront2(w.gx_fb, d.Npad_fb / 16, 0, pk + p.fb_whh0, pk + p.fb_wih1, pk + p.fb_b1,
+                                           pk + p.fb_whh1, w.hseq_fb0, w.hseq_fb1, d.Npad_fb, 0, w.c_fb,
+                                           w.c_fb + (size_t)d.Npad_fb * d.Hf, d.Tp, d.Npad_fb / 16, d.Hf, s));
     }
     {
         StageTimer st(ST_FB_GEMM, s);
@@ -432,7 +429,16 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         c.bias = pk + p.sb_b0;
         FSN_TRY(fsn_launch_gemm(a, pk + p.sb_wih0, c, d.Tp * d.rec.left_tiles, 4 * d.Hs / 16, p.sb_kin_pad / 16, s));
     }
-    {
+    // Small batches (no persistent part): both layers as one wavefront of per-step launches on the
+    // projection computed above.
+    const bool sb_wave = d.rec.main_wgs == 0 && d.rec.left_tiles < kWavefrontBelowTiles;
+    if (sb_wave) {
+        StageTimer st(ST_SB_REC_L0, s);
+        FSN_TRY(fsn_launch_lstm_wavefront2(w.gx_sb, d.rec.left_tiles, 0, pk + p.sb_whh0, pk + p.sb_wih1, pk + p.sb_b1,
+                                           pk + p.sb_whh1, w.hseq_sb0, w.hseq_sb1, d.Npad, 0, w.c_left,
+                                           w.c_left + (size_t)d.rec.left_tiles * 16 * d.Hs, d.Tp, d.rec.left_tiles,
+                                           d.Hs, s));
+    } else {
         StageTimer st(ST_SB_REC_L0, s);
         FsnSbInput xin{};
         xin.mag = magT;
@@ -452,7 +458,7 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         FSN_TRY(run_sb_recurrence(nullptr, &xin, w.gx_sb, d.rec.left_tiles, 0, pk + p.sb_whh0, w.hseq_sb0, w.c_left,
                                   d, s));
     }
-    {
+    if (!sb_wave) {
         StageTimer st(ST_SB_GEMM_L1, s);
         a = FsnGemmA{};
         c = FsnGemmC{};
@@ -464,7 +470,7 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         c.bias = pk + p.sb_b1;
         FSN_TRY(fsn_launch_gemm(a, pk + p.sb_wih1, c, sb_rt, 4 * d.Hs / 16, d.Hs / 16, s));
     }
-    {
+    if (!sb_wave) {
         StageTimer st(ST_SB_REC_L1, s);
         FSN_TRY(run_sb_recurrence(w.gx_sb, nullptr, w.gx_sb, d.rec.tiles, main_rows / 16, pk + p.sb_whh1, w.hseq_sb1,
                                   w.c_left, d, s));

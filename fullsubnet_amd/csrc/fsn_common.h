@@ -189,3 +189,6 @@ int fsn_launch_lstm_step_train(const float* gx, const float* whh_p, const float*
 // input projection of the sub-band model's first layer is computed inside the kernel from xin.
 int fsn_launch_lstm_rec(const float* gx, const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad,
                         int H, int RT, int main_wgs, hipStream_t s);
+int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, const float* whh0_p, const float* wih1_p,
+                               const float* bias1, const float* whh1_p, float* hseq0, float* hseq1, long hs_stride,
+                               long hs_off, float* c0, float* c1, int T, int row_tiles, int H, hipStream_t s);

@@ -486,6 +486,132 @@ __global__ __launch_bounds__(256) void lstm_step1_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-layer wavefront step: ONE launch advances layer 0 by step i and layer 1 by step i - 1
+// (blockIdx.z picks the job), so a two-layer LSTM over T frames is T + 1 dependent launches instead
+// of 2 T.  Used where the recurrence is a chain of tiny latency-bound launches: the full-band model
+// (N = B rows) and the sub-band model of small batches.  The layer-1 job has no precomputed input
+// projection (its input row h0_t has only just been produced): it accumulates x W_ih^T and
+// h W_hh^T in the same 4-way split-K pass and adds the bias in the epilogue.
+struct FsnStepJob {
+    const float* gx;     // layer-0 form: fragment-ordered projection incl. bias; else NULL
+    const float* xw_p;   // layer-1 form: packed W_ih [4H/16][kx_chunks][64][4]
+    const float* x;      // layer-1 form: input rows [rows][ldx] (h of the layer below at this step)
+    const float* bias;   // layer-1 form: b_ih + b_hh [4H]
+    const float* whh_p;
+    const float* h_prev;
+    float* h_out;
+    float* c;
+    long gx_rt0;
+    int kx_chunks, ldx, first, active;
+};
+
+__global__ __launch_bounds__(256) void lstm_step2_kernel(const FsnStepJob ja, const FsnStepJob jb, int H) {
+    const FsnStepJob& job = blockIdx.z == 0 ? ja : jb;
+    if (!job.active) return;
+    __shared__ f32x4 red[3][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int ug = blockIdx.x, rtile = blockIdx.y;
+    const int KC = H >> 4, CT = 4 * KC;
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool both = job.xw_p && !job.first && job.kx_chunks == KC;
+    if (both) {
+        // layer-1 job in steady state: x W_ih^T and h W_hh^T share one loop, so that the loads of both
+        // products are in flight together (two back-to-back loops would pay the L2 latency twice)
+        const int kc0 = wave * (KC >> 2), kc1 = kc0 + (KC >> 2);
+        const float* ax = job.x + ((long)rtile * 16 + lr) * job.ldx + 4 * lq;
+        const float* ah = job.h_prev + ((long)rtile * 16 + lr) * H + 4 * lq;
+#pragma unroll 2
+        for (int kc = kc0; kc < kc1; ++kc) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ax + kc * 16);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(ah + kc * 16);
+            f32x4 b0[4], b1[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const long o = (((long)(g * KC + ug) * KC + kc) * 64 + lane) * 4;
+                b0[g] = *reinterpret_cast<const f32x4*>(job.xw_p + o);
+                b1[g] = *reinterpret_cast<const f32x4*>(job.whh_p + o);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = mfma16(a0[j], b0[g][j], acc[g]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = mfma16(a1[j], b1[g][j], acc[g]);
+        }
+    }
+    if (job.xw_p && !both) {
+        const int q = job.kx_chunks >> 2, kc0 = wave * q, kc1 = kc0 + q;
+        const float* ap = job.x + ((long)rtile * 16 + lr) * job.ldx + 4 * lq;
+#pragma unroll 2
+        for (int kc = kc0; kc < kc1; ++kc) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kc * 16);
+            f32x4 b[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                b[g] = *reinterpret_cast<const f32x4*>(job.xw_p +
+                                                       (((long)(g * KC + ug) * job.kx_chunks + kc) * 64 + lane) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = mfma16(a[j], b[g][j], acc[g]);
+        }
+    }
+    if (!job.first && !both) {
+        const int kc0 = wave * (KC >> 2), kc1 = kc0 + (KC >> 2);
+        const float* ap = job.h_prev + ((long)rtile * 16 + lr) * H + 4 * lq;
+#pragma unroll 2
+        for (int kc = kc0; kc < kc1; ++kc) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kc * 16);
+            f32x4 b[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                b[g] = *reinterpret_cast<const f32x4*>(job.whh_p + (((long)(g * KC + ug) * KC + kc) * 64 + lane) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = mfma16(a[j], b[g][j], acc[g]);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[wave - 1][g][lane] = acc[g];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const f32x4 r = red[w][g][lane];
+            acc[g] = f32x4{acc[g][0] + r[0], acc[g][1] + r[1], acc[g][2] + r[2], acc[g][3] + r[3]};
+        }
+        if (job.gx) {
+            const f32x4 x =
+                *reinterpret_cast<const f32x4*>(job.gx + (((job.gx_rt0 + rtile) * CT + g * KC + ug) * 64 + lane) * 4);
+            acc[g] = f32x4{acc[g][0] + x[0], acc[g][1] + x[1], acc[g][2] + x[2], acc[g][3] + x[3]};
+        } else {
+            const float bv = job.bias[(g * KC + ug) * 16 + lr];
+            acc[g] = f32x4{acc[g][0] + bv, acc[g][1] + bv, acc[g][2] + bv, acc[g][3] + bv};
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long idx = ((long)rtile * 16 + 4 * lq + i) * H + ug * 16 + lr;
+        const float c_old = job.first ? 0.f : job.c[idx];
+        const float ig = sigmoid_f(acc[0][i]), fg = sigmoid_f(acc[1][i]);
+        const float gg = tanhf(acc[2][i]), og = sigmoid_f(acc[3][i]);
+        const float cn = fg * c_old + ig * gg;
+        job.c[idx] = cn;
+        job.h_out[idx] = og * tanhf(cn);
+    }
+}
+
 template <int H, int RT, bool XIN, int UG = 2>
 int launch_rec(const float* gx, const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad,
                int main_wgs, hipStream_t s) {
@@ -623,4 +749,50 @@ int fsn_launch_lstm_step_train(const float* gx, const float* whh_p, const float*
         FSN_STEP_CASE(1);
 #undef FSN_STEP_CASE
     return fsn_check_launch("lstm_step_kernel");
+}
+
+// Two-layer LSTM over T steps on `row_tiles` 16-row tiles, layers advanced in a wavefront (see
+// lstm_step2_kernel).  gx0: layer-0 projection, tile (t, i) at t * gx_stride + gx_off + i; wih1_p / bias1:
+// layer-1 packed input weights [4H/16][H/16][64][4] and b_ih + b_hh; hseq0 / hseq1: [T][hs_stride rows][H]
+// with this launch's rows starting at row hs_off; c0 / c1: [row_tiles * 16][H].
+int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, const float* whh0_p, const float* wih1_p,
+                               const float* bias1, const float* whh1_p, float* hseq0, float* hseq1, long hs_stride,
+                               long hs_off, float* c0, float* c1, int T, int row_tiles, int H, hipStream_t s) {
+    if (H % 64 != 0) {
+        fsn_set_error("lstm_wavefront2: hidden size %d must be a multiple of 64", H);
+        return FSN_ERR_ARG;
+    }
+    const size_t step = (size_t)hs_stride * H;
+    float* h0 = hseq0 + (size_t)hs_off * H;
+    float* h1 = hseq1 + (size_t)hs_off * H;
+    for (int i = 0; i <= T; ++i) {
+        FsnStepJob a{}, b{};
+        if (i < T) {
+            a.active = 1;
+            a.gx = gx0;
+            a.gx_rt0 = (long)i * gx_stride + gx_off;
+            a.whh_p = whh0_p;
+            a.h_prev = i ? h0 + (i - 1) * step : h0;
+            a.h_out = h0 + i * step;
+            a.c = c0;
+            a.first = i == 0;
+        }
+        if (i >= 1) {
+            const int t = i - 1;
+            b.active = 1;
+            b.xw_p = wih1_p;
+            b.x = h0 + t * step;
+            b.ldx = H;
+            b.kx_chunks = H / 16;
+            b.bias = bias1;
+            b.whh_p = whh1_p;
+            b.h_prev = t ? h1 + (t - 1) * step : h1;
+            b.h_out = h1 + t * step;
+            b.c = c1;
+            b.first = t == 0;
+        }
+        hipLaunchKernelGGL(lstm_step2_kernel, dim3(H / 16, row_tiles, 2), dim3(256), 0, s, a, b, H);
+        FSN_TRY_LAUNCH("lstm_step2_kernel");
+    }
+    return FSN_OK;
 }
