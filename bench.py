@@ -85,9 +85,10 @@ def cpu_baseline(params, length, budget_s=20.0):
 
 def measured_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_hbm_traffic.json: FETCH_SIZE x2 (gfx950) + WRITE_SIZE at this exact config)."""
+    (profiles/r01_hbm_traffic_end.json: FETCH_SIZE x2 (gfx950) + WRITE_SIZE at this exact config, mean of the
+    two launches per step)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_end.json")) as f:
             return json.load(f)["dominant_kernel"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None

@@ -225,6 +225,7 @@ struct CoreDims {
     int Npad_fb;       // full-band rows per step (batch, padded to 16)
     int N, Npad;       // sub-band rows per step, padded rows (row stride of the [t][n] buffers)
     FsnRecPlan rec;    // how those rows are spread over the CUs
+    bool fc_fused;     // output layer fused into the layer-1 persistent kernel (its hseq is never stored)
 };
 static CoreDims core_dims(const fsn_fullsubnet_cfg* c, int B, int T) {
     CoreDims d;
@@ -241,6 +242,7 @@ static CoreDims core_dims(const fsn_fullsubnet_cfg* c, int B, int T) {
     d.N = B * d.F;
     d.rec = fsn_lstm_rec_plan(d.N, d.Hs);
     d.Npad = d.rec.npad;
+    d.fc_fused = d.rec.main_wgs > 0 && fsn_lstm_rec_can_fuse_fc(d.rec.rt, false);
     return d;
 }
 struct CoreWs {
@@ -261,7 +263,9 @@ static CoreWs core_carve(Carver& cv, const CoreDims& d, int norm_type) {
     w.den_sb = cv.take<float>(cum ? rows_sb : (size_t)d.B);
     w.gx_sb = cv.take<float>(rows_sb * 4 * d.Hs);
     w.hseq_sb0 = cv.take<float>(rows_sb * d.Hs);
-    w.hseq_sb1 = cv.take<float>(rows_sb * d.Hs);
+    // fused output layer: only the left-over rows of layer 1 are ever stored, [t][left rows][H]
+    w.hseq_sb1 = cv.take<float>(d.fc_fused ? (size_t)d.Tp * (d.rec.left_tiles > 0 ? d.rec.left_tiles : 1) * 16 * d.Hs
+                                           : rows_sb * d.Hs);
     w.c_left = cv.take<float>((size_t)2 * (d.rec.left_tiles > 0 ? d.rec.left_tiles : 1) * 16 * d.Hs);
     return w;
 }
@@ -289,7 +293,7 @@ static int aux_init() {
 // in-kernel from `xin`.  Left-over tiles: projection tiles in `gx_left` at t * left_stride + left_off + i.
 static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* gx_left, long left_stride,
                           long left_off, const float* whh, float* hseq, float* c_left, int Tp, int Npad, int H,
-                          const FsnRecPlan& r, hipStream_t s) {
+                          const FsnRecPlan& r, hipStream_t s, const FsnRecFc* fc = nullptr, long left_hs_stride = -1) {
     const bool fork = r.left_tiles > 0 && r.main_wgs > 0;  // no persistent part: the steps run on `s` itself
     hipStream_t ls = s;
     if (fork) {
@@ -300,12 +304,15 @@ static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* g
         }
         ls = g_aux_stream;
     }
-    if (r.main_wgs > 0) FSN_TRY(fsn_launch_lstm_rec(gx, xin, whh, hseq, Tp, Npad, H, r.rt, r.main_wgs, s));
+    if (r.main_wgs > 0) FSN_TRY(fsn_launch_lstm_rec(gx, xin, whh, hseq, Tp, Npad, H, r.rt, r.main_wgs, s, fc));
     if (r.left_tiles > 0) {
-        const long main_rows = (long)r.main_wgs * r.rt * 16;
+        // left-over rows of step t: rows [main_rows, Npad) of the full [t][Npad] matrix, or - when the
+        // persistent part stores nothing (fused output layer) - a compact [t][left rows] matrix
+        const long hs_stride = left_hs_stride >= 0 ? left_hs_stride : Npad;
+        const long hs_off = left_hs_stride >= 0 ? 0 : (long)r.main_wgs * r.rt * 16;
         for (int t = 0; t < Tp; ++t) {
-            float* h_out = hseq + ((size_t)t * Npad + main_rows) * H;
-            const float* h_prev = t ? hseq + ((size_t)(t - 1) * Npad + main_rows) * H : h_out;
+            float* h_out = hseq + ((size_t)t * hs_stride + hs_off) * H;
+            const float* h_prev = t ? hseq + ((size_t)(t - 1) * hs_stride + hs_off) * H : h_out;
             FSN_TRY(fsn_launch_lstm_step(gx_left, whh, h_prev, h_out, c_left, (long)t * left_stride + left_off,
                                          r.left_tiles, H, t == 0, ls, fork ? 1 : 0));
         }
@@ -321,8 +328,9 @@ static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* g
 
 static int run_sb_recurrence(const float* gx, const FsnSbInput* xin, const float* gx_left, long left_stride,
                              long left_off, const float* whh, float* hseq, float* c_left, const CoreDims& d,
-                             hipStream_t s) {
-    return run_recurrence(gx, xin, gx_left, left_stride, left_off, whh, hseq, c_left, d.Tp, d.Npad, d.Hs, d.rec, s);
+                             hipStream_t s, const FsnRecFc* fc = nullptr) {
+    return run_recurrence(gx, xin, gx_left, left_stride, left_off, whh, hseq, c_left, d.Tp, d.Npad, d.Hs, d.rec, s,
+                          fc, fc ? (long)d.rec.left_tiles * 16 : -1);
 }
 
 // below this many sub-band row tiles (batch <= 5) the two layers of the small-batch step path also run as
@@ -470,12 +478,28 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         c.bias = pk + p.sb_b1;
         FSN_TRY(fsn_launch_gemm(a, pk + p.sb_wih1, c, sb_rt, 4 * d.Hs / 16, d.Hs / 16, s));
     }
+    // Output layer (model.py:53-61,129-135).  Where the persistent 4-pass kernel runs layer 1 it forms the two
+    // mask values of a row from h_t in LDS and that layer's 4.8 GB hidden sequence is never written or read
+    // back; only rows that went step by step (left-over tiles, small batches) go through the GEMM below.
+    const bool fc_fused = d.fc_fused;
+    FsnRecFc fc{};
+    if (fc_fused) {
+        fc.w_p = pk + p.sb_fc;
+        fc.bias = pk + p.sb_fcb;
+        fc.crm_r = crm_r;
+        fc.crm_i = crm_i;
+        fc.N = d.N;
+        fc.F = d.F;
+        fc.FP = d.FP;
+        fc.T = d.T;
+        fc.la = d.la;
+    }
     if (!sb_wave) {
         StageTimer st(ST_SB_REC_L1, s);
         FSN_TRY(run_sb_recurrence(w.gx_sb, nullptr, w.gx_sb, d.rec.tiles, main_rows / 16, pk + p.sb_whh1, w.hseq_sb1,
-                                  w.c_left, d, s));
+                                  w.c_left, d, s, fc_fused ? &fc : nullptr));
     }
-    {
+    if (!fc_fused || d.rec.left_tiles > 0) {
         StageTimer st(ST_SB_FC, s);
         a = FsnGemmA{};
         c = FsnGemmC{};
@@ -492,7 +516,13 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         c.Npad = d.Npad;
         c.N = d.N;
         c.la = d.la;
-        FSN_TRY(fsn_launch_gemm(a, pk + p.sb_fc, c, sb_rt, 1, d.Hs / 16, s));
+        int rows_t = sb_rt;
+        if (fc_fused) {  // only the left-over rows: hseq_sb1 is the compact [t][left rows][H] matrix
+            c.Npad = d.rec.left_tiles * 16;
+            c.n_off = (int)main_rows;
+            rows_t = d.Tp * d.rec.left_tiles;
+        }
+        FSN_TRY(fsn_launch_gemm(a, pk + p.sb_fc, c, rows_t, 1, d.Hs / 16, s));
     }
     return FSN_OK;
 }

@@ -126,6 +126,7 @@ struct FsnGemmC {  // C store description
     float* p1;
     const float* bias;
     int B, Tp, T, F, FP, Npad, N, la;
+    int n_off;     // kind 2: first unit of the rows (row r is step r / Npad, unit n_off + r % Npad)
     long ld;       // kind 3: leading dimension of p0
     int rows, cols;  // kind 3: valid extent
 };
@@ -170,6 +171,17 @@ struct FsnSbInput {
     int B, Tp, F, FP, N, nb, kin_chunks;
 };
 
+// Output layer (nn.Linear(H, 2), fullsubnet/model.py:53-61 + the reshape of :129-135) fused into the
+// last sub-band recurrent layer: the two mask values of a row are formed from h_t while it sits in LDS
+// and go straight to the compressed-mask planes; the hidden sequence of that layer is never written.
+struct FsnRecFc {
+    const float* w_p;   // packed output weights [1][H/16][64][4] (rows 0, 1); NULL: not fused
+    const float* bias;  // [16]
+    float* crm_r;
+    float* crm_i;       // [B][T][FP]
+    int N, F, FP, T, la;
+};
+
 struct FsnRecPlan {
     int rt;          // 16-row tiles per workgroup of the persistent recurrent kernel
     int main_wgs;    // its grid: rows [0, main_wgs * rt * 16)
@@ -188,7 +200,8 @@ int fsn_launch_lstm_step_train(const float* gx, const float* whh_p, const float*
 // xin == NULL: accumulators start from the precomputed projection gx; otherwise the (K = 2nb+2)
 // input projection of the sub-band model's first layer is computed inside the kernel from xin.
 int fsn_launch_lstm_rec(const float* gx, const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad,
-                        int H, int RT, int main_wgs, hipStream_t s);
+                        int H, int RT, int main_wgs, hipStream_t s, const FsnRecFc* fc = nullptr);
+bool fsn_lstm_rec_can_fuse_fc(int RT, bool xin);
 int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, const float* whh0_p, const float* wih1_p,
                                const float* bias1, const float* whh1_p, float* hseq0, float* hseq1, long hs_stride,
                                long hs_off, float* c0, float* c1, int T, int row_tiles, int H, hipStream_t s);

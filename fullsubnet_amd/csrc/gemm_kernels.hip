@@ -140,7 +140,7 @@ __device__ __forceinline__ void store_tile(const FsnGemmC& c, f32x4 acc, float b
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long row = rtile * 16 + 4 * (lane >> 4) + i;
-            const int t = (int)(row / c.Npad), n = (int)(row % c.Npad);
+            const int t = (int)(row / c.Npad), n = (int)(row % c.Npad) + (KIND == 2 ? c.n_off : 0);
             if (KIND == 1) {  // full-band output layer: ReLU(h W^T + b) -> fb_out[b][t][f]
                 if (n < c.B && col < c.FP) {
                     const float v = col < c.F ? fmaxf(acc[i] + bias, 0.f) : 0.f;

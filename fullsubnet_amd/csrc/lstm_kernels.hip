@@ -48,7 +48,8 @@ template <int H, int RT, int UG, bool XIN>
 __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const float* __restrict__ gx,
                                                                         const FsnSbInput xin,
                                                                         const float* __restrict__ whh_p,
-                                                                        float* __restrict__ hseq, int Tp, int Npad) {
+                                                                        float* __restrict__ hseq, int Tp, int Npad,
+                                                                        const FsnRecFc fc) {
     constexpr int NW = H / (16 * UG);   // waves per workgroup
     constexpr int KC = H / 16;          // k chunks == unit groups
     constexpr int CT = 4 * KC;          // column tiles of the gate matrix
@@ -61,10 +62,18 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const fl
     // reading a 19.2 GB precomputed gx that an HBM-write-bound GEMM would have to produce first.
     const int XS = XIN ? 16 * xin.kin_chunks + 4 : 0;
     float* xl = hl + ROWS * HS;
+    float* wl = xl;  // !XIN with the output layer fused: its two weight rows [2][H] sit here instead
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const long n0 = (long)blockIdx.x * ROWS;
+    const bool fuse_fc = !XIN && fc.w_p != nullptr;
+    if (fuse_fc) {  // un-tile rows 0 / 1 of the packed output weights: element (c, k) of fragment order
+        for (int i = threadIdx.x; i < 2 * H; i += NW * 64) {
+            const int c = i / H, k = i % H;
+            wl[i] = fc.w_p[(((k >> 4) * 64) + ((k & 15) >> 2) * 16 + c) * 4 + (k & 3)];
+        }
+    }
 
     f32x4 cst[RT][UG], tmp[RT][UG];
 #pragma unroll
@@ -166,12 +175,46 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const fl
                 for (int i = 0; i < 4; ++i)
                     hl[(rt * 16 + 4 * lq + i) * HS + (wave * UG + u) * 16 + lr] = tmp[rt][u][i];
         __syncthreads();  // h_t complete in LDS
-        // stream h_t out as whole rows: hseq[t][n0 + row][0..H)
-        float* dst = hseq + ((long)t * Npad + n0) * H;
-        for (int i = threadIdx.x; i < ROWS * (H / 4); i += NW * 64) {
-            const int row = i / (H / 4), c4 = i % (H / 4);
-            *reinterpret_cast<f32x4*>(dst + (long)row * H + c4 * 4) =
-                *reinterpret_cast<const f32x4*>(hl + row * HS + c4 * 4);
+        if (fuse_fc) {
+            // output layer on the spot: 4 threads per (row, output), a quarter of K each, joined by two
+            // lane shuffles; frame t - la of the mask (the first la steps are the look-ahead warm-up)
+            const int tid = threadIdx.x;
+            if (tid < ROWS * 8) {
+                const int part = tid & 3, c = (tid >> 2) & 1, row = tid >> 3;
+                const float* hp = hl + row * HS + part * (H / 4);
+                const float* wp = wl + c * H + part * (H / 4);
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll 2  // deeper unrolling costs the registers the left-over step kernels need beside this one
+                for (int k = 0; k < H / 4; k += 8) {
+                    const f32x4 h0 = *reinterpret_cast<const f32x4*>(hp + k), w0 = *reinterpret_cast<const f32x4*>(wp + k);
+                    const f32x4 h1 = *reinterpret_cast<const f32x4*>(hp + k + 4),
+                                w1 = *reinterpret_cast<const f32x4*>(wp + k + 4);
+                    a0 = fmaf(h0[0], w0[0], a0);
+                    a0 = fmaf(h0[1], w0[1], a0);
+                    a0 = fmaf(h0[2], w0[2], a0);
+                    a0 = fmaf(h0[3], w0[3], a0);
+                    a1 = fmaf(h1[0], w1[0], a1);
+                    a1 = fmaf(h1[1], w1[1], a1);
+                    a1 = fmaf(h1[2], w1[2], a1);
+                    a1 = fmaf(h1[3], w1[3], a1);
+                }
+                float v = a0 + a1;
+                v += __shfl_xor(v, 1, 64);
+                v += __shfl_xor(v, 2, 64);
+                const long n = n0 + row;
+                if (part == 0 && t >= fc.la && n < fc.N) {
+                    const int b = (int)(n / fc.F), f = (int)(n % fc.F);
+                    (c ? fc.crm_i : fc.crm_r)[((long)b * fc.T + (t - fc.la)) * fc.FP + f] = v + fc.bias[c];
+                }
+            }
+        } else {
+            // stream h_t out as whole rows: hseq[t][n0 + row][0..H)
+            float* dst = hseq + ((long)t * Npad + n0) * H;
+            for (int i = threadIdx.x; i < ROWS * (H / 4); i += NW * 64) {
+                const int row = i / (H / 4), c4 = i % (H / 4);
+                *reinterpret_cast<f32x4*>(dst + (long)row * H + c4 * 4) =
+                    *reinterpret_cast<const f32x4*>(hl + row * HS + c4 * 4);
+            }
         }
     }
 }
@@ -188,7 +231,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_small_kernel(co
                                                                               const FsnSbInput xin,
                                                                               const float* __restrict__ whh_p,
                                                                               float* __restrict__ hseq, int Tp,
-                                                                              int Npad) {
+                                                                              int Npad, const FsnRecFc) {
     constexpr int NW = H / (16 * UG);
     constexpr int KC = H / 16;
     constexpr int CT = 4 * KC;
@@ -614,15 +657,22 @@ __global__ __launch_bounds__(256) void lstm_step2_kernel(const FsnStepJob ja, co
 
 template <int H, int RT, bool XIN, int UG = 2>
 int launch_rec(const float* gx, const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad,
-               int main_wgs, hipStream_t s) {
+               int main_wgs, hipStream_t s, const FsnRecFc* fc = nullptr) {
     constexpr int NW = H / (16 * UG);
     size_t lds = (size_t)RT * 16 * (H + 4) * sizeof(float);
     if (XIN) lds += (size_t)2 * RT * 16 * (16 * xin->kin_chunks + 4) * sizeof(float);
+    const bool fuse = fc && fc->w_p;
+    if (fuse && (XIN || RT <= 1)) {
+        fsn_set_error("lstm_rec: the output layer can only be fused into the 4-pass kernel without input staging");
+        return FSN_ERR_ARG;
+    }
+    if (fuse) lds += (size_t)2 * H * sizeof(float);
     // RT == 1 (fewer row tiles than CUs): the one-pass-all-gates variant, ~10 % faster there (8.8 vs
     // 10.0 ms per layer; a 16-row workgroup still owes 9216 MFMAs = 31 us per step, so small batches
     // stay bound by one tile per CU until the hidden units of a tile are split across CUs).  At
     // RT = 2 it spills and loses.
-    void (*kern)(const float*, const FsnSbInput, const float*, float*, int, int) = lstm_rec_kernel<H, RT, UG, XIN>;
+    void (*kern)(const float*, const FsnSbInput, const float*, float*, int, int, const FsnRecFc) =
+        lstm_rec_kernel<H, RT, UG, XIN>;
     if constexpr (RT <= 1) kern = lstm_rec_small_kernel<H, RT, UG, XIN>;
     if (lds > 160 * 1024 ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -631,7 +681,7 @@ int launch_rec(const float* gx, const FsnSbInput* xin, const float* whh_p, float
         return FSN_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)main_wgs), dim3(NW * 64), lds, s, gx, XIN ? *xin : FsnSbInput{}, whh_p,
-                       hseq, Tp, Npad);
+                       hseq, Tp, Npad, fuse ? *fc : FsnRecFc{});
     return fsn_check_launch("lstm_rec_kernel");
 }
 
@@ -699,12 +749,14 @@ FsnRecPlan fsn_lstm_rec_plan(int N, int H) {
     return p;
 }
 
+bool fsn_lstm_rec_can_fuse_fc(int RT, bool xin) { return !xin && RT >= 2; }
+
 int fsn_launch_lstm_rec(const float* gx, const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad,
-                        int H, int RT, int main_wgs, hipStream_t s) {
+                        int H, int RT, int main_wgs, hipStream_t s, const FsnRecFc* fc) {
 #define FSN_REC_CASE(HH, R)                                                                              \
     if (H == HH && RT == R)                                                                              \
-        return xin ? launch_rec<HH, R, true>(gx, xin, whh_p, hseq, Tp, Npad, main_wgs, s)                \
-                   : launch_rec<HH, R, false>(gx, xin, whh_p, hseq, Tp, Npad, main_wgs, s);
+        return xin ? launch_rec<HH, R, true>(gx, xin, whh_p, hseq, Tp, Npad, main_wgs, s, fc)            \
+                   : launch_rec<HH, R, false>(gx, xin, whh_p, hseq, Tp, Npad, main_wgs, s, fc);
     FSN_REC_CASE(384, 1)
     FSN_REC_CASE(384, 2)
     FSN_REC_CASE(384, 3)
