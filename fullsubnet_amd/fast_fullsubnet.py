@@ -42,81 +42,78 @@ class MelScale(nn.Module):
         return torch.matmul(specgram.transpose(-1, -2), self.fb).transpose(-1, -2)
 
 
+def _lstm_block(kind, n_in, n_hidden, n_out, layers=1, act=None):
+    return SequenceModel(n_in, n_out, n_hidden, layers, False, kind, act)
+
+
 class Model(BaseModel):
+    """Constructor keywords and parameter names (``encoder.{0,1}``, ``mel_scale.fb``, ``bottleneck``,
+    ``decoder_lstm.{0,1}``) are the reference's (fast_fullsubnet/model.py:12-106)."""
+
     def __init__(self, look_ahead, shrink_size, sequence_model, num_mels, encoder_input_size,
                  bottleneck_hidden_size, bottleneck_num_layers, noisy_input_num_neighbors,
                  encoder_output_num_neighbors, norm_type="offline_laplace_norm", weight_init=False):
         super().__init__()
-        assert sequence_model in ("GRU", "LSTM"), f"{self.__class__.__name__} only support GRU and LSTM."
-        # F_l2m (model.py:35-54)
-        self.encoder = nn.Sequential(
-            SequenceModel(input_size=64, hidden_size=384, output_size=0, num_layers=1, bidirectional=False,
-                          sequence_model=sequence_model, output_activate_function=None),
-            SequenceModel(input_size=384, hidden_size=257, output_size=64, num_layers=1, bidirectional=False,
-                          sequence_model=sequence_model, output_activate_function="ReLU"),
-        )
-        self.mel_scale = MelScale(n_mels=num_mels, sample_rate=16000, f_min=0, f_max=8000, n_stft=encoder_input_size)
-        # S (model.py:66-74)
-        self.bottleneck = SequenceModel(
-            input_size=(noisy_input_num_neighbors * 2 + 1) + (encoder_output_num_neighbors * 2 + 1), output_size=1,
-            hidden_size=bottleneck_hidden_size, num_layers=bottleneck_num_layers, bidirectional=False,
-            sequence_model=sequence_model, output_activate_function="ReLU")
-        # F_m2l (model.py:77-96)
-        self.decoder_lstm = nn.Sequential(
-            SequenceModel(input_size=64 + 64, hidden_size=512, output_size=0, num_layers=1, bidirectional=False,
-                          sequence_model=sequence_model, output_activate_function=None),
-            SequenceModel(input_size=512, hidden_size=512, output_size=257 * 2, num_layers=1, bidirectional=False,
-                          sequence_model=sequence_model, output_activate_function=None),
-        )
-        self.shrink_size = shrink_size
-        self.look_ahead = look_ahead
-        self.num_mels = num_mels
+        if sequence_model not in ("GRU", "LSTM"):
+            raise AssertionError(f"{self.__class__.__name__} only support GRU and LSTM.")
+        self.look_ahead, self.shrink_size, self.num_mels = look_ahead, shrink_size, num_mels
         self.noisy_input_num_neighbors = noisy_input_num_neighbors
         self.enc_output_num_neighbors = encoder_output_num_neighbors
         self.norm = self.norm_wrapper(norm_type)
+        cell = sequence_model
+        # the widths below are literals in the reference too (model.py:36-96): 64 mel bands, 257 bins
+        self.encoder = nn.Sequential(_lstm_block(cell, 64, 384, 0),                    # F_l2m, part 1
+                                     _lstm_block(cell, 384, 257, 64, act="ReLU"))      # F_l2m, part 2
+        self.mel_scale = MelScale(n_mels=num_mels, sample_rate=16000, f_min=0, f_max=8000, n_stft=encoder_input_size)
+        unit_width = (2 * noisy_input_num_neighbors + 1) + (2 * encoder_output_num_neighbors + 1)
+        self.bottleneck = _lstm_block(cell, unit_width, bottleneck_hidden_size, 1, bottleneck_num_layers, "ReLU")  # S
+        self.decoder_lstm = nn.Sequential(_lstm_block(cell, 64 + 64, 512, 0),         # F_m2l, part 1
+                                          _lstm_block(cell, 512, 512, 257 * 2))       # F_m2l, part 2
         if weight_init:
             self.apply(self.weight_init)
 
     def real_time_downsampling(self, input):
-        """model.py:108-129: frame 0 kept, then means over consecutive blocks of shrink_size frames
-        (the last block may be shorter): [B, C, F, T] -> [B, C, F, 1 + ceil((T - 1) / shrink_size)]."""
+        """model.py:108-129: frame 0 is kept, the remaining frames are averaged in consecutive blocks of
+        ``shrink_size`` (a shorter last block is averaged over what it has):
+        [B, C, F, T] -> [B, C, F, 1 + ceil((T - 1) / shrink_size)]."""
         s = self.shrink_size
-        rest = input[..., 1:]
-        n_full = rest.shape[-1] // s
-        parts = [input[..., 0:1]]
-        if rest.shape[-1] % s == 0:
-            # the reference's "last block" is then a full block: blocks 0 .. n_full-2 stacked, last apart
-            n_full -= 1
-        if n_full > 0:
-            parts.append(rest[..., :n_full * s].reshape(*rest.shape[:-1], n_full, s).mean(dim=-1))
-        parts.append(rest[..., n_full * s:].mean(dim=-1, keepdim=True))
-        return torch.cat(parts, dim=-1)
+        head, rest = input[..., :1], input[..., 1:]
+        n_rest = rest.shape[-1]
+        n_whole = n_rest // s
+        if n_rest % s == 0:
+            n_whole -= 1  # the reference averages its last block separately even when it is a whole one
+        pieces = [head]
+        if n_whole > 0:
+            pieces.append(rest[..., :n_whole * s].unflatten(-1, (n_whole, s)).mean(dim=-1))
+        pieces.append(rest[..., n_whole * s:].mean(dim=-1, keepdim=True))
+        return torch.cat(pieces, dim=-1)
 
     def real_time_upsampling(self, input, target_len=False):
-        """model.py:131-140: repeat every frame shrink_size times, trim to target_len."""
-        out = input.repeat_interleave(self.shrink_size, dim=-1)
-        return out[..., :target_len] if target_len else out
+        """model.py:131-140: hold every low-rate frame for ``shrink_size`` frames, cut to ``target_len``."""
+        held = torch.repeat_interleave(input, self.shrink_size, dim=-1)
+        return held[..., :target_len] if target_len else held
+
+    def _unit_windows(self, x, neighbors):
+        """[B, 1, M, T] -> [B, M, 2 n + 1, T]: every mel band with its ``neighbors`` on each side."""
+        b, _, m, t = x.shape
+        return self.freq_unfold(x, num_neighbors=neighbors).reshape(b, m, 2 * neighbors + 1, t)
 
     def forward(self, mix_mag):
         """mix_mag [B, 1, F, T] -> [B, 2, F, T] (model.py:143-202)."""
-        assert mix_mag.dim() == 4
-        mix_mag = look_ahead_pad(mix_mag, self.look_ahead)
-        batch_size, num_channels, num_freqs, num_frames = mix_mag.size()
-        assert num_channels == 1, f"{self.__class__.__name__} takes a magnitude feature as the input."
-        mix_mel_mag = self.mel_scale(mix_mag)  # [B, 1, F_mel, T]
-        enc_input = self.norm(mix_mel_mag).reshape(batch_size, -1, num_frames)
-        enc_output = self.encoder(enc_input).reshape(batch_size, num_channels, -1, num_frames)
-        noisy_unfold = self.freq_unfold(mix_mel_mag, num_neighbors=self.noisy_input_num_neighbors)
-        noisy_unfold = noisy_unfold.reshape(batch_size, self.num_mels, self.noisy_input_num_neighbors * 2 + 1, num_frames)
-        enc_unfold = self.freq_unfold(enc_output, num_neighbors=self.enc_output_num_neighbors)
-        enc_unfold = enc_unfold.reshape(batch_size, self.num_mels, self.enc_output_num_neighbors * 2 + 1, num_frames)
-        bn_input = torch.cat([noisy_unfold, enc_unfold], dim=2)
-        num_sb_unit_freqs = bn_input.shape[2]
-        bn_input_shrink = self.norm(self.real_time_downsampling(bn_input))
-        bn_input_shrink = bn_input_shrink.reshape(batch_size * self.num_mels, num_sb_unit_freqs, -1)
-        bn_output_shrink = self.bottleneck(bn_input_shrink)  # [B * F_mel, 1, T // shrink]
-        bn_output_shrink = bn_output_shrink.reshape(batch_size, self.num_mels, 1, -1).permute(0, 2, 1, 3)
-        bn_output = self.real_time_upsampling(bn_output_shrink, target_len=num_frames)  # [B, 1, F_mel, T]
-        dec_input = torch.cat([enc_output, bn_output], dim=2).reshape(batch_size, -1, num_frames)
-        dec_output = self.decoder_lstm(dec_input).reshape(batch_size, 2, num_freqs, num_frames)
-        return dec_output[:, :, :, self.look_ahead:]
+        if mix_mag.dim() != 4 or mix_mag.shape[1] != 1:
+            raise AssertionError(f"{self.__class__.__name__} takes a magnitude feature as the input ([B, 1, F, T]).")
+        mag = look_ahead_pad(mix_mag, self.look_ahead)
+        n_batch, _, n_bins, n_frames = mag.shape
+        mel = self.mel_scale(mag)                                                         # [B, 1, M, T]
+        enc = self.encoder(self.norm(mel).reshape(n_batch, -1, n_frames))                 # [B, M, T]
+        enc = enc.reshape(n_batch, 1, -1, n_frames)
+        units = torch.cat([self._unit_windows(mel, self.noisy_input_num_neighbors),
+                           self._unit_windows(enc, self.enc_output_num_neighbors)], dim=2)  # [B, M, W, T]
+        width = units.shape[2]
+        slow = self.norm(self.real_time_downsampling(units))                              # [B, M, W, T / s]
+        slow_out = self.bottleneck(slow.reshape(n_batch * self.num_mels, width, -1))      # [B M, 1, T / s]
+        slow_out = slow_out.reshape(n_batch, self.num_mels, 1, -1).permute(0, 2, 1, 3)
+        band_gain = self.real_time_upsampling(slow_out, target_len=n_frames)              # [B, 1, M, T]
+        dec_in = torch.cat([enc, band_gain], dim=2).reshape(n_batch, -1, n_frames)
+        mask = self.decoder_lstm(dec_in).reshape(n_batch, 2, n_bins, n_frames)
+        return mask[..., self.look_ahead:]
