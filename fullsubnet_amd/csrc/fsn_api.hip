@@ -147,6 +147,7 @@ static int check_cfg(const fsn_fullsubnet_cfg* cfg) {
 struct Packed {  // float offsets into the packed blob
     size_t fb_wih0, fb_whh0, fb_b0, fb_wih1, fb_whh1, fb_b1, fb_fc, fb_fcb;
     size_t sb_wih0, sb_whh0, sb_b0, sb_wih1, sb_whh1, sb_b1, sb_fc, sb_fcb;
+    size_t fb_b1_frag, sb_b1_frag;  // layer-1 biases as accumulator-fragment tiles (wavefront step kernel)
     size_t total;
     int FP, sb_kin_pad;
 };
@@ -178,6 +179,8 @@ static Packed packed_layout(const fsn_fullsubnet_cfg* c) {
     p.sb_b1 = take(4 * Hs);
     p.sb_fc = take(16 * Hs);
     p.sb_fcb = take(16);
+    p.fb_b1_frag = take(4 * Hf * 16);  // [4H/16 column tiles][64 lanes][4]
+    p.sb_b1_frag = take(4 * Hs * 16);
     p.total = fsn_round_up_sz(o, 64);
     return p;
 }
@@ -216,6 +219,8 @@ extern "C" int fsn_fullsubnet_pack(const fsn_fullsubnet_cfg* cfg, const fsn_full
     FSN_TRY(fsn_launch_bias_sum(w->sb_b_ih_l1, w->sb_b_hh_l1, o + p.sb_b1, 4 * Hs, 4 * Hs, s));
     FSN_TRY(fsn_launch_pack(w->sb_fc_w, o + p.sb_fc, 2, Hs, 16, Hs, s));
     FSN_TRY(fsn_launch_bias_sum(w->sb_fc_b, nullptr, o + p.sb_fcb, 2, 16, s));
+    FSN_TRY(fsn_launch_bias_frag(o + p.fb_b1, o + p.fb_b1_frag, 4 * Hf, s));
+    FSN_TRY(fsn_launch_bias_frag(o + p.sb_b1, o + p.sb_b1_frag, 4 * Hs, s));
     return FSN_OK;
 }
 
@@ -379,7 +384,7 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         // N = B rows only: a chain of tiny dependent launches, so the two layers advance as a wavefront
         // (layer 1 at step t next to layer 0 at step t + 1): T' + 1 launches instead of 2 T'
         StageTimer st(ST_FB_REC, s);
-        FSN_TRY(fsn_launch_lstm_wavefront2(w.gx_fb, d.Npad_fb / 16, 0, pk + p.fb_whh0, pk + p.fb_wih1, pk + p.fb_b1,
+        FSN_TRY(fsn_launch_lstm_wavefront2(w.gx_fb, d.Npad_fb / 16, 0, pk + p.fb_whh0, pk + p.fb_wih1, pk + p.fb_b1_frag,
                                            pk + p.fb_whh1, w.hseq_fb0, w.hseq_fb1, d.Npad_fb, 0, w.c_fb,
                                            w.c_fb + (size_t)d.Npad_fb * d.Hf, d.Tp, d.Npad_fb / 16, d.Hf, s));
     }
@@ -442,7 +447,7 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
     const bool sb_wave = d.rec.main_wgs == 0 && d.rec.left_tiles < kWavefrontBelowTiles;
     if (sb_wave) {
         StageTimer st(ST_SB_REC_L0, s);
-        FSN_TRY(fsn_launch_lstm_wavefront2(w.gx_sb, d.rec.left_tiles, 0, pk + p.sb_whh0, pk + p.sb_wih1, pk + p.sb_b1,
+        FSN_TRY(fsn_launch_lstm_wavefront2(w.gx_sb, d.rec.left_tiles, 0, pk + p.sb_whh0, pk + p.sb_wih1, pk + p.sb_b1_frag,
                                            pk + p.sb_whh1, w.hseq_sb0, w.hseq_sb1, d.Npad, 0, w.c_left,
                                            w.c_left + (size_t)d.rec.left_tiles * 16 * d.Hs, d.Tp, d.rec.left_tiles,
                                            d.Hs, s));

@@ -136,6 +136,7 @@ int fsn_launch_gemm(const FsnGemmA& a, const float* w_packed, const FsnGemmC& c,
 int fsn_launch_pack(const float* w, float* wp, int n_out, int k, int n_out_pad, int k_pad, hipStream_t s,
                     int transposed = 0, int ldw = 0);
 int fsn_launch_bias_sum(const float* a, const float* b, float* out, int n, int n_pad, hipStream_t s);
+int fsn_launch_bias_frag(const float* bias, float* frag, int n, hipStream_t s);
 
 // lstm_train_kernels.hip (training step: BPTT pieces)
 // C [M][Nc] = sum_k A[k][M]^T B[k][Nc]   (both operands row-major over k; split-K, deterministic 2-pass)

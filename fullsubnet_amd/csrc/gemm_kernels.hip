@@ -368,6 +368,17 @@ int fsn_launch_pack(const float* w, float* wp, int n_out, int k, int n_out_pad, 
     return fsn_check_launch("pack_kernel");
 }
 
+// bias[n] -> accumulator-fragment tiles [n/16][64][4]: lane l of column tile ct holds bias[16 ct + (l & 15)] x 4
+__global__ void bias_frag_kernel(const float* __restrict__ bias, float* __restrict__ frag, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * 16) frag[i] = bias[(i >> 8) * 16 + ((i >> 2) & 15)];
+}
+
+int fsn_launch_bias_frag(const float* bias, float* frag, int n, hipStream_t s) {
+    hipLaunchKernelGGL(bias_frag_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, s, bias, frag, n);
+    return fsn_check_launch("bias_frag_kernel");
+}
+
 int fsn_launch_bias_sum(const float* a, const float* b, float* out, int n, int n_pad, hipStream_t s) {
     hipLaunchKernelGGL(bias_sum_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, s, a, b, out, n, n_pad);
     return fsn_check_launch("bias_sum_kernel");

@@ -537,20 +537,23 @@ __global__ __launch_bounds__(256) void lstm_step1_kernel(const float* __restrict
 // projection (its input row h0_t has only just been produced): it accumulates x W_ih^T and
 // h W_hh^T in the same 4-way split-K pass and adds the bias in the epilogue.
 struct FsnStepJob {
-    const float* gx;     // layer-0 form: fragment-ordered projection incl. bias; else NULL
-    const float* xw_p;   // layer-1 form: packed W_ih [4H/16][kx_chunks][64][4]
-    const float* x;      // layer-1 form: input rows [rows][ldx] (h of the layer below at this step)
-    const float* bias;   // layer-1 form: b_ih + b_hh [4H]
+    const float* add;    // fragment-ordered tiles added to the accumulators: the layer-0 projection incl. bias
+                         // (tile (add_rt0 + rtile) * CT + column tile), or the layer-1 bias tiles (add_rs = 0)
+    const float* xw_p;   // layer-1 form: packed W_ih [4H/16][H/16][64][4]; NULL for the layer-0 form
+    const float* x;      // layer-1 form: input rows [rows][H] (h of the layer below at this step)
     const float* whh_p;
     const float* h_prev;
     float* h_out;
     float* c;
-    long gx_rt0;
-    int kx_chunks, ldx, first, active;
+    long add_rt0;
+    int add_rs, first, active;
+};
+struct FsnStepJobs {
+    FsnStepJob j[2];
 };
 
-__global__ __launch_bounds__(256) void lstm_step2_kernel(const FsnStepJob ja, const FsnStepJob jb, int H) {
-    const FsnStepJob& job = blockIdx.z == 0 ? ja : jb;
+__global__ __launch_bounds__(256) void lstm_step2_kernel(const FsnStepJobs jobs, int H) {
+    const FsnStepJob job = jobs.j[blockIdx.z];  // one uniform kernarg fetch, no per-member branching
     if (!job.active) return;
     __shared__ f32x4 red[3][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -560,13 +563,29 @@ __global__ __launch_bounds__(256) void lstm_step2_kernel(const FsnStepJob ja, co
     f32x4 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool both = job.xw_p && !job.first && job.kx_chunks == KC;
-    if (both) {
+    // the finishing wave asks for everything its epilogue needs (projection / bias tiles, previous cell
+    // state) before the K loop: these are cold lines whose latency would otherwise follow the barrier
+    f32x4 addv[4];
+    float c_old[4];
+    const long cidx = ((long)rtile * 16 + 4 * lq) * H + ug * 16 + lr;
+    if (wave == 0) {
+        const float* ap = job.add + (((job.add_rt0 + (long)rtile * job.add_rs) * CT + ug) * 64 + lane) * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) addv[g] = *reinterpret_cast<const f32x4*>(ap + (long)g * KC * 256);
+        const float* cp = job.first ? job.add : job.c + cidx;  // first step: any valid address, value unused
+        const long cs = job.first ? 0 : H;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c_old[i] = cp[i * cs];
+    }
+    const int kc0 = wave * (KC >> 2), kc1 = kc0 + (KC >> 2);
+    const float* ah = job.h_prev + ((long)rtile * 16 + lr) * H + 4 * lq;
+    const float* bh = job.whh_p + ((long)ug * KC * 64 + lane) * 4;
+    const long gstride = (long)KC * KC * 256;  // gate g of unit group ug: column tile g KC + ug
+    if (job.xw_p && !job.first) {
         // layer-1 job in steady state: x W_ih^T and h W_hh^T share one loop, so that the loads of both
         // products are in flight together (two back-to-back loops would pay the L2 latency twice)
-        const int kc0 = wave * (KC >> 2), kc1 = kc0 + (KC >> 2);
-        const float* ax = job.x + ((long)rtile * 16 + lr) * job.ldx + 4 * lq;
-        const float* ah = job.h_prev + ((long)rtile * 16 + lr) * H + 4 * lq;
+        const float* ax = job.x + ((long)rtile * 16 + lr) * H + 4 * lq;
+        const float* bx = job.xw_p + ((long)ug * KC * 64 + lane) * 4;
 #pragma unroll 2
         for (int kc = kc0; kc < kc1; ++kc) {
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(ax + kc * 16);
@@ -574,9 +593,8 @@ __global__ __launch_bounds__(256) void lstm_step2_kernel(const FsnStepJob ja, co
             f32x4 b0[4], b1[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const long o = (((long)(g * KC + ug) * KC + kc) * 64 + lane) * 4;
-                b0[g] = *reinterpret_cast<const f32x4*>(job.xw_p + o);
-                b1[g] = *reinterpret_cast<const f32x4*>(job.whh_p + o);
+                b0[g] = *reinterpret_cast<const f32x4*>(bx + g * gstride + (long)kc * 256);
+                b1[g] = *reinterpret_cast<const f32x4*>(bh + g * gstride + (long)kc * 256);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -587,34 +605,16 @@ __global__ __launch_bounds__(256) void lstm_step2_kernel(const FsnStepJob ja, co
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[g] = mfma16(a1[j], b1[g][j], acc[g]);
         }
-    }
-    if (job.xw_p && !both) {
-        const int q = job.kx_chunks >> 2, kc0 = wave * q, kc1 = kc0 + q;
-        const float* ap = job.x + ((long)rtile * 16 + lr) * job.ldx + 4 * lq;
+    } else if (job.xw_p || !job.first) {
+        // one product only: layer 0 in steady state (h W_hh^T) or layer 1 at its first step (x W_ih^T)
+        const float* a1p = job.xw_p ? job.x + ((long)rtile * 16 + lr) * H + 4 * lq : ah;
+        const float* b1p = job.xw_p ? job.xw_p + ((long)ug * KC * 64 + lane) * 4 : bh;
 #pragma unroll 2
         for (int kc = kc0; kc < kc1; ++kc) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kc * 16);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(a1p + kc * 16);
             f32x4 b[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                b[g] = *reinterpret_cast<const f32x4*>(job.xw_p +
-                                                       (((long)(g * KC + ug) * job.kx_chunks + kc) * 64 + lane) * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = mfma16(a[j], b[g][j], acc[g]);
-        }
-    }
-    if (!job.first && !both) {
-        const int kc0 = wave * (KC >> 2), kc1 = kc0 + (KC >> 2);
-        const float* ap = job.h_prev + ((long)rtile * 16 + lr) * H + 4 * lq;
-#pragma unroll 2
-        for (int kc = kc0; kc < kc1; ++kc) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kc * 16);
-            f32x4 b[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                b[g] = *reinterpret_cast<const f32x4*>(job.whh_p + (((long)(g * KC + ug) * KC + kc) * 64 + lane) * 4);
+            for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4*>(b1p + g * gstride + (long)kc * 256);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -634,24 +634,18 @@ __global__ __launch_bounds__(256) void lstm_step2_kernel(const FsnStepJob ja, co
             const f32x4 r = red[w][g][lane];
             acc[g] = f32x4{acc[g][0] + r[0], acc[g][1] + r[1], acc[g][2] + r[2], acc[g][3] + r[3]};
         }
-        if (job.gx) {
-            const f32x4 x =
-                *reinterpret_cast<const f32x4*>(job.gx + (((job.gx_rt0 + rtile) * CT + g * KC + ug) * 64 + lane) * 4);
-            acc[g] = f32x4{acc[g][0] + x[0], acc[g][1] + x[1], acc[g][2] + x[2], acc[g][3] + x[3]};
-        } else {
-            const float bv = job.bias[(g * KC + ug) * 16 + lr];
-            acc[g] = f32x4{acc[g][0] + bv, acc[g][1] + bv, acc[g][2] + bv, acc[g][3] + bv};
-        }
+        acc[g] = f32x4{acc[g][0] + addv[g][0], acc[g][1] + addv[g][1], acc[g][2] + addv[g][2], acc[g][3] + addv[g][3]};
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const long idx = ((long)rtile * 16 + 4 * lq + i) * H + ug * 16 + lr;
-        const float c_old = job.first ? 0.f : job.c[idx];
-        const float ig = sigmoid_f(acc[0][i]), fg = sigmoid_f(acc[1][i]);
-        const float gg = tanhf(acc[2][i]), og = sigmoid_f(acc[3][i]);
-        const float cn = fg * c_old + ig * gg;
+        const long idx = cidx + (long)i * H;
+        // hardware exp / rcp forms as in the persistent kernel: the libm ones are ~2 us of this one-wave
+        // epilogue, a sixth of the whole step
+        const float ig = sigmoid_fast(acc[0][i]), fg = sigmoid_fast(acc[1][i]);
+        const float gg = tanh_fast(acc[2][i]), og = sigmoid_fast(acc[3][i]);
+        const float cn = fg * (job.first ? 0.f : c_old[i]) + ig * gg;
         job.c[idx] = cn;
-        job.h_out[idx] = og * tanhf(cn);
+        job.h_out[idx] = og * tanh_fast(cn);
     }
 }
 
@@ -808,7 +802,7 @@ int fsn_launch_lstm_step_train(const float* gx, const float* whh_p, const float*
 // layer-1 packed input weights [4H/16][H/16][64][4] and b_ih + b_hh; hseq0 / hseq1: [T][hs_stride rows][H]
 // with this launch's rows starting at row hs_off; c0 / c1: [row_tiles * 16][H].
 int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, const float* whh0_p, const float* wih1_p,
-                               const float* bias1, const float* whh1_p, float* hseq0, float* hseq1, long hs_stride,
+                               const float* bias1_frag, const float* whh1_p, float* hseq0, float* hseq1, long hs_stride,
                                long hs_off, float* c0, float* c1, int T, int row_tiles, int H, hipStream_t s) {
     if (H % 64 != 0) {
         fsn_set_error("lstm_wavefront2: hidden size %d must be a multiple of 64", H);
@@ -818,11 +812,14 @@ int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, co
     float* h0 = hseq0 + (size_t)hs_off * H;
     float* h1 = hseq1 + (size_t)hs_off * H;
     for (int i = 0; i <= T; ++i) {
-        FsnStepJob a{}, b{};
+        FsnStepJobs jobs{};
+        FsnStepJob& a = jobs.j[0];
+        FsnStepJob& b = jobs.j[1];
         if (i < T) {
             a.active = 1;
-            a.gx = gx0;
-            a.gx_rt0 = (long)i * gx_stride + gx_off;
+            a.add = gx0;
+            a.add_rt0 = (long)i * gx_stride + gx_off;
+            a.add_rs = 1;
             a.whh_p = whh0_p;
             a.h_prev = i ? h0 + (i - 1) * step : h0;
             a.h_out = h0 + i * step;
@@ -832,18 +829,18 @@ int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, co
         if (i >= 1) {
             const int t = i - 1;
             b.active = 1;
+            b.add = bias1_frag;
+            b.add_rt0 = 0;
+            b.add_rs = 0;
             b.xw_p = wih1_p;
             b.x = h0 + t * step;
-            b.ldx = H;
-            b.kx_chunks = H / 16;
-            b.bias = bias1;
             b.whh_p = whh1_p;
             b.h_prev = t ? h1 + (t - 1) * step : h1;
             b.h_out = h1 + t * step;
             b.c = c1;
             b.first = t == 0;
         }
-        hipLaunchKernelGGL(lstm_step2_kernel, dim3(H / 16, row_tiles, 2), dim3(256), 0, s, a, b, H);
+        hipLaunchKernelGGL(lstm_step2_kernel, dim3(H / 16, row_tiles, 2), dim3(256), 0, s, jobs, H);
         FSN_TRY_LAUNCH("lstm_step2_kernel");
     }
     return FSN_OK;
