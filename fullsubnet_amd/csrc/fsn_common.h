@@ -42,7 +42,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// Gate non-linearities of the MFMA-bound recurrent kernel on the hardware transcendentals
+// Gate non-linearities of every LSTM forward kernel (persistent, per-step, wavefront) on the hardware transcendentals
 // (v_exp_f32 / v_rcp_f32, ~1 ULP each): 4-5 VALU instructions per value instead of ~30 for the
 // libm-accurate forms.  Absolute error <= ~2e-7, the size of one fp32 rounding of the gate
 // pre-activation itself; the end-to-end effect on the compressed mask is measured by the parity
