@@ -28,7 +28,8 @@ class Model(nn.Module):
         from .base_model import BaseModel
         BaseModel().norm_wrapper(norm_type)  # unknown norm: NotImplementedError here, like model.py:62
         self._fused = (sequence_model == "LSTM" and fb_num_neighbors == 0 and fb_output_activate_function == "ReLU"
-                       and not sb_output_activate_function and norm_type in _lib.NORM_TYPES)
+                       and not sb_output_activate_function and norm_type in _lib.NORM_TYPES
+                       and sb_model_hidden_size == 384 and fb_model_hidden_size % 64 == 0)
         self.fb_model = SequenceModel(num_freqs, num_freqs, fb_model_hidden_size, 2, False, sequence_model,
                                       fb_output_activate_function)
         self.sb_model = SequenceModel((sb_num_neighbors * 2 + 1) + (fb_num_neighbors * 2 + 1), 2,

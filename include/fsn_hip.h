@@ -68,8 +68,8 @@ typedef struct fsn_fullsubnet_cfg {
     int num_freqs;        /* model.py:12  (257)                                   */
     int look_ahead;       /* model.py:13  (2)                                     */
     int sb_num_neighbors; /* model.py:16  (15); fb_num_neighbors must be 0        */
-    int fb_hidden;        /* model.py:19  (512), multiple of 32                   */
-    int sb_hidden;        /* model.py:20  (384), multiple of 32                   */
+    int fb_hidden;        /* model.py:19  (512), multiple of 64                   */
+    int sb_hidden;        /* model.py:20  384 (the persistent kernel's size)      */
     int norm_type;        /* model.py:21  FSN_NORM_*                              */
 } fsn_fullsubnet_cfg;
 

@@ -208,3 +208,22 @@ def test_fullsubnet_gru_training_step_runs_and_learns(fsn):
     losses = [train_step(m, opt, noisy, clean).item() for _ in range(3)]
     assert all(np.isfinite(losses)) and losses[2] < losses[0]
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_fullsubnet_other_hidden_sizes_run_composed(fsn):
+    """Hidden sizes the fused kernels are not built for (sb != 384, fb not a multiple of 64) take the composed
+    path; checked against the oracle."""
+    from oracle import fullsubnet_oracle as O
+    kw = dict(num_freqs=257, look_ahead=2, sequence_model="LSTM", fb_num_neighbors=0, sb_num_neighbors=15,
+              fb_output_activate_function="ReLU", sb_output_activate_function=False, fb_model_hidden_size=200,
+              sb_model_hidden_size=96, norm_type="offline_laplace_norm", num_groups_in_drop_band=1, weight_init=False)
+    params = O.make_params(seed=9, fb_hidden=200, sb_hidden=96, gain=2.0, mask_gain=8.0)
+    m = fsn.Model(**kw)
+    assert not m._fused
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.cuda().eval()
+    mag = np.abs(np.random.default_rng(1).standard_normal((2, 1, 257, 12))).astype(np.float32)
+    with torch.no_grad():
+        crm = m(torch.from_numpy(mag).cuda()).cpu().numpy()
+    want = O.fullsubnet_forward(mag, params)
+    assert np.abs(crm - want).max() <= 1e-4 * max(1.0, np.abs(want).max() / 10)
