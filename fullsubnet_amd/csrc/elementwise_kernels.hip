@@ -108,15 +108,19 @@ __global__ __launch_bounds__(256) void offline_den_kernel(const double* __restri
         if (threadIdx.x == 0) den_fb[b] = (float)(tot / ((double)F * Tp)) + 1e-5f;
     } else {
         for (int f = threadIdx.x; f < F; f += blockDim.x) {
-            int m = 0;
-            for (int u = max(0, f - 2 * nb); u <= min(F - 1, f + 2 * nb); ++u)
-                for (int k = -nb; k <= nb; ++k) m += (reflect_idx(u + k, F) == f) ? 1 : 0;
-            acc += (double)m * binsum[(long)b * FP + f];
+            // m[f] in closed form: pairs (u, k), u in [0, F), k in [-nb, nb], whose source bin is f -
+            // directly (u + k = f), mirrored at the low edge (u + k = -f) or at the high edge
+            // (u + k = 2 (F - 1) - f); checked against the brute-force count in tests/test_host_cpu.py
+            const int direct = min(nb, f) - max(-nb, f - (F - 1)) + 1;
+            const int low = f >= 1 ? max(0, min(F - 1, nb - f) + 1) : 0;
+            const int high = f <= F - 2 ? max(0, F - max(0, 2 * (F - 1) - f - nb)) : 0;
+            acc += (double)(direct + low + high) * binsum[(long)b * FP + f];
         }
-        const float* p = fb_out + (long)b * Tp * FP;
-        for (long i = threadIdx.x; i < (long)Tp * FP; i += blockDim.x) {
-            const int f = (int)(i % FP);
-            if (f < F) acc += (double)p[i];
+        // columns F..FP-1 of fb_out are written as zeros by the output layer: whole rows can be summed
+        const f32x4* p = reinterpret_cast<const f32x4*>(fb_out + (long)b * Tp * FP);
+        for (long i = threadIdx.x; i < (long)Tp * FP / 4; i += blockDim.x) {
+            const f32x4 v = p[i];
+            acc += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
         }
         const double tot = block_sum(acc, scratch);
         if (threadIdx.x == 0) den_sb[b] = (float)(tot / ((double)F * (2 * nb + 2) * Tp)) + 1e-5f;

@@ -159,3 +159,30 @@ def test_leftover_step_kernel_fits_next_to_persistent_kernel(tmp_path):
     # dynamic LDS of the persistent kernel: 16 RT (H + 4) floats for h + the double-buffered layer-0 input tile
     lds_rec = 4 * (64 * 388) + 4 * (2 * 64 * 36)
     assert lds_rec + 3 * step["group_segment_fixed_size"] <= 160 * 1024
+
+
+def test_subband_multiplicity_closed_form():
+    """offline_den_kernel (elementwise_kernels.hip) weighs bin f by m[f] = number of (unit, row) pairs of
+    freq_unfold that read it; the kernel's closed form against the brute-force count over the reflect map."""
+    def brute(F, nb):
+        m = [0] * F
+        for u in range(F):
+            for k in range(-nb, nb + 1):
+                j = abs(u + k)
+                j = 2 * (F - 1) - j if j >= F else j
+                m[j] += 1
+        return m
+
+    def closed(F, nb):
+        out = []
+        for f in range(F):
+            direct = min(nb, f) - max(-nb, f - (F - 1)) + 1
+            low = max(0, min(F - 1, nb - f) + 1) if f >= 1 else 0
+            high = max(0, F - max(0, 2 * (F - 1) - f - nb)) if f <= F - 2 else 0
+            out.append(direct + low + high)
+        return out
+
+    for F, nb in [(257, 15), (257, 0), (64, 5), (481, 15), (33, 15), (20, 7)]:
+        assert brute(F, nb) == closed(F, nb), (F, nb)
+    m = closed(257, 15)
+    assert m[0] == m[256] == 16 and m[1] == 32 and m[100] == 31 and sum(m) == 31 * 257  # SURVEY §8a row A7
