@@ -213,3 +213,44 @@ def test_errors_are_loud(fsn):
     m = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=1, **MODEL_KW).cuda().eval()
     with pytest.raises(fsn._lib.FsnError):
         m.enhance(torch.zeros(1, 4000).cuda(), n_fft=1024, hop_length=512)  # the fused path is 512 / 256 only
+
+
+@pytest.mark.parametrize("F,la,nb,fbh,B,T,norm", [
+    (257, 0, 15, 512, 1, 1, "offline_laplace_norm"),      # a single frame, no look-ahead
+    (161, 1, 7, 256, 3, 9, "offline_laplace_norm"),       # another spectrum size / neighbourhood / full-band width
+    (129, 3, 0, 128, 2, 6, "cumulative_laplace_norm"),    # no neighbours at all: K = 2 -> one padded chunk
+    (65, 2, 31, 64, 5, 4, "cumulative_laplace_norm"),     # neighbourhood almost as wide as the spectrum
+    (257, 2, 15, 512, 17, 3, "offline_laplace_norm"),     # 273 row tiles: persistent kernel + 17 left-over tiles
+])
+def test_fused_forward_other_shapes_vs_oracle(fsn, F, la, nb, fbh, B, T, norm):
+    """fsn_fullsubnet_forward away from the shipped configuration (cfg fields are free: num_freqs, look_ahead,
+    sb_num_neighbors, fb_hidden) against the oracle."""
+    params = O.make_params(seed=F + nb, num_freqs=F, fb_hidden=fbh, sb_hidden=384, sb_num_neighbors=nb, gain=2.0,
+                           mask_gain=12.0)
+    kw = dict(MODEL_KW, num_freqs=F, look_ahead=la, sb_num_neighbors=nb, fb_model_hidden_size=fbh)
+    m = fsn.Model(norm_type=norm, num_groups_in_drop_band=1, **kw)
+    assert m._fused
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.cuda().eval()
+    mag = (np.abs(np.random.default_rng(B * T).standard_normal((B, 1, F, T))) + 0.05).astype(np.float32)
+    with torch.no_grad():
+        crm = m(dev(mag)).cpu().numpy()
+    want = O.fullsubnet_forward(mag, params, look_ahead=la, sb_num_neighbors=nb, norm_type=norm)
+    assert crm.shape == want.shape == (B, 2, F, T)
+    assert np.abs(crm - want).max() <= 1e-4 * max(1.0, np.abs(want).max() / 10)
+
+
+@pytest.mark.parametrize("B,L", [(2, 300), (1, 257), (3, 1024), (2, 4097)])
+def test_enhance_short_and_ragged_lengths_vs_oracle(fsn, B, L):
+    """fsn_enhance at the shortest legal inputs (L = n_fft / 2 + 1: two frames, all reflect padding) and lengths
+    that are / are not multiples of the hop, against the oracle's full path."""
+    params = O.make_params(seed=1, gain=2.0, mask_gain=24.0)
+    m = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=1, **MODEL_KW)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.cuda().eval()
+    noisy = O.make_noisy(B, L, seed=L)
+    enh, crm = m.enhance(dev(noisy), return_crm=True)
+    want, inter = O.full_band_crm_mask(noisy, params, return_intermediates=True)
+    assert enh.shape == (B, L) and crm.shape == inter["crm"].shape
+    assert np.abs(crm.cpu().numpy() - inter["crm"]).max() <= 1e-4
+    assert np.abs(enh.cpu().numpy() - want).max() <= 2e-3 * max(np.abs(want).max(), 1e-6)
