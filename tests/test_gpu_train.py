@@ -165,3 +165,22 @@ def test_mse_loss_vs_torch(fsn, shape):
     (3.0 * ld).backward()
     assert abs(ld.item() - lr_.item()) <= 2e-6 * lr_.item()
     assert (xd.grad.cpu() - xr.grad).abs().max().item() <= 1e-6 * xr.grad.abs().max().item() + 1e-12
+
+
+@pytest.mark.parametrize("norm", ["offline_laplace_norm", "cumulative_laplace_norm"])
+def test_train_mode_forward_equals_eval_forward(fsn, norm):
+    """The autograd graph of the training step (per-layer kernels with saved activations) and the fused
+    inference kernels compute the same forward, for both norms the fused path supports (B > 1: both apply
+    the reference's drop_band)."""
+    model = fsn.Model(norm_type=norm, num_groups_in_drop_band=2, **MODEL_KW)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in O.make_params(seed=3).items()}, strict=True)
+    model = model.cuda()
+    noisy = torch.from_numpy(O.make_noisy(4, 4096, seed=1)).cuda()
+    mag, _, _, _ = fsn.stft(noisy, 512, 256, 512)
+    out_train = model.train()(mag.unsqueeze(1))
+    assert out_train.requires_grad and out_train.shape == (4, 2, 128, 17)
+    with torch.no_grad():
+        out_eval = model.eval()(mag.unsqueeze(1))
+    assert (out_train.detach() - out_eval).abs().max().item() <= 2e-6
+    out_train.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
