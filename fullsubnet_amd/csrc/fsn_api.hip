@@ -802,27 +802,55 @@ extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_i
 }
 
 // Streaming form (frame-by-frame / chunked inference with carried state): T more steps from the state
-// (h, c) [N][H], which is updated in place.  Always on the per-step kernels.
-extern "C" int fsn_lstm_layer_forward_state(const float* x, long ldx, const float* w_ih, const float* w_hh,
-                                            const float* b_ih, const float* b_hh, int T, int N, int I, int H,
+// (h, c) [N][H], which is updated in place.  Always on the per-step kernels.  The weights are re-tiled
+// once (fsn_lstm_layer_pack) - a per-frame caller must not pay three pack launches per layer per call.
+struct LayerPacked {
+    size_t wih, whh, bias, total;  // float offsets
+};
+static LayerPacked layer_packed_layout(int I, int H) {
+    LayerPacked p;
+    const size_t Ipad = fsn_round_up(I, 16);
+    p.wih = 0;
+    p.whh = fsn_round_up_sz(4 * (size_t)H * Ipad, 64);
+    p.bias = p.whh + fsn_round_up_sz(4 * (size_t)H * H, 64);
+    p.total = p.bias + fsn_round_up_sz(4 * (size_t)H, 64);
+    return p;
+}
+extern "C" size_t fsn_lstm_layer_packed_bytes(int I, int H) {
+    if (I < 1 || H < 64 || H % 64) return 0;
+    return layer_packed_layout(I, H).total * sizeof(float);
+}
+extern "C" int fsn_lstm_layer_pack(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int I,
+                                   int H, void* packed, size_t packed_bytes, void* stream) {
+    FSN_REQUIRE(w_ih && w_hh && b_ih && b_hh && packed, "NULL pointer argument");
+    FSN_REQUIRE(I >= 1 && H >= 64 && H % 64 == 0, "lstm layer: need I >= 1 and H a multiple of 64 (got %d, %d)", I, H);
+    if (packed_bytes < fsn_lstm_layer_packed_bytes(I, H)) {
+        fsn_set_error("lstm layer pack: buffer too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const LayerPacked p = layer_packed_layout(I, H);
+    float* o = static_cast<float*>(packed);
+    FSN_TRY(fsn_launch_pack(w_ih, o + p.wih, 4 * H, I, 4 * H, fsn_round_up(I, 16), s));
+    FSN_TRY(fsn_launch_pack(w_hh, o + p.whh, 4 * H, H, 4 * H, H, s));
+    return fsn_launch_bias_sum(b_ih, b_hh, o + p.bias, 4 * H, 4 * H, s);
+}
+extern "C" size_t fsn_lstm_layer_state_workspace_bytes(int T, int N, int H) {
+    return fsn_round_up_sz((size_t)T * N * 4 * H * sizeof(float), 256);  // the input projection of the T steps
+}
+extern "C" int fsn_lstm_layer_forward_state(const float* x, long ldx, const void* packed, int T, int N, int I, int H,
                                             float* hseq, float* h_state, float* c_state, void* workspace,
                                             size_t workspace_bytes, void* stream) {
     FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
-    FSN_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && hseq && h_state && c_state && workspace, "NULL pointer argument");
-    if (workspace_bytes < fsn_lstm_layer_fwd_workspace_bytes(T, N, I, H)) {
+    FSN_REQUIRE(x && packed && hseq && h_state && c_state && workspace, "NULL pointer argument");
+    if (workspace_bytes < fsn_lstm_layer_state_workspace_bytes(T, N, H)) {
         fsn_set_error("lstm layer forward: workspace too small");
         return FSN_ERR_WORKSPACE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int Ipad = fsn_round_up(I, 16);
-    Carver cv(workspace);
-    float* wih_p = cv.take<float>((size_t)4 * H * Ipad);
-    float* whh_p = cv.take<float>((size_t)4 * H * H);
-    float* bias = cv.take<float>((size_t)4 * H);
-    float* gx = cv.take<float>((size_t)T * N * 4 * H);
-    FSN_TRY(fsn_launch_pack(w_ih, wih_p, 4 * H, I, 4 * H, Ipad, s));
-    FSN_TRY(fsn_launch_pack(w_hh, whh_p, 4 * H, H, 4 * H, H, s));
-    FSN_TRY(fsn_launch_bias_sum(b_ih, b_hh, bias, 4 * H, 4 * H, s));
+    const LayerPacked p = layer_packed_layout(I, H);
+    const float* pk = static_cast<const float*>(packed);
+    float* gx = static_cast<float*>(workspace);
     FsnGemmA a{};
     a.kind = 0;
     a.p0 = x;
@@ -830,11 +858,11 @@ extern "C" int fsn_lstm_layer_forward_state(const float* x, long ldx, const floa
     FsnGemmC c{};
     c.kind = 0;
     c.p0 = gx;
-    c.bias = bias;
-    FSN_TRY(fsn_launch_gemm(a, wih_p, c, T * (N / 16), 4 * H / 16, Ipad / 16, s));
+    c.bias = pk + p.bias;
+    FSN_TRY(fsn_launch_gemm(a, pk + p.wih, c, T * (N / 16), 4 * H / 16, fsn_round_up(I, 16) / 16, s));
     const size_t step = (size_t)N * H;
     for (int t = 0; t < T; ++t)
-        FSN_TRY(fsn_launch_lstm_step(gx, whh_p, t ? hseq + (t - 1) * step : h_state, hseq + t * step, c_state,
+        FSN_TRY(fsn_launch_lstm_step(gx, pk + p.whh, t ? hseq + (t - 1) * step : h_state, hseq + t * step, c_state,
                                      (long)t * (N / 16), N / 16, H, 0, s));
     if (hipMemcpyAsync(h_state, hseq + (size_t)(T - 1) * step, step * sizeof(float), hipMemcpyDeviceToDevice, s) !=
         hipSuccess) {

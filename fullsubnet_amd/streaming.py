@@ -24,6 +24,25 @@ from .base_model import EPSILON, BaseModel
 from .sequence_model import _round_up, linear_infer
 
 
+def _packed_layers(block):
+    """MFMA-fragment copies of the block's (padded) layer weights, rebuilt only when a parameter changed."""
+    layers, fc = block._inference_weights()
+    key = block._padded_key  # (data_ptr, version, device) of every parameter
+    cached = getattr(block, "_stream_packed", None)
+    if cached is None or cached[0] != key:
+        L = _lib.lib()
+        packed = []
+        for w_ih, w_hh, b_ih, b_hh in layers:
+            I, H = w_ih.shape[1], w_hh.shape[1]
+            buf = _lib.workspace(L.fsn_lstm_layer_packed_bytes(I, H), w_ih.device)
+            _lib.check(L.fsn_lstm_layer_pack(_lib.dev_ptr(w_ih), _lib.dev_ptr(w_hh), _lib.dev_ptr(b_ih), _lib.dev_ptr(b_hh),
+                                             I, H, buf.data_ptr(), buf.numel(), _lib.stream_ptr(w_ih.device)))
+            packed.append((buf, I, H))
+        cached = (key, packed)
+        block._stream_packed = cached
+    return cached[1], fc
+
+
 def _block_forward_state(block, x, state):
     """SequenceModel.forward for k more frames.  x [B, F, k]; state: list of (h, c) [Np, Hp] per layer
     (updated in place).  Returns [B, O, k]."""
@@ -33,17 +52,15 @@ def _block_forward_state(block, x, state):
     B, F, k = x.shape
     H, Hp = block.hidden_size, _round_up(block.hidden_size, 64)
     Np, Ip = _round_up(B, 16), _round_up(F, 16)
-    layers, fc = block._inference_weights()
+    packed, fc = _packed_layers(block)
     h = torch.zeros((k, Np, Ip), dtype=torch.float32, device=x.device)
     h[:, :B, :F] = x.permute(2, 0, 1)
-    for (w_ih, w_hh, b_ih, b_hh), (hs, cs) in zip(layers, state):
-        I = w_ih.shape[1]
-        hseq = torch.empty((k, Np, Hp), dtype=torch.float32, device=x.device)
-        ws = _lib.workspace(L.fsn_lstm_layer_fwd_workspace_bytes(k, Np, I, Hp), x.device)
+    for (buf, I, Hl), (hs, cs) in zip(packed, state):
+        hseq = torch.empty((k, Np, Hl), dtype=torch.float32, device=x.device)
+        ws = _lib.workspace(L.fsn_lstm_layer_state_workspace_bytes(k, Np, Hl), x.device)
         _lib.check(L.fsn_lstm_layer_forward_state(
-            _lib.dev_ptr(h, "x"), h.shape[2], _lib.dev_ptr(w_ih), _lib.dev_ptr(w_hh), _lib.dev_ptr(b_ih),
-            _lib.dev_ptr(b_hh), k, Np, I, Hp, _lib.dev_ptr(hseq), _lib.dev_ptr(hs), _lib.dev_ptr(cs), ws.data_ptr(),
-            ws.numel(), _lib.stream_ptr(x.device)))
+            _lib.dev_ptr(h, "x"), h.shape[2], buf.data_ptr(), k, Np, I, Hl, _lib.dev_ptr(hseq), _lib.dev_ptr(hs),
+            _lib.dev_ptr(cs), ws.data_ptr(), ws.numel(), _lib.stream_ptr(x.device)))
         h = hseq
     relu = block.output_activate_function == "ReLU"
     if fc is not None:

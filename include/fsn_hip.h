@@ -124,10 +124,16 @@ int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_ih, const fl
                            size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream);
 /* Streaming inference (chunked / frame-by-frame processing with carried state - the real-time use the
  * model is designed for; the reference has no such entry point, nn.LSTM's (h_0, c_0) argument is the
- * analogue): T more steps starting from h_state / c_state [N][H], both updated in place. */
-int fsn_lstm_layer_forward_state(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
-                                 const float* b_hh, int T, int N, int I, int H, float* hseq, float* h_state,
-                                 float* c_state, void* workspace, size_t workspace_bytes, void* stream);
+ * analogue).  fsn_lstm_layer_pack re-tiles one layer's weights once; fsn_lstm_layer_forward_state then runs
+ * T more steps starting from h_state / c_state [N][H], both updated in place, with two launches plus one per
+ * step.  workspace >= fsn_lstm_layer_state_workspace_bytes(T, N, H). */
+size_t fsn_lstm_layer_packed_bytes(int I, int H);
+int fsn_lstm_layer_pack(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int I, int H,
+                        void* packed, size_t packed_bytes, void* stream);
+size_t fsn_lstm_layer_state_workspace_bytes(int T, int N, int H);
+int fsn_lstm_layer_forward_state(const float* x, long ldx, const void* packed, int T, int N, int I, int H,
+                                 float* hseq, float* h_state, float* c_state, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 /* dh [T][N][H] = dLoss/dhseq.  Outputs: dx [T][N][lddx] (may be NULL), dw_ih [4H][I], dw_hh [4H][H],
  * db [4H] (= d b_ih = d b_hh). */
 size_t fsn_lstm_layer_bwd_workspace_bytes(int T, int N, int I, int H);
