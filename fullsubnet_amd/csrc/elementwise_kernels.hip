@@ -129,18 +129,21 @@ __global__ __launch_bounds__(256) void offline_den_kernel(const double* __restri
 
 // cumulative_laplace_norm (base_model.py:221-251) for the full-band input [B,1,F,Tp]:
 // den[b][t] = (sum_{tau<=t} sum_f mag[b][tau][f]) / (F (t+1)) + EPSILON.  One block per utterance.
+// `carry` (may be NULL) / `t0`: streaming - the running sum of the t0 frames seen before this call, updated.
 __global__ __launch_bounds__(256) void cumulative_den_fb_kernel(const float* __restrict__ mag,
-                                                                float* __restrict__ den, int Tp, int F, int FP) {
+                                                                float* __restrict__ den, int Tp, int F, int FP,
+                                                                double* __restrict__ carry, int t0) {
     __shared__ double scratch[4];
     const int b = blockIdx.x;
-    double run = 0.0;
+    double run = carry ? carry[b] : 0.0;
     for (int t = 0; t < Tp; ++t) {
         double acc = 0.0;
         for (int f = threadIdx.x; f < F; f += blockDim.x) acc += (double)mag[((long)b * Tp + t) * FP + f];
         run += block_sum(acc, scratch);
         if (threadIdx.x == 0)
-            den[(long)b * Tp + t] = (float)(run / ((double)F * (t + 1))) + 1.1920928955078125e-07f;
+            den[(long)b * Tp + t] = (float)(run / ((double)F * (t0 + t + 1))) + 1.1920928955078125e-07f;
     }
+    if (carry && threadIdx.x == 0) carry[b] = run;
 }
 
 // cumulative_laplace_norm on the 4-D sub-band tensor [B, F, 2nb+2, Tp] (quirk Q4): every unit
@@ -150,18 +153,20 @@ __global__ __launch_bounds__(256) void cumulative_den_fb_kernel(const float* __r
 __global__ __launch_bounds__(256) void cumulative_den_sb_kernel(const float* __restrict__ mag,
                                                                 const float* __restrict__ fb_out,
                                                                 float* __restrict__ den, int B, int Tp, int F,
-                                                                int FP, int nb, int Npad) {
+                                                                int FP, int nb, int Npad, double* __restrict__ carry,
+                                                                int t0) {
     const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= (long)B * F) return;
     const int b = (int)(n / F), f = (int)(n % F);
-    double run = 0.0;
+    double run = carry ? carry[n] : 0.0;
     for (int t = 0; t < Tp; ++t) {
         const float* row = mag + ((long)b * Tp + t) * FP;
         double acc = (double)fb_out[((long)b * Tp + t) * FP + f];
         for (int k = -nb; k <= nb; ++k) acc += (double)row[reflect_idx(f + k, F)];
         run += acc;
-        den[(long)t * Npad + n] = (float)(run / ((double)(2 * nb + 2) * (t + 1))) + 1.1920928955078125e-07f;
+        den[(long)t * Npad + n] = (float)(run / ((double)(2 * nb + 2) * (t0 + t + 1))) + 1.1920928955078125e-07f;
     }
+    if (carry) carry[n] = run;
 }
 
 }  // namespace
@@ -201,14 +206,15 @@ int fsn_launch_offline_den(const double* binsum, const float* fb_out, float* den
                        which);
     return fsn_check_launch("offline_den_kernel");
 }
-int fsn_launch_cumulative_den_fb(const float* mag, float* den, int B, int Tp, int F, int FP, hipStream_t s) {
-    hipLaunchKernelGGL(cumulative_den_fb_kernel, dim3(B), dim3(256), 0, s, mag, den, Tp, F, FP);
+int fsn_launch_cumulative_den_fb(const float* mag, float* den, int B, int Tp, int F, int FP, hipStream_t s,
+                                 double* carry, int t0) {
+    hipLaunchKernelGGL(cumulative_den_fb_kernel, dim3(B), dim3(256), 0, s, mag, den, Tp, F, FP, carry, t0);
     return fsn_check_launch("cumulative_den_fb_kernel");
 }
 int fsn_launch_cumulative_den_sb(const float* mag, const float* fb_out, float* den, int B, int Tp, int F, int FP,
-                                 int nb, int Npad, hipStream_t s) {
+                                 int nb, int Npad, hipStream_t s, double* carry, int t0) {
     const long n = (long)B * F;
     hipLaunchKernelGGL(cumulative_den_sb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mag, fb_out, den,
-                       B, Tp, F, FP, nb, Npad);
+                       B, Tp, F, FP, nb, Npad, carry, t0);
     return fsn_check_launch("cumulative_den_sb_kernel");
 }

@@ -578,6 +578,169 @@ extern "C" int fsn_fullsubnet_forward(const fsn_fullsubnet_cfg* cfg, const void*
     return FSN_OK;
 }
 
+// ---- streaming: k more frames of the model with carried state -------------------------------------
+// State (caller-owned, zero-filled for a new stream): (h, c) of the four LSTM layers and the running sums
+// of the two cumulative Laplace norms.
+struct StreamState {
+    float *fb_h0, *fb_h1, *fb_c0, *fb_c1, *sb_h0, *sb_h1, *sb_c0, *sb_c1;
+    double *fb_sum, *sb_sum;
+};
+static StreamState stream_carve(Carver& cv, const fsn_fullsubnet_cfg* cfg, int B) {
+    StreamState st;
+    const size_t nfb = (size_t)fsn_round_up(B, 16) * cfg->fb_hidden;
+    const size_t nsb = (size_t)fsn_round_up(B * cfg->num_freqs, 16) * cfg->sb_hidden;
+    st.fb_h0 = cv.take<float>(nfb);
+    st.fb_h1 = cv.take<float>(nfb);
+    st.fb_c0 = cv.take<float>(nfb);
+    st.fb_c1 = cv.take<float>(nfb);
+    st.sb_h0 = cv.take<float>(nsb);
+    st.sb_h1 = cv.take<float>(nsb);
+    st.sb_c0 = cv.take<float>(nsb);
+    st.sb_c1 = cv.take<float>(nsb);
+    st.fb_sum = cv.take<double>((size_t)B);
+    st.sb_sum = cv.take<double>((size_t)B * cfg->num_freqs);
+    return st;
+}
+struct StreamWs {
+    float *magT, *crm_r, *crm_i, *den_fb, *gx_fb, *hseq_fb0, *hseq_fb1, *fb_out, *den_sb, *gx_sb, *hseq_sb0, *hseq_sb1;
+};
+static StreamWs stream_ws_carve(Carver& cv, const fsn_fullsubnet_cfg* cfg, int B, int k) {
+    StreamWs w;
+    const int FP = fsn_fpad(cfg->num_freqs), Npad_fb = fsn_round_up(B, 16), Npad = fsn_round_up(B * cfg->num_freqs, 16);
+    const size_t plane = (size_t)B * k * FP;
+    w.magT = cv.take<float>(plane);
+    w.crm_r = cv.take<float>(plane);
+    w.crm_i = cv.take<float>(plane);
+    w.den_fb = cv.take<float>((size_t)B * k);
+    w.gx_fb = cv.take<float>((size_t)k * Npad_fb * 4 * cfg->fb_hidden);
+    w.hseq_fb0 = cv.take<float>((size_t)k * Npad_fb * cfg->fb_hidden);
+    w.hseq_fb1 = cv.take<float>((size_t)k * Npad_fb * cfg->fb_hidden);
+    w.fb_out = cv.take<float>(plane);
+    w.den_sb = cv.take<float>((size_t)k * Npad);
+    w.gx_sb = cv.take<float>((size_t)k * Npad * 4 * cfg->sb_hidden);
+    w.hseq_sb0 = cv.take<float>((size_t)k * Npad * cfg->sb_hidden);
+    w.hseq_sb1 = cv.take<float>((size_t)k * Npad * cfg->sb_hidden);
+    return w;
+}
+static int check_stream(const fsn_fullsubnet_cfg* cfg, int B, int k) {
+    FSN_TRY(check_cfg(cfg));
+    FSN_REQUIRE(cfg->norm_type == FSN_NORM_CUMULATIVE_LAPLACE, "streaming needs the causal norm (FSN_NORM_CUMULATIVE_LAPLACE)");
+    FSN_REQUIRE(B >= 1 && B <= 4096 && k >= 1 && k <= 4096, "streaming: batch %d / frames %d out of range", B, k);
+    return FSN_OK;
+}
+extern "C" size_t fsn_fullsubnet_stream_state_bytes(const fsn_fullsubnet_cfg* cfg, int B) {
+    if (check_stream(cfg, B, 1) != FSN_OK) return 0;
+    Carver cv(nullptr);
+    stream_carve(cv, cfg, B);
+    return fsn_round_up_sz(cv.off, 256);
+}
+extern "C" size_t fsn_fullsubnet_stream_workspace_bytes(const fsn_fullsubnet_cfg* cfg, int B, int k) {
+    if (check_stream(cfg, B, k) != FSN_OK) return 0;
+    Carver cv(nullptr);
+    stream_ws_carve(cv, cfg, B, k);
+    return fsn_round_up_sz(cv.off, 256);
+}
+
+extern "C" int fsn_fullsubnet_stream_step(const fsn_fullsubnet_cfg* cfg, const void* packed, void* state,
+                                          size_t state_bytes, int steps_done, const float* mag, int B, int k,
+                                          float* crm_out, void* workspace, size_t workspace_bytes, void* stream) {
+    FSN_TRY(check_stream(cfg, B, k));
+    FSN_REQUIRE(packed && state && mag && crm_out && workspace && steps_done >= 0, "NULL pointer argument / negative step count");
+    if (state_bytes < fsn_fullsubnet_stream_state_bytes(cfg, B) ||
+        workspace_bytes < fsn_fullsubnet_stream_workspace_bytes(cfg, B, k)) {
+        fsn_set_error("streaming: state / workspace buffer too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Packed p = packed_layout(cfg);
+    const float* pk = static_cast<const float*>(packed);
+    const int F = cfg->num_freqs, FP = fsn_fpad(F), Hf = cfg->fb_hidden, Hs = cfg->sb_hidden, nb = cfg->sb_num_neighbors;
+    const int Npad_fb = fsn_round_up(B, 16), N = B * F, Npad = fsn_round_up(N, 16);
+    Carver cs(state), cw(workspace);
+    const StreamState st = stream_carve(cs, cfg, B);
+    const StreamWs w = stream_ws_carve(cw, cfg, B, k);
+    // [B, 1, F, k] -> frame-major [B][k][FP]
+    FSN_TRY(fsn_launch_transpose(mag, w.magT, B, FP, k, k, (long)F * k, FP, (long)k * FP, F, k, s));
+    FSN_TRY(fsn_launch_cumulative_den_fb(w.magT, w.den_fb, B, k, F, FP, s, st.fb_sum, steps_done));
+    FsnGemmA a{};
+    FsnGemmC c{};
+    a.kind = 1;
+    a.p0 = w.magT;
+    a.den = w.den_fb;
+    a.den_mode = 1;
+    a.B = B;
+    a.Tp = k;
+    a.F = F;
+    a.FP = FP;
+    a.Npad = Npad_fb;
+    c.kind = 0;
+    c.p0 = w.gx_fb;
+    c.bias = pk + p.fb_b0;
+    const int fb_rt = k * Npad_fb / 16;
+    FSN_TRY(fsn_launch_gemm(a, pk + p.fb_wih0, c, fb_rt, 4 * Hf / 16, FP / 16, s));
+    FSN_TRY(fsn_launch_lstm_wavefront2(w.gx_fb, Npad_fb / 16, 0, pk + p.fb_whh0, pk + p.fb_wih1, pk + p.fb_b1_frag,
+                                       pk + p.fb_whh1, w.hseq_fb0, w.hseq_fb1, Npad_fb, 0, st.fb_c0, st.fb_c1, k,
+                                       Npad_fb / 16, Hf, s, st.fb_h0, st.fb_h1));
+    a = FsnGemmA{};
+    c = FsnGemmC{};
+    a.kind = 0;
+    a.p0 = w.hseq_fb1;
+    a.ld = Hf;
+    c.kind = 1;
+    c.p0 = w.fb_out;
+    c.bias = pk + p.fb_fcb;
+    c.B = B;
+    c.Tp = k;
+    c.F = F;
+    c.FP = FP;
+    c.Npad = Npad_fb;
+    FSN_TRY(fsn_launch_gemm(a, pk + p.fb_fc, c, fb_rt, FP / 16, Hf / 16, s));
+    FSN_TRY(fsn_launch_cumulative_den_sb(w.magT, w.fb_out, w.den_sb, B, k, F, FP, nb, Npad, s, st.sb_sum, steps_done));
+    a = FsnGemmA{};
+    c = FsnGemmC{};
+    a.kind = 2;
+    a.p0 = w.magT;
+    a.p1 = w.fb_out;
+    a.den = w.den_sb;
+    a.den_mode = 1;
+    a.den_stride = Npad;
+    a.B = B;
+    a.Tp = k;
+    a.F = F;
+    a.FP = FP;
+    a.Npad = Npad;
+    a.n_offset = 0;
+    a.N = N;
+    a.nb = nb;
+    c.kind = 0;
+    c.p0 = w.gx_sb;
+    c.bias = pk + p.sb_b0;
+    const int sb_rt = (int)((long)k * Npad / 16);
+    FSN_TRY(fsn_launch_gemm(a, pk + p.sb_wih0, c, sb_rt, 4 * Hs / 16, p.sb_kin_pad / 16, s));
+    FSN_TRY(fsn_launch_lstm_wavefront2(w.gx_sb, Npad / 16, 0, pk + p.sb_whh0, pk + p.sb_wih1, pk + p.sb_b1_frag,
+                                       pk + p.sb_whh1, w.hseq_sb0, w.hseq_sb1, Npad, 0, st.sb_c0, st.sb_c1, k, Npad / 16,
+                                       Hs, s, st.sb_h0, st.sb_h1));
+    a = FsnGemmA{};
+    c = FsnGemmC{};
+    a.kind = 0;
+    a.p0 = w.hseq_sb1;
+    a.ld = Hs;
+    c.kind = 2;
+    c.p0 = w.crm_r;
+    c.p1 = w.crm_i;
+    c.bias = pk + p.sb_fcb;
+    c.T = k;
+    c.F = F;
+    c.FP = FP;
+    c.Npad = Npad;
+    c.N = N;
+    c.la = 0;  // every model step is handed back; the caller matches step s to output frame s - look_ahead
+    FSN_TRY(fsn_launch_gemm(a, pk + p.sb_fc, c, sb_rt, 1, Hs / 16, s));
+    FSN_TRY(fsn_launch_transpose(w.crm_r, crm_out, B, k, F, FP, (long)k * FP, k, 2L * F * k, k, F, s));
+    FSN_TRY(fsn_launch_transpose(w.crm_i, crm_out + (size_t)F * k, B, k, F, FP, (long)k * FP, k, 2L * F * k, k, F, s));
+    return FSN_OK;
+}
+
 // ---- STFT / iSTFT boundary -------------------------------------------------------------------
 static bool fast_fft(int n_fft, int hop) { return n_fft == 512 && hop == 256; }
 

@@ -104,9 +104,11 @@ int fsn_launch_transpose(const float* in, float* out, int batch, int R, int C, l
 int fsn_launch_binsum(const float* mag, double* binsum, int B, int Tp, int FP, hipStream_t s);
 int fsn_launch_offline_den(const double* binsum, const float* fb_out, float* den_fb, float* den_sb, int B,
                            int Tp, int F, int FP, int nb, int which, hipStream_t s);
-int fsn_launch_cumulative_den_fb(const float* mag, float* den, int B, int Tp, int F, int FP, hipStream_t s);
+// carry / t0: streaming continuation (running sums of the t0 frames already seen, updated in place); NULL / 0 offline
+int fsn_launch_cumulative_den_fb(const float* mag, float* den, int B, int Tp, int F, int FP, hipStream_t s,
+                                 double* carry = nullptr, int t0 = 0);
 int fsn_launch_cumulative_den_sb(const float* mag, const float* fb_out, float* den, int B, int Tp, int F,
-                                 int FP, int nb, int Npad, hipStream_t s);
+                                 int FP, int nb, int Npad, hipStream_t s, double* carry = nullptr, int t0 = 0);
 
 // gemm_kernels.hip
 struct FsnGemmA {  // A operand description
@@ -203,6 +205,9 @@ int fsn_launch_lstm_step_train(const float* gx, const float* whh_p, const float*
 int fsn_launch_lstm_rec(const float* gx, const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad,
                         int H, int RT, int main_wgs, hipStream_t s, const FsnRecFc* fc = nullptr);
 bool fsn_lstm_rec_can_fuse_fc(int RT, bool xin);
+// state_h0 / state_h1 (may be NULL): streaming continuation - the hidden states before this call ([rows][H],
+// updated to the last step's on return); c0 / c1 then hold the carried cell states.
 int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, const float* whh0_p, const float* wih1_p,
-                               const float* bias1, const float* whh1_p, float* hseq0, float* hseq1, long hs_stride,
-                               long hs_off, float* c0, float* c1, int T, int row_tiles, int H, hipStream_t s);
+                               const float* bias1_frag, const float* whh1_p, float* hseq0, float* hseq1, long hs_stride,
+                               long hs_off, float* c0, float* c1, int T, int row_tiles, int H, hipStream_t s,
+                               float* state_h0 = nullptr, float* state_h1 = nullptr);

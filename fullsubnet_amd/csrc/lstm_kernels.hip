@@ -804,11 +804,13 @@ int fsn_launch_lstm_step_train(const float* gx, const float* whh_p, const float*
 // with this launch's rows starting at row hs_off; c0 / c1: [row_tiles * 16][H].
 int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, const float* whh0_p, const float* wih1_p,
                                const float* bias1_frag, const float* whh1_p, float* hseq0, float* hseq1, long hs_stride,
-                               long hs_off, float* c0, float* c1, int T, int row_tiles, int H, hipStream_t s) {
-    if (H % 64 != 0) {
-        fsn_set_error("lstm_wavefront2: hidden size %d must be a multiple of 64", H);
+                               long hs_off, float* c0, float* c1, int T, int row_tiles, int H, hipStream_t s,
+                               float* state_h0, float* state_h1) {
+    if (H % 64 != 0 || (state_h0 == nullptr) != (state_h1 == nullptr)) {
+        fsn_set_error("lstm_wavefront2: hidden size %d must be a multiple of 64 (and both states or none)", H);
         return FSN_ERR_ARG;
     }
+    const bool cont = state_h0 != nullptr;
     const size_t step = (size_t)hs_stride * H;
     float* h0 = hseq0 + (size_t)hs_off * H;
     float* h1 = hseq1 + (size_t)hs_off * H;
@@ -822,10 +824,10 @@ int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, co
             a.add_rt0 = (long)i * gx_stride + gx_off;
             a.add_rs = 1;
             a.whh_p = whh0_p;
-            a.h_prev = i ? h0 + (i - 1) * step : h0;
+            a.h_prev = i ? h0 + (i - 1) * step : (cont ? state_h0 : h0);
             a.h_out = h0 + i * step;
             a.c = c0;
-            a.first = i == 0;
+            a.first = i == 0 && !cont;
         }
         if (i >= 1) {
             const int t = i - 1;
@@ -836,13 +838,21 @@ int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, co
             b.xw_p = wih1_p;
             b.x = h0 + t * step;
             b.whh_p = whh1_p;
-            b.h_prev = t ? h1 + (t - 1) * step : h1;
+            b.h_prev = t ? h1 + (t - 1) * step : (cont ? state_h1 : h1);
             b.h_out = h1 + t * step;
             b.c = c1;
-            b.first = t == 0;
+            b.first = t == 0 && !cont;
         }
         hipLaunchKernelGGL(lstm_step2_kernel, dim3(H / 16, row_tiles, 2), dim3(256), 0, s, jobs, H);
         FSN_TRY_LAUNCH("lstm_step2_kernel");
+    }
+    if (cont) {
+        const size_t bytes = (size_t)row_tiles * 16 * H * sizeof(float);
+        if (hipMemcpyAsync(state_h0, h0 + (size_t)(T - 1) * step, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(state_h1, h1 + (size_t)(T - 1) * step, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            fsn_set_error("lstm_wavefront2: state copy failed");
+            return FSN_ERR_LAUNCH;
+        }
     }
     return FSN_OK;
 }

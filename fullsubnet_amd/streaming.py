@@ -10,11 +10,15 @@ utterance); ``StreamingEnhancer`` produces the same samples incrementally:
     out.append(enh.flush())                   # the rest; concatenation == offline result
 
 What is carried between calls: the last input samples (STFT overlap), the running sums of the two
-cumulative Laplace norms (base_model.py:221-251), (h, c) of the four LSTM layers
-(``fsn_lstm_layer_forward_state``), the spectra waiting for their mask (``look_ahead`` frames) and the
-last enhanced frame (overlap-add).  Every stage is the same kernel as in the offline path, applied to
-the new frames only; tests/test_gpu_streaming.py checks chunked == whole-utterance.
+cumulative Laplace norms (base_model.py:221-251) and (h, c) of the four LSTM layers (one device blob
+advanced by ``fsn_fullsubnet_stream_step``: the whole model on k more frames in one C call), the spectra
+waiting for their mask (``look_ahead`` frames) and the last enhanced frame (overlap-add).  Every stage is
+the same kernel as in the offline path, applied to the new frames only; tests/test_gpu_streaming.py checks
+chunked == whole-utterance.  Configurations outside the fused kernels (other hidden sizes, neighbours ...)
+run the same steps from the per-layer stateful entry (``fsn_lstm_layer_forward_state``) and tensor algebra.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -101,10 +105,16 @@ class StreamingEnhancer:
         self._n_in = 0          # samples received
         self._t_next = 0        # next STFT frame to compute
         self._tau = 0           # model steps done (input frames incl. the look-ahead zeros at the end)
-        self._fb_state = _new_state(m.fb_model, B, dev)
-        self._sb_state = _new_state(m.sb_model, B * m.num_freqs, dev)
-        self._fb_sum = torch.zeros((B,), dtype=torch.float32, device=dev)
-        self._sb_sum = torch.zeros((B * m.num_freqs,), dtype=torch.float32, device=dev)
+        if m._fused:  # the whole frame step is one C call (fsn_fullsubnet_stream_step) on one state blob
+            nbytes = _lib.lib().fsn_fullsubnet_stream_state_bytes(ctypes.byref(m._cfg), B)
+            if nbytes == 0:
+                raise _lib.FsnError(_lib.lib().fsn_last_error().decode())
+            self._state = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        else:         # composed configurations: per-block stateful layers + tensor algebra
+            self._fb_state = _new_state(m.fb_model, B, dev)
+            self._sb_state = _new_state(m.sb_model, B * m.num_freqs, dev)
+            self._fb_sum = torch.zeros((B,), dtype=torch.float32, device=dev)
+            self._sb_sum = torch.zeros((B * m.num_freqs,), dtype=torch.float32, device=dev)
         self._spec = []         # (re, im) [B, F, 1] of frames waiting for their mask, oldest first
         self._m_next = 0        # next output frame to mask
         self._prev = None       # enhanced (re, im) of frame _m_next - 1 (overlap-add partner)
@@ -117,6 +127,17 @@ class StreamingEnhancer:
         """mag [B, F, k] -> compressed cIRM of model steps tau .. tau + k - 1, [B, 2, F, k]."""
         m = self.model
         B, F, k = mag.shape
+        if m._fused:
+            L = _lib.lib()
+            x = mag.contiguous()
+            out = torch.empty((B, 2, F, k), dtype=torch.float32, device=x.device)
+            ws = _lib.workspace(L.fsn_fullsubnet_stream_workspace_bytes(ctypes.byref(m._cfg), B, k), x.device)
+            _lib.check(L.fsn_fullsubnet_stream_step(
+                ctypes.byref(m._cfg), m.packed_weights().data_ptr(), self._state.data_ptr(), self._state.numel(),
+                self._tau, _lib.dev_ptr(x, "mag"), B, k, _lib.dev_ptr(out), ws.data_ptr(), ws.numel(),
+                _lib.stream_ptr(x.device)))
+            self._tau += k
+            return out
         t = torch.arange(self._tau + 1, self._tau + k + 1, dtype=torch.float32, device=mag.device)  # frames so far
         # full-band cumulative Laplace norm (base_model.py:221-251) continued from the carried sum
         cum = self._fb_sum[:, None] + torch.cumsum(mag.sum(dim=1), dim=-1)

@@ -107,6 +107,22 @@ int fsn_enhance(const fsn_fullsubnet_cfg* cfg, const void* packed, const float* 
                 const float* noisy, int B, int L, int n_fft, int hop, float* enhanced, float* crm_out,
                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- streaming: the model on k more frames with carried state --------------------------------- */
+
+/* Frame-by-frame / chunked form of fsn_fullsubnet_forward for real-time use (not in the reference, which only
+ * has the whole-utterance loop of inferencer.py:130-145): `state` carries (h, c) of the four LSTM layers and the
+ * running sums of the two cumulative Laplace norms (base_model.py:221-251; norm_type must be
+ * FSN_NORM_CUMULATIVE_LAPLACE) from call to call - zero-fill it for a new stream.  mag [B, 1, F, k] are the
+ * next k input frames of the model (the caller appends the look_ahead zero frames of model.py:85 at the end of
+ * the stream), steps_done the number of frames passed in before this call, crm_out [B, 2, F, k] the model
+ * output of exactly these steps (step s is the compressed mask of frame s - look_ahead).  Feeding a stream in
+ * any chunking gives the offline result. */
+size_t fsn_fullsubnet_stream_state_bytes(const fsn_fullsubnet_cfg* cfg, int B);
+size_t fsn_fullsubnet_stream_workspace_bytes(const fsn_fullsubnet_cfg* cfg, int B, int k);
+int fsn_fullsubnet_stream_step(const fsn_fullsubnet_cfg* cfg, const void* packed, void* state, size_t state_bytes,
+                               int steps_done, const float* mag, int B, int k, float* crm_out, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
 /* ---- training step: one nn.LSTM layer with back-propagation through time ----------------- */
 
 /* audio_zen/model/module/sequence_model.py:52-58 (nn.LSTM, one layer, batch_first, h0 = c0 = 0) as

@@ -83,3 +83,21 @@ def test_streaming_is_chunking_invariant_and_resettable(setup):
         enh.process(noisy)
     with pytest.raises(ValueError):
         StreamingEnhancer(fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=1, **MODEL_KW).cuda())
+
+
+def test_streaming_composed_configuration(setup):
+    """A configuration outside the fused kernels (other hidden sizes) streams through the per-layer stateful
+    entry point (fsn_lstm_layer_forward_state); same contract: chunked == offline."""
+    fsn, _, _ = setup
+    kw = dict(MODEL_KW, fb_model_hidden_size=192, sb_model_hidden_size=128)
+    params = O.make_params(seed=6, fb_hidden=192, sb_hidden=128, gain=2.0, mask_gain=8.0)
+    m = fsn.Model(norm_type="cumulative_laplace_norm", num_groups_in_drop_band=1, **kw)
+    assert not m._fused
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.cuda().eval()
+    noisy = torch.from_numpy(O.make_noisy(2, 3000, seed=8)).cuda()
+    got, _ = run_stream(fsn, m, noisy, [256, 700, 44, 2000])
+    offline = m.enhance(noisy)
+    assert (got - offline).abs().max().item() <= 1e-4 * offline.abs().max().item()
+    want = O.full_band_crm_mask(noisy.cpu().numpy(), params, norm_type="cumulative_laplace_norm")
+    assert np.abs(got.cpu().numpy() - want).max() <= 2e-3 * np.abs(want).max()
