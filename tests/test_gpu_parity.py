@@ -254,3 +254,50 @@ def test_enhance_short_and_ragged_lengths_vs_oracle(fsn, B, L):
     assert enh.shape == (B, L) and crm.shape == inter["crm"].shape
     assert np.abs(crm.cpu().numpy() - inter["crm"]).max() <= 1e-4
     assert np.abs(enh.cpu().numpy() - want).max() <= 2e-3 * max(np.abs(want).max(), 1e-6)
+
+
+def test_poisoned_buffers_do_not_leak_into_results(fsn, monkeypatch):
+    """Every output element is written and no kernel reads workspace it has not written: with all output
+    tensors and the whole workspace pre-filled with NaN bit patterns the results are finite and bit-identical
+    to a normal run (padded rows / bins / look-ahead frames included)."""
+    params = O.make_params(seed=0, gain=2.0, mask_gain=24.0)
+    noisy = dev(O.make_noisy(5, 3000, seed=3))  # 81 row tiles: step path; 17 utterances below: persistent + left-over
+    noisy17 = dev(O.make_noisy(17, 1500, seed=4))
+
+    def run(model):
+        out = []
+        for y in (noisy, noisy17):
+            enh, crm = model.enhance(y, return_crm=True)
+            mag, _, re, im = fsn.stft(y, 512, 256, 512)
+            with torch.no_grad():
+                fwd = model(mag.unsqueeze(1))
+            back = fsn.istft((re, im), 512, 256, 512, length=y.shape[1], input_type="real_imag")
+            out += [enh, crm, mag, re, im, fwd, back]
+        torch.cuda.synchronize()
+        return [t.clone() for t in out]
+
+    for norm in ("offline_laplace_norm", "cumulative_laplace_norm"):
+        m = fsn.Model(norm_type=norm, num_groups_in_drop_band=1, **MODEL_KW)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        m = m.cuda().eval()
+        clean = run(m)
+        real_empty, real_ws = torch.empty, fsn._lib.workspace
+
+        def poisoned_empty(*a, **k):
+            t = real_empty(*a, **k)
+            if t.is_cuda and t.dtype == torch.float32:
+                t.fill_(float("nan"))
+            return t
+
+        def poisoned_ws(nbytes, device):
+            return real_ws(nbytes, device).fill_(0xFF)  # 0xFFFFFFFF is a NaN
+
+        monkeypatch.setattr(torch, "empty", poisoned_empty)
+        monkeypatch.setattr(fsn._lib, "workspace", poisoned_ws)
+        try:
+            dirty = run(m)
+        finally:
+            monkeypatch.undo()
+        for a, b in zip(clean, dirty):
+            assert torch.isfinite(b).all()
+            assert torch.equal(a, b)
