@@ -184,3 +184,40 @@ def test_train_mode_forward_equals_eval_forward(fsn, norm):
     assert (out_train.detach() - out_eval).abs().max().item() <= 2e-6
     out_train.square().mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_training_step_with_poisoned_buffers(fsn, monkeypatch):
+    """The training graph (saved activations, BPTT workspaces, split-K partials) never reads memory it has not
+    written: NaN-poisoned empty tensors and workspaces give the same loss and gradients bit for bit."""
+    from fullsubnet_amd.train import train_step
+    params = O.make_params(seed=7)
+    noisy = torch.from_numpy(O.make_noisy(4, 3000, seed=1)).cuda()
+    clean = torch.from_numpy(0.7 * O.make_noisy(4, 3000, seed=2)).cuda()
+
+    def run():
+        model = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=2, **MODEL_KW)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        model = model.cuda().train()
+        opt = fsn.ClipAdam(model.parameters(), lr=1e-3)
+        loss = train_step(model, opt, noisy, clean)
+        torch.cuda.synchronize()
+        return loss.item(), [p.grad.clone() for p in model.parameters()], [p.detach().clone() for p in model.parameters()]
+
+    ref = run()
+    real_empty, real_like, real_ws = torch.empty, torch.empty_like, fsn._lib.workspace
+
+    def poison(t):
+        if t.is_cuda and t.dtype == torch.float32:
+            t.fill_(float("nan"))
+        return t
+
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: poison(real_empty(*a, **k)))
+    monkeypatch.setattr(torch, "empty_like", lambda *a, **k: poison(real_like(*a, **k)))
+    monkeypatch.setattr(fsn._lib, "workspace", lambda n, d: real_ws(n, d).fill_(0xFF))
+    try:
+        got = run()
+    finally:
+        monkeypatch.undo()
+    assert got[0] == ref[0]
+    for a, b in zip(ref[1] + ref[2], got[1] + got[2]):
+        assert torch.isfinite(b).all() and torch.equal(a, b)
