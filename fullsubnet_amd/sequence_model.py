@@ -58,6 +58,23 @@ def lstm_layer_infer(x, w_ih, w_hh, b_ih, b_hh):
     return hseq
 
 
+WAVEFRONT_BELOW_ROWS = 96 * 16  # fewer rows than this: two equal-width LSTM layers run as one wavefront
+
+
+def lstm2_infer(x, layer0, layer1):
+    """Two stacked LSTM layers of equal hidden size, inference mode, as one wavefront of per-step launches
+    (fsn_lstm2_forward).  x [T, N, ldx]; layer0 / layer1 = (w_ih, w_hh, b_ih, b_hh).  Returns hseq of layer 1."""
+    L = _lib.lib()
+    T, N, ldx = x.shape
+    I, H = layer0[0].shape[1], layer0[1].shape[1]
+    hseq = torch.empty((T, N, H), dtype=torch.float32, device=x.device)
+    ws = _lib.workspace(L.fsn_lstm2_fwd_workspace_bytes(T, N, I, H), x.device)
+    ptrs = [_lib.dev_ptr(t, "weight") for t in (*layer0, *layer1)]
+    _lib.check(L.fsn_lstm2_forward(_lib.dev_ptr(x, "x"), ldx, *ptrs, T, N, I, H, _lib.dev_ptr(hseq), ws.data_ptr(),
+                                   ws.numel(), _lib.stream_ptr(x.device)))
+    return hseq
+
+
 def gru_layer_infer(x, w_ih, w_hh, b_ih, b_hh):
     """One GRU layer, inference mode (same conventions as lstm_layer_infer, 3H gate rows r, z, n)."""
     L = _lib.lib()
@@ -151,8 +168,11 @@ class SequenceModel(nn.Module):
         h = torch.zeros((T, Np, Ip), dtype=torch.float32, device=x.device)
         h[:, :B, :F] = x.permute(2, 0, 1)
         layer_infer = lstm_layer_infer if self.cell == "LSTM" else gru_layer_infer
-        for w_ih, w_hh, b_ih, b_hh in layers:
-            h = layer_infer(h, w_ih, w_hh, b_ih, b_hh)
+        if self.cell == "LSTM" and len(layers) == 2 and Np < WAVEFRONT_BELOW_ROWS:
+            h = lstm2_infer(h, layers[0], layers[1])  # few rows: latency-bound, halve the dependent launches
+        else:
+            for w_ih, w_hh, b_ih, b_hh in layers:
+                h = layer_infer(h, w_ih, w_hh, b_ih, b_hh)
         relu = self.output_activate_function == "ReLU"
         if fc is not None:
             o = linear_infer(h.reshape(T * Np, Hp), fc[0], fc[1], relu).reshape(T, Np, self.output_size)

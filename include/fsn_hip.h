@@ -138,6 +138,15 @@ size_t fsn_lstm_layer_fwd_workspace_bytes(int T, int N, int I, int H);
 int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
                            const float* b_hh, int T, int N, int I, int H, float* hseq, void* save,
                            size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream);
+/* Two stacked nn.LSTM layers of equal hidden size (num_layers = 2 of sequence_model.py:52-58) in inference
+ * mode, advanced as a wavefront: T + 1 dependent launches instead of 2 T.  For blocks with few rows (the
+ * latency-bound regime); hseq1 [T][N][H] is the hidden sequence of the second layer. */
+size_t fsn_lstm2_fwd_workspace_bytes(int T, int N, int I, int H);
+int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, const float* w_hh0, const float* b_ih0,
+                      const float* b_hh0, const float* w_ih1, const float* w_hh1, const float* b_ih1,
+                      const float* b_hh1, int T, int N, int I, int H, float* hseq1, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* Streaming inference (chunked / frame-by-frame processing with carried state - the real-time use the
  * model is designed for; the reference has no such entry point, nn.LSTM's (h_0, c_0) argument is the
  * analogue).  fsn_lstm_layer_pack re-tiles one layer's weights once; fsn_lstm_layer_forward_state then runs
