@@ -941,6 +941,23 @@ extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_i
     FSN_TRY(fsn_launch_pack(w_ih, wih_p, 4 * H, I, 4 * H, Ipad, s));
     FSN_TRY(fsn_launch_pack(w_hh, whh_p, 4 * H, H, 4 * H, H, s));
     FSN_TRY(fsn_launch_bias_sum(b_ih, b_hh, bias, 4 * H, 4 * H, s));
+    if (!save) {
+        // inference with a narrow input on the persistent kernel (e.g. Fast FullSubNet's bottleneck: 12 inputs,
+        // 16 384 rows): the K <= 32 projection is formed inside the recurrent kernel from a staged LDS tile,
+        // like the sub-band model's layer 0, instead of writing and re-reading a [T][N][4H] projection
+        const FsnRecPlan plan = layer_plan(N, H);
+        if (plan.main_wgs > 0 && plan.left_tiles == 0 && Ipad <= 32) {
+            FsnSbInput xin{};
+            xin.x_rows = x;
+            xin.x_ld = ldx;
+            xin.x_step = N;
+            xin.N = N;
+            xin.kin_chunks = Ipad / 16;
+            xin.wih_p = wih_p;
+            xin.bias = bias;
+            return run_recurrence(nullptr, &xin, nullptr, 0, 0, whh_p, hseq, c_state, T, N, H, plan, s);
+        }
+    }
     FsnGemmA a{};
     a.kind = 0;
     a.p0 = x;

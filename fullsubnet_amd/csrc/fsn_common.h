@@ -172,6 +172,10 @@ struct FsnSbInput {
     const float* bias;   // b_ih + b_hh [4H]
     int den_mode, den_stride;
     int B, Tp, F, FP, N, nb, kin_chunks;
+    // generic form (x_rows != NULL): the layer input is a plain row-major matrix, element (t, n, c) at
+    // x_rows[(t * x_step + n) * x_ld + c] with zero padding up to 16 kin_chunks columns; N = valid rows
+    const float* x_rows;
+    long x_ld, x_step;
 };
 
 // Output layer (nn.Linear(H, 2), fullsubnet/model.py:53-61 + the reshape of :129-135) fused into the

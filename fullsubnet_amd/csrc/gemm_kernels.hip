@@ -353,6 +353,8 @@ int fsn_launch_gemm(const FsnGemmA& a, const float* wp, const FsnGemmC& c, int r
     if (a.kind == 0 && c.kind == 3) {
         if (row_tiles >= 2048 && col_tiles >= 4)
             return launch<0, 3, 8, 4, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s, 1, kOnePerCu);
+        // a one-tile-wide output layer over many rows is HBM-bound on reading its input: many waves in flight
+        if (row_tiles >= 2048 && col_tiles == 1) return launch<0, 3, 4, 1, 4, 1>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
         return launch<0, 3, 2, 2, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
     }
     fsn_set_error("fsn_launch_gemm: unsupported operand kinds A=%d C=%d", a.kind, c.kind);

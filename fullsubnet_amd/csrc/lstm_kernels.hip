@@ -31,7 +31,9 @@ __device__ __forceinline__ void stage_sb_input(const FsnSbInput& x, float* xl, i
         const int row = i / kin, c = i % kin;
         const long n = n0 + row;
         float v = 0.f;
-        if (n < x.N && c <= 2 * x.nb + 1) {
+        if (x.x_rows) {  // plain row-major layer input (a narrow first layer of a SequenceModel block)
+            if (n < x.N) v = x.x_rows[((long)t * x.x_step + n) * x.x_ld + c];
+        } else if (n < x.N && c <= 2 * x.nb + 1) {
             const int b = (int)(n / x.F), f = (int)(n % x.F);
             const long fo = ((long)b * x.Tp + t) * x.FP;
             int j = f + c - x.nb;
