@@ -984,48 +984,52 @@ extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_i
 // Two stacked LSTM layers of equal width in inference mode as one wavefront (layer 1 at step t next to layer 0
 // at step t + 1: T + 1 dependent launches instead of 2 T).  For the latency-bound regime - few rows - where
 // SequenceModel blocks of the sibling models live (Improved FullSubNet's band sections: B x {20, 25, 6, 4} rows).
-extern "C" size_t fsn_lstm2_fwd_workspace_bytes(int T, int N, int I, int H) {
+extern "C" size_t fsn_lstm2_fwd_workspace_bytes(int T, int N, int I, int H0, int H1) {
     Carver cv(nullptr);
-    cv.take<float>((size_t)4 * H * fsn_round_up(I, 16));  // W_ih0 fragments
-    cv.take<float>((size_t)3 * 4 * H * H);                // W_hh0, W_ih1, W_hh1 fragments
-    cv.take<float>((size_t)2 * 4 * H);                    // b0, b1
-    cv.take<float>((size_t)4 * H * 16);                   // b1 as fragment tiles
-    cv.take<float>((size_t)T * N * 4 * H);                // layer-0 projection
-    cv.take<float>((size_t)T * N * H);                    // layer-0 hidden sequence
-    cv.take<float>((size_t)2 * N * H);                    // cell states
+    cv.take<float>((size_t)4 * H0 * fsn_round_up(I, 16));  // W_ih0 fragments
+    cv.take<float>((size_t)4 * H0 * H0);                   // W_hh0
+    cv.take<float>((size_t)4 * H1 * H0);                   // W_ih1
+    cv.take<float>((size_t)4 * H1 * H1);                   // W_hh1
+    cv.take<float>((size_t)4 * H0);                        // b0
+    cv.take<float>((size_t)4 * H1);                        // b1
+    cv.take<float>((size_t)4 * H1 * 16);                   // b1 as fragment tiles
+    cv.take<float>((size_t)T * N * 4 * H0);                // layer-0 projection
+    cv.take<float>((size_t)T * N * H0);                    // layer-0 hidden sequence
+    cv.take<float>((size_t)N * (H0 + H1));                 // cell states
     return fsn_round_up_sz(cv.off, 256);
 }
 extern "C" int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, const float* w_hh0, const float* b_ih0,
                                  const float* b_hh0, const float* w_ih1, const float* w_hh1, const float* b_ih1,
-                                 const float* b_hh1, int T, int N, int I, int H, float* hseq1, void* workspace,
+                                 const float* b_hh1, int T, int N, int I, int H0, int H1, float* hseq1, void* workspace,
                                  size_t workspace_bytes, void* stream) {
-    FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
+    FSN_TRY(check_lstm_layer(T, N, I, H0, ldx));
+    FSN_REQUIRE(H1 >= 64 && H1 % 64 == 0, "lstm2: second hidden size %d must be a multiple of 64", H1);
     FSN_REQUIRE(x && w_ih0 && w_hh0 && b_ih0 && b_hh0 && w_ih1 && w_hh1 && b_ih1 && b_hh1 && hseq1 && workspace,
                 "NULL pointer argument");
-    if (workspace_bytes < fsn_lstm2_fwd_workspace_bytes(T, N, I, H)) {
+    if (workspace_bytes < fsn_lstm2_fwd_workspace_bytes(T, N, I, H0, H1)) {
         fsn_set_error("lstm2 forward: workspace too small");
         return FSN_ERR_WORKSPACE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int Ipad = fsn_round_up(I, 16), G = 4 * H;
+    const int Ipad = fsn_round_up(I, 16), G0 = 4 * H0, G1 = 4 * H1;
     Carver cv(workspace);
-    float* wih0_p = cv.take<float>((size_t)G * Ipad);
-    float* whh0_p = cv.take<float>((size_t)G * H);
-    float* wih1_p = cv.take<float>((size_t)G * H);
-    float* whh1_p = cv.take<float>((size_t)G * H);
-    float* b0 = cv.take<float>((size_t)G);
-    float* b1 = cv.take<float>((size_t)G);
-    float* b1_frag = cv.take<float>((size_t)G * 16);
-    float* gx = cv.take<float>((size_t)T * N * G);
-    float* hseq0 = cv.take<float>((size_t)T * N * H);
-    float* cst = cv.take<float>((size_t)2 * N * H);
-    FSN_TRY(fsn_launch_pack(w_ih0, wih0_p, G, I, G, Ipad, s));
-    FSN_TRY(fsn_launch_pack(w_hh0, whh0_p, G, H, G, H, s));
-    FSN_TRY(fsn_launch_pack(w_ih1, wih1_p, G, H, G, H, s));
-    FSN_TRY(fsn_launch_pack(w_hh1, whh1_p, G, H, G, H, s));
-    FSN_TRY(fsn_launch_bias_sum(b_ih0, b_hh0, b0, G, G, s));
-    FSN_TRY(fsn_launch_bias_sum(b_ih1, b_hh1, b1, G, G, s));
-    FSN_TRY(fsn_launch_bias_frag(b1, b1_frag, G, s));
+    float* wih0_p = cv.take<float>((size_t)G0 * Ipad);
+    float* whh0_p = cv.take<float>((size_t)G0 * H0);
+    float* wih1_p = cv.take<float>((size_t)G1 * H0);
+    float* whh1_p = cv.take<float>((size_t)G1 * H1);
+    float* b0 = cv.take<float>((size_t)G0);
+    float* b1 = cv.take<float>((size_t)G1);
+    float* b1_frag = cv.take<float>((size_t)G1 * 16);
+    float* gx = cv.take<float>((size_t)T * N * G0);
+    float* hseq0 = cv.take<float>((size_t)T * N * H0);
+    float* cst = cv.take<float>((size_t)N * (H0 + H1));
+    FSN_TRY(fsn_launch_pack(w_ih0, wih0_p, G0, I, G0, Ipad, s));
+    FSN_TRY(fsn_launch_pack(w_hh0, whh0_p, G0, H0, G0, H0, s));
+    FSN_TRY(fsn_launch_pack(w_ih1, wih1_p, G1, H0, G1, H0, s));
+    FSN_TRY(fsn_launch_pack(w_hh1, whh1_p, G1, H1, G1, H1, s));
+    FSN_TRY(fsn_launch_bias_sum(b_ih0, b_hh0, b0, G0, G0, s));
+    FSN_TRY(fsn_launch_bias_sum(b_ih1, b_hh1, b1, G1, G1, s));
+    FSN_TRY(fsn_launch_bias_frag(b1, b1_frag, G1, s));
     FsnGemmA a{};
     a.kind = 0;
     a.p0 = x;
@@ -1034,9 +1038,9 @@ extern "C" int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, c
     c.kind = 0;
     c.p0 = gx;
     c.bias = b0;
-    FSN_TRY(fsn_launch_gemm(a, wih0_p, c, T * (N / 16), G / 16, Ipad / 16, s));
-    return fsn_launch_lstm_wavefront2(gx, N / 16, 0, whh0_p, wih1_p, b1_frag, whh1_p, hseq0, hseq1, N, 0, cst,
-                                      cst + (size_t)N * H, T, N / 16, H, s);
+    FSN_TRY(fsn_launch_gemm(a, wih0_p, c, T * (N / 16), G0 / 16, Ipad / 16, s));
+    return fsn_launch_lstm_wavefront2w(gx, N / 16, 0, whh0_p, wih1_p, b1_frag, whh1_p, hseq0, hseq1, N, 0, cst,
+                                       cst + (size_t)N * H0, T, N / 16, H0, H1, s);
 }
 
 // Streaming form (frame-by-frame / chunked inference with carried state): T more steps from the state

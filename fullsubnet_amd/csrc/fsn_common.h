@@ -215,3 +215,7 @@ int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, co
                                const float* bias1_frag, const float* whh1_p, float* hseq0, float* hseq1, long hs_stride,
                                long hs_off, float* c0, float* c1, int T, int row_tiles, int H, hipStream_t s,
                                float* state_h0 = nullptr, float* state_h1 = nullptr);
+int fsn_launch_lstm_wavefront2w(const float* gx0, long gx_stride, long gx_off, const float* whh0_p,
+                                const float* wih1_p, const float* bias1_frag, const float* whh1_p, float* hseq0,
+                                float* hseq1, long hs_stride, long hs_off, float* c0, float* c1, int T, int row_tiles,
+                                int H0, int H1, hipStream_t s, float* state_h0 = nullptr, float* state_h1 = nullptr);

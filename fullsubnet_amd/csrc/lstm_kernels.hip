@@ -550,14 +550,18 @@ struct FsnStepJob {
     float* c;
     long add_rt0;
     int add_rs, first, active;
+    int H;          // hidden units of this job's layer (row stride of h / c); the two jobs may differ
+    int kx_chunks;  // layer-1 form: input width / 16 (= hidden units / 16 of the layer below)
+    int x_ld;       // layer-1 form: row stride of x
 };
 struct FsnStepJobs {
     FsnStepJob j[2];
 };
 
-__global__ __launch_bounds__(256) void lstm_step2_kernel(const FsnStepJobs jobs, int H) {
+__global__ __launch_bounds__(256) void lstm_step2_kernel(const FsnStepJobs jobs) {
     const FsnStepJob job = jobs.j[blockIdx.z];  // one uniform kernarg fetch, no per-member branching
-    if (!job.active) return;
+    const int H = job.H;
+    if (!job.active || (int)blockIdx.x * 16 >= H) return;  // the grid is sized for the wider layer
     __shared__ f32x4 red[3][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
@@ -584,10 +588,12 @@ __global__ __launch_bounds__(256) void lstm_step2_kernel(const FsnStepJobs jobs,
     const float* ah = job.h_prev + ((long)rtile * 16 + lr) * H + 4 * lq;
     const float* bh = job.whh_p + ((long)ug * KC * 64 + lane) * 4;
     const long gstride = (long)KC * KC * 256;  // gate g of unit group ug: column tile g KC + ug
-    if (job.xw_p && !job.first) {
+    const int KX = job.kx_chunks;
+    const long xstride = (long)KC * KX * 256;
+    if (job.xw_p && !job.first && KX == KC) {
         // layer-1 job in steady state: x W_ih^T and h W_hh^T share one loop, so that the loads of both
         // products are in flight together (two back-to-back loops would pay the L2 latency twice)
-        const float* ax = job.x + ((long)rtile * 16 + lr) * H + 4 * lq;
+        const float* ax = job.x + ((long)rtile * 16 + lr) * job.x_ld + 4 * lq;
         const float* bx = job.xw_p + ((long)ug * KC * 64 + lane) * 4;
 #pragma unroll 2
         for (int kc = kc0; kc < kc1; ++kc) {
@@ -608,20 +614,37 @@ __global__ __launch_bounds__(256) void lstm_step2_kernel(const FsnStepJobs jobs,
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[g] = mfma16(a1[j], b1[g][j], acc[g]);
         }
-    } else if (job.xw_p || !job.first) {
-        // one product only: layer 0 in steady state (h W_hh^T) or layer 1 at its first step (x W_ih^T)
-        const float* a1p = job.xw_p ? job.x + ((long)rtile * 16 + lr) * H + 4 * lq : ah;
-        const float* b1p = job.xw_p ? job.xw_p + ((long)ug * KC * 64 + lane) * 4 : bh;
+    } else {
+        // the two products one after the other: layer 0 (h W_hh^T only), layer 1 at its first step
+        // (x W_ih^T only), or a layer 1 whose input width differs from its own (blocks of different widths)
+        if (job.xw_p) {
+            const int x0 = wave * (KX >> 2), x1 = x0 + (KX >> 2);
+            const float* a1p = job.x + ((long)rtile * 16 + lr) * job.x_ld + 4 * lq;
+            const float* b1p = job.xw_p + ((long)ug * KX * 64 + lane) * 4;
 #pragma unroll 2
-        for (int kc = kc0; kc < kc1; ++kc) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(a1p + kc * 16);
-            f32x4 b[4];
+            for (int kc = x0; kc < x1; ++kc) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(a1p + kc * 16);
+                f32x4 b[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4*>(b1p + g * gstride + (long)kc * 256);
+                for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4*>(b1p + g * xstride + (long)kc * 256);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = mfma16(a[j], b[g][j], acc[g]);
+                    for (int g = 0; g < 4; ++g) acc[g] = mfma16(a[j], b[g][j], acc[g]);
+            }
+        }
+        if (!job.first) {
+#pragma unroll 2
+            for (int kc = kc0; kc < kc1; ++kc) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(ah + kc * 16);
+                f32x4 b[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4*>(bh + g * gstride + (long)kc * 256);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = mfma16(a[j], b[g][j], acc[g]);
+            }
         }
     }
     if (wave > 0) {
@@ -800,34 +823,38 @@ int fsn_launch_lstm_step_train(const float* gx, const float* whh_p, const float*
     return fsn_check_launch("lstm_step_kernel");
 }
 
-// Two-layer LSTM over T steps on `row_tiles` 16-row tiles, layers advanced in a wavefront (see
-// lstm_step2_kernel).  gx0: layer-0 projection, tile (t, i) at t * gx_stride + gx_off + i; wih1_p / bias1:
-// layer-1 packed input weights [4H/16][H/16][64][4] and b_ih + b_hh; hseq0 / hseq1: [T][hs_stride rows][H]
-// with this launch's rows starting at row hs_off; c0 / c1: [row_tiles * 16][H].
-int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, const float* whh0_p, const float* wih1_p,
-                               const float* bias1_frag, const float* whh1_p, float* hseq0, float* hseq1, long hs_stride,
-                               long hs_off, float* c0, float* c1, int T, int row_tiles, int H, hipStream_t s,
-                               float* state_h0, float* state_h1) {
-    if (H % 64 != 0 || (state_h0 == nullptr) != (state_h1 == nullptr)) {
-        fsn_set_error("lstm_wavefront2: hidden size %d must be a multiple of 64 (and both states or none)", H);
+// Two LSTM layers over T steps on `row_tiles` 16-row tiles, advanced in a wavefront (see lstm_step2_kernel).
+// Layer 0 has H0 units, layer 1 H1 units and H0 inputs.  gx0: layer-0 projection, tile (t, i) at
+// t * gx_stride + gx_off + i; wih1_p: layer-1 input weights [4 H1 / 16][H0 / 16][64][4]; bias1_frag: b_ih + b_hh
+// of layer 1 as fragment tiles; hseq0 / hseq1: [T][hs_stride rows][H0 / H1] with this launch's rows starting at
+// row hs_off; c0 / c1: [row_tiles * 16][H0 / H1].  state_h0 / state_h1: streaming continuation (see header).
+int fsn_launch_lstm_wavefront2w(const float* gx0, long gx_stride, long gx_off, const float* whh0_p,
+                                const float* wih1_p, const float* bias1_frag, const float* whh1_p, float* hseq0,
+                                float* hseq1, long hs_stride, long hs_off, float* c0, float* c1, int T, int row_tiles,
+                                int H0, int H1, hipStream_t s, float* state_h0, float* state_h1) {
+    if (H0 % 64 != 0 || H1 % 64 != 0 || (state_h0 == nullptr) != (state_h1 == nullptr)) {
+        fsn_set_error("lstm_wavefront2: hidden sizes %d / %d must be multiples of 64 (and both states or none)", H0, H1);
         return FSN_ERR_ARG;
     }
     const bool cont = state_h0 != nullptr;
-    const size_t step = (size_t)hs_stride * H;
-    float* h0 = hseq0 + (size_t)hs_off * H;
-    float* h1 = hseq1 + (size_t)hs_off * H;
+    const size_t step0 = (size_t)hs_stride * H0, step1 = (size_t)hs_stride * H1;
+    float* h0 = hseq0 + (size_t)hs_off * H0;
+    float* h1 = hseq1 + (size_t)hs_off * H1;
+    const int Hmax = H0 > H1 ? H0 : H1;
     for (int i = 0; i <= T; ++i) {
         FsnStepJobs jobs{};
         FsnStepJob& a = jobs.j[0];
         FsnStepJob& b = jobs.j[1];
+        a.H = H0;
+        b.H = H1;
         if (i < T) {
             a.active = 1;
             a.add = gx0;
             a.add_rt0 = (long)i * gx_stride + gx_off;
             a.add_rs = 1;
             a.whh_p = whh0_p;
-            a.h_prev = i ? h0 + (i - 1) * step : (cont ? state_h0 : h0);
-            a.h_out = h0 + i * step;
+            a.h_prev = i ? h0 + (i - 1) * step0 : (cont ? state_h0 : h0);
+            a.h_out = h0 + i * step0;
             a.c = c0;
             a.first = i == 0 && !cont;
         }
@@ -838,23 +865,35 @@ int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, co
             b.add_rt0 = 0;
             b.add_rs = 0;
             b.xw_p = wih1_p;
-            b.x = h0 + t * step;
+            b.x = h0 + t * step0;
+            b.x_ld = H0;
+            b.kx_chunks = H0 / 16;
             b.whh_p = whh1_p;
-            b.h_prev = t ? h1 + (t - 1) * step : (cont ? state_h1 : h1);
-            b.h_out = h1 + t * step;
+            b.h_prev = t ? h1 + (t - 1) * step1 : (cont ? state_h1 : h1);
+            b.h_out = h1 + t * step1;
             b.c = c1;
             b.first = t == 0 && !cont;
         }
-        hipLaunchKernelGGL(lstm_step2_kernel, dim3(H / 16, row_tiles, 2), dim3(256), 0, s, jobs, H);
+        hipLaunchKernelGGL(lstm_step2_kernel, dim3(Hmax / 16, row_tiles, 2), dim3(256), 0, s, jobs);
         FSN_TRY_LAUNCH("lstm_step2_kernel");
     }
     if (cont) {
-        const size_t bytes = (size_t)row_tiles * 16 * H * sizeof(float);
-        if (hipMemcpyAsync(state_h0, h0 + (size_t)(T - 1) * step, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess ||
-            hipMemcpyAsync(state_h1, h1 + (size_t)(T - 1) * step, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        const size_t rows = (size_t)row_tiles * 16;
+        if (hipMemcpyAsync(state_h0, h0 + (size_t)(T - 1) * step0, rows * H0 * sizeof(float), hipMemcpyDeviceToDevice,
+                           s) != hipSuccess ||
+            hipMemcpyAsync(state_h1, h1 + (size_t)(T - 1) * step1, rows * H1 * sizeof(float), hipMemcpyDeviceToDevice,
+                           s) != hipSuccess) {
             fsn_set_error("lstm_wavefront2: state copy failed");
             return FSN_ERR_LAUNCH;
         }
     }
     return FSN_OK;
+}
+
+int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, const float* whh0_p, const float* wih1_p,
+                               const float* bias1_frag, const float* whh1_p, float* hseq0, float* hseq1, long hs_stride,
+                               long hs_off, float* c0, float* c1, int T, int row_tiles, int H, hipStream_t s,
+                               float* state_h0, float* state_h1) {
+    return fsn_launch_lstm_wavefront2w(gx0, gx_stride, gx_off, whh0_p, wih1_p, bias1_frag, whh1_p, hseq0, hseq1,
+                                       hs_stride, hs_off, c0, c1, T, row_tiles, H, H, s, state_h0, state_h1);
 }

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from .base_model import BaseModel, look_ahead_pad
-from .sequence_model import SequenceModel
+from .sequence_model import SequenceModel, pair_forward
 
 
 def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate):
@@ -105,7 +105,7 @@ class Model(BaseModel):
         mag = look_ahead_pad(mix_mag, self.look_ahead)
         n_batch, _, n_bins, n_frames = mag.shape
         mel = self.mel_scale(mag)                                                         # [B, 1, M, T]
-        enc = self.encoder(self.norm(mel).reshape(n_batch, -1, n_frames))                 # [B, M, T]
+        enc = pair_forward(*self.encoder, self.norm(mel).reshape(n_batch, -1, n_frames))  # [B, M, T]
         enc = enc.reshape(n_batch, 1, -1, n_frames)
         units = torch.cat([self._unit_windows(mel, self.noisy_input_num_neighbors),
                            self._unit_windows(enc, self.enc_output_num_neighbors)], dim=2)  # [B, M, W, T]
@@ -115,5 +115,5 @@ class Model(BaseModel):
         slow_out = slow_out.reshape(n_batch, self.num_mels, 1, -1).permute(0, 2, 1, 3)
         band_gain = self.real_time_upsampling(slow_out, target_len=n_frames)              # [B, 1, M, T]
         dec_in = torch.cat([enc, band_gain], dim=2).reshape(n_batch, -1, n_frames)
-        mask = self.decoder_lstm(dec_in).reshape(n_batch, 2, n_bins, n_frames)
+        mask = pair_forward(*self.decoder_lstm, dec_in).reshape(n_batch, 2, n_bins, n_frames)
         return mask[..., self.look_ahead:]

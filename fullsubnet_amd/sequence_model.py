@@ -62,16 +62,19 @@ WAVEFRONT_BELOW_ROWS = 96 * 16  # fewer rows than this: two equal-width LSTM lay
 
 
 def lstm2_infer(x, layer0, layer1):
-    """Two stacked LSTM layers of equal hidden size, inference mode, as one wavefront of per-step launches
-    (fsn_lstm2_forward).  x [T, N, ldx]; layer0 / layer1 = (w_ih, w_hh, b_ih, b_hh).  Returns hseq of layer 1."""
+    """Two stacked LSTM layers (equal or different hidden sizes), inference mode, as one wavefront of per-step
+    launches (fsn_lstm2_forward).  x [T, N, ldx]; layer0 / layer1 = (w_ih, w_hh, b_ih, b_hh), padded.  Returns the
+    hidden sequence of layer 1."""
     L = _lib.lib()
     T, N, ldx = x.shape
-    I, H = layer0[0].shape[1], layer0[1].shape[1]
-    hseq = torch.empty((T, N, H), dtype=torch.float32, device=x.device)
-    ws = _lib.workspace(L.fsn_lstm2_fwd_workspace_bytes(T, N, I, H), x.device)
+    I, H0, H1 = layer0[0].shape[1], layer0[1].shape[1], layer1[1].shape[1]
+    if layer1[0].shape[1] != H0:
+        raise _lib.FsnError("lstm2_infer: the second layer must take the first layer's (padded) hidden size as input")
+    hseq = torch.empty((T, N, H1), dtype=torch.float32, device=x.device)
+    ws = _lib.workspace(L.fsn_lstm2_fwd_workspace_bytes(T, N, I, H0, H1), x.device)
     ptrs = [_lib.dev_ptr(t, "weight") for t in (*layer0, *layer1)]
-    _lib.check(L.fsn_lstm2_forward(_lib.dev_ptr(x, "x"), ldx, *ptrs, T, N, I, H, _lib.dev_ptr(hseq), ws.data_ptr(),
-                                   ws.numel(), _lib.stream_ptr(x.device)))
+    _lib.check(L.fsn_lstm2_forward(_lib.dev_ptr(x, "x"), ldx, *ptrs, T, N, I, H0, H1, _lib.dev_ptr(hseq),
+                                   ws.data_ptr(), ws.numel(), _lib.stream_ptr(x.device)))
     return hseq
 
 
@@ -201,3 +204,36 @@ class SequenceModel(nn.Module):
         if self.output_activate_function and not relu:
             o = self.activate_function(o)
         return o.permute(1, 2, 0)
+
+
+def pair_forward(block0, block1, x):
+    """``block1(block0(x))`` for two consecutive SequenceModel blocks (an ``nn.Sequential`` pair of the sibling
+    models).  In inference, when both are single-layer LSTM blocks, block0 has no output layer / activation and
+    there are few rows, the two recurrences advance as one wavefront (fsn_lstm2_forward); otherwise block by
+    block."""
+    fusable = (not torch.is_grad_enabled() and x.is_cuda and block0.cell == block1.cell == "LSTM"
+               and block0.num_layers == block1.num_layers == 1 and not block0.output_size
+               and not block0.output_activate_function and block1.input_size == block0.hidden_size
+               and _round_up(x.shape[0], 16) < WAVEFRONT_BELOW_ROWS)
+    if not fusable:
+        return block1(block0(x))
+    B, F, T = x.shape
+    Np, Ip = _round_up(B, 16), _round_up(F, 16)
+    (layer0,), _ = block0._inference_weights()
+    Hp0 = layer0[1].shape[1]
+    # block1's own padded weights take block0.hidden_size inputs; widen them to block0's padded width
+    w_ih1, w_hh1, b_ih1, b_hh1 = (t.detach() for t in pad_lstm_weights(*block1._layer_tensors(0), Hp0))
+    layer1 = (w_ih1.contiguous(), w_hh1.contiguous(), b_ih1.contiguous(), b_hh1.contiguous())
+    _, fc = block1._inference_weights()
+    h = torch.zeros((T, Np, Ip), dtype=torch.float32, device=x.device)
+    h[:, :B, :F] = x.permute(2, 0, 1)
+    h = lstm2_infer(h, layer0, layer1)
+    Hp1, H1 = h.shape[2], block1.hidden_size
+    relu = block1.output_activate_function == "ReLU"
+    if fc is not None:
+        o = linear_infer(h.reshape(T * Np, Hp1), fc[0], fc[1], relu).reshape(T, Np, block1.output_size)[:, :B]
+    else:
+        o, relu = h[:, :B, :H1], False
+    if block1.output_activate_function and not relu:
+        o = block1.activate_function(o)
+    return o.permute(1, 2, 0)

@@ -138,13 +138,15 @@ size_t fsn_lstm_layer_fwd_workspace_bytes(int T, int N, int I, int H);
 int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
                            const float* b_hh, int T, int N, int I, int H, float* hseq, void* save,
                            size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream);
-/* Two stacked nn.LSTM layers of equal hidden size (num_layers = 2 of sequence_model.py:52-58) in inference
- * mode, advanced as a wavefront: T + 1 dependent launches instead of 2 T.  For blocks with few rows (the
- * latency-bound regime); hseq1 [T][N][H] is the hidden sequence of the second layer. */
-size_t fsn_lstm2_fwd_workspace_bytes(int T, int N, int I, int H);
+/* Two stacked LSTM layers in inference mode, advanced as a wavefront (layer 1 at step t next to layer 0 at
+ * step t + 1): T + 1 dependent launches instead of 2 T.  Either nn.LSTM(num_layers = 2) of one SequenceModel
+ * (H1 == H0, sequence_model.py:52-58) or two consecutive single-layer blocks of different widths (the
+ * encoder / decoder pairs of fast_fullsubnet/model.py:35-96; layer 1 takes the H0 outputs of layer 0).  For
+ * blocks with few rows (the latency-bound regime); hseq1 [T][N][H1] is the hidden sequence of the second layer. */
+size_t fsn_lstm2_fwd_workspace_bytes(int T, int N, int I, int H0, int H1);
 int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, const float* w_hh0, const float* b_ih0,
                       const float* b_hh0, const float* w_ih1, const float* w_hh1, const float* b_ih1,
-                      const float* b_hh1, int T, int N, int I, int H, float* hseq1, void* workspace,
+                      const float* b_hh1, int T, int N, int I, int H0, int H1, float* hseq1, void* workspace,
                       size_t workspace_bytes, void* stream);
 
 /* Streaming inference (chunked / frame-by-frame processing with carried state - the real-time use the
