@@ -359,7 +359,8 @@ int fsn_launch_bptt_step(const float* dh_out, const float* dgates_next, const fl
                          const float* gates, const float* c_t, const float* c_prev, float* dgates, int row_tiles, int H,
                          int last, int first, hipStream_t s) {
     // measured at 129 row tiles (tools/bench_train.py): 2 x 2 72.2 ms per training step, 1 x 2 73.0, 2 x 1 75.1,
-    // 1 x 1 76.3, 4 x 2 76.8, 2 x 4 77.8, 4 x 4 89.0
+    // 1 x 1 76.3, 4 x 2 76.8, 2 x 4 77.8, 4 x 4 89.0; a no-split-K form (a wave per tile for the whole K = 4H
+    // range, which pays off in the forward step) is 10 % slower here: K is four times longer
     const int cfg = row_tiles >= 64 && H % 32 == 0 ? 22 : 11;
 #define FSN_BPTT_CASE(R, C)                                                                                        \
     hipLaunchKernelGGL((bptt_step_kernel<R, C>), dim3(H / 16 / C, (row_tiles + R - 1) / R), dim3(256), 0, s, dh_out, \
