@@ -1182,14 +1182,15 @@ extern "C" int fsn_lstm_layer_backward(const float* dh, const float* x, long ldx
         c.cols = I;
         FSN_TRY(fsn_launch_gemm(a, wihT_p, c, T * (N / 16), Ipad / 16, G / 16, s));
     }
-    FSN_TRY(fsn_launch_gemm_tn(dgates, G, x, ldx, dw_ih, I, G, I, (long)T * N, scratch, s));
+    // dW_ih = dgates^T X and, from the same pass over dgates, db = its column sums
+    FSN_TRY(fsn_launch_gemm_tn(dgates, G, x, ldx, dw_ih, I, G, I, (long)T * N, scratch, s, db));
     if (T > 1) {
         FSN_TRY(fsn_launch_gemm_tn(dgates + (size_t)N * G, G, hseq, H, dw_hh, H, G, H, (long)(T - 1) * N, scratch, s));
     } else if (hipMemsetAsync(dw_hh, 0, (size_t)G * H * sizeof(float), s) != hipSuccess) {
         fsn_set_error("memset failed");
         return FSN_ERR_LAUNCH;
     }
-    return fsn_launch_colsum(dgates, G, db, G, (long)T * N, scratch, s);
+    return FSN_OK;
 }
 
 // ---- nn.GRU layer (sequence_model.py:59-66): forward (inference / training) + BPTT -----------------

@@ -144,7 +144,7 @@ int fsn_launch_bias_frag(const float* bias, float* frag, int n, hipStream_t s);
 // C [M][Nc] = sum_k A[k][M]^T B[k][Nc]   (both operands row-major over k; split-K, deterministic 2-pass)
 size_t fsn_gemm_tn_workspace_bytes(int M, int Nc, long K);
 int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int Nc, long K,
-                       void* workspace, hipStream_t s);
+                       void* workspace, hipStream_t s, float* colsum_out = nullptr);
 int fsn_launch_colsum(const float* A, long lda, float* out, int cols, long rows, void* workspace, hipStream_t s);
 size_t fsn_colsum_workspace_bytes(int cols, long rows);
 int fsn_launch_bptt_step(const float* dh_out, const float* dgates_next, const float* whhT_p, float* dc,

@@ -144,7 +144,7 @@ template <int RTW, int CTW, int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, long lda,
                                                       const float* __restrict__ B, long ldb,
                                                       float* __restrict__ part, int M, int Nc, long K, long k_per_split,
-                                                      int m_blocks, int n_blocks) {
+                                                      int m_blocks, int n_blocks, float* __restrict__ asum_part) {
     constexpr int PF = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
@@ -177,6 +177,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < CTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // column sums of A over k (= the bias gradient when A is dgates) ride along for free: the A fragments are in
+    // registers anyway; 8 adds per chunk next to 128 MFMAs.  Written by the n-block-0 / wave-column-0 waves only.
+    float asum[RTW];
+#pragma unroll
+    for (int i = 0; i < RTW; ++i) asum[i] = 0.f;
     float abuf[PF][RTW][4], bbuf[PF][CTW][4];
     auto fetch = [&](int p, int kc) {
 #pragma unroll
@@ -196,6 +201,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
             for (int i = 0; i < RTW; ++i)
 #pragma unroll
                 for (int jj = 0; jj < CTW; ++jj) acc[i][jj] = mfma16(abuf[p][i][j], bbuf[p][jj][j], acc[i][jj]);
+#pragma unroll
+        for (int i = 0; i < RTW; ++i) asum[i] += (abuf[p][i][0] + abuf[p][i][1]) + (abuf[p][i][2] + abuf[p][i][3]);
     };
 #pragma unroll
     for (int p = 0; p < PF; ++p) fetch(p, p < last ? p : last);
@@ -222,6 +229,27 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                 const int m = m0 + i * 16 + 4 * lq + r, n = n0 + jj * 16 + lr;
                 if (m < M && n < Nc) out[(long)m * Nc + n] = acc[i][jj][r];
             }
+    if (asum_part && nb == 0 && wn == 0) {
+#pragma unroll
+        for (int i = 0; i < RTW; ++i) {
+            float v = asum[i];  // lanes r, r + 16, r + 32, r + 48 hold the four k phases of column m0 + 16 i + r
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int m = m0 + i * 16 + lr;
+            if (lq == 0 && m < M) asum_part[(long)split * M + m] = v;
+        }
+    }
+}
+
+// column sums riding on gemm_tn: sum of the split partials (fixed order) + the K % 16 tail rows
+__global__ void tn_colsum_reduce_kernel(const float* __restrict__ asum_part, float* __restrict__ out, int M, int splits,
+                                        const float* __restrict__ A, long lda, long k_tail0, long K) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float acc = 0.f;
+    for (int s = 0; s < splits; ++s) acc += asum_part[(long)s * M + m];
+    for (long k = k_tail0; k < K; ++k) acc += A[k * lda + m];
+    out[m] = acc;
 }
 
 // out[i] = sum_s part[s][i] in a fixed order
@@ -293,24 +321,31 @@ constexpr long kColsumRows = 2048;
 
 size_t fsn_gemm_tn_workspace_bytes(int M, int Nc, long K) {
     const bool swap = M <= 32 && Nc > 32;
-    if ((K & ~15L) <= 0) return (size_t)M * Nc * sizeof(float);
+    if ((K & ~15L) <= 0) return (size_t)M * (Nc + 1) * sizeof(float);
     const TnPlan p = swap ? tn_plan(Nc, M, K & ~15L) : tn_plan(M, Nc, K & ~15L);
-    return (size_t)(p.splits > 0 ? p.splits : 1) * M * Nc * sizeof(float);
+    return (size_t)(p.splits > 0 ? p.splits : 1) * M * (Nc + 1) * sizeof(float);  // + one column-sum row per split
 }
 
+// colsum_out (may be NULL): also out[m] = sum_k A[k][m], from the same pass over A (not with a narrow M)
 int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int Nc, long K,
-                       void* workspace, hipStream_t s) {
+                       void* workspace, hipStream_t s, float* colsum_out) {
     if (K <= 0 || lda * 16 > 0x7fffffffL || ldb * 16 > 0x7fffffffL) {
         fsn_set_error("gemm_tn: bad K = %ld or leading dimension", K);
         return FSN_ERR_ARG;
     }
     // a narrow M (the 2-row dW of the sub-band output layer) goes on the narrow side of the tile
     const bool swap = M <= 32 && Nc > 32;
+    if (swap && colsum_out) {
+        fsn_set_error("gemm_tn: fused column sums are not available for M <= 32");
+        return FSN_ERR_ARG;
+    }
     const long K16 = K & ~15L;
     float* part = static_cast<float*>(workspace);
+    float* asum_part = nullptr;
     int splits = 0;
     if (K16 > 0) {
         const TnPlan p = swap ? tn_plan(Nc, M, K16) : tn_plan(M, Nc, K16);
+        if (colsum_out) asum_part = part + (size_t)p.splits * M * Nc;
         auto wide = gemm_tn_kernel<8, 4, 2, 2>;
         auto narrow = gemm_tn_kernel<8, 2, 4, 1>;
         static bool attr_set = false;
@@ -327,17 +362,23 @@ int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float
         const dim3 grid((unsigned)(p.m_blocks * p.n_blocks * p.splits));
         if (swap)
             hipLaunchKernelGGL(p.narrow ? narrow : wide, grid, dim3(256), kTnOnePerCu, s, B, ldb, A, lda, part, Nc, M,
-                               K16, p.k_per_split, p.m_blocks, p.n_blocks);
+                               K16, p.k_per_split, p.m_blocks, p.n_blocks, (float*)nullptr);
         else
             hipLaunchKernelGGL(p.narrow ? narrow : wide, grid, dim3(256), kTnOnePerCu, s, A, lda, B, ldb, part, M, Nc,
-                               K16, p.k_per_split, p.m_blocks, p.n_blocks);
+                               K16, p.k_per_split, p.m_blocks, p.n_blocks, asum_part);
         FSN_TRY_LAUNCH("gemm_tn_kernel");
         splits = p.splits;
     }
     const long n = (long)M * Nc;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, C, ldc, M, Nc, splits,
                        swap ? 1 : 0, A, lda, B, ldb, K16, K);
-    return fsn_check_launch("tn_reduce_kernel");
+    FSN_TRY_LAUNCH("tn_reduce_kernel");
+    if (colsum_out) {
+        hipLaunchKernelGGL(tn_colsum_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, s, asum_part, colsum_out, M,
+                           splits, A, lda, K16, K);
+        return fsn_check_launch("tn_colsum_reduce_kernel");
+    }
+    return FSN_OK;
 }
 
 size_t fsn_colsum_workspace_bytes(int cols, long rows) {
