@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256) void bptt_elem_kernel(const float* __restrict_
 // 4-way split-K over the waves: one dgates fragment feeds CTS MFMAs, one W_hh^T fragment RTS of them;
 // partials reduced through LDS in a fixed order) followed by the cell derivative of those blocks ->
 // dgates_t.  The mirror image of lstm_step_kernel; grid = (H/16/CTS, ceil(row tiles / RTS)).
-template <int RTS, int CTS>
-__global__ __launch_bounds__(256) void bptt_step_kernel(const float* __restrict__ dh_out,
+template <int RTS, int CTS, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void bptt_step_kernel(const float* __restrict__ dh_out,
                                                         const float* __restrict__ dgates_next,
                                                         const float* __restrict__ whhT_p, float* __restrict__ dc,
                                                         const float* __restrict__ gates,
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void bptt_step_kernel(const float* __restrict_
                                                         const float* __restrict__ c_prev,
                                                         float* __restrict__ dgates, int row_tiles, int H, int last,
                                                         int first) {
-    __shared__ f32x4 red[4][RTS][CTS][64];
+    __shared__ f32x4 red[NW][RTS][CTS][64];  // NW-way split-K (16 for the full-band model's single row tile)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int ug0 = blockIdx.x * CTS, rtile0 = blockIdx.y * RTS;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void bptt_step_kernel(const float* __restrict_
         for (int rt = 0; rt < RTS; ++rt)
 #pragma unroll
             for (int ct = 0; ct < CTS; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int kc0 = wave * (KC >> 2), kc1 = kc0 + (KC >> 2);
+        const int kc0 = wave * (KC / NW), kc1 = kc0 + KC / NW;
         const float* ap[RTS];
         const float* bp[CTS];
 #pragma unroll
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void bptt_step_kernel(const float* __restrict_
             for (int ct = 0; ct < CTS; ++ct) red[wave][rt][ct][lane] = acc[rt][ct];
         __syncthreads();
     }
-    for (int tt = wave; tt < RTS * CTS; tt += 4) {
+    for (int tt = wave; tt < RTS * CTS; tt += NW) {
         const int rt = tt / CTS, ct = tt % CTS;
         const int rtile = rtile0 + rt;
         if (rtile >= row_tiles) continue;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void bptt_step_kernel(const float* __restrict_
         if (!last) {
             v = red[0][rt][ct][lane];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) {
+            for (int w = 1; w < NW; ++w) {
                 const f32x4 r = red[w][rt][ct][lane];
                 v = f32x4{v[0] + r[0], v[1] + r[1], v[2] + r[2], v[3] + r[3]};
             }
@@ -407,6 +407,9 @@ int fsn_launch_bptt_step(const float* dh_out, const float* dgates_next, const fl
     hipLaunchKernelGGL((bptt_step_kernel<R, C>), dim3(H / 16 / C, (row_tiles + R - 1) / R), dim3(256), 0, s, dh_out, \
                        dgates_next, whhT_p, dc, gates, c_t, c_prev, dgates, row_tiles, H, last, first)
     if (cfg == 22) FSN_BPTT_CASE(2, 2);
+    else if (row_tiles <= 4 && (4 * H / 16) % 16 == 0)  // a handful of rows (full-band model): 16-way split-K
+        hipLaunchKernelGGL((bptt_step_kernel<1, 1, 16>), dim3(H / 16, row_tiles), dim3(1024), 0, s, dh_out, dgates_next,
+                           whhT_p, dc, gates, c_t, c_prev, dgates, row_tiles, H, last, first);
     else FSN_BPTT_CASE(1, 1);
 #undef FSN_BPTT_CASE
     return fsn_check_launch("bptt_step_kernel");
