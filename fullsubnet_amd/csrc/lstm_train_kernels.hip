@@ -291,6 +291,28 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     part[(long)blockIdx.y * cols + c] = acc;
 }
 
+// the same for at most 16 columns (the 2-wide output layer): 16 row groups x 16 columns per block instead of two
+// busy threads; the row groups are combined in a fixed order
+__global__ __launch_bounds__(256) void colsum_narrow_kernel(const float* __restrict__ A, long lda,
+                                                            float* __restrict__ part, int cols, long rows,
+                                                            long rows_per_block) {
+    __shared__ float red[16][17];
+    const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    r1 = r1 < rows ? r1 : rows;
+    float acc = 0.f;
+    if (c < cols)
+        for (long r = r0 + rg; r < r1; r += 16) acc += A[r * lda + c];
+    red[rg][c] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16 && c < cols) {
+        float t = 0.f;
+        for (int g = 0; g < 16; ++g) t += red[g][c];
+        part[(long)blockIdx.x * cols + c] = t;
+    }
+}
+
 struct TnPlan {
     int m_blocks, n_blocks, splits, narrow;
     long k_per_split;
@@ -388,8 +410,11 @@ size_t fsn_colsum_workspace_bytes(int cols, long rows) {
 int fsn_launch_colsum(const float* A, long lda, float* out, int cols, long rows, void* workspace, hipStream_t s) {
     const int rb = (int)((rows + kColsumRows - 1) / kColsumRows);
     float* part = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, rb), dim3(256), 0, s, A, lda, part, cols, rows,
-                       kColsumRows);
+    if (cols <= 16)
+        hipLaunchKernelGGL(colsum_narrow_kernel, dim3(rb), dim3(256), 0, s, A, lda, part, cols, rows, kColsumRows);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, rb), dim3(256), 0, s, A, lda, part, cols, rows,
+                           kColsumRows);
     FSN_TRY_LAUNCH("colsum_partial_kernel");
     hipLaunchKernelGGL(reduce_splits_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, part, out, (long)cols, 1, cols,
                        rb);
