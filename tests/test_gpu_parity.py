@@ -301,3 +301,33 @@ def test_poisoned_buffers_do_not_leak_into_results(fsn, monkeypatch):
         for a, b in zip(clean, dirty):
             assert torch.isfinite(b).all()
             assert torch.equal(a, b)
+
+
+def test_fused_forward_random_configurations(fsn):
+    """Property-style sweep (fixed seed): 24 random (num_freqs, look_ahead, neighbours, full-band width, batch,
+    frames, norm) combinations of the fused forward against the oracle - step path, wavefront path and the
+    persistent kernel with left-over tiles all occur."""
+    rng = np.random.default_rng(12345)
+    worst = 0.0
+    for it in range(24):
+        F = int(rng.choice([65, 129, 161, 257]))
+        la = int(rng.integers(0, 4))
+        nb = min(int(rng.choice([0, 3, 7, 15])), F - 1)
+        fbh = int(rng.choice([64, 128, 256, 512]))
+        B, T = int(rng.integers(1, 21)), int(rng.integers(1, 13))
+        norm = str(rng.choice(["offline_laplace_norm", "cumulative_laplace_norm"]))
+        params = O.make_params(seed=it, num_freqs=F, fb_hidden=fbh, sb_hidden=384, sb_num_neighbors=nb, gain=2.0,
+                               mask_gain=12.0)
+        kw = dict(MODEL_KW, num_freqs=F, look_ahead=la, sb_num_neighbors=nb, fb_model_hidden_size=fbh)
+        m = fsn.Model(norm_type=norm, num_groups_in_drop_band=1, **kw)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        m = m.cuda().eval()
+        mag = (np.abs(rng.standard_normal((B, 1, F, T))) + 0.05).astype(np.float32)
+        with torch.no_grad():
+            crm = m(dev(mag)).cpu().numpy()
+        want = O.fullsubnet_forward(mag, params, look_ahead=la, sb_num_neighbors=nb, norm_type=norm)
+        lim = 1e-4 * max(1.0, np.abs(want).max() / 10)
+        err = np.abs(crm - want).max()
+        assert err <= lim, (F, la, nb, fbh, B, T, norm, err)
+        worst = max(worst, err / lim)
+    assert worst <= 0.5  # measured 0.07: a drift towards the limit is worth a look before it becomes a failure
