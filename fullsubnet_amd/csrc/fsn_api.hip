@@ -148,6 +148,7 @@ struct Packed {  // float offsets into the packed blob
     size_t fb_wih0, fb_whh0, fb_b0, fb_wih1, fb_whh1, fb_b1, fb_fc, fb_fcb;
     size_t sb_wih0, sb_whh0, sb_b0, sb_wih1, sb_whh1, sb_b1, sb_fc, sb_fcb;
     size_t fb_b1_frag, sb_b1_frag;  // layer-1 biases as accumulator-fragment tiles (wavefront step kernel)
+    size_t sb_wih1_f16x3;           // experimental: sub-band W_ih of layer 1 split into fp16 halves (FSN_F16X3=1)
     size_t total;
     int FP, sb_kin_pad;
 };
@@ -181,6 +182,7 @@ static Packed packed_layout(const fsn_fullsubnet_cfg* c) {
     p.sb_fcb = take(16);
     p.fb_b1_frag = take(4 * Hf * 16);  // [4H/16 column tiles][64 lanes][4]
     p.sb_b1_frag = take(4 * Hs * 16);
+    p.sb_wih1_f16x3 = take((fsn_f16x3_packed_halves(4 * (int)Hs, (int)Hs) + 1) / 2);  // halves -> floats
     p.total = fsn_round_up_sz(o, 64);
     return p;
 }
@@ -221,6 +223,7 @@ extern "C" int fsn_fullsubnet_pack(const fsn_fullsubnet_cfg* cfg, const fsn_full
     FSN_TRY(fsn_launch_bias_sum(w->sb_fc_b, nullptr, o + p.sb_fcb, 2, 16, s));
     FSN_TRY(fsn_launch_bias_frag(o + p.fb_b1, o + p.fb_b1_frag, 4 * Hf, s));
     FSN_TRY(fsn_launch_bias_frag(o + p.sb_b1, o + p.sb_b1_frag, 4 * Hs, s));
+    if (Hs % 32 == 0) FSN_TRY(fsn_launch_pack_f16x3(w->sb_w_ih_l1, o + p.sb_wih1_f16x3, 4 * Hs, Hs, s));
     return FSN_OK;
 }
 
@@ -481,7 +484,12 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         c.kind = 0;
         c.p0 = w.gx_sb;
         c.bias = pk + p.sb_b1;
-        FSN_TRY(fsn_launch_gemm(a, pk + p.sb_wih1, c, sb_rt, 4 * d.Hs / 16, d.Hs / 16, s));
+        static const bool f16x3 = getenv("FSN_F16X3") && getenv("FSN_F16X3")[0] == '1';  // experimental, see the kernel file
+        if (f16x3)
+            FSN_TRY(fsn_launch_gemm_f16x3(w.hseq_sb0, d.Hs, pk + p.sb_wih1_f16x3, pk + p.sb_b1, w.gx_sb, sb_rt, 4 * d.Hs,
+                                          d.Hs, s));
+        else
+            FSN_TRY(fsn_launch_gemm(a, pk + p.sb_wih1, c, sb_rt, 4 * d.Hs / 16, d.Hs / 16, s));
     }
     // Output layer (model.py:53-61,129-135).  Where the persistent 4-pass kernel runs layer 1 it forms the two
     // mask values of a row from h_t in LDS and that layer's 4.8 GB hidden sequence is never written or read

@@ -219,3 +219,9 @@ int fsn_launch_lstm_wavefront2w(const float* gx0, long gx_stride, long gx_off, c
                                 const float* wih1_p, const float* bias1_frag, const float* whh1_p, float* hseq0,
                                 float* hseq1, long hs_stride, long hs_off, float* c0, float* c1, int T, int row_tiles,
                                 int H0, int H1, hipStream_t s, float* state_h0 = nullptr, float* state_h1 = nullptr);
+
+// gemm_f16x3_kernels.hip (experimental, opt-in: FSN_F16X3=1)
+size_t fsn_f16x3_packed_halves(int n_out, int k);
+int fsn_launch_pack_f16x3(const float* w, void* packed, int n_out, int k, hipStream_t s);
+int fsn_launch_gemm_f16x3(const float* A, long lda, const void* packed, const float* bias, float* C, long row_tiles,
+                          int n_out, int k, hipStream_t s);
