@@ -331,3 +331,31 @@ def test_fused_forward_random_configurations(fsn):
         assert err <= lim, (F, la, nb, fbh, B, T, norm, err)
         worst = max(worst, err / lim)
     assert worst <= 0.5  # measured 0.07: a drift towards the limit is worth a look before it becomes a failure
+
+
+def test_experimental_f16x3_projection_matches_fp32(fsn, tmp_path):
+    """The opt-in split-precision GEMM (FSN_F16X3=1, read once per process -> run in a subprocess) for the
+    sub-band layer-1 projection: same mask as the fp32 path to well inside the parity budget."""
+    import subprocess
+    import sys
+    out = tmp_path / "crm.npy"
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "import fullsubnet_amd as fsn; from fsn_synthetic import make_params, make_noisy\n"
+        "kw = %r\n"
+        "m = fsn.Model(norm_type='offline_laplace_norm', num_groups_in_drop_band=1, **kw)\n"
+        "m.load_state_dict({k: torch.from_numpy(v) for k, v in make_params(seed=0, gain=2.0, mask_gain=24.0).items()})\n"
+        "m = m.cuda().eval()\n"
+        "enh, crm = m.enhance(torch.from_numpy(make_noisy(16, 2048, seed=1)).cuda(), return_crm=True)\n"
+        "np.save(%r, crm.cpu().numpy())\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), MODEL_KW, str(out)))
+    env = dict(os.environ, FSN_F16X3="1")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
+    got = np.load(out)
+    params = O.make_params(seed=0, gain=2.0, mask_gain=24.0)
+    m = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=1, **MODEL_KW)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.cuda().eval()
+    _, ref = m.enhance(dev(O.make_noisy(16, 2048, seed=1)), return_crm=True)  # 257 row tiles: the projection GEMM runs
+    ref = ref.cpu().numpy()
+    assert not np.array_equal(got, ref)          # the switch really changed the arithmetic ...
+    assert np.abs(got - ref).max() <= 2e-5       # ... and stayed within a fifth of the 1e-4 budget
