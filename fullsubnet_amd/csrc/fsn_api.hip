@@ -149,6 +149,7 @@ struct Packed {  // float offsets into the packed blob
     size_t sb_wih0, sb_whh0, sb_b0, sb_wih1, sb_whh1, sb_b1, sb_fc, sb_fcb;
     size_t fb_b1_frag, sb_b1_frag;  // layer-1 biases as accumulator-fragment tiles (wavefront step kernel)
     size_t sb_wih1_f16x3;           // experimental: sub-band W_ih of layer 1 split into fp16 halves (FSN_F16X3=1)
+    size_t sb_whh1_f16x3;           // experimental: likewise W_hh of layer 1
     size_t total;
     int FP, sb_kin_pad;
 };
@@ -183,6 +184,7 @@ static Packed packed_layout(const fsn_fullsubnet_cfg* c) {
     p.fb_b1_frag = take(4 * Hf * 16);  // [4H/16 column tiles][64 lanes][4]
     p.sb_b1_frag = take(4 * Hs * 16);
     p.sb_wih1_f16x3 = take((fsn_f16x3_packed_halves(4 * (int)Hs, (int)Hs) + 1) / 2);  // halves -> floats
+    p.sb_whh1_f16x3 = take((fsn_f16x3_packed_halves(4 * (int)Hs, (int)Hs) + 1) / 2);
     p.total = fsn_round_up_sz(o, 64);
     return p;
 }
@@ -223,7 +225,10 @@ extern "C" int fsn_fullsubnet_pack(const fsn_fullsubnet_cfg* cfg, const fsn_full
     FSN_TRY(fsn_launch_bias_sum(w->sb_fc_b, nullptr, o + p.sb_fcb, 2, 16, s));
     FSN_TRY(fsn_launch_bias_frag(o + p.fb_b1, o + p.fb_b1_frag, 4 * Hf, s));
     FSN_TRY(fsn_launch_bias_frag(o + p.sb_b1, o + p.sb_b1_frag, 4 * Hs, s));
-    if (Hs % 32 == 0) FSN_TRY(fsn_launch_pack_f16x3(w->sb_w_ih_l1, o + p.sb_wih1_f16x3, 4 * Hs, Hs, s));
+    if (Hs % 32 == 0) {
+        FSN_TRY(fsn_launch_pack_f16x3(w->sb_w_ih_l1, o + p.sb_wih1_f16x3, 4 * Hs, Hs, s));
+        FSN_TRY(fsn_launch_pack_f16x3(w->sb_w_hh_l1, o + p.sb_whh1_f16x3, 4 * Hs, Hs, s));
+    }
     return FSN_OK;
 }
 
@@ -301,7 +306,8 @@ static int aux_init() {
 // in-kernel from `xin`.  Left-over tiles: projection tiles in `gx_left` at t * left_stride + left_off + i.
 static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* gx_left, long left_stride,
                           long left_off, const float* whh, float* hseq, float* c_left, int Tp, int Npad, int H,
-                          const FsnRecPlan& r, hipStream_t s, const FsnRecFc* fc = nullptr, long left_hs_stride = -1) {
+                          const FsnRecPlan& r, hipStream_t s, const FsnRecFc* fc = nullptr, long left_hs_stride = -1,
+                          const void* whh_f16x3 = nullptr) {
     const bool fork = r.left_tiles > 0 && r.main_wgs > 0;  // no persistent part: the steps run on `s` itself
     hipStream_t ls = s;
     if (fork) {
@@ -312,7 +318,12 @@ static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* g
         }
         ls = g_aux_stream;
     }
-    if (r.main_wgs > 0) FSN_TRY(fsn_launch_lstm_rec(gx, xin, whh, hseq, Tp, Npad, H, r.rt, r.main_wgs, s, fc));
+    if (r.main_wgs > 0) {
+        if (whh_f16x3 && fc && !xin && r.rt >= 2)  // experimental split-precision persistent kernel (FSN_F16X3=1)
+            FSN_TRY(fsn_launch_lstm_rec_f16x3(gx, whh_f16x3, Tp, Npad, H, r.rt, r.main_wgs, fc, s));
+        else
+            FSN_TRY(fsn_launch_lstm_rec(gx, xin, whh, hseq, Tp, Npad, H, r.rt, r.main_wgs, s, fc));
+    }
     if (r.left_tiles > 0) {
         // left-over rows of step t: rows [main_rows, Npad) of the full [t][Npad] matrix, or - when the
         // persistent part stores nothing (fused output layer) - a compact [t][left rows] matrix
@@ -336,9 +347,9 @@ static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* g
 
 static int run_sb_recurrence(const float* gx, const FsnSbInput* xin, const float* gx_left, long left_stride,
                              long left_off, const float* whh, float* hseq, float* c_left, const CoreDims& d,
-                             hipStream_t s, const FsnRecFc* fc = nullptr) {
+                             hipStream_t s, const FsnRecFc* fc = nullptr, const void* whh_f16x3 = nullptr) {
     return run_recurrence(gx, xin, gx_left, left_stride, left_off, whh, hseq, c_left, d.Tp, d.Npad, d.Hs, d.rec, s,
-                          fc, fc ? (long)d.rec.left_tiles * 16 : -1);
+                          fc, fc ? (long)d.rec.left_tiles * 16 : -1, whh_f16x3);
 }
 
 // below this many sub-band row tiles (batch <= 5) the two layers of the small-batch step path also run as
@@ -509,8 +520,10 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
     }
     if (!sb_wave) {
         StageTimer st(ST_SB_REC_L1, s);
+        static const bool f16x3 = getenv("FSN_F16X3") && getenv("FSN_F16X3")[0] == '1';  // experimental
         FSN_TRY(run_sb_recurrence(w.gx_sb, nullptr, w.gx_sb, d.rec.tiles, main_rows / 16, pk + p.sb_whh1, w.hseq_sb1,
-                                  w.c_left, d, s, fc_fused ? &fc : nullptr));
+                                  w.c_left, d, s, fc_fused ? &fc : nullptr,
+                                  f16x3 && fc_fused ? pk + p.sb_whh1_f16x3 : nullptr));
     }
     if (!fc_fused || d.rec.left_tiles > 0) {
         StageTimer st(ST_SB_FC, s);

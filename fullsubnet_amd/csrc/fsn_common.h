@@ -225,3 +225,6 @@ size_t fsn_f16x3_packed_halves(int n_out, int k);
 int fsn_launch_pack_f16x3(const float* w, void* packed, int n_out, int k, hipStream_t s);
 int fsn_launch_gemm_f16x3(const float* A, long lda, const void* packed, const float* bias, float* C, long row_tiles,
                           int n_out, int k, hipStream_t s);
+// lstm_f16x3_kernels.hip (experimental, opt-in: FSN_F16X3=1)
+int fsn_launch_lstm_rec_f16x3(const float* gx, const void* packed, int Tp, int Npad, int H, int RT, int main_wgs,
+                              const FsnRecFc* fc, hipStream_t s);

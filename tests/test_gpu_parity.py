@@ -334,8 +334,10 @@ def test_fused_forward_random_configurations(fsn):
 
 
 def test_experimental_f16x3_projection_matches_fp32(fsn, tmp_path):
-    """The opt-in split-precision GEMM (FSN_F16X3=1, read once per process -> run in a subprocess) for the
-    sub-band layer-1 projection: same mask as the fp32 path to well inside the parity budget."""
+    """The opt-in split-precision kernels (FSN_F16X3=1, read once per process -> run in a subprocess; sub-band
+    layer-1 projection and recurrence): same mask as the fp32 path to well inside the parity budget."""
+    if os.environ.get("FSN_F16X3") == "1":
+        pytest.skip("the whole session runs with the switch on: nothing to compare against")
     import subprocess
     import sys
     out = tmp_path / "crm.npy"
