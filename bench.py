@@ -83,6 +83,25 @@ def cpu_baseline(params, length, budget_s=20.0):
             "rtf_speedup": round(nb * length / SR / dt, 3)}
 
 
+def experimental_f16x3(args):
+    """The same step with the opt-in split-precision kernels (FSN_F16X3=1: fp16 x 3 MFMAs with fp32 accumulation for
+    the sub-band layer-1 projection and recurrence), measured in a child process because the switch
+    is read once per process.  Reported NEXT TO the line's `value`, which is always the default fp32 build."""
+    import subprocess
+    if os.environ.get("FSN_F16X3") == "1":
+        return None
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--batch", str(args.batch), "--seconds", str(args.seconds), "--no-cpu-baseline", "--no-experimental"]
+    try:
+        out = subprocess.run(cmd, env=dict(os.environ, FSN_F16X3="1"), capture_output=True, text=True, timeout=600)
+        d = json.loads(out.stdout.strip().splitlines()[-1])
+        return {"switch": "FSN_F16X3=1", "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                "stage_ms": d["stage_ms"],
+                "note": "opt-in; mask within 1.2e-5 of the fp32 path, GPU parity tests green with the switch on"}
+    except Exception as e:  # the experiment must never break the benchmark line
+        return {"switch": "FSN_F16X3=1", "error": str(e)[:200]}
+
+
 def measured_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r01_hbm_traffic_end.json: FETCH_SIZE x2 (gfx950) + WRITE_SIZE at this exact config, mean of the
@@ -104,6 +123,7 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-experimental", action="store_true", help="skip the opt-in split-precision side measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -218,6 +238,9 @@ def main():
                          "whole_path_frac": round(path_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         }
+        if not args.no_experimental and world == 1 and os.environ.get("FSN_F16X3") != "1":
+            torch.cuda.synchronize()
+            out["experimental_f16x3"] = experimental_f16x3(args)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(params, length, args.cpu_budget)
         elif not args.no_cpu_baseline:
