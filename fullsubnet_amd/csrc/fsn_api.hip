@@ -150,6 +150,8 @@ struct Packed {  // float offsets into the packed blob
     size_t fb_b1_frag, sb_b1_frag;  // layer-1 biases as accumulator-fragment tiles (wavefront step kernel)
     size_t sb_wih1_f16x3;           // experimental: sub-band W_ih of layer 1 split into fp16 halves (FSN_F16X3=1)
     size_t sb_whh1_f16x3;           // experimental: likewise W_hh of layer 1
+    size_t sb_wih0_f16x3;           // experimental: W_ih of layer 0 (only when its padded width is 32), scale 4096
+    size_t sb_whh0_f16x3;           // experimental: W_hh of layer 0
     size_t total;
     int FP, sb_kin_pad;
 };
@@ -185,6 +187,8 @@ static Packed packed_layout(const fsn_fullsubnet_cfg* c) {
     p.sb_b1_frag = take(4 * Hs * 16);
     p.sb_wih1_f16x3 = take((fsn_f16x3_packed_halves(4 * (int)Hs, (int)Hs) + 1) / 2);  // halves -> floats
     p.sb_whh1_f16x3 = take((fsn_f16x3_packed_halves(4 * (int)Hs, (int)Hs) + 1) / 2);
+    p.sb_wih0_f16x3 = take((fsn_f16x3_packed_halves(4 * (int)Hs, 32) + 1) / 2);
+    p.sb_whh0_f16x3 = take((fsn_f16x3_packed_halves(4 * (int)Hs, (int)Hs) + 1) / 2);
     p.total = fsn_round_up_sz(o, 64);
     return p;
 }
@@ -228,6 +232,9 @@ extern "C" int fsn_fullsubnet_pack(const fsn_fullsubnet_cfg* cfg, const fsn_full
     if (Hs % 32 == 0) {
         FSN_TRY(fsn_launch_pack_f16x3(w->sb_w_ih_l1, o + p.sb_wih1_f16x3, 4 * Hs, Hs, s));
         FSN_TRY(fsn_launch_pack_f16x3(w->sb_w_hh_l1, o + p.sb_whh1_f16x3, 4 * Hs, Hs, s));
+        FSN_TRY(fsn_launch_pack_f16x3(w->sb_w_hh_l0, o + p.sb_whh0_f16x3, 4 * Hs, Hs, s));
+        if (kin == 32)
+            FSN_TRY(fsn_launch_pack_f16x3(w->sb_w_ih_l0, o + p.sb_wih0_f16x3, 4 * Hs, 32, s, fsn_f16x3_wih0_scale()));
     }
     return FSN_OK;
 }
@@ -307,7 +314,7 @@ static int aux_init() {
 static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* gx_left, long left_stride,
                           long left_off, const float* whh, float* hseq, float* c_left, int Tp, int Npad, int H,
                           const FsnRecPlan& r, hipStream_t s, const FsnRecFc* fc = nullptr, long left_hs_stride = -1,
-                          const void* whh_f16x3 = nullptr) {
+                          const void* whh_f16x3 = nullptr, const void* wih_f16x3 = nullptr) {
     const bool fork = r.left_tiles > 0 && r.main_wgs > 0;  // no persistent part: the steps run on `s` itself
     hipStream_t ls = s;
     if (fork) {
@@ -321,6 +328,8 @@ static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* g
     if (r.main_wgs > 0) {
         if (whh_f16x3 && fc && !xin && r.rt >= 2)  // experimental split-precision persistent kernel (FSN_F16X3=1)
             FSN_TRY(fsn_launch_lstm_rec_f16x3(gx, whh_f16x3, Tp, Npad, H, r.rt, r.main_wgs, fc, s));
+        else if (whh_f16x3 && wih_f16x3 && xin && !xin->x_rows && xin->kin_chunks == 2 && r.rt >= 2)
+            FSN_TRY(fsn_launch_lstm_rec_xin_f16x3(xin, wih_f16x3, whh_f16x3, hseq, Tp, Npad, H, r.rt, r.main_wgs, s));
         else
             FSN_TRY(fsn_launch_lstm_rec(gx, xin, whh, hseq, Tp, Npad, H, r.rt, r.main_wgs, s, fc));
     }
@@ -347,9 +356,10 @@ static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* g
 
 static int run_sb_recurrence(const float* gx, const FsnSbInput* xin, const float* gx_left, long left_stride,
                              long left_off, const float* whh, float* hseq, float* c_left, const CoreDims& d,
-                             hipStream_t s, const FsnRecFc* fc = nullptr, const void* whh_f16x3 = nullptr) {
+                             hipStream_t s, const FsnRecFc* fc = nullptr, const void* whh_f16x3 = nullptr,
+                             const void* wih_f16x3 = nullptr) {
     return run_recurrence(gx, xin, gx_left, left_stride, left_off, whh, hseq, c_left, d.Tp, d.Npad, d.Hs, d.rec, s,
-                          fc, fc ? (long)d.rec.left_tiles * 16 : -1, whh_f16x3);
+                          fc, fc ? (long)d.rec.left_tiles * 16 : -1, whh_f16x3, wih_f16x3);
 }
 
 // below this many sub-band row tiles (batch <= 5) the two layers of the small-batch step path also run as
@@ -482,8 +492,11 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         xin.N = d.N;
         xin.nb = d.nb;
         xin.kin_chunks = p.sb_kin_pad / 16;
+        static const bool f16x3 = getenv("FSN_F16X3") && getenv("FSN_F16X3")[0] == '1';  // experimental
+        const bool l0_split = f16x3 && d.Hs == 384 && 2 * d.nb + 2 == 32;
         FSN_TRY(run_sb_recurrence(nullptr, &xin, w.gx_sb, d.rec.left_tiles, 0, pk + p.sb_whh0, w.hseq_sb0, w.c_left,
-                                  d, s));
+                                  d, s, nullptr, l0_split ? pk + p.sb_whh0_f16x3 : nullptr,
+                                  l0_split ? pk + p.sb_wih0_f16x3 : nullptr));
     }
     if (!sb_wave) {
         StageTimer st(ST_SB_GEMM_L1, s);

@@ -178,6 +178,23 @@ struct FsnSbInput {
     long x_ld, x_step;
 };
 
+#ifdef __HIPCC__
+// Element (row n, column c) of frame t of the sub-band model input: freq_unfold + cat + norm of
+// fullsubnet/model.py:98-111 (reflect-padded neighbours of the noisy magnitude, then the full-band output,
+// divided by the norm statistic), or the plain row-major form; zero beyond the valid rows / columns.
+__device__ __forceinline__ float fsn_sb_input_value(const FsnSbInput& x, long n, int c, int t) {
+    if (x.x_rows) return n < x.N ? x.x_rows[((long)t * x.x_step + n) * x.x_ld + c] : 0.f;
+    if (n >= x.N || c > 2 * x.nb + 1) return 0.f;
+    const int b = (int)(n / x.F), f = (int)(n % x.F);
+    const long fo = ((long)b * x.Tp + t) * x.FP;
+    int j = f + c - x.nb;
+    j = j < 0 ? -j : j;
+    j = j >= x.F ? 2 * (x.F - 1) - j : j;
+    const float raw = c <= 2 * x.nb ? x.mag[fo + j] : x.fb_out[fo + f];
+    return raw / x.den[x.den_mode ? (long)t * x.den_stride + n : b];
+}
+#endif
+
 // Output layer (nn.Linear(H, 2), fullsubnet/model.py:53-61 + the reshape of :129-135) fused into the
 // last sub-band recurrent layer: the two mask values of a row are formed from h_t while it sits in LDS
 // and go straight to the compressed-mask planes; the hidden sequence of that layer is never written.
@@ -222,9 +239,12 @@ int fsn_launch_lstm_wavefront2w(const float* gx0, long gx_stride, long gx_off, c
 
 // gemm_f16x3_kernels.hip (experimental, opt-in: FSN_F16X3=1)
 size_t fsn_f16x3_packed_halves(int n_out, int k);
-int fsn_launch_pack_f16x3(const float* w, void* packed, int n_out, int k, hipStream_t s);
+int fsn_launch_pack_f16x3(const float* w, void* packed, int n_out, int k, hipStream_t s, float scale = 256.f);
 int fsn_launch_gemm_f16x3(const float* A, long lda, const void* packed, const float* bias, float* C, long row_tiles,
                           int n_out, int k, hipStream_t s);
 // lstm_f16x3_kernels.hip (experimental, opt-in: FSN_F16X3=1)
 int fsn_launch_lstm_rec_f16x3(const float* gx, const void* packed, int Tp, int Npad, int H, int RT, int main_wgs,
                               const FsnRecFc* fc, hipStream_t s);
+float fsn_f16x3_wih0_scale();
+int fsn_launch_lstm_rec_xin_f16x3(const FsnSbInput* xin, const void* wih_packed, const void* whh_packed, float* hseq,
+                                  int Tp, int Npad, int H, int RT, int main_wgs, hipStream_t s);

@@ -29,19 +29,7 @@ __device__ __forceinline__ void stage_sb_input(const FsnSbInput& x, float* xl, i
     const int kin = 16 * x.kin_chunks;
     for (int i = threadIdx.x; i < rows * kin; i += NTHREADS) {
         const int row = i / kin, c = i % kin;
-        const long n = n0 + row;
-        float v = 0.f;
-        if (x.x_rows) {  // plain row-major layer input (a narrow first layer of a SequenceModel block)
-            if (n < x.N) v = x.x_rows[((long)t * x.x_step + n) * x.x_ld + c];
-        } else if (n < x.N && c <= 2 * x.nb + 1) {
-            const int b = (int)(n / x.F), f = (int)(n % x.F);
-            const long fo = ((long)b * x.Tp + t) * x.FP;
-            int j = f + c - x.nb;
-            j = j < 0 ? -j : j;
-            j = j >= x.F ? 2 * (x.F - 1) - j : j;
-            const float raw = c <= 2 * x.nb ? x.mag[fo + j] : x.fb_out[fo + f];
-            v = raw / x.den[x.den_mode ? (long)t * x.den_stride + n : b];
-        }
+        const float v = fsn_sb_input_value(x, n0 + row, c, t);
         xl[row * xs + c] = v;
     }
 }
