@@ -85,7 +85,7 @@ def cpu_baseline(params, length, budget_s=20.0):
 
 def experimental_f16x3(args):
     """The same step with the opt-in split-precision kernels (FSN_F16X3=1: fp16 x 3 MFMAs with fp32 accumulation for
-    the sub-band layer-1 projection and recurrence), measured in a child process because the switch
+    both sub-band recurrent layers and the projection between them), measured in a child process because the switch
     is read once per process.  Reported NEXT TO the line's `value`, which is always the default fp32 build."""
     import subprocess
     if os.environ.get("FSN_F16X3") == "1":
@@ -97,7 +97,8 @@ def experimental_f16x3(args):
         d = json.loads(out.stdout.strip().splitlines()[-1])
         return {"switch": "FSN_F16X3=1", "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
                 "stage_ms": d["stage_ms"],
-                "note": "opt-in; mask within 1.2e-5 of the fp32 path, GPU parity tests green with the switch on"}
+                "note": "opt-in (fp32 operands split into two fp16 halves, three 16-bit MFMAs per product block, fp32 "
+                        "accumulation); mask within 1.2e-5 of the fp32 path, GPU parity tests green with the switch on"}
     except Exception as e:  # the experiment must never break the benchmark line
         return {"switch": "FSN_F16X3=1", "error": str(e)[:200]}
 

@@ -26,7 +26,8 @@ __global__ void pack_f16x3_kernel(const float* __restrict__ w, _Float16* __restr
         const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
         const long blk = i >> 9;
         const int kc = (int)(blk % kc32), ct = (int)(blk / kc32);
-        const float v = w[(long)(ct * 16 + (lane & 15)) * k + kc * 32 + 8 * (lane >> 4) + j] * scale;
+        float v = w[(long)(ct * 16 + (lane & 15)) * k + kc * 32 + 8 * (lane >> 4) + j] * scale;
+        v = fminf(fmaxf(v, -65504.f), 65504.f);  // |w| >= 256 (16 for the layer-0 input weights): saturate, no inf
         const _Float16 h = (_Float16)v;
         whi[i] = h;
         wlo[i] = (_Float16)(v - (float)h);

@@ -45,7 +45,9 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_f16x3_kernel(co
         _Float16* dl = xlo + (t & 1) * ROWS * kXSH;
         for (int i = threadIdx.x; i < ROWS * 32; i += NW * 64) {
             const int row = i >> 5, c = i & 31;
-            const float v = fsn_sb_input_value(xin, (long)blockIdx.x * ROWS + row, c, t) * kSX;
+            // saturate instead of overflowing to inf: a bin 16 000 times the utterance mean (a lone tone burst in
+            // digital silence) drives every gate it touches far into saturation either way
+            const float v = fminf(fsn_sb_input_value(xin, (long)blockIdx.x * ROWS + row, c, t) * kSX, 65504.f);
             const _Float16 hi = (_Float16)v;
             dh[row * kXSH + c] = hi;
             dl[row * kXSH + c] = (_Float16)(v - (float)hi);
