@@ -315,7 +315,12 @@ static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* g
                           long left_off, const float* whh, float* hseq, float* c_left, int Tp, int Npad, int H,
                           const FsnRecPlan& r, hipStream_t s, const FsnRecFc* fc = nullptr, long left_hs_stride = -1,
                           const void* whh_f16x3 = nullptr, const void* wih_f16x3 = nullptr) {
-    const bool fork = r.left_tiles > 0 && r.main_wgs > 0;  // no persistent part: the steps run on `s` itself
+    // No persistent part (fewer than ~160 tiles): the steps run on `s` itself - groups of four tiles through the
+    // one-workgroup-per-CU step kernel, the up to three tiles that do not fill a group beside it on the
+    // auxiliary stream (a 33rd group of 8 workgroups would be a second round on 8 CUs and double the step).
+    const int cu_tiles = r.main_wgs == 0 && r.left_tiles >= 8 ? r.left_tiles / 4 * 4 : 0;
+    const int aux_tiles = r.left_tiles - cu_tiles;
+    const bool fork = aux_tiles > 0 && (r.main_wgs > 0 || cu_tiles > 0);
     hipStream_t ls = s;
     if (fork) {
         FSN_TRY(aux_init());
@@ -341,8 +346,14 @@ static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* g
         for (int t = 0; t < Tp; ++t) {
             float* h_out = hseq + ((size_t)t * hs_stride + hs_off) * H;
             const float* h_prev = t ? hseq + ((size_t)(t - 1) * hs_stride + hs_off) * H : h_out;
-            FSN_TRY(fsn_launch_lstm_step(gx_left, whh, h_prev, h_out, c_left, (long)t * left_stride + left_off,
-                                         r.left_tiles, H, t == 0, ls, fork ? 1 : 0));
+            const long gx_rt0 = (long)t * left_stride + left_off;
+            if (cu_tiles > 0)
+                FSN_TRY(fsn_launch_lstm_step_cu(gx_left, whh, h_prev, h_out, c_left, gx_rt0, cu_tiles, H, t == 0, s));
+            if (aux_tiles > 0) {
+                const size_t ro = (size_t)cu_tiles * 16 * H;
+                FSN_TRY(fsn_launch_lstm_step(gx_left, whh, h_prev + ro, h_out + ro, c_left + ro, gx_rt0 + cu_tiles,
+                                             aux_tiles, H, t == 0, ls, fork ? 1 : 0));
+            }
         }
     }
     if (fork) {
@@ -468,7 +479,8 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
     }
     // Small batches (no persistent part): both layers as one wavefront of per-step launches on the
     // projection computed above.
-    const bool sb_wave = d.rec.main_wgs == 0 && d.rec.left_tiles < kWavefrontBelowTiles;
+    static const int wave_below = getenv("FSN_WAVE_BELOW") ? atoi(getenv("FSN_WAVE_BELOW")) : kWavefrontBelowTiles;
+    const bool sb_wave = d.rec.main_wgs == 0 && d.rec.left_tiles < wave_below;
     if (sb_wave) {
         StageTimer st(ST_SB_REC_L0, s);
         FSN_TRY(fsn_launch_lstm_wavefront2(w.gx_sb, d.rec.left_tiles, 0, pk + p.sb_whh0, pk + p.sb_wih1, pk + p.sb_b1_frag,

@@ -9,6 +9,9 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef FSN_F16X3_UG
+#define FSN_F16X3_UG 2  // hidden-unit groups of 16 per wave: 2 -> 12 waves, 3 -> 8 waves
+#endif
 #ifndef FSN_PROBE_ABLATE  // tools/probe_rec_f16x3.hip only: 1 no W refills, 2 no LDS operand reads, 3 no cell math
 #define FSN_PROBE_ABLATE 0
 #endif
@@ -242,7 +245,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_f16x3_kernel(co
 template <int RT, bool XIN>
 int launch(const float* gx, const FsnSbInput& xin, const void* wih_packed, const void* packed, float* hseq, int Tp,
            int Npad, int main_wgs, const FsnRecFc& fc, hipStream_t s) {
-    constexpr int H = 384, UG = 2, NW = H / (16 * UG);
+    constexpr int H = 384, UG = FSN_F16X3_UG, NW = H / (16 * UG);
     const size_t lds = (size_t)2 * RT * 16 * (H + 8) * sizeof(_Float16) +
                        (XIN ? (size_t)4 * RT * 16 * kXSH * sizeof(_Float16) : (size_t)2 * H * sizeof(float));
     auto kern = lstm_rec_f16x3_kernel<H, RT, UG, XIN>;

@@ -375,6 +375,16 @@ __device__ __forceinline__ void lstm_step_body(const float* __restrict__ gx, con
     for (int rt = 0; rt < RTS; ++rt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[rt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // what the finishing wave's epilogue reads (projection tiles, previous cell state) is requested before the K
+    // loop: cold lines, each of which would otherwise cost a memory round trip after the barrier
+    const int ftile = rtile0 + wave < row_tiles ? rtile0 + wave : row_tiles - 1;
+    f32x4 addv[4];
+    float c_old[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        addv[g] = *reinterpret_cast<const f32x4*>(gx + (((gx_rt0 + ftile) * CT + g * KC + ug) * 64 + lane) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c_old[i] = first ? 0.f : c_prev[((long)ftile * 16 + 4 * lq + i) * H + ug * 16 + lr];
     if (!first) {
         const int kc0 = wave * (KC >> 2), kc1 = kc0 + (KC >> 2);
         const float* ap[RTS];
@@ -419,18 +429,17 @@ __device__ __forceinline__ void lstm_step_body(const float* __restrict__ gx, con
                 v = f32x4{v[0] + r[0], v[1] + r[1], v[2] + r[2], v[3] + r[3]};
             }
         }
-        const f32x4 x = *reinterpret_cast<const f32x4*>(gx + (((gx_rt0 + rtile) * CT + g * KC + ug) * 64 + lane) * 4);
+        const f32x4 x = addv[g];
         pre[g] = f32x4{v[0] + x[0], v[1] + x[1], v[2] + x[2], v[3] + x[3]};
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const long row = (long)rtile * 16 + 4 * lq + i;
         const long idx = row * H + ug * 16 + lr;
-        const float c_old = first ? 0.f : c_prev[idx];
         // hardware exp / rcp forms (fsn_common.h): the libm ones were ~12 % of this kernel at 129 row tiles
         const float ig = sigmoid_fast(pre[0][i]), fg = sigmoid_fast(pre[1][i]);
         const float gg = tanh_fast(pre[2][i]), og = sigmoid_fast(pre[3][i]);
-        const float cn = fg * c_old + ig * gg;
+        const float cn = fg * c_old[i] + ig * gg;
         c[idx] = cn;
         h_out[idx] = og * tanh_fast(cn);
         if (gates_out) {  // training: keep the activated gates for the backward pass, [row][4H]
@@ -478,6 +487,14 @@ __global__ __launch_bounds__(256) void lstm_step_rows_kernel(const float* __rest
         for (int g = 0; g < 4; ++g)
             acc[rt][g] = *reinterpret_cast<const f32x4*>(gx + (((gx_rt0 + rtile[rt]) * CT + g * KC + ug) * 64 + lane) * 4);
     }
+    // previous cell state requested before the K loop: read in the epilogue, every element would pay its own
+    // memory round trip (and the wait for it also waits for the stores of the element before)
+    float c_old[RW][4];
+#pragma unroll
+    for (int rt = 0; rt < RW; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            c_old[rt][i] = first ? 0.f : c_prev[((long)rtile[rt] * 16 + 4 * lq + i) * H + ug * 16 + lr];
     if (!first) {
         const float* ap[RW];
 #pragma unroll
@@ -506,10 +523,9 @@ __global__ __launch_bounds__(256) void lstm_step_rows_kernel(const float* __rest
         for (int i = 0; i < 4; ++i) {
             const long row = (long)rtile[rt] * 16 + 4 * lq + i;
             const long idx = row * H + ug * 16 + lr;
-            const float c_old = first ? 0.f : c_prev[idx];
             const float ig = sigmoid_fast(acc[rt][0][i]), fg = sigmoid_fast(acc[rt][1][i]);
             const float gg = tanh_fast(acc[rt][2][i]), og = sigmoid_fast(acc[rt][3][i]);
-            const float cn = fg * c_old + ig * gg;
+            const float cn = fg * c_old[rt][i] + ig * gg;
             c[idx] = cn;
             h_out[idx] = og * tanh_fast(cn);
             if (gates_out) {
@@ -521,6 +537,81 @@ __global__ __launch_bounds__(256) void lstm_step_rows_kernel(const float* __rest
             }
         }
     }
+}
+
+// One step for a row count that fills the chip about once (2 - 9 utterances, 4 x groups of row tiles): the
+// launch is shaped so that every CU gets ONE workgroup of four waves, one wave per SIMD, and every wave the same
+// work - row tile w of its group x UGW hidden-unit groups x all four gates - with the operands of the next K
+// chunk fetched (pinned) while the 16 UGW MFMAs of this one issue.  Against lstm_step_rows_kernel (one unit
+// group per wave, 3.1 workgroups per CU at 129 tiles, loads and MFMAs of a chunk back to back): 40 -> 2x us per
+// step at 128 tiles.  Inference only (cell state in place, no saved gates); row_tiles must be a multiple of 4.
+template <int UGW>
+__global__ __launch_bounds__(256) void lstm_step_cu_kernel(const float* __restrict__ gx,
+                                                           const float* __restrict__ whh_p,
+                                                           const float* __restrict__ h_prev,
+                                                           float* __restrict__ h_out, float* __restrict__ c,
+                                                           long gx_rt0, int H, int first) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int ug0 = blockIdx.x * UGW;
+    const long rtile = (long)blockIdx.y * 4 + wave;
+    const int KC = H >> 4, CT = 4 * KC;
+    f32x4 acc[UGW][4];
+#pragma unroll
+    for (int u = 0; u < UGW; ++u)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            acc[u][g] = *reinterpret_cast<const f32x4*>(gx + (((gx_rt0 + rtile) * CT + g * KC + ug0 + u) * 64 + lane) * 4);
+    // the previous cell state is asked for now: these are cold lines, and read in the epilogue each one would
+    // cost its own memory round trip (the value is unused on the first step; the buffer exists either way)
+    float c_old[UGW][4];
+#pragma unroll
+    for (int u = 0; u < UGW; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c_old[u][i] = c[(rtile * 16 + 4 * lq + i) * H + (ug0 + u) * 16 + lr];
+    if (!first) {
+        const float* ap = h_prev + (rtile * 16 + lr) * H + 4 * lq;
+        const float* bp = whh_p + ((long)ug0 * KC * 64 + lane) * 4;
+        const long gstride = (long)KC * KC * 256, ustride = (long)KC * 256;
+        f32x4 an, bn[UGW][4];
+        auto fetch = [&](int kc) {
+            an = *reinterpret_cast<const f32x4*>(ap + kc * 16);
+#pragma unroll
+            for (int u = 0; u < UGW; ++u)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    bn[u][g] = *reinterpret_cast<const f32x4*>(bp + g * gstride + u * ustride + (long)kc * 256);
+        };
+        fetch(0);
+        for (int kc = 0; kc < KC; ++kc) {
+            const f32x4 a = an;
+            f32x4 b[UGW][4];
+#pragma unroll
+            for (int u = 0; u < UGW; ++u)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) b[u][g] = bn[u][g];
+            __builtin_amdgcn_sched_barrier(0);  // refill first, pinned: the MFMAs below cover its L2 round trip
+            fetch(kc + 1 < KC ? kc + 1 : kc);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int u = 0; u < UGW; ++u)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[u][g] = mfma16(a[j], b[u][g][j], acc[u][g]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < UGW; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long idx = (rtile * 16 + 4 * lq + i) * H + (ug0 + u) * 16 + lr;
+            const float ig = sigmoid_fast(acc[u][0][i]), fg = sigmoid_fast(acc[u][1][i]);
+            const float gg = tanh_fast(acc[u][2][i]), og = sigmoid_fast(acc[u][3][i]);
+            const float cn = fg * (first ? 0.f : c_old[u][i]) + ig * gg;
+            c[idx] = cn;
+            h_out[idx] = og * tanh_fast(cn);
+        }
 }
 
 // The single-tile form also runs the left-over tiles of the sub-band model NEXT TO the resident
@@ -859,6 +950,38 @@ int fsn_launch_lstm_step(const float* gx, const float* whh_p, const float* h_pre
         return fsn_check_launch("lstm_step1_kernel");
     }
     return fsn_launch_lstm_step_train(gx, whh_p, h_prev, h_out, c, c, nullptr, gx_rt0, row_tiles, H, first, s);
+}
+
+// One step on row_tiles (a multiple of 4) tiles with the one-workgroup-per-CU kernel; picks the unit groups per
+// wave that fill the chip best: cost = rounds of workgroups over the CUs x work per workgroup.
+int fsn_launch_lstm_step_cu(const float* gx, const float* whh_p, const float* h_prev, float* h_out, float* c,
+                            long gx_rt0, int row_tiles, int H, int first, hipStream_t s) {
+    if (H % 16 != 0 || row_tiles % 4 != 0 || row_tiles <= 0) {
+        fsn_set_error("lstm_step_cu: H %d must be a multiple of 16 and row_tiles %d a positive multiple of 4", H, row_tiles);
+        return FSN_ERR_ARG;
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int ugs = H / 16, groups = row_tiles / 4;
+    int best = 1;
+    long best_cost = -1;
+    for (int ugw = 1; ugw <= 3; ++ugw) {
+        if (ugs % ugw) continue;
+        const long wgs = (long)groups * (ugs / ugw);
+        const long cost = ((wgs + cus - 1) / cus) * ugw;
+        if (best_cost < 0 || cost <= best_cost) {  // ties: the wider wave tile (fewer operand loads per MFMA)
+            best = ugw;
+            best_cost = cost;
+        }
+    }
+#define FSN_STEP_CU(U)                                                                                             \
+    hipLaunchKernelGGL(lstm_step_cu_kernel<U>, dim3(ugs / U, groups), dim3(256), 0, s, gx, whh_p, h_prev, h_out, c, \
+                       gx_rt0, H, first)
+    if (best == 3) FSN_STEP_CU(3);
+    else if (best == 2) FSN_STEP_CU(2);
+    else FSN_STEP_CU(1);
+#undef FSN_STEP_CU
+    return fsn_check_launch("lstm_step_cu_kernel");
 }
 
 // Training form: c_{t-1} is read from c_prev, c_t written to c_out (the saved cell sequence) and the
