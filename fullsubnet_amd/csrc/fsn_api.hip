@@ -479,8 +479,7 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
     }
     // Small batches (no persistent part): both layers as one wavefront of per-step launches on the
     // projection computed above.
-    static const int wave_below = getenv("FSN_WAVE_BELOW") ? atoi(getenv("FSN_WAVE_BELOW")) : kWavefrontBelowTiles;
-    const bool sb_wave = d.rec.main_wgs == 0 && d.rec.left_tiles < wave_below;
+    const bool sb_wave = d.rec.main_wgs == 0 && d.rec.left_tiles < kWavefrontBelowTiles;
     if (sb_wave) {
         StageTimer st(ST_SB_REC_L0, s);
         FSN_TRY(fsn_launch_lstm_wavefront2(w.gx_sb, d.rec.left_tiles, 0, pk + p.sb_whh0, pk + p.sb_wih1, pk + p.sb_b1_frag,

@@ -539,6 +539,55 @@ __global__ __launch_bounds__(256) void lstm_step_rows_kernel(const float* __rest
     }
 }
 
+// K loop of lstm_step_cu_kernel: acc[u][g] += A(16 rows x H) W_hh(u, g)^T for the
+// wave's row tile, UGW unit groups and four gates.  The four waves of the workgroup need the SAME 4 UGW weight
+// fragments per K chunk (they differ in the row tile only): fetched per wave that is 13 KB per wave and chunk
+// against 48 MFMAs, 35 B/clk per CU on the vector memory path.  Here every wave
+// fetches UGW of the fragments, parks them in LDS (two stages, one barrier per chunk) and all four read them from
+// there; only the A fragment is per wave.  ap: this lane's A address for chunk 0; bp: packed W_hh at unit group
+// ug0 (+ lane * 4).
+template <int UGW>
+__device__ __forceinline__ void cu_kloop(f32x4 (&acc)[UGW][4], const float* ap, const float* bp, int KC,
+                                         f32x4 (*bsh)[UGW * 4][64]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long gstride = (long)KC * KC * 256, ustride = (long)KC * 256;
+    f32x4 an, bn[UGW];
+    auto fetch = [&](int kc) {
+        an = *reinterpret_cast<const f32x4*>(ap + kc * 16);
+#pragma unroll
+        for (int k = 0; k < UGW; ++k) {
+            const int f = wave * UGW + k, u = f >> 2, g = f & 3;  // fragment f = (unit group u, gate g)
+            bn[k] = *reinterpret_cast<const f32x4*>(bp + g * gstride + u * ustride + (long)kc * 256);
+        }
+    };
+    fetch(0);
+#pragma unroll
+    for (int k = 0; k < UGW; ++k) bsh[0][wave * UGW + k][lane] = bn[k];
+    f32x4 a = an;
+    __syncthreads();
+    for (int kc = 0; kc < KC; ++kc) {
+        __builtin_amdgcn_sched_barrier(0);  // next chunk's global fetch first, pinned under this chunk's MFMAs
+        fetch(kc + 1 < KC ? kc + 1 : kc);
+        __builtin_amdgcn_sched_barrier(0);
+        const int buf = kc & 1;
+#pragma unroll
+        for (int u = 0; u < UGW; ++u) {
+            f32x4 b[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b[g] = bsh[buf][u * 4 + g][lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[u][g] = mfma16(a[j], b[g][j], acc[u][g]);
+        }
+        // the other stage was last read in the previous iteration, which ended with the barrier below
+#pragma unroll
+        for (int k = 0; k < UGW; ++k) bsh[buf ^ 1][wave * UGW + k][lane] = bn[k];
+        a = an;
+        __syncthreads();
+    }
+}
+
 // One step for a row count that fills the chip about once (2 - 9 utterances, 4 x groups of row tiles): the
 // launch is shaped so that every CU gets ONE workgroup of four waves, one wave per SIMD, and every wave the same
 // work - row tile w of its group x UGW hidden-unit groups x all four gates - with the operands of the next K
@@ -569,37 +618,9 @@ __global__ __launch_bounds__(256) void lstm_step_cu_kernel(const float* __restri
     for (int u = 0; u < UGW; ++u)
 #pragma unroll
         for (int i = 0; i < 4; ++i) c_old[u][i] = c[(rtile * 16 + 4 * lq + i) * H + (ug0 + u) * 16 + lr];
-    if (!first) {
-        const float* ap = h_prev + (rtile * 16 + lr) * H + 4 * lq;
-        const float* bp = whh_p + ((long)ug0 * KC * 64 + lane) * 4;
-        const long gstride = (long)KC * KC * 256, ustride = (long)KC * 256;
-        f32x4 an, bn[UGW][4];
-        auto fetch = [&](int kc) {
-            an = *reinterpret_cast<const f32x4*>(ap + kc * 16);
-#pragma unroll
-            for (int u = 0; u < UGW; ++u)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    bn[u][g] = *reinterpret_cast<const f32x4*>(bp + g * gstride + u * ustride + (long)kc * 256);
-        };
-        fetch(0);
-        for (int kc = 0; kc < KC; ++kc) {
-            const f32x4 a = an;
-            f32x4 b[UGW][4];
-#pragma unroll
-            for (int u = 0; u < UGW; ++u)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) b[u][g] = bn[u][g];
-            __builtin_amdgcn_sched_barrier(0);  // refill first, pinned: the MFMAs below cover its L2 round trip
-            fetch(kc + 1 < KC ? kc + 1 : kc);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int u = 0; u < UGW; ++u)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[u][g] = mfma16(a[j], b[u][g][j], acc[u][g]);
-        }
+    if (!first) {  // uniform over the workgroup (barriers inside)
+        __shared__ f32x4 bsh[2][UGW * 4][64];
+        cu_kloop<UGW>(acc, h_prev + (rtile * 16 + lr) * H + 4 * lq, whh_p + ((long)ug0 * KC * 64 + lane) * 4, KC, bsh);
     }
 #pragma unroll
     for (int u = 0; u < UGW; ++u)

@@ -221,6 +221,10 @@ def test_errors_are_loud(fsn):
     (129, 3, 0, 128, 2, 6, "cumulative_laplace_norm"),    # no neighbours at all: K = 2 -> one padded chunk
     (65, 2, 31, 64, 5, 4, "cumulative_laplace_norm"),     # neighbourhood almost as wide as the spectrum
     (257, 2, 15, 512, 17, 3, "offline_laplace_norm"),     # 273 row tiles: persistent kernel + 17 left-over tiles
+    (257, 2, 15, 512, 8, 3, "offline_laplace_norm"),      # 129 row tiles: 32 groups of four through the
+                                                          # one-workgroup-per-CU step kernel + 1 tile beside it
+    (161, 1, 7, 256, 11, 4, "cumulative_laplace_norm"),   # 111 row tiles: 27 groups (two unit groups per wave) + 3
+    (257, 1, 15, 512, 6, 2, "offline_laplace_norm"),      # 97 row tiles: the first size of the step regime
 ])
 def test_fused_forward_other_shapes_vs_oracle(fsn, F, la, nb, fbh, B, T, norm):
     """fsn_fullsubnet_forward away from the shipped configuration (cfg fields are free: num_freqs, look_ahead,
