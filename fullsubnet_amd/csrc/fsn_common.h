@@ -219,7 +219,8 @@ FsnRecPlan fsn_lstm_rec_plan(int N, int H);
 int fsn_launch_lstm_step(const float* gx, const float* whh_p, const float* h_prev, float* h_out, float* c,
                          long gx_rt0, int row_tiles, int H, int first, hipStream_t s, int beside_persistent = 0);
 int fsn_launch_lstm_step_cu(const float* gx, const float* whh_p, const float* h_prev, float* h_out, float* c,
-                            long gx_rt0, int row_tiles, int H, int first, hipStream_t s);
+                            long gx_rt0, int row_tiles, int H, int first, hipStream_t s, const float* c_prev = nullptr,
+                            float* gates_out = nullptr);
 int fsn_launch_lstm_step_train(const float* gx, const float* whh_p, const float* h_prev, float* h_out,
                                const float* c_prev, float* c_out, float* gates_out, long gx_rt0, int row_tiles, int H,
                                int first, hipStream_t s);

@@ -593,17 +593,20 @@ __device__ __forceinline__ void cu_kloop(f32x4 (&acc)[UGW][4], const float* ap, 
 // work - row tile w of its group x UGW hidden-unit groups x all four gates - with the operands of the next K
 // chunk fetched (pinned) while the 16 UGW MFMAs of this one issue.  Against lstm_step_rows_kernel (one unit
 // group per wave, 3.1 workgroups per CU at 129 tiles, loads and MFMAs of a chunk back to back): 40 -> 2x us per
-// step at 128 tiles.  Inference only (cell state in place, no saved gates); row_tiles must be a multiple of 4.
+// step at 128 tiles.  c_prev / c / gates_out as in lstm_step_rows_kernel (inference: c in place, no gates);
+// row_tiles must be a multiple of 4.
 template <int UGW>
 __global__ __launch_bounds__(256) void lstm_step_cu_kernel(const float* __restrict__ gx,
                                                            const float* __restrict__ whh_p,
                                                            const float* __restrict__ h_prev,
-                                                           float* __restrict__ h_out, float* __restrict__ c,
-                                                           long gx_rt0, int H, int first) {
+                                                           float* __restrict__ h_out, const float* c_prev,
+                                                           float* c, float* __restrict__ gates_out, long gx_rt0,
+                                                           int H, int first) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int ug0 = blockIdx.x * UGW;
     const long rtile = (long)blockIdx.y * 4 + wave;
+    if (first) c_prev = c;  // any valid address: the value is not used on the first step
     const int KC = H >> 4, CT = 4 * KC;
     f32x4 acc[UGW][4];
 #pragma unroll
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(256) void lstm_step_cu_kernel(const float* __restri
 #pragma unroll
     for (int u = 0; u < UGW; ++u)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) c_old[u][i] = c[(rtile * 16 + 4 * lq + i) * H + (ug0 + u) * 16 + lr];
+        for (int i = 0; i < 4; ++i) c_old[u][i] = c_prev[(rtile * 16 + 4 * lq + i) * H + (ug0 + u) * 16 + lr];
     if (!first) {  // uniform over the workgroup (barriers inside)
         __shared__ f32x4 bsh[2][UGW * 4][64];
         cu_kloop<UGW>(acc, h_prev + (rtile * 16 + lr) * H + 4 * lq, whh_p + ((long)ug0 * KC * 64 + lane) * 4, KC, bsh);
@@ -632,6 +635,13 @@ __global__ __launch_bounds__(256) void lstm_step_cu_kernel(const float* __restri
             const float cn = fg * (first ? 0.f : c_old[u][i]) + ig * gg;
             c[idx] = cn;
             h_out[idx] = og * tanh_fast(cn);
+            if (gates_out) {  // training: the activated gates for the backward pass, [row][4H]
+                float* gp = gates_out + (rtile * 16 + 4 * lq + i) * 4 * H + (ug0 + u) * 16 + lr;
+                gp[0] = ig;
+                gp[H] = fg;
+                gp[2 * H] = gg;
+                gp[3 * H] = og;
+            }
         }
 }
 
@@ -976,7 +986,9 @@ int fsn_launch_lstm_step(const float* gx, const float* whh_p, const float* h_pre
 // One step on row_tiles (a multiple of 4) tiles with the one-workgroup-per-CU kernel; picks the unit groups per
 // wave that fill the chip best: cost = rounds of workgroups over the CUs x work per workgroup.
 int fsn_launch_lstm_step_cu(const float* gx, const float* whh_p, const float* h_prev, float* h_out, float* c,
-                            long gx_rt0, int row_tiles, int H, int first, hipStream_t s) {
+                            long gx_rt0, int row_tiles, int H, int first, hipStream_t s, const float* c_prev,
+                            float* gates_out) {
+    if (!c_prev) c_prev = c;
     if (H % 16 != 0 || row_tiles % 4 != 0 || row_tiles <= 0) {
         fsn_set_error("lstm_step_cu: H %d must be a multiple of 16 and row_tiles %d a positive multiple of 4", H, row_tiles);
         return FSN_ERR_ARG;
@@ -996,8 +1008,8 @@ int fsn_launch_lstm_step_cu(const float* gx, const float* whh_p, const float* h_
         }
     }
 #define FSN_STEP_CU(U)                                                                                             \
-    hipLaunchKernelGGL(lstm_step_cu_kernel<U>, dim3(ugs / U, groups), dim3(256), 0, s, gx, whh_p, h_prev, h_out, c, \
-                       gx_rt0, H, first)
+    hipLaunchKernelGGL(lstm_step_cu_kernel<U>, dim3(ugs / U, groups), dim3(256), 0, s, gx, whh_p, h_prev, h_out,    \
+                       c_prev, c, gates_out, gx_rt0, H, first)
     if (best == 3) FSN_STEP_CU(3);
     else if (best == 2) FSN_STEP_CU(2);
     else FSN_STEP_CU(1);
@@ -1014,6 +1026,8 @@ int fsn_launch_lstm_step_train(const float* gx, const float* whh_p, const float*
         fsn_set_error("lstm_step: hidden size %d must be a multiple of 64", H);
         return FSN_ERR_ARG;
     }
+    if (row_tiles >= 64 && row_tiles % 4 == 0)  // config 3: 16 x 128 bins = 128 tiles = one workgroup per CU
+        return fsn_launch_lstm_step_cu(gx, whh_p, h_prev, h_out, c_out, gx_rt0, row_tiles, H, first, s, c_prev, gates_out);
     if (row_tiles >= 64) {  // measured at 129 tiles: 65.1 ms per training step against 66.3 for the split-K form
         hipLaunchKernelGGL(lstm_step_rows_kernel<1>, dim3(H / 16, (row_tiles + 3) / 4), dim3(256), 0, s, gx, whh_p, h_prev,
                            h_out, c_prev, c_out, gates_out, gx_rt0, row_tiles, H, first);

@@ -421,12 +421,121 @@ int fsn_launch_colsum(const float* A, long lda, float* out, int cols, long rows,
     return fsn_check_launch("reduce_splits_kernel");
 }
 
+// The BPTT step in the one-workgroup-per-CU shape of lstm_step_cu_kernel (lstm_kernels.hip), for row counts that
+// fill the chip at least once (used from 192 row tiles): a workgroup = four row tiles x CTW
+// column tiles of dh_rec = dgates_{t+1} W_hh, one row tile per wave, the whole K = 4H range per wave (no split-K
+// exchange).  A stage is four K chunks: wave w fetches chunk w's CTW weight fragments for everybody (two-stage LDS
+// buffer, one barrier per stage) and its own four A fragments; the next stage's fetch is pinned under the 16 CTW
+// MFMAs of this one.  Everything the element-wise part reads (saved gates, dh, c_t, dc, c_{t-1}) is requested
+// before the K loop - with one wave per SIMD there are registers to spare, and read afterwards each of the 8 CTW x 4
+// values per lane would pay its own memory round trip.
+template <int CTW>
+__global__ __launch_bounds__(256) void bptt_step_cu_kernel(const float* __restrict__ dh_out,
+                                                           const float* __restrict__ dgates_next,
+                                                           const float* __restrict__ whhT_p, float* __restrict__ dc,
+                                                           const float* __restrict__ gates,
+                                                           const float* __restrict__ c_t, const float* c_prev,
+                                                           float* __restrict__ dgates, int H, int last, int first) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int ug0 = blockIdx.x * CTW;
+    const long rtile = (long)blockIdx.y * 4 + wave;
+    const int G = 4 * H, KC = G >> 4, stages = KC >> 2;
+    if (first) c_prev = c_t;  // any valid address: the value is not used at t = 0
+    float e_gate[CTW][4][4], e_dh[CTW][4], e_ct[CTW][4], e_dc[CTW][4], e_cp[CTW][4];
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long row = rtile * 16 + 4 * lq + i;
+            const int u = (ug0 + ct) * 16 + lr;
+            const float* gp = gates + row * G + u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) e_gate[ct][i][g] = gp[(long)g * H];
+            e_dh[ct][i] = dh_out[row * H + u];
+            e_ct[ct][i] = c_t[row * H + u];
+            e_dc[ct][i] = last ? 0.f : dc[row * H + u];
+            e_cp[ct][i] = c_prev[row * H + u];
+        }
+    f32x4 acc[CTW];
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!last) {  // uniform over the workgroup (barriers inside)
+        __shared__ f32x4 bsh[2][4 * CTW][64];
+        const float* ap = dgates_next + (rtile * 16 + lr) * G + 4 * lq;
+        const float* bp = whhT_p + ((long)ug0 * KC * 64 + lane) * 4;
+        f32x4 an[4], bn[CTW];
+        auto fetch = [&](int st) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) an[q] = *reinterpret_cast<const f32x4*>(ap + (st * 4 + q) * 16);
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct)
+                bn[ct] = *reinterpret_cast<const f32x4*>(bp + ((long)ct * KC + st * 4 + wave) * 256);
+        };
+        fetch(0);
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) bsh[0][wave * CTW + ct][lane] = bn[ct];
+        f32x4 a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = an[q];
+        __syncthreads();
+        for (int st = 0; st < stages; ++st) {
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(st + 1 < stages ? st + 1 : st);
+            __builtin_amdgcn_sched_barrier(0);
+            const int buf = st & 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 b[CTW];
+#pragma unroll
+                for (int ct = 0; ct < CTW; ++ct) b[ct] = bsh[buf][q * CTW + ct][lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ct = 0; ct < CTW; ++ct) acc[ct] = mfma16(a[q][j], b[ct][j], acc[ct]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CTW; ++ct) bsh[buf ^ 1][wave * CTW + ct][lane] = bn[ct];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = an[q];
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long row = rtile * 16 + 4 * lq + i;
+            const int u = (ug0 + ct) * 16 + lr;
+            const long idx = row * H + u;
+            const float ig = e_gate[ct][i][0], fg = e_gate[ct][i][1], gg = e_gate[ct][i][2], og = e_gate[ct][i][3];
+            const float dh = e_dh[ct][i] + acc[ct][i];
+            const float tc = tanhf(e_ct[ct][i]);
+            const float d_o = dh * tc;
+            const float dct = e_dc[ct][i] + dh * og * (1.f - tc * tc);
+            const float cp = first ? 0.f : e_cp[ct][i];
+            float* dg = dgates + row * G + u;
+            dg[0] = dct * gg * ig * (1.f - ig);
+            dg[H] = dct * cp * fg * (1.f - fg);
+            dg[2 * H] = dct * ig * (1.f - gg * gg);
+            dg[3 * H] = d_o * og * (1.f - og);
+            dc[idx] = dct * fg;
+        }
+}
+
 int fsn_launch_bptt_step(const float* dh_out, const float* dgates_next, const float* whhT_p, float* dc,
                          const float* gates, const float* c_t, const float* c_prev, float* dgates, int row_tiles, int H,
                          int last, int first, hipStream_t s) {
     // measured at 129 row tiles (tools/bench_train.py): 2 x 2 72.2 ms per training step, 1 x 2 73.0, 2 x 1 75.1,
     // 1 x 1 76.3, 4 x 2 76.8, 2 x 4 77.8, 4 x 4 89.0; a no-split-K form (a wave per tile for the whole K = 4H
     // range, which pays off in the forward step) is 10 % slower here: K is four times longer
+    // measured (tools/bench_train.py): 256 row tiles 103.3 -> 96.8 ms per training step; at 128 tiles (one workgroup
+    // per CU, nothing left to overlap its element-wise part with) 57.9 against 57.0 for the split-K form below
+    if (row_tiles >= 192 && row_tiles % 4 == 0 && H % 48 == 0) {
+        hipLaunchKernelGGL(bptt_step_cu_kernel<3>, dim3(H / 48, row_tiles / 4), dim3(256), 0, s, dh_out, dgates_next,
+                           whhT_p, dc, gates, c_t, c_prev, dgates, H, last, first);
+        return fsn_check_launch("bptt_step_cu_kernel");
+    }
     const int cfg = row_tiles >= 64 && H % 32 == 0 ? 22 : 11;
 #define FSN_BPTT_CASE(R, C)                                                                                        \
     hipLaunchKernelGGL((bptt_step_kernel<R, C>), dim3(H / 16 / C, (row_tiles + R - 1) / R), dim3(256), 0, s, dh_out, \
