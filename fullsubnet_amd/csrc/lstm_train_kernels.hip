@@ -61,6 +61,26 @@ __global__ __launch_bounds__(NW * 64) void bptt_step_kernel(const float* __restr
     const int lr = lane & 15, lq = lane >> 4;
     const int ug0 = blockIdx.x * CTS, rtile0 = blockIdx.y * RTS;
     const int G = 4 * H, KC = G >> 4;
+    static_assert(RTS * CTS <= NW, "one finished tile per wave at most");
+    // The wave that finishes tile (ert, ect) asks for everything the element-wise part reads - saved gates, dh, c_t,
+    // dc, c_{t-1}: 8 cold values per element - before the K loop instead of after the barrier.
+    const int ert = wave / CTS, ect = wave % CTS;
+    const bool fin = wave < RTS * CTS && rtile0 + ert < row_tiles;
+    float e_gate[4][4], e_dh[4], e_ct[4], e_dc[4], e_cp[4];
+    if (fin) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long row = (long)(rtile0 + ert) * 16 + 4 * lq + i;
+            const int u = (ug0 + ect) * 16 + lr;
+            const float* gp = gates + row * G + u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) e_gate[i][g] = gp[(long)g * H];
+            e_dh[i] = dh_out[row * H + u];
+            e_ct[i] = c_t[row * H + u];
+            e_dc[i] = last ? 0.f : dc[row * H + u];
+            e_cp[i] = first ? 0.f : c_prev[row * H + u];
+        }
+    }
     if (!last) {
         f32x4 acc[RTS][CTS];
 #pragma unroll
@@ -98,10 +118,9 @@ __global__ __launch_bounds__(NW * 64) void bptt_step_kernel(const float* __restr
             for (int ct = 0; ct < CTS; ++ct) red[wave][rt][ct][lane] = acc[rt][ct];
         __syncthreads();
     }
-    for (int tt = wave; tt < RTS * CTS; tt += NW) {
-        const int rt = tt / CTS, ct = tt % CTS;
+    if (fin) {
+        const int rt = ert, ct = ect;
         const int rtile = rtile0 + rt;
-        if (rtile >= row_tiles) continue;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (!last) {
             v = red[0][rt][ct][lane];
@@ -116,13 +135,12 @@ __global__ __launch_bounds__(NW * 64) void bptt_step_kernel(const float* __restr
             const long row = (long)rtile * 16 + 4 * lq + i;
             const int u = (ug0 + ct) * 16 + lr;
             const long idx = row * H + u;
-            const float* gp = gates + row * G + u;
-            const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
-            const float dh = dh_out[idx] + v[i];
-            const float tc = tanhf(c_t[idx]);
+            const float ig = e_gate[i][0], fg = e_gate[i][1], gg = e_gate[i][2], og = e_gate[i][3];
+            const float dh = e_dh[i] + v[i];
+            const float tc = tanhf(e_ct[i]);
             const float d_o = dh * tc;
-            const float dct = (last ? 0.f : dc[idx]) + dh * og * (1.f - tc * tc);
-            const float cp = first ? 0.f : c_prev[idx];
+            const float dct = e_dc[i] + dh * og * (1.f - tc * tc);
+            const float cp = e_cp[i];
             float* dg = dgates + row * G + u;
             dg[0] = dct * gg * ig * (1.f - ig);
             dg[H] = dct * cp * fg * (1.f - fg);
