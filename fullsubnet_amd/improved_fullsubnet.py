@@ -123,38 +123,88 @@ class SubbandModel(BaseModel):
         out = input[:, 0][:, idx, :]  # [B, N, c + 2n, T]
         return out.unsqueeze(2).contiguous()
 
-    def forward(self, noisy_input, fb_output):
-        batch_size, num_channels, num_freqs, num_frames = noisy_input.size()
-        assert num_channels == 1, "Only mono audio is supported."
-        last = len(self.sb_models) - 1
+    def _band(self, sb_idx, num_freqs):
+        lower = 0 if sb_idx == 0 else self.freq_cutoffs[sb_idx - 1]
+        upper = num_freqs if sb_idx == len(self.sb_models) - 1 else self.freq_cutoffs[sb_idx]
+        return lower, upper
 
-        def section(sb_idx):
-            lower = 0 if sb_idx == 0 else self.freq_cutoffs[sb_idx - 1]
-            upper = num_freqs if sb_idx == last else self.freq_cutoffs[sb_idx]
-            noisy_subband = self._freq_unfold(noisy_input, lower, upper, self.sb_num_center_freqs[sb_idx],
-                                              self.sb_num_neighbor_freqs[sb_idx])
-            fb_subband = self._freq_unfold(fb_output, lower, upper, self.fb_num_center_freqs[sb_idx],
-                                           self.fb_num_neighbor_freqs[sb_idx])
-            sb_model_input = self.norm(torch.cat([noisy_subband, fb_subband], dim=-2))
-            return self.sb_models[sb_idx](sb_model_input)
+    def num_units(self, num_freqs):
+        """Sub-band units of every section for a ``num_freqs``-bin input (model.py:315-400)."""
+        return [(hi - lo) // c for (lo, hi), c in
+                zip((self._band(i, num_freqs) for i in range(len(self.sb_models))), self.sb_num_center_freqs)]
 
+    def _section(self, noisy_input, fb_output, sb_idx, units=None):
+        """One section (model.py:402-449).  ``units = (lo, hi)`` restricts the sequence model to that range of the
+        section's units; the norm statistics are always taken over the whole section, as in the reference."""
+        lower, upper = self._band(sb_idx, noisy_input.size(2))
+        noisy_subband = self._freq_unfold(noisy_input, lower, upper, self.sb_num_center_freqs[sb_idx],
+                                          self.sb_num_neighbor_freqs[sb_idx])
+        fb_subband = self._freq_unfold(fb_output, lower, upper, self.fb_num_center_freqs[sb_idx],
+                                       self.fb_num_neighbor_freqs[sb_idx])
+        sb_model_input = self.norm(torch.cat([noisy_subband, fb_subband], dim=-2))
+        if units is not None:
+            lo, hi = units
+            if hi <= lo:  # more ranks than units: nothing of this section here
+                return sb_model_input.new_zeros((sb_model_input.size(0), 2, 0, sb_model_input.size(-1)))
+            sb_model_input = sb_model_input[:, lo:hi].contiguous()
+        return self.sb_models[sb_idx](sb_model_input)
+
+    def _run_sections(self, noisy_input, fb_output, units):
+        """All sections, ``units[i]`` = None or the unit range of section i -> list of [B, 2, n_i c_i, T]."""
+        num = len(self.sb_models)
         if torch.is_grad_enabled() or not noisy_input.is_cuda:
-            return torch.cat([section(i) for i in range(last + 1)], dim=-2)
+            return [self._section(noisy_input, fb_output, i, units[i]) for i in range(num)]
         # inference: the sections are independent and each one is a chain of small dependent launches
         # (B x units rows only), so they run concurrently on one HIP stream each and join on the caller's
         main = torch.cuda.current_stream(noisy_input.device)
-        if getattr(self, "_streams", None) is None or len(self._streams) != last + 1:
-            self._streams = [torch.cuda.Stream(noisy_input.device) for _ in range(last + 1)]
+        if getattr(self, "_streams", None) is None or len(self._streams) != num:
+            self._streams = [torch.cuda.Stream(noisy_input.device) for _ in range(num)]
         subband_output = []
         for sb_idx, st in enumerate(self._streams):
             st.wait_stream(main)
             with torch.cuda.stream(st):
-                out = section(sb_idx)
+                out = self._section(noisy_input, fb_output, sb_idx, units[sb_idx])
             out.record_stream(main)
             subband_output.append(out)
         for st in self._streams:
             main.wait_stream(st)
-        return torch.cat(subband_output, dim=-2)
+        return subband_output
+
+    def forward_units(self, noisy_input, fb_output, rank, world):
+        """Frequency-axis shard (BASELINE config 5): rank ``rank`` of ``world`` runs only its contiguous share of
+        every section's units.  Returns one unit-major tensor ``[n_local_i, B, 2, c_i, T]`` per section (the
+        layout ``parallel.gather_ragged`` re-assembles along the unit axis)."""
+        from .parallel import shard_bounds
+        B, _, num_freqs, T = noisy_input.shape
+        units = [shard_bounds(n, rank, world) for n in self.num_units(num_freqs)]
+        outs = self._run_sections(noisy_input, fb_output, units)
+        return [o.reshape(B, 2, hi - lo, c, T).permute(2, 0, 1, 3, 4).contiguous()
+                for o, (lo, hi), c in zip(outs, units, self.sb_num_center_freqs)]
+
+    @staticmethod
+    def assemble_units(full):
+        """Unit-major section outputs ``[n_i, B, 2, c_i, T]`` (all units) -> the mask ``[B, 2, F - 1, T]``."""
+        parts = []
+        for o in full:
+            n, B, _, c, T = o.shape
+            parts.append(o.permute(1, 2, 0, 3, 4).reshape(B, 2, n * c, T))
+        return torch.cat(parts, dim=-2)
+
+    def forward(self, noisy_input, fb_output, unit_group=None):
+        """model.py:402-449.  With ``unit_group`` (a torch.distributed process group, or True for the default one)
+        the sub-band units are sharded across that group's ranks - every rank holds the whole ``noisy_input`` /
+        ``fb_output``, runs its share of the units and one all-gather re-assembles the mask on every rank."""
+        batch_size, num_channels, num_freqs, num_frames = noisy_input.size()
+        assert num_channels == 1, "Only mono audio is supported."
+        if unit_group is not None and unit_group is not False:
+            import torch.distributed as dist
+            from .parallel import gather_ragged
+            group = None if unit_group is True else unit_group
+            world = dist.get_world_size(group)
+            if world > 1:
+                local = self.forward_units(noisy_input, fb_output, dist.get_rank(group), world)
+                return self.assemble_units(gather_ragged(local, self.num_units(num_freqs), group=group))
+        return torch.cat(self._run_sections(noisy_input, fb_output, [None] * len(self.sb_models)), dim=-2)
 
 
 class Model(BaseModel):
@@ -178,8 +228,10 @@ class Model(BaseModel):
                                      sequence_model=sequence_model, activate_function=sb_output_activate_function)
         self.norm = self.norm_wrapper(norm_type)
 
-    def forward(self, y):
-        """model.py:541-591: y [B, L] or [B, 1, L] -> enhanced [B, 1, L]."""
+    def forward(self, y, unit_group=None):
+        """model.py:541-591: y [B, L] or [B, 1, L] -> enhanced [B, 1, L].  ``unit_group``: shard the sub-band units
+        over that process group (every rank gets the same ``y`` and returns the same result; for fewer utterances
+        than GPUs - otherwise shard the utterances, ``parallel.enhance_sharded``)."""
         ndim = y.dim()
         assert ndim in (2, 3), "Input must be 2D (B, T) or 3D tensor (B, 1, T)"
         if ndim == 3:
@@ -190,7 +242,7 @@ class Model(BaseModel):
         noisy_mag = noisy_mag[..., :-1, :]  # the last bin is left out (model.py:566) and masked with 0 below
         B, _, Fm, T = noisy_mag.shape
         fb_output = self.fb_model(self.norm(noisy_mag).reshape(B, Fm, T)).reshape(B, 1, Fm, T)
-        cRM = self.sb_model(noisy_mag, fb_output)  # [B, 2, F - 1, T]
+        cRM = self.sb_model(noisy_mag, fb_output, unit_group=unit_group)  # [B, 2, F - 1, T]
         cRM = functional.pad(cRM, (0, 0, 0, 1), mode="constant", value=0.0)
         # model.py:576-577: the mask multiplies real and imaginary parts separately (no complex product)
         enhanced = istft((cRM[:, 0] * real, cRM[:, 1] * imag), self.n_fft, self.hop_length, self.win_length,

@@ -42,3 +42,48 @@ def enhance_sharded(enhance_fn, noisy_full, group=None):
     lo, hi = shard_bounds(noisy_full.shape[0], rank, world)
     local = enhance_fn(noisy_full[lo:hi]) if hi > lo else noisy_full[:0]
     return gather_shards(local, noisy_full.shape[0], group=group)
+
+
+def pack_ragged(parts, n_flat):
+    """Flatten a list of tensors into one zero-padded 1-D buffer of ``n_flat`` elements."""
+    ref = parts[0]
+    buf = torch.zeros(n_flat, dtype=ref.dtype, device=ref.device)
+    o = 0
+    for p in parts:
+        buf[o:o + p.numel()].copy_(p.reshape(-1))
+        o += p.numel()
+    return buf
+
+
+def gather_ragged(parts, n_items, group=None):
+    """Several differently shaped tensors, each sharded along its leading axis, re-assembled with ONE collective.
+
+    ``parts[i]`` is this rank's shard ``[n_local_i, *trailing_i]`` of a tensor with ``n_items[i]`` leading entries
+    (contiguous split of ``shard_bounds(n_items[i], rank, world)``; a rank may own nothing of a short axis).  Every
+    rank packs its shards into one flat buffer padded to the largest rank's size, a single all_gather_into_tensor
+    moves everything (few large collectives suit the point-to-point xGMI links better than one per tensor), and the
+    full tensors ``[n_items[i], *trailing_i]`` are cut out of the result on every rank."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return list(parts)
+    trailing = [tuple(p.shape[1:]) for p in parts]
+    row = [int(torch.Size(t).numel()) for t in trailing]
+
+    def flat_size(r):
+        return sum((shard_bounds(n, r, world)[1] - shard_bounds(n, r, world)[0]) * w for n, w in zip(n_items, row))
+
+    n_flat = max(flat_size(r) for r in range(world))
+    send = pack_ragged(parts, n_flat)
+    out = torch.empty(world * n_flat, dtype=send.dtype, device=send.device)
+    dist.all_gather_into_tensor(out, send, group=group)
+    out = out.view(world, n_flat)
+    full = []
+    offsets = [0] * world
+    for n, w, t in zip(n_items, row, trailing):
+        pieces = []
+        for r in range(world):
+            lo, hi = shard_bounds(n, r, world)
+            pieces.append(out[r, offsets[r]:offsets[r] + (hi - lo) * w].view((hi - lo,) + t))
+            offsets[r] += (hi - lo) * w
+        full.append(torch.cat(pieces, dim=0))
+    return full

@@ -173,6 +173,38 @@ def test_improved_fullsubnet_vs_reference(fsn, golden_dir, name, cfg):
     assert np.abs(enh - z["enhanced"]).max() <= 1e-4 * np.abs(z["enhanced"]).max()
 
 
+@pytest.mark.parametrize("world", [3, 8])
+@pytest.mark.parametrize("name,cfg", [("improved_16k_b2", MF.IMPROVED_16K), ("improved_48k_b2", MF.IMPROVED_48K)])
+def test_improved_fullsubnet_unit_shard_vs_reference(fsn, golden_dir, name, cfg, world):
+    """The frequency-axis shard of BASELINE config 5 (SubbandModel.forward_units: every rank runs its share of each
+    section's units, at 8 ranks some sections leave ranks without any) with the ranks played one after the other on
+    this GPU and the all-gather replaced by a concatenation in rank order - what parallel.gather_ragged produces
+    (tests/test_parallel_cpu.py holds the collective itself to that).  Same tolerance as the unsharded model."""
+    from oracle import fullsubnet_oracle as O
+    from fullsubnet_amd.improved_fullsubnet import Model
+    z, meta = load(golden_dir, name)
+    params = MF.make_improved_params(cfg, seed=meta["seed_w"])
+    m = Model(**cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.cuda().eval()
+    sb = m.sb_model
+    seen = []
+
+    def ranks_in_turn(noisy_mag, fb_output, unit_group=None):
+        per_rank = [sb.forward_units(noisy_mag, fb_output, r, world) for r in range(world)]
+        seen.append([[int(t.shape[0]) for t in parts] for parts in per_rank])
+        return sb.assemble_units([torch.cat(sec, dim=0) for sec in zip(*per_rank)])
+
+    sb.forward = ranks_in_turn
+    noisy = O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_x"])
+    with torch.no_grad():
+        enh = m(torch.from_numpy(noisy).cuda().unsqueeze(1)).cpu().numpy()
+    units = sb.num_units(cfg["num_freqs"] - 1)
+    assert [sum(col) for col in zip(*seen[0])] == units
+    assert enh.shape == z["enhanced"].shape
+    assert np.abs(enh - z["enhanced"]).max() <= 1e-4 * np.abs(z["enhanced"]).max()
+
+
 @pytest.mark.parametrize("name", ["var_gru_b2", "var_gaussian_b2", "var_cln_b2", "var_forgetting_b2",
                                   "var_fbnn2_tanh_b3"])
 def test_fullsubnet_constructor_variants_vs_reference(fsn, golden_dir, name):

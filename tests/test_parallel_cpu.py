@@ -45,3 +45,75 @@ def _worker(rank, world, port, n_items):
 @pytest.mark.parametrize("world,n_items", [(2, 64), (2, 5), (3, 7)])
 def test_sharded_enhance_reassembles_the_batch(world, n_items):
     mp.spawn(_worker, args=(world, _free_port(), n_items), nprocs=world, join=True)
+
+
+# ---- frequency-axis (sub-band unit) shard of Improved FullSubNet (BASELINE config 5) -------------------------------
+
+def _fake_section_model(c):
+    """Stands in for SubBandSequenceWrapper (which only runs on the GPU library): per-unit independent, like the
+    real one - [B, N, 1, F_sub, T] -> [B, 2, N c, T]."""
+    def run(x):
+        B, N, _, Fs, T = x.shape
+        a = x[:, :, 0, :c, :] * 2.0 + x[:, :, 0, Fs - c:, :]          # [B, N, c, T]
+        b = x[:, :, 0, :c, :].cumsum(-1) - x[:, :, 0, 1:c + 1, :]
+        return torch.stack([a, b], dim=1).reshape(B, 2, N * c, T)     # [B, 2, N, c, T] -> [B, 2, N c, T]
+    return run
+
+
+def _subband_model(num_freqs, cutoffs, centres, norm):
+    from fullsubnet_amd.improved_fullsubnet import SubbandModel
+    m = SubbandModel(freq_cutoffs=cutoffs, sb_num_center_freqs=centres, sb_num_neighbor_freqs=[15] * len(centres),
+                     fb_num_center_freqs=centres, fb_num_neighbor_freqs=[15] * len(centres), sequence_model="LSTM",
+                     hidden_size=64, norm_type=norm)
+    del m.sb_models  # replaced by CPU stand-ins (the real ones only run on the HIP library)
+    m.sb_models = [_fake_section_model(c) for c in centres]
+    return m
+
+
+_UNIT_CASES = [
+    (256, [20, 80], [1, 4, 8], "offline_laplace_norm"),                 # 16 kHz default: 20 + 15 + 22 units
+    (480, [32, 128, 192], [1, 4, 8, 16], "offline_laplace_norm"),       # a four-section layout, uneven over 3 ranks
+    (64, [32], [1, 16], "offline_gaussian_norm"),                       # 2 units in the last section: ranks with none
+]
+
+
+def _unit_worker(rank, world, port, case):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        num_freqs, cutoffs, centres, norm = case
+        g = torch.Generator().manual_seed(5)
+        noisy = torch.rand(2, 1, num_freqs, 7, generator=g) + 0.1
+        fb = torch.rand(2, 1, num_freqs, 7, generator=g) + 0.1
+        m = _subband_model(num_freqs, cutoffs, centres, norm)
+        with torch.no_grad():
+            whole = m(noisy, fb)
+            sharded = m(noisy, fb, unit_group=True)
+        assert whole.shape == (2, 2, num_freqs, 7)
+        assert torch.equal(whole, sharded), f"rank {rank}"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", _UNIT_CASES, ids=["16k", "four_sections", "fewer_units_than_ranks"])
+def test_unit_sharded_subband_model_equals_the_unsharded_one(world, case):
+    mp.spawn(_unit_worker, args=(world, _free_port(), case), nprocs=world, join=True)
+
+
+def test_gather_ragged_single_process_layout():
+    """The packing used by the unit shard, without a process group: emulate every rank's buffer by hand."""
+    from fullsubnet_amd.parallel import pack_ragged
+    n_items, world = [5, 2, 7], 3
+    full = [torch.arange(n * 6, dtype=torch.float32).reshape(n, 2, 3) + 100 * i for i, n in enumerate(n_items)]
+    bufs = []
+    for r in range(world):
+        parts = [f[slice(*shard_bounds(n, r, world))] for f, n in zip(full, n_items)]
+        bufs.append(pack_ragged(parts, 64))
+        assert bufs[-1].numel() == 64
+        assert bufs[-1][sum(p.numel() for p in parts):].abs().sum() == 0
+    # rank 2 owns nothing of the 2-entry tensor, so its second tensor's data follows the first directly
+    lo, hi = shard_bounds(5, 2, world)
+    assert torch.equal(bufs[2][: (hi - lo) * 6].view(hi - lo, 2, 3), full[0][lo:hi])
+    assert shard_bounds(2, 2, world) == (2, 2)
