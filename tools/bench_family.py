@@ -1,5 +1,7 @@
 """Time the sibling model families on one MI355X (BASELINE configs 1 and 4):
-python tools/bench_family.py [fast|fullband] [batch]"""
+python tools/bench_family.py [fast|fullband|improved16|improved48] [batch] [units=r/w]
+units=r/w (improved* only): time what rank r of w computes under the frequency-axis shard (its share of every
+section's units; the all-gather is not part of this single-GPU measurement)."""
 import os
 import sys
 import time
@@ -46,6 +48,23 @@ else:
     mmac = 6.032384e6
 model.load_state_dict(sd, strict=True)
 model = model.cuda().eval()
+shard = [a for a in sys.argv[3:] if a.startswith("units=")]
+if shard:
+    r, w = (int(v) for v in shard[0][6:].split("/"))
+    sb = model.sb_model
+
+    def one_rank(noisy_mag, fb_output, unit_group=None):
+        local = sb.forward_units(noisy_mag, fb_output, r, w)
+        # stand-in for the gathered result (timing only): this rank's units repeated to the full count
+        full = [t.repeat((n + max(t.shape[0], 1) - 1) // max(t.shape[0], 1), 1, 1, 1, 1)[:n] if t.shape[0]
+                else t.new_zeros((n,) + tuple(t.shape[1:]))
+                for t, n in zip(local, sb.num_units(noisy_mag.size(2)))]
+        return sb.assemble_units(full)
+
+    sb.forward = one_rank
+    which_label = f" units {r}/{w}"
+else:
+    which_label = ""
 noisy = torch.from_numpy(make_noisy(min(B, 8), L, seed=1)).cuda().repeat((B + 7) // 8, 1)[:B].contiguous()
 
 
@@ -72,5 +91,5 @@ dt = (time.perf_counter() - t0) / K
 T = 1 + L // hop
 la = 0 if which.startswith("improved") else 2
 sr = 48000 if which == "improved48" else 16000
-print(f"{which} B={B}: {dt * 1e3:.2f} ms / batch, {B * T / dt:.0f} frames/s ({B * L / sr / dt:.0f} x real time), "
+print(f"{which}{which_label} B={B}: {dt * 1e3:.2f} ms / batch, {B * T / dt:.0f} frames/s ({B * L / sr / dt:.0f} x real time), "
       f"~{2 * mmac * B * (T + la) / dt / 1e12:.1f} TFLOP/s, finite={bool(torch.isfinite(out).all())}")
