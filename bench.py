@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-experimental", action="store_true", help="skip the opt-in split-precision side measurement")
+    ap.add_argument("--host-io", action="store_true",
+                    help="side measurement for DESIGN.md: every step also copies its input from pinned host memory and "
+                         "its result back (the PCIe-inclusive rate; never the headline `value`, which is HBM-resident)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -171,8 +174,16 @@ def main():
     gathered = torch.empty((world * b_max, length), dtype=torch.float32, device=device) if world > 1 else None
     send = torch.zeros((b_max, length), dtype=torch.float32, device=device) if world > 1 else None
 
+    if args.host_io:
+        host_in = torch.from_numpy(noisy_np).pin_memory()
+        host_out = torch.empty_like(host_in).pin_memory()
+
     def step():
+        if args.host_io:
+            noisy.copy_(host_in, non_blocking=True)
         enh = model.enhance(noisy, n_fft=N_FFT, hop_length=HOP)
+        if args.host_io:
+            host_out.copy_(enh, non_blocking=True)
         if world > 1:
             send[:b_loc].copy_(enh)
             dist.all_gather_into_tensor(gathered, send)  # RCCL over xGMI: re-assemble the node batch
@@ -219,7 +230,8 @@ def main():
             "metric": "frames/sec (16 kHz, 512-FFT, hop 256), whole job", "value": round(value, 1),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" + (" (host buffers in and out over PCIe every step: --host-io)" if args.host_io else ""),
             "config": {"workload": f"FullSubNet inference (full_band_crm_mask path), 16 kHz, n_fft 512, hop 256, "
                                    f"n_neighbour 15, look_ahead 2, batch {b_loc} x {args.seconds:g} s per GPU "
                                    f"({b_total} utterances per step in total), offline_laplace_norm, full 257-bin "
