@@ -77,6 +77,9 @@ SIGNATURES = {
     "fsn_fullsubnet_workspace_bytes": (_c.c_size_t, [_c.POINTER(Cfg), _c.c_int, _c.c_int]),
     "fsn_fullsubnet_forward": (_c.c_int, [_c.POINTER(Cfg), _c.c_void_p, _f32p, _c.c_int, _c.c_int, _f32p, _c.c_void_p,
                                           _c.c_size_t, _c.c_void_p]),
+    "fsn_fullsubnet_rows_workspace_bytes": (_c.c_size_t, [_c.POINTER(Cfg), _c.c_int, _c.c_int, _c.c_long, _c.c_long]),
+    "fsn_fullsubnet_forward_rows": (_c.c_int, [_c.POINTER(Cfg), _c.c_void_p, _f32p, _c.c_int, _c.c_int, _c.c_long,
+                                               _c.c_long, _f32p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "fsn_enhance_workspace_bytes": (_c.c_size_t, [_c.POINTER(Cfg), _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "fsn_enhance": (_c.c_int, [_c.POINTER(Cfg), _c.c_void_p, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                _f32p, _f32p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),

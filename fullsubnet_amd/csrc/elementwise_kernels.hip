@@ -169,6 +169,34 @@ __global__ __launch_bounds__(256) void cumulative_den_sb_kernel(const float* __r
     if (carry) carry[n] = run;
 }
 
+// Rows [r0, r0 + n) of the flattened (b, f) index space out of the frame-major mask planes [B][T][FP] into
+// [row][2][T] (fullsubnet/model.py:129-135 restricted to a row range): 16 rows x 64 frames per workgroup through
+// LDS, so that both the plane reads (along f) and the row writes (along t) are contiguous runs.
+__global__ __launch_bounds__(256) void crm_rows_kernel(const float* __restrict__ crm_r, const float* __restrict__ crm_i,
+                                                       float* __restrict__ out, long r0, long n, int F, int FP, int T) {
+    __shared__ float tile[2][64][17];
+    const long row0 = (long)blockIdx.x * 16;
+    const int t0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 2 * 64 * 16; i += 256) {
+        const int r = i & 15, t = (i >> 4) & 63, c = i >> 10;
+        const long row = row0 + r;
+        float v = 0.f;
+        if (row < n && t0 + t < T) {
+            const long ng = r0 + row;
+            const long b = ng / F;
+            const int f = (int)(ng % F);
+            v = (c ? crm_i : crm_r)[(b * T + t0 + t) * FP + f];
+        }
+        tile[c][t][r] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * 64 * 16; i += 256) {
+        const int t = i & 63, c = (i >> 6) & 1, r = i >> 7;
+        const long row = row0 + r;
+        if (row < n && t0 + t < T) out[(row * 2 + c) * T + t0 + t] = tile[c][t][r];
+    }
+}
+
 }  // namespace
 
 static unsigned ew_grid(size_t n) {
@@ -195,6 +223,12 @@ int fsn_launch_transpose(const float* in, float* out, int batch, int R, int C, l
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, out, R, C, ld_in, bs_in, ld_out, bs_out, R_valid,
                        C_valid);
     return fsn_check_launch("transpose_kernel");
+}
+int fsn_launch_crm_rows(const float* crm_r, const float* crm_i, float* out, long r0, long n, int F, int FP, int T,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(crm_rows_kernel, dim3((unsigned)((n + 15) / 16), (unsigned)((T + 63) / 64)), dim3(256), 0, s, crm_r,
+                       crm_i, out, r0, n, F, FP, T);
+    return fsn_check_launch("crm_rows_kernel");
 }
 int fsn_launch_binsum(const float* mag, double* binsum, int B, int Tp, int FP, hipStream_t s) {
     hipLaunchKernelGGL(binsum_kernel, dim3((FP + 255) / 256, B), dim3(256), 0, s, mag, binsum, Tp, FP);

@@ -246,8 +246,12 @@ struct CoreDims {
     int N, Npad;       // sub-band rows per step, padded rows (row stride of the [t][n] buffers)
     FsnRecPlan rec;    // how those rows are spread over the CUs
     bool fc_fused;     // output layer fused into the layer-1 persistent kernel (its hseq is never stored)
+    long row0;         // row-range calls: the N sub-band rows are rows row0 .. row0 + N - 1 of the B F rows
+    int den_stride;    // row stride of the per-row (cumulative) sub-band divisors: they are indexed by GLOBAL row
 };
-static CoreDims core_dims(const fsn_fullsubnet_cfg* c, int B, int T) {
+// n_rows < 0: all B F sub-band rows; otherwise the rows [row0, row0 + n_rows) of the flattened (b, f) index space
+// (the full-band model and the norm statistics always cover the B whole utterances).
+static CoreDims core_dims(const fsn_fullsubnet_cfg* c, int B, int T, long row0 = 0, long n_rows = -1) {
     CoreDims d;
     d.B = B;
     d.T = T;
@@ -259,9 +263,11 @@ static CoreDims core_dims(const fsn_fullsubnet_cfg* c, int B, int T) {
     d.Hs = c->sb_hidden;
     d.nb = c->sb_num_neighbors;
     d.Npad_fb = fsn_round_up(B, 16);
-    d.N = B * d.F;
+    d.N = n_rows < 0 ? B * d.F : (int)n_rows;
+    d.row0 = n_rows < 0 ? 0 : row0;
     d.rec = fsn_lstm_rec_plan(d.N, d.Hs);
     d.Npad = d.rec.npad;
+    d.den_stride = n_rows < 0 ? d.Npad : fsn_round_up(B * d.F, 16);
     d.fc_fused = d.rec.main_wgs > 0 && fsn_lstm_rec_can_fuse_fc(d.rec.rt, false);
     return d;
 }
@@ -280,7 +286,7 @@ static CoreWs core_carve(Carver& cv, const CoreDims& d, int norm_type) {
     w.binsum = cv.take<double>((size_t)d.B * d.FP);
     const bool cum = norm_type == FSN_NORM_CUMULATIVE_LAPLACE;
     w.den_fb = cv.take<float>(cum ? (size_t)d.B * d.Tp : (size_t)d.B);
-    w.den_sb = cv.take<float>(cum ? rows_sb : (size_t)d.B);
+    w.den_sb = cv.take<float>(cum ? (size_t)d.Tp * d.den_stride : (size_t)d.B);
     w.gx_sb = cv.take<float>(rows_sb * 4 * d.Hs);
     w.hseq_sb0 = cv.take<float>(rows_sb * d.Hs);
     // fused output layer: only the left-over rows of layer 1 are ever stored, [t][left rows][H]
@@ -444,7 +450,7 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
     {
         StageTimer st(ST_NORM, s);
         if (cum) {
-            FSN_TRY(fsn_launch_cumulative_den_sb(magT, w.fb_out, w.den_sb, d.B, d.Tp, d.F, d.FP, d.nb, d.Npad, s));
+            FSN_TRY(fsn_launch_cumulative_den_sb(magT, w.fb_out, w.den_sb, d.B, d.Tp, d.F, d.FP, d.nb, d.den_stride, s));
         } else {
             FSN_TRY(fsn_launch_offline_den(w.binsum, w.fb_out, nullptr, w.den_sb, d.B, d.Tp, d.F, d.FP, d.nb, 1, s));
         }
@@ -463,14 +469,14 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         a.p1 = w.fb_out;
         a.den = w.den_sb;
         a.den_mode = cum ? 1 : 0;
-        a.den_stride = d.Npad;
+        a.den_stride = d.den_stride;
         a.B = d.B;
         a.Tp = d.Tp;
         a.F = d.F;
         a.FP = d.FP;
         a.Npad = d.rec.left_tiles * 16;
-        a.n_offset = (int)main_rows;
-        a.N = d.N;
+        a.n_offset = (int)(d.row0 + main_rows);  // the provider works on global rows: first row and row limit
+        a.N = (int)(d.row0 + d.N);
         a.nb = d.nb;
         c.kind = 0;
         c.p0 = w.gx_sb;
@@ -495,7 +501,8 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         xin.wih_p = pk + p.sb_wih0;
         xin.bias = pk + p.sb_b0;
         xin.den_mode = cum ? 1 : 0;
-        xin.den_stride = d.Npad;
+        xin.den_stride = d.den_stride;
+        xin.row0 = d.row0;
         xin.B = d.B;
         xin.Tp = d.Tp;
         xin.F = d.F;
@@ -537,6 +544,7 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         fc.crm_r = crm_r;
         fc.crm_i = crm_i;
         fc.N = d.N;
+        fc.row0 = d.row0;
         fc.F = d.F;
         fc.FP = d.FP;
         fc.T = d.T;
@@ -564,12 +572,13 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         c.F = d.F;
         c.FP = d.FP;
         c.Npad = d.Npad;
-        c.N = d.N;
+        c.N = (int)(d.row0 + d.N);  // global rows, like the A provider above
+        c.n_off = (int)d.row0;
         c.la = d.la;
         int rows_t = sb_rt;
         if (fc_fused) {  // only the left-over rows: hseq_sb1 is the compact [t][left rows][H] matrix
             c.Npad = d.rec.left_tiles * 16;
-            c.n_off = (int)main_rows;
+            c.n_off = (int)(d.row0 + main_rows);
             rows_t = d.Tp * d.rec.left_tiles;
         }
         FSN_TRY(fsn_launch_gemm(a, pk + p.sb_fc, c, rows_t, 1, d.Hs / 16, s));
@@ -622,6 +631,70 @@ extern "C" int fsn_fullsubnet_forward(const fsn_fullsubnet_cfg* cfg, const void*
                                  T, d.F, s));
     return FSN_OK;
 }
+
+// ---- row-range form: the sub-band model on a contiguous slice of the flattened (b, f) rows -------------------
+// "rank r owns a contiguous slice of the flattened (b, f) index space".  Only the utterances the
+// slice touches are looked at: their full-band model and norm statistics are computed whole (they couple all
+// bins of an utterance), the sub-band model only on rows [row_begin, row_end).  A slice that is aligned to
+// utterances is exactly fsn_fullsubnet_forward on those utterances.
+struct RowSlice {
+    int b_lo, Bs;
+    long r0, n;
+};
+static int row_slice(const fsn_fullsubnet_cfg* cfg, int B, long row_begin, long row_end, RowSlice* out) {
+    const long F = cfg->num_freqs;
+    FSN_REQUIRE(row_begin >= 0 && row_begin < row_end && row_end <= (long)B * F,
+                "row range [%ld, %ld) is not inside the %ld sub-band rows of the batch", row_begin, row_end, (long)B * F);
+    out->b_lo = (int)(row_begin / F);
+    out->Bs = (int)((row_end - 1) / F) - out->b_lo + 1;
+    out->r0 = row_begin - (long)out->b_lo * F;
+    out->n = row_end - row_begin;
+    return FSN_OK;
+}
+
+extern "C" size_t fsn_fullsubnet_rows_workspace_bytes(const fsn_fullsubnet_cfg* cfg, int B, int T, long row_begin,
+                                                      long row_end) {
+    RowSlice r;
+    if (check_cfg(cfg) != FSN_OK || check_bt(B, T) != FSN_OK || row_slice(cfg, B, row_begin, row_end, &r) != FSN_OK)
+        return 0;
+    const CoreDims d = core_dims(cfg, r.Bs, T, r.r0, r.n);
+    Carver cv(nullptr);
+    cv.take<float>((size_t)r.Bs * d.Tp * d.FP);  // magT
+    cv.take<float>((size_t)r.Bs * d.T * d.FP);   // crm_r
+    cv.take<float>((size_t)r.Bs * d.T * d.FP);   // crm_i
+    core_carve(cv, d, cfg->norm_type);
+    return fsn_round_up_sz(cv.off, 256);
+}
+
+extern "C" int fsn_fullsubnet_forward_rows(const fsn_fullsubnet_cfg* cfg, const void* packed, const float* noisy_mag,
+                                           int B, int T, long row_begin, long row_end, float* crm_rows,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+    FSN_TRY(check_cfg(cfg));
+    FSN_TRY(check_bt(B, T));
+    RowSlice r;
+    FSN_TRY(row_slice(cfg, B, row_begin, row_end, &r));
+    FSN_REQUIRE(packed && noisy_mag && crm_rows && workspace, "NULL pointer argument");
+    const size_t need = fsn_fullsubnet_rows_workspace_bytes(cfg, B, T, row_begin, row_end);
+    if (workspace_bytes < need) {
+        fsn_set_error("workspace too small: %zu < %zu bytes", workspace_bytes, need);
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const CoreDims d = core_dims(cfg, r.Bs, T, r.r0, r.n);
+    Carver cv(workspace);
+    float* magT = cv.take<float>((size_t)r.Bs * d.Tp * d.FP);
+    float* crm_r = cv.take<float>((size_t)r.Bs * d.T * d.FP);
+    float* crm_i = cv.take<float>((size_t)r.Bs * d.T * d.FP);
+    const CoreWs w = core_carve(cv, d, cfg->norm_type);
+    prof_reset();
+    const float* mag_lo = noisy_mag + (size_t)r.b_lo * d.F * T;  // [B, 1, F, T]: utterances are contiguous
+    FSN_TRY(fsn_launch_transpose(mag_lo, magT, r.Bs, d.FP, d.Tp, T, (long)d.F * T, d.FP, (long)d.Tp * d.FP, d.F, T, s));
+    FSN_TRY(run_core(cfg, static_cast<const float*>(packed), magT, d, w, crm_r, crm_i, s));
+    // this slice's rows of the frame-major planes -> [row][2][T] (what the ranks all-gather)
+    FSN_TRY(fsn_launch_crm_rows(crm_r, crm_i, crm_rows, r.r0, r.n, d.F, d.FP, T, s));
+    return FSN_OK;
+}
+
 
 // ---- streaming: k more frames of the model with carried state -------------------------------------
 // State (caller-owned, zero-filled for a new stream): (h, c) of the four LSTM layers and the running sums

@@ -101,6 +101,8 @@ int fsn_launch_build_cirm(const float* nr, const float* ni, const float* cr, con
                           size_t n, hipStream_t s);
 int fsn_launch_transpose(const float* in, float* out, int batch, int R, int C, long ld_in, long bs_in,
                          long ld_out, long bs_out, int R_valid, int C_valid, hipStream_t s);
+int fsn_launch_crm_rows(const float* crm_r, const float* crm_i, float* out, long r0, long n, int F, int FP, int T,
+                        hipStream_t s);
 int fsn_launch_binsum(const float* mag, double* binsum, int B, int Tp, int FP, hipStream_t s);
 int fsn_launch_offline_den(const double* binsum, const float* fb_out, float* den_fb, float* den_sb, int B,
                            int Tp, int F, int FP, int nb, int which, hipStream_t s);
@@ -176,6 +178,9 @@ struct FsnSbInput {
     // x_rows[(t * x_step + n) * x_ld + c] with zero padding up to 16 kin_chunks columns; N = valid rows
     const float* x_rows;
     long x_ld, x_step;
+    // row-range calls (fsn_fullsubnet_forward_rows): local row n of this launch is row n + row0 of the flattened
+    // (b, f) index space; N stays the number of valid LOCAL rows.  0 everywhere else.
+    long row0;
 };
 
 #ifdef __HIPCC__
@@ -185,6 +190,7 @@ struct FsnSbInput {
 __device__ __forceinline__ float fsn_sb_input_value(const FsnSbInput& x, long n, int c, int t) {
     if (x.x_rows) return n < x.N ? x.x_rows[((long)t * x.x_step + n) * x.x_ld + c] : 0.f;
     if (n >= x.N || c > 2 * x.nb + 1) return 0.f;
+    n += x.row0;
     const int b = (int)(n / x.F), f = (int)(n % x.F);
     const long fo = ((long)b * x.Tp + t) * x.FP;
     int j = f + c - x.nb;
@@ -204,6 +210,7 @@ struct FsnRecFc {
     float* crm_r;
     float* crm_i;       // [B][T][FP]
     int N, F, FP, T, la;
+    long row0;          // first row of a row-range call in the flattened (b, f) space (N = valid local rows)
 };
 
 struct FsnRecPlan {

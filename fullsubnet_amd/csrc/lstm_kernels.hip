@@ -193,7 +193,8 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const fl
                 v += __shfl_xor(v, 2, 64);
                 const long n = n0 + row;
                 if (part == 0 && t >= fc.la && n < fc.N) {
-                    const int b = (int)(n / fc.F), f = (int)(n % fc.F);
+                    const long ng = n + fc.row0;
+                    const int b = (int)(ng / fc.F), f = (int)(ng % fc.F);
                     (c ? fc.crm_i : fc.crm_r)[((long)b * fc.T + (t - fc.la)) * fc.FP + f] = v + fc.bias[c];
                 }
             }

@@ -111,6 +111,53 @@ class Model(nn.Module):
             out = drop_band(out, num_groups=self.num_groups_in_drop_band)
         return out
 
+    @torch.no_grad()
+    def forward_rows(self, noisy_mag, row_begin, row_end):
+        """The sub-band model on the rows [row_begin, row_end) of the B*F flattened (b, f) sequences that
+        fullsubnet/model.py:121-128 feeds the sub-band LSTM - the multi-GPU partition of the path.
+        noisy_mag [B, 1, F, T] is the whole batch (only the utterances the slice touches are read; their full-band
+        model and norm statistics are computed whole).  Returns [row_end - row_begin, 2, T]: row n = b F + f of the
+        compressed cIRM, i.e. ``forward(noisy_mag)[b, :, f, :]`` without the band dropping of quirk Q1.  Inference,
+        fused configurations only."""
+        assert noisy_mag.dim() == 4
+        batch_size, num_channels, num_freqs, num_frames = noisy_mag.size()
+        assert num_channels == 1 and num_freqs == self.num_freqs
+        if not self._fused:
+            raise _lib.FsnError("forward_rows is built for the fused configurations (shipped TOMLs); shard composed "
+                                "configurations by utterance (parallel.enhance_sharded)")
+        if not 0 <= row_begin < row_end <= batch_size * num_freqs:
+            raise _lib.FsnError(f"row range [{row_begin}, {row_end}) is not inside the {batch_size * num_freqs} "
+                                f"sub-band rows of the batch")
+        x = noisy_mag.contiguous()
+        L = _lib.lib()
+        out = torch.empty((row_end - row_begin, 2, num_frames), dtype=torch.float32, device=x.device)
+        ws = _lib.workspace(L.fsn_fullsubnet_rows_workspace_bytes(ctypes.byref(self._cfg), batch_size, num_frames,
+                                                                  row_begin, row_end), x.device)
+        _lib.check(L.fsn_fullsubnet_forward_rows(ctypes.byref(self._cfg), self.packed_weights().data_ptr(),
+                                                 _lib.dev_ptr(x, "noisy_mag"), batch_size, num_frames, row_begin,
+                                                 row_end, _lib.dev_ptr(out), ws.data_ptr(), ws.numel(),
+                                                 _lib.stream_ptr(x.device)))
+        return out
+
+    @torch.no_grad()
+    def forward_row_sharded(self, noisy_mag, group=None):
+        """``forward`` with the batch x frequency rows sharded over a torch.distributed group: every rank holds the
+        whole ``noisy_mag``, runs ``forward_rows`` on its contiguous share of the B*F rows and ONE all-gather
+        (RCCL over xGMI with backend "nccl") re-assembles the full-band mask [B, 2, F, T] on every rank.  Full masks
+        for every sample (no band dropping)."""
+        import torch.distributed as dist
+        from .parallel import gather_shards, shard_bounds
+        B, _, F, T = noisy_mag.shape
+        world = dist.get_world_size(group)
+        if world == 1:
+            rows = self.forward_rows(noisy_mag, 0, B * F)
+        else:
+            lo, hi = shard_bounds(B * F, dist.get_rank(group), world)
+            local = (self.forward_rows(noisy_mag, lo, hi) if hi > lo
+                     else noisy_mag.new_empty((0, 2, T)))
+            rows = gather_shards(local, B * F, group=group)
+        return rows.view(B, F, 2, T).permute(0, 2, 1, 3).contiguous()
+
     def _forward_composed(self, noisy_mag):
         """fullsubnet/model.py:72-136 operation by operation, for the configurations the fused kernels
         are not specialised for: the two SequenceModel blocks run on the HIP LSTM / GRU / GEMM kernels

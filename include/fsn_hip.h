@@ -98,6 +98,19 @@ int fsn_fullsubnet_forward(const fsn_fullsubnet_cfg* cfg, const void* packed, co
                            int B, int T, float* crm_out, void* workspace, size_t workspace_bytes,
                            void* stream);
 
+/* The same model on a contiguous slice [row_begin, row_end) of the B*F flattened (b, f) rows that
+ * model.py:121-128 hands to the sub-band LSTM as independent sequences - the multi-GPU partition of the path
+ * (one rank per slice, then one all-gather of the slices).  noisy_mag is the WHOLE batch [B,1,F,T]; only the
+ * utterances the slice touches are read: their full-band model (model.py:95) and norm statistics (model.py:92,111)
+ * are computed whole, the sub-band model only on the slice.  crm_rows [row_end - row_begin][2][T] receives
+ * the compressed cIRM of row n = b*F + f at crm_rows[n - row_begin] (= crm[b, :, f, :] of the full result).
+ * A slice aligned to utterances does exactly the work of fsn_fullsubnet_forward on those utterances. */
+size_t fsn_fullsubnet_rows_workspace_bytes(const fsn_fullsubnet_cfg* cfg, int B, int T, long row_begin,
+                                           long row_end);
+int fsn_fullsubnet_forward_rows(const fsn_fullsubnet_cfg* cfg, const void* packed, const float* noisy_mag,
+                                int B, int T, long row_begin, long row_end, float* crm_rows,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
 /* recipes/dns_interspeech_2020/inferencer.py:130-145  Inferencer.full_band_crm_mask:
  * noisy [B, L] -> enhanced [B, L] (stft -> model -> decompress -> complex mask -> istft), all
  * intermediates kept in the frame-major device layout.  crm_out (optional, may be NULL) receives

@@ -201,6 +201,72 @@ def test_config2_full_size(fsn):
         assert (solo[0] - enh[b]).abs().max().item() <= 1e-3 * enh.abs().max().item()
 
 
+def _rows_of(crm):
+    """[B, 2, F, T] -> [B F, 2, T]: the row order fsn_fullsubnet_forward_rows uses (n = b F + f)."""
+    B, _, F, T = crm.shape
+    return crm.permute(0, 2, 1, 3).reshape(B * F, 2, T)
+
+
+@pytest.mark.parametrize("name,cuts", [
+    ("fsn_offline_b2", [0, 100, 257, 300, 514]),          # inside one utterance / aligned / across the boundary
+    ("fsn_offline_b2", [0, 65, 129, 193, 257, 322, 386, 450, 514]),  # 8 ranks
+    ("fsn_cumulative_b2", [0, 171, 343, 514]),            # per-row (cumulative) divisors indexed by global row
+    ("fsn_offline_b1_odd", [0, 33, 65, 97, 129, 161, 193, 225, 257]),  # one utterance over 8 ranks
+    ("fsn_dropband_b4", [0, 500, 1028]),
+])
+def test_row_slices_vs_reference(fsn, golden_dir, name, cuts):
+    """the batch x frequency rows in contiguous slices (one per rank), each through
+    fsn_fullsubnet_forward_rows; concatenated they are the reference's mask.  Slices cut utterances anywhere."""
+    z, meta = load(golden_dir, name)
+    model, _ = build_model(fsn, meta, groups=1)
+    x = dev(z["mag"][:, None])
+    with torch.no_grad():
+        whole = _rows_of(model(x))
+        parts = [model.forward_rows(x, lo, hi) for lo, hi in zip(cuts, cuts[1:])]
+    got = torch.cat(parts, dim=0)
+    assert got.shape == whole.shape
+    assert (got - whole).abs().max().item() <= 2e-5  # other kernels for fewer rows, same arithmetic
+    if meta["groups"] == 1:  # goldens with band dropping hold other rows; the unsharded forward is held to them
+        err = np.abs(got.cpu().numpy() - _rows_of(torch.from_numpy(z["crm"])).numpy())
+        assert err.max() <= 1e-4, err.max()
+    # an utterance-aligned slice is the plain forward on those utterances, bit for bit
+    F = 257
+    if x.shape[0] >= 2:
+        with torch.no_grad():
+            a = model.forward_rows(x, F, 2 * F)
+            b = _rows_of(model(x[1:2]))
+        assert torch.equal(a, b)
+
+
+def test_row_slice_on_the_persistent_kernel(fsn):
+    """A slice large enough for the persistent recurrent kernel with left-over tiles beside it (258 row tiles:
+    256 + 2) that starts and ends inside utterances, against the unsharded forward; and the workspace only covers
+    the utterances the slice touches."""
+    import ctypes
+    meta = dict(seed_w=5, gain=2.0, mask_gain=24.0, norm_type="offline_laplace_norm", groups=1)
+    model, params = build_model(fsn, meta)
+    noisy = O.make_noisy(20, 1300, seed=31)
+    mag = fsn.stft(dev(noisy), 512, 256, 512)[0][:, None].contiguous()
+    lo, hi = 300, 300 + 258 * 16 - 5
+    with torch.no_grad():
+        whole = _rows_of(model(mag))
+        part = model.forward_rows(mag, lo, hi)
+        tail = model.forward_rows(mag, hi, 20 * 257)
+    assert (part - whole[lo:hi]).abs().max().item() <= 2e-5
+    assert (tail - whole[hi:]).abs().max().item() <= 2e-5
+    want = O.fullsubnet_forward(mag[2:3].cpu().numpy(), params)  # utterance 2 lies wholly inside the slice
+    got = part[2 * 257 - lo:3 * 257 - lo].reshape(1, 257, 2, -1).permute(0, 2, 1, 3).cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-4
+    L = fsn._lib.lib()
+    T = mag.shape[-1]
+    assert (L.fsn_fullsubnet_rows_workspace_bytes(ctypes.byref(model._cfg), 20, T, lo, hi)
+            < L.fsn_fullsubnet_workspace_bytes(ctypes.byref(model._cfg), 20, T))
+    with pytest.raises(fsn._lib.FsnError):
+        model.forward_rows(mag, 10, 10)
+    with pytest.raises(fsn._lib.FsnError):
+        model.forward_rows(mag, 0, 20 * 257 + 1)
+
+
 def test_errors_are_loud(fsn):
     with pytest.raises(Exception):
         fsn.stft(torch.zeros(2, 4000), 512, 256, 512)  # CPU tensor: no fallback

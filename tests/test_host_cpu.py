@@ -55,6 +55,15 @@ def test_argument_validation_without_a_gpu():
     assert L.fsn_enhance_workspace_bytes(ctypes.byref(ok), 2, 16000, 400, 100) == 0  # unsupported FFT
     with pytest.raises(_lib.FsnError):
         _lib.dev_ptr(torch.zeros(4), "x")  # CPU tensor is rejected, no fallback
+    # row-range form: a slice only pays for the utterances it touches; an aligned full range is the plain forward
+    full = L.fsn_fullsubnet_workspace_bytes(ctypes.byref(ok), 8, 100)
+    assert L.fsn_fullsubnet_rows_workspace_bytes(ctypes.byref(ok), 8, 100, 0, 8 * 257) == full
+    one = L.fsn_fullsubnet_workspace_bytes(ctypes.byref(ok), 1, 100)
+    assert L.fsn_fullsubnet_rows_workspace_bytes(ctypes.byref(ok), 8, 100, 3 * 257, 4 * 257) == one
+    assert one < L.fsn_fullsubnet_rows_workspace_bytes(ctypes.byref(ok), 8, 100, 3 * 257 - 1, 4 * 257) < full
+    for lo, hi in ((5, 5), (-1, 10), (0, 8 * 257 + 1)):
+        assert L.fsn_fullsubnet_rows_workspace_bytes(ctypes.byref(ok), 8, 100, lo, hi) == 0
+        assert b"row range" in L.fsn_last_error()
 
 
 def test_model_surface_matches_reference_state_dict():
