@@ -122,6 +122,10 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="utterances per step: per GPU (weak) / whole job (strong)")
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--shard", choices=["utterances", "rows"], default="utterances",
+                    help="strong scaling only: whole utterances per rank (all-gather of waveforms), or contiguous slices "
+                         "of the batch x frequency rows of the sub-band model (all-gather of the full-band mask; "
+                         "balances any batch over any number of ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--no-experimental", action="store_true", help="skip the opt-in split-precision side measurement")
@@ -163,6 +167,9 @@ def main():
     if args.scaling == "weak":
         b_total, b_loc = args.batch * world, args.batch
         noisy_np = make_noisy(b_loc, length, seed=1234 + rank)
+    elif args.shard == "rows":
+        b_total = b_loc = args.batch  # every rank holds the batch; its share is a slice of the B F sub-band rows
+        noisy_np = make_noisy(b_total, length, seed=1234)
     else:
         b_total = args.batch
         lo, hi = shard_bounds(b_total, rank, world)
@@ -178,9 +185,16 @@ def main():
         host_in = torch.from_numpy(noisy_np).pin_memory()
         host_out = torch.empty_like(host_in).pin_memory()
 
+    row_sharded = args.scaling == "strong" and args.shard == "rows"
+    if row_sharded:
+        from fullsubnet_amd.parallel import enhance_row_sharded
+        gathered = send = None
+
     def step():
         if args.host_io:
             noisy.copy_(host_in, non_blocking=True)
+        if row_sharded:  # stft -> this rank's rows of the model -> all-gather of the mask -> decompress, apply, istft
+            return enhance_row_sharded(model, noisy, N_FFT, HOP)
         enh = model.enhance(noisy, n_fft=N_FFT, hop_length=HOP)
         if args.host_io:
             host_out.copy_(enh, non_blocking=True)
@@ -220,11 +234,12 @@ def main():
         value = b_total * T * args.steps / dt
         stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
         # dominant kernel: lstm_rec_kernel, launched twice per step (sub-band layers 0 and 1)
-        rows_steps = float(b_loc * F) * Tp
+        rows_loc = shard_bounds(b_total * F, 0, world)[1] if row_sharded else b_loc * F
+        rows_steps = float(rows_loc) * Tp
         rec_flops = 2.0 * (MAC_REC_L0 + MAC_REC_L1) * rows_steps  # both launches
         rec_ms = stage_ms["sb_rec_l0"] + stage_ms["sb_rec_l1"]
         achieved = rec_flops / (rec_ms * 1e-3) / 1e12 if rec_ms > 0 else 0.0
-        path_flops = 2.0 * MAC_PER_FRAME * b_loc * Tp
+        path_flops = 2.0 * (MAC_FB * b_loc + MAC_SB_PER_BIN * rows_loc) * Tp
         at_config2 = world == 1 and b_loc == 64 and length == 48000
         out = {
             "metric": "frames/sec (16 kHz, 512-FFT, hop 256), whole job", "value": round(value, 1),
@@ -238,7 +253,9 @@ def main():
                                    f"mask per utterance",
                        "batch_per_gpu": b_loc, "batch_total": b_total, "samples": length,
                        "frames_per_utterance": T,
-                       "parallelism": f"utterance-shard x{world}" + (" + all-gather" if world > 1 else "")},
+                       "parallelism": (f"row-shard x{world} ({rows_loc} of {b_total * F} sub-band rows per rank) + "
+                                       f"all-gather of the mask" if row_sharded else
+                                       f"utterance-shard x{world}" + (" + all-gather" if world > 1 else ""))},
             "rtf_speedup_audio_s_per_s": round(value / (SR / HOP), 1),
             "rtf_classic": round((SR / HOP) / value, 6),
             "roofline": {"bound": "mfma", "kernel": "lstm_rec_kernel<384,RT,2,*> (sub-band recurrent; 2 launches/step)",

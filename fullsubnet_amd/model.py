@@ -148,7 +148,7 @@ class Model(nn.Module):
         import torch.distributed as dist
         from .parallel import gather_shards, shard_bounds
         B, _, F, T = noisy_mag.shape
-        world = dist.get_world_size(group)
+        world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         if world == 1:
             rows = self.forward_rows(noisy_mag, 0, B * F)
         else:

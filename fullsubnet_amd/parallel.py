@@ -87,3 +87,20 @@ def gather_ragged(parts, n_items, group=None):
             offsets[r] += (hi - lo) * w
         full.append(torch.cat(pieces, dim=0))
     return full
+
+
+def enhance_row_sharded(model, noisy, n_fft=512, hop_length=256, group=None):
+    """inferencer.py:130-145 with the batch x frequency rows of the sub-band model sharded over the group (SURVEY
+    8e): every rank holds the whole ``noisy [B, L]``; the transforms and the mask application are cheap and run
+    replicated, the model runs on this rank's contiguous share of the B F rows (``Model.forward_rows``: the full-band
+    model only for the utterances that share touches), and ONE all-gather re-assembles the full-band mask
+    [B, 2, F, T] before it is decompressed and applied.  Use it when there are fewer utterances than ranks or the
+    batch does not divide evenly; with whole utterances per rank ``enhance_sharded`` does the same work with a
+    smaller all-gather (waveforms instead of masks)."""
+    from .acoustics.feature import istft, stft
+    from .acoustics.mask import decompress_cIRM
+    mag, _, re, im = stft(noisy, n_fft, hop_length, n_fft)
+    crm = model.forward_row_sharded(mag.unsqueeze(1), group=group)  # [B, 2, F, T]
+    m = decompress_cIRM(crm.permute(0, 2, 3, 1))
+    return istft((m[..., 0] * re - m[..., 1] * im, m[..., 1] * re + m[..., 0] * im), n_fft, hop_length, n_fft,
+                 length=noisy.size(-1), input_type="real_imag")

@@ -117,3 +117,37 @@ def test_gather_ragged_single_process_layout():
     lo, hi = shard_bounds(5, 2, world)
     assert torch.equal(bufs[2][: (hi - lo) * 6].view(hi - lo, 2, 3), full[0][lo:hi])
     assert shard_bounds(2, 2, world) == (2, 2)
+
+
+# ---- batch x frequency row shard of the fused FullSubNet forward ---------------------------------------
+
+def _row_worker(rank, world, port, B, F, T):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fullsubnet_amd
+        kw = dict(num_freqs=F, look_ahead=2, sequence_model="LSTM", fb_num_neighbors=0, sb_num_neighbors=15,
+                  fb_output_activate_function="ReLU", sb_output_activate_function=False, fb_model_hidden_size=64,
+                  sb_model_hidden_size=384, weight_init=False)
+        m = fullsubnet_amd.Model(**kw)
+        mag = torch.rand(B, 1, F, T, generator=torch.Generator().manual_seed(3))
+        calls = []
+
+        def fake_rows(noisy_mag, lo, hi):  # stands in for the HIP entry: row n = b F + f -> [2, T], per-row independent
+            calls.append((lo, hi))
+            rows = noisy_mag[:, 0].reshape(B * F, T)[lo:hi]
+            return torch.stack([rows * 2 + 1, rows.flip(-1)], dim=1)
+
+        m.forward_rows = fake_rows
+        got = m.forward_row_sharded(mag)
+        want = torch.stack([mag[:, 0] * 2 + 1, mag[:, 0].flip(-1)], dim=1)  # [B, 2, F, T]
+        assert torch.equal(got, want), f"rank {rank}"
+        assert calls == ([shard_bounds(B * F, rank, world)] if shard_bounds(B * F, rank, world)[1] > shard_bounds(B * F, rank, world)[0] else [])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B,F", [(2, 3, 257), (3, 1, 257), (3, 2, 5)])
+def test_row_sharded_forward_reassembles_the_mask(world, B, F):
+    mp.spawn(_row_worker, args=(world, _free_port(), B, F, 6), nprocs=world, join=True)
