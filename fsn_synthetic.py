@@ -68,7 +68,13 @@ IMPROVED_48K = dict(n_fft=960, hop_length=480, win_length=960, fdrc=0.5, num_fre
                     sb_num_center_freqs=[1, 4, 20, 60], sb_num_neighbor_freqs=[15, 15, 15, 15],
                     fb_num_center_freqs=[1, 4, 20, 60], fb_num_neighbor_freqs=[15, 15, 15, 15], fb_hidden_size=512,
                     sb_hidden_size=384)
-
+# BASELINE config 5 names "769 bins" (n_fft 1536 at 48 kHz); the reference has no hyper-parameters for it (its own
+# 48 kHz example is the 481-bin one above, improved_fullsubnet/model.py:603-620).  A scaling experiment with cut-offs
+# chosen to satisfy (upper - lower) % centre == 0 (model.py:341-346): 32 + 40 + 12 + 6 = 90 units per utterance.
+IMPROVED_48K_769 = dict(n_fft=1536, hop_length=768, win_length=1536, fdrc=0.5, num_freqs=769,
+                        freq_cutoffs=[32, 192, 384], sb_num_center_freqs=[1, 4, 16, 64],
+                        sb_num_neighbor_freqs=[15, 15, 15, 15], fb_num_center_freqs=[1, 4, 16, 64],
+                        fb_num_neighbor_freqs=[15, 15, 15, 15], fb_hidden_size=512, sb_hidden_size=384)
 
 
 def _block_params(rng, p, prefix, I, H, O_, num_layers):

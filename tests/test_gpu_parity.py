@@ -267,6 +267,21 @@ def test_row_slice_on_the_persistent_kernel(fsn):
         model.forward_rows(mag, 0, 20 * 257 + 1)
 
 
+def test_enhance_row_sharded_single_process_equals_the_fused_call(fsn, golden_dir):
+    """parallel.enhance_row_sharded without a process group (one rank owns every row): stft -> forward_rows ->
+    decompress -> mask -> istft as separate calls must reproduce the fused fsn_enhance (the collective itself is
+    covered on CPU, tests/test_parallel_cpu.py)."""
+    from fullsubnet_amd.parallel import enhance_row_sharded
+    z, meta = load(golden_dir, "fsn_offline_b2")
+    model, _ = build_model(fsn, meta, groups=1)
+    noisy = dev(O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_x"]))
+    fused, crm = model.enhance(noisy, return_crm=True)
+    split = enhance_row_sharded(model, noisy)
+    assert split.shape == fused.shape
+    assert (split - fused).abs().max().item() <= 1e-4 * fused.abs().max().item()  # same mask, other rounding points
+    assert np.abs(split.cpu().numpy() - z["enhanced"]).max() <= 2e-3 * np.abs(z["enhanced"]).max()
+
+
 def test_errors_are_loud(fsn):
     with pytest.raises(Exception):
         fsn.stft(torch.zeros(2, 4000), 512, 256, 512)  # CPU tensor: no fallback

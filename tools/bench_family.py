@@ -1,5 +1,5 @@
 """Time the sibling model families on one MI355X (BASELINE configs 1 and 4):
-python tools/bench_family.py [fast|fullband|improved16|improved48] [batch] [units=r/w]
+python tools/bench_family.py [fast|fullband|improved16|improved48|improved769] [batch] [units=r/w]
 units=r/w (improved* only): time what rank r of w computes under the frequency-axis shard (its share of every
 section's units; the all-gather is not part of this single-GPU measurement)."""
 import os
@@ -11,17 +11,18 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fullsubnet_amd  # noqa: E402
 from fullsubnet_amd import decompress_cIRM, istft, stft  # noqa: E402
-from fsn_synthetic import (IMPROVED_16K, IMPROVED_48K, make_fast_params, make_fullband_params,  # noqa: E402
+from fsn_synthetic import (IMPROVED_16K, IMPROVED_48K, IMPROVED_48K_769, make_fast_params, make_fullband_params,  # noqa: E402
                            make_improved_params, make_noisy)
 
 which = sys.argv[1] if len(sys.argv) > 1 else "fast"
-B = int(sys.argv[2]) if len(sys.argv) > 2 else {"fast": 256, "improved48": 32, "improved16": 32}.get(which, 1)
+B = int(sys.argv[2]) if len(sys.argv) > 2 else {"fast": 256, "improved48": 32, "improved769": 32,
+                                                "improved16": 32}.get(which, 1)
 L = 48000
 hop = 256
 if which.startswith("improved"):
     from fullsubnet_amd.improved_fullsubnet import Model
-    cfg = IMPROVED_48K if which == "improved48" else IMPROVED_16K
-    L = 144000 if which == "improved48" else 48000  # 3 s
+    cfg = {"improved48": IMPROVED_48K, "improved769": IMPROVED_48K_769}.get(which, IMPROVED_16K)
+    L = 48000 if which == "improved16" else 144000  # 3 s
     hop = cfg["hop_length"]
     model = Model(**cfg)
     sd = {k: torch.from_numpy(v) for k, v in make_improved_params(cfg, seed=3).items()}
@@ -90,6 +91,6 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
 T = 1 + L // hop
 la = 0 if which.startswith("improved") else 2
-sr = 48000 if which == "improved48" else 16000
+sr = 48000 if which in ("improved48", "improved769") else 16000
 print(f"{which}{which_label} B={B}: {dt * 1e3:.2f} ms / batch, {B * T / dt:.0f} frames/s ({B * L / sr / dt:.0f} x real time), "
       f"~{2 * mmac * B * (T + la) / dt / 1e12:.1f} TFLOP/s, finite={bool(torch.isfinite(out).all())}")
