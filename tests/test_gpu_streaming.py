@@ -101,3 +101,32 @@ def test_streaming_composed_configuration(setup):
     assert (got - offline).abs().max().item() <= 1e-4 * offline.abs().max().item()
     want = O.full_band_crm_mask(noisy.cpu().numpy(), params, norm_type="cumulative_laplace_norm")
     assert np.abs(got.cpu().numpy() - want).max() <= 2e-3 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("batch", [1, 17])
+def test_enhance_is_capturable_in_a_hip_graph(setup, batch):
+    """The C ABI only enqueues on the caller's stream (its auxiliary stream is forked and joined with events), so
+    the whole path can be captured once and replayed (torch.cuda.CUDAGraph = hipGraph): the replay on new input in
+    the static buffer must be bit-identical to the eager call.  batch 17: the persistent kernel with a left-over
+    tile on the auxiliary stream inside the capture; batch 1: the per-step wavefront chain."""
+    fsn, model, _ = setup
+    noisy = torch.from_numpy(O.make_noisy(batch, 2048, seed=21)).cuda()
+    other = torch.from_numpy(O.make_noisy(batch, 2048, seed=22)).cuda()
+    eager = model.enhance(noisy)  # also creates the auxiliary stream and packs the weights outside the capture
+    static_in = other.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        model.enhance(static_in)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_out = model.enhance(static_in)
+    static_in.copy_(noisy)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, eager)
+    static_in.copy_(other)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, model.enhance(other))
