@@ -54,7 +54,9 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const fl
     float* xl = hl + ROWS * HS;
     float* wl = xl;  // !XIN with the output layer fused: its two weight rows [2][H] sit here instead
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // wave-uniform, and told so: everything derived from it (unit group, weight / projection tile bases) then lives in
+    // scalar registers and the loads take the scalar-base + 32-bit lane offset form
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const long n0 = (long)blockIdx.x * ROWS;
     const bool fuse_fc = !XIN && fc.w_p != nullptr;
@@ -65,11 +67,13 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const fl
         }
     }
 
-    f32x4 cst[RT][UG], tmp[RT][UG];
+    float cst[RT][UG][4], tmp[RT][UG][4];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int u = 0; u < UG; ++u) cst[rt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < UG; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cst[rt][u][i] = 0.f;
     for (int i = threadIdx.x; i < ROWS * HS; i += NW * 64) hl[i] = 0.f;
     if (XIN) stage_sb_input<NW * 64>(xin, xl, XS, n0, ROWS, 0);
     __syncthreads();
@@ -81,15 +85,21 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const fl
         if (XIN && t + 1 < Tp) stage_sb_input<NW * 64>(xin, xl + ((t + 1) & 1) * ROWS * XS, XS, n0, ROWS, t + 1);
         const float* xt = xl + (t & 1) * ROWS * XS;
         // gate order of evaluation: f (1), i (0), g (2), o (3)
-#pragma unroll 1
+#pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
-            const int g = pass == 0 ? 1 : (pass == 1 ? 0 : pass);
+            // The four passes are unrolled, so that the cell update of each is straight-line code that updates c and
+            // the temporary in place.  Two things keep the register count of the rolled loop: nothing is scheduled
+            // across a pass boundary, and the gate index is opaque to the optimiser - as a constant, the per-gate
+            // operand addresses of all four passes are hoisted out of the time loop and held live (85+ spills).
+            __builtin_amdgcn_sched_barrier(0);
+            int g = pass == 0 ? 1 : (pass == 1 ? 0 : pass);
+            asm volatile("" : "+s"(g));
             f32x4 acc[RT][UG];
-            const float* bp[UG];
+            unsigned bo[UG];  // 32-bit element offsets from the (uniform) weight base: one register per stream
 #pragma unroll
             for (int u = 0; u < UG; ++u) {
                 const int ug = wave * UG + u;
-                bp[u] = whh_p + ((long)(g * KC + ug) * KC * 64 + lane) * 4;
+                bo[u] = (unsigned)(((g * KC + ug) * KC * 64 + lane) * 4);
                 if (!XIN) {
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
@@ -121,7 +131,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const fl
             if (t > 0) {  // h_{-1} = 0
                 f32x4 bn[UG];
 #pragma unroll
-                for (int u = 0; u < UG; ++u) bn[u] = *reinterpret_cast<const f32x4*>(bp[u]);
+                for (int u = 0; u < UG; ++u) bn[u] = *reinterpret_cast<const f32x4*>(whh_p + bo[u]);
 #pragma unroll UNR
                 for (int kc = 0; kc < KC; ++kc) {
                     f32x4 bc[UG];
@@ -130,7 +140,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const fl
                     if (kc + 1 < KC) {
 #pragma unroll
                         for (int u = 0; u < UG; ++u)
-                            bn[u] = *reinterpret_cast<const f32x4*>(bp[u] + (long)(kc + 1) * 256);
+                            bn[u] = *reinterpret_cast<const f32x4*>(whh_p + (bo[u] + (unsigned)(kc + 1) * 256u));
                     }
                     const float* ap = hl + lr * HS + kc * 16 + 4 * lq;
 #pragma unroll
@@ -143,18 +153,27 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const fl
                     }
                 }
             }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int u = 0; u < UG; ++u)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float x = acc[rt][u][i];
-                        if (pass == 0) cst[rt][u][i] = sigmoid_fast(x) * cst[rt][u][i];
-                        else if (pass == 1) tmp[rt][u][i] = sigmoid_fast(x);
-                        else if (pass == 2) cst[rt][u][i] = cst[rt][u][i] + tmp[rt][u][i] * tanh_fast(x);
-                        else tmp[rt][u][i] = sigmoid_fast(x) * tanh_fast(cst[rt][u][i]);
-                    }
+            // the branch on the (uniform) pass sits OUTSIDE the unrolled element loops, and c / the temporary are
+            // scalar arrays rather than 4-vectors: written per element on vectors, hipcc emits a four-way scalar
+            // branch tree and register-tuple copies around every single value
+#define FSN_REC_EPILOGUE(VAR, EXPR)                                                                   \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                 \
+    _Pragma("unroll") for (int u = 0; u < UG; ++u)                                                    \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+        VAR[rt][u][i] = EXPR;                                                                         \
+        asm volatile("" : "+v"(VAR[rt][u][i])); /* computed HERE: not sunk towards its use two passes later */ \
+    }
+            if (pass == 0) {
+                FSN_REC_EPILOGUE(cst, sigmoid_fast(acc[rt][u][i]) * cst[rt][u][i])
+            } else if (pass == 1) {
+                FSN_REC_EPILOGUE(tmp, sigmoid_fast(acc[rt][u][i]))
+            } else if (pass == 2) {
+                FSN_REC_EPILOGUE(cst, cst[rt][u][i] + tmp[rt][u][i] * tanh_fast(acc[rt][u][i]))
+            } else {
+                FSN_REC_EPILOGUE(tmp, sigmoid_fast(acc[rt][u][i]) * tanh_fast(cst[rt][u][i]))
+            }
+#undef FSN_REC_EPILOGUE
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();  // every wave has finished reading h_{t-1}
 #pragma unroll
