@@ -170,6 +170,26 @@ def test_leftover_step_kernel_fits_next_to_persistent_kernel(tmp_path):
     assert lds_rec + 3 * step["group_segment_fixed_size"] <= 160 * 1024
 
 
+def test_built_library_holds_the_same_budget():
+    """The same contract on the kernels INSIDE libfsn_hip.so - what actually travels to the GPU box (a stale or
+    differently built library once cost 4.5 ms per batch unnoticed: its persistent kernels had 168 registers)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("so_kernel_resources",
+                                                  os.path.join(ROOT, "tools", "so_kernel_resources.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(mod.READELF):
+        pytest.skip("llvm-readelf not available")
+    ks = mod.kernels()
+    step = next(v for k, v in ks.items() if "lstm_step1_kernel" in k)
+    recs = {k: v for k, v in ks.items() if "lstm_rec_kernelILi384ELi4ELi2E" in k}
+    assert len(recs) == 2
+    gran = lambda n: (n + 7) // 8 * 8
+    for name, rec in recs.items():
+        assert rec["vgpr_spill_count"] == 0 and rec["private_segment_fixed_size"] == 0, (name, rec)
+        assert 3 * gran(rec["vgpr_count"]) + gran(step["vgpr_count"]) <= 512, (name, rec, step)
+
+
 def test_subband_multiplicity_closed_form():
     """offline_den_kernel (elementwise_kernels.hip) weighs bin f by m[f] = number of (unit, row) pairs of
     freq_unfold that read it; the kernel's closed form against the brute-force count over the reflect map."""
