@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include "../fullsubnet_amd/csrc/lstm_kernels.hip"
 #include "experimental_rec1.hip"
+#include "experimental_rec_pf.hip"
 void fsn_set_error(const char*, ...) {}
 int fsn_check_launch(const char*) { return hipGetLastError() == hipSuccess ? 0 : -3; }
 __global__ void fill_kernel(float* p, size_t n, unsigned seed, float scale) {
@@ -39,6 +40,34 @@ int main(int argc, char** argv) {
                                 "rec UG=6 (4 waves)"};
         printf("%s ablate=%d: %.3f ms  %.1f TFLOP/s (ideal %.3f ms)\n", names[ver], FSN_REC1_ABLATE, best,
                flops / best / 1e9, flops / 156e9);
+    }
+    // projection tiles prefetched into released accumulators + LDS-only barriers, against the
+    // shipped kernel: time and bit-for-bit comparison of the stored hidden sequences
+    {
+        float* hseq2;
+        hipMalloc(&hseq2, (size_t)Tp * Npad * H * 4);
+        hipMemset(hseq, 0, (size_t)Tp * Npad * H * 4);
+        hipMemset(hseq2, 0, (size_t)Tp * Npad * H * 4);
+        float best[2] = {1e30f, 1e30f};
+        for (int it = 0; it < 3; ++it)
+            for (int ver = 0; ver < 2; ++ver) {
+                hipEventRecord(e0, 0);
+                if (ver == 0) launch_rec<384, 4, false, 2>(gx, nullptr, w, hseq, Tp, Npad, 256, 0);
+                else launch_rec_pf<384, 4, 2>(gx, w, hseq2, Tp, Npad, 256, 0);
+                hipEventRecord(e1, 0); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1); if (it > 0 && ms < best[ver]) best[ver] = ms;
+            }
+        const size_t n = (size_t)Tp * 256 * 64 * H;  // rows of the 256 workgroups
+        float* a = (float*)malloc(n * 4);
+        float* b = (float*)malloc(n * 4);
+        size_t bad = 0;
+        for (int t = 0; t < Tp; ++t) {
+            hipMemcpy(a + (size_t)t * 256 * 64 * H, hseq + (size_t)t * Npad * H, (size_t)256 * 64 * H * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(b + (size_t)t * 256 * 64 * H, hseq2 + (size_t)t * Npad * H, (size_t)256 * 64 * H * 4, hipMemcpyDeviceToHost);
+        }
+        for (size_t i = 0; i < n; ++i) bad += (a[i] != b[i]) || !(a[i] == a[i]);
+        printf("shipped lstm_rec_kernel<384,4,2,false>: %.3f ms   prefetching variant: %.3f ms   differing values: %zu of %zu\n",
+               best[0], best[1], bad, n);
     }
     return 0;
 }
