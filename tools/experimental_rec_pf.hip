@@ -10,7 +10,11 @@
 // the probe times it against the shipped kernel and compares the stored hidden sequences bit for bit.
 namespace {
 
-template <int H, int RT, int UG>
+// SKEW (third experiment): the three waves a SIMD holds leave the step barrier together and reach
+// every pass boundary together, so their cell updates (VALU / transcendental work, ~0.8 us per wave and pass) run back
+// to back with the matrix pipe idle.  SKEW > 0 delays wave slot k of a SIMD by k * SKEW * 64 clocks after the barrier
+// (s_sleep): the updates of one wave then fall under the MFMAs of the other two.
+template <int H, int RT, int UG, int SKEW>
 __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_pf_kernel(const float* __restrict__ gx,
                                                                            const float* __restrict__ whh_p,
                                                                            float* __restrict__ hseq, int Tp, int Npad) {
@@ -51,6 +55,10 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_pf_kernel(const
     __syncthreads();
 
     for (int t = 0; t < Tp; ++t) {
+        if (SKEW > 0) {  // waves w, w + 4, w + 8 share SIMD w % 4: slot = wave / 4
+            if (wave >= 8) __builtin_amdgcn_s_sleep(2 * SKEW);
+            else if (wave >= 4) __builtin_amdgcn_s_sleep(SKEW);
+        }
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
             __builtin_amdgcn_sched_barrier(0);
@@ -130,14 +138,14 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_pf_kernel(const
     }
 }
 
-template <int H, int RT, int UG = 2>
+template <int H, int RT, int UG = 2, int SKEW = 0>
 int launch_rec_pf(const float* gx, const float* whh_p, float* hseq, int Tp, int Npad, int wgs, hipStream_t s) {
     constexpr int NW = H / (16 * UG);
     const size_t lds = (size_t)RT * 16 * (H + 4) * sizeof(float);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_pf_kernel<H, RT, UG>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_rec_pf_kernel<H, RT, UG, SKEW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return -3;
-    hipLaunchKernelGGL((lstm_rec_pf_kernel<H, RT, UG>), dim3((unsigned)wgs), dim3(NW * 64), lds, s, gx, whh_p, hseq, Tp, Npad);
+    hipLaunchKernelGGL((lstm_rec_pf_kernel<H, RT, UG, SKEW>), dim3((unsigned)wgs), dim3(NW * 64), lds, s, gx, whh_p, hseq, Tp, Npad);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

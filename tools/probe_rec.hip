@@ -48,12 +48,15 @@ int main(int argc, char** argv) {
         hipMalloc(&hseq2, (size_t)Tp * Npad * H * 4);
         hipMemset(hseq, 0, (size_t)Tp * Npad * H * 4);
         hipMemset(hseq2, 0, (size_t)Tp * Npad * H * 4);
-        float best[2] = {1e30f, 1e30f};
+        float best[5] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
         for (int it = 0; it < 3; ++it)
-            for (int ver = 0; ver < 2; ++ver) {
+            for (int ver = 0; ver < 5; ++ver) {
                 hipEventRecord(e0, 0);
                 if (ver == 0) launch_rec<384, 4, false, 2>(gx, nullptr, w, hseq, Tp, Npad, 256, 0);
-                else launch_rec_pf<384, 4, 2>(gx, w, hseq2, Tp, Npad, 256, 0);
+                else if (ver == 1) launch_rec_pf<384, 4, 2, 0>(gx, w, hseq2, Tp, Npad, 256, 0);
+                else if (ver == 2) launch_rec_pf<384, 4, 2, 8>(gx, w, hseq2, Tp, Npad, 256, 0);
+                else if (ver == 3) launch_rec_pf<384, 4, 2, 16>(gx, w, hseq2, Tp, Npad, 256, 0);
+                else launch_rec_pf<384, 4, 2, 32>(gx, w, hseq2, Tp, Npad, 256, 0);
                 hipEventRecord(e1, 0); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1); if (it > 0 && ms < best[ver]) best[ver] = ms;
             }
@@ -66,8 +69,9 @@ int main(int argc, char** argv) {
             hipMemcpy(b + (size_t)t * 256 * 64 * H, hseq2 + (size_t)t * Npad * H, (size_t)256 * 64 * H * 4, hipMemcpyDeviceToHost);
         }
         for (size_t i = 0; i < n; ++i) bad += (a[i] != b[i]) || !(a[i] == a[i]);
-        printf("shipped lstm_rec_kernel<384,4,2,false>: %.3f ms   prefetching variant: %.3f ms   differing values: %zu of %zu\n",
-               best[0], best[1], bad, n);
+        printf("shipped lstm_rec_kernel<384,4,2,false>: %.3f ms   prefetching variant: %.3f ms   + wave skew 8 / 16 / 32 x 64 clk: "
+               "%.3f / %.3f / %.3f ms   differing values (last variant run): %zu of %zu\n",
+               best[0], best[1], best[2], best[3], best[4], bad, n);
     }
     return 0;
 }
