@@ -148,6 +148,6 @@ def _row_worker(rank, world, port, B, F, T):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,B,F", [(2, 3, 257), (3, 1, 257), (3, 2, 5)])
+@pytest.mark.parametrize("world,B,F", [(2, 3, 257), (3, 1, 257), (3, 2, 5), (3, 1, 2)])  # last: a rank without rows
 def test_row_sharded_forward_reassembles_the_mask(world, B, F):
     mp.spawn(_row_worker, args=(world, _free_port(), B, F, 6), nprocs=world, join=True)
