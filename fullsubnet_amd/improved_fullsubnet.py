@@ -197,6 +197,9 @@ class SubbandModel(BaseModel):
         batch_size, num_channels, num_freqs, num_frames = noisy_input.size()
         assert num_channels == 1, "Only mono audio is supported."
         if unit_group is not None and unit_group is not False:
+            if torch.is_grad_enabled():
+                raise RuntimeError("the sub-band unit shard is an inference layout (its all-gather is not differentiable): "
+                                   "call it under torch.no_grad(); training shards the batch (DDP)")
             import torch.distributed as dist
             from .parallel import gather_ragged
             group = None if unit_group is True else unit_group

@@ -102,6 +102,13 @@ def test_unit_sharded_subband_model_equals_the_unsharded_one(world, case):
     mp.spawn(_unit_worker, args=(world, _free_port(), case), nprocs=world, join=True)
 
 
+def test_unit_shard_refuses_to_build_an_autograd_graph():
+    m = _subband_model(64, [32], [1, 16], "offline_laplace_norm")
+    x = torch.rand(1, 1, 64, 3) + 0.1
+    with pytest.raises(RuntimeError, match="inference layout"):
+        m(x, x, unit_group=True)
+
+
 def test_gather_ragged_single_process_layout():
     """The packing used by the unit shard, without a process group: emulate every rank's buffer by hand."""
     from fullsubnet_amd.parallel import pack_ragged
