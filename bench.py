@@ -6,18 +6,21 @@
 
 One "step" = one pass of the whole hot path (STFT -> FullSubNet -> cIRM decompress/apply -> iSTFT,
 inferencer.py:130-145) over a batch of synthetic 3 s / 16 kHz utterances already resident in HBM:
-64 utterances per GPU (BASELINE config 2).  Utterances (and with them the batch x frequency rows of
-the sub-band model) are independent, so with N ranks every rank runs the unchanged single-GPU path
-on its own 64 utterances with no data-path collective, and one RCCL all-gather re-assembles the
-enhanced node batch: per-GPU work is fixed -> "scaling": "weak" (the default).  `--scaling strong`
-instead shards ONE 64-utterance batch across the ranks (8 utterances per rank at N = 8).
+one batch of 64 utterances (BASELINE config 2).  Utterances (and with them the batch x frequency rows of the
+sub-band model) are independent, so with N ranks that ONE batch is sharded - 64 / N whole utterances per rank (or
+contiguous slices of the B F sub-band rows, --shard rows) - every rank runs the unchanged single-GPU path on its
+share with no data-path collective, and one RCCL all-gather re-assembles the node batch: total work is fixed ->
+"scaling": "strong", the north-star target (>= 6x at 8 GPUs).  The weak form (64 utterances per rank,
+`--scaling weak`) is measured next to it as the side figure `other_scaling`.
 
 Prints ONE JSON line (rank 0) with the driver's contract keys plus
   roofline     - fp32-MFMA roofline fraction of the dominant kernel (the sub-band recurrent kernel,
                  two launches per step) from its algorithmic FLOPs / its HIP-event duration on the
-                 launch stream; `traffic` from the committed rocprofv3 PMC passes of this config
-  cpu_baseline - the CPU oracle (numpy/MKL port of the reference path) timed on this box's host
-                 cores on a bounded sample of the same workload (rank 0, N = 1 only).
+                 launch stream; `traffic` / `mfma_busy_frac` from the committed rocprofv3 PMC passes of this config
+  cpu_baseline - the reference's ATen operator sequence (oracle/aten_baseline.py) timed on this box's host cores
+                 on a bounded sample of the same workload (rank 0, N = 1 only); the numpy oracle as `oracle_port`
+  experimental_f16x3, train_step - side figures (N = 1): the opt-in split-precision kernels and one training step
+                 at BASELINE config 3's per-rank shape.
 """
 import argparse
 import json
@@ -57,61 +60,117 @@ def build_model(device):
     return model.to(device).eval(), params
 
 
+def _time_aten(model, length, batch, threads):
+    from fsn_synthetic import make_noisy
+    from oracle import aten_baseline as A
+    torch.set_num_threads(threads)
+    noisy = torch.from_numpy(make_noisy(batch, length, seed=78))
+    t0 = time.perf_counter()
+    A.full_band_crm_mask(model, noisy)
+    return time.perf_counter() - t0
+
+
 def cpu_baseline(params, length, budget_s=20.0):
-    """Reference path restated on the CPU (oracle/), timed on a bounded sample: whole utterances of
-    the same shape in one batch, as many as fit ~budget_s."""
+    """The reference's CPU arithmetic on this box's host cores, on a bounded sample of the same workload.
+
+    Headline figure (`value`): oracle/aten_baseline.py - the ATen operator sequence the reference itself executes
+    (torch.stft, nn.LSTM(257,512,2) + Linear + ReLU, F.unfold, nn.LSTM(32,384,2) + Linear, decompress, torch.istft;
+    oneDNN / MKL kernels of the PyTorch build on this box) - whole 3 s utterances in one batch, as many as fit
+    ~2/3 of the budget, with the thread count that measured fastest in a one-utterance calibration.
+    Second, labelled figure (`oracle_port`): the numpy restatement that the parity tests use as their checker."""
+    from oracle import aten_baseline as A
     from oracle import fullsubnet_oracle as O
-    # the port scales to ~16 threads (MKL GEMMs of 257-row panels + numpy elementwise); more threads
-    # only add contention on a 256-core host, so that is what is used and what `cores` reports
-    cores = min(16, len(os.sched_getaffinity(0)))
+    avail = len(os.sched_getaffinity(0))
+    frames_per_utt = 1 + length // HOP
+    model = A.AtenFullSubNet(params).eval()
+    _time_aten(model, length, 1, min(avail, 16))  # warm-up: thread pools, oneDNN primitive cache, page faults
+    cal = {}
+    for th in sorted({min(avail, t) for t in (8, 16, 32, 64)}):
+        cal[th] = _time_aten(model, length, 1, th)
+    threads = min(cal, key=cal.get)
+    nb = int(max(1, min(64, (budget_s * 0.66) // max(cal[threads], 1e-3))))
+    dt = min(_time_aten(model, length, nb, threads) for _ in range(1 if nb > 4 else 2))
+    out = {"value": round(nb * frames_per_utt / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+           "sample": f"{nb} x {length / SR:.1f} s utterance(s) in one batch, full path stft -> model -> decompress -> "
+                     f"mask -> istft as the ATen operator sequence of the reference (oracle/aten_baseline.py: torch "
+                     f"{torch.__version__} CPU kernels, oneDNN LSTM + MKL FFT), {threads} of {avail} host threads "
+                     f"(fastest of {sorted(cal)} in a 1-utterance calibration), {dt:.1f} s wall",
+           "rtf_speedup": round(nb * length / SR / dt, 3)}
+    # the parity checker (numpy + torch-CPU matmuls), for the record: it scales to ~16 threads
+    cores = min(16, avail)
     torch.set_num_threads(cores)
     win = torch.hann_window(N_FFT).numpy()
-    frames_per_utt = 1 + length // HOP
     noisy = O.make_noisy(2, length, seed=77)
-    O.full_band_crm_mask(noisy[:1], params, window=win)  # warm-up (thread pools, page faults)
-    t0 = time.perf_counter()
-    O.full_band_crm_mask(noisy, params, window=win)  # calibration
-    per_utt = (time.perf_counter() - t0) / 2
-    nb = int(max(2, min(64, budget_s // max(per_utt, 1e-3))))
-    noisy = O.make_noisy(nb, length, seed=78)
+    O.full_band_crm_mask(noisy[:1], params, window=win)
     t0 = time.perf_counter()
     O.full_band_crm_mask(noisy, params, window=win)
     dt = time.perf_counter() - t0
-    return {"value": round(nb * frames_per_utt / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{nb} x {length / SR:.1f} s utterance(s) in one batch, full path (oracle/fullsubnet_oracle.py: "
-                      f"numpy {np.__version__} + torch-CPU/MKL GEMMs, {cores} threads), {dt:.1f} s wall",
-            "rtf_speedup": round(nb * length / SR / dt, 3)}
+    out["oracle_port"] = {"value": round(2 * frames_per_utt / dt, 2), "unit": "frames/s", "cores": cores,
+                          "sample": f"2 x {length / SR:.1f} s, oracle/fullsubnet_oracle.py (numpy {np.__version__} + "
+                                    f"torch-CPU matmuls), {dt:.1f} s wall"}
+    return out
 
 
-def experimental_f16x3(args):
-    """The same step with the opt-in split-precision kernels (FSN_F16X3=1: fp16 x 3 MFMAs with fp32 accumulation for
-    both sub-band recurrent layers and the projection between them), measured in a child process because the switch
-    is read once per process.  Reported NEXT TO the line's `value`, which is always the default fp32 build."""
-    import subprocess
-    if os.environ.get("FSN_F16X3") == "1":
-        return None
-    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--batch", str(args.batch), "--seconds", str(args.seconds), "--no-cpu-baseline", "--no-experimental"]
-    try:
-        out = subprocess.run(cmd, env=dict(os.environ, FSN_F16X3="1"), capture_output=True, text=True, timeout=600)
-        d = json.loads(out.stdout.strip().splitlines()[-1])
-        return {"switch": "FSN_F16X3=1", "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
-                "stage_ms": d["stage_ms"],
-                "note": "opt-in (fp32 operands split into two fp16 halves, three 16-bit MFMAs per product block, fp32 "
-                        "accumulation); mask within 1.2e-5 of the fp32 path, GPU parity tests green with the switch on"}
-    except Exception as e:  # the experiment must never break the benchmark line
-        return {"switch": "FSN_F16X3=1", "error": str(e)[:200]}
+def timed_steps(step, fence, steps, read_profile=None):
+    """K steps bracketed by fence() on both sides; returns (seconds, summed stage ms)."""
+    stage_ms = {}
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+        if read_profile is not None:
+            for k, v in read_profile().items():  # waits for this step's events only
+                stage_ms[k] = stage_ms.get(k, 0.0) + v
+    fence()
+    return time.perf_counter() - t0, stage_ms
 
 
-def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_hbm_traffic_end.json: FETCH_SIZE x2 (gfx950) + WRITE_SIZE at this exact config, mean of the
-    two launches per step)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_end.json")) as f:
-            return json.load(f)["dominant_kernel"]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+def training_step_ms(device, steps=5):
+    """Side figure (BASELINE config 3, per-rank shape): one step of fullsubnet/trainer.py:41-71 - 16 utterances x
+    49 152 samples, drop_band groups 2, MSE on the compressed cIRM, clip_grad_norm_(10) + Adam - fp32, one GPU."""
+    import fullsubnet_amd
+    from fullsubnet_amd.train import train_step
+    from fsn_synthetic import make_noisy, make_params
+    model = fullsubnet_amd.Model(num_freqs=F, look_ahead=LA, sequence_model="LSTM", fb_num_neighbors=0,
+                                 sb_num_neighbors=NB, fb_output_activate_function="ReLU",
+                                 sb_output_activate_function=False, fb_model_hidden_size=H_FB,
+                                 sb_model_hidden_size=H_SB, norm_type="offline_laplace_norm",
+                                 num_groups_in_drop_band=2, weight_init=False)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in make_params(seed=3).items()})
+    model = model.to(device).train()
+    opt = fullsubnet_amd.ClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    noisy = torch.from_numpy(make_noisy(16, 49152, seed=41)).to(device)
+    clean = torch.from_numpy(0.7 * make_noisy(16, 49152, seed=42)).to(device)
+    for _ in range(2):
+        train_step(model, opt, noisy, clean)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = train_step(model, opt, noisy, clean)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    T = 1 + 49152 // HOP
+    flops = 3 * 2.0 * 16 * (T + LA) * (MAC_FB + 128 * MAC_SB_PER_BIN)  # SURVEY 8(d): ~3x forward, 128 bins kept
+    del model, opt
+    torch.cuda.empty_cache()
+    return {"ms_per_step": round(ms, 2), "config": "BASELINE config 3 per-rank shape: 16 x 49152 samples, drop_band "
+            "groups 2, cIRM MSE + clip_grad_norm_(10) + Adam, fp32", "loss": round(float(loss), 6),
+            "tflops": round(flops / (ms * 1e-3) / 1e12, 1),
+            "frac_fp32_mfma_peak": round(flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3)}
+
+
+def measured_counters():
+    """PMC figures of the dominant kernel from the committed rocprofv3 passes of this round (profiles/
+    r02_pmc.json, produced by tools/rocprof_pmc.py from separate --pmc runs of `bench.py` at config 2): HBM bytes
+    per launch (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE) and the MFMA-busy fraction of the launch."""
+    for name in ("r02_pmc.json", "r01_hbm_traffic_end.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)["dominant_kernel"]
+            return d.get("hbm_bytes_per_launch"), d.get("mfma_busy_frac"), "profiles/" + name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None, None
 
 
 def main():
@@ -119,16 +178,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="utterances per step: per GPU (weak) / whole job (strong)")
+    ap.add_argument("--batch", type=int, default=64, help="utterances per step: whole job (strong) / per GPU (weak)")
     ap.add_argument("--seconds", type=float, default=3.0)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--shard", choices=["utterances", "rows"], default="utterances",
-                    help="strong scaling only: whole utterances per rank (all-gather of waveforms), or contiguous slices "
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N > 1: strong (default, north star) = ONE --batch-utterance step sharded over the ranks; "
+                         "weak = --batch utterances per rank.  The other mode is measured as a side figure.")
+    ap.add_argument("--shard", choices=["auto", "utterances", "rows"], default="auto",
+                    help="strong scaling: whole utterances per rank (all-gather of waveforms), or contiguous slices "
                          "of the batch x frequency rows of the sub-band model (all-gather of the full-band mask; "
-                         "balances any batch over any number of ranks)")
+                         "balances any batch over any number of ranks).  auto: utterances when they divide evenly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--no-experimental", action="store_true", help="skip the opt-in split-precision side measurement")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the side measurements (other scaling mode, opt-in arithmetic, training step)")
     ap.add_argument("--host-io", action="store_true",
                     help="side measurement for DESIGN.md: every step also copies its input from pinned host memory and "
                          "its result back (the PCIe-inclusive rate; never the headline `value`, which is HBM-resident)")
@@ -158,51 +220,14 @@ def main():
             dist.init_process_group(backend=backend)
 
     from fullsubnet_amd import _lib
-    from fullsubnet_amd.parallel import shard_bounds
+    from fullsubnet_amd.parallel import enhance_row_sharded, shard_bounds
     from fsn_synthetic import make_noisy  # seeded synthetic input
 
     length = int(round(args.seconds * SR))
     T = 1 + length // HOP
     Tp = T + LA
-    if args.scaling == "weak":
-        b_total, b_loc = args.batch * world, args.batch
-        noisy_np = make_noisy(b_loc, length, seed=1234 + rank)
-    elif args.shard == "rows":
-        b_total = b_loc = args.batch  # every rank holds the batch; its share is a slice of the B F sub-band rows
-        noisy_np = make_noisy(b_total, length, seed=1234)
-    else:
-        b_total = args.batch
-        lo, hi = shard_bounds(b_total, rank, world)
-        b_loc = hi - lo
-        noisy_np = make_noisy(b_total, length, seed=1234)[lo:hi]
-    b_max = shard_bounds(b_total, 0, world)[1]
     model, params = build_model(device)
-    noisy = torch.from_numpy(noisy_np).to(device)  # resident in HBM before the timed region
-    gathered = torch.empty((world * b_max, length), dtype=torch.float32, device=device) if world > 1 else None
-    send = torch.zeros((b_max, length), dtype=torch.float32, device=device) if world > 1 else None
-
-    if args.host_io:
-        host_in = torch.from_numpy(noisy_np).pin_memory()
-        host_out = torch.empty_like(host_in).pin_memory()
-
-    row_sharded = args.scaling == "strong" and args.shard == "rows"
-    if row_sharded:
-        from fullsubnet_amd.parallel import enhance_row_sharded
-        gathered = send = None
-
-    def step():
-        if args.host_io:
-            noisy.copy_(host_in, non_blocking=True)
-        if row_sharded:  # stft -> this rank's rows of the model -> all-gather of the mask -> decompress, apply, istft
-            return enhance_row_sharded(model, noisy, N_FFT, HOP)
-        enh = model.enhance(noisy, n_fft=N_FFT, hop_length=HOP)
-        if args.host_io:
-            host_out.copy_(enh, non_blocking=True)
-        if world > 1:
-            send[:b_loc].copy_(enh)
-            dist.all_gather_into_tensor(gathered, send)  # RCCL over xGMI: re-assemble the node batch
-            return gathered
-        return enh
+    L = _lib.lib()
 
     def fence():
         torch.cuda.synchronize()
@@ -210,68 +235,139 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    L = _lib.lib()
-    L.fsn_profile_enable(1)  # hipEvents on the launch stream around every stage (no host sync inside)
-    stage_ms = {}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        for k, v in _lib.profile_read().items():  # waits for this step's events only
-            stage_ms[k] = stage_ms.get(k, 0.0) + v
-    fence()
-    dt = time.perf_counter() - t0
-    L.fsn_profile_enable(0)
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def make_mode(scaling):
+        """(step(), b_total, b_loc, rows_loc, description) of one scaling mode; inputs resident in HBM."""
+        row_sharded = False
+        if scaling == "weak" or world == 1:
+            b_total, b_loc = args.batch * world, args.batch
+            noisy_np = make_noisy(b_loc, length, seed=1234 + rank)
+        else:
+            b_total = args.batch
+            row_sharded = args.shard == "rows" or (args.shard == "auto" and b_total % world != 0)
+            if row_sharded:  # every rank holds the batch; its share is a slice of the B F sub-band rows
+                b_loc = b_total
+                noisy_np = make_noisy(b_total, length, seed=1234)
+            else:
+                lo, hi = shard_bounds(b_total, rank, world)
+                b_loc = hi - lo
+                noisy_np = make_noisy(b_total, length, seed=1234)[lo:hi]
+        b_max = shard_bounds(b_total, 0, world)[1]
+        noisy = torch.from_numpy(noisy_np).to(device)  # resident in HBM before the timed region
+        gathered = send = None
+        if world > 1 and not row_sharded:
+            gathered = torch.empty((world * b_max, length), dtype=torch.float32, device=device)
+            send = torch.zeros((b_max, length), dtype=torch.float32, device=device)
+        host_in = host_out = None
+        if args.host_io:
+            host_in = torch.from_numpy(noisy_np).pin_memory()
+            host_out = torch.empty_like(host_in).pin_memory()
+
+        def step():
+            if args.host_io:
+                noisy.copy_(host_in, non_blocking=True)
+            if row_sharded:  # stft -> this rank's rows of the model -> all-gather of the mask -> decompress, apply, istft
+                return enhance_row_sharded(model, noisy, N_FFT, HOP)
+            enh = model.enhance(noisy, n_fft=N_FFT, hop_length=HOP)
+            if args.host_io:
+                host_out.copy_(enh, non_blocking=True)
+            if world > 1:
+                if b_loc == b_max:
+                    dist.all_gather_into_tensor(gathered, enh)  # RCCL over xGMI: re-assemble the node batch
+                else:
+                    send[:b_loc].copy_(enh)
+                    dist.all_gather_into_tensor(gathered, send)
+                return gathered
+            return enh
+
+        rows_loc = shard_bounds(b_total * F, 0, world)[1] if row_sharded else b_loc * F
+        par = (f"row-shard x{world} ({rows_loc} of {b_total * F} sub-band rows per rank) + all-gather of the mask"
+               if row_sharded else f"utterance-shard x{world}" + (" + all-gather of the waveforms" if world > 1 else ""))
+        return step, b_total, b_loc, rows_loc, par
+
+    def run_mode(scaling, steps, warmup, profile):
+        step, b_total, b_loc, rows_loc, par = make_mode(scaling)
+        for _ in range(warmup):
+            step()
+        if profile:
+            L.fsn_profile_enable(1)  # hipEvents on the launch stream around every stage (no host sync inside)
+        dt, stage_ms = timed_steps(step, fence, steps, (lambda: _lib.profile_read(device)) if profile else None)
+        if profile:
+            L.fsn_profile_enable(0)
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dict(dt=dt, stage_ms={k: v / steps for k, v in stage_ms.items()}, b_total=b_total, b_loc=b_loc,
+                    rows_loc=rows_loc, par=par, steps=steps)
+
+    scaling = args.scaling if world > 1 else "weak"  # one GPU: the two modes are the same workload
+    head = run_mode(scaling, args.steps, args.warmup, profile=True)
+    scaling_label = args.scaling  # at N = 1 both modes are the same 64-utterance step
+
+    extras = {}
+    if not args.no_extras and world > 1:  # the other mode, a few steps, for the record
+        other = "weak" if scaling == "strong" else "strong"
+        o = run_mode(other, max(2, min(args.steps, 5)), 1, profile=False)
+        extras["other_scaling"] = {"scaling": other, "value": round(o["b_total"] * T * o["steps"] / o["dt"], 1),
+                                   "unit": "frames/s", "ms_per_step": round(1e3 * o["dt"] / o["steps"], 3),
+                                   "batch_total": o["b_total"], "parallelism": o["par"]}
 
     if rank == 0:
+        dt, stage_ms, b_total, b_loc, rows_loc = head["dt"], head["stage_ms"], head["b_total"], head["b_loc"], head["rows_loc"]
         ms_per_step = 1e3 * dt / args.steps
         value = b_total * T * args.steps / dt
-        stage_ms = {k: v / args.steps for k, v in stage_ms.items()}
-        # dominant kernel: lstm_rec_kernel, launched twice per step (sub-band layers 0 and 1)
-        rows_loc = shard_bounds(b_total * F, 0, world)[1] if row_sharded else b_loc * F
+        # dominant kernel: the persistent sub-band recurrent kernel, launched twice per step (layers 0 and 1)
         rows_steps = float(rows_loc) * Tp
         rec_flops = 2.0 * (MAC_REC_L0 + MAC_REC_L1) * rows_steps  # both launches
-        rec_ms = stage_ms["sb_rec_l0"] + stage_ms["sb_rec_l1"]
+        rec_ms = stage_ms.get("sb_rec_l0", 0.0) + stage_ms.get("sb_rec_l1", 0.0)
         achieved = rec_flops / (rec_ms * 1e-3) / 1e12 if rec_ms > 0 else 0.0
         path_flops = 2.0 * (MAC_FB * b_loc + MAC_SB_PER_BIN * rows_loc) * Tp
         at_config2 = world == 1 and b_loc == 64 and length == 48000
+        traffic, mfma_busy, pmc_src = measured_counters() if at_config2 else (None, None, None)
         out = {
             "metric": "frames/sec (16 kHz, 512-FFT, hop 256), whole job", "value": round(value, 1),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling_label,
             "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" + (" (host buffers in and out over PCIe every step: --host-io)" if args.host_io else ""),
             "config": {"workload": f"FullSubNet inference (full_band_crm_mask path), 16 kHz, n_fft 512, hop 256, "
-                                   f"n_neighbour 15, look_ahead 2, batch {b_loc} x {args.seconds:g} s per GPU "
-                                   f"({b_total} utterances per step in total), offline_laplace_norm, full 257-bin "
-                                   f"mask per utterance",
+                                   f"n_neighbour 15, look_ahead 2, {b_total} x {args.seconds:g} s utterances per step "
+                                   f"({b_loc} per GPU), offline_laplace_norm, full 257-bin mask per utterance "
+                                   f"(BASELINE config 2" + (")" if b_total == 64 else f" at batch {b_total})"),
                        "batch_per_gpu": b_loc, "batch_total": b_total, "samples": length,
-                       "frames_per_utterance": T,
-                       "parallelism": (f"row-shard x{world} ({rows_loc} of {b_total * F} sub-band rows per rank) + "
-                                       f"all-gather of the mask" if row_sharded else
-                                       f"utterance-shard x{world}" + (" + all-gather" if world > 1 else ""))},
+                       "frames_per_utterance": T, "parallelism": head["par"]},
             "rtf_speedup_audio_s_per_s": round(value / (SR / HOP), 1),
             "rtf_classic": round((SR / HOP) / value, 6),
             "roofline": {"bound": "mfma", "kernel": "lstm_rec_kernel<384,RT,2,*> (sub-band recurrent; 2 launches/step)",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          # PMC passes are separate rocprofv3 runs at config 2 (B = 64, 1 GPU)
-                         "traffic": measured_traffic() if at_config2 else None,
+                         "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc)",
+                         "mfma_busy_frac": mfma_busy, "pmc_source": pmc_src,
                          "flops_per_launch": rec_flops / 2, "ms_per_launch": round(rec_ms / 2, 3),
                          "whole_path_frac": round(path_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         }
-        if not args.no_experimental and world == 1 and os.environ.get("FSN_F16X3") != "1":
-            torch.cuda.synchronize()
-            out["experimental_f16x3"] = experimental_f16x3(args)
+        out.update(extras)
+    if not args.no_extras and world == 1:
+        # the opt-in split-precision kernels (Model.arithmetic -> cfg.arith), reported NEXT TO `value`, never as it
+        model.arithmetic = "f16x3"
+        x = run_mode("weak", max(2, min(args.steps, 5)), 1, profile=True)
+        model.arithmetic = "f32"
+        out["experimental_f16x3"] = {
+            "switch": 'Model.arithmetic = "f16x3"', "value": round(x["b_total"] * T * x["steps"] / x["dt"], 1),
+            "unit": "frames/s", "ms_per_step": round(1e3 * x["dt"] / x["steps"], 3),
+            "stage_ms": {k: round(v, 3) for k, v in x["stage_ms"].items()},
+            "note": "opt-in (fp32 operands split into two fp16 halves, three 16-bit MFMAs per product block, fp32 "
+                    "accumulation); NOT the arithmetic of `value`"}
+        try:
+            out["train_step"] = training_step_ms(device)
+        except Exception as e:  # a side figure must never break the benchmark line
+            out["train_step"] = {"error": str(e)[:200]}
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
+            torch.cuda.synchronize()
             out["cpu_baseline"] = cpu_baseline(params, length, args.cpu_budget)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None  # reported at N = 1 only

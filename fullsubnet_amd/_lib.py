@@ -23,7 +23,18 @@ class FsnError(RuntimeError):
 
 class Cfg(ctypes.Structure):
     _fields_ = [("num_freqs", ctypes.c_int), ("look_ahead", ctypes.c_int), ("sb_num_neighbors", ctypes.c_int),
-                ("fb_hidden", ctypes.c_int), ("sb_hidden", ctypes.c_int), ("norm_type", ctypes.c_int)]
+                ("fb_hidden", ctypes.c_int), ("sb_hidden", ctypes.c_int), ("norm_type", ctypes.c_int),
+                ("arith", ctypes.c_int)]
+
+
+# FSN_ARITH_* of include/fsn_hip.h.  "f32" is the default and what every parity claim refers to; "f16x3" is
+# the opt-in split-precision experiment (Model.arithmetic = "f16x3", or FSN_F16X3=1 in the environment of the
+# HOST process - the library itself reads no environment variables).
+ARITH = {"f32": 0, "f16x3": 1}
+
+
+def default_arith():
+    return "f16x3" if os.environ.get("FSN_F16X3", "")[:1] == "1" else "f32"
 
 
 PARAM_FIELDS = [
@@ -77,6 +88,8 @@ SIGNATURES = {
     "fsn_fullsubnet_workspace_bytes": (_c.c_size_t, [_c.POINTER(Cfg), _c.c_int, _c.c_int]),
     "fsn_fullsubnet_forward": (_c.c_int, [_c.POINTER(Cfg), _c.c_void_p, _f32p, _c.c_int, _c.c_int, _f32p, _c.c_void_p,
                                           _c.c_size_t, _c.c_void_p]),
+    "fsn_fullsubnet_fullband": (_c.c_int, [_c.POINTER(Cfg), _c.c_void_p, _f32p, _c.c_int, _c.c_int, _f32p, _c.c_void_p,
+                                           _c.c_size_t, _c.c_void_p]),
     "fsn_fullsubnet_rows_workspace_bytes": (_c.c_size_t, [_c.POINTER(Cfg), _c.c_int, _c.c_int, _c.c_long, _c.c_long]),
     "fsn_fullsubnet_forward_rows": (_c.c_int, [_c.POINTER(Cfg), _c.c_void_p, _f32p, _c.c_int, _c.c_int, _c.c_long,
                                                _c.c_long, _f32p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
@@ -128,7 +141,7 @@ SIGNATURES = {
     "fsn_profile_enable": (_c.c_int, [_c.c_int]),
     "fsn_profile_num_stages": (_c.c_int, []),
     "fsn_profile_stage_name": (_c.c_char_p, [_c.c_int]),
-    "fsn_profile_read": (_c.c_int, [_c.POINTER(_c.c_float), _c.c_int]),
+    "fsn_profile_read": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_float), _c.c_int]),
 }
 
 
@@ -185,9 +198,10 @@ def profile_stage_names():
     return [L.fsn_profile_stage_name(i).decode() for i in range(L.fsn_profile_num_stages())]
 
 
-def profile_read():
+def profile_read(device=None):
+    """Stage times (ms) of the last profiled call on the current stream of `device`."""
     L = lib()
     n = L.fsn_profile_num_stages()
     buf = (ctypes.c_float * n)()
-    check(L.fsn_profile_read(buf, n))
+    check(L.fsn_profile_read(stream_ptr(device), buf, n))
     return dict(zip(profile_stage_names(), list(buf)))

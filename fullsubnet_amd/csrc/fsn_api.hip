@@ -1,11 +1,17 @@
 // C ABI of libfsn_hip.so (see include/fsn_hip.h): argument validation, workspace carving and the
-// kernel sequence of the FullSubNet enhancement path.  No allocation, no host synchronisation and
-// no global state on the hot path (the optional per-stage profiler owns a few hipEvents).
+// kernel sequence of the FullSubNet enhancement path.  No allocation and no host synchronisation on the hot
+// path.  The only state the library owns is a small per-(device, caller stream) record - an auxiliary
+// stream with its fork / join events for the left-over sub-band tiles and the events of the optional
+// per-stage profiler - created on first use and never shared between two caller streams or two devices.
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
 
 #include <stdlib.h>
+
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "fsn_common.h"
 
@@ -51,59 +57,121 @@ enum Stage {
 };
 static const char* kStageNames[ST_COUNT] = {"stft",       "norm",       "fb_gemm",    "fb_rec", "sb_gemm_l0",
                                             "sb_rec_l0",  "sb_gemm_l1", "sb_rec_l1",  "sb_fc",  "mask_istft"};
-static int g_prof_on = 0;
 constexpr int kMaxSpans = 4;  // a stage may be entered several times per call (once per layer)
-static hipEvent_t g_ev[ST_COUNT][kMaxSpans][2];
-static bool g_ev_made = false;
-static int g_spans[ST_COUNT];
+
+// ---- per-(device, caller stream) state ---------------------------------------------------------------
+// Everything a call needs beyond its arguments.  Two caller streams (or two devices, or two host threads that
+// each drive their own stream) never see each other's events; calls that share ONE stream must be issued
+// from one thread at a time, like any stream-ordered API.
+struct StreamCtx {
+    int dev = 0;
+    hipStream_t aux = nullptr;           // left-over sub-band tiles beside the persistent kernel
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool prof_events = false;            // profiler events exist
+    hipEvent_t ev[ST_COUNT][kMaxSpans][2];
+    int spans[ST_COUNT] = {0};
+};
+static std::mutex g_ctx_mutex;
+static std::map<std::pair<int, hipStream_t>, StreamCtx*> g_ctx;
+static int g_prof_on = 0;  // process-wide request (a debugging switch); its events live in the StreamCtx
+
+// What the running call works on (set by CallScope for the duration of one entry point on this host thread).
+static thread_local StreamCtx* t_ctx = nullptr;
+static thread_local hipStream_t t_stream = nullptr;
+static thread_local int t_dev = 0;
+
+static StreamCtx* ctx_lookup(int dev, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    StreamCtx*& c = g_ctx[std::make_pair(dev, s)];
+    if (!c) {
+        c = new StreamCtx();
+        c->dev = dev;
+    }
+    return c;
+}
+static StreamCtx* cur_ctx() {
+    if (!t_ctx) t_ctx = ctx_lookup(t_dev, t_stream);
+    return t_ctx;
+}
+
+// Every entry point that enqueues work opens one of these: the device the caller's stream belongs to becomes
+// the current device for the duration of the call (restored afterwards), so that a process that drives several
+// GPUs needs no device bookkeeping around the C ABI, and the per-stream record is resolved lazily.
+FsnCallScope::FsnCallScope(void* stream) : prev(-1), switched(false) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    hipDevice_t sd = cur;
+    if (s && hipStreamGetDevice(s, &sd) != hipSuccess) {
+        (void)hipGetLastError();
+        sd = cur;
+    }
+    if ((int)sd != cur && hipSetDevice((int)sd) == hipSuccess) {
+        prev = cur;
+        switched = true;
+    }
+    t_dev = (int)sd;
+    t_stream = s;
+    t_ctx = nullptr;
+}
+FsnCallScope::~FsnCallScope() {
+    t_ctx = nullptr;
+    if (switched) (void)hipSetDevice(prev);
+}
+typedef FsnCallScope CallScope;
 
 struct StageTimer {
     int st, span;
     hipStream_t s;
-    StageTimer(int stage, hipStream_t stream) : st(stage), span(-1), s(stream) {
+    StreamCtx* c;
+    StageTimer(int stage, hipStream_t stream) : st(stage), span(-1), s(stream), c(nullptr) {
         if (!g_prof_on) return;
-        if (!g_ev_made) {
+        c = cur_ctx();
+        if (!c->prof_events) {
             for (int i = 0; i < ST_COUNT; ++i)
                 for (int j = 0; j < kMaxSpans; ++j) {
-                    (void)hipEventCreate(&g_ev[i][j][0]);
-                    (void)hipEventCreate(&g_ev[i][j][1]);
+                    (void)hipEventCreate(&c->ev[i][j][0]);
+                    (void)hipEventCreate(&c->ev[i][j][1]);
                 }
-            g_ev_made = true;
+            c->prof_events = true;
         }
-        if (g_spans[st] >= kMaxSpans) return;
-        span = g_spans[st];
-        (void)hipEventRecord(g_ev[st][span][0], s);
+        if (c->spans[st] >= kMaxSpans) return;
+        span = c->spans[st];
+        (void)hipEventRecord(c->ev[st][span][0], s);
     }
     ~StageTimer() {
         if (span < 0) return;
-        (void)hipEventRecord(g_ev[st][span][1], s);
-        g_spans[st] = span + 1;
+        (void)hipEventRecord(c->ev[st][span][1], s);
+        c->spans[st] = span + 1;
     }
 };
 static void prof_reset() {
-    for (int i = 0; i < ST_COUNT; ++i) g_spans[i] = 0;
+    if (!g_prof_on) return;
+    StreamCtx* c = cur_ctx();
+    for (int i = 0; i < ST_COUNT; ++i) c->spans[i] = 0;
 }
 extern "C" int fsn_profile_enable(int on) {
     g_prof_on = on ? 1 : 0;
-    prof_reset();
     return FSN_OK;
 }
 extern "C" int fsn_profile_num_stages(void) { return ST_COUNT; }
 extern "C" const char* fsn_profile_stage_name(int stage) {
     return (stage >= 0 && stage < ST_COUNT) ? kStageNames[stage] : "";
 }
-// Milliseconds per stage of the LAST profiled call; waits for that call's events only.
-extern "C" int fsn_profile_read(float* ms, int n) {
+// Milliseconds per stage of the LAST profiled call on `stream`; waits for that call's events only.
+extern "C" int fsn_profile_read(void* stream, float* ms, int n) {
     if (!ms || n < ST_COUNT) {
         fsn_set_error("fsn_profile_read: need room for %d stages", (int)ST_COUNT);
         return FSN_ERR_ARG;
     }
+    CallScope scope(stream);
+    StreamCtx* c = cur_ctx();
     for (int i = 0; i < ST_COUNT; ++i) {
         float v = 0.f;
-        for (int j = 0; j < g_spans[i]; ++j) {
+        for (int j = 0; j < c->spans[i]; ++j) {
             float e = 0.f;
-            if (hipEventSynchronize(g_ev[i][j][1]) != hipSuccess ||
-                hipEventElapsedTime(&e, g_ev[i][j][0], g_ev[i][j][1]) != hipSuccess) {
+            if (hipEventSynchronize(c->ev[i][j][1]) != hipSuccess ||
+                hipEventElapsedTime(&e, c->ev[i][j][0], c->ev[i][j][1]) != hipSuccess) {
                 fsn_set_error("fsn_profile_read: event query failed for stage %s", kStageNames[i]);
                 return FSN_ERR_LAUNCH;
             }
@@ -140,6 +208,7 @@ static int check_cfg(const fsn_fullsubnet_cfg* cfg) {
                 cfg->sb_hidden);
     FSN_REQUIRE(cfg->norm_type == FSN_NORM_OFFLINE_LAPLACE || cfg->norm_type == FSN_NORM_CUMULATIVE_LAPLACE,
                 "norm_type %d unsupported", cfg->norm_type);
+    FSN_REQUIRE(cfg->arith == FSN_ARITH_F32 || cfg->arith == FSN_ARITH_F16X3, "arith %d unsupported", cfg->arith);
     return FSN_OK;
 }
 
@@ -200,6 +269,7 @@ extern "C" size_t fsn_fullsubnet_packed_bytes(const fsn_fullsubnet_cfg* cfg) {
 
 extern "C" int fsn_fullsubnet_pack(const fsn_fullsubnet_cfg* cfg, const fsn_fullsubnet_params* w, void* packed,
                                    size_t packed_bytes, void* stream) {
+    CallScope scope(stream);
     FSN_TRY(check_cfg(cfg));
     FSN_REQUIRE(w && packed, "params / packed is NULL");
     const float* const* all = reinterpret_cast<const float* const*>(w);
@@ -297,17 +367,15 @@ static CoreWs core_carve(Carver& cv, const CoreDims& d, int norm_type) {
 }
 
 // ---- auxiliary stream for the left-over sub-band rows (see fsn_lstm_rec_plan) -------------------
-// Created lazily, once per process; besides the profiler's events this is the only state the
-// library owns.  The fork/join below uses events only, so it is also legal under stream capture.
-static hipStream_t g_aux_stream = nullptr;
-static hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
-static int aux_init() {
-    if (g_aux_stream) return FSN_OK;
-    if (hipStreamCreateWithFlags(&g_aux_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming) != hipSuccess) {
+// One per (device, caller stream), created lazily on the caller stream's device (StreamCtx).  The fork / join
+// below uses events only, so it is also legal under stream capture.
+static int aux_init(StreamCtx* c) {
+    if (c->aux) return FSN_OK;
+    if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         fsn_set_error("cannot create the auxiliary stream / events");
-        g_aux_stream = nullptr;
+        c->aux = nullptr;
         return FSN_ERR_LAUNCH;
     }
     return FSN_OK;
@@ -328,13 +396,15 @@ static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* g
     const int aux_tiles = r.left_tiles - cu_tiles;
     const bool fork = aux_tiles > 0 && (r.main_wgs > 0 || cu_tiles > 0);
     hipStream_t ls = s;
+    StreamCtx* cx = nullptr;
     if (fork) {
-        FSN_TRY(aux_init());
-        if (hipEventRecord(g_ev_fork, s) != hipSuccess || hipStreamWaitEvent(g_aux_stream, g_ev_fork, 0) != hipSuccess) {
+        cx = cur_ctx();
+        FSN_TRY(aux_init(cx));
+        if (hipEventRecord(cx->ev_fork, s) != hipSuccess || hipStreamWaitEvent(cx->aux, cx->ev_fork, 0) != hipSuccess) {
             fsn_set_error("aux stream fork failed");
             return FSN_ERR_LAUNCH;
         }
-        ls = g_aux_stream;
+        ls = cx->aux;
     }
     if (r.main_wgs > 0) {
         if (whh_f16x3 && fc && !xin && r.rt >= 2)  // experimental split-precision persistent kernel (FSN_F16X3=1)
@@ -363,7 +433,7 @@ static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* g
         }
     }
     if (fork) {
-        if (hipEventRecord(g_ev_join, g_aux_stream) != hipSuccess || hipStreamWaitEvent(s, g_ev_join, 0) != hipSuccess) {
+        if (hipEventRecord(cx->ev_join, cx->aux) != hipSuccess || hipStreamWaitEvent(s, cx->ev_join, 0) != hipSuccess) {
             fsn_set_error("aux stream join failed");
             return FSN_ERR_LAUNCH;
         }
@@ -385,7 +455,7 @@ static int run_sb_recurrence(const float* gx, const FsnSbInput* xin, const float
 constexpr int kWavefrontBelowTiles = 96;
 
 static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float* magT, const CoreDims& d,
-                    const CoreWs& w, float* crm_r, float* crm_i, hipStream_t s) {
+                    const CoreWs& w, float* crm_r, float* crm_i, hipStream_t s, bool fullband_only = false) {
     const Packed p = packed_layout(cfg);
     const bool cum = cfg->norm_type == FSN_NORM_CUMULATIVE_LAPLACE;
 
@@ -446,6 +516,7 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         c.Npad = d.Npad_fb;
         FSN_TRY(fsn_launch_gemm(a, pk + p.fb_fc, c, fb_rt, d.FP / 16, d.Hf / 16, s));
     }
+    if (fullband_only) return FSN_OK;  // fsn_fullsubnet_fullband: w.fb_out is the result
     // sub-band norm divisor over the (virtual) concatenated sub-band input (model.py:110-111)
     {
         StageTimer st(ST_NORM, s);
@@ -510,7 +581,7 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         xin.N = d.N;
         xin.nb = d.nb;
         xin.kin_chunks = p.sb_kin_pad / 16;
-        static const bool f16x3 = getenv("FSN_F16X3") && getenv("FSN_F16X3")[0] == '1';  // experimental
+        const bool f16x3 = cfg->arith == FSN_ARITH_F16X3;  // opt-in experiment, chosen by the caller
         const bool l0_split = f16x3 && d.Hs == 384 && 2 * d.nb + 2 == 32;
         FSN_TRY(run_sb_recurrence(nullptr, &xin, w.gx_sb, d.rec.left_tiles, 0, pk + p.sb_whh0, w.hseq_sb0, w.c_left,
                                   d, s, nullptr, l0_split ? pk + p.sb_whh0_f16x3 : nullptr,
@@ -526,7 +597,7 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         c.kind = 0;
         c.p0 = w.gx_sb;
         c.bias = pk + p.sb_b1;
-        static const bool f16x3 = getenv("FSN_F16X3") && getenv("FSN_F16X3")[0] == '1';  // experimental, see the kernel file
+        const bool f16x3 = cfg->arith == FSN_ARITH_F16X3;  // opt-in experiment, chosen by the caller
         if (f16x3)
             FSN_TRY(fsn_launch_gemm_f16x3(w.hseq_sb0, d.Hs, pk + p.sb_wih1_f16x3, pk + p.sb_b1, w.gx_sb, sb_rt, 4 * d.Hs,
                                           d.Hs, s));
@@ -552,7 +623,7 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
     }
     if (!sb_wave) {
         StageTimer st(ST_SB_REC_L1, s);
-        static const bool f16x3 = getenv("FSN_F16X3") && getenv("FSN_F16X3")[0] == '1';  // experimental
+        const bool f16x3 = cfg->arith == FSN_ARITH_F16X3;  // opt-in experiment, chosen by the caller
         FSN_TRY(run_sb_recurrence(w.gx_sb, nullptr, w.gx_sb, d.rec.tiles, main_rows / 16, pk + p.sb_whh1, w.hseq_sb1,
                                   w.c_left, d, s, fc_fused ? &fc : nullptr,
                                   f16x3 && fc_fused ? pk + p.sb_whh1_f16x3 : nullptr));
@@ -606,6 +677,7 @@ extern "C" size_t fsn_fullsubnet_workspace_bytes(const fsn_fullsubnet_cfg* cfg, 
 extern "C" int fsn_fullsubnet_forward(const fsn_fullsubnet_cfg* cfg, const void* packed, const float* noisy_mag,
                                       int B, int T, float* crm_out, void* workspace, size_t workspace_bytes,
                                       void* stream) {
+    CallScope scope(stream);
     FSN_TRY(check_cfg(cfg));
     FSN_TRY(check_bt(B, T));
     FSN_REQUIRE(packed && noisy_mag && crm_out && workspace, "NULL pointer argument");
@@ -629,6 +701,37 @@ extern "C" int fsn_fullsubnet_forward(const fsn_fullsubnet_cfg* cfg, const void*
     FSN_TRY(fsn_launch_transpose(crm_r, crm_out, B, T, d.F, d.FP, (long)T * d.FP, T, 2L * d.F * T, T, d.F, s));
     FSN_TRY(fsn_launch_transpose(crm_i, crm_out + (size_t)d.F * T, B, T, d.F, d.FP, (long)T * d.FP, T, 2L * d.F * T,
                                  T, d.F, s));
+    return FSN_OK;
+}
+
+// ---- the full-band stage alone: model.py:85-95 ---------------------------------------------------
+// look-ahead pad -> norm -> fb_model, i.e. the tensor `fb_output` of model.py:95 in the reference's layout
+// [B, F, T + look_ahead].  Stage-level parity checks read it; a batch-sharded full-band model would too.
+extern "C" int fsn_fullsubnet_fullband(const fsn_fullsubnet_cfg* cfg, const void* packed, const float* noisy_mag,
+                                       int B, int T, float* fb_output, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    CallScope scope(stream);
+    FSN_TRY(check_cfg(cfg));
+    FSN_TRY(check_bt(B, T));
+    FSN_REQUIRE(packed && noisy_mag && fb_output && workspace, "NULL pointer argument");
+    const size_t need = fsn_fullsubnet_workspace_bytes(cfg, B, T);
+    if (workspace_bytes < need) {
+        fsn_set_error("workspace too small: %zu < %zu bytes", workspace_bytes, need);
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const CoreDims d = core_dims(cfg, B, T);
+    Carver cv(workspace);
+    float* magT = cv.take<float>((size_t)B * d.Tp * d.FP);
+    cv.take<float>((size_t)B * d.T * d.FP);
+    cv.take<float>((size_t)B * d.T * d.FP);
+    const CoreWs w = core_carve(cv, d, cfg->norm_type);
+    prof_reset();
+    FSN_TRY(fsn_launch_transpose(noisy_mag, magT, B, d.FP, d.Tp, T, (long)d.F * T, d.FP, (long)d.Tp * d.FP, d.F, T, s));
+    FSN_TRY(run_core(cfg, static_cast<const float*>(packed), magT, d, w, nullptr, nullptr, s, true));
+    // frame-major [B][T'][FP] -> [B, F, T']
+    FSN_TRY(fsn_launch_transpose(w.fb_out, fb_output, B, d.Tp, d.F, d.FP, (long)d.Tp * d.FP, d.Tp, (long)d.F * d.Tp,
+                                 d.Tp, d.F, s));
     return FSN_OK;
 }
 
@@ -669,6 +772,7 @@ extern "C" size_t fsn_fullsubnet_rows_workspace_bytes(const fsn_fullsubnet_cfg* 
 extern "C" int fsn_fullsubnet_forward_rows(const fsn_fullsubnet_cfg* cfg, const void* packed, const float* noisy_mag,
                                            int B, int T, long row_begin, long row_end, float* crm_rows,
                                            void* workspace, size_t workspace_bytes, void* stream) {
+    CallScope scope(stream);
     FSN_TRY(check_cfg(cfg));
     FSN_TRY(check_bt(B, T));
     RowSlice r;
@@ -762,6 +866,7 @@ extern "C" size_t fsn_fullsubnet_stream_workspace_bytes(const fsn_fullsubnet_cfg
 extern "C" int fsn_fullsubnet_stream_step(const fsn_fullsubnet_cfg* cfg, const void* packed, void* state,
                                           size_t state_bytes, int steps_done, const float* mag, int B, int k,
                                           float* crm_out, void* workspace, size_t workspace_bytes, void* stream) {
+    CallScope scope(stream);
     FSN_TRY(check_stream(cfg, B, k));
     FSN_REQUIRE(packed && state && mag && crm_out && workspace && steps_done >= 0, "NULL pointer argument / negative step count");
     if (state_bytes < fsn_fullsubnet_stream_state_bytes(cfg, B) ||
@@ -879,6 +984,7 @@ static int check_fft_generic(int n_fft, int hop, int win_length) {
 
 extern "C" int fsn_stft(const float* y, int B, int L, int n_fft, int hop, int win_length, const float* window,
                         float* real, float* imag, float* mag, void* stream) {
+    CallScope scope(stream);
     FSN_TRY(check_fft_generic(n_fft, hop, win_length));
     FSN_REQUIRE(y && window, "NULL pointer argument");
     FSN_REQUIRE(B >= 1 && L > n_fft / 2, "need B >= 1 and L > n_fft/2 (reflect padding), got B=%d L=%d", B, L);
@@ -898,6 +1004,7 @@ extern "C" size_t fsn_istft_workspace_bytes(int B, int T, int n_fft) {
 extern "C" int fsn_istft(const float* real, const float* imag, int B, int T, int n_fft, int hop, int win_length,
                          const float* window, int length, float* y, void* workspace, size_t workspace_bytes,
                          void* stream) {
+    CallScope scope(stream);
     FSN_TRY(check_fft_generic(n_fft, hop, win_length));
     FSN_TRY(check_bt(B, T));
     FSN_REQUIRE(real && imag && window && y && workspace, "NULL pointer argument");
@@ -916,15 +1023,18 @@ extern "C" int fsn_istft(const float* real, const float* imag, int B, int T, int
 
 // ---- elementwise boundary --------------------------------------------------------------------
 extern "C" int fsn_decompress_cirm(const float* mask, float* out, size_t n, void* stream) {
+    CallScope scope(stream);
     FSN_REQUIRE(mask && out, "NULL pointer argument");
     return n ? fsn_launch_decompress(mask, out, n, static_cast<hipStream_t>(stream)) : FSN_OK;
 }
 extern "C" int fsn_compress_cirm(const float* mask, float* out, size_t n, void* stream) {
+    CallScope scope(stream);
     FSN_REQUIRE(mask && out, "NULL pointer argument");
     return n ? fsn_launch_compress(mask, out, n, static_cast<hipStream_t>(stream)) : FSN_OK;
 }
 extern "C" int fsn_build_cirm(const float* nr, const float* ni, const float* cr, const float* ci, float* out,
                               size_t n, void* stream) {
+    CallScope scope(stream);
     FSN_REQUIRE(nr && ni && cr && ci && out, "NULL pointer argument");
     return n ? fsn_launch_build_cirm(nr, ni, cr, ci, out, n, static_cast<hipStream_t>(stream)) : FSN_OK;
 }
@@ -949,6 +1059,7 @@ extern "C" size_t fsn_enhance_workspace_bytes(const fsn_fullsubnet_cfg* cfg, int
 extern "C" int fsn_enhance(const fsn_fullsubnet_cfg* cfg, const void* packed, const float* window,
                            const float* noisy, int B, int L, int n_fft, int hop, float* enhanced, float* crm_out,
                            void* workspace, size_t workspace_bytes, void* stream) {
+    CallScope scope(stream);
     FSN_TRY(check_cfg(cfg));
     FSN_TRY(check_fft(n_fft, hop, n_fft));
     FSN_REQUIRE(packed && window && noisy && enhanced && workspace, "NULL pointer argument");
@@ -1039,6 +1150,7 @@ extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_i
                                       const float* b_ih, const float* b_hh, int T, int N, int I, int H, float* hseq,
                                       void* save, size_t save_bytes, void* workspace, size_t workspace_bytes,
                                       void* stream) {
+    CallScope scope(stream);
     FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
     FSN_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && hseq && workspace, "NULL pointer argument");
     if ((save && save_bytes < fsn_lstm_layer_save_bytes(T, N, H)) ||
@@ -1120,6 +1232,7 @@ extern "C" int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, c
                                  const float* b_hh0, const float* w_ih1, const float* w_hh1, const float* b_ih1,
                                  const float* b_hh1, int T, int N, int I, int H0, int H1, float* hseq1, void* workspace,
                                  size_t workspace_bytes, void* stream) {
+    CallScope scope(stream);
     FSN_TRY(check_lstm_layer(T, N, I, H0, ldx));
     FSN_REQUIRE(H1 >= 64 && H1 % 64 == 0, "lstm2: second hidden size %d must be a multiple of 64", H1);
     FSN_REQUIRE(x && w_ih0 && w_hh0 && b_ih0 && b_hh0 && w_ih1 && w_hh1 && b_ih1 && b_hh1 && hseq1 && workspace,
@@ -1182,6 +1295,7 @@ extern "C" size_t fsn_lstm_layer_packed_bytes(int I, int H) {
 }
 extern "C" int fsn_lstm_layer_pack(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int I,
                                    int H, void* packed, size_t packed_bytes, void* stream) {
+    CallScope scope(stream);
     FSN_REQUIRE(w_ih && w_hh && b_ih && b_hh && packed, "NULL pointer argument");
     FSN_REQUIRE(I >= 1 && H >= 64 && H % 64 == 0, "lstm layer: need I >= 1 and H a multiple of 64 (got %d, %d)", I, H);
     if (packed_bytes < fsn_lstm_layer_packed_bytes(I, H)) {
@@ -1201,6 +1315,7 @@ extern "C" size_t fsn_lstm_layer_state_workspace_bytes(int T, int N, int H) {
 extern "C" int fsn_lstm_layer_forward_state(const float* x, long ldx, const void* packed, int T, int N, int I, int H,
                                             float* hseq, float* h_state, float* c_state, void* workspace,
                                             size_t workspace_bytes, void* stream) {
+    CallScope scope(stream);
     FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
     FSN_REQUIRE(x && packed && hseq && h_state && c_state && workspace, "NULL pointer argument");
     if (workspace_bytes < fsn_lstm_layer_state_workspace_bytes(T, N, H)) {
@@ -1252,6 +1367,7 @@ extern "C" int fsn_lstm_layer_backward(const float* dh, const float* x, long ldx
                                        const float* w_hh, int T, int N, int I, int H, const float* hseq,
                                        const void* save, float* dx, long lddx, float* dw_ih, float* dw_hh, float* db,
                                        void* workspace, size_t workspace_bytes, void* stream) {
+    CallScope scope(stream);
     FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
     FSN_REQUIRE(dh && x && w_ih && w_hh && hseq && save && dw_ih && dw_hh && db && workspace, "NULL pointer argument");
     FSN_REQUIRE(!dx || lddx >= I, "dx row stride %ld < I", lddx);
@@ -1327,6 +1443,7 @@ extern "C" size_t fsn_gru_layer_fwd_workspace_bytes(int T, int N, int I, int H) 
 extern "C" int fsn_gru_layer_forward(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
                                      const float* b_hh, int T, int N, int I, int H, float* hseq, void* save,
                                      size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+    CallScope scope(stream);
     FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
     FSN_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && hseq && workspace, "NULL pointer argument");
     if ((save && save_bytes < fsn_gru_layer_save_bytes(T, N, H)) ||
@@ -1383,6 +1500,7 @@ extern "C" int fsn_gru_layer_backward(const float* dh, const float* x, long ldx,
                                       int T, int N, int I, int H, const float* hseq, const void* save, float* dx,
                                       long lddx, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, void* workspace,
                                       size_t workspace_bytes, void* stream) {
+    CallScope scope(stream);
     FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
     FSN_REQUIRE(dh && x && w_ih && w_hh && hseq && save && dw_ih && dw_hh && db_ih && db_hh && workspace,
                 "NULL pointer argument");
@@ -1457,6 +1575,7 @@ extern "C" size_t fsn_linear_workspace_bytes(int R, int I, int O) {
 
 extern "C" int fsn_linear_forward(const float* x, long ldx, const float* w, const float* b, int R, int I, int O,
                                   int relu, float* y, void* workspace, size_t workspace_bytes, void* stream) {
+    CallScope scope(stream);
     FSN_REQUIRE(x && w && b && y && workspace, "NULL pointer argument");
     FSN_REQUIRE(R >= 1 && I >= 1 && O >= 1 && ldx >= fsn_round_up(I, 16) && ldx % 4 == 0, "linear: bad shape");
     if (workspace_bytes < fsn_linear_workspace_bytes(R, I, O)) {
@@ -1490,6 +1609,7 @@ extern "C" int fsn_linear_forward(const float* x, long ldx, const float* w, cons
 extern "C" int fsn_linear_backward(const float* dy, long lddy, const float* x, long ldx, const float* w, int R, int I,
                                    int O, float* dx, long lddx, float* dw, float* db, void* workspace,
                                    size_t workspace_bytes, void* stream) {
+    CallScope scope(stream);
     FSN_REQUIRE(dy && x && w && dw && db && workspace, "NULL pointer argument");
     FSN_REQUIRE(R >= 1 && I >= 1 && O >= 1 && lddy >= fsn_round_up(O, 16) && lddy % 4 == 0 && ldx >= I,
                 "linear backward: bad shape");

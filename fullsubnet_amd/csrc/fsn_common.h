@@ -18,6 +18,15 @@ static inline size_t fsn_round_up_sz(size_t x, size_t m) { return (x + m - 1) / 
 static inline int fsn_fpad(int F) { return fsn_round_up(F, 16); }
 
 void fsn_set_error(const char* fmt, ...);
+
+// Opened by every entry point that enqueues work (fsn_api.hip): makes the device of the caller's stream the
+// current one for the duration of the call and selects the per-(device, stream) record of the library.
+struct FsnCallScope {
+    int prev;
+    bool switched;
+    explicit FsnCallScope(void* stream);
+    ~FsnCallScope();
+};
 int fsn_check_launch(const char* what);
 
 #define FSN_TRY_LAUNCH(what)                        \

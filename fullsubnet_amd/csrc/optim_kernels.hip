@@ -156,6 +156,7 @@ extern "C" size_t fsn_clip_adam_workspace_bytes(int n_tensors, const size_t* num
 extern "C" int fsn_clip_adam_step(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                                   float* const* exp_avg_sq, const size_t* numel, const fsn_adam_cfg* cfg,
                                   float* total_norm_out, void* workspace, size_t workspace_bytes, void* stream) {
+    FsnCallScope scope(stream);
     FSN_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel && cfg && workspace, "NULL pointer argument");
     FSN_REQUIRE(n_tensors >= 1 && n_tensors <= kMaxTensors, "clip_adam: 1..%d tensors per call (got %d)", kMaxTensors,
                 n_tensors);
@@ -196,6 +197,7 @@ extern "C" size_t fsn_mse_loss_workspace_bytes(size_t n) {
 
 extern "C" int fsn_mse_loss(const float* input, const float* target, size_t n, float* loss, float* grad_input,
                             void* workspace, size_t workspace_bytes, void* stream) {
+    FsnCallScope scope(stream);
     FSN_REQUIRE(input && target && loss && workspace, "NULL pointer argument");
     FSN_REQUIRE(n >= 1, "mse_loss: empty input");
     if (workspace_bytes < fsn_mse_loss_workspace_bytes(n)) {

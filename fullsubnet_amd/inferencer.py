@@ -69,7 +69,7 @@ class Inferencer:
     @staticmethod
     def _load_model(model_config, checkpoint_path, device):
         model = initialize_module(model_config["path"], args=model_config["args"])
-        checkpoint = torch.load(Path(checkpoint_path).expanduser().absolute(), map_location="cpu")
+        checkpoint = torch.load(Path(checkpoint_path).expanduser().absolute(), map_location="cpu", weights_only=False)
         state = {k.replace("module.", ""): v for k, v in checkpoint["model"].items()}  # DDP prefix
         model.load_state_dict(state)  # strict
         return model.to(device).eval(), checkpoint["epoch"]

@@ -41,11 +41,22 @@ class Model(nn.Module):
         self.norm_type = norm_type
         self.num_groups_in_drop_band = num_groups_in_drop_band
         self._cfg = _lib.Cfg(num_freqs, look_ahead, sb_num_neighbors, fb_model_hidden_size, sb_model_hidden_size,
-                             _lib.NORM_TYPES.get(norm_type, 0))
+                             _lib.NORM_TYPES.get(norm_type, 0), _lib.ARITH[_lib.default_arith()])
         self._packed = None
         self._packed_key = None
         if weight_init:
             self.apply(self.weight_init)
+
+    @property
+    def arithmetic(self):
+        """"f32" (default: fp32 MFMA, what every parity claim refers to) or "f16x3" (opt-in experiment)."""
+        return {v: k for k, v in _lib.ARITH.items()}[self._cfg.arith]
+
+    @arithmetic.setter
+    def arithmetic(self, name):
+        if name not in _lib.ARITH:
+            raise _lib.FsnError(f"unknown arithmetic {name!r} (choose from {sorted(_lib.ARITH)})")
+        self._cfg.arith = _lib.ARITH[name]
 
     # base_model.py:374-439 (pure initialisation, no kernels involved)
     @staticmethod
@@ -53,7 +64,7 @@ class Model(nn.Module):
         if isinstance(m, nn.Linear):
             nn.init.xavier_normal_(m.weight.data)
             nn.init.normal_(m.bias.data)
-        elif isinstance(m, nn.LSTM):
+        elif isinstance(m, (nn.LSTM, nn.GRU)):  # base_model.py:416-421: both recurrent cell types
             for param in m.parameters():
                 if len(param.shape) >= 2:
                     nn.init.orthogonal_(param.data)
@@ -109,6 +120,24 @@ class Model(nn.Module):
             # model.py:114-119 drops bands for any B > 1; rows of the sub-band model are independent
             # and the norm statistics are taken before the drop, so selecting afterwards is identical.
             out = drop_band(out, num_groups=self.num_groups_in_drop_band)
+        return out
+
+    @torch.no_grad()
+    def fullband_output(self, noisy_mag):
+        """The intermediate ``fb_output`` of fullsubnet/model.py:95 (look-ahead pad -> norm -> fb_model):
+        noisy_mag [B, 1, F, T] -> [B, F, T + look_ahead].  Stage-level parity checks; fused configurations only."""
+        assert noisy_mag.dim() == 4
+        B, C, F, T = noisy_mag.size()
+        assert C == 1 and F == self.num_freqs
+        if not self._fused:
+            raise _lib.FsnError("fullband_output is built for the fused configurations (shipped TOMLs)")
+        x = noisy_mag.contiguous()
+        L = _lib.lib()
+        out = torch.empty((B, F, T + self.look_ahead), dtype=torch.float32, device=x.device)
+        ws = _lib.workspace(L.fsn_fullsubnet_workspace_bytes(ctypes.byref(self._cfg), B, T), x.device)
+        _lib.check(L.fsn_fullsubnet_fullband(ctypes.byref(self._cfg), self.packed_weights().data_ptr(),
+                                             _lib.dev_ptr(x, "noisy_mag"), B, T, _lib.dev_ptr(out), ws.data_ptr(),
+                                             ws.numel(), _lib.stream_ptr(x.device)))
         return out
 
     @torch.no_grad()

@@ -6,7 +6,14 @@ Mirror of the two calls at recipes/dns_interspeech_2020/fullsubnet/trainer.py:65
 `ClipAdam.step()` runs both in two multi-tensor launches (`fsn_clip_adam_step`).  It subclasses
 `torch.optim.Optimizer`, keeps torch.optim.Adam's state layout (`step`, `exp_avg`, `exp_avg_sq`), so
 `state_dict()` / `load_state_dict()` interoperate with the reference's checkpoints
-(base_trainer.py:134,185 save / restore `optimizer.state_dict()`).
+(base_trainer.py:134,185 save / restore `optimizer.state_dict()`): a loaded torch.optim.Adam group lacks
+`clip_grad_norm_value` (read with a default of 0 = no clipping until train_step sets it) and must have
+`weight_decay == 0`, `amsgrad == False`, `maximize == False` - the recipe's settings (train.py:55-59); anything
+else is rejected instead of being silently ignored.
+
+The parameters are updated through raw device pointers, which autograd's version counters do not see; `step()`
+therefore bumps every updated parameter's version itself, so that the packed-weight caches of the inference
+path (keyed on data_ptr / _version) are rebuilt after a training step.
 """
 import ctypes
 
@@ -33,6 +40,9 @@ class ClipAdam(torch.optim.Optimizer):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
+            if group.get("weight_decay", 0) or group.get("amsgrad", False) or group.get("maximize", False):
+                raise _lib.FsnError("ClipAdam implements the recipe's Adam (train.py:55-59): weight_decay = 0, "
+                                    "amsgrad = False, maximize = False")
             if len(ps) > _lib.ADAM_MAX_TENSORS:
                 raise _lib.FsnError(f"ClipAdam: at most {_lib.ADAM_MAX_TENSORS} tensors per parameter group")
             step = None
@@ -56,9 +66,10 @@ class ClipAdam(torch.optim.Optimizer):
             numel = (ctypes.c_size_t * n)(*[p.numel() for p in ps])
             dev = ps[0].device
             cfg = _lib.AdamCfg(group["lr"], group["betas"][0], group["betas"][1], group["eps"],
-                               float(group["clip_grad_norm_value"] or 0.0), step)
+                               float(group.get("clip_grad_norm_value", 0.0) or 0.0), step)
             ws = _lib.workspace(L.fsn_clip_adam_workspace_bytes(n, numel), dev)
             self.total_norm = torch.empty(1, dtype=torch.float32, device=dev)
             _lib.check(L.fsn_clip_adam_step(n, P, G, M, V, numel, ctypes.byref(cfg), _lib.dev_ptr(self.total_norm),
                                             ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_ptr(dev)))
+            torch._C._increment_version(ps)  # the raw-pointer update above is invisible to autograd's counters
         return loss

@@ -6,9 +6,13 @@
  *
  * Conventions
  *   - all pointers are DEVICE pointers to contiguous fp32 arrays owned by the caller (PyTorch's
- *     caching allocator in practice); the library never allocates on the hot path and keeps no
- *     global state besides its code objects;
- *   - `stream` is a hipStream_t passed as void*; work is enqueued and the call returns at once;
+ *     caching allocator in practice); the library never allocates device memory;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued and the call returns at once.  The
+ *     device the stream belongs to is made current for the duration of the call (and restored), so one
+ *     process may drive several GPUs.  The only state the library keeps is one small record per
+ *     (device, stream) - an auxiliary stream with fork / join events for the left-over sub-band tiles and
+ *     the profiler's events - so calls on DIFFERENT streams (from one or several host threads) are
+ *     independent; calls that share a stream must be issued one at a time, like any stream-ordered API;
  *   - return value 0 = OK, < 0 = error; fsn_last_error() gives the thread-local message;
  *   - tensor shapes use the reference's names: B batch, L samples, F = n_fft/2+1 bins,
  *     T = 1 + L/hop frames, la = look_ahead.
@@ -29,6 +33,12 @@ extern "C" {
 
 #define FSN_NORM_OFFLINE_LAPLACE 0    /* audio_zen/model/base_model.py:204-218 */
 #define FSN_NORM_CUMULATIVE_LAPLACE 1 /* audio_zen/model/base_model.py:221-251 */
+
+/* Arithmetic of the three large sub-band kernels.  F32 (the default, what every parity claim and bench.py's
+ * `value` refer to): v_mfma_f32_16x16x4_f32, bit-equal to an fmaf chain.  F16X3: opt-in experiment - fp32
+ * operands split into two fp16 halves, three 16-bit MFMAs per product block, fp32 accumulation. */
+#define FSN_ARITH_F32 0
+#define FSN_ARITH_F16X3 1
 
 const char* fsn_last_error(void);
 int fsn_version(void);
@@ -71,6 +81,7 @@ typedef struct fsn_fullsubnet_cfg {
     int fb_hidden;        /* model.py:19  (512), multiple of 64                   */
     int sb_hidden;        /* model.py:20  384 (the persistent kernel's size)      */
     int norm_type;        /* model.py:21  FSN_NORM_*                              */
+    int arith;            /* FSN_ARITH_* (0 = fp32 MFMA)                          */
 } fsn_fullsubnet_cfg;
 
 /* The 20 tensors of Model.state_dict() in the reference's layout (nn.LSTM: weight_ih [4H, I],
@@ -97,6 +108,12 @@ size_t fsn_fullsubnet_workspace_bytes(const fsn_fullsubnet_cfg* cfg, int B, int 
 int fsn_fullsubnet_forward(const fsn_fullsubnet_cfg* cfg, const void* packed, const float* noisy_mag,
                            int B, int T, float* crm_out, void* workspace, size_t workspace_bytes,
                            void* stream);
+
+/* model.py:85-95 alone: look-ahead pad, norm, full-band model.  fb_output [B, F, T + look_ahead] is the tensor
+ * `fb_output` of model.py:95 (stage-level parity checks; the input a batch-sharded full-band stage would
+ * all-gather).  workspace >= fsn_fullsubnet_workspace_bytes(cfg, B, T). */
+int fsn_fullsubnet_fullband(const fsn_fullsubnet_cfg* cfg, const void* packed, const float* noisy_mag, int B,
+                            int T, float* fb_output, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same model on a contiguous slice [row_begin, row_end) of the B*F flattened (b, f) rows that
  * model.py:121-128 hands to the sub-band LSTM as independent sequences - the multi-GPU partition of the path
@@ -232,13 +249,13 @@ int fsn_clip_adam_step(int n_tensors, float* const* params, float* const* grads,
                        float* const* exp_avg_sq, const size_t* numel, const fsn_adam_cfg* cfg,
                        float* total_norm_out, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Per-stage kernel timing of the last fsn_enhance / fsn_fullsubnet_forward call made with
- * profiling enabled (hipEvents on `stream`; forces a stream sync when read).  Stage ids are listed
+/* Per-stage kernel timing of the last fsn_enhance / fsn_fullsubnet_forward call made ON `stream` with
+ * profiling enabled (hipEvents on that stream, kept per (device, stream); forces a sync of them when read).  Stage ids are listed
  * by fsn_profile_stage_name(); used by bench.py for the roofline line.  */
 int fsn_profile_enable(int on);
 int fsn_profile_num_stages(void);
 const char* fsn_profile_stage_name(int stage);
-int fsn_profile_read(float* ms_per_stage, int n);
+int fsn_profile_read(void* stream, float* ms_per_stage, int n);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ from oracle.fullsubnet_oracle import make_noisy, make_params  # noqa: E402
 SAMPLE = 97  # stride of the per-parameter samples
 
 
-def main(batch=4, length=2560, groups=2):
+def main(batch=4, length=2560, groups=2, name="fsn_train_b4", sample=SAMPLE):
     params = make_params(seed=3)
     noisy = make_noisy(batch, length, seed=41)
     clean = 0.7 * make_noisy(batch, length, seed=42)
@@ -53,15 +53,19 @@ def main(batch=4, length=2560, groups=2):
     opt.step()
     for k, p in model.named_parameters():
         out["gnorm/" + k] = np.float64(grads[k].norm().item())
-        out["g/" + k] = grads[k].reshape(-1)[::SAMPLE].numpy().copy()
-        out["p/" + k] = p.detach().reshape(-1)[::SAMPLE].numpy().copy()
+        out["g/" + k] = grads[k].reshape(-1)[::sample].numpy().copy()
+        out["p/" + k] = p.detach().reshape(-1)[::sample].numpy().copy()
     out["meta"] = np.array(repr(dict(batch=batch, length=length, groups=groups, seed_w=3, seed_noisy=41, seed_clean=42,
-                                     clean_gain=0.7, sample=SAMPLE, torch=torch.__version__)))
-    path = os.path.join(HERE, "fsn_train_b4.npz")
+                                     clean_gain=0.7, sample=sample, torch=torch.__version__)))
+    path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"loss {loss.item():.6f} total grad norm {total_norm.item():.4f} -> {os.path.getsize(path) / 1024:.0f} KiB")
 
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    main()
+    if "--config3" in sys.argv:
+        # BASELINE config 3 per-rank shape (fullsubnet/train.toml:46,92: 16 utterances x 3.072 s, drop_band groups 2)
+        main(batch=16, length=49152, groups=2, name="fsn_train_c3", sample=397)
+    else:
+        main()

@@ -33,6 +33,21 @@ def test_fast_fullsubnet_oracle_vs_reference(golden_dir, name):
     assert np.abs(crm - z["crm"]).max() <= 2e-5
 
 
+def test_fast_fullsubnet_oracle_at_baseline_length(golden_dir):
+    """T = 188 frames (3 s): the 190-step recurrences of BASELINE config 4 against the reference's output
+    (tests/golden/fast_long_b2.npz, every 4th bin)."""
+    z, meta = load(golden_dir, "fast_long_b2")
+    params = MF.make_fast_params(seed=meta["seed_w"], gain=meta["gain"])
+    assert crc(np.concatenate([v.ravel() for v in params.values()])) == meta["crc_w"]
+    params["mel_scale.fb"] = z["fb"]
+    noisy = O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_x"])
+    assert crc(noisy) == meta["crc_noisy"]
+    mag = O.stft(noisy)[0]
+    crm = MF.fast_fullsubnet_forward(mag[:, None], params)[:, :, z["bins"]]
+    assert crm.shape == z["crm"].shape
+    assert np.abs(crm - z["crm"]).max() <= 1e-4
+
+
 def test_fullband_baseline_oracle_vs_reference(golden_dir):
     z, meta = load(golden_dir, "fullband_b2")
     params = MF.make_fullband_params(seed=meta["seed_w"], gain=meta["gain"])
@@ -136,6 +151,21 @@ def test_improved_fullsubnet_oracle_vs_reference(golden_dir, name, cfg):
     enh = MF.improved_fullsubnet_forward(noisy, params, cfg, z["window"])
     assert enh.shape == z["enhanced"].shape
     assert np.abs(enh - z["enhanced"]).max() <= 2e-5 * np.abs(z["enhanced"]).max()
+
+
+def test_improved_fullsubnet_oracle_at_baseline_length(golden_dir):
+    """3 s at 48 kHz (301 frames, the reference's own 481-bin example): BASELINE config 5's sequence length against
+    the reference's output (tests/golden/improved_48k_long_b1.npz, every 8th sample)."""
+    z, meta = load(golden_dir, "improved_48k_long_b1")
+    cfg = MF.IMPROVED_48K
+    params = MF.make_improved_params(cfg, seed=meta["seed_w"])
+    assert crc(np.concatenate([v.ravel() for v in params.values()])) == meta["crc_w"]
+    noisy = O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_x"])
+    assert crc(noisy) == meta["crc_noisy"]
+    enh = MF.improved_fullsubnet_forward(noisy, params, cfg, torch.hann_window(cfg["win_length"]).numpy())
+    got = enh[..., ::meta["sample_stride"]]
+    assert got.shape == z["enhanced"].shape
+    assert np.abs(got - z["enhanced"]).max() <= 1e-4 * float(z["enhanced_absmax"])
 
 
 def test_improved_banded_unfold_matches_product_glue():

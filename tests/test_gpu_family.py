@@ -47,6 +47,26 @@ def test_fast_fullsubnet_vs_reference(fsn, golden_dir, name):
     assert np.abs(crm - z["crm"]).max() <= 1e-4  # north-star tolerance on the (compressed) mask
 
 
+def test_fast_fullsubnet_at_baseline_length_vs_reference(fsn, golden_dir):
+    """BASELINE config 4's sequence length (3 s, T = 188: 190 steps in the encoder / decoder, 96 in the bottleneck)
+    against the reference model's output (tests/golden/fast_long_b2.npz, every 4th bin)."""
+    from oracle import fullsubnet_oracle as O
+    from fullsubnet_amd.fast_fullsubnet import Model
+    z, meta = load(golden_dir, "fast_long_b2")
+    params = MF.make_fast_params(seed=meta["seed_w"], gain=meta["gain"])
+    m = Model(**FAST_KW)
+    sd = {k: torch.from_numpy(v) for k, v in params.items()}
+    sd["mel_scale.fb"] = torch.from_numpy(z["fb"])
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    noisy = torch.from_numpy(O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_x"])).cuda()
+    mag = fsn.stft(noisy, 512, 256, 512)[0]
+    with torch.no_grad():
+        crm = m(mag.unsqueeze(1)).cpu().numpy()[:, :, z["bins"]]
+    assert crm.shape == z["crm"].shape
+    assert np.abs(crm - z["crm"]).max() <= 1e-4
+
+
 def test_fast_fullsubnet_batch64_rows_on_persistent_kernel(fsn):
     """B = 64 -> 4096 bottleneck rows = 256 tiles: the rows run on the persistent recurrent kernel
     (not the step kernels of the small golden cases); checked against the oracle on 2 utterances."""
@@ -171,6 +191,24 @@ def test_improved_fullsubnet_vs_reference(fsn, golden_dir, name, cfg):
         enh = m(torch.from_numpy(noisy).cuda().unsqueeze(1)).cpu().numpy()
     assert enh.shape == z["enhanced"].shape
     assert np.abs(enh - z["enhanced"]).max() <= 1e-4 * np.abs(z["enhanced"]).max()
+
+
+def test_improved_fullsubnet_at_baseline_length_vs_reference(fsn, golden_dir):
+    """BASELINE config 5's clip: 3 s at 48 kHz through the reference's own 481-bin example (301 frames) against the
+    reference model's output (tests/golden/improved_48k_long_b1.npz, every 8th sample)."""
+    from oracle import fullsubnet_oracle as O
+    from fullsubnet_amd.improved_fullsubnet import Model
+    z, meta = load(golden_dir, "improved_48k_long_b1")
+    cfg = MF.IMPROVED_48K
+    params = MF.make_improved_params(cfg, seed=meta["seed_w"])
+    m = Model(**cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.cuda().eval()
+    noisy = O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_x"])
+    with torch.no_grad():
+        enh = m(torch.from_numpy(noisy).cuda().unsqueeze(1)).cpu().numpy()[..., ::meta["sample_stride"]]
+    assert enh.shape == z["enhanced"].shape
+    assert np.abs(enh - z["enhanced"]).max() <= 1e-4 * float(z["enhanced_absmax"])
 
 
 @pytest.mark.parametrize("world", [3, 8])

@@ -1,9 +1,10 @@
 """Parity of the HIP path (through the C ABI) against the reference's golden vectors and the CPU
 oracle.  Needs a real MI355X:  python -m pytest tests -m gpu
 
-Tolerances (north star): compressed cIRM within 1e-4 absolute (fp32); STFT bins within 2 ULP of the
-exactly-rounded transform at frame-max scale (the reference's own MKL FFT is up to ~3 ULP from it,
-so 4 ULP is allowed against the golden file)."""
+Tolerances (north star): compressed cIRM within 1e-4 absolute (fp32); STFT bins within 2 ULP - asserted at
+frame-max scale both against the exactly-rounded transform (<= 1 ULP) and against the reference's own MKL
+output in the golden files (<= 2 ULP; measured 1.5).  At each bin's OWN scale no independent FFT can be within
+2 ULP of MKL (cancellation bins); that figure is printed, not asserted."""
 import ast
 import os
 
@@ -39,12 +40,16 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def build_model(fsn, meta, groups=None):
+def build_model(fsn, meta, groups=None, arith="f32"):
     params = O.make_params(seed=meta["seed_w"], gain=meta["gain"], mask_gain=meta["mask_gain"])
     m = fsn.Model(norm_type=meta["norm_type"], num_groups_in_drop_band=meta["groups"] if groups is None else groups,
                   **MODEL_KW)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m.arithmetic = arith  # "f32" unless a test asks for the opt-in split-precision kernels
     return m.cuda().eval(), params
+
+
+ARITHS = ["f32", "f16x3"]
 
 
 def ulp_at_frame_max(err, ref_re, ref_im):
@@ -67,7 +72,9 @@ def test_stft(fsn, golden_dir, name):
     # vs the reference's MKL output
     u = np.maximum(ulp_at_frame_max(re - z["real"], z["real"], z["imag"]),
                    ulp_at_frame_max(im - z["imag"], z["real"], z["imag"]))
-    assert u.max() <= 4.0 and np.percentile(u, 99) <= 2.0, (u.max(), np.percentile(u, 99))
+    assert u.max() <= 2.0 and np.percentile(u, 99) <= 1.5, (u.max(), np.percentile(u, 99))
+    own = np.maximum(np.abs(re - z["real"]) / np.spacing(np.abs(z["real"])), np.abs(im - z["imag"]) / np.spacing(np.abs(z["imag"])))
+    print(f"stft {name}: vs MKL max {u.max():.2f} ULP at frame-max scale, p99 {np.percentile(own, 99):.0f} ULP at own scale")
     np.testing.assert_allclose(mag, z["mag"], rtol=0, atol=4 * np.spacing(np.float32(z["mag"].max())))
     np.testing.assert_allclose(phase.cpu().numpy(), np.arctan2(im, re), atol=1e-6)
 
@@ -106,16 +113,72 @@ def test_mask_algebra(fsn, golden_dir):
 
 
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("arith", ARITHS)
 @pytest.mark.parametrize("name", ["fsn_offline_b2", "fsn_offline_b1_odd", "fsn_cumulative_b2", "fsn_dropband_b4"])
-def test_model_forward_vs_reference(fsn, golden_dir, name):
+def test_model_forward_vs_reference(fsn, golden_dir, name, arith):
     z, meta = load(golden_dir, name)
-    model, _ = build_model(fsn, meta)
+    model, _ = build_model(fsn, meta, arith=arith)
     with torch.no_grad():
         crm = model(dev(z["mag"][:, None])).cpu().numpy()
     assert crm.shape == z["crm"].shape
     err = np.abs(crm - z["crm"])
     assert err.max() <= 1e-4, f"max |d cIRM| = {err.max():.3e} (L1 {err.mean():.3e})"
     assert np.abs(z["crm"]).max() > 5.0  # the check is not vacuous
+
+
+@pytest.mark.parametrize("name", ["fsn_offline_b2", "fsn_offline_b1_odd", "fsn_cumulative_b2", "fsn_long_b2"])
+def test_fullband_stage_vs_reference(fsn, golden_dir, name):
+    """Row A5 on its own: the intermediate ``fb_output`` (fullsubnet/model.py:95: look-ahead pad -> norm -> full-band
+    LSTM x 2 -> Linear -> ReLU) of the reference against fsn_fullsubnet_fullband, incl. the 190-step utterances."""
+    z, meta = load(golden_dir, name)
+    model, _ = build_model(fsn, meta)
+    if "mag" in z:
+        mag = dev(z["mag"][:, None])
+        want = z["fb_output"]
+        bins = slice(None)
+    else:  # long fixtures store a strided subset of the bins; the magnitude is recomputed from the seeded waveform
+        noisy = O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_x"])
+        mag = fsn.stft(dev(noisy), 512, 256, 512)[0].unsqueeze(1)
+        want = z["fb_output"]
+        bins = z["bins"]
+    got = model.fullband_output(mag).cpu().numpy()[:, bins]
+    assert got.shape == want.shape
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 2e-5 * max(scale, 1.0), (np.abs(got - want).max(), scale)
+    assert scale > 0.1 and (want == 0).mean() > 0.05  # the ReLU is active and the stage is not trivially zero
+
+
+@pytest.mark.parametrize("arith", ARITHS)
+def test_config2_length_vs_reference(fsn, golden_dir, arith):
+    """BASELINE config 2's sequence length pinned on the REFERENCE (not only on the oracle): 2 utterances x 48 000
+    samples, T = 188 frames, 190 recurrent steps - STFT, compressed mask and enhanced waveform against
+    tests/golden/fsn_long_b2.npz (fullsubnet/model.py:72-136, inferencer.py:130-145).  The fixture holds every 4th bin
+    / sample.  Also run inside a 64-utterance batch, where these rows go through the persistent kernels."""
+    z, meta = load(golden_dir, "fsn_long_b2")
+    model, _ = build_model(fsn, meta, arith=arith)
+    noisy = O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_x"])
+    b, ss = z["bins"], meta["sample_stride"]
+    _, _, re, im = fsn.stft(dev(noisy), 512, 256, 512)
+    re, im = re.cpu().numpy()[:, b], im.cpu().numpy()[:, b]
+    ulp = np.spacing(z["frame_max"].astype(np.float32))  # per-frame max |X| over ALL bins of the reference
+    u = np.maximum(np.abs(re - z["real"]), np.abs(im - z["imag"])) / ulp
+    # 376 frames: MKL's own fp32 FFT is up to 2.95 ULP from the exact transform at this scale (BASELINE.md section 2:
+    # median 0.44 / p99 1.36 / max 2.95), so against MKL the bound is MKL's error; vs the exact transform it is <= 1
+    assert u.max() <= 3.0 and np.percentile(u, 99) <= 1.5, (u.max(), np.percentile(u, 99))
+    _, _, ore, oim = O.stft(noisy)
+    assert (np.maximum(np.abs(re - ore[:, b]), np.abs(im - oim[:, b])) / ulp).max() <= 1.0
+    enh, crm = model.enhance(dev(noisy), return_crm=True)
+    err = np.abs(crm.cpu().numpy()[:, :, b] - z["crm"])
+    print(f"config-2 length, {arith}: max |d cIRM| vs reference {err.max():.2e} (L1 {err.mean():.2e})")
+    assert err.max() <= 1e-4, err.max()
+    assert np.abs(z["crm"]).max() > 9.9  # the mask crosses the decompression clamp
+    assert np.abs(enh.cpu().numpy()[:, ::ss] - z["enhanced"]).max() <= 2e-3 * float(z["enhanced_absmax"])
+    # the same two utterances as rows of a config-2 sized batch (16 448 rows: persistent kernels + left-over tiles)
+    big = np.concatenate([noisy, O.make_noisy(62, meta["length"], seed=99)], axis=0)
+    _, crm64 = model.enhance(dev(big), return_crm=True)
+    err64 = np.abs(crm64[:2].cpu().numpy()[:, :, b] - z["crm"])
+    print(f"config-2 batch 64, {arith}: max |d cIRM| vs reference {err64.max():.2e}")
+    assert err64.max() <= 1e-4, err64.max()
 
 
 @pytest.mark.parametrize("name", ["fsn_offline_b2", "fsn_offline_b1_odd", "fsn_cumulative_b2"])
@@ -177,12 +240,13 @@ def test_more_row_tiles_than_cus(fsn, batch):
     assert np.abs(enh.cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
 
 
-def test_config2_full_size(fsn):
+@pytest.mark.parametrize("arith", ARITHS)
+def test_config2_full_size(fsn, arith):
     """BASELINE config 2 at full size (batch 64 x 3 s): the oracle checks two utterances (a few
     seconds of CPU each); the rest is covered by size-independent properties - every utterance of
     the batch equals its own solo run (batch independence), and two runs are bit-identical."""
     meta = dict(seed_w=0, gain=2.0, mask_gain=24.0, norm_type="offline_laplace_norm", groups=1)
-    model, params = build_model(fsn, meta)
+    model, params = build_model(fsn, meta, arith=arith)
     noisy = O.make_noisy(64, 48000, seed=1234)
     x = dev(noisy)
     enh, crm = model.enhance(x, return_crm=True)
@@ -428,43 +492,27 @@ def _tone_burst(batch, samples):
     return x
 
 
-def test_experimental_f16x3_matches_fp32(fsn, tmp_path):
-    """The opt-in split-precision kernels (FSN_F16X3=1, read once per process -> run in a subprocess; both sub-band
-    recurrent layers and the projection between them): same mask as the fp32 path to well inside the parity
-    budget, on the usual noisy input and on tone bursts in silence (fp16 range of the staged layer-0 input)."""
-    if os.environ.get("FSN_F16X3") == "1":
-        pytest.skip("the whole session runs with the switch on: nothing to compare against")
-    import subprocess
-    import sys
-    out = tmp_path / "crm.npz"
-    burst = tmp_path / "burst.npy"
-    np.save(burst, _tone_burst(16, 16000))
-    code = (
-        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
-        "import fullsubnet_amd as fsn; from fsn_synthetic import make_params, make_noisy\n"
-        "kw = %r\n"
-        "m = fsn.Model(norm_type='offline_laplace_norm', num_groups_in_drop_band=1, **kw)\n"
-        "m.load_state_dict({k: torch.from_numpy(v) for k, v in make_params(seed=0, gain=2.0, mask_gain=24.0).items()})\n"
-        "m = m.cuda().eval()\n"
-        "_, a = m.enhance(torch.from_numpy(make_noisy(16, 2048, seed=1)).cuda(), return_crm=True)\n"
-        "_, b = m.enhance(torch.from_numpy(np.load(%r)).cuda(), return_crm=True)\n"
-        "np.savez(%r, noisy=a.cpu().numpy(), burst=b.cpu().numpy())\n"
-        % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), MODEL_KW, str(burst), str(out)))
-    env = dict(os.environ, FSN_F16X3="1")
-    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
-    got = np.load(out)
+def test_experimental_f16x3_matches_fp32(fsn):
+    """The opt-in split-precision kernels (Model.arithmetic = "f16x3" -> cfg.arith; both sub-band recurrent layers and
+    the projection between them): same mask as the fp32 path to well inside the parity budget, on the usual noisy
+    input and on tone bursts in silence (fp16 range of the staged layer-0 input)."""
     params = O.make_params(seed=0, gain=2.0, mask_gain=24.0)
     m = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=1, **MODEL_KW)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
     m = m.cuda().eval()
-    _, ref = m.enhance(dev(O.make_noisy(16, 2048, seed=1)), return_crm=True)  # 257 row tiles: persistent kernels + GEMM
-    ref = ref.cpu().numpy()
-    assert not np.array_equal(got["noisy"], ref)          # the switch really changed the arithmetic ...
-    dev_noisy = np.abs(got["noisy"] - ref).max()
+    noisy, burst = dev(O.make_noisy(16, 2048, seed=1)), dev(_tone_burst(16, 16000))  # 257 row tiles each
+    with pytest.raises(fsn._lib.FsnError):
+        m.arithmetic = "fp8"
+    assert m.arithmetic == "f32"
+    ref, ref_b = m.enhance(noisy, return_crm=True)[1].cpu().numpy(), m.enhance(burst, return_crm=True)[1].cpu().numpy()
+    m.arithmetic = "f16x3"
+    got, got_b = m.enhance(noisy, return_crm=True)[1].cpu().numpy(), m.enhance(burst, return_crm=True)[1].cpu().numpy()
+    m.arithmetic = "f32"
+    assert np.array_equal(m.enhance(noisy, return_crm=True)[1].cpu().numpy(), ref)  # and back, bit for bit
+    assert not np.array_equal(got, ref)                   # the switch really changed the arithmetic ...
+    dev_noisy = np.abs(got - ref).max()
     assert dev_noisy <= 2e-5                              # ... and stayed within a fifth of the 1e-4 budget
-    _, ref_b = m.enhance(dev(_tone_burst(16, 16000)), return_crm=True)
-    ref_b = ref_b.cpu().numpy()
-    assert np.isfinite(got["burst"]).all() and np.isfinite(ref_b).all()
-    dev_burst = np.abs(got["burst"] - ref_b).max()
+    assert np.isfinite(got_b).all() and np.isfinite(ref_b).all()
+    dev_burst = np.abs(got_b - ref_b).max()
     print(f"f16x3 vs fp32 mask deviation: noisy {dev_noisy:.2e}, tone burst {dev_burst:.2e}")
     assert dev_burst <= 1e-4

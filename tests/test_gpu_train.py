@@ -51,9 +51,13 @@ def test_lstm_layer_forward_and_bptt(fsn, T, N, I, H):
         assert err <= 1e-4 * max(b.abs().max().item(), 1e-3), (name, err, b.abs().max().item())
 
 
-def test_train_step_vs_reference_and_oracle(fsn, golden_dir):
+@pytest.mark.parametrize("name", ["fsn_train_b4", "fsn_train_c3"])
+def test_train_step_vs_reference_and_oracle(fsn, golden_dir, name):
+    """One step of fullsubnet/trainer.py:41-71 (use_amp = false) against the reference's own loss, clipped gradients
+    and Adam-updated parameters: a short batch (4 x 2560 samples) and BASELINE config 3's per-rank shape
+    (fullsubnet/train.toml: 16 utterances x 49 152 samples = 193 frames, drop_band groups 2)."""
     from fullsubnet_amd.train import train_step
-    z = np.load(os.path.join(golden_dir, "fsn_train_b4.npz"))
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
     meta = ast.literal_eval(str(z["meta"]))
     params = O.make_params(seed=meta["seed_w"])
     noisy = O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_noisy"])
@@ -65,6 +69,7 @@ def test_train_step_vs_reference_and_oracle(fsn, golden_dir):
     opt = fsn.ClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
     loss = train_step(model, opt, torch.from_numpy(noisy).cuda(), torch.from_numpy(clean).cuda())
     assert abs(loss.item() - float(z["loss"])) <= 1e-5 * float(z["loss"])
+    assert abs(float(opt.total_norm) - float(z["total_norm"])) <= 2e-3 * float(z["total_norm"])
     s = meta["sample"]
     named = dict(model.named_parameters())
     for k in params:
@@ -72,8 +77,15 @@ def test_train_step_vs_reference_and_oracle(fsn, golden_dir):
         gn = float(z["gnorm/" + k])
         assert abs(float(named[k].grad.norm()) - gn) <= 2e-3 * gn + 1e-9, k
         assert np.abs(g - z["g/" + k]).max() <= 2e-3 * max(np.abs(z["g/" + k]).max(), 1e-3 * gn) + 1e-9, k
+        # Adam's first step moves every weight by lr g / (|g| + eps) ~ +-1e-3: where the reference's gradient is well
+        # above eps = 1e-8 the update is insensitive to rounding and must agree to 1e-5; elsewhere (|g| ~ eps, the
+        # step's size depends on the last bits of g) only that it is a step of at most lr
         p = named[k].detach().reshape(-1)[::s].cpu().numpy()
-        assert np.abs(p - z["p/" + k]).max() <= 2.5e-3, k
+        p0 = params[k].reshape(-1)[::s]
+        firm = np.abs(z["g/" + k]) > 1e-6
+        if firm.any():
+            assert np.abs(p - z["p/" + k])[firm].max() <= 1e-5, k
+        assert np.abs(p - p0).max() <= 1.001e-3 + 1e-7, k
         assert np.mean(np.abs(p - z["p/" + k]) > 1e-5) <= 0.02, k
     # a second step must lower the loss on the same batch (the optimiser really moved the weights)
     loss2 = train_step(model, opt, torch.from_numpy(noisy).cuda(), torch.from_numpy(clean).cuda())

@@ -1,0 +1,221 @@
+"""Trainer surface on the HIP path: checkpoint save / resume in the reference's format, the validation epoch,
+cache invalidation after the fused optimizer step, and the two-process forms (DistributedDataParallel gradients,
+row-sharded enhancement) with two ranks sharing the one GPU of the test box over gloo (RCCL refuses two ranks on
+one device; the collective semantics are the same).  Needs an MI355X:  python -m pytest tests -m gpu"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fullsubnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MODEL_KW = dict(num_freqs=257, look_ahead=2, sequence_model="LSTM", fb_num_neighbors=0, sb_num_neighbors=15,
+                fb_output_activate_function="ReLU", sb_output_activate_function=False, fb_model_hidden_size=512,
+                sb_model_hidden_size=384, weight_init=False)
+
+
+@pytest.fixture(scope="module")
+def fsn():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu tests need a ROCm device")
+    import fullsubnet_amd
+    fullsubnet_amd._lib.lib()
+    return fullsubnet_amd
+
+
+def make_model(fsn, seed=3, groups=2, **kw):
+    params = O.make_params(seed=seed, **kw)
+    m = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=groups, **MODEL_KW)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    return m.cuda()
+
+
+def wav(batch, length, seed):
+    return torch.from_numpy(O.make_noisy(batch, length, seed=seed))
+
+
+def test_fused_optimizer_step_invalidates_the_inference_weight_caches(fsn):
+    """eval forward -> ClipAdam.step() (raw-pointer update) -> eval forward must use the NEW weights: compared with a
+    freshly constructed model that loads the trained state_dict."""
+    from fullsubnet_amd.train import train_step
+    model = make_model(fsn, gain=2.0, mask_gain=24.0)
+    noisy, clean = wav(4, 2560, 41).cuda(), (0.7 * wav(4, 2560, 42)).cuda()
+    mag = fsn.stft(noisy, 512, 256, 512)[0].unsqueeze(1)
+    model.eval()
+    with torch.no_grad():
+        before = model(mag[:1]).clone()          # populates the packed-weight cache
+    opt = fsn.ClipAdam(model.parameters(), lr=1e-2, betas=(0.9, 0.999))
+    model.train()
+    versions = [p._version for p in model.parameters()]
+    train_step(model, opt, noisy, clean)
+    assert all(p._version > v for p, v in zip(model.parameters(), versions))
+    model.eval()
+    with torch.no_grad():
+        after = model(mag[:1]).clone()
+    fresh = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=2, **MODEL_KW)
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()}, strict=True)
+    fresh = fresh.cuda().eval()
+    with torch.no_grad():
+        want = fresh(mag[:1])
+    assert not torch.equal(before, after)        # lr 1e-2 moved the mask
+    assert torch.equal(after, want)              # and the cached pack was rebuilt from the updated weights
+
+
+def _config(tmp_path, epochs=2):
+    return {"meta": {"save_dir": str(tmp_path), "experiment_name": "exp", "use_amp": True, "preloaded_model_path": ""},
+            "acoustics": {"n_fft": 512, "hop_length": 256, "win_length": 512, "sr": 16000},
+            "trainer": {"train": {"epochs": epochs, "save_checkpoint_interval": 1, "clip_grad_norm_value": 10},
+                        "validation": {"validation_interval": 1, "save_max_metric_score": True},
+                        "visualization": {}},
+            "model": {"path": "fullsubnet_amd.model.Model",
+                      "args": dict(MODEL_KW, norm_type="offline_laplace_norm", num_groups_in_drop_band=2)},
+            "inferencer": {"type": "full_band_crm_mask", "args": {}}}
+
+
+def _loaders():
+    train = [(wav(2, 2560, 50 + i), 0.7 * wav(2, 2560, 60 + i)) for i in range(2)]
+    valid = [(wav(1, 3000, 70), 0.7 * wav(1, 3000, 71), ["a"], ["With_reverb"]),
+             (wav(1, 2800, 72), 0.7 * wav(1, 2800, 73), ["b"], ["No_reverb"]),
+             (wav(1, 2600, 74), 0.7 * wav(1, 2600, 75), ["c"], ["With_reverb"])]
+    return train, valid
+
+
+def test_trainer_checkpoint_validation_and_resume(fsn, tmp_path):
+    """base_trainer.py:157-237 / fullsubnet/trainer.py:78-181: train two epochs with checkpoints and validation,
+    resume a second Trainer from latest_model.tar (same weights, optimizer moments and epoch counter; a third epoch
+    continues bit-identically to an uninterrupted run), and load the file the way BaseInferencer._load_model does."""
+    from fullsubnet_amd.trainer import Trainer, si_sdr
+    train, valid = _loaders()
+    cfg = _config(tmp_path)
+
+    def new(resume, epochs=2, seed=3):
+        model = make_model(fsn, seed=seed)
+        opt = fsn.ClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
+        c = dict(cfg, trainer=dict(cfg["trainer"], train=dict(cfg["trainer"]["train"], epochs=epochs)))
+        return Trainer(None, 0, c, resume, False, model, None, opt, train, valid)
+
+    t1 = new(False)
+    t1.train()
+    ck = tmp_path / "exp" / "checkpoints"
+    assert sorted(p.name for p in ck.iterdir()) == ["best_model.tar", "latest_model.tar", "model_0001.pth",
+                                                    "model_0002.pth"]
+    assert set(t1.history["Loss/Train"]) == {1, 2} and t1.history["Loss/Train"][2] < t1.history["Loss/Train"][1]
+    assert t1.validation_score_kind in ("SI_SDR", "(STOI + WB_PESQ) / 2")
+    latest = torch.load(ck / "latest_model.tar", map_location="cpu", weights_only=False)
+    assert set(latest) == {"epoch", "best_score", "optimizer", "scaler", "model"}  # base_trainer.py:209-219
+    assert latest["epoch"] == 2 and np.isfinite(latest["best_score"])
+    assert list(latest["model"]) == list(O.make_params(seed=0))               # the reference's state_dict keys
+    assert set(latest["optimizer"]["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}  # torch.optim.Adam's layout
+
+    # validation epoch by hand on one utterance: loss and enhanced signal through the separate calls
+    t1.model.eval()
+    score = t1._validation_epoch(99)
+    assert isinstance(score, float) and np.isfinite(score)
+    lists = t1.last_validation
+    assert [len(lists[k]["enhanced"]) for k in ("With_reverb", "No_reverb")] == [2, 1]
+    noisy, clean = valid[0][0].cuda(), valid[0][1].cuda()
+    enh = t1.model.enhance(noisy)[0].cpu().numpy()
+    assert np.abs(enh - lists["With_reverb"]["enhanced"][0]).max() <= 1e-4 * np.abs(enh).max()
+    if t1.validation_score_kind == "SI_SDR":
+        want = np.mean([si_sdr(c, e) for c, e in zip(lists["With_reverb"]["clean"], lists["With_reverb"]["enhanced"])])
+        assert abs(score - want) <= 1e-6 * abs(want)
+
+    # resume: another seed's weights are overwritten by the checkpoint; epoch 3 equals the uninterrupted run's
+    t2 = new(True, epochs=3, seed=11)
+    assert t2.start_epoch == 3 and t2.best_score == latest["best_score"]
+    for (k, a), (_, b) in zip(t1.model.state_dict().items(), t2.model.state_dict().items()):
+        assert torch.equal(a, b), k
+    t1.epochs = 3
+    t1.start_epoch = 3
+    t1.train()
+    t2.train()
+    for (k, a), (_, b) in zip(t1.model.state_dict().items(), t2.model.state_dict().items()):
+        assert torch.equal(a, b), k
+    # only_validation (base_trainer.py:380-391) and resume without a checkpoint
+    with pytest.raises(AssertionError):
+        Trainer(None, 0, dict(cfg, meta=dict(cfg["meta"], experiment_name="nothing_here")), True, False,
+                make_model(fsn), None, None, train, valid)
+    # the inference side accepts the file: base_inferencer.py:146-160
+    inf = fsn.Inferencer(cfg, checkpoint_path=str(ck / "latest_model.tar"))
+    one = inf.full_band_crm_mask(valid[0][0].cuda(), {})
+    assert one.shape == (3000,) and np.isfinite(one).all()
+
+    # a torch.optim.Adam checkpoint of the reference loads into ClipAdam and steps (no clip key in its groups)
+    ref_opt = torch.optim.Adam(make_model(fsn).parameters(), lr=1e-3, betas=(0.9, 0.999))
+    t3 = new(False)
+    t3.optimizer.load_state_dict(ref_opt.state_dict())
+    t3._train_epoch(1)
+    bad = torch.optim.Adam(make_model(fsn).parameters(), lr=1e-3, weight_decay=0.1)
+    t3.optimizer.load_state_dict(bad.state_dict())
+    with pytest.raises(fsn._lib.FsnError):
+        t3._train_epoch(2)
+
+
+# ---- two processes on one GPU ---------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _ddp_worker(rank, world, port):
+    import torch.distributed as dist
+    import fullsubnet_amd as fsn
+    from fullsubnet_amd.train import train_step
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        noisy, clean = wav(4, 2560, 41).cuda(), (0.7 * wav(4, 2560, 42)).cuda()
+        ref = make_model(fsn).train()
+        train_step(ref, torch.optim.SGD(ref.parameters(), lr=0.0), noisy, clean)  # whole batch, one process
+        ddp = torch.nn.parallel.DistributedDataParallel(make_model(fsn).train(), device_ids=[0])  # base_trainer.py:32
+        lo, hi = 2 * rank, 2 * rank + 2   # drop_band groups = 2 keeps the sample parity of the global batch
+        loss = train_step(ddp, torch.optim.SGD(ddp.parameters(), lr=0.0), noisy[lo:hi], clean[lo:hi])
+        assert torch.isfinite(loss)
+        for (k, p), (_, q) in zip(ref.named_parameters(), ddp.module.named_parameters()):
+            scale = max(p.grad.abs().max().item(), 1e-6)
+            err = (p.grad - q.grad).abs().max().item()
+            assert err <= 2e-4 * scale, (rank, k, err, scale)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_gradients_equal_the_single_process_double_batch(fsn):
+    """base_trainer.py:32 / train.py:29: DistributedDataParallel around fullsubnet_amd.Model, two ranks with half
+    the batch each: the all-reduced gradients are the single-process gradients of the whole batch."""
+    import torch.multiprocessing as mp
+    mp.spawn(_ddp_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _row_shard_worker(rank, world, port):
+    import torch.distributed as dist
+    import fullsubnet_amd as fsn
+    from fullsubnet_amd.parallel import enhance_row_sharded, enhance_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        model = make_model(fsn, seed=0, groups=1, gain=2.0, mask_gain=24.0).eval()
+        noisy = wav(3, 4096, 1234).cuda()   # 771 rows: rank 0 ends inside utterance 1
+        fused = model.enhance(noisy)
+        rows = enhance_row_sharded(model, noisy)
+        assert rows.shape == fused.shape
+        assert (rows - fused).abs().max().item() <= 1e-4 * fused.abs().max().item()
+        utt = enhance_sharded(model.enhance, noisy)
+        assert (utt - fused).abs().max().item() <= 1e-5 * fused.abs().max().item()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_enhancement_two_processes(fsn):
+    """fullsubnet/model.py:95,121-128 over two ranks: every rank runs its contiguous half of the B F sub-band rows
+    (fsn_fullsubnet_forward_rows), ONE all-gather re-assembles the mask; result = the fused single-process call."""
+    import torch.multiprocessing as mp
+    mp.spawn(_row_shard_worker, args=(2, _free_port()), nprocs=2, join=True)
