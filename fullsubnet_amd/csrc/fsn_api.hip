@@ -316,6 +316,7 @@ struct CoreDims {
     int N, Npad;       // sub-band rows per step, padded rows (row stride of the [t][n] buffers)
     FsnRecPlan rec;    // how those rows are spread over the CUs
     bool fc_fused;     // output layer fused into the layer-1 persistent kernel (its hseq is never stored)
+    bool l1x;          // layer 1 forms its input projection itself (lstm_rec_x_kernel): no projection GEMM, no gx
     long row0;         // row-range calls: the N sub-band rows are rows row0 .. row0 + N - 1 of the B F rows
     int den_stride;    // row stride of the per-row (cumulative) sub-band divisors: they are indexed by GLOBAL row
 };
@@ -339,10 +340,12 @@ static CoreDims core_dims(const fsn_fullsubnet_cfg* c, int B, int T, long row0 =
     d.Npad = d.rec.npad;
     d.den_stride = n_rows < 0 ? d.Npad : fsn_round_up(B * d.F, 16);
     d.fc_fused = d.rec.main_wgs > 0 && fsn_lstm_rec_can_fuse_fc(d.rec.rt, false);
+    d.l1x = d.fc_fused && c->arith == FSN_ARITH_F32 && fsn_lstm_rec_x_supported(d.Hs, d.rec.rt);
     return d;
 }
 struct CoreWs {
     float *gx_fb, *hseq_fb0, *hseq_fb1, *c_fb, *fb_out, *den_fb, *den_sb, *gx_sb, *hseq_sb0, *hseq_sb1, *c_left;
+    float* hseq_left0;  // l1x: layer-0 hidden sequence of the left-over rows, compact [t][left rows][H]
     double* binsum;
 };
 static CoreWs core_carve(Carver& cv, const CoreDims& d, int norm_type) {
@@ -357,8 +360,11 @@ static CoreWs core_carve(Carver& cv, const CoreDims& d, int norm_type) {
     const bool cum = norm_type == FSN_NORM_CUMULATIVE_LAPLACE;
     w.den_fb = cv.take<float>(cum ? (size_t)d.B * d.Tp : (size_t)d.B);
     w.den_sb = cv.take<float>(cum ? (size_t)d.Tp * d.den_stride : (size_t)d.B);
-    w.gx_sb = cv.take<float>(rows_sb * 4 * d.Hs);
+    // l1x: only the left-over rows (which run step by step) still need a precomputed projection
+    const size_t rows_left = (size_t)d.Tp * (d.rec.left_tiles > 0 ? d.rec.left_tiles : 1) * 16;
+    w.gx_sb = cv.take<float>((d.l1x ? rows_left : rows_sb) * 4 * d.Hs);
     w.hseq_sb0 = cv.take<float>(rows_sb * d.Hs);
+    w.hseq_left0 = d.l1x ? cv.take<float>(rows_left * d.Hs) : nullptr;
     // fused output layer: only the left-over rows of layer 1 are ever stored, [t][left rows][H]
     w.hseq_sb1 = cv.take<float>(d.fc_fused ? (size_t)d.Tp * (d.rec.left_tiles > 0 ? d.rec.left_tiles : 1) * 16 * d.Hs
                                            : rows_sb * d.Hs);
@@ -385,10 +391,15 @@ static int aux_init(StreamCtx* c) {
 // few left-over row tiles as per-step launches on the auxiliary stream.
 // Main kernel: input projection either precomputed (`gx`, tile (t, i) at t * tiles + i) or built
 // in-kernel from `xin`.  Left-over tiles: projection tiles in `gx_left` at t * left_stride + left_off + i.
+// x_main (with wih_main, bias_main): the main rows run on lstm_rec_x_kernel, which reads the hidden sequence of the
+// layer below (x_main [Tp][Npad][H]) and forms its input projection itself.  hseq_left: the left-over rows' hidden
+// sequence goes to this compact [t][left rows][H] buffer instead of rows [main rows, Npad) of hseq.
 static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* gx_left, long left_stride,
                           long left_off, const float* whh, float* hseq, float* c_left, int Tp, int Npad, int H,
                           const FsnRecPlan& r, hipStream_t s, const FsnRecFc* fc = nullptr, long left_hs_stride = -1,
-                          const void* whh_f16x3 = nullptr, const void* wih_f16x3 = nullptr) {
+                          const void* whh_f16x3 = nullptr, const void* wih_f16x3 = nullptr,
+                          const float* x_main = nullptr, const float* wih_main = nullptr,
+                          const float* bias_main = nullptr, float* hseq_left = nullptr) {
     // No persistent part (fewer than ~160 tiles): the steps run on `s` itself - groups of four tiles through the
     // one-workgroup-per-CU step kernel, the up to three tiles that do not fill a group beside it on the
     // auxiliary stream (a 33rd group of 8 workgroups would be a second round on 8 CUs and double the step).
@@ -407,7 +418,9 @@ static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* g
         ls = cx->aux;
     }
     if (r.main_wgs > 0) {
-        if (whh_f16x3 && fc && !xin && r.rt >= 2)  // experimental split-precision persistent kernel (FSN_F16X3=1)
+        if (x_main)
+            FSN_TRY(fsn_launch_lstm_rec_x(x_main, wih_main, whh, bias_main, Tp, Npad, H, r.rt, r.main_wgs, s, fc));
+        else if (whh_f16x3 && fc && !xin && r.rt >= 2)  // experimental split-precision persistent kernel (FSN_F16X3=1)
             FSN_TRY(fsn_launch_lstm_rec_f16x3(gx, whh_f16x3, Tp, Npad, H, r.rt, r.main_wgs, fc, s));
         else if (whh_f16x3 && wih_f16x3 && xin && !xin->x_rows && xin->kin_chunks == 2 && r.rt >= 2)
             FSN_TRY(fsn_launch_lstm_rec_xin_f16x3(xin, wih_f16x3, whh_f16x3, hseq, Tp, Npad, H, r.rt, r.main_wgs, s));
@@ -417,11 +430,13 @@ static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* g
     if (r.left_tiles > 0) {
         // left-over rows of step t: rows [main_rows, Npad) of the full [t][Npad] matrix, or - when the
         // persistent part stores nothing (fused output layer) - a compact [t][left rows] matrix
+        if (hseq_left) left_hs_stride = (long)r.left_tiles * 16;
+        float* hl = hseq_left ? hseq_left : hseq;
         const long hs_stride = left_hs_stride >= 0 ? left_hs_stride : Npad;
         const long hs_off = left_hs_stride >= 0 ? 0 : (long)r.main_wgs * r.rt * 16;
         for (int t = 0; t < Tp; ++t) {
-            float* h_out = hseq + ((size_t)t * hs_stride + hs_off) * H;
-            const float* h_prev = t ? hseq + ((size_t)(t - 1) * hs_stride + hs_off) * H : h_out;
+            float* h_out = hl + ((size_t)t * hs_stride + hs_off) * H;
+            const float* h_prev = t ? hl + ((size_t)(t - 1) * hs_stride + hs_off) * H : h_out;
             const long gx_rt0 = (long)t * left_stride + left_off;
             if (cu_tiles > 0)
                 FSN_TRY(fsn_launch_lstm_step_cu(gx_left, whh, h_prev, h_out, c_left, gx_rt0, cu_tiles, H, t == 0, s));
@@ -444,9 +459,12 @@ static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* g
 static int run_sb_recurrence(const float* gx, const FsnSbInput* xin, const float* gx_left, long left_stride,
                              long left_off, const float* whh, float* hseq, float* c_left, const CoreDims& d,
                              hipStream_t s, const FsnRecFc* fc = nullptr, const void* whh_f16x3 = nullptr,
-                             const void* wih_f16x3 = nullptr) {
+                             const void* wih_f16x3 = nullptr, const float* x_main = nullptr,
+                             const float* wih_main = nullptr, const float* bias_main = nullptr,
+                             float* hseq_left = nullptr) {
     return run_recurrence(gx, xin, gx_left, left_stride, left_off, whh, hseq, c_left, d.Tp, d.Npad, d.Hs, d.rec, s,
-                          fc, fc ? (long)d.rec.left_tiles * 16 : -1, whh_f16x3, wih_f16x3);
+                          fc, fc ? (long)d.rec.left_tiles * 16 : -1, whh_f16x3, wih_f16x3, x_main, wih_main,
+                          bias_main, hseq_left);
 }
 
 // below this many sub-band row tiles (batch <= 5) the two layers of the small-batch step path also run as
@@ -585,9 +603,24 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         const bool l0_split = f16x3 && d.Hs == 384 && 2 * d.nb + 2 == 32;
         FSN_TRY(run_sb_recurrence(nullptr, &xin, w.gx_sb, d.rec.left_tiles, 0, pk + p.sb_whh0, w.hseq_sb0, w.c_left,
                                   d, s, nullptr, l0_split ? pk + p.sb_whh0_f16x3 : nullptr,
-                                  l0_split ? pk + p.sb_wih0_f16x3 : nullptr));
+                                  l0_split ? pk + p.sb_wih0_f16x3 : nullptr, nullptr, nullptr, nullptr,
+                                  d.l1x ? w.hseq_left0 : nullptr));
     }
-    if (!sb_wave) {
+    if (!sb_wave && d.l1x) {
+        // the main rows form this projection inside lstm_rec_x_kernel; only the left-over rows (step kernels) get one
+        if (d.rec.left_tiles > 0) {
+            StageTimer st(ST_SB_GEMM_L1, s);
+            a = FsnGemmA{};
+            c = FsnGemmC{};
+            a.kind = 0;
+            a.p0 = w.hseq_left0;
+            a.ld = d.Hs;
+            c.kind = 0;
+            c.p0 = w.gx_sb;
+            c.bias = pk + p.sb_b1;
+            FSN_TRY(fsn_launch_gemm(a, pk + p.sb_wih1, c, d.Tp * d.rec.left_tiles, 4 * d.Hs / 16, d.Hs / 16, s));
+        }
+    } else if (!sb_wave) {
         StageTimer st(ST_SB_GEMM_L1, s);
         a = FsnGemmA{};
         c = FsnGemmC{};
@@ -621,7 +654,11 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         fc.T = d.T;
         fc.la = d.la;
     }
-    if (!sb_wave) {
+    if (!sb_wave && d.l1x) {
+        StageTimer st(ST_SB_REC_L1, s);
+        FSN_TRY(run_sb_recurrence(nullptr, nullptr, w.gx_sb, d.rec.left_tiles, 0, pk + p.sb_whh1, w.hseq_sb1, w.c_left, d,
+                                  s, &fc, nullptr, nullptr, w.hseq_sb0, pk + p.sb_wih1, pk + p.sb_b1));
+    } else if (!sb_wave) {
         StageTimer st(ST_SB_REC_L1, s);
         const bool f16x3 = cfg->arith == FSN_ARITH_F16X3;  // opt-in experiment, chosen by the caller
         FSN_TRY(run_sb_recurrence(w.gx_sb, nullptr, w.gx_sb, d.rec.tiles, main_rows / 16, pk + p.sb_whh1, w.hseq_sb1,

@@ -230,6 +230,278 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// Last sub-band layer with its INPUT PROJECTION INSIDE: gates = b + x_t W_ih^T + h_{t-1} W_hh^T with x_t = h_t of the
+// layer below, read from that layer's hidden sequence (4.8 GB at config 2).  The separate K = 384 projection GEMM and
+// its 19.2 GB fragment-ordered `gx` round trip (written once, read back once per batch) are gone; the K loop of a gate
+// pass is twice as long (768), so the per-pass costs - cell update, pass boundary, barriers - weigh half as much.
+//
+// h_{t-1} stays in LDS as in lstm_rec_kernel (16 RT x (H + 4) floats); x_t does not fit next to it, so it streams
+// through a two-stage LDS ring in K slices of SK chunks (RT x SK fragments of 1 KB per stage).  The ring is filled by
+// LDS-DMA (global_load_lds_dwordx4: no registers, nothing for the waves to wait on), one fragment per instruction:
+// lane (row i, quarter q) fetches the 16 bytes x[row i][16 kc + 4 q ..] so that a stage holds the A fragments in the
+// lane order ds_read_b128 wants (conflict-free by construction).  A gate pass walks the four slices of x_t and then
+// h_{t-1}; the four passes of a step re-stream the same 96 KB tile (L2 hits), the next slice always in flight behind
+// the current one.  Slice boundaries are LDS-only barriers (the DMA a wave issued a whole slice earlier has long
+// landed: it is older than a dozen weight fragments the wave has consumed since, and loads return in order).
+// Output layer fused exactly as in lstm_rec_kernel (the hidden sequence of this layer is never stored).
+// One 16-byte-per-lane LDS-DMA fragment (1 KB per wave): lane l's 16 bytes at `g` land at LDS byte address
+// lds_base + 16 l.  Written as asm so that the compiler neither serialises later LDS reads behind it (it cannot tell
+// the ring stages apart and would wait for vmcnt(0) before every ds_read) nor counts it in its own vmcnt bookkeeping
+// (an extra, OLDER request in the queue can only make its counted waits longer, never too short).
+__device__ __forceinline__ void lds_dma_fragment(const float* g, unsigned lds_base) {
+    unsigned saved;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, off\n\t"
+        "s_nop 0\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(saved)
+        : "s"(lds_base), "v"(g)
+        : "memory");
+}
+
+template <int H, int RT, int UG>
+__global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgpr(76))) void lstm_rec_x_kernel(const float* __restrict__ xseq,
+                                                                          const float* __restrict__ w_p,
+                                                                          unsigned whh_off,
+                                                                          const float* __restrict__ bias, int Tp,
+                                                                          int Npad, const FsnRecFc fc) {
+    constexpr int NW = H / (16 * UG);
+    constexpr int KC = H / 16;
+    constexpr int HS = H + 4;
+    constexpr int ROWS = RT * 16;
+    constexpr int SK = 6;              // K chunks per x slice
+    constexpr int NSL = KC / SK;       // slices per pass
+    constexpr int NF = RT * SK;        // 1 KB fragments per ring stage
+    static_assert(KC % SK == 0 && SK % 2 == 0 && KC % 2 == 0, "slice width must divide the K range; chunks go in pairs");
+    // xs [2][NF][256] | hl [ROWS][HS] | wl [2][H].  The ring comes first: its LDS-DMA destination travels in M0,
+    // and byte addresses below 64 KB are safe whatever width of M0 the DMA path honours.
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    float* hl = xs + 2 * NF * 256;
+    float* wl = hl + ROWS * HS;
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const long n0 = (long)blockIdx.x * ROWS;
+    for (int i = threadIdx.x; i < 2 * H; i += NW * 64) {  // rows 0 / 1 of the packed output weights, un-tiled
+        const int c = i / H, k = i % H;
+        wl[i] = fc.w_p[(((k >> 4) * 64) + ((k & 15) >> 2) * 16 + c) * 4 + (k & 3)];
+    }
+    float cst[RT][UG][4], tmp[RT][UG][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int u = 0; u < UG; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cst[rt][u][i] = 0.f;
+    for (int i = threadIdx.x; i < ROWS * HS; i += NW * 64) hl[i] = 0.f;
+
+    // ring stage `buf` <- slice `sl` of x_t: this wave's share of the NF fragments
+    const unsigned xlane = (unsigned)(lr * H + 4 * lq);  // lane part of the source address; the rest is uniform
+    const unsigned xs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)xs;  // LDS byte address
+    auto fill = [&](int buf, int t, int sl) {
+        const float* src = xseq + ((long)t * Npad + n0) * H + sl * (SK * 16);  // wave-uniform
+        for (int f = wave; f < NF; f += NW) {
+            const int rt = f / SK, kcl = f - rt * SK;
+            lds_dma_fragment(src + (rt * 16 * H + kcl * 16) + xlane,
+                             __builtin_amdgcn_readfirstlane(xs_lds + (unsigned)((buf * NF + f) * 1024)));
+        }
+    };
+    fill(0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // Weight fragments travel in a two-deep ring (b0 / b1, written out by hand so that no copy is needed and every
+    // wait is for the older of two requests); b0 always holds - or has in flight - the first fragments the next
+    // K chunk needs, across slice, pass and step boundaries (the first chunk of a pass never starts cold).
+    f32x4 b0[UG], b1[UG];
+    // fragment (gate g, unit group u of this wave, chunk kc): element offset from w_p (W_ih, with W_hh whh_off
+    // elements behind it) = a wave-uniform part (scalar registers) + 256 kc, + this lane's 16 bytes
+    // buffer loads (T8): resource descriptor + scalar byte offset + this lane's constant 16 l - no per-load VGPR
+    // address arithmetic at all
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w_p), 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto wofs = [&](int g, int u) { return (unsigned)((g * KC + wave * UG + u) * KC) * 256u; };
+    auto wload = [&](unsigned ofs) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, ofs * 4u, 0));
+    };
+    {
+        int g0 = 1;
+        asm volatile("" : "+s"(g0));
+#pragma unroll
+        for (int u = 0; u < UG; ++u) b0[u] = wload(wofs(g0, u));
+    }
+    // acc[rt][u] += A(16 rows x 16 k) B(16 k x 16 units): a = this lane's A fragment address of row tile 0
+    auto mma = [&](f32x4 (&acc)[RT][UG], const float* a, int a_rt_stride, const f32x4 (&b)[UG]) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(a + rt * a_rt_stride);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[jj], b[u][jj], acc[rt][u]);
+        }
+    };
+
+    for (int t = 0; t < Tp; ++t) {
+        // gate order of evaluation: f (1), i (0), g (2), o (3)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            __builtin_amdgcn_sched_barrier(0);
+            int g = pass == 0 ? 1 : (pass == 1 ? 0 : pass);
+            int gn = pass == 0 ? 0 : (pass == 1 ? 2 : (pass == 2 ? 3 : 1));  // the gate after this one
+            asm volatile("" : "+s"(g));  // opaque: see lstm_rec_kernel
+            asm volatile("" : "+s"(gn));
+            f32x4 acc[RT][UG];
+            unsigned wx[UG], wh[UG], wxn[UG];  // uniform offsets: W_ih / W_hh of this gate, W_ih of the next one
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {
+                wx[u] = wofs(g, u);
+                wh[u] = wx[u] + whh_off;
+                wxn[u] = wofs(gn, u);
+                const float b = bias[(g * KC + wave * UG + u) * 16 + lr];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][u] = f32x4{b, b, b, b};
+            }
+            // ---- x_t W_ih^T, slice by slice ------------------------------------------------------
+#pragma unroll 1
+            for (int sl = 0; sl < NSL; ++sl) {
+                const int j = pass * NSL + sl;  // slice counter of the step: ring stage j & 1
+                if (j > 0) {
+                    // this wave's fills of stage j & 1 were issued a slice ago, before UG SK weight fragments it has
+                    // consumed since; at most the UG prefetched ones are still in flight
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UG) : "memory");
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                }
+                // next slice into the other stage (last read in slice j - 1, which every wave has left):
+                // same x_t for the next pass, x_{t+1} after the last pass
+                {
+                    const int nsl = sl + 1 < NSL ? sl + 1 : 0;
+                    const int nt = (sl + 1 < NSL || pass < 3) ? t : t + 1;
+                    if (nt < Tp) fill((j + 1) & 1, nt, nsl);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const float* xa = xs + ((j & 1) * NF) * 256 + lane * 4;
+#pragma unroll
+                for (int kk = 0; kk < SK; kk += 2) {
+                    const int kc = sl * SK + kk;
+#pragma unroll
+                    for (int u = 0; u < UG; ++u)
+                        b1[u] = wload(wx[u] + (unsigned)(kc + 1) * 256u);
+                    __builtin_amdgcn_sched_barrier(0);  // requests first, pinned: hipcc otherwise sinks them to their use
+                    mma(acc, xa + kk * 256, SK * 256, b0);
+                    // chunk kc + 2: W_ih, or the first chunk of W_hh, or (h_{-1} = 0: no W_hh product) of the next pass
+                    const bool more_x = kc + 2 < KC;
+#pragma unroll
+                    for (int u = 0; u < UG; ++u) {
+                        b0[u] = wload(more_x ? wx[u] + (unsigned)(kc + 2) * 256u : (t > 0 ? wh[u] : wxn[u]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(acc, xa + (kk + 1) * 256, SK * 256, b1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- h_{t-1} W_hh^T (h_{-1} = 0) -------------------------------------------------------
+            if (t > 0) {
+                const float* ha = hl + lr * HS + 4 * lq;
+#pragma unroll 1
+                for (int kc = 0; kc < KC; kc += 2) {
+#pragma unroll
+                    for (int u = 0; u < UG; ++u)
+                        b1[u] = wload(wh[u] + (unsigned)(kc + 1) * 256u);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(acc, ha + kc * 16, 16 * HS, b0);
+                    const bool more_h = kc + 2 < KC;
+#pragma unroll
+                    for (int u = 0; u < UG; ++u) {
+                        b0[u] = wload(more_h ? wh[u] + (unsigned)(kc + 2) * 256u : wxn[u]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(acc, ha + (kc + 1) * 16, 16 * HS, b1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#define FSN_REC_EPILOGUE(VAR, EXPR)                                                                   \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                 \
+    _Pragma("unroll") for (int u = 0; u < UG; ++u)                                                    \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+        VAR[rt][u][i] = EXPR;                                                                         \
+        asm volatile("" : "+v"(VAR[rt][u][i]));                                                       \
+    }
+            if (pass == 0) {
+                FSN_REC_EPILOGUE(cst, sigmoid_fast(acc[rt][u][i]) * cst[rt][u][i])
+            } else if (pass == 1) {
+                FSN_REC_EPILOGUE(tmp, sigmoid_fast(acc[rt][u][i]))
+            } else if (pass == 2) {
+                FSN_REC_EPILOGUE(cst, cst[rt][u][i] + tmp[rt][u][i] * tanh_fast(acc[rt][u][i]))
+            } else {
+                FSN_REC_EPILOGUE(tmp, sigmoid_fast(acc[rt][u][i]) * tanh_fast(cst[rt][u][i]))
+            }
+#undef FSN_REC_EPILOGUE
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // every wave has finished reading h_{t-1}; the fill of the next step's first slice stays in flight
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        {
+            // one base register, re-derived every step (opaque to the optimiser): hoisted out of the time loop the
+            // 32 store addresses become 32 live registers that end up in scratch
+            unsigned hwb = (unsigned)((4 * lq) * HS + (wave * UG) * 16 + lr);
+            asm volatile("" : "+v"(hwb));
+            float* hw = hl + hwb;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int u = 0; u < UG; ++u)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hw[(rt * 16 + i) * HS + u * 16] = tmp[rt][u][i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();  // h_t complete in LDS
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        {
+            // output layer on the spot (nn.Linear(H, 2)): 4 threads per (row, output), a quarter of K each
+            const int tid = threadIdx.x;
+            if (tid < ROWS * 8) {
+                const int part = tid & 3, c = (tid >> 2) & 1, row = tid >> 3;
+                const float* hp = hl + row * HS + part * (H / 4);
+                const float* wp = wl + c * H + part * (H / 4);
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll 2
+                for (int k = 0; k < H / 4; k += 8) {
+                    const f32x4 h0 = *reinterpret_cast<const f32x4*>(hp + k), w0 = *reinterpret_cast<const f32x4*>(wp + k);
+                    const f32x4 h1 = *reinterpret_cast<const f32x4*>(hp + k + 4),
+                                w1 = *reinterpret_cast<const f32x4*>(wp + k + 4);
+                    a0 = fmaf(h0[0], w0[0], a0);
+                    a0 = fmaf(h0[1], w0[1], a0);
+                    a0 = fmaf(h0[2], w0[2], a0);
+                    a0 = fmaf(h0[3], w0[3], a0);
+                    a1 = fmaf(h1[0], w1[0], a1);
+                    a1 = fmaf(h1[1], w1[1], a1);
+                    a1 = fmaf(h1[2], w1[2], a1);
+                    a1 = fmaf(h1[3], w1[3], a1);
+                }
+                float v = a0 + a1;
+                v += __shfl_xor(v, 1, 64);
+                v += __shfl_xor(v, 2, 64);
+                const long n = n0 + row;
+                if (part == 0 && t >= fc.la && n < fc.N) {
+                    const long ng = n + fc.row0;
+                    const int b = (int)(ng / fc.F), f = (int)(ng % fc.F);
+                    (c ? fc.crm_i : fc.crm_r)[((long)b * fc.T + (t - fc.la)) * fc.FP + f] = v + fc.bias[c];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Small-N variant (RT <= 2, i.e. fewer row tiles than ~2 per CU: small batches, per-rank shards of a
 // strong-scaled batch, single utterances).  With 16-32 rows per workgroup a K chunk is only 8-16 MFMAs
 // per gate, far shorter than the L2 latency of its B fragments, and lstm_rec_kernel's four sequential
@@ -671,12 +943,14 @@ __global__ __launch_bounds__(256) void lstm_step_cu_kernel(const float* __restri
 // inference-only instance without the training outputs (40 + 16 registers; checked by
 // tests/test_host_cpu.py on the code object).  With more it silently waits for the 32 ms persistent
 // kernel to end (measured: +1.4 ms per batch).
-__global__ __launch_bounds__(256) void lstm_step1_kernel(const float* __restrict__ gx,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(24))) void lstm_step1_kernel(const float* __restrict__ gx,
                                                          const float* __restrict__ whh_p,
                                                          const float* __restrict__ h_prev,
                                                          float* __restrict__ h_out, float* __restrict__ c,
                                                          long gx_rt0, int H, int first) {
-    __shared__ f32x4 red[3][4][64];
+    // split-K partials meet pairwise (8 KB of LDS instead of 12): next to lstm_rec_x_kernel's 151.5 KB there is
+    // room for exactly one such workgroup per CU, and this chain has ~10 x slack against the kernel it runs beside
+    __shared__ f32x4 red[2][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int ug = blockIdx.x, rtile = blockIdx.y;
@@ -699,9 +973,21 @@ __global__ __launch_bounds__(256) void lstm_step1_kernel(const float* __restrict
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[g] = mfma16(a[j], b[g][j], acc[g]);
         }
-        if (wave > 0) {
+        if (wave >= 2) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) red[wave - 1][g][lane] = acc[g];
+            for (int g = 0; g < 4; ++g) red[wave - 2][g][lane] = acc[g];
+        }
+        __syncthreads();
+        if (wave >= 2) return;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // wave 0 += wave 2, wave 1 += wave 3
+            const f32x4 r = red[wave][g][lane];
+            acc[g] = f32x4{acc[g][0] + r[0], acc[g][1] + r[1], acc[g][2] + r[2], acc[g][3] + r[3]};
+        }
+        __syncthreads();
+        if (wave == 1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) red[0][g][lane] = acc[g];
         }
         __syncthreads();
     }
@@ -710,12 +996,9 @@ __global__ __launch_bounds__(256) void lstm_step1_kernel(const float* __restrict
     // templated form over the register budget
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        if (!first) {
-#pragma unroll
-            for (int w = 0; w < 3; ++w) {
-                const f32x4 r = red[w][g][lane];
-                acc[g] = f32x4{acc[g][0] + r[0], acc[g][1] + r[1], acc[g][2] + r[2], acc[g][3] + r[3]};
-            }
+        if (!first) {  // (w0 + w2) + (w1 + w3)
+            const f32x4 r = red[0][g][lane];
+            acc[g] = f32x4{acc[g][0] + r[0], acc[g][1] + r[1], acc[g][2] + r[2], acc[g][3] + r[3]};
         }
         const f32x4 x = *reinterpret_cast<const f32x4*>(gx + (((gx_rt0 + rtile) * CT + g * KC + ug) * 64 + lane) * 4);
         acc[g] = f32x4{acc[g][0] + x[0], acc[g][1] + x[1], acc[g][2] + x[2], acc[g][3] + x[3]};
@@ -905,7 +1188,44 @@ int launch_rec(const float* gx, const FsnSbInput* xin, const float* whh_p, float
     return fsn_check_launch("lstm_rec_kernel");
 }
 
+template <int H, int RT, int UG = 2>
+int launch_rec_x(const float* xseq, const float* wih_p, const float* whh_p, const float* bias, int Tp, int Npad,
+                 int main_wgs, hipStream_t s, const FsnRecFc* fc) {
+    constexpr int NW = H / (16 * UG);
+    const size_t lds = ((size_t)RT * 16 * (H + 4) + 2 * H + (size_t)2 * RT * 6 * 256) * sizeof(float);
+    auto kern = lstm_rec_x_kernel<H, RT, UG>;
+    if (lds > 160 * 1024 ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
+        fsn_set_error("lstm_rec_x: cannot reserve %zu bytes of LDS", lds);
+        return FSN_ERR_LAUNCH;
+    }
+    if (whh_p < wih_p || whh_p - wih_p > 0x3fffffffL) {
+        fsn_set_error("lstm_rec_x: W_hh must follow W_ih in one packed buffer");
+        return FSN_ERR_ARG;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)main_wgs), dim3(NW * 64), lds, s, xseq, wih_p, (unsigned)(whh_p - wih_p), bias,
+                       Tp, Npad, *fc);
+    return fsn_check_launch("lstm_rec_x_kernel");
+}
+
 }  // namespace
+
+// The last sub-band layer with its input projection inside (lstm_rec_x_kernel): built for H = 384 and 2 - 4 row
+// tiles per workgroup (at 5 the x ring no longer fits beside the hidden state; the caller then keeps the
+// projection GEMM + lstm_rec_kernel pair).
+bool fsn_lstm_rec_x_supported(int H, int RT) { return H == 384 && RT >= 2 && RT <= 4; }
+
+int fsn_launch_lstm_rec_x(const float* xseq, const float* wih_p, const float* whh_p, const float* bias, int Tp, int Npad,
+                          int H, int RT, int main_wgs, hipStream_t s, const FsnRecFc* fc) {
+    if (!fc || !fc->w_p || !fsn_lstm_rec_x_supported(H, RT)) {
+        fsn_set_error("lstm_rec_x: needs the fused output layer, H = 384 and 2 - 4 row tiles (got H %d, RT %d)", H, RT);
+        return FSN_ERR_ARG;
+    }
+    if (RT == 2) return launch_rec_x<384, 2>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, fc);
+    if (RT == 3) return launch_rec_x<384, 3>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, fc);
+    return launch_rec_x<384, 4>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, fc);
+}
 
 // How the N sub-band sequences are laid out on the chip.  One workgroup per CU (LDS-bound), RT
 // 16-row tiles per workgroup, so a single launch is worth max-RT tile-times and

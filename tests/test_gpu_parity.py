@@ -225,11 +225,13 @@ def test_oracle_parity_fresh_weights(fsn):
     assert np.abs(enh.cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("batch", [16, 33])
+@pytest.mark.parametrize("batch", [16, 33, 48])
 def test_more_row_tiles_than_cus(fsn, batch):
     """B*F/16 > 256 tiles: the persistent recurrent kernel takes floor(tiles/CUs) tiles per CU and
     the left-over tiles run step by step on the auxiliary stream (B=16: 257 tiles -> 256 + 1;
-    B=33: 531 tiles -> 2 x 256 + 19 -> general multi-round plan).  Every row must still match."""
+    B=33: 531 tiles -> 2 x 256 + 19 -> general multi-round plan; B=48: 771 tiles -> 3 x 256 + 3).  At 2 - 4 tiles
+    per workgroup the last layer forms its input projection itself (lstm_rec_x_kernel); at one tile per workgroup it
+    runs on the projection GEMM + lstm_rec_kernel pair.  Every row must still match."""
     meta = dict(seed_w=5, gain=2.0, mask_gain=24.0, norm_type="offline_laplace_norm", groups=1)
     model, params = build_model(fsn, meta)
     noisy = O.make_noisy(batch, 1300, seed=31)
@@ -516,3 +518,55 @@ def test_experimental_f16x3_matches_fp32(fsn):
     dev_burst = np.abs(got_b - ref_b).max()
     print(f"f16x3 vs fp32 mask deviation: noisy {dev_noisy:.2e}, tone burst {dev_burst:.2e}")
     assert dev_burst <= 1e-4
+
+
+def test_two_streams_and_two_host_threads_are_independent(fsn):
+    """re-entrant across streams.  The library's only state is one record per (device, caller stream)
+    (auxiliary stream + fork / join events for the left-over tiles, profiler events): two host threads, each on its
+    own torch stream, run the 257-row-tile plan (persistent kernel + a left-over tile on the auxiliary stream)
+    concurrently and repeatedly; every result is bit-identical to the serial one."""
+    import threading
+    meta = dict(seed_w=0, gain=2.0, mask_gain=24.0, norm_type="offline_laplace_norm", groups=1)
+    model, _ = build_model(fsn, meta)
+    inputs = [dev(O.make_noisy(16, 2048, seed=s)) for s in (1, 2)]
+    serial = [model.enhance(x).clone() for x in inputs]
+    model.packed_weights()
+    torch.cuda.synchronize()
+    results, errors = [None, None], []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                out = None
+                for _ in range(3):
+                    out = model.enhance(inputs[i])
+                st.synchronize()
+                results[i] = out.clone()
+        except Exception as e:  # surfaced in the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    for got, want in zip(results, serial):
+        assert torch.equal(got, want)
+    # profiler records are per stream as well: a profiled call on a side stream does not disturb the default stream's
+    L = fsn._lib.lib()
+    L.fsn_profile_enable(1)
+    try:
+        model.enhance(inputs[0])
+        main_ms = fsn._lib.profile_read(inputs[0].device)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            model.enhance(inputs[1])
+            side_ms = fsn._lib.profile_read(inputs[1].device)
+        again = fsn._lib.profile_read(inputs[0].device)
+    finally:
+        L.fsn_profile_enable(0)
+    assert main_ms["sb_rec_l0"] > 0 and side_ms["sb_rec_l0"] > 0
+    assert again == main_ms
