@@ -77,7 +77,7 @@ def _config(tmp_path, epochs=2):
 
 
 def _loaders():
-    train = [(wav(2, 2560, 50 + i), 0.7 * wav(2, 2560, 60 + i)) for i in range(2)]
+    train = [(wav(4, 2560, 50 + i), 0.7 * wav(4, 2560, 60 + i)) for i in range(2)]  # drop_band needs B > groups
     valid = [(wav(1, 3000, 70), 0.7 * wav(1, 3000, 71), ["a"], ["With_reverb"]),
              (wav(1, 2800, 72), 0.7 * wav(1, 2800, 73), ["b"], ["No_reverb"]),
              (wav(1, 2600, 74), 0.7 * wav(1, 2600, 75), ["c"], ["With_reverb"])]
@@ -171,11 +171,11 @@ def _ddp_worker(rank, world, port):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
-        noisy, clean = wav(4, 2560, 41).cuda(), (0.7 * wav(4, 2560, 42)).cuda()
+        noisy, clean = wav(8, 2560, 41).cuda(), (0.7 * wav(8, 2560, 42)).cuda()
         ref = make_model(fsn).train()
         train_step(ref, torch.optim.SGD(ref.parameters(), lr=0.0), noisy, clean)  # whole batch, one process
         ddp = torch.nn.parallel.DistributedDataParallel(make_model(fsn).train(), device_ids=[0])  # base_trainer.py:32
-        lo, hi = 2 * rank, 2 * rank + 2   # drop_band groups = 2 keeps the sample parity of the global batch
+        lo, hi = 4 * rank, 4 * rank + 4   # drop_band groups = 2 keeps the sample parity of the global batch
         loss = train_step(ddp, torch.optim.SGD(ddp.parameters(), lr=0.0), noisy[lo:hi], clean[lo:hi])
         assert torch.isfinite(loss)
         for (k, p), (_, q) in zip(ref.named_parameters(), ddp.module.named_parameters()):

@@ -83,10 +83,12 @@ def test_config2_length_vs_reference(golden_dir):
     z, meta = load(golden_dir, "fsn_long_b2")
     params, noisy = inputs(meta)
     b, ss = z["bins"], meta["sample_stride"]
-    y, inter = O.full_band_crm_mask(noisy, params, return_intermediates=True)
+    import torch
+    win = torch.hann_window(512).numpy()  # the reference's window (SLEEF cosine; numpy's differs in the last bit)
+    y, inter = O.full_band_crm_mask(noisy, params, window=win, return_intermediates=True)
     assert np.abs(inter["crm"][:, :, b] - z["crm"]).max() <= 1e-4
     assert np.abs(y[:, ::ss] - z["enhanced"]).max() <= 2e-3 * float(z["enhanced_absmax"])
-    _, _, re, im = O.stft(noisy)
+    _, _, re, im = O.stft(noisy, window=win)
     ulp = np.spacing(z["frame_max"].astype(np.float32))  # per-frame max |X| over ALL bins of the reference
     u = np.maximum(np.abs(re[:, b] - z["real"]), np.abs(im[:, b] - z["imag"])) / ulp
     # the oracle is the exactly-rounded DFT; at 376 frames MKL's own error reaches 2.4 ULP here (2.95 in BASELINE.md)
