@@ -41,10 +41,11 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, de
 MAC_FB = 2048 * (257 + 512) + 2048 * (512 + 512) + 512 * 257
 MAC_SB_PER_BIN = 1536 * (32 + 384) + 1536 * (384 + 384) + 384 * 2
 MAC_PER_FRAME = MAC_FB + 257 * MAC_SB_PER_BIN
-# the recurrent kernel, per sub-band row and step: layer 0 = W_hh h + the fused W_ih x (K = 32),
-# layer 1 = W_hh h only (its K = 384 input projection is a separate GEMM)
+# the two persistent recurrent kernels, per sub-band row and step: layer 0 (lstm_rec_in_kernel) = W_hh h + W_ih x with
+# K = 32 + 384; layer 1 (lstm_rec_x_kernel) = W_ih h0 + W_hh h with K = 384 + 384 (its input projection is inside
+# since round 2: no projection GEMM, no gx round trip)
 MAC_REC_L0 = 1536 * (384 + 32)
-MAC_REC_L1 = 1536 * 384
+MAC_REC_L1 = 1536 * (384 + 384)
 
 
 def build_model(device):
@@ -338,7 +339,8 @@ def main():
                        "frames_per_utterance": T, "parallelism": head["par"]},
             "rtf_speedup_audio_s_per_s": round(value / (SR / HOP), 1),
             "rtf_classic": round((SR / HOP) / value, 6),
-            "roofline": {"bound": "mfma", "kernel": "lstm_rec_kernel<384,RT,2,*> (sub-band recurrent; 2 launches/step)",
+            "roofline": {"bound": "mfma", "kernel": "lstm_rec_in_kernel<384,4,2> + lstm_rec_x_kernel<384,4,2> (the two "
+                                                     "persistent sub-band recurrent launches of a step)",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                          # PMC passes are separate rocprofv3 runs at config 2 (B = 64, 1 GPU)
@@ -346,6 +348,10 @@ def main():
                          "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc)",
                          "mfma_busy_frac": mfma_busy, "pmc_source": pmc_src,
                          "flops_per_launch": rec_flops / 2, "ms_per_launch": round(rec_ms / 2, 3),
+                         "launches": {"sb_rec_l0": {"flops": 2.0 * MAC_REC_L0 * rows_steps,
+                                                    "ms": round(stage_ms.get("sb_rec_l0", 0.0), 3)},
+                                      "sb_rec_l1": {"flops": 2.0 * MAC_REC_L1 * rows_steps,
+                                                    "ms": round(stage_ms.get("sb_rec_l1", 0.0), 3)}},
                          "whole_path_frac": round(path_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         }

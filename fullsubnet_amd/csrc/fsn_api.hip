@@ -420,6 +420,8 @@ static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* g
     if (r.main_wgs > 0) {
         if (x_main)
             FSN_TRY(fsn_launch_lstm_rec_x(x_main, wih_main, whh, bias_main, Tp, Npad, H, r.rt, r.main_wgs, s, fc));
+        else if (xin && !fc && !whh_f16x3 && fsn_lstm_rec_in_supported(xin, whh, H, r.rt))
+            FSN_TRY(fsn_launch_lstm_rec_in(xin, whh, hseq, Tp, Npad, H, r.rt, r.main_wgs, s));
         else if (whh_f16x3 && fc && !xin && r.rt >= 2)  // experimental split-precision persistent kernel (FSN_F16X3=1)
             FSN_TRY(fsn_launch_lstm_rec_f16x3(gx, whh_f16x3, Tp, Npad, H, r.rt, r.main_wgs, fc, s));
         else if (whh_f16x3 && wih_f16x3 && xin && !xin->x_rows && xin->kin_chunks == 2 && r.rt >= 2)

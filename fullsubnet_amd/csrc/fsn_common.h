@@ -245,6 +245,10 @@ int fsn_launch_lstm_step_train(const float* gx, const float* whh_p, const float*
 int fsn_launch_lstm_rec(const float* gx, const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad,
                         int H, int RT, int main_wgs, hipStream_t s, const FsnRecFc* fc = nullptr);
 bool fsn_lstm_rec_can_fuse_fc(int RT, bool xin);
+// first sub-band layer on the persistent kernel with the weight ring / deferred input staging (see the kernel)
+bool fsn_lstm_rec_in_supported(const FsnSbInput* xin, const float* whh_p, int H, int RT);
+int fsn_launch_lstm_rec_in(const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad, int H, int RT,
+                           int main_wgs, hipStream_t s);
 // last layer with its input projection inside: xseq [Tp][Npad][H] is the hidden sequence of the layer below,
 // wih_p / whh_p the packed weights, bias = b_ih + b_hh [4H]; the output layer (fc) is always fused
 bool fsn_lstm_rec_x_supported(int H, int RT);

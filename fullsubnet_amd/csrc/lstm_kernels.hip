@@ -244,6 +244,223 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const fl
 // the current one.  Slice boundaries are LDS-only barriers (the DMA a wave issued a whole slice earlier has long
 // landed: it is older than a dozen weight fragments the wave has consumed since, and loads return in order).
 // Output layer fused exactly as in lstm_rec_kernel (the hidden sequence of this layer is never stored).
+// ---------------------------------------------------------------------------------------------
+// One frame of the sub-band model input for the persistent first-layer kernel, in two halves so that the memory
+// latency is never exposed: `issue` requests ALL of a thread's elements (and their divisors) at once, `commit`
+// divides and writes them to the LDS tile a gate pass later.  No 64-bit division per element: the rows of a
+// workgroup are consecutive, so (b, f) of a row follow from (b0, f0) of the workgroup's first row by a carry.
+// Same operands, same IEEE division as fsn_sb_input_value: bit-identical values.
+template <int NTHREADS, int ROWS, int EPT>
+struct SbStage {
+    float raw[EPT], den[EPT];
+    __device__ __forceinline__ void issue(const FsnSbInput& x, long n0, int b0, int f0, int t) {
+        // the element indices do not depend on the step; left visible, the optimiser computes them once and keeps
+        // a dozen registers live through the whole kernel
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + e * NTHREADS;
+            const int row = i >> 5, c = i & 31;  // 32 input columns (two K chunks)
+            const long n = n0 + row;             // local row (validity, per-row divisors); (b, f) are global
+            const bool ok = i < ROWS * 32 && n < x.N && c <= 2 * x.nb + 1;
+            const unsigned fr = (unsigned)(f0 + row), q = fr / (unsigned)x.F;  // the carry: rows are consecutive
+            const int b = b0 + (int)q, f = (int)(fr - q * (unsigned)x.F);
+            const long fo = ((long)b * x.Tp + t) * x.FP;
+            int j = f + c - x.nb;
+            j = j < 0 ? -j : j;
+            j = j >= x.F ? 2 * (x.F - 1) - j : j;
+            const float* src = c <= 2 * x.nb ? x.mag + fo + j : x.fb_out + fo + f;
+            // branch-free: an element that is not there reads element 0 and is replaced by zero in commit()
+            raw[e] = *(ok ? src : x.mag);
+            den[e] = x.den[ok ? (x.den_mode ? (long)t * x.den_stride + (n + x.row0) : (long)b) : 0];
+        }
+    }
+    __device__ __forceinline__ void commit(const FsnSbInput& x, float* xl, int xs, long n0) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + e * NTHREADS;
+            const int row = i >> 5, c = i & 31;
+            const bool ok = n0 + row < x.N && c <= 2 * x.nb + 1;
+            if (i < ROWS * 32) xl[row * xs + c] = ok ? raw[e] / den[e] : 0.f;
+        }
+    }
+};
+
+// First sub-band layer, persistent (the successor of lstm_rec_kernel<.., XIN = true> for the 32-column sub-band
+// input): gates = b + x_t W_ih^T (K = 32, x_t = freq_unfold ++ fb_output, normalised: fullsubnet/model.py:98-111,
+// gathered into a double-buffered LDS tile) + h_{t-1} W_hh^T.  Against its predecessor:
+//   - weight fragments travel in a two-deep buffer-load ring that runs through the x chunks, the h chunks, and on
+//     into the next pass / step (a gate pass never starts cold; no per-load address arithmetic);
+//   - the next frame's gather is requested at the start of a step and written to LDS one gate pass later, into
+//     registers that are dead during that pass (its latency used to be exposed on all 12 waves once per step);
+//   - the two barriers of a step only order LDS traffic;
+//   - the bias of the next pass is requested a pass ahead.
+// W_hh must follow W_ih in one packed buffer (element offset whh_off).  hseq [Tp][Npad][H] receives h_t.
+template <int H, int RT, int UG>
+__global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgpr(76))) void lstm_rec_in_kernel(
+    const FsnSbInput xin, const float* __restrict__ w_p, unsigned whh_off, float* __restrict__ hseq, int Tp, int Npad) {
+    constexpr int NW = H / (16 * UG);
+    constexpr int KC = H / 16;
+    constexpr int KX = 2;   // x chunks (32 input columns)
+    constexpr int HS = H + 4;
+    constexpr int XS = 36;  // row stride of the x tile
+    constexpr int ROWS = RT * 16;
+    constexpr int EPT = (ROWS * 32 + NW * 64 - 1) / (NW * 64);
+    extern __shared__ __attribute__((aligned(16))) float hl[];  // [ROWS][HS] | xl [2][ROWS][XS]
+    float* xl = hl + ROWS * HS;
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const long n0 = (long)blockIdx.x * ROWS;
+    const int sb_b0 = (int)((n0 + xin.row0) / xin.F);  // (b, f) of the workgroup's first row, once
+    const int sb_f0 = (int)((n0 + xin.row0) - (long)sb_b0 * xin.F);
+
+    float cst[RT][UG][4], tmp[RT][UG][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int u = 0; u < UG; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cst[rt][u][i] = 0.f;
+    for (int i = threadIdx.x; i < ROWS * HS; i += NW * 64) hl[i] = 0.f;
+    SbStage<NW * 64, ROWS, EPT> stage;
+    stage.issue(xin, n0, sb_b0, sb_f0, 0);
+    stage.commit(xin, xl, XS, n0);
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w_p), 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto wload = [&](unsigned ofs) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, ofs * 4u, 0));
+    };
+    auto wxofs = [&](int g, int u) { return (unsigned)((g * KC + wave * UG + u) * KX) * 256u; };
+    auto whofs = [&](int g, int u) { return whh_off + (unsigned)((g * KC + wave * UG + u) * KC) * 256u; };
+    f32x4 b0[UG], b1[UG];
+    float bias_n[UG];
+    {
+        int g0 = 1;
+        asm volatile("" : "+s"(g0));
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            b0[u] = wload(wxofs(g0, u));
+            bias_n[u] = xin.bias[(g0 * KC + wave * UG + u) * 16 + lr];
+        }
+    }
+    auto mma = [&](f32x4 (&acc)[RT][UG], const float* a, int a_rt_stride, const f32x4 (&b)[UG]) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(a + rt * a_rt_stride);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[jj], b[u][jj], acc[rt][u]);
+        }
+    };
+
+    for (int t = 0; t < Tp; ++t) {
+        // frame t + 1: requested now, written to the other x buffer after the first gate pass (that buffer was last
+        // read in step t - 1 and is first read after the two barriers that end this step)
+        const bool more = t + 1 < Tp;
+        if (more) stage.issue(xin, n0, sb_b0, sb_f0, t + 1);
+        const float* xa = xl + (t & 1) * ROWS * XS + lr * XS + 4 * lq;
+        const float* ha = hl + lr * HS + 4 * lq;
+        // gate order of evaluation: f (1), i (0), g (2), o (3)
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            __builtin_amdgcn_sched_barrier(0);
+            int g = pass == 0 ? 1 : (pass == 1 ? 0 : pass);
+            int gn = pass == 0 ? 0 : (pass == 1 ? 2 : (pass == 2 ? 3 : 1));  // the gate after this one
+            asm volatile("" : "+s"(g));  // opaque: see lstm_rec_kernel
+            asm volatile("" : "+s"(gn));
+            f32x4 acc[RT][UG];
+            unsigned wx[UG], wh[UG], wxn[UG];
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {
+                wx[u] = wxofs(g, u);
+                wh[u] = whofs(g, u);
+                wxn[u] = wxofs(gn, u);
+                const float b = bias_n[u];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][u] = f32x4{b, b, b, b};
+                bias_n[u] = xin.bias[(gn * KC + wave * UG + u) * 16 + lr];  // a pass ahead
+            }
+            // ---- x_t W_ih^T: two chunks -----------------------------------------------------------
+#pragma unroll
+            for (int u = 0; u < UG; ++u) b1[u] = wload(wx[u] + 256u);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(acc, xa, 16 * XS, b0);
+#pragma unroll
+            for (int u = 0; u < UG; ++u) b0[u] = wload(t > 0 ? wh[u] : wxn[u]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(acc, xa + 16, 16 * XS, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- h_{t-1} W_hh^T (h_{-1} = 0) -------------------------------------------------------
+            if (t > 0) {
+#pragma unroll 1
+                for (int kc = 0; kc < KC; kc += 2) {
+#pragma unroll
+                    for (int u = 0; u < UG; ++u) b1[u] = wload(wh[u] + (unsigned)(kc + 1) * 256u);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(acc, ha + kc * 16, 16 * HS, b0);
+                    const bool more_h = kc + 2 < KC;
+#pragma unroll
+                    for (int u = 0; u < UG; ++u) b0[u] = wload(more_h ? wh[u] + (unsigned)(kc + 2) * 256u : wxn[u]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(acc, ha + (kc + 1) * 16, 16 * HS, b1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#define FSN_REC_EPILOGUE(VAR, EXPR)                                                                   \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                 \
+    _Pragma("unroll") for (int u = 0; u < UG; ++u)                                                    \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+        VAR[rt][u][i] = EXPR;                                                                         \
+        asm volatile("" : "+v"(VAR[rt][u][i]));                                                       \
+    }
+            if (pass == 0) {
+                FSN_REC_EPILOGUE(cst, sigmoid_fast(acc[rt][u][i]) * cst[rt][u][i])
+                if (more) stage.commit(xin, xl + ((t + 1) & 1) * ROWS * XS, XS, n0);  // tmp's registers are free here
+            } else if (pass == 1) {
+                FSN_REC_EPILOGUE(tmp, sigmoid_fast(acc[rt][u][i]))
+            } else if (pass == 2) {
+                FSN_REC_EPILOGUE(cst, cst[rt][u][i] + tmp[rt][u][i] * tanh_fast(acc[rt][u][i]))
+            } else {
+                FSN_REC_EPILOGUE(tmp, sigmoid_fast(acc[rt][u][i]) * tanh_fast(cst[rt][u][i]))
+            }
+#undef FSN_REC_EPILOGUE
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // every wave has finished reading h_{t-1}
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        {
+            unsigned hwb = (unsigned)((4 * lq) * HS + (wave * UG) * 16 + lr);
+            asm volatile("" : "+v"(hwb));  // re-derived every step: see lstm_rec_x_kernel
+            float* hw = hl + hwb;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int u = 0; u < UG; ++u)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hw[(rt * 16 + i) * HS + u * 16] = tmp[rt][u][i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();  // h_t complete in LDS
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        // stream h_t out as whole rows: hseq[t][n0 + row][0..H)
+        float* dst = hseq + ((long)t * Npad + n0) * H;
+        for (int i = threadIdx.x; i < ROWS * (H / 4); i += NW * 64) {
+            const int row = i / (H / 4), c4 = i % (H / 4);
+            *reinterpret_cast<f32x4*>(dst + (long)row * H + c4 * 4) = *reinterpret_cast<const f32x4*>(hl + row * HS + c4 * 4);
+        }
+    }
+}
+
 // One 16-byte-per-lane LDS-DMA fragment (1 KB per wave): lane l's 16 bytes at `g` land at LDS byte address
 // lds_base + 16 l.  Written as asm so that the compiler neither serialises later LDS reads behind it (it cannot tell
 // the ring stages apart and would wait for vmcnt(0) before every ds_read) nor counts it in its own vmcnt bookkeeping
@@ -328,11 +545,15 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
     auto wload = [&](unsigned ofs) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, ofs * 4u, 0));
     };
+    float bias_n[UG];  // the bias of the coming pass, requested a pass ahead
     {
         int g0 = 1;
         asm volatile("" : "+s"(g0));
 #pragma unroll
-        for (int u = 0; u < UG; ++u) b0[u] = wload(wofs(g0, u));
+        for (int u = 0; u < UG; ++u) {
+            b0[u] = wload(wofs(g0, u));
+            bias_n[u] = bias[(g0 * KC + wave * UG + u) * 16 + lr];
+        }
     }
     // acc[rt][u] += A(16 rows x 16 k) B(16 k x 16 units): a = this lane's A fragment address of row tile 0
     auto mma = [&](f32x4 (&acc)[RT][UG], const float* a, int a_rt_stride, const f32x4 (&b)[UG]) {
@@ -362,9 +583,10 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 wx[u] = wofs(g, u);
                 wh[u] = wx[u] + whh_off;
                 wxn[u] = wofs(gn, u);
-                const float b = bias[(g * KC + wave * UG + u) * 16 + lr];
+                const float b = bias_n[u];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) acc[rt][u] = f32x4{b, b, b, b};
+                bias_n[u] = bias[(gn * KC + wave * UG + u) * 16 + lr];
             }
             // ---- x_t W_ih^T, slice by slice ------------------------------------------------------
 #pragma unroll 1
@@ -1209,7 +1431,41 @@ int launch_rec_x(const float* xseq, const float* wih_p, const float* whh_p, cons
     return fsn_check_launch("lstm_rec_x_kernel");
 }
 
+template <int H, int RT, int UG = 2>
+int launch_rec_in(const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad, int main_wgs, hipStream_t s) {
+    constexpr int NW = H / (16 * UG);
+    const size_t lds = ((size_t)RT * 16 * (H + 4) + (size_t)2 * RT * 16 * 36) * sizeof(float);
+    auto kern = lstm_rec_in_kernel<H, RT, UG>;
+    if (lds > 160 * 1024 ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
+        fsn_set_error("lstm_rec_in: cannot reserve %zu bytes of LDS", lds);
+        return FSN_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)main_wgs), dim3(NW * 64), lds, s, *xin, xin->wih_p,
+                       (unsigned)(whh_p - xin->wih_p), hseq, Tp, Npad);
+    return fsn_check_launch("lstm_rec_in_kernel");
+}
+
 }  // namespace
+
+// First sub-band layer on lstm_rec_in_kernel: the 32-column sub-band input (two K chunks), H = 384, 2 - 4 row tiles
+// per workgroup, W_hh packed right behind W_ih.  Anything else stays on lstm_rec_kernel<.., XIN = true>.
+bool fsn_lstm_rec_in_supported(const FsnSbInput* xin, const float* whh_p, int H, int RT) {
+    return xin && !xin->x_rows && xin->kin_chunks == 2 && H == 384 && RT >= 2 && RT <= 4 && whh_p > xin->wih_p &&
+           whh_p - xin->wih_p < 0x3fffffffL;
+}
+
+int fsn_launch_lstm_rec_in(const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad, int H, int RT,
+                           int main_wgs, hipStream_t s) {
+    if (!fsn_lstm_rec_in_supported(xin, whh_p, H, RT)) {
+        fsn_set_error("lstm_rec_in: unsupported configuration");
+        return FSN_ERR_ARG;
+    }
+    if (RT == 2) return launch_rec_in<384, 2>(xin, whh_p, hseq, Tp, Npad, main_wgs, s);
+    if (RT == 3) return launch_rec_in<384, 3>(xin, whh_p, hseq, Tp, Npad, main_wgs, s);
+    return launch_rec_in<384, 4>(xin, whh_p, hseq, Tp, Npad, main_wgs, s);
+}
 
 // The last sub-band layer with its input projection inside (lstm_rec_x_kernel): built for H = 384 and 2 - 4 row
 // tiles per workgroup (at 5 the x ring no longer fits beside the hidden state; the caller then keeps the
