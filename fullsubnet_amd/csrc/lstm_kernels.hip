@@ -479,8 +479,16 @@ __device__ __forceinline__ void lds_dma_fragment(const float* g, unsigned lds_ba
         : "memory");
 }
 
-template <int H, int RT, int UG>
-__global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgpr(76))) void lstm_rec_x_kernel(const float* __restrict__ xseq,
+// ABL (experiment knob of tools/probe_rec_x.hip, 0 in the library; results are WRONG with any bit set): leaves out one
+// ingredient at a time to price it - 1 slice barriers, 2 gate non-linearities, 4 output layer, 8 ring fills,
+// 16 the two barriers that end a step.  Measured (tools/probe_rec_x.hip, 52.7 ms shipped): 0.5 / 1.3 / 0.45 / 1.5 /
+// 0.4 ms, 49.3 ms without all five, 47.1 ms = the MFMAs alone at the 2.38 GHz the kernel runs at.  (Touching the next
+// step's tile ahead of its fills, so that they hit L2, changes nothing: tried.)
+#ifndef FSN_REC_VCAP
+#define FSN_REC_VCAP 76  // x 2 on gfx950's unified register file = 152: three waves per SIMD + room for a step workgroup
+#endif
+template <int H, int RT, int UG, int ABL = 0>
+__global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgpr(FSN_REC_VCAP))) void lstm_rec_x_kernel(const float* __restrict__ xseq,
                                                                           const float* __restrict__ w_p,
                                                                           unsigned whh_off,
                                                                           const float* __restrict__ bias, int Tp,
@@ -592,7 +600,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
 #pragma unroll 1
             for (int sl = 0; sl < NSL; ++sl) {
                 const int j = pass * NSL + sl;  // slice counter of the step: ring stage j & 1
-                if (j > 0) {
+                if (j > 0 && !(ABL & 1)) {
                     // this wave's fills of stage j & 1 were issued a slice ago, before UG SK weight fragments it has
                     // consumed since; at most the UG prefetched ones are still in flight
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UG) : "memory");
@@ -605,7 +613,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 {
                     const int nsl = sl + 1 < NSL ? sl + 1 : 0;
                     const int nt = (sl + 1 < NSL || pass < 3) ? t : t + 1;
-                    if (nt < Tp) fill((j + 1) & 1, nt, nsl);
+                    if (nt < Tp && !(ABL & 8)) fill((j + 1) & 1, nt, nsl);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const float* xa = xs + ((j & 1) * NF) * 256 + lane * 4;
@@ -655,7 +663,13 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
         VAR[rt][u][i] = EXPR;                                                                         \
         asm volatile("" : "+v"(VAR[rt][u][i]));                                                       \
     }
-            if (pass == 0) {
+            if (ABL & 2) {
+                if (pass == 0 || pass == 2) {
+                    FSN_REC_EPILOGUE(cst, acc[rt][u][i] * 0.5f)
+                } else {
+                    FSN_REC_EPILOGUE(tmp, acc[rt][u][i] * 0.5f)
+                }
+            } else if (pass == 0) {
                 FSN_REC_EPILOGUE(cst, sigmoid_fast(acc[rt][u][i]) * cst[rt][u][i])
             } else if (pass == 1) {
                 FSN_REC_EPILOGUE(tmp, sigmoid_fast(acc[rt][u][i]))
@@ -668,9 +682,11 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
             __builtin_amdgcn_sched_barrier(0);
         }
         // every wave has finished reading h_{t-1}; the fill of the next step's first slice stays in flight
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        if (!(ABL & 16)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
         {
             // one base register, re-derived every step (opaque to the optimiser): hoisted out of the time loop the
             // 32 store addresses become 32 live registers that end up in scratch
@@ -684,10 +700,12 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
 #pragma unroll
                     for (int i = 0; i < 4; ++i) hw[(rt * 16 + i) * HS + u * 16] = tmp[rt][u][i];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        __builtin_amdgcn_s_barrier();  // h_t complete in LDS
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-        {
+        if (!(ABL & 16)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();  // h_t complete in LDS
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
+        if (!(ABL & 4)) {
             // output layer on the spot (nn.Linear(H, 2)): 4 threads per (row, output), a quarter of K each
             const int tid = threadIdx.x;
             if (tid < ROWS * 8) {

@@ -1,0 +1,66 @@
+// Timing probe for lstm_rec_x_kernel (not part of the library): the shipped kernel and ablations that leave out one
+// ingredient at a time (template parameter ABL, see the kernel) to price it.
+#include <cstdio>
+#include <cstdlib>
+#include "../fullsubnet_amd/csrc/lstm_kernels.hip"
+void fsn_set_error(const char*, ...) {}
+int fsn_check_launch(const char*) { return hipGetLastError() == hipSuccess ? 0 : -3; }
+FsnCallScope::FsnCallScope(void*) : prev(-1), switched(false) {}
+FsnCallScope::~FsnCallScope() {}
+__global__ void fill_kernel(float* p, size_t n, unsigned seed, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 747796405u + seed; x ^= x >> 16; x *= 2246822519u; x ^= x >> 13;
+        p[i] = ((x & 0xffff) / 32768.0f - 1.0f) * scale;
+    }
+}
+#ifndef PROBE_RT
+#define PROBE_RT 4
+#define PROBE_UG 2
+#endif
+template <int ABL>
+float run(const float* xseq, const float* w, const float* bias, int Tp, int Npad, const FsnRecFc& fc) {
+    constexpr int H = 384, RT = PROBE_RT, UG = PROBE_UG, NW = H / (16 * UG);
+    const size_t lds = ((size_t)RT * 16 * (H + 4) + 2 * H + (size_t)2 * RT * 6 * 256) * sizeof(float);
+    auto kern = lstm_rec_x_kernel<H, RT, UG, ABL>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int it = 0; it < 3; ++it) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(kern, dim3(256 * 4 / RT), dim3(NW * 64), lds, 0, xseq, w, (unsigned)(4 * H * H), bias, Tp, Npad, fc);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (it > 0 && ms < best) best = ms;
+    }
+    return best;
+}
+int main(int argc, char** argv) {
+    const int Tp = argc > 1 ? atoi(argv[1]) : 190;
+    const int H = 384, tiles = 1028, Npad = tiles * 16, F = 257, T = Tp - 2;
+    float *xseq, *w, *bias, *fcw, *fcb, *cr, *ci;
+    hipMalloc(&xseq, (size_t)Tp * Npad * H * 4);
+    hipMalloc(&w, (size_t)8 * H * H * 4);
+    hipMalloc(&bias, 4 * H * 4);
+    hipMalloc(&fcw, 16 * H * 4);
+    hipMalloc(&fcb, 64);
+    hipMalloc(&cr, (size_t)64 * T * 272 * 4);
+    hipMalloc(&ci, (size_t)64 * T * 272 * 4);
+    fill_kernel<<<4096, 256>>>(xseq, (size_t)Tp * Npad * H, 1, 1.0f);
+    fill_kernel<<<256, 256>>>(w, (size_t)8 * H * H, 2, 0.05f);
+    fill_kernel<<<8, 256>>>(bias, 4 * H, 3, 0.1f);
+    fill_kernel<<<8, 256>>>(fcw, 16 * H, 4, 0.1f);
+    hipMemset(fcb, 0, 64);
+    hipDeviceSynchronize();
+    FsnRecFc fc{};
+    fc.w_p = fcw; fc.bias = fcb; fc.crm_r = cr; fc.crm_i = ci; fc.N = 64 * F; fc.F = F; fc.FP = 272; fc.T = T; fc.la = 2; fc.row0 = 0;
+    const double flops = 2.0 * 256 * 64 * 768.0 * 1536 * Tp;
+    const float t0 = run<0>(xseq, w, bias, Tp, Npad, fc);
+    printf("lstm_rec_x_kernel<384,%d,%d> x %d workgroups: %.3f ms = %.1f TFLOP/s (ideal at 157.3: %.3f ms)\n", PROBE_RT, PROBE_UG, 256 * 4 / PROBE_RT, t0, flops / t0 / 1e9, flops / 157.3e9);
+    printf("  without slice barriers      : %.3f ms\n", run<1>(xseq, w, bias, Tp, Npad, fc));
+    printf("  without gate non-linearities: %.3f ms\n", run<2>(xseq, w, bias, Tp, Npad, fc));
+    printf("  without the output layer    : %.3f ms\n", run<4>(xseq, w, bias, Tp, Npad, fc));
+    printf("  without ring fills          : %.3f ms\n", run<8>(xseq, w, bias, Tp, Npad, fc));
+    printf("  without end-of-step barriers: %.3f ms\n", run<16>(xseq, w, bias, Tp, Npad, fc));
+    printf("  without all of them         : %.3f ms\n", run<31>(xseq, w, bias, Tp, Npad, fc));
+    printf("  shipped again               : %.3f ms\n", run<0>(xseq, w, bias, Tp, Npad, fc));
+    return 0;
+}

@@ -11,12 +11,12 @@ def main(outdir):
     db = sorted(glob.glob(outdir + "/**/*.db", recursive=True))[-1]
     c = sqlite3.connect(db)
     rows = list(c.execute("select name, start, end, vgpr_count, lds_size, scratch_size from kernels order by start"))
-    recs = [r for r in rows if "lstm_rec_kernel" in r[0]]
+    recs = [r for r in rows if "lstm_rec_kernel" in r[0] or "lstm_rec_in_kernel" in r[0] or "lstm_rec_x_kernel" in r[0]]
     steps = [r for r in rows if "lstm_step1_kernel" in r[0]]
     for n, s, e, vg, lds, scr in recs:
         inside = [x for x in steps if x[1] >= s and x[2] <= e]
         after = [x for x in steps if x[2] > e and x[1] < e + 5e6]
-        kind = "layer 0 (XIN)" if "true>" in n else "layer 1"
+        kind = "layer 0" if ("true>" in n or "rec_in" in n) else "layer 1"
         tail = f", last one ends {(e - max(x[2] for x in inside)) / 1e6:.1f} ms before the persistent kernel" if inside else ""
         print(f"{kind}: persistent kernel {(e - s) / 1e6:.2f} ms (vgpr field {vg}, lds {lds}, scratch {scr}); "
               f"{len(inside)} step launches inside its window{tail}; {len(after)} finished after it")
