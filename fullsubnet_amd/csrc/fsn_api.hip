@@ -309,6 +309,10 @@ extern "C" int fsn_fullsubnet_pack(const fsn_fullsubnet_cfg* cfg, const fsn_full
     return FSN_OK;
 }
 
+// below this many sub-band row tiles (batch <= 5) the two layers of the small-batch step path run as a wavefront of
+// per-step launches; from here up to the persistent regime (160 tiles) they run on the group kernel
+constexpr int kWavefrontBelowTiles = 96;
+
 // ---- model core: magT [B][Tp][FP] -> crm_r, crm_i [B][T][FP] ------------------------------------
 struct CoreDims {
     int B, T, Tp, F, FP, Hf, Hs, nb, la;
@@ -317,6 +321,7 @@ struct CoreDims {
     FsnRecPlan rec;    // how those rows are spread over the CUs
     bool fc_fused;     // output layer fused into the layer-1 persistent kernel (its hseq is never stored)
     bool l1x;          // layer 1 forms its input projection itself (lstm_rec_x_kernel): no projection GEMM, no gx
+    int grp_clusters;  // > 0: the step regime runs on the group kernel (lstm_group_kernels.hip), that many clusters of 64 rows
     long row0;         // row-range calls: the N sub-band rows are rows row0 .. row0 + N - 1 of the B F rows
     int den_stride;    // row stride of the per-row (cumulative) sub-band divisors: they are indexed by GLOBAL row
 };
@@ -341,11 +346,18 @@ static CoreDims core_dims(const fsn_fullsubnet_cfg* c, int B, int T, long row0 =
     d.den_stride = n_rows < 0 ? d.Npad : fsn_round_up(B * d.F, 16);
     d.fc_fused = d.rec.main_wgs > 0 && fsn_lstm_rec_can_fuse_fc(d.rec.rt, false);
     d.l1x = d.fc_fused && c->arith == FSN_ARITH_F32 && fsn_lstm_rec_x_supported(d.Hs, d.rec.rt);
+    // 96 - 159 row tiles (6 - 9 utterances; below that the two-layer wavefront of per-step launches is as fast)
+    d.grp_clusters = 0;
+    if (d.rec.main_wgs == 0 && d.rec.left_tiles >= kWavefrontBelowTiles && d.Hs == 384 &&
+        fsn_round_up(2 * c->sb_num_neighbors + 2, 16) == 32)
+        d.grp_clusters = fsn_lstm2_group_clusters(d.rec.left_tiles);
     return d;
 }
 struct CoreWs {
     float *gx_fb, *hseq_fb0, *hseq_fb1, *c_fb, *fb_out, *den_fb, *den_sb, *gx_sb, *hseq_sb0, *hseq_sb1, *c_left;
     float* hseq_left0;  // l1x: layer-0 hidden sequence of the left-over rows, compact [t][left rows][H]
+    float* grp_exchange;  // group kernel: h exchange buffers of the clusters
+    unsigned* grp_flags;
     double* binsum;
 };
 static CoreWs core_carve(Carver& cv, const CoreDims& d, int norm_type) {
@@ -369,6 +381,8 @@ static CoreWs core_carve(Carver& cv, const CoreDims& d, int norm_type) {
     w.hseq_sb1 = cv.take<float>(d.fc_fused ? (size_t)d.Tp * (d.rec.left_tiles > 0 ? d.rec.left_tiles : 1) * 16 * d.Hs
                                            : rows_sb * d.Hs);
     w.c_left = cv.take<float>((size_t)2 * (d.rec.left_tiles > 0 ? d.rec.left_tiles : 1) * 16 * d.Hs);
+    w.grp_exchange = d.grp_clusters ? cv.take<float>(fsn_lstm2_group_exchange_floats(d.grp_clusters)) : nullptr;
+    w.grp_flags = d.grp_clusters ? cv.take<unsigned>(fsn_lstm2_group_flag_words(d.grp_clusters)) : nullptr;
     return w;
 }
 
@@ -469,11 +483,6 @@ static int run_sb_recurrence(const float* gx, const FsnSbInput* xin, const float
                           bias_main, hseq_left);
 }
 
-// below this many sub-band row tiles (batch <= 5) the two layers of the small-batch step path also run as
-// a wavefront; measured: batch 4 14.4 -> 13.5 ms, batch 8 (129 tiles) 22.4 -> 22.1, batch 1 unchanged
-// (host-launch bound there)
-constexpr int kWavefrontBelowTiles = 96;
-
 static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float* magT, const CoreDims& d,
                     const CoreWs& w, float* crm_r, float* crm_i, hipStream_t s, bool fullband_only = false) {
     const Packed p = packed_layout(cfg);
@@ -545,6 +554,110 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         } else {
             FSN_TRY(fsn_launch_offline_den(w.binsum, w.fb_out, nullptr, w.den_sb, d.B, d.Tp, d.F, d.FP, d.nb, 1, s));
         }
+    }
+    if (d.grp_clusters > 0) {
+        // Few rows (6 - 9 utterances): both layers + output layer of the first 64 x clusters rows as ONE persistent launch
+        // (lstm_group_kernels.hip); what does not fill a cluster runs beside it on the auxiliary stream as the two-layer
+        // wavefront of per-step launches (its projection GEMM first, its output layer last).
+        const long grp_rows = (long)d.grp_clusters * 64;
+        const int aux_tiles = d.rec.tiles - d.grp_clusters * 4;
+        FsnSbInput xin{};
+        xin.mag = magT;
+        xin.fb_out = w.fb_out;
+        xin.den = w.den_sb;
+        xin.wih_p = pk + p.sb_wih0;
+        xin.bias = pk + p.sb_b0;
+        xin.den_mode = cum ? 1 : 0;
+        xin.den_stride = d.den_stride;
+        xin.row0 = d.row0;
+        xin.B = d.B;
+        xin.Tp = d.Tp;
+        xin.F = d.F;
+        xin.FP = d.FP;
+        xin.N = d.N < grp_rows ? d.N : (int)grp_rows;
+        xin.nb = d.nb;
+        xin.kin_chunks = p.sb_kin_pad / 16;
+        FsnRecFc gfc{};
+        gfc.w_p = pk + p.sb_fc;
+        gfc.bias = pk + p.sb_fcb;
+        gfc.crm_r = crm_r;
+        gfc.crm_i = crm_i;
+        gfc.N = xin.N;
+        gfc.row0 = d.row0;
+        gfc.F = d.F;
+        gfc.FP = d.FP;
+        gfc.T = d.T;
+        gfc.la = d.la;
+        // The group kernel fills every CU with two 216-register workgroups: what runs beside it must fit in the 80
+        // registers per lane that are left - the two-layer wavefront step kernel (78) and the output-layer GEMM (52) do,
+        // the projection GEMM of the left-over rows does not, so it goes first, on the caller's stream.
+        StreamCtx* cx = nullptr;
+        hipStream_t as = s;
+        if (aux_tiles > 0) {
+            a = FsnGemmA{};
+            c = FsnGemmC{};
+            a.kind = 2;
+            a.p0 = magT;
+            a.p1 = w.fb_out;
+            a.den = w.den_sb;
+            a.den_mode = cum ? 1 : 0;
+            a.den_stride = d.den_stride;
+            a.B = d.B;
+            a.Tp = d.Tp;
+            a.F = d.F;
+            a.FP = d.FP;
+            a.Npad = aux_tiles * 16;
+            a.n_offset = (int)(d.row0 + grp_rows);
+            a.N = (int)(d.row0 + d.N);
+            a.nb = d.nb;
+            c.kind = 0;
+            c.p0 = w.gx_sb;
+            c.bias = pk + p.sb_b0;
+            {
+                StageTimer st(ST_SB_GEMM_L0, s);
+                FSN_TRY(fsn_launch_gemm(a, pk + p.sb_wih0, c, d.Tp * aux_tiles, 4 * d.Hs / 16, p.sb_kin_pad / 16, s));
+            }
+            cx = cur_ctx();
+            FSN_TRY(aux_init(cx));
+            if (hipEventRecord(cx->ev_fork, s) != hipSuccess || hipStreamWaitEvent(cx->aux, cx->ev_fork, 0) != hipSuccess) {
+                fsn_set_error("aux stream fork failed");
+                return FSN_ERR_LAUNCH;
+            }
+            as = cx->aux;
+        }
+        {
+            StageTimer st(ST_SB_REC_L0, s);
+            FSN_TRY(fsn_launch_lstm2_group(&xin, pk + p.sb_whh0, pk + p.sb_wih1, pk + p.sb_whh1, pk + p.sb_b1,
+                                           w.grp_exchange, w.grp_flags, &gfc, d.Tp, d.grp_clusters, d.Hs, s));
+        }
+        if (aux_tiles > 0) {
+            FSN_TRY(fsn_launch_lstm_wavefront2(w.gx_sb, aux_tiles, 0, pk + p.sb_whh0, pk + p.sb_wih1, pk + p.sb_b1_frag,
+                                               pk + p.sb_whh1, w.hseq_sb0, w.hseq_sb1, (long)aux_tiles * 16, 0, w.c_left,
+                                               w.c_left + (size_t)aux_tiles * 16 * d.Hs, d.Tp, aux_tiles, d.Hs, as, nullptr,
+                                               nullptr, 1));
+            a = FsnGemmA{};
+            c = FsnGemmC{};
+            a.kind = 0;
+            a.p0 = w.hseq_sb1;
+            a.ld = d.Hs;
+            c.kind = 2;
+            c.p0 = crm_r;
+            c.p1 = crm_i;
+            c.bias = pk + p.sb_fcb;
+            c.T = d.T;
+            c.F = d.F;
+            c.FP = d.FP;
+            c.Npad = aux_tiles * 16;
+            c.N = (int)(d.row0 + d.N);
+            c.n_off = (int)(d.row0 + grp_rows);
+            c.la = d.la;
+            FSN_TRY(fsn_launch_gemm(a, pk + p.sb_fc, c, d.Tp * aux_tiles, 1, d.Hs / 16, as));
+            if (hipEventRecord(cx->ev_join, cx->aux) != hipSuccess || hipStreamWaitEvent(s, cx->ev_join, 0) != hipSuccess) {
+                fsn_set_error("aux stream join failed");
+                return FSN_ERR_LAUNCH;
+            }
+        }
+        return FSN_OK;
     }
     // sub-band model (model.py:121-128): N = B F sequences, 2 LSTM layers + Linear(2)
     const int sb_rt = (int)((long)d.Tp * d.Npad / 16);

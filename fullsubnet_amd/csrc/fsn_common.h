@@ -259,11 +259,22 @@ int fsn_launch_lstm_rec_x(const float* xseq, const float* wih_p, const float* wh
 int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, const float* whh0_p, const float* wih1_p,
                                const float* bias1_frag, const float* whh1_p, float* hseq0, float* hseq1, long hs_stride,
                                long hs_off, float* c0, float* c1, int T, int row_tiles, int H, hipStream_t s,
-                               float* state_h0 = nullptr, float* state_h1 = nullptr);
+                               float* state_h0 = nullptr, float* state_h1 = nullptr, int beside_group = 0);
 int fsn_launch_lstm_wavefront2w(const float* gx0, long gx_stride, long gx_off, const float* whh0_p,
                                 const float* wih1_p, const float* bias1_frag, const float* whh1_p, float* hseq0,
                                 float* hseq1, long hs_stride, long hs_off, float* c0, float* c1, int T, int row_tiles,
-                                int H0, int H1, hipStream_t s, float* state_h0 = nullptr, float* state_h1 = nullptr);
+                                int H0, int H1, hipStream_t s, float* state_h0 = nullptr, float* state_h1 = nullptr,
+                                int beside_group = 0);
+
+// lstm_group_kernels.hip: the sub-band model for few rows as ONE persistent launch (clusters of 8 workgroups per 64
+// rows, both layers + output layer; see the file).  exchange: fsn_lstm2_group_exchange_floats(clusters) floats,
+// flags: fsn_lstm2_group_flag_words(clusters) 32-bit words (cleared inside the launcher).
+size_t fsn_lstm2_group_exchange_floats(int clusters);
+size_t fsn_lstm2_group_flag_words(int clusters);
+int fsn_lstm2_group_clusters(int tiles);
+int fsn_launch_lstm2_group(const FsnSbInput* xin, const float* whh0_p, const float* wih1_p, const float* whh1_p,
+                           const float* bias1, float* exchange, unsigned* flags, const FsnRecFc* fc, int Tp, int clusters,
+                           int H, hipStream_t s);
 
 // gemm_f16x3_kernels.hip (experimental, opt-in: FSN_F16X3=1)
 size_t fsn_f16x3_packed_halves(int n_out, int k);

@@ -1,0 +1,417 @@
+// Sub-band model for FEW rows (6 - 9 utterances: the per-rank share of a strong-scaled batch, small serving batches):
+// both LSTM layers and the output layer as ONE persistent launch in which clusters of workgroups share a group of 64
+// rows (fullsubnet/model.py:121-128: the rows are independent sequences).
+//
+// Why: with ~8 rows per CU the persistent kernels of lstm_kernels.hip cannot be used - a workgroup that owns rows
+// must stream ALL of W_hh (2.4 MB) from L2 every step whatever its row count, which bounds a step at ~31 us - so
+// this regime ran as one launch per step and layer (hidden units x row tiles spread over all CUs, h and c through
+// L2): 29 us per step against 15 us of MFMA work (launch boundary, cold operand fetches, drain), plus a separate
+// projection GEMM per layer with its gx round trip.  Here the same work split stays resident:
+//   - workgroup (cluster c, member m, layer l) owns hidden units [48 m, 48 m + 48) of layer l for the 64 rows of
+//     cluster c: wave w = row tile w, 3 unit groups x 4 gates = 12 accumulator tiles, c_t in registers.  Eight members
+//     x two layers = 16 workgroups per cluster, two per CU: the layer-0 and the layer-1 workgroups of a CU are
+//     independent instruction streams, so one's barriers, cell update and hand-off waits run under the other's MFMAs;
+//   - each layer's K loop contains its input projection (K = 32 + 384 and 384 + 384: no projection GEMMs, no gx);
+//     layer 1 follows layer 0 at a distance of up to two steps (the depth of layer 0's exchange buffer);
+//   - members exchange h slices through a small global buffer per cluster (48 columns written, 384 read) with the
+//     write-through / flag / acquire recipe of the CDNA guide (Guideline 16, R1: sc1 stores, drained, ONE flag store;
+//     relaxed poll by one wave, ONE agent-scope acquire, barrier, plain loads);
+//   - weight fragments are fetched once per workgroup and shared by its four waves through a two-stage LDS buffer
+//     (the K loop of lstm_step_cu_kernel), 0.9 MB per CU and step instead of 2.4 - 4.7 MB; the A fragments (other
+//     CUs' write-through data: first touch comes from the Infinity Cache / HBM) are requested four chunks ahead.
+// The output layer of step s is computed by layer-1 member m for rows 8 m .. 8 m + 7 when h1_s has been gathered for the
+// next step anyway.  Every spin is bounded: on a timeout the workgroup raises `status` and all waits fall through (the
+// results are then garbage, never a hang); flags and status are zeroed by the host before every launch.
+#include "fsn_common.h"
+
+namespace {
+
+constexpr int GH = 384;          // hidden units (both layers)
+constexpr int GKC = GH / 16;     // K chunks of an H-wide operand
+constexpr int GM = 8;            // members per cluster and layer
+constexpr int GU = GH / 16 / GM; // unit groups per member (3)
+constexpr int GROWS = 64;        // rows per cluster
+constexpr int GD0 = 4;           // depth of layer 0's exchange buffer: layer 0 may run GD0 - 2 steps ahead of layer 1
+constexpr unsigned kSpinLimit = 1u << 21;
+
+struct GrpArgs {
+    FsnSbInput xin;        // layer-0 input (mag, fb_out, den, row0, N ...); xin.bias = b0
+    const float* wbase;    // the four packed weight matrices live in one buffer: element offsets from wbase
+    unsigned o_wih0;       // packed [4H/16][2][64][4]
+    unsigned o_whh0;       // packed [4H/16][KC][64][4]
+    unsigned o_wih1, o_whh1;
+    const float* bias1;    // b_ih + b_hh of layer 1 [4H]
+    float* hx0;            // [clusters][GD0][64][H]   h of layer 0
+    float* hx1;            // [clusters][2][64][H]     h of layer 1
+    unsigned* flags;       // [clusters][2][GM]: steps published so far by (layer, member)
+    unsigned* status;      // 0 = fine
+    FsnRecFc fc;           // output layer; fc.N = valid local rows
+    int Tp;
+};
+
+__device__ __forceinline__ void store_sc1(float* p, float v) {
+    // write-through store (sc1): the line leaves this XCD's L2, any CU of the chip reads it after an agent-scope acquire
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wave polls the eight member flags of a layer (relaxed agent-scope loads, never served by this CU's L1) until all
+// have reached `epoch`; bounded.  Returns false after a timeout (status raised).
+__device__ __forceinline__ bool grp_poll(unsigned* flags8, unsigned epoch, unsigned* status) {
+    const int lane = threadIdx.x & 63;
+    for (unsigned spins = 0;; ++spins) {
+        unsigned v = epoch;
+        if (lane < GM) v = __hip_atomic_load(flags8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all((int)(v >= epoch))) return true;
+        if ((spins & 255u) == 255u) {
+            const unsigned st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (st != 0 || spins >= kSpinLimit) {
+                if (lane == 0 && st == 0) __hip_atomic_store(status, 1u + epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// ABL: experiment knob of tools/probe_group.hip (0 in the library; any bit set gives WRONG results): 1 no acquire
+// fence, 2 no flag polling, 4 plain instead of write-through stores, 8 no gate non-linearities, 16 no output layer,
+// 32 A fragments not loaded (a constant instead).
+template <int LAYER, int ABL>
+__device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int member, f32x4 (*bsh)[GU * 4][64]) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int Tp = a.Tp;
+    const long row_l = (long)cluster * GROWS + wave * 16 + lr;  // this lane's A-operand row (local to the launch)
+    float* hx0 = a.hx0 + (size_t)cluster * GD0 * GROWS * GH;
+    float* hx1 = a.hx1 + (size_t)cluster * 2 * GROWS * GH;
+    unsigned* fl0 = a.flags + ((size_t)cluster * 2 + 0) * GM;
+    unsigned* fl1 = a.flags + ((size_t)cluster * 2 + 1) * GM;
+    // this lane's A fragment inside a [64][H] tile of the exchange buffers (byte offset), read with sc1 buffer loads: the
+    // partners stored write-through (sc1), so an sc1 load - never served by this CU's L1 - needs no acquire fence
+    const unsigned a_off = (unsigned)(((wave * 16 + lr) * GH + 4 * lq) * 4);
+    const __amdgpu_buffer_rsrc_t xrsrc0 = __builtin_amdgcn_make_buffer_rsrc(hx0, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrsrc1 = __builtin_amdgcn_make_buffer_rsrc(hx1, 0, 0x7fffffff, 0x00020000);
+    auto xload = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16));  // aux 16 = sc1
+    };
+
+    // layer-0 input of this lane's row: (b, f) once; element c of frame t is gathered per step
+    const FsnSbInput& x = a.xin;
+    const bool row_ok = row_l < x.N;
+    const long ng = row_l + x.row0;
+    const int xb = row_ok ? (int)(ng / x.F) : 0, xf = row_ok ? (int)(ng % x.F) : 0;
+
+    // biases of this member's 12 column tiles (registers are plentiful at two waves per SIMD)
+    float bias[GU][4];
+#pragma unroll
+    for (int u = 0; u < GU; ++u)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias[u][g] = (LAYER ? a.bias1 : x.bias)[(g * GKC + member * GU + u) * 16 + lr];
+    float c[GU][4];
+#pragma unroll
+    for (int u = 0; u < GU; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[u][i] = 0.f;
+
+    // ---- K loop: acc += A(16 rows x 16 n) B(16 n x [3 unit groups x 4 gates x 16]) over two operand segments -------
+    // segment 1: n1 chunks, A from registers (xa) or from a1 (global, row stride GH), B from b1 (chunk stride 256,
+    // column-tile stride s1); segment 2: n2 chunks, A from a2, B from b2 (column-tile stride s2).  Fragment f of a chunk
+    // = (unit group f >> 2, gate f & 3); wave w fetches fragments 3 w .. 3 w + 2 and parks them in LDS.
+    // weight fragments by buffer load: resource descriptor + scalar byte offset + this lane's 16 l (no per-fragment
+    // pointers in vector registers)
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wbase), 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    // A operand: xa (registers, layer-0 input) or tile `at1` / `at2` (byte offset) of exchange buffer ab1 / ab2 (0 / 1)
+    auto kloop = [&](f32x4 (&acc)[GU][4], const f32x4* xa, int ab1, unsigned at1, unsigned b1, unsigned s1, int n1,
+                     int ab2, unsigned at2, unsigned b2, unsigned s2, int n2) {
+        const int n = n1 + n2;
+        // The A fragments come from the exchange buffers, which were written through to memory by other CUs: their
+        // first touch after the acquire costs a trip to the Infinity Cache / HBM, several chunks of MFMA time.  They
+        // are therefore requested AD chunks ahead (a register ring, indexed statically by unrolling the loop AD-fold);
+        // the weight fragments (L2 hits) one chunk ahead, through LDS.
+        constexpr int AD = 4;
+        f32x4 ar[AD], bn[GU];
+        auto fetch_a = [&](int k) -> f32x4 {
+            const int kc = k < n ? k : n - 1;
+            if (ABL & 32) return f32x4{0.5f, 0.25f, 0.125f, 0.0625f};
+            if (kc < n1) {
+                if (xa) return kc == 0 ? xa[0] : xa[1];
+                return xload(ab1 ? xrsrc1 : xrsrc0, a_off, at1 + (unsigned)kc * 64u);
+            }
+            return xload(ab2 ? xrsrc1 : xrsrc0, a_off, at2 + (unsigned)(kc - n1) * 64u);
+        };
+        auto fetch_b = [&](int k) {
+            const int kc = k < n ? k : n - 1;
+            const bool first = kc < n1;
+            const int kk = first ? kc : kc - n1;
+            const unsigned bb = first ? b1 : b2, cs = first ? s1 : s2;
+#pragma unroll
+            for (int j = 0; j < GU; ++j) {
+                const int f = wave * GU + j, u = f >> 2, g = f & 3;
+                const unsigned ofs = bb + ((unsigned)(g * GKC + member * GU + u) * cs + (unsigned)kk) * 256u;
+                bn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, ofs * 4u, 0));
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < AD; ++d) ar[d] = fetch_a(d);
+        fetch_b(0);
+#pragma unroll
+        for (int j = 0; j < GU; ++j) bsh[0][wave * GU + j][lane] = bn[j];
+        __syncthreads();
+        for (int k0 = 0; k0 < n; k0 += AD) {
+#pragma unroll
+            for (int d = 0; d < AD; ++d) {
+                const int k = k0 + d;
+                if (k < n) {  // uniform
+                    __builtin_amdgcn_sched_barrier(0);  // requests first, pinned under this chunk's MFMAs
+                    fetch_b(k + 1);
+                    const f32x4 av = ar[d];
+                    ar[d] = fetch_a(k + AD);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int buf = k & 1;
+#pragma unroll
+                    for (int u = 0; u < GU; ++u) {
+                        f32x4 b[4];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) b[g] = bsh[buf][u * 4 + g][lane];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) acc[u][g] = mfma16(av[j], b[g][j], acc[u][g]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < GU; ++j) bsh[buf ^ 1][wave * GU + j][lane] = bn[j];
+                    __syncthreads();
+                }
+            }
+        }
+    };
+
+    // Flags are looked at EARLY (before a K loop) and checked after it: in the steady state the early look already
+    // shows the awaited epoch and the check costs nothing; only otherwise does wave 0 poll.  No acquire fence: every
+    // load of exchanged data is an sc1 load (see xload).
+    auto peek = [&](unsigned* flags8) -> unsigned {
+        unsigned v = 0xffffffffu;
+        if (wave == 0 && lane < GM) v = __hip_atomic_load(flags8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;
+    };
+    auto wait_peeked = [&](unsigned v, unsigned* flags8, unsigned epoch) {
+        if (wave == 0 && !(ABL & 2) && !__all((int)(v >= epoch))) (void)grp_poll(flags8, epoch, a.status);
+        __syncthreads();  // one wave looked for all four
+    };
+    // h slice of this step is in flight (write-through): every wave drains, then one lane bumps the flag
+    auto publish = [&](unsigned* flag, unsigned epoch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // cell update of this wave's 16 rows x 48 units; h_t slice -> exchange buffer
+    auto cell = [&](f32x4 (&acc)[GU][4], float* hdst) {
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float ig, fg, gg, og;
+                if (ABL & 8) {
+                    ig = acc[u][0][i], fg = acc[u][1][i], gg = acc[u][2][i], og = acc[u][3][i];
+                } else {
+                    ig = sigmoid_fast(acc[u][0][i]), fg = sigmoid_fast(acc[u][1][i]);
+                    gg = tanh_fast(acc[u][2][i]), og = sigmoid_fast(acc[u][3][i]);
+                }
+                const float cn = fg * c[u][i] + ig * gg;
+                c[u][i] = cn;
+                float* hp = hdst + (size_t)(wave * 16 + 4 * lq + i) * GH + (member * GU + u) * 16 + lr;
+                const float hv = (ABL & 8) ? og * cn : og * tanh_fast(cn);
+                if (ABL & 4) *hp = hv;
+                else store_sc1(hp, hv);
+            }
+    };
+
+    if (LAYER == 0) {
+        for (int t = 0; t < Tp; ++t) {
+            // the layer-0 input of this lane's row at frame t (two A fragments: columns 4 lq .. and 16 + 4 lq ..):
+            // requested now, divided after the wait below
+            float raw[8];
+            const float den = row_ok ? x.den[x.den_mode ? (long)t * x.den_stride + ng : (long)xb] : 1.f;
+            {
+                const long fo = ((long)xb * x.Tp + t) * x.FP;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int cc = (e >> 2) * 16 + 4 * lq + (e & 3);
+                    int jj = xf + cc - x.nb;
+                    jj = jj < 0 ? -jj : jj;
+                    jj = jj >= x.F ? 2 * (x.F - 1) - jj : jj;
+                    const bool ok = row_ok && cc <= 2 * x.nb + 1;
+                    const float* src = cc <= 2 * x.nb ? x.mag + fo + jj : x.fb_out + fo + xf;
+                    raw[e] = *(ok ? src : x.mag);
+                }
+            }
+            if (t > 0) wait_peeked(peek(fl0), fl0, (unsigned)t);  // h0_{t-1} of all members (just published: polls)
+            f32x4 xa[2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int cc = (e >> 2) * 16 + 4 * lq + (e & 3);
+                xa[e >> 2][e & 3] = (row_ok && cc <= 2 * x.nb + 1) ? raw[e] / den : 0.f;
+            }
+            f32x4 acc[GU][4];
+#pragma unroll
+            for (int u = 0; u < GU; ++u)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[u][g] = f32x4{bias[u][g], bias[u][g], bias[u][g], bias[u][g]};
+            const unsigned ring = t >= GD0 ? peek(fl1) : 0xffffffffu;
+            kloop(acc, xa, 0, 0, a.o_wih0, 2, 2, 0, (unsigned)(((t + GD0 - 1) % GD0) * GROWS * GH * 4), a.o_whh0, GKC,
+                  t > 0 ? GKC : 0);
+            // slot t % GD0 still holds h0_{t-GD0}: layer 1 must have finished its step t - GD0 (it reads that slot
+            // there) - all eight layer-1 members, i.e. they have published step t - GD0 + 1
+            if (t >= GD0) wait_peeked(ring, fl1, (unsigned)(t - GD0 + 1));
+            cell(acc, hx0 + (size_t)(t % GD0) * GROWS * GH);
+            publish(fl0 + member, (unsigned)t + 1);
+        }
+    } else {
+        // output layer: thread (d = tid >> 4, p = tid & 15) owns 24 of the 384 terms of dot product d (row d >> 1 of
+        // this member's eight rows, output d & 1)
+        const int d = threadIdx.x >> 4, p = threadIdx.x & 15;
+        const int frow = member * 8 + (d >> 1), fcc = d & 1;
+        unsigned seen0 = peek(fl0);
+        for (int s = 0; s <= Tp; ++s) {
+            // Step s: x_s W_ih^T first - it only needs h0_s, which layer 0 published long ago - so that the partners'
+            // h1_{s-1}, published a moment ago, has a whole half K loop to arrive before anyone waits for it.  The extra
+            // iteration s = Tp only computes the output layer of the last step.
+            f32x4 acc[GU][4];
+            unsigned seen1 = 0xffffffffu;
+            if (s < Tp) {
+                wait_peeked(seen0, fl0, (unsigned)s + 1);
+                seen1 = peek(fl1);
+#pragma unroll
+                for (int u = 0; u < GU; ++u)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[u][g] = f32x4{bias[u][g], bias[u][g], bias[u][g], bias[u][g]};
+                kloop(acc, nullptr, 0, (unsigned)((s % GD0) * GROWS * GH * 4), a.o_wih1, GKC, GKC, 0, 0, 0, 0, 0);
+            } else {
+                seen1 = peek(fl1);
+            }
+            if (s > 0) {
+                wait_peeked(seen1, fl1, (unsigned)s);  // h1_{s-1} of all members
+                // Output layer (nn.Linear(384, 2)) of step s - 1 for rows 8 m .. 8 m + 7 of the cluster, from h1_{s-1} as
+                // it has just been gathered: 16 dot products x 16 threads (~1 us, covered by the layer-0 workgroup
+                // that shares the CU)
+                if (!(ABL & 16)) {
+                    const unsigned hoff = (unsigned)((((s - 1) & 1) * GROWS * GH + frow * GH + p * 24) * 4);
+                    f32x4 hv[6], fw[6];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) {
+                        const int kk = p * 24 + 4 * q;  // four consecutive k: one 16-byte group of the packed weights
+                        hv[q] = xload(xrsrc1, hoff, 16u * q);
+                        fw[q] = *reinterpret_cast<const f32x4*>(a.fc.w_p + (((kk >> 4) * 64) + ((kk & 15) >> 2) * 16 + fcc) * 4);
+                    }
+                    float acc1 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc1 = fmaf(hv[q][j], fw[q][j], acc1);
+                    acc1 += __shfl_xor(acc1, 1, 64);
+                    acc1 += __shfl_xor(acc1, 2, 64);
+                    acc1 += __shfl_xor(acc1, 4, 64);
+                    acc1 += __shfl_xor(acc1, 8, 64);
+                    const long n = (long)cluster * GROWS + frow;
+                    const int so = s - 1;
+                    if (p == 0 && so >= a.fc.la && n < a.fc.N) {
+                        const long ngl = n + a.fc.row0;
+                        const int b = (int)(ngl / a.fc.F), f = (int)(ngl % a.fc.F);
+                        (fcc ? a.fc.crm_i : a.fc.crm_r)[((long)b * a.fc.T + (so - a.fc.la)) * a.fc.FP + f] = acc1 + a.fc.bias[fcc];
+                    }
+                }
+            }
+            seen0 = peek(fl0);  // for the next step: layer 0 is ahead, this usually shows s + 2 already
+            if (s > 0 && s < Tp)
+                kloop(acc, nullptr, 1, (unsigned)((((s + 1) & 1) * GROWS * GH) * 4), a.o_whh1, GKC, GKC, 0, 0, 0, 0, 0);
+            if (s < Tp) {
+                // slot s & 1 held h1_{s-2}: read by every member in step s - 1, which they have left (flag1 >= s above)
+                cell(acc, hx1 + (size_t)(s & 1) * GROWS * GH);
+                publish(fl1 + member, (unsigned)s + 1);
+            }
+        }
+    }
+}
+
+template <int ABL>
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void lstm2_group_kernel(const GrpArgs a) {
+    // weight fragments of one K chunk, shared by the four waves: two stages x 12 fragments x 1 KB
+    __shared__ f32x4 bsh[2][GU * 4][64];
+    // The first half of the grid runs layer 0, the second half layer 1: blocks are handed out in order, one per CU
+    // before any CU gets its second, so that every CU ends up with one workgroup of each layer (speed only).  Within a
+    // half: observed, block b runs on XCD b % 8; when the cluster count allows it the eight members of a cluster are
+    // blocks with the same b % 8, i.e. share one L2 (speed only as well).
+    const int half = gridDim.x >> 1;
+    const int layer = (int)blockIdx.x >= half ? 1 : 0;
+    const int bid = (int)blockIdx.x - layer * half;
+    const int nclusters = half / GM;
+    int cluster, member;
+    if (nclusters % 8 == 0) {
+        const int xcd = bid & 7, j = bid >> 3;  // j-th block of that XCD
+        cluster = xcd * (nclusters / 8) + j / GM;
+        member = j % GM;
+    } else {
+        cluster = bid / GM;
+        member = bid % GM;
+    }
+    // Layer 1 is the longer dependent chain (K = 768 per step against 416) and layer 0 is throttled to stay within
+    // GD0 - 2 steps of it: layer 1's waves issue first, layer 0's fill the gaps.
+    if (layer == 1 && !(ABL & 64)) __builtin_amdgcn_s_setprio(2);
+    if (layer == 0) group_body<0, ABL>(a, cluster, member, bsh);
+    else group_body<1, ABL>(a, cluster, member, bsh);
+}
+
+}  // namespace
+
+size_t fsn_lstm2_group_exchange_floats(int clusters) { return (size_t)clusters * (GD0 + 2) * GROWS * GH; }
+size_t fsn_lstm2_group_flag_words(int clusters) { return (size_t)clusters * 2 * GM + 16; }
+
+// Clusters of 64 rows that run on the group kernel for `tiles` 16-row tiles: at most one cluster per eight CUs (its 16
+// workgroups, two per CU, must all be resident at once); what is left runs step by step beside it.
+int fsn_lstm2_group_clusters(int tiles) {
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cap = cus / GM;
+    const int c = tiles / 4;
+    return c < cap ? c : cap;
+}
+
+int fsn_launch_lstm2_group(const FsnSbInput* xin, const float* whh0_p, const float* wih1_p, const float* whh1_p,
+                           const float* bias1, float* exchange, unsigned* flags, const FsnRecFc* fc, int Tp, int clusters,
+                           int H, hipStream_t s) {
+    if (H != GH || !xin || xin->x_rows || xin->kin_chunks != 2 || !fc || !fc->w_p || clusters < 1) {
+        fsn_set_error("lstm2_group: built for the sub-band model (H = 384, 32 input columns, fused output layer)");
+        return FSN_ERR_ARG;
+    }
+    const size_t words = fsn_lstm2_group_flag_words(clusters);
+    if (hipMemsetAsync(flags, 0, words * sizeof(unsigned), s) != hipSuccess) {  // flags and status: zero before EVERY launch
+        fsn_set_error("lstm2_group: cannot clear the flags");
+        return FSN_ERR_LAUNCH;
+    }
+    // the four matrices sit in one packed blob: address them as offsets from the lowest pointer
+    const float* lo = xin->wih_p;
+    for (const float* q : {whh0_p, wih1_p, whh1_p}) lo = q < lo ? q : lo;
+    for (const float* q : {xin->wih_p, whh0_p, wih1_p, whh1_p})
+        if (q - lo > 0x1fffffffL) {
+            fsn_set_error("lstm2_group: the packed weight matrices must share one buffer");
+            return FSN_ERR_ARG;
+        }
+    GrpArgs a{};
+    a.xin = *xin;
+    a.wbase = lo;
+    a.o_wih0 = (unsigned)(xin->wih_p - lo);
+    a.o_whh0 = (unsigned)(whh0_p - lo);
+    a.o_wih1 = (unsigned)(wih1_p - lo);
+    a.o_whh1 = (unsigned)(whh1_p - lo);
+    a.bias1 = bias1;
+    a.hx0 = exchange;
+    a.hx1 = exchange + (size_t)clusters * GD0 * GROWS * GH;
+    a.flags = flags;
+    a.status = flags + (size_t)clusters * 2 * GM;
+    a.fc = *fc;
+    a.Tp = Tp;
+    hipLaunchKernelGGL(lstm2_group_kernel<0>, dim3((unsigned)clusters * GM * 2), dim3(256), 0, s, a);
+    return fsn_check_launch("lstm2_group_kernel");
+}

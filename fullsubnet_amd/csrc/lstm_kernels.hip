@@ -1281,7 +1281,7 @@ struct FsnStepJobs {
     FsnStepJob j[2];
 };
 
-__global__ __launch_bounds__(256) void lstm_step2_kernel(const FsnStepJobs jobs) {
+__device__ __forceinline__ void lstm_step2_body(const FsnStepJobs& jobs) {
     const FsnStepJob job = jobs.j[blockIdx.z];  // one uniform kernarg fetch, no per-member branching
     const int H = job.H;
     if (!job.active || (int)blockIdx.x * 16 >= H) return;  // the grid is sized for the wider layer
@@ -1396,6 +1396,14 @@ __global__ __launch_bounds__(256) void lstm_step2_kernel(const FsnStepJobs jobs)
         job.c[idx] = cn;
         job.h_out[idx] = og * tanh_fast(cn);
     }
+}
+
+__global__ __launch_bounds__(256) void lstm_step2_kernel(const FsnStepJobs jobs) { lstm_step2_body(jobs); }
+
+// The same step beside the group kernel of lstm_group_kernels.hip (two 216-register workgroups per CU): capped at the 80
+// registers per lane that are left there; it spills a little, on a chain that has ten times the slack.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(40))) void lstm_step2_small_kernel(const FsnStepJobs jobs) {
+    lstm_step2_body(jobs);
 }
 
 template <int H, int RT, bool XIN, int UG = 2>
@@ -1666,7 +1674,7 @@ int fsn_launch_lstm_step_train(const float* gx, const float* whh_p, const float*
 int fsn_launch_lstm_wavefront2w(const float* gx0, long gx_stride, long gx_off, const float* whh0_p,
                                 const float* wih1_p, const float* bias1_frag, const float* whh1_p, float* hseq0,
                                 float* hseq1, long hs_stride, long hs_off, float* c0, float* c1, int T, int row_tiles,
-                                int H0, int H1, hipStream_t s, float* state_h0, float* state_h1) {
+                                int H0, int H1, hipStream_t s, float* state_h0, float* state_h1, int beside_group) {
     if (H0 % 64 != 0 || H1 % 64 != 0 || (state_h0 == nullptr) != (state_h1 == nullptr)) {
         fsn_set_error("lstm_wavefront2: hidden sizes %d / %d must be multiples of 64 (and both states or none)", H0, H1);
         return FSN_ERR_ARG;
@@ -1709,7 +1717,8 @@ int fsn_launch_lstm_wavefront2w(const float* gx0, long gx_stride, long gx_off, c
             b.c = c1;
             b.first = t == 0 && !cont;
         }
-        hipLaunchKernelGGL(lstm_step2_kernel, dim3(Hmax / 16, row_tiles, 2), dim3(256), 0, s, jobs);
+        if (beside_group) hipLaunchKernelGGL(lstm_step2_small_kernel, dim3(Hmax / 16, row_tiles, 2), dim3(256), 0, s, jobs);
+        else hipLaunchKernelGGL(lstm_step2_kernel, dim3(Hmax / 16, row_tiles, 2), dim3(256), 0, s, jobs);
         FSN_TRY_LAUNCH("lstm_step2_kernel");
     }
     if (cont) {
@@ -1728,7 +1737,7 @@ int fsn_launch_lstm_wavefront2w(const float* gx0, long gx_stride, long gx_off, c
 int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, const float* whh0_p, const float* wih1_p,
                                const float* bias1_frag, const float* whh1_p, float* hseq0, float* hseq1, long hs_stride,
                                long hs_off, float* c0, float* c1, int T, int row_tiles, int H, hipStream_t s,
-                               float* state_h0, float* state_h1) {
+                               float* state_h0, float* state_h1, int beside_group) {
     return fsn_launch_lstm_wavefront2w(gx0, gx_stride, gx_off, whh0_p, wih1_p, bias1_frag, whh1_p, hseq0, hseq1,
-                                       hs_stride, hs_off, c0, c1, T, row_tiles, H, H, s, state_h0, state_h1);
+                                       hs_stride, hs_off, c0, c1, T, row_tiles, H, H, s, state_h0, state_h1, beside_group);
 }

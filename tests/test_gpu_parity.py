@@ -571,3 +571,37 @@ def test_two_streams_and_two_host_threads_are_independent(fsn):
         L.fsn_profile_enable(0)
     assert main_ms["sb_rec_l0"] > 0 and side_ms["sb_rec_l0"] > 0
     assert again == main_ms
+
+
+@pytest.mark.parametrize("batch", [6, 8, 9])
+def test_few_rows_on_the_group_kernel(fsn, batch):
+    """6 - 9 utterances (97 - 145 row tiles, the per-rank share of a strong-scaled batch): both sub-band layers and
+    the output layer run as ONE persistent launch in which clusters of eight workgroups exchange hidden-state slices
+    through global memory (lstm_group_kernels.hip); rows that do not fill a cluster run beside it step by step
+    (batch 6: 24 clusters + 1 tile, batch 8: 32 + 1, batch 9: 32 + 17).  Against the oracle, against every
+    utterance's solo run (other kernels), and bit-identical from run to run."""
+    meta = dict(seed_w=0, gain=2.0, mask_gain=24.0, norm_type="offline_laplace_norm", groups=1)
+    model, params = build_model(fsn, meta)
+    noisy = O.make_noisy(batch, 12000, seed=400 + batch)  # 47 frames -> 49 steps
+    x = dev(noisy)
+    enh, crm = model.enhance(x, return_crm=True)
+    for _ in range(3):
+        enh2, crm2 = model.enhance(x, return_crm=True)
+        assert torch.equal(crm, crm2) and torch.equal(enh, enh2)
+    assert bool(torch.isfinite(crm).all())
+    win = torch.hann_window(512).numpy()
+    for b in (0, batch - 1):
+        ref, inter = O.full_band_crm_mask(noisy[b:b + 1], params, window=win, return_intermediates=True)
+        err = np.abs(crm[b:b + 1].cpu().numpy() - inter["crm"])
+        assert err.max() <= 1e-4, (b, err.max())
+        assert np.abs(enh[b:b + 1].cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
+    for b in range(batch):
+        _, solo = model.enhance(x[b:b + 1], return_crm=True)
+        assert (solo[0] - crm[b]).abs().max().item() <= 5e-5, b
+    # the cumulative norm (per-row, per-step divisors) through the same kernel
+    meta_c = dict(meta, norm_type="cumulative_laplace_norm")
+    model_c, params_c = build_model(fsn, meta_c)
+    _, crm_c = model_c.enhance(x, return_crm=True)
+    _, inter = O.full_band_crm_mask(noisy[:1], params_c, window=win, return_intermediates=True,
+                                    norm_type="cumulative_laplace_norm")
+    assert np.abs(crm_c[:1].cpu().numpy() - inter["crm"]).max() <= 1e-4
