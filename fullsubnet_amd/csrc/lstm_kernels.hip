@@ -1717,6 +1717,8 @@ int fsn_launch_lstm_wavefront2w(const float* gx0, long gx_stride, long gx_off, c
             b.c = c1;
             b.first = t == 0 && !cont;
         }
+        // (a 16-wave split of the K range - every wave's operands in one round trip - was tried for the full-band
+        // model and lost: 13.3 us per step against 10.5; dispatching and joining 16 waves costs more than it saves)
         if (beside_group) hipLaunchKernelGGL(lstm_step2_small_kernel, dim3(Hmax / 16, row_tiles, 2), dim3(256), 0, s, jobs);
         else hipLaunchKernelGGL(lstm_step2_kernel, dim3(Hmax / 16, row_tiles, 2), dim3(256), 0, s, jobs);
         FSN_TRY_LAUNCH("lstm_step2_kernel");
