@@ -356,6 +356,20 @@ def main():
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         }
         out.update(extras)
+    if not args.no_extras and world == 1 and args.batch % 8 == 0:
+        # One rank's share of the strong-scaled batch at 8 GPUs (batch / 8 utterances), measured on this GPU: the
+        # north-star target (>= 6x at 8 GPUs) is this time against ms_per_step, before the all-gather of the waveforms
+        # (12 MB over xGMI) - a driver-visible prediction for boxes without an 8-GPU node.
+        keep = args.batch
+        args.batch = keep // 8
+        sh = run_mode("weak", max(5, args.steps), 3, profile=True)
+        args.batch = keep
+        sh_ms = 1e3 * sh["dt"] / sh["steps"]
+        out["strong_scaling_share"] = {
+            "ranks": 8, "utterances_per_rank": keep // 8, "ms_per_step": round(sh_ms, 3),
+            "predicted_speedup_at_8_gpus": round(ms_per_step / sh_ms, 2),
+            "stage_ms": {k: round(v, 3) for k, v in sh["stage_ms"].items()},
+            "note": "one rank's share measured on ONE GPU (sub-band model on lstm2_group_kernel); excludes the all-gather"}
     if not args.no_extras and world == 1:
         # the opt-in split-precision kernels (Model.arithmetic -> cfg.arith), reported NEXT TO `value`, never as it
         model.arithmetic = "f16x3"

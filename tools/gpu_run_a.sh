@@ -2,7 +2,7 @@
 # GPU session A of round 2: full GPU test suite, the bench line, a rocprofv3 kernel trace and the PMC passes.
 # Everything lands under gpurun_out/r02a/.
 set -u
-O=gpurun_out/r02a
+O=gpurun_out/${1:-r02a}
 mkdir -p $O
 export TMPDIR=/tmp
 (time timeout 900 python -m pytest tests -m gpu -x -q) > $O/pytest.log 2>&1
