@@ -374,12 +374,22 @@ static CoreWs core_carve(Carver& cv, const CoreDims& d, int norm_type) {
     w.den_sb = cv.take<float>(cum ? (size_t)d.Tp * d.den_stride : (size_t)d.B);
     // l1x: only the left-over rows (which run step by step) still need a precomputed projection
     const size_t rows_left = (size_t)d.Tp * (d.rec.left_tiles > 0 ? d.rec.left_tiles : 1) * 16;
-    w.gx_sb = cv.take<float>((d.l1x ? rows_left : rows_sb) * 4 * d.Hs);
-    w.hseq_sb0 = cv.take<float>(rows_sb * d.Hs);
-    w.hseq_left0 = d.l1x ? cv.take<float>(rows_left * d.Hs) : nullptr;
-    // fused output layer: only the left-over rows of layer 1 are ever stored, [t][left rows][H]
-    w.hseq_sb1 = cv.take<float>(d.fc_fused ? (size_t)d.Tp * (d.rec.left_tiles > 0 ? d.rec.left_tiles : 1) * 16 * d.Hs
-                                           : rows_sb * d.Hs);
+    if (d.grp_clusters > 0) {
+        // group kernel: projections and hidden sequences only exist for the rows that do not fill a cluster
+        const int aux_tiles = d.rec.tiles - 4 * d.grp_clusters;
+        const size_t rows_aux = (size_t)d.Tp * (aux_tiles > 0 ? aux_tiles : 1) * 16;
+        w.gx_sb = cv.take<float>(rows_aux * 4 * d.Hs);
+        w.hseq_sb0 = cv.take<float>(rows_aux * d.Hs);
+        w.hseq_left0 = nullptr;
+        w.hseq_sb1 = cv.take<float>(rows_aux * d.Hs);
+    } else {
+        w.gx_sb = cv.take<float>((d.l1x ? rows_left : rows_sb) * 4 * d.Hs);
+        w.hseq_sb0 = cv.take<float>(rows_sb * d.Hs);
+        w.hseq_left0 = d.l1x ? cv.take<float>(rows_left * d.Hs) : nullptr;
+        // fused output layer: only the left-over rows of layer 1 are ever stored, [t][left rows][H]
+        w.hseq_sb1 = cv.take<float>(d.fc_fused ? (size_t)d.Tp * (d.rec.left_tiles > 0 ? d.rec.left_tiles : 1) * 16 * d.Hs
+                                               : rows_sb * d.Hs);
+    }
     w.c_left = cv.take<float>((size_t)2 * (d.rec.left_tiles > 0 ? d.rec.left_tiles : 1) * 16 * d.Hs);
     w.grp_exchange = d.grp_clusters ? cv.take<float>(fsn_lstm2_group_exchange_floats(d.grp_clusters)) : nullptr;
     w.grp_flags = d.grp_clusters ? cv.take<unsigned>(fsn_lstm2_group_flag_words(d.grp_clusters)) : nullptr;
