@@ -317,6 +317,7 @@ constexpr int kWavefrontBelowTiles = 96;
 struct CoreDims {
     int B, T, Tp, F, FP, Hf, Hs, nb, la;
     int Npad_fb;       // full-band rows per step (batch, padded to 16)
+    bool fb_chain;     // the full-band LSTM layers run as one persistent launch (fb_chain_kernels.hip)
     int N, Npad;       // sub-band rows per step, padded rows (row stride of the [t][n] buffers)
     FsnRecPlan rec;    // how those rows are spread over the CUs
     bool fc_fused;     // output layer fused into the layer-1 persistent kernel (its hseq is never stored)
@@ -339,6 +340,7 @@ static CoreDims core_dims(const fsn_fullsubnet_cfg* c, int B, int T, long row0 =
     d.Hs = c->sb_hidden;
     d.nb = c->sb_num_neighbors;
     d.Npad_fb = fsn_round_up(B, 16);
+    d.fb_chain = fsn_fb_chain_supported(d.Hf, d.Npad_fb);
     d.N = n_rows < 0 ? B * d.F : (int)n_rows;
     d.row0 = n_rows < 0 ? 0 : row0;
     d.rec = fsn_lstm_rec_plan(d.N, d.Hs);
@@ -358,6 +360,8 @@ struct CoreWs {
     float* hseq_left0;  // l1x: layer-0 hidden sequence of the left-over rows, compact [t][left rows][H]
     float* grp_exchange;  // group kernel: h exchange buffers of the clusters
     unsigned* grp_flags;
+    float* fb_exchange;   // full-band chain kernel: per-step h / projection hand-off buffers
+    unsigned* fb_flags;
     double* binsum;
 };
 static CoreWs core_carve(Carver& cv, const CoreDims& d, int norm_type) {
@@ -393,6 +397,8 @@ static CoreWs core_carve(Carver& cv, const CoreDims& d, int norm_type) {
     w.c_left = cv.take<float>((size_t)2 * (d.rec.left_tiles > 0 ? d.rec.left_tiles : 1) * 16 * d.Hs);
     w.grp_exchange = d.grp_clusters ? cv.take<float>(fsn_lstm2_group_exchange_floats(d.grp_clusters)) : nullptr;
     w.grp_flags = d.grp_clusters ? cv.take<unsigned>(fsn_lstm2_group_flag_words(d.grp_clusters)) : nullptr;
+    w.fb_exchange = d.fb_chain ? cv.take<float>(fsn_fb_chain_exchange_floats(d.Tp, d.Npad_fb)) : nullptr;
+    w.fb_flags = d.fb_chain ? cv.take<unsigned>(fsn_fb_chain_flag_words()) : nullptr;
     return w;
 }
 
@@ -534,9 +540,14 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         // N = B rows only: a chain of tiny dependent launches, so the two layers advance as a wavefront
         // (layer 1 at step t next to layer 0 at step t + 1): T' + 1 launches instead of 2 T'
         StageTimer st(ST_FB_REC, s);
-        FSN_TRY(fsn_launch_lstm_wavefront2(w.gx_fb, d.Npad_fb / 16, 0, pk + p.fb_whh0, pk + p.fb_wih1, pk + p.fb_b1_frag,
-                                           pk + p.fb_whh1, w.hseq_fb0, w.hseq_fb1, d.Npad_fb, 0, w.c_fb,
-                                           w.c_fb + (size_t)d.Npad_fb * d.Hf, d.Tp, d.Npad_fb / 16, d.Hf, s));
+        if (d.fb_chain) {  // up to 64 utterances, H = 512: the whole chain as one persistent launch
+            FSN_TRY(fsn_launch_fb_chain(w.gx_fb, pk + p.fb_whh0, pk + p.fb_wih1, pk + p.fb_whh1, pk + p.fb_b1,
+                                        w.fb_exchange, w.fb_flags, w.hseq_fb1, d.Tp, d.Npad_fb, d.Hf, s));
+        } else {
+            FSN_TRY(fsn_launch_lstm_wavefront2(w.gx_fb, d.Npad_fb / 16, 0, pk + p.fb_whh0, pk + p.fb_wih1,
+                                               pk + p.fb_b1_frag, pk + p.fb_whh1, w.hseq_fb0, w.hseq_fb1, d.Npad_fb, 0,
+                                               w.c_fb, w.c_fb + (size_t)d.Npad_fb * d.Hf, d.Tp, d.Npad_fb / 16, d.Hf, s));
+        }
     }
     {
         StageTimer st(ST_FB_GEMM, s);

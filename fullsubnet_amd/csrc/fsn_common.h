@@ -151,6 +151,13 @@ int fsn_launch_pack(const float* w, float* wp, int n_out, int k, int n_out_pad, 
 int fsn_launch_bias_sum(const float* a, const float* b, float* out, int n, int n_pad, hipStream_t s);
 int fsn_launch_bias_frag(const float* bias, float* frag, int n, hipStream_t s);
 
+// fb_chain_kernels.hip: the full-band model's two LSTM layers over all frames as one persistent launch
+bool fsn_fb_chain_supported(int H, int Npad);
+size_t fsn_fb_chain_exchange_floats(int Tp, int Npad);
+size_t fsn_fb_chain_flag_words();
+int fsn_launch_fb_chain(const float* gx0, const float* whh0_p, const float* wih1_p, const float* whh1_p, const float* b1,
+                        float* exchange, unsigned* flags, float* hseq1, int Tp, int Npad, int H, hipStream_t s);
+
 // lstm_train_kernels.hip (training step: BPTT pieces)
 // C [M][Nc] = sum_k A[k][M]^T B[k][Nc]   (both operands row-major over k; split-K, deterministic 2-pass)
 size_t fsn_gemm_tn_workspace_bytes(int M, int Nc, long K);

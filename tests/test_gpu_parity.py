@@ -570,7 +570,9 @@ def test_two_streams_and_two_host_threads_are_independent(fsn):
     finally:
         L.fsn_profile_enable(0)
     assert main_ms["sb_rec_l0"] > 0 and side_ms["sb_rec_l0"] > 0
-    assert again == main_ms
+    # the same events read twice (elapsed times are re-derived from the timestamps: equal to rounding)
+    assert again.keys() == main_ms.keys()
+    assert all(again[k] == pytest.approx(main_ms[k], rel=1e-3, abs=1e-5) for k in main_ms)
 
 
 @pytest.mark.parametrize("batch", [6, 8, 9])
