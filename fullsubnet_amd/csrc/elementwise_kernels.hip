@@ -274,3 +274,15 @@ int fsn_launch_cumulative_den_sb(const float* mag, const float* fb_out, float* d
                        B, Tp, F, FP, nb, Npad, carry, t0);
     return fsn_check_launch("cumulative_den_sb_kernel");
 }
+
+// Zero n 32-bit words (flags of the persistent kernels).  A kernel instead of hipMemsetAsync: measured on ROCm 7.2,
+// the memset node of a captured graph took effect in the first replay only (tests/test_gpu_streaming.py: replays on new
+// input read the previous replay's flags and hand-off buffers), a kernel node is replayed every time.
+__global__ void zero_words_kernel(unsigned* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+int fsn_launch_zero_words(unsigned* p, size_t n, hipStream_t s) {
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
+    hipLaunchKernelGGL(zero_words_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, p, n);
+    return fsn_check_launch("zero_words_kernel");
+}

@@ -4,20 +4,24 @@
 // Why: the full-band LSTM has B <= 64 rows (one per utterance) and 2 x 512 hidden units - 0.1 TFLOP per batch - but
 // its frames are a dependent chain, so it ran as a wavefront of T' + 1 launches of ~10.6 us each: 2.0 ms that no other
 // work of the forward can hide (the sub-band input needs the mean of the WHOLE full-band output, model.py:110).  A
-// launch boundary costs a drain, a dispatch and cold operand fetches; here the chain stays resident and a step costs one
-// hand-off through memory (~3 us) plus its MFMAs:
-//   - three stages of H / 4 = 128 workgroups each: L0 (layer 0: h0_t from gx0_t + h0_{t-1} W_hh0), L1x (feed-forward:
-//     gx1_t = h0_t W_ih1 + b1, one step behind L0) and L1h (layer 1: h1_t from gx1_t + h1_{t-1} W_hh1).  Splitting
-//     layer 1 in two keeps every stage at K = 512 per step and takes the input half of layer 1 off its recurrence;
-//   - a workgroup owns FOUR hidden units = one 16-column MFMA tile (4 gates x 4 units) for all rows: its weight slice
-//     (512 x 16 floats) is read ONCE into registers and stays there for all frames - the K loop has no weight traffic;
+// launch boundary costs a drain, a dispatch and cold operand fetches; here the chain stays resident and a step costs
+// its MFMAs plus one hand-off through memory:
+//   - two stages of H / 4 = 128 workgroups, one workgroup per CU: L0 (layer 0) and L1 (layer 1's recurrence).  A
+//     workgroup owns FOUR hidden units = one 16-column MFMA tile (4 gates x 4 units) for all rows; its weight slices
+//     (512 x 16 floats each) are read ONCE into registers and stay there for all frames - no weight traffic at all;
+//   - the input half of layer 1 (h0_t W_ih1 + b1) has the same A operand as layer 0's recurrence at step t + 1
+//     (h0_t W_hh0): the L0 workgroup computes both from one set of A fragments - its own gates first (critical path),
+//     cell update, h0 store, flag, and then layer 1's projection tile while the partners' flags are on their way.
+//     Layer 1 is left with K = 512 per step like layer 0;
 //   - wave w = row tile w (B > 32), or K is split over the waves (2 row tiles x 2 halves, 1 tile x 4 quarters) and the
 //     partial tiles are summed in a fixed order through LDS;
 //   - h_t goes to per-step buffers in A-fragment order (a wave's K chunk is one contiguous 1 KB block) with the
 //     write-through / flag recipe of the CDNA guide (Guideline 16, R1: sc1 stores, every storing wave drains, ONE flag
-//     store; one wave polls the 128 flags of the producing stage, barrier, sc1 loads).  No buffer is ever reused, so
-//     there is no back-pressure and the dependence graph is acyclic: with all 384 workgroups resident (two per CU
-//     fit) the launch cannot deadlock; every spin is bounded anyway (status raised, results garbage, never a hang).
+//     store per copy; one wave polls the 128 flags of the producing stage, barrier, sc1 loads).  No buffer is ever
+//     reused, so there is no back-pressure and the dependence graph is acyclic: with all 256 workgroups resident the
+//     launch cannot deadlock; every spin is bounded anyway (status raised, results garbage, never a hang).  The host
+//     serialises persistent launches of different streams (fsn_api.hip) so that two of them never share the CUs.
+// Measured with tools/probe_chain.hip (190 steps): see DESIGN.md 4.6.
 #include "fsn_common.h"
 
 namespace {
@@ -25,6 +29,7 @@ namespace {
 constexpr int CH = 512;         // hidden units per layer
 constexpr int CKC = CH / 16;    // K chunks of an H-wide operand
 constexpr int CNW = CH / 4;     // workgroups per stage
+constexpr int CREP = 16;        // copies of a stage's flag array: a poller reads copy (its index % CREP)
 constexpr unsigned kChainSpin = 1u << 21;
 
 struct ChainArgs {
@@ -37,24 +42,23 @@ struct ChainArgs {
     float* hx1;           // likewise layer 1
     float* gx1;           // [Tp][CNW][4 waves][64][4]: partial projection tiles of layer 1
     float* hseq1;         // [Tp][Npad][H] row-major (the output layer's A operand)
-    unsigned* flags;      // [3][CNW]: steps published by (stage, workgroup); stage 0 = L0, 1 = L1h, 2 = L1x
+    unsigned* flags;      // [2][CREP][CNW] steps published by (stage 0 = L0 / 1 = L1, workgroup), CREP copies
     unsigned* status;
     int Tp, RT, Npad;
 };
 
-// wave 0: all 128 flags of a stage >= epoch, and (optionally) one more flag >= its epoch
+// wave 0: all 128 flags of a stage >= epoch and (optionally) one more flag >= its epoch, both looked at in the same
+// round trip; bounded
 __device__ __forceinline__ bool chain_wait(const unsigned* flags, unsigned epoch, const unsigned* one, unsigned one_epoch,
                                            unsigned* status) {
     const int lane = threadIdx.x & 63;
+    const unsigned long long* f = reinterpret_cast<const unsigned long long*>(flags) + lane;
     for (unsigned spins = 0;; ++spins) {
-        bool ok = true;
-        if (epoch > 0) {
-            const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(flags) + lane,
-                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok = (unsigned)v >= epoch && (unsigned)(v >> 32) >= epoch;
-        }
-        if (one && lane == 0) ok = ok && __hip_atomic_load(one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= one_epoch;
-        if (__all((int)ok)) return true;
+        unsigned long long v = ~0ull;
+        unsigned w = ~0u;
+        if (epoch > 0) v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (one && lane == 0) w = __hip_atomic_load(one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all((int)((unsigned)v >= epoch && (unsigned)(v >> 32) >= epoch && w >= one_epoch))) return true;
         if ((spins & 255u) == 255u) {
             const unsigned st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (st != 0 || spins >= kChainSpin) {
@@ -62,66 +66,74 @@ __device__ __forceinline__ bool chain_wait(const unsigned* flags, unsigned epoch
                 return false;
             }
         }
-        __builtin_amdgcn_s_sleep(1);
     }
 }
 
-__device__ __forceinline__ void chain_store(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: write-through
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte write-through store (sc1): whole 16-byte groups, never single dwords - a step of the chain publishes ~0.8 MB,
+// and as dword stores that was 200 k partial-line write transactions per step (measured: 2 us of a 9.6 us step)
+__device__ __forceinline__ void chain_store16(const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff, f32x4 v,
+                                              bool plain) {
+    if (plain) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 16);  // aux 16 = sc1
+}
+// value of quad lane Q (lanes 4 k .. 4 k + 3 form a quad) in every lane of the quad
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), Q * 0x55, 0xf, 0xf, true));
 }
 
 // KS = K split over the waves: 1 (up to 4 row tiles), 2 (up to 2), 4 (one row tile)
-template <int KS>
-__global__ __launch_bounds__(256, 2) void fb_chain_kernel(const ChainArgs a) {
+// ABL: experiment knob of tools/probe_chain.hip (0 in the library; any bit set gives WRONG results): 1 no flag polling,
+// 2 no h / projection stores, 4 A fragments not loaded, 8 plain instead of write-through stores, 16 no drain before
+// the flag store, 32 no flag stores, 64 no layer-1 projection in L0 (L1 does not wait for it)
+template <int KS, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void fb_chain_kernel(const ChainArgs a) {
     constexpr int RTW = 4 / KS;    // row tiles a workgroup can hold
     constexpr int CW = CKC / KS;   // K chunks per wave
-    constexpr int AD = CW < 16 ? CW : 16;  // A fragments in flight
     __shared__ f32x4 red[KS > 1 ? (KS - 1) * RTW * 64 : 1];
 
-    const int stage = (int)blockIdx.x / CNW, j = (int)blockIdx.x % CNW;  // stage 2 (L1x) is dispatched last: it shares CUs
+    const int stage = (int)blockIdx.x / CNW, j = (int)blockIdx.x % CNW;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rt = wave % RTW, kp = wave / RTW;
     const int lr = lane & 15, lq = lane >> 4, g = lr >> 2, ul = lr & 3;
     const int Tp = a.Tp, RT = a.RT;
-    const bool active = rt < RT;
+    const bool active = rt < RT, owner = active && kp == 0;
 
-    unsigned* fl0 = a.flags;
-    unsigned* fl1 = a.flags + CNW;
-    unsigned* flx = a.flags + 2 * CNW;
-
-    // this workgroup's weight slice: column tile = (gate g, units 4 j .. 4 j + 3), K chunks kp CW .. kp CW + CW - 1
-    f32x4 wreg[CW];
-    {
-        const float* wsel = stage == 0 ? a.whh0_p : (stage == 1 ? a.whh1_p : a.wih1_p);
-        const float* wp = wsel + ((size_t)(g * CKC + (j >> 2)) * CKC * 64 + lq * 16 + 4 * (j & 3) + ul) * 4;
-#pragma unroll
-        for (int q = 0; q < CW; ++q) wreg[q] = *reinterpret_cast<const f32x4*>(wp + (size_t)(kp * CW + q) * 256);
-    }
-    const float bias1 = a.b1[g * CH + 4 * j + ul];
+    // Every workgroup polls ALL flags of a stage.  With one copy of the flags that is hundreds of pollers on the same
+    // four cache lines (one memory channel each): measured, 128 extra pollers doubled the step time.  So a producer
+    // writes CREP copies (one store instruction, CREP lanes) and a consumer polls copy (its index % CREP).
+    unsigned* fl0 = a.flags;               // [CREP][CNW]
+    unsigned* fl1 = a.flags + CREP * CNW;  // [CREP][CNW]
+    const int rep = j % CREP;
 
     const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(a.hx0, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(a.hx1, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(a.gx1, 0, 0x7fffffff, 0x00020000);
     const unsigned lane16 = (unsigned)lane * 16u;
-    // acc += h[tile (ts, rt)][K part kp] W: A fragments by sc1 buffer loads (written through by other CUs), AD in flight
-    auto kpart = [&](f32x4 acc, const __amdgpu_buffer_rsrc_t& r, int ts) -> f32x4 {
-        const unsigned base = (unsigned)((((size_t)ts * RT + rt) * CKC + kp * CW) * 1024);
-        f32x4 ar[AD];
+
+    // weight slice of column tile (gate g, units 4 j .. 4 j + 3), K chunks kp CW .. kp CW + CW - 1, from the packed
+    // [4H/16][KC][64][4] order: this lane's fragment of chunk kc is one 16-byte group
+    auto load_w = [&](const float* packed, f32x4 (&w)[CW]) {
+        const float* wp = packed + ((size_t)(g * CKC + (j >> 2)) * CKC * 64 + lq * 16 + 4 * (j & 3) + ul) * 4;
 #pragma unroll
-        for (int d = 0; d < AD; ++d)
-            ar[d] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane16, base + d * 1024u, 16));
-        __builtin_amdgcn_sched_barrier(0);  // all AD requests leave before the first MFMA waits for one of them
+        for (int q = 0; q < CW; ++q) w[q] = *reinterpret_cast<const f32x4*>(wp + (size_t)(kp * CW + q) * 256);
+    };
+    // all A fragments of tile (ts, rt), K part kp: sc1 buffer loads (the producers wrote through), all in flight at once
+    auto load_a = [&](f32x4 (&ar)[CW], const __amdgpu_buffer_rsrc_t& r, int ts) {
+        const unsigned base = (unsigned)((((size_t)ts * RT + rt) * CKC + kp * CW) * 1024);
 #pragma unroll
         for (int q = 0; q < CW; ++q) {
-            const f32x4 av = ar[q % AD];
-            if (q + AD < CW) {
-                ar[q % AD] = __builtin_bit_cast(
-                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane16, base + (unsigned)(q + AD) * 1024u, 16));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc = mfma16(av[jj], wreg[q][jj], acc);
+            if (ABL & 4) ar[q] = f32x4{0.5f, 0.25f, -0.125f, 0.0625f};
+            else ar[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane16, base + q * 1024u, 16));
         }
+        __builtin_amdgcn_sched_barrier(0);  // every request leaves before the first MFMA waits for one of them
+    };
+    auto mac = [&](f32x4 acc, const f32x4 (&ar)[CW], const f32x4 (&w)[CW]) -> f32x4 {
+#pragma unroll
+        for (int q = 0; q < CW; ++q)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc = mfma16(ar[q][jj], w[q][jj], acc);
         return acc;
     };
     // partial tiles of the K parts -> the kp = 0 wave of each row tile, summed in the fixed order 1, 2, 3
@@ -139,90 +151,149 @@ __global__ __launch_bounds__(256, 2) void fb_chain_kernel(const ChainArgs a) {
         }
         return acc;
     };
-    auto publish = [&](unsigned* flag, unsigned epoch) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // every wave drains its stores, then one flag store per copy
+    auto publish = [&](unsigned* flags, unsigned epoch) {
+        if (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)threadIdx.x < CREP && !(ABL & 32))
+            __hip_atomic_store(flags + (size_t)threadIdx.x * CNW + j, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-
-    if (stage == 2) {
-        // ---- L1x: gx1_t = h0_t W_ih1^T + b1, partial per K part (summed by L1h's reduction) ---------------------
-        float* out = a.gx1 + ((size_t)j * 4 + wave) * 256 + lane * 4;
-        for (int t = 0; t < Tp; ++t) {
-            if (wave == 0) (void)chain_wait(fl0, (unsigned)t + 1, nullptr, 0, a.status);
-            __syncthreads();
-            if (active) {
-                const float b = kp == 0 ? bias1 : 0.f;
-                const f32x4 acc = kpart(f32x4{b, b, b, b}, r0, t);
-                float* o = out + (size_t)t * CNW * 1024;
+    auto hstore = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff, f32x4 v) {
+        if (!(ABL & 2)) chain_store16(r, voff, soff, v, (ABL & 8) != 0);
+    };
+    // LSTM cell of this wave's 16 rows x 4 units from the gate tile; returns h[row 4 lq + ul][units 0..3] (lanes g = 0)
+    auto cell = [&](f32x4 acc, float (&c)[4]) -> f32x4 {
+        float act[4], hq[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) chain_store(o + i, acc[i]);
+        for (int i = 0; i < 4; ++i) act[i] = g == 2 ? tanh_fast(acc[i]) : sigmoid_fast(acc[i]);
+        // lanes ul (gate i, g = 0) gather f, g, o of their unit from lanes ul + 4, + 8, + 12 of the same 16-lane row
+        // group; the other lanes compute along on garbage (no branch)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float fg = __shfl(act[i], lane + 4, 64);
+            const float gg = __shfl(act[i], lane + 8, 64);
+            const float og = __shfl(act[i], lane + 12, 64);
+            const float cn = fg * c[i] + act[i] * gg;
+            c[i] = cn;
+            hq[i] = og * tanh_fast(cn);
+        }
+        // lane (ul, lq) holds h[row 4 lq + i][unit ul]: 4 x 4 transpose inside the quad -> h[row 4 lq + ul][units 0..3],
+        // one 16-byte group of the A-fragment buffer (and of the row-major sequence) per lane
+        f32x4 hv;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float t0 = u == 0 ? quad_bcast<0>(hq[0]) : u == 1 ? quad_bcast<1>(hq[0]) : u == 2 ? quad_bcast<2>(hq[0]) : quad_bcast<3>(hq[0]);
+            const float t1 = u == 0 ? quad_bcast<0>(hq[1]) : u == 1 ? quad_bcast<1>(hq[1]) : u == 2 ? quad_bcast<2>(hq[1]) : quad_bcast<3>(hq[1]);
+            const float t2 = u == 0 ? quad_bcast<0>(hq[2]) : u == 1 ? quad_bcast<1>(hq[2]) : u == 2 ? quad_bcast<2>(hq[2]) : quad_bcast<3>(hq[2]);
+            const float t3 = u == 0 ? quad_bcast<0>(hq[3]) : u == 1 ? quad_bcast<1>(hq[3]) : u == 2 ? quad_bcast<2>(hq[3]) : quad_bcast<3>(hq[3]);
+            hv[u] = ul == 0 ? t0 : ul == 1 ? t1 : ul == 2 ? t2 : t3;
+        }
+        return hv;
+    };
+    const int hrow = 4 * lq + ul;                                     // the row a g = 0 lane stores
+    const unsigned hvoff = (unsigned)(((j & 3) * 16 + hrow) * 16);    // its 16-byte group inside chunk j / 4
+    auto hsoff = [&](int t) { return (unsigned)((((size_t)t * RT + rt) * CKC + (j >> 2)) * 1024); };
+    const unsigned gx1_wave = (unsigned)(((size_t)j * 4 + wave) * 1024);  // this wave's projection tile inside a step
+    const unsigned gx1_step = (unsigned)CNW * 4096u;
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+
+    if (stage == 0) {
+        // ---- L0: layer 0's recurrence for units 4 j .. 4 j + 3, and layer 1's input projection for ITS units 4 j .. --
+        f32x4 whh[CW], wih[CW], ar[CW];
+        load_w(a.whh0_p, whh);
+        load_w(a.wih1_p, wih);
+        const float bias1 = a.b1[g * CH + 4 * j + ul];
+        // the layer-0 projection tile of this lane: rows 4 lq + i, column (g, 4 j + ul) = lane lq 16 + 4 (j & 3) + ul of
+        // column tile g KC + j / 4
+        const float* gx0p = a.gx0 + ((size_t)(g * CKC + (j >> 2)) * 64 + lq * 16 + 4 * (j & 3) + ul) * 4 +
+                            (size_t)rt * (4 * CKC) * 256;
+        const size_t gx0_step = (size_t)RT * (4 * CKC) * 256;
+        f32x4 gxn = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (owner) gxn = *reinterpret_cast<const f32x4*>(gx0p);
+        // iteration t: h0_t (t < Tp) and the projection of h0_{t-1} (t > 0), both from the A fragments of h0_{t-1}
+        for (int t = 0; t <= Tp; ++t) {
+            f32x4 acc = gxn;
+            if (owner && t + 1 < Tp) gxn = *reinterpret_cast<const f32x4*>(gx0p + (size_t)(t + 1) * gx0_step);
+            if (t > 0) {
+                if (wave == 0 && !(ABL & 1)) (void)chain_wait(fl0 + rep * CNW, (unsigned)t, nullptr, 0, a.status);
+                __syncthreads();
+                if (active) load_a(ar, r0, t - 1);
             }
-            publish(flx + j, (unsigned)t + 1);
+            if (t < Tp) {
+                if (active && t > 0) acc = mac(acc, ar, whh);
+                acc = reduce(acc);
+                if (owner) {
+                    const f32x4 hv = cell(acc, c);
+                    if (g == 0) hstore(r0, hvoff, hsoff(t), hv);
+                }
+            }
+            // Layer 1's projection tile of step t - 1 (partial per K part; L1's reduction sums the parts) AFTER the flag
+            // of this step: its MFMAs run while the partners' flags are on their way (measured: before the flag they
+            // cost their full 1.7 us at 64 rows - a write-through store is acknowledged faster than that).  The tile's
+            // store is awaited by the next drain: tile s is complete once this workgroup has published s + 3.  Inline
+            // asm: a store the compiler sees makes every later wait for a load a wait for ALL memory operations.
+            const bool proj = t > 0 && active && !(ABL & 64);
+            const float b = kp == 0 ? bias1 : 0.f;
+            if (t < Tp) publish(fl0, (unsigned)t + 1);
+            if (proj) {
+                const f32x4 accx = mac(f32x4{b, b, b, b}, ar, wih);
+                const unsigned so = (unsigned)(t - 1) * gx1_step + gx1_wave;
+                if (ABL & 2) {
+                } else if (ABL & 8) {
+                    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" ::"v"(accx), "v"(lane16), "s"(rx), "s"(so) : "memory");
+                } else {
+                    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1" ::"v"(accx), "v"(lane16), "s"(rx), "s"(so) : "memory");
+                }
+            }
+            if (t == Tp) publish(fl0, (unsigned)Tp + 2);
         }
         return;
     }
 
-    // ---- L0 / L1h: one LSTM layer's recurrence for units 4 j .. 4 j + 3 ------------------------------------------
-    const bool l1 = stage == 1;
-    unsigned* flown = l1 ? fl1 : fl0;
-    float* hx = l1 ? a.hx1 : a.hx0;
-    // the projection tile of this lane: rows 4 lq + i, column (g, 4 j + ul) = lane lq 16 + 4 (j & 3) + ul of column
-    // tile g KC + j / 4
-    const float* gx0p = a.gx0 + ((size_t)(g * CKC + (j >> 2)) * 64 + lq * 16 + 4 * (j & 3) + ul) * 4;
-    const size_t gx0_step = (size_t)RT * (4 * CKC) * 256;
-    const bool owner = active && kp == 0;
-    float c[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x4 gxn = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!l1 && owner) gxn = *reinterpret_cast<const f32x4*>(gx0p + (size_t)rt * (4 * CKC) * 256);
-    for (int t = 0; t < Tp; ++t) {
-        f32x4 acc = gxn;
-        if (!l1 && owner && t + 1 < Tp)
-            gxn = *reinterpret_cast<const f32x4*>(gx0p + (size_t)(t + 1) * gx0_step + (size_t)rt * (4 * CKC) * 256);
-        if (l1 || t > 0) {
-            if (wave == 0) (void)chain_wait(flown, (unsigned)t, l1 ? flx + j : nullptr, (unsigned)t + 1, a.status);
-            __syncthreads();
-        }
-        if (l1) {
-            acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (active)
-                acc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                    rx, lane16, (unsigned)((((size_t)t * CNW + j) * 4 + wave) * 1024), 16));
-        }
-        if (active && t > 0) acc = kpart(acc, l1 ? r1 : r0, t - 1);
-        acc = reduce(acc);
-        if (owner) {
-            float act[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) act[i] = g == 2 ? tanh_fast(acc[i]) : sigmoid_fast(acc[i]);
-            // lanes ul (gate i) gather f, g, o of their unit from lanes ul + 4, + 8, + 12 of the same 16-lane row group
-            float* hdst = hx + (((size_t)t * RT + rt) * CKC + (j >> 2)) * 256 + ((j & 3) * 16 + 4 * lq) * 4 + ul;
-            float* hrow = a.hseq1 + ((size_t)t * a.Npad + rt * 16 + 4 * lq) * CH + 4 * j + ul;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float fg = __shfl(act[i], lane + 4, 64);
-                const float gg = __shfl(act[i], lane + 8, 64);
-                const float og = __shfl(act[i], lane + 12, 64);
-                if (g == 0) {
-                    const float cn = fg * c[i] + act[i] * gg;
-                    c[i] = cn;
-                    const float hv = og * tanh_fast(cn);
-                    chain_store(hdst + i * 4, hv);
-                    if (l1) hrow[(size_t)i * CH] = hv;
-                }
+    // ---- L1: layer 1's recurrence for units 4 j .. 4 j + 3 ------------------------------------------------------------
+    f32x4 whh[CW], ar[CW];
+    load_w(a.whh1_p, whh);
+    for (int s = 0; s < Tp; ++s) {
+        // h1_{s-1} of all workgroups, and the projection tile of step s from L0 workgroup j (complete at flag s + 3)
+        if (wave == 0 && !(ABL & 1))
+            (void)chain_wait(fl1 + rep * CNW, (unsigned)s, (ABL & 64) ? nullptr : fl0 + rep * CNW + j, (unsigned)s + 3, a.status);
+        __syncthreads();
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (active) {
+            acc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, lane16, (unsigned)s * gx1_step + gx1_wave, 16));
+            if (s > 0) {
+                load_a(ar, r1, s - 1);
+                acc = mac(acc, ar, whh);
             }
         }
-        publish(flown + j, (unsigned)t + 1);
+        acc = reduce(acc);
+        if (owner) {
+            const f32x4 hv = cell(acc, c);
+            if (g == 0) {
+                hstore(r1, hvoff, hsoff(s), hv);
+                *reinterpret_cast<f32x4*>(a.hseq1 + ((size_t)s * a.Npad + rt * 16 + hrow) * CH + 4 * j) = hv;
+            }
+        }
+        publish(fl1, (unsigned)s + 1);
     }
 }
 
 }  // namespace
 
-bool fsn_fb_chain_supported(int H, int Npad) { return H == CH && Npad >= 16 && Npad <= 64 && Npad % 16 == 0; }
+// H = 512, up to 64 rows, and a device with one CU per workgroup (2 x 128: the 64-row variant needs a CU's whole
+// register file)
+bool fsn_fb_chain_supported(int H, int Npad) {
+    if (H != CH || Npad < 16 || Npad > 64 || Npad % 16 != 0) return false;
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return false;
+    return cus >= 2 * CNW;
+}
 size_t fsn_fb_chain_exchange_floats(int Tp, int Npad) {
     return (size_t)2 * Tp * Npad * CH + (size_t)Tp * CNW * 1024;  // hx0, hx1, gx1
 }
-size_t fsn_fb_chain_flag_words() { return (size_t)3 * CNW + 16; }
+size_t fsn_fb_chain_flag_words() { return (size_t)2 * CREP * CNW + 16; }
 
 // gx0: fragment-order projection of layer 0 (bias included); hseq1 [Tp][Npad][H] row-major out.
 int fsn_launch_fb_chain(const float* gx0, const float* whh0_p, const float* wih1_p, const float* whh1_p, const float* b1,
@@ -231,10 +302,8 @@ int fsn_launch_fb_chain(const float* gx0, const float* whh0_p, const float* wih1
         fsn_set_error("fb_chain: built for H = 512 and at most 64 rows");
         return FSN_ERR_ARG;
     }
-    if (hipMemsetAsync(flags, 0, fsn_fb_chain_flag_words() * sizeof(unsigned), s) != hipSuccess) {
-        fsn_set_error("fb_chain: cannot clear the flags");
-        return FSN_ERR_LAUNCH;
-    }
+    // flags and status: zero before EVERY launch (a kernel, not hipMemsetAsync: see fsn_launch_zero_words)
+    if (fsn_launch_zero_words(flags, fsn_fb_chain_flag_words(), s) != FSN_OK) return FSN_ERR_LAUNCH;
     ChainArgs a{};
     a.gx0 = gx0;
     a.whh0_p = whh0_p;
@@ -246,13 +315,13 @@ int fsn_launch_fb_chain(const float* gx0, const float* whh0_p, const float* wih1
     a.gx1 = exchange + (size_t)2 * Tp * Npad * CH;
     a.hseq1 = hseq1;
     a.flags = flags;
-    a.status = flags + 3 * CNW;
+    a.status = flags + 2 * CREP * CNW;
     a.Tp = Tp;
     a.RT = Npad / 16;
     a.Npad = Npad;
-    const dim3 grid(3 * CNW), block(256);
-    if (a.RT == 1) hipLaunchKernelGGL(fb_chain_kernel<4>, grid, block, 0, s, a);
-    else if (a.RT == 2) hipLaunchKernelGGL(fb_chain_kernel<2>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(fb_chain_kernel<1>, grid, block, 0, s, a);
+    const dim3 grid(2 * CNW), block(256);
+    if (a.RT == 1) hipLaunchKernelGGL((fb_chain_kernel<4, 0>), grid, block, 0, s, a);
+    else if (a.RT == 2) hipLaunchKernelGGL((fb_chain_kernel<2, 0>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((fb_chain_kernel<1, 0>), grid, block, 0, s, a);
     return fsn_check_launch("fb_chain_kernel");
 }

@@ -75,6 +75,52 @@ static std::mutex g_ctx_mutex;
 static std::map<std::pair<int, hipStream_t>, StreamCtx*> g_ctx;
 static int g_prof_on = 0;  // process-wide request (a debugging switch); its events live in the StreamCtx
 
+// Persistent kernels whose workgroups wait for each other (the group kernel, the full-band chain) need ALL their
+// workgroups resident at once.  Two of them launched from different streams could each take a part of the chip and wait
+// for the rest until the spin bound.  So these launches are ordered across the streams of a device: a launch waits for
+// the completion event of the previous one (nothing else of the two streams is ordered).  Not under stream capture: the
+// replays of a graph are ordered by whoever launches them.
+struct PersistGate {
+    hipEvent_t ev = nullptr;
+    hipStream_t last = nullptr;
+    bool any = false;
+};
+static std::mutex g_persist_mutex;
+static std::map<int, PersistGate> g_persist;
+class PersistLaunch {
+  public:
+    explicit PersistLaunch(hipStream_t s) : s_(s), lock_(g_persist_mutex) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return;
+        }
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        gate_ = &g_persist[dev];
+        if (!gate_->ev && hipEventCreateWithFlags(&gate_->ev, hipEventDisableTiming) != hipSuccess) {
+            gate_->ev = nullptr;
+            gate_ = nullptr;
+            return;
+        }
+        if (gate_->any && gate_->last != s) (void)hipStreamWaitEvent(s, gate_->ev, 0);
+    }
+    ~PersistLaunch() {
+        if (!gate_) return;
+        if (hipEventRecord(gate_->ev, s_) == hipSuccess) {
+            gate_->last = s_;
+            gate_->any = true;
+        }
+    }
+    PersistLaunch(const PersistLaunch&) = delete;
+    PersistLaunch& operator=(const PersistLaunch&) = delete;
+
+  private:
+    hipStream_t s_;
+    std::unique_lock<std::mutex> lock_;
+    PersistGate* gate_ = nullptr;
+};
+
 // What the running call works on (set by CallScope for the duration of one entry point on this host thread).
 static thread_local StreamCtx* t_ctx = nullptr;
 static thread_local hipStream_t t_stream = nullptr;
@@ -541,6 +587,7 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         // (layer 1 at step t next to layer 0 at step t + 1): T' + 1 launches instead of 2 T'
         StageTimer st(ST_FB_REC, s);
         if (d.fb_chain) {  // up to 64 utterances, H = 512: the whole chain as one persistent launch
+            PersistLaunch gate(s);
             FSN_TRY(fsn_launch_fb_chain(w.gx_fb, pk + p.fb_whh0, pk + p.fb_wih1, pk + p.fb_whh1, pk + p.fb_b1,
                                         w.fb_exchange, w.fb_flags, w.hseq_fb1, d.Tp, d.Npad_fb, d.Hf, s));
         } else {
@@ -648,6 +695,7 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         }
         {
             StageTimer st(ST_SB_REC_L0, s);
+            PersistLaunch gate(s);
             FSN_TRY(fsn_launch_lstm2_group(&xin, pk + p.sb_whh0, pk + p.sb_wih1, pk + p.sb_whh1, pk + p.sb_b1,
                                            w.grp_exchange, w.grp_flags, &gfc, d.Tp, d.grp_clusters, d.Hs, s));
         }

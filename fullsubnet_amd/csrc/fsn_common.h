@@ -151,6 +151,8 @@ int fsn_launch_pack(const float* w, float* wp, int n_out, int k, int n_out_pad, 
 int fsn_launch_bias_sum(const float* a, const float* b, float* out, int n, int n_pad, hipStream_t s);
 int fsn_launch_bias_frag(const float* bias, float* frag, int n, hipStream_t s);
 
+int fsn_launch_zero_words(unsigned* p, size_t n, hipStream_t s);  // elementwise_kernels.hip
+
 // fb_chain_kernels.hip: the full-band model's two LSTM layers over all frames as one persistent launch
 bool fsn_fb_chain_supported(int H, int Npad);
 size_t fsn_fb_chain_exchange_floats(int Tp, int Npad);

@@ -385,11 +385,8 @@ int fsn_launch_lstm2_group(const FsnSbInput* xin, const float* whh0_p, const flo
         fsn_set_error("lstm2_group: built for the sub-band model (H = 384, 32 input columns, fused output layer)");
         return FSN_ERR_ARG;
     }
-    const size_t words = fsn_lstm2_group_flag_words(clusters);
-    if (hipMemsetAsync(flags, 0, words * sizeof(unsigned), s) != hipSuccess) {  // flags and status: zero before EVERY launch
-        fsn_set_error("lstm2_group: cannot clear the flags");
-        return FSN_ERR_LAUNCH;
-    }
+    // flags and status: zero before EVERY launch (a kernel, not hipMemsetAsync: see fsn_launch_zero_words)
+    if (fsn_launch_zero_words(flags, fsn_lstm2_group_flag_words(clusters), s) != FSN_OK) return FSN_ERR_LAUNCH;
     // the four matrices sit in one packed blob: address them as offsets from the lowest pointer
     const float* lo = xin->wih_p;
     for (const float* q : {whh0_p, wih1_p, whh1_p}) lo = q < lo ? q : lo;

@@ -225,9 +225,11 @@ def test_oracle_parity_fresh_weights(fsn):
     assert np.abs(enh.cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("batch", [16, 33, 48])
+@pytest.mark.parametrize("batch", [16, 24, 33, 48])
 def test_more_row_tiles_than_cus(fsn, batch):
-    """B*F/16 > 256 tiles: the persistent recurrent kernel takes floor(tiles/CUs) tiles per CU and
+    """(Also the three shapes of the full-band chain kernel: one row tile with K split over four waves, two row tiles
+    x two K halves at batch 24, one row tile per wave from batch 33.)
+    B*F/16 > 256 tiles: the persistent recurrent kernel takes floor(tiles/CUs) tiles per CU and
     the left-over tiles run step by step on the auxiliary stream (B=16: 257 tiles -> 256 + 1;
     B=33: 531 tiles -> 2 x 256 + 19 -> general multi-round plan; B=48: 771 tiles -> 3 x 256 + 3).  At 2 - 4 tiles
     per workgroup the last layer forms its input projection itself (lstm_rec_x_kernel); at one tile per workgroup it

@@ -103,12 +103,13 @@ def test_streaming_composed_configuration(setup):
     assert np.abs(got.cpu().numpy() - want).max() <= 2e-3 * np.abs(want).max()
 
 
-@pytest.mark.parametrize("batch", [1, 17])
+@pytest.mark.parametrize("batch", [1, 8, 17])
 def test_enhance_is_capturable_in_a_hip_graph(setup, batch):
     """The C ABI only enqueues on the caller's stream (its auxiliary stream is forked and joined with events), so
     the whole path can be captured once and replayed (torch.cuda.CUDAGraph = hipGraph): the replay on new input in
     the static buffer must be bit-identical to the eager call.  batch 17: the persistent kernel with a left-over
-    tile on the auxiliary stream inside the capture; batch 1: the per-step wavefront chain."""
+    tile on the auxiliary stream inside the capture; batch 1: the per-step wavefront chain; batch 8: the group kernel.
+    All three contain the full-band chain kernel, whose flags must be cleared by every replay."""
     fsn, model, _ = setup
     noisy = torch.from_numpy(O.make_noisy(batch, 2048, seed=21)).cuda()
     other = torch.from_numpy(O.make_noisy(batch, 2048, seed=22)).cuda()

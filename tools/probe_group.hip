@@ -5,6 +5,7 @@
 #include "../fullsubnet_amd/csrc/lstm_group_kernels.hip"
 void fsn_set_error(const char*, ...) {}
 int fsn_check_launch(const char*) { return hipGetLastError() == hipSuccess ? 0 : -3; }
+int fsn_launch_zero_words(unsigned* p, size_t n, hipStream_t s) { return hipMemsetAsync(p, 0, n * 4, s) == hipSuccess ? 0 : -3; }
 __global__ void fill_kernel(float* p, size_t n, unsigned seed, float scale, float offset) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         unsigned x = (unsigned)i * 747796405u + seed; x ^= x >> 16; x *= 2246822519u; x ^= x >> 13;
