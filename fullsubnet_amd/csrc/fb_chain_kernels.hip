@@ -42,6 +42,11 @@ struct ChainArgs {
     float* hx1;           // likewise layer 1
     float* gx1;           // [Tp][CNW][4 waves][64][4]: partial projection tiles of layer 1
     float* hseq1;         // [Tp][Npad][H] row-major (the output layer's A operand)
+    float* hseq0;         // training (SAVE): layer 0's hidden sequence, row-major
+    float* gates0;        // training: activated gates i | f | g | o of layer 0, [Tp][Npad][4H]
+    float* cseq0;         // training: cell sequence of layer 0, [Tp][Npad][H]
+    float* gates1;
+    float* cseq1;
     unsigned* flags;      // [2][CREP][CNW] steps published by (stage 0 = L0 / 1 = L1, workgroup), CREP copies
     unsigned* status;
     int Tp, RT, Npad;
@@ -87,7 +92,9 @@ __device__ __forceinline__ float quad_bcast(float v) {
 // ABL: experiment knob of tools/probe_chain.hip (0 in the library; any bit set gives WRONG results): 1 no flag polling,
 // 2 no h / projection stores, 4 A fragments not loaded, 8 plain instead of write-through stores, 16 no drain before
 // the flag store, 32 no flag stores, 64 no layer-1 projection in L0 (L1 does not wait for it)
-template <int KS, int ABL = 0>
+// SAVE: the training form - every step also keeps the activated gates, the cell state and layer 0's hidden sequence
+// (fsn_lstm_layer_backward's inputs, the layouts of fsn_lstm_layer_forward)
+template <int KS, int ABL = 0, bool SAVE = false>
 __global__ __launch_bounds__(256, 1) void fb_chain_kernel(const ChainArgs a) {
     constexpr int RTW = 4 / KS;    // row tiles a workgroup can hold
     constexpr int CW = CKC / KS;   // K chunks per wave
@@ -161,8 +168,24 @@ __global__ __launch_bounds__(256, 1) void fb_chain_kernel(const ChainArgs a) {
     auto hstore = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff, f32x4 v) {
         if (!(ABL & 2)) chain_store16(r, voff, soff, v, (ABL & 8) != 0);
     };
-    // LSTM cell of this wave's 16 rows x 4 units from the gate tile; returns h[row 4 lq + ul][units 0..3] (lanes g = 0)
-    auto cell = [&](f32x4 acc, float (&c)[4]) -> f32x4 {
+    // lane (u', lq) of a quad holds v[i] = x[row 4 lq + i][unit u']: 4 x 4 transpose inside the quad ->
+    // x[row 4 lq + ul][units 0..3], one 16-byte group of a row-major (or A-fragment) buffer per lane
+    auto quad_transpose = [&](const float (&v)[4]) -> f32x4 {
+        f32x4 o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float t0 = u == 0 ? quad_bcast<0>(v[0]) : u == 1 ? quad_bcast<1>(v[0]) : u == 2 ? quad_bcast<2>(v[0]) : quad_bcast<3>(v[0]);
+            const float t1 = u == 0 ? quad_bcast<0>(v[1]) : u == 1 ? quad_bcast<1>(v[1]) : u == 2 ? quad_bcast<2>(v[1]) : quad_bcast<3>(v[1]);
+            const float t2 = u == 0 ? quad_bcast<0>(v[2]) : u == 1 ? quad_bcast<1>(v[2]) : u == 2 ? quad_bcast<2>(v[2]) : quad_bcast<3>(v[2]);
+            const float t3 = u == 0 ? quad_bcast<0>(v[3]) : u == 1 ? quad_bcast<1>(v[3]) : u == 2 ? quad_bcast<2>(v[3]) : quad_bcast<3>(v[3]);
+            o[u] = ul == 0 ? t0 : ul == 1 ? t1 : ul == 2 ? t2 : t3;
+        }
+        return o;
+    };
+    const int hrow = 4 * lq + ul;                                     // the row a lane stores after the transpose
+    // LSTM cell of this wave's 16 rows x 4 units from the gate tile; returns h[row 4 lq + ul][units 0..3] (lanes g = 0).
+    // SAVE: activated gates -> gates_t [Npad][4H] (every lane: its gate, 4 units of row 4 lq + ul), c_t -> cseq_t.
+    auto cell = [&](f32x4 acc, float (&c)[4], float* gates_t, float* cseq_t) -> f32x4 {
         float act[4], hq[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) act[i] = g == 2 ? tanh_fast(acc[i]) : sigmoid_fast(acc[i]);
@@ -177,20 +200,14 @@ __global__ __launch_bounds__(256, 1) void fb_chain_kernel(const ChainArgs a) {
             c[i] = cn;
             hq[i] = og * tanh_fast(cn);
         }
-        // lane (ul, lq) holds h[row 4 lq + i][unit ul]: 4 x 4 transpose inside the quad -> h[row 4 lq + ul][units 0..3],
-        // one 16-byte group of the A-fragment buffer (and of the row-major sequence) per lane
-        f32x4 hv;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float t0 = u == 0 ? quad_bcast<0>(hq[0]) : u == 1 ? quad_bcast<1>(hq[0]) : u == 2 ? quad_bcast<2>(hq[0]) : quad_bcast<3>(hq[0]);
-            const float t1 = u == 0 ? quad_bcast<0>(hq[1]) : u == 1 ? quad_bcast<1>(hq[1]) : u == 2 ? quad_bcast<2>(hq[1]) : quad_bcast<3>(hq[1]);
-            const float t2 = u == 0 ? quad_bcast<0>(hq[2]) : u == 1 ? quad_bcast<1>(hq[2]) : u == 2 ? quad_bcast<2>(hq[2]) : quad_bcast<3>(hq[2]);
-            const float t3 = u == 0 ? quad_bcast<0>(hq[3]) : u == 1 ? quad_bcast<1>(hq[3]) : u == 2 ? quad_bcast<2>(hq[3]) : quad_bcast<3>(hq[3]);
-            hv[u] = ul == 0 ? t0 : ul == 1 ? t1 : ul == 2 ? t2 : t3;
+        if (SAVE) {
+            const size_t row = (size_t)rt * 16 + hrow;
+            *reinterpret_cast<f32x4*>(gates_t + row * (4 * CH) + g * CH + 4 * j) = quad_transpose(act);
+            const f32x4 cv = quad_transpose(c);
+            if (g == 0) *reinterpret_cast<f32x4*>(cseq_t + row * CH + 4 * j) = cv;
         }
-        return hv;
+        return quad_transpose(hq);
     };
-    const int hrow = 4 * lq + ul;                                     // the row a g = 0 lane stores
     const unsigned hvoff = (unsigned)(((j & 3) * 16 + hrow) * 16);    // its 16-byte group inside chunk j / 4
     auto hsoff = [&](int t) { return (unsigned)((((size_t)t * RT + rt) * CKC + (j >> 2)) * 1024); };
     const unsigned gx1_wave = (unsigned)(((size_t)j * 4 + wave) * 1024);  // this wave's projection tile inside a step
@@ -223,8 +240,12 @@ __global__ __launch_bounds__(256, 1) void fb_chain_kernel(const ChainArgs a) {
                 if (active && t > 0) acc = mac(acc, ar, whh);
                 acc = reduce(acc);
                 if (owner) {
-                    const f32x4 hv = cell(acc, c);
-                    if (g == 0) hstore(r0, hvoff, hsoff(t), hv);
+                    const f32x4 hv = cell(acc, c, SAVE ? a.gates0 + (size_t)t * a.Npad * 4 * CH : nullptr,
+                                          SAVE ? a.cseq0 + (size_t)t * a.Npad * CH : nullptr);
+                    if (g == 0) {
+                        hstore(r0, hvoff, hsoff(t), hv);
+                        if (SAVE) *reinterpret_cast<f32x4*>(a.hseq0 + ((size_t)t * a.Npad + rt * 16 + hrow) * CH + 4 * j) = hv;
+                    }
                 }
             }
             // Layer 1's projection tile of step t - 1 (partial per K part; L1's reduction sums the parts) AFTER the flag
@@ -268,7 +289,8 @@ __global__ __launch_bounds__(256, 1) void fb_chain_kernel(const ChainArgs a) {
         }
         acc = reduce(acc);
         if (owner) {
-            const f32x4 hv = cell(acc, c);
+            const f32x4 hv = cell(acc, c, SAVE ? a.gates1 + (size_t)s * a.Npad * 4 * CH : nullptr,
+                                  SAVE ? a.cseq1 + (size_t)s * a.Npad * CH : nullptr);
             if (g == 0) {
                 hstore(r1, hvoff, hsoff(s), hv);
                 *reinterpret_cast<f32x4*>(a.hseq1 + ((size_t)s * a.Npad + rt * 16 + hrow) * CH + 4 * j) = hv;
@@ -296,10 +318,18 @@ size_t fsn_fb_chain_exchange_floats(int Tp, int Npad) {
 size_t fsn_fb_chain_flag_words() { return (size_t)2 * CREP * CNW + 16; }
 
 // gx0: fragment-order projection of layer 0 (bias included); hseq1 [Tp][Npad][H] row-major out.
+// Training form: hseq0, save0, save1 non-NULL (save = gates [Tp][Npad][4H] followed by the cell sequence [Tp][Npad][H],
+// the layout of fsn_lstm_layer_forward).
 int fsn_launch_fb_chain(const float* gx0, const float* whh0_p, const float* wih1_p, const float* whh1_p, const float* b1,
-                        float* exchange, unsigned* flags, float* hseq1, int Tp, int Npad, int H, hipStream_t s) {
+                        float* exchange, unsigned* flags, float* hseq1, int Tp, int Npad, int H, hipStream_t s,
+                        float* hseq0, float* save0, float* save1) {
     if (!fsn_fb_chain_supported(H, Npad) || Tp < 1) {
         fsn_set_error("fb_chain: built for H = 512 and at most 64 rows");
+        return FSN_ERR_ARG;
+    }
+    const bool save = hseq0 || save0 || save1;
+    if (save && !(hseq0 && save0 && save1)) {
+        fsn_set_error("fb_chain: the training form needs hseq0, save0 and save1");
         return FSN_ERR_ARG;
     }
     // flags and status: zero before EVERY launch (a kernel, not hipMemsetAsync: see fsn_launch_zero_words)
@@ -314,14 +344,25 @@ int fsn_launch_fb_chain(const float* gx0, const float* whh0_p, const float* wih1
     a.hx1 = exchange + (size_t)Tp * Npad * CH;
     a.gx1 = exchange + (size_t)2 * Tp * Npad * CH;
     a.hseq1 = hseq1;
+    a.hseq0 = hseq0;
+    a.gates0 = save0;
+    a.cseq0 = save0 ? save0 + (size_t)Tp * Npad * 4 * CH : nullptr;
+    a.gates1 = save1;
+    a.cseq1 = save1 ? save1 + (size_t)Tp * Npad * 4 * CH : nullptr;
     a.flags = flags;
     a.status = flags + 2 * CREP * CNW;
     a.Tp = Tp;
     a.RT = Npad / 16;
     a.Npad = Npad;
     const dim3 grid(2 * CNW), block(256);
-    if (a.RT == 1) hipLaunchKernelGGL((fb_chain_kernel<4, 0>), grid, block, 0, s, a);
-    else if (a.RT == 2) hipLaunchKernelGGL((fb_chain_kernel<2, 0>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((fb_chain_kernel<1, 0>), grid, block, 0, s, a);
+    if (save) {
+        if (a.RT == 1) hipLaunchKernelGGL((fb_chain_kernel<4, 0, true>), grid, block, 0, s, a);
+        else if (a.RT == 2) hipLaunchKernelGGL((fb_chain_kernel<2, 0, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((fb_chain_kernel<1, 0, true>), grid, block, 0, s, a);
+    } else {
+        if (a.RT == 1) hipLaunchKernelGGL((fb_chain_kernel<4, 0, false>), grid, block, 0, s, a);
+        else if (a.RT == 2) hipLaunchKernelGGL((fb_chain_kernel<2, 0, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((fb_chain_kernel<1, 0, false>), grid, block, 0, s, a);
+    }
     return fsn_check_launch("fb_chain_kernel");
 }

@@ -1432,6 +1432,79 @@ extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_i
     return FSN_OK;
 }
 
+// ---- training: two stacked nn.LSTM layers of equal width, forward with saved activations ----------------------
+// (sequence_model.py:52-58 with num_layers = 2, under autograd: fullsubnet/trainer.py:56-63).  The result is that of two
+// fsn_lstm_layer_forward calls; what it adds is the persistent kernels: the full-band shape (H = 512, up to 64 rows)
+// runs on fb_chain_kernel, one launch for both layers and all steps instead of 2 T.
+static bool lstm2_train_on_chain(int N, int H) { return fsn_fb_chain_supported(H, N); }
+extern "C" size_t fsn_lstm2_train_workspace_bytes(int T, int N, int I, int H) {
+    const int Ipad = fsn_round_up(I, 16);
+    Carver cv(nullptr);
+    if (lstm2_train_on_chain(N, H)) {
+        cv.take<float>((size_t)4 * H * Ipad);
+        cv.take<float>((size_t)3 * 4 * H * H);
+        cv.take<float>((size_t)2 * 4 * H);
+        cv.take<float>((size_t)T * N * 4 * H);
+        cv.take<float>(fsn_fb_chain_exchange_floats(T, N));
+        cv.take<unsigned>(fsn_fb_chain_flag_words());
+        return fsn_round_up_sz(cv.off, 256);
+    }
+    const size_t l0 = fsn_lstm_layer_fwd_workspace_bytes(T, N, I, H), l1 = fsn_lstm_layer_fwd_workspace_bytes(T, N, H, H);
+    return l0 > l1 ? l0 : l1;
+}
+extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_ih0, const float* w_hh0,
+                                       const float* b_ih0, const float* b_hh0, const float* w_ih1, const float* w_hh1,
+                                       const float* b_ih1, const float* b_hh1, int T, int N, int I, int H, float* hseq0,
+                                       float* hseq1, void* save0, void* save1, size_t save_bytes, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    CallScope scope(stream);
+    FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
+    FSN_REQUIRE(x && w_ih0 && w_hh0 && b_ih0 && b_hh0 && w_ih1 && w_hh1 && b_ih1 && b_hh1 && hseq0 && hseq1 && save0 &&
+                    save1 && workspace,
+                "NULL pointer argument");
+    if (save_bytes < fsn_lstm_layer_save_bytes(T, N, H) || workspace_bytes < fsn_lstm2_train_workspace_bytes(T, N, I, H)) {
+        fsn_set_error("lstm2 forward (training): save / workspace buffer too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    if (!lstm2_train_on_chain(N, H)) {  // layer by layer
+        FSN_TRY(fsn_lstm_layer_forward(x, ldx, w_ih0, w_hh0, b_ih0, b_hh0, T, N, I, H, hseq0, save0, save_bytes, workspace,
+                                       workspace_bytes, stream));
+        return fsn_lstm_layer_forward(hseq0, H, w_ih1, w_hh1, b_ih1, b_hh1, T, N, H, H, hseq1, save1, save_bytes, workspace,
+                                      workspace_bytes, stream);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Ipad = fsn_round_up(I, 16);
+    Carver cv(workspace);
+    float* wih0_p = cv.take<float>((size_t)4 * H * Ipad);
+    float* whh0_p = cv.take<float>((size_t)4 * H * H);
+    float* wih1_p = whh0_p + (size_t)4 * H * H;
+    float* whh1_p = wih1_p + (size_t)4 * H * H;
+    cv.take<float>((size_t)2 * 4 * H * H);
+    float* b0 = cv.take<float>((size_t)2 * 4 * H);
+    float* b1 = b0 + 4 * H;
+    float* gx0 = cv.take<float>((size_t)T * N * 4 * H);
+    float* exchange = cv.take<float>(fsn_fb_chain_exchange_floats(T, N));
+    unsigned* flags = cv.take<unsigned>(fsn_fb_chain_flag_words());
+    FSN_TRY(fsn_launch_pack(w_ih0, wih0_p, 4 * H, I, 4 * H, Ipad, s));
+    FSN_TRY(fsn_launch_pack(w_hh0, whh0_p, 4 * H, H, 4 * H, H, s));
+    FSN_TRY(fsn_launch_pack(w_ih1, wih1_p, 4 * H, H, 4 * H, H, s));
+    FSN_TRY(fsn_launch_pack(w_hh1, whh1_p, 4 * H, H, 4 * H, H, s));
+    FSN_TRY(fsn_launch_bias_sum(b_ih0, b_hh0, b0, 4 * H, 4 * H, s));
+    FSN_TRY(fsn_launch_bias_sum(b_ih1, b_hh1, b1, 4 * H, 4 * H, s));
+    FsnGemmA a{};
+    a.kind = 0;
+    a.p0 = x;
+    a.ld = ldx;
+    FsnGemmC c{};
+    c.kind = 0;
+    c.p0 = gx0;
+    c.bias = b0;
+    FSN_TRY(fsn_launch_gemm(a, wih0_p, c, T * (N / 16), 4 * H / 16, Ipad / 16, s));
+    PersistLaunch gate(s);
+    return fsn_launch_fb_chain(gx0, whh0_p, wih1_p, whh1_p, b1, exchange, flags, hseq1, T, N, H, s, hseq0,
+                               static_cast<float*>(save0), static_cast<float*>(save1));
+}
+
 // Two stacked LSTM layers of equal width in inference mode as one wavefront (layer 1 at step t next to layer 0
 // at step t + 1: T + 1 dependent launches instead of 2 T).  For the latency-bound regime - few rows - where
 // SequenceModel blocks of the sibling models live (Improved FullSubNet's band sections: B x {20, 25, 6, 4} rows).

@@ -158,7 +158,8 @@ bool fsn_fb_chain_supported(int H, int Npad);
 size_t fsn_fb_chain_exchange_floats(int Tp, int Npad);
 size_t fsn_fb_chain_flag_words();
 int fsn_launch_fb_chain(const float* gx0, const float* whh0_p, const float* wih1_p, const float* whh1_p, const float* b1,
-                        float* exchange, unsigned* flags, float* hseq1, int Tp, int Npad, int H, hipStream_t s);
+                        float* exchange, unsigned* flags, float* hseq1, int Tp, int Npad, int H, hipStream_t s,
+                        float* hseq0 = nullptr, float* save0 = nullptr, float* save1 = nullptr);
 
 // lstm_train_kernels.hip (training step: BPTT pieces)
 // C [M][Nc] = sum_k A[k][M]^T B[k][Nc]   (both operands row-major over k; split-K, deterministic 2-pass)

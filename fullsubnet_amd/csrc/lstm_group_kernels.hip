@@ -32,6 +32,7 @@ constexpr int GM = 8;            // members per cluster and layer
 constexpr int GU = GH / 16 / GM; // unit groups per member (3)
 constexpr int GROWS = 64;        // rows per cluster
 constexpr int GD0 = 4;           // depth of layer 0's exchange buffer: layer 0 may run GD0 - 2 steps ahead of layer 1
+constexpr int GFS = 32;          // words between the flag groups of (cluster, layer): one 128-byte line each
 constexpr unsigned kSpinLimit = 1u << 21;
 
 struct GrpArgs {
@@ -43,7 +44,7 @@ struct GrpArgs {
     const float* bias1;    // b_ih + b_hh of layer 1 [4H]
     float* hx0;            // [clusters][GD0][64][H]   h of layer 0
     float* hx1;            // [clusters][2][64][H]     h of layer 1
-    unsigned* flags;       // [clusters][2][GM]: steps published so far by (layer, member)
+    unsigned* flags;       // [clusters][2][GFS]: steps published so far by (layer, member), GM words used per group
     unsigned* status;      // 0 = fine
     FsnRecFc fc;           // output layer; fc.N = valid local rows
     int Tp;
@@ -84,8 +85,8 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int me
     const long row_l = (long)cluster * GROWS + wave * 16 + lr;  // this lane's A-operand row (local to the launch)
     float* hx0 = a.hx0 + (size_t)cluster * GD0 * GROWS * GH;
     float* hx1 = a.hx1 + (size_t)cluster * 2 * GROWS * GH;
-    unsigned* fl0 = a.flags + ((size_t)cluster * 2 + 0) * GM;
-    unsigned* fl1 = a.flags + ((size_t)cluster * 2 + 1) * GM;
+    unsigned* fl0 = a.flags + ((size_t)cluster * 2 + 0) * GFS;
+    unsigned* fl1 = a.flags + ((size_t)cluster * 2 + 1) * GFS;
     // this lane's A fragment inside a [64][H] tile of the exchange buffers (byte offset), read with sc1 buffer loads: the
     // partners stored write-through (sc1), so an sc1 load - never served by this CU's L1 - needs no acquire fence
     const unsigned a_off = (unsigned)(((wave * 16 + lr) * GH + 4 * lq) * 4);
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void 
 }  // namespace
 
 size_t fsn_lstm2_group_exchange_floats(int clusters) { return (size_t)clusters * (GD0 + 2) * GROWS * GH; }
-size_t fsn_lstm2_group_flag_words(int clusters) { return (size_t)clusters * 2 * GM + 16; }
+size_t fsn_lstm2_group_flag_words(int clusters) { return (size_t)clusters * 2 * GFS + 16; }
 
 // Clusters of 64 rows that run on the group kernel for `tiles` 16-row tiles: at most one cluster per eight CUs (its 16
 // workgroups, two per CU, must all be resident at once); what is left runs step by step beside it.
@@ -406,7 +407,7 @@ int fsn_launch_lstm2_group(const FsnSbInput* xin, const float* whh0_p, const flo
     a.hx0 = exchange;
     a.hx1 = exchange + (size_t)clusters * GD0 * GROWS * GH;
     a.flags = flags;
-    a.status = flags + (size_t)clusters * 2 * GM;
+    a.status = flags + (size_t)clusters * 2 * GFS;
     a.fc = *fc;
     a.Tp = Tp;
     hipLaunchKernelGGL(lstm2_group_kernel<0>, dim3((unsigned)clusters * GM * 2), dim3(256), 0, s, a);

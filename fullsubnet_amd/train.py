@@ -64,6 +64,67 @@ class LstmLayerFunction(torch.autograd.Function):
         return (dx[:, :N, :I] if need_dx else None), dw_ih, dw_hh, db, db.clone()
 
 
+class Lstm2Function(torch.autograd.Function):
+    """nn.LSTM(num_layers=2) (unidirectional, h0 = c0 = 0, both layers H wide) on time-major x [T, N, I] -> [T, N, H]:
+    fsn_lstm2_forward_train (for the full-band shape - H = 512, up to 64 rows - ONE persistent launch for both layers
+    and all steps) and two fsn_lstm_layer_backward calls."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1):
+        L = _lib.lib()
+        T, N, I = x.shape
+        H = w_hh0.shape[1]
+        Np, Ip = (N + 15) // 16 * 16, (I + 15) // 16 * 16
+        xp = x
+        if Np != N or Ip != I or not x.is_contiguous():
+            xp = torch.zeros((T, Np, Ip), dtype=torch.float32, device=x.device)
+            xp[:, :N, :I] = x
+        ws_ = [t.detach().contiguous() for t in (w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1)]
+        hseq0 = torch.empty((T, Np, H), dtype=torch.float32, device=x.device)
+        hseq1 = torch.empty((T, Np, H), dtype=torch.float32, device=x.device)
+        nsave = L.fsn_lstm_layer_save_bytes(T, Np, H)
+        save0, save1 = _lib.workspace(nsave, x.device), _lib.workspace(nsave, x.device)
+        ws = _lib.workspace(L.fsn_lstm2_train_workspace_bytes(T, Np, I, H), x.device)
+        _lib.check(L.fsn_lstm2_forward_train(
+            _lib.dev_ptr(xp, "x"), Ip, *[_lib.dev_ptr(t) for t in ws_], T, Np, I, H, _lib.dev_ptr(hseq0),
+            _lib.dev_ptr(hseq1), save0.data_ptr(), save1.data_ptr(), nsave, ws.data_ptr(), ws.numel(),
+            _lib.stream_ptr(x.device)))
+        ctx.save_for_backward(xp, ws_[0], ws_[1], ws_[4], ws_[5], hseq0, hseq1, save0, save1)
+        ctx.dims = (T, N, I, H, Np, Ip)
+        return hseq1[:, :N]
+
+    @staticmethod
+    def backward(ctx, dh):
+        L = _lib.lib()
+        xp, w_ih0, w_hh0, w_ih1, w_hh1, hseq0, hseq1, save0, save1 = ctx.saved_tensors
+        T, N, I, H, Np, Ip = ctx.dims
+        dev = dh.device
+        dhp = dh
+        if Np != N or not dh.is_contiguous():
+            dhp = torch.zeros((T, Np, H), dtype=torch.float32, device=dev)
+            dhp[:, :N] = dh
+        stream = _lib.stream_ptr(dev)
+        # layer 1: x = hseq0; its dx is d loss / d hseq0
+        dh0 = torch.empty((T, Np, H), dtype=torch.float32, device=dev)
+        dw_ih1, dw_hh1 = torch.empty_like(w_ih1), torch.empty_like(w_hh1)
+        db1 = torch.empty((4 * H,), dtype=torch.float32, device=dev)
+        ws = _lib.workspace(max(L.fsn_lstm_layer_bwd_workspace_bytes(T, Np, H, H),
+                                L.fsn_lstm_layer_bwd_workspace_bytes(T, Np, I, H)), dev)
+        _lib.check(L.fsn_lstm_layer_backward(
+            _lib.dev_ptr(dhp, "dh"), _lib.dev_ptr(hseq0), H, _lib.dev_ptr(w_ih1), _lib.dev_ptr(w_hh1), T, Np, H, H,
+            _lib.dev_ptr(hseq1), save1.data_ptr(), _lib.dev_ptr(dh0), H, _lib.dev_ptr(dw_ih1), _lib.dev_ptr(dw_hh1),
+            _lib.dev_ptr(db1), ws.data_ptr(), ws.numel(), stream))
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty((T, Np, Ip), dtype=torch.float32, device=dev) if need_dx else None
+        dw_ih0, dw_hh0 = torch.empty_like(w_ih0), torch.empty_like(w_hh0)
+        db0 = torch.empty((4 * H,), dtype=torch.float32, device=dev)
+        _lib.check(L.fsn_lstm_layer_backward(
+            _lib.dev_ptr(dh0), _lib.dev_ptr(xp), Ip, _lib.dev_ptr(w_ih0), _lib.dev_ptr(w_hh0), T, Np, I, H,
+            _lib.dev_ptr(hseq0), save0.data_ptr(), _lib.dev_ptr(dx, allow_none=True), Ip, _lib.dev_ptr(dw_ih0),
+            _lib.dev_ptr(dw_hh0), _lib.dev_ptr(db0), ws.data_ptr(), ws.numel(), stream))
+        return ((dx[:, :N, :I] if need_dx else None), dw_ih0, dw_hh0, db0, db0.clone(), dw_ih1, dw_hh1, db1, db1.clone())
+
+
 class GruLayerFunction(torch.autograd.Function):
     """One nn.GRU layer (unidirectional, h0 = 0) on time-major input x [T, N, I] -> [T, N, H]
     (fsn_gru_layer_forward with saved r, z, n, hn + fsn_gru_layer_backward)."""
@@ -165,6 +226,9 @@ class LinearFunction(torch.autograd.Function):
 def lstm_stack(x_tn, lstm):
     """Two stacked layers of an nn.LSTM parameter container on time-major x [T, N, I]."""
     h = x_tn
+    if lstm.num_layers == 2 and lstm.weight_hh_l0.shape == lstm.weight_hh_l1.shape:
+        return Lstm2Function.apply(h, *[getattr(lstm, f"{n}_l{k}") for k in (0, 1)
+                                        for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")])
     for k in range(lstm.num_layers):
         h = LstmLayerFunction.apply(h, getattr(lstm, f"weight_ih_l{k}"), getattr(lstm, f"weight_hh_l{k}"),
                                     getattr(lstm, f"bias_ih_l{k}"), getattr(lstm, f"bias_hh_l{k}"))

@@ -168,6 +168,16 @@ size_t fsn_lstm_layer_fwd_workspace_bytes(int T, int N, int I, int H);
 int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
                            const float* b_hh, int T, int N, int I, int H, float* hseq, void* save,
                            size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream);
+/* Two stacked layers of equal width H (nn.LSTM(num_layers = 2), sequence_model.py:52-58) forward with saved
+ * activations: the result of two fsn_lstm_layer_forward calls (hseq0 / save0 and hseq1 / save1 in that entry's
+ * layouts, each save buffer >= fsn_lstm_layer_save_bytes(T, N, H)), ready for two fsn_lstm_layer_backward calls.
+ * The full-band shape (H = 512, N <= 64) runs as ONE persistent launch for both layers and all steps
+ * (fb_chain_kernel) instead of 2 T launches; other shapes run layer by layer. */
+size_t fsn_lstm2_train_workspace_bytes(int T, int N, int I, int H);
+int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_ih0, const float* w_hh0, const float* b_ih0,
+                            const float* b_hh0, const float* w_ih1, const float* w_hh1, const float* b_ih1,
+                            const float* b_hh1, int T, int N, int I, int H, float* hseq0, float* hseq1, void* save0,
+                            void* save1, size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream);
 /* Two stacked LSTM layers in inference mode, advanced as a wavefront (layer 1 at step t next to layer 0 at
  * step t + 1): T + 1 dependent launches instead of 2 T.  Either nn.LSTM(num_layers = 2) of one SequenceModel
  * (H1 == H0, sequence_model.py:52-58) or two consecutive single-layer blocks of different widths (the
