@@ -1437,9 +1437,27 @@ extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_i
 // fsn_lstm_layer_forward calls; what it adds is the persistent kernels: the full-band shape (H = 512, up to 64 rows)
 // runs on fb_chain_kernel, one launch for both layers and all steps instead of 2 T.
 static bool lstm2_train_on_chain(int N, int H) { return fsn_fb_chain_supported(H, N); }
+// The sub-band shape (H = 384, up to 32 input columns, 96+ row tiles that fill whole 64-row clusters up to a few
+// left-over tiles): clusters on the group kernel, 0 = not this shape.
+static int lstm2_train_group_clusters(int T, int N, int I, int H) {
+    if (H != 384 || fsn_round_up(I, 16) != 32 || N / 16 < kWavefrontBelowTiles) return 0;
+    if ((size_t)T * N * H * sizeof(float) > 0xffffffffull) return 0;
+    const int c = fsn_lstm2_group_clusters(N / 16);
+    return N / 16 - 4 * c <= 8 ? c : 0;
+}
 extern "C" size_t fsn_lstm2_train_workspace_bytes(int T, int N, int I, int H) {
     const int Ipad = fsn_round_up(I, 16);
     Carver cv(nullptr);
+    if (const int clusters = lstm2_train_group_clusters(T, N, I, H)) {
+        const size_t left = (size_t)(N / 16 - 4 * clusters) * 16;
+        cv.take<float>((size_t)4 * H * Ipad + (size_t)3 * 4 * H * H);
+        cv.take<float>((size_t)2 * 4 * H);
+        cv.take<unsigned>(fsn_lstm2_group_flag_words(clusters));
+        cv.take<float>((size_t)T * left * Ipad);
+        cv.take<float>((size_t)T * left * H);
+        cv.take<float>((size_t)T * left * 4 * H);
+        return fsn_round_up_sz(cv.off, 256);
+    }
     if (lstm2_train_on_chain(N, H)) {
         cv.take<float>((size_t)4 * H * Ipad);
         cv.take<float>((size_t)3 * 4 * H * H);
@@ -1466,14 +1484,89 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
         fsn_set_error("lstm2 forward (training): save / workspace buffer too small");
         return FSN_ERR_WORKSPACE;
     }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Ipad = fsn_round_up(I, 16);
+    if (const int clusters = lstm2_train_group_clusters(T, N, I, H)) {
+        // whole 64-row clusters on the group kernel (both layers, one launch); the few rows that do not fill a cluster
+        // step by step on the auxiliary stream beside it, straight into the same output buffers
+        const int left_tiles = N / 16 - 4 * clusters, left = left_tiles * 16, row0 = 64 * clusters;
+        FSN_REQUIRE(ldx == Ipad, "lstm2 forward (training): this shape needs x rows of exactly %d columns (got %ld)", Ipad, ldx);
+        Carver cv(workspace);
+        float* wih0_p = cv.take<float>((size_t)4 * H * Ipad + (size_t)3 * 4 * H * H);
+        float* whh0_p = wih0_p + (size_t)4 * H * Ipad;
+        float* wih1_p = whh0_p + (size_t)4 * H * H;
+        float* whh1_p = wih1_p + (size_t)4 * H * H;
+        float* b0 = cv.take<float>((size_t)2 * 4 * H);
+        float* b1 = b0 + 4 * H;
+        unsigned* flags = cv.take<unsigned>(fsn_lstm2_group_flag_words(clusters));
+        float* x_left = cv.take<float>((size_t)T * left * Ipad);
+        float* h0_left = cv.take<float>((size_t)T * left * H);
+        float* gx_left = cv.take<float>((size_t)T * left * 4 * H);
+        FSN_TRY(fsn_launch_pack(w_ih0, wih0_p, 4 * H, I, 4 * H, Ipad, s));
+        FSN_TRY(fsn_launch_pack(w_hh0, whh0_p, 4 * H, H, 4 * H, H, s));
+        FSN_TRY(fsn_launch_pack(w_ih1, wih1_p, 4 * H, H, 4 * H, H, s));
+        FSN_TRY(fsn_launch_pack(w_hh1, whh1_p, 4 * H, H, 4 * H, H, s));
+        FSN_TRY(fsn_launch_bias_sum(b_ih0, b_hh0, b0, 4 * H, 4 * H, s));
+        FSN_TRY(fsn_launch_bias_sum(b_ih1, b_hh1, b1, 4 * H, 4 * H, s));
+        float* sv0 = static_cast<float*>(save0);
+        float* sv1 = static_cast<float*>(save1);
+        StreamCtx* cx = cur_ctx();
+        if (left > 0) {
+            FSN_TRY(aux_init(cx));
+            if (hipEventRecord(cx->ev_fork, s) != hipSuccess || hipStreamWaitEvent(cx->aux, cx->ev_fork, 0) != hipSuccess) {
+                fsn_set_error("aux stream fork failed");
+                return FSN_ERR_LAUNCH;
+            }
+        }
+        {
+            PersistLaunch gate(s);
+            FSN_TRY(fsn_launch_lstm2_group_train(x, ldx, N, wih0_p, whh0_p, wih1_p, whh1_p, b0, b1, hseq0, hseq1, sv0, sv1,
+                                                 flags, T, clusters, H, s));
+        }
+        if (left > 0) {
+            hipStream_t as = cx->aux;
+            const size_t stepH = (size_t)N * H, stepG = (size_t)N * 4 * H;
+            for (int layer = 0; layer < 2; ++layer) {
+                // the left-over rows of this layer's input as a compact [T][left][K] matrix -> projection tiles
+                const float* src = layer ? hseq0 + (size_t)row0 * H : x + (size_t)row0 * ldx;
+                const size_t src_ld = layer ? (size_t)H : (size_t)ldx, K = layer ? (size_t)H : (size_t)Ipad;
+                float* dst = layer ? h0_left : x_left;
+                if (hipMemcpy2DAsync(dst, left * K * sizeof(float), src, (size_t)N * src_ld * sizeof(float),
+                                     left * src_ld * sizeof(float), T, hipMemcpyDeviceToDevice, as) != hipSuccess) {
+                    fsn_set_error("lstm2 forward (training): cannot gather the left-over rows");
+                    return FSN_ERR_LAUNCH;
+                }
+                FsnGemmA a{};
+                a.kind = 0;
+                a.p0 = dst;
+                a.ld = (long)K;
+                FsnGemmC c{};
+                c.kind = 0;
+                c.p0 = gx_left;
+                c.bias = layer ? b1 : b0;
+                FSN_TRY(fsn_launch_gemm(a, layer ? wih1_p : wih0_p, c, T * left_tiles, 4 * H / 16, (int)K / 16, as));
+                float* hs = (layer ? hseq1 : hseq0) + (size_t)row0 * H;
+                float* sv = layer ? sv1 : sv0;
+                float* gates = sv + (size_t)row0 * 4 * H;
+                float* cseq = sv + (size_t)T * N * 4 * H + (size_t)row0 * H;
+                for (int t = 0; t < T; ++t)
+                    FSN_TRY(fsn_launch_lstm_step_train(gx_left, layer ? whh1_p : whh0_p, t ? hs + (t - 1) * stepH : hs,
+                                                       hs + t * stepH, t ? cseq + (t - 1) * stepH : cseq, cseq + t * stepH,
+                                                       gates + t * stepG, (long)t * left_tiles, left_tiles, H, t == 0, as));
+            }
+            if (hipEventRecord(cx->ev_join, cx->aux) != hipSuccess || hipStreamWaitEvent(s, cx->ev_join, 0) != hipSuccess) {
+                fsn_set_error("aux stream join failed");
+                return FSN_ERR_LAUNCH;
+            }
+        }
+        return FSN_OK;
+    }
     if (!lstm2_train_on_chain(N, H)) {  // layer by layer
         FSN_TRY(fsn_lstm_layer_forward(x, ldx, w_ih0, w_hh0, b_ih0, b_hh0, T, N, I, H, hseq0, save0, save_bytes, workspace,
                                        workspace_bytes, stream));
         return fsn_lstm_layer_forward(hseq0, H, w_ih1, w_hh1, b_ih1, b_hh1, T, N, H, H, hseq1, save1, save_bytes, workspace,
                                       workspace_bytes, stream);
     }
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int Ipad = fsn_round_up(I, 16);
     Carver cv(workspace);
     float* wih0_p = cv.take<float>((size_t)4 * H * Ipad);
     float* whh0_p = cv.take<float>((size_t)4 * H * H);

@@ -153,6 +153,11 @@ int fsn_launch_bias_frag(const float* bias, float* frag, int n, hipStream_t s);
 
 int fsn_launch_zero_words(unsigned* p, size_t n, hipStream_t s);  // elementwise_kernels.hip
 
+int fsn_launch_lstm2_group_train(const float* x, long x_ld, int Nrows, const float* wih0_p, const float* whh0_p,
+                                 const float* wih1_p, const float* whh1_p, const float* bias0, const float* bias1,
+                                 float* hseq0, float* hseq1, float* save0, float* save1, unsigned* flags, int Tp,
+                                 int clusters, int H, hipStream_t s);  // lstm_group_kernels.hip
+
 // fb_chain_kernels.hip: the full-band model's two LSTM layers over all frames as one persistent launch
 bool fsn_fb_chain_supported(int H, int Npad);
 size_t fsn_fb_chain_exchange_floats(int Tp, int Npad);

@@ -48,6 +48,11 @@ struct GrpArgs {
     unsigned* status;      // 0 = fine
     FsnRecFc fc;           // output layer; fc.N = valid local rows
     int Tp;
+    // training form (TRAIN): the exchange buffers ARE the hidden sequences - hx0 / hx1 = hseq0 / hseq1 [Tp][Nrows][H],
+    // a cluster's tile of step t at rows 64 c .. of step t (nothing is reused) - and every step keeps the activated
+    // gates [Tp][Nrows][4H] and the cell state [Tp][Nrows][H] (the layouts of fsn_lstm_layer_forward)
+    float *gates0, *cseq0, *gates1, *cseq1;
+    int Nrows;
 };
 
 __device__ __forceinline__ void store_sc1(float* p, float v) {
@@ -77,14 +82,18 @@ __device__ __forceinline__ bool grp_poll(unsigned* flags8, unsigned epoch, unsig
 // ABL: experiment knob of tools/probe_group.hip (0 in the library; any bit set gives WRONG results): 1 no acquire
 // fence, 2 no flag polling, 4 plain instead of write-through stores, 8 no gate non-linearities, 16 no output layer,
 // 32 A fragments not loaded (a constant instead).
-template <int LAYER, int ABL>
+template <int LAYER, int ABL, bool TRAIN>
 __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int member, f32x4 (*bsh)[GU * 4][64]) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const int Tp = a.Tp;
     const long row_l = (long)cluster * GROWS + wave * 16 + lr;  // this lane's A-operand row (local to the launch)
-    float* hx0 = a.hx0 + (size_t)cluster * GD0 * GROWS * GH;
-    float* hx1 = a.hx1 + (size_t)cluster * 2 * GROWS * GH;
+    float* hx0 = a.hx0 + (TRAIN ? (size_t)cluster * GROWS * GH : (size_t)cluster * GD0 * GROWS * GH);
+    float* hx1 = a.hx1 + (TRAIN ? (size_t)cluster * GROWS * GH : (size_t)cluster * 2 * GROWS * GH);
+    // byte offset of the tile that holds h0_t / h1_t inside hx0 / hx1
+    const unsigned step_bytes = TRAIN ? (unsigned)a.Nrows * GH * 4u : 0u;
+    auto slot0 = [&](int t) { return TRAIN ? (unsigned)t * step_bytes : (unsigned)((t % GD0) * GROWS * GH * 4); };
+    auto slot1 = [&](int t) { return TRAIN ? (unsigned)t * step_bytes : (unsigned)((t & 1) * GROWS * GH * 4); };
     unsigned* fl0 = a.flags + ((size_t)cluster * 2 + 0) * GFS;
     unsigned* fl1 = a.flags + ((size_t)cluster * 2 + 1) * GFS;
     // this lane's A fragment inside a [64][H] tile of the exchange buffers (byte offset), read with sc1 buffer loads: the
@@ -208,7 +217,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int me
         if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     // cell update of this wave's 16 rows x 48 units; h_t slice -> exchange buffer
-    auto cell = [&](f32x4 (&acc)[GU][4], float* hdst) {
+    auto cell = [&](f32x4 (&acc)[GU][4], float* hdst, float* gates_t, float* cseq_t) {
 #pragma unroll
         for (int u = 0; u < GU; ++u)
 #pragma unroll
@@ -226,6 +235,16 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int me
                 const float hv = (ABL & 8) ? og * cn : og * tanh_fast(cn);
                 if (ABL & 4) *hp = hv;
                 else store_sc1(hp, hv);
+                if (TRAIN) {  // rows of this cluster inside step t's [Nrows][...] slabs
+                    const size_t row = (size_t)cluster * GROWS + wave * 16 + 4 * lq + i;
+                    const int unit = (member * GU + u) * 16 + lr;
+                    float* gp = gates_t + row * (4 * GH) + unit;
+                    gp[0] = ig;
+                    gp[GH] = fg;
+                    gp[2 * GH] = gg;
+                    gp[3 * GH] = og;
+                    cseq_t[row * GH + unit] = cn;
+                }
             }
     };
 
@@ -234,8 +253,13 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int me
             // the layer-0 input of this lane's row at frame t (two A fragments: columns 4 lq .. and 16 + 4 lq ..):
             // requested now, divided after the wait below
             float raw[8];
-            const float den = row_ok ? x.den[x.den_mode ? (long)t * x.den_stride + ng : (long)xb] : 1.f;
-            {
+            const float den = (row_ok && !TRAIN) ? x.den[x.den_mode ? (long)t * x.den_stride + ng : (long)xb] : 1.f;
+            if (TRAIN) {  // plain row-major input [Tp][x_step][x_ld], 32 columns (zero-padded by the caller)
+                const float* xr = x.x_rows + ((long)t * x.x_step + (row_ok ? row_l : 0)) * x.x_ld + 4 * lq;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(xr), v1 = *reinterpret_cast<const f32x4*>(xr + 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) raw[e] = v0[e], raw[4 + e] = v1[e];
+            } else {
                 const long fo = ((long)xb * x.Tp + t) * x.FP;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -253,7 +277,8 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int me
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int cc = (e >> 2) * 16 + 4 * lq + (e & 3);
-                xa[e >> 2][e & 3] = (row_ok && cc <= 2 * x.nb + 1) ? raw[e] / den : 0.f;
+                if (TRAIN) xa[e >> 2][e & 3] = row_ok ? raw[e] : 0.f;
+                else xa[e >> 2][e & 3] = (row_ok && cc <= 2 * x.nb + 1) ? raw[e] / den : 0.f;
             }
             f32x4 acc[GU][4];
 #pragma unroll
@@ -261,12 +286,12 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int me
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[u][g] = f32x4{bias[u][g], bias[u][g], bias[u][g], bias[u][g]};
             const unsigned ring = t >= GD0 ? peek(fl1) : 0xffffffffu;
-            kloop(acc, xa, 0, 0, a.o_wih0, 2, 2, 0, (unsigned)(((t + GD0 - 1) % GD0) * GROWS * GH * 4), a.o_whh0, GKC,
-                  t > 0 ? GKC : 0);
+            kloop(acc, xa, 0, 0, a.o_wih0, 2, 2, 0, t > 0 ? slot0(t - 1) : 0u, a.o_whh0, GKC, t > 0 ? GKC : 0);
             // slot t % GD0 still holds h0_{t-GD0}: layer 1 must have finished its step t - GD0 (it reads that slot
             // there) - all eight layer-1 members, i.e. they have published step t - GD0 + 1
             if (t >= GD0) wait_peeked(ring, fl1, (unsigned)(t - GD0 + 1));
-            cell(acc, hx0 + (size_t)(t % GD0) * GROWS * GH);
+            cell(acc, reinterpret_cast<float*>(reinterpret_cast<char*>(hx0) + slot0(t)),
+                 TRAIN ? a.gates0 + (size_t)t * a.Nrows * 4 * GH : nullptr, TRAIN ? a.cseq0 + (size_t)t * a.Nrows * GH : nullptr);
             publish(fl0 + member, (unsigned)t + 1);
         }
     } else {
@@ -275,7 +300,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int me
         const int d = threadIdx.x >> 4, p = threadIdx.x & 15;
         const int frow = member * 8 + (d >> 1), fcc = d & 1;
         unsigned seen0 = peek(fl0);
-        for (int s = 0; s <= Tp; ++s) {
+        for (int s = 0; s <= (TRAIN ? Tp - 1 : Tp); ++s) {
             // Step s: x_s W_ih^T first - it only needs h0_s, which layer 0 published long ago - so that the partners'
             // h1_{s-1}, published a moment ago, has a whole half K loop to arrive before anyone waits for it.  The extra
             // iteration s = Tp only computes the output layer of the last step.
@@ -288,7 +313,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int me
                 for (int u = 0; u < GU; ++u)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) acc[u][g] = f32x4{bias[u][g], bias[u][g], bias[u][g], bias[u][g]};
-                kloop(acc, nullptr, 0, (unsigned)((s % GD0) * GROWS * GH * 4), a.o_wih1, GKC, GKC, 0, 0, 0, 0, 0);
+                kloop(acc, nullptr, 0, slot0(s), a.o_wih1, GKC, GKC, 0, 0, 0, 0, 0);
             } else {
                 seen1 = peek(fl1);
             }
@@ -297,7 +322,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int me
                 // Output layer (nn.Linear(384, 2)) of step s - 1 for rows 8 m .. 8 m + 7 of the cluster, from h1_{s-1} as
                 // it has just been gathered: 16 dot products x 16 threads (~1 us, covered by the layer-0 workgroup
                 // that shares the CU)
-                if (!(ABL & 16)) {
+                if (!(ABL & 16) && !TRAIN) {
                     const unsigned hoff = (unsigned)((((s - 1) & 1) * GROWS * GH + frow * GH + p * 24) * 4);
                     f32x4 hv[6], fw[6];
 #pragma unroll
@@ -326,17 +351,18 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int me
             }
             seen0 = peek(fl0);  // for the next step: layer 0 is ahead, this usually shows s + 2 already
             if (s > 0 && s < Tp)
-                kloop(acc, nullptr, 1, (unsigned)((((s + 1) & 1) * GROWS * GH) * 4), a.o_whh1, GKC, GKC, 0, 0, 0, 0, 0);
+                kloop(acc, nullptr, 1, slot1(s - 1), a.o_whh1, GKC, GKC, 0, 0, 0, 0, 0);
             if (s < Tp) {
                 // slot s & 1 held h1_{s-2}: read by every member in step s - 1, which they have left (flag1 >= s above)
-                cell(acc, hx1 + (size_t)(s & 1) * GROWS * GH);
+                cell(acc, reinterpret_cast<float*>(reinterpret_cast<char*>(hx1) + slot1(s)),
+                     TRAIN ? a.gates1 + (size_t)s * a.Nrows * 4 * GH : nullptr, TRAIN ? a.cseq1 + (size_t)s * a.Nrows * GH : nullptr);
                 publish(fl1 + member, (unsigned)s + 1);
             }
         }
     }
 }
 
-template <int ABL>
+template <int ABL, bool TRAIN = false>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void lstm2_group_kernel(const GrpArgs a) {
     // weight fragments of one K chunk, shared by the four waves: two stages x 12 fragments x 1 KB
     __shared__ f32x4 bsh[2][GU * 4][64];
@@ -360,8 +386,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void 
     // Layer 1 is the longer dependent chain (K = 768 per step against 416) and layer 0 is throttled to stay within
     // GD0 - 2 steps of it: layer 1's waves issue first, layer 0's fill the gaps.
     if (layer == 1 && !(ABL & 64)) __builtin_amdgcn_s_setprio(2);
-    if (layer == 0) group_body<0, ABL>(a, cluster, member, bsh);
-    else group_body<1, ABL>(a, cluster, member, bsh);
+    if (layer == 0) group_body<0, ABL, TRAIN>(a, cluster, member, bsh);
+    else group_body<1, ABL, TRAIN>(a, cluster, member, bsh);
 }
 
 }  // namespace
@@ -410,6 +436,53 @@ int fsn_launch_lstm2_group(const FsnSbInput* xin, const float* whh0_p, const flo
     a.status = flags + (size_t)clusters * 2 * GFS;
     a.fc = *fc;
     a.Tp = Tp;
-    hipLaunchKernelGGL(lstm2_group_kernel<0>, dim3((unsigned)clusters * GM * 2), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((lstm2_group_kernel<0, false>), dim3((unsigned)clusters * GM * 2), dim3(256), 0, s, a);
     return fsn_check_launch("lstm2_group_kernel");
+}
+
+// Training form: rows [0, 64 clusters) of x [Tp][Nrows][x_ld] (32 zero-padded input columns) through both layers with
+// saved activations; hseq0 / hseq1 [Tp][Nrows][H], save = gates [Tp][Nrows][4H] followed by the cell sequence
+// [Tp][Nrows][H] (fsn_lstm_layer_forward's layouts).  bias0 / bias1 = b_ih + b_hh.
+int fsn_launch_lstm2_group_train(const float* x, long x_ld, int Nrows, const float* wih0_p, const float* whh0_p,
+                                 const float* wih1_p, const float* whh1_p, const float* bias0, const float* bias1,
+                                 float* hseq0, float* hseq1, float* save0, float* save1, unsigned* flags, int Tp,
+                                 int clusters, int H, hipStream_t s) {
+    if (H != GH || clusters < 1 || (long)clusters * GROWS > Nrows || (size_t)Tp * Nrows * GH * 4 > 0xffffffffull) {
+        fsn_set_error("lstm2_group (training): H = 384, clusters * 64 <= rows, hidden sequence below 4 GB");
+        return FSN_ERR_ARG;
+    }
+    if (fsn_launch_zero_words(flags, fsn_lstm2_group_flag_words(clusters), s) != FSN_OK) return FSN_ERR_LAUNCH;
+    const float* lo = wih0_p;
+    for (const float* q : {whh0_p, wih1_p, whh1_p}) lo = q < lo ? q : lo;
+    for (const float* q : {wih0_p, whh0_p, wih1_p, whh1_p})
+        if (q - lo > 0x1fffffffL) {
+            fsn_set_error("lstm2_group: the packed weight matrices must share one buffer");
+            return FSN_ERR_ARG;
+        }
+    GrpArgs a{};
+    a.xin.x_rows = x;
+    a.xin.x_ld = x_ld;
+    a.xin.x_step = Nrows;
+    a.xin.N = clusters * GROWS;
+    a.xin.F = 1;
+    a.xin.kin_chunks = 2;
+    a.xin.bias = bias0;
+    a.wbase = lo;
+    a.o_wih0 = (unsigned)(wih0_p - lo);
+    a.o_whh0 = (unsigned)(whh0_p - lo);
+    a.o_wih1 = (unsigned)(wih1_p - lo);
+    a.o_whh1 = (unsigned)(whh1_p - lo);
+    a.bias1 = bias1;
+    a.hx0 = hseq0;
+    a.hx1 = hseq1;
+    a.flags = flags;
+    a.status = flags + (size_t)clusters * 2 * GFS;
+    a.Tp = Tp;
+    a.gates0 = save0;
+    a.cseq0 = save0 + (size_t)Tp * Nrows * 4 * GH;
+    a.gates1 = save1;
+    a.cseq1 = save1 + (size_t)Tp * Nrows * 4 * GH;
+    a.Nrows = Nrows;
+    hipLaunchKernelGGL((lstm2_group_kernel<0, true>), dim3((unsigned)clusters * GM * 2), dim3(256), 0, s, a);
+    return fsn_check_launch("lstm2_group_kernel (training)");
 }
