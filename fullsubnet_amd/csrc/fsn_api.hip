@@ -1441,7 +1441,7 @@ static bool lstm2_train_on_chain(int N, int H) { return fsn_fb_chain_supported(H
 // left-over tiles): clusters on the group kernel, 0 = not this shape.
 static int lstm2_train_group_clusters(int T, int N, int I, int H) {
     if (H != 384 || fsn_round_up(I, 16) != 32 || N / 16 < kWavefrontBelowTiles) return 0;
-    if ((size_t)T * N * H * sizeof(float) > 0xffffffffull) return 0;
+    if ((size_t)T * N * H * sizeof(float) > 0x7fffffffull) return 0;  // the reach of a buffer resource's offsets
     const int c = fsn_lstm2_group_clusters(N / 16);
     return N / 16 - 4 * c <= 8 ? c : 0;
 }
@@ -1808,6 +1808,165 @@ extern "C" int fsn_lstm_layer_backward(const float* dh, const float* x, long ldx
     if (T > 1) {
         FSN_TRY(fsn_launch_gemm_tn(dgates + (size_t)N * G, G, hseq, H, dw_hh, H, G, H, (long)(T - 1) * N, scratch, s));
     } else if (hipMemsetAsync(dw_hh, 0, (size_t)G * H * sizeof(float), s) != hipSuccess) {
+        fsn_set_error("memset failed");
+        return FSN_ERR_LAUNCH;
+    }
+    return FSN_OK;
+}
+
+// ---- training: backward of two stacked layers (the counterpart of fsn_lstm2_forward_train) ------------------------
+// Two fsn_lstm_layer_backward calls in one; the sub-band shape runs its BPTT - both layers, all steps, the
+// layer-to-layer dX included - as ONE persistent launch (lstm_group_bptt_kernels.hip).
+static int lstm2_bptt_group_clusters(int T, int N, int I, int H) {
+    if (H != 384 || N / 16 < kWavefrontBelowTiles) return 0;
+    const int c = fsn_lstm2_group_clusters(N / 16);
+    (void)I;
+    return N / 16 - 4 * c <= 8 ? c : 0;
+}
+extern "C" size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H) {
+    const int Ipad = fsn_round_up(I, 16), G = 4 * H;
+    const size_t l1 = fsn_lstm_layer_bwd_workspace_bytes(T, N, H, H), l0 = fsn_lstm_layer_bwd_workspace_bytes(T, N, I, H);
+    Carver cv(nullptr);
+    if (const int clusters = lstm2_bptt_group_clusters(T, N, I, H)) {
+        const size_t left = (size_t)(N / 16 - 4 * clusters) * 16;
+        cv.take<float>((size_t)3 * H * G + (size_t)Ipad * G);  // W_hh1^T, W_ih1^T, W_hh0^T, W_ih0^T fragments
+        cv.take<float>((size_t)2 * T * N * G);                 // dgates of both layers
+        cv.take<unsigned>(fsn_lstm2_group_bptt_flag_words(clusters));
+        cv.take<float>((size_t)T * left * G);                  // left-over rows: compact dgates1
+        cv.take<float>((size_t)T * left * H);                  // ... their dh0
+        cv.take<float>((size_t)left * H);                      // ... dc
+        size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
+        const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
+        cv.take<char>(tn > tn2 ? tn : tn2);
+        return fsn_round_up_sz(cv.off, 256);
+    }
+    cv.take<float>((size_t)T * N * H);  // dh0
+    cv.take<char>(l1 > l0 ? l1 : l0);
+    return fsn_round_up_sz(cv.off, 256);
+}
+extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, const float* w_ih0, const float* w_hh0,
+                                  const float* w_ih1, const float* w_hh1, int T, int N, int I, int H, const float* hseq0,
+                                  const float* hseq1, const void* save0, const void* save1, float* dx, long lddx,
+                                  float* dw_ih0, float* dw_hh0, float* db0, float* dw_ih1, float* dw_hh1, float* db1,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    CallScope scope(stream);
+    FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
+    FSN_REQUIRE(dh1 && x && w_ih0 && w_hh0 && w_ih1 && w_hh1 && hseq0 && hseq1 && save0 && save1 && dw_ih0 && dw_hh0 && db0 &&
+                    dw_ih1 && dw_hh1 && db1 && workspace,
+                "NULL pointer argument");
+    FSN_REQUIRE(!dx || lddx >= I, "dx row stride %ld < I", lddx);
+    if (workspace_bytes < fsn_lstm2_bwd_workspace_bytes(T, N, I, H)) {
+        fsn_set_error("lstm2 backward: workspace too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    const int clusters = lstm2_bptt_group_clusters(T, N, I, H);
+    if (!clusters) {  // layer by layer; layer 1's dx is d loss / d hseq0
+        Carver cv(workspace);
+        float* dh0 = cv.take<float>((size_t)T * N * H);
+        const size_t l1 = fsn_lstm_layer_bwd_workspace_bytes(T, N, H, H), l0 = fsn_lstm_layer_bwd_workspace_bytes(T, N, I, H);
+        void* ws = cv.take<char>(l1 > l0 ? l1 : l0);
+        FSN_TRY(fsn_lstm_layer_backward(dh1, hseq0, H, w_ih1, w_hh1, T, N, H, H, hseq1, save1, dh0, H, dw_ih1, dw_hh1, db1, ws,
+                                        l1 > l0 ? l1 : l0, stream));
+        return fsn_lstm_layer_backward(dh0, x, ldx, w_ih0, w_hh0, T, N, I, H, hseq0, save0, dx, lddx, dw_ih0, dw_hh0, db0, ws,
+                                       l1 > l0 ? l1 : l0, stream);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Ipad = fsn_round_up(I, 16), G = 4 * H;
+    const int left_tiles = N / 16 - 4 * clusters, left = left_tiles * 16, row0 = 64 * clusters;
+    Carver cv(workspace);
+    float* whh1T_p = cv.take<float>((size_t)3 * H * G + (size_t)Ipad * G);
+    float* wih1T_p = whh1T_p + (size_t)H * G;
+    float* whh0T_p = wih1T_p + (size_t)H * G;
+    float* wih0T_p = whh0T_p + (size_t)H * G;
+    float* dg1 = cv.take<float>((size_t)2 * T * N * G);
+    float* dg0 = dg1 + (size_t)T * N * G;
+    unsigned* flags = cv.take<unsigned>(fsn_lstm2_group_bptt_flag_words(clusters));
+    float* dg1_left = cv.take<float>((size_t)T * left * G);
+    float* dh0_left = cv.take<float>((size_t)T * left * H);
+    float* dc_left = cv.take<float>((size_t)left * H);
+    size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
+    const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
+    void* scratch = cv.take<char>(tn > tn2 ? tn : tn2);
+    const float* sv0 = static_cast<const float*>(save0);
+    const float* sv1 = static_cast<const float*>(save1);
+    // "weights" of dh = dgates W are W^T: out = H columns, k = 4H; nn.LSTM stores exactly that transposed
+    FSN_TRY(fsn_launch_pack(w_hh1, whh1T_p, H, G, H, G, s, 1, H));
+    FSN_TRY(fsn_launch_pack(w_ih1, wih1T_p, H, G, H, G, s, 1, H));
+    FSN_TRY(fsn_launch_pack(w_hh0, whh0T_p, H, G, H, G, s, 1, H));
+    FSN_TRY(fsn_launch_pack(w_ih0, wih0T_p, I, G, Ipad, G, s, 1, I));
+    StreamCtx* cx = cur_ctx();
+    if (left > 0) {
+        FSN_TRY(aux_init(cx));
+        if (hipEventRecord(cx->ev_fork, s) != hipSuccess || hipStreamWaitEvent(cx->aux, cx->ev_fork, 0) != hipSuccess) {
+            fsn_set_error("aux stream fork failed");
+            return FSN_ERR_LAUNCH;
+        }
+    }
+    {
+        PersistLaunch gate(s);
+        FSN_TRY(fsn_launch_lstm2_group_bptt(dh1, whh1T_p, wih1T_p, whh0T_p, sv0, sv1, dg0, dg1, flags, T, N, clusters, H, s));
+    }
+    if (left > 0) {
+        // the rows that do not fill a cluster: step by step on the auxiliary stream, straight into the same buffers
+        hipStream_t as = cx->aux;
+        const size_t stepH = (size_t)N * H, stepG = (size_t)N * G;
+        for (int layer = 1; layer >= 0; --layer) {
+            const float* sv = layer ? sv1 : sv0;
+            const float* gates = sv + (size_t)row0 * G;
+            const float* cseq = sv + (size_t)T * N * G + (size_t)row0 * H;
+            float* dg = (layer ? dg1 : dg0) + (size_t)row0 * G;
+            const float* whhT = layer ? whh1T_p : whh0T_p;
+            for (int t = T - 1; t >= 0; --t) {
+                const float* dh_t = layer ? dh1 + t * stepH + (size_t)row0 * H : dh0_left + (size_t)t * left * H;
+                FSN_TRY(fsn_launch_bptt_step(dh_t, t + 1 < T ? dg + (t + 1) * stepG : dg, whhT, dc_left, gates + t * stepG,
+                                             cseq + t * stepH, t ? cseq + (t - 1) * stepH : cseq, dg + t * stepG, left_tiles, H,
+                                             t == T - 1, t == 0, as));
+            }
+            if (layer) {  // dh0 of these rows = dgates1 W_ih1: compact copy of their dgates1, one small GEMM
+                if (hipMemcpy2DAsync(dg1_left, (size_t)left * G * sizeof(float), dg, stepG * sizeof(float),
+                                     (size_t)left * G * sizeof(float), T, hipMemcpyDeviceToDevice, as) != hipSuccess) {
+                    fsn_set_error("lstm2 backward: cannot gather the left-over rows");
+                    return FSN_ERR_LAUNCH;
+                }
+                FsnGemmA a{};
+                a.kind = 0;
+                a.p0 = dg1_left;
+                a.ld = G;
+                FsnGemmC c{};
+                c.kind = 3;
+                c.p0 = dh0_left;
+                c.ld = H;
+                c.rows = T * left;
+                c.cols = H;
+                FSN_TRY(fsn_launch_gemm(a, wih1T_p, c, T * left_tiles, H / 16, G / 16, as));
+            }
+        }
+        if (hipEventRecord(cx->ev_join, cx->aux) != hipSuccess || hipStreamWaitEvent(s, cx->ev_join, 0) != hipSuccess) {
+            fsn_set_error("aux stream join failed");
+            return FSN_ERR_LAUNCH;
+        }
+    }
+    FsnGemmA a{};
+    FsnGemmC c{};
+    if (dx) {
+        a.kind = 0;
+        a.p0 = dg0;
+        a.ld = G;
+        c.kind = 3;
+        c.p0 = dx;
+        c.ld = lddx;
+        c.rows = T * N;
+        c.cols = I;
+        FSN_TRY(fsn_launch_gemm(a, wih0T_p, c, T * (N / 16), Ipad / 16, G / 16, s));
+    }
+    // dW_ih = dgates^T X (+ db = its column sums), dW_hh = dgates_{1..}^T H_{0..T-2}
+    FSN_TRY(fsn_launch_gemm_tn(dg1, G, hseq0, H, dw_ih1, H, G, H, (long)T * N, scratch, s, db1));
+    FSN_TRY(fsn_launch_gemm_tn(dg0, G, x, ldx, dw_ih0, I, G, I, (long)T * N, scratch, s, db0));
+    if (T > 1) {
+        FSN_TRY(fsn_launch_gemm_tn(dg1 + (size_t)N * G, G, hseq1, H, dw_hh1, H, G, H, (long)(T - 1) * N, scratch, s));
+        FSN_TRY(fsn_launch_gemm_tn(dg0 + (size_t)N * G, G, hseq0, H, dw_hh0, H, G, H, (long)(T - 1) * N, scratch, s));
+    } else if (hipMemsetAsync(dw_hh1, 0, (size_t)G * H * sizeof(float), s) != hipSuccess ||
+               hipMemsetAsync(dw_hh0, 0, (size_t)G * H * sizeof(float), s) != hipSuccess) {
         fsn_set_error("memset failed");
         return FSN_ERR_LAUNCH;
     }

@@ -1,0 +1,288 @@
+// Back-propagation through time of the sub-band model's two LSTM layers (training step, fullsubnet/trainer.py:56-63
+// through sequence_model.py:52-58) as ONE persistent launch: the mirror image of lstm_group_kernels.hip.
+//
+// Per step t = T-1 .. 0 (formulas: lstm_train_kernels.hip):
+//   layer 1: dh1_t = dH1_t (from the output layer) + dgates1_{t+1} W_hh1          -> cell derivative -> dgates1_t
+//   layer 0: dh0_t = dgates1_t W_ih1 (the layer-to-layer dX, no GEMM) + dgates0_{t+1} W_hh0 -> ... -> dgates0_t
+// As 2 x 193 launches of bptt_step_kernel plus a dX GEMM this cost 14.6 + 1.9 ms of a 50.5 ms training step (one step:
+// a 2064 x 1536 x 384 product, 15 us of MFMA work, 37 us as a launch).  Here the same work split stays resident:
+//   - workgroup (cluster c, member m, layer l) owns hidden units [48 m, 48 m + 48) of layer l for the 64 rows of
+//     cluster c: wave w = row tile w, 3 accumulator tiles (dh of 3 unit groups), dc_t in registers; 16 workgroups per
+//     cluster, two per CU, layer 1 (the leading chain) in the first half of the grid;
+//   - the exchange buffers ARE the outputs: a member stores its 4 x 48 gate-gradient columns of step t into
+//     dgates[t] (write-through), which every member reads as the A operand of step t - 1 (K = 1536 per product) and the
+//     weight-gradient GEMMs read afterwards; nothing is reused, so there is no back-pressure;
+//   - W^T fragments (the [k][out] order nn.LSTM stores) are fetched once per workgroup and shared by its four waves
+//     through a two-stage LDS buffer, four K chunks x three column tiles per stage (one barrier per 48 MFMAs, the
+//     cadence of the forward kernel); A fragments come through an eight-deep register ring;
+//   - the saved activations of a step (gates, c_t, c_{t-1}, dH: 7 values per element) are requested before the flag
+//     wait;
+//   - flags / bounded spins / status exactly as in lstm_group_kernels.hip.
+#include "fsn_common.h"
+
+namespace {
+
+constexpr int BH = 384;           // hidden units (both layers)
+constexpr int BG = 4 * BH;        // gate columns = K of every product
+constexpr int BKC = BG / 16;      // K chunks (96)
+constexpr int BM = 8;             // members per cluster and layer
+constexpr int BU = BH / 16 / BM;  // 16-unit groups per member (3)
+constexpr int BROWS = 64;         // rows per cluster
+constexpr int BCH = 4;            // K chunks per LDS stage
+constexpr int BFS = 32;           // words between flag groups (one cache line each)
+constexpr unsigned kBpttSpin = 1u << 21;
+
+struct BpttArgs {
+    const float* dh1;     // [Tp][N][H]   d loss / d hseq1
+    const float* wbase;   // packed W^T matrices ([H/16][KC][64][4]) live in one buffer: element offsets
+    unsigned o_whh1T, o_wih1T, o_whh0T;
+    const float *gates0, *cseq0, *gates1, *cseq1;  // saved by the forward pass: [Tp][N][4H], [Tp][N][H]
+    float *dg0, *dg1;     // [Tp][N][4H]: gate gradients (outputs and exchange buffers)
+    unsigned* flags;      // [clusters][2][BFS]: steps published by (layer 1 | layer 0, member)
+    unsigned* status;
+    int Tp, Nrows;
+};
+
+__device__ __forceinline__ void bptt_store_sc1(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
+}
+
+__device__ __forceinline__ bool bptt_poll(unsigned* flags8, unsigned epoch, unsigned* status) {
+    const int lane = threadIdx.x & 63;
+    for (unsigned spins = 0;; ++spins) {
+        unsigned v = epoch;
+        if (lane < BM) v = __hip_atomic_load(flags8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all((int)(v >= epoch))) return true;
+        if ((spins & 255u) == 255u) {
+            const unsigned st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (st != 0 || spins >= kBpttSpin) {
+                if (lane == 0 && st == 0) __hip_atomic_store(status, 1u + epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <int LAYER>
+__device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int member, f32x4 (*bsh)[BCH * BU][64]) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int Tp = a.Tp;
+    const size_t N = (size_t)a.Nrows;
+    unsigned* fl1 = a.flags + ((size_t)cluster * 2 + 0) * BFS;
+    unsigned* fl0 = a.flags + ((size_t)cluster * 2 + 1) * BFS;
+    // this lane's A fragment inside a cluster's [64][4H] tile of a gate-gradient buffer (byte offset)
+    const unsigned a_off = (unsigned)(((wave * 16 + lr) * BG + 4 * lq) * 4);
+    // the cluster's [64][4H] tile of step t of a gate-gradient buffer as a buffer resource (one per step: the whole
+    // buffer - 2.5 GB at config 3's shape - is beyond the 2 GB a resource's offsets reach)
+    auto tile = [&](float* dg, int t) {
+        return __builtin_amdgcn_make_buffer_rsrc(dg + ((size_t)t * N + (size_t)cluster * BROWS) * BG, 0, BROWS * BG * 4,
+                                                 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wbase), 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+
+    // acc[u] += A(16 rows x K) W^T(K x 16 units of group u): n chunks (a multiple of 2 BCH) of the tile behind `xr`
+    // (sc1 loads: the partners wrote through) against the packed matrix at element offset b of the weight buffer.
+    // (The descriptor is passed by value: a reference to one of two descriptors chosen at run time puts both on the
+    // stack.)
+    auto kloop = [&](f32x4 (&acc)[BU], const __amdgpu_buffer_rsrc_t xr, unsigned b, int n) {
+        constexpr int AD = 2 * BCH;  // A fragments in flight (write-through data of other CUs: first touch is far)
+        f32x4 ar[AD], bn[BU];
+        auto fetch_a = [&](int k) -> f32x4 {
+            const int kc = k < n ? k : n - 1;
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, a_off, (unsigned)kc * 64u, 16));
+        };
+        // stage s holds chunks BCH s .. BCH s + 3, fragment (c, u) at index c BU + u; wave w fetches fragments 3 w ..
+        auto fetch_b = [&](int s) {
+#pragma unroll
+            for (int j = 0; j < BU; ++j) {
+                const int f = wave * BU + j, c = f / BU, u = f % BU;
+                int k = s * BCH + c;
+                k = k < n ? k : n - 1;
+                const unsigned ofs = b + ((unsigned)(member * BU + u) * BKC + (unsigned)k) * 256u;
+                bn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, ofs * 4u, 0));
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < AD; ++d) ar[d] = fetch_a(d);
+        fetch_b(0);
+#pragma unroll
+        for (int j = 0; j < BU; ++j) bsh[0][wave * BU + j][lane] = bn[j];
+        __syncthreads();
+        for (int s0 = 0; s0 < n / BCH; s0 += 2) {  // two stages = one turn of the A ring (statically indexed)
+#pragma unroll
+            for (int d = 0; d < AD; ++d) {
+                const int ds = d / BCH, c = d % BCH, s = s0 + ds, buf = ds;  // n / BCH is even: stage parity = ds
+                if (c == 0) {
+                    __builtin_amdgcn_sched_barrier(0);  // requests first, pinned under this stage's MFMAs
+                    fetch_b(s + 1);
+                }
+                const f32x4 av = ar[d];
+                ar[d] = fetch_a(s * BCH + c + AD);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < BU; ++u) {
+                    const f32x4 b = bsh[buf][c * BU + u][lane];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[u] = mfma16(av[j], b[j], acc[u]);
+                }
+                if (c == BCH - 1) {
+#pragma unroll
+                    for (int j = 0; j < BU; ++j) bsh[buf ^ 1][wave * BU + j][lane] = bn[j];
+                    __syncthreads();
+                }
+            }
+        }
+    };
+
+    auto peek = [&](unsigned* flags8) -> unsigned {
+        unsigned v = 0xffffffffu;
+        if (wave == 0 && lane < BM) v = __hip_atomic_load(flags8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;
+    };
+    auto wait_peeked = [&](unsigned v, unsigned* flags8, unsigned epoch) {
+        if (wave == 0 && !__all((int)(v >= epoch))) (void)bptt_poll(flags8, epoch, a.status);
+        __syncthreads();
+    };
+    auto publish = [&](unsigned* flag, unsigned epoch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+
+    const float* gates = LAYER ? a.gates1 : a.gates0;
+    const float* cseq = LAYER ? a.cseq1 : a.cseq0;
+    float* dgout = LAYER ? a.dg1 : a.dg0;
+    const size_t row0 = (size_t)cluster * BROWS + wave * 16 + 4 * lq;  // + i
+    float dc[BU][4];
+#pragma unroll
+    for (int u = 0; u < BU; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dc[u][i] = 0.f;
+
+    unsigned seen1 = LAYER ? 0xffffffffu : peek(fl1);
+    for (int t = Tp - 1; t >= 0; --t) {
+        const unsigned done = (unsigned)(Tp - 1 - t);  // steps every member has published when step t + 1 is complete
+        // saved activations of step t for this lane's 3 x 4 elements: requested now, used after the K loops
+        float e_g[BU][4][4], e_ct[BU][4], e_cp[BU][4], e_dh[BU][4];
+#pragma unroll
+        for (int u = 0; u < BU; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const size_t row = row0 + i;
+                const int unit = (member * BU + u) * 16 + lr;
+                const float* gp = gates + ((size_t)t * N + row) * BG + unit;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) e_g[u][i][g] = gp[g * BH];
+                e_ct[u][i] = cseq[((size_t)t * N + row) * BH + unit];
+                e_cp[u][i] = t > 0 ? cseq[((size_t)(t - 1) * N + row) * BH + unit] : 0.f;
+                e_dh[u][i] = LAYER ? a.dh1[((size_t)t * N + row) * BH + unit] : 0.f;
+            }
+        f32x4 acc[BU];
+#pragma unroll
+        for (int u = 0; u < BU; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (LAYER) {
+            if (t < Tp - 1) {
+                wait_peeked(peek(fl1), fl1, done);  // dgates1_{t+1} of all members (just published: polls)
+                kloop(acc, tile(a.dg1, t + 1), a.o_whh1T, BKC);
+            }
+        } else {
+            // dgates1_t W_ih1 first - layer 1 published it a while ago - so that the partners' dgates0_{t+1},
+            // published a moment ago, has a whole K loop to arrive
+            wait_peeked(seen1, fl1, done + 1);
+            const unsigned seen0 = t < Tp - 1 ? peek(fl0) : 0xffffffffu;
+            kloop(acc, tile(a.dg1, t), a.o_wih1T, BKC);
+            if (t < Tp - 1) {
+                wait_peeked(seen0, fl0, done);
+                seen1 = peek(fl1);  // for the next step: layer 1 is ahead
+                kloop(acc, tile(a.dg0, t + 1), a.o_whh0T, BKC);
+            } else {
+                seen1 = peek(fl1);
+            }
+        }
+        // cell derivative of this wave's 16 rows x 48 units -> dgates_t (write-through: the partners' next A operand)
+#pragma unroll
+        for (int u = 0; u < BU; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float ig = e_g[u][i][0], fg = e_g[u][i][1], gg = e_g[u][i][2], og = e_g[u][i][3];
+                const float dh = e_dh[u][i] + acc[u][i];
+                const float tc = tanhf(e_ct[u][i]);
+                const float d_o = dh * tc;
+                const float dct = dc[u][i] + dh * og * (1.f - tc * tc);
+                float* dg = dgout + ((size_t)t * N + row0 + i) * BG + (member * BU + u) * 16 + lr;
+                bptt_store_sc1(dg, dct * gg * ig * (1.f - ig));
+                bptt_store_sc1(dg + BH, dct * e_cp[u][i] * fg * (1.f - fg));
+                bptt_store_sc1(dg + 2 * BH, dct * ig * (1.f - gg * gg));
+                bptt_store_sc1(dg + 3 * BH, d_o * og * (1.f - og));
+                dc[u][i] = dct * fg;
+            }
+        publish((LAYER ? fl1 : fl0) + member, done + 1);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(116))) void lstm2_group_bptt_kernel(const BpttArgs a) {
+    __shared__ f32x4 bsh[2][BCH * BU][64];  // two stages x (4 chunks x 3 column tiles) x 1 KB
+    // first half of the grid: layer 1 (the leading chain), second half: layer 0; cluster members on one XCD when the
+    // cluster count allows it (speed only), as in lstm2_group_kernel
+    const int half = gridDim.x >> 1;
+    const int second = (int)blockIdx.x >= half ? 1 : 0;
+    const int bid = (int)blockIdx.x - second * half;
+    const int nclusters = half / BM;
+    int cluster, member;
+    if (nclusters % 8 == 0) {
+        const int xcd = bid & 7, j = bid >> 3;
+        cluster = xcd * (nclusters / 8) + j / BM;
+        member = j % BM;
+    } else {
+        cluster = bid / BM;
+        member = bid % BM;
+    }
+    if (!second) bptt_body<1>(a, cluster, member, bsh);
+    else bptt_body<0>(a, cluster, member, bsh);
+}
+
+}  // namespace
+
+size_t fsn_lstm2_group_bptt_flag_words(int clusters) { return (size_t)clusters * 2 * BFS + 16; }
+
+// Rows [0, 64 clusters) of the two layers: dh1 [Tp][Nrows][H]; whh1T_p / wih1T_p / whh0T_p = W_hh1 / W_ih1 / W_hh0
+// packed TRANSPOSED ([H/16][4H/16][64][4], fsn_launch_pack(..., transposed = 1)) in one buffer; save0 / save1 in
+// fsn_lstm_layer_forward's layout; dg0 / dg1 [Tp][Nrows][4H] out.
+int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const float* wih1T_p, const float* whh0T_p,
+                                const float* save0, const float* save1, float* dg0, float* dg1, unsigned* flags, int Tp,
+                                int Nrows, int clusters, int H, hipStream_t s) {
+    if (H != BH || clusters < 1 || (long)clusters * BROWS > Nrows) {
+        fsn_set_error("lstm2_group_bptt: H = 384, clusters * 64 <= rows");
+        return FSN_ERR_ARG;
+    }
+    if (fsn_launch_zero_words(flags, fsn_lstm2_group_bptt_flag_words(clusters), s) != FSN_OK) return FSN_ERR_LAUNCH;
+    const float* lo = whh1T_p;
+    for (const float* q : {wih1T_p, whh0T_p}) lo = q < lo ? q : lo;
+    for (const float* q : {whh1T_p, wih1T_p, whh0T_p})
+        if (q - lo > 0x1fffffffL) {
+            fsn_set_error("lstm2_group_bptt: the packed weight matrices must share one buffer");
+            return FSN_ERR_ARG;
+        }
+    BpttArgs a{};
+    a.dh1 = dh1;
+    a.wbase = lo;
+    a.o_whh1T = (unsigned)(whh1T_p - lo);
+    a.o_wih1T = (unsigned)(wih1T_p - lo);
+    a.o_whh0T = (unsigned)(whh0T_p - lo);
+    a.gates0 = save0;
+    a.cseq0 = save0 + (size_t)Tp * Nrows * BG;
+    a.gates1 = save1;
+    a.cseq1 = save1 + (size_t)Tp * Nrows * BG;
+    a.dg0 = dg0;
+    a.dg1 = dg1;
+    a.flags = flags;
+    a.status = flags + (size_t)clusters * 2 * BFS;
+    a.Tp = Tp;
+    a.Nrows = Nrows;
+    hipLaunchKernelGGL(lstm2_group_bptt_kernel, dim3((unsigned)clusters * BM * 2), dim3(256), 0, s, a);
+    return fsn_check_launch("lstm2_group_bptt_kernel");
+}

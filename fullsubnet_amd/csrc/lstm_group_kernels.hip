@@ -447,8 +447,8 @@ int fsn_launch_lstm2_group_train(const float* x, long x_ld, int Nrows, const flo
                                  const float* wih1_p, const float* whh1_p, const float* bias0, const float* bias1,
                                  float* hseq0, float* hseq1, float* save0, float* save1, unsigned* flags, int Tp,
                                  int clusters, int H, hipStream_t s) {
-    if (H != GH || clusters < 1 || (long)clusters * GROWS > Nrows || (size_t)Tp * Nrows * GH * 4 > 0xffffffffull) {
-        fsn_set_error("lstm2_group (training): H = 384, clusters * 64 <= rows, hidden sequence below 4 GB");
+    if (H != GH || clusters < 1 || (long)clusters * GROWS > Nrows || (size_t)Tp * Nrows * GH * 4 > 0x7fffffffull) {
+        fsn_set_error("lstm2_group (training): H = 384, clusters * 64 <= rows, hidden sequence below 2 GB");
         return FSN_ERR_ARG;
     }
     if (fsn_launch_zero_words(flags, fsn_lstm2_group_flag_words(clusters), s) != FSN_OK) return FSN_ERR_LAUNCH;

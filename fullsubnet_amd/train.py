@@ -66,8 +66,9 @@ class LstmLayerFunction(torch.autograd.Function):
 
 class Lstm2Function(torch.autograd.Function):
     """nn.LSTM(num_layers=2) (unidirectional, h0 = c0 = 0, both layers H wide) on time-major x [T, N, I] -> [T, N, H]:
-    fsn_lstm2_forward_train (for the full-band shape - H = 512, up to 64 rows - ONE persistent launch for both layers
-    and all steps) and two fsn_lstm_layer_backward calls."""
+    fsn_lstm2_forward_train (the full-band shape - H = 512, up to 64 rows - and the sub-band shape - H = 384, 96+ row
+    tiles - each as ONE persistent launch for both layers and all steps) and fsn_lstm2_backward (the sub-band shape's
+    back-propagation through time as one persistent launch as well)."""
 
     @staticmethod
     def forward(ctx, x, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1):
@@ -103,25 +104,17 @@ class Lstm2Function(torch.autograd.Function):
         if Np != N or not dh.is_contiguous():
             dhp = torch.zeros((T, Np, H), dtype=torch.float32, device=dev)
             dhp[:, :N] = dh
-        stream = _lib.stream_ptr(dev)
-        # layer 1: x = hseq0; its dx is d loss / d hseq0
-        dh0 = torch.empty((T, Np, H), dtype=torch.float32, device=dev)
-        dw_ih1, dw_hh1 = torch.empty_like(w_ih1), torch.empty_like(w_hh1)
-        db1 = torch.empty((4 * H,), dtype=torch.float32, device=dev)
-        ws = _lib.workspace(max(L.fsn_lstm_layer_bwd_workspace_bytes(T, Np, H, H),
-                                L.fsn_lstm_layer_bwd_workspace_bytes(T, Np, I, H)), dev)
-        _lib.check(L.fsn_lstm_layer_backward(
-            _lib.dev_ptr(dhp, "dh"), _lib.dev_ptr(hseq0), H, _lib.dev_ptr(w_ih1), _lib.dev_ptr(w_hh1), T, Np, H, H,
-            _lib.dev_ptr(hseq1), save1.data_ptr(), _lib.dev_ptr(dh0), H, _lib.dev_ptr(dw_ih1), _lib.dev_ptr(dw_hh1),
-            _lib.dev_ptr(db1), ws.data_ptr(), ws.numel(), stream))
         need_dx = ctx.needs_input_grad[0]
         dx = torch.empty((T, Np, Ip), dtype=torch.float32, device=dev) if need_dx else None
-        dw_ih0, dw_hh0 = torch.empty_like(w_ih0), torch.empty_like(w_hh0)
+        dw_ih0, dw_hh0, dw_ih1, dw_hh1 = (torch.empty_like(w) for w in (w_ih0, w_hh0, w_ih1, w_hh1))
         db0 = torch.empty((4 * H,), dtype=torch.float32, device=dev)
-        _lib.check(L.fsn_lstm_layer_backward(
-            _lib.dev_ptr(dh0), _lib.dev_ptr(xp), Ip, _lib.dev_ptr(w_ih0), _lib.dev_ptr(w_hh0), T, Np, I, H,
-            _lib.dev_ptr(hseq0), save0.data_ptr(), _lib.dev_ptr(dx, allow_none=True), Ip, _lib.dev_ptr(dw_ih0),
-            _lib.dev_ptr(dw_hh0), _lib.dev_ptr(db0), ws.data_ptr(), ws.numel(), stream))
+        db1 = torch.empty((4 * H,), dtype=torch.float32, device=dev)
+        ws = _lib.workspace(L.fsn_lstm2_bwd_workspace_bytes(T, Np, I, H), dev)
+        _lib.check(L.fsn_lstm2_backward(
+            _lib.dev_ptr(dhp, "dh"), _lib.dev_ptr(xp), Ip, _lib.dev_ptr(w_ih0), _lib.dev_ptr(w_hh0), _lib.dev_ptr(w_ih1),
+            _lib.dev_ptr(w_hh1), T, Np, I, H, _lib.dev_ptr(hseq0), _lib.dev_ptr(hseq1), save0.data_ptr(), save1.data_ptr(),
+            _lib.dev_ptr(dx, allow_none=True), Ip, _lib.dev_ptr(dw_ih0), _lib.dev_ptr(dw_hh0), _lib.dev_ptr(db0),
+            _lib.dev_ptr(dw_ih1), _lib.dev_ptr(dw_hh1), _lib.dev_ptr(db1), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)))
         return ((dx[:, :N, :I] if need_dx else None), dw_ih0, dw_hh0, db0, db0.clone(), dw_ih1, dw_hh1, db1, db1.clone())
 
 

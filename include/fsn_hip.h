@@ -209,6 +209,17 @@ int fsn_lstm_layer_backward(const float* dh, const float* x, long ldx, const flo
                             float* dw_ih, float* dw_hh, float* db, void* workspace, size_t workspace_bytes,
                             void* stream);
 
+/* Backward of two stacked layers (the counterpart of fsn_lstm2_forward_train): dh1 [T][N][H] = dLoss/dhseq1;
+ * outputs as two fsn_lstm_layer_backward calls would give them (dx may be NULL).  The sub-band shape (H = 384, 96+
+ * row tiles) runs its back-propagation through time - both layers, all steps, the layer-to-layer dX - as ONE
+ * persistent launch (lstm2_group_bptt_kernel) followed by the weight-gradient GEMMs. */
+size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H);
+int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, const float* w_ih0, const float* w_hh0,
+                       const float* w_ih1, const float* w_hh1, int T, int N, int I, int H, const float* hseq0,
+                       const float* hseq1, const void* save0, const void* save1, float* dx, long lddx, float* dw_ih0,
+                       float* dw_hh0, float* db0, float* dw_ih1, float* dw_hh1, float* db1, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
 /* nn.GRU branch of SequenceModel (sequence_model.py:59-66), one layer, unidirectional, h0 = 0; same
  * conventions as the LSTM layer above with 3H gate rows (r, z, n).  save == NULL: inference.  The two
  * bias gradients differ in the n block (b_hn sits inside r * (W_hn h + b_hn)), hence two outputs. */

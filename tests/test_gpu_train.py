@@ -51,6 +51,37 @@ def test_lstm_layer_forward_and_bptt(fsn, T, N, I, H):
         assert err <= 1e-4 * max(b.abs().max().item(), 1e-3), (name, err, b.abs().max().item())
 
 
+@pytest.mark.parametrize("T,N,I,H", [(6, 2064, 32, 384), (5, 1552, 20, 384), (4, 16, 257, 512), (3, 40, 64, 512),
+                                     (4, 48, 32, 384)])
+def test_two_layer_lstm_on_the_persistent_kernels(fsn, T, N, I, H):
+    """Lstm2Function (fsn_lstm2_forward_train + fsn_lstm2_backward) against two stacked LstmLayerFunction calls (the
+    per-step kernels, themselves held to the oracle above): the sub-band shape - 129 row tiles = 32 clusters on the
+    group kernels (forward with saves, BPTT) + one left-over tile step by step beside them; 97 tiles with a narrower
+    input - the full-band shape on the chain kernel (one and three row tiles), and a shape that falls back to the
+    layer-by-layer path.  Outputs and every gradient; the persistent path twice, bit-identical."""
+    from fullsubnet_amd.train import Lstm2Function, LstmLayerFunction
+    g = torch.Generator().manual_seed(T * 1000 + N)
+    k = 1.0 / np.sqrt(H)
+    x = torch.randn(T, N, I, generator=g)
+    shapes = ((4 * H, I), (4 * H, H), (4 * H,), (4 * H,), (4 * H, H), (4 * H, H), (4 * H,), (4 * H,))
+    w = [(torch.rand(s_, generator=g) * 2 - 1) * k * 2 for s_ in shapes]
+    dy = torch.randn(T, N, H, generator=g).cuda()
+
+    def run(two):
+        xd = x.cuda().requires_grad_(True)
+        wd = [t.cuda().requires_grad_(True) for t in w]
+        y = Lstm2Function.apply(xd, *wd) if two else LstmLayerFunction.apply(LstmLayerFunction.apply(xd, *wd[:4]), *wd[4:])
+        (y * dy).sum().backward()
+        return [y.detach()] + [xd.grad] + [t.grad for t in wd]
+
+    ref, got, again = run(False), run(True), run(True)
+    names = ["y", "dx", "dw_ih0", "dw_hh0", "db_ih0", "db_hh0", "dw_ih1", "dw_hh1", "db_ih1", "db_hh1"]
+    for name, a, b, c in zip(names, got, ref, again):
+        assert torch.equal(a, c), name
+        err = (a - b).abs().max().item()
+        assert err <= 1e-4 * max(b.abs().max().item(), 1e-3), (name, err, b.abs().max().item())
+
+
 @pytest.mark.parametrize("name", ["fsn_train_b4", "fsn_train_c3"])
 def test_train_step_vs_reference_and_oracle(fsn, golden_dir, name):
     """One step of fullsubnet/trainer.py:41-71 (use_amp = false) against the reference's own loss, clipped gradients
