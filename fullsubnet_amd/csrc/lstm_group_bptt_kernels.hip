@@ -20,6 +20,13 @@
 //   - flags / bounded spins / status exactly as in lstm_group_kernels.hip.
 #include "fsn_common.h"
 
+#ifndef FSN_BPTT_A_AUX
+// 16: sc1 loads of the A operand (never cached: 0.3 GB per step through the fabric); 0: ordinary loads after an
+// agent-scope acquire (buffer_inv sc1), shared through the XCD's L2 - measured slower (48.5 against 47.1 ms per training
+// step: the invalidates of 64 workgroups per XCD and step take the weights out of the L2 as well)
+#define FSN_BPTT_A_AUX 16
+#endif
+
 namespace {
 
 constexpr int BH = 384;           // hidden units (both layers)
@@ -93,7 +100,7 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
         f32x4 ar[AD], bn[BU];
         auto fetch_a = [&](int k) -> f32x4 {
             const int kc = k < n ? k : n - 1;
-            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, a_off, (unsigned)kc * 64u, 16));
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, a_off, (unsigned)kc * 64u, FSN_BPTT_A_AUX));
         };
         // stage s holds chunks BCH s .. BCH s + 3, fragment (c, u) at index c BU + u; wave w fetches fragments 3 w ..
         auto fetch_b = [&](int s) {
@@ -146,6 +153,11 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
     auto wait_peeked = [&](unsigned v, unsigned* flags8, unsigned epoch) {
         if (wave == 0 && !__all((int)(v >= epoch))) (void)bptt_poll(flags8, epoch, a.status);
         __syncthreads();
+#if FSN_BPTT_A_AUX == 0
+        // agent-scope acquire (buffer_inv sc1): the A operand is then read with ordinary loads, which the 16 workgroups
+        // of a cluster - on one XCD when the grid allows it - share through that XCD's L2
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
     };
     auto publish = [&](unsigned* flag, unsigned epoch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
