@@ -1831,6 +1831,7 @@ extern "C" size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H) {
         const size_t left = (size_t)(N / 16 - 4 * clusters) * 16;
         cv.take<float>((size_t)3 * H * G + (size_t)Ipad * G);  // W_hh1^T, W_ih1^T, W_hh0^T, W_ih0^T fragments
         cv.take<float>((size_t)2 * T * N * G);                 // dgates of both layers
+        cv.take<float>((size_t)T * N * H);                     // layer 0's dH (dgates1 W_ih1), produced by the kernel
         cv.take<unsigned>(fsn_lstm2_group_bptt_flag_words(clusters));
         cv.take<float>((size_t)T * left * G);                  // left-over rows: compact dgates1
         cv.take<float>((size_t)T * left * H);                  // ... their dh0
@@ -1880,6 +1881,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     float* wih0T_p = whh0T_p + (size_t)H * G;
     float* dg1 = cv.take<float>((size_t)2 * T * N * G);
     float* dg0 = dg1 + (size_t)T * N * G;
+    float* dxbuf = cv.take<float>((size_t)T * N * H);
     unsigned* flags = cv.take<unsigned>(fsn_lstm2_group_bptt_flag_words(clusters));
     float* dg1_left = cv.take<float>((size_t)T * left * G);
     float* dh0_left = cv.take<float>((size_t)T * left * H);
@@ -1904,7 +1906,8 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     }
     {
         PersistLaunch gate(s);
-        FSN_TRY(fsn_launch_lstm2_group_bptt(dh1, whh1T_p, wih1T_p, whh0T_p, sv0, sv1, dg0, dg1, flags, T, N, clusters, H, s));
+        FSN_TRY(fsn_launch_lstm2_group_bptt(dh1, whh1T_p, wih1T_p, whh0T_p, sv0, sv1, dg0, dg1, dxbuf, flags, T, N, clusters,
+                                            H, s));
     }
     if (left > 0) {
         // the rows that do not fill a cluster: step by step on the auxiliary stream, straight into the same buffers

@@ -153,8 +153,8 @@ int fsn_launch_bias_frag(const float* bias, float* frag, int n, hipStream_t s);
 
 size_t fsn_lstm2_group_bptt_flag_words(int clusters);  // lstm_group_bptt_kernels.hip
 int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const float* wih1T_p, const float* whh0T_p,
-                                const float* save0, const float* save1, float* dg0, float* dg1, unsigned* flags, int Tp,
-                                int Nrows, int clusters, int H, hipStream_t s);
+                                const float* save0, const float* save1, float* dg0, float* dg1, float* dx, unsigned* flags,
+                                int Tp, int Nrows, int clusters, int H, hipStream_t s);
 int fsn_launch_zero_words(unsigned* p, size_t n, hipStream_t s);  // elementwise_kernels.hip
 
 int fsn_launch_lstm2_group_train(const float* x, long x_ld, int Nrows, const float* wih0_p, const float* whh0_p,

@@ -45,6 +45,7 @@ struct BpttArgs {
     unsigned o_whh1T, o_wih1T, o_whh0T;
     const float *gates0, *cseq0, *gates1, *cseq1;  // saved by the forward pass: [Tp][N][4H], [Tp][N][H]
     float *dg0, *dg1;     // [Tp][N][4H]: gate gradients (outputs and exchange buffers)
+    float* dx;            // [Tp][N][H]: dgates1_t W_ih1 = layer 0's dH, produced by layer 1 (see below)
     unsigned* flags;      // [clusters][2][BFS]: steps published by (layer 1 | layer 0, member)
     unsigned* status;
     int Tp, Nrows;
@@ -72,7 +73,7 @@ __device__ __forceinline__ bool bptt_poll(unsigned* flags8, unsigned epoch, unsi
 }
 
 template <int LAYER>
-__device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int member, f32x4 (*bsh)[BCH * BU][64]) {
+__device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int member, f32x4 (*bsh)[BCH * 2 * BU][64]) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const int Tp = a.Tp;
@@ -95,21 +96,24 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
     // (sc1 loads: the partners wrote through) against the packed matrix at element offset b of the weight buffer.
     // (The descriptor is passed by value: a reference to one of two descriptors chosen at run time puts both on the
     // stack.)
-    auto kloop = [&](f32x4 (&acc)[BU], const __amdgpu_buffer_rsrc_t xr, unsigned b, int n) {
+    // NT = 3: one matrix (element offset b); NT = 6: two matrices against the SAME A fragments (tiles 0..2 from b, 3..5
+    // from b2) - layer 1 forms dgates1_{t+1} W_hh1 (its own dh) and dgates1_{t+1} W_ih1 (layer 0's dH) in one pass.
+    auto kloop = [&](auto& acc, const __amdgpu_buffer_rsrc_t xr, unsigned b, unsigned b2, int n) {
+        constexpr int NT = (int)(sizeof(acc) / sizeof(f32x4));
         constexpr int AD = 2 * BCH;  // A fragments in flight (write-through data of other CUs: first touch is far)
-        f32x4 ar[AD], bn[BU];
+        f32x4 ar[AD], bn[NT];
         auto fetch_a = [&](int k) -> f32x4 {
             const int kc = k < n ? k : n - 1;
             return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, a_off, (unsigned)kc * 64u, FSN_BPTT_A_AUX));
         };
-        // stage s holds chunks BCH s .. BCH s + 3, fragment (c, u) at index c BU + u; wave w fetches fragments 3 w ..
+        // stage s holds chunks BCH s .. BCH s + 3, fragment (c, u) at index c NT + u; wave w fetches fragments NT w ..
         auto fetch_b = [&](int s) {
 #pragma unroll
-            for (int j = 0; j < BU; ++j) {
-                const int f = wave * BU + j, c = f / BU, u = f % BU;
+            for (int j = 0; j < NT; ++j) {
+                const int f = wave * NT + j, c = f / NT, u = f % NT;
                 int k = s * BCH + c;
                 k = k < n ? k : n - 1;
-                const unsigned ofs = b + ((unsigned)(member * BU + u) * BKC + (unsigned)k) * 256u;
+                const unsigned ofs = (u < BU ? b : b2) + ((unsigned)(member * BU + u % BU) * BKC + (unsigned)k) * 256u;
                 bn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, ofs * 4u, 0));
             }
         };
@@ -117,7 +121,7 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
         for (int d = 0; d < AD; ++d) ar[d] = fetch_a(d);
         fetch_b(0);
 #pragma unroll
-        for (int j = 0; j < BU; ++j) bsh[0][wave * BU + j][lane] = bn[j];
+        for (int j = 0; j < NT; ++j) bsh[0][wave * NT + j][lane] = bn[j];
         __syncthreads();
         for (int s0 = 0; s0 < n / BCH; s0 += 2) {  // two stages = one turn of the A ring (statically indexed)
 #pragma unroll
@@ -131,14 +135,14 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
                 ar[d] = fetch_a(s * BCH + c + AD);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < BU; ++u) {
-                    const f32x4 b = bsh[buf][c * BU + u][lane];
+                for (int u = 0; u < NT; ++u) {
+                    const f32x4 bf = bsh[buf][c * NT + u][lane];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[u] = mfma16(av[j], b[j], acc[u]);
+                    for (int j = 0; j < 4; ++j) acc[u] = mfma16(av[j], bf[j], acc[u]);
                 }
                 if (c == BCH - 1) {
 #pragma unroll
-                    for (int j = 0; j < BU; ++j) bsh[buf ^ 1][wave * BU + j][lane] = bn[j];
+                    for (int j = 0; j < NT; ++j) bsh[buf ^ 1][wave * NT + j][lane] = bn[j];
                     __syncthreads();
                 }
             }
@@ -175,9 +179,15 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
 #pragma unroll
         for (int i = 0; i < 4; ++i) dc[u][i] = 0.f;
 
+    // Work split: layer 0's dh is dgates1_t W_ih1 + dgates0_{t+1} W_hh0 - twice layer 1's K.  The first product has the
+    // same A operand as layer 1's own (dgates1 of the step before), so LAYER 1 forms it, for its member's 48 units, in
+    // the same pass over the A fragments (six accumulator tiles instead of three) and hands it over through `dx`;
+    // layer 0 is left with one product, and nobody reads a dgates1 tile twice.  Layer 1 runs one extra iteration
+    // (t = -1) that only produces dx_0.
     unsigned seen1 = LAYER ? 0xffffffffu : peek(fl1);
-    for (int t = Tp - 1; t >= 0; --t) {
+    for (int t = Tp - 1; t >= (LAYER ? -1 : 0); --t) {
         const unsigned done = (unsigned)(Tp - 1 - t);  // steps every member has published when step t + 1 is complete
+        const int tt = t < 0 ? 0 : t;
         // saved activations of step t for this lane's 3 x 4 elements: requested now, used after the K loops
         float e_g[BU][4][4], e_ct[BU][4], e_cp[BU][4], e_dh[BU][4];
 #pragma unroll
@@ -186,58 +196,71 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
             for (int i = 0; i < 4; ++i) {
                 const size_t row = row0 + i;
                 const int unit = (member * BU + u) * 16 + lr;
-                const float* gp = gates + ((size_t)t * N + row) * BG + unit;
+                const float* gp = gates + ((size_t)tt * N + row) * BG + unit;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) e_g[u][i][g] = gp[g * BH];
-                e_ct[u][i] = cseq[((size_t)t * N + row) * BH + unit];
+                e_ct[u][i] = cseq[((size_t)tt * N + row) * BH + unit];
                 e_cp[u][i] = t > 0 ? cseq[((size_t)(t - 1) * N + row) * BH + unit] : 0.f;
-                e_dh[u][i] = LAYER ? a.dh1[((size_t)t * N + row) * BH + unit] : 0.f;
+                e_dh[u][i] = LAYER ? a.dh1[((size_t)tt * N + row) * BH + unit] : 0.f;
             }
         f32x4 acc[BU];
 #pragma unroll
         for (int u = 0; u < BU; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (LAYER) {
             if (t < Tp - 1) {
+                f32x4 acc6[2 * BU];
+#pragma unroll
+                for (int u = 0; u < 2 * BU; ++u) acc6[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 wait_peeked(peek(fl1), fl1, done);  // dgates1_{t+1} of all members (just published: polls)
-                kloop(acc, tile(a.dg1, t + 1), a.o_whh1T, BKC);
+                kloop(acc6, tile(a.dg1, t + 1), a.o_whh1T, a.o_wih1T, BKC);
+#pragma unroll
+                for (int u = 0; u < BU; ++u) {
+                    acc[u] = acc6[u];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)  // dx_{t+1}: layer 0's dH of step t + 1
+                        bptt_store_sc1(a.dx + ((size_t)(t + 1) * N + row0 + i) * BH + (member * BU + u) * 16 + lr, acc6[BU + u][i]);
+                }
             }
         } else {
-            // dgates1_t W_ih1 first - layer 1 published it a while ago - so that the partners' dgates0_{t+1},
-            // published a moment ago, has a whole K loop to arrive
-            wait_peeked(seen1, fl1, done + 1);
-            const unsigned seen0 = t < Tp - 1 ? peek(fl0) : 0xffffffffu;
-            kloop(acc, tile(a.dg1, t), a.o_wih1T, BKC);
+            // dx_t was produced by layer 1's iteration t - 1: all its members have published Tp - (t - 1)
+            wait_peeked(seen1, fl1, done + 2);
+#pragma unroll
+            for (int u = 0; u < BU; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[u][i] = __hip_atomic_load(a.dx + ((size_t)t * N + row0 + i) * BH + (member * BU + u) * 16 + lr,
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (t < Tp - 1) {
-                wait_peeked(seen0, fl0, done);
-                seen1 = peek(fl1);  // for the next step: layer 1 is ahead
-                kloop(acc, tile(a.dg0, t + 1), a.o_whh0T, BKC);
-            } else {
-                seen1 = peek(fl1);
+                wait_peeked(peek(fl0), fl0, done);  // dgates0_{t+1} of all members
+                kloop(acc, tile(a.dg0, t + 1), a.o_whh0T, 0u, BKC);
             }
+            seen1 = peek(fl1);  // for the next step: layer 1 is ahead
         }
         // cell derivative of this wave's 16 rows x 48 units -> dgates_t (write-through: the partners' next A operand)
+        if (t >= 0) {
 #pragma unroll
-        for (int u = 0; u < BU; ++u)
+            for (int u = 0; u < BU; ++u)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float ig = e_g[u][i][0], fg = e_g[u][i][1], gg = e_g[u][i][2], og = e_g[u][i][3];
-                const float dh = e_dh[u][i] + acc[u][i];
-                const float tc = tanhf(e_ct[u][i]);
-                const float d_o = dh * tc;
-                const float dct = dc[u][i] + dh * og * (1.f - tc * tc);
-                float* dg = dgout + ((size_t)t * N + row0 + i) * BG + (member * BU + u) * 16 + lr;
-                bptt_store_sc1(dg, dct * gg * ig * (1.f - ig));
-                bptt_store_sc1(dg + BH, dct * e_cp[u][i] * fg * (1.f - fg));
-                bptt_store_sc1(dg + 2 * BH, dct * ig * (1.f - gg * gg));
-                bptt_store_sc1(dg + 3 * BH, d_o * og * (1.f - og));
-                dc[u][i] = dct * fg;
-            }
+                for (int i = 0; i < 4; ++i) {
+                    const float ig = e_g[u][i][0], fg = e_g[u][i][1], gg = e_g[u][i][2], og = e_g[u][i][3];
+                    const float dh = e_dh[u][i] + acc[u][i];
+                    const float tc = tanhf(e_ct[u][i]);
+                    const float d_o = dh * tc;
+                    const float dct = dc[u][i] + dh * og * (1.f - tc * tc);
+                    float* dg = dgout + ((size_t)t * N + row0 + i) * BG + (member * BU + u) * 16 + lr;
+                    bptt_store_sc1(dg, dct * gg * ig * (1.f - ig));
+                    bptt_store_sc1(dg + BH, dct * e_cp[u][i] * fg * (1.f - fg));
+                    bptt_store_sc1(dg + 2 * BH, dct * ig * (1.f - gg * gg));
+                    bptt_store_sc1(dg + 3 * BH, d_o * og * (1.f - og));
+                    dc[u][i] = dct * fg;
+                }
+        }
         publish((LAYER ? fl1 : fl0) + member, done + 1);
     }
 }
 
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(116))) void lstm2_group_bptt_kernel(const BpttArgs a) {
-    __shared__ f32x4 bsh[2][BCH * BU][64];  // two stages x (4 chunks x 3 column tiles) x 1 KB
+    __shared__ f32x4 bsh[2][BCH * 2 * BU][64];  // two stages x (4 chunks x up to 6 column tiles) x 1 KB
     // first half of the grid: layer 1 (the leading chain), second half: layer 0; cluster members on one XCD when the
     // cluster count allows it (speed only), as in lstm2_group_kernel
     const int half = gridDim.x >> 1;
@@ -253,8 +276,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(116))) void 
         cluster = bid / BM;
         member = bid % BM;
     }
-    if (!second) bptt_body<1>(a, cluster, member, bsh);
-    else bptt_body<0>(a, cluster, member, bsh);
+    if (!second) {
+        __builtin_amdgcn_s_setprio(2);  // layer 1 is the longer chain (six tiles per A fragment against three)
+        bptt_body<1>(a, cluster, member, bsh);
+    } else {
+        bptt_body<0>(a, cluster, member, bsh);
+    }
 }
 
 }  // namespace
@@ -263,10 +290,10 @@ size_t fsn_lstm2_group_bptt_flag_words(int clusters) { return (size_t)clusters *
 
 // Rows [0, 64 clusters) of the two layers: dh1 [Tp][Nrows][H]; whh1T_p / wih1T_p / whh0T_p = W_hh1 / W_ih1 / W_hh0
 // packed TRANSPOSED ([H/16][4H/16][64][4], fsn_launch_pack(..., transposed = 1)) in one buffer; save0 / save1 in
-// fsn_lstm_layer_forward's layout; dg0 / dg1 [Tp][Nrows][4H] out.
+// fsn_lstm_layer_forward's layout; dg0 / dg1 [Tp][Nrows][4H] out; dx [Tp][Nrows][H] scratch (layer 0's dH).
 int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const float* wih1T_p, const float* whh0T_p,
-                                const float* save0, const float* save1, float* dg0, float* dg1, unsigned* flags, int Tp,
-                                int Nrows, int clusters, int H, hipStream_t s) {
+                                const float* save0, const float* save1, float* dg0, float* dg1, float* dx, unsigned* flags,
+                                int Tp, int Nrows, int clusters, int H, hipStream_t s) {
     if (H != BH || clusters < 1 || (long)clusters * BROWS > Nrows) {
         fsn_set_error("lstm2_group_bptt: H = 384, clusters * 64 <= rows");
         return FSN_ERR_ARG;
@@ -291,6 +318,7 @@ int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const fl
     a.cseq1 = save1 + (size_t)Tp * Nrows * BG;
     a.dg0 = dg0;
     a.dg1 = dg1;
+    a.dx = dx;
     a.flags = flags;
     a.status = flags + (size_t)clusters * 2 * BFS;
     a.Tp = Tp;
