@@ -1613,6 +1613,10 @@ extern "C" size_t fsn_lstm2_fwd_workspace_bytes(int T, int N, int I, int H0, int
     cv.take<float>((size_t)T * N * 4 * H0);                // layer-0 projection
     cv.take<float>((size_t)T * N * H0);                    // layer-0 hidden sequence
     cv.take<float>((size_t)N * (H0 + H1));                 // cell states
+    if (H0 == H1 && fsn_fb_chain_supported(H0, N)) {       // the persistent chain kernel instead of the wavefront
+        cv.take<float>(fsn_fb_chain_exchange_floats(T, N));
+        cv.take<unsigned>(fsn_fb_chain_flag_words());
+    }
     return fsn_round_up_sz(cv.off, 256);
 }
 extern "C" int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, const float* w_hh0, const float* b_ih0,
@@ -1657,6 +1661,12 @@ extern "C" int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, c
     c.p0 = gx;
     c.bias = b0;
     FSN_TRY(fsn_launch_gemm(a, wih0_p, c, T * (N / 16), G0 / 16, Ipad / 16, s));
+    if (H0 == H1 && fsn_fb_chain_supported(H0, N)) {  // H = 512, up to 64 rows: one persistent launch (fb_chain_kernels.hip)
+        float* exchange = cv.take<float>(fsn_fb_chain_exchange_floats(T, N));
+        unsigned* flags = cv.take<unsigned>(fsn_fb_chain_flag_words());
+        PersistLaunch gate(s);
+        return fsn_launch_fb_chain(gx, whh0_p, wih1_p, whh1_p, b1, exchange, flags, hseq1, T, N, H0, s);
+    }
     return fsn_launch_lstm_wavefront2w(gx, N / 16, 0, whh0_p, wih1_p, b1_frag, whh1_p, hseq0, hseq1, N, 0, cst,
                                        cst + (size_t)N * H0, T, N / 16, H0, H1, s);
 }
