@@ -25,6 +25,9 @@
 // agent-scope acquire (buffer_inv sc1), shared through the XCD's L2 - measured slower (48.5 against 47.1 ms per training
 // step: the invalidates of 64 workgroups per XCD and step take the weights out of the L2 as well)
 #define FSN_BPTT_A_AUX 16
+#ifndef FSN_BPTT_TURN
+#define FSN_BPTT_TURN 2  // x 4 chunks = A fragments in flight (must divide 24 stages); measured: 2 -> 12.5 ms, 3 -> 12.9, 4 -> 13.2
+#endif
 #endif
 
 namespace {
@@ -72,7 +75,10 @@ __device__ __forceinline__ bool bptt_poll(unsigned* flags8, unsigned epoch, unsi
     }
 }
 
-template <int LAYER>
+// ABL: experiment knob of tools/probe_bptt.hip (0 in the library; any bit set gives WRONG results): 1 no flag polling,
+// 2 no gate-gradient / dx stores, 4 A fragments not loaded, 8 saved activations not loaded, 16 plain instead of
+// write-through stores, 32 no tanhf in the cell derivative
+template <int LAYER, int ABL>
 __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int member, f32x4 (*bsh)[BCH * 2 * BU][64]) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
@@ -88,6 +94,18 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
         return __builtin_amdgcn_make_buffer_rsrc(dg + ((size_t)t * N + (size_t)cluster * BROWS) * BG, 0, BROWS * BG * 4,
                                                  0x00020000);
     };
+    // likewise the cluster's [64][H] tile of a [Tp][N][H] buffer (cell states, dH, dx)
+    auto tileh = [&](const float* p, int t) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p) + ((size_t)t * N + (size_t)cluster * BROWS) * BH, 0,
+                                                 BROWS * BH * 4, 0x00020000);
+    };
+    // Element (row 4 lq + i of this wave's tile, unit 16 u + lr of this member) of such tiles: ONE lane offset each and
+    // compile-time scalar offsets for (i, u, gate) - no per-element address registers (84 loads and 60 stores per step)
+    const unsigned voff_g = (unsigned)(((wave * 16 + 4 * lq) * BG + member * BU * 16 + lr) * 4);
+    const unsigned voff_h = (unsigned)(((wave * 16 + 4 * lq) * BH + member * BU * 16 + lr) * 4);
+    auto ldf = [&](const __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    };
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wbase), 0, 0x7fffffff, 0x00020000);
     const unsigned lane16 = (unsigned)lane * 16u;
@@ -98,38 +116,57 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
     // stack.)
     // NT = 3: one matrix (element offset b); NT = 6: two matrices against the SAME A fragments (tiles 0..2 from b, 3..5
     // from b2) - layer 1 forms dgates1_{t+1} W_hh1 (its own dh) and dgates1_{t+1} W_ih1 (layer 0's dH) in one pass.
-    auto kloop = [&](auto& acc, const __amdgpu_buffer_rsrc_t xr, unsigned b, unsigned b2, int n) {
+    // `mid` runs once, after the fourth stage: the step's saved activations are requested THERE - loads return in order,
+    // so requested before the loop they hold up the first A fragment for an HBM latency every step (measured: 9 us of
+    // a 69 us step), while behind sixteen chunks of buffered MFMA work the same wait is covered.
+    auto kloop = [&](auto& acc, const __amdgpu_buffer_rsrc_t xr, unsigned b, unsigned b2, int n, auto&& mid) {
         constexpr int NT = (int)(sizeof(acc) / sizeof(f32x4));
-        constexpr int AD = 2 * BCH;  // A fragments in flight (write-through data of other CUs: first touch is far)
-        f32x4 ar[AD], bn[NT];
+        constexpr int TURN = FSN_BPTT_TURN;  // stages per turn of the A ring
+        constexpr int AD = TURN * BCH;       // A fragments in flight (write-through data of other CUs: first touch is far)
+        constexpr int NB = BU;       // B fragments a wave holds in registers at a time (NT = 6: fetched in two halves)
+        f32x4 ar[AD], bn[NB];
         auto fetch_a = [&](int k) -> f32x4 {
             const int kc = k < n ? k : n - 1;
+            if (ABL & 4) return f32x4{0.5f, 0.25f, -0.125f, 0.0625f};
             return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, a_off, (unsigned)kc * 64u, FSN_BPTT_A_AUX));
         };
         // stage s holds chunks BCH s .. BCH s + 3, fragment (c, u) at index c NT + u; wave w fetches fragments NT w ..
-        auto fetch_b = [&](int s) {
+        // NT w + NT - 1, `half` selects the first / second three of them
+        auto fetch_b = [&](int s, int half) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int f = wave * NT + j, c = f / NT, u = f % NT;
+            for (int j = 0; j < NB; ++j) {
+                const int f = wave * NT + half * NB + j, c = f / NT, u = f % NT;
                 int k = s * BCH + c;
                 k = k < n ? k : n - 1;
                 const unsigned ofs = (u < BU ? b : b2) + ((unsigned)(member * BU + u % BU) * BKC + (unsigned)k) * 256u;
                 bn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, ofs * 4u, 0));
             }
         };
+        auto park_b = [&](int buf, int half) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bsh[buf][wave * NT + half * NB + j][lane] = bn[j];
+        };
 #pragma unroll
         for (int d = 0; d < AD; ++d) ar[d] = fetch_a(d);
-        fetch_b(0);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bsh[0][wave * NT + j][lane] = bn[j];
+        for (int half = 0; half < NT / NB; ++half) {
+            fetch_b(0, half);
+            park_b(0, half);
+        }
         __syncthreads();
-        for (int s0 = 0; s0 < n / BCH; s0 += 2) {  // two stages = one turn of the A ring (statically indexed)
+        for (int s0 = 0; s0 < n / BCH; s0 += TURN) {  // TURN stages = one turn of the A ring (statically indexed)
+            if (s0 == 2 * TURN) mid();
 #pragma unroll
             for (int d = 0; d < AD; ++d) {
-                const int ds = d / BCH, c = d % BCH, s = s0 + ds, buf = ds;  // n / BCH is even: stage parity = ds
+                const int ds = d / BCH, c = d % BCH, s = s0 + ds, buf = s & 1;
                 if (c == 0) {
                     __builtin_amdgcn_sched_barrier(0);  // requests first, pinned under this stage's MFMAs
-                    fetch_b(s + 1);
+                    fetch_b(s + 1, 0);
+                }
+                if (NT > NB && c == BCH / 2) {  // second half of the next stage's fragments, through the same registers
+                    park_b(buf ^ 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fetch_b(s + 1, 1);
                 }
                 const f32x4 av = ar[d];
                 ar[d] = fetch_a(s * BCH + c + AD);
@@ -141,8 +178,7 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
                     for (int j = 0; j < 4; ++j) acc[u] = mfma16(av[j], bf[j], acc[u]);
                 }
                 if (c == BCH - 1) {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) bsh[buf ^ 1][wave * NT + j][lane] = bn[j];
+                    park_b(buf ^ 1, NT / NB - 1);
                     __syncthreads();
                 }
             }
@@ -155,7 +191,7 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
         return v;
     };
     auto wait_peeked = [&](unsigned v, unsigned* flags8, unsigned epoch) {
-        if (wave == 0 && !__all((int)(v >= epoch))) (void)bptt_poll(flags8, epoch, a.status);
+        if (wave == 0 && !(ABL & 1) && !__all((int)(v >= epoch))) (void)bptt_poll(flags8, epoch, a.status);
         __syncthreads();
 #if FSN_BPTT_A_AUX == 0
         // agent-scope acquire (buffer_inv sc1): the A operand is then read with ordinary loads, which the 16 workgroups
@@ -169,10 +205,14 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
         if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
+    auto gstore = [&](const __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
+        if (ABL & 2) return;
+        if (ABL & 16) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 16);  // sc1: write-through
+    };
     const float* gates = LAYER ? a.gates1 : a.gates0;
     const float* cseq = LAYER ? a.cseq1 : a.cseq0;
     float* dgout = LAYER ? a.dg1 : a.dg0;
-    const size_t row0 = (size_t)cluster * BROWS + wave * 16 + 4 * lq;  // + i
     float dc[BU][4];
 #pragma unroll
     for (int u = 0; u < BU; ++u)
@@ -188,21 +228,24 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
     for (int t = Tp - 1; t >= (LAYER ? -1 : 0); --t) {
         const unsigned done = (unsigned)(Tp - 1 - t);  // steps every member has published when step t + 1 is complete
         const int tt = t < 0 ? 0 : t;
-        // saved activations of step t for this lane's 3 x 4 elements: requested now, used after the K loops
+        // saved activations of step t for this lane's 3 x 4 elements (requested inside the K loop, see kloop)
         float e_g[BU][4][4], e_ct[BU][4], e_cp[BU][4], e_dh[BU][4];
+        auto load_saved = [&]() {
+            const __amdgpu_buffer_rsrc_t rg = tile(const_cast<float*>(gates), tt), rc = tileh(cseq, tt),
+                                         rp = tileh(cseq, t > 0 ? t - 1 : 0), rd = tileh(LAYER ? a.dh1 : cseq, tt);
 #pragma unroll
-        for (int u = 0; u < BU; ++u)
+            for (int u = 0; u < BU; ++u)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const size_t row = row0 + i;
-                const int unit = (member * BU + u) * 16 + lr;
-                const float* gp = gates + ((size_t)tt * N + row) * BG + unit;
+                for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) e_g[u][i][g] = gp[g * BH];
-                e_ct[u][i] = cseq[((size_t)tt * N + row) * BH + unit];
-                e_cp[u][i] = t > 0 ? cseq[((size_t)(t - 1) * N + row) * BH + unit] : 0.f;
-                e_dh[u][i] = LAYER ? a.dh1[((size_t)tt * N + row) * BH + unit] : 0.f;
-            }
+                    for (int g = 0; g < 4; ++g)
+                        e_g[u][i][g] = (ABL & 8) ? 0.4f : ldf(rg, voff_g, (unsigned)((i * BG + g * BH + u * 16) * 4));
+                    const unsigned so = (unsigned)((i * BH + u * 16) * 4);
+                    e_ct[u][i] = (ABL & 8) ? 0.3f : ldf(rc, voff_h, so);
+                    e_cp[u][i] = (ABL & 8) ? 0.2f : (t > 0 ? ldf(rp, voff_h, so) : 0.f);
+                    e_dh[u][i] = (ABL & 8) ? 0.1f : (LAYER ? ldf(rd, voff_h, so) : 0.f);
+                }
+        };
         f32x4 acc[BU];
 #pragma unroll
         for (int u = 0; u < BU; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -212,46 +255,55 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
 #pragma unroll
                 for (int u = 0; u < 2 * BU; ++u) acc6[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 wait_peeked(peek(fl1), fl1, done);  // dgates1_{t+1} of all members (just published: polls)
-                kloop(acc6, tile(a.dg1, t + 1), a.o_whh1T, a.o_wih1T, BKC);
+                kloop(acc6, tile(a.dg1, t + 1), a.o_whh1T, a.o_wih1T, BKC, load_saved);
+                const __amdgpu_buffer_rsrc_t rx = tileh(a.dx, t + 1);
 #pragma unroll
                 for (int u = 0; u < BU; ++u) {
                     acc[u] = acc6[u];
 #pragma unroll
                     for (int i = 0; i < 4; ++i)  // dx_{t+1}: layer 0's dH of step t + 1
-                        bptt_store_sc1(a.dx + ((size_t)(t + 1) * N + row0 + i) * BH + (member * BU + u) * 16 + lr, acc6[BU + u][i]);
+                        gstore(rx, voff_h, (unsigned)((i * BH + u * 16) * 4), acc6[BU + u][i]);
                 }
+            } else {
+                load_saved();
             }
         } else {
             // dx_t was produced by layer 1's iteration t - 1: all its members have published Tp - (t - 1)
             wait_peeked(seen1, fl1, done + 2);
+            {
+                const __amdgpu_buffer_rsrc_t rx = tileh(a.dx, t);
 #pragma unroll
-            for (int u = 0; u < BU; ++u)
+                for (int u = 0; u < BU; ++u)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[u][i] = __hip_atomic_load(a.dx + ((size_t)t * N + row0 + i) * BH + (member * BU + u) * 16 + lr,
-                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int i = 0; i < 4; ++i)  // sc1: written through by layer 1's workgroup
+                        acc[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                                  rx, voff_h, (unsigned)((i * BH + u * 16) * 4), 16));
+            }
             if (t < Tp - 1) {
                 wait_peeked(peek(fl0), fl0, done);  // dgates0_{t+1} of all members
-                kloop(acc, tile(a.dg0, t + 1), a.o_whh0T, 0u, BKC);
+                kloop(acc, tile(a.dg0, t + 1), a.o_whh0T, 0u, BKC, load_saved);
+            } else {
+                load_saved();
             }
             seen1 = peek(fl1);  // for the next step: layer 1 is ahead
         }
         // cell derivative of this wave's 16 rows x 48 units -> dgates_t (write-through: the partners' next A operand)
         if (t >= 0) {
+            const __amdgpu_buffer_rsrc_t ro = tile(dgout, t);
 #pragma unroll
             for (int u = 0; u < BU; ++u)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float ig = e_g[u][i][0], fg = e_g[u][i][1], gg = e_g[u][i][2], og = e_g[u][i][3];
                     const float dh = e_dh[u][i] + acc[u][i];
-                    const float tc = tanhf(e_ct[u][i]);
+                    const float tc = (ABL & 32) ? e_ct[u][i] : tanhf(e_ct[u][i]);
                     const float d_o = dh * tc;
                     const float dct = dc[u][i] + dh * og * (1.f - tc * tc);
-                    float* dg = dgout + ((size_t)t * N + row0 + i) * BG + (member * BU + u) * 16 + lr;
-                    bptt_store_sc1(dg, dct * gg * ig * (1.f - ig));
-                    bptt_store_sc1(dg + BH, dct * e_cp[u][i] * fg * (1.f - fg));
-                    bptt_store_sc1(dg + 2 * BH, dct * ig * (1.f - gg * gg));
-                    bptt_store_sc1(dg + 3 * BH, d_o * og * (1.f - og));
+                    const unsigned so = (unsigned)((i * BG + u * 16) * 4);
+                    gstore(ro, voff_g, so, dct * gg * ig * (1.f - ig));
+                    gstore(ro, voff_g, so + BH * 4, dct * e_cp[u][i] * fg * (1.f - fg));
+                    gstore(ro, voff_g, so + 2 * BH * 4, dct * ig * (1.f - gg * gg));
+                    gstore(ro, voff_g, so + 3 * BH * 4, d_o * og * (1.f - og));
                     dc[u][i] = dct * fg;
                 }
         }
@@ -259,6 +311,7 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
     }
 }
 
+template <int ABL>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(116))) void lstm2_group_bptt_kernel(const BpttArgs a) {
     __shared__ f32x4 bsh[2][BCH * 2 * BU][64];  // two stages x (4 chunks x up to 6 column tiles) x 1 KB
     // first half of the grid: layer 1 (the leading chain), second half: layer 0; cluster members on one XCD when the
@@ -278,9 +331,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(116))) void 
     }
     if (!second) {
         __builtin_amdgcn_s_setprio(2);  // layer 1 is the longer chain (six tiles per A fragment against three)
-        bptt_body<1>(a, cluster, member, bsh);
+        bptt_body<1, ABL>(a, cluster, member, bsh);
     } else {
-        bptt_body<0>(a, cluster, member, bsh);
+        bptt_body<0, ABL>(a, cluster, member, bsh);
     }
 }
 
@@ -323,6 +376,6 @@ int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const fl
     a.status = flags + (size_t)clusters * 2 * BFS;
     a.Tp = Tp;
     a.Nrows = Nrows;
-    hipLaunchKernelGGL(lstm2_group_bptt_kernel, dim3((unsigned)clusters * BM * 2), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(lstm2_group_bptt_kernel<0>, dim3((unsigned)clusters * BM * 2), dim3(256), 0, s, a);
     return fsn_check_launch("lstm2_group_bptt_kernel");
 }
