@@ -286,3 +286,18 @@ int fsn_launch_zero_words(unsigned* p, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(zero_words_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, p, n);
     return fsn_check_launch("zero_words_kernel");
 }
+
+// The persistent kernels whose workgroups wait for each other bound every spin; when a bound is hit (a workgroup could
+// not be placed because something else held the CUs for seconds) they raise `status` and finish with garbage.  This
+// makes that visible: the output becomes NaN (nothing is written when status is 0: the kernel costs its launch).
+__global__ void poison_if_kernel(const unsigned* __restrict__ status, float* __restrict__ out, size_t n) {
+    if (*status == 0u) return;
+    const float nan = __builtin_nanf("");
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = nan;
+}
+int fsn_launch_poison_if(const unsigned* status, float* out, size_t n, hipStream_t s) {
+    if (!status || !out || n == 0) return FSN_OK;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(poison_if_kernel, dim3(blocks), dim3(256), 0, s, status, out, n);
+    return fsn_check_launch("poison_if_kernel");
+}

@@ -316,6 +316,7 @@ size_t fsn_fb_chain_exchange_floats(int Tp, int Npad) {
     return (size_t)2 * Tp * Npad * CH + (size_t)Tp * CNW * 1024;  // hx0, hx1, gx1
 }
 size_t fsn_fb_chain_flag_words() { return (size_t)2 * CREP * CNW + 16; }
+size_t fsn_fb_chain_status_word() { return (size_t)2 * CREP * CNW; }
 
 // gx0: fragment-order projection of layer 0 (bias included); hseq1 [Tp][Npad][H] row-major out.
 // Training form: hseq0, save0, save1 non-NULL (save = gates [Tp][Npad][4H] followed by the cell sequence [Tp][Npad][H],

@@ -590,6 +590,8 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
             PersistLaunch gate(s);
             FSN_TRY(fsn_launch_fb_chain(w.gx_fb, pk + p.fb_whh0, pk + p.fb_wih1, pk + p.fb_whh1, pk + p.fb_b1,
                                         w.fb_exchange, w.fb_flags, w.hseq_fb1, d.Tp, d.Npad_fb, d.Hf, s));
+            FSN_TRY(fsn_launch_poison_if(w.fb_flags + fsn_fb_chain_status_word(), w.hseq_fb1,
+                                         (size_t)d.Tp * d.Npad_fb * d.Hf, s));
         } else {
             FSN_TRY(fsn_launch_lstm_wavefront2(w.gx_fb, d.Npad_fb / 16, 0, pk + p.fb_whh0, pk + p.fb_wih1,
                                                pk + p.fb_b1_frag, pk + p.fb_whh1, w.hseq_fb0, w.hseq_fb1, d.Npad_fb, 0,
@@ -698,6 +700,10 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
             PersistLaunch gate(s);
             FSN_TRY(fsn_launch_lstm2_group(&xin, pk + p.sb_whh0, pk + p.sb_wih1, pk + p.sb_whh1, pk + p.sb_b1,
                                            w.grp_exchange, w.grp_flags, &gfc, d.Tp, d.grp_clusters, d.Hs, s));
+            // a spin bound hit inside it (see fsn_launch_poison_if): the mask planes become NaN instead of garbage
+            const unsigned* st_word = w.grp_flags + fsn_lstm2_group_status_word(d.grp_clusters);
+            FSN_TRY(fsn_launch_poison_if(st_word, crm_r, (size_t)d.B * d.T * d.FP, s));
+            FSN_TRY(fsn_launch_poison_if(st_word, crm_i, (size_t)d.B * d.T * d.FP, s));
         }
         if (aux_tiles > 0) {
             FSN_TRY(fsn_launch_lstm_wavefront2(w.gx_sb, aux_tiles, 0, pk + p.sb_whh0, pk + p.sb_wih1, pk + p.sb_b1_frag,
@@ -1522,6 +1528,7 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
             PersistLaunch gate(s);
             FSN_TRY(fsn_launch_lstm2_group_train(x, ldx, N, wih0_p, whh0_p, wih1_p, whh1_p, b0, b1, hseq0, hseq1, sv0, sv1,
                                                  flags, T, clusters, H, s));
+            FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_status_word(clusters), hseq1, (size_t)T * N * H, s));
         }
         if (left > 0) {
             hipStream_t as = cx->aux;
@@ -1594,8 +1601,9 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
     c.bias = b0;
     FSN_TRY(fsn_launch_gemm(a, wih0_p, c, T * (N / 16), 4 * H / 16, Ipad / 16, s));
     PersistLaunch gate(s);
-    return fsn_launch_fb_chain(gx0, whh0_p, wih1_p, whh1_p, b1, exchange, flags, hseq1, T, N, H, s, hseq0,
-                               static_cast<float*>(save0), static_cast<float*>(save1));
+    FSN_TRY(fsn_launch_fb_chain(gx0, whh0_p, wih1_p, whh1_p, b1, exchange, flags, hseq1, T, N, H, s, hseq0,
+                                static_cast<float*>(save0), static_cast<float*>(save1)));
+    return fsn_launch_poison_if(flags + fsn_fb_chain_status_word(), hseq1, (size_t)T * N * H, s);
 }
 
 // Two stacked LSTM layers of equal width in inference mode as one wavefront (layer 1 at step t next to layer 0
@@ -1665,7 +1673,8 @@ extern "C" int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, c
         float* exchange = cv.take<float>(fsn_fb_chain_exchange_floats(T, N));
         unsigned* flags = cv.take<unsigned>(fsn_fb_chain_flag_words());
         PersistLaunch gate(s);
-        return fsn_launch_fb_chain(gx, whh0_p, wih1_p, whh1_p, b1, exchange, flags, hseq1, T, N, H0, s);
+        FSN_TRY(fsn_launch_fb_chain(gx, whh0_p, wih1_p, whh1_p, b1, exchange, flags, hseq1, T, N, H0, s));
+        return fsn_launch_poison_if(flags + fsn_fb_chain_status_word(), hseq1, (size_t)T * N * H0, s);
     }
     return fsn_launch_lstm_wavefront2w(gx, N / 16, 0, whh0_p, wih1_p, b1_frag, whh1_p, hseq0, hseq1, N, 0, cst,
                                        cst + (size_t)N * H0, T, N / 16, H0, H1, s);
@@ -1918,6 +1927,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
         PersistLaunch gate(s);
         FSN_TRY(fsn_launch_lstm2_group_bptt(dh1, whh1T_p, wih1T_p, whh0T_p, sv0, sv1, dg0, dg1, dxbuf, flags, T, N, clusters,
                                             H, s));
+        FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_bptt_status_word(clusters), dg0, (size_t)T * N * G, s));
     }
     if (left > 0) {
         // the rows that do not fill a cluster: step by step on the auxiliary stream, straight into the same buffers

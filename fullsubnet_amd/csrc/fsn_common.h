@@ -156,6 +156,11 @@ int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const fl
                                 const float* save0, const float* save1, float* dg0, float* dg1, float* dx, unsigned* flags,
                                 int Tp, int Nrows, int clusters, int H, hipStream_t s);
 int fsn_launch_zero_words(unsigned* p, size_t n, hipStream_t s);  // elementwise_kernels.hip
+// out[0..n) = NaN if *status != 0 (a persistent kernel hit a spin bound); status words of the three kernels' flag arrays
+int fsn_launch_poison_if(const unsigned* status, float* out, size_t n, hipStream_t s);
+size_t fsn_fb_chain_status_word();
+size_t fsn_lstm2_group_status_word(int clusters);
+size_t fsn_lstm2_group_bptt_status_word(int clusters);
 
 int fsn_launch_lstm2_group_train(const float* x, long x_ld, int Nrows, const float* wih0_p, const float* whh0_p,
                                  const float* wih1_p, const float* whh1_p, const float* bias0, const float* bias1,

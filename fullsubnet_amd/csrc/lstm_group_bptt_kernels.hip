@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(116))) void 
 }  // namespace
 
 size_t fsn_lstm2_group_bptt_flag_words(int clusters) { return (size_t)clusters * 2 * BFS + 16; }
+size_t fsn_lstm2_group_bptt_status_word(int clusters) { return (size_t)clusters * 2 * BFS; }
 
 // Rows [0, 64 clusters) of the two layers: dh1 [Tp][Nrows][H]; whh1T_p / wih1T_p / whh0T_p = W_hh1 / W_ih1 / W_hh0
 // packed TRANSPOSED ([H/16][4H/16][64][4], fsn_launch_pack(..., transposed = 1)) in one buffer; save0 / save1 in

@@ -394,6 +394,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void 
 
 size_t fsn_lstm2_group_exchange_floats(int clusters) { return (size_t)clusters * (GD0 + 2) * GROWS * GH; }
 size_t fsn_lstm2_group_flag_words(int clusters) { return (size_t)clusters * 2 * GFS + 16; }
+size_t fsn_lstm2_group_status_word(int clusters) { return (size_t)clusters * 2 * GFS; }
 
 // Clusters of 64 rows that run on the group kernel for `tiles` 16-row tiles: at most one cluster per eight CUs (its 16
 // workgroups, two per CU, must all be resident at once); what is left runs step by step beside it.
