@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfsn_hip.so")
-SOURCES = ["fft_kernels.hip", "dft_kernels.hip", "elementwise_kernels.hip", "gemm_kernels.hip", "gemm_f16x3_kernels.hip", "lstm_kernels.hip", "lstm_group_kernels.hip", "lstm_group_bptt_kernels.hip", "fb_chain_kernels.hip", "lstm_f16x3_kernels.hip",
+SOURCES = ["fft_kernels.hip", "dft_kernels.hip", "elementwise_kernels.hip", "gemm_kernels.hip", "gemm_f16x3_kernels.hip", "lstm_kernels.hip", "lstm_group_kernels.hip", "lstm_group_bptt_kernels.hip", "fb_chain_kernels.hip", "fb_chain_bptt_kernels.hip", "lstm_f16x3_kernels.hip",
            "lstm_train_kernels.hip", "gru_kernels.hip", "optim_kernels.hip", "fsn_api.hip"]
 # -ffp-contract=off: elementwise code follows the reference's mul/add rounding sequence; fused
 # multiply-adds are written explicitly (fma / MFMA) where they are wanted.

@@ -1,0 +1,254 @@
+// Back-propagation through time of the full-band model's two LSTM layers (training step; 16 rows = one row tile,
+// H = 512) as ONE persistent launch: the backward counterpart of fb_chain_kernels.hip, with the work split of
+// lstm_group_bptt_kernels.hip.
+//
+//   layer 1: dh1_t = dH1_t + dgates1_{t+1} W_hh1 -> cell derivative -> dgates1_t
+//   layer 0: dh0_t = dgates1_t W_ih1 + dgates0_{t+1} W_hh0 -> ... -> dgates0_t
+// As 2 x 193 launches of bptt_step_kernel<1, 1, 16> (7.8 us each) this was 3.0 ms of a 45 ms training step.  Here:
+//   - two stages of H / 16 = 32 workgroups: L1 and L0.  A workgroup owns 16 hidden units = one 16-column MFMA tile of
+//     dh for the 16 rows; K = 2048 gate columns is split over its four waves (fixed-order sum through LDS); its slice of
+//     every W^T it needs (2048 x 16 floats each) is read ONCE into registers;
+//   - dgates1_{t+1} W_ih1 (layer 0's dH of step t + 1) has the same A operand as layer 1's own product: the L1
+//     workgroup forms it from the same A fragments AFTER publishing dgates1_t, while its partners' flags are on their
+//     way, and hands the four partial tiles over (summed by L0's reduction); L0 is left with one product;
+//   - the gate-gradient buffers dgates[t] ([16][2048] per step; the weight-gradient GEMMs read them afterwards) are the
+//     exchange buffers: write-through stores, drain, flag copies; one wave polls; sc1 loads; nothing is reused;
+//   - the saved activations of a step are requested AFTER the A fragments (loads return in order: requested first they
+//     would hold the MFMAs up for an HBM latency).
+#include "fsn_common.h"
+
+namespace {
+
+constexpr int QH = 512;           // hidden units per layer
+constexpr int QG = 4 * QH;        // gate columns = K
+constexpr int QKC = QG / 16;      // K chunks (128)
+constexpr int QCW = QKC / 4;      // K chunks per wave (32)
+constexpr int QNW = QH / 16;      // workgroups per stage (32)
+constexpr int QREP = 4;           // copies of a stage's flag array
+constexpr unsigned kQSpin = 1u << 21;
+
+struct ChainBpttArgs {
+    const float* dh1;     // [Tp][16][H]  d loss / d hseq1
+    const float *whh1T_p, *wih1T_p, *whh0T_p;  // W^T packed [H/16][4H/16][64][4]
+    const float *gates0, *cseq0, *gates1, *cseq1;  // saved by the forward pass: [Tp][16][4H], [Tp][16][H]
+    float *dg0, *dg1;     // [Tp][16][4H]: gate gradients (outputs and exchange buffers)
+    float* dx;            // [Tp][QNW][4 waves][64][4]: partial tiles of dgates1_t W_ih1 (layer 0's dH)
+    unsigned* flags;      // [2][QREP][QNW]: steps published by (L1 | L0, workgroup)
+    unsigned* status;
+    int Tp;
+};
+
+// wave 0: all 32 flags of a stage copy >= epoch and (optionally) one more flag >= its epoch; bounded
+__device__ __forceinline__ bool qwait(const unsigned* flags, unsigned epoch, const unsigned* one, unsigned one_epoch,
+                                      unsigned* status) {
+    const int lane = threadIdx.x & 63;
+    for (unsigned spins = 0;; ++spins) {
+        unsigned v = ~0u, w = ~0u;
+        if (epoch > 0 && lane < QNW) v = __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (one && lane == 0) w = __hip_atomic_load(one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all((int)(v >= epoch && w >= one_epoch))) return true;
+        if ((spins & 255u) == 255u) {
+            const unsigned st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (st != 0 || spins >= kQSpin) {
+                if (lane == 0 && st == 0) __hip_atomic_store(status, 1u + epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void fb_chain_bptt_kernel(const ChainBpttArgs a) {
+    __shared__ f32x4 red[3][64];
+    const int l1 = (int)blockIdx.x < QNW ? 1 : 0, j = (int)blockIdx.x % QNW;  // first half of the grid: layer 1
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int Tp = a.Tp;
+    unsigned* fl1 = a.flags;                 // [QREP][QNW]
+    unsigned* fl0 = a.flags + QREP * QNW;
+    const int rep = j % QREP;
+    const unsigned lane16 = (unsigned)lane * 16u;
+
+    // this wave's K quarter of column tile j of a packed W^T: chunk kc's fragment is 1 KB at ((j KC + kc) 64 + lane) 4
+    auto load_w = [&](const float* packed, f32x4 (&w)[QCW]) {
+        const float* wp = packed + ((size_t)j * QKC * 64 + lane) * 4 + (size_t)(wave * QCW) * 256;
+#pragma unroll
+        for (int q = 0; q < QCW; ++q) w[q] = *reinterpret_cast<const f32x4*>(wp + (size_t)q * 256);
+    };
+    // step t of a [Tp][16][...] buffer as a buffer resource
+    auto slab = [&](const float* p, int t, int width) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p) + (size_t)t * 16 * width, 0, 16 * width * 4, 0x00020000);
+    };
+    // this wave's A fragments of dgates[t] (row lr, k = 16 kc + 4 lq ..): sc1 loads, all in flight at once
+    const unsigned a_off = (unsigned)((lr * QG + 4 * lq) * 4);
+    auto load_a = [&](f32x4 (&ar)[QCW], const float* dg, int t) {
+        const __amdgpu_buffer_rsrc_t r = slab(dg, t, QG);
+#pragma unroll
+        for (int q = 0; q < QCW; ++q)
+            ar[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, a_off, (unsigned)((wave * QCW + q) * 64), 16));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mac = [&](f32x4 acc, const f32x4 (&ar)[QCW], const f32x4 (&w)[QCW]) -> f32x4 {
+#pragma unroll
+        for (int q = 0; q < QCW; ++q)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc = mfma16(ar[q][jj], w[q][jj], acc);
+        return acc;
+    };
+    auto reduce = [&](f32x4 acc) -> f32x4 {  // -> wave 0, fixed order 1, 2, 3
+        if (wave > 0) red[wave - 1][lane] = acc;
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const f32x4 o = red[p][lane];
+                acc = f32x4{acc[0] + o[0], acc[1] + o[1], acc[2] + o[2], acc[3] + o[3]};
+            }
+        }
+        return acc;
+    };
+    auto publish = [&](unsigned* flags, unsigned epoch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if ((int)threadIdx.x < QREP)
+            __hip_atomic_store(flags + (size_t)threadIdx.x * QNW + j, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // element (row 4 lq + i, unit 16 j + lr) of a step's slabs: one lane offset, compile-time scalar offsets
+    const unsigned voff_g = (unsigned)(((4 * lq) * QG + j * 16 + lr) * 4);
+    const unsigned voff_h = (unsigned)(((4 * lq) * QH + j * 16 + lr) * 4);
+    auto ldf = [&](const __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    };
+    const float* gates = l1 ? a.gates1 : a.gates0;
+    const float* cseq = l1 ? a.cseq1 : a.cseq0;
+    float* dgout = l1 ? a.dg1 : a.dg0;
+    const unsigned dx_wave = (unsigned)(((size_t)j * 4 + wave) * 1024);  // this wave's partial tile inside a step of dx
+    const unsigned dx_step = (unsigned)QNW * 4096u;
+    const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(a.dx, 0, 0x7fffffff, 0x00020000);
+    float dc[4] = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 whh[QCW], ar[QCW];
+    load_w(l1 ? a.whh1T_p : a.whh0T_p, whh);
+
+    // cell derivative of rows 4 lq + i, unit 16 j + lr (wave 0) from dh -> dgates_t (write-through)
+    auto cell = [&](int t, f32x4 dh, const float (&e_g)[4][4], const float (&e_ct)[4], const float (&e_cp)[4]) {
+        const __amdgpu_buffer_rsrc_t ro = slab(dgout, t, QG);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float ig = e_g[i][0], fg = e_g[i][1], gg = e_g[i][2], og = e_g[i][3];
+            const float tc = tanhf(e_ct[i]);
+            const float d_o = dh[i] * tc;
+            const float dct = dc[i] + dh[i] * og * (1.f - tc * tc);
+            const unsigned so = (unsigned)(i * QG * 4);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dct * gg * ig * (1.f - ig)), ro, voff_g, so, 16);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dct * e_cp[i] * fg * (1.f - fg)), ro, voff_g, so + QH * 4, 16);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dct * ig * (1.f - gg * gg)), ro, voff_g, so + 2 * QH * 4, 16);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d_o * og * (1.f - og)), ro, voff_g, so + 3 * QH * 4, 16);
+            dc[i] = dct * fg;
+        }
+    };
+    // saved activations of step t for wave 0's 4 elements (requested after the A fragments)
+    auto load_saved = [&](int t, float (&e_g)[4][4], float (&e_ct)[4], float (&e_cp)[4], float (&e_dh)[4]) {
+        const __amdgpu_buffer_rsrc_t rg = slab(gates, t, QG), rc = slab(cseq, t, QH), rp = slab(cseq, t > 0 ? t - 1 : 0, QH),
+                                     rd = slab(l1 ? a.dh1 : cseq, t, QH);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) e_g[i][g] = ldf(rg, voff_g, (unsigned)((i * QG + g * QH) * 4));
+            e_ct[i] = ldf(rc, voff_h, (unsigned)(i * QH * 4));
+            e_cp[i] = t > 0 ? ldf(rp, voff_h, (unsigned)(i * QH * 4)) : 0.f;
+            e_dh[i] = l1 ? ldf(rd, voff_h, (unsigned)(i * QH * 4)) : 0.f;
+        }
+    };
+
+    if (l1) {
+        f32x4 wih[QCW];
+        load_w(a.wih1T_p, wih);
+        // iteration t: dgates1_t (t >= 0) and the partial tiles of dgates1_{t+1} W_ih1 (t < Tp - 1), both from the A
+        // fragments of dgates1_{t+1}; t = -1 only produces dx_0.  Epoch Tp - t is published after dgates1_t is stored
+        // and drained; the dx tile of step t + 1 is stored after that flag and covered by the NEXT drain: complete once
+        // this workgroup has published Tp - t + 1.
+        for (int t = Tp - 1; t >= -1; --t) {
+            const unsigned done = (unsigned)(Tp - 1 - t);
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            float e_g[4][4], e_ct[4], e_cp[4], e_dh[4];
+            if (t < Tp - 1) {
+                if (wave == 0) (void)qwait(fl1 + rep * QNW, done, nullptr, 0, a.status);
+                __syncthreads();
+                load_a(ar, a.dg1, t + 1);
+            }
+            if (t >= 0) {
+                if (wave == 0) load_saved(t, e_g, e_ct, e_cp, e_dh);
+                if (t < Tp - 1) acc = mac(acc, ar, whh);
+                acc = reduce(acc);
+                if (wave == 0)
+                    cell(t, f32x4{acc[0] + e_dh[0], acc[1] + e_dh[1], acc[2] + e_dh[2], acc[3] + e_dh[3]}, e_g, e_ct, e_cp);
+            }
+            publish(fl1, done + 1);
+            if (t < Tp - 1) {
+                const f32x4 accx = mac(f32x4{0.f, 0.f, 0.f, 0.f}, ar, wih);
+                const unsigned so = (unsigned)(t + 1) * dx_step + dx_wave;
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1" ::"v"(accx), "v"(lane16), "s"(rdx), "s"(so) : "memory");
+            }
+        }
+        publish(fl1, (unsigned)Tp + 2);  // covers dx_0
+        return;
+    }
+    // ---- L0: dh0_t = dx_t (four partial tiles from L1 workgroup j, one per wave) + dgates0_{t+1} W_hh0 -------------
+    for (int t = Tp - 1; t >= 0; --t) {
+        const unsigned done = (unsigned)(Tp - 1 - t);
+        // dx_t was stored by L1 workgroup j in its iteration t - 1, complete at its epoch Tp - (t - 1) + 1 = done + 3
+        if (wave == 0) (void)qwait(fl0 + rep * QNW, done, fl1 + rep * QNW + j, done + 3, a.status);
+        __syncthreads();
+        f32x4 acc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdx, lane16, (unsigned)t * dx_step + dx_wave, 16));
+        float e_g[4][4], e_ct[4], e_cp[4], e_dh[4];
+        if (t < Tp - 1) load_a(ar, a.dg0, t + 1);
+        if (wave == 0) load_saved(t, e_g, e_ct, e_cp, e_dh);
+        if (t < Tp - 1) acc = mac(acc, ar, whh);
+        acc = reduce(acc);
+        if (wave == 0) cell(t, acc, e_g, e_ct, e_cp);
+        publish(fl0, done + 1);
+    }
+}
+
+}  // namespace
+
+bool fsn_fb_chain_bptt_supported(int H, int N) {
+    if (H != QH || N != 16) return false;
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return false;
+    return cus >= 2 * QNW;
+}
+size_t fsn_fb_chain_bptt_dx_floats(int Tp) { return (size_t)Tp * QNW * 1024; }
+size_t fsn_fb_chain_bptt_flag_words() { return (size_t)2 * QREP * QNW + 16; }
+size_t fsn_fb_chain_bptt_status_word() { return (size_t)2 * QREP * QNW; }
+
+// dh1 [Tp][16][H]; W^T matrices packed by fsn_launch_pack(..., transposed = 1); save0 / save1 in
+// fsn_lstm_layer_forward's layout; dg0 / dg1 [Tp][16][4H] out; dx: fsn_fb_chain_bptt_dx_floats(Tp) scratch.
+int fsn_launch_fb_chain_bptt(const float* dh1, const float* whh1T_p, const float* wih1T_p, const float* whh0T_p,
+                             const float* save0, const float* save1, float* dg0, float* dg1, float* dx, unsigned* flags,
+                             int Tp, int N, int H, hipStream_t s) {
+    if (!fsn_fb_chain_bptt_supported(H, N) || Tp < 1) {
+        fsn_set_error("fb_chain_bptt: built for H = 512 and 16 rows");
+        return FSN_ERR_ARG;
+    }
+    if (fsn_launch_zero_words(flags, fsn_fb_chain_bptt_flag_words(), s) != FSN_OK) return FSN_ERR_LAUNCH;
+    ChainBpttArgs a{};
+    a.dh1 = dh1;
+    a.whh1T_p = whh1T_p;
+    a.wih1T_p = wih1T_p;
+    a.whh0T_p = whh0T_p;
+    a.gates0 = save0;
+    a.cseq0 = save0 + (size_t)Tp * 16 * QG;
+    a.gates1 = save1;
+    a.cseq1 = save1 + (size_t)Tp * 16 * QG;
+    a.dg0 = dg0;
+    a.dg1 = dg1;
+    a.dx = dx;
+    a.flags = flags;
+    a.status = flags + fsn_fb_chain_bptt_status_word();
+    a.Tp = Tp;
+    hipLaunchKernelGGL(fb_chain_bptt_kernel, dim3(2 * QNW), dim3(256), 0, s, a);
+    return fsn_check_launch("fb_chain_bptt_kernel");
+}

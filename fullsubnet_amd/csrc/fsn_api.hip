@@ -1860,6 +1860,16 @@ extern "C" size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H) {
         cv.take<char>(tn > tn2 ? tn : tn2);
         return fsn_round_up_sz(cv.off, 256);
     }
+    if (fsn_fb_chain_bptt_supported(H, N)) {
+        cv.take<float>((size_t)3 * H * G + (size_t)Ipad * G);  // W_hh1^T, W_ih1^T, W_hh0^T, W_ih0^T fragments
+        cv.take<float>((size_t)2 * T * N * G);                 // dgates of both layers
+        cv.take<float>(fsn_fb_chain_bptt_dx_floats(T));
+        cv.take<unsigned>(fsn_fb_chain_bptt_flag_words());
+        size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
+        const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
+        cv.take<char>(tn > tn2 ? tn : tn2);
+        return fsn_round_up_sz(cv.off, 256);
+    }
     cv.take<float>((size_t)T * N * H);  // dh0
     cv.take<char>(l1 > l0 ? l1 : l0);
     return fsn_round_up_sz(cv.off, 256);
@@ -1880,6 +1890,58 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
         return FSN_ERR_WORKSPACE;
     }
     const int clusters = lstm2_bptt_group_clusters(T, N, I, H);
+    if (!clusters && fsn_fb_chain_bptt_supported(H, N)) {
+        // the full-band shape (16 rows, H = 512): both layers' BPTT as one persistent launch (fb_chain_bptt_kernels.hip),
+        // then the weight-gradient GEMMs
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        const int Ipad = fsn_round_up(I, 16), G = 4 * H;
+        Carver cv(workspace);
+        float* whh1T_p = cv.take<float>((size_t)3 * H * G + (size_t)Ipad * G);
+        float* wih1T_p = whh1T_p + (size_t)H * G;
+        float* whh0T_p = wih1T_p + (size_t)H * G;
+        float* wih0T_p = whh0T_p + (size_t)H * G;
+        float* dg1 = cv.take<float>((size_t)2 * T * N * G);
+        float* dg0 = dg1 + (size_t)T * N * G;
+        float* dxp = cv.take<float>(fsn_fb_chain_bptt_dx_floats(T));
+        unsigned* flags = cv.take<unsigned>(fsn_fb_chain_bptt_flag_words());
+        size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
+        const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
+        void* scratch = cv.take<char>(tn > tn2 ? tn : tn2);
+        FSN_TRY(fsn_launch_pack(w_hh1, whh1T_p, H, G, H, G, s, 1, H));
+        FSN_TRY(fsn_launch_pack(w_ih1, wih1T_p, H, G, H, G, s, 1, H));
+        FSN_TRY(fsn_launch_pack(w_hh0, whh0T_p, H, G, H, G, s, 1, H));
+        if (dx) FSN_TRY(fsn_launch_pack(w_ih0, wih0T_p, I, G, Ipad, G, s, 1, I));
+        {
+            PersistLaunch gate(s);
+            FSN_TRY(fsn_launch_fb_chain_bptt(dh1, whh1T_p, wih1T_p, whh0T_p, static_cast<const float*>(save0),
+                                             static_cast<const float*>(save1), dg0, dg1, dxp, flags, T, N, H, s));
+            FSN_TRY(fsn_launch_poison_if(flags + fsn_fb_chain_bptt_status_word(), dg0, (size_t)T * N * G, s));
+        }
+        if (dx) {
+            FsnGemmA a{};
+            a.kind = 0;
+            a.p0 = dg0;
+            a.ld = G;
+            FsnGemmC c{};
+            c.kind = 3;
+            c.p0 = dx;
+            c.ld = lddx;
+            c.rows = T * N;
+            c.cols = I;
+            FSN_TRY(fsn_launch_gemm(a, wih0T_p, c, T * (N / 16), Ipad / 16, G / 16, s));
+        }
+        FSN_TRY(fsn_launch_gemm_tn(dg1, G, hseq0, H, dw_ih1, H, G, H, (long)T * N, scratch, s, db1));
+        FSN_TRY(fsn_launch_gemm_tn(dg0, G, x, ldx, dw_ih0, I, G, I, (long)T * N, scratch, s, db0));
+        if (T > 1) {
+            FSN_TRY(fsn_launch_gemm_tn(dg1 + (size_t)N * G, G, hseq1, H, dw_hh1, H, G, H, (long)(T - 1) * N, scratch, s));
+            FSN_TRY(fsn_launch_gemm_tn(dg0 + (size_t)N * G, G, hseq0, H, dw_hh0, H, G, H, (long)(T - 1) * N, scratch, s));
+        } else if (hipMemsetAsync(dw_hh1, 0, (size_t)G * H * sizeof(float), s) != hipSuccess ||
+                   hipMemsetAsync(dw_hh0, 0, (size_t)G * H * sizeof(float), s) != hipSuccess) {
+            fsn_set_error("memset failed");
+            return FSN_ERR_LAUNCH;
+        }
+        return FSN_OK;
+    }
     if (!clusters) {  // layer by layer; layer 1's dx is d loss / d hseq0
         Carver cv(workspace);
         float* dh0 = cv.take<float>((size_t)T * N * H);

@@ -155,6 +155,14 @@ size_t fsn_lstm2_group_bptt_flag_words(int clusters);  // lstm_group_bptt_kernel
 int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const float* wih1T_p, const float* whh0T_p,
                                 const float* save0, const float* save1, float* dg0, float* dg1, float* dx, unsigned* flags,
                                 int Tp, int Nrows, int clusters, int H, hipStream_t s);
+// fb_chain_bptt_kernels.hip: BPTT of the full-band model's two layers (16 rows, H = 512) as one persistent launch
+bool fsn_fb_chain_bptt_supported(int H, int N);
+size_t fsn_fb_chain_bptt_dx_floats(int Tp);
+size_t fsn_fb_chain_bptt_flag_words();
+size_t fsn_fb_chain_bptt_status_word();
+int fsn_launch_fb_chain_bptt(const float* dh1, const float* whh1T_p, const float* wih1T_p, const float* whh0T_p,
+                             const float* save0, const float* save1, float* dg0, float* dg1, float* dx, unsigned* flags,
+                             int Tp, int N, int H, hipStream_t s);
 int fsn_launch_zero_words(unsigned* p, size_t n, hipStream_t s);  // elementwise_kernels.hip
 // out[0..n) = NaN if *status != 0 (a persistent kernel hit a spin bound); status words of the three kernels' flag arrays
 int fsn_launch_poison_if(const unsigned* status, float* out, size_t n, hipStream_t s);
