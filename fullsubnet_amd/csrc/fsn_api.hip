@@ -358,6 +358,8 @@ extern "C" int fsn_fullsubnet_pack(const fsn_fullsubnet_cfg* cfg, const fsn_full
 // below this many sub-band row tiles (batch <= 5) the two layers of the small-batch step path run as a wavefront of
 // per-step launches; from here up to the persistent regime (160 tiles) they run on the group kernel
 constexpr int kWavefrontBelowTiles = 96;
+constexpr int kGroupTwoFromTiles = 224;  // 56+ clusters: two per workgroup set
+constexpr int kGroupMaxTiles = 264;      // 64 clusters + up to 8 left-over tiles
 
 // ---- model core: magT [B][Tp][FP] -> crm_r, crm_i [B][T][FP] ------------------------------------
 struct CoreDims {
@@ -390,6 +392,15 @@ static CoreDims core_dims(const fsn_fullsubnet_cfg* c, int B, int T, long row0 =
     d.N = n_rows < 0 ? B * d.F : (int)n_rows;
     d.row0 = n_rows < 0 ? 0 : row0;
     d.rec = fsn_lstm_rec_plan(d.N, d.Hs);
+    // 224 - 264 row tiles (14 - 16 utterances: one rank's share of config 2 at 4 GPUs) run on the group kernel with two
+    // clusters per workgroup set (lstm_group_kernels.hip) instead of the persistent kernels at ONE row tile per CU
+    // (every CU streams all weights every step there): 26.5 -> 23.4 ms at 16 utterances
+    const bool grp_shape = d.Hs == 384 && fsn_round_up(2 * c->sb_num_neighbors + 2, 16) == 32 && c->arith == FSN_ARITH_F32;
+    if (grp_shape && d.rec.tiles >= kGroupTwoFromTiles && d.rec.tiles <= kGroupMaxTiles && d.rec.main_wgs > 0) {
+        d.rec.rt = 1;
+        d.rec.main_wgs = 0;
+        d.rec.left_tiles = d.rec.tiles;
+    }
     d.Npad = d.rec.npad;
     d.den_stride = n_rows < 0 ? d.Npad : fsn_round_up(B * d.F, 16);
     d.fc_fused = d.rec.main_wgs > 0 && fsn_lstm_rec_can_fuse_fc(d.rec.rt, false);

@@ -53,6 +53,7 @@ struct GrpArgs {
     // gates [Tp][Nrows][4H] and the cell state [Tp][Nrows][H] (the layouts of fsn_lstm_layer_forward)
     float *gates0, *cseq0, *gates1, *cseq1;
     int Nrows;
+    int nclusters;         // clusters of this launch (the grid has min(nclusters, CUs / 8) workgroup sets)
 };
 
 __device__ __forceinline__ void store_sc1(float* p, float v) {
@@ -82,46 +83,74 @@ __device__ __forceinline__ bool grp_poll(unsigned* flags8, unsigned epoch, unsig
 // ABL: experiment knob of tools/probe_group.hip (0 in the library; any bit set gives WRONG results): 1 no acquire
 // fence, 2 no flag polling, 4 plain instead of write-through stores, 8 no gate non-linearities, 16 no output layer,
 // 32 A fragments not loaded (a constant instead).
-template <int LAYER, int ABL, bool TRAIN>
-__device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int member, f32x4 (*bsh)[GU * 4][64]) {
+// What a workgroup keeps per cluster.  A workgroup serves one cluster, or TWO alternately (batches of 9 - 16 utterances:
+// more clusters than the chip holds at once): step t of cluster A, step t of cluster B, step t + 1 of A ... - while it
+// works on one cluster the partners' flags and write-through data of the other are on their way.
+struct GrpCl {
+    int cluster;
+    int row_l;    // this lane's A-operand row (local to the launch)
+    bool row_ok;
+    long ng;
+    int xb, xf;   // layer-0 input of this lane's row: (b, f)
+    float *hx0, *hx1;
+    unsigned *fl0, *fl1;
+    __amdgpu_buffer_rsrc_t xrsrc0, xrsrc1;
+    float c[GU][4];
+    unsigned seen0;
+};
+
+template <int LAYER, int ABL, bool TRAIN, int NCL>
+__device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int cluster_b, int member,
+                                           f32x4 (*bsh)[GU * 4][64], float (*bias_sh)[16]) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const int Tp = a.Tp;
-    const long row_l = (long)cluster * GROWS + wave * 16 + lr;  // this lane's A-operand row (local to the launch)
-    float* hx0 = a.hx0 + (TRAIN ? (size_t)cluster * GROWS * GH : (size_t)cluster * GD0 * GROWS * GH);
-    float* hx1 = a.hx1 + (TRAIN ? (size_t)cluster * GROWS * GH : (size_t)cluster * 2 * GROWS * GH);
+    const FsnSbInput& x = a.xin;
     // byte offset of the tile that holds h0_t / h1_t inside hx0 / hx1
     const unsigned step_bytes = TRAIN ? (unsigned)a.Nrows * GH * 4u : 0u;
     auto slot0 = [&](int t) { return TRAIN ? (unsigned)t * step_bytes : (unsigned)((t % GD0) * GROWS * GH * 4); };
     auto slot1 = [&](int t) { return TRAIN ? (unsigned)t * step_bytes : (unsigned)((t & 1) * GROWS * GH * 4); };
-    unsigned* fl0 = a.flags + ((size_t)cluster * 2 + 0) * GFS;
-    unsigned* fl1 = a.flags + ((size_t)cluster * 2 + 1) * GFS;
+    auto init = [&](GrpCl& k, int cluster) {
+        k.cluster = cluster;
+        k.row_l = cluster * GROWS + wave * 16 + lr;
+        k.hx0 = a.hx0 + (TRAIN ? (size_t)cluster * GROWS * GH : (size_t)cluster * GD0 * GROWS * GH);
+        k.hx1 = a.hx1 + (TRAIN ? (size_t)cluster * GROWS * GH : (size_t)cluster * 2 * GROWS * GH);
+        k.fl0 = a.flags + ((size_t)cluster * 2 + 0) * GFS;
+        k.fl1 = a.flags + ((size_t)cluster * 2 + 1) * GFS;
+        k.xrsrc0 = __builtin_amdgcn_make_buffer_rsrc(k.hx0, 0, 0x7fffffff, 0x00020000);
+        k.xrsrc1 = __builtin_amdgcn_make_buffer_rsrc(k.hx1, 0, 0x7fffffff, 0x00020000);
+        k.row_ok = k.row_l < x.N;
+        k.ng = k.row_l + x.row0;
+        k.xb = k.row_ok ? (int)(k.ng / x.F) : 0;
+        k.xf = k.row_ok ? (int)(k.ng % x.F) : 0;
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) k.c[u][i] = 0.f;
+        k.seen0 = 0u;
+    };
     // this lane's A fragment inside a [64][H] tile of the exchange buffers (byte offset), read with sc1 buffer loads: the
     // partners stored write-through (sc1), so an sc1 load - never served by this CU's L1 - needs no acquire fence
     const unsigned a_off = (unsigned)(((wave * 16 + lr) * GH + 4 * lq) * 4);
-    const __amdgpu_buffer_rsrc_t xrsrc0 = __builtin_amdgcn_make_buffer_rsrc(hx0, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t xrsrc1 = __builtin_amdgcn_make_buffer_rsrc(hx1, 0, 0x7fffffff, 0x00020000);
     auto xload = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16));  // aux 16 = sc1
     };
 
-    // layer-0 input of this lane's row: (b, f) once; element c of frame t is gathered per step
-    const FsnSbInput& x = a.xin;
-    const bool row_ok = row_l < x.N;
-    const long ng = row_l + x.row0;
-    const int xb = row_ok ? (int)(ng / x.F) : 0, xf = row_ok ? (int)(ng % x.F) : 0;
-
-    // biases of this member's 12 column tiles (registers are plentiful at two waves per SIMD)
+    // biases of this member's 12 column tiles: registers, or LDS when the workgroup keeps two clusters' state (12
+    // registers decide between fitting and spilling there; with one cluster the registers are faster)
     float bias[GU][4];
+    if (NCL > 1) {
+        if (threadIdx.x < GU * 4 * 16) {
+            const int f = threadIdx.x >> 4, u = f >> 2, g = f & 3, l = threadIdx.x & 15;
+            bias_sh[f][l] = (LAYER ? a.bias1 : a.xin.bias)[(g * GKC + member * GU + u) * 16 + l];
+        }
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int u = 0; u < GU; ++u)
+        for (int u = 0; u < GU; ++u)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bias[u][g] = (LAYER ? a.bias1 : x.bias)[(g * GKC + member * GU + u) * 16 + lr];
-    float c[GU][4];
-#pragma unroll
-    for (int u = 0; u < GU; ++u)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) c[u][i] = 0.f;
+            for (int g = 0; g < 4; ++g) bias[u][g] = (LAYER ? a.bias1 : a.xin.bias)[(g * GKC + member * GU + u) * 16 + lr];
+    }
 
     // ---- K loop: acc += A(16 rows x 16 n) B(16 n x [3 unit groups x 4 gates x 16]) over two operand segments -------
     // segment 1: n1 chunks, A from registers (xa) or from a1 (global, row stride GH), B from b1 (chunk stride 256,
@@ -133,8 +162,9 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int me
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wbase), 0, 0x7fffffff, 0x00020000);
     const unsigned lane16 = (unsigned)lane * 16u;
     // A operand: xa (registers, layer-0 input) or tile `at1` / `at2` (byte offset) of exchange buffer ab1 / ab2 (0 / 1)
-    auto kloop = [&](f32x4 (&acc)[GU][4], const f32x4* xa, int ab1, unsigned at1, unsigned b1, unsigned s1, int n1,
-                     int ab2, unsigned at2, unsigned b2, unsigned s2, int n2) {
+    // (descriptors by value: a reference to one of two descriptors puts both on the stack)
+    auto kloop = [&](f32x4 (&acc)[GU][4], const f32x4* xa, const __amdgpu_buffer_rsrc_t r1, unsigned at1, unsigned b1,
+                     unsigned s1, int n1, const __amdgpu_buffer_rsrc_t r2, unsigned at2, unsigned b2, unsigned s2, int n2) {
         const int n = n1 + n2;
         // The A fragments come from the exchange buffers, which were written through to memory by other CUs: their
         // first touch after the acquire costs a trip to the Infinity Cache / HBM, several chunks of MFMA time.  They
@@ -147,9 +177,9 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int me
             if (ABL & 32) return f32x4{0.5f, 0.25f, 0.125f, 0.0625f};
             if (kc < n1) {
                 if (xa) return kc == 0 ? xa[0] : xa[1];
-                return xload(ab1 ? xrsrc1 : xrsrc0, a_off, at1 + (unsigned)kc * 64u);
+                return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, a_off, at1 + (unsigned)kc * 64u, 16));
             }
-            return xload(ab2 ? xrsrc1 : xrsrc0, a_off, at2 + (unsigned)(kc - n1) * 64u);
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, a_off, at2 + (unsigned)(kc - n1) * 64u, 16));
         };
         auto fetch_b = [&](int k) {
             const int kc = k < n ? k : n - 1;
@@ -217,7 +247,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int me
         if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     // cell update of this wave's 16 rows x 48 units; h_t slice -> exchange buffer
-    auto cell = [&](f32x4 (&acc)[GU][4], float* hdst, float* gates_t, float* cseq_t) {
+    auto cell = [&](GrpCl& k, f32x4 (&acc)[GU][4], float* hdst, float* gates_t, float* cseq_t) {
 #pragma unroll
         for (int u = 0; u < GU; ++u)
 #pragma unroll
@@ -229,14 +259,14 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int me
                     ig = sigmoid_fast(acc[u][0][i]), fg = sigmoid_fast(acc[u][1][i]);
                     gg = tanh_fast(acc[u][2][i]), og = sigmoid_fast(acc[u][3][i]);
                 }
-                const float cn = fg * c[u][i] + ig * gg;
-                c[u][i] = cn;
+                const float cn = fg * k.c[u][i] + ig * gg;
+                k.c[u][i] = cn;
                 float* hp = hdst + (size_t)(wave * 16 + 4 * lq + i) * GH + (member * GU + u) * 16 + lr;
                 const float hv = (ABL & 8) ? og * cn : og * tanh_fast(cn);
                 if (ABL & 4) *hp = hv;
                 else store_sc1(hp, hv);
                 if (TRAIN) {  // rows of this cluster inside step t's [Nrows][...] slabs
-                    const size_t row = (size_t)cluster * GROWS + wave * 16 + 4 * lq + i;
+                    const size_t row = (size_t)k.cluster * GROWS + wave * 16 + 4 * lq + i;
                     const int unit = (member * GU + u) * 16 + lr;
                     float* gp = gates_t + row * (4 * GH) + unit;
                     gp[0] = ig;
@@ -249,76 +279,88 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int me
     };
 
     if (LAYER == 0) {
-        for (int t = 0; t < Tp; ++t) {
+        auto iter0 = [&](int t, GrpCl& k) {
             // the layer-0 input of this lane's row at frame t (two A fragments: columns 4 lq .. and 16 + 4 lq ..):
             // requested now, divided after the wait below
             float raw[8];
-            const float den = (row_ok && !TRAIN) ? x.den[x.den_mode ? (long)t * x.den_stride + ng : (long)xb] : 1.f;
+            const float den = (k.row_ok && !TRAIN) ? x.den[x.den_mode ? (long)t * x.den_stride + k.ng : (long)k.xb] : 1.f;
             if (TRAIN) {  // plain row-major input [Tp][x_step][x_ld], 32 columns (zero-padded by the caller)
-                const float* xr = x.x_rows + ((long)t * x.x_step + (row_ok ? row_l : 0)) * x.x_ld + 4 * lq;
+                const float* xr = x.x_rows + ((long)t * x.x_step + (k.row_ok ? k.row_l : 0)) * x.x_ld + 4 * lq;
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(xr), v1 = *reinterpret_cast<const f32x4*>(xr + 16);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) raw[e] = v0[e], raw[4 + e] = v1[e];
             } else {
-                const long fo = ((long)xb * x.Tp + t) * x.FP;
+                const long fo = ((long)k.xb * x.Tp + t) * x.FP;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int cc = (e >> 2) * 16 + 4 * lq + (e & 3);
-                    int jj = xf + cc - x.nb;
+                    int jj = k.xf + cc - x.nb;
                     jj = jj < 0 ? -jj : jj;
                     jj = jj >= x.F ? 2 * (x.F - 1) - jj : jj;
-                    const bool ok = row_ok && cc <= 2 * x.nb + 1;
-                    const float* src = cc <= 2 * x.nb ? x.mag + fo + jj : x.fb_out + fo + xf;
+                    const bool ok = k.row_ok && cc <= 2 * x.nb + 1;
+                    const float* src = cc <= 2 * x.nb ? x.mag + fo + jj : x.fb_out + fo + k.xf;
                     raw[e] = *(ok ? src : x.mag);
                 }
             }
-            if (t > 0) wait_peeked(peek(fl0), fl0, (unsigned)t);  // h0_{t-1} of all members (just published: polls)
+            if (t > 0) wait_peeked(peek(k.fl0), k.fl0, (unsigned)t);  // h0_{t-1} of all members (just published: polls)
             f32x4 xa[2];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int cc = (e >> 2) * 16 + 4 * lq + (e & 3);
-                if (TRAIN) xa[e >> 2][e & 3] = row_ok ? raw[e] : 0.f;
-                else xa[e >> 2][e & 3] = (row_ok && cc <= 2 * x.nb + 1) ? raw[e] / den : 0.f;
+                if (TRAIN) xa[e >> 2][e & 3] = k.row_ok ? raw[e] : 0.f;
+                else xa[e >> 2][e & 3] = (k.row_ok && cc <= 2 * x.nb + 1) ? raw[e] / den : 0.f;
             }
             f32x4 acc[GU][4];
 #pragma unroll
             for (int u = 0; u < GU; ++u)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[u][g] = f32x4{bias[u][g], bias[u][g], bias[u][g], bias[u][g]};
-            const unsigned ring = t >= GD0 ? peek(fl1) : 0xffffffffu;
-            kloop(acc, xa, 0, 0, a.o_wih0, 2, 2, 0, t > 0 ? slot0(t - 1) : 0u, a.o_whh0, GKC, t > 0 ? GKC : 0);
+                for (int g = 0; g < 4; ++g) {
+                    const float b = NCL > 1 ? bias_sh[u * 4 + g][lr] : bias[u][g];
+                    acc[u][g] = f32x4{b, b, b, b};
+                }
+            const unsigned ring = t >= GD0 ? peek(k.fl1) : 0xffffffffu;
+            kloop(acc, xa, k.xrsrc0, 0, a.o_wih0, 2, 2, k.xrsrc0, t > 0 ? slot0(t - 1) : 0u, a.o_whh0, GKC, t > 0 ? GKC : 0);
             // slot t % GD0 still holds h0_{t-GD0}: layer 1 must have finished its step t - GD0 (it reads that slot
             // there) - all eight layer-1 members, i.e. they have published step t - GD0 + 1
-            if (t >= GD0) wait_peeked(ring, fl1, (unsigned)(t - GD0 + 1));
-            cell(acc, reinterpret_cast<float*>(reinterpret_cast<char*>(hx0) + slot0(t)),
+            if (t >= GD0) wait_peeked(ring, k.fl1, (unsigned)(t - GD0 + 1));
+            cell(k, acc, reinterpret_cast<float*>(reinterpret_cast<char*>(k.hx0) + slot0(t)),
                  TRAIN ? a.gates0 + (size_t)t * a.Nrows * 4 * GH : nullptr, TRAIN ? a.cseq0 + (size_t)t * a.Nrows * GH : nullptr);
-            publish(fl0 + member, (unsigned)t + 1);
+            publish(k.fl0 + member, (unsigned)t + 1);
+        };
+        GrpCl ka, kb;
+        init(ka, cluster_a);
+        if (NCL > 1 && cluster_b >= 0) init(kb, cluster_b);
+        for (int t = 0; t < Tp; ++t) {
+            iter0(t, ka);
+            if (NCL > 1 && cluster_b >= 0) iter0(t, kb);
         }
     } else {
         // output layer: thread (d = tid >> 4, p = tid & 15) owns 24 of the 384 terms of dot product d (row d >> 1 of
         // this member's eight rows, output d & 1)
         const int d = threadIdx.x >> 4, p = threadIdx.x & 15;
         const int frow = member * 8 + (d >> 1), fcc = d & 1;
-        unsigned seen0 = peek(fl0);
-        for (int s = 0; s <= (TRAIN ? Tp - 1 : Tp); ++s) {
+        auto iter1 = [&](int s, GrpCl& k) {
             // Step s: x_s W_ih^T first - it only needs h0_s, which layer 0 published long ago - so that the partners'
             // h1_{s-1}, published a moment ago, has a whole half K loop to arrive before anyone waits for it.  The extra
             // iteration s = Tp only computes the output layer of the last step.
             f32x4 acc[GU][4];
             unsigned seen1 = 0xffffffffu;
             if (s < Tp) {
-                wait_peeked(seen0, fl0, (unsigned)s + 1);
-                seen1 = peek(fl1);
+                wait_peeked(k.seen0, k.fl0, (unsigned)s + 1);
+                seen1 = peek(k.fl1);
 #pragma unroll
                 for (int u = 0; u < GU; ++u)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[u][g] = f32x4{bias[u][g], bias[u][g], bias[u][g], bias[u][g]};
-                kloop(acc, nullptr, 0, slot0(s), a.o_wih1, GKC, GKC, 0, 0, 0, 0, 0);
+                    for (int g = 0; g < 4; ++g) {
+                        const float b = NCL > 1 ? bias_sh[u * 4 + g][lr] : bias[u][g];
+                        acc[u][g] = f32x4{b, b, b, b};
+                    }
+                kloop(acc, nullptr, k.xrsrc0, slot0(s), a.o_wih1, GKC, GKC, k.xrsrc0, 0, 0, 0, 0);
             } else {
-                seen1 = peek(fl1);
+                seen1 = peek(k.fl1);
             }
             if (s > 0) {
-                wait_peeked(seen1, fl1, (unsigned)s);  // h1_{s-1} of all members
+                wait_peeked(seen1, k.fl1, (unsigned)s);  // h1_{s-1} of all members
                 // Output layer (nn.Linear(384, 2)) of step s - 1 for rows 8 m .. 8 m + 7 of the cluster, from h1_{s-1} as
                 // it has just been gathered: 16 dot products x 16 threads (~1 us, covered by the layer-0 workgroup
                 // that shares the CU)
@@ -328,7 +370,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int me
 #pragma unroll
                     for (int q = 0; q < 6; ++q) {
                         const int kk = p * 24 + 4 * q;  // four consecutive k: one 16-byte group of the packed weights
-                        hv[q] = xload(xrsrc1, hoff, 16u * q);
+                        hv[q] = xload(k.xrsrc1, hoff, 16u * q);
                         fw[q] = *reinterpret_cast<const f32x4*>(a.fc.w_p + (((kk >> 4) * 64) + ((kk & 15) >> 2) * 16 + fcc) * 4);
                     }
                     float acc1 = 0.f;
@@ -340,7 +382,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int me
                     acc1 += __shfl_xor(acc1, 2, 64);
                     acc1 += __shfl_xor(acc1, 4, 64);
                     acc1 += __shfl_xor(acc1, 8, 64);
-                    const long n = (long)cluster * GROWS + frow;
+                    const long n = (long)k.cluster * GROWS + frow;
                     const int so = s - 1;
                     if (p == 0 && so >= a.fc.la && n < a.fc.N) {
                         const long ngl = n + a.fc.row0;
@@ -349,45 +391,60 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster, int me
                     }
                 }
             }
-            seen0 = peek(fl0);  // for the next step: layer 0 is ahead, this usually shows s + 2 already
+            k.seen0 = peek(k.fl0);  // for the next step: layer 0 is ahead, this usually shows s + 2 already
             if (s > 0 && s < Tp)
-                kloop(acc, nullptr, 1, slot1(s - 1), a.o_whh1, GKC, GKC, 0, 0, 0, 0, 0);
+                kloop(acc, nullptr, k.xrsrc1, slot1(s - 1), a.o_whh1, GKC, GKC, k.xrsrc1, 0, 0, 0, 0);
             if (s < Tp) {
                 // slot s & 1 held h1_{s-2}: read by every member in step s - 1, which they have left (flag1 >= s above)
-                cell(acc, reinterpret_cast<float*>(reinterpret_cast<char*>(hx1) + slot1(s)),
+                cell(k, acc, reinterpret_cast<float*>(reinterpret_cast<char*>(k.hx1) + slot1(s)),
                      TRAIN ? a.gates1 + (size_t)s * a.Nrows * 4 * GH : nullptr, TRAIN ? a.cseq1 + (size_t)s * a.Nrows * GH : nullptr);
-                publish(fl1 + member, (unsigned)s + 1);
+                publish(k.fl1 + member, (unsigned)s + 1);
             }
+        };
+        GrpCl ka, kb;
+        init(ka, cluster_a);
+        ka.seen0 = peek(ka.fl0);
+        if (NCL > 1 && cluster_b >= 0) {
+            init(kb, cluster_b);
+            kb.seen0 = peek(kb.fl0);
+        }
+        for (int s = 0; s <= (TRAIN ? Tp - 1 : Tp); ++s) {
+            iter1(s, ka);
+            if (NCL > 1 && cluster_b >= 0) iter1(s, kb);
         }
     }
 }
 
-template <int ABL, bool TRAIN = false>
+template <int ABL, bool TRAIN = false, int NCL = 1>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void lstm2_group_kernel(const GrpArgs a) {
     // weight fragments of one K chunk, shared by the four waves: two stages x 12 fragments x 1 KB
     __shared__ f32x4 bsh[2][GU * 4][64];
+    __shared__ float bias_sh[GU * 4][16];
     // The first half of the grid runs layer 0, the second half layer 1: blocks are handed out in order, one per CU
     // before any CU gets its second, so that every CU ends up with one workgroup of each layer (speed only).  Within a
     // half: observed, block b runs on XCD b % 8; when the cluster count allows it the eight members of a cluster are
     // blocks with the same b % 8, i.e. share one L2 (speed only as well).
+    // The grid holds `slots` = min(clusters, CUs / 8) workgroup sets; slot s serves cluster s and, when there are more
+    // clusters than slots, cluster s + slots as well (alternately, see GrpCl).
     const int half = gridDim.x >> 1;
     const int layer = (int)blockIdx.x >= half ? 1 : 0;
     const int bid = (int)blockIdx.x - layer * half;
-    const int nclusters = half / GM;
-    int cluster, member;
-    if (nclusters % 8 == 0) {
+    const int slots = half / GM;
+    int slot, member;
+    if (slots % 8 == 0) {
         const int xcd = bid & 7, j = bid >> 3;  // j-th block of that XCD
-        cluster = xcd * (nclusters / 8) + j / GM;
+        slot = xcd * (slots / 8) + j / GM;
         member = j % GM;
     } else {
-        cluster = bid / GM;
+        slot = bid / GM;
         member = bid % GM;
     }
+    const int cluster = slot, cluster_b = slot + slots < a.nclusters ? slot + slots : -1;
     // Layer 1 is the longer dependent chain (K = 768 per step against 416) and layer 0 is throttled to stay within
     // GD0 - 2 steps of it: layer 1's waves issue first, layer 0's fill the gaps.
     if (layer == 1 && !(ABL & 64)) __builtin_amdgcn_s_setprio(2);
-    if (layer == 0) group_body<0, ABL, TRAIN>(a, cluster, member, bsh);
-    else group_body<1, ABL, TRAIN>(a, cluster, member, bsh);
+    if (layer == 0) group_body<0, ABL, TRAIN, NCL>(a, cluster, cluster_b, member, bsh, bias_sh);
+    else group_body<1, ABL, TRAIN, NCL>(a, cluster, cluster_b, member, bsh, bias_sh);
 }
 
 }  // namespace
@@ -398,11 +455,18 @@ size_t fsn_lstm2_group_status_word(int clusters) { return (size_t)clusters * 2 *
 
 // Clusters of 64 rows that run on the group kernel for `tiles` 16-row tiles: at most one cluster per eight CUs (its 16
 // workgroups, two per CU, must all be resident at once); what is left runs step by step beside it.
-int fsn_lstm2_group_clusters(int tiles) {
+static int grp_slots_cap() {
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int cap = cus / GM;
+    return cus / GM;
+}
+// One cluster per workgroup set (one set per eight CUs: its 16 workgroups, two per CU, must all be resident), or two
+// when (nearly) every set gets two: a launch takes the time of its fullest set - measured 22.3 ms for 64 clusters
+// against 11.7 ms for 32, so 33 - 55 clusters are better off with one launch of 32 and the rest elsewhere.
+int fsn_lstm2_group_clusters(int tiles) {
+    const int cap = grp_slots_cap();
     const int c = tiles / 4;
+    if (c >= 2 * cap - cap / 4) return c < 2 * cap ? c : 2 * cap;
     return c < cap ? c : cap;
 }
 
@@ -437,7 +501,10 @@ int fsn_launch_lstm2_group(const FsnSbInput* xin, const float* whh0_p, const flo
     a.status = flags + (size_t)clusters * 2 * GFS;
     a.fc = *fc;
     a.Tp = Tp;
-    hipLaunchKernelGGL((lstm2_group_kernel<0, false>), dim3((unsigned)clusters * GM * 2), dim3(256), 0, s, a);
+    a.nclusters = clusters;
+    const int cap = grp_slots_cap(), slots = clusters < cap ? clusters : cap;
+    if (clusters > slots) hipLaunchKernelGGL((lstm2_group_kernel<0, false, 2>), dim3((unsigned)slots * GM * 2), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((lstm2_group_kernel<0, false, 1>), dim3((unsigned)slots * GM * 2), dim3(256), 0, s, a);
     return fsn_check_launch("lstm2_group_kernel");
 }
 
@@ -484,6 +551,9 @@ int fsn_launch_lstm2_group_train(const float* x, long x_ld, int Nrows, const flo
     a.gates1 = save1;
     a.cseq1 = save1 + (size_t)Tp * Nrows * 4 * GH;
     a.Nrows = Nrows;
-    hipLaunchKernelGGL((lstm2_group_kernel<0, true>), dim3((unsigned)clusters * GM * 2), dim3(256), 0, s, a);
+    a.nclusters = clusters;
+    const int cap = grp_slots_cap(), slots = clusters < cap ? clusters : cap;
+    if (clusters > slots) hipLaunchKernelGGL((lstm2_group_kernel<0, true, 2>), dim3((unsigned)slots * GM * 2), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((lstm2_group_kernel<0, true, 1>), dim3((unsigned)slots * GM * 2), dim3(256), 0, s, a);
     return fsn_check_launch("lstm2_group_kernel (training)");
 }
