@@ -1849,7 +1849,7 @@ extern "C" int fsn_lstm_layer_backward(const float* dh, const float* x, long ldx
 // layer-to-layer dX included - as ONE persistent launch (lstm_group_bptt_kernels.hip).
 static int lstm2_bptt_group_clusters(int T, int N, int I, int H) {
     if (H != 384 || N / 16 < kWavefrontBelowTiles) return 0;
-    const int c = fsn_lstm2_group_clusters(N / 16);
+    const int c = fsn_lstm2_group_bptt_clusters(N / 16);
     (void)I;
     return N / 16 - 4 * c <= 8 ? c : 0;
 }

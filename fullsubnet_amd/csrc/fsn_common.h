@@ -152,6 +152,7 @@ int fsn_launch_bias_sum(const float* a, const float* b, float* out, int n, int n
 int fsn_launch_bias_frag(const float* bias, float* frag, int n, hipStream_t s);
 
 size_t fsn_lstm2_group_bptt_flag_words(int clusters);  // lstm_group_bptt_kernels.hip
+int fsn_lstm2_group_bptt_clusters(int tiles);
 int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const float* wih1T_p, const float* whh0T_p,
                                 const float* save0, const float* save1, float* dg0, float* dg1, float* dx, unsigned* flags,
                                 int Tp, int Nrows, int clusters, int H, hipStream_t s);

@@ -339,6 +339,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(116))) void 
 
 }  // namespace
 
+// one cluster per workgroup set: at most CUs / 8 clusters
+int fsn_lstm2_group_bptt_clusters(int tiles) {
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cap = cus / BM, c = tiles / 4;
+    return c < cap ? c : cap;
+}
 size_t fsn_lstm2_group_bptt_flag_words(int clusters) { return (size_t)clusters * 2 * BFS + 16; }
 size_t fsn_lstm2_group_bptt_status_word(int clusters) { return (size_t)clusters * 2 * BFS; }
 
@@ -348,8 +355,8 @@ size_t fsn_lstm2_group_bptt_status_word(int clusters) { return (size_t)clusters 
 int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const float* wih1T_p, const float* whh0T_p,
                                 const float* save0, const float* save1, float* dg0, float* dg1, float* dx, unsigned* flags,
                                 int Tp, int Nrows, int clusters, int H, hipStream_t s) {
-    if (H != BH || clusters < 1 || (long)clusters * BROWS > Nrows) {
-        fsn_set_error("lstm2_group_bptt: H = 384, clusters * 64 <= rows");
+    if (H != BH || clusters < 1 || clusters > fsn_lstm2_group_bptt_clusters(Nrows / 16)) {
+        fsn_set_error("lstm2_group_bptt: H = 384, clusters * 64 <= rows, one cluster per eight CUs at most");
         return FSN_ERR_ARG;
     }
     if (fsn_launch_zero_words(flags, fsn_lstm2_group_bptt_flag_words(clusters), s) != FSN_OK) return FSN_ERR_LAUNCH;
