@@ -100,6 +100,7 @@ SIGNATURES = {
     "fsn_fullsubnet_stream_workspace_bytes": (_c.c_size_t, [_c.POINTER(Cfg), _c.c_int, _c.c_int]),
     "fsn_fullsubnet_stream_step": (_c.c_int, [_c.POINTER(Cfg), _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_int, _f32p,
                                               _c.c_int, _c.c_int, _f32p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "fsn_debug_poison_if": (_c.c_int, [_c.c_void_p, _f32p, _c.c_size_t, _c.c_void_p]),
     "fsn_lstm_layer_save_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
     "fsn_lstm_layer_fwd_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "fsn_lstm_layer_forward": (_c.c_int, [_f32p, _c.c_long, _f32p, _f32p, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_int,

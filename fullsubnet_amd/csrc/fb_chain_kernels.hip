@@ -26,9 +26,8 @@
 
 namespace {
 
-constexpr int CH = 512;         // hidden units per layer
-constexpr int CKC = CH / 16;    // K chunks of an H-wide operand
-constexpr int CNW = CH / 4;     // workgroups per stage
+constexpr int CHMAX = 512;      // largest hidden size built (384 and 512 are)
+constexpr int CFS = CHMAX / 4;  // words per copy of a stage's flag array (H / 4 workgroups per stage use it)
 constexpr int CREP = 16;        // copies of a stage's flag array: a poller reads copy (its index % CREP)
 constexpr unsigned kChainSpin = 1u << 21;
 
@@ -47,21 +46,21 @@ struct ChainArgs {
     float* cseq0;         // training: cell sequence of layer 0, [Tp][Npad][H]
     float* gates1;
     float* cseq1;
-    unsigned* flags;      // [2][CREP][CNW] steps published by (stage 0 = L0 / 1 = L1, workgroup), CREP copies
+    unsigned* flags;      // [2][CREP][CFS] steps published by (stage 0 = L0 / 1 = L1, workgroup), CREP copies
     unsigned* status;
     int Tp, RT, Npad;
 };
 
 // wave 0: all 128 flags of a stage >= epoch and (optionally) one more flag >= its epoch, both looked at in the same
 // round trip; bounded
-__device__ __forceinline__ bool chain_wait(const unsigned* flags, unsigned epoch, const unsigned* one, unsigned one_epoch,
-                                           unsigned* status) {
+__device__ __forceinline__ bool chain_wait(const unsigned* flags, int nflags, unsigned epoch, const unsigned* one,
+                                           unsigned one_epoch, unsigned* status) {
     const int lane = threadIdx.x & 63;
     const unsigned long long* f = reinterpret_cast<const unsigned long long*>(flags) + lane;
     for (unsigned spins = 0;; ++spins) {
         unsigned long long v = ~0ull;
         unsigned w = ~0u;
-        if (epoch > 0) v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (epoch > 0 && 2 * lane < nflags) v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (one && lane == 0) w = __hip_atomic_load(one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (__all((int)((unsigned)v >= epoch && (unsigned)(v >> 32) >= epoch && w >= one_epoch))) return true;
         if ((spins & 255u) == 255u) {
@@ -94,8 +93,11 @@ __device__ __forceinline__ float quad_bcast(float v) {
 // the flag store, 32 no flag stores, 64 no layer-1 projection in L0 (L1 does not wait for it)
 // SAVE: the training form - every step also keeps the activated gates, the cell state and layer 0's hidden sequence
 // (fsn_lstm_layer_backward's inputs, the layouts of fsn_lstm_layer_forward)
-template <int KS, int ABL = 0, bool SAVE = false>
+template <int CH, int KS, int ABL = 0, bool SAVE = false>
 __global__ __launch_bounds__(256, 1) void fb_chain_kernel(const ChainArgs a) {
+    constexpr int CKC = CH / 16;   // K chunks of an H-wide operand (and column tiles per gate)
+    constexpr int CNW = CH / 4;    // workgroups per stage
+    static_assert(CKC % 4 == 0 && CNW % 2 == 0 && CNW <= CFS, "hidden size: a multiple of 64, at most 512");
     constexpr int RTW = 4 / KS;    // row tiles a workgroup can hold
     constexpr int CW = CKC / KS;   // K chunks per wave
     __shared__ f32x4 red[KS > 1 ? (KS - 1) * RTW * 64 : 1];
@@ -110,8 +112,8 @@ __global__ __launch_bounds__(256, 1) void fb_chain_kernel(const ChainArgs a) {
     // Every workgroup polls ALL flags of a stage.  With one copy of the flags that is hundreds of pollers on the same
     // four cache lines (one memory channel each): measured, 128 extra pollers doubled the step time.  So a producer
     // writes CREP copies (one store instruction, CREP lanes) and a consumer polls copy (its index % CREP).
-    unsigned* fl0 = a.flags;               // [CREP][CNW]
-    unsigned* fl1 = a.flags + CREP * CNW;  // [CREP][CNW]
+    unsigned* fl0 = a.flags;               // [CREP][CFS]
+    unsigned* fl1 = a.flags + CREP * CFS;  // [CREP][CFS]
     const int rep = j % CREP;
 
     const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(a.hx0, 0, 0x7fffffff, 0x00020000);
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void fb_chain_kernel(const ChainArgs a) {
         if (!(ABL & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if ((int)threadIdx.x < CREP && !(ABL & 32))
-            __hip_atomic_store(flags + (size_t)threadIdx.x * CNW + j, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flags + (size_t)threadIdx.x * CFS + j, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto hstore = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff, f32x4 v) {
         if (!(ABL & 2)) chain_store16(r, voff, soff, v, (ABL & 8) != 0);
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void fb_chain_kernel(const ChainArgs a) {
             f32x4 acc = gxn;
             if (owner && t + 1 < Tp) gxn = *reinterpret_cast<const f32x4*>(gx0p + (size_t)(t + 1) * gx0_step);
             if (t > 0) {
-                if (wave == 0 && !(ABL & 1)) (void)chain_wait(fl0 + rep * CNW, (unsigned)t, nullptr, 0, a.status);
+                if (wave == 0 && !(ABL & 1)) (void)chain_wait(fl0 + rep * CFS, CNW, (unsigned)t, nullptr, 0, a.status);
                 __syncthreads();
                 if (active) load_a(ar, r0, t - 1);
             }
@@ -277,7 +279,8 @@ __global__ __launch_bounds__(256, 1) void fb_chain_kernel(const ChainArgs a) {
     for (int s = 0; s < Tp; ++s) {
         // h1_{s-1} of all workgroups, and the projection tile of step s from L0 workgroup j (complete at flag s + 3)
         if (wave == 0 && !(ABL & 1))
-            (void)chain_wait(fl1 + rep * CNW, (unsigned)s, (ABL & 64) ? nullptr : fl0 + rep * CNW + j, (unsigned)s + 3, a.status);
+            (void)chain_wait(fl1 + rep * CFS, CNW, (unsigned)s, (ABL & 64) ? nullptr : fl0 + rep * CFS + j, (unsigned)s + 3,
+                             a.status);
         __syncthreads();
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
         if (active) {
@@ -302,21 +305,31 @@ __global__ __launch_bounds__(256, 1) void fb_chain_kernel(const ChainArgs a) {
 
 }  // namespace
 
-// H = 512, up to 64 rows, and a device with one CU per workgroup (2 x 128: the 64-row variant needs a CU's whole
-// register file)
+// H = 384 or 512, up to 64 rows, and a device with one CU per workgroup (2 x H / 4: the 64-row variant needs a CU's
+// whole register file)
 bool fsn_fb_chain_supported(int H, int Npad) {
-    if (H != CH || Npad < 16 || Npad > 64 || Npad % 16 != 0) return false;
+    if ((H != 512 && H != 384) || Npad < 16 || Npad > 64 || Npad % 16 != 0) return false;
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return false;
-    return cus >= 2 * CNW;
+    return cus >= 2 * (H / 4);
 }
 size_t fsn_fb_chain_exchange_floats(int Tp, int Npad) {
-    return (size_t)2 * Tp * Npad * CH + (size_t)Tp * CNW * 1024;  // hx0, hx1, gx1
+    return (size_t)2 * Tp * Npad * CHMAX + (size_t)Tp * (CHMAX / 4) * 1024;  // hx0, hx1, gx1 (sized for H = 512)
 }
-size_t fsn_fb_chain_flag_words() { return (size_t)2 * CREP * CNW + 16; }
-size_t fsn_fb_chain_status_word() { return (size_t)2 * CREP * CNW; }
+size_t fsn_fb_chain_flag_words() { return (size_t)2 * CREP * CFS + 16; }
+size_t fsn_fb_chain_status_word() { return (size_t)2 * CREP * CFS; }
+
+namespace {
+template <int CH, bool SAVE>
+void chain_launch(const ChainArgs& a, hipStream_t s) {
+    const dim3 grid(2 * (CH / 4)), block(256);
+    if (a.RT == 1) hipLaunchKernelGGL((fb_chain_kernel<CH, 4, 0, SAVE>), grid, block, 0, s, a);
+    else if (a.RT == 2) hipLaunchKernelGGL((fb_chain_kernel<CH, 2, 0, SAVE>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((fb_chain_kernel<CH, 1, 0, SAVE>), grid, block, 0, s, a);
+}
+}  // namespace
 
 // gx0: fragment-order projection of layer 0 (bias included); hseq1 [Tp][Npad][H] row-major out.
 // Training form: hseq0, save0, save1 non-NULL (save = gates [Tp][Npad][4H] followed by the cell sequence [Tp][Npad][H],
@@ -325,7 +338,7 @@ int fsn_launch_fb_chain(const float* gx0, const float* whh0_p, const float* wih1
                         float* exchange, unsigned* flags, float* hseq1, int Tp, int Npad, int H, hipStream_t s,
                         float* hseq0, float* save0, float* save1) {
     if (!fsn_fb_chain_supported(H, Npad) || Tp < 1) {
-        fsn_set_error("fb_chain: built for H = 512 and at most 64 rows");
+        fsn_set_error("fb_chain: built for H = 384 / 512 and at most 64 rows");
         return FSN_ERR_ARG;
     }
     const bool save = hseq0 || save0 || save1;
@@ -342,28 +355,25 @@ int fsn_launch_fb_chain(const float* gx0, const float* whh0_p, const float* wih1
     a.whh1_p = whh1_p;
     a.b1 = b1;
     a.hx0 = exchange;
-    a.hx1 = exchange + (size_t)Tp * Npad * CH;
-    a.gx1 = exchange + (size_t)2 * Tp * Npad * CH;
+    a.hx1 = exchange + (size_t)Tp * Npad * H;
+    a.gx1 = exchange + (size_t)2 * Tp * Npad * H;
     a.hseq1 = hseq1;
     a.hseq0 = hseq0;
     a.gates0 = save0;
-    a.cseq0 = save0 ? save0 + (size_t)Tp * Npad * 4 * CH : nullptr;
+    a.cseq0 = save0 ? save0 + (size_t)Tp * Npad * 4 * H : nullptr;
     a.gates1 = save1;
-    a.cseq1 = save1 ? save1 + (size_t)Tp * Npad * 4 * CH : nullptr;
+    a.cseq1 = save1 ? save1 + (size_t)Tp * Npad * 4 * H : nullptr;
     a.flags = flags;
-    a.status = flags + 2 * CREP * CNW;
+    a.status = flags + fsn_fb_chain_status_word();
     a.Tp = Tp;
     a.RT = Npad / 16;
     a.Npad = Npad;
-    const dim3 grid(2 * CNW), block(256);
-    if (save) {
-        if (a.RT == 1) hipLaunchKernelGGL((fb_chain_kernel<4, 0, true>), grid, block, 0, s, a);
-        else if (a.RT == 2) hipLaunchKernelGGL((fb_chain_kernel<2, 0, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((fb_chain_kernel<1, 0, true>), grid, block, 0, s, a);
+    if (H == 512) {
+        if (save) chain_launch<512, true>(a, s);
+        else chain_launch<512, false>(a, s);
     } else {
-        if (a.RT == 1) hipLaunchKernelGGL((fb_chain_kernel<4, 0, false>), grid, block, 0, s, a);
-        else if (a.RT == 2) hipLaunchKernelGGL((fb_chain_kernel<2, 0, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((fb_chain_kernel<1, 0, false>), grid, block, 0, s, a);
+        if (save) chain_launch<384, true>(a, s);
+        else chain_launch<384, false>(a, s);
     }
     return fsn_check_launch("fb_chain_kernel");
 }

@@ -196,6 +196,13 @@ static void prof_reset() {
     StreamCtx* c = cur_ctx();
     for (int i = 0; i < ST_COUNT; ++i) c->spans[i] = 0;
 }
+// Test hook for the safety net of the persistent kernels (fsn_launch_poison_if): out[0..n) becomes NaN iff *status != 0.
+extern "C" int fsn_debug_poison_if(const void* status, float* out, size_t n, void* stream) {
+    CallScope scope(stream);
+    FSN_REQUIRE(status && out, "NULL pointer argument");
+    return fsn_launch_poison_if(static_cast<const unsigned*>(status), out, n, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int fsn_profile_enable(int on) {
     g_prof_on = on ? 1 : 0;
     return FSN_OK;

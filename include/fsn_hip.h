@@ -274,6 +274,10 @@ int fsn_clip_adam_step(int n_tensors, float* const* params, float* const* grads,
  * profiling enabled (hipEvents on that stream, kept per (device, stream); forces a sync of them when read).  Stage ids are listed
  * by fsn_profile_stage_name(); used by bench.py for the roofline line.  */
 int fsn_profile_enable(int on);
+/* Test hook: the persistent kernels (full-band chain, sub-band group kernels) bound every spin; a launch that hit a
+ * bound raises a status word and a follow-up kernel turns its output into NaN instead of leaving garbage.  This entry
+ * runs that follow-up kernel on caller data: out[0..n) = NaN iff *status (a device word) != 0. */
+int fsn_debug_poison_if(const void* status, float* out, size_t n, void* stream);
 int fsn_profile_num_stages(void);
 const char* fsn_profile_stage_name(int stage);
 int fsn_profile_read(void* stream, float* ms_per_stage, int n);

@@ -577,6 +577,21 @@ def test_two_streams_and_two_host_threads_are_independent(fsn):
     assert all(again[k] == pytest.approx(main_ms[k], rel=1e-3, abs=1e-5) for k in main_ms)
 
 
+def test_a_spin_bound_poisons_the_output(fsn):
+    """The persistent kernels bound every spin; a launch that hit a bound raises its status word and the follow-up
+    kernel (poison_if_kernel, here through its test hook) turns the output into NaN - never silent garbage - and
+    leaves it alone otherwise."""
+    L = fsn._lib.lib()
+    out = torch.arange(5000, dtype=torch.float32, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    stream = fsn._lib.stream_ptr(out.device)
+    fsn._lib.check(L.fsn_debug_poison_if(status.data_ptr(), fsn._lib.dev_ptr(out), out.numel(), stream))
+    assert torch.equal(out, torch.arange(5000, dtype=torch.float32, device="cuda"))
+    status.fill_(7)
+    fsn._lib.check(L.fsn_debug_poison_if(status.data_ptr(), fsn._lib.dev_ptr(out), out.numel(), stream))
+    assert bool(torch.isnan(out).all())
+
+
 @pytest.mark.parametrize("batch", [6, 8, 9])
 def test_few_rows_on_the_group_kernel(fsn, batch):
     """6 - 9 utterances (97 - 145 row tiles, the per-rank share of a strong-scaled batch): both sub-band layers and

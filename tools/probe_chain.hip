@@ -19,7 +19,7 @@ float run(ChainArgs a) {
     for (int it = 0; it < 4; ++it) {
         hipMemsetAsync(a.flags, 0, fsn_fb_chain_flag_words() * 4, 0);
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((fb_chain_kernel<KS, ABL>), dim3(2 * CNW), dim3(256), 0, 0, a);
+        hipLaunchKernelGGL((fb_chain_kernel<512, KS, ABL>), dim3(2 * 128), dim3(256), 0, 0, a);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (it > 0 && ms < best) best = ms;
     }
@@ -46,7 +46,7 @@ void sweep(ChainArgs a, int Tp) {
 }
 int main(int argc, char** argv) {
     const int Tp = argc > 1 ? atoi(argv[1]) : 190, Npad = argc > 2 ? atoi(argv[2]) : 64;
-    const int H = CH;
+    const int H = 512;
     float *gx0, *w, *b1, *ex, *hseq; unsigned* flags;
     hipMalloc(&gx0, (size_t)Tp * Npad * 4 * H * 4); hipMalloc(&w, (size_t)3 * 4 * H * H * 4); hipMalloc(&b1, 4 * H * 4);
     hipMalloc(&ex, fsn_fb_chain_exchange_floats(Tp, Npad) * 4); hipMalloc(&hseq, (size_t)Tp * Npad * H * 4);
@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
     ChainArgs a{};
     a.gx0 = gx0; a.whh0_p = w; a.wih1_p = w + (size_t)4 * H * H; a.whh1_p = w + (size_t)8 * H * H; a.b1 = b1;
     a.hx0 = ex; a.hx1 = ex + (size_t)Tp * Npad * H; a.gx1 = ex + (size_t)2 * Tp * Npad * H; a.hseq1 = hseq;
-    a.flags = flags; a.status = flags + 2 * CREP * CNW; a.Tp = Tp; a.RT = Npad / 16; a.Npad = Npad;
+    a.flags = flags; a.status = flags + fsn_fb_chain_status_word(); a.Tp = Tp; a.RT = Npad / 16; a.Npad = Npad;
     if (a.RT == 1) sweep<4>(a, Tp);
     else if (a.RT == 2) sweep<2>(a, Tp);
     else sweep<1>(a, Tp);
