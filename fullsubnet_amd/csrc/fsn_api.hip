@@ -1544,7 +1544,7 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
         }
         {
             PersistLaunch gate(s);
-            FSN_TRY(fsn_launch_lstm2_group_train(x, ldx, N, wih0_p, whh0_p, wih1_p, whh1_p, b0, b1, hseq0, hseq1, sv0, sv1,
+            FSN_TRY(fsn_launch_lstm2_group_train(x, ldx, 32, N, wih0_p, whh0_p, wih1_p, whh1_p, b0, b1, hseq0, hseq1, sv0, sv1,
                                                  flags, T, clusters, H, s));
             FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_status_word(clusters), hseq1, (size_t)T * N * H, s));
         }
@@ -1627,6 +1627,13 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
 // Two stacked LSTM layers of equal width in inference mode as one wavefront (layer 1 at step t next to layer 0
 // at step t + 1: T + 1 dependent launches instead of 2 T).  For the latency-bound regime - few rows - where
 // SequenceModel blocks of the sibling models live (Improved FullSubNet's band sections: B x {20, 25, 6, 4} rows).
+// H = 384 twice, up to 32 input columns, whole 64-row clusters in the group kernel's ranges (96 - 159 and 224 - 256 row
+// tiles: e.g. Fast FullSubNet's bottleneck at 24 - 39 utterances per rank): clusters, 0 = not this shape
+static int lstm2_infer_group_clusters(int N, int I, int H0, int H1) {
+    if (H0 != 384 || H1 != 384 || I > 32 || N % 64 != 0 || N / 16 < kWavefrontBelowTiles) return 0;
+    const int tiles = N / 16, c = fsn_lstm2_group_clusters(tiles);
+    return 4 * c == tiles ? c : 0;
+}
 extern "C" size_t fsn_lstm2_fwd_workspace_bytes(int T, int N, int I, int H0, int H1) {
     Carver cv(nullptr);
     cv.take<float>((size_t)4 * H0 * fsn_round_up(I, 16));  // W_ih0 fragments
@@ -1643,7 +1650,16 @@ extern "C" size_t fsn_lstm2_fwd_workspace_bytes(int T, int N, int I, int H0, int
         cv.take<float>(fsn_fb_chain_exchange_floats(T, N));
         cv.take<unsigned>(fsn_fb_chain_flag_words());
     }
+    if (const int clusters = lstm2_infer_group_clusters(N, I, H0, H1)) {  // the group kernel (general two-layer form)
+        cv.take<float>((size_t)4 * H0 * 32 + (size_t)3 * 4 * H0 * H0);
+        cv.take<unsigned>(fsn_lstm2_group_flag_words(clusters));
+    }
     return fsn_round_up_sz(cv.off, 256);
+}
+// 1 when fsn_lstm2_forward has a persistent kernel for this shape (callers that would otherwise run layer by layer on
+// the per-layer persistent kernels - 1536+ rows - should then prefer it)
+extern "C" int fsn_lstm2_forward_is_persistent(int N, int I, int H0, int H1) {
+    return (H0 == H1 && fsn_fb_chain_supported(H0, N)) || lstm2_infer_group_clusters(N, I, H0, H1) > 0;
 }
 extern "C" int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, const float* w_hh0, const float* b_ih0,
                                  const float* b_hh0, const float* w_ih1, const float* w_hh1, const float* b_ih1,
@@ -1671,6 +1687,31 @@ extern "C" int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, c
     float* gx = cv.take<float>((size_t)T * N * G0);
     float* hseq0 = cv.take<float>((size_t)T * N * H0);
     float* cst = cv.take<float>((size_t)N * (H0 + H1));
+    if (const int clusters = lstm2_infer_group_clusters(N, I, H0, H1)) {
+        // both layers, all steps, as one persistent launch of the group kernel (no projection GEMM, no gx): the four
+        // packed matrices in one buffer, W_ih0 32 columns wide
+        if (H0 == H1 && fsn_fb_chain_supported(H0, N)) {
+            cv.take<float>(fsn_fb_chain_exchange_floats(T, N));
+            cv.take<unsigned>(fsn_fb_chain_flag_words());
+        }
+        float* gw = cv.take<float>((size_t)G0 * 32 + (size_t)3 * G0 * H0);
+        unsigned* flags = cv.take<unsigned>(fsn_lstm2_group_flag_words(clusters));
+        float* g_wih0 = gw;
+        float* g_whh0 = g_wih0 + (size_t)G0 * 32;
+        float* g_wih1 = g_whh0 + (size_t)G0 * H0;
+        float* g_whh1 = g_wih1 + (size_t)G0 * H0;
+        FSN_REQUIRE(ldx == 16 || ldx == 32, "lstm2 forward: this shape needs x rows of 16 or 32 columns (got %ld)", ldx);
+        FSN_TRY(fsn_launch_pack(w_ih0, g_wih0, G0, I, G0, 32, s));
+        FSN_TRY(fsn_launch_pack(w_hh0, g_whh0, G0, H0, G0, H0, s));
+        FSN_TRY(fsn_launch_pack(w_ih1, g_wih1, G1, H0, G1, H0, s));
+        FSN_TRY(fsn_launch_pack(w_hh1, g_whh1, G1, H1, G1, H1, s));
+        FSN_TRY(fsn_launch_bias_sum(b_ih0, b_hh0, b0, G0, G0, s));
+        FSN_TRY(fsn_launch_bias_sum(b_ih1, b_hh1, b1, G1, G1, s));
+        PersistLaunch gate(s);
+        FSN_TRY(fsn_launch_lstm2_group_train(x, ldx, (int)ldx, N, g_wih0, g_whh0, g_wih1, g_whh1, b0, b1, hseq0, hseq1, nullptr,
+                                             nullptr, flags, T, clusters, H0, s));
+        return fsn_launch_poison_if(flags + fsn_lstm2_group_status_word(clusters), hseq1, (size_t)T * N * H1, s);
+    }
     FSN_TRY(fsn_launch_pack(w_ih0, wih0_p, G0, I, G0, Ipad, s));
     FSN_TRY(fsn_launch_pack(w_hh0, whh0_p, G0, H0, G0, H0, s));
     FSN_TRY(fsn_launch_pack(w_ih1, wih1_p, G1, H0, G1, H0, s));

@@ -171,7 +171,7 @@ size_t fsn_fb_chain_status_word();
 size_t fsn_lstm2_group_status_word(int clusters);
 size_t fsn_lstm2_group_bptt_status_word(int clusters);
 
-int fsn_launch_lstm2_group_train(const float* x, long x_ld, int Nrows, const float* wih0_p, const float* whh0_p,
+int fsn_launch_lstm2_group_train(const float* x, long x_ld, int x_cols, int Nrows, const float* wih0_p, const float* whh0_p,
                                  const float* wih1_p, const float* whh1_p, const float* bias0, const float* bias1,
                                  float* hseq0, float* hseq1, float* save0, float* save1, unsigned* flags, int Tp,
                                  int clusters, int H, hipStream_t s);  // lstm_group_kernels.hip

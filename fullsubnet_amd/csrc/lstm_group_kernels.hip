@@ -99,7 +99,9 @@ struct GrpCl {
     unsigned seen0;
 };
 
-template <int LAYER, int ABL, bool TRAIN, int NCL>
+// TRAIN: the general two-layer form (plain row-major input, hidden sequences = exchange buffers, no output layer);
+// SAVE (with TRAIN): also keep the activated gates and cell states (the training forward)
+template <int LAYER, int ABL, bool TRAIN, int NCL, bool SAVE>
 __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int cluster_b, int member,
                                            f32x4 (*bsh)[GU * 4][64], float (*bias_sh)[16]) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -265,7 +267,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
                 const float hv = (ABL & 8) ? og * cn : og * tanh_fast(cn);
                 if (ABL & 4) *hp = hv;
                 else store_sc1(hp, hv);
-                if (TRAIN) {  // rows of this cluster inside step t's [Nrows][...] slabs
+                if (TRAIN && SAVE) {  // rows of this cluster inside step t's [Nrows][...] slabs
                     const size_t row = (size_t)k.cluster * GROWS + wave * 16 + 4 * lq + i;
                     const int unit = (member * GU + u) * 16 + lr;
                     float* gp = gates_t + row * (4 * GH) + unit;
@@ -286,7 +288,8 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
             const float den = (k.row_ok && !TRAIN) ? x.den[x.den_mode ? (long)t * x.den_stride + k.ng : (long)k.xb] : 1.f;
             if (TRAIN) {  // plain row-major input [Tp][x_step][x_ld], 32 columns (zero-padded by the caller)
                 const float* xr = x.x_rows + ((long)t * x.x_step + (k.row_ok ? k.row_l : 0)) * x.x_ld + 4 * lq;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(xr), v1 = *reinterpret_cast<const f32x4*>(xr + 16);
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(xr);
+                const f32x4 v1 = x.kin_chunks > 1 ? *reinterpret_cast<const f32x4*>(xr + 16) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) raw[e] = v0[e], raw[4 + e] = v1[e];
             } else {
@@ -415,7 +418,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
     }
 }
 
-template <int ABL, bool TRAIN = false, int NCL = 1>
+template <int ABL, bool TRAIN = false, int NCL = 1, bool SAVE = TRAIN>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void lstm2_group_kernel(const GrpArgs a) {
     // weight fragments of one K chunk, shared by the four waves: two stages x 12 fragments x 1 KB
     __shared__ f32x4 bsh[2][GU * 4][64];
@@ -443,8 +446,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void 
     // Layer 1 is the longer dependent chain (K = 768 per step against 416) and layer 0 is throttled to stay within
     // GD0 - 2 steps of it: layer 1's waves issue first, layer 0's fill the gaps.
     if (layer == 1 && !(ABL & 64)) __builtin_amdgcn_s_setprio(2);
-    if (layer == 0) group_body<0, ABL, TRAIN, NCL>(a, cluster, cluster_b, member, bsh, bias_sh);
-    else group_body<1, ABL, TRAIN, NCL>(a, cluster, cluster_b, member, bsh, bias_sh);
+    if (layer == 0) group_body<0, ABL, TRAIN, NCL, SAVE>(a, cluster, cluster_b, member, bsh, bias_sh);
+    else group_body<1, ABL, TRAIN, NCL, SAVE>(a, cluster, cluster_b, member, bsh, bias_sh);
 }
 
 }  // namespace
@@ -508,10 +511,11 @@ int fsn_launch_lstm2_group(const FsnSbInput* xin, const float* whh0_p, const flo
     return fsn_check_launch("lstm2_group_kernel");
 }
 
-// Training form: rows [0, 64 clusters) of x [Tp][Nrows][x_ld] (32 zero-padded input columns) through both layers with
-// saved activations; hseq0 / hseq1 [Tp][Nrows][H], save = gates [Tp][Nrows][4H] followed by the cell sequence
-// [Tp][Nrows][H] (fsn_lstm_layer_forward's layouts).  bias0 / bias1 = b_ih + b_hh.
-int fsn_launch_lstm2_group_train(const float* x, long x_ld, int Nrows, const float* wih0_p, const float* whh0_p,
+// General two-layer form: rows [0, 64 clusters) of x [Tp][Nrows][x_ld] (16 or 32 zero-padded input columns: x_cols;
+// wih0_p packed 32 columns wide either way) through both layers; hseq0 / hseq1 [Tp][Nrows][H].  Training: save0 / save1
+// non-NULL = gates [Tp][Nrows][4H] followed by the cell sequence [Tp][Nrows][H] (fsn_lstm_layer_forward's layouts).
+// bias0 / bias1 = b_ih + b_hh.
+int fsn_launch_lstm2_group_train(const float* x, long x_ld, int x_cols, int Nrows, const float* wih0_p, const float* whh0_p,
                                  const float* wih1_p, const float* whh1_p, const float* bias0, const float* bias1,
                                  float* hseq0, float* hseq1, float* save0, float* save1, unsigned* flags, int Tp,
                                  int clusters, int H, hipStream_t s) {
@@ -533,7 +537,7 @@ int fsn_launch_lstm2_group_train(const float* x, long x_ld, int Nrows, const flo
     a.xin.x_step = Nrows;
     a.xin.N = clusters * GROWS;
     a.xin.F = 1;
-    a.xin.kin_chunks = 2;
+    a.xin.kin_chunks = x_cols > 16 ? 2 : 1;
     a.xin.bias = bias0;
     a.wbase = lo;
     a.o_wih0 = (unsigned)(wih0_p - lo);
@@ -546,14 +550,21 @@ int fsn_launch_lstm2_group_train(const float* x, long x_ld, int Nrows, const flo
     a.flags = flags;
     a.status = flags + (size_t)clusters * 2 * GFS;
     a.Tp = Tp;
+    const bool save = save0 && save1;
     a.gates0 = save0;
-    a.cseq0 = save0 + (size_t)Tp * Nrows * 4 * GH;
+    a.cseq0 = save ? save0 + (size_t)Tp * Nrows * 4 * GH : nullptr;
     a.gates1 = save1;
-    a.cseq1 = save1 + (size_t)Tp * Nrows * 4 * GH;
+    a.cseq1 = save ? save1 + (size_t)Tp * Nrows * 4 * GH : nullptr;
     a.Nrows = Nrows;
     a.nclusters = clusters;
     const int cap = grp_slots_cap(), slots = clusters < cap ? clusters : cap;
-    if (clusters > slots) hipLaunchKernelGGL((lstm2_group_kernel<0, true, 2>), dim3((unsigned)slots * GM * 2), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((lstm2_group_kernel<0, true, 1>), dim3((unsigned)slots * GM * 2), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)slots * GM * 2), block(256);
+    if (save) {
+        if (clusters > slots) hipLaunchKernelGGL((lstm2_group_kernel<0, true, 2, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((lstm2_group_kernel<0, true, 1, true>), grid, block, 0, s, a);
+    } else {
+        if (clusters > slots) hipLaunchKernelGGL((lstm2_group_kernel<0, true, 2, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((lstm2_group_kernel<0, true, 1, false>), grid, block, 0, s, a);
+    }
     return fsn_check_launch("lstm2_group_kernel (training)");
 }

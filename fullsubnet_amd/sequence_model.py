@@ -171,8 +171,10 @@ class SequenceModel(nn.Module):
         h = torch.zeros((T, Np, Ip), dtype=torch.float32, device=x.device)
         h[:, :B, :F] = x.permute(2, 0, 1)
         layer_infer = lstm_layer_infer if self.cell == "LSTM" else gru_layer_infer
-        if self.cell == "LSTM" and len(layers) == 2 and Np < WAVEFRONT_BELOW_ROWS:
-            h = lstm2_infer(h, layers[0], layers[1])  # few rows: latency-bound, halve the dependent launches
+        if self.cell == "LSTM" and len(layers) == 2 and (
+                Np < WAVEFRONT_BELOW_ROWS or _lib.lib().fsn_lstm2_forward_is_persistent(Np, Ip, Hp, Hp)):
+            # few rows: latency-bound, halve the dependent launches; or a shape with a persistent two-layer kernel
+            h = lstm2_infer(h, layers[0], layers[1])
         else:
             for w_ih, w_hh, b_ih, b_hh in layers:
                 h = layer_infer(h, w_ih, w_hh, b_ih, b_hh)

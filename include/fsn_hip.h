@@ -184,6 +184,10 @@ int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_ih0, const 
  * encoder / decoder pairs of fast_fullsubnet/model.py:35-96; layer 1 takes the H0 outputs of layer 0).  For
  * blocks with few rows (the latency-bound regime); hseq1 [T][N][H1] is the hidden sequence of the second layer. */
 size_t fsn_lstm2_fwd_workspace_bytes(int T, int N, int I, int H0, int H1);
+/* 1 when fsn_lstm2_forward runs this shape as ONE persistent launch (equal widths of 384 / 512 with up to 64 rows: the
+ * chain kernel; 384 twice, up to 32 input columns and 1536 - 2559 or 3584 - 4096 rows in whole 64-row clusters: the
+ * group kernel) - then it is also the better choice above the few-row regime it was made for. */
+int fsn_lstm2_forward_is_persistent(int N, int I, int H0, int H1);
 int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, const float* w_hh0, const float* b_ih0,
                       const float* b_hh0, const float* w_ih1, const float* w_hh1, const float* b_ih1,
                       const float* b_hh1, int T, int N, int I, int H0, int H1, float* hseq1, void* workspace,

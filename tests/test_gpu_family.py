@@ -67,9 +67,11 @@ def test_fast_fullsubnet_at_baseline_length_vs_reference(fsn, golden_dir):
     assert np.abs(crm - z["crm"]).max() <= 1e-4
 
 
-def test_fast_fullsubnet_batch64_rows_on_persistent_kernel(fsn):
-    """B = 64 -> 4096 bottleneck rows = 256 tiles: the rows run on the persistent recurrent kernel
-    (not the step kernels of the small golden cases); checked against the oracle on 2 utterances."""
+@pytest.mark.parametrize("batch", [32, 48, 64])
+def test_fast_fullsubnet_many_rows_on_the_persistent_kernels(fsn, batch):
+    """B = 32 / 48 / 64 -> 2048 / 3072 / 4096 bottleneck rows (not the step kernels of the small golden cases): both
+    bottleneck layers as one launch of the group kernel (32 clusters; 64 clusters, two per workgroup set), or - 192
+    row tiles - layer by layer on the persistent recurrent kernels; checked against the oracle on 2 utterances."""
     from fullsubnet_amd.fast_fullsubnet import Model
     params = MF.make_fast_params(seed=5)
     m = Model(**FAST_KW)
@@ -78,13 +80,15 @@ def test_fast_fullsubnet_batch64_rows_on_persistent_kernel(fsn):
     m.load_state_dict(sd, strict=True)
     m = m.cuda().eval()
     rng = np.random.default_rng(0)
-    mag = np.abs(rng.standard_normal((64, 1, 257, 21))).astype(np.float32)
+    mag = np.abs(rng.standard_normal((batch, 1, 257, 21))).astype(np.float32)
     mag[1] *= 3.0
     with torch.no_grad():
         crm = m(torch.from_numpy(mag).cuda()).cpu().numpy()
+        crm2 = m(torch.from_numpy(mag).cuda()).cpu().numpy()
+    assert np.array_equal(crm, crm2)
     params["mel_scale.fb"] = m.mel_scale.fb.cpu().numpy()
-    want = MF.fast_fullsubnet_forward(mag[[1, 63]], params)
-    assert np.abs(crm[[1, 63]] - want).max() <= 1e-4
+    want = MF.fast_fullsubnet_forward(mag[[1, batch - 1]], params)
+    assert np.abs(crm[[1, batch - 1]] - want).max() <= 1e-4
 
 
 def test_fullband_baseline_vs_reference(fsn, golden_dir):
