@@ -315,6 +315,8 @@ bool fsn_fb_chain_supported(int H, int Npad) {
         return false;
     return cus >= 2 * (H / 4);
 }
+// the per-step hand-off buffers are addressed through buffer resources, whose offsets reach 2 GB: 4095 steps
+int fsn_fb_chain_max_steps() { return (int)(0x7fffffffu / ((unsigned)(CHMAX / 4) * 4096u)); }
 size_t fsn_fb_chain_exchange_floats(int Tp, int Npad) {
     return (size_t)2 * Tp * Npad * CHMAX + (size_t)Tp * (CHMAX / 4) * 1024;  // hx0, hx1, gx1 (sized for H = 512)
 }
@@ -337,8 +339,8 @@ void chain_launch(const ChainArgs& a, hipStream_t s) {
 int fsn_launch_fb_chain(const float* gx0, const float* whh0_p, const float* wih1_p, const float* whh1_p, const float* b1,
                         float* exchange, unsigned* flags, float* hseq1, int Tp, int Npad, int H, hipStream_t s,
                         float* hseq0, float* save0, float* save1) {
-    if (!fsn_fb_chain_supported(H, Npad) || Tp < 1) {
-        fsn_set_error("fb_chain: built for H = 384 / 512 and at most 64 rows");
+    if (!fsn_fb_chain_supported(H, Npad) || Tp < 1 || Tp > fsn_fb_chain_max_steps()) {
+        fsn_set_error("fb_chain: built for H = 384 / 512, at most 64 rows and 4095 steps");
         return FSN_ERR_ARG;
     }
     const bool save = hseq0 || save0 || save1;

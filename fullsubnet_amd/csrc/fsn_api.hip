@@ -395,7 +395,7 @@ static CoreDims core_dims(const fsn_fullsubnet_cfg* c, int B, int T, long row0 =
     d.Hs = c->sb_hidden;
     d.nb = c->sb_num_neighbors;
     d.Npad_fb = fsn_round_up(B, 16);
-    d.fb_chain = fsn_fb_chain_supported(d.Hf, d.Npad_fb);
+    d.fb_chain = fsn_fb_chain_supported(d.Hf, d.Npad_fb) && d.Tp <= fsn_fb_chain_max_steps();
     d.N = n_rows < 0 ? B * d.F : (int)n_rows;
     d.row0 = n_rows < 0 ? 0 : row0;
     d.rec = fsn_lstm_rec_plan(d.N, d.Hs);
@@ -1460,7 +1460,7 @@ extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_i
 // (sequence_model.py:52-58 with num_layers = 2, under autograd: fullsubnet/trainer.py:56-63).  The result is that of two
 // fsn_lstm_layer_forward calls; what it adds is the persistent kernels: the full-band shape (H = 512, up to 64 rows)
 // runs on fb_chain_kernel, one launch for both layers and all steps instead of 2 T.
-static bool lstm2_train_on_chain(int N, int H) { return fsn_fb_chain_supported(H, N); }
+static bool lstm2_on_chain(int T, int N, int H) { return fsn_fb_chain_supported(H, N) && T <= fsn_fb_chain_max_steps(); }
 // The sub-band shape (H = 384, up to 32 input columns, 96+ row tiles that fill whole 64-row clusters up to a few
 // left-over tiles): clusters on the group kernel, 0 = not this shape.
 static int lstm2_train_group_clusters(int T, int N, int I, int H) {
@@ -1482,7 +1482,7 @@ extern "C" size_t fsn_lstm2_train_workspace_bytes(int T, int N, int I, int H) {
         cv.take<float>((size_t)T * left * 4 * H);
         return fsn_round_up_sz(cv.off, 256);
     }
-    if (lstm2_train_on_chain(N, H)) {
+    if (lstm2_on_chain(T, N, H)) {
         cv.take<float>((size_t)4 * H * Ipad);
         cv.take<float>((size_t)3 * 4 * H * H);
         cv.take<float>((size_t)2 * 4 * H);
@@ -1586,7 +1586,7 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
         }
         return FSN_OK;
     }
-    if (!lstm2_train_on_chain(N, H)) {  // layer by layer
+    if (!lstm2_on_chain(T, N, H)) {  // layer by layer
         FSN_TRY(fsn_lstm_layer_forward(x, ldx, w_ih0, w_hh0, b_ih0, b_hh0, T, N, I, H, hseq0, save0, save_bytes, workspace,
                                        workspace_bytes, stream));
         return fsn_lstm_layer_forward(hseq0, H, w_ih1, w_hh1, b_ih1, b_hh1, T, N, H, H, hseq1, save1, save_bytes, workspace,
@@ -1629,8 +1629,9 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
 // SequenceModel blocks of the sibling models live (Improved FullSubNet's band sections: B x {20, 25, 6, 4} rows).
 // H = 384 twice, up to 32 input columns, whole 64-row clusters in the group kernel's ranges (96 - 159 and 224 - 256 row
 // tiles: e.g. Fast FullSubNet's bottleneck at 24 - 39 utterances per rank): clusters, 0 = not this shape
-static int lstm2_infer_group_clusters(int N, int I, int H0, int H1) {
+static int lstm2_infer_group_clusters(int T, int N, int I, int H0, int H1) {
     if (H0 != 384 || H1 != 384 || I > 32 || N % 64 != 0 || N / 16 < kWavefrontBelowTiles) return 0;
+    if ((size_t)T * N * H0 * sizeof(float) > 0x7fffffffull) return 0;  // the reach of a buffer resource's offsets
     const int tiles = N / 16, c = fsn_lstm2_group_clusters(tiles);
     return 4 * c == tiles ? c : 0;
 }
@@ -1646,11 +1647,11 @@ extern "C" size_t fsn_lstm2_fwd_workspace_bytes(int T, int N, int I, int H0, int
     cv.take<float>((size_t)T * N * 4 * H0);                // layer-0 projection
     cv.take<float>((size_t)T * N * H0);                    // layer-0 hidden sequence
     cv.take<float>((size_t)N * (H0 + H1));                 // cell states
-    if (H0 == H1 && fsn_fb_chain_supported(H0, N)) {       // the persistent chain kernel instead of the wavefront
+    if (H0 == H1 && lstm2_on_chain(T, N, H0)) {            // the persistent chain kernel instead of the wavefront
         cv.take<float>(fsn_fb_chain_exchange_floats(T, N));
         cv.take<unsigned>(fsn_fb_chain_flag_words());
     }
-    if (const int clusters = lstm2_infer_group_clusters(N, I, H0, H1)) {  // the group kernel (general two-layer form)
+    if (const int clusters = lstm2_infer_group_clusters(T, N, I, H0, H1)) {  // the group kernel (general two-layer form)
         cv.take<float>((size_t)4 * H0 * 32 + (size_t)3 * 4 * H0 * H0);
         cv.take<unsigned>(fsn_lstm2_group_flag_words(clusters));
     }
@@ -1659,7 +1660,7 @@ extern "C" size_t fsn_lstm2_fwd_workspace_bytes(int T, int N, int I, int H0, int
 // 1 when fsn_lstm2_forward has a persistent kernel for this shape (callers that would otherwise run layer by layer on
 // the per-layer persistent kernels - 1536+ rows - should then prefer it)
 extern "C" int fsn_lstm2_forward_is_persistent(int N, int I, int H0, int H1) {
-    return (H0 == H1 && fsn_fb_chain_supported(H0, N)) || lstm2_infer_group_clusters(N, I, H0, H1) > 0;
+    return (H0 == H1 && fsn_fb_chain_supported(H0, N)) || lstm2_infer_group_clusters(1, N, I, H0, H1) > 0;
 }
 extern "C" int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, const float* w_hh0, const float* b_ih0,
                                  const float* b_hh0, const float* w_ih1, const float* w_hh1, const float* b_ih1,
@@ -1687,10 +1688,10 @@ extern "C" int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, c
     float* gx = cv.take<float>((size_t)T * N * G0);
     float* hseq0 = cv.take<float>((size_t)T * N * H0);
     float* cst = cv.take<float>((size_t)N * (H0 + H1));
-    if (const int clusters = lstm2_infer_group_clusters(N, I, H0, H1)) {
+    if (const int clusters = lstm2_infer_group_clusters(T, N, I, H0, H1)) {
         // both layers, all steps, as one persistent launch of the group kernel (no projection GEMM, no gx): the four
         // packed matrices in one buffer, W_ih0 32 columns wide
-        if (H0 == H1 && fsn_fb_chain_supported(H0, N)) {
+        if (H0 == H1 && lstm2_on_chain(T, N, H0)) {
             cv.take<float>(fsn_fb_chain_exchange_floats(T, N));
             cv.take<unsigned>(fsn_fb_chain_flag_words());
         }
@@ -1728,7 +1729,7 @@ extern "C" int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, c
     c.p0 = gx;
     c.bias = b0;
     FSN_TRY(fsn_launch_gemm(a, wih0_p, c, T * (N / 16), G0 / 16, Ipad / 16, s));
-    if (H0 == H1 && fsn_fb_chain_supported(H0, N)) {  // H = 512, up to 64 rows: one persistent launch (fb_chain_kernels.hip)
+    if (H0 == H1 && lstm2_on_chain(T, N, H0)) {  // H = 384 / 512, up to 64 rows: one persistent launch (fb_chain_kernels.hip)
         float* exchange = cv.take<float>(fsn_fb_chain_exchange_floats(T, N));
         unsigned* flags = cv.take<unsigned>(fsn_fb_chain_flag_words());
         PersistLaunch gate(s);

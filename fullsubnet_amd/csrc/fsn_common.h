@@ -178,6 +178,7 @@ int fsn_launch_lstm2_group_train(const float* x, long x_ld, int x_cols, int Nrow
 
 // fb_chain_kernels.hip: the full-band model's two LSTM layers over all frames as one persistent launch
 bool fsn_fb_chain_supported(int H, int Npad);
+int fsn_fb_chain_max_steps();
 size_t fsn_fb_chain_exchange_floats(int Tp, int Npad);
 size_t fsn_fb_chain_flag_words();
 int fsn_launch_fb_chain(const float* gx0, const float* whh0_p, const float* wih1_p, const float* whh1_p, const float* b1,

@@ -577,6 +577,20 @@ def test_two_streams_and_two_host_threads_are_independent(fsn):
     assert all(again[k] == pytest.approx(main_ms[k], rel=1e-3, abs=1e-5) for k in main_ms)
 
 
+def test_minute_long_utterances_chain_kernel_vs_per_step_launches(fsn):
+    """The full-band chain kernel addresses its per-step hand-off buffers through 2 GB buffer resources: 4095 steps;
+    longer inputs fall back to the wavefront of per-step launches.  Both paths on the same audio - 70 s (4376 frames,
+    wavefront) and its first 60 s (3751 frames, chain kernel) - with the causal cumulative norm: the first 59 s agree,
+    which also holds the chain kernel to the per-step kernels over 3700 dependent steps."""
+    meta = dict(seed_w=0, gain=2.0, mask_gain=24.0, norm_type="cumulative_laplace_norm", groups=1)
+    model, _ = build_model(fsn, meta)
+    x = dev(O.make_noisy(2, 16000 * 70, seed=3))
+    long = model.enhance(x)
+    short = model.enhance(x[:, :16000 * 60].contiguous())
+    assert bool(torch.isfinite(long).all())
+    assert (long[:, :16000 * 59] - short[:, :16000 * 59]).abs().max().item() <= 2e-5 * short.abs().max().item()
+
+
 def test_a_spin_bound_poisons_the_output(fsn):
     """The persistent kernels bound every spin; a launch that hit a bound raises its status word and the follow-up
     kernel (poison_if_kernel, here through its test hook) turns the output into NaN - never silent garbage - and
