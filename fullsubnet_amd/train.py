@@ -282,7 +282,8 @@ class SubbandInputOffline(torch.autograd.Function):
     """fullsubnet/model.py:98-125 for norm_type = offline_laplace_norm without materialising the
     unfolded tensor twice: freq_unfold(noisy, n) ++ fb_output, divided by the per-utterance mean of
     the FULL [F, 2n+2, T'] tensor (computed analytically from per-bin sums), restricted to the rows
-    drop_band keeps.  Gradient flows to fb_output only (directly and through the mean)."""
+    drop_band keeps.  Gradients to fb_output and, when asked for, to the noisy magnitude (directly and through the
+    mean)."""
 
     @staticmethod
     def forward(ctx, x, fb_out, n, groups):
@@ -292,13 +293,13 @@ class SubbandInputOffline(torch.autograd.Function):
         count = float(F * (2 * n + 2) * Tp)
         mu = ((x[:, 0].sum(dim=2) * mult[None, :]).sum(dim=1) + fb_out.sum(dim=(1, 2, 3))) / count  # [B]
         den = (mu + 1e-5)[rb]  # [R]
-        ctx.save_for_backward(raw, den, rb, rf)
+        ctx.save_for_backward(raw, den, rb, rf, win_idx, mult)
         ctx.dims = (B, F, Tp, Fs, count)
         return raw / den[:, None, None]
 
     @staticmethod
     def backward(ctx, dy):
-        raw, den, rb, rf = ctx.saved_tensors
+        raw, den, rb, rf, win_idx, mult = ctx.saved_tensors
         B, F, Tp, Fs, count = ctx.dims
         d_fb = torch.zeros((B, 1, F, Tp), dtype=dy.dtype, device=dy.device)
         d_fb[rb, 0, rf, :] = dy[:, -1, :] / den[:, None]
@@ -307,7 +308,14 @@ class SubbandInputOffline(torch.autograd.Function):
         d_mu = torch.zeros((B,), dtype=dy.dtype, device=dy.device)
         d_mu[rb[::Fs]] = -per_row.reshape(-1, Fs).sum(dim=1)  # a sample's rows are one contiguous block
         d_fb += (d_mu / count)[:, None, None, None]
-        return None, d_fb, None, None
+        d_x = None
+        if ctx.needs_input_grad[0]:
+            # x[b, f] feeds every kept row whose window holds bin f (directly) and the mean (with its multiplicity)
+            d_x = torch.zeros((B, F, Tp), dtype=dy.dtype, device=dy.device)
+            d_x.index_put_((rb[:, None].expand_as(win_idx), win_idx), dy[:, :-1, :] / den[:, None, None], accumulate=True)
+            d_x += (d_mu / count)[:, None, None] * mult[None, :, None]
+            d_x = d_x[:, None]
+        return d_x, d_fb, None, None
 
 
 def forward_train(model, noisy_mag):

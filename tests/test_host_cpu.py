@@ -120,11 +120,12 @@ def test_subband_input_function_matches_unfold_cat_norm_dropband():
     from fullsubnet_amd.acoustics.feature import drop_band
     torch.manual_seed(0)
     for B, F, Tp, n, G in [(4, 33, 6, 5, 2), (1, 17, 5, 3, 2), (6, 20, 4, 4, 3)]:
-        x = torch.rand(B, 1, F, Tp)
+        x = torch.rand(B, 1, F, Tp, requires_grad=True)
+        x2 = x.detach().clone().requires_grad_(True)
         fb = torch.rand(B, 1, F, Tp, requires_grad=True)
         fb2 = fb.detach().clone().requires_grad_(True)
         a = SubbandInputOffline.apply(x, fb, n, G)
-        ref = torch.cat([_freq_unfold(x, n).reshape(B, F, 2 * n + 1, Tp), _freq_unfold(fb2, 0).reshape(B, F, 1, Tp)], 2)
+        ref = torch.cat([_freq_unfold(x2, n).reshape(B, F, 2 * n + 1, Tp), _freq_unfold(fb2, 0).reshape(B, F, 1, Tp)], 2)
         ref = _norm(ref, "offline_laplace_norm")
         if B > 1:
             ref = drop_band(ref.permute(0, 2, 1, 3), G).permute(0, 2, 1, 3)
@@ -135,6 +136,7 @@ def test_subband_input_function_matches_unfold_cat_norm_dropband():
         (a * w).sum().backward()
         (ref * w).sum().backward()
         assert torch.allclose(fb.grad, fb2.grad, rtol=1e-4, atol=1e-6), (B, F)
+        assert torch.allclose(x.grad, x2.grad, rtol=1e-4, atol=1e-6), (B, F)  # the input gradient as well
 
 
 def test_leftover_step_kernel_fits_next_to_persistent_kernel(tmp_path):
