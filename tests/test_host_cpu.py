@@ -68,6 +68,21 @@ def test_argument_validation_without_a_gpu():
         assert b"row range" in L.fsn_last_error()
 
 
+def test_two_layer_training_entries_size_queries_without_a_gpu():
+    """fsn_lstm2_forward_train / fsn_lstm2_backward / fsn_lstm2_forward: the workspace queries answer without a device
+    (whatever kernel the shape will run on there) and cover at least what the layer-by-layer path needs."""
+    from fullsubnet_amd import _lib
+    L = _lib.lib()
+    for T, N, I, H in [(193, 2064, 32, 384), (193, 16, 257, 512), (10, 48, 64, 512), (5, 4128, 32, 384)]:
+        fwd = L.fsn_lstm2_train_workspace_bytes(T, N, I, H)
+        bwd = L.fsn_lstm2_bwd_workspace_bytes(T, N, I, H)
+        assert fwd > 0 and bwd >= T * N * 4 * H * 4  # one layer's gate gradients at least (layer by layer)
+        assert L.fsn_lstm2_fwd_workspace_bytes(T, N, I, H, H) >= L.fsn_lstm_layer_fwd_workspace_bytes(T, N, I, H) // 2
+    assert L.fsn_lstm2_forward_is_persistent(2048, 16, 384, 384) in (0, 1)
+    assert L.fsn_lstm2_forward_is_persistent(2048, 64, 384, 384) == 0   # more than 32 input columns
+    assert L.fsn_lstm2_forward_is_persistent(2048, 16, 384, 512) == 0   # unequal widths
+
+
 def test_model_surface_matches_reference_state_dict():
     from fullsubnet_amd import Model, _lib
     from oracle.fullsubnet_oracle import make_params
