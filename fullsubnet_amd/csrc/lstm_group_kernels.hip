@@ -24,6 +24,13 @@
 // results are then garbage, never a hang); flags and status are zeroed by the host before every launch.
 #include "fsn_common.h"
 
+#ifndef FSN_GRP_AD
+#define FSN_GRP_AD 6        // A fragments in flight (probe, 32 clusters: 4 -> 11.34 ms, 6 -> 11.2, 8 -> 11.4 with spills)
+#endif
+#ifndef FSN_GRP_BIAS_LDS
+#define FSN_GRP_BIAS_LDS 1  // biases in LDS also with one cluster per workgroup set (frees 12 registers for the ring)
+#endif
+
 namespace {
 
 constexpr int GH = 384;          // hidden units (both layers)
@@ -140,8 +147,9 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
 
     // biases of this member's 12 column tiles: registers, or LDS when the workgroup keeps two clusters' state (12
     // registers decide between fitting and spilling there; with one cluster the registers are faster)
+    constexpr bool kBiasLds = NCL > 1 || FSN_GRP_BIAS_LDS;
     float bias[GU][4];
-    if (NCL > 1) {
+    if (kBiasLds) {
         if (threadIdx.x < GU * 4 * 16) {
             const int f = threadIdx.x >> 4, u = f >> 2, g = f & 3, l = threadIdx.x & 15;
             bias_sh[f][l] = (LAYER ? a.bias1 : a.xin.bias)[(g * GKC + member * GU + u) * 16 + l];
@@ -172,7 +180,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
         // first touch after the acquire costs a trip to the Infinity Cache / HBM, several chunks of MFMA time.  They
         // are therefore requested AD chunks ahead (a register ring, indexed statically by unrolling the loop AD-fold);
         // the weight fragments (L2 hits) one chunk ahead, through LDS.
-        constexpr int AD = 4;
+        constexpr int AD = FSN_GRP_AD;
         f32x4 ar[AD], bn[GU];
         auto fetch_a = [&](int k) -> f32x4 {
             const int kc = k < n ? k : n - 1;
@@ -318,7 +326,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
             for (int u = 0; u < GU; ++u)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float b = NCL > 1 ? bias_sh[u * 4 + g][lr] : bias[u][g];
+                    const float b = kBiasLds ? bias_sh[u * 4 + g][lr] : bias[u][g];
                     acc[u][g] = f32x4{b, b, b, b};
                 }
             const unsigned ring = t >= GD0 ? peek(k.fl1) : 0xffffffffu;
@@ -355,7 +363,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
                 for (int u = 0; u < GU; ++u)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const float b = NCL > 1 ? bias_sh[u * 4 + g][lr] : bias[u][g];
+                        const float b = kBiasLds ? bias_sh[u * 4 + g][lr] : bias[u][g];
                         acc[u][g] = f32x4{b, b, b, b};
                     }
                 kloop(acc, nullptr, k.xrsrc0, slot0(s), a.o_wih1, GKC, GKC, k.xrsrc0, 0, 0, 0, 0);
