@@ -6,9 +6,10 @@
 // work of the forward can hide (the sub-band input needs the mean of the WHOLE full-band output, model.py:110).  A
 // launch boundary costs a drain, a dispatch and cold operand fetches; here the chain stays resident and a step costs
 // its MFMAs plus one hand-off through memory:
-//   - two stages of H / 4 = 128 workgroups, one workgroup per CU: L0 (layer 0) and L1 (layer 1's recurrence).  A
-//     workgroup owns FOUR hidden units = one 16-column MFMA tile (4 gates x 4 units) for all rows; its weight slices
-//     (512 x 16 floats each) are read ONCE into registers and stay there for all frames - no weight traffic at all;
+//   - two stages of H / 4 workgroups (128 at H = 512; the kernel is a template over H, built for 512 and 384), one
+//     workgroup per CU: L0 (layer 0) and L1 (layer 1's recurrence).  A workgroup owns FOUR hidden units = one 16-column
+//     MFMA tile (4 gates x 4 units) for all rows; its weight slices (H x 16 floats each) are read ONCE into registers
+//     and stay there for all frames - no weight traffic at all;
 //   - the input half of layer 1 (h0_t W_ih1 + b1) has the same A operand as layer 0's recurrence at step t + 1
 //     (h0_t W_hh0): the L0 workgroup computes both from one set of A fragments - its own gates first (critical path),
 //     cell update, h0 store, flag, and then layer 1's projection tile while the partners' flags are on their way.
@@ -19,8 +20,9 @@
 //     write-through / flag recipe of the CDNA guide (Guideline 16, R1: sc1 stores, every storing wave drains, ONE flag
 //     store per copy; one wave polls the 128 flags of the producing stage, barrier, sc1 loads).  No buffer is ever
 //     reused, so there is no back-pressure and the dependence graph is acyclic: with all 256 workgroups resident the
-//     launch cannot deadlock; every spin is bounded anyway (status raised, results garbage, never a hang).  The host
-//     serialises persistent launches of different streams (fsn_api.hip) so that two of them never share the CUs.
+//     launch cannot deadlock; every spin is bounded anyway (status raised, never a hang; the host then turns the
+//     output into NaN, fsn_launch_poison_if).  The host serialises persistent launches of different streams
+//     (fsn_api.hip) so that two of them never share the CUs.  Up to 4095 steps (the reach of a buffer resource).
 // Measured with tools/probe_chain.hip (190 steps): see DESIGN.md 4.6.
 #include "fsn_common.h"
 
