@@ -27,6 +27,9 @@
 #ifndef FSN_GRP_AD
 #define FSN_GRP_AD 6        // A fragments in flight (probe, 32 clusters: 4 -> 11.34 ms, 6 -> 11.2, 8 -> 11.4 with spills)
 #endif
+#ifndef FSN_GRP_CPS
+#define FSN_GRP_CPS 2       // K chunks per LDS stage of the weight fragments = per workgroup barrier (probe: 1 -> 11.09 ms, 2 -> 10.88)
+#endif
 #ifndef FSN_GRP_BIAS_LDS
 #define FSN_GRP_BIAS_LDS 1  // biases in LDS also with one cluster per workgroup set (frees 12 registers for the ring)
 #endif
@@ -110,7 +113,7 @@ struct GrpCl {
 // SAVE (with TRAIN): also keep the activated gates and cell states (the training forward)
 template <int LAYER, int ABL, bool TRAIN, int NCL, bool SAVE>
 __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int cluster_b, int member,
-                                           f32x4 (*bsh)[GU * 4][64], float (*bias_sh)[16]) {
+                                           f32x4 (*bsh)[GU * 4 * FSN_GRP_CPS][64], float (*bias_sh)[16]) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const int Tp = a.Tp;
@@ -205,34 +208,39 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
         };
 #pragma unroll
         for (int d = 0; d < AD; ++d) ar[d] = fetch_a(d);
-        fetch_b(0);
+        constexpr int CPS = FSN_GRP_CPS;
+        static_assert(AD % CPS == 0, "the A ring turns in whole stages");
 #pragma unroll
-        for (int j = 0; j < GU; ++j) bsh[0][wave * GU + j][lane] = bn[j];
+        for (int c = 0; c < CPS; ++c) {
+            fetch_b(c);
+#pragma unroll
+            for (int j = 0; j < GU; ++j) bsh[0][c * GU * 4 + wave * GU + j][lane] = bn[j];
+        }
         __syncthreads();
         for (int k0 = 0; k0 < n; k0 += AD) {
 #pragma unroll
             for (int d = 0; d < AD; ++d) {
                 const int k = k0 + d;
-                if (k < n) {  // uniform
+                if (k < n) {  // uniform (n is a multiple of CPS)
+                    const int c = d % CPS, buf = (k / CPS) & 1;
                     __builtin_amdgcn_sched_barrier(0);  // requests first, pinned under this chunk's MFMAs
-                    fetch_b(k + 1);
+                    fetch_b(k + CPS);                   // the same chunk of the next stage
                     const f32x4 av = ar[d];
                     ar[d] = fetch_a(k + AD);
                     __builtin_amdgcn_sched_barrier(0);
-                    const int buf = k & 1;
 #pragma unroll
                     for (int u = 0; u < GU; ++u) {
                         f32x4 b[4];
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) b[g] = bsh[buf][u * 4 + g][lane];
+                        for (int g = 0; g < 4; ++g) b[g] = bsh[buf][c * GU * 4 + u * 4 + g][lane];
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
                             for (int g = 0; g < 4; ++g) acc[u][g] = mfma16(av[j], b[g][j], acc[u][g]);
                     }
 #pragma unroll
-                    for (int j = 0; j < GU; ++j) bsh[buf ^ 1][wave * GU + j][lane] = bn[j];
-                    __syncthreads();
+                    for (int j = 0; j < GU; ++j) bsh[buf ^ 1][c * GU * 4 + wave * GU + j][lane] = bn[j];
+                    if (c == CPS - 1) __syncthreads();
                 }
             }
         }
@@ -429,7 +437,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
 template <int ABL, bool TRAIN = false, int NCL = 1, bool SAVE = TRAIN>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void lstm2_group_kernel(const GrpArgs a) {
     // weight fragments of one K chunk, shared by the four waves: two stages x 12 fragments x 1 KB
-    __shared__ f32x4 bsh[2][GU * 4][64];
+    __shared__ f32x4 bsh[2][GU * 4 * FSN_GRP_CPS][64];
     __shared__ float bias_sh[GU * 4][16];
     // The first half of the grid runs layer 0, the second half layer 1: blocks are handed out in order, one per CU
     // before any CU gets its second, so that every CU ends up with one workgroup of each layer (speed only).  Within a
