@@ -38,7 +38,10 @@ constexpr int BKC = BG / 16;      // K chunks (96)
 constexpr int BM = 8;             // members per cluster and layer
 constexpr int BU = BH / 16 / BM;  // 16-unit groups per member (3)
 constexpr int BROWS = 64;         // rows per cluster
-constexpr int BCH = 4;            // K chunks per LDS stage
+#ifndef FSN_BPTT_BCH
+#define FSN_BPTT_BCH 4  // probe: 4 -> 12.8 ms, 6 -> 13.0
+#endif
+constexpr int BCH = FSN_BPTT_BCH;  // K chunks per LDS stage
 constexpr int BFS = 32;           // words between flag groups (one cache line each)
 constexpr unsigned kBpttSpin = 1u << 21;
 
@@ -130,28 +133,37 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
             if (ABL & 4) return f32x4{0.5f, 0.25f, -0.125f, 0.0625f};
             return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, a_off, (unsigned)kc * 64u, FSN_BPTT_A_AUX));
         };
-        // stage s holds chunks BCH s .. BCH s + 3, fragment (c, u) at index c NT + u; wave w fetches fragments NT w ..
-        // NT w + NT - 1, `half` selects the first / second three of them
-        auto fetch_b = [&](int s, int half) {
+        // Stage s holds chunks BCH s .. BCH s + BCH - 1, fragment (c, u) at index c NT + u.  The BCH NT fragments of a
+        // stage are fetched in batches of NB (the registers a wave spends on them): batch id = fragments NB id ..;
+        // wave w takes batches w, w + 4, ... - its q-th one at chunk q QSTEP of the stage before, parked in LDS when the
+        // registers are needed again or at the end of that stage.
+        constexpr int NBATCH = BCH * NT / NB, QMAX = (NBATCH + 3) / 4, QSTEP = BCH / QMAX;
+        auto fetch_b = [&](int s, int q) {
+            const int id = wave + 4 * q;
+            if (id < NBATCH) {
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int f = wave * NT + half * NB + j, c = f / NT, u = f % NT;
-                int k = s * BCH + c;
-                k = k < n ? k : n - 1;
-                const unsigned ofs = (u < BU ? b : b2) + ((unsigned)(member * BU + u % BU) * BKC + (unsigned)k) * 256u;
-                bn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, ofs * 4u, 0));
+                for (int j = 0; j < NB; ++j) {
+                    const int f = id * NB + j, c = f / NT, u = f % NT;
+                    int k = s * BCH + c;
+                    k = k < n ? k : n - 1;
+                    const unsigned ofs = (u < BU ? b : b2) + ((unsigned)(member * BU + u % BU) * BKC + (unsigned)k) * 256u;
+                    bn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, ofs * 4u, 0));
+                }
             }
         };
-        auto park_b = [&](int buf, int half) {
+        auto park_b = [&](int buf, int q) {
+            const int id = wave + 4 * q;
+            if (id < NBATCH) {
 #pragma unroll
-            for (int j = 0; j < NB; ++j) bsh[buf][wave * NT + half * NB + j][lane] = bn[j];
+                for (int j = 0; j < NB; ++j) bsh[buf][id * NB + j][lane] = bn[j];
+            }
         };
 #pragma unroll
         for (int d = 0; d < AD; ++d) ar[d] = fetch_a(d);
 #pragma unroll
-        for (int half = 0; half < NT / NB; ++half) {
-            fetch_b(0, half);
-            park_b(0, half);
+        for (int q = 0; q < QMAX; ++q) {
+            fetch_b(0, q);
+            park_b(0, q);
         }
         __syncthreads();
         for (int s0 = 0; s0 < n / BCH; s0 += TURN) {  // TURN stages = one turn of the A ring (statically indexed)
@@ -159,14 +171,10 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
 #pragma unroll
             for (int d = 0; d < AD; ++d) {
                 const int ds = d / BCH, c = d % BCH, s = s0 + ds, buf = s & 1;
-                if (c == 0) {
+                if (c % QSTEP == 0 && c / QSTEP < QMAX) {  // the next stage's fragments, batch by batch
+                    if (c > 0) park_b(buf ^ 1, c / QSTEP - 1);
                     __builtin_amdgcn_sched_barrier(0);  // requests first, pinned under this stage's MFMAs
-                    fetch_b(s + 1, 0);
-                }
-                if (NT > NB && c == BCH / 2) {  // second half of the next stage's fragments, through the same registers
-                    park_b(buf ^ 1, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    fetch_b(s + 1, 1);
+                    fetch_b(s + 1, c / QSTEP);
                 }
                 const f32x4 av = ar[d];
                 ar[d] = fetch_a(s * BCH + c + AD);
@@ -178,7 +186,7 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
                     for (int j = 0; j < 4; ++j) acc[u] = mfma16(av[j], bf[j], acc[u]);
                 }
                 if (c == BCH - 1) {
-                    park_b(buf ^ 1, NT / NB - 1);
+                    park_b(buf ^ 1, QMAX - 1);
                     __syncthreads();
                 }
             }
