@@ -290,10 +290,10 @@ def main():
         for _ in range(warmup):
             step()
         if profile:
-            L.fsn_profile_enable(1)  # hipEvents on the launch stream around every stage (no host sync inside)
+            _lib.profile_enable(True, device)  # hipEvents on the launch stream around every stage (no host sync inside)
         dt, stage_ms = timed_steps(step, fence, steps, (lambda: _lib.profile_read(device)) if profile else None)
         if profile:
-            L.fsn_profile_enable(0)
+            _lib.profile_enable(False, device)
         if world > 1:
             tmax = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

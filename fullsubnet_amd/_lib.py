@@ -117,7 +117,7 @@ SIGNATURES = {
     "fsn_lstm_layer_backward": (_c.c_int, [_f32p, _f32p, _c.c_long, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_int,
                                            _c.c_int, _f32p, _c.c_void_p, _f32p, _c.c_long, _f32p, _f32p, _f32p,
                                            _c.c_void_p, _c.c_size_t, _c.c_void_p]),
-    "fsn_lstm2_forward_is_persistent": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "fsn_lstm2_forward_is_persistent": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_int]),
     "fsn_lstm2_fwd_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "fsn_lstm2_forward": (_c.c_int, [_f32p, _c.c_long] + [_f32p] * 8 + [_c.c_int] * 5 + [_f32p, _c.c_void_p, _c.c_size_t,
                                                                                          _c.c_void_p]),
@@ -146,8 +146,13 @@ SIGNATURES = {
     "fsn_clip_adam_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.POINTER(_c.c_size_t)]),
     "fsn_clip_adam_step": (_c.c_int, [_c.c_int, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_void_p),
                                       _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
-                                      _c.c_void_p, _f32p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
-    "fsn_profile_enable": (_c.c_int, [_c.c_int]),
+                                      _c.c_void_p, _f32p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "fsn_profile_enable": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "fsn_set_persistent_mode": (_c.c_int, [_c.c_int]),
+    "fsn_set_persistent_timeout_ms": (_c.c_int, [_c.c_int]),
+    "fsn_stream_status": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_uint), _c.POINTER(_c.c_uint)]),
+    "fsn_stream_status_clear": (_c.c_int, [_c.c_void_p]),
+    "fsn_debug_hog": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float, _f32p, _c.c_void_p]),
     "fsn_profile_num_stages": (_c.c_int, []),
     "fsn_profile_stage_name": (_c.c_char_p, [_c.c_int]),
     "fsn_profile_read": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_float), _c.c_int]),
@@ -171,9 +176,40 @@ def lib():
     return _lib
 
 
+class FsnTimeout(FsnError):
+    """A persistent kernel ran out of time waiting for its partner workgroups (FSN_ERR_TIMEOUT, include/fsn_hip.h
+    "residency contract"): its outputs are NaN and the stream refuses further persistent launches until
+    `stream_status_clear()`."""
+
+
 def check(rc):
+    if rc == -4:
+        raise FsnTimeout(f"libfsn_hip error {rc}: {lib().fsn_last_error().decode()}")
     if rc != 0:
         raise FsnError(f"libfsn_hip error {rc}: {lib().fsn_last_error().decode()}")
+
+
+def stream_status(device=None, synchronize=True, raise_on_timeout=True):
+    """(status, events) of the current stream of `device`: the sticky record of persistent launches that ran out of
+    time (0, 0 = none).  Raises FsnTimeout when raised (unless raise_on_timeout is False)."""
+    st, ev = ctypes.c_uint(0), ctypes.c_uint(0)
+    rc = lib().fsn_stream_status(stream_ptr(device), 1 if synchronize else 0, ctypes.byref(st), ctypes.byref(ev))
+    if rc != 0 and (raise_on_timeout or rc != -4):
+        check(rc)
+    return st.value, ev.value
+
+
+def stream_status_clear(device=None):
+    check(lib().fsn_stream_status_clear(stream_ptr(device)))
+
+
+def set_persistent_mode(mode):
+    """"auto" (default) or "never": whether the kernels that need their whole grid resident may be used."""
+    check(lib().fsn_set_persistent_mode({"auto": 0, "never": 1}[mode]))
+
+
+def set_persistent_timeout_ms(ms):
+    check(lib().fsn_set_persistent_timeout_ms(int(ms)))
 
 
 def dev_ptr(t, name="tensor", allow_none=False):
@@ -200,6 +236,12 @@ def workspace(nbytes, device):
     if nbytes <= 0:
         raise FsnError(f"workspace query failed: {lib().fsn_last_error().decode()}")
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def profile_enable(on, device=None):
+    """Per-stage hipEvent timing for calls made on the current stream of `device` (per stream: two callers do not
+    race on it)."""
+    check(lib().fsn_profile_enable(stream_ptr(device), 1 if on else 0))
 
 
 def profile_stage_names():

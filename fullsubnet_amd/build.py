@@ -1,24 +1,49 @@
-"""Build libfsn_hip.so (gfx950 only) in-tree with hipcc.  Used by __graft_entry__.build()."""
+"""Build libfsn_hip.so (gfx950 only) in-tree with hipcc.  Used by __graft_entry__.build().
+
+Every translation unit is compiled to its own object under csrc/_obj/ (only the stale ones, in parallel), then linked.
+"""
+import concurrent.futures
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libfsn_hip.so")
-SOURCES = ["fft_kernels.hip", "dft_kernels.hip", "elementwise_kernels.hip", "gemm_kernels.hip", "gemm_f16x3_kernels.hip", "lstm_kernels.hip", "lstm_group_kernels.hip", "lstm_group_bptt_kernels.hip", "fb_chain_kernels.hip", "fb_chain_bptt_kernels.hip", "lstm_f16x3_kernels.hip",
-           "lstm_train_kernels.hip", "gru_kernels.hip", "optim_kernels.hip", "fsn_api.hip"]
+HEADERS = [os.path.join(CSRC, "fsn_common.h"), os.path.join(HERE, "..", "include", "fsn_hip.h")]
+SOURCES = ["fft_kernels.hip", "dft_kernels.hip", "elementwise_kernels.hip", "gemm_kernels.hip",
+           "gemm_f16x3_kernels.hip", "gemm_bf16_kernels.hip", "lstm_kernels.hip", "lstm_group_kernels.hip",
+           "lstm_group_bptt_kernels.hip", "fb_chain_kernels.hip", "fb_chain_bptt_kernels.hip",
+           "lstm_f16x3_kernels.hip", "lstm_train_kernels.hip", "gru_kernels.hip", "optim_kernels.hip",
+           "norm_kernels.hip", "fsn_api.hip"]
 # -ffp-contract=off: elementwise code follows the reference's mul/add rounding sequence; fused
 # multiply-adds are written explicitly (fma / MFMA) where they are wanted.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wno-pass-failed", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-pass-failed",
+         "-Wno-unused-value"]
+
+
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _obj(src):
+    return os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+
+
+def _stale(src):
+    o = _obj(src)
+    if not os.path.exists(o):
+        return True
+    t = os.path.getmtime(o)
+    return any(os.path.getmtime(d) > t for d in [os.path.join(CSRC, src)] + HEADERS)
 
 
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "fsn_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in _sources()] + HEADERS
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -26,7 +51,18 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    os.makedirs(OBJ, exist_ok=True)
+    todo = [s for s in _sources() if force or _stale(s)]
+
+    def compile_one(src):
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", _obj(src)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as pool:
+        list(pool.map(compile_one, todo))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in _sources()] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

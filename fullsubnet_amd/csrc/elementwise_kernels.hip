@@ -290,14 +290,59 @@ int fsn_launch_zero_words(unsigned* p, size_t n, hipStream_t s) {
 // The persistent kernels whose workgroups wait for each other bound every spin; when a bound is hit (a workgroup could
 // not be placed because something else held the CUs for seconds) they raise `status` and finish with garbage.  This
 // makes that visible: the output becomes NaN (nothing is written when status is 0: the kernel costs its launch).
-__global__ void poison_if_kernel(const unsigned* __restrict__ status, float* __restrict__ out, size_t n) {
-    if (*status == 0u) return;
+// It also tells the host: sticky (pinned host memory, may be NULL) = {status of the first such launch, how many}.  A
+// launch with several outputs is reported once per output; the count is a count of poisoned tensors.
+__global__ void poison_if_kernel(const unsigned* __restrict__ status, float* __restrict__ out, size_t n,
+                                 unsigned* __restrict__ sticky) {
+    const unsigned st = *status;
+    if (st == 0u) return;
+    if (sticky && blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned expected = 0u;
+        (void)__hip_atomic_compare_exchange_strong(sticky, &expected, st, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        (void)__hip_atomic_fetch_add(sticky + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const float nan = __builtin_nanf("");
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = nan;
 }
 int fsn_launch_poison_if(const unsigned* status, float* out, size_t n, hipStream_t s) {
     if (!status || !out || n == 0) return FSN_OK;
     const unsigned blocks = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    hipLaunchKernelGGL(poison_if_kernel, dim3(blocks), dim3(256), 0, s, status, out, n);
+    hipLaunchKernelGGL(poison_if_kernel, dim3(blocks), dim3(256), 0, s, status, out, n, fsn_ctx_sticky());
     return fsn_check_launch("poison_if_kernel");
+}
+
+// Test hook (fsn_debug_hog): a foreign kernel that holds CUs for a while.  `heavy`: every wave keeps ~200 registers
+// live (one wave per SIMD then excludes the 216-register group workgroups from that SIMD); LDS is whatever the
+// launch asks for dynamically.  Spins on the constant-rate counter until `ticks` have passed.
+template <bool HEAVY>
+__global__ __launch_bounds__(256) void hog_kernel(unsigned long long ticks, float* sink) {
+    extern __shared__ float hog_lds[];
+    const unsigned long long t0 = (unsigned long long)wall_clock64();
+    float acc[HEAVY ? 192 : 4];
+    constexpr int NA = HEAVY ? 192 : 4;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = (float)(threadIdx.x + i);
+    if (threadIdx.x == 0) hog_lds[0] = 1.0f;
+    __syncthreads();
+    while ((unsigned long long)wall_clock64() - t0 < ticks) {
+        const float m = hog_lds[0];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) acc[i] = __builtin_fmaf(acc[i], m, 1e-9f);
+        __builtin_amdgcn_s_sleep(8);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) sum += acc[i];
+    if (sum == 12345.678f) sink[0] = sum;  // keeps the registers live; never true in practice
+}
+int fsn_launch_hog(int workgroups, int lds_bytes, int heavy, unsigned long long ticks, float* sink, hipStream_t s) {
+    if (lds_bytes > 64 * 1024) {  // above 64 KB of dynamic LDS a kernel opts in
+        (void)hipFuncSetAttribute(heavy ? (const void*)hog_kernel<true> : (const void*)hog_kernel<false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        (void)hipGetLastError();
+    }
+    if (heavy) hipLaunchKernelGGL((hog_kernel<true>), dim3(workgroups), dim3(256), (size_t)lds_bytes, s, ticks, sink);
+    else hipLaunchKernelGGL((hog_kernel<false>), dim3(workgroups), dim3(256), (size_t)lds_bytes, s, ticks, sink);
+    return fsn_check_launch("hog_kernel");
 }

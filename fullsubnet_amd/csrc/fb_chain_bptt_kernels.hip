@@ -25,7 +25,6 @@ constexpr int QKC = QG / 16;      // K chunks (128)
 constexpr int QCW = QKC / 4;      // K chunks per wave (32)
 constexpr int QNW = QH / 16;      // workgroups per stage (32)
 constexpr int QREP = 4;           // copies of a stage's flag array
-constexpr unsigned kQSpin = 1u << 21;
 
 struct ChainBpttArgs {
     const float* dh1;     // [Tp][16][H]  d loss / d hseq1
@@ -35,25 +34,21 @@ struct ChainBpttArgs {
     float* dx;            // [Tp][QNW][4 waves][64][4]: partial tiles of dgates1_t W_ih1 (layer 0's dH)
     unsigned* flags;      // [2][QREP][QNW]: steps published by (L1 | L0, workgroup)
     unsigned* status;
+    unsigned long long spin_ticks;  // wait bound (fsn_spin_ticks)
     int Tp;
 };
 
 // wave 0: all 32 flags of a stage copy >= epoch and (optionally) one more flag >= its epoch; bounded
 __device__ __forceinline__ bool qwait(const unsigned* flags, unsigned epoch, const unsigned* one, unsigned one_epoch,
-                                      unsigned* status) {
+                                      unsigned* status, unsigned long long ticks) {
     const int lane = threadIdx.x & 63;
+    unsigned long long t0 = 0;
     for (unsigned spins = 0;; ++spins) {
         unsigned v = ~0u, w = ~0u;
         if (epoch > 0 && lane < QNW) v = __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (one && lane == 0) w = __hip_atomic_load(one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (__all((int)(v >= epoch && w >= one_epoch))) return true;
-        if ((spins & 255u) == 255u) {
-            const unsigned st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (st != 0 || spins >= kQSpin) {
-                if (lane == 0 && st == 0) __hip_atomic_store(status, 1u + epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
+        if ((spins & 255u) == 255u && fsn_wait_give_up(status, spins, t0, ticks, 1u + epoch)) return false;
     }
 }
 
@@ -172,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void fb_chain_bptt_kernel(const ChainBpttAr
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
             float e_g[4][4], e_ct[4], e_cp[4], e_dh[4];
             if (t < Tp - 1) {
-                if (wave == 0) (void)qwait(fl1 + rep * QNW, done, nullptr, 0, a.status);
+                if (wave == 0) (void)qwait(fl1 + rep * QNW, done, nullptr, 0, a.status, a.spin_ticks);
                 __syncthreads();
                 load_a(ar, a.dg1, t + 1);
             }
@@ -197,7 +192,7 @@ __global__ __launch_bounds__(256, 1) void fb_chain_bptt_kernel(const ChainBpttAr
     for (int t = Tp - 1; t >= 0; --t) {
         const unsigned done = (unsigned)(Tp - 1 - t);
         // dx_t was stored by L1 workgroup j in its iteration t - 1, complete at its epoch Tp - (t - 1) + 1 = done + 3
-        if (wave == 0) (void)qwait(fl0 + rep * QNW, done, fl1 + rep * QNW + j, done + 3, a.status);
+        if (wave == 0) (void)qwait(fl0 + rep * QNW, done, fl1 + rep * QNW + j, done + 3, a.status, a.spin_ticks);
         __syncthreads();
         f32x4 acc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdx, lane16, (unsigned)t * dx_step + dx_wave, 16));
         float e_g[4][4], e_ct[4], e_cp[4], e_dh[4];
@@ -213,13 +208,11 @@ __global__ __launch_bounds__(256, 1) void fb_chain_bptt_kernel(const ChainBpttAr
 }  // namespace
 
 bool fsn_fb_chain_bptt_supported(int H, int N) {
-    if (H != QH || N != 16) return false;
-    int cus = 0, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return false;
-    return cus >= 2 * QNW;
+    if (H != QH || N != 16 || !fsn_persistent_allowed()) return false;
+    return fsn_grid_fits((const void*)fb_chain_bptt_kernel, 256, 2 * QNW);  // residency contract
 }
+// dx is addressed as t * 128 KB through 32-bit byte offsets
+int fsn_fb_chain_bptt_max_steps() { return (int)(0x7fffffffu / ((unsigned)QNW * 4096u)) - 1; }
 size_t fsn_fb_chain_bptt_dx_floats(int Tp) { return (size_t)Tp * QNW * 1024; }
 size_t fsn_fb_chain_bptt_flag_words() { return (size_t)2 * QREP * QNW + 16; }
 size_t fsn_fb_chain_bptt_status_word() { return (size_t)2 * QREP * QNW; }
@@ -229,8 +222,8 @@ size_t fsn_fb_chain_bptt_status_word() { return (size_t)2 * QREP * QNW; }
 int fsn_launch_fb_chain_bptt(const float* dh1, const float* whh1T_p, const float* wih1T_p, const float* whh0T_p,
                              const float* save0, const float* save1, float* dg0, float* dg1, float* dx, unsigned* flags,
                              int Tp, int N, int H, hipStream_t s) {
-    if (!fsn_fb_chain_bptt_supported(H, N) || Tp < 1) {
-        fsn_set_error("fb_chain_bptt: built for H = 512 and 16 rows");
+    if (!fsn_fb_chain_bptt_supported(H, N) || Tp < 1 || Tp > fsn_fb_chain_bptt_max_steps()) {
+        fsn_set_error("fb_chain_bptt: built for H = 512, 16 rows and at most %d steps", fsn_fb_chain_bptt_max_steps());
         return FSN_ERR_ARG;
     }
     if (fsn_launch_zero_words(flags, fsn_fb_chain_bptt_flag_words(), s) != FSN_OK) return FSN_ERR_LAUNCH;
@@ -248,6 +241,7 @@ int fsn_launch_fb_chain_bptt(const float* dh1, const float* whh1T_p, const float
     a.dx = dx;
     a.flags = flags;
     a.status = flags + fsn_fb_chain_bptt_status_word();
+    a.spin_ticks = fsn_spin_ticks();
     a.Tp = Tp;
     hipLaunchKernelGGL(fb_chain_bptt_kernel, dim3(2 * QNW), dim3(256), 0, s, a);
     return fsn_check_launch("fb_chain_bptt_kernel");

@@ -31,7 +31,6 @@ namespace {
 constexpr int CHMAX = 512;      // largest hidden size built (384 and 512 are)
 constexpr int CFS = CHMAX / 4;  // words per copy of a stage's flag array (H / 4 workgroups per stage use it)
 constexpr int CREP = 16;        // copies of a stage's flag array: a poller reads copy (its index % CREP)
-constexpr unsigned kChainSpin = 1u << 21;
 
 struct ChainArgs {
     const float* gx0;     // layer-0 projection incl. bias, fragment order: tile (t * RT + rt, ct) = [64][4]
@@ -50,28 +49,24 @@ struct ChainArgs {
     float* cseq1;
     unsigned* flags;      // [2][CREP][CFS] steps published by (stage 0 = L0 / 1 = L1, workgroup), CREP copies
     unsigned* status;
+    unsigned long long spin_ticks;  // wait bound (fsn_spin_ticks)
     int Tp, RT, Npad;
 };
 
 // wave 0: all 128 flags of a stage >= epoch and (optionally) one more flag >= its epoch, both looked at in the same
 // round trip; bounded
 __device__ __forceinline__ bool chain_wait(const unsigned* flags, int nflags, unsigned epoch, const unsigned* one,
-                                           unsigned one_epoch, unsigned* status) {
+                                           unsigned one_epoch, unsigned* status, unsigned long long ticks) {
     const int lane = threadIdx.x & 63;
     const unsigned long long* f = reinterpret_cast<const unsigned long long*>(flags) + lane;
+    unsigned long long t0 = 0;
     for (unsigned spins = 0;; ++spins) {
         unsigned long long v = ~0ull;
         unsigned w = ~0u;
         if (epoch > 0 && 2 * lane < nflags) v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (one && lane == 0) w = __hip_atomic_load(one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (__all((int)((unsigned)v >= epoch && (unsigned)(v >> 32) >= epoch && w >= one_epoch))) return true;
-        if ((spins & 255u) == 255u) {
-            const unsigned st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (st != 0 || spins >= kChainSpin) {
-                if (lane == 0 && st == 0) __hip_atomic_store(status, 1u + epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
+        if ((spins & 255u) == 255u && fsn_wait_give_up(status, spins, t0, ticks, 1u + epoch)) return false;
     }
 }
 
@@ -236,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void fb_chain_kernel(const ChainArgs a) {
             f32x4 acc = gxn;
             if (owner && t + 1 < Tp) gxn = *reinterpret_cast<const f32x4*>(gx0p + (size_t)(t + 1) * gx0_step);
             if (t > 0) {
-                if (wave == 0 && !(ABL & 1)) (void)chain_wait(fl0 + rep * CFS, CNW, (unsigned)t, nullptr, 0, a.status);
+                if (wave == 0 && !(ABL & 1)) (void)chain_wait(fl0 + rep * CFS, CNW, (unsigned)t, nullptr, 0, a.status, a.spin_ticks);
                 __syncthreads();
                 if (active) load_a(ar, r0, t - 1);
             }
@@ -282,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void fb_chain_kernel(const ChainArgs a) {
         // h1_{s-1} of all workgroups, and the projection tile of step s from L0 workgroup j (complete at flag s + 3)
         if (wave == 0 && !(ABL & 1))
             (void)chain_wait(fl1 + rep * CFS, CNW, (unsigned)s, (ABL & 64) ? nullptr : fl0 + rep * CFS + j, (unsigned)s + 3,
-                             a.status);
+                             a.status, a.spin_ticks);
         __syncthreads();
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
         if (active) {
@@ -309,13 +304,22 @@ __global__ __launch_bounds__(256, 1) void fb_chain_kernel(const ChainArgs a) {
 
 // H = 384 or 512, up to 64 rows, and a device with one CU per workgroup (2 x H / 4: the 64-row variant needs a CU's
 // whole register file)
+namespace {
+template <int CH>
+bool chain_grid_fits(int RT) {
+    const unsigned grid = 2 * (CH / 4);
+    const void *k, *ks;
+    if (RT == 1) k = (const void*)fb_chain_kernel<CH, 4, 0, false>, ks = (const void*)fb_chain_kernel<CH, 4, 0, true>;
+    else if (RT == 2) k = (const void*)fb_chain_kernel<CH, 2, 0, false>, ks = (const void*)fb_chain_kernel<CH, 2, 0, true>;
+    else k = (const void*)fb_chain_kernel<CH, 1, 0, false>, ks = (const void*)fb_chain_kernel<CH, 1, 0, true>;
+    return fsn_grid_fits(k, 256, grid) && fsn_grid_fits(ks, 256, grid);
+}
+}  // namespace
 bool fsn_fb_chain_supported(int H, int Npad) {
     if ((H != 512 && H != 384) || Npad < 16 || Npad > 64 || Npad % 16 != 0) return false;
-    int cus = 0, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return false;
-    return cus >= 2 * (H / 4);
+    if (!fsn_persistent_allowed()) return false;
+    // residency contract: all 2 x H / 4 workgroups at once, by the compiled kernels' own occupancy on this device
+    return H == 512 ? chain_grid_fits<512>(Npad / 16) : chain_grid_fits<384>(Npad / 16);
 }
 // the per-step hand-off buffers are addressed through buffer resources, whose offsets reach 2 GB: 4095 steps
 int fsn_fb_chain_max_steps() { return (int)(0x7fffffffu / ((unsigned)(CHMAX / 4) * 4096u)); }
@@ -369,6 +373,7 @@ int fsn_launch_fb_chain(const float* gx0, const float* whh0_p, const float* wih1
     a.cseq1 = save1 ? save1 + (size_t)Tp * Npad * 4 * H : nullptr;
     a.flags = flags;
     a.status = flags + fsn_fb_chain_status_word();
+    a.spin_ticks = fsn_spin_ticks();
     a.Tp = Tp;
     a.RT = Npad / 16;
     a.Npad = Npad;

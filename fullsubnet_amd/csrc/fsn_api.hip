@@ -9,6 +9,7 @@
 
 #include <stdlib.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -67,13 +68,19 @@ struct StreamCtx {
     int dev = 0;
     hipStream_t aux = nullptr;           // left-over sub-band tiles beside the persistent kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool prof_on = false;                // per-stage profiler requested for this stream (fsn_profile_enable_stream)
     bool prof_events = false;            // profiler events exist
     hipEvent_t ev[ST_COUNT][kMaxSpans][2];
     int spans[ST_COUNT] = {0};
+    // sticky status record of the persistent kernels launched on this stream: pinned host memory the device writes
+    // ({status word of the first launch that ran out of time, number of such launches}); NULL until first needed
+    unsigned* sticky_host = nullptr;
+    unsigned* sticky_dev = nullptr;
 };
 static std::mutex g_ctx_mutex;
 static std::map<std::pair<int, hipStream_t>, StreamCtx*> g_ctx;
-static int g_prof_on = 0;  // process-wide request (a debugging switch); its events live in the StreamCtx
+static std::atomic<int> g_persist_mode{0};          // fsn_set_persistent_mode: 0 auto, 1 never
+static std::atomic<int> g_persist_timeout_ms{20000};  // fsn_set_persistent_timeout_ms
 
 // Persistent kernels whose workgroups wait for each other (the group kernel, the full-band chain) need ALL their
 // workgroups resident at once.  Two of them launched from different streams could each take a part of the chip and wait
@@ -171,8 +178,11 @@ struct StageTimer {
     hipStream_t s;
     StreamCtx* c;
     StageTimer(int stage, hipStream_t stream) : st(stage), span(-1), s(stream), c(nullptr) {
-        if (!g_prof_on) return;
         c = cur_ctx();
+        if (!c->prof_on) {
+            c = nullptr;
+            return;
+        }
         if (!c->prof_events) {
             for (int i = 0; i < ST_COUNT; ++i)
                 for (int j = 0; j < kMaxSpans; ++j) {
@@ -192,9 +202,126 @@ struct StageTimer {
     }
 };
 static void prof_reset() {
-    if (!g_prof_on) return;
     StreamCtx* c = cur_ctx();
+    if (!c->prof_on) return;
     for (int i = 0; i < ST_COUNT; ++i) c->spans[i] = 0;
+}
+
+// ---- residency contract of the persistent kernels (fsn_common.h) -------------------------------------------------
+bool fsn_persistent_allowed() { return g_persist_mode.load(std::memory_order_relaxed) == 0; }
+unsigned long long fsn_spin_ticks() {
+    int khz = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) {
+        (void)hipGetLastError();
+        khz = 100000;  // gfx9: the constant-rate counter runs at 100 MHz
+    }
+    return (unsigned long long)g_persist_timeout_ms.load(std::memory_order_relaxed) * (unsigned long long)khz;
+}
+bool fsn_grid_fits(const void* kernel, int block_threads, unsigned grid) {
+    static std::mutex m;
+    static std::map<std::pair<const void*, int>, int> per_cu;  // (kernel, device) -> resident workgroups per CU
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    std::lock_guard<std::mutex> lock(m);
+    auto it = per_cu.find(std::make_pair(kernel, dev));
+    if (it == per_cu.end()) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block_threads, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            n = 0;
+        }
+        it = per_cu.emplace(std::make_pair(kernel, dev), n).first;
+    }
+    return (unsigned long long)it->second * (unsigned long long)cus >= grid;
+}
+// The sticky record of the running call's stream (created on first use; not under stream capture, where pinned
+// allocations are not allowed: a captured launch then only poisons its outputs).
+unsigned* fsn_ctx_sticky() {
+    StreamCtx* c = cur_ctx();
+    if (c->sticky_dev) return c->sticky_dev;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(t_stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    memset(h, 0, 64);
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostFree(h);
+        return nullptr;
+    }
+    c->sticky_host = static_cast<unsigned*>(h);
+    c->sticky_dev = static_cast<unsigned*>(d);
+    return c->sticky_dev;
+}
+// Called before every persistent launch: a stream on which such a launch ran out of time keeps failing until the
+// caller has looked (fsn_stream_status) and cleared the record - garbage is never consumed silently.
+static int persist_precheck() {
+    StreamCtx* c = cur_ctx();
+    if (c->sticky_host) {
+        const unsigned st = __atomic_load_n(&c->sticky_host[0], __ATOMIC_ACQUIRE);
+        if (st != 0) {
+            fsn_set_error("a persistent kernel launched earlier on this stream ran out of time waiting for its partner "
+                          "workgroups (status %u, %u such launches): its outputs are NaN; see fsn_stream_status / "
+                          "fsn_stream_status_clear", st, __atomic_load_n(&c->sticky_host[1], __ATOMIC_ACQUIRE));
+            return FSN_ERR_TIMEOUT;
+        }
+    }
+    (void)fsn_ctx_sticky();
+    return FSN_OK;
+}
+#define FSN_PERSIST_BEGIN(s)        \
+    FSN_TRY(persist_precheck());    \
+    PersistLaunch gate(s)
+
+extern "C" int fsn_set_persistent_mode(int mode) {
+    FSN_REQUIRE(mode == FSN_PERSISTENT_AUTO || mode == FSN_PERSISTENT_NEVER, "persistent mode %d unknown", mode);
+    g_persist_mode.store(mode, std::memory_order_relaxed);
+    return FSN_OK;
+}
+extern "C" int fsn_set_persistent_timeout_ms(int ms) {
+    FSN_REQUIRE(ms >= 1 && ms <= 3600000, "timeout %d ms out of range [1, 3600000]", ms);
+    g_persist_timeout_ms.store(ms, std::memory_order_relaxed);
+    return FSN_OK;
+}
+extern "C" int fsn_stream_status(void* stream, int synchronize, unsigned* status_out, unsigned* events_out) {
+    CallScope scope(stream);
+    if (synchronize && hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) {
+        fsn_set_error("fsn_stream_status: hipStreamSynchronize failed: %s", hipGetErrorString(hipGetLastError()));
+        return FSN_ERR_LAUNCH;
+    }
+    StreamCtx* c = cur_ctx();
+    const unsigned st = c->sticky_host ? __atomic_load_n(&c->sticky_host[0], __ATOMIC_ACQUIRE) : 0u;
+    const unsigned ev = c->sticky_host ? __atomic_load_n(&c->sticky_host[1], __ATOMIC_ACQUIRE) : 0u;
+    if (status_out) *status_out = st;
+    if (events_out) *events_out = ev;
+    if (st != 0) {
+        fsn_set_error("a persistent kernel on this stream ran out of time waiting for its partner workgroups (status %u, "
+                      "%u such launches): something else held the CUs longer than the bound (fsn_set_persistent_timeout_ms)",
+                      st, ev);
+        return FSN_ERR_TIMEOUT;
+    }
+    return FSN_OK;
+}
+extern "C" int fsn_stream_status_clear(void* stream) {
+    CallScope scope(stream);
+    StreamCtx* c = cur_ctx();
+    if (c->sticky_host) {
+        __atomic_store_n(&c->sticky_host[0], 0u, __ATOMIC_RELEASE);
+        __atomic_store_n(&c->sticky_host[1], 0u, __ATOMIC_RELEASE);
+    }
+    return FSN_OK;
 }
 // Test hook for the safety net of the persistent kernels (fsn_launch_poison_if): out[0..n) becomes NaN iff *status != 0.
 extern "C" int fsn_debug_poison_if(const void* status, float* out, size_t n, void* stream) {
@@ -203,8 +330,22 @@ extern "C" int fsn_debug_poison_if(const void* status, float* out, size_t n, voi
     return fsn_launch_poison_if(static_cast<const unsigned*>(status), out, n, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int fsn_profile_enable(int on) {
-    g_prof_on = on ? 1 : 0;
+// Test hook: a foreign kernel of `workgroups` x 256 threads that holds its CUs (lds_bytes of LDS each, ~200 registers
+// per lane when heavy) for `ms` milliseconds on `stream`; sink is one device float it never writes.
+extern "C" int fsn_debug_hog(int workgroups, int lds_bytes, int heavy, float ms, float* sink, void* stream) {
+    CallScope scope(stream);
+    FSN_REQUIRE(workgroups >= 1 && workgroups <= 65536 && lds_bytes >= 4 && lds_bytes <= 160 * 1024 && ms >= 0.f &&
+                    ms <= 10000.f && sink,
+                "fsn_debug_hog: workgroups in [1, 65536], lds_bytes in [4, 163840], ms in [0, 10000], sink non-NULL");
+    int khz = 100000;
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, t_dev);
+    if (khz <= 0) khz = 100000;
+    return fsn_launch_hog(workgroups, lds_bytes, heavy, (unsigned long long)((double)ms * khz), sink,
+                          static_cast<hipStream_t>(stream));
+}
+extern "C" int fsn_profile_enable(void* stream, int on) {
+    CallScope scope(stream);
+    cur_ctx()->prof_on = on != 0;
     return FSN_OK;
 }
 extern "C" int fsn_profile_num_stages(void) { return ST_COUNT; }
@@ -403,7 +544,8 @@ static CoreDims core_dims(const fsn_fullsubnet_cfg* c, int B, int T, long row0 =
     // clusters per workgroup set (lstm_group_kernels.hip) instead of the persistent kernels at ONE row tile per CU
     // (every CU streams all weights every step there): 26.5 -> 23.4 ms at 16 utterances
     const bool grp_shape = d.Hs == 384 && fsn_round_up(2 * c->sb_num_neighbors + 2, 16) == 32 && c->arith == FSN_ARITH_F32;
-    if (grp_shape && d.rec.tiles >= kGroupTwoFromTiles && d.rec.tiles <= kGroupMaxTiles && d.rec.main_wgs > 0) {
+    if (grp_shape && d.rec.tiles >= kGroupTwoFromTiles && d.rec.tiles <= kGroupMaxTiles && d.rec.main_wgs > 0 &&
+        4 * fsn_lstm2_group_clusters(d.rec.tiles) + 8 >= d.rec.tiles) {  // ... and the device holds (nearly) all of them
         d.rec.rt = 1;
         d.rec.main_wgs = 0;
         d.rec.left_tiles = d.rec.tiles;
@@ -414,8 +556,7 @@ static CoreDims core_dims(const fsn_fullsubnet_cfg* c, int B, int T, long row0 =
     d.l1x = d.fc_fused && c->arith == FSN_ARITH_F32 && fsn_lstm_rec_x_supported(d.Hs, d.rec.rt);
     // 96 - 159 row tiles (6 - 9 utterances; below that the two-layer wavefront of per-step launches is as fast)
     d.grp_clusters = 0;
-    if (d.rec.main_wgs == 0 && d.rec.left_tiles >= kWavefrontBelowTiles && d.Hs == 384 &&
-        fsn_round_up(2 * c->sb_num_neighbors + 2, 16) == 32)
+    if (d.rec.main_wgs == 0 && d.rec.left_tiles >= kWavefrontBelowTiles && grp_shape)  // fp32 only: the group kernel has no f16x3 form
         d.grp_clusters = fsn_lstm2_group_clusters(d.rec.left_tiles);
     return d;
 }
@@ -605,7 +746,7 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         // (layer 1 at step t next to layer 0 at step t + 1): T' + 1 launches instead of 2 T'
         StageTimer st(ST_FB_REC, s);
         if (d.fb_chain) {  // up to 64 utterances, H = 512: the whole chain as one persistent launch
-            PersistLaunch gate(s);
+            FSN_PERSIST_BEGIN(s);
             FSN_TRY(fsn_launch_fb_chain(w.gx_fb, pk + p.fb_whh0, pk + p.fb_wih1, pk + p.fb_whh1, pk + p.fb_b1,
                                         w.fb_exchange, w.fb_flags, w.hseq_fb1, d.Tp, d.Npad_fb, d.Hf, s));
             FSN_TRY(fsn_launch_poison_if(w.fb_flags + fsn_fb_chain_status_word(), w.hseq_fb1,
@@ -715,7 +856,7 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
         }
         {
             StageTimer st(ST_SB_REC_L0, s);
-            PersistLaunch gate(s);
+            FSN_PERSIST_BEGIN(s);
             FSN_TRY(fsn_launch_lstm2_group(&xin, pk + p.sb_whh0, pk + p.sb_wih1, pk + p.sb_whh1, pk + p.sb_b1,
                                            w.grp_exchange, w.grp_flags, &gfc, d.Tp, d.grp_clusters, d.Hs, s));
             // a spin bound hit inside it (see fsn_launch_poison_if): the mask planes become NaN instead of garbage
@@ -1461,14 +1602,34 @@ extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_i
 // fsn_lstm_layer_forward calls; what it adds is the persistent kernels: the full-band shape (H = 512, up to 64 rows)
 // runs on fb_chain_kernel, one launch for both layers and all steps instead of 2 T.
 static bool lstm2_on_chain(int T, int N, int H) { return fsn_fb_chain_supported(H, N) && T <= fsn_fb_chain_max_steps(); }
-// The sub-band shape (H = 384, up to 32 input columns, 96+ row tiles that fill whole 64-row clusters up to a few
-// left-over tiles): clusters on the group kernel, 0 = not this shape.
-static int lstm2_train_group_clusters(int T, int N, int I, int H) {
-    if (H != 384 || fsn_round_up(I, 16) != 32 || N / 16 < kWavefrontBelowTiles) return 0;
-    if ((size_t)T * N * H * sizeof(float) > 0x7fffffffull) return 0;  // the reach of a buffer resource's offsets
-    const int c = fsn_lstm2_group_clusters(N / 16);
-    return N / 16 - 4 * c <= 8 ? c : 0;
+// ONE plan for both directions of the two-layer training entries (fsn_lstm2_forward_train, fsn_lstm2_backward and their
+// workspace queries).  Forward and backward may land on different kernels - every path reads and writes the one save
+// layout of fsn_lstm_layer_forward (gates [T][N][4H] | cell sequence [T][N][H]) and the one hseq layout - so each
+// direction only has to honour its own kernel's bounds, all of which live here:
+//   fwd_group  : clusters of lstm2_group_kernel<.., TRAIN, SAVE> - H = 384, 17 - 32 input columns, 96+ row tiles that
+//                fill whole 64-row clusters up to 8 left-over tiles, hidden sequence within a buffer resource's 2 GB;
+//   fwd_chain  : fb_chain_kernel<.., SAVE> - H = 384 / 512, up to 64 rows, up to 4095 steps (its hand-off offsets);
+//   bptt_group : clusters of lstm2_group_bptt_kernel - H = 384, the same row shape, any input width (dX is a GEMM
+//                afterwards) and any T (one buffer resource per (step, cluster) tile);
+//   bptt_chain : fb_chain_bptt_kernel - H = 512, 16 rows, T below fsn_fb_chain_bptt_max_steps (32-bit dx offsets).
+struct Lstm2TrainPlan {
+    int fwd_group, bptt_group;
+    bool fwd_chain, bptt_chain;
+};
+static Lstm2TrainPlan lstm2_train_plan(int T, int N, int I, int H) {
+    Lstm2TrainPlan p{0, 0, false, false};
+    const int tiles = N / 16;
+    if (H == 384 && tiles >= kWavefrontBelowTiles) {
+        const int cf = fsn_lstm2_group_clusters(tiles), cb = fsn_lstm2_group_bptt_clusters(tiles);
+        if (fsn_round_up(I, 16) == 32 && (size_t)T * N * H * sizeof(float) <= 0x7fffffffull && cf > 0 && tiles - 4 * cf <= 8)
+            p.fwd_group = cf;
+        if (cb > 0 && tiles - 4 * cb <= 8) p.bptt_group = cb;
+    }
+    p.fwd_chain = !p.fwd_group && lstm2_on_chain(T, N, H);
+    p.bptt_chain = !p.bptt_group && fsn_fb_chain_bptt_supported(H, N) && T <= fsn_fb_chain_bptt_max_steps();
+    return p;
 }
+static int lstm2_train_group_clusters(int T, int N, int I, int H) { return lstm2_train_plan(T, N, I, H).fwd_group; }
 extern "C" size_t fsn_lstm2_train_workspace_bytes(int T, int N, int I, int H) {
     const int Ipad = fsn_round_up(I, 16);
     Carver cv(nullptr);
@@ -1482,7 +1643,7 @@ extern "C" size_t fsn_lstm2_train_workspace_bytes(int T, int N, int I, int H) {
         cv.take<float>((size_t)T * left * 4 * H);
         return fsn_round_up_sz(cv.off, 256);
     }
-    if (lstm2_on_chain(T, N, H)) {
+    if (lstm2_train_plan(T, N, I, H).fwd_chain) {
         cv.take<float>((size_t)4 * H * Ipad);
         cv.take<float>((size_t)3 * 4 * H * H);
         cv.take<float>((size_t)2 * 4 * H);
@@ -1543,7 +1704,7 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
             }
         }
         {
-            PersistLaunch gate(s);
+            FSN_PERSIST_BEGIN(s);
             FSN_TRY(fsn_launch_lstm2_group_train(x, ldx, 32, N, wih0_p, whh0_p, wih1_p, whh1_p, b0, b1, hseq0, hseq1, sv0, sv1,
                                                  flags, T, clusters, H, s));
             FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_status_word(clusters), hseq1, (size_t)T * N * H, s));
@@ -1586,7 +1747,7 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
         }
         return FSN_OK;
     }
-    if (!lstm2_on_chain(T, N, H)) {  // layer by layer
+    if (!lstm2_train_plan(T, N, I, H).fwd_chain) {  // layer by layer
         FSN_TRY(fsn_lstm_layer_forward(x, ldx, w_ih0, w_hh0, b_ih0, b_hh0, T, N, I, H, hseq0, save0, save_bytes, workspace,
                                        workspace_bytes, stream));
         return fsn_lstm_layer_forward(hseq0, H, w_ih1, w_hh1, b_ih1, b_hh1, T, N, H, H, hseq1, save1, save_bytes, workspace,
@@ -1618,7 +1779,7 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
     c.p0 = gx0;
     c.bias = b0;
     FSN_TRY(fsn_launch_gemm(a, wih0_p, c, T * (N / 16), 4 * H / 16, Ipad / 16, s));
-    PersistLaunch gate(s);
+    FSN_PERSIST_BEGIN(s);
     FSN_TRY(fsn_launch_fb_chain(gx0, whh0_p, wih1_p, whh1_p, b1, exchange, flags, hseq1, T, N, H, s, hseq0,
                                 static_cast<float*>(save0), static_cast<float*>(save1)));
     return fsn_launch_poison_if(flags + fsn_fb_chain_status_word(), hseq1, (size_t)T * N * H, s);
@@ -1629,13 +1790,19 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
 // SequenceModel blocks of the sibling models live (Improved FullSubNet's band sections: B x {20, 25, 6, 4} rows).
 // H = 384 twice, up to 32 input columns, whole 64-row clusters in the group kernel's ranges (96 - 159 and 224 - 256 row
 // tiles: e.g. Fast FullSubNet's bottleneck at 24 - 39 utterances per rank): clusters, 0 = not this shape
-static int lstm2_infer_group_clusters(int T, int N, int I, int H0, int H1) {
+static int lstm2_infer_group_clusters(int T, int N, int I, int H0, int H1, long ldx) {
     if (H0 != 384 || H1 != 384 || I > 32 || N % 64 != 0 || N / 16 < kWavefrontBelowTiles) return 0;
+    if (ldx != 16 && ldx != 32) return 0;  // the kernel reads x rows of exactly one or two K chunks; anything else: generic path
     if ((size_t)T * N * H0 * sizeof(float) > 0x7fffffffull) return 0;  // the reach of a buffer resource's offsets
     const int tiles = N / 16, c = fsn_lstm2_group_clusters(tiles);
     return 4 * c == tiles ? c : 0;
 }
+static size_t lstm2_fwd_workspace(int T, int N, int I, int H0, int H1, int group_clusters);
+// sized for either row stride of x (the group kernel's buffers are included whenever the shape COULD take it)
 extern "C" size_t fsn_lstm2_fwd_workspace_bytes(int T, int N, int I, int H0, int H1) {
+    return lstm2_fwd_workspace(T, N, I, H0, H1, lstm2_infer_group_clusters(T, N, I, H0, H1, fsn_round_up(I, 16)));
+}
+static size_t lstm2_fwd_workspace(int T, int N, int I, int H0, int H1, int group_clusters) {
     Carver cv(nullptr);
     cv.take<float>((size_t)4 * H0 * fsn_round_up(I, 16));  // W_ih0 fragments
     cv.take<float>((size_t)4 * H0 * H0);                   // W_hh0
@@ -1651,7 +1818,7 @@ extern "C" size_t fsn_lstm2_fwd_workspace_bytes(int T, int N, int I, int H0, int
         cv.take<float>(fsn_fb_chain_exchange_floats(T, N));
         cv.take<unsigned>(fsn_fb_chain_flag_words());
     }
-    if (const int clusters = lstm2_infer_group_clusters(T, N, I, H0, H1)) {  // the group kernel (general two-layer form)
+    if (const int clusters = group_clusters) {  // the group kernel (general two-layer form)
         cv.take<float>((size_t)4 * H0 * 32 + (size_t)3 * 4 * H0 * H0);
         cv.take<unsigned>(fsn_lstm2_group_flag_words(clusters));
     }
@@ -1659,8 +1826,8 @@ extern "C" size_t fsn_lstm2_fwd_workspace_bytes(int T, int N, int I, int H0, int
 }
 // 1 when fsn_lstm2_forward has a persistent kernel for this shape (callers that would otherwise run layer by layer on
 // the per-layer persistent kernels - 1536+ rows - should then prefer it)
-extern "C" int fsn_lstm2_forward_is_persistent(int N, int I, int H0, int H1) {
-    return (H0 == H1 && fsn_fb_chain_supported(H0, N)) || lstm2_infer_group_clusters(1, N, I, H0, H1) > 0;
+extern "C" int fsn_lstm2_forward_is_persistent(int T, int N, int I, long ldx, int H0, int H1) {
+    return (H0 == H1 && lstm2_on_chain(T, N, H0)) || lstm2_infer_group_clusters(T, N, I, H0, H1, ldx) > 0;
 }
 extern "C" int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, const float* w_hh0, const float* b_ih0,
                                  const float* b_hh0, const float* w_ih1, const float* w_hh1, const float* b_ih1,
@@ -1688,7 +1855,7 @@ extern "C" int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, c
     float* gx = cv.take<float>((size_t)T * N * G0);
     float* hseq0 = cv.take<float>((size_t)T * N * H0);
     float* cst = cv.take<float>((size_t)N * (H0 + H1));
-    if (const int clusters = lstm2_infer_group_clusters(T, N, I, H0, H1)) {
+    if (const int clusters = lstm2_infer_group_clusters(T, N, I, H0, H1, ldx)) {
         // both layers, all steps, as one persistent launch of the group kernel (no projection GEMM, no gx): the four
         // packed matrices in one buffer, W_ih0 32 columns wide
         if (H0 == H1 && lstm2_on_chain(T, N, H0)) {
@@ -1701,14 +1868,13 @@ extern "C" int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, c
         float* g_whh0 = g_wih0 + (size_t)G0 * 32;
         float* g_wih1 = g_whh0 + (size_t)G0 * H0;
         float* g_whh1 = g_wih1 + (size_t)G0 * H0;
-        FSN_REQUIRE(ldx == 16 || ldx == 32, "lstm2 forward: this shape needs x rows of 16 or 32 columns (got %ld)", ldx);
         FSN_TRY(fsn_launch_pack(w_ih0, g_wih0, G0, I, G0, 32, s));
         FSN_TRY(fsn_launch_pack(w_hh0, g_whh0, G0, H0, G0, H0, s));
         FSN_TRY(fsn_launch_pack(w_ih1, g_wih1, G1, H0, G1, H0, s));
         FSN_TRY(fsn_launch_pack(w_hh1, g_whh1, G1, H1, G1, H1, s));
         FSN_TRY(fsn_launch_bias_sum(b_ih0, b_hh0, b0, G0, G0, s));
         FSN_TRY(fsn_launch_bias_sum(b_ih1, b_hh1, b1, G1, G1, s));
-        PersistLaunch gate(s);
+        FSN_PERSIST_BEGIN(s);
         FSN_TRY(fsn_launch_lstm2_group_train(x, ldx, (int)ldx, N, g_wih0, g_whh0, g_wih1, g_whh1, b0, b1, hseq0, hseq1, nullptr,
                                              nullptr, flags, T, clusters, H0, s));
         return fsn_launch_poison_if(flags + fsn_lstm2_group_status_word(clusters), hseq1, (size_t)T * N * H1, s);
@@ -1732,7 +1898,7 @@ extern "C" int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, c
     if (H0 == H1 && lstm2_on_chain(T, N, H0)) {  // H = 384 / 512, up to 64 rows: one persistent launch (fb_chain_kernels.hip)
         float* exchange = cv.take<float>(fsn_fb_chain_exchange_floats(T, N));
         unsigned* flags = cv.take<unsigned>(fsn_fb_chain_flag_words());
-        PersistLaunch gate(s);
+        FSN_PERSIST_BEGIN(s);
         FSN_TRY(fsn_launch_fb_chain(gx, whh0_p, wih1_p, whh1_p, b1, exchange, flags, hseq1, T, N, H0, s));
         return fsn_launch_poison_if(flags + fsn_fb_chain_status_word(), hseq1, (size_t)T * N * H0, s);
     }
@@ -1896,12 +2062,7 @@ extern "C" int fsn_lstm_layer_backward(const float* dh, const float* x, long ldx
 // ---- training: backward of two stacked layers (the counterpart of fsn_lstm2_forward_train) ------------------------
 // Two fsn_lstm_layer_backward calls in one; the sub-band shape runs its BPTT - both layers, all steps, the
 // layer-to-layer dX included - as ONE persistent launch (lstm_group_bptt_kernels.hip).
-static int lstm2_bptt_group_clusters(int T, int N, int I, int H) {
-    if (H != 384 || N / 16 < kWavefrontBelowTiles) return 0;
-    const int c = fsn_lstm2_group_bptt_clusters(N / 16);
-    (void)I;
-    return N / 16 - 4 * c <= 8 ? c : 0;
-}
+static int lstm2_bptt_group_clusters(int T, int N, int I, int H) { return lstm2_train_plan(T, N, I, H).bptt_group; }
 extern "C" size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H) {
     const int Ipad = fsn_round_up(I, 16), G = 4 * H;
     const size_t l1 = fsn_lstm_layer_bwd_workspace_bytes(T, N, H, H), l0 = fsn_lstm_layer_bwd_workspace_bytes(T, N, I, H);
@@ -1920,7 +2081,7 @@ extern "C" size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H) {
         cv.take<char>(tn > tn2 ? tn : tn2);
         return fsn_round_up_sz(cv.off, 256);
     }
-    if (fsn_fb_chain_bptt_supported(H, N)) {
+    if (lstm2_train_plan(T, N, I, H).bptt_chain) {
         cv.take<float>((size_t)3 * H * G + (size_t)Ipad * G);  // W_hh1^T, W_ih1^T, W_hh0^T, W_ih0^T fragments
         cv.take<float>((size_t)2 * T * N * G);                 // dgates of both layers
         cv.take<float>(fsn_fb_chain_bptt_dx_floats(T));
@@ -1950,7 +2111,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
         return FSN_ERR_WORKSPACE;
     }
     const int clusters = lstm2_bptt_group_clusters(T, N, I, H);
-    if (!clusters && fsn_fb_chain_bptt_supported(H, N)) {
+    if (!clusters && lstm2_train_plan(T, N, I, H).bptt_chain) {
         // the full-band shape (16 rows, H = 512): both layers' BPTT as one persistent launch (fb_chain_bptt_kernels.hip),
         // then the weight-gradient GEMMs
         hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1972,10 +2133,11 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
         FSN_TRY(fsn_launch_pack(w_hh0, whh0T_p, H, G, H, G, s, 1, H));
         if (dx) FSN_TRY(fsn_launch_pack(w_ih0, wih0T_p, I, G, Ipad, G, s, 1, I));
         {
-            PersistLaunch gate(s);
+            FSN_PERSIST_BEGIN(s);
             FSN_TRY(fsn_launch_fb_chain_bptt(dh1, whh1T_p, wih1T_p, whh0T_p, static_cast<const float*>(save0),
                                              static_cast<const float*>(save1), dg0, dg1, dxp, flags, T, N, H, s));
-            FSN_TRY(fsn_launch_poison_if(flags + fsn_fb_chain_bptt_status_word(), dg0, (size_t)T * N * G, s));
+            // both gate-gradient buffers (dg1 | dg0 are adjacent): every weight gradient and dx derive from them
+            FSN_TRY(fsn_launch_poison_if(flags + fsn_fb_chain_bptt_status_word(), dg1, (size_t)2 * T * N * G, s));
         }
         if (dx) {
             FsnGemmA a{};
@@ -2046,10 +2208,11 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
         }
     }
     {
-        PersistLaunch gate(s);
+        FSN_PERSIST_BEGIN(s);
         FSN_TRY(fsn_launch_lstm2_group_bptt(dh1, whh1T_p, wih1T_p, whh0T_p, sv0, sv1, dg0, dg1, dxbuf, flags, T, N, clusters,
                                             H, s));
-        FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_bptt_status_word(clusters), dg0, (size_t)T * N * G, s));
+        // both gate-gradient buffers (dg1 | dg0 are adjacent): every weight gradient and dx derive from them
+        FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_bptt_status_word(clusters), dg1, (size_t)2 * T * N * G, s));
     }
     if (left > 0) {
         // the rows that do not fill a cluster: step by step on the auxiliary stream, straight into the same buffers

@@ -158,6 +158,7 @@ int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const fl
                                 int Tp, int Nrows, int clusters, int H, hipStream_t s);
 // fb_chain_bptt_kernels.hip: BPTT of the full-band model's two layers (16 rows, H = 512) as one persistent launch
 bool fsn_fb_chain_bptt_supported(int H, int N);
+int fsn_fb_chain_bptt_max_steps();
 size_t fsn_fb_chain_bptt_dx_floats(int Tp);
 size_t fsn_fb_chain_bptt_flag_words();
 size_t fsn_fb_chain_bptt_status_word();
@@ -165,8 +166,38 @@ int fsn_launch_fb_chain_bptt(const float* dh1, const float* whh1T_p, const float
                              const float* save0, const float* save1, float* dg0, float* dg1, float* dx, unsigned* flags,
                              int Tp, int N, int H, hipStream_t s);
 int fsn_launch_zero_words(unsigned* p, size_t n, hipStream_t s);  // elementwise_kernels.hip
-// out[0..n) = NaN if *status != 0 (a persistent kernel hit a spin bound); status words of the three kernels' flag arrays
+// out[0..n) = NaN if *status != 0 (a persistent kernel hit its wait bound); status words of the kernels' flag arrays.
+// The same kernel reports the event to the host: the sticky status record of the caller's stream (fsn_stream_status).
 int fsn_launch_poison_if(const unsigned* status, float* out, size_t n, hipStream_t s);
+int fsn_launch_hog(int workgroups, int lds_bytes, int heavy, unsigned long long ticks, float* sink, hipStream_t s);
+
+// ---- residency contract of the persistent kernels whose workgroups wait for each other ----------
+// (fsn_api.hip)  fb_chain_kernel, lstm2_group_kernel, lstm2_group_bptt_kernel and fb_chain_bptt_kernel make progress
+// only when their WHOLE grid is resident.  The library guarantees what it can decide alone - the grid fits an idle
+// device (fsn_grid_fits, from the compiled kernel's occupancy), its own persistent launches never overlap
+// (PersistLaunch) - and bounds what it cannot: a foreign kernel (RCCL, another stream of the process) that holds CUs
+// delays the missing workgroups until it ends; the resident ones wait for them, by the CLOCK (fsn_spin_ticks, not by a
+// poll count), and a wait that runs out raises the launch's status word: outputs become NaN and the host learns of it
+// through the stream's sticky status (FSN_ERR_TIMEOUT).
+bool fsn_persistent_allowed();        // false: the caller switched these kernels off (fsn_set_persistent_mode)
+unsigned long long fsn_spin_ticks();  // the wait bound in ticks of wall_clock64() on the current device
+// whole grid co-resident on an idle device?  (blocks per CU from hipOccupancyMaxActiveBlocksPerMultiprocessor, cached)
+bool fsn_grid_fits(const void* kernel, int block_threads, unsigned grid);
+unsigned* fsn_ctx_sticky();           // device-visible sticky status record {status, events} of the running call's stream
+
+#ifdef __HIPCC__
+// One 256-poll round of a bounded wait has passed: give up?  The first round only takes the time (t0), so that a wait
+// that succeeds at once never touches the clock.  `code` identifies the wait (1 + step) in the status word.
+__device__ __forceinline__ bool fsn_wait_give_up(unsigned* status, unsigned spins, unsigned long long& t0,
+                                                 unsigned long long ticks, unsigned code) {
+    const unsigned st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long now = (unsigned long long)wall_clock64();
+    if (spins < 256u) t0 = now;
+    if (st == 0 && now - t0 <= ticks) return false;
+    if ((threadIdx.x & 63) == 0 && st == 0) __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+#endif
 size_t fsn_fb_chain_status_word();
 size_t fsn_lstm2_group_status_word(int clusters);
 size_t fsn_lstm2_group_bptt_status_word(int clusters);

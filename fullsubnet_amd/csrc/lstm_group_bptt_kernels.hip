@@ -43,7 +43,6 @@ constexpr int BROWS = 64;         // rows per cluster
 #endif
 constexpr int BCH = FSN_BPTT_BCH;  // K chunks per LDS stage
 constexpr int BFS = 32;           // words between flag groups (one cache line each)
-constexpr unsigned kBpttSpin = 1u << 21;
 
 struct BpttArgs {
     const float* dh1;     // [Tp][N][H]   d loss / d hseq1
@@ -54,6 +53,7 @@ struct BpttArgs {
     float* dx;            // [Tp][N][H]: dgates1_t W_ih1 = layer 0's dH, produced by layer 1 (see below)
     unsigned* flags;      // [clusters][2][BFS]: steps published by (layer 1 | layer 0, member)
     unsigned* status;
+    unsigned long long spin_ticks;  // wait bound (fsn_spin_ticks)
     int Tp, Nrows;
 };
 
@@ -61,19 +61,14 @@ __device__ __forceinline__ void bptt_store_sc1(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
 }
 
-__device__ __forceinline__ bool bptt_poll(unsigned* flags8, unsigned epoch, unsigned* status) {
+__device__ __forceinline__ bool bptt_poll(unsigned* flags8, unsigned epoch, unsigned* status, unsigned long long ticks) {
     const int lane = threadIdx.x & 63;
+    unsigned long long t0 = 0;
     for (unsigned spins = 0;; ++spins) {
         unsigned v = epoch;
         if (lane < BM) v = __hip_atomic_load(flags8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (__all((int)(v >= epoch))) return true;
-        if ((spins & 255u) == 255u) {
-            const unsigned st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (st != 0 || spins >= kBpttSpin) {
-                if (lane == 0 && st == 0) __hip_atomic_store(status, 1u + epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
+        if ((spins & 255u) == 255u && fsn_wait_give_up(status, spins, t0, ticks, 1u + epoch)) return false;
         __builtin_amdgcn_s_sleep(1);
     }
 }
@@ -199,7 +194,7 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
         return v;
     };
     auto wait_peeked = [&](unsigned v, unsigned* flags8, unsigned epoch) {
-        if (wave == 0 && !(ABL & 1) && !__all((int)(v >= epoch))) (void)bptt_poll(flags8, epoch, a.status);
+        if (wave == 0 && !(ABL & 1) && !__all((int)(v >= epoch))) (void)bptt_poll(flags8, epoch, a.status, a.spin_ticks);
         __syncthreads();
 #if FSN_BPTT_A_AUX == 0
         // agent-scope acquire (buffer_inv sc1): the A operand is then read with ordinary loads, which the 16 workgroups
@@ -349,8 +344,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(116))) void 
 
 // one cluster per workgroup set: at most CUs / 8 clusters
 int fsn_lstm2_group_bptt_clusters(int tiles) {
-    int cus = 256, dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int cus = 0, dev = 0;
+    if (!fsn_persistent_allowed() || hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return 0;
+    // residency contract: two workgroups per CU, by the compiled kernel's occupancy
+    if (!fsn_grid_fits((const void*)lstm2_group_bptt_kernel<0>, 256, 2u * (unsigned)cus)) return 0;
     const int cap = cus / BM, c = tiles / 4;
     return c < cap ? c : cap;
 }
@@ -390,6 +389,7 @@ int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const fl
     a.dx = dx;
     a.flags = flags;
     a.status = flags + (size_t)clusters * 2 * BFS;
+    a.spin_ticks = fsn_spin_ticks();
     a.Tp = Tp;
     a.Nrows = Nrows;
     hipLaunchKernelGGL(lstm2_group_bptt_kernel<0>, dim3((unsigned)clusters * BM * 2), dim3(256), 0, s, a);

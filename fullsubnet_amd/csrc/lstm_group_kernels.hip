@@ -43,7 +43,6 @@ constexpr int GU = GH / 16 / GM; // unit groups per member (3)
 constexpr int GROWS = 64;        // rows per cluster
 constexpr int GD0 = 4;           // depth of layer 0's exchange buffer: layer 0 may run GD0 - 2 steps ahead of layer 1
 constexpr int GFS = 32;          // words between the flag groups of (cluster, layer): one 128-byte line each
-constexpr unsigned kSpinLimit = 1u << 21;
 
 struct GrpArgs {
     FsnSbInput xin;        // layer-0 input (mag, fb_out, den, row0, N ...); xin.bias = b0
@@ -56,6 +55,7 @@ struct GrpArgs {
     float* hx1;            // [clusters][2][64][H]     h of layer 1
     unsigned* flags;       // [clusters][2][GFS]: steps published so far by (layer, member), GM words used per group
     unsigned* status;      // 0 = fine
+    unsigned long long spin_ticks;  // wait bound (fsn_spin_ticks)
     FsnRecFc fc;           // output layer; fc.N = valid local rows
     int Tp;
     // training form (TRAIN): the exchange buffers ARE the hidden sequences - hx0 / hx1 = hseq0 / hseq1 [Tp][Nrows][H],
@@ -73,19 +73,14 @@ __device__ __forceinline__ void store_sc1(float* p, float v) {
 
 // One wave polls the eight member flags of a layer (relaxed agent-scope loads, never served by this CU's L1) until all
 // have reached `epoch`; bounded.  Returns false after a timeout (status raised).
-__device__ __forceinline__ bool grp_poll(unsigned* flags8, unsigned epoch, unsigned* status) {
+__device__ __forceinline__ bool grp_poll(unsigned* flags8, unsigned epoch, unsigned* status, unsigned long long ticks) {
     const int lane = threadIdx.x & 63;
+    unsigned long long t0 = 0;
     for (unsigned spins = 0;; ++spins) {
         unsigned v = epoch;
         if (lane < GM) v = __hip_atomic_load(flags8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (__all((int)(v >= epoch))) return true;
-        if ((spins & 255u) == 255u) {
-            const unsigned st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (st != 0 || spins >= kSpinLimit) {
-                if (lane == 0 && st == 0) __hip_atomic_store(status, 1u + epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
+        if ((spins & 255u) == 255u && fsn_wait_give_up(status, spins, t0, ticks, 1u + epoch)) return false;
         __builtin_amdgcn_s_sleep(1);
     }
 }
@@ -255,7 +250,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
         return v;
     };
     auto wait_peeked = [&](unsigned v, unsigned* flags8, unsigned epoch) {
-        if (wave == 0 && !(ABL & 2) && !__all((int)(v >= epoch))) (void)grp_poll(flags8, epoch, a.status);
+        if (wave == 0 && !(ABL & 2) && !__all((int)(v >= epoch))) (void)grp_poll(flags8, epoch, a.status, a.spin_ticks);
         __syncthreads();  // one wave looked for all four
     };
     // h slice of this step is in flight (write-through): every wave drains, then one lane bumps the flag
@@ -475,8 +470,17 @@ size_t fsn_lstm2_group_status_word(int clusters) { return (size_t)clusters * 2 *
 // Clusters of 64 rows that run on the group kernel for `tiles` 16-row tiles: at most one cluster per eight CUs (its 16
 // workgroups, two per CU, must all be resident at once); what is left runs step by step beside it.
 static int grp_slots_cap() {
-    int cus = 256, dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int cus = 0, dev = 0;
+    if (!fsn_persistent_allowed() || hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return 0;
+    // residency contract: two workgroups per CU of EVERY form of the kernel (compiled occupancy, not an assumption)
+    const unsigned grid = 2u * (unsigned)cus;
+    const void* forms[] = {(const void*)lstm2_group_kernel<0, false, 1>,      (const void*)lstm2_group_kernel<0, false, 2>,
+                           (const void*)lstm2_group_kernel<0, true, 1, true>, (const void*)lstm2_group_kernel<0, true, 2, true>,
+                           (const void*)lstm2_group_kernel<0, true, 1, false>, (const void*)lstm2_group_kernel<0, true, 2, false>};
+    for (const void* k : forms)
+        if (!fsn_grid_fits(k, 256, grid)) return 0;
     return cus / GM;
 }
 // One cluster per workgroup set (one set per eight CUs: its 16 workgroups, two per CU, must all be resident), or two
@@ -485,6 +489,7 @@ static int grp_slots_cap() {
 int fsn_lstm2_group_clusters(int tiles) {
     const int cap = grp_slots_cap();
     const int c = tiles / 4;
+    if (cap == 0) return 0;
     if (c >= 2 * cap - cap / 4) return c < 2 * cap ? c : 2 * cap;
     return c < cap ? c : cap;
 }
@@ -518,10 +523,15 @@ int fsn_launch_lstm2_group(const FsnSbInput* xin, const float* whh0_p, const flo
     a.hx1 = exchange + (size_t)clusters * GD0 * GROWS * GH;
     a.flags = flags;
     a.status = flags + (size_t)clusters * 2 * GFS;
+    a.spin_ticks = fsn_spin_ticks();
     a.fc = *fc;
     a.Tp = Tp;
     a.nclusters = clusters;
     const int cap = grp_slots_cap(), slots = clusters < cap ? clusters : cap;
+    if (cap == 0 || clusters > 2 * cap) {
+        fsn_set_error("lstm2_group: %d clusters cannot be co-resident on this device (persistent kernels off, or occupancy)", clusters);
+        return FSN_ERR_ARG;
+    }
     if (clusters > slots) hipLaunchKernelGGL((lstm2_group_kernel<0, false, 2>), dim3((unsigned)slots * GM * 2), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((lstm2_group_kernel<0, false, 1>), dim3((unsigned)slots * GM * 2), dim3(256), 0, s, a);
     return fsn_check_launch("lstm2_group_kernel");
@@ -565,6 +575,7 @@ int fsn_launch_lstm2_group_train(const float* x, long x_ld, int x_cols, int Nrow
     a.hx1 = hseq1;
     a.flags = flags;
     a.status = flags + (size_t)clusters * 2 * GFS;
+    a.spin_ticks = fsn_spin_ticks();
     a.Tp = Tp;
     const bool save = save0 && save1;
     a.gates0 = save0;
@@ -574,6 +585,10 @@ int fsn_launch_lstm2_group_train(const float* x, long x_ld, int x_cols, int Nrow
     a.Nrows = Nrows;
     a.nclusters = clusters;
     const int cap = grp_slots_cap(), slots = clusters < cap ? clusters : cap;
+    if (cap == 0 || clusters > 2 * cap) {
+        fsn_set_error("lstm2_group: %d clusters cannot be co-resident on this device (persistent kernels off, or occupancy)", clusters);
+        return FSN_ERR_ARG;
+    }
     const dim3 grid((unsigned)slots * GM * 2), block(256);
     if (save) {
         if (clusters > slots) hipLaunchKernelGGL((lstm2_group_kernel<0, true, 2, true>), grid, block, 0, s, a);

@@ -41,8 +41,11 @@ __device__ __forceinline__ double block_sum(double x, double* sh) {
     return t;  // valid in thread 0
 }
 
-__global__ __launch_bounds__(256) void grad_sumsq_kernel(TensorTable tt, double* __restrict__ partial) {
+// skipped (may be NULL): {updates skipped so far, snapshot of that count taken here for the update kernel}
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(TensorTable tt, double* __restrict__ partial,
+                                                         unsigned* __restrict__ skipped) {
     __shared__ double sh[4];
+    if (skipped && blockIdx.x == 0 && threadIdx.x == 0) skipped[1] = skipped[0];
     const int ti = find_tensor(tt, blockIdx.x);
     const long base = (long)(blockIdx.x - tt.chunk0[ti]) * kChunk;
     const float* g = tt.g[ti];
@@ -61,16 +64,24 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(TensorTable tt, double*
 
 struct AdamScalars {
     float one_minus_beta1, beta2, one_minus_beta2, step_size, bc2_sqrt, eps, max_norm;
+    double lr, beta1_d, beta2_d;  // for the bias corrections of a step count that skipped updates have shifted
+    int step;
 };
 
 // every block: total norm from the partials (same order everywhere), clip coefficient as
 // torch.nn.utils.clip_grad_norm_ computes it (max_norm / (norm + 1e-6), clamped to 1), then the
 // Adam update of its chunk in torch.optim.Adam's single-tensor operation order:
 //   m.lerp_(g, 1-b1); v.mul_(b2).addcmul_(g, g, 1-b2); denom = sqrt(v)/sqrt(bc2) + eps; p += -step_size * m/denom
+// A non-finite gradient norm (an overflow, or the NaN outputs of a persistent kernel that ran out of time) skips the
+// whole update - parameters, both moments and the gradients stay as they are - like GradScaler.step() does in the
+// reference (fullsubnet/trainer.py:69), and counts it in skipped[0]; the skipped updates do not advance Adam's step
+// count (the host keeps counting calls: the kernel subtracts the snapshot skipped[1]).
 __global__ __launch_bounds__(256) void clip_adam_kernel(TensorTable tt, const double* __restrict__ partial,
-                                                        int n_partials, AdamScalars a, float* __restrict__ norm_out) {
+                                                        int n_partials, AdamScalars a, float* __restrict__ norm_out,
+                                                        unsigned* __restrict__ skipped) {
     __shared__ double sh[4];
-    __shared__ float coef_sh;
+    __shared__ float coef_sh, step_size_sh, bc2_sqrt_sh;
+    __shared__ int ok_sh;
     double acc = 0.0;
     for (int i = threadIdx.x; i < n_partials; i += 256) acc += partial[i];
     const double t = block_sum(acc, sh);
@@ -78,9 +89,25 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(TensorTable tt, const do
         const float norm = (float)sqrt(t);
         float coef = a.max_norm / (norm + 1e-6f);
         coef_sh = coef < 1.0f ? coef : 1.0f;
-        if (blockIdx.x == 0 && norm_out) *norm_out = norm;
+        const bool ok = __builtin_isfinite(norm);
+        ok_sh = ok ? 1 : 0;
+        step_size_sh = a.step_size;
+        bc2_sqrt_sh = a.bc2_sqrt;
+        const unsigned before = skipped ? skipped[1] : 0u;
+        if (before != 0u) {
+            const int k = a.step - (int)before > 1 ? a.step - (int)before : 1;
+            step_size_sh = (float)(a.lr / (1.0 - pow(a.beta1_d, (double)k)));
+            bc2_sqrt_sh = (float)sqrt(1.0 - pow(a.beta2_d, (double)k));
+        }
+        if (blockIdx.x == 0) {
+            if (norm_out) *norm_out = norm;
+            if (!ok && skipped) skipped[0] = before + 1u;
+        }
     }
     __syncthreads();
+    if (!ok_sh) return;
+    a.step_size = step_size_sh;
+    a.bc2_sqrt = bc2_sqrt_sh;
     const float coef = a.max_norm > 0.f ? coef_sh : 1.0f;
     const int ti = find_tensor(tt, blockIdx.x);
     const long base = (long)(blockIdx.x - tt.chunk0[ti]) * kChunk;
@@ -155,7 +182,8 @@ extern "C" size_t fsn_clip_adam_workspace_bytes(int n_tensors, const size_t* num
 
 extern "C" int fsn_clip_adam_step(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                                   float* const* exp_avg_sq, const size_t* numel, const fsn_adam_cfg* cfg,
-                                  float* total_norm_out, void* workspace, size_t workspace_bytes, void* stream) {
+                                  float* total_norm_out, unsigned* skipped_steps, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
     FsnCallScope scope(stream);
     FSN_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel && cfg && workspace, "NULL pointer argument");
     FSN_REQUIRE(n_tensors >= 1 && n_tensors <= kMaxTensors, "clip_adam: 1..%d tensors per call (got %d)", kMaxTensors,
@@ -173,7 +201,7 @@ extern "C" int fsn_clip_adam_step(int n_tensors, float* const* params, float* co
     TensorTable tt;
     const int chunks = build_table(tt, n_tensors, params, grads, exp_avg, exp_avg_sq, numel);
     double* partial = static_cast<double*>(workspace);
-    hipLaunchKernelGGL(grad_sumsq_kernel, dim3(chunks), dim3(256), 0, s, tt, partial);
+    hipLaunchKernelGGL(grad_sumsq_kernel, dim3(chunks), dim3(256), 0, s, tt, partial, skipped_steps);
     FSN_TRY_LAUNCH("grad_sumsq_kernel");
     // scalars exactly as torch.optim.adam._single_tensor_adam forms them (Python doubles -> fp32 kernel scalars)
     const double b1 = cfg->beta1, b2 = cfg->beta2;
@@ -186,7 +214,12 @@ extern "C" int fsn_clip_adam_step(int n_tensors, float* const* params, float* co
     a.bc2_sqrt = (float)sqrt(bc2);
     a.eps = cfg->eps;
     a.max_norm = cfg->max_norm;
-    hipLaunchKernelGGL(clip_adam_kernel, dim3(chunks), dim3(256), 0, s, tt, partial, chunks, a, total_norm_out);
+    a.lr = (double)cfg->lr;
+    a.beta1_d = b1;
+    a.beta2_d = b2;
+    a.step = cfg->step;
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(chunks), dim3(256), 0, s, tt, partial, chunks, a, total_norm_out,
+                       skipped_steps);
     return fsn_check_launch("clip_adam_kernel");
 }
 

@@ -28,6 +28,30 @@ class ClipAdam(torch.optim.Optimizer):
             raise ValueError("ClipAdam: invalid hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, clip_grad_norm_value=clip_grad_norm_value))
         self.total_norm = None  # device scalar: gradient 2-norm before clipping (of the last group stepped)
+        # device counter {updates skipped because the gradient norm was not finite, scratch}: the kernel decides and
+        # counts without a host sync (GradScaler.step()'s inf-skip, fullsubnet/trainer.py:69); `skipped_steps()` reads it
+        self._skipped = {}  # one counter per parameter group (index -> int32[2] on the group's device)
+
+    def skipped_steps(self, group=0):
+        """Updates of parameter group `group` skipped so far because the gradient norm was not finite (one host sync)."""
+        return int(self._skipped[group][0].item()) if group in self._skipped else 0
+
+    def state_dict(self):
+        """torch.optim.Adam's layout; `step` counts the updates APPLIED (skipped ones do not advance Adam's step)."""
+        sd = super().state_dict()
+        skipped = {gi: self.skipped_steps(gi) for gi in self._skipped}
+        if any(skipped.values()):
+            sd = {"state": {i: dict(st) for i, st in sd["state"].items()}, "param_groups": sd["param_groups"]}
+            for gi, g in enumerate(sd["param_groups"]):
+                for i in g["params"]:
+                    if i in sd["state"] and skipped.get(gi, 0):
+                        sd["state"][i]["step"] = sd["state"][i]["step"] - skipped[gi]
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for c in self._skipped.values():
+            c.zero_()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -36,7 +60,7 @@ class ClipAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         L = _lib.lib()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
@@ -69,7 +93,10 @@ class ClipAdam(torch.optim.Optimizer):
                                float(group.get("clip_grad_norm_value", 0.0) or 0.0), step)
             ws = _lib.workspace(L.fsn_clip_adam_workspace_bytes(n, numel), dev)
             self.total_norm = torch.empty(1, dtype=torch.float32, device=dev)
+            if gi not in self._skipped or self._skipped[gi].device != dev:
+                self._skipped[gi] = torch.zeros(2, dtype=torch.int32, device=dev)
             _lib.check(L.fsn_clip_adam_step(n, P, G, M, V, numel, ctypes.byref(cfg), _lib.dev_ptr(self.total_norm),
+                                            ctypes.c_void_p(self._skipped[gi].data_ptr()),
                                             ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_ptr(dev)))
             torch._C._increment_version(ps)  # the raw-pointer update above is invisible to autograd's counters
         return loss

@@ -172,7 +172,7 @@ class SequenceModel(nn.Module):
         h[:, :B, :F] = x.permute(2, 0, 1)
         layer_infer = lstm_layer_infer if self.cell == "LSTM" else gru_layer_infer
         if self.cell == "LSTM" and len(layers) == 2 and (
-                Np < WAVEFRONT_BELOW_ROWS or _lib.lib().fsn_lstm2_forward_is_persistent(Np, Ip, Hp, Hp)):
+                Np < WAVEFRONT_BELOW_ROWS or _lib.lib().fsn_lstm2_forward_is_persistent(T, Np, Ip, Ip, Hp, Hp)):
             # few rows: latency-bound, halve the dependent launches; or a shape with a persistent two-layer kernel
             h = lstm2_infer(h, layers[0], layers[1])
         else:

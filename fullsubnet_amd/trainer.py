@@ -33,6 +33,7 @@ import torch
 
 from .acoustics.feature import istft, stft
 from .acoustics.mask import build_complex_ideal_ratio_mask, decompress_cIRM
+from . import _lib
 from .train import mse_loss, train_step
 
 
@@ -126,6 +127,8 @@ class Trainer:
         self.history = {"Loss/Train": {}, "Loss/Validation_Total": {}, "Loss/With_reverb": {}, "Loss/No_reverb": {},
                         "Score": {}}
         self.last_loss = None
+        self.persistent_timeouts = 0  # training steps in which a persistent kernel ran out of time (update skipped)
+        self.nonfinite_losses = 0     # training steps whose loss was not finite (update skipped on the device)
 
         if resume:
             self._resume_checkpoint()
@@ -172,6 +175,9 @@ class Trainer:
     def _save_checkpoint(self, epoch, is_best_epoch=False):
         d = self._need_dir()
         d.mkdir(parents=True, exist_ok=True)
+        bad = [k for k, v in self._inner().state_dict().items() if not bool(torch.isfinite(v).all())]
+        if bad:  # never write a poisoned state over latest_model.tar
+            raise RuntimeError(f"refusing to checkpoint: non-finite values in {bad[:4]}{' ...' if len(bad) > 4 else ''}")
         state_dict = {
             "epoch": epoch,
             "best_score": self.best_score,
@@ -206,7 +212,21 @@ class Trainer:
         for noisy, clean in self.train_dataloader:
             loss = train_step(self.model, self.optimizer, noisy.to(self.device), clean.to(self.device), self.n_fft,
                               self.hop_length, self.win_length, self.clip_grad_norm_value, self.loss_function)
-            loss_total += loss.item()  # host sync every step, like trainer.py:71
+            value = loss.item()  # host sync every step, like trainer.py:71
+            # the step is complete on the device: did one of its persistent kernels run out of time (include/fsn_hip.h,
+            # "residency contract")?  Its outputs were NaN then, the update was skipped on the device (non-finite
+            # gradient norm), and the stream would refuse further persistent launches until the record is cleared
+            status, events = _lib.stream_status(self.device, synchronize=False, raise_on_timeout=False)
+            if status:
+                self.persistent_timeouts += 1
+                _lib.stream_status_clear(self.device)
+                if self.rank == 0:
+                    print(f"fullsubnet_amd.Trainer: a persistent kernel ran out of time in this step (status {status}, "
+                          f"{events} outputs poisoned); the update was skipped")
+            if not np.isfinite(value):
+                self.nonfinite_losses += 1  # an overflow or a timeout: the update was skipped, keep it out of the mean
+                continue
+            loss_total += value
             n += 1
         self.last_loss = loss_total / max(n, 1)
         self.history["Loss/Train"][epoch] = self.last_loss

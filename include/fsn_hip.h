@@ -30,6 +30,7 @@ extern "C" {
 #define FSN_ERR_ARG (-1)       /* bad shape / null pointer / unsupported configuration */
 #define FSN_ERR_WORKSPACE (-2) /* workspace too small                                  */
 #define FSN_ERR_LAUNCH (-3)    /* hipLaunch / hipMemsetAsync failed                    */
+#define FSN_ERR_TIMEOUT (-4)   /* a persistent kernel ran out of time (see "residency contract" below) */
 
 #define FSN_NORM_OFFLINE_LAPLACE 0    /* audio_zen/model/base_model.py:204-218 */
 #define FSN_NORM_CUMULATIVE_LAPLACE 1 /* audio_zen/model/base_model.py:221-251 */
@@ -184,10 +185,12 @@ int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_ih0, const 
  * encoder / decoder pairs of fast_fullsubnet/model.py:35-96; layer 1 takes the H0 outputs of layer 0).  For
  * blocks with few rows (the latency-bound regime); hseq1 [T][N][H1] is the hidden sequence of the second layer. */
 size_t fsn_lstm2_fwd_workspace_bytes(int T, int N, int I, int H0, int H1);
-/* 1 when fsn_lstm2_forward runs this shape as ONE persistent launch (equal widths of 384 / 512 with up to 64 rows: the
- * chain kernel; 384 twice, up to 32 input columns and 1536 - 2559 or 3584 - 4096 rows in whole 64-row clusters: the
- * group kernel) - then it is also the better choice above the few-row regime it was made for. */
-int fsn_lstm2_forward_is_persistent(int N, int I, int H0, int H1);
+/* 1 when fsn_lstm2_forward runs this call (T steps, N rows of ldx floats) as ONE persistent launch (equal widths of
+ * 384 / 512 with up to 64 rows and 4095 steps: the chain kernel; 384 twice, up to 32 input columns in rows of exactly
+ * 16 or 32 floats, 1536 - 2559 or 3584 - 4096 rows in whole 64-row clusters, hidden sequence below 2 GB: the group
+ * kernel) - then it is also the better choice above the few-row regime it was made for.  Anything else runs on the
+ * generic path of fsn_lstm2_forward (never an error). */
+int fsn_lstm2_forward_is_persistent(int T, int N, int I, long ldx, int H0, int H1);
 int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, const float* w_hh0, const float* b_ih0,
                       const float* b_hh0, const float* w_ih1, const float* w_hh1, const float* b_ih1,
                       const float* b_hh1, int T, int N, int I, int H0, int H1, float* hseq1, void* workspace,
@@ -262,7 +265,11 @@ int fsn_mse_loss(const float* input, const float* target, size_t n, float* loss,
  * two multi-tensor launches.  The arrays are HOST arrays of n_tensors device pointers / element
  * counts.  grads are scaled in place by min(1, max_norm / (total_norm + 1e-6)) exactly like
  * clip_grad_norm_ (max_norm <= 0 disables clipping); total_norm_out (device, may be NULL) receives
- * the unclipped 2-norm.  `step` is the 1-based count of this update (bias corrections). */
+ * the unclipped 2-norm.  `step` is the 1-based count of this call (bias corrections).
+ * A non-finite gradient norm SKIPS the update (parameters, moments and gradients untouched), as GradScaler.step()
+ * does in the reference (trainer.py:69), with no host synchronisation: skipped_steps (device, two words, may be
+ * NULL; zero it once) counts the skipped updates in word 0 (word 1 is scratch), and a skipped update does not
+ * advance Adam's step count - the kernel uses step - skipped for the bias corrections. */
 #define FSN_ADAM_MAX_TENSORS 32
 typedef struct fsn_adam_cfg {
     float lr, beta1, beta2, eps;
@@ -272,16 +279,44 @@ typedef struct fsn_adam_cfg {
 size_t fsn_clip_adam_workspace_bytes(int n_tensors, const size_t* numel);
 int fsn_clip_adam_step(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                        float* const* exp_avg_sq, const size_t* numel, const fsn_adam_cfg* cfg,
-                       float* total_norm_out, void* workspace, size_t workspace_bytes, void* stream);
+                       float* total_norm_out, unsigned* skipped_steps, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* ---- residency contract of the persistent kernels ----------------------------------------------------------
+ * Four kernels - the full-band chain (forward, BPTT) and the sub-band group kernel (forward, BPTT) - run a whole
+ * recurrence as ONE launch whose workgroups hand results to each other step by step; they make progress only while
+ * their whole grid is resident.  What the library guarantees by itself: such a launch is only chosen when the grid
+ * fits an idle device (from the compiled kernel's occupancy on THAT device; other shapes take the per-step paths),
+ * and the library's own persistent launches never overlap, whatever streams they come from (one process).  What it
+ * cannot control is bounded instead: a FOREIGN kernel holding CUs (an RCCL collective beside DDP's backward, work
+ * of another stream) merely delays the workgroups that found no room until it ends - the resident ones wait for
+ * them, by the device's wall clock, up to fsn_set_persistent_timeout_ms (default 20 s).  A wait that runs out means
+ * the foreign kernel was itself waiting for this one (two processes sharing a GPU each holding part of it, graph
+ * replays of two persistent launches on two streams): the launch then finishes with NaN outputs, never garbage and
+ * never a hang, the stream's sticky status is raised, and every later persistent launch on that stream returns
+ * FSN_ERR_TIMEOUT until fsn_stream_status_clear.  Callers that cannot rule that situation out switch the
+ * persistent kernels off (FSN_PERSISTENT_NEVER: the per-step paths, same results, slower for few rows). */
+#define FSN_PERSISTENT_AUTO 0
+#define FSN_PERSISTENT_NEVER 1
+int fsn_set_persistent_mode(int mode);       /* process-wide */
+int fsn_set_persistent_timeout_ms(int ms);   /* process-wide, [1, 3600000] */
+/* The sticky status of `stream`: *status_out = status word of the first launch that ran out of time (0 = none),
+ * *events_out = number of outputs poisoned since the last clear; either may be NULL.  synchronize != 0 waits for the
+ * stream first (the record is written by the device when the launch ends).  Returns FSN_ERR_TIMEOUT when raised. */
+int fsn_stream_status(void* stream, int synchronize, unsigned* status_out, unsigned* events_out);
+int fsn_stream_status_clear(void* stream);
 
 /* Per-stage kernel timing of the last fsn_enhance / fsn_fullsubnet_forward call made ON `stream` with
- * profiling enabled (hipEvents on that stream, kept per (device, stream); forces a sync of them when read).  Stage ids are listed
- * by fsn_profile_stage_name(); used by bench.py for the roofline line.  */
-int fsn_profile_enable(int on);
-/* Test hook: the persistent kernels (full-band chain, sub-band group kernels) bound every spin; a launch that hit a
- * bound raises a status word and a follow-up kernel turns its output into NaN instead of leaving garbage.  This entry
- * runs that follow-up kernel on caller data: out[0..n) = NaN iff *status (a device word) != 0. */
+ * profiling enabled for THAT stream (hipEvents on it, kept per (device, stream); forces a sync of them when read).
+ * Stage ids are listed by fsn_profile_stage_name(); used by bench.py for the roofline line.  */
+int fsn_profile_enable(void* stream, int on);
+/* Test hook: a launch of a persistent kernel that ran out of time raises a status word and a follow-up kernel turns
+ * its output into NaN instead of leaving garbage.  This entry runs that follow-up kernel on caller data:
+ * out[0..n) = NaN iff *status (a device word) != 0, and the stream's sticky status is raised like a real event. */
 int fsn_debug_poison_if(const void* status, float* out, size_t n, void* stream);
+/* Test hook: a foreign kernel - `workgroups` x 256 threads, lds_bytes of LDS each, ~200 registers per lane when
+ * heavy != 0 - that holds its CUs for `ms` milliseconds on `stream`.  sink: one device float (never written). */
+int fsn_debug_hog(int workgroups, int lds_bytes, int heavy, float ms, float* sink, void* stream);
 int fsn_profile_num_stages(void);
 const char* fsn_profile_stage_name(int stage);
 int fsn_profile_read(void* stream, float* ms_per_stage, int n);

@@ -531,8 +531,8 @@ def test_two_streams_and_two_host_threads_are_independent(fsn):
     import threading
     meta = dict(seed_w=0, gain=2.0, mask_gain=24.0, norm_type="offline_laplace_norm", groups=1)
     model, _ = build_model(fsn, meta)
-    inputs = [dev(O.make_noisy(16, 2048, seed=s)) for s in (1, 2)]
-    serial = [model.enhance(x).clone() for x in inputs]
+    inputs = [dev(O.make_noisy(16, 2048, seed=s)) for s in (1, 2, 3)]
+    serial = [model.enhance(x).clone() for x in inputs[:2]]
     model.packed_weights()
     torch.cuda.synchronize()
     results, errors = [None, None], []
@@ -559,19 +559,25 @@ def test_two_streams_and_two_host_threads_are_independent(fsn):
     for got, want in zip(results, serial):
         assert torch.equal(got, want)
     # profiler records are per stream as well: a profiled call on a side stream does not disturb the default stream's
-    L = fsn._lib.lib()
-    L.fsn_profile_enable(1)
+    # and the switch itself is per stream (fsn_profile_enable(stream, on)): a stream that did not ask records nothing
+    side, quiet = torch.cuda.Stream(), torch.cuda.Stream()
+    fsn._lib.profile_enable(True, inputs[0].device)
     try:
         model.enhance(inputs[0])
         main_ms = fsn._lib.profile_read(inputs[0].device)
-        side = torch.cuda.Stream()
         with torch.cuda.stream(side):
+            fsn._lib.profile_enable(True, inputs[1].device)
             model.enhance(inputs[1])
             side_ms = fsn._lib.profile_read(inputs[1].device)
+            fsn._lib.profile_enable(False, inputs[1].device)
+        with torch.cuda.stream(quiet):
+            model.enhance(inputs[2])
+            quiet_ms = fsn._lib.profile_read(inputs[2].device)
         again = fsn._lib.profile_read(inputs[0].device)
     finally:
-        L.fsn_profile_enable(0)
+        fsn._lib.profile_enable(False, inputs[0].device)
     assert main_ms["sb_rec_l0"] > 0 and side_ms["sb_rec_l0"] > 0
+    assert all(v == 0 for v in quiet_ms.values()), quiet_ms
     # the same events read twice (elapsed times are re-derived from the timestamps: equal to rounding)
     assert again.keys() == main_ms.keys()
     assert all(again[k] == pytest.approx(main_ms[k], rel=1e-3, abs=1e-5) for k in main_ms)
@@ -601,9 +607,18 @@ def test_a_spin_bound_poisons_the_output(fsn):
     stream = fsn._lib.stream_ptr(out.device)
     fsn._lib.check(L.fsn_debug_poison_if(status.data_ptr(), fsn._lib.dev_ptr(out), out.numel(), stream))
     assert torch.equal(out, torch.arange(5000, dtype=torch.float32, device="cuda"))
+    assert fsn._lib.stream_status(out.device) == (0, 0)
     status.fill_(7)
     fsn._lib.check(L.fsn_debug_poison_if(status.data_ptr(), fsn._lib.dev_ptr(out), out.numel(), stream))
     assert bool(torch.isnan(out).all())
+    # ... and the host hears of it: the stream's sticky status carries the status word until it is cleared
+    try:
+        with pytest.raises(fsn._lib.FsnTimeout):
+            fsn._lib.stream_status(out.device)
+        assert fsn._lib.stream_status(out.device, raise_on_timeout=False) == (7, 1)
+    finally:
+        fsn._lib.stream_status_clear(out.device)
+    assert fsn._lib.stream_status(out.device) == (0, 0)
 
 
 @pytest.mark.parametrize("batch", [6, 8, 9])

@@ -1,0 +1,274 @@
+"""The residency contract of the persistent kernels (include/fsn_hip.h): fb_chain_kernel,
+lstm2_group_kernel, lstm2_group_bptt_kernel and fb_chain_bptt_kernel need their whole grid resident, and RCCL's
+kernels (the all-gather of a sharded batch, DDP's bucketed all-reduce during backward - base_trainer.py:32,
+recipes/dns_interspeech_2020/train.py:29) are foreign kernels that may hold CUs beside them.  Here: a foreign "hog"
+kernel of growing size beside config 2 at 8 utterances and beside a config-3 training step (bit-equal results, clean
+status); a hog the persistent grid cannot outwait (the time-out surfaces as FsnTimeout, outputs NaN, never garbage;
+the optimizer skips the update); the persistent kernels switched off; and RCCL itself at world size 1 around the same
+stream graph.  Needs an MI355X:  python -m pytest tests -m gpu"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fullsubnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MODEL_KW = dict(num_freqs=257, look_ahead=2, sequence_model="LSTM", fb_num_neighbors=0, sb_num_neighbors=15,
+                fb_output_activate_function="ReLU", sb_output_activate_function=False, fb_model_hidden_size=512,
+                sb_model_hidden_size=384, weight_init=False)
+
+
+@pytest.fixture(scope="module")
+def fsn():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu tests need a ROCm device")
+    import fullsubnet_amd
+    fullsubnet_amd._lib.lib()
+    return fullsubnet_amd
+
+
+def make_model(fsn, seed=0, groups=1, **kw):
+    params = O.make_params(seed=seed, **kw)
+    m = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=groups, **MODEL_KW)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    return m.cuda()
+
+
+def wav(batch, length, seed):
+    return torch.from_numpy(O.make_noisy(batch, length, seed=seed)).cuda()
+
+
+class Hog:
+    """A foreign kernel on its own stream: `workgroups` x 256 threads holding `lds` bytes of LDS each (and ~200
+    registers per lane when heavy) for `ms` milliseconds (fsn_debug_hog)."""
+
+    def __init__(self, fsn):
+        self.fsn = fsn
+        self.stream = torch.cuda.Stream()
+        self.sink = torch.zeros(1, device="cuda")
+
+    def launch(self, workgroups, lds, heavy, ms):
+        L = self.fsn._lib.lib()
+        self.fsn._lib.check(L.fsn_debug_hog(workgroups, lds, 1 if heavy else 0, float(ms), self.fsn._lib.dev_ptr(self.sink),
+                                            self.stream.cuda_stream))
+
+    def wait(self):
+        self.stream.synchronize()
+
+
+def timed(fn):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    out = fn()
+    b.record()
+    b.synchronize()
+    return out, a.elapsed_time(b)
+
+
+# (workgroups, LDS bytes, heavy): a few workgroups .. one per CU .. two per CU; LDS-light / LDS-heavy / register-heavy
+HOGS = [(8, 1024, True), (64, 64 * 1024, False), (128, 160 * 1024, False), (256, 64 * 1024, True),
+        (256, 160 * 1024, False), (512, 32 * 1024, True)]
+
+
+def test_inference_beside_a_foreign_kernel(fsn):
+    """Config 2 at 8 utterances (the per-rank share at 8 GPUs: fb_chain_kernel on 256 workgroups, then lstm2_group_kernel
+    on 512) while a foreign kernel holds a part of the chip or all of it: the workgroups that find no room start when
+    it ends, the resident ones wait for them by the clock.  Bit-equal to the undisturbed run, status clean."""
+    model = make_model(fsn, gain=2.0, mask_gain=24.0).eval()
+    x = wav(8, 24000, 77)
+    ref, t_ref = timed(lambda: model.enhance(x, return_crm=True))
+    ref, t_ref = timed(lambda: model.enhance(x, return_crm=True))
+    assert bool(torch.isfinite(ref[1]).all())
+    hog = Hog(fsn)
+    hog_ms = 60.0
+    for wgs, lds, heavy in HOGS:
+        hog.launch(wgs, lds, heavy, hog_ms)
+        got, t = timed(lambda: model.enhance(x, return_crm=True))
+        hog.wait()
+        status, events = fsn._lib.stream_status(x.device, synchronize=True)
+        print(f"hog {wgs:4d} wgs x {lds // 1024:3d} KB {'heavy' if heavy else 'light'}: enhance {t:6.1f} ms "
+              f"(undisturbed {t_ref:.1f} ms, hog {hog_ms:.0f} ms)")
+        assert (status, events) == (0, 0)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (wgs, lds, heavy)
+        if wgs >= 256 and lds >= 160 * 1024:
+            # a hog that owns every CU's LDS: nothing of the path can start before it ends - the test is not vacuous
+            assert t >= 0.5 * hog_ms, t
+
+
+def test_training_step_beside_a_foreign_kernel(fsn):
+    """One training step at config 3's per-rank shape (16 x 49 152 samples, drop_band groups 2: the full-band chain and
+    its BPTT, the group kernel with saves and the group BPTT kernel - all four persistent kernels) while foreign
+    kernels come and go on another stream, as DDP's bucketed all-reduces do during backward: loss, gradients and updated
+    parameters bit-equal to the undisturbed step."""
+    from fullsubnet_amd.train import train_step
+    noisy, clean = wav(16, 49152, 5), 0.7 * wav(16, 49152, 6)
+
+    def run(hog=None):
+        model = make_model(fsn, seed=3, groups=2).train()
+        opt = fsn.ClipAdam(model.parameters(), lr=1e-3)
+        if hog is not None:
+            for wgs, lds, heavy in [(64, 64 * 1024, True), (256, 160 * 1024, False), (128, 96 * 1024, True)]:
+                hog.launch(wgs, lds, heavy, 25.0)  # back to back on the hog's stream: ~75 ms beside a ~45 ms step
+        loss = train_step(model, opt, noisy, clean)
+        torch.cuda.synchronize()
+        assert fsn._lib.stream_status(noisy.device) == (0, 0)
+        assert opt.skipped_steps() == 0
+        return loss.item(), [p.grad.clone() for p in model.parameters()], [p.detach().clone() for p in model.parameters()]
+
+    ref = run()
+    got = run(Hog(fsn))
+    assert np.isfinite(ref[0]) and got[0] == ref[0]
+    for a, b in zip(ref[1] + ref[2], got[1] + got[2]):
+        assert torch.isfinite(b).all() and torch.equal(a, b)
+
+
+def test_a_wait_that_runs_out_is_reported_not_silent(fsn):
+    """A foreign kernel that holds half the chip for longer than the wait bound (set to 5 ms here; 20 s by default):
+    the resident half of fb_chain_kernel gives up, the launch ends with NaN outputs (never garbage, never a hang), the
+    stream's sticky status is raised - fsn_stream_status reports it, every later persistent launch on the stream is
+    refused with FSN_ERR_TIMEOUT until the record is cleared - and afterwards the stream works as before."""
+    model = make_model(fsn, gain=2.0, mask_gain=24.0).eval()
+    x = wav(8, 12000, 78)
+    ref = model.enhance(x, return_crm=True)
+    torch.cuda.synchronize()
+    hog = Hog(fsn)
+    fsn._lib.set_persistent_timeout_ms(5)
+    try:
+        hog.launch(128, 160 * 1024, False, 400.0)
+        enh, crm = model.enhance(x, return_crm=True)
+        with pytest.raises(fsn._lib.FsnTimeout):
+            fsn._lib.stream_status(x.device, synchronize=True)
+        status, events = fsn._lib.stream_status(x.device, raise_on_timeout=False)
+        assert status != 0 and events >= 1
+        assert bool(torch.isnan(crm).all()) and bool(torch.isnan(enh).all())
+        with pytest.raises(fsn._lib.FsnTimeout):
+            model.enhance(x)
+        hog.wait()
+    finally:
+        fsn._lib.set_persistent_timeout_ms(20000)
+        fsn._lib.stream_status_clear(x.device)
+    assert fsn._lib.stream_status(x.device) == (0, 0)
+    again = model.enhance(x, return_crm=True)
+    assert torch.equal(again[0], ref[0]) and torch.equal(again[1], ref[1])
+
+
+def test_a_poisoned_step_skips_the_update(fsn):
+    """one poisoned launch must not turn the weights and Adam's moments into NaN for good.  A non-finite
+    gradient norm skips the update on the device (no host sync), counts it, and does not advance Adam's step count:
+    the next clean step is bit-equal to the step an undisturbed optimizer takes."""
+    from fullsubnet_amd.train import train_step
+    noisy, clean = wav(4, 2560, 11), 0.7 * wav(4, 2560, 12)
+
+    def fresh():
+        model = make_model(fsn, seed=3, groups=2).train()
+        return model, fsn.ClipAdam(model.parameters(), lr=1e-3, clip_grad_norm_value=10.0)
+
+    m_ref, o_ref = fresh()
+    loss_ref = train_step(m_ref, o_ref, noisy, clean).item()
+
+    model, opt = fresh()
+    before = [p.detach().clone() for p in model.parameters()]
+    bad = noisy.clone()
+    bad[0, 100] = float("nan")  # a NaN in the input: NaN loss, NaN gradients, like a poisoned launch
+    loss_bad = train_step(model, opt, bad, clean)
+    assert not np.isfinite(loss_bad.item())
+    assert opt.skipped_steps() == 1
+    for p, q in zip(model.parameters(), before):
+        assert torch.equal(p.detach(), q)
+    for st in opt.state.values():
+        assert float(st["exp_avg"].abs().max()) == 0.0 and float(st["exp_avg_sq"].abs().max()) == 0.0
+    assert all(int(st["step"]) == 0 for st in opt.state_dict()["state"].values())  # applied updates, not calls
+    loss = train_step(model, opt, noisy, clean).item()
+    assert loss == loss_ref
+    for p, q in zip(model.parameters(), m_ref.parameters()):
+        # the bias corrections of the shifted step count are formed on the device (fp64 pow): equal to the last bit or so
+        assert (p.detach() - q.detach()).abs().max().item() <= 1e-9
+    assert opt.skipped_steps() == 1
+
+
+def test_persistent_kernels_switched_off(fsn):
+    """FSN_PERSISTENT_NEVER: the same calls on the per-step paths (what a caller that cannot rule out a second process
+    on its GPU selects) - same results to rounding, inference and training."""
+    from fullsubnet_amd.train import train_step
+    model = make_model(fsn, gain=2.0, mask_gain=24.0).eval()
+    x = wav(8, 12000, 79)
+    noisy, clean = wav(16, 8192, 5), 0.7 * wav(16, 8192, 6)
+
+    def step():
+        m = make_model(fsn, seed=3, groups=2).train()
+        loss = train_step(m, torch.optim.SGD(m.parameters(), lr=0.0), noisy, clean)
+        return loss.item(), [p.grad.clone() for p in m.parameters()]
+
+    ref = model.enhance(x, return_crm=True)
+    ref_step = step()
+    fsn._lib.set_persistent_mode("never")
+    try:
+        got = model.enhance(x, return_crm=True)
+        got_step = step()
+    finally:
+        fsn._lib.set_persistent_mode("auto")
+    assert (got[1] - ref[1]).abs().max().item() <= 5e-5
+    assert (got[0] - ref[0]).abs().max().item() <= 1e-4 * ref[0].abs().max().item()
+    assert abs(got_step[0] - ref_step[0]) <= 1e-5 * abs(ref_step[0])
+    for a, b in zip(ref_step[1], got_step[1]):
+        assert (a - b).abs().max().item() <= 2e-4 * max(a.abs().max().item(), 1e-6)
+    back = model.enhance(x, return_crm=True)
+    assert torch.equal(back[1], ref[1])
+
+
+# ---- RCCL itself (world size 1: one rank per GPU is all a one-GPU box allows) -----------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rccl_worker(rank, world, port):
+    import torch.distributed as dist
+    import fullsubnet_amd as fsn
+    from fullsubnet_amd.parallel import enhance_row_sharded, enhance_sharded
+    from fullsubnet_amd.train import train_step
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        model = make_model(fsn, gain=2.0, mask_gain=24.0).eval()
+        x = wav(8, 12000, 80)
+        fused = model.enhance(x)
+        # the sharded entry points with their RCCL all-gathers (all_gather_into_tensor) on the real backend
+        utt = enhance_sharded(model.enhance, x)
+        rows = enhance_row_sharded(model, x)
+        assert torch.equal(utt, fused)
+        assert (rows - fused).abs().max().item() <= 1e-4 * fused.abs().max().item()
+        # an all-gather in flight on RCCL's stream while the persistent kernels run on the compute stream
+        big = torch.randn(32 << 20, device="cuda")
+        out = torch.empty_like(big)
+        work = dist.all_gather_into_tensor(out, big, async_op=True)
+        again = model.enhance(x)
+        work.wait()
+        assert torch.equal(again, fused) and torch.equal(out, big)
+        # DistributedDataParallel around Model (base_trainer.py:32): bucketed all-reduce hooks fire during backward,
+        # beside the persistent BPTT kernels; gradients = the plain model's
+        noisy, clean = wav(16, 8192, 5), 0.7 * wav(16, 8192, 6)
+        ref = make_model(fsn, seed=3, groups=2).train()
+        train_step(ref, torch.optim.SGD(ref.parameters(), lr=0.0), noisy, clean)
+        ddp = torch.nn.parallel.DistributedDataParallel(make_model(fsn, seed=3, groups=2).train(), device_ids=[0])
+        loss = train_step(ddp, torch.optim.SGD(ddp.parameters(), lr=0.0), noisy, clean)
+        assert torch.isfinite(loss)
+        for (k, p), (_, q) in zip(ref.named_parameters(), ddp.module.named_parameters()):
+            assert torch.equal(p.grad, q.grad), k
+        assert fsn._lib.stream_status(x.device) == (0, 0)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world_size_one(fsn):
+    """`nccl` (= RCCL) has run on this stream graph at least once: process-group init on the GPU, the two sharded
+    enhancement entry points, an all-gather in flight beside the persistent kernels, DDP around Model."""
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_worker, args=(1, _free_port()), nprocs=1, join=True)

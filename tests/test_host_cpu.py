@@ -78,9 +78,10 @@ def test_two_layer_training_entries_size_queries_without_a_gpu():
         bwd = L.fsn_lstm2_bwd_workspace_bytes(T, N, I, H)
         assert fwd > 0 and bwd >= T * N * 4 * H * 4  # one layer's gate gradients at least (layer by layer)
         assert L.fsn_lstm2_fwd_workspace_bytes(T, N, I, H, H) >= L.fsn_lstm_layer_fwd_workspace_bytes(T, N, I, H) // 2
-    assert L.fsn_lstm2_forward_is_persistent(2048, 16, 384, 384) in (0, 1)
-    assert L.fsn_lstm2_forward_is_persistent(2048, 64, 384, 384) == 0   # more than 32 input columns
-    assert L.fsn_lstm2_forward_is_persistent(2048, 16, 384, 512) == 0   # unequal widths
+    assert L.fsn_lstm2_forward_is_persistent(100, 2048, 16, 16, 384, 384) in (0, 1)
+    assert L.fsn_lstm2_forward_is_persistent(100, 2048, 64, 64, 384, 384) == 0   # more than 32 input columns
+    assert L.fsn_lstm2_forward_is_persistent(100, 2048, 16, 16, 384, 512) == 0   # unequal widths
+    assert L.fsn_lstm2_forward_is_persistent(100, 2048, 16, 48, 384, 384) == 0   # x rows wider than two K chunks
 
 
 def test_model_surface_matches_reference_state_dict():

@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
     BpttArgs a{};
     a.dh1 = dh1; a.wbase = w; a.o_whh1T = 0; a.o_wih1T = BH * BG; a.o_whh0T = 2 * BH * BG;
     a.gates0 = sv0; a.cseq0 = sv0 + TN * BG; a.gates1 = sv1; a.cseq1 = sv1 + TN * BG; a.dg1 = dg; a.dg0 = dg + TN * BG; a.dx = dx;
-    a.flags = flags; a.status = flags + (size_t)clusters * 2 * BFS; a.Tp = Tp; a.Nrows = N;
+    a.flags = flags; a.status = flags + (size_t)clusters * 2 * BFS; a.spin_ticks = 1ull << 31; a.Tp = Tp; a.Nrows = N;
     const double mfma_us = 2.0 * 64 * 48 * (3.0 * BG) / (64.0 * 4 * 2.4e3);  // per step and CU (one member of each layer) at 2.4 GHz
     const float t0 = run<0>(a, clusters);
     unsigned st = 0; hipMemcpy(&st, a.status, 4, hipMemcpyDeviceToHost);

@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
     ChainArgs a{};
     a.gx0 = gx0; a.whh0_p = w; a.wih1_p = w + (size_t)4 * H * H; a.whh1_p = w + (size_t)8 * H * H; a.b1 = b1;
     a.hx0 = ex; a.hx1 = ex + (size_t)Tp * Npad * H; a.gx1 = ex + (size_t)2 * Tp * Npad * H; a.hseq1 = hseq;
-    a.flags = flags; a.status = flags + fsn_fb_chain_status_word(); a.Tp = Tp; a.RT = Npad / 16; a.Npad = Npad;
+    a.flags = flags; a.status = flags + fsn_fb_chain_status_word(); a.spin_ticks = 1ull << 31; a.Tp = Tp; a.RT = Npad / 16; a.Npad = Npad;
     if (a.RT == 1) sweep<4>(a, Tp);
     else if (a.RT == 2) sweep<2>(a, Tp);
     else sweep<1>(a, Tp);

@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
     a.xin.mag = mag; a.xin.fb_out = fb; a.xin.den = den; a.xin.bias = bias; a.xin.den_mode = 0;
     a.xin.B = B; a.xin.Tp = Tp; a.xin.F = F; a.xin.FP = FP; a.xin.N = B * F < clusters * 64 ? B * F : clusters * 64; a.xin.nb = 15; a.xin.kin_chunks = 2;
     a.wbase = w; a.o_wih0 = 0; a.o_whh0 = 4 * H * 32; a.o_wih1 = a.o_whh0 + 4 * H * H; a.o_whh1 = a.o_wih1 + 4 * H * H;
-    a.bias1 = bias + 4 * H; a.hx0 = ex; a.hx1 = ex + (size_t)clusters * GD0 * 64 * H; a.flags = flags; a.status = flags + (size_t)clusters * 2 * GFS;
+    a.bias1 = bias + 4 * H; a.hx0 = ex; a.hx1 = ex + (size_t)clusters * GD0 * 64 * H; a.flags = flags; a.status = flags + (size_t)clusters * 2 * GFS; a.spin_ticks = 1ull << 31;
     a.fc.w_p = fcw; a.fc.bias = fcb; a.fc.crm_r = cr; a.fc.crm_i = ci; a.fc.N = a.xin.N; a.fc.F = F; a.fc.FP = FP; a.fc.T = T; a.fc.la = 2;
     a.Tp = Tp;
     const double mfma_us = 2.0 * 64 * (1536.0 / 8) * (416 + 768) / (64.0 * 4 * 2.4e3);  // per iteration and CU at 2.4 GHz
