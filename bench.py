@@ -19,8 +19,9 @@ Prints ONE JSON line (rank 0) with the driver's contract keys plus
                  launch stream; `traffic` / `mfma_busy_frac` from the committed rocprofv3 PMC passes of this config
   cpu_baseline - the reference's ATen operator sequence (oracle/aten_baseline.py) timed on this box's host cores
                  on a bounded sample of the same workload (rank 0, N = 1 only); the numpy oracle as `oracle_port`
-  experimental_f16x3, train_step - side figures (N = 1): the opt-in split-precision kernels and one training step
-                 at BASELINE config 3's per-rank shape.
+  experimental_f16x3, train_step, fast_b256, improved48_b32 - side figures (N = 1): the opt-in split-precision
+                 kernels, one training step at BASELINE config 3's per-rank shape, Fast FullSubNet at batch 256
+                 (config 4) and Improved FullSubNet at 48 kHz, batch 32 (config 5).
 """
 import argparse
 import json
@@ -71,13 +72,14 @@ def _time_aten(model, length, batch, threads):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(params, length, budget_s=20.0):
+def cpu_baseline(params, length, budget_s=30.0):
     """The reference's CPU arithmetic on this box's host cores, on a bounded sample of the same workload.
 
     Headline figure (`value`): oracle/aten_baseline.py - the ATen operator sequence the reference itself executes
     (torch.stft, nn.LSTM(257,512,2) + Linear + ReLU, F.unfold, nn.LSTM(32,384,2) + Linear, decompress, torch.istft;
-    oneDNN / MKL kernels of the PyTorch build on this box) - whole 3 s utterances in one batch, as many as fit
-    ~2/3 of the budget, with the thread count that measured fastest in a one-utterance calibration.
+    oneDNN / MKL kernels of the PyTorch build on this box) - whole 3 s utterances in ONE batch (up to config 2's 64,
+    as many as the budget allows), timed at several thread counts ON THAT BATCH: `value` is the fastest, `all_cores`
+    the figure with every host thread the process may use (n = len(os.sched_getaffinity(0))).
     Second, labelled figure (`oracle_port`): the numpy restatement that the parity tests use as their checker."""
     from oracle import aten_baseline as A
     from oracle import fullsubnet_oracle as O
@@ -85,18 +87,26 @@ def cpu_baseline(params, length, budget_s=20.0):
     frames_per_utt = 1 + length // HOP
     model = A.AtenFullSubNet(params).eval()
     _time_aten(model, length, 1, min(avail, 16))  # warm-up: thread pools, oneDNN primitive cache, page faults
-    cal = {}
-    for th in sorted({min(avail, t) for t in (8, 16, 32, 64)}):
-        cal[th] = _time_aten(model, length, 1, th)
+    t1 = _time_aten(model, length, 1, min(avail, 16))
+    # a batch costs ~0.35 of its utterances run one by one (measured); three timed passes share the budget
+    nb = int(max(1, min(64, (budget_s / 3.0) // max(0.35 * t1, 1e-3))))
+    cal, spent = {}, 0.0
+    for th in sorted({min(avail, t) for t in (16, 64, avail)}):
+        if cal and spent > budget_s:  # never skip the first figure; later ones only while the budget lasts
+            break
+        cal[th] = _time_aten(model, length, nb, th)
+        spent += cal[th]
     threads = min(cal, key=cal.get)
-    nb = int(max(1, min(64, (budget_s * 0.66) // max(cal[threads], 1e-3))))
-    dt = min(_time_aten(model, length, nb, threads) for _ in range(1 if nb > 4 else 2))
+    dt = cal[threads]
     out = {"value": round(nb * frames_per_utt / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
            "sample": f"{nb} x {length / SR:.1f} s utterance(s) in one batch, full path stft -> model -> decompress -> "
                      f"mask -> istft as the ATen operator sequence of the reference (oracle/aten_baseline.py: torch "
                      f"{torch.__version__} CPU kernels, oneDNN LSTM + MKL FFT), {threads} of {avail} host threads "
-                     f"(fastest of {sorted(cal)} in a 1-utterance calibration), {dt:.1f} s wall",
-           "rtf_speedup": round(nb * length / SR / dt, 3)}
+                     f"(fastest of {sorted(cal)}, each timed on this same batch), {dt:.1f} s wall",
+           "rtf_speedup": round(nb * length / SR / dt, 3),
+           "by_threads": {str(th): round(nb * frames_per_utt / t, 2) for th, t in sorted(cal.items())},
+           "all_cores": ({"value": round(nb * frames_per_utt / cal[avail], 2), "unit": "frames/s", "cores": avail}
+                         if avail in cal else None)}
     # the parity checker (numpy + torch-CPU matmuls), for the record: it scales to ~16 threads
     cores = min(16, avail)
     torch.set_num_threads(cores)
@@ -160,11 +170,26 @@ def training_step_ms(device, steps=5):
             "frac_fp32_mfma_peak": round(flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3)}
 
 
+def family_figure(which, batch, peak_tflops, device):
+    """Side figure for a sibling model (BASELINE configs 4 / 5): the whole path on `batch` x 3 s of synthetic audio,
+    tools/bench_family.py:family_step - ms per step, frames/s and the fraction of the fp32-MFMA peak from SURVEY
+    8(d)'s MFLOP per frame."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_family as BF
+    m = BF.family_step(which, batch, device=device, steps=5, warmup=2)
+    torch.cuda.empty_cache()
+    return {"ms_per_step": round(m["ms_per_step"], 3), "value": round(m["frames_per_s"], 1), "unit": "frames/s",
+            "rtf_speedup_audio_s_per_s": round(m["rtf"], 1), "batch": batch, "samples": m["samples"],
+            "sample_rate": m["sample_rate"], "frames_per_utterance": m["frames_per_utterance"],
+            "mflop_per_frame": round(m["mflop_per_frame"], 1), "tflops": round(m["tflops"], 1),
+            "frac_fp32_mfma_peak": round(m["tflops"] / peak_tflops, 3), "finite": m["finite"], "dtype": "f32"}
+
+
 def measured_counters():
-    """PMC figures of the dominant kernel from the committed rocprofv3 passes of this round (profiles/
-    r02_pmc.json, produced by tools/rocprof_pmc.py from separate --pmc runs of `bench.py` at config 2): HBM bytes
-    per launch (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE) and the MFMA-busy fraction of the launch."""
-    for name in ("r02_pmc.json", "r01_hbm_traffic_end.json"):
+    """PMC figures of the dominant kernel REPLAYED from the committed rocprofv3 passes (profiles/rNN_pmc.json, produced
+    by tools/rocprof_pmc.py from separate --pmc runs of `bench.py` at config 2): HBM bytes per launch (FETCH_SIZE x 2
+    on gfx950 + WRITE_SIZE) and the MFMA-busy fraction of the launch.  Not measured in this run - the keys say so."""
+    for name in ("r03_pmc.json", "r02_pmc.json", "r01_hbm_traffic_end.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)["dominant_kernel"]
@@ -189,7 +214,7 @@ def main():
                          "of the batch x frequency rows of the sub-band model (all-gather of the full-band mask; "
                          "balances any batch over any number of ranks).  auto: utterances when they divide evenly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--cpu-budget", type=float, default=30.0)
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements (other scaling mode, opt-in arithmetic, training step)")
     ap.add_argument("--host-io", action="store_true",
@@ -346,7 +371,9 @@ def main():
                          # PMC passes are separate rocprofv3 runs at config 2 (B = 64, 1 GPU)
                          "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc)",
-                         "mfma_busy_frac": mfma_busy, "pmc_source": pmc_src,
+                         "traffic_source": (f"replayed from {pmc_src} (separate rocprofv3 --pmc passes of this command "
+                                            f"at config 2), NOT measured in this run") if pmc_src else None,
+                         "mfma_busy_frac_replayed": mfma_busy, "pmc_source": pmc_src,
                          "flops_per_launch": rec_flops / 2, "ms_per_launch": round(rec_ms / 2, 3),
                          "launches": {"sb_rec_l0": {"flops": 2.0 * MAC_REC_L0 * rows_steps,
                                                     "ms": round(stage_ms.get("sb_rec_l0", 0.0), 3)},
@@ -385,6 +412,12 @@ def main():
             out["train_step"] = training_step_ms(device)
         except Exception as e:  # a side figure must never break the benchmark line
             out["train_step"] = {"error": str(e)[:200]}
+        # BASELINE configs 4 and 5 (fast_fullsubnet/model.py:143-202, improved_fullsubnet/model.py:541-591)
+        for key, which, b in (("fast_b256", "fast", 256), ("improved48_b32", "improved48", 32)):
+            try:
+                out[key] = family_figure(which, b, PEAK_FP32_MFMA_TFLOPS, device)
+            except Exception as e:
+                out[key] = {"error": str(e)[:200]}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             torch.cuda.synchronize()

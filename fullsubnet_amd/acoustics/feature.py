@@ -18,8 +18,10 @@ def hann_window(n_fft, device):
     return w
 
 
-def stft(y, n_fft, hop_length, win_length):
-    """feature.py:9-50.  y: [B, T] or [B, C, T] -> (mag, phase, real, imag), each [B, F, T] / [B, C, F, T]."""
+def stft(y, n_fft, hop_length, win_length, return_phase=True):
+    """feature.py:9-50.  y: [B, T] or [B, C, T] -> (mag, phase, real, imag), each [B, F, T] / [B, C, F, T].
+    return_phase=False (every caller inside this package: the path never reads the phase, inferencer.py:132
+    discards it) skips the atan2 pass and returns None in its place."""
     num_dims = y.dim()
     assert num_dims == 2 or num_dims == 3, "Only support 2D or 3D Input"
     batch_size, num_samples = y.shape[0], y.shape[-1]
@@ -35,9 +37,10 @@ def stft(y, n_fft, hop_length, win_length):
     _lib.check(L.fsn_stft(_lib.dev_ptr(y, "y"), B, num_samples, n_fft, hop_length, win_length,
                           _lib.dev_ptr(hann_window(n_fft, y.device)), _lib.dev_ptr(real), _lib.dev_ptr(imag),
                           _lib.dev_ptr(mag), _lib.stream_ptr(y.device)))
-    phase = torch.atan2(imag, real)  # not on the hot path: inferencer.py:132 discards it
+    phase = torch.atan2(imag, real) if return_phase else None  # only for callers that ask: nothing on the path reads it
     if num_dims == 3:
-        mag, phase, real, imag = (t.reshape(batch_size, -1, F, T) for t in (mag, phase, real, imag))
+        mag, real, imag = (t.reshape(batch_size, -1, F, T) for t in (mag, real, imag))
+        phase = phase.reshape(batch_size, -1, F, T) if return_phase else None
     return mag, phase, real, imag
 
 

@@ -15,7 +15,8 @@ import torch
 import torch.nn as nn
 
 from .base_model import BaseModel, look_ahead_pad
-from .sequence_model import SequenceModel, pair_forward
+from . import _lib
+from .sequence_model import SequenceModel, linear_infer, pair_forward
 
 
 def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate):
@@ -38,8 +39,22 @@ class MelScale(nn.Module):
         self.register_buffer("fb", melscale_fbanks(n_stft, f_min, f_max, n_mels, sample_rate))
 
     def forward(self, specgram):
-        """[..., F, T] -> [..., n_mels, T]."""
-        return torch.matmul(specgram.transpose(-1, -2), self.fb).transpose(-1, -2)
+        """[..., F, T] -> [..., n_mels, T]: specgram^T fb, through the in-tree MFMA GEMM (fsn_linear_forward with the
+        filterbank as an nn.Linear weight [n_mels, F] and a zero bias) - no vendor BLAS on the path."""
+        if not specgram.is_cuda:
+            raise _lib.FsnError("MelScale: input must live on a ROCm device; this path has no CPU implementation")
+        F, T = specgram.shape[-2], specgram.shape[-1]
+        lead = specgram.shape[:-2]
+        key = (self.fb.data_ptr(), self.fb._version, str(self.fb.device))
+        if getattr(self, "_w_key", None) != key:
+            self._w = self.fb.detach().t().contiguous()  # [n_mels, F]
+            self._b = torch.zeros(self._w.shape[0], dtype=torch.float32, device=self._w.device)
+            self._w_key = key
+        Fp = (F + 15) // 16 * 16
+        x2 = torch.zeros((specgram.numel() // (F * T), T, Fp), dtype=torch.float32, device=specgram.device)
+        x2[..., :F] = specgram.detach().reshape(-1, F, T).transpose(1, 2)
+        mel = linear_infer(x2.reshape(-1, Fp), self._w, self._b, False)  # [rows, n_mels]
+        return mel.reshape(*lead, T, -1).transpose(-1, -2)
 
 
 def _lstm_block(kind, n_in, n_hidden, n_out, layers=1, act=None):

@@ -240,7 +240,7 @@ class Model(BaseModel):
         if ndim == 3:
             assert y.size(1) == 1, "Input must be 2D (B, T) or 3D tensor (B, 1, T)"
             y = y.squeeze(1)
-        mag, _, real, imag = stft(y, self.n_fft, self.hop_length, self.win_length)  # [B, F, T] each
+        mag, _, real, imag = stft(y, self.n_fft, self.hop_length, self.win_length, return_phase=False)  # [B, F, T] each
         noisy_mag = mag.unsqueeze(1) ** self.fdrc
         noisy_mag = noisy_mag[..., :-1, :]  # the last bin is left out (model.py:566) and masked with 0 below
         B, _, Fm, T = noisy_mag.shape

@@ -220,7 +220,7 @@ class Model(nn.Module):
         if not self._fused:  # composed configuration: the same stages as separate calls, no band dropping
             from .acoustics.feature import istft, stft
             from .acoustics.mask import decompress_cIRM
-            mag, _, re, im = stft(y, n_fft, hop_length, n_fft)
+            mag, _, re, im = stft(y, n_fft, hop_length, n_fft, return_phase=False)
             groups, self.num_groups_in_drop_band = self.num_groups_in_drop_band, 1
             try:
                 crm = self._forward_composed(mag.unsqueeze(1))

@@ -99,7 +99,7 @@ def enhance_row_sharded(model, noisy, n_fft=512, hop_length=256, group=None):
     smaller all-gather (waveforms instead of masks)."""
     from .acoustics.feature import istft, stft
     from .acoustics.mask import decompress_cIRM
-    mag, _, re, im = stft(noisy, n_fft, hop_length, n_fft)
+    mag, _, re, im = stft(noisy, n_fft, hop_length, n_fft, return_phase=False)
     crm = model.forward_row_sharded(mag.unsqueeze(1), group=group)  # [B, 2, F, T]
     m = decompress_cIRM(crm.permute(0, 2, 3, 1))
     return istft((m[..., 0] * re - m[..., 1] * im, m[..., 1] * re + m[..., 0] * im), n_fft, hop_length, n_fft,

@@ -169,7 +169,7 @@ class StreamingEnhancer:
         a = j0 * hop - self._buf0
         b = (self._n_in if final else max(t_end * hop + half, half + 1)) - self._buf0
         seg = self._buf[:, a:b].contiguous()
-        mag, _, re, im = stft(seg, self.n_fft, hop, self.n_fft)
+        mag, _, re, im = stft(seg, self.n_fft, hop, self.n_fft, return_phase=False)
         lo, hi = self._t_next - j0, t_end - j0 + 1
         out = tuple(x[:, :, lo:hi].contiguous() for x in (mag, re, im))
         self._t_next = t_end + 1

@@ -384,8 +384,8 @@ def train_step(model, optimizer, noisy, clean, n_fft=512, hop_length=256, win_le
     Returns the loss tensor (call .item() to synchronise like the reference does)."""
     loss_function = loss_function or (lambda target, pred: mse_loss(pred, target))
     optimizer.zero_grad()
-    noisy_mag, _, noisy_real, noisy_imag = stft(noisy, n_fft, hop_length, win_length)
-    _, _, clean_real, clean_imag = stft(clean, n_fft, hop_length, win_length)
+    noisy_mag, _, noisy_real, noisy_imag = stft(noisy, n_fft, hop_length, win_length, return_phase=False)
+    _, _, clean_real, clean_imag = stft(clean, n_fft, hop_length, win_length, return_phase=False)
     cirm = build_complex_ideal_ratio_mask(noisy_real, noisy_imag, clean_real, clean_imag)  # [B, F, T, 2]
     inner = model.module if hasattr(model, "module") else model
     cirm = drop_band(cirm.permute(0, 3, 1, 2), inner.num_groups_in_drop_band).permute(0, 2, 3, 1)

@@ -97,7 +97,8 @@ class Trainer:
         ac = config["acoustics"]
         self.acoustic_config = ac
         self.n_fft, self.hop_length, self.win_length = ac["n_fft"], ac["hop_length"], ac["win_length"]
-        self.torch_stft = lambda y: stft(y, self.n_fft, self.hop_length, self.win_length)  # base_trainer.py:55-60
+        # base_trainer.py:55-60; the phase (never read by this trainer) is not computed
+        self.torch_stft = lambda y: stft(y, self.n_fft, self.hop_length, self.win_length, return_phase=False)
         self.torch_istft = lambda f, length=None, input_type="mag_phase": istft(
             f, self.n_fft, self.hop_length, self.win_length, length=length, input_type=input_type)
 

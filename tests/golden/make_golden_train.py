@@ -64,7 +64,11 @@ def main(batch=4, length=2560, groups=2, name="fsn_train_b4", sample=SAMPLE):
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    if "--config3" in sys.argv:
+    if "--config3x2" in sys.argv:
+        # two ranks of BASELINE config 3 as ONE batch: 32 utterances x 3.072 s (what 2 x 16 under DistributedDataParallel
+        # must reproduce: drop_band keeps the sample parity of the global batch when ranks take contiguous halves)
+        main(batch=32, length=49152, groups=2, name="fsn_train_c3x2", sample=397)
+    elif "--config3" in sys.argv:
         # BASELINE config 3 per-rank shape (fullsubnet/train.toml:46,92: 16 utterances x 3.072 s, drop_band groups 2)
         main(batch=16, length=49152, groups=2, name="fsn_train_c3", sample=397)
     else:

@@ -83,6 +83,11 @@ def test_two_layer_lstm_on_the_persistent_kernels(fsn, T, N, I, H):
         assert err <= 1e-4 * max(b.abs().max().item(), 1e-3), (name, err, b.abs().max().item())
 
 
+# (relative bound on the total / per-tensor gradient norms, on sampled elements relative to the tensor's largest): set
+# from the margins measured on MI355X (printed by the test), about 3x above them
+TRAIN_TOL = {"fsn_train_b4": (2e-3, 2e-3), "fsn_train_c3": (2e-3, 2e-3)}
+
+
 @pytest.mark.parametrize("name", ["fsn_train_b4", "fsn_train_c3"])
 def test_train_step_vs_reference_and_oracle(fsn, golden_dir, name):
     """One step of fullsubnet/trainer.py:41-71 (use_amp = false) against the reference's own loss, clipped gradients
@@ -101,14 +106,26 @@ def test_train_step_vs_reference_and_oracle(fsn, golden_dir, name):
     opt = fsn.ClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
     loss = train_step(model, opt, torch.from_numpy(noisy).cuda(), torch.from_numpy(clean).cuda())
     assert abs(loss.item() - float(z["loss"])) <= 1e-5 * float(z["loss"])
-    assert abs(float(opt.total_norm) - float(z["total_norm"])) <= 2e-3 * float(z["total_norm"])
+    # the measured margins are printed (pytest -s / the captured log); the bounds in TRAIN_TOL sit ~3x above them
+    tol_norm, tol_elem = TRAIN_TOL[name]
+    rel_total = abs(float(opt.total_norm) - float(z["total_norm"])) / float(z["total_norm"])
     s = meta["sample"]
     named = dict(model.named_parameters())
+    worst_norm, worst_elem = ("", 0.0), ("", 0.0)
     for k in params:
         g = named[k].grad.detach().reshape(-1)[::s].cpu().numpy()
         gn = float(z["gnorm/" + k])
-        assert abs(float(named[k].grad.norm()) - gn) <= 2e-3 * gn + 1e-9, k
-        assert np.abs(g - z["g/" + k]).max() <= 2e-3 * max(np.abs(z["g/" + k]).max(), 1e-3 * gn) + 1e-9, k
+        rel_n = abs(float(named[k].grad.norm()) - gn) / (gn + 1e-30)
+        rel_e = np.abs(g - z["g/" + k]).max() / max(np.abs(z["g/" + k]).max(), 1e-3 * gn, 1e-30)
+        worst_norm = max(worst_norm, (k, rel_n), key=lambda kv: kv[1])
+        worst_elem = max(worst_elem, (k, float(rel_e)), key=lambda kv: kv[1])
+    print(f"{name}: gradient margins vs the reference: total norm {rel_total:.2e}, worst tensor norm {worst_norm[1]:.2e} "
+          f"({worst_norm[0]}), worst sampled element {worst_elem[1]:.2e} of the tensor's max ({worst_elem[0]}); bounds "
+          f"{tol_norm:.0e} / {tol_elem:.0e}")
+    assert rel_total <= tol_norm
+    assert worst_norm[1] <= tol_norm, worst_norm
+    assert worst_elem[1] <= tol_elem, worst_elem
+    for k in params:
         # Adam's first step moves every weight by lr g / (|g| + eps) ~ +-1e-3: where the reference's gradient is well
         # above eps = 1e-8 the update is insensitive to rounding and must agree to 1e-5; elsewhere (|g| ~ eps, the
         # step's size depends on the last bits of g) only that it is a step of at most lr
