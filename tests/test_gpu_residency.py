@@ -52,21 +52,30 @@ class Hog:
         self.sink = torch.zeros(1, device="cuda")
 
     def launch(self, workgroups, lds, heavy, ms):
+        """Returns (start, end) events on the hog's stream and the host time the launch call took."""
+        import time
         L = self.fsn._lib.lib()
-        self.fsn._lib.check(L.fsn_debug_hog(workgroups, lds, 1 if heavy else 0, float(ms), self.fsn._lib.dev_ptr(self.sink),
-                                            self.stream.cuda_stream))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(self.stream):
+            a.record()
+            t0 = time.perf_counter()
+            self.fsn._lib.check(L.fsn_debug_hog(workgroups, lds, 1 if heavy else 0, float(ms),
+                                                self.fsn._lib.dev_ptr(self.sink), self.stream.cuda_stream))
+            host_ms = 1e3 * (time.perf_counter() - t0)
+            b.record()
+        return a, b, host_ms
 
     def wait(self):
         self.stream.synchronize()
 
 
-def timed(fn):
+def timed(fn, with_events=False):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     out = fn()
     b.record()
     b.synchronize()
-    return out, a.elapsed_time(b)
+    return (out, a.elapsed_time(b), a, b) if with_events else (out, a.elapsed_time(b))
 
 
 # (workgroups, LDS bytes, heavy): a few workgroups .. one per CU .. two per CU; LDS-light / LDS-heavy / register-heavy
@@ -86,17 +95,22 @@ def test_inference_beside_a_foreign_kernel(fsn):
     hog = Hog(fsn)
     hog_ms = 60.0
     for wgs, lds, heavy in HOGS:
-        hog.launch(wgs, lds, heavy, hog_ms)
-        got, t = timed(lambda: model.enhance(x, return_crm=True))
+        torch.cuda.synchronize()
+        h0, h1, host_ms = hog.launch(wgs, lds, heavy, hog_ms)
+        got, t, e0, e1 = timed(lambda: model.enhance(x, return_crm=True), with_events=True)
         hog.wait()
         status, events = fsn._lib.stream_status(x.device, synchronize=True)
+        # the timeline on one clock: the hog [0, h] and the call [s, e] relative to the hog's start
+        h, s, e = h0.elapsed_time(h1), h0.elapsed_time(e0), h0.elapsed_time(e1)
         print(f"hog {wgs:4d} wgs x {lds // 1024:3d} KB {'heavy' if heavy else 'light'}: enhance {t:6.1f} ms "
-              f"(undisturbed {t_ref:.1f} ms, hog {hog_ms:.0f} ms)")
+              f"(undisturbed {t_ref:.1f} ms); hog ran [0, {h:.1f}] ms, the call [{s:.1f}, {e:.1f}] ms, "
+              f"launching the hog took {host_ms:.2f} ms of host time")
         assert (status, events) == (0, 0)
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (wgs, lds, heavy)
+        assert h >= 0.9 * hog_ms and s < 0.5 * hog_ms, "the hog was not running when the call started: vacuous"
         if wgs >= 256 and lds >= 160 * 1024:
-            # a hog that owns every CU's LDS: nothing of the path can start before it ends - the test is not vacuous
-            assert t >= 0.5 * hog_ms, t
+            # a hog that owns every CU's LDS: nothing of the path can finish before it ends
+            assert e >= 0.9 * h, (e, h)
 
 
 def test_training_step_beside_a_foreign_kernel(fsn):
@@ -110,11 +124,20 @@ def test_training_step_beside_a_foreign_kernel(fsn):
     def run(hog=None):
         model = make_model(fsn, seed=3, groups=2).train()
         opt = fsn.ClipAdam(model.parameters(), lr=1e-3)
+        marks = []
         if hog is not None:
+            torch.cuda.synchronize()
             for wgs, lds, heavy in [(64, 64 * 1024, True), (256, 160 * 1024, False), (128, 96 * 1024, True)]:
-                hog.launch(wgs, lds, heavy, 25.0)  # back to back on the hog's stream: ~75 ms beside a ~45 ms step
-        loss = train_step(model, opt, noisy, clean)
+                marks.append(hog.launch(wgs, lds, heavy, 25.0))  # back to back on the hog's stream: ~75 ms beside a ~45 ms step
+        (loss, t, e0, e1) = timed(lambda: train_step(model, opt, noisy, clean), with_events=True)
         torch.cuda.synchronize()
+        if marks:
+            h0, h1 = marks[0][0], marks[-1][1]
+            print(f"training step {t:.1f} ms; hogs ran [0, {h0.elapsed_time(h1):.1f}] ms, the step "
+                  f"[{h0.elapsed_time(e0):.1f}, {h0.elapsed_time(e1):.1f}] ms")
+            assert h0.elapsed_time(e0) < 25.0, "the hogs were not running when the step started: vacuous"
+        else:
+            print(f"training step undisturbed {t:.1f} ms")
         assert fsn._lib.stream_status(noisy.device) == (0, 0)
         assert opt.skipped_steps() == 0
         return loss.item(), [p.grad.clone() for p in model.parameters()], [p.detach().clone() for p in model.parameters()]

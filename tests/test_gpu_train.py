@@ -83,9 +83,11 @@ def test_two_layer_lstm_on_the_persistent_kernels(fsn, T, N, I, H):
         assert err <= 1e-4 * max(b.abs().max().item(), 1e-3), (name, err, b.abs().max().item())
 
 
-# (relative bound on the total / per-tensor gradient norms, on sampled elements relative to the tensor's largest): set
+# (relative bounds on the total gradient norm, on every tensor's norm, on sampled elements relative to the tensor's largest): set
 # from the margins measured on MI355X (printed by the test), about 3x above them
-TRAIN_TOL = {"fsn_train_b4": (2e-3, 2e-3), "fsn_train_c3": (2e-3, 2e-3)}
+# measured r03 (b4 / c3): total norm 2.1e-6 / 3.2e-6, worst tensor norm 1.0e-4 / 6.8e-5, worst sampled element
+# 1.4e-4 / 6.4e-5 (fp32 rounding through ~50 / ~195 recurrent steps each way; r02's bounds were 2e-3 throughout)
+TRAIN_TOL = {"fsn_train_b4": (1e-5, 3e-4, 4e-4), "fsn_train_c3": (1e-5, 2e-4, 2e-4)}
 
 
 @pytest.mark.parametrize("name", ["fsn_train_b4", "fsn_train_c3"])
@@ -107,7 +109,7 @@ def test_train_step_vs_reference_and_oracle(fsn, golden_dir, name):
     loss = train_step(model, opt, torch.from_numpy(noisy).cuda(), torch.from_numpy(clean).cuda())
     assert abs(loss.item() - float(z["loss"])) <= 1e-5 * float(z["loss"])
     # the measured margins are printed (pytest -s / the captured log); the bounds in TRAIN_TOL sit ~3x above them
-    tol_norm, tol_elem = TRAIN_TOL[name]
+    tol_total, tol_norm, tol_elem = TRAIN_TOL[name]
     rel_total = abs(float(opt.total_norm) - float(z["total_norm"])) / float(z["total_norm"])
     s = meta["sample"]
     named = dict(model.named_parameters())
@@ -121,8 +123,8 @@ def test_train_step_vs_reference_and_oracle(fsn, golden_dir, name):
         worst_elem = max(worst_elem, (k, float(rel_e)), key=lambda kv: kv[1])
     print(f"{name}: gradient margins vs the reference: total norm {rel_total:.2e}, worst tensor norm {worst_norm[1]:.2e} "
           f"({worst_norm[0]}), worst sampled element {worst_elem[1]:.2e} of the tensor's max ({worst_elem[0]}); bounds "
-          f"{tol_norm:.0e} / {tol_elem:.0e}")
-    assert rel_total <= tol_norm
+          f"{tol_total:.0e} / {tol_norm:.0e} / {tol_elem:.0e}")
+    assert rel_total <= tol_total
     assert worst_norm[1] <= tol_norm, worst_norm
     assert worst_elem[1] <= tol_elem, worst_elem
     for k in params:

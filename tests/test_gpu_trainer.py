@@ -171,6 +171,7 @@ def _ddp_worker(rank, world, port):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
+        fsn._lib.set_persistent_mode("never")  # two processes on one GPU: outside the residency contract (fsn_hip.h)
         noisy, clean = wav(8, 2560, 41).cuda(), (0.7 * wav(8, 2560, 42)).cuda()
         ref = make_model(fsn).train()
         train_step(ref, torch.optim.SGD(ref.parameters(), lr=0.0), noisy, clean)  # whole batch, one process
@@ -193,6 +194,64 @@ def test_ddp_gradients_equal_the_single_process_double_batch(fsn):
     mp.spawn(_ddp_worker, args=(2, _free_port()), nprocs=2, join=True)
 
 
+def _ddp_config3_worker(rank, world, port, golden_dir):
+    import ast
+    import torch.distributed as dist
+    import fullsubnet_amd as fsn
+    from fullsubnet_amd.train import train_step
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        # two PROCESSES share this GPU: exactly the situation the residency contract excludes for the persistent
+        # kernels (include/fsn_hip.h) - each process would hold a part of the chip and wait for the rest - so the ranks
+        # select the per-step paths, as the header tells such callers to
+        fsn._lib.set_persistent_mode("never")
+        z = np.load(os.path.join(golden_dir, "fsn_train_c3x2.npz"))
+        meta = ast.literal_eval(str(z["meta"]))
+        per = meta["batch"] // world
+        lo, hi = per * rank, per * rank + per
+        noisy = torch.from_numpy(O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_noisy"])[lo:hi]).cuda()
+        clean = torch.from_numpy((meta["clean_gain"] * O.make_noisy(meta["batch"], meta["length"],
+                                                                    seed=meta["seed_clean"])).astype(np.float32)[lo:hi]).cuda()
+        ddp = torch.nn.parallel.DistributedDataParallel(make_model(fsn, seed=meta["seed_w"], groups=meta["groups"]).train(),
+                                                        device_ids=[0])
+        opt = fsn.ClipAdam(ddp.parameters(), lr=1e-3, betas=(0.9, 0.999))
+        loss = train_step(ddp, opt, noisy, clean)
+        # the mean of the two ranks' losses is the loss of the whole batch (equal element counts)
+        both = torch.stack([loss.detach()]).clone()
+        dist.all_reduce(both)
+        assert abs(both.item() / world - float(z["loss"])) <= 1e-5 * float(z["loss"])
+        rel_total = abs(float(opt.total_norm) - float(z["total_norm"])) / float(z["total_norm"])
+        s = meta["sample"]
+        worst_norm = worst_elem = 0.0
+        for k, p in ddp.module.named_parameters():
+            gn = float(z["gnorm/" + k])
+            g = p.grad.detach().reshape(-1)[::s].cpu().numpy()
+            worst_norm = max(worst_norm, abs(float(p.grad.norm()) - gn) / (gn + 1e-30))
+            worst_elem = max(worst_elem, float(np.abs(g - z["g/" + k]).max() / max(np.abs(z["g/" + k]).max(), 1e-3 * gn, 1e-30)))
+            firm = np.abs(z["g/" + k]) > 1e-6
+            pv = p.detach().reshape(-1)[::s].cpu().numpy()
+            if firm.any():
+                assert np.abs(pv - z["p/" + k])[firm].max() <= 1e-5, k
+        if rank == 0:
+            print(f"DDP 2 x 16 vs the 32-utterance reference step: total norm {rel_total:.2e}, worst tensor norm "
+                  f"{worst_norm:.2e}, worst sampled element {worst_elem:.2e}")
+        assert rel_total <= 1e-5 and worst_norm <= 3e-4 and worst_elem <= 4e-4, (rel_total, worst_norm, worst_elem)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_config3_two_ranks_vs_the_reference_double_batch(fsn, golden_dir):
+    """BASELINE config 3's layout at two ranks: 2 x 16 utterances x 49 152 samples under DistributedDataParallel
+    (base_trainer.py:32) against ONE reference step on the 32-utterance batch (tests/golden/fsn_train_c3x2.npz,
+    make_golden_train.py --config3x2): loss, clipped gradients and Adam-updated parameters (drop_band keeps the
+    sample parity of the global batch when ranks take contiguous halves, fullsubnet/trainer.py:41-71)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_ddp_config3_worker, args=(2, _free_port(), golden_dir), nprocs=2, join=True)
+
+
 def _row_shard_worker(rank, world, port):
     import torch.distributed as dist
     import fullsubnet_amd as fsn
@@ -202,6 +261,7 @@ def _row_shard_worker(rank, world, port):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
+        fsn._lib.set_persistent_mode("never")  # two processes on one GPU: outside the residency contract (fsn_hip.h)
         model = make_model(fsn, seed=0, groups=1, gain=2.0, mask_gain=24.0).eval()
         noisy = wav(3, 4096, 1234).cuda()   # 771 rows: rank 0 ends inside utterance 1
         fused = model.enhance(noisy)
