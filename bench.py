@@ -72,7 +72,7 @@ def _time_aten(model, length, batch, threads):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(params, length, budget_s=30.0):
+def cpu_baseline(params, length, budget_s=30.0, all_cores_too=False):
     """The reference's CPU arithmetic on this box's host cores, on a bounded sample of the same workload.
 
     Headline figure (`value`): oracle/aten_baseline.py - the ATen operator sequence the reference itself executes
@@ -98,11 +98,17 @@ def cpu_baseline(params, length, budget_s=30.0):
         spent += cal[th]
     threads = min(cal, key=cal.get)
     dt = cal[threads]
-    # every host thread the process may use: on a 256-thread box oneDNN's LSTM is far slower oversubscribed
-    # than at 16 threads (measured r03: 66 frames/s against 1310 on the same 64-utterance batch, 182 s of wall), so this
-    # figure is taken on a 4-utterance batch to stay inside the run's budget - and says so
-    nb_all = min(nb, 4)
-    t_all = _time_aten(model, length, nb_all, avail) if avail not in cal else cal[avail] * nb_all / nb
+    # every host thread the process may use (n = len(os.sched_getaffinity(0))): on the 256-thread GPU box
+    # oneDNN's LSTM collapses when oversubscribed - measured in r03: 66 frames/s on the 64-utterance batch (182 s of wall)
+    # and 5 frames/s on 4 utterances (150 s), against 1310 - 1356 at 16 threads - so the figure is opt-in
+    # (--cpu-all-cores); the default run reports the scaling over 16 / 32 / 64 threads instead
+    all_cores = None
+    if avail in cal:
+        all_cores = {"value": round(nb * frames_per_utt / cal[avail], 2), "unit": "frames/s", "cores": avail}
+    elif all_cores_too:
+        t_all = _time_aten(model, length, nb, avail)
+        all_cores = {"value": round(nb * frames_per_utt / t_all, 2), "unit": "frames/s", "cores": avail,
+                     "sample": f"the same {nb}-utterance batch, {t_all:.1f} s wall"}
     out = {"value": round(nb * frames_per_utt / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
            "sample": f"{nb} x {length / SR:.1f} s utterance(s) in one batch, full path stft -> model -> decompress -> "
                      f"mask -> istft as the ATen operator sequence of the reference (oracle/aten_baseline.py: torch "
@@ -110,8 +116,10 @@ def cpu_baseline(params, length, budget_s=30.0):
                      f"(fastest of {sorted(cal)}, each timed on this same batch), {dt:.1f} s wall",
            "rtf_speedup": round(nb * length / SR / dt, 3),
            "by_threads": {str(th): round(nb * frames_per_utt / t, 2) for th, t in sorted(cal.items())},
-           "all_cores": {"value": round(nb_all * frames_per_utt / t_all, 2), "unit": "frames/s", "cores": avail,
-                         "sample": f"{nb_all} x {length / SR:.1f} s utterance(s) in one batch, {t_all:.1f} s wall"}}
+           "all_cores": all_cores,
+           "all_cores_note": (None if all_cores else
+                              f"not timed in this run (--cpu-all-cores): with all {avail} host threads the same batch "
+                              f"measured 66 frames/s in r03 (oneDNN's LSTM oversubscribed; profiles/r03_cpu_threads.md)")}
     # the parity checker (numpy + torch-CPU matmuls), for the record: it scales to ~16 threads
     cores = min(16, avail)
     torch.set_num_threads(cores)
@@ -220,6 +228,8 @@ def main():
                          "balances any batch over any number of ranks).  auto: utterances when they divide evenly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time the CPU baseline with every host thread (minutes on a 256-thread box)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements (other scaling mode, opt-in arithmetic, training step)")
     ap.add_argument("--host-io", action="store_true",
@@ -426,7 +436,7 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             torch.cuda.synchronize()
-            out["cpu_baseline"] = cpu_baseline(params, length, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(params, length, args.cpu_budget, args.cpu_all_cores)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None  # reported at N = 1 only
         print(json.dumps(out), flush=True)

@@ -1573,6 +1573,13 @@ extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_i
             xin.bias = bias;
             return run_recurrence(nullptr, &xin, nullptr, 0, 0, whh_p, hseq, c_state, T, N, H, plan, s);
         }
+        // a layer of a stack on the persistent kernel (input = the hidden sequence of an equally wide layer below, e.g.
+        // the second bottleneck layer of Fast FullSubNet, fast_fullsubnet/model.py:66-74): the K = H projection is
+        // formed inside the recurrent kernel from x streamed through its LDS ring (lstm_rec_x_kernel<.., HSEQ>) - no
+        // projection GEMM, no [T][N][4H] gx round trip
+        if (plan.main_wgs > 0 && plan.left_tiles == 0 && I == H && ldx == H && fsn_lstm_rec_x_supported(H, plan.rt) &&
+            whh_p > wih_p)
+            return fsn_launch_lstm_rec_x(x, wih_p, whh_p, bias, T, N, H, plan.rt, plan.main_wgs, s, nullptr, hseq);
     }
     FsnGemmA a{};
     a.kind = 0;

@@ -314,11 +314,12 @@ bool fsn_lstm_rec_can_fuse_fc(int RT, bool xin);
 bool fsn_lstm_rec_in_supported(const FsnSbInput* xin, const float* whh_p, int H, int RT);
 int fsn_launch_lstm_rec_in(const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad, int H, int RT,
                            int main_wgs, hipStream_t s);
-// last layer with its input projection inside: xseq [Tp][Npad][H] is the hidden sequence of the layer below,
-// wih_p / whh_p the packed weights, bias = b_ih + b_hh [4H]; the output layer (fc) is always fused
+// a layer with its input projection inside: xseq [Tp][Npad][H] is the hidden sequence of the layer below,
+// wih_p / whh_p the packed weights, bias = b_ih + b_hh [4H]; either the output layer (fc) is fused and nothing else is
+// stored (the last layer of the sub-band model), or hseq_out [Tp][Npad][H] receives h_t (a layer inside a stack)
 bool fsn_lstm_rec_x_supported(int H, int RT);
 int fsn_launch_lstm_rec_x(const float* xseq, const float* wih_p, const float* whh_p, const float* bias, int Tp, int Npad,
-                          int H, int RT, int main_wgs, hipStream_t s, const FsnRecFc* fc);
+                          int H, int RT, int main_wgs, hipStream_t s, const FsnRecFc* fc, float* hseq_out = nullptr);
 // state_h0 / state_h1 (may be NULL): streaming continuation - the hidden states before this call ([rows][H],
 // updated to the last step's on return); c0 / c1 then hold the carried cell states.
 int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, const float* whh0_p, const float* wih1_p,

@@ -487,12 +487,18 @@ __device__ __forceinline__ void lds_dma_fragment(const float* g, unsigned lds_ba
 #ifndef FSN_REC_VCAP
 #define FSN_REC_VCAP 76  // x 2 on gfx950's unified register file = 152: three waves per SIMD + room for a step workgroup
 #endif
-template <int H, int RT, int UG, int ABL = 0>
+// HSEQ: the layer is not the last one of its stack (or its output layer is not the fused two-row one): h_t is streamed
+// out as whole rows to hseq_out [Tp][Npad][H], like lstm_rec_in_kernel does, and no output layer is formed - every
+// stacked nn.LSTM layer of a SequenceModel (sequence_model.py:52-58) then takes its input from the layer below with
+// no projection GEMM and no gx round trip (Fast FullSubNet's bottleneck: fast_fullsubnet/model.py:66-74).
+template <int H, int RT, int UG, int ABL = 0, bool HSEQ = false>
 __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgpr(FSN_REC_VCAP))) void lstm_rec_x_kernel(const float* __restrict__ xseq,
                                                                           const float* __restrict__ w_p,
                                                                           unsigned whh_off,
                                                                           const float* __restrict__ bias, int Tp,
                                                                           int Npad, const FsnRecFc fc) {
+    // (HSEQ: the destination travels in fc.crm_r - the kernel's signature, and with it the register allocation of the
+    // fused form, stays what it was)
     constexpr int NW = H / (16 * UG);
     constexpr int KC = H / 16;
     constexpr int HS = H + 4;
@@ -510,10 +516,11 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const long n0 = (long)blockIdx.x * ROWS;
-    for (int i = threadIdx.x; i < 2 * H; i += NW * 64) {  // rows 0 / 1 of the packed output weights, un-tiled
-        const int c = i / H, k = i % H;
-        wl[i] = fc.w_p[(((k >> 4) * 64) + ((k & 15) >> 2) * 16 + c) * 4 + (k & 3)];
-    }
+    if (!HSEQ)
+        for (int i = threadIdx.x; i < 2 * H; i += NW * 64) {  // rows 0 / 1 of the packed output weights, un-tiled
+            const int c = i / H, k = i % H;
+            wl[i] = fc.w_p[(((k >> 4) * 64) + ((k & 15) >> 2) * 16 + c) * 4 + (k & 3)];
+        }
     float cst[RT][UG][4], tmp[RT][UG][4];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -705,7 +712,15 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
             __builtin_amdgcn_s_barrier();  // h_t complete in LDS
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         }
-        if (!(ABL & 4)) {
+        if (HSEQ) {
+            // stream h_t out as whole rows: hseq_out[t][n0 + row][0..H)
+            float* dst = fc.crm_r + ((long)t * Npad + n0) * H;
+            for (int i = threadIdx.x; i < ROWS * (H / 4); i += NW * 64) {
+                const int row = i / (H / 4), c4 = i % (H / 4);
+                *reinterpret_cast<f32x4*>(dst + (long)row * H + c4 * 4) =
+                    *reinterpret_cast<const f32x4*>(hl + row * HS + c4 * 4);
+            }
+        } else if (!(ABL & 4)) {
             // output layer on the spot (nn.Linear(H, 2)): 4 threads per (row, output), a quarter of K each
             const int tid = threadIdx.x;
             if (tid < ROWS * 8) {
@@ -1436,12 +1451,12 @@ int launch_rec(const float* gx, const FsnSbInput* xin, const float* whh_p, float
     return fsn_check_launch("lstm_rec_kernel");
 }
 
-template <int H, int RT, int UG = 2>
+template <int H, int RT, bool HSEQ, int UG = 2>
 int launch_rec_x(const float* xseq, const float* wih_p, const float* whh_p, const float* bias, int Tp, int Npad,
-                 int main_wgs, hipStream_t s, const FsnRecFc* fc) {
+                 int main_wgs, hipStream_t s, const FsnRecFc* fc, float* hseq_out) {
     constexpr int NW = H / (16 * UG);
     const size_t lds = ((size_t)RT * 16 * (H + 4) + 2 * H + (size_t)2 * RT * 6 * 256) * sizeof(float);
-    auto kern = lstm_rec_x_kernel<H, RT, UG>;
+    auto kern = lstm_rec_x_kernel<H, RT, UG, 0, HSEQ>;
     if (lds > 160 * 1024 ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
@@ -1452,8 +1467,11 @@ int launch_rec_x(const float* xseq, const float* wih_p, const float* whh_p, cons
         fsn_set_error("lstm_rec_x: W_hh must follow W_ih in one packed buffer");
         return FSN_ERR_ARG;
     }
+    FsnRecFc a{};
+    if (fc) a = *fc;
+    if (HSEQ) a.crm_r = hseq_out;
     hipLaunchKernelGGL(kern, dim3((unsigned)main_wgs), dim3(NW * 64), lds, s, xseq, wih_p, (unsigned)(whh_p - wih_p), bias,
-                       Tp, Npad, *fc);
+                       Tp, Npad, a);
     return fsn_check_launch("lstm_rec_x_kernel");
 }
 
@@ -1499,14 +1517,20 @@ int fsn_launch_lstm_rec_in(const FsnSbInput* xin, const float* whh_p, float* hse
 bool fsn_lstm_rec_x_supported(int H, int RT) { return H == 384 && RT >= 2 && RT <= 4; }
 
 int fsn_launch_lstm_rec_x(const float* xseq, const float* wih_p, const float* whh_p, const float* bias, int Tp, int Npad,
-                          int H, int RT, int main_wgs, hipStream_t s, const FsnRecFc* fc) {
-    if (!fc || !fc->w_p || !fsn_lstm_rec_x_supported(H, RT)) {
-        fsn_set_error("lstm_rec_x: needs the fused output layer, H = 384 and 2 - 4 row tiles (got H %d, RT %d)", H, RT);
+                          int H, int RT, int main_wgs, hipStream_t s, const FsnRecFc* fc, float* hseq_out) {
+    if (((!fc || !fc->w_p) && !hseq_out) || !fsn_lstm_rec_x_supported(H, RT)) {
+        fsn_set_error("lstm_rec_x: needs the fused output layer or a hidden-sequence buffer, H = 384 and 2 - 4 row tiles "
+                      "(got H %d, RT %d)", H, RT);
         return FSN_ERR_ARG;
     }
-    if (RT == 2) return launch_rec_x<384, 2>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, fc);
-    if (RT == 3) return launch_rec_x<384, 3>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, fc);
-    return launch_rec_x<384, 4>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, fc);
+    if (hseq_out) {  // a layer inside a stack: h_t stored, no output layer
+        if (RT == 2) return launch_rec_x<384, 2, true>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, nullptr, hseq_out);
+        if (RT == 3) return launch_rec_x<384, 3, true>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, nullptr, hseq_out);
+        return launch_rec_x<384, 4, true>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, nullptr, hseq_out);
+    }
+    if (RT == 2) return launch_rec_x<384, 2, false>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, fc, nullptr);
+    if (RT == 3) return launch_rec_x<384, 3, false>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, fc, nullptr);
+    return launch_rec_x<384, 4, false>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, fc, nullptr);
 }
 
 // How the N sub-band sequences are laid out on the chip.  One workgroup per CU (LDS-bound), RT

@@ -48,8 +48,25 @@ class Hog:
 
     def __init__(self, fsn):
         self.fsn = fsn
-        self.stream = torch.cuda.Stream()
         self.sink = torch.zeros(1, device="cuda")
+        # HIP multiplexes streams onto a few hardware queues (round robin): a new stream may share the queue of the
+        # current stream, and kernels of one queue never overlap.  Take a stream that demonstrably runs BESIDE the
+        # current one: a 4 ms hog on it, then a trivial kernel on the current stream that must finish long before.
+        self.stream, keep = None, []
+        for _ in range(16):
+            cand = torch.cuda.Stream()
+            keep.append(cand)  # keep the rejected ones alive so that the next candidate lands on another queue
+            self.stream = cand
+            torch.cuda.synchronize()
+            h0, h1, _ = self.launch(8, 1024, False, 4.0)
+            e = torch.cuda.Event(enable_timing=True)
+            self.sink.add_(0.0)
+            e.record()
+            torch.cuda.synchronize()
+            if h0.elapsed_time(e) < 2.0:
+                break
+            self.stream = None
+        assert self.stream is not None, "no stream that runs concurrently with the current one"
 
     def launch(self, workgroups, lds, heavy, ms):
         """Returns (start, end) events on the hog's stream and the host time the launch call took."""
