@@ -149,9 +149,11 @@ def timed_steps(step, fence, steps, read_profile=None):
     return time.perf_counter() - t0, stage_ms
 
 
-def training_step_ms(device, steps=5):
+def training_step_ms(device, steps=5, arith="f32"):
     """Side figure (BASELINE config 3, per-rank shape): one step of fullsubnet/trainer.py:41-71 - 16 utterances x
-    49 152 samples, drop_band groups 2, MSE on the compressed cIRM, clip_grad_norm_(10) + Adam - fp32, one GPU."""
+    49 152 samples, drop_band groups 2, MSE on the compressed cIRM, clip_grad_norm_(10) + Adam, one GPU.
+    arith "f32": use_amp = false.  "f16": the reference's own mode (train.toml:5 use_amp = true): autocast arithmetic
+    (16-bit matrix-core operands, fp32 accumulation) with torch.amp.GradScaler around the fused optimizer."""
     import fullsubnet_amd
     from fullsubnet_amd.train import train_step
     from fsn_synthetic import make_noisy, make_params
@@ -162,25 +164,34 @@ def training_step_ms(device, steps=5):
                                  num_groups_in_drop_band=2, weight_init=False)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in make_params(seed=3).items()})
     model = model.to(device).train()
+    model.train_arithmetic = arith
+    scaler = torch.amp.GradScaler("cuda", enabled=arith != "f32")
     opt = fullsubnet_amd.ClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
     noisy = torch.from_numpy(make_noisy(16, 49152, seed=41)).to(device)
     clean = torch.from_numpy(0.7 * make_noisy(16, 49152, seed=42)).to(device)
     for _ in range(2):
-        train_step(model, opt, noisy, clean)
+        train_step(model, opt, noisy, clean, scaler=scaler)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = train_step(model, opt, noisy, clean)
+        loss = train_step(model, opt, noisy, clean, scaler=scaler)
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
     T = 1 + 49152 // HOP
     flops = 3 * 2.0 * 16 * (T + LA) * (MAC_FB + 128 * MAC_SB_PER_BIN)  # ~3x forward, 128 bins kept
     del model, opt
     torch.cuda.empty_cache()
-    return {"ms_per_step": round(ms, 2), "config": "BASELINE config 3 per-rank shape: 16 x 49152 samples, drop_band "
-            "groups 2, cIRM MSE + clip_grad_norm_(10) + Adam, fp32", "loss": round(float(loss), 6),
-            "tflops": round(flops / (ms * 1e-3) / 1e12, 1),
-            "frac_fp32_mfma_peak": round(flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3)}
+    skipped = opt.skipped_steps()
+    out = {"ms_per_step": round(ms, 2), "dtype": arith,
+           "config": "BASELINE config 3 per-rank shape: 16 x 49152 samples, drop_band groups 2, cIRM MSE + "
+                     "clip_grad_norm_(10) + Adam" + ("" if arith == "f32" else
+                                                     f", use_amp = true: {arith} matrix-core operands with fp32 accumulation "
+                                                     f"on the sub-band kernels + torch.amp.GradScaler (scale "
+                                                     f"{scaler.get_scale():g}, {skipped} skipped updates)"),
+           "loss": round(float(loss), 6), "tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
+    if arith == "f32":
+        out["frac_fp32_mfma_peak"] = round(flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3)
+    return out
 
 
 def family_figure(which, batch, peak_tflops, device):
@@ -423,10 +434,11 @@ def main():
             "stage_ms": {k: round(v, 3) for k, v in x["stage_ms"].items()},
             "note": "opt-in (fp32 operands split into two fp16 halves, three 16-bit MFMAs per product block, fp32 "
                     "accumulation); NOT the arithmetic of `value`"}
-        try:
-            out["train_step"] = training_step_ms(device)
-        except Exception as e:  # a side figure must never break the benchmark line
-            out["train_step"] = {"error": str(e)[:200]}
+        for key, arith in (("train_step", "f32"), ("train_step_amp", "f16")):
+            try:
+                out[key] = training_step_ms(device, arith=arith)
+            except Exception as e:  # a side figure must never break the benchmark line
+                out[key] = {"error": str(e)[:200]}
         # BASELINE configs 4 and 5 (fast_fullsubnet/model.py:143-202, improved_fullsubnet/model.py:541-591)
         for key, which, b in (("fast_b256", "fast", 256), ("improved48_b32", "improved48", 32)):
             try:

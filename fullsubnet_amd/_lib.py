@@ -30,7 +30,7 @@ class Cfg(ctypes.Structure):
 # FSN_ARITH_* of include/fsn_hip.h.  "f32" is the default and what every parity claim refers to; "f16x3" is
 # the opt-in split-precision experiment (Model.arithmetic = "f16x3", or FSN_F16X3=1 in the environment of the
 # HOST process - the library itself reads no environment variables).
-ARITH = {"f32": 0, "f16x3": 1}
+ARITH = {"f32": 0, "f16x3": 1, "f16": 2, "bf16": 3}  # "f16" / "bf16": training entries only (autocast arithmetic)
 
 
 def default_arith():
@@ -109,11 +109,11 @@ SIGNATURES = {
     "fsn_lstm_layer_bwd_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "fsn_lstm2_train_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "fsn_lstm2_forward_train": (_c.c_int, [_f32p, _c.c_long] + [_f32p] * 8 + [_c.c_int] * 4 + [_f32p, _f32p, _c.c_void_p,
-                                           _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+                                           _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_void_p]),
     "fsn_lstm2_bwd_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "fsn_lstm2_backward": (_c.c_int, [_f32p, _f32p, _c.c_long, _f32p, _f32p, _f32p, _f32p] + [_c.c_int] * 4 +
                            [_f32p, _f32p, _c.c_void_p, _c.c_void_p, _f32p, _c.c_long] + [_f32p] * 6 +
-                           [_c.c_void_p, _c.c_size_t, _c.c_void_p]),
+                           [_c.c_void_p, _c.c_size_t, _c.c_int, _c.c_void_p]),
     "fsn_lstm_layer_backward": (_c.c_int, [_f32p, _f32p, _c.c_long, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_int,
                                            _c.c_int, _f32p, _c.c_void_p, _f32p, _c.c_long, _f32p, _f32p, _f32p,
                                            _c.c_void_p, _c.c_size_t, _c.c_void_p]),
@@ -146,7 +146,7 @@ SIGNATURES = {
     "fsn_clip_adam_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.POINTER(_c.c_size_t)]),
     "fsn_clip_adam_step": (_c.c_int, [_c.c_int, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_void_p),
                                       _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
-                                      _c.c_void_p, _f32p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+                                      _c.c_void_p, _f32p, _f32p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "fsn_profile_enable": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "fsn_set_persistent_mode": (_c.c_int, [_c.c_int]),
     "fsn_set_persistent_timeout_ms": (_c.c_int, [_c.c_int]),

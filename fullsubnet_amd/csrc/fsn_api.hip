@@ -1666,9 +1666,11 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
                                        const float* b_ih0, const float* b_hh0, const float* w_ih1, const float* w_hh1,
                                        const float* b_ih1, const float* b_hh1, int T, int N, int I, int H, float* hseq0,
                                        float* hseq1, void* save0, void* save1, size_t save_bytes, void* workspace,
-                                       size_t workspace_bytes, void* stream) {
+                                       size_t workspace_bytes, int arith, void* stream) {
     CallScope scope(stream);
     FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
+    FSN_REQUIRE(arith == FSN_ARITH_F32 || arith == FSN_ARITH_F16 || arith == FSN_ARITH_BF16,
+                "lstm2 forward (training): arithmetic %d unknown (FSN_ARITH_F32 / _F16 / _BF16)", arith);
     FSN_REQUIRE(x && w_ih0 && w_hh0 && b_ih0 && b_hh0 && w_ih1 && w_hh1 && b_ih1 && b_hh1 && hseq0 && hseq1 && save0 &&
                     save1 && workspace,
                 "NULL pointer argument");
@@ -1713,7 +1715,7 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
         {
             FSN_PERSIST_BEGIN(s);
             FSN_TRY(fsn_launch_lstm2_group_train(x, ldx, 32, N, wih0_p, whh0_p, wih1_p, whh1_p, b0, b1, hseq0, hseq1, sv0, sv1,
-                                                 flags, T, clusters, H, s));
+                                                 flags, T, clusters, H, s, arith));
             FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_status_word(clusters), hseq1, (size_t)T * N * H, s));
         }
         if (left > 0) {
@@ -2106,9 +2108,11 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
                                   const float* w_ih1, const float* w_hh1, int T, int N, int I, int H, const float* hseq0,
                                   const float* hseq1, const void* save0, const void* save1, float* dx, long lddx,
                                   float* dw_ih0, float* dw_hh0, float* db0, float* dw_ih1, float* dw_hh1, float* db1,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
+                                  void* workspace, size_t workspace_bytes, int arith, void* stream) {
     CallScope scope(stream);
     FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
+    FSN_REQUIRE(arith == FSN_ARITH_F32 || arith == FSN_ARITH_F16 || arith == FSN_ARITH_BF16,
+                "lstm2 backward: arithmetic %d unknown (FSN_ARITH_F32 / _F16 / _BF16)", arith);
     FSN_REQUIRE(dh1 && x && w_ih0 && w_hh0 && w_ih1 && w_hh1 && hseq0 && hseq1 && save0 && save1 && dw_ih0 && dw_hh0 && db0 &&
                     dw_ih1 && dw_hh1 && db1 && workspace,
                 "NULL pointer argument");
@@ -2217,7 +2221,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     {
         FSN_PERSIST_BEGIN(s);
         FSN_TRY(fsn_launch_lstm2_group_bptt(dh1, whh1T_p, wih1T_p, whh0T_p, sv0, sv1, dg0, dg1, dxbuf, flags, T, N, clusters,
-                                            H, s));
+                                            H, s, arith));
         // both gate-gradient buffers (dg1 | dg0 are adjacent): every weight gradient and dx derive from them
         FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_bptt_status_word(clusters), dg1, (size_t)2 * T * N * G, s));
     }
@@ -2274,12 +2278,14 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
         c.cols = I;
         FSN_TRY(fsn_launch_gemm(a, wih0T_p, c, T * (N / 16), Ipad / 16, G / 16, s));
     }
-    // dW_ih = dgates^T X (+ db = its column sums), dW_hh = dgates_{1..}^T H_{0..T-2}
-    FSN_TRY(fsn_launch_gemm_tn(dg1, G, hseq0, H, dw_ih1, H, G, H, (long)T * N, scratch, s, db1));
-    FSN_TRY(fsn_launch_gemm_tn(dg0, G, x, ldx, dw_ih0, I, G, I, (long)T * N, scratch, s, db0));
+    // dW_ih = dgates^T X (+ db = its column sums: fp32 adds in every arithmetic), dW_hh = dgates_{1..}^T H_{0..T-2}
+    FSN_TRY(fsn_launch_gemm_tn(dg1, G, hseq0, H, dw_ih1, H, G, H, (long)T * N, scratch, s, db1, arith));
+    FSN_TRY(fsn_launch_gemm_tn(dg0, G, x, ldx, dw_ih0, I, G, I, (long)T * N, scratch, s, db0, arith));
     if (T > 1) {
-        FSN_TRY(fsn_launch_gemm_tn(dg1 + (size_t)N * G, G, hseq1, H, dw_hh1, H, G, H, (long)(T - 1) * N, scratch, s));
-        FSN_TRY(fsn_launch_gemm_tn(dg0 + (size_t)N * G, G, hseq0, H, dw_hh0, H, G, H, (long)(T - 1) * N, scratch, s));
+        FSN_TRY(fsn_launch_gemm_tn(dg1 + (size_t)N * G, G, hseq1, H, dw_hh1, H, G, H, (long)(T - 1) * N, scratch, s, nullptr,
+                                   arith));
+        FSN_TRY(fsn_launch_gemm_tn(dg0 + (size_t)N * G, G, hseq0, H, dw_hh0, H, G, H, (long)(T - 1) * N, scratch, s, nullptr,
+                                   arith));
     } else if (hipMemsetAsync(dw_hh1, 0, (size_t)G * H * sizeof(float), s) != hipSuccess ||
                hipMemsetAsync(dw_hh0, 0, (size_t)G * H * sizeof(float), s) != hipSuccess) {
         fsn_set_error("memset failed");

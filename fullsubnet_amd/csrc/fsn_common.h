@@ -49,6 +49,55 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// One K = 16 block of a product, D = A(16 x 16) B(16 x 16) + C, from the fp32 fragments every kernel of this library
+// moves (lane (i, q) holds A[i][4q .. 4q+3] / B[4q .. 4q+3][i]), in the arithmetic AR of the call:
+//   FSN_ARITH_F32   four v_mfma_f32_16x16x4_f32: exact fp32 products, the arithmetic of every parity claim;
+//   FSN_ARITH_F16   both operands rounded to fp16 (round to nearest even) AT THE MATRIX CORE'S INPUT, one
+//   FSN_ARITH_BF16  v_mfma_f32_16x16x16_{f16,bf16}, fp32 accumulation - what torch.autocast does to nn.LSTM / nn.Linear
+//                   (recipes/dns_interspeech_2020/fullsubnet/trainer.py:56), an eighth of the matrix-core time.
+// Everything around the product (storage, cell update, reductions) is fp32 in every mode.
+typedef _Float16 fsn_f16x4 __attribute__((ext_vector_type(4)));
+typedef short fsn_s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned fsn_u32x2 __attribute__((ext_vector_type(2)));
+template <int AR>
+struct FsnOperand {
+    typedef f32x4 type;
+};
+template <>
+struct FsnOperand<FSN_ARITH_F16> {
+    typedef fsn_f16x4 type;
+};
+template <>
+struct FsnOperand<FSN_ARITH_BF16> {
+    typedef fsn_s16x4 type;
+};
+template <int AR>
+__device__ __forceinline__ typename FsnOperand<AR>::type fsn_operand(const f32x4 v) {
+    if constexpr (AR == FSN_ARITH_F16) {
+        return __builtin_convertvector(v, fsn_f16x4);  // v_cvt_pk_f16_f32 x 2
+    } else if constexpr (AR == FSN_ARITH_BF16) {
+        fsn_u32x2 r;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r[0]) : "v"(v[0]), "v"(v[1]));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r[1]) : "v"(v[2]), "v"(v[3]));
+        return __builtin_bit_cast(fsn_s16x4, r);
+    } else {
+        return v;
+    }
+}
+template <int AR>
+__device__ __forceinline__ f32x4 fsn_mma_k16(const typename FsnOperand<AR>::type a, const typename FsnOperand<AR>::type b,
+                                             f32x4 c) {
+    if constexpr (AR == FSN_ARITH_F16) {
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+    } else if constexpr (AR == FSN_ARITH_BF16) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = mfma16(a[j], b[j], c);
+        return c;
+    }
+}
+
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // Gate non-linearities of every LSTM forward kernel (persistent, per-step, wavefront) on the hardware transcendentals
@@ -155,7 +204,7 @@ size_t fsn_lstm2_group_bptt_flag_words(int clusters);  // lstm_group_bptt_kernel
 int fsn_lstm2_group_bptt_clusters(int tiles);
 int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const float* wih1T_p, const float* whh0T_p,
                                 const float* save0, const float* save1, float* dg0, float* dg1, float* dx, unsigned* flags,
-                                int Tp, int Nrows, int clusters, int H, hipStream_t s);
+                                int Tp, int Nrows, int clusters, int H, hipStream_t s, int arith = FSN_ARITH_F32);
 // fb_chain_bptt_kernels.hip: BPTT of the full-band model's two layers (16 rows, H = 512) as one persistent launch
 bool fsn_fb_chain_bptt_supported(int H, int N);
 int fsn_fb_chain_bptt_max_steps();
@@ -205,7 +254,7 @@ size_t fsn_lstm2_group_bptt_status_word(int clusters);
 int fsn_launch_lstm2_group_train(const float* x, long x_ld, int x_cols, int Nrows, const float* wih0_p, const float* whh0_p,
                                  const float* wih1_p, const float* whh1_p, const float* bias0, const float* bias1,
                                  float* hseq0, float* hseq1, float* save0, float* save1, unsigned* flags, int Tp,
-                                 int clusters, int H, hipStream_t s);  // lstm_group_kernels.hip
+                                 int clusters, int H, hipStream_t s, int arith = FSN_ARITH_F32);  // lstm_group_kernels.hip
 
 // fb_chain_kernels.hip: the full-band model's two LSTM layers over all frames as one persistent launch
 bool fsn_fb_chain_supported(int H, int Npad);
@@ -220,7 +269,7 @@ int fsn_launch_fb_chain(const float* gx0, const float* whh0_p, const float* wih1
 // C [M][Nc] = sum_k A[k][M]^T B[k][Nc]   (both operands row-major over k; split-K, deterministic 2-pass)
 size_t fsn_gemm_tn_workspace_bytes(int M, int Nc, long K);
 int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int Nc, long K,
-                       void* workspace, hipStream_t s, float* colsum_out = nullptr);
+                       void* workspace, hipStream_t s, float* colsum_out = nullptr, int arith = FSN_ARITH_F32);
 int fsn_launch_colsum(const float* A, long lda, float* out, int cols, long rows, void* workspace, hipStream_t s);
 size_t fsn_colsum_workspace_bytes(int cols, long rows);
 int fsn_launch_bptt_step(const float* dh_out, const float* dgates_next, const float* whhT_p, float* dc,

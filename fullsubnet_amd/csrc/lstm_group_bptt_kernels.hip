@@ -76,7 +76,8 @@ __device__ __forceinline__ bool bptt_poll(unsigned* flags8, unsigned epoch, unsi
 // ABL: experiment knob of tools/probe_bptt.hip (0 in the library; any bit set gives WRONG results): 1 no flag polling,
 // 2 no gate-gradient / dx stores, 4 A fragments not loaded, 8 saved activations not loaded, 16 plain instead of
 // write-through stores, 32 no tanhf in the cell derivative
-template <int LAYER, int ABL>
+// AR: arithmetic of the products (fsn_mma_k16); everything stored stays fp32
+template <int LAYER, int ABL, int AR>
 __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int member, f32x4 (*bsh)[BCH * 2 * BU][64]) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
@@ -174,11 +175,17 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
                 const f32x4 av = ar[d];
                 ar[d] = fetch_a(s * BCH + c + AD);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (AR == FSN_ARITH_F32) {
 #pragma unroll
-                for (int u = 0; u < NT; ++u) {
-                    const f32x4 bf = bsh[buf][c * NT + u][lane];
+                    for (int u = 0; u < NT; ++u) {
+                        const f32x4 bf = bsh[buf][c * NT + u][lane];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[u] = mfma16(av[j], bf[j], acc[u]);
+                        for (int j = 0; j < 4; ++j) acc[u] = mfma16(av[j], bf[j], acc[u]);
+                    }
+                } else {  // 16-bit operands: one matrix instruction per tile and K chunk
+                    const typename FsnOperand<AR>::type ao = fsn_operand<AR>(av);
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) acc[u] = fsn_mma_k16<AR>(ao, fsn_operand<AR>(bsh[buf][c * NT + u][lane]), acc[u]);
                 }
                 if (c == BCH - 1) {
                     park_b(buf ^ 1, QMAX - 1);
@@ -314,7 +321,7 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
     }
 }
 
-template <int ABL>
+template <int ABL, int AR = FSN_ARITH_F32>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(116))) void lstm2_group_bptt_kernel(const BpttArgs a) {
     __shared__ f32x4 bsh[2][BCH * 2 * BU][64];  // two stages x (4 chunks x up to 6 column tiles) x 1 KB
     // first half of the grid: layer 1 (the leading chain), second half: layer 0; cluster members on one XCD when the
@@ -334,9 +341,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(116))) void 
     }
     if (!second) {
         __builtin_amdgcn_s_setprio(2);  // layer 1 is the longer chain (six tiles per A fragment against three)
-        bptt_body<1, ABL>(a, cluster, member, bsh);
+        bptt_body<1, ABL, AR>(a, cluster, member, bsh);
     } else {
-        bptt_body<0, ABL>(a, cluster, member, bsh);
+        bptt_body<0, ABL, AR>(a, cluster, member, bsh);
     }
 }
 
@@ -349,7 +356,9 @@ int fsn_lstm2_group_bptt_clusters(int tiles) {
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return 0;
     // residency contract: two workgroups per CU, by the compiled kernel's occupancy
-    if (!fsn_grid_fits((const void*)lstm2_group_bptt_kernel<0>, 256, 2u * (unsigned)cus)) return 0;
+    for (const void* k : {(const void*)lstm2_group_bptt_kernel<0>, (const void*)lstm2_group_bptt_kernel<0, FSN_ARITH_F16>,
+                          (const void*)lstm2_group_bptt_kernel<0, FSN_ARITH_BF16>})
+        if (!fsn_grid_fits(k, 256, 2u * (unsigned)cus)) return 0;
     const int cap = cus / BM, c = tiles / 4;
     return c < cap ? c : cap;
 }
@@ -361,7 +370,7 @@ size_t fsn_lstm2_group_bptt_status_word(int clusters) { return (size_t)clusters 
 // fsn_lstm_layer_forward's layout; dg0 / dg1 [Tp][Nrows][4H] out; dx [Tp][Nrows][H] scratch (layer 0's dH).
 int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const float* wih1T_p, const float* whh0T_p,
                                 const float* save0, const float* save1, float* dg0, float* dg1, float* dx, unsigned* flags,
-                                int Tp, int Nrows, int clusters, int H, hipStream_t s) {
+                                int Tp, int Nrows, int clusters, int H, hipStream_t s, int arith) {
     if (H != BH || clusters < 1 || clusters > fsn_lstm2_group_bptt_clusters(Nrows / 16)) {
         fsn_set_error("lstm2_group_bptt: H = 384, clusters * 64 <= rows, one cluster per eight CUs at most");
         return FSN_ERR_ARG;
@@ -392,6 +401,13 @@ int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const fl
     a.spin_ticks = fsn_spin_ticks();
     a.Tp = Tp;
     a.Nrows = Nrows;
-    hipLaunchKernelGGL(lstm2_group_bptt_kernel<0>, dim3((unsigned)clusters * BM * 2), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)clusters * BM * 2), block(256);
+    if (arith == FSN_ARITH_F16) hipLaunchKernelGGL((lstm2_group_bptt_kernel<0, FSN_ARITH_F16>), grid, block, 0, s, a);
+    else if (arith == FSN_ARITH_BF16) hipLaunchKernelGGL((lstm2_group_bptt_kernel<0, FSN_ARITH_BF16>), grid, block, 0, s, a);
+    else if (arith == FSN_ARITH_F32) hipLaunchKernelGGL(lstm2_group_bptt_kernel<0>, grid, block, 0, s, a);
+    else {
+        fsn_set_error("lstm2_group_bptt: arithmetic %d unknown", arith);
+        return FSN_ERR_ARG;
+    }
     return fsn_check_launch("lstm2_group_bptt_kernel");
 }

@@ -106,7 +106,9 @@ struct GrpCl {
 
 // TRAIN: the general two-layer form (plain row-major input, hidden sequences = exchange buffers, no output layer);
 // SAVE (with TRAIN): also keep the activated gates and cell states (the training forward)
-template <int LAYER, int ABL, bool TRAIN, int NCL, bool SAVE>
+// AR: arithmetic of the products (fsn_mma_k16: FSN_ARITH_F32, or 16-bit operands with fp32 accumulation for autocast
+// training); data movement and everything stored are the same in every mode
+template <int LAYER, int ABL, bool TRAIN, int NCL, bool SAVE, int AR>
 __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int cluster_b, int member,
                                            f32x4 (*bsh)[GU * 4 * FSN_GRP_CPS][64], float (*bias_sh)[16]) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -223,15 +225,24 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
                     const f32x4 av = ar[d];
                     ar[d] = fetch_a(k + AD);
                     __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (AR == FSN_ARITH_F32) {
 #pragma unroll
-                    for (int u = 0; u < GU; ++u) {
-                        f32x4 b[4];
+                        for (int u = 0; u < GU; ++u) {
+                            f32x4 b[4];
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) b[g] = bsh[buf][c * GU * 4 + u * 4 + g][lane];
+                            for (int g = 0; g < 4; ++g) b[g] = bsh[buf][c * GU * 4 + u * 4 + g][lane];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) acc[u][g] = mfma16(av[j], b[g][j], acc[u][g]);
+                                for (int g = 0; g < 4; ++g) acc[u][g] = mfma16(av[j], b[g][j], acc[u][g]);
+                        }
+                    } else {  // 16-bit operands: one matrix instruction per tile and K chunk
+                        const typename FsnOperand<AR>::type ao = fsn_operand<AR>(av);
+#pragma unroll
+                        for (int u = 0; u < GU; ++u)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+                                acc[u][g] = fsn_mma_k16<AR>(ao, fsn_operand<AR>(bsh[buf][c * GU * 4 + u * 4 + g][lane]), acc[u][g]);
                     }
 #pragma unroll
                     for (int j = 0; j < GU; ++j) bsh[buf ^ 1][c * GU * 4 + wave * GU + j][lane] = bn[j];
@@ -429,7 +440,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
     }
 }
 
-template <int ABL, bool TRAIN = false, int NCL = 1, bool SAVE = TRAIN>
+template <int ABL, bool TRAIN = false, int NCL = 1, bool SAVE = TRAIN, int AR = FSN_ARITH_F32>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void lstm2_group_kernel(const GrpArgs a) {
     // weight fragments of one K chunk, shared by the four waves: two stages x 12 fragments x 1 KB
     __shared__ f32x4 bsh[2][GU * 4 * FSN_GRP_CPS][64];
@@ -457,8 +468,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void 
     // Layer 1 is the longer dependent chain (K = 768 per step against 416) and layer 0 is throttled to stay within
     // GD0 - 2 steps of it: layer 1's waves issue first, layer 0's fill the gaps.
     if (layer == 1 && !(ABL & 64)) __builtin_amdgcn_s_setprio(2);
-    if (layer == 0) group_body<0, ABL, TRAIN, NCL, SAVE>(a, cluster, cluster_b, member, bsh, bias_sh);
-    else group_body<1, ABL, TRAIN, NCL, SAVE>(a, cluster, cluster_b, member, bsh, bias_sh);
+    if (layer == 0) group_body<0, ABL, TRAIN, NCL, SAVE, AR>(a, cluster, cluster_b, member, bsh, bias_sh);
+    else group_body<1, ABL, TRAIN, NCL, SAVE, AR>(a, cluster, cluster_b, member, bsh, bias_sh);
 }
 
 }  // namespace
@@ -478,7 +489,11 @@ static int grp_slots_cap() {
     const unsigned grid = 2u * (unsigned)cus;
     const void* forms[] = {(const void*)lstm2_group_kernel<0, false, 1>,      (const void*)lstm2_group_kernel<0, false, 2>,
                            (const void*)lstm2_group_kernel<0, true, 1, true>, (const void*)lstm2_group_kernel<0, true, 2, true>,
-                           (const void*)lstm2_group_kernel<0, true, 1, false>, (const void*)lstm2_group_kernel<0, true, 2, false>};
+                           (const void*)lstm2_group_kernel<0, true, 1, false>, (const void*)lstm2_group_kernel<0, true, 2, false>,
+                           (const void*)lstm2_group_kernel<0, true, 1, true, FSN_ARITH_F16>,
+                           (const void*)lstm2_group_kernel<0, true, 2, true, FSN_ARITH_F16>,
+                           (const void*)lstm2_group_kernel<0, true, 1, true, FSN_ARITH_BF16>,
+                           (const void*)lstm2_group_kernel<0, true, 2, true, FSN_ARITH_BF16>};
     for (const void* k : forms)
         if (!fsn_grid_fits(k, 256, grid)) return 0;
     return cus / GM;
@@ -544,9 +559,13 @@ int fsn_launch_lstm2_group(const FsnSbInput* xin, const float* whh0_p, const flo
 int fsn_launch_lstm2_group_train(const float* x, long x_ld, int x_cols, int Nrows, const float* wih0_p, const float* whh0_p,
                                  const float* wih1_p, const float* whh1_p, const float* bias0, const float* bias1,
                                  float* hseq0, float* hseq1, float* save0, float* save1, unsigned* flags, int Tp,
-                                 int clusters, int H, hipStream_t s) {
+                                 int clusters, int H, hipStream_t s, int arith) {
     if (H != GH || clusters < 1 || (long)clusters * GROWS > Nrows || (size_t)Tp * Nrows * GH * 4 > 0x7fffffffull) {
         fsn_set_error("lstm2_group (training): H = 384, clusters * 64 <= rows, hidden sequence below 2 GB");
+        return FSN_ERR_ARG;
+    }
+    if (arith != FSN_ARITH_F32 && !((arith == FSN_ARITH_F16 || arith == FSN_ARITH_BF16) && save0 && save1)) {
+        fsn_set_error("lstm2_group: arithmetic %d is built for the training form (fp16 / bf16 operands) only", arith);
         return FSN_ERR_ARG;
     }
     if (fsn_launch_zero_words(flags, fsn_lstm2_group_flag_words(clusters), s) != FSN_OK) return FSN_ERR_LAUNCH;
@@ -590,7 +609,13 @@ int fsn_launch_lstm2_group_train(const float* x, long x_ld, int x_cols, int Nrow
         return FSN_ERR_ARG;
     }
     const dim3 grid((unsigned)slots * GM * 2), block(256);
-    if (save) {
+    if (save && arith == FSN_ARITH_F16) {
+        if (clusters > slots) hipLaunchKernelGGL((lstm2_group_kernel<0, true, 2, true, FSN_ARITH_F16>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((lstm2_group_kernel<0, true, 1, true, FSN_ARITH_F16>), grid, block, 0, s, a);
+    } else if (save && arith == FSN_ARITH_BF16) {
+        if (clusters > slots) hipLaunchKernelGGL((lstm2_group_kernel<0, true, 2, true, FSN_ARITH_BF16>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((lstm2_group_kernel<0, true, 1, true, FSN_ARITH_BF16>), grid, block, 0, s, a);
+    } else if (save) {
         if (clusters > slots) hipLaunchKernelGGL((lstm2_group_kernel<0, true, 2, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((lstm2_group_kernel<0, true, 1, true>), grid, block, 0, s, a);
     } else {

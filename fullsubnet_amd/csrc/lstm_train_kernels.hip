@@ -158,7 +158,8 @@ __global__ __launch_bounds__(NW * 64) void bptt_step_kernel(const float* __restr
 // q = l>>4) feeds A[k0 + 4q + j][m0 + r] / B[k0 + 4q + j][n0 + r] to the j-th MFMA of a 16-deep
 // chunk: 16 lanes read 64 contiguous bytes of one k row, the row base is wave-uniform (SGPR) and
 // the lane part a fixed 32-bit offset.  Out-of-range columns are clamped on load and never stored.
-template <int RTW, int CTW, int WM, int WN>
+// AR: arithmetic of the products (fsn_mma_k16): the lane's four k of a chunk ARE the 16-bit instruction's operand.
+template <int RTW, int CTW, int WM, int WN, int AR = FSN_ARITH_F32>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, long lda,
                                                       const float* __restrict__ B, long ldb,
                                                       float* __restrict__ part, int M, int Nc, long K, long k_per_split,
@@ -213,12 +214,26 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         }
     };
     auto consume = [&](int p) {
+        if constexpr (AR == FSN_ARITH_F32) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < RTW; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < CTW; ++jj) acc[i][jj] = mfma16(abuf[p][i][j], bbuf[p][jj][j], acc[i][jj]);
+        } else {
+            typename FsnOperand<AR>::type ao[RTW], bo[CTW];
+#pragma unroll
+            for (int i = 0; i < RTW; ++i)
+                ao[i] = fsn_operand<AR>(f32x4{abuf[p][i][0], abuf[p][i][1], abuf[p][i][2], abuf[p][i][3]});
+#pragma unroll
+            for (int jj = 0; jj < CTW; ++jj)
+                bo[jj] = fsn_operand<AR>(f32x4{bbuf[p][jj][0], bbuf[p][jj][1], bbuf[p][jj][2], bbuf[p][jj][3]});
 #pragma unroll
             for (int i = 0; i < RTW; ++i)
 #pragma unroll
-                for (int jj = 0; jj < CTW; ++jj) acc[i][jj] = mfma16(abuf[p][i][j], bbuf[p][jj][j], acc[i][jj]);
+                for (int jj = 0; jj < CTW; ++jj) acc[i][jj] = fsn_mma_k16<AR>(ao[i], bo[jj], acc[i][jj]);
+        }
 #pragma unroll
         for (int i = 0; i < RTW; ++i) asum[i] += (abuf[p][i][0] + abuf[p][i][1]) + (abuf[p][i][2] + abuf[p][i][3]);
     };
@@ -368,7 +383,11 @@ size_t fsn_gemm_tn_workspace_bytes(int M, int Nc, long K) {
 
 // colsum_out (may be NULL): also out[m] = sum_k A[k][m], from the same pass over A (not with a narrow M)
 int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int Nc, long K,
-                       void* workspace, hipStream_t s, float* colsum_out) {
+                       void* workspace, hipStream_t s, float* colsum_out, int arith) {
+    if (arith != FSN_ARITH_F32 && arith != FSN_ARITH_F16 && arith != FSN_ARITH_BF16) {
+        fsn_set_error("gemm_tn: arithmetic %d unknown", arith);
+        return FSN_ERR_ARG;
+    }
     if (K <= 0 || lda * 16 > 0x7fffffffL || ldb * 16 > 0x7fffffffL) {
         fsn_set_error("gemm_tn: bad K = %ld or leading dimension", K);
         return FSN_ERR_ARG;
@@ -386,10 +405,14 @@ int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float
     if (K16 > 0) {
         const TnPlan p = swap ? tn_plan(Nc, M, K16) : tn_plan(M, Nc, K16);
         if (colsum_out) asum_part = part + (size_t)p.splits * M * Nc;
-        auto wide = gemm_tn_kernel<8, 4, 2, 2>;
-        auto narrow = gemm_tn_kernel<8, 2, 4, 1>;
-        static bool attr_set = false;
-        if (!attr_set) {
+        auto wide = arith == FSN_ARITH_F16    ? gemm_tn_kernel<8, 4, 2, 2, FSN_ARITH_F16>
+                    : arith == FSN_ARITH_BF16 ? gemm_tn_kernel<8, 4, 2, 2, FSN_ARITH_BF16>
+                                              : gemm_tn_kernel<8, 4, 2, 2>;
+        auto narrow = arith == FSN_ARITH_F16    ? gemm_tn_kernel<8, 2, 4, 1, FSN_ARITH_F16>
+                      : arith == FSN_ARITH_BF16 ? gemm_tn_kernel<8, 2, 4, 1, FSN_ARITH_BF16>
+                                                : gemm_tn_kernel<8, 2, 4, 1>;
+        static bool attr_set[4] = {false, false, false, false};
+        if (!attr_set[arith]) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(wide), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)kTnOnePerCu) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(narrow), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -397,7 +420,7 @@ int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float
                 fsn_set_error("gemm_tn: cannot reserve %zu bytes of LDS", kTnOnePerCu);
                 return FSN_ERR_LAUNCH;
             }
-            attr_set = true;
+            attr_set[arith] = true;
         }
         const dim3 grid((unsigned)(p.m_blocks * p.n_blocks * p.splits));
         if (swap)

@@ -42,10 +42,13 @@ __device__ __forceinline__ double block_sum(double x, double* sh) {
 }
 
 // skipped (may be NULL): {updates skipped so far, snapshot of that count taken here for the update kernel}
+// grad_scale (may be NULL): the loss scale the gradients carry; the norm is that of g / scale
 __global__ __launch_bounds__(256) void grad_sumsq_kernel(TensorTable tt, double* __restrict__ partial,
-                                                         unsigned* __restrict__ skipped) {
+                                                         unsigned* __restrict__ skipped,
+                                                         const float* __restrict__ grad_scale) {
     __shared__ double sh[4];
     if (skipped && blockIdx.x == 0 && threadIdx.x == 0) skipped[1] = skipped[0];
+    const float inv_scale = grad_scale ? 1.0f / *grad_scale : 1.0f;
     const int ti = find_tensor(tt, blockIdx.x);
     const long base = (long)(blockIdx.x - tt.chunk0[ti]) * kChunk;
     const float* g = tt.g[ti];
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(TensorTable tt, double*
     for (int i = threadIdx.x; i < kChunk; i += 256) {
         const long k = base + i;
         if (k < n) {
-            const double x = g[k];
+            const double x = g[k] * inv_scale;  // the fp32 value GradScaler.unscale_ would leave in g
             acc += x * x;
         }
     }
@@ -78,7 +81,8 @@ struct AdamScalars {
 // count (the host keeps counting calls: the kernel subtracts the snapshot skipped[1]).
 __global__ __launch_bounds__(256) void clip_adam_kernel(TensorTable tt, const double* __restrict__ partial,
                                                         int n_partials, AdamScalars a, float* __restrict__ norm_out,
-                                                        unsigned* __restrict__ skipped) {
+                                                        unsigned* __restrict__ skipped,
+                                                        const float* __restrict__ grad_scale) {
     __shared__ double sh[4];
     __shared__ float coef_sh, step_size_sh, bc2_sqrt_sh;
     __shared__ int ok_sh;
@@ -109,6 +113,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(TensorTable tt, const do
     a.step_size = step_size_sh;
     a.bc2_sqrt = bc2_sqrt_sh;
     const float coef = a.max_norm > 0.f ? coef_sh : 1.0f;
+    const float inv_scale = grad_scale ? 1.0f / *grad_scale : 1.0f;
     const int ti = find_tensor(tt, blockIdx.x);
     const long base = (long)(blockIdx.x - tt.chunk0[ti]) * kChunk;
     const long n = tt.numel[ti];
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(TensorTable tt, const do
     for (int i = threadIdx.x; i < kChunk; i += 256) {
         const long k = base + i;
         if (k >= n) break;
-        const float gk = g[k] * coef;
+        const float gk = (grad_scale ? g[k] * inv_scale : g[k]) * coef;  // unscale (GradScaler.unscale_), then clip
         const float mk = m[k] + a.one_minus_beta1 * (gk - m[k]);
         const float vk = v[k] * a.beta2 + a.one_minus_beta2 * (gk * gk);
         const float denom = sqrtf(vk) / a.bc2_sqrt + a.eps;
@@ -182,8 +187,8 @@ extern "C" size_t fsn_clip_adam_workspace_bytes(int n_tensors, const size_t* num
 
 extern "C" int fsn_clip_adam_step(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                                   float* const* exp_avg_sq, const size_t* numel, const fsn_adam_cfg* cfg,
-                                  float* total_norm_out, unsigned* skipped_steps, void* workspace, size_t workspace_bytes,
-                                  void* stream) {
+                                  float* total_norm_out, const float* grad_scale, unsigned* skipped_steps, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
     FsnCallScope scope(stream);
     FSN_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel && cfg && workspace, "NULL pointer argument");
     FSN_REQUIRE(n_tensors >= 1 && n_tensors <= kMaxTensors, "clip_adam: 1..%d tensors per call (got %d)", kMaxTensors,
@@ -201,7 +206,7 @@ extern "C" int fsn_clip_adam_step(int n_tensors, float* const* params, float* co
     TensorTable tt;
     const int chunks = build_table(tt, n_tensors, params, grads, exp_avg, exp_avg_sq, numel);
     double* partial = static_cast<double*>(workspace);
-    hipLaunchKernelGGL(grad_sumsq_kernel, dim3(chunks), dim3(256), 0, s, tt, partial, skipped_steps);
+    hipLaunchKernelGGL(grad_sumsq_kernel, dim3(chunks), dim3(256), 0, s, tt, partial, skipped_steps, grad_scale);
     FSN_TRY_LAUNCH("grad_sumsq_kernel");
     // scalars exactly as torch.optim.adam._single_tensor_adam forms them (Python doubles -> fp32 kernel scalars)
     const double b1 = cfg->beta1, b2 = cfg->beta2;
@@ -219,7 +224,7 @@ extern "C" int fsn_clip_adam_step(int n_tensors, float* const* params, float* co
     a.beta2_d = b2;
     a.step = cfg->step;
     hipLaunchKernelGGL(clip_adam_kernel, dim3(chunks), dim3(256), 0, s, tt, partial, chunks, a, total_norm_out,
-                       skipped_steps);
+                       skipped_steps, grad_scale);
     return fsn_check_launch("clip_adam_kernel");
 }
 

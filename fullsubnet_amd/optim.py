@@ -23,6 +23,10 @@ from . import _lib
 
 
 class ClipAdam(torch.optim.Optimizer):
+    # torch.amp.GradScaler.step() then sets `self.grad_scale` / `self.found_inf` (device tensors) and calls step()
+    # directly: the kernel unscales (g / scale before the norm), and skips on a non-finite norm without a host sync
+    _step_supports_amp_scaling = True
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, clip_grad_norm_value=0.0):
         if lr <= 0 or eps <= 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("ClipAdam: invalid hyper-parameters")
@@ -95,7 +99,11 @@ class ClipAdam(torch.optim.Optimizer):
             self.total_norm = torch.empty(1, dtype=torch.float32, device=dev)
             if gi not in self._skipped or self._skipped[gi].device != dev:
                 self._skipped[gi] = torch.zeros(2, dtype=torch.int32, device=dev)
+            scale = getattr(self, "grad_scale", None)  # set by GradScaler.step for the duration of this call
+            if scale is not None:
+                scale = scale.to(device=dev, dtype=torch.float32).reshape(1)
             _lib.check(L.fsn_clip_adam_step(n, P, G, M, V, numel, ctypes.byref(cfg), _lib.dev_ptr(self.total_norm),
+                                            _lib.dev_ptr(scale, "grad_scale", allow_none=True),
                                             ctypes.c_void_p(self._skipped[gi].data_ptr()),
                                             ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_ptr(dev)))
             torch._C._increment_version(ps)  # the raw-pointer update above is invisible to autograd's counters

@@ -68,11 +68,16 @@ class Lstm2Function(torch.autograd.Function):
     """nn.LSTM(num_layers=2) (unidirectional, h0 = c0 = 0, both layers H wide) on time-major x [T, N, I] -> [T, N, H]:
     fsn_lstm2_forward_train (the full-band shape - H = 512, up to 64 rows - and the sub-band shape - H = 384, 96+ row
     tiles - each as ONE persistent launch for both layers and all steps) and fsn_lstm2_backward (the sub-band shape's
-    back-propagation through time as one persistent launch as well)."""
+    back-propagation through time as one persistent launch as well).  `arith`: "f32", or "f16" / "bf16" = the
+    arithmetic of torch.autocast (fullsubnet/trainer.py:56): 16-bit matrix-core operands, fp32 accumulation, on the
+    sub-band shape's kernels; the gradient coming in is then expected to carry the caller's loss scale (GradScaler)."""
 
     @staticmethod
-    def forward(ctx, x, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1):
+    def forward(ctx, x, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, arith="f32"):
         L = _lib.lib()
+        ctx.arith = _lib.ARITH[arith]
+        if arith not in ("f32", "f16", "bf16"):
+            raise _lib.FsnError(f"training arithmetic {arith!r}: one of 'f32', 'f16', 'bf16'")
         T, N, I = x.shape
         H = w_hh0.shape[1]
         Np, Ip = (N + 15) // 16 * 16, (I + 15) // 16 * 16
@@ -88,7 +93,7 @@ class Lstm2Function(torch.autograd.Function):
         ws = _lib.workspace(L.fsn_lstm2_train_workspace_bytes(T, Np, I, H), x.device)
         _lib.check(L.fsn_lstm2_forward_train(
             _lib.dev_ptr(xp, "x"), Ip, *[_lib.dev_ptr(t) for t in ws_], T, Np, I, H, _lib.dev_ptr(hseq0),
-            _lib.dev_ptr(hseq1), save0.data_ptr(), save1.data_ptr(), nsave, ws.data_ptr(), ws.numel(),
+            _lib.dev_ptr(hseq1), save0.data_ptr(), save1.data_ptr(), nsave, ws.data_ptr(), ws.numel(), ctx.arith,
             _lib.stream_ptr(x.device)))
         ctx.save_for_backward(xp, ws_[0], ws_[1], ws_[4], ws_[5], hseq0, hseq1, save0, save1)
         ctx.dims = (T, N, I, H, Np, Ip)
@@ -114,8 +119,10 @@ class Lstm2Function(torch.autograd.Function):
             _lib.dev_ptr(dhp, "dh"), _lib.dev_ptr(xp), Ip, _lib.dev_ptr(w_ih0), _lib.dev_ptr(w_hh0), _lib.dev_ptr(w_ih1),
             _lib.dev_ptr(w_hh1), T, Np, I, H, _lib.dev_ptr(hseq0), _lib.dev_ptr(hseq1), save0.data_ptr(), save1.data_ptr(),
             _lib.dev_ptr(dx, allow_none=True), Ip, _lib.dev_ptr(dw_ih0), _lib.dev_ptr(dw_hh0), _lib.dev_ptr(db0),
-            _lib.dev_ptr(dw_ih1), _lib.dev_ptr(dw_hh1), _lib.dev_ptr(db1), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)))
-        return ((dx[:, :N, :I] if need_dx else None), dw_ih0, dw_hh0, db0, db0.clone(), dw_ih1, dw_hh1, db1, db1.clone())
+            _lib.dev_ptr(dw_ih1), _lib.dev_ptr(dw_hh1), _lib.dev_ptr(db1), ws.data_ptr(), ws.numel(), ctx.arith,
+            _lib.stream_ptr(dev)))
+        return ((dx[:, :N, :I] if need_dx else None), dw_ih0, dw_hh0, db0, db0.clone(), dw_ih1, dw_hh1, db1, db1.clone(),
+                None)
 
 
 class GruLayerFunction(torch.autograd.Function):
@@ -216,12 +223,12 @@ class LinearFunction(torch.autograd.Function):
         return (dx[:, :I].reshape(*lead, I) if need_dx else None), dw, db, None
 
 
-def lstm_stack(x_tn, lstm):
+def lstm_stack(x_tn, lstm, arith="f32"):
     """Two stacked layers of an nn.LSTM parameter container on time-major x [T, N, I]."""
     h = x_tn
     if lstm.num_layers == 2 and lstm.weight_hh_l0.shape == lstm.weight_hh_l1.shape:
         return Lstm2Function.apply(h, *[getattr(lstm, f"{n}_l{k}") for k in (0, 1)
-                                        for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")])
+                                        for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")], arith)
     for k in range(lstm.num_layers):
         h = LstmLayerFunction.apply(h, getattr(lstm, f"weight_ih_l{k}"), getattr(lstm, f"weight_hh_l{k}"),
                                     getattr(lstm, f"bias_ih_l{k}"), getattr(lstm, f"bias_hh_l{k}"))
@@ -324,7 +331,8 @@ def forward_train(model, noisy_mag):
     x = functional.pad(noisy_mag, [0, model.look_ahead])
     B, C, F, Tp = x.shape
     fb_in = _norm(x, model.norm_type).reshape(B, F, Tp)
-    h = lstm_stack(fb_in.permute(2, 0, 1), model.fb_model.sequence_model)  # [Tp, B, Hf]
+    arith = getattr(model, "train_arithmetic", "f32")  # "f16" / "bf16": autocast arithmetic (Trainer, use_amp)
+    h = lstm_stack(fb_in.permute(2, 0, 1), model.fb_model.sequence_model, arith)  # [Tp, B, Hf]
     fc = model.fb_model.fc_output_layer
     fb_out = LinearFunction.apply(h, fc.weight, fc.bias, True)  # ReLU(h W^T + b): [Tp, B, F]
     fb_out = fb_out.permute(1, 2, 0).reshape(B, 1, F, Tp)
@@ -342,7 +350,7 @@ def forward_train(model, noisy_mag):
             Fs = sb_in.shape[2]
             sb_in = sb_in.permute(0, 2, 1, 3)
         sb_in = sb_in.reshape(B * Fs, 2 * n + 2, Tp)
-    h = lstm_stack(sb_in.permute(2, 0, 1), model.sb_model.sequence_model)  # [Tp, B Fs, Hs]
+    h = lstm_stack(sb_in.permute(2, 0, 1), model.sb_model.sequence_model, arith)  # [Tp, B Fs, Hs]
     fc = model.sb_model.fc_output_layer
     mask = LinearFunction.apply(h, fc.weight, fc.bias, False)  # [Tp, B Fs, 2]
     mask = mask.permute(1, 2, 0).reshape(B, Fs, 2, Tp).permute(0, 2, 1, 3).contiguous()
@@ -379,9 +387,15 @@ def mse_loss(input, target):
 
 
 def train_step(model, optimizer, noisy, clean, n_fft=512, hop_length=256, win_length=512, clip_grad_norm_value=10.0,
-               loss_function=None):
-    """One iteration of Trainer._train_epoch (fullsubnet/trainer.py:41-71), fp32 (use_amp = false).
-    Returns the loss tensor (call .item() to synchronise like the reference does)."""
+               loss_function=None, scaler=None):
+    """One iteration of Trainer._train_epoch (fullsubnet/trainer.py:41-71).  Returns the (unscaled) loss tensor
+    (call .item() to synchronise like the reference does).
+
+    fp32 by default (use_amp = false).  With `scaler` (a torch.amp.GradScaler, the reference's own object,
+    trainer.py:63-69) and `model.train_arithmetic` in ("f16", "bf16") the step is the reference's autocast step: the
+    transforms and the cIRM target stay fp32 (outside the autocast context there too, trainer.py:46-54), the LSTM
+    products take 16-bit operands, the loss is scaled before backward, and scaler.step / scaler.update skip the
+    update and back the scale off when a gradient is not finite."""
     loss_function = loss_function or (lambda target, pred: mse_loss(pred, target))
     optimizer.zero_grad()
     noisy_mag, _, noisy_real, noisy_imag = stft(noisy, n_fft, hop_length, win_length, return_phase=False)
@@ -391,6 +405,20 @@ def train_step(model, optimizer, noisy, clean, n_fft=512, hop_length=256, win_le
     cirm = drop_band(cirm.permute(0, 3, 1, 2), inner.num_groups_in_drop_band).permute(0, 2, 3, 1)
     crm = model(noisy_mag.unsqueeze(1)).permute(0, 2, 3, 1)
     loss = loss_function(cirm, crm)
+    if scaler is not None and scaler.is_enabled():
+        scaler.scale(loss).backward()
+        if isinstance(optimizer, ClipAdam):
+            # unscale + clip + Adam fused: GradScaler hands the scale to the optimizer (`_step_supports_amp_scaling`),
+            # which divides by it before the norm, and skips the update itself when the norm is not finite
+            for group in optimizer.param_groups:
+                group["clip_grad_norm_value"] = clip_grad_norm_value
+            scaler.step(optimizer)
+        else:  # the reference's sequence, trainer.py:65-69
+            scaler.unscale_(optimizer)
+            torch.nn.utils.clip_grad_norm_(model.parameters(), clip_grad_norm_value)
+            scaler.step(optimizer)
+        scaler.update()
+        return loss.detach()
     loss.backward()
     if isinstance(optimizer, ClipAdam):  # clip + Adam fused (two launches)
         for group in optimizer.param_groups:

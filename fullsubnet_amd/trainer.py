@@ -86,13 +86,14 @@ class Trainer:
         self.valid_dataloader = validation_dataloader
 
         meta = config.get("meta", {})
-        # meta.use_amp = true asks for fp16 autocast + GradScaler (fullsubnet/trainer.py:56,63-69).  The HIP
-        # training kernels compute in fp32 - at least the precision the flag asks for - so loss scaling is the identity.
+        # meta.use_amp = true (every shipped TOML) = fp16 autocast + GradScaler (fullsubnet/trainer.py:56,63-69,
+        # base_trainer.py:63): the LSTM products of the sub-band kernels take 16-bit operands with fp32 accumulation
+        # (Model.train_arithmetic; meta.amp_dtype = "bf16" selects bfloat16 operands instead of the recipe's fp16), the
+        # transforms and the cIRM target stay fp32 as they are outside the autocast context there, and the reference's
+        # own GradScaler scales the loss, skips overflowed steps and adapts the scale.
         self.use_amp = bool(meta.get("use_amp", False))
-        self.scaler = torch.amp.GradScaler("cuda", enabled=False)
-        if self.use_amp and rank == 0:
-            print("fullsubnet_amd.Trainer: meta.use_amp = true -> computing in fp32 (the only mode of the HIP "
-                  "training kernels); GradScaler disabled")
+        self.scaler = torch.amp.GradScaler("cuda", enabled=self.use_amp)
+        self._inner().train_arithmetic = str(meta.get("amp_dtype", "f16")) if self.use_amp else "f32"
 
         ac = config["acoustics"]
         self.acoustic_config = ac
@@ -166,8 +167,8 @@ class Trainer:
         self.start_epoch = checkpoint["epoch"] + 1
         self.best_score = checkpoint["best_score"]
         self.optimizer.load_state_dict(checkpoint["optimizer"])
-        if checkpoint.get("scaler"):  # a reference run with AMP: its loss scale has no meaning for fp32 compute
-            pass
+        if checkpoint.get("scaler") and self.scaler.is_enabled():  # base_trainer.py:186
+            self.scaler.load_state_dict(checkpoint["scaler"])
         state = {k.replace("module.", ""): v for k, v in checkpoint["model"].items()}
         self._inner().load_state_dict(state)
         if self.rank == 0:
@@ -212,7 +213,8 @@ class Trainer:
         loss_total, n = 0.0, 0
         for noisy, clean in self.train_dataloader:
             loss = train_step(self.model, self.optimizer, noisy.to(self.device), clean.to(self.device), self.n_fft,
-                              self.hop_length, self.win_length, self.clip_grad_norm_value, self.loss_function)
+                              self.hop_length, self.win_length, self.clip_grad_norm_value, self.loss_function,
+                              scaler=self.scaler)
             value = loss.item()  # host sync every step, like trainer.py:71
             # the step is complete on the device: did one of its persistent kernels run out of time (include/fsn_hip.h,
             # "residency contract")?  Its outputs were NaN then, the update was skipped on the device (non-finite

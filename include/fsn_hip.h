@@ -40,6 +40,11 @@ extern "C" {
  * operands split into two fp16 halves, three 16-bit MFMAs per product block, fp32 accumulation. */
 #define FSN_ARITH_F32 0
 #define FSN_ARITH_F16X3 1
+/* Training entries only (fsn_lstm2_forward_train / fsn_lstm2_backward): the arithmetic of torch.autocast, which the
+ * reference trains under (fullsubnet/trainer.py:56, train.toml:5 use_amp = true) - both operands of every LSTM
+ * product are rounded to fp16 / bf16 at the matrix core's input, accumulation and everything stored stay fp32. */
+#define FSN_ARITH_F16 2
+#define FSN_ARITH_BF16 3
 
 const char* fsn_last_error(void);
 int fsn_version(void);
@@ -173,12 +178,18 @@ int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_ih, const fl
  * activations: the result of two fsn_lstm_layer_forward calls (hseq0 / save0 and hseq1 / save1 in that entry's
  * layouts, each save buffer >= fsn_lstm_layer_save_bytes(T, N, H)), ready for two fsn_lstm_layer_backward calls.
  * The full-band shape (H = 512, N <= 64) runs as ONE persistent launch for both layers and all steps
- * (fb_chain_kernel) instead of 2 T launches; other shapes run layer by layer. */
+ * (fb_chain_kernel) instead of 2 T launches; other shapes run layer by layer.
+ * arith: FSN_ARITH_F32, or FSN_ARITH_F16 / FSN_ARITH_BF16 = the autocast arithmetic the reference trains under
+ * (trainer.py:56): on the sub-band shape (the group kernels, 99 % of the step's products) both operands of every
+ * product are rounded to 16 bits at the matrix core's input, accumulation and everything stored stay fp32; shapes
+ * that run on other kernels compute in fp32 (wider than asked for).  Same rule for fsn_lstm2_backward, which then
+ * expects dh1 scaled by the caller's loss scale (GradScaler) like any autocast backward. */
 size_t fsn_lstm2_train_workspace_bytes(int T, int N, int I, int H);
 int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_ih0, const float* w_hh0, const float* b_ih0,
                             const float* b_hh0, const float* w_ih1, const float* w_hh1, const float* b_ih1,
                             const float* b_hh1, int T, int N, int I, int H, float* hseq0, float* hseq1, void* save0,
-                            void* save1, size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream);
+                            void* save1, size_t save_bytes, void* workspace, size_t workspace_bytes, int arith,
+                            void* stream);
 /* Two stacked LSTM layers in inference mode, advanced as a wavefront (layer 1 at step t next to layer 0 at
  * step t + 1): T + 1 dependent launches instead of 2 T.  Either nn.LSTM(num_layers = 2) of one SequenceModel
  * (H1 == H0, sequence_model.py:52-58) or two consecutive single-layer blocks of different widths (the
@@ -225,7 +236,7 @@ int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, const float* 
                        const float* w_ih1, const float* w_hh1, int T, int N, int I, int H, const float* hseq0,
                        const float* hseq1, const void* save0, const void* save1, float* dx, long lddx, float* dw_ih0,
                        float* dw_hh0, float* db0, float* dw_ih1, float* dw_hh1, float* db1, void* workspace,
-                       size_t workspace_bytes, void* stream);
+                       size_t workspace_bytes, int arith, void* stream);
 
 /* nn.GRU branch of SequenceModel (sequence_model.py:59-66), one layer, unidirectional, h0 = 0; same
  * conventions as the LSTM layer above with 3H gate rows (r, z, n).  save == NULL: inference.  The two
@@ -269,7 +280,10 @@ int fsn_mse_loss(const float* input, const float* target, size_t n, float* loss,
  * A non-finite gradient norm SKIPS the update (parameters, moments and gradients untouched), as GradScaler.step()
  * does in the reference (trainer.py:69), with no host synchronisation: skipped_steps (device, two words, may be
  * NULL; zero it once) counts the skipped updates in word 0 (word 1 is scratch), and a skipped update does not
- * advance Adam's step count - the kernel uses step - skipped for the bias corrections. */
+ * advance Adam's step count - the kernel uses step - skipped for the bias corrections.
+ * grad_scale (device scalar, may be NULL = 1): the loss scale the gradients carry (GradScaler, trainer.py:63-69):
+ * they are divided by it first (GradScaler.unscale_), so total_norm_out, the clipping and the update see unscaled
+ * gradients; an overflowed (inf / NaN) gradient makes the norm non-finite and the update is skipped as above. */
 #define FSN_ADAM_MAX_TENSORS 32
 typedef struct fsn_adam_cfg {
     float lr, beta1, beta2, eps;
@@ -279,8 +293,8 @@ typedef struct fsn_adam_cfg {
 size_t fsn_clip_adam_workspace_bytes(int n_tensors, const size_t* numel);
 int fsn_clip_adam_step(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                        float* const* exp_avg_sq, const size_t* numel, const fsn_adam_cfg* cfg,
-                       float* total_norm_out, unsigned* skipped_steps, void* workspace, size_t workspace_bytes,
-                       void* stream);
+                       float* total_norm_out, const float* grad_scale, unsigned* skipped_steps, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* ---- residency contract of the persistent kernels ----------------------------------------------------------
  * Four kernels - the full-band chain (forward, BPTT) and the sub-band group kernel (forward, BPTT) - run a whole

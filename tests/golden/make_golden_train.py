@@ -29,7 +29,7 @@ from oracle.fullsubnet_oracle import make_noisy, make_params  # noqa: E402
 SAMPLE = 97  # stride of the per-parameter samples
 
 
-def main(batch=4, length=2560, groups=2, name="fsn_train_b4", sample=SAMPLE):
+def main(batch=4, length=2560, groups=2, name="fsn_train_b4", sample=SAMPLE, autocast=None):
     params = make_params(seed=3)
     noisy = make_noisy(batch, length, seed=41)
     clean = 0.7 * make_noisy(batch, length, seed=42)
@@ -44,8 +44,12 @@ def main(batch=4, length=2560, groups=2, name="fsn_train_b4", sample=SAMPLE):
     _, _, cr, ci = stft(torch.from_numpy(clean), 512, 256, 512)
     cirm = build_complex_ideal_ratio_mask(nr, ni, cr, ci)
     cirm = drop_band(cirm.permute(0, 3, 1, 2), groups).permute(0, 2, 3, 1)
-    crm = model(noisy_mag.unsqueeze(1)).permute(0, 2, 3, 1)
-    loss = torch.nn.MSELoss()(cirm, crm)
+    # autocast: the reference's use_amp = true graph (trainer.py:56-62: model forward and loss inside the context, the
+    # transforms and the target outside).  On the CPU the only 16-bit type nn.LSTM runs in is bfloat16 (oneDNN has no
+    # fp16 LSTM primitive), and bf16 needs no loss scaling: GradScaler(enabled) would be the identity here.
+    with torch.autocast("cpu", dtype=autocast, enabled=autocast is not None):
+        crm = model(noisy_mag.unsqueeze(1)).permute(0, 2, 3, 1)
+        loss = torch.nn.MSELoss()(cirm, crm)
     loss.backward()
     total_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
     out = dict(loss=np.float64(loss.item()), total_norm=np.float64(total_norm.item()))
@@ -56,7 +60,8 @@ def main(batch=4, length=2560, groups=2, name="fsn_train_b4", sample=SAMPLE):
         out["g/" + k] = grads[k].reshape(-1)[::sample].numpy().copy()
         out["p/" + k] = p.detach().reshape(-1)[::sample].numpy().copy()
     out["meta"] = np.array(repr(dict(batch=batch, length=length, groups=groups, seed_w=3, seed_noisy=41, seed_clean=42,
-                                     clean_gain=0.7, sample=sample, torch=torch.__version__)))
+                                     clean_gain=0.7, sample=sample, torch=torch.__version__,
+                                     autocast=str(autocast))))
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"loss {loss.item():.6f} total grad norm {total_norm.item():.4f} -> {os.path.getsize(path) / 1024:.0f} KiB")
@@ -64,7 +69,11 @@ def main(batch=4, length=2560, groups=2, name="fsn_train_b4", sample=SAMPLE):
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    if "--config3x2" in sys.argv:
+    if "--amp-bf16" in sys.argv:
+        # the same two steps under torch.autocast("cpu", dtype=torch.bfloat16)
+        main(name="fsn_train_b4_bf16", autocast=torch.bfloat16)
+        main(batch=16, length=49152, groups=2, name="fsn_train_c3_bf16", sample=397, autocast=torch.bfloat16)
+    elif "--config3x2" in sys.argv:
         # two ranks of BASELINE config 3 as ONE batch: 32 utterances x 3.072 s (what 2 x 16 under DistributedDataParallel
         # must reproduce: drop_band keeps the sample parity of the global batch when ranks take contiguous halves)
         main(batch=32, length=49152, groups=2, name="fsn_train_c3x2", sample=397)

@@ -1,0 +1,240 @@
+"""The reference's own training arithmetic (recipes/dns_interspeech_2020/fullsubnet/trainer.py:56,63-69 with
+train.toml:5 use_amp = true: torch.autocast + GradScaler) on the HIP path: `model.train_arithmetic = "f16" / "bf16"` -
+both operands of every LSTM product of the sub-band kernels rounded to 16 bits at the matrix core's input, fp32
+accumulation, everything stored in fp32 - with the reference's GradScaler around the fused optimizer.
+
+What is held to what:
+  * the kernels to an EXACT emulation of that arithmetic (operands rounded to the 16-bit type, products and sums in
+    fp64) - outputs and every gradient: the mode changes the products and nothing else;
+  * the whole step to the reference: against its fp32 step (how far the 16-bit operands move loss and gradients) and,
+    for bf16, against the reference's own step under torch.autocast("cpu", dtype=torch.bfloat16) (the only 16-bit
+    type nn.LSTM runs in on the CPU); measured margins are printed, the bounds sit ~3x above them;
+  * GradScaler semantics: scale unchanged after a finite step, an overflowing step skipped and the scale backed off.
+Needs an MI355X:  python -m pytest tests -m gpu"""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fullsubnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MODEL_KW = dict(num_freqs=257, look_ahead=2, sequence_model="LSTM", fb_num_neighbors=0, sb_num_neighbors=15,
+                fb_output_activate_function="ReLU", sb_output_activate_function=False, fb_model_hidden_size=512,
+                sb_model_hidden_size=384, weight_init=False)
+DTYPES = {"f16": torch.float16, "bf16": torch.bfloat16}
+
+
+@pytest.fixture(scope="module")
+def fsn():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu tests need a ROCm device")
+    import fullsubnet_amd
+    fullsubnet_amd._lib.lib()
+    return fullsubnet_amd
+
+
+class RoundedLinear(torch.autograd.Function):
+    """y = r(x) r(w)^T with r = round to `dt`: forward and BOTH backward products take rounded operands, as the kernels'
+    matrix instructions do (dx = r(dy) r(w), dw = r(dy)^T r(x)); round_dx = False leaves dx's product exact (the
+    layer-0 input gradient is a plain fp32 GEMM on the HIP path)."""
+
+    @staticmethod
+    def forward(ctx, x, w, dt, round_dx):
+        r = lambda t: t.to(dt).to(torch.float64)
+        ctx.save_for_backward(x, w)
+        ctx.dt, ctx.round_dx = dt, round_dx
+        return r(x) @ r(w).t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        r = lambda t: t.to(ctx.dt).to(torch.float64)
+        dx = (r(dy) @ r(w)) if ctx.round_dx else (dy @ w)
+        return dx, r(dy).t() @ r(x), None, None
+
+
+def emulated_lstm2(x, w, dt):
+    """Two stacked LSTM layers, time-major x [T, N, I] (fp64), every product through RoundedLinear."""
+    h_in = x
+    for layer in range(2):
+        w_ih, w_hh, b_ih, b_hh = w[4 * layer:4 * layer + 4]
+        T, N, _ = h_in.shape
+        H = w_hh.shape[1]
+        h = x.new_zeros((N, H))
+        c = x.new_zeros((N, H))
+        outs = []
+        for t in range(T):
+            gates = (RoundedLinear.apply(h_in[t], w_ih, dt, layer > 0) + RoundedLinear.apply(h, w_hh, dt, True)
+                     + (b_ih + b_hh))
+            i, f, g, o = gates.split(H, dim=1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            outs.append(h)
+        h_in = torch.stack(outs, dim=0)
+    return h_in
+
+
+@pytest.mark.parametrize("arith", ["f16", "bf16"])
+def test_two_layer_lstm_16bit_operands_vs_an_exact_emulation(fsn, arith):
+    """fsn_lstm2_forward_train / fsn_lstm2_backward with 16-bit operands on the sub-band shape (32 whole clusters: every
+    row on lstm2_group_kernel / lstm2_group_bptt_kernel, the weight gradients on gemm_tn_kernel) against the emulation
+    above in fp64: what differs is the fp32 accumulation and the hardware gate functions, as in the fp32 mode."""
+    from fullsubnet_amd.train import Lstm2Function
+    T, N, I, H = 5, 2048, 32, 384
+    g = torch.Generator().manual_seed(11)
+    k = 1.0 / np.sqrt(H)
+    x = torch.randn(T, N, I, generator=g)
+    shapes = ((4 * H, I), (4 * H, H), (4 * H,), (4 * H,), (4 * H, H), (4 * H, H), (4 * H,), (4 * H,))
+    w = [(torch.rand(s_, generator=g) * 2 - 1) * k * 2 for s_ in shapes]
+    dy = torch.randn(T, N, H, generator=g) * 64.0  # like a loss-scaled gradient
+
+    xd = x.cuda().requires_grad_(True)
+    wd = [t.cuda().requires_grad_(True) for t in w]
+    y = Lstm2Function.apply(xd, *wd, arith)
+    (y * dy.cuda()).sum().backward()
+    got = [y.detach().cpu()] + [xd.grad.cpu()] + [t.grad.cpu() for t in wd]
+
+    xe = x.double().requires_grad_(True)
+    we = [t.double().requires_grad_(True) for t in w]
+    ye = emulated_lstm2(xe, we, DTYPES[arith])
+    (ye * dy.double()).sum().backward()
+    ref = [ye.detach()] + [xe.grad] + [t.grad for t in we]
+
+    xf = x.cuda().requires_grad_(True)
+    wf = [t.cuda().requires_grad_(True) for t in w]
+    yf = Lstm2Function.apply(xf, *wf, "f32")
+    (yf * dy.cuda()).sum().backward()
+    f32 = [yf.detach().cpu()] + [xf.grad.cpu()] + [t.grad.cpu() for t in wf]
+
+    names = ["y", "dx", "dw_ih0", "dw_hh0", "db_ih0", "db_hh0", "dw_ih1", "dw_hh1", "db_ih1", "db_hh1"]
+    worst = ("", 0.0)
+    for name, a, b, c in zip(names, got, ref, f32):
+        scale = max(b.abs().max().item(), 1e-3)
+        err = (a.double() - b).abs().max().item() / scale
+        moved = (c.double() - b).abs().max().item() / scale
+        worst = max(worst, (name, err), key=lambda kv: kv[1])
+        print(f"{arith} {name:7s}: vs the emulation {err:.2e}, the fp32 mode differs from it by {moved:.2e}")
+        assert err <= 2e-4, (name, err)
+        if name in ("y", "dw_hh1", "dw_hh0"):
+            assert moved > 4 * err, "the 16-bit mode is indistinguishable from fp32 here: is it running?"
+    print(f"{arith}: worst deviation from the exact emulation {worst[1]:.2e} ({worst[0]})")
+
+
+def build(fsn, arith, seed=3, groups=2):
+    params = O.make_params(seed=seed)
+    model = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=groups, **MODEL_KW)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    model = model.cuda().train()
+    model.train_arithmetic = arith
+    return model, params
+
+
+def margins(model, opt, z, meta, params):
+    rel_total = abs(float(opt.total_norm) - float(z["total_norm"])) / float(z["total_norm"])
+    s = meta["sample"]
+    worst_norm, worst_elem = ("", 0.0), ("", 0.0)
+    dot = n1 = n2 = 0.0
+    for k, p in model.named_parameters():
+        g = p.grad.detach().reshape(-1)[::s].cpu().numpy().astype(np.float64)
+        r = z["g/" + k].astype(np.float64)
+        gn = float(z["gnorm/" + k])
+        worst_norm = max(worst_norm, (k, abs(float(p.grad.norm()) - gn) / (gn + 1e-30)), key=lambda kv: kv[1])
+        worst_elem = max(worst_elem, (k, float(np.abs(g - r).max() / max(np.abs(r).max(), 1e-3 * gn, 1e-30))),
+                         key=lambda kv: kv[1])
+        dot += float((g * r).sum())
+        n1 += float((g * g).sum())
+        n2 += float((r * r).sum())
+    return rel_total, worst_norm, worst_elem, 1.0 - dot / np.sqrt(n1 * n2)
+
+
+# (loss, total norm, tensor norm, sampled element, 1 - cosine): bounds ~3x the margins measured on MI355X (printed)
+AMP_TOL = {
+    ("f16", "fsn_train_b4"): (2e-4, 2e-3, 2e-2, 4e-2, 1e-4),
+    ("f16", "fsn_train_c3"): (2e-4, 2e-3, 2e-2, 4e-2, 1e-4),
+    ("bf16", "fsn_train_b4"): (2e-3, 2e-2, 1e-1, 2e-1, 2e-3),
+    ("bf16", "fsn_train_c3"): (2e-3, 2e-2, 1e-1, 2e-1, 2e-3),
+    ("bf16", "fsn_train_b4_bf16"): (2e-3, 2e-2, 1e-1, 2e-1, 2e-3),
+    ("bf16", "fsn_train_c3_bf16"): (2e-3, 2e-2, 1e-1, 2e-1, 2e-3),
+}
+
+
+@pytest.mark.parametrize("arith,name", sorted(AMP_TOL))
+def test_amp_train_step_vs_the_reference(fsn, golden_dir, arith, name):
+    """One autocast step (GradScaler at the reference's default scale 65536) against the reference's step: fp32 goldens
+    (how far the 16-bit operands move things) and, for bf16, the reference's own bf16-autocast goldens."""
+    from fullsubnet_amd.train import train_step
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    meta = ast.literal_eval(str(z["meta"]))
+    model, params = build(fsn, arith, seed=meta["seed_w"], groups=meta["groups"])
+    noisy = torch.from_numpy(O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_noisy"])).cuda()
+    clean = torch.from_numpy((meta["clean_gain"] * O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_clean"]))
+                             .astype(np.float32)).cuda()
+    opt = fsn.ClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    scaler = torch.amp.GradScaler("cuda")  # trainer.py:63 (base_trainer.py:63: GradScaler(enabled=use_amp))
+    loss = train_step(model, opt, noisy, clean, scaler=scaler)
+    rel_loss = abs(loss.item() - float(z["loss"])) / float(z["loss"])
+    # (p.grad holds the unscaled, clipped gradients after the step: the fused kernel writes them back like
+    # GradScaler.unscale_ + clip_grad_norm_ do)
+    rel_total, worst_norm, worst_elem, one_minus_cos = margins(model, opt, z, meta, params)
+    print(f"{arith} vs {name}: loss {rel_loss:.2e}, total norm {rel_total:.2e}, worst tensor norm {worst_norm[1]:.2e} "
+          f"({worst_norm[0]}), worst sampled element {worst_elem[1]:.2e} ({worst_elem[0]}), 1 - cos(g, g_ref) "
+          f"{one_minus_cos:.2e}")
+    assert scaler.get_scale() == 65536.0 and opt.skipped_steps() == 0
+    t_loss, t_total, t_norm, t_elem, t_cos = AMP_TOL[(arith, name)]
+    assert rel_loss <= t_loss and rel_total <= t_total and worst_norm[1] <= t_norm and worst_elem[1] <= t_elem
+    assert one_minus_cos <= t_cos
+    # the update itself: where the reference's gradient is firm the first Adam step is +-lr whatever its size
+    s = meta["sample"]
+    moved = 0
+    for k, p in model.named_parameters():
+        pv = p.detach().reshape(-1)[::s].cpu().numpy()
+        firm = np.abs(z["g/" + k]) > 1e-5
+        if firm.any():
+            assert np.abs(pv - z["p/" + k])[firm].max() <= 2.1e-3, k  # a sign flip of a firm gradient would be 2 lr
+            moved += int((np.abs(pv - params[k].reshape(-1)[::s]) > 5e-4).sum())
+    assert moved > 0
+
+
+def test_gradscaler_skips_an_overflowing_step_and_backs_off(fsn):
+    """trainer.py:63-69: a loss scale far too large for fp16 operands overflows the scaled gradients -> the update is
+    skipped (parameters and moments untouched, on the device, no host sync) and GradScaler halves the scale; the next
+    steps run at the smaller scale.  With a sane scale the scale stays and the step is applied."""
+    from fullsubnet_amd.train import train_step
+    model, _ = build(fsn, "f16")
+    noisy = torch.from_numpy(O.make_noisy(16, 8192, seed=5)).cuda()
+    clean = torch.from_numpy((0.7 * O.make_noisy(16, 8192, seed=6)).astype(np.float32)).cuda()
+    opt = fsn.ClipAdam(model.parameters(), lr=1e-3)
+    before = [p.detach().clone() for p in model.parameters()]
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 100)
+    loss = train_step(model, opt, noisy, clean, scaler=scaler)
+    assert np.isfinite(loss.item())                       # the loss itself is fine: only its scaled gradient overflowed
+    assert scaler.get_scale() == 2.0 ** 99                # backoff_factor 0.5
+    assert opt.skipped_steps() == 1
+    for p, q in zip(model.parameters(), before):
+        assert torch.equal(p.detach(), q)
+    good = torch.amp.GradScaler("cuda")
+    loss2 = train_step(model, opt, noisy, clean, scaler=good)
+    assert np.isfinite(loss2.item()) and good.get_scale() == 65536.0 and opt.skipped_steps() == 1
+    assert any(not torch.equal(p.detach(), q) for p, q in zip(model.parameters(), before))
+
+
+def test_trainer_use_amp_selects_the_16bit_arithmetic(fsn):
+    """meta.use_amp = true (every shipped TOML, fullsubnet/train.toml:5): Trainer trains under the 16-bit arithmetic
+    with an ENABLED GradScaler, whose state goes into the checkpoint dictionary like the reference's
+    (base_trainer.py:134)."""
+    model, _ = build(fsn, "f32")
+    loader = [(torch.from_numpy(O.make_noisy(4, 4096, seed=s)), torch.from_numpy(0.7 * O.make_noisy(4, 4096, seed=s + 9)))
+              for s in (1, 2)]
+    cfg = {"meta": {"use_amp": True}, "acoustics": {"n_fft": 512, "hop_length": 256, "win_length": 512, "sr": 16000},
+           "trainer": {"train": {"epochs": 1, "clip_grad_norm_value": 10}}}
+    opt = fsn.ClipAdam(model.parameters(), lr=1e-3)
+    tr = fsn.Trainer(None, 0, cfg, False, False, model, None, opt, loader)
+    assert tr.use_amp and tr.scaler.is_enabled() and tr._inner().train_arithmetic == "f16"
+    tr._set_models_to_train_mode()
+    loss = tr._train_epoch(1)
+    assert np.isfinite(loss) and tr.scaler.get_scale() == 65536.0
+    assert "scale" in tr.scaler.state_dict()

@@ -1,4 +1,5 @@
-"""Time one training step (BASELINE config 3 per-rank shape: 16 x 3.072 s) on one MI355X."""
+"""Time one training step (BASELINE config 3 per-rank shape: 16 x 3.072 s) on one MI355X.
+python tools/bench_train.py [batch] [f32|f16|bf16]   (f16 / bf16: autocast arithmetic + GradScaler)"""
 import os
 import sys
 import time
@@ -11,25 +12,28 @@ from fullsubnet_amd.train import train_step  # noqa: E402
 from fsn_synthetic import make_noisy, make_params  # noqa: E402
 
 B, L = int(sys.argv[1]) if len(sys.argv) > 1 else 16, 49152
+ARITH = sys.argv[2] if len(sys.argv) > 2 else "f32"
 model = fullsubnet_amd.Model(num_freqs=257, look_ahead=2, sequence_model="LSTM", fb_num_neighbors=0,
                              sb_num_neighbors=15, fb_output_activate_function="ReLU",
                              sb_output_activate_function=False, fb_model_hidden_size=512, sb_model_hidden_size=384,
                              norm_type="offline_laplace_norm", num_groups_in_drop_band=2, weight_init=False)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in make_params(seed=3).items()})
 model = model.cuda().train()
+model.train_arithmetic = ARITH
+scaler = torch.amp.GradScaler("cuda", enabled=ARITH != "f32")
 opt = fullsubnet_amd.ClipAdam(model.parameters(), lr=1e-3)
 noisy = torch.from_numpy(make_noisy(B, L, seed=1)).cuda()
 clean = torch.from_numpy(0.7 * make_noisy(B, L, seed=2)).cuda()
 for _ in range(2):
-    loss = train_step(model, opt, noisy, clean)
+    loss = train_step(model, opt, noisy, clean, scaler=scaler)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 K = 3
 for _ in range(K):
-    loss = train_step(model, opt, noisy, clean)
+    loss = train_step(model, opt, noisy, clean, scaler=scaler)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
 T = 1 + L // 256
 flops = 3 * 2 * (3803648 + 128 * 1819392) * B * (T + 2)  # ~3x forward, F -> 128 sub-band bins
-print(f"train step B={B}: {dt * 1e3:.1f} ms, loss {loss.item():.5f}, ~{flops / dt / 1e12:.1f} TFLOP/s "
+print(f"train step B={B} {ARITH}: {dt * 1e3:.1f} ms, loss {loss.item():.5f}, ~{flops / dt / 1e12:.1f} TFLOP/s "
       f"({B * T / dt:.0f} frames/s), peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
