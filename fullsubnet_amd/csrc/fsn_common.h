@@ -59,6 +59,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 typedef _Float16 fsn_f16x4 __attribute__((ext_vector_type(4)));
 typedef short fsn_s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned fsn_u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 fsn_bf16x2 __attribute__((ext_vector_type(2)));
 template <int AR>
 struct FsnOperand {
     typedef f32x4 type;
@@ -76,9 +77,12 @@ __device__ __forceinline__ typename FsnOperand<AR>::type fsn_operand(const f32x4
     if constexpr (AR == FSN_ARITH_F16) {
         return __builtin_convertvector(v, fsn_f16x4);  // v_cvt_pk_f16_f32 x 2
     } else if constexpr (AR == FSN_ARITH_BF16) {
-        fsn_u32x2 r;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r[0]) : "v"(v[0]), "v"(v[1]));
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r[1]) : "v"(v[2]), "v"(v[3]));
+        // pairs through __builtin_convertvector: one v_cvt_pk_bf16_f32 each (round to nearest even), and - unlike the
+        // same instruction from inline asm, which produced NaNs here - the compiler knows it is a VALU write feeding a
+        // matrix instruction and inserts the wait state that hazard needs
+        const fsn_bf16x2 lo = __builtin_convertvector(f32x2{v[0], v[1]}, fsn_bf16x2);
+        const fsn_bf16x2 hi = __builtin_convertvector(f32x2{v[2], v[3]}, fsn_bf16x2);
+        const fsn_u32x2 r = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
         return __builtin_bit_cast(fsn_s16x4, r);
     } else {
         return v;

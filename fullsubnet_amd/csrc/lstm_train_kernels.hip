@@ -163,12 +163,21 @@ template <int RTW, int CTW, int WM, int WN, int AR = FSN_ARITH_F32>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, long lda,
                                                       const float* __restrict__ B, long ldb,
                                                       float* __restrict__ part, int M, int Nc, long K, long k_per_split,
-                                                      int m_blocks, int n_blocks, float* __restrict__ asum_part) {
+                                                      int m_blocks, int n_blocks, float* __restrict__ asum_part,
+                                                      int xcd_grouped) {
     constexpr int PF = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int wm = wave / WN, wn = wave % WN;
-    const int tile = blockIdx.x % (m_blocks * n_blocks), split = blockIdx.x / (m_blocks * n_blocks);
+    int tile = blockIdx.x % (m_blocks * n_blocks), split = blockIdx.x / (m_blocks * n_blocks);
+    if (xcd_grouped) {
+        // all tiles of a K split on ONE XCD (block b runs on XCD b % 8: observed, speed only): the split's A rows are
+        // read by n_blocks workgroups and its B rows by m_blocks - from that XCD's L2 after the first touch instead of
+        // once each from HBM (the 16-bit forms are bandwidth-bound: 11 GB per GEMM at config 3's shape otherwise)
+        const int tiles = m_blocks * n_blocks, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tile = j % tiles;
+        split = xcd * ((int)(gridDim.x >> 3) / tiles) + j / tiles;
+    }
     const int mb = tile / n_blocks, nb = tile % n_blocks;
     const int m0 = (mb * WM + wm) * RTW * 16, n0 = (nb * WN + wn) * CTW * 16;
     const long k_begin = (long)split * k_per_split;
@@ -348,19 +357,34 @@ __global__ __launch_bounds__(256) void colsum_narrow_kernel(const float* __restr
 
 struct TnPlan {
     int m_blocks, n_blocks, splits, narrow;
+    int square;  // 192 x 192 tiles, every K split's tiles on one XCD (16-bit arithmetic: bandwidth-bound)
     long k_per_split;
 };
 // Workgroup tile 256 x 128 (wave tile 8 x 4, waves 2 x 2) or, for narrow outputs (the K = 2nb+2
 // input projection), 512 x 32 (wave tile 8 x 2, waves 4 x 1).  K is split so that the grid is one
 // workgroup per CU (or as close below it as the tile count allows).
-TnPlan tn_plan(int M, int Nc, long K) {
+TnPlan tn_plan(int M, int Nc, long K, int arith = FSN_ARITH_F32) {
     TnPlan p;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     p.narrow = Nc <= 32;
+    p.square = 0;
+    if (arith != FSN_ARITH_F32 && M % 192 == 0 && Nc % 192 == 0 && cus % 8 == 0 && (cus / 8) % ((M / 192) * (Nc / 192)) == 0 &&
+        K >= (long)(cus / ((M / 192) * (Nc / 192))) * 128) {
+        const long s = cus / ((M / 192) * (Nc / 192));  // whole splits per XCD, one workgroup per CU
+        const long kps = ((K + s - 1) / s + 15) / 16 * 16;
+        if ((K + kps - 1) / kps == s) {  // every split non-empty (the kernel's grid is fixed by the XCD mapping)
+            p.square = 1;
+            p.m_blocks = M / 192;
+            p.n_blocks = Nc / 192;
+            p.k_per_split = kps;
+            p.splits = (int)s;
+            return p;
+        }
+    }
     p.m_blocks = p.narrow ? (M + 511) / 512 : (M + 255) / 256;
     p.n_blocks = p.narrow ? (Nc + 31) / 32 : (Nc + 127) / 128;
     const long tiles = (long)p.m_blocks * p.n_blocks;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     long s = cus / tiles;
     const long max_s = (K + 127) / 128;  // at least 8 chunks per split
     s = s < max_s ? s : max_s;
@@ -377,8 +401,11 @@ constexpr long kColsumRows = 2048;
 size_t fsn_gemm_tn_workspace_bytes(int M, int Nc, long K) {
     const bool swap = M <= 32 && Nc > 32;
     if ((K & ~15L) <= 0) return (size_t)M * (Nc + 1) * sizeof(float);
+    // sized for the plan with the most splits of any arithmetic (the 16-bit forms may split K further)
     const TnPlan p = swap ? tn_plan(Nc, M, K & ~15L) : tn_plan(M, Nc, K & ~15L);
-    return (size_t)(p.splits > 0 ? p.splits : 1) * M * (Nc + 1) * sizeof(float);  // + one column-sum row per split
+    const TnPlan q = swap ? p : tn_plan(M, Nc, K & ~15L, FSN_ARITH_F16);
+    const int splits = p.splits > q.splits ? p.splits : q.splits;
+    return (size_t)(splits > 0 ? splits : 1) * M * (Nc + 1) * sizeof(float);  // + one column-sum row per split
 }
 
 // colsum_out (may be NULL): also out[m] = sum_k A[k][m], from the same pass over A (not with a narrow M)
@@ -403,7 +430,7 @@ int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float
     float* asum_part = nullptr;
     int splits = 0;
     if (K16 > 0) {
-        const TnPlan p = swap ? tn_plan(Nc, M, K16) : tn_plan(M, Nc, K16);
+        const TnPlan p = swap ? tn_plan(Nc, M, K16) : tn_plan(M, Nc, K16, arith);
         if (colsum_out) asum_part = part + (size_t)p.splits * M * Nc;
         auto wide = arith == FSN_ARITH_F16    ? gemm_tn_kernel<8, 4, 2, 2, FSN_ARITH_F16>
                     : arith == FSN_ARITH_BF16 ? gemm_tn_kernel<8, 4, 2, 2, FSN_ARITH_BF16>
@@ -423,12 +450,26 @@ int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float
             attr_set[arith] = true;
         }
         const dim3 grid((unsigned)(p.m_blocks * p.n_blocks * p.splits));
-        if (swap)
+        if (p.square) {
+            auto square = arith == FSN_ARITH_F16 ? gemm_tn_kernel<6, 6, 2, 2, FSN_ARITH_F16>
+                                                 : gemm_tn_kernel<6, 6, 2, 2, FSN_ARITH_BF16>;
+            static bool sq_set[4] = {false, false, false, false};
+            if (!sq_set[arith]) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(square), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)kTnOnePerCu) != hipSuccess) {
+                    fsn_set_error("gemm_tn: cannot reserve %zu bytes of LDS", kTnOnePerCu);
+                    return FSN_ERR_LAUNCH;
+                }
+                sq_set[arith] = true;
+            }
+            hipLaunchKernelGGL(square, grid, dim3(256), kTnOnePerCu, s, A, lda, B, ldb, part, M, Nc, K16, p.k_per_split,
+                               p.m_blocks, p.n_blocks, asum_part, 1);
+        } else if (swap)
             hipLaunchKernelGGL(p.narrow ? narrow : wide, grid, dim3(256), kTnOnePerCu, s, B, ldb, A, lda, part, Nc, M,
-                               K16, p.k_per_split, p.m_blocks, p.n_blocks, (float*)nullptr);
+                               K16, p.k_per_split, p.m_blocks, p.n_blocks, (float*)nullptr, 0);
         else
             hipLaunchKernelGGL(p.narrow ? narrow : wide, grid, dim3(256), kTnOnePerCu, s, A, lda, B, ldb, part, M, Nc,
-                               K16, p.k_per_split, p.m_blocks, p.n_blocks, asum_part);
+                               K16, p.k_per_split, p.m_blocks, p.n_blocks, asum_part, 0);
         FSN_TRY_LAUNCH("gemm_tn_kernel");
         splits = p.splits;
     }

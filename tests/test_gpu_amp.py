@@ -118,9 +118,11 @@ def test_two_layer_lstm_16bit_operands_vs_an_exact_emulation(fsn, arith):
         moved = (c.double() - b).abs().max().item() / scale
         worst = max(worst, (name, err), key=lambda kv: kv[1])
         print(f"{arith} {name:7s}: vs the emulation {err:.2e}, the fp32 mode differs from it by {moved:.2e}")
-        assert err <= 2e-4, (name, err)
+        # measured r03: f16 <= 2.2e-4, bf16 <= 7.6e-4 (fp32 accumulation, and operands that sit on a rounding boundary
+        # of the 16-bit type and fall to the other side when the fp32 value differs in its last bit)
+        assert err <= (6e-4 if arith == "f16" else 2.5e-3), (name, err)
         if name in ("y", "dw_hh1", "dw_hh0"):
-            assert moved > 4 * err, "the 16-bit mode is indistinguishable from fp32 here: is it running?"
+            assert moved > 2 * err, "the 16-bit mode is indistinguishable from fp32 here: is it running?"
     print(f"{arith}: worst deviation from the exact emulation {worst[1]:.2e} ({worst[0]})")
 
 
@@ -152,13 +154,22 @@ def margins(model, opt, z, meta, params):
 
 
 # (loss, total norm, tensor norm, sampled element, 1 - cosine): bounds ~3x the margins measured on MI355X (printed)
+# measured r03 (gpurun_out/r03f):                 loss     total    tensor   element  1 - cos
+#   f16  vs fp32 reference, b4 (*)                 3.6e-7   2.1e-6   1.0e-4   1.4e-4   1.4e-10
+#   f16  vs fp32 reference, c3                     6.9e-8   4.5e-6   6.8e-5   1.8e-3   9.6e-10
+#   bf16 vs fp32 reference, c3                     1.6e-6   1.6e-3   2.0e-3   7.6e-3   9.3e-8
+#   bf16 vs the reference under bf16 autocast, b4  2.6e-6   1.4e-3   2.3e-2   3.1e-1   5.2e-5   (*)
+#   bf16 vs the reference under bf16 autocast, c3  6.2e-7   9.8e-4   2.6e-3   4.6e-2   2.2e-7
+# (*) the b4 shape has too few sub-band rows for the group kernels and computes in fp32 whatever the mode (the ABI's
+# rule: shapes on other kernels are wider than asked for): its bf16 row is the distance between the reference's own
+# fp32 and bf16-autocast steps.  fp16 operands leave the step where fp32 rounding already puts it.
 AMP_TOL = {
-    ("f16", "fsn_train_b4"): (2e-4, 2e-3, 2e-2, 4e-2, 1e-4),
-    ("f16", "fsn_train_c3"): (2e-4, 2e-3, 2e-2, 4e-2, 1e-4),
-    ("bf16", "fsn_train_b4"): (2e-3, 2e-2, 1e-1, 2e-1, 2e-3),
-    ("bf16", "fsn_train_c3"): (2e-3, 2e-2, 1e-1, 2e-1, 2e-3),
-    ("bf16", "fsn_train_b4_bf16"): (2e-3, 2e-2, 1e-1, 2e-1, 2e-3),
-    ("bf16", "fsn_train_c3_bf16"): (2e-3, 2e-2, 1e-1, 2e-1, 2e-3),
+    ("f16", "fsn_train_b4"): (2e-6, 1e-5, 3e-4, 5e-4, 1e-8),
+    ("f16", "fsn_train_c3"): (2e-6, 2e-5, 3e-4, 6e-3, 1e-8),
+    ("bf16", "fsn_train_b4"): (2e-6, 1e-5, 3e-4, 5e-4, 1e-8),
+    ("bf16", "fsn_train_c3"): (1e-5, 5e-3, 6e-3, 2.5e-2, 3e-7),
+    ("bf16", "fsn_train_b4_bf16"): (1e-5, 5e-3, 7e-2, 1.0, 2e-4),
+    ("bf16", "fsn_train_c3_bf16"): (1e-5, 3e-3, 8e-3, 1.5e-1, 7e-7),
 }
 
 
@@ -232,7 +243,8 @@ def test_trainer_use_amp_selects_the_16bit_arithmetic(fsn):
     cfg = {"meta": {"use_amp": True}, "acoustics": {"n_fft": 512, "hop_length": 256, "win_length": 512, "sr": 16000},
            "trainer": {"train": {"epochs": 1, "clip_grad_norm_value": 10}}}
     opt = fsn.ClipAdam(model.parameters(), lr=1e-3)
-    tr = fsn.Trainer(None, 0, cfg, False, False, model, None, opt, loader)
+    from fullsubnet_amd.trainer import Trainer
+    tr = Trainer(None, 0, cfg, False, False, model, None, opt, loader)
     assert tr.use_amp and tr.scaler.is_enabled() and tr._inner().train_arithmetic == "f16"
     tr._set_models_to_train_mode()
     loss = tr._train_epoch(1)
