@@ -107,10 +107,10 @@ SIGNATURES = {
                                           _c.c_int, _f32p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t,
                                           _c.c_void_p]),
     "fsn_lstm_layer_bwd_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),
-    "fsn_lstm2_train_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "fsn_lstm2_train_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "fsn_lstm2_forward_train": (_c.c_int, [_f32p, _c.c_long] + [_f32p] * 8 + [_c.c_int] * 4 + [_f32p, _f32p, _c.c_void_p,
                                            _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_void_p]),
-    "fsn_lstm2_bwd_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "fsn_lstm2_bwd_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "fsn_lstm2_backward": (_c.c_int, [_f32p, _f32p, _c.c_long, _f32p, _f32p, _f32p, _f32p] + [_c.c_int] * 4 +
                            [_f32p, _f32p, _c.c_void_p, _c.c_void_p, _f32p, _c.c_long] + [_f32p] * 6 +
                            [_c.c_void_p, _c.c_size_t, _c.c_int, _c.c_void_p]),

@@ -1637,7 +1637,7 @@ static Lstm2TrainPlan lstm2_train_plan(int T, int N, int I, int H) {
     return p;
 }
 static int lstm2_train_group_clusters(int T, int N, int I, int H) { return lstm2_train_plan(T, N, I, H).fwd_group; }
-extern "C" size_t fsn_lstm2_train_workspace_bytes(int T, int N, int I, int H) {
+extern "C" size_t fsn_lstm2_train_workspace_bytes(int T, int N, int I, int H, int arith) {
     const int Ipad = fsn_round_up(I, 16);
     Carver cv(nullptr);
     if (const int clusters = lstm2_train_group_clusters(T, N, I, H)) {
@@ -1648,6 +1648,7 @@ extern "C" size_t fsn_lstm2_train_workspace_bytes(int T, int N, int I, int H) {
         cv.take<float>((size_t)T * left * Ipad);
         cv.take<float>((size_t)T * left * H);
         cv.take<float>((size_t)T * left * 4 * H);
+        if (arith != FSN_ARITH_F32) cv.take<unsigned short>((size_t)2 * T * N * H);  // 16-bit copies of h0 / h1 (exchange)
         return fsn_round_up_sz(cv.off, 256);
     }
     if (lstm2_train_plan(T, N, I, H).fwd_chain) {
@@ -1674,7 +1675,7 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
     FSN_REQUIRE(x && w_ih0 && w_hh0 && b_ih0 && b_hh0 && w_ih1 && w_hh1 && b_ih1 && b_hh1 && hseq0 && hseq1 && save0 &&
                     save1 && workspace,
                 "NULL pointer argument");
-    if (save_bytes < fsn_lstm_layer_save_bytes(T, N, H) || workspace_bytes < fsn_lstm2_train_workspace_bytes(T, N, I, H)) {
+    if (save_bytes < fsn_lstm_layer_save_bytes(T, N, H) || workspace_bytes < fsn_lstm2_train_workspace_bytes(T, N, I, H, arith)) {
         fsn_set_error("lstm2 forward (training): save / workspace buffer too small");
         return FSN_ERR_WORKSPACE;
     }
@@ -1696,6 +1697,7 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
         float* x_left = cv.take<float>((size_t)T * left * Ipad);
         float* h0_left = cv.take<float>((size_t)T * left * H);
         float* gx_left = cv.take<float>((size_t)T * left * 4 * H);
+        unsigned short* hx16 = arith != FSN_ARITH_F32 ? cv.take<unsigned short>((size_t)2 * T * N * H) : nullptr;
         FSN_TRY(fsn_launch_pack(w_ih0, wih0_p, 4 * H, I, 4 * H, Ipad, s));
         FSN_TRY(fsn_launch_pack(w_hh0, whh0_p, 4 * H, H, 4 * H, H, s));
         FSN_TRY(fsn_launch_pack(w_ih1, wih1_p, 4 * H, H, 4 * H, H, s));
@@ -1715,7 +1717,7 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
         {
             FSN_PERSIST_BEGIN(s);
             FSN_TRY(fsn_launch_lstm2_group_train(x, ldx, 32, N, wih0_p, whh0_p, wih1_p, whh1_p, b0, b1, hseq0, hseq1, sv0, sv1,
-                                                 flags, T, clusters, H, s, arith));
+                                                 flags, T, clusters, H, s, arith, hx16));
             FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_status_word(clusters), hseq1, (size_t)T * N * H, s));
         }
         if (left > 0) {
@@ -2072,7 +2074,7 @@ extern "C" int fsn_lstm_layer_backward(const float* dh, const float* x, long ldx
 // Two fsn_lstm_layer_backward calls in one; the sub-band shape runs its BPTT - both layers, all steps, the
 // layer-to-layer dX included - as ONE persistent launch (lstm_group_bptt_kernels.hip).
 static int lstm2_bptt_group_clusters(int T, int N, int I, int H) { return lstm2_train_plan(T, N, I, H).bptt_group; }
-extern "C" size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H) {
+extern "C" size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H, int arith) {
     const int Ipad = fsn_round_up(I, 16), G = 4 * H;
     const size_t l1 = fsn_lstm_layer_bwd_workspace_bytes(T, N, H, H), l0 = fsn_lstm_layer_bwd_workspace_bytes(T, N, I, H);
     Carver cv(nullptr);
@@ -2088,6 +2090,7 @@ extern "C" size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H) {
         size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
         const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
         cv.take<char>(tn > tn2 ? tn : tn2);
+        if (arith != FSN_ARITH_F32) cv.take<unsigned short>((size_t)2 * T * N * G);  // 16-bit copies of the dgates (exchange)
         return fsn_round_up_sz(cv.off, 256);
     }
     if (lstm2_train_plan(T, N, I, H).bptt_chain) {
@@ -2117,7 +2120,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
                     dw_ih1 && dw_hh1 && db1 && workspace,
                 "NULL pointer argument");
     FSN_REQUIRE(!dx || lddx >= I, "dx row stride %ld < I", lddx);
-    if (workspace_bytes < fsn_lstm2_bwd_workspace_bytes(T, N, I, H)) {
+    if (workspace_bytes < fsn_lstm2_bwd_workspace_bytes(T, N, I, H, arith)) {
         fsn_set_error("lstm2 backward: workspace too small");
         return FSN_ERR_WORKSPACE;
     }
@@ -2203,6 +2206,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
     const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
     void* scratch = cv.take<char>(tn > tn2 ? tn : tn2);
+    unsigned short* dg16 = arith != FSN_ARITH_F32 ? cv.take<unsigned short>((size_t)2 * T * N * G) : nullptr;
     const float* sv0 = static_cast<const float*>(save0);
     const float* sv1 = static_cast<const float*>(save1);
     // "weights" of dh = dgates W are W^T: out = H columns, k = 4H; nn.LSTM stores exactly that transposed
@@ -2221,7 +2225,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     {
         FSN_PERSIST_BEGIN(s);
         FSN_TRY(fsn_launch_lstm2_group_bptt(dh1, whh1T_p, wih1T_p, whh0T_p, sv0, sv1, dg0, dg1, dxbuf, flags, T, N, clusters,
-                                            H, s, arith));
+                                            H, s, arith, dg16));
         // both gate-gradient buffers (dg1 | dg0 are adjacent): every weight gradient and dx derive from them
         FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_bptt_status_word(clusters), dg1, (size_t)2 * T * N * G, s));
     }

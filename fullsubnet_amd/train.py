@@ -90,7 +90,7 @@ class Lstm2Function(torch.autograd.Function):
         hseq1 = torch.empty((T, Np, H), dtype=torch.float32, device=x.device)
         nsave = L.fsn_lstm_layer_save_bytes(T, Np, H)
         save0, save1 = _lib.workspace(nsave, x.device), _lib.workspace(nsave, x.device)
-        ws = _lib.workspace(L.fsn_lstm2_train_workspace_bytes(T, Np, I, H), x.device)
+        ws = _lib.workspace(L.fsn_lstm2_train_workspace_bytes(T, Np, I, H, ctx.arith), x.device)
         _lib.check(L.fsn_lstm2_forward_train(
             _lib.dev_ptr(xp, "x"), Ip, *[_lib.dev_ptr(t) for t in ws_], T, Np, I, H, _lib.dev_ptr(hseq0),
             _lib.dev_ptr(hseq1), save0.data_ptr(), save1.data_ptr(), nsave, ws.data_ptr(), ws.numel(), ctx.arith,
@@ -114,7 +114,7 @@ class Lstm2Function(torch.autograd.Function):
         dw_ih0, dw_hh0, dw_ih1, dw_hh1 = (torch.empty_like(w) for w in (w_ih0, w_hh0, w_ih1, w_hh1))
         db0 = torch.empty((4 * H,), dtype=torch.float32, device=dev)
         db1 = torch.empty((4 * H,), dtype=torch.float32, device=dev)
-        ws = _lib.workspace(L.fsn_lstm2_bwd_workspace_bytes(T, Np, I, H), dev)
+        ws = _lib.workspace(L.fsn_lstm2_bwd_workspace_bytes(T, Np, I, H, ctx.arith), dev)
         _lib.check(L.fsn_lstm2_backward(
             _lib.dev_ptr(dhp, "dh"), _lib.dev_ptr(xp), Ip, _lib.dev_ptr(w_ih0), _lib.dev_ptr(w_hh0), _lib.dev_ptr(w_ih1),
             _lib.dev_ptr(w_hh1), T, Np, I, H, _lib.dev_ptr(hseq0), _lib.dev_ptr(hseq1), save0.data_ptr(), save1.data_ptr(),

@@ -184,7 +184,7 @@ int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_ih, const fl
  * product are rounded to 16 bits at the matrix core's input, accumulation and everything stored stay fp32; shapes
  * that run on other kernels compute in fp32 (wider than asked for).  Same rule for fsn_lstm2_backward, which then
  * expects dh1 scaled by the caller's loss scale (GradScaler) like any autocast backward. */
-size_t fsn_lstm2_train_workspace_bytes(int T, int N, int I, int H);
+size_t fsn_lstm2_train_workspace_bytes(int T, int N, int I, int H, int arith);
 int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_ih0, const float* w_hh0, const float* b_ih0,
                             const float* b_hh0, const float* w_ih1, const float* w_hh1, const float* b_ih1,
                             const float* b_hh1, int T, int N, int I, int H, float* hseq0, float* hseq1, void* save0,
@@ -231,7 +231,7 @@ int fsn_lstm_layer_backward(const float* dh, const float* x, long ldx, const flo
  * outputs as two fsn_lstm_layer_backward calls would give them (dx may be NULL).  The sub-band shape (H = 384, 96+
  * row tiles) runs its back-propagation through time - both layers, all steps, the layer-to-layer dX - as ONE
  * persistent launch (lstm2_group_bptt_kernel) followed by the weight-gradient GEMMs. */
-size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H);
+size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H, int arith);
 int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, const float* w_ih0, const float* w_hh0,
                        const float* w_ih1, const float* w_hh1, int T, int N, int I, int H, const float* hseq0,
                        const float* hseq1, const void* save0, const void* save1, float* dx, long lddx, float* dw_ih0,

@@ -74,8 +74,8 @@ def test_two_layer_training_entries_size_queries_without_a_gpu():
     from fullsubnet_amd import _lib
     L = _lib.lib()
     for T, N, I, H in [(193, 2064, 32, 384), (193, 16, 257, 512), (10, 48, 64, 512), (5, 4128, 32, 384)]:
-        fwd = L.fsn_lstm2_train_workspace_bytes(T, N, I, H)
-        bwd = L.fsn_lstm2_bwd_workspace_bytes(T, N, I, H)
+        fwd = L.fsn_lstm2_train_workspace_bytes(T, N, I, H, 0)
+        bwd = L.fsn_lstm2_bwd_workspace_bytes(T, N, I, H, 0)
         assert fwd > 0 and bwd >= T * N * 4 * H * 4  # one layer's gate gradients at least (layer by layer)
         assert L.fsn_lstm2_fwd_workspace_bytes(T, N, I, H, H) >= L.fsn_lstm_layer_fwd_workspace_bytes(T, N, I, H) // 2
     assert L.fsn_lstm2_forward_is_persistent(100, 2048, 16, 16, 384, 384) in (0, 1)
