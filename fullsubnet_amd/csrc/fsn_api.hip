@@ -1648,7 +1648,6 @@ extern "C" size_t fsn_lstm2_train_workspace_bytes(int T, int N, int I, int H, in
         cv.take<float>((size_t)T * left * Ipad);
         cv.take<float>((size_t)T * left * H);
         cv.take<float>((size_t)T * left * 4 * H);
-        if (arith != FSN_ARITH_F32) cv.take<unsigned short>((size_t)2 * T * N * H);  // 16-bit copies of h0 / h1 (exchange)
         return fsn_round_up_sz(cv.off, 256);
     }
     if (lstm2_train_plan(T, N, I, H).fwd_chain) {
@@ -1697,7 +1696,6 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
         float* x_left = cv.take<float>((size_t)T * left * Ipad);
         float* h0_left = cv.take<float>((size_t)T * left * H);
         float* gx_left = cv.take<float>((size_t)T * left * 4 * H);
-        unsigned short* hx16 = arith != FSN_ARITH_F32 ? cv.take<unsigned short>((size_t)2 * T * N * H) : nullptr;
         FSN_TRY(fsn_launch_pack(w_ih0, wih0_p, 4 * H, I, 4 * H, Ipad, s));
         FSN_TRY(fsn_launch_pack(w_hh0, whh0_p, 4 * H, H, 4 * H, H, s));
         FSN_TRY(fsn_launch_pack(w_ih1, wih1_p, 4 * H, H, 4 * H, H, s));
@@ -1717,7 +1715,7 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
         {
             FSN_PERSIST_BEGIN(s);
             FSN_TRY(fsn_launch_lstm2_group_train(x, ldx, 32, N, wih0_p, whh0_p, wih1_p, whh1_p, b0, b1, hseq0, hseq1, sv0, sv1,
-                                                 flags, T, clusters, H, s, arith, hx16));
+                                                 flags, T, clusters, H, s, arith));
             FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_status_word(clusters), hseq1, (size_t)T * N * H, s));
         }
         if (left > 0) {
@@ -2090,7 +2088,6 @@ extern "C" size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H, int 
         size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
         const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
         cv.take<char>(tn > tn2 ? tn : tn2);
-        if (arith != FSN_ARITH_F32) cv.take<unsigned short>((size_t)2 * T * N * G);  // 16-bit copies of the dgates (exchange)
         return fsn_round_up_sz(cv.off, 256);
     }
     if (lstm2_train_plan(T, N, I, H).bptt_chain) {
@@ -2206,7 +2203,6 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
     const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
     void* scratch = cv.take<char>(tn > tn2 ? tn : tn2);
-    unsigned short* dg16 = arith != FSN_ARITH_F32 ? cv.take<unsigned short>((size_t)2 * T * N * G) : nullptr;
     const float* sv0 = static_cast<const float*>(save0);
     const float* sv1 = static_cast<const float*>(save1);
     // "weights" of dh = dgates W are W^T: out = H columns, k = 4H; nn.LSTM stores exactly that transposed
@@ -2225,7 +2221,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     {
         FSN_PERSIST_BEGIN(s);
         FSN_TRY(fsn_launch_lstm2_group_bptt(dh1, whh1T_p, wih1T_p, whh0T_p, sv0, sv1, dg0, dg1, dxbuf, flags, T, N, clusters,
-                                            H, s, arith, dg16));
+                                            H, s, arith));
         // both gate-gradient buffers (dg1 | dg0 are adjacent): every weight gradient and dx derive from them
         FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_bptt_status_word(clusters), dg1, (size_t)2 * T * N * G, s));
     }

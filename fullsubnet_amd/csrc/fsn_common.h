@@ -59,7 +59,6 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 typedef _Float16 fsn_f16x4 __attribute__((ext_vector_type(4)));
 typedef short fsn_s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned fsn_u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned fsn_u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 fsn_bf16x2 __attribute__((ext_vector_type(2)));
 template <int AR>
 struct FsnOperand {
@@ -101,44 +100,6 @@ __device__ __forceinline__ f32x4 fsn_mma_k16(const typename FsnOperand<AR>::type
         for (int j = 0; j < 4; ++j) c = mfma16(a[j], b[j], c);
         return c;
     }
-}
-
-// 4 x 4 transpose inside a lane quad (lanes 4 k .. 4 k + 3): lane r holds v[i] = X[i][r] and gets X[r][0 .. 3].  An
-// accumulator fragment (lane = column, register = row 4 q + i) becomes four consecutive columns of ONE row per lane: a
-// 16-byte (fp32) or 8-byte (16-bit) group of a row-major buffer instead of four scattered scalars.  Two rounds of
-// pair exchanges: 4 DPP moves + selects.
-__device__ __forceinline__ f32x4 fsn_quad_transpose(const float (&v)[4]) {
-    const int r = threadIdx.x & 3;
-    const bool odd = (r & 1) != 0, hi = (r & 2) != 0;
-    auto swap1 = [](float x) {  // from lane r ^ 1: quad_perm [1, 0, 3, 2]
-        return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));
-    };
-    auto swap2 = [](float x) {  // from lane r ^ 2: quad_perm [2, 3, 0, 1]
-        return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));
-    };
-    // round 1: rows pair up as (0, 1) and (2, 3); an even lane keeps the even row and gets its neighbour's element of it
-    const float g0 = swap1(odd ? v[0] : v[1]), g1 = swap1(odd ? v[2] : v[3]);
-    const float k0 = odd ? v[1] : v[0], k1 = odd ? v[3] : v[2];
-    const float w00 = odd ? g0 : k0, w01 = odd ? k0 : g0;  // row (r & 1), columns (r & ~1, r | 1)
-    const float w10 = odd ? g1 : k1, w11 = odd ? k1 : g1;  // row 2 + (r & 1), same columns
-    // round 2: lanes 0, 1 keep rows 0, 1 and lanes 2, 3 rows 2, 3; the other pair goes to lane r ^ 2
-    const float ga = swap2(hi ? w00 : w10), gb = swap2(hi ? w01 : w11);
-    const float ka = hi ? w10 : w00, kb = hi ? w11 : w01;
-    return hi ? f32x4{ga, gb, ka, kb} : f32x4{ka, kb, ga, gb};
-}
-// four fp32 values -> four 16-bit values (8 bytes) in the operand type of arithmetic AR, as two dwords
-// (the FSN_ARITH_F32 forms exist so that code shared between the arithmetics compiles; they are never executed)
-template <int AR>
-__device__ __forceinline__ fsn_u32x2 fsn_pack16(const f32x4 v) {
-    if constexpr (AR == FSN_ARITH_F32) return fsn_u32x2{0u, 0u};
-    else return __builtin_bit_cast(fsn_u32x2, fsn_operand<AR>(v));
-}
-// the lane's four consecutive 16-bit k of an exchange tile (8 bytes, write-through data of another CU: sc1 load)
-template <int AR>
-__device__ __forceinline__ typename FsnOperand<AR>::type fsn_load_operand16(const __amdgpu_buffer_rsrc_t r, unsigned voff,
-                                                                           unsigned soff) {
-    if constexpr (AR == FSN_ARITH_F32) return f32x4{0.f, 0.f, 0.f, 0.f};
-    else return __builtin_bit_cast(typename FsnOperand<AR>::type, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 16));
 }
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -247,8 +208,7 @@ size_t fsn_lstm2_group_bptt_flag_words(int clusters);  // lstm_group_bptt_kernel
 int fsn_lstm2_group_bptt_clusters(int tiles);
 int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const float* wih1T_p, const float* whh0T_p,
                                 const float* save0, const float* save1, float* dg0, float* dg1, float* dx, unsigned* flags,
-                                int Tp, int Nrows, int clusters, int H, hipStream_t s, int arith = FSN_ARITH_F32,
-                                unsigned short* dg16 = nullptr);  // dg16: 2 Tp Nrows 4H halves
+                                int Tp, int Nrows, int clusters, int H, hipStream_t s, int arith = FSN_ARITH_F32);
 // fb_chain_bptt_kernels.hip: BPTT of the full-band model's two layers (16 rows, H = 512) as one persistent launch
 bool fsn_fb_chain_bptt_supported(int H, int N);
 int fsn_fb_chain_bptt_max_steps();
@@ -298,8 +258,7 @@ size_t fsn_lstm2_group_bptt_status_word(int clusters);
 int fsn_launch_lstm2_group_train(const float* x, long x_ld, int x_cols, int Nrows, const float* wih0_p, const float* whh0_p,
                                  const float* wih1_p, const float* whh1_p, const float* bias0, const float* bias1,
                                  float* hseq0, float* hseq1, float* save0, float* save1, unsigned* flags, int Tp,
-                                 int clusters, int H, hipStream_t s, int arith = FSN_ARITH_F32,
-                                 unsigned short* hx16 = nullptr);  // lstm_group_kernels.hip; hx16: 2 Tp Nrows H halves
+                                 int clusters, int H, hipStream_t s, int arith = FSN_ARITH_F32);  // lstm_group_kernels.hip
 
 // fb_chain_kernels.hip: the full-band model's two LSTM layers over all frames as one persistent launch
 bool fsn_fb_chain_supported(int H, int Npad);

@@ -51,10 +51,6 @@ struct BpttArgs {
     const float *gates0, *cseq0, *gates1, *cseq1;  // saved by the forward pass: [Tp][N][4H], [Tp][N][H]
     float *dg0, *dg1;     // [Tp][N][4H]: gate gradients (outputs and exchange buffers)
     float* dx;            // [Tp][N][H]: dgates1_t W_ih1 = layer 0's dH, produced by layer 1 (see below)
-    // 16-bit arithmetic: the members exchange the gate gradients through 16-bit copies [Tp][N][4H] (the operand the
-    // matrix instruction takes anyway, rounded once where it is produced: half of what every member reads per step);
-    // dg0 / dg1 (fp32: the weight-gradient GEMMs' operand) are then plain outputs
-    unsigned short *dg16_0, *dg16_1;
     unsigned* flags;      // [clusters][2][BFS]: steps published by (layer 1 | layer 0, member)
     unsigned* status;
     unsigned long long spin_ticks;  // wait bound (fsn_spin_ticks)
@@ -179,84 +175,18 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
                 const f32x4 av = ar[d];
                 ar[d] = fetch_a(s * BCH + c + AD);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (AR == FSN_ARITH_F32) {
 #pragma unroll
-                for (int u = 0; u < NT; ++u) {
-                    const f32x4 bf = bsh[buf][c * NT + u][lane];
+                    for (int u = 0; u < NT; ++u) {
+                        const f32x4 bf = bsh[buf][c * NT + u][lane];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[u] = mfma16(av[j], bf[j], acc[u]);
+                        for (int j = 0; j < 4; ++j) acc[u] = mfma16(av[j], bf[j], acc[u]);
+                    }
+                } else {  // 16-bit operands: one matrix instruction per tile and K chunk
+                    const typename FsnOperand<AR>::type ao = fsn_operand<AR>(av);
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) acc[u] = fsn_mma_k16<AR>(ao, fsn_operand<AR>(bsh[buf][c * NT + u][lane]), acc[u]);
                 }
-                if (c == BCH - 1) {
-                    park_b(buf ^ 1, QMAX - 1);
-                    __syncthreads();
-                }
-            }
-        }
-    };
-
-    // The same loop for 16-bit operands: the A fragment of a chunk is the lane's four consecutive gate columns as 8 bytes
-    // of a 16-bit exchange tile (resource xr16) - the matrix instruction's operand as it stands; one
-    // v_mfma_f32_16x16x16 per tile and chunk; the W^T fragments stay fp32 in L2 / LDS and are rounded where they are used.
-    constexpr bool X16 = AR != FSN_ARITH_F32;
-    using Op = typename FsnOperand<AR>::type;
-    const unsigned a_off16 = (unsigned)(((wave * 16 + lr) * BG + 4 * lq) * 2);
-    auto tile16 = [&](unsigned short* dg, int t) {
-        return __builtin_amdgcn_make_buffer_rsrc(dg + ((size_t)t * N + (size_t)cluster * BROWS) * BG, 0, BROWS * BG * 2, 0x00020000);
-    };
-    auto kloop16 = [&](auto& acc, const __amdgpu_buffer_rsrc_t xr, unsigned b, unsigned b2, int n, auto&& mid) {
-        constexpr int NT = (int)(sizeof(acc) / sizeof(f32x4));
-        constexpr int TURN = FSN_BPTT_TURN;
-        constexpr int AD = TURN * BCH;
-        constexpr int NB = BU;
-        Op ar[AD];
-        f32x4 bn[NB];
-        auto fetch_a = [&](int k) -> Op {
-            const int kc = k < n ? k : n - 1;
-            return fsn_load_operand16<AR>(xr, a_off16, (unsigned)kc * 32u);
-        };
-        constexpr int NBATCH = BCH * NT / NB, QMAX = (NBATCH + 3) / 4, QSTEP = BCH / QMAX;
-        auto fetch_b = [&](int s, int q) {
-            const int id = wave + 4 * q;
-            if (id < NBATCH) {
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const int f = id * NB + j, c = f / NT, u = f % NT;
-                    int k = s * BCH + c;
-                    k = k < n ? k : n - 1;
-                    const unsigned ofs = (u < BU ? b : b2) + ((unsigned)(member * BU + u % BU) * BKC + (unsigned)k) * 256u;
-                    bn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, ofs * 4u, 0));
-                }
-            }
-        };
-        auto park_b = [&](int buf, int q) {
-            const int id = wave + 4 * q;
-            if (id < NBATCH) {
-#pragma unroll
-                for (int j = 0; j < NB; ++j) bsh[buf][id * NB + j][lane] = bn[j];
-            }
-        };
-#pragma unroll
-        for (int d = 0; d < AD; ++d) ar[d] = fetch_a(d);
-#pragma unroll
-        for (int q = 0; q < QMAX; ++q) {
-            fetch_b(0, q);
-            park_b(0, q);
-        }
-        __syncthreads();
-        for (int s0 = 0; s0 < n / BCH; s0 += TURN) {
-            if (s0 == 2 * TURN) mid();
-#pragma unroll
-            for (int d = 0; d < AD; ++d) {
-                const int ds = d / BCH, c = d % BCH, s = s0 + ds, buf = s & 1;
-                if (c % QSTEP == 0 && c / QSTEP < QMAX) {
-                    if (c > 0) park_b(buf ^ 1, c / QSTEP - 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    fetch_b(s + 1, c / QSTEP);
-                }
-                const Op ao = ar[d];
-                ar[d] = fetch_a(s * BCH + c + AD);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < NT; ++u) acc[u] = fsn_mma_k16<AR>(ao, fsn_operand<AR>(bsh[buf][c * NT + u][lane]), acc[u]);
                 if (c == BCH - 1) {
                     park_b(buf ^ 1, QMAX - 1);
                     __syncthreads();
@@ -335,8 +265,7 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
 #pragma unroll
                 for (int u = 0; u < 2 * BU; ++u) acc6[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 wait_peeked(peek(fl1), fl1, done);  // dgates1_{t+1} of all members (just published: polls)
-                if constexpr (X16) kloop16(acc6, tile16(a.dg16_1, t + 1), a.o_whh1T, a.o_wih1T, BKC, load_saved);
-                else kloop(acc6, tile(a.dg1, t + 1), a.o_whh1T, a.o_wih1T, BKC, load_saved);
+                kloop(acc6, tile(a.dg1, t + 1), a.o_whh1T, a.o_wih1T, BKC, load_saved);
                 const __amdgpu_buffer_rsrc_t rx = tileh(a.dx, t + 1);
 #pragma unroll
                 for (int u = 0; u < BU; ++u) {
@@ -362,52 +291,14 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
             }
             if (t < Tp - 1) {
                 wait_peeked(peek(fl0), fl0, done);  // dgates0_{t+1} of all members
-                if constexpr (X16) kloop16(acc, tile16(a.dg16_0, t + 1), a.o_whh0T, 0u, BKC, load_saved);
-                else kloop(acc, tile(a.dg0, t + 1), a.o_whh0T, 0u, BKC, load_saved);
+                kloop(acc, tile(a.dg0, t + 1), a.o_whh0T, 0u, BKC, load_saved);
             } else {
                 load_saved();
             }
             seen1 = peek(fl1);  // for the next step: layer 1 is ahead
         }
         // cell derivative of this wave's 16 rows x 48 units -> dgates_t (write-through: the partners' next A operand)
-        if constexpr (X16) {
-          if (t >= 0) {
-            // 16-bit exchange: every gate gradient is transposed inside its lane quad, so that a lane holds four
-            // consecutive units of ONE row: the 16-bit copy (the partners' next A operand) leaves as write-through 8-byte
-            // stores, the fp32 gate gradients (operand of the weight-gradient GEMMs) as plain 16-byte stores
-            const __amdgpu_buffer_rsrc_t ro = tile(dgout, t), ro16 = tile16(LAYER ? a.dg16_1 : a.dg16_0, t);
-            const int row = wave * 16 + 4 * lq + (lr & 3);
-#pragma unroll
-            for (int u = 0; u < BU; ++u) {
-                float di[4], df[4], dgg[4], dO[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float ig = e_g[u][i][0], fg = e_g[u][i][1], gg = e_g[u][i][2], og = e_g[u][i][3];
-                    const float dh = e_dh[u][i] + acc[u][i];
-                    const float tc = tanhf(e_ct[u][i]);
-                    const float d_o = dh * tc;
-                    const float dct = dc[u][i] + dh * og * (1.f - tc * tc);
-                    di[i] = dct * gg * ig * (1.f - ig);
-                    df[i] = dct * e_cp[u][i] * fg * (1.f - fg);
-                    dgg[i] = dct * ig * (1.f - gg * gg);
-                    dO[i] = d_o * og * (1.f - og);
-                    dc[u][i] = dct * fg;
-                }
-                const int col = (member * BU + u) * 16 + 4 * (lr >> 2);
-                const f32x4 t0 = fsn_quad_transpose(di), t1 = fsn_quad_transpose(df), t2 = fsn_quad_transpose(dgg),
-                            t3 = fsn_quad_transpose(dO);
-                const unsigned v16 = (unsigned)((row * BG + col) * 2), v32 = (unsigned)((row * BG + col) * 4);
-                __builtin_amdgcn_raw_buffer_store_b64(fsn_pack16<AR>(t0), ro16, v16, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b64(fsn_pack16<AR>(t1), ro16, v16, BH * 2, 16);
-                __builtin_amdgcn_raw_buffer_store_b64(fsn_pack16<AR>(t2), ro16, v16, 2 * BH * 2, 16);
-                __builtin_amdgcn_raw_buffer_store_b64(fsn_pack16<AR>(t3), ro16, v16, 3 * BH * 2, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fsn_u32x4, t0), ro, v32, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fsn_u32x4, t1), ro, v32, BH * 4, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fsn_u32x4, t2), ro, v32, 2 * BH * 4, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fsn_u32x4, t3), ro, v32, 3 * BH * 4, 0);
-            }
-          }
-        } else if (t >= 0) {
+        if (t >= 0) {
             const __amdgpu_buffer_rsrc_t ro = tile(dgout, t);
 #pragma unroll
             for (int u = 0; u < BU; ++u)
@@ -479,7 +370,7 @@ size_t fsn_lstm2_group_bptt_status_word(int clusters) { return (size_t)clusters 
 // fsn_lstm_layer_forward's layout; dg0 / dg1 [Tp][Nrows][4H] out; dx [Tp][Nrows][H] scratch (layer 0's dH).
 int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const float* wih1T_p, const float* whh0T_p,
                                 const float* save0, const float* save1, float* dg0, float* dg1, float* dx, unsigned* flags,
-                                int Tp, int Nrows, int clusters, int H, hipStream_t s, int arith, unsigned short* dg16) {
+                                int Tp, int Nrows, int clusters, int H, hipStream_t s, int arith) {
     if (H != BH || clusters < 1 || clusters > fsn_lstm2_group_bptt_clusters(Nrows / 16)) {
         fsn_set_error("lstm2_group_bptt: H = 384, clusters * 64 <= rows, one cluster per eight CUs at most");
         return FSN_ERR_ARG;
@@ -510,12 +401,6 @@ int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const fl
     a.spin_ticks = fsn_spin_ticks();
     a.Tp = Tp;
     a.Nrows = Nrows;
-    a.dg16_1 = dg16;  // [Tp][Nrows][4H] 16-bit copies of dgates1 / dgates0 (16-bit arithmetic only)
-    a.dg16_0 = dg16 ? dg16 + (size_t)Tp * Nrows * BG : nullptr;
-    if (arith != FSN_ARITH_F32 && !dg16) {
-        fsn_set_error("lstm2_group_bptt: 16-bit arithmetic needs the 16-bit exchange buffers");
-        return FSN_ERR_ARG;
-    }
     const dim3 grid((unsigned)clusters * BM * 2), block(256);
     if (arith == FSN_ARITH_F16) hipLaunchKernelGGL((lstm2_group_bptt_kernel<0, FSN_ARITH_F16>), grid, block, 0, s, a);
     else if (arith == FSN_ARITH_BF16) hipLaunchKernelGGL((lstm2_group_bptt_kernel<0, FSN_ARITH_BF16>), grid, block, 0, s, a);

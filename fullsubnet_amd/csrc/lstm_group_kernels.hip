@@ -62,10 +62,6 @@ struct GrpArgs {
     // a cluster's tile of step t at rows 64 c .. of step t (nothing is reused) - and every step keeps the activated
     // gates [Tp][Nrows][4H] and the cell state [Tp][Nrows][H] (the layouts of fsn_lstm_layer_forward)
     float *gates0, *cseq0, *gates1, *cseq1;
-    // 16-bit arithmetic (AR != FSN_ARITH_F32, training form): the members exchange h through 16-bit copies
-    // [Tp][Nrows][H] - the operand the matrix instruction takes anyway, rounded once where it is produced - which halves
-    // what every member reads per step; hx0 / hx1 (the fp32 hidden sequences) are then plain outputs
-    unsigned short *hx16_0, *hx16_1;
     int Nrows;
     int nclusters;         // clusters of this launch (the grid has min(nclusters, CUs / 8) workgroup sets)
 };
@@ -119,11 +115,8 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
     const int lr = lane & 15, lq = lane >> 4;
     const int Tp = a.Tp;
     const FsnSbInput& x = a.xin;
-    constexpr bool X16 = AR != FSN_ARITH_F32;  // 16-bit exchange buffers (training form only)
-    static_assert(!X16 || (TRAIN && SAVE && NCL >= 1), "16-bit operands: training form");
-    using Op = typename FsnOperand<AR>::type;
-    // byte offset of the tile that holds h0_t / h1_t inside the exchange buffers (hx0 / hx1, or their 16-bit copies)
-    const unsigned step_bytes = TRAIN ? (unsigned)a.Nrows * GH * (X16 ? 2u : 4u) : 0u;
+    // byte offset of the tile that holds h0_t / h1_t inside hx0 / hx1
+    const unsigned step_bytes = TRAIN ? (unsigned)a.Nrows * GH * 4u : 0u;
     auto slot0 = [&](int t) { return TRAIN ? (unsigned)t * step_bytes : (unsigned)((t % GD0) * GROWS * GH * 4); };
     auto slot1 = [&](int t) { return TRAIN ? (unsigned)t * step_bytes : (unsigned)((t & 1) * GROWS * GH * 4); };
     auto init = [&](GrpCl& k, int cluster) {
@@ -133,13 +126,8 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
         k.hx1 = a.hx1 + (TRAIN ? (size_t)cluster * GROWS * GH : (size_t)cluster * 2 * GROWS * GH);
         k.fl0 = a.flags + ((size_t)cluster * 2 + 0) * GFS;
         k.fl1 = a.flags + ((size_t)cluster * 2 + 1) * GFS;
-        if (X16) {
-            k.xrsrc0 = __builtin_amdgcn_make_buffer_rsrc(a.hx16_0 + (size_t)cluster * GROWS * GH, 0, 0x7fffffff, 0x00020000);
-            k.xrsrc1 = __builtin_amdgcn_make_buffer_rsrc(a.hx16_1 + (size_t)cluster * GROWS * GH, 0, 0x7fffffff, 0x00020000);
-        } else {
-            k.xrsrc0 = __builtin_amdgcn_make_buffer_rsrc(k.hx0, 0, 0x7fffffff, 0x00020000);
-            k.xrsrc1 = __builtin_amdgcn_make_buffer_rsrc(k.hx1, 0, 0x7fffffff, 0x00020000);
-        }
+        k.xrsrc0 = __builtin_amdgcn_make_buffer_rsrc(k.hx0, 0, 0x7fffffff, 0x00020000);
+        k.xrsrc1 = __builtin_amdgcn_make_buffer_rsrc(k.hx1, 0, 0x7fffffff, 0x00020000);
         k.row_ok = k.row_l < x.N;
         k.ng = k.row_l + x.row0;
         k.xb = k.row_ok ? (int)(k.ng / x.F) : 0;
@@ -152,7 +140,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
     };
     // this lane's A fragment inside a [64][H] tile of the exchange buffers (byte offset), read with sc1 buffer loads: the
     // partners stored write-through (sc1), so an sc1 load - never served by this CU's L1 - needs no acquire fence
-    const unsigned a_off = (unsigned)(((wave * 16 + lr) * GH + 4 * lq) * (X16 ? 2 : 4));
+    const unsigned a_off = (unsigned)(((wave * 16 + lr) * GH + 4 * lq) * 4);
     auto xload = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16));  // aux 16 = sc1
     };
@@ -237,118 +225,30 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
                     const f32x4 av = ar[d];
                     ar[d] = fetch_a(k + AD);
                     __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (AR == FSN_ARITH_F32) {
 #pragma unroll
-                    for (int u = 0; u < GU; ++u) {
-                        f32x4 b[4];
+                        for (int u = 0; u < GU; ++u) {
+                            f32x4 b[4];
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) b[g] = bsh[buf][c * GU * 4 + u * 4 + g][lane];
+                            for (int g = 0; g < 4; ++g) b[g] = bsh[buf][c * GU * 4 + u * 4 + g][lane];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) acc[u][g] = mfma16(av[j], b[g][j], acc[u][g]);
+                                for (int g = 0; g < 4; ++g) acc[u][g] = mfma16(av[j], b[g][j], acc[u][g]);
+                        }
+                    } else {  // 16-bit operands: one matrix instruction per tile and K chunk
+                        const typename FsnOperand<AR>::type ao = fsn_operand<AR>(av);
+#pragma unroll
+                        for (int u = 0; u < GU; ++u)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+                                acc[u][g] = fsn_mma_k16<AR>(ao, fsn_operand<AR>(bsh[buf][c * GU * 4 + u * 4 + g][lane]), acc[u][g]);
                     }
 #pragma unroll
                     for (int j = 0; j < GU; ++j) bsh[buf ^ 1][c * GU * 4 + wave * GU + j][lane] = bn[j];
                     if (c == CPS - 1) __syncthreads();
                 }
             }
-        }
-    };
-
-    // The same loop for 16-bit operands: the A fragment of a chunk is the lane's four consecutive k as 8 bytes of a
-    // 16-bit exchange tile - the matrix instruction's operand as it stands, no conversion - or the layer-0 input from
-    // registers (converted); one v_mfma_f32_16x16x16 per tile and chunk; the weight fragments stay fp32 in L2 / LDS and
-    // are rounded where they are used.
-    auto kloop16 = [&](f32x4 (&acc)[GU][4], const f32x4* xa, const __amdgpu_buffer_rsrc_t r1, unsigned at1, unsigned b1,
-                       unsigned s1, int n1, const __amdgpu_buffer_rsrc_t r2, unsigned at2, unsigned b2, unsigned s2, int n2) {
-        const int n = n1 + n2;
-        constexpr int AD = FSN_GRP_AD;
-        Op ar[AD];
-        f32x4 bn[GU];
-        auto fetch_a = [&](int k) -> Op {
-            const int kc = k < n ? k : n - 1;
-            if (kc < n1) {
-                if (xa) return fsn_operand<AR>(kc == 0 ? xa[0] : xa[1]);
-                return fsn_load_operand16<AR>(r1, a_off, at1 + (unsigned)kc * 32u);
-            }
-            return fsn_load_operand16<AR>(r2, a_off, at2 + (unsigned)(kc - n1) * 32u);
-        };
-        auto fetch_b = [&](int k) {
-            const int kc = k < n ? k : n - 1;
-            const bool first = kc < n1;
-            const int kk = first ? kc : kc - n1;
-            const unsigned bb = first ? b1 : b2, cs = first ? s1 : s2;
-#pragma unroll
-            for (int j = 0; j < GU; ++j) {
-                const int f = wave * GU + j, u = f >> 2, g = f & 3;
-                const unsigned ofs = bb + ((unsigned)(g * GKC + member * GU + u) * cs + (unsigned)kk) * 256u;
-                bn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, ofs * 4u, 0));
-            }
-        };
-#pragma unroll
-        for (int d = 0; d < AD; ++d) ar[d] = fetch_a(d);
-        constexpr int CPS = FSN_GRP_CPS;
-#pragma unroll
-        for (int c = 0; c < CPS; ++c) {
-            fetch_b(c);
-#pragma unroll
-            for (int j = 0; j < GU; ++j) bsh[0][c * GU * 4 + wave * GU + j][lane] = bn[j];
-        }
-        __syncthreads();
-        for (int k0 = 0; k0 < n; k0 += AD) {
-#pragma unroll
-            for (int d = 0; d < AD; ++d) {
-                const int k = k0 + d;
-                if (k < n) {  // uniform (n is a multiple of CPS)
-                    const int c = d % CPS, buf = (k / CPS) & 1;
-                    __builtin_amdgcn_sched_barrier(0);
-                    fetch_b(k + CPS);
-                    const Op ao = ar[d];
-                    ar[d] = fetch_a(k + AD);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < GU; ++u)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            acc[u][g] = fsn_mma_k16<AR>(ao, fsn_operand<AR>(bsh[buf][c * GU * 4 + u * 4 + g][lane]), acc[u][g]);
-#pragma unroll
-                    for (int j = 0; j < GU; ++j) bsh[buf ^ 1][c * GU * 4 + wave * GU + j][lane] = bn[j];
-                    if (c == CPS - 1) __syncthreads();
-                }
-            }
-        }
-    };
-    // Cell update with 16-bit exchange: every value is transposed inside its lane quad first, so that a lane holds four
-    // consecutive units of ONE row - the 16-bit copy of h_t (the partners' next A operand) leaves as one write-through
-    // 8-byte store per unit group, the fp32 outputs (h_t, activated gates, c_t) as 16-byte stores instead of scalars.
-    auto cell16 = [&](GrpCl& k, f32x4 (&acc)[GU][4], const __amdgpu_buffer_rsrc_t xr, unsigned slot, float* hdst,
-                      float* gates_t, float* cseq_t) {
-        const int row = wave * 16 + 4 * lq + (lr & 3);  // the row (inside the cluster's tile) this lane stores
-#pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            float iq[4], fq[4], gq[4], oq[4], cq[4], hq[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                iq[i] = sigmoid_fast(acc[u][0][i]);
-                fq[i] = sigmoid_fast(acc[u][1][i]);
-                gq[i] = tanh_fast(acc[u][2][i]);
-                oq[i] = sigmoid_fast(acc[u][3][i]);
-                const float cn = fq[i] * k.c[u][i] + iq[i] * gq[i];
-                k.c[u][i] = cn;
-                cq[i] = cn;
-                hq[i] = oq[i] * tanh_fast(cn);
-            }
-            const int col = (member * GU + u) * 16 + 4 * (lr >> 2);  // the first of its four units
-            const f32x4 ht = fsn_quad_transpose(hq);
-            __builtin_amdgcn_raw_buffer_store_b64(fsn_pack16<AR>(ht), xr, (unsigned)((row * GH + col) * 2), slot, 16);  // sc1
-            *reinterpret_cast<f32x4*>(hdst + (size_t)row * GH + col) = ht;
-            const size_t grow = (size_t)k.cluster * GROWS + row;
-            float* gp = gates_t + grow * (4 * GH) + col;
-            *reinterpret_cast<f32x4*>(gp) = fsn_quad_transpose(iq);
-            *reinterpret_cast<f32x4*>(gp + GH) = fsn_quad_transpose(fq);
-            *reinterpret_cast<f32x4*>(gp + 2 * GH) = fsn_quad_transpose(gq);
-            *reinterpret_cast<f32x4*>(gp + 3 * GH) = fsn_quad_transpose(oq);
-            *reinterpret_cast<f32x4*>(cseq_t + grow * GH + col) = fsn_quad_transpose(cq);
         }
     };
 
@@ -444,19 +344,12 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
                     acc[u][g] = f32x4{b, b, b, b};
                 }
             const unsigned ring = t >= GD0 ? peek(k.fl1) : 0xffffffffu;
-            if constexpr (X16)
-                kloop16(acc, xa, k.xrsrc0, 0, a.o_wih0, 2, 2, k.xrsrc0, t > 0 ? slot0(t - 1) : 0u, a.o_whh0, GKC, t > 0 ? GKC : 0);
-            else
-                kloop(acc, xa, k.xrsrc0, 0, a.o_wih0, 2, 2, k.xrsrc0, t > 0 ? slot0(t - 1) : 0u, a.o_whh0, GKC, t > 0 ? GKC : 0);
+            kloop(acc, xa, k.xrsrc0, 0, a.o_wih0, 2, 2, k.xrsrc0, t > 0 ? slot0(t - 1) : 0u, a.o_whh0, GKC, t > 0 ? GKC : 0);
             // slot t % GD0 still holds h0_{t-GD0}: layer 1 must have finished its step t - GD0 (it reads that slot
             // there) - all eight layer-1 members, i.e. they have published step t - GD0 + 1
             if (t >= GD0) wait_peeked(ring, k.fl1, (unsigned)(t - GD0 + 1));
-            if constexpr (X16)
-                cell16(k, acc, k.xrsrc0, slot0(t), k.hx0 + (size_t)t * a.Nrows * GH, a.gates0 + (size_t)t * a.Nrows * 4 * GH,
-                       a.cseq0 + (size_t)t * a.Nrows * GH);
-            else
-                cell(k, acc, reinterpret_cast<float*>(reinterpret_cast<char*>(k.hx0) + slot0(t)),
-                     TRAIN ? a.gates0 + (size_t)t * a.Nrows * 4 * GH : nullptr, TRAIN ? a.cseq0 + (size_t)t * a.Nrows * GH : nullptr);
+            cell(k, acc, reinterpret_cast<float*>(reinterpret_cast<char*>(k.hx0) + slot0(t)),
+                 TRAIN ? a.gates0 + (size_t)t * a.Nrows * 4 * GH : nullptr, TRAIN ? a.cseq0 + (size_t)t * a.Nrows * GH : nullptr);
             publish(k.fl0 + member, (unsigned)t + 1);
         };
         GrpCl ka, kb;
@@ -487,8 +380,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
                         const float b = kBiasLds ? bias_sh[u * 4 + g][lr] : bias[u][g];
                         acc[u][g] = f32x4{b, b, b, b};
                     }
-                if constexpr (X16) kloop16(acc, nullptr, k.xrsrc0, slot0(s), a.o_wih1, GKC, GKC, k.xrsrc0, 0, 0, 0, 0);
-                else kloop(acc, nullptr, k.xrsrc0, slot0(s), a.o_wih1, GKC, GKC, k.xrsrc0, 0, 0, 0, 0);
+                kloop(acc, nullptr, k.xrsrc0, slot0(s), a.o_wih1, GKC, GKC, k.xrsrc0, 0, 0, 0, 0);
             } else {
                 seen1 = peek(k.fl1);
             }
@@ -525,18 +417,12 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
                 }
             }
             k.seen0 = peek(k.fl0);  // for the next step: layer 0 is ahead, this usually shows s + 2 already
-            if (s > 0 && s < Tp) {
-                if constexpr (X16) kloop16(acc, nullptr, k.xrsrc1, slot1(s - 1), a.o_whh1, GKC, GKC, k.xrsrc1, 0, 0, 0, 0);
-                else kloop(acc, nullptr, k.xrsrc1, slot1(s - 1), a.o_whh1, GKC, GKC, k.xrsrc1, 0, 0, 0, 0);
-            }
+            if (s > 0 && s < Tp)
+                kloop(acc, nullptr, k.xrsrc1, slot1(s - 1), a.o_whh1, GKC, GKC, k.xrsrc1, 0, 0, 0, 0);
             if (s < Tp) {
                 // slot s & 1 held h1_{s-2}: read by every member in step s - 1, which they have left (flag1 >= s above)
-                if constexpr (X16)
-                    cell16(k, acc, k.xrsrc1, slot1(s), k.hx1 + (size_t)s * a.Nrows * GH, a.gates1 + (size_t)s * a.Nrows * 4 * GH,
-                           a.cseq1 + (size_t)s * a.Nrows * GH);
-                else
-                    cell(k, acc, reinterpret_cast<float*>(reinterpret_cast<char*>(k.hx1) + slot1(s)),
-                         TRAIN ? a.gates1 + (size_t)s * a.Nrows * 4 * GH : nullptr, TRAIN ? a.cseq1 + (size_t)s * a.Nrows * GH : nullptr);
+                cell(k, acc, reinterpret_cast<float*>(reinterpret_cast<char*>(k.hx1) + slot1(s)),
+                     TRAIN ? a.gates1 + (size_t)s * a.Nrows * 4 * GH : nullptr, TRAIN ? a.cseq1 + (size_t)s * a.Nrows * GH : nullptr);
                 publish(k.fl1 + member, (unsigned)s + 1);
             }
         };
@@ -673,14 +559,13 @@ int fsn_launch_lstm2_group(const FsnSbInput* xin, const float* whh0_p, const flo
 int fsn_launch_lstm2_group_train(const float* x, long x_ld, int x_cols, int Nrows, const float* wih0_p, const float* whh0_p,
                                  const float* wih1_p, const float* whh1_p, const float* bias0, const float* bias1,
                                  float* hseq0, float* hseq1, float* save0, float* save1, unsigned* flags, int Tp,
-                                 int clusters, int H, hipStream_t s, int arith, unsigned short* hx16) {
+                                 int clusters, int H, hipStream_t s, int arith) {
     if (H != GH || clusters < 1 || (long)clusters * GROWS > Nrows || (size_t)Tp * Nrows * GH * 4 > 0x7fffffffull) {
         fsn_set_error("lstm2_group (training): H = 384, clusters * 64 <= rows, hidden sequence below 2 GB");
         return FSN_ERR_ARG;
     }
-    if (arith != FSN_ARITH_F32 && !((arith == FSN_ARITH_F16 || arith == FSN_ARITH_BF16) && save0 && save1 && hx16)) {
-        fsn_set_error("lstm2_group: arithmetic %d is built for the training form (fp16 / bf16 operands, with the 16-bit "
-                      "exchange buffers) only", arith);
+    if (arith != FSN_ARITH_F32 && !((arith == FSN_ARITH_F16 || arith == FSN_ARITH_BF16) && save0 && save1)) {
+        fsn_set_error("lstm2_group: arithmetic %d is built for the training form (fp16 / bf16 operands) only", arith);
         return FSN_ERR_ARG;
     }
     if (fsn_launch_zero_words(flags, fsn_lstm2_group_flag_words(clusters), s) != FSN_OK) return FSN_ERR_LAUNCH;
@@ -718,8 +603,6 @@ int fsn_launch_lstm2_group_train(const float* x, long x_ld, int x_cols, int Nrow
     a.cseq1 = save ? save1 + (size_t)Tp * Nrows * 4 * GH : nullptr;
     a.Nrows = Nrows;
     a.nclusters = clusters;
-    a.hx16_0 = hx16;  // [Tp][Nrows][H] 16-bit copies of h0 / h1 (16-bit arithmetic only)
-    a.hx16_1 = hx16 ? hx16 + (size_t)Tp * Nrows * GH : nullptr;
     const int cap = grp_slots_cap(), slots = clusters < cap ? clusters : cap;
     if (cap == 0 || clusters > 2 * cap) {
         fsn_set_error("lstm2_group: %d clusters cannot be co-resident on this device (persistent kernels off, or occupancy)", clusters);

@@ -395,6 +395,14 @@ TnPlan tn_plan(int M, int Nc, long K, int arith = FSN_ARITH_F32) {
 }
 constexpr size_t kTnOnePerCu = 96 * 1024;  // LDS reservation (never touched): one workgroup per CU
 constexpr long kColsumRows = 2048;
+// rows per block of a column-sum launch: 2048, or fewer when that would leave most of the chip idle - the full-band
+// output layer's 257 columns x 3120 rows ran on 4 workgroups walking 2048 rows each (0.46 ms; 49 blocks of 64: ~0.02)
+static long colsum_rows_per_block(int cols, long rows) {
+    long r = kColsumRows;
+    const long col_blocks = cols <= 16 ? 1 : (cols + 255) / 256;
+    while (r > 64 && ((rows + r - 1) / r) * col_blocks < 256) r >>= 1;
+    return r;
+}
 
 }  // namespace
 
@@ -486,17 +494,19 @@ int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float
 }
 
 size_t fsn_colsum_workspace_bytes(int cols, long rows) {
-    return (size_t)((rows + kColsumRows - 1) / kColsumRows) * cols * sizeof(float);
+    const long r = colsum_rows_per_block(cols, rows);
+    return (size_t)((rows + r - 1) / r) * cols * sizeof(float);
 }
 
 int fsn_launch_colsum(const float* A, long lda, float* out, int cols, long rows, void* workspace, hipStream_t s) {
-    const int rb = (int)((rows + kColsumRows - 1) / kColsumRows);
+    const long rpb = colsum_rows_per_block(cols, rows);
+    const int rb = (int)((rows + rpb - 1) / rpb);
     float* part = static_cast<float*>(workspace);
     if (cols <= 16)
-        hipLaunchKernelGGL(colsum_narrow_kernel, dim3(rb), dim3(256), 0, s, A, lda, part, cols, rows, kColsumRows);
+        hipLaunchKernelGGL(colsum_narrow_kernel, dim3(rb), dim3(256), 0, s, A, lda, part, cols, rows, rpb);
     else
         hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, rb), dim3(256), 0, s, A, lda, part, cols, rows,
-                           kColsumRows);
+                           rpb);
     FSN_TRY_LAUNCH("colsum_partial_kernel");
     hipLaunchKernelGGL(reduce_splits_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, part, out, (long)cols, 1, cols,
                        rb);

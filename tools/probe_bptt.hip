@@ -4,6 +4,10 @@
 #include <cstdlib>
 #include "../fullsubnet_amd/csrc/lstm_group_bptt_kernels.hip"
 void fsn_set_error(const char*, ...) {}
+bool fsn_persistent_allowed() { return true; }
+bool fsn_grid_fits(const void*, int, unsigned) { return true; }
+unsigned long long fsn_spin_ticks() { return 1ull << 31; }
+unsigned* fsn_ctx_sticky() { return nullptr; }
 int fsn_check_launch(const char*) { return hipGetLastError() == hipSuccess ? 0 : -3; }
 int fsn_launch_zero_words(unsigned* p, size_t n, hipStream_t s) { return hipMemsetAsync(p, 0, n * 4, s) == hipSuccess ? 0 : -3; }
 __global__ void fill_kernel(float* p, size_t n, unsigned seed, float scale, float offset) {
@@ -12,6 +16,9 @@ __global__ void fill_kernel(float* p, size_t n, unsigned seed, float scale, floa
         p[i] = ((x & 0xffff) / 32768.0f - 1.0f) * scale + offset;
     }
 }
+#ifndef PROBE_AR
+#define PROBE_AR 0  // -DPROBE_AR=2 / 3: fp16 / bf16 matrix-core operands
+#endif
 template <int ABL>
 float run(BpttArgs a, int clusters) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -19,7 +26,7 @@ float run(BpttArgs a, int clusters) {
     for (int it = 0; it < 3; ++it) {
         hipMemsetAsync(a.flags, 0, fsn_lstm2_group_bptt_flag_words(clusters) * 4, 0);
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(lstm2_group_bptt_kernel<ABL>, dim3(clusters * BM * 2), dim3(256), 0, 0, a);
+        hipLaunchKernelGGL((lstm2_group_bptt_kernel<ABL, PROBE_AR>), dim3(clusters * BM * 2), dim3(256), 0, 0, a);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (it > 0 && ms < best) best = ms;
     }
@@ -43,6 +50,7 @@ int main(int argc, char** argv) {
     const double mfma_us = 2.0 * 64 * 48 * (3.0 * BG) / (64.0 * 4 * 2.4e3);  // per step and CU (one member of each layer) at 2.4 GHz
     const float t0 = run<0>(a, clusters);
     unsigned st = 0; hipMemcpy(&st, a.status, 4, hipMemcpyDeviceToHost);
+    printf("arithmetic %d: ", PROBE_AR);
     printf("lstm2_group_bptt_kernel, %d clusters, %d steps: %.3f ms = %.1f us per step (MFMA alone %.1f us), status %u\n", clusters, Tp, t0, 1e3 * t0 / Tp, mfma_us, st);
 #define V(abl, what) { const float t = run<abl>(a, clusters); printf("  %-52s: %.3f ms = %.1f us per step\n", what, t, 1e3 * t / Tp); }
     V(16, "plain instead of write-through stores");

@@ -4,6 +4,10 @@
 #include <cstdlib>
 #include "../fullsubnet_amd/csrc/fb_chain_kernels.hip"
 void fsn_set_error(const char*, ...) {}
+bool fsn_persistent_allowed() { return true; }
+bool fsn_grid_fits(const void*, int, unsigned) { return true; }
+unsigned long long fsn_spin_ticks() { return 1ull << 31; }
+unsigned* fsn_ctx_sticky() { return nullptr; }
 int fsn_check_launch(const char*) { return hipGetLastError() == hipSuccess ? 0 : -3; }
 int fsn_launch_zero_words(unsigned* p, size_t n, hipStream_t s) { return hipMemsetAsync(p, 0, n * 4, s) == hipSuccess ? 0 : -3; }
 __global__ void fill_kernel(float* p, size_t n, unsigned seed, float scale, float offset) {
