@@ -179,9 +179,9 @@ def training_step_ms(device, steps=5, arith="f32"):
     ms = 1e3 * (time.perf_counter() - t0) / steps
     T = 1 + 49152 // HOP
     flops = 3 * 2.0 * 16 * (T + LA) * (MAC_FB + 128 * MAC_SB_PER_BIN)  # ~3x forward, 128 bins kept
+    skipped = opt.skipped_steps()
     del model, opt
     torch.cuda.empty_cache()
-    skipped = opt.skipped_steps()
     out = {"ms_per_step": round(ms, 2), "dtype": arith,
            "config": "BASELINE config 3 per-rank shape: 16 x 49152 samples, drop_band groups 2, cIRM MSE + "
                      "clip_grad_norm_(10) + Adam" + ("" if arith == "f32" else

@@ -11,7 +11,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfsn_hip.so")
 
-NORM_TYPES = {"offline_laplace_norm": 0, "cumulative_laplace_norm": 1}
+NORM_TYPES = {"offline_laplace_norm": 0, "cumulative_laplace_norm": 1}  # the fused FullSubNet kernels (cfg.norm_type)
+ALL_NORM_TYPES = {"offline_laplace_norm": 0, "cumulative_laplace_norm": 1, "offline_gaussian_norm": 2,
+                  "cumulative_layer_norm": 3, "forgetting_norm": 4}  # fsn_norm
 
 _f32p = ctypes.c_void_p
 _lib = None
@@ -83,6 +85,9 @@ SIGNATURES = {
     "fsn_decompress_cirm": (_c.c_int, [_f32p, _f32p, _c.c_size_t, _c.c_void_p]),
     "fsn_compress_cirm": (_c.c_int, [_f32p, _f32p, _c.c_size_t, _c.c_void_p]),
     "fsn_build_cirm": (_c.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _c.c_size_t, _c.c_void_p]),
+    "fsn_norm_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "fsn_norm": (_c.c_int, [_f32p, _f32p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float,
+                            _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "fsn_fullsubnet_packed_bytes": (_c.c_size_t, [_c.POINTER(Cfg)]),
     "fsn_fullsubnet_pack": (_c.c_int, [_c.POINTER(Cfg), _c.POINTER(Params), _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "fsn_fullsubnet_workspace_bytes": (_c.c_size_t, [_c.POINTER(Cfg), _c.c_int, _c.c_int]),

@@ -1,10 +1,11 @@
 """``BaseModel`` of audio_zen/model/base_model.py for the model families composed from
 ``SequenceModel`` blocks (Fast FullSubNet, the full-band baseline).
 
-Helper semantics follow the reference line by line (cited per method); they are the thin,
-HBM-light glue between the LSTM blocks, written as plain tensor algebra.  The FullSubNet model
-itself does not use these: its norms, unfold and concat are fused into the HIP kernels
-(fullsubnet_amd/model.py).
+Helper semantics follow the reference line by line (cited per method).  The five norms run on the HIP kernels of
+norm_kernels.hip (`fsn_norm`) for GPU tensors outside autograd (inference: every composed model) and as the same
+tensor algebra, autograd-tracked, inside training graphs and in the CPU unit tests; the other helpers are thin,
+HBM-light glue between the LSTM blocks.  The FullSubNet model itself does not use these: its norms, unfold and
+concat are fused into the HIP kernels (fullsubnet_amd/model.py).
 """
 import torch
 import torch.nn as nn
@@ -13,6 +14,31 @@ from torch.nn import functional
 from .acoustics.feature import drop_band
 
 EPSILON = float(torch.finfo(torch.float32).eps)  # audio_zen/constant.py
+
+
+def _hip_norm(name, input, sample_length=192, eps=0.0):
+    """fsn_norm (norm_kernels.hip) when the tensor lives on the GPU and nothing asks for a gradient; None otherwise (the
+    caller then runs the same norm as autograd-tracked tensor algebra: training graphs, and the CPU unit tests).
+    eps = 0: the constant of audio_zen/model/base_model.py for that norm."""
+    from . import _lib
+    if not input.is_cuda or (torch.is_grad_enabled() and input.requires_grad) or input.dtype != torch.float32:
+        return None
+    offline = name in ("offline_laplace_norm", "offline_gaussian_norm")
+    if input.dim() != 4 and not (offline and input.dim() >= 2):
+        return None
+    x = input.contiguous()
+    if input.dim() == 4:
+        B, C, F, T = x.shape
+    else:  # the offline norms take their statistic over everything but the batch axis, whatever the rank
+        B, C, T = x.shape[0], 1, x.shape[-1]
+        F = x.numel() // (B * T)
+    L = _lib.lib()
+    nt = _lib.ALL_NORM_TYPES[name]
+    y = torch.empty_like(x)
+    ws = _lib.workspace(L.fsn_norm_workspace_bytes(nt, B, C, F, T), x.device)
+    _lib.check(L.fsn_norm(_lib.dev_ptr(x, "input"), _lib.dev_ptr(y), nt, B, C, F, T, int(sample_length), float(eps),
+                          ws.data_ptr(), ws.numel(), _lib.stream_ptr(x.device)))
+    return y
 
 
 class BaseModel(nn.Module):
@@ -37,12 +63,18 @@ class BaseModel(nn.Module):
     # base_model.py:204-218
     @staticmethod
     def offline_laplace_norm(input):
+        y = _hip_norm("offline_laplace_norm", input)
+        if y is not None:
+            return y
         mu = torch.mean(input, dim=list(range(1, input.dim())), keepdim=True)
         return input / (mu + 1e-5)
 
     # base_model.py:221-251
     @staticmethod
     def cumulative_laplace_norm(input):
+        y = _hip_norm("cumulative_laplace_norm", input)
+        if y is not None:
+            return y
         B, C, F, T = input.size()
         x = input.reshape(B * C, F, T)
         cum = torch.cumsum(torch.sum(x, dim=1), dim=-1)
@@ -53,6 +85,9 @@ class BaseModel(nn.Module):
     # base_model.py:295-310
     @staticmethod
     def offline_gaussian_norm(input):
+        y = _hip_norm("offline_gaussian_norm", input)
+        if y is not None:
+            return y
         mu = torch.mean(input, dim=(1, 2, 3), keepdim=True)
         std = torch.std(input, dim=(1, 2, 3), keepdim=True)
         return (input - mu) / (std + 1e-5)
@@ -60,6 +95,9 @@ class BaseModel(nn.Module):
     # base_model.py:312-354
     @staticmethod
     def cumulative_layer_norm(input):
+        y = _hip_norm("cumulative_layer_norm", input)
+        if y is not None:
+            return y
         B, C, F, T = input.size()
         x = input.reshape(B * C, F, T)
         s1 = torch.cumsum(torch.sum(x, dim=1), dim=-1)
@@ -76,6 +114,9 @@ class BaseModel(nn.Module):
         """mu_t = a_t mu_{t-1} + (1 - a_t) mean_f x[:, :, t] with a_t = min((t-1)/(t+1), alpha) for
         t < sample_length (a_0 = -1, i.e. mu_0 = 2 mean_0 - the reference's own start-up) and alpha after."""
         assert input.ndim == 4
+        y = _hip_norm("forgetting_norm", input, sample_length)
+        if y is not None:
+            return y
         B, C, F, T = input.size()
         x = input.reshape(B, C * F, T)
         frame_mean = torch.mean(x, dim=1)  # [B, T]

@@ -13,6 +13,7 @@ import torch.nn as nn
 from torch.nn import functional
 
 from .acoustics.feature import istft, stft
+from .base_model import _hip_norm
 from .sequence_model import SequenceModel as _SequenceModel
 
 EPSILON = float(torch.finfo(torch.float32).eps)
@@ -34,12 +35,19 @@ class BaseModel(nn.Module):
 
     @staticmethod
     def offline_laplace_norm(input, return_mu=False):
+        if not return_mu:
+            y = _hip_norm("offline_laplace_norm", input, eps=EPSILON)  # fsn_norm outside autograd, on the GPU
+            if y is not None:
+                return y
         mu = torch.mean(input, dim=list(range(1, input.dim())), keepdim=True)
         normed = input / (mu + EPSILON)
         return (normed, mu) if return_mu else normed
 
     @staticmethod
     def cumulative_laplace_norm(input):
+        y = _hip_norm("cumulative_laplace_norm", input)
+        if y is not None:
+            return y
         B, C, F, T = input.size()
         x = input.reshape(B * C, F, T)
         cum = torch.cumsum(torch.sum(x, dim=1), dim=-1)
@@ -49,6 +57,9 @@ class BaseModel(nn.Module):
 
     @staticmethod
     def offline_gaussian_norm(input):
+        y = _hip_norm("offline_gaussian_norm", input, eps=EPSILON)
+        if y is not None:
+            return y
         dims = list(range(1, input.dim()))
         mu = torch.mean(input, dim=dims, keepdim=True)
         std = torch.std(input, dim=dims, keepdim=True)

@@ -34,6 +34,9 @@ extern "C" {
 
 #define FSN_NORM_OFFLINE_LAPLACE 0    /* audio_zen/model/base_model.py:204-218 */
 #define FSN_NORM_CUMULATIVE_LAPLACE 1 /* audio_zen/model/base_model.py:221-251 */
+#define FSN_NORM_OFFLINE_GAUSSIAN 2   /* audio_zen/model/base_model.py:295-310 (fsn_norm only) */
+#define FSN_NORM_CUMULATIVE_LAYER 3   /* audio_zen/model/base_model.py:312-354 (fsn_norm only) */
+#define FSN_NORM_FORGETTING 4         /* audio_zen/model/base_model.py:103-151 (fsn_norm only) */
 
 /* Arithmetic of the three large sub-band kernels.  F32 (the default, what every parity claim and bench.py's
  * `value` refer to): v_mfma_f32_16x16x4_f32, bit-equal to an fmaf chain.  F16X3: opt-in experiment - fp32
@@ -77,6 +80,18 @@ int fsn_compress_cirm(const float* mask, float* out, size_t n, void* stream);
 /* mask.py:7-29  build_complex_ideal_ratio_mask: four [n] planes -> out [n, 2] (compressed). */
 int fsn_build_cirm(const float* noisy_real, const float* noisy_imag, const float* clean_real,
                    const float* clean_imag, float* out, size_t n, void* stream);
+
+/* ---- feature norms : audio_zen/model/base_model.py --------------------------------------- */
+
+/* norm_wrapper (base_model.py:356-372): any of the five norms on x [B, C, F, T] -> y (same shape; y may alias x), as
+ * the composed models call them between their SequenceModel blocks.  sample_length: forgetting_norm's argument
+ * (192 in the reference's signature; ignored by the others).  eps <= 0: the reference's constant for that norm
+ * (1e-5 / fp32 epsilon / 1e-5 / fp32 epsilon / 1e-10); improved_fullsubnet/model.py:124-216 uses fp32 epsilon in its
+ * offline norms and passes it.  Statistics are summed exactly (fp64) and then follow the reference's fp32 tensor
+ * arithmetic operation by operation. */
+size_t fsn_norm_workspace_bytes(int norm_type, int B, int C, int F, int T);
+int fsn_norm(const float* x, float* y, int norm_type, int B, int C, int F, int T, int sample_length, float eps,
+             void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- FullSubNet model : recipes/dns_interspeech_2020/fullsubnet/model.py --------------- */
 

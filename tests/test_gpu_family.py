@@ -301,3 +301,42 @@ def test_fullsubnet_other_hidden_sizes_run_composed(fsn):
         crm = m(torch.from_numpy(mag).cuda()).cpu().numpy()
     want = O.fullsubnet_forward(mag, params)
     assert np.abs(crm - want).max() <= 1e-4 * max(1.0, np.abs(want).max() / 10)
+
+
+@pytest.mark.parametrize("shape", [(3, 1, 257, 63), (2, 64, 12, 97), (2, 5, 33, 250), (1, 2, 7, 1)])
+@pytest.mark.parametrize("name", ["offline_laplace_norm", "cumulative_laplace_norm", "offline_gaussian_norm",
+                                  "cumulative_layer_norm", "forgetting_norm"])
+def test_feature_norms_on_the_hip_kernels(fsn, name, shape):
+    """norm_wrapper (audio_zen/model/base_model.py:356-372): fsn_norm (norm_kernels.hip) against the reference's tensor
+    algebra as restated in base_model.py (itself pinned on the reference through the var_* goldens) - positive
+    magnitude-like input, and for the zero-mean norms a signed one; 250 frames cross forgetting_norm's sample_length."""
+    from fullsubnet_amd.base_model import BaseModel
+    if name == "offline_gaussian_norm" and shape[1] * shape[2] * shape[3] < 2:
+        pytest.skip("torch.std of one value")
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.rand(shape, generator=g) * 3.0 + 0.01
+    if name in ("offline_gaussian_norm", "cumulative_layer_norm"):
+        x = x - 1.2
+    fn = getattr(BaseModel, name)
+    want = fn(x.double()).float()                       # the algebra, in fp64 on the CPU
+    algebra32 = fn(x.clone())                           # ... and in fp32 as the reference runs it
+    got = fn(x.cuda())                                  # GPU tensor, no autograd: the HIP kernels
+    assert got.is_cuda and got.shape == x.shape
+    scale = want.abs().max().item()
+    err = (got.cpu() - want).abs().max().item() / scale
+    ref_err = (algebra32 - want).abs().max().item() / scale
+    print(f"{name} {shape}: HIP vs fp64 algebra {err:.2e} (the reference's fp32 algebra: {ref_err:.2e})")
+    assert err <= max(3 * ref_err, 2e-6)
+    # and under autograd the same call is the algebra itself (training graphs): gradients flow
+    xg = x.cuda().requires_grad_(True)
+    fn(xg).sum().backward()
+    assert xg.grad is not None and bool(torch.isfinite(xg.grad).all())
+
+
+def test_improved_fullsubnet_offline_norm_of_a_five_dimensional_tensor(fsn):
+    """improved_fullsubnet/model.py:124-216: the offline norm there runs over [B, N, 1, F_sub, T] with fp32 epsilon."""
+    from fullsubnet_amd.improved_fullsubnet import BaseModel as IB
+    x = torch.rand((2, 6, 1, 20, 40), generator=torch.Generator().manual_seed(5)) + 0.05
+    want = IB.offline_laplace_norm(x.double()).float()
+    got = IB.offline_laplace_norm(x.cuda())
+    assert (got.cpu() - want).abs().max().item() <= 2e-6 * want.abs().max().item()
