@@ -23,6 +23,8 @@ def _hip_norm(name, input, sample_length=192, eps=0.0):
     from . import _lib
     if not input.is_cuda or (torch.is_grad_enabled() and input.requires_grad) or input.dtype != torch.float32:
         return None
+    if input.shape[-1] > 6144:  # FSN_NORM_MAX_FRAMES: longer inputs take the tensor algebra below
+        return None
     offline = name in ("offline_laplace_norm", "offline_gaussian_norm")
     if input.dim() != 4 and not (offline and input.dim() >= 2):
         return None

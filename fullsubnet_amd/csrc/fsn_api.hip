@@ -1930,95 +1930,6 @@ static LayerPacked layer_packed_layout(int I, int H) {
     p.total = p.bias + fsn_round_up_sz(4 * (size_t)H, 64);
     return p;
 }
-// ---- several independent two-layer stacks over the same frames, one wavefront ------------------------------------
-// (improved_fullsubnet/model.py:402-449: the band sections' SequenceModels all see the same T frames; as separate chains
-// of T + 1 launches each they ran one after the other - see lstm_stepn_kernel)
-static size_t lstm2_multi_stack_floats(const fsn_lstm2_stack& q, int T, Carver& cv, float** out /* 10 pointers or NULL */) {
-    const int Ipad = fsn_round_up(q.I, 16), G0 = 4 * q.H0, G1 = 4 * q.H1;
-    float* p[10];
-    p[0] = cv.take<float>((size_t)G0 * Ipad);     // W_ih0 fragments
-    p[1] = cv.take<float>((size_t)G0 * q.H0);     // W_hh0
-    p[2] = cv.take<float>((size_t)G1 * q.H0);     // W_ih1
-    p[3] = cv.take<float>((size_t)G1 * q.H1);     // W_hh1
-    p[4] = cv.take<float>((size_t)G0);            // b0
-    p[5] = cv.take<float>((size_t)G1);            // b1
-    p[6] = cv.take<float>((size_t)G1 * 16);       // b1 as fragment tiles
-    p[7] = cv.take<float>((size_t)T * q.N * G0);  // layer-0 projection
-    p[8] = cv.take<float>((size_t)T * q.N * q.H0);  // layer-0 hidden sequence
-    p[9] = cv.take<float>((size_t)q.N * (q.H0 + q.H1));  // cell states
-    if (out)
-        for (int i = 0; i < 10; ++i) out[i] = p[i];
-    return cv.off;
-}
-static int check_lstm2_stacks(int n, const fsn_lstm2_stack* st, int T) {
-    FSN_REQUIRE(st && n >= 1 && n <= 4, "lstm2 multi: 1 .. 4 stacks (got %d)", n);
-    for (int k = 0; k < n; ++k) {
-        FSN_TRY(check_lstm_layer(T, st[k].N, st[k].I, st[k].H0, st[k].ldx));
-        FSN_REQUIRE(st[k].H1 >= 64 && st[k].H1 % 64 == 0, "lstm2 multi: stack %d: second hidden size %d must be a multiple of 64", k,
-                    st[k].H1);
-    }
-    return FSN_OK;
-}
-extern "C" size_t fsn_lstm2_multi_workspace_bytes(int n, const fsn_lstm2_stack* stacks, int T) {
-    if (check_lstm2_stacks(n, stacks, T) != FSN_OK) return 0;
-    Carver cv(nullptr);
-    for (int k = 0; k < n; ++k) (void)lstm2_multi_stack_floats(stacks[k], T, cv, nullptr);
-    return fsn_round_up_sz(cv.off, 256);
-}
-extern "C" int fsn_lstm2_forward_multi(int n, const fsn_lstm2_stack* stacks, int T, void* workspace, size_t workspace_bytes,
-                                       void* stream) {
-    CallScope scope(stream);
-    FSN_TRY(check_lstm2_stacks(n, stacks, T));
-    FSN_REQUIRE(workspace, "NULL pointer argument");
-    if (workspace_bytes < fsn_lstm2_multi_workspace_bytes(n, stacks, T)) {
-        fsn_set_error("lstm2 multi: workspace too small");
-        return FSN_ERR_WORKSPACE;
-    }
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    Carver cv(workspace);
-    FsnWavefrontStack ws[4];
-    for (int k = 0; k < n; ++k) {
-        const fsn_lstm2_stack& q = stacks[k];
-        FSN_REQUIRE(q.x && q.w_ih0 && q.w_hh0 && q.b_ih0 && q.b_hh0 && q.w_ih1 && q.w_hh1 && q.b_ih1 && q.b_hh1 && q.hseq1,
-                    "lstm2 multi: stack %d: NULL pointer argument", k);
-        const int Ipad = fsn_round_up(q.I, 16), G0 = 4 * q.H0, G1 = 4 * q.H1;
-        float* p[10];
-        (void)lstm2_multi_stack_floats(q, T, cv, p);
-        FSN_TRY(fsn_launch_pack(q.w_ih0, p[0], G0, q.I, G0, Ipad, s));
-        FSN_TRY(fsn_launch_pack(q.w_hh0, p[1], G0, q.H0, G0, q.H0, s));
-        FSN_TRY(fsn_launch_pack(q.w_ih1, p[2], G1, q.H0, G1, q.H0, s));
-        FSN_TRY(fsn_launch_pack(q.w_hh1, p[3], G1, q.H1, G1, q.H1, s));
-        FSN_TRY(fsn_launch_bias_sum(q.b_ih0, q.b_hh0, p[4], G0, G0, s));
-        FSN_TRY(fsn_launch_bias_sum(q.b_ih1, q.b_hh1, p[5], G1, G1, s));
-        FSN_TRY(fsn_launch_bias_frag(p[5], p[6], G1, s));
-        FsnGemmA a{};
-        a.kind = 0;
-        a.p0 = q.x;
-        a.ld = q.ldx;
-        FsnGemmC c{};
-        c.kind = 0;
-        c.p0 = p[7];
-        c.bias = p[4];
-        FSN_TRY(fsn_launch_gemm(a, p[0], c, T * (q.N / 16), G0 / 16, Ipad / 16, s));
-        FsnWavefrontStack& w = ws[k];
-        w.gx0 = p[7];
-        w.whh0_p = p[1];
-        w.wih1_p = p[2];
-        w.bias1_frag = p[6];
-        w.whh1_p = p[3];
-        w.hseq0 = p[8];
-        w.hseq1 = q.hseq1;
-        w.c0 = p[9];
-        w.c1 = p[9] + (size_t)q.N * q.H0;
-        w.gx_stride = q.N / 16;
-        w.hs_stride = q.N;
-        w.row_tiles = q.N / 16;
-        w.H0 = q.H0;
-        w.H1 = q.H1;
-    }
-    return fsn_launch_lstm_wavefront2_multi(n, ws, T, s);
-}
-
 extern "C" size_t fsn_lstm_layer_packed_bytes(int I, int H) {
     if (I < 1 || H < 64 || H % 64) return 0;
     return layer_packed_layout(I, H).total * sizeof(float);

@@ -379,13 +379,6 @@ int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, co
                                const float* bias1_frag, const float* whh1_p, float* hseq0, float* hseq1, long hs_stride,
                                long hs_off, float* c0, float* c1, int T, int row_tiles, int H, hipStream_t s,
                                float* state_h0 = nullptr, float* state_h1 = nullptr, int beside_group = 0);
-struct FsnWavefrontStack {  // one two-layer stack of fsn_launch_lstm_wavefront2_multi
-    const float *gx0, *whh0_p, *wih1_p, *bias1_frag, *whh1_p;
-    float *hseq0, *hseq1, *c0, *c1;
-    long gx_stride, hs_stride;  // row tiles / rows per step of gx0 and of the hidden sequences
-    int row_tiles, H0, H1;
-};
-int fsn_launch_lstm_wavefront2_multi(int n, const FsnWavefrontStack* st, int T, hipStream_t s);
 int fsn_launch_lstm_wavefront2w(const float* gx0, long gx_stride, long gx_off, const float* whh0_p,
                                 const float* wih1_p, const float* bias1_frag, const float* whh1_p, float* hseq0,
                                 float* hseq1, long hs_stride, long hs_off, float* c0, float* c1, int T, int row_tiles,

@@ -1296,15 +1296,6 @@ struct FsnStepJob {
 struct FsnStepJobs {
     FsnStepJob j[2];
 };
-// Several independent two-layer stacks advanced by ONE launch per step (blockIdx.z = 2 x stack + layer): the band
-// sections of Improved FullSubNet (improved_fullsubnet/model.py:402-449: four SequenceModels of B x {20, 25, 6, 4}
-// rows over the same frames) ran as four chains of 302 launches each, which the hardware queues serialised - 75 % of
-// that model's step (profiles/r02_kernel_stats_improved48_b32.md).
-constexpr int kMaxStacks = 4;
-struct FsnStepJobsN {
-    FsnStepJob j[2 * kMaxStacks];
-};
-
 template <class Jobs>
 __device__ __forceinline__ void lstm_step2_body(const Jobs& jobs) {
     const FsnStepJob job = jobs.j[blockIdx.z];  // one uniform kernarg fetch, no per-member branching
@@ -1424,7 +1415,6 @@ __device__ __forceinline__ void lstm_step2_body(const Jobs& jobs) {
 }
 
 __global__ __launch_bounds__(256) void lstm_step2_kernel(const FsnStepJobs jobs) { lstm_step2_body(jobs); }
-__global__ __launch_bounds__(256) void lstm_stepn_kernel(const FsnStepJobsN jobs) { lstm_step2_body(jobs); }
 
 // The same step beside the group kernel of lstm_group_kernels.hip (two 216-register workgroups per CU): capped at the 80
 // registers per lane that are left there; it spills a little, on a chain that has ten times the slack.
@@ -1768,67 +1758,6 @@ int fsn_launch_lstm_wavefront2w(const float* gx0, long gx_stride, long gx_off, c
             fsn_set_error("lstm_wavefront2: state copy failed");
             return FSN_ERR_LAUNCH;
         }
-    }
-    return FSN_OK;
-}
-
-// n independent two-layer stacks (hidden sizes H0 -> H1 each, their own row counts) over the same T steps as one
-// wavefront: T + 1 launches in all.  Per stack: the layout of fsn_launch_lstm_wavefront2w with gx_off = hs_off = 0.
-int fsn_launch_lstm_wavefront2_multi(int n, const FsnWavefrontStack* st, int T, hipStream_t s) {
-    if (n < 1 || n > kMaxStacks) {
-        fsn_set_error("lstm_wavefront2_multi: 1 .. %d stacks (got %d)", kMaxStacks, n);
-        return FSN_ERR_ARG;
-    }
-    int Hmax = 0, rt_max = 0;
-    for (int k = 0; k < n; ++k) {
-        if (st[k].H0 % 64 != 0 || st[k].H1 % 64 != 0 || st[k].row_tiles < 1) {
-            fsn_set_error("lstm_wavefront2_multi: stack %d: hidden sizes must be multiples of 64, at least one row tile", k);
-            return FSN_ERR_ARG;
-        }
-        Hmax = st[k].H0 > Hmax ? st[k].H0 : Hmax;
-        Hmax = st[k].H1 > Hmax ? st[k].H1 : Hmax;
-        rt_max = st[k].row_tiles > rt_max ? st[k].row_tiles : rt_max;
-    }
-    for (int i = 0; i <= T; ++i) {
-        FsnStepJobsN jobs{};
-        for (int k = 0; k < n; ++k) {
-            const FsnWavefrontStack& q = st[k];
-            const size_t step0 = (size_t)q.hs_stride * q.H0, step1 = (size_t)q.hs_stride * q.H1;
-            FsnStepJob& a = jobs.j[2 * k];
-            FsnStepJob& b = jobs.j[2 * k + 1];
-            a.H = q.H0;
-            b.H = q.H1;
-            a.row_tiles = b.row_tiles = q.row_tiles;
-            if (i < T) {
-                a.active = 1;
-                a.add = q.gx0;
-                a.add_rt0 = (long)i * q.gx_stride;
-                a.add_rs = 1;
-                a.whh_p = q.whh0_p;
-                a.h_prev = i ? q.hseq0 + (i - 1) * step0 : q.hseq0;
-                a.h_out = q.hseq0 + i * step0;
-                a.c = q.c0;
-                a.first = i == 0;
-            }
-            if (i >= 1) {
-                const int t = i - 1;
-                b.active = 1;
-                b.add = q.bias1_frag;
-                b.add_rt0 = 0;
-                b.add_rs = 0;
-                b.xw_p = q.wih1_p;
-                b.x = q.hseq0 + t * step0;
-                b.x_ld = q.H0;
-                b.kx_chunks = q.H0 / 16;
-                b.whh_p = q.whh1_p;
-                b.h_prev = t ? q.hseq1 + (t - 1) * step1 : q.hseq1;
-                b.h_out = q.hseq1 + t * step1;
-                b.c = q.c1;
-                b.first = t == 0;
-            }
-        }
-        hipLaunchKernelGGL(lstm_stepn_kernel, dim3(Hmax / 16, rt_max, 2 * n), dim3(256), 0, s, jobs);
-        FSN_TRY_LAUNCH("lstm_stepn_kernel");
     }
     return FSN_OK;
 }

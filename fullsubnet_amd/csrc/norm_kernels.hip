@@ -17,34 +17,71 @@ namespace {
 
 constexpr float kEpsF32 = 1.1920928955078125e-07f;  // torch.finfo(torch.float32).eps = audio_zen.constant.EPSILON
 
-// x viewed as [R][Fr][T] (T contiguous): s1[r][t] = sum_f x, s2[r][t] = sum_f x^2
+// x viewed as [R][Fr][T] (T contiguous): s1[r][t] = sum_f x, s2[r][t] = sum_f x^2.  A workgroup = 64 frames x 4 slices
+// of the Fr extent (a wave each; 64 lanes x 4 B = one 256-byte row segment per load), the slices combined through LDS in
+// a fixed order; blockIdx.z splits Fr further when there are few rows (the offline norms of a small batch: R = B), the
+// parts being added by norm_scan_kernel in index order.  Fixed order everywhere: results do not depend on timing.
 __global__ __launch_bounds__(256) void norm_frame_sums_kernel(const float* __restrict__ x, double* __restrict__ s1,
-                                                              double* __restrict__ s2, int Fr, int T, int want_sq) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+                                                              double* __restrict__ s2, int Fr, int T, int want_sq, long R,
+                                                              int f_per_part) {
+    __shared__ double red[2][3][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + lane;
     const long r = blockIdx.y;
-    if (t >= T) return;
-    const float* p = x + r * (long)Fr * T + t;
+    const int f0 = blockIdx.z * f_per_part;
+    int f1 = f0 + f_per_part;
+    f1 = f1 < Fr ? f1 : Fr;
     double a = 0.0, b = 0.0;
-    for (int f = 0; f < Fr; ++f) {
-        const double v = p[(long)f * T];
-        a += v;
-        if (want_sq) b += v * v;
+    if (t < T) {
+        const float* p = x + r * (long)Fr * T + t;
+        for (int f = f0 + w; f < f1; f += 4) {
+            const double v = p[(long)f * T];
+            a += v;
+            if (want_sq) b += v * v;
+        }
     }
-    s1[r * T + t] = a;
-    if (want_sq) s2[r * T + t] = b;
+    if (w > 0) {
+        red[0][w - 1][lane] = a;
+        red[1][w - 1][lane] = b;
+    }
+    __syncthreads();
+    if (w == 0 && t < T) {
+        for (int k = 0; k < 3; ++k) {
+            a += red[0][k][lane];
+            b += red[1][k][lane];
+        }
+        const long o = ((long)blockIdx.z * R + r) * T + t;
+        s1[o] = a;
+        if (want_sq) s2[o] = b;
+    }
 }
 
-// one thread per row: (shift, divisor) per frame.  The arithmetic after the sums follows the reference's fp32 tensor
-// operations (same operand types, same order) - the sums themselves are the exactly-summed fp64 values rounded once.
+// one wave per row: (shift, divisor) per frame.  The lanes fetch 64 frames' sums at a time (coalesced, the Fr parts
+// added in index order) into LDS; the recurrence over the frames then runs in lane 0 out of LDS - it is sequential by
+// nature (a running sum, or the forgetting norm's fp32 recurrence) but no longer pays a memory round trip per frame.
+// The arithmetic after the sums follows the reference's fp32 tensor operations (same operand types, same order) - the
+// sums themselves are exactly-summed fp64 values rounded once.
 __global__ __launch_bounds__(64) void norm_scan_kernel(const double* __restrict__ s1, const double* __restrict__ s2,
                                                        float* __restrict__ shift, float* __restrict__ den, int R, int Fr,
-                                                       int T, int norm_type, int sample_length, float eps) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    const double* a = s1 + (long)r * T;
-    const double* b = s2 + (long)r * T;
-    float* sh = shift + (long)r * T;
-    float* dn = den + (long)r * T;
+                                                       int T, int norm_type, int sample_length, float eps, int parts,
+                                                       int want_sq) {
+    extern __shared__ double row[];  // a[T] | b[T] | shift[T] | den[T] (the last two as floats)
+    const int r = blockIdx.x, lane = threadIdx.x;
+    double* a = row;
+    double* b = row + T;
+    float* sh = reinterpret_cast<float*>(row + 2 * T);
+    float* dn = sh + T;
+    for (int t = lane; t < T; t += 64) {
+        double va = 0.0, vb = 0.0;
+        for (int z = 0; z < parts; ++z) {
+            va += s1[((long)z * R + r) * T + t];
+            if (want_sq) vb += s2[((long)z * R + r) * T + t];
+        }
+        a[t] = va;
+        b[t] = vb;
+    }
+    __syncthreads();
+    if (lane == 0) {
     if (norm_type == FSN_NORM_OFFLINE_LAPLACE || norm_type == FSN_NORM_OFFLINE_GAUSSIAN) {
         double tot = 0.0, tot2 = 0.0;
         for (int t = 0; t < T; ++t) {
@@ -102,6 +139,12 @@ __global__ __launch_bounds__(64) void norm_scan_kernel(const double* __restrict_
             dn[t] = mu + eps;
         }
     }
+    }
+    __syncthreads();
+    for (int t = lane; t < T; t += 64) {
+        shift[(long)r * T + t] = sh[t];
+        den[(long)r * T + t] = dn[t];
+    }
 }
 
 // y[r][f][t] = (x - shift[rs][t]) / den[rs][t], rs = r / rows_per_stat (a statistic row may span several tensor rows)
@@ -119,20 +162,28 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
 }
 
 struct NormDims {
-    long R;   // statistic rows
-    int Fr;   // extent summed per frame
+    long R;     // statistic rows
+    int Fr;     // extent summed per frame
+    int parts;  // the Fr extent is summed in this many parts (more workgroups when there are few rows)
+    int f_per_part;
 };
-NormDims norm_dims(int norm_type, int B, int C, int F) {
+NormDims norm_dims(int norm_type, int B, int C, int F, int T) {
     const bool per_channel = norm_type == FSN_NORM_CUMULATIVE_LAPLACE || norm_type == FSN_NORM_CUMULATIVE_LAYER;
-    return per_channel ? NormDims{(long)B * C, F} : NormDims{(long)B, C * F};
+    NormDims d = per_channel ? NormDims{(long)B * C, F, 1, F} : NormDims{(long)B, C * F, 1, C * F};
+    const long blocks = d.R * ((T + 63) / 64);
+    int parts = 1;
+    while (parts < 64 && blocks * parts < 1024 && d.Fr / (parts * 2) >= 16) parts *= 2;
+    d.parts = parts;
+    d.f_per_part = (d.Fr + parts - 1) / parts;
+    return d;
 }
 
 }  // namespace
 
 extern "C" size_t fsn_norm_workspace_bytes(int norm_type, int B, int C, int F, int T) {
     if (norm_type < FSN_NORM_OFFLINE_LAPLACE || norm_type > FSN_NORM_FORGETTING || B < 1 || C < 1 || F < 1 || T < 1) return 0;
-    const NormDims d = norm_dims(norm_type, B, C, F);
-    return fsn_round_up_sz((size_t)d.R * T * (2 * sizeof(double) + 2 * sizeof(float)), 256);
+    const NormDims d = norm_dims(norm_type, B, C, F, T);
+    return fsn_round_up_sz((size_t)d.R * T * ((size_t)d.parts * 2 * sizeof(double) + 2 * sizeof(float)), 256);
 }
 
 extern "C" int fsn_norm(const float* x, float* y, int norm_type, int B, int C, int F, int T, int sample_length, float eps,
@@ -149,31 +200,38 @@ extern "C" int fsn_norm(const float* x, float* y, int norm_type, int B, int C, i
         return FSN_ERR_WORKSPACE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const NormDims d = norm_dims(norm_type, B, C, F);
-    FSN_REQUIRE(d.R <= 65535L * 64, "norm: too many statistic rows");
+    const NormDims d = norm_dims(norm_type, B, C, F, T);
+    const size_t scan_lds = (size_t)T * (2 * sizeof(double) + 2 * sizeof(float));
+    FSN_REQUIRE(d.R <= 0x7fffffffL && scan_lds <= 144 * 1024, "norm: too many statistic rows or frames (T <= %d)",
+                FSN_NORM_MAX_FRAMES);
+    if (scan_lds > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(norm_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)scan_lds);
+        (void)hipGetLastError();
+    }
     double* s1 = static_cast<double*>(workspace);
-    double* s2 = s1 + d.R * T;
-    float* shift = reinterpret_cast<float*>(s2 + d.R * T);
+    double* s2 = s1 + (size_t)d.parts * d.R * T;
+    float* shift = reinterpret_cast<float*>(s2 + (size_t)d.parts * d.R * T);
     float* den = shift + d.R * T;
     const int want_sq = norm_type == FSN_NORM_OFFLINE_GAUSSIAN || norm_type == FSN_NORM_CUMULATIVE_LAYER;
-    const unsigned tb = (unsigned)((T + 255) / 256);
-    // grid.y carries the rows: chunked for row counts beyond the 65535 limit
+    // grid.y carries the rows: chunked for row counts beyond the 65535 limit (a chunk's parts land where the whole
+    // launch's would: the row index inside the kernel is offset through the pointers, R stays the full count)
     for (long r0 = 0; r0 < d.R; r0 += 65535) {
         const long nr = d.R - r0 < 65535 ? d.R - r0 : 65535;
-        hipLaunchKernelGGL(norm_frame_sums_kernel, dim3(tb, (unsigned)nr), dim3(256), 0, s, x + r0 * (long)d.Fr * T,
-                           s1 + r0 * T, s2 + r0 * T, d.Fr, T, want_sq);
+        hipLaunchKernelGGL(norm_frame_sums_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)nr, (unsigned)d.parts), dim3(256), 0, s,
+                           x + r0 * (long)d.Fr * T, s1 + r0 * T, s2 + r0 * T, d.Fr, T, want_sq, d.R, d.f_per_part);
     }
     FSN_TRY_LAUNCH("norm_frame_sums_kernel");
     if (!(eps > 0.f))  // the constants of audio_zen/model/base_model.py
         eps = (norm_type == FSN_NORM_OFFLINE_LAPLACE || norm_type == FSN_NORM_OFFLINE_GAUSSIAN) ? 1e-5f
               : norm_type == FSN_NORM_FORGETTING                                               ? 1e-10f
                                                                                                : kEpsF32;
-    hipLaunchKernelGGL(norm_scan_kernel, dim3((unsigned)((d.R + 63) / 64)), dim3(64), 0, s, s1, s2, shift, den, (int)d.R, d.Fr, T,
-                       norm_type, sample_length, eps);
+    hipLaunchKernelGGL(norm_scan_kernel, dim3((unsigned)d.R), dim3(64), scan_lds, s, s1,
+                       s2, shift, den, (int)d.R, d.Fr, T, norm_type, sample_length, eps, d.parts, want_sq);
     FSN_TRY_LAUNCH("norm_scan_kernel");
     const long rows = (long)B * C * F;
     const unsigned gy = (unsigned)(rows < 32768 ? rows : 32768);
-    hipLaunchKernelGGL(norm_apply_kernel, dim3(tb, gy), dim3(256), 0, s, x, y, shift, den, rows, T, d.Fr,
+    hipLaunchKernelGGL(norm_apply_kernel, dim3((unsigned)((T + 255) / 256), gy), dim3(256), 0, s, x, y, shift, den, rows, T, d.Fr,
                        norm_type == FSN_NORM_OFFLINE_GAUSSIAN || norm_type == FSN_NORM_CUMULATIVE_LAYER);
     return fsn_check_launch("norm_apply_kernel");
 }

@@ -144,23 +144,6 @@ class SubbandModel(BaseModel):
         return [(hi - lo) // c for (lo, hi), c in
                 zip((self._band(i, num_freqs) for i in range(len(self.sb_models))), self.sb_num_center_freqs)]
 
-    def _section_input(self, noisy_input, fb_output, sb_idx, units=None):
-        """The normalised input of one section's sequence model [B, n, 1, F_sub, T] (model.py:402-440).  ``units = (lo,
-        hi)`` restricts it to that range of the section's units; the norm statistics are always taken over the whole
-        section, as in the reference.  None: this rank owns no unit of the section."""
-        lower, upper = self._band(sb_idx, noisy_input.size(2))
-        noisy_subband = self._freq_unfold(noisy_input, lower, upper, self.sb_num_center_freqs[sb_idx],
-                                          self.sb_num_neighbor_freqs[sb_idx])
-        fb_subband = self._freq_unfold(fb_output, lower, upper, self.fb_num_center_freqs[sb_idx],
-                                       self.fb_num_neighbor_freqs[sb_idx])
-        sb_model_input = self.norm(torch.cat([noisy_subband, fb_subband], dim=-2))
-        if units is not None:
-            lo, hi = units
-            if hi <= lo:
-                return None
-            sb_model_input = sb_model_input[:, lo:hi].contiguous()
-        return sb_model_input
-
     def _section(self, noisy_input, fb_output, sb_idx, units=None):
         """One section (model.py:402-449).  ``units = (lo, hi)`` restricts the sequence model to that range of the
         section's units; the norm statistics are always taken over the whole section, as in the reference."""
@@ -182,30 +165,8 @@ class SubbandModel(BaseModel):
         num = len(self.sb_models)
         if torch.is_grad_enabled() or not noisy_input.is_cuda:
             return [self._section(noisy_input, fb_output, i, units[i]) for i in range(num)]
-        # inference: the sections are independent chains of small dependent launches over the same frames.  With more
-        # than 64 rows in some section (beyond the persistent chain kernel) they advance as ONE wavefront - a launch per
-        # step for all sections together (sequence_model.multi_forward): as four chains of 302 launches the hardware
-        # queues ran them one after the other, 75 % of the model's step at batch 32
-        n_units = self.num_units(noisy_input.size(2))
-        span = [n_units[i] if units[i] is None else max(units[i][1] - units[i][0], 0) for i in range(num)]
-        live = [i for i in range(num) if span[i] > 0]
-        if (live and max(noisy_input.size(0) * span[i] for i in live) > 64 and len(live) <= 4
-                and all(self.sb_models[i].cell == "LSTM" and self.sb_models[i].num_layers == 2 for i in live)):
-            from .sequence_model import multi_forward
-            inputs = [self._section_input(noisy_input, fb_output, i, units[i]) if i in live else None for i in range(num)]
-            flat = [inputs[i].reshape(inputs[i].shape[0] * inputs[i].shape[1], inputs[i].shape[3], inputs[i].shape[4])
-                    for i in live]
-            outs = multi_forward([self.sb_models[i] for i in live], flat)
-            result = []
-            for i in range(num):
-                if inputs[i] is None:
-                    result.append(noisy_input.new_zeros((noisy_input.size(0), 2, 0, noisy_input.size(-1))))
-                    continue
-                o = outs[live.index(i)]
-                B, N = inputs[i].shape[0], inputs[i].shape[1]
-                o = o.reshape(B, N, 2, -1, o.shape[-1]).permute(0, 2, 1, 3, 4).contiguous()
-                result.append(o.reshape(B, 2, -1, o.shape[-1]))
-            return result
+        # inference: the sections are independent and each one is a chain of small dependent launches
+        # (B x units rows only), so they run concurrently on one HIP stream each and join on the caller's
         main = torch.cuda.current_stream(noisy_input.device)
         if getattr(self, "_streams", None) is None or len(self._streams) != num:
             self._streams = [torch.cuda.Stream(noisy_input.device) for _ in range(num)]

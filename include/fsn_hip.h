@@ -89,6 +89,7 @@ int fsn_build_cirm(const float* noisy_real, const float* noisy_imag, const float
  * (1e-5 / fp32 epsilon / 1e-5 / fp32 epsilon / 1e-10); improved_fullsubnet/model.py:124-216 uses fp32 epsilon in its
  * offline norms and passes it.  Statistics are summed exactly (fp64) and then follow the reference's fp32 tensor
  * arithmetic operation by operation. */
+#define FSN_NORM_MAX_FRAMES 6144 /* T of one fsn_norm call (a row's per-frame statistics sit in LDS) */
 size_t fsn_norm_workspace_bytes(int norm_type, int B, int C, int F, int T);
 int fsn_norm(const float* x, float* y, int norm_type, int B, int C, int F, int T, int sample_length, float eps,
              void* workspace, size_t workspace_bytes, void* stream);
@@ -221,20 +222,6 @@ int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, const float*
                       const float* b_hh0, const float* w_ih1, const float* w_hh1, const float* b_ih1,
                       const float* b_hh1, int T, int N, int I, int H0, int H1, float* hseq1, void* workspace,
                       size_t workspace_bytes, void* stream);
-
-/* Up to four INDEPENDENT two-layer stacks over the same T frames as one wavefront (T + 1 launches in all instead of
- * T + 1 per stack): the band sections of improved_fullsubnet/model.py:402-449, whose SequenceModels have B x {20, 25, 6,
- * 4} rows and different input widths.  Per stack the arguments of fsn_lstm2_forward. */
-typedef struct fsn_lstm2_stack {
-    const float* x; /* [T][N][ldx], columns I .. ldx-1 zero */
-    long ldx;
-    const float *w_ih0, *w_hh0, *b_ih0, *b_hh0, *w_ih1, *w_hh1, *b_ih1, *b_hh1;
-    int N, I, H0, H1;
-    float* hseq1; /* [T][N][H1] out */
-} fsn_lstm2_stack;
-size_t fsn_lstm2_multi_workspace_bytes(int n, const fsn_lstm2_stack* stacks, int T);
-int fsn_lstm2_forward_multi(int n, const fsn_lstm2_stack* stacks, int T, void* workspace, size_t workspace_bytes,
-                            void* stream);
 
 /* Streaming inference (chunked / frame-by-frame processing with carried state - the real-time use the
  * model is designed for; the reference has no such entry point, nn.LSTM's (h_0, c_0) argument is the
