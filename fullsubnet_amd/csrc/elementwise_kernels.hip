@@ -312,6 +312,27 @@ int fsn_launch_poison_if(const unsigned* status, float* out, size_t n, hipStream
     return fsn_check_launch("poison_if_kernel");
 }
 
+template <int AR>
+__global__ void to16_kernel(const f32x4* __restrict__ src, fsn_u32x2* __restrict__ dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = __builtin_bit_cast(fsn_u32x2, fsn_operand<AR>(src[i]));
+}
+int fsn_launch_to16(const float* src, void* dst, size_t n, int arith, hipStream_t s) {
+    if (n % 4 != 0 || (arith != FSN_ARITH_F16 && arith != FSN_ARITH_BF16)) {
+        fsn_set_error("to16: element count %zu must be a multiple of 4, arithmetic fp16 / bf16", n);
+        return FSN_ERR_ARG;
+    }
+    const size_t n4 = n / 4;
+    const unsigned blocks = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    if (arith == FSN_ARITH_F16)
+        hipLaunchKernelGGL(to16_kernel<FSN_ARITH_F16>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const f32x4*>(src),
+                           static_cast<fsn_u32x2*>(dst), n4);
+    else
+        hipLaunchKernelGGL(to16_kernel<FSN_ARITH_BF16>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const f32x4*>(src),
+                           static_cast<fsn_u32x2*>(dst), n4);
+    return fsn_check_launch("to16_kernel");
+}
+
 // Test hook (fsn_debug_hog): a foreign kernel that holds CUs for a while.  `heavy`: every wave keeps ~200 registers
 // live (one wave per SIMD then excludes the 216-register group workgroups from that SIMD); LDS is whatever the
 // launch asks for dynamically.  Spins on the constant-rate counter until `ticks` have passed.

@@ -1648,6 +1648,7 @@ extern "C" size_t fsn_lstm2_train_workspace_bytes(int T, int N, int I, int H, in
         cv.take<float>((size_t)T * left * Ipad);
         cv.take<float>((size_t)T * left * H);
         cv.take<float>((size_t)T * left * 4 * H);
+        if (arith != FSN_ARITH_F32) cv.take<unsigned short>((size_t)4 * H * Ipad + (size_t)3 * 4 * H * H);  // 16-bit weights
         return fsn_round_up_sz(cv.off, 256);
     }
     if (lstm2_train_plan(T, N, I, H).fwd_chain) {
@@ -1696,12 +1697,15 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
         float* x_left = cv.take<float>((size_t)T * left * Ipad);
         float* h0_left = cv.take<float>((size_t)T * left * H);
         float* gx_left = cv.take<float>((size_t)T * left * 4 * H);
+        const size_t wfloats = (size_t)4 * H * Ipad + (size_t)3 * 4 * H * H;
+        unsigned short* w16 = arith != FSN_ARITH_F32 ? cv.take<unsigned short>(wfloats) : nullptr;
         FSN_TRY(fsn_launch_pack(w_ih0, wih0_p, 4 * H, I, 4 * H, Ipad, s));
         FSN_TRY(fsn_launch_pack(w_hh0, whh0_p, 4 * H, H, 4 * H, H, s));
         FSN_TRY(fsn_launch_pack(w_ih1, wih1_p, 4 * H, H, 4 * H, H, s));
         FSN_TRY(fsn_launch_pack(w_hh1, whh1_p, 4 * H, H, 4 * H, H, s));
         FSN_TRY(fsn_launch_bias_sum(b_ih0, b_hh0, b0, 4 * H, 4 * H, s));
         FSN_TRY(fsn_launch_bias_sum(b_ih1, b_hh1, b1, 4 * H, 4 * H, s));
+        if (w16) FSN_TRY(fsn_launch_to16(wih0_p, w16, wfloats, arith, s));  // the group kernel's weight fragments in 16 bits
         float* sv0 = static_cast<float*>(save0);
         float* sv1 = static_cast<float*>(save1);
         StreamCtx* cx = cur_ctx();
@@ -1715,7 +1719,7 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
         {
             FSN_PERSIST_BEGIN(s);
             FSN_TRY(fsn_launch_lstm2_group_train(x, ldx, 32, N, wih0_p, whh0_p, wih1_p, whh1_p, b0, b1, hseq0, hseq1, sv0, sv1,
-                                                 flags, T, clusters, H, s, arith));
+                                                 flags, T, clusters, H, s, arith, w16));
             FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_status_word(clusters), hseq1, (size_t)T * N * H, s));
         }
         if (left > 0) {
@@ -2088,6 +2092,7 @@ extern "C" size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H, int 
         size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
         const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
         cv.take<char>(tn > tn2 ? tn : tn2);
+        if (arith != FSN_ARITH_F32) cv.take<unsigned short>((size_t)3 * H * G);  // 16-bit W^T fragments
         return fsn_round_up_sz(cv.off, 256);
     }
     if (lstm2_train_plan(T, N, I, H).bptt_chain) {
@@ -2203,6 +2208,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
     const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
     void* scratch = cv.take<char>(tn > tn2 ? tn : tn2);
+    unsigned short* w16 = arith != FSN_ARITH_F32 ? cv.take<unsigned short>((size_t)3 * H * G) : nullptr;
     const float* sv0 = static_cast<const float*>(save0);
     const float* sv1 = static_cast<const float*>(save1);
     // "weights" of dh = dgates W are W^T: out = H columns, k = 4H; nn.LSTM stores exactly that transposed
@@ -2210,6 +2216,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     FSN_TRY(fsn_launch_pack(w_ih1, wih1T_p, H, G, H, G, s, 1, H));
     FSN_TRY(fsn_launch_pack(w_hh0, whh0T_p, H, G, H, G, s, 1, H));
     FSN_TRY(fsn_launch_pack(w_ih0, wih0T_p, I, G, Ipad, G, s, 1, I));
+    if (w16) FSN_TRY(fsn_launch_to16(whh1T_p, w16, (size_t)3 * H * G, arith, s));  // the BPTT kernel's W^T fragments in 16 bits
     StreamCtx* cx = cur_ctx();
     if (left > 0) {
         FSN_TRY(aux_init(cx));
@@ -2221,7 +2228,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     {
         FSN_PERSIST_BEGIN(s);
         FSN_TRY(fsn_launch_lstm2_group_bptt(dh1, whh1T_p, wih1T_p, whh0T_p, sv0, sv1, dg0, dg1, dxbuf, flags, T, N, clusters,
-                                            H, s, arith));
+                                            H, s, arith, w16));
         // both gate-gradient buffers (dg1 | dg0 are adjacent): every weight gradient and dx derive from them
         FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_bptt_status_word(clusters), dg1, (size_t)2 * T * N * G, s));
     }

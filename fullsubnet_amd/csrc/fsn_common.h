@@ -72,6 +72,35 @@ template <>
 struct FsnOperand<FSN_ARITH_BF16> {
     typedef fsn_s16x4 type;
 };
+// A weight fragment as it travels L2 -> registers -> LDS under arithmetic AR: fp32 (16 bytes per lane), or - 16-bit
+// arithmetic - the 16-bit copy of the packed weights (8 bytes per lane: half the L2 traffic and half the LDS of a K
+// loop whose matrix work is an eighth); fragment ORDER is the same, so element offsets carry over.
+template <int AR>
+struct FsnWFrag {
+    typedef f32x4 type;
+};
+template <>
+struct FsnWFrag<FSN_ARITH_F16> {
+    typedef fsn_u32x2 type;
+};
+template <>
+struct FsnWFrag<FSN_ARITH_BF16> {
+    typedef fsn_u32x2 type;
+};
+// the lane's fragment at element offset `ofs` of the packed weight buffer behind resource r
+template <int AR>
+__device__ __forceinline__ typename FsnWFrag<AR>::type fsn_load_wfrag(const __amdgpu_buffer_rsrc_t r, unsigned lane,
+                                                                     unsigned ofs) {
+    if constexpr (AR == FSN_ARITH_F32)
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16u, ofs * 4u, 0));
+    else
+        return __builtin_bit_cast(fsn_u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, lane * 8u, ofs * 2u, 0));
+}
+template <int AR>
+__device__ __forceinline__ typename FsnOperand<AR>::type fsn_wfrag_operand(const typename FsnWFrag<AR>::type w) {
+    if constexpr (AR == FSN_ARITH_F32) return w;
+    else return __builtin_bit_cast(typename FsnOperand<AR>::type, w);
+}
 template <int AR>
 __device__ __forceinline__ typename FsnOperand<AR>::type fsn_operand(const f32x4 v) {
     if constexpr (AR == FSN_ARITH_F16) {
@@ -208,7 +237,8 @@ size_t fsn_lstm2_group_bptt_flag_words(int clusters);  // lstm_group_bptt_kernel
 int fsn_lstm2_group_bptt_clusters(int tiles);
 int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const float* wih1T_p, const float* whh0T_p,
                                 const float* save0, const float* save1, float* dg0, float* dg1, float* dx, unsigned* flags,
-                                int Tp, int Nrows, int clusters, int H, hipStream_t s, int arith = FSN_ARITH_F32);
+                                int Tp, int Nrows, int clusters, int H, hipStream_t s, int arith = FSN_ARITH_F32,
+                                const void* w16 = nullptr);
 // fb_chain_bptt_kernels.hip: BPTT of the full-band model's two layers (16 rows, H = 512) as one persistent launch
 bool fsn_fb_chain_bptt_supported(int H, int N);
 int fsn_fb_chain_bptt_max_steps();
@@ -219,6 +249,8 @@ int fsn_launch_fb_chain_bptt(const float* dh1, const float* whh1T_p, const float
                              const float* save0, const float* save1, float* dg0, float* dg1, float* dx, unsigned* flags,
                              int Tp, int N, int H, hipStream_t s);
 int fsn_launch_zero_words(unsigned* p, size_t n, hipStream_t s);  // elementwise_kernels.hip
+// dst[i] = src[i] rounded to fp16 / bf16 (arith = FSN_ARITH_F16 / _BF16): the 16-bit copy of a packed weight buffer
+int fsn_launch_to16(const float* src, void* dst, size_t n, int arith, hipStream_t s);
 // out[0..n) = NaN if *status != 0 (a persistent kernel hit its wait bound); status words of the kernels' flag arrays.
 // The same kernel reports the event to the host: the sticky status record of the caller's stream (fsn_stream_status).
 int fsn_launch_poison_if(const unsigned* status, float* out, size_t n, hipStream_t s);
@@ -258,7 +290,8 @@ size_t fsn_lstm2_group_bptt_status_word(int clusters);
 int fsn_launch_lstm2_group_train(const float* x, long x_ld, int x_cols, int Nrows, const float* wih0_p, const float* whh0_p,
                                  const float* wih1_p, const float* whh1_p, const float* bias0, const float* bias1,
                                  float* hseq0, float* hseq1, float* save0, float* save1, unsigned* flags, int Tp,
-                                 int clusters, int H, hipStream_t s, int arith = FSN_ARITH_F32);  // lstm_group_kernels.hip
+                                 int clusters, int H, hipStream_t s, int arith = FSN_ARITH_F32,
+                                 const void* w16 = nullptr);  // lstm_group_kernels.hip; w16: fsn_launch_to16 of the packed weights
 
 // fb_chain_kernels.hip: the full-band model's two LSTM layers over all frames as one persistent launch
 bool fsn_fb_chain_supported(int H, int Npad);

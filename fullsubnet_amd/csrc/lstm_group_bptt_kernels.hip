@@ -78,7 +78,8 @@ __device__ __forceinline__ bool bptt_poll(unsigned* flags8, unsigned epoch, unsi
 // write-through stores, 32 no tanhf in the cell derivative
 // AR: arithmetic of the products (fsn_mma_k16); everything stored stays fp32
 template <int LAYER, int ABL, int AR>
-__device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int member, f32x4 (*bsh)[BCH * 2 * BU][64]) {
+__device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int member,
+                                          typename FsnWFrag<AR>::type (*bsh)[BCH * 2 * BU][64]) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const int Tp = a.Tp;
@@ -107,7 +108,6 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
     };
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wbase), 0, 0x7fffffff, 0x00020000);
-    const unsigned lane16 = (unsigned)lane * 16u;
 
     // acc[u] += A(16 rows x K) W^T(K x 16 units of group u): n chunks (a multiple of 2 BCH) of the tile behind `xr`
     // (sc1 loads: the partners wrote through) against the packed matrix at element offset b of the weight buffer.
@@ -123,7 +123,8 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
         constexpr int TURN = FSN_BPTT_TURN;  // stages per turn of the A ring
         constexpr int AD = TURN * BCH;       // A fragments in flight (write-through data of other CUs: first touch is far)
         constexpr int NB = BU;       // B fragments a wave holds in registers at a time (NT = 6: fetched in two halves)
-        f32x4 ar[AD], bn[NB];
+        f32x4 ar[AD];
+        typename FsnWFrag<AR>::type bn[NB];
         auto fetch_a = [&](int k) -> f32x4 {
             const int kc = k < n ? k : n - 1;
             if (ABL & 4) return f32x4{0.5f, 0.25f, -0.125f, 0.0625f};
@@ -143,7 +144,7 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
                     int k = s * BCH + c;
                     k = k < n ? k : n - 1;
                     const unsigned ofs = (u < BU ? b : b2) + ((unsigned)(member * BU + u % BU) * BKC + (unsigned)k) * 256u;
-                    bn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, ofs * 4u, 0));
+                    bn[j] = fsn_load_wfrag<AR>(wrsrc, (unsigned)lane, ofs);
                 }
             }
         };
@@ -185,7 +186,7 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
                 } else {  // 16-bit operands: one matrix instruction per tile and K chunk
                     const typename FsnOperand<AR>::type ao = fsn_operand<AR>(av);
 #pragma unroll
-                    for (int u = 0; u < NT; ++u) acc[u] = fsn_mma_k16<AR>(ao, fsn_operand<AR>(bsh[buf][c * NT + u][lane]), acc[u]);
+                    for (int u = 0; u < NT; ++u) acc[u] = fsn_mma_k16<AR>(ao, fsn_wfrag_operand<AR>(bsh[buf][c * NT + u][lane]), acc[u]);
                 }
                 if (c == BCH - 1) {
                     park_b(buf ^ 1, QMAX - 1);
@@ -323,7 +324,7 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
 
 template <int ABL, int AR = FSN_ARITH_F32>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(116))) void lstm2_group_bptt_kernel(const BpttArgs a) {
-    __shared__ f32x4 bsh[2][BCH * 2 * BU][64];  // two stages x (4 chunks x up to 6 column tiles) x 1 KB
+    __shared__ typename FsnWFrag<AR>::type bsh[2][BCH * 2 * BU][64];  // two stages x (4 chunks x up to 6 column tiles) x 1 KB (512 B in 16 bits)
     // first half of the grid: layer 1 (the leading chain), second half: layer 0; cluster members on one XCD when the
     // cluster count allows it (speed only), as in lstm2_group_kernel
     const int half = gridDim.x >> 1;
@@ -370,7 +371,7 @@ size_t fsn_lstm2_group_bptt_status_word(int clusters) { return (size_t)clusters 
 // fsn_lstm_layer_forward's layout; dg0 / dg1 [Tp][Nrows][4H] out; dx [Tp][Nrows][H] scratch (layer 0's dH).
 int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const float* wih1T_p, const float* whh0T_p,
                                 const float* save0, const float* save1, float* dg0, float* dg1, float* dx, unsigned* flags,
-                                int Tp, int Nrows, int clusters, int H, hipStream_t s, int arith) {
+                                int Tp, int Nrows, int clusters, int H, hipStream_t s, int arith, const void* w16) {
     if (H != BH || clusters < 1 || clusters > fsn_lstm2_group_bptt_clusters(Nrows / 16)) {
         fsn_set_error("lstm2_group_bptt: H = 384, clusters * 64 <= rows, one cluster per eight CUs at most");
         return FSN_ERR_ARG;
@@ -383,9 +384,13 @@ int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const fl
             fsn_set_error("lstm2_group_bptt: the packed weight matrices must share one buffer");
             return FSN_ERR_ARG;
         }
+    if (arith != FSN_ARITH_F32 && !w16) {
+        fsn_set_error("lstm2_group_bptt: 16-bit arithmetic needs the 16-bit copy of the packed weights");
+        return FSN_ERR_ARG;
+    }
     BpttArgs a{};
     a.dh1 = dh1;
-    a.wbase = lo;
+    a.wbase = arith == FSN_ARITH_F32 ? lo : static_cast<const float*>(w16);  // the 16-bit mirror of the buffer from `lo`
     a.o_whh1T = (unsigned)(whh1T_p - lo);
     a.o_wih1T = (unsigned)(wih1T_p - lo);
     a.o_whh0T = (unsigned)(whh0T_p - lo);

@@ -110,7 +110,7 @@ struct GrpCl {
 // training); data movement and everything stored are the same in every mode
 template <int LAYER, int ABL, bool TRAIN, int NCL, bool SAVE, int AR>
 __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int cluster_b, int member,
-                                           f32x4 (*bsh)[GU * 4 * FSN_GRP_CPS][64], float (*bias_sh)[16]) {
+                                           typename FsnWFrag<AR>::type (*bsh)[GU * 4 * FSN_GRP_CPS][64], float (*bias_sh)[16]) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const int Tp = a.Tp;
@@ -170,7 +170,6 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
     // pointers in vector registers)
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wbase), 0, 0x7fffffff, 0x00020000);
-    const unsigned lane16 = (unsigned)lane * 16u;
     // A operand: xa (registers, layer-0 input) or tile `at1` / `at2` (byte offset) of exchange buffer ab1 / ab2 (0 / 1)
     // (descriptors by value: a reference to one of two descriptors puts both on the stack)
     auto kloop = [&](f32x4 (&acc)[GU][4], const f32x4* xa, const __amdgpu_buffer_rsrc_t r1, unsigned at1, unsigned b1,
@@ -181,7 +180,8 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
         // are therefore requested AD chunks ahead (a register ring, indexed statically by unrolling the loop AD-fold);
         // the weight fragments (L2 hits) one chunk ahead, through LDS.
         constexpr int AD = FSN_GRP_AD;
-        f32x4 ar[AD], bn[GU];
+        f32x4 ar[AD];
+        typename FsnWFrag<AR>::type bn[GU];
         auto fetch_a = [&](int k) -> f32x4 {
             const int kc = k < n ? k : n - 1;
             if (ABL & 32) return f32x4{0.5f, 0.25f, 0.125f, 0.0625f};
@@ -200,7 +200,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
             for (int j = 0; j < GU; ++j) {
                 const int f = wave * GU + j, u = f >> 2, g = f & 3;
                 const unsigned ofs = bb + ((unsigned)(g * GKC + member * GU + u) * cs + (unsigned)kk) * 256u;
-                bn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane16, ofs * 4u, 0));
+                bn[j] = fsn_load_wfrag<AR>(wrsrc, (unsigned)lane, ofs);
             }
         };
 #pragma unroll
@@ -242,7 +242,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
                         for (int u = 0; u < GU; ++u)
 #pragma unroll
                             for (int g = 0; g < 4; ++g)
-                                acc[u][g] = fsn_mma_k16<AR>(ao, fsn_operand<AR>(bsh[buf][c * GU * 4 + u * 4 + g][lane]), acc[u][g]);
+                                acc[u][g] = fsn_mma_k16<AR>(ao, fsn_wfrag_operand<AR>(bsh[buf][c * GU * 4 + u * 4 + g][lane]), acc[u][g]);
                     }
 #pragma unroll
                     for (int j = 0; j < GU; ++j) bsh[buf ^ 1][c * GU * 4 + wave * GU + j][lane] = bn[j];
@@ -443,7 +443,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
 template <int ABL, bool TRAIN = false, int NCL = 1, bool SAVE = TRAIN, int AR = FSN_ARITH_F32>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void lstm2_group_kernel(const GrpArgs a) {
     // weight fragments of one K chunk, shared by the four waves: two stages x 12 fragments x 1 KB
-    __shared__ f32x4 bsh[2][GU * 4 * FSN_GRP_CPS][64];
+    __shared__ typename FsnWFrag<AR>::type bsh[2][GU * 4 * FSN_GRP_CPS][64];
     __shared__ float bias_sh[GU * 4][16];
     // The first half of the grid runs layer 0, the second half layer 1: blocks are handed out in order, one per CU
     // before any CU gets its second, so that every CU ends up with one workgroup of each layer (speed only).  Within a
@@ -559,13 +559,14 @@ int fsn_launch_lstm2_group(const FsnSbInput* xin, const float* whh0_p, const flo
 int fsn_launch_lstm2_group_train(const float* x, long x_ld, int x_cols, int Nrows, const float* wih0_p, const float* whh0_p,
                                  const float* wih1_p, const float* whh1_p, const float* bias0, const float* bias1,
                                  float* hseq0, float* hseq1, float* save0, float* save1, unsigned* flags, int Tp,
-                                 int clusters, int H, hipStream_t s, int arith) {
+                                 int clusters, int H, hipStream_t s, int arith, const void* w16) {
     if (H != GH || clusters < 1 || (long)clusters * GROWS > Nrows || (size_t)Tp * Nrows * GH * 4 > 0x7fffffffull) {
         fsn_set_error("lstm2_group (training): H = 384, clusters * 64 <= rows, hidden sequence below 2 GB");
         return FSN_ERR_ARG;
     }
-    if (arith != FSN_ARITH_F32 && !((arith == FSN_ARITH_F16 || arith == FSN_ARITH_BF16) && save0 && save1)) {
-        fsn_set_error("lstm2_group: arithmetic %d is built for the training form (fp16 / bf16 operands) only", arith);
+    if (arith != FSN_ARITH_F32 && !((arith == FSN_ARITH_F16 || arith == FSN_ARITH_BF16) && save0 && save1 && w16)) {
+        fsn_set_error("lstm2_group: arithmetic %d is built for the training form (fp16 / bf16 operands, with the 16-bit copy "
+                      "of the packed weights) only", arith);
         return FSN_ERR_ARG;
     }
     if (fsn_launch_zero_words(flags, fsn_lstm2_group_flag_words(clusters), s) != FSN_OK) return FSN_ERR_LAUNCH;
@@ -584,7 +585,9 @@ int fsn_launch_lstm2_group_train(const float* x, long x_ld, int x_cols, int Nrow
     a.xin.F = 1;
     a.xin.kin_chunks = x_cols > 16 ? 2 : 1;
     a.xin.bias = bias0;
-    a.wbase = lo;
+    // 16-bit arithmetic: the kernel fetches its weight fragments from w16, the 16-bit mirror (element for element) of
+    // the packed buffer that starts at the lowest of the four matrices
+    a.wbase = arith == FSN_ARITH_F32 ? lo : static_cast<const float*>(w16);
     a.o_wih0 = (unsigned)(wih0_p - lo);
     a.o_whh0 = (unsigned)(whh0_p - lo);
     a.o_wih1 = (unsigned)(wih1_p - lo);
