@@ -38,6 +38,9 @@ constexpr int BKC = BG / 16;      // K chunks (96)
 constexpr int BM = 8;             // members per cluster and layer
 constexpr int BU = BH / 16 / BM;  // 16-unit groups per member (3)
 constexpr int BROWS = 64;         // rows per cluster
+#ifndef FSN_BPTT_TURN16
+#define FSN_BPTT_TURN16 2  // the same under the 16-bit arithmetic (the K loop is 8x shorter: the A operand's latency shows)
+#endif
 #ifndef FSN_BPTT_BCH
 #define FSN_BPTT_BCH 4  // probe: 4 -> 12.8 ms, 6 -> 13.0
 #endif
@@ -120,7 +123,7 @@ __device__ __forceinline__ void bptt_body(const BpttArgs& a, int cluster, int me
     // a 69 us step), while behind sixteen chunks of buffered MFMA work the same wait is covered.
     auto kloop = [&](auto& acc, const __amdgpu_buffer_rsrc_t xr, unsigned b, unsigned b2, int n, auto&& mid) {
         constexpr int NT = (int)(sizeof(acc) / sizeof(f32x4));
-        constexpr int TURN = FSN_BPTT_TURN;  // stages per turn of the A ring
+        constexpr int TURN = AR == FSN_ARITH_F32 ? FSN_BPTT_TURN : FSN_BPTT_TURN16;  // stages per turn of the A ring
         constexpr int AD = TURN * BCH;       // A fragments in flight (write-through data of other CUs: first touch is far)
         constexpr int NB = BU;       // B fragments a wave holds in registers at a time (NT = 6: fetched in two halves)
         f32x4 ar[AD];
