@@ -60,6 +60,14 @@ STATE_KEYS = [
 ]
 
 
+class Lstm2Stack(ctypes.Structure):
+    """fsn_lstm2_stack (include/fsn_hip.h)."""
+    _fields_ = ([("x", ctypes.c_void_p), ("ldx", ctypes.c_long)] +
+                [(n, ctypes.c_void_p) for n in ("w_ih0", "w_hh0", "b_ih0", "b_hh0", "w_ih1", "w_hh1", "b_ih1", "b_hh1")] +
+                [("N", ctypes.c_int), ("I", ctypes.c_int), ("H0", ctypes.c_int), ("H1", ctypes.c_int),
+                 ("hseq1", ctypes.c_void_p)])
+
+
 class AdamCfg(ctypes.Structure):
     _fields_ = [("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
                 ("max_norm", ctypes.c_float), ("step", ctypes.c_int)]
@@ -126,6 +134,9 @@ SIGNATURES = {
     "fsn_lstm2_fwd_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "fsn_lstm2_forward": (_c.c_int, [_f32p, _c.c_long] + [_f32p] * 8 + [_c.c_int] * 5 + [_f32p, _c.c_void_p, _c.c_size_t,
                                                                                          _c.c_void_p]),
+    "fsn_lstm2_multi_is_persistent": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_int]),
+    "fsn_lstm2_multi_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_void_p, _c.c_int]),
+    "fsn_lstm2_forward_multi": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "fsn_lstm_layer_packed_bytes": (_c.c_size_t, [_c.c_int, _c.c_int]),
     "fsn_lstm_layer_pack": (_c.c_int, [_f32p, _f32p, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_size_t,
                                        _c.c_void_p]),

@@ -243,6 +243,6 @@ int fsn_launch_fb_chain_bptt(const float* dh1, const float* whh1T_p, const float
     a.status = flags + fsn_fb_chain_bptt_status_word();
     a.spin_ticks = fsn_spin_ticks();
     a.Tp = Tp;
-    hipLaunchKernelGGL(fb_chain_bptt_kernel, dim3(2 * QNW), dim3(256), 0, s, a);
+    FSN_PERSIST_LAUNCH(fb_chain_bptt_kernel, dim3(2 * QNW), dim3(256), s, a);
     return fsn_check_launch("fb_chain_bptt_kernel");
 }

@@ -333,9 +333,9 @@ namespace {
 template <int CH, bool SAVE>
 void chain_launch(const ChainArgs& a, hipStream_t s) {
     const dim3 grid(2 * (CH / 4)), block(256);
-    if (a.RT == 1) hipLaunchKernelGGL((fb_chain_kernel<CH, 4, 0, SAVE>), grid, block, 0, s, a);
-    else if (a.RT == 2) hipLaunchKernelGGL((fb_chain_kernel<CH, 2, 0, SAVE>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((fb_chain_kernel<CH, 1, 0, SAVE>), grid, block, 0, s, a);
+    if (a.RT == 1) FSN_PERSIST_LAUNCH((fb_chain_kernel<CH, 4, 0, SAVE>), grid, block, s, a);
+    else if (a.RT == 2) FSN_PERSIST_LAUNCH((fb_chain_kernel<CH, 2, 0, SAVE>), grid, block, s, a);
+    else FSN_PERSIST_LAUNCH((fb_chain_kernel<CH, 1, 0, SAVE>), grid, block, s, a);
 }
 }  // namespace
 

@@ -11,6 +11,7 @@
 
 #include <atomic>
 #include <map>
+#include <vector>
 #include <mutex>
 #include <utility>
 
@@ -84,16 +85,59 @@ static std::atomic<int> g_persist_timeout_ms{20000};  // fsn_set_persistent_time
 
 // Persistent kernels whose workgroups wait for each other (the group kernel, the full-band chain) need ALL their
 // workgroups resident at once.  Two of them launched from different streams could each take a part of the chip and wait
-// for the rest until the spin bound.  So these launches are ordered across the streams of a device: a launch waits for
-// the completion event of the previous one (nothing else of the two streams is ordered).  Not under stream capture: the
-// replays of a graph are ordered by whoever launches them.
+// for the rest until the spin bound.  So these launches are admitted against a residency budget per device: every
+// launcher reports its kernel's footprint (fsn_persist_admit: grid, resident workgroups per CU by the occupancy API)
+// right before the launch, and the launch waits for the completion events of earlier persistent launches on OTHER
+// streams, oldest first, until the set that may run beside it is provably placeable whatever order the dispatcher
+// hands out workgroups in:
+//   a CU holding a_j workgroups of kernel j is "used" u = sum_j a_j / occ_j in the model (occ_j = resident workgroups
+//   per CU of kernel j alone; the model is conservative: where it has room for a workgroup, the hardware has);
+//   a workgroup of kernel k finds no CU only if EVERY CU has u > 1 - 1 / occ_k, i.e. u >= umin(k), the smallest sum of
+//   the set's workgroup sizes above that threshold; all CUs together then hold >= CUs x umin(k), while the kernels of
+//   the set can place at most sum_j grid_j / occ_j = CUs x sum_j frac_j.  Hence: admitted iff sum_j frac_j < umin(k)
+//   for every k of the set.
+// One kernel alone is always admitted (its own grid was checked against occ x CUs at plan time).  Examples on 256 CUs:
+// two chain launches of H = 384 with two row tiles (192 workgroups, 2 per CU each) run side by side, a third waits; two
+// group launches of 28 clusters (448 workgroups, 4 per CU) do not.  Nothing else of the streams is ordered.  Not under
+// stream capture: the replays of a graph are ordered by whoever launches them.
+struct PersistEntry {
+    hipEvent_t ev;
+    hipStream_t stream;
+    double frac;  // grid / (occ x CUs)
+    int occ;
+};
 struct PersistGate {
-    hipEvent_t ev = nullptr;
-    hipStream_t last = nullptr;
-    bool any = false;
+    std::vector<PersistEntry> live;
+    std::vector<hipEvent_t> pool;
 };
 static std::mutex g_persist_mutex;
 static std::map<int, PersistGate> g_persist;
+// umin(k) in units of 1 / 840 (= lcm(1 .. 8); occupancies above 8 count as 8, which only makes workgroups larger)
+static int persist_umin(const std::vector<int>& occs, int occ_k) {
+    bool reach[841] = {};
+    reach[0] = true;
+    for (int o : occs) {
+        const int sz = 840 / o;
+        for (int u = sz; u <= 840; ++u)
+            if (reach[u - sz]) reach[u] = true;  // unbounded multiples, ascending
+    }
+    for (int u = 840 - 840 / occ_k + 1; u <= 840; ++u)
+        if (reach[u]) return u;
+    return 1 << 20;  // no CU state blocks kernel k
+}
+static bool persist_set_fits(const std::vector<const PersistEntry*>& set) {
+    std::vector<int> occs;
+    double sum = 0.0;
+    for (const PersistEntry* e : set) {
+        occs.push_back(e->occ);
+        sum += e->frac;
+    }
+    for (const PersistEntry* e : set)
+        if (!(sum * 840.0 < (double)persist_umin(occs, e->occ))) return false;
+    return true;
+}
+class PersistLaunch;
+static thread_local PersistLaunch* t_persist = nullptr;
 class PersistLaunch {
   public:
     explicit PersistLaunch(hipStream_t s) : s_(s), lock_(g_persist_mutex) {
@@ -105,27 +149,70 @@ class PersistLaunch {
         int dev = 0;
         (void)hipGetDevice(&dev);
         gate_ = &g_persist[dev];
-        if (!gate_->ev && hipEventCreateWithFlags(&gate_->ev, hipEventDisableTiming) != hipSuccess) {
-            gate_->ev = nullptr;
-            gate_ = nullptr;
-            return;
+        // retire what has completed
+        std::vector<PersistEntry>& live = gate_->live;
+        for (size_t i = 0; i < live.size();) {
+            if (hipEventQuery(live[i].ev) == hipSuccess) {
+                gate_->pool.push_back(live[i].ev);
+                live.erase(live.begin() + (long)i);
+            } else {
+                (void)hipGetLastError();
+                ++i;
+            }
         }
-        if (gate_->any && gate_->last != s) (void)hipStreamWaitEvent(s, gate_->ev, 0);
+        t_persist = this;
+    }
+    // the launcher's report, right before its launch (fsn_persist_admit)
+    void admit(double frac, int occ) {
+        if (!gate_) return;
+        me_.frac = frac;
+        me_.occ = occ < 1 ? 1 : occ > 8 ? 8 : occ;
+        admitted_ = true;
+        std::vector<const PersistEntry*> set;
+        for (const PersistEntry& e : gate_->live)
+            if (e.stream != s_) set.push_back(&e);  // same stream: ordered anyway
+        set.push_back(&me_);
+        while (set.size() > 1 && !persist_set_fits(set)) {
+            (void)hipStreamWaitEvent(s_, set.front()->ev, 0);  // oldest first
+            set.erase(set.begin());
+        }
     }
     ~PersistLaunch() {
+        t_persist = nullptr;
         if (!gate_) return;
-        if (hipEventRecord(gate_->ev, s_) == hipSuccess) {
-            gate_->last = s_;
-            gate_->any = true;
+        hipEvent_t ev = nullptr;
+        if (!gate_->pool.empty()) {
+            ev = gate_->pool.back();
+            gate_->pool.pop_back();
+        } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(s_);  // no event to order later launches by: drain instead
+            return;
         }
+        if (hipEventRecord(ev, s_) != hipSuccess) {
+            (void)hipGetLastError();
+            gate_->pool.push_back(ev);
+            (void)hipStreamSynchronize(s_);
+            return;
+        }
+        me_.ev = ev;
+        me_.stream = s_;
+        if (!admitted_) {  // a launcher that did not report: treated as filling the chip
+            me_.frac = 1.0;
+            me_.occ = 1;
+        }
+        gate_->live.push_back(me_);
     }
     PersistLaunch(const PersistLaunch&) = delete;
     PersistLaunch& operator=(const PersistLaunch&) = delete;
+    bool admitted() const { return admitted_ || !gate_; }
 
   private:
     hipStream_t s_;
     std::unique_lock<std::mutex> lock_;
     PersistGate* gate_ = nullptr;
+    PersistEntry me_{};
+    bool admitted_ = false;
 };
 
 // What the running call works on (set by CallScope for the duration of one entry point on this host thread).
@@ -218,15 +305,17 @@ unsigned long long fsn_spin_ticks() {
     }
     return (unsigned long long)g_persist_timeout_ms.load(std::memory_order_relaxed) * (unsigned long long)khz;
 }
-bool fsn_grid_fits(const void* kernel, int block_threads, unsigned grid) {
+// resident workgroups per CU of `kernel` alone (occupancy API, cached per device); 0 on failure
+static int persist_occupancy(const void* kernel, int block_threads, int* cus_out) {
     static std::mutex m;
     static std::map<std::pair<const void*, int>, int> per_cu;  // (kernel, device) -> resident workgroups per CU
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
         (void)hipGetLastError();
-        return false;
+        return 0;
     }
+    if (cus_out) *cus_out = cus;
     std::lock_guard<std::mutex> lock(m);
     auto it = per_cu.find(std::make_pair(kernel, dev));
     if (it == per_cu.end()) {
@@ -237,7 +326,24 @@ bool fsn_grid_fits(const void* kernel, int block_threads, unsigned grid) {
         }
         it = per_cu.emplace(std::make_pair(kernel, dev), n).first;
     }
-    return (unsigned long long)it->second * (unsigned long long)cus >= grid;
+    return it->second;
+}
+bool fsn_grid_fits(const void* kernel, int block_threads, unsigned grid) {
+    int cus = 0;
+    const int occ = persist_occupancy(kernel, block_threads, &cus);
+    return (unsigned long long)occ * (unsigned long long)cus >= grid;
+}
+// Called by every launcher of a kernel that needs its whole grid resident, right before the launch (inside the API
+// function's FSN_PERSIST_BEGIN scope; a no-op outside one, e.g. under stream capture).
+void fsn_persist_admit(const void* kernel, int block_threads, unsigned grid) {
+    if (!t_persist) return;
+    int cus = 0;
+    const int occ = persist_occupancy(kernel, block_threads, &cus);
+    if (occ < 1 || cus < 1) {
+        t_persist->admit(1.0, 1);
+        return;
+    }
+    t_persist->admit((double)grid / ((double)occ * (double)cus), occ);
 }
 // The sticky record of the running call's stream (created on first use; not under stream capture, where pinned
 // allocations are not allowed: a captured launch then only poisons its outputs).
@@ -1934,6 +2040,145 @@ static LayerPacked layer_packed_layout(int I, int H) {
     p.total = p.bias + fsn_round_up_sz(4 * (size_t)H, 64);
     return p;
 }
+// ---- several independent two-layer stacks over the same frames ------------------------------------------------------
+// (improved_fullsubnet/model.py:402-449: the band sections' SequenceModels - B x {20, 25, 6, 4} rows at 48 kHz, input
+// widths 62 .. 180 - all see the same T frames.)  When every stack is H = 384 twice and together they fill most of the
+// chip's workgroup sets, all of them run as ONE persistent launch of the group kernel (GX form: projection GEMM per
+// stack, then lstm2_group_multi_kernel); otherwise stack by stack through fsn_lstm2_forward's forms.
+static int lstm2_multi_clusters(int n, const fsn_lstm2_stack* st, int T) {
+    const int cap = fsn_lstm2_group_multi_cap();
+    if (cap == 0 || n < 1 || n > 8 || T < 4) return 0;
+    int clusters = 0;
+    for (int k = 0; k < n; ++k) {
+        if (st[k].H0 != 384 || st[k].H1 != 384 || st[k].N % 16 || (size_t)T * st[k].N * 384 * 4 > 0x7fffffffull) return 0;
+        clusters += (st[k].N + 63) / 64;
+    }
+    // below ~3/4 of the sets the stacks are faster as wavefronts on their own streams (a persistent step costs the same
+    // ~58 us whatever the cluster count)
+    return clusters <= cap && 4 * clusters >= 3 * cap ? clusters : 0;
+}
+struct Lstm2MultiPlan {
+    float *whh0, *wih1, *whh1, *wih0, *b0, *b1, *gx, *hseq0;
+};
+static void lstm2_multi_carve(int n, const fsn_lstm2_stack* st, int T, int clusters, Carver& cv, Lstm2MultiPlan* out,
+                              unsigned** flags) {
+    // the recurrent matrices of all stacks first (one buffer: 32-bit offsets inside the kernel)
+    for (int k = 0; k < n; ++k) {
+        const size_t G = 4 * (size_t)st[k].H0, H = st[k].H0;
+        Lstm2MultiPlan p{};
+        p.whh0 = cv.take<float>(G * H);
+        p.wih1 = cv.take<float>(G * H);
+        p.whh1 = cv.take<float>(G * H);
+        if (out) out[k] = p;
+    }
+    for (int k = 0; k < n; ++k) {
+        const size_t G = 4 * (size_t)st[k].H0, H = st[k].H0, Ipad = fsn_round_up(st[k].I, 16);
+        Lstm2MultiPlan p = out ? out[k] : Lstm2MultiPlan{};
+        p.wih0 = cv.take<float>(G * Ipad);
+        p.b0 = cv.take<float>(G);
+        p.b1 = cv.take<float>(G);
+        p.gx = cv.take<float>((size_t)T * st[k].N * G);
+        p.hseq0 = cv.take<float>((size_t)T * st[k].N * H);
+        if (out) out[k] = p;
+    }
+    unsigned* f = cv.take<unsigned>(fsn_lstm2_group_flag_words(clusters));
+    if (flags) *flags = f;
+}
+static int check_lstm2_stacks(int n, const fsn_lstm2_stack* st, int T) {
+    FSN_REQUIRE(st && n >= 1 && n <= 8, "lstm2 multi: 1 .. 8 stacks (got %d)", n);
+    for (int k = 0; k < n; ++k) {
+        FSN_TRY(check_lstm_layer(T, st[k].N, st[k].I, st[k].H0, st[k].ldx));
+        FSN_REQUIRE(st[k].H1 >= 64 && st[k].H1 % 64 == 0, "lstm2 multi: stack %d: second hidden size %d must be a multiple of 64", k,
+                    st[k].H1);
+    }
+    return FSN_OK;
+}
+extern "C" int fsn_lstm2_multi_is_persistent(int n, const fsn_lstm2_stack* stacks, int T) {
+    if (!stacks || n < 1 || n > 8) return 0;
+    for (int k = 0; k < n; ++k)
+        if (stacks[k].N < 16 || stacks[k].I < 1) return 0;
+    return lstm2_multi_clusters(n, stacks, T) > 0 ? 1 : 0;
+}
+extern "C" size_t fsn_lstm2_multi_workspace_bytes(int n, const fsn_lstm2_stack* stacks, int T) {
+    if (check_lstm2_stacks(n, stacks, T) != FSN_OK) return 0;
+    if (const int clusters = lstm2_multi_clusters(n, stacks, T)) {
+        Carver cv(nullptr);
+        lstm2_multi_carve(n, stacks, T, clusters, cv, nullptr, nullptr);
+        return fsn_round_up_sz(cv.off, 256);
+    }
+    size_t most = 0;  // stack by stack: one stack's workspace at a time
+    for (int k = 0; k < n; ++k) {
+        const size_t b = fsn_lstm2_fwd_workspace_bytes(T, stacks[k].N, stacks[k].I, stacks[k].H0, stacks[k].H1);
+        most = b > most ? b : most;
+    }
+    return most;
+}
+extern "C" int fsn_lstm2_forward_multi(int n, const fsn_lstm2_stack* stacks, int T, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    CallScope scope(stream);
+    FSN_TRY(check_lstm2_stacks(n, stacks, T));
+    FSN_REQUIRE(workspace, "NULL pointer argument");
+    for (int k = 0; k < n; ++k) {
+        const fsn_lstm2_stack& q = stacks[k];
+        FSN_REQUIRE(q.x && q.w_ih0 && q.w_hh0 && q.b_ih0 && q.b_hh0 && q.w_ih1 && q.w_hh1 && q.b_ih1 && q.b_hh1 && q.hseq1,
+                    "lstm2 multi: stack %d: NULL pointer argument", k);
+    }
+    if (workspace_bytes < fsn_lstm2_multi_workspace_bytes(n, stacks, T)) {
+        fsn_set_error("lstm2 multi: workspace too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    const int clusters = lstm2_multi_clusters(n, stacks, T);
+    if (!clusters) {
+        for (int k = 0; k < n; ++k) {
+            const fsn_lstm2_stack& q = stacks[k];
+            FSN_TRY(fsn_lstm2_forward(q.x, q.ldx, q.w_ih0, q.w_hh0, q.b_ih0, q.b_hh0, q.w_ih1, q.w_hh1, q.b_ih1, q.b_hh1, T, q.N,
+                                      q.I, q.H0, q.H1, q.hseq1, workspace, workspace_bytes, stream));
+        }
+        return FSN_OK;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Carver cv(workspace);
+    Lstm2MultiPlan plan[8];
+    unsigned* flags = nullptr;
+    lstm2_multi_carve(n, stacks, T, clusters, cv, plan, &flags);
+    FsnGroupStack gs[8];
+    for (int k = 0; k < n; ++k) {
+        const fsn_lstm2_stack& q = stacks[k];
+        const Lstm2MultiPlan& p = plan[k];
+        const int H = q.H0, G = 4 * H, Ipad = fsn_round_up(q.I, 16);
+        FSN_TRY(fsn_launch_pack(q.w_ih0, p.wih0, G, q.I, G, Ipad, s));
+        FSN_TRY(fsn_launch_pack(q.w_hh0, p.whh0, G, H, G, H, s));
+        FSN_TRY(fsn_launch_pack(q.w_ih1, p.wih1, G, H, G, H, s));
+        FSN_TRY(fsn_launch_pack(q.w_hh1, p.whh1, G, H, G, H, s));
+        FSN_TRY(fsn_launch_bias_sum(q.b_ih0, q.b_hh0, p.b0, G, G, s));
+        FSN_TRY(fsn_launch_bias_sum(q.b_ih1, q.b_hh1, p.b1, G, G, s));
+        FsnGemmA a{};
+        a.kind = 0;
+        a.p0 = q.x;
+        a.ld = q.ldx;
+        FsnGemmC c{};
+        c.kind = 0;
+        c.p0 = p.gx;
+        c.bias = p.b0;
+        FSN_TRY(fsn_launch_gemm(a, p.wih0, c, T * (q.N / 16), G / 16, Ipad / 16, s));
+        FsnGroupStack& g = gs[k];
+        g.gx = p.gx;
+        g.whh0_p = p.whh0;
+        g.wih1_p = p.wih1;
+        g.whh1_p = p.whh1;
+        g.bias1 = p.b1;
+        g.hseq0 = p.hseq0;
+        g.hseq1 = q.hseq1;
+        g.N = q.N;
+    }
+    FSN_PERSIST_BEGIN(s);
+    FSN_TRY(fsn_launch_lstm2_group_multi(n, gs, flags, T, 384, s));
+    for (int k = 0; k < n; ++k)
+        FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_status_word(clusters), stacks[k].hseq1,
+                                     (size_t)T * stacks[k].N * stacks[k].H1, s));
+    return FSN_OK;
+}
+
 extern "C" size_t fsn_lstm_layer_packed_bytes(int I, int H) {
     if (I < 1 || H < 64 || H % 64) return 0;
     return layer_packed_layout(I, H).total * sizeof(float);

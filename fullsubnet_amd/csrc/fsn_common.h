@@ -268,6 +268,14 @@ bool fsn_persistent_allowed();        // false: the caller switched these kernel
 unsigned long long fsn_spin_ticks();  // the wait bound in ticks of wall_clock64() on the current device
 // whole grid co-resident on an idle device?  (blocks per CU from hipOccupancyMaxActiveBlocksPerMultiprocessor, cached)
 bool fsn_grid_fits(const void* kernel, int block_threads, unsigned grid);
+// every launch of such a kernel reports its footprint first: the launch then waits for earlier persistent launches on
+// other streams until the set that may run beside it is provably placeable (fsn_api.hip, PersistLaunch)
+void fsn_persist_admit(const void* kernel, int block_threads, unsigned grid);
+#define FSN_PERSIST_LAUNCH(kernel, grid, block, s, ...)                                   \
+    do {                                                                                  \
+        fsn_persist_admit((const void*)(kernel), (int)(block).x, (unsigned)(grid).x);     \
+        hipLaunchKernelGGL((kernel), grid, block, 0, s, __VA_ARGS__);                     \
+    } while (0)
 unsigned* fsn_ctx_sticky();           // device-visible sticky status record {status, events} of the running call's stream
 
 #ifdef __HIPCC__
@@ -287,6 +295,15 @@ size_t fsn_fb_chain_status_word();
 size_t fsn_lstm2_group_status_word(int clusters);
 size_t fsn_lstm2_group_bptt_status_word(int clusters);
 
+// one stack of fsn_launch_lstm2_group_multi (lstm_group_kernels.hip)
+struct FsnGroupStack {
+    const float* gx;
+    const float *whh0_p, *wih1_p, *whh1_p, *bias1;
+    float *hseq0, *hseq1;
+    int N;
+};
+int fsn_lstm2_group_multi_cap();
+int fsn_launch_lstm2_group_multi(int n, const FsnGroupStack* st, unsigned* flags, int Tp, int H, hipStream_t s);
 int fsn_launch_lstm2_group_train(const float* x, long x_ld, int x_cols, int Nrows, const float* wih0_p, const float* whh0_p,
                                  const float* wih1_p, const float* whh1_p, const float* bias0, const float* bias1,
                                  float* hseq0, float* hseq1, float* save0, float* save1, unsigned* flags, int Tp,

@@ -410,9 +410,9 @@ int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const fl
     a.Tp = Tp;
     a.Nrows = Nrows;
     const dim3 grid((unsigned)clusters * BM * 2), block(256);
-    if (arith == FSN_ARITH_F16) hipLaunchKernelGGL((lstm2_group_bptt_kernel<0, FSN_ARITH_F16>), grid, block, 0, s, a);
-    else if (arith == FSN_ARITH_BF16) hipLaunchKernelGGL((lstm2_group_bptt_kernel<0, FSN_ARITH_BF16>), grid, block, 0, s, a);
-    else if (arith == FSN_ARITH_F32) hipLaunchKernelGGL(lstm2_group_bptt_kernel<0>, grid, block, 0, s, a);
+    if (arith == FSN_ARITH_F16) FSN_PERSIST_LAUNCH((lstm2_group_bptt_kernel<0, FSN_ARITH_F16>), grid, block, s, a);
+    else if (arith == FSN_ARITH_BF16) FSN_PERSIST_LAUNCH((lstm2_group_bptt_kernel<0, FSN_ARITH_BF16>), grid, block, s, a);
+    else if (arith == FSN_ARITH_F32) FSN_PERSIST_LAUNCH(lstm2_group_bptt_kernel<0>, grid, block, s, a);
     else {
         fsn_set_error("lstm2_group_bptt: arithmetic %d unknown", arith);
         return FSN_ERR_ARG;

@@ -64,6 +64,28 @@ struct GrpArgs {
     float *gates0, *cseq0, *gates1, *cseq1;
     int Nrows;
     int nclusters;         // clusters of this launch (the grid has min(nclusters, CUs / 8) workgroup sets)
+    // GX form (with TRAIN): layer 0 starts from its projection, computed beforehand by a GEMM (any input width) - gx as
+    // fragment tiles [Tp][gx_tiles][4H/16][64][4], bias included - and Nrows need not be a multiple of 64 (the last
+    // cluster's missing 16-row tiles load a valid tile's rows and store nothing)
+    const float* gx;
+    int gx_tiles;
+};
+
+// Several weight sets in one launch (GX form): the sections of improved_fullsubnet/model.py:402-449 are independent
+// two-layer stacks over the same frames, each with its own weights, input width and row count.  Set i owns clusters
+// [cluster0_i, cluster0_{i+1}).
+constexpr int GSETS = 8;
+struct GrpSet {
+    const float* gx;
+    float *hseq0, *hseq1;
+    const float* bias1;
+    unsigned o_whh0, o_wih1, o_whh1;  // element offsets from GrpArgs::wbase
+    int N;                            // rows of the set (a multiple of 16)
+    int cluster0;
+};
+struct GrpSets {
+    GrpSet s[GSETS];
+    int n;
 };
 
 __device__ __forceinline__ void store_sc1(float* p, float v) {
@@ -95,6 +117,7 @@ struct GrpCl {
     int cluster;
     int row_l;    // this lane's A-operand row (local to the launch)
     bool row_ok;
+    bool tile_ok;  // GX form: this wave's 16-row tile exists (wave-uniform)
     long ng;
     int xb, xf;   // layer-0 input of this lane's row: (b, f)
     float *hx0, *hx1;
@@ -108,7 +131,7 @@ struct GrpCl {
 // SAVE (with TRAIN): also keep the activated gates and cell states (the training forward)
 // AR: arithmetic of the products (fsn_mma_k16: FSN_ARITH_F32, or 16-bit operands with fp32 accumulation for autocast
 // training); data movement and everything stored are the same in every mode
-template <int LAYER, int ABL, bool TRAIN, int NCL, bool SAVE, int AR>
+template <int LAYER, int ABL, bool TRAIN, int NCL, bool SAVE, int AR, bool GX = false>
 __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int cluster_b, int member,
                                            typename FsnWFrag<AR>::type (*bsh)[GU * 4 * FSN_GRP_CPS][64], float (*bias_sh)[16]) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -129,6 +152,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
         k.xrsrc0 = __builtin_amdgcn_make_buffer_rsrc(k.hx0, 0, 0x7fffffff, 0x00020000);
         k.xrsrc1 = __builtin_amdgcn_make_buffer_rsrc(k.hx1, 0, 0x7fffffff, 0x00020000);
         k.row_ok = k.row_l < x.N;
+        k.tile_ok = !GX || cluster * GROWS + wave * 16 < a.Nrows;
         k.ng = k.row_l + x.row0;
         k.xb = k.row_ok ? (int)(k.ng / x.F) : 0;
         k.xf = k.row_ok ? (int)(k.ng % x.F) : 0;
@@ -140,7 +164,10 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
     };
     // this lane's A fragment inside a [64][H] tile of the exchange buffers (byte offset), read with sc1 buffer loads: the
     // partners stored write-through (sc1), so an sc1 load - never served by this CU's L1 - needs no acquire fence
-    const unsigned a_off = (unsigned)(((wave * 16 + lr) * GH + 4 * lq) * 4);
+    // (GX form: a missing tile of the last cluster reads the cluster's first tile instead)
+    static_assert(!GX || (TRAIN && NCL == 1 && !SAVE), "the GX form is the general inference form, one cluster per set");
+    const bool my_tile = !GX || cluster_a * GROWS + wave * 16 < a.Nrows;
+    const unsigned a_off = (unsigned)((((my_tile ? wave * 16 : 0) + lr) * GH + 4 * lq) * 4);
     auto xload = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16));  // aux 16 = sc1
     };
@@ -149,7 +176,9 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
     // registers decide between fitting and spilling there; with one cluster the registers are faster)
     constexpr bool kBiasLds = NCL > 1 || FSN_GRP_BIAS_LDS;
     float bias[GU][4];
-    if (kBiasLds) {
+    if (GX && LAYER == 0) {
+        // the projection tiles carry layer 0's bias
+    } else if (kBiasLds) {
         if (threadIdx.x < GU * 4 * 16) {
             const int f = threadIdx.x >> 4, u = f >> 2, g = f & 3, l = threadIdx.x & 15;
             bias_sh[f][l] = (LAYER ? a.bias1 : a.xin.bias)[(g * GKC + member * GU + u) * 16 + l];
@@ -287,6 +316,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
                 k.c[u][i] = cn;
                 float* hp = hdst + (size_t)(wave * 16 + 4 * lq + i) * GH + (member * GU + u) * 16 + lr;
                 const float hv = (ABL & 8) ? og * cn : og * tanh_fast(cn);
+                if (GX && !k.tile_ok) continue;
                 if (ABL & 4) *hp = hv;
                 else store_sc1(hp, hv);
                 if (TRAIN && SAVE) {  // rows of this cluster inside step t's [Nrows][...] slabs
@@ -307,8 +337,17 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
             // the layer-0 input of this lane's row at frame t (two A fragments: columns 4 lq .. and 16 + 4 lq ..):
             // requested now, divided after the wait below
             float raw[8];
+            f32x4 acc[GU][4];
             const float den = (k.row_ok && !TRAIN) ? x.den[x.den_mode ? (long)t * x.den_stride + k.ng : (long)k.xb] : 1.f;
-            if (TRAIN) {  // plain row-major input [Tp][x_step][x_ld], 32 columns (zero-padded by the caller)
+            if (GX) {  // the projection tiles of this wave's rows at frame t (bias included): requested before the wait
+                const int tile = k.cluster * (GROWS / 16) + (k.tile_ok ? wave : 0);
+                const float* gp = a.gx + (((size_t)t * a.gx_tiles + tile) * (4 * GKC)) * 256 + lane * 4;
+#pragma unroll
+                for (int u = 0; u < GU; ++u)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        acc[u][g] = *reinterpret_cast<const f32x4*>(gp + (size_t)(g * GKC + member * GU + u) * 256);
+            } else if (TRAIN) {  // plain row-major input [Tp][x_step][x_ld], 32 columns (zero-padded by the caller)
                 const float* xr = x.x_rows + ((long)t * x.x_step + (k.row_ok ? k.row_l : 0)) * x.x_ld + 4 * lq;
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(xr);
                 const f32x4 v1 = x.kin_chunks > 1 ? *reinterpret_cast<const f32x4*>(xr + 16) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -329,22 +368,24 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
             }
             if (t > 0) wait_peeked(peek(k.fl0), k.fl0, (unsigned)t);  // h0_{t-1} of all members (just published: polls)
             f32x4 xa[2];
+            if (!GX) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int cc = (e >> 2) * 16 + 4 * lq + (e & 3);
-                if (TRAIN) xa[e >> 2][e & 3] = k.row_ok ? raw[e] : 0.f;
-                else xa[e >> 2][e & 3] = (k.row_ok && cc <= 2 * x.nb + 1) ? raw[e] / den : 0.f;
-            }
-            f32x4 acc[GU][4];
-#pragma unroll
-            for (int u = 0; u < GU; ++u)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float b = kBiasLds ? bias_sh[u * 4 + g][lr] : bias[u][g];
-                    acc[u][g] = f32x4{b, b, b, b};
+                for (int e = 0; e < 8; ++e) {
+                    const int cc = (e >> 2) * 16 + 4 * lq + (e & 3);
+                    if (TRAIN) xa[e >> 2][e & 3] = k.row_ok ? raw[e] : 0.f;
+                    else xa[e >> 2][e & 3] = (k.row_ok && cc <= 2 * x.nb + 1) ? raw[e] / den : 0.f;
                 }
+#pragma unroll
+                for (int u = 0; u < GU; ++u)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float b = kBiasLds ? bias_sh[u * 4 + g][lr] : bias[u][g];
+                        acc[u][g] = f32x4{b, b, b, b};
+                    }
+            }
             const unsigned ring = t >= GD0 ? peek(k.fl1) : 0xffffffffu;
-            kloop(acc, xa, k.xrsrc0, 0, a.o_wih0, 2, 2, k.xrsrc0, t > 0 ? slot0(t - 1) : 0u, a.o_whh0, GKC, t > 0 ? GKC : 0);
+            if (!GX) kloop(acc, xa, k.xrsrc0, 0, a.o_wih0, 2, 2, k.xrsrc0, t > 0 ? slot0(t - 1) : 0u, a.o_whh0, GKC, t > 0 ? GKC : 0);
+            else if (t > 0) kloop(acc, nullptr, k.xrsrc0, 0, 0, 0, 0, k.xrsrc0, slot0(t - 1), a.o_whh0, GKC, GKC);
             // slot t % GD0 still holds h0_{t-GD0}: layer 1 must have finished its step t - GD0 (it reads that slot
             // there) - all eight layer-1 members, i.e. they have published step t - GD0 + 1
             if (t >= GD0) wait_peeked(ring, k.fl1, (unsigned)(t - GD0 + 1));
@@ -472,6 +513,47 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void 
     else group_body<1, ABL, TRAIN, NCL, SAVE, AR>(a, cluster, cluster_b, member, bsh, bias_sh);
 }
 
+// Several independent two-layer stacks (weight sets) in one launch, GX form: workgroup set `slot` serves cluster `slot`
+// of the launch, which belongs to the set whose cluster range contains it.
+template <int ABL>
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void lstm2_group_multi_kernel(const GrpArgs a0,
+                                                                                                          const GrpSets sets) {
+    __shared__ typename FsnWFrag<FSN_ARITH_F32>::type bsh[2][GU * 4 * FSN_GRP_CPS][64];
+    __shared__ float bias_sh[GU * 4][16];
+    const int half = gridDim.x >> 1;
+    const int layer = (int)blockIdx.x >= half ? 1 : 0;
+    const int bid = (int)blockIdx.x - layer * half;
+    const int slots = half / GM;
+    int slot, member;
+    if (slots % 8 == 0) {
+        const int xcd = bid & 7, j = bid >> 3;
+        slot = xcd * (slots / 8) + j / GM;
+        member = j % GM;
+    } else {
+        slot = bid / GM;
+        member = bid % GM;
+    }
+    int si = 0;
+    for (int i = 1; i < sets.n; ++i)
+        if (slot >= sets.s[i].cluster0) si = i;
+    const GrpSet& q = sets.s[si];
+    GrpArgs a = a0;
+    a.gx = q.gx;
+    a.gx_tiles = q.N / 16;
+    a.hx0 = q.hseq0;
+    a.hx1 = q.hseq1;
+    a.bias1 = q.bias1;
+    a.o_whh0 = q.o_whh0;
+    a.o_wih1 = q.o_wih1;
+    a.o_whh1 = q.o_whh1;
+    a.Nrows = q.N;
+    a.flags = a0.flags + (size_t)q.cluster0 * 2 * GFS;
+    const int cluster = slot - q.cluster0;  // within the set
+    if (layer == 1 && !(ABL & 64)) __builtin_amdgcn_s_setprio(2);
+    if (layer == 0) group_body<0, ABL, true, 1, false, FSN_ARITH_F32, true>(a, cluster, -1, member, bsh, bias_sh);
+    else group_body<1, ABL, true, 1, false, FSN_ARITH_F32, true>(a, cluster, -1, member, bsh, bias_sh);
+}
+
 }  // namespace
 
 size_t fsn_lstm2_group_exchange_floats(int clusters) { return (size_t)clusters * (GD0 + 2) * GROWS * GH; }
@@ -493,7 +575,8 @@ static int grp_slots_cap() {
                            (const void*)lstm2_group_kernel<0, true, 1, true, FSN_ARITH_F16>,
                            (const void*)lstm2_group_kernel<0, true, 2, true, FSN_ARITH_F16>,
                            (const void*)lstm2_group_kernel<0, true, 1, true, FSN_ARITH_BF16>,
-                           (const void*)lstm2_group_kernel<0, true, 2, true, FSN_ARITH_BF16>};
+                           (const void*)lstm2_group_kernel<0, true, 2, true, FSN_ARITH_BF16>,
+                           (const void*)lstm2_group_multi_kernel<0>};
     for (const void* k : forms)
         if (!fsn_grid_fits(k, 256, grid)) return 0;
     return cus / GM;
@@ -547,8 +630,8 @@ int fsn_launch_lstm2_group(const FsnSbInput* xin, const float* whh0_p, const flo
         fsn_set_error("lstm2_group: %d clusters cannot be co-resident on this device (persistent kernels off, or occupancy)", clusters);
         return FSN_ERR_ARG;
     }
-    if (clusters > slots) hipLaunchKernelGGL((lstm2_group_kernel<0, false, 2>), dim3((unsigned)slots * GM * 2), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((lstm2_group_kernel<0, false, 1>), dim3((unsigned)slots * GM * 2), dim3(256), 0, s, a);
+    if (clusters > slots) FSN_PERSIST_LAUNCH((lstm2_group_kernel<0, false, 2>), dim3((unsigned)slots * GM * 2), dim3(256), s, a);
+    else FSN_PERSIST_LAUNCH((lstm2_group_kernel<0, false, 1>), dim3((unsigned)slots * GM * 2), dim3(256), s, a);
     return fsn_check_launch("lstm2_group_kernel");
 }
 
@@ -613,17 +696,73 @@ int fsn_launch_lstm2_group_train(const float* x, long x_ld, int x_cols, int Nrow
     }
     const dim3 grid((unsigned)slots * GM * 2), block(256);
     if (save && arith == FSN_ARITH_F16) {
-        if (clusters > slots) hipLaunchKernelGGL((lstm2_group_kernel<0, true, 2, true, FSN_ARITH_F16>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((lstm2_group_kernel<0, true, 1, true, FSN_ARITH_F16>), grid, block, 0, s, a);
+        if (clusters > slots) FSN_PERSIST_LAUNCH((lstm2_group_kernel<0, true, 2, true, FSN_ARITH_F16>), grid, block, s, a);
+        else FSN_PERSIST_LAUNCH((lstm2_group_kernel<0, true, 1, true, FSN_ARITH_F16>), grid, block, s, a);
     } else if (save && arith == FSN_ARITH_BF16) {
-        if (clusters > slots) hipLaunchKernelGGL((lstm2_group_kernel<0, true, 2, true, FSN_ARITH_BF16>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((lstm2_group_kernel<0, true, 1, true, FSN_ARITH_BF16>), grid, block, 0, s, a);
+        if (clusters > slots) FSN_PERSIST_LAUNCH((lstm2_group_kernel<0, true, 2, true, FSN_ARITH_BF16>), grid, block, s, a);
+        else FSN_PERSIST_LAUNCH((lstm2_group_kernel<0, true, 1, true, FSN_ARITH_BF16>), grid, block, s, a);
     } else if (save) {
-        if (clusters > slots) hipLaunchKernelGGL((lstm2_group_kernel<0, true, 2, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((lstm2_group_kernel<0, true, 1, true>), grid, block, 0, s, a);
+        if (clusters > slots) FSN_PERSIST_LAUNCH((lstm2_group_kernel<0, true, 2, true>), grid, block, s, a);
+        else FSN_PERSIST_LAUNCH((lstm2_group_kernel<0, true, 1, true>), grid, block, s, a);
     } else {
-        if (clusters > slots) hipLaunchKernelGGL((lstm2_group_kernel<0, true, 2, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((lstm2_group_kernel<0, true, 1, false>), grid, block, 0, s, a);
+        if (clusters > slots) FSN_PERSIST_LAUNCH((lstm2_group_kernel<0, true, 2, false>), grid, block, s, a);
+        else FSN_PERSIST_LAUNCH((lstm2_group_kernel<0, true, 1, false>), grid, block, s, a);
     }
     return fsn_check_launch("lstm2_group_kernel (training)");
+}
+
+// Several two-layer stacks with their own weights over the same Tp frames as ONE launch (GX form): stack i has N[i] rows
+// (a multiple of 16), its layer-0 projection gx[i] as fragment tiles [Tp][N[i] / 16][4H / 16][64][4] (bias included),
+// packed W_hh0 / W_ih1 / W_hh1 (all stacks' matrices inside one buffer), bias1 = b_ih + b_hh of layer 1 and its hidden
+// sequences hseq0 / hseq1 [Tp][N[i]][H].  Clusters: sum of ceil(N[i] / 64) <= fsn_lstm2_group_multi_cap().
+int fsn_lstm2_group_multi_cap() { return grp_slots_cap(); }
+int fsn_launch_lstm2_group_multi(int n, const FsnGroupStack* st, unsigned* flags, int Tp, int H, hipStream_t s) {
+    if (H != GH || n < 1 || n > GSETS || !st || !flags) {
+        fsn_set_error("lstm2_group (several stacks): H = 384, 1 .. %d stacks", GSETS);
+        return FSN_ERR_ARG;
+    }
+    GrpSets sets{};
+    sets.n = n;
+    const float* lo = st[0].whh0_p;
+    for (int i = 0; i < n; ++i)
+        for (const float* q : {st[i].whh0_p, st[i].wih1_p, st[i].whh1_p}) lo = q < lo ? q : lo;
+    int clusters = 0;
+    for (int i = 0; i < n; ++i) {
+        const FsnGroupStack& q = st[i];
+        if (q.N < 16 || q.N % 16 || (size_t)Tp * q.N * GH * 4 > 0x7fffffffull || !q.gx || !q.hseq0 || !q.hseq1 || !q.bias1) {
+            fsn_set_error("lstm2_group (several stacks): stack %d: rows a multiple of 16, hidden sequence below 2 GB", i);
+            return FSN_ERR_ARG;
+        }
+        for (const float* w : {q.whh0_p, q.wih1_p, q.whh1_p})
+            if (w - lo > 0x1fffffffL) {
+                fsn_set_error("lstm2_group: the packed weight matrices must share one buffer");
+                return FSN_ERR_ARG;
+            }
+        GrpSet& g = sets.s[i];
+        g.gx = q.gx;
+        g.hseq0 = q.hseq0;
+        g.hseq1 = q.hseq1;
+        g.bias1 = q.bias1;
+        g.o_whh0 = (unsigned)(q.whh0_p - lo);
+        g.o_wih1 = (unsigned)(q.wih1_p - lo);
+        g.o_whh1 = (unsigned)(q.whh1_p - lo);
+        g.N = q.N;
+        g.cluster0 = clusters;
+        clusters += (q.N + GROWS - 1) / GROWS;
+    }
+    const int cap = grp_slots_cap();
+    if (cap == 0 || clusters > cap) {
+        fsn_set_error("lstm2_group: %d clusters cannot be co-resident on this device (persistent kernels off, or occupancy)", clusters);
+        return FSN_ERR_ARG;
+    }
+    if (fsn_launch_zero_words(flags, fsn_lstm2_group_flag_words(clusters), s) != FSN_OK) return FSN_ERR_LAUNCH;
+    GrpArgs a{};
+    a.wbase = lo;
+    a.flags = flags;
+    a.status = flags + (size_t)clusters * 2 * GFS;
+    a.spin_ticks = fsn_spin_ticks();
+    a.Tp = Tp;
+    a.nclusters = clusters;
+    FSN_PERSIST_LAUNCH((lstm2_group_multi_kernel<0>), dim3((unsigned)clusters * GM * 2), dim3(256), s, a, sets);
+    return fsn_check_launch("lstm2_group_multi_kernel");
 }

@@ -144,9 +144,10 @@ class SubbandModel(BaseModel):
         return [(hi - lo) // c for (lo, hi), c in
                 zip((self._band(i, num_freqs) for i in range(len(self.sb_models))), self.sb_num_center_freqs)]
 
-    def _section(self, noisy_input, fb_output, sb_idx, units=None):
-        """One section (model.py:402-449).  ``units = (lo, hi)`` restricts the sequence model to that range of the
-        section's units; the norm statistics are always taken over the whole section, as in the reference."""
+    def _section_input(self, noisy_input, fb_output, sb_idx, units=None):
+        """The normalised input of one section's sequence model [B, n, 1, F_sub, T] (model.py:402-440).  ``units = (lo,
+        hi)`` restricts it to that range of the section's units; the norm statistics are always taken over the whole
+        section, as in the reference.  None: more ranks than units, nothing of this section here."""
         lower, upper = self._band(sb_idx, noisy_input.size(2))
         noisy_subband = self._freq_unfold(noisy_input, lower, upper, self.sb_num_center_freqs[sb_idx],
                                           self.sb_num_neighbor_freqs[sb_idx])
@@ -155,9 +156,16 @@ class SubbandModel(BaseModel):
         sb_model_input = self.norm(torch.cat([noisy_subband, fb_subband], dim=-2))
         if units is not None:
             lo, hi = units
-            if hi <= lo:  # more ranks than units: nothing of this section here
-                return sb_model_input.new_zeros((sb_model_input.size(0), 2, 0, sb_model_input.size(-1)))
+            if hi <= lo:
+                return None
             sb_model_input = sb_model_input[:, lo:hi].contiguous()
+        return sb_model_input
+
+    def _section(self, noisy_input, fb_output, sb_idx, units=None):
+        """One section (model.py:402-449)."""
+        sb_model_input = self._section_input(noisy_input, fb_output, sb_idx, units)
+        if sb_model_input is None:
+            return noisy_input.new_zeros((noisy_input.size(0), 2, 0, noisy_input.size(-1)))
         return self.sb_models[sb_idx](sb_model_input)
 
     def _run_sections(self, noisy_input, fb_output, units):
@@ -165,8 +173,30 @@ class SubbandModel(BaseModel):
         num = len(self.sb_models)
         if torch.is_grad_enabled() or not noisy_input.is_cuda:
             return [self._section(noisy_input, fb_output, i, units[i]) for i in range(num)]
-        # inference: the sections are independent and each one is a chain of small dependent launches
-        # (B x units rows only), so they run concurrently on one HIP stream each and join on the caller's
+        # inference: the sections are independent two-layer stacks over the same frames.  When together they fill the
+        # chip's workgroup sets (batches around 32 at 48 kHz) they run as ONE persistent launch of the group kernel with
+        # a weight set per section (sequence_model.multi_forward -> fsn_lstm2_forward_multi)
+        from .sequence_model import multi_forward, multi_plan
+        B, T = noisy_input.size(0), noisy_input.size(-1)
+        n_units = self.num_units(noisy_input.size(2))
+        span = [n_units[i] if units[i] is None else max(units[i][1] - units[i][0], 0) for i in range(num)]
+        live = [i for i in range(num) if span[i] > 0]
+        widths = [(sc + 2 * sn) + (fc + 2 * fn) for sc, sn, fc, fn in
+                  zip(self.sb_num_center_freqs, self.sb_num_neighbor_freqs, self.fb_num_center_freqs, self.fb_num_neighbor_freqs)]
+        if live and multi_plan([self.sb_models[i] for i in live], [(B * span[i], widths[i], T) for i in live]):
+            inputs = {i: self._section_input(noisy_input, fb_output, i, units[i]) for i in live}
+            flat = [inputs[i].reshape(B * span[i], widths[i], T) for i in live]
+            outs = multi_forward([self.sb_models[i] for i in live], flat)
+            result = []
+            for i in range(num):
+                if i not in inputs:
+                    result.append(noisy_input.new_zeros((B, 2, 0, T)))
+                    continue
+                o = outs[live.index(i)].reshape(B, span[i], 2, -1, T).permute(0, 2, 1, 3, 4).contiguous()
+                result.append(o.reshape(B, 2, -1, T))
+            return result
+        # otherwise each one is a chain of small dependent launches (B x units rows only): they run concurrently on one
+        # HIP stream each and join on the caller's
         main = torch.cuda.current_stream(noisy_input.device)
         if getattr(self, "_streams", None) is None or len(self._streams) != num:
             self._streams = [torch.cuda.Stream(noisy_input.device) for _ in range(num)]

@@ -208,6 +208,68 @@ class SequenceModel(nn.Module):
         return o.permute(1, 2, 0)
 
 
+def multi_plan(models, shapes):
+    """Whether ``multi_forward`` would run these two-layer LSTM SequenceModels on inputs of ``shapes`` [(B_i, F_i, T)] as
+    ONE persistent launch (fsn_lstm2_multi_is_persistent); callers keep small stacks on one stream each otherwise."""
+    import ctypes
+    n = len(models)
+    if n < 1 or n > 8 or any(m.cell != "LSTM" or m.num_layers != 2 for m in models):
+        return False
+    stacks = (_lib.Lstm2Stack * n)()
+    for q, m, (B, F, T) in zip(stacks, models, shapes):
+        Hp = _round_up(m.hidden_size, 64)
+        q.N, q.I, q.H0, q.H1 = _round_up(B, 16), F, Hp, Hp
+    return bool(_lib.lib().fsn_lstm2_multi_is_persistent(n, ctypes.byref(stacks), shapes[0][2]))
+
+
+def multi_forward(models, xs):
+    """Several independent two-layer LSTM SequenceModels over the SAME frames (the band sections of Improved FullSubNet,
+    improved_fullsubnet/model.py:402-449) through fsn_lstm2_forward_multi: one persistent launch of the group kernel with
+    one weight set per model when ``multi_plan`` says so.  models[i](xs[i]) for xs[i] [B_i, F_i, T] -> list of
+    [B_i, O_i, T].  Inference only."""
+    import ctypes
+    L = _lib.lib()
+    n = len(models)
+    if n < 1 or n > 8 or len(xs) != n:
+        raise _lib.FsnError("multi_forward: 1 .. 8 models with one input each")
+    T = xs[0].shape[2]
+    dev = xs[0].device
+    stacks = (_lib.Lstm2Stack * n)()
+    keep, hseqs, meta = [], [], []
+    for i, (m, x) in enumerate(zip(models, xs)):
+        if m.cell != "LSTM" or m.num_layers != 2 or x.dim() != 3 or x.shape[2] != T or not x.is_cuda:
+            raise _lib.FsnError("multi_forward: two-layer LSTM SequenceModels on GPU inputs [B, F, T] with a common T")
+        B, F, _ = x.shape
+        Hp = _round_up(m.hidden_size, 64)
+        Np, Ip = _round_up(B, 16), _round_up(F, 16)
+        layers, fc = m._inference_weights()
+        h = torch.zeros((T, Np, Ip), dtype=torch.float32, device=dev)
+        h[:, :B, :F] = x.permute(2, 0, 1)
+        hseq = torch.empty((T, Np, Hp), dtype=torch.float32, device=dev)
+        q = stacks[i]
+        q.x, q.ldx = h.data_ptr(), Ip
+        for name, t in zip(("w_ih0", "w_hh0", "b_ih0", "b_hh0", "w_ih1", "w_hh1", "b_ih1", "b_hh1"), (*layers[0], *layers[1])):
+            setattr(q, name, _lib.dev_ptr(t, name).value)
+        q.N, q.I, q.H0, q.H1, q.hseq1 = Np, layers[0][0].shape[1], Hp, Hp, hseq.data_ptr()
+        keep.append((h, layers))
+        hseqs.append(hseq)
+        meta.append((B, Np, Hp, fc))
+    nbytes = L.fsn_lstm2_multi_workspace_bytes(n, ctypes.byref(stacks), T)
+    ws = _lib.workspace(nbytes, dev)
+    _lib.check(L.fsn_lstm2_forward_multi(n, ctypes.byref(stacks), T, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)))
+    outs = []
+    for m, hseq, (B, Np, Hp, fc) in zip(models, hseqs, meta):
+        relu = m.output_activate_function == "ReLU"
+        if fc is not None:
+            o = linear_infer(hseq.reshape(T * Np, Hp), fc[0], fc[1], relu).reshape(T, Np, m.output_size)[:, :B]
+        else:
+            o, relu = hseq[:, :B, :m.hidden_size], False
+        if m.output_activate_function and not relu:
+            o = m.activate_function(o)
+        outs.append(o.permute(1, 2, 0))
+    return outs
+
+
 def pair_forward(block0, block1, x):
     """``block1(block0(x))`` for two consecutive SequenceModel blocks (an ``nn.Sequential`` pair of the sibling
     models).  In inference, when both are single-layer LSTM blocks, block0 has no output layer / activation and

@@ -223,6 +223,25 @@ int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, const float*
                       const float* b_hh1, int T, int N, int I, int H0, int H1, float* hseq1, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* Up to eight INDEPENDENT two-layer stacks over the same T frames: the band sections of
+ * improved_fullsubnet/model.py:402-449, whose SequenceModels have B x {20, 25, 6, 4} rows and input widths 62 .. 180 at
+ * 48 kHz.  Per stack the arguments of fsn_lstm2_forward.  When every stack has H0 = H1 = 384 and together they fill
+ * most of the chip (fsn_lstm2_multi_is_persistent: 3/4 .. 1 x CUs / 8 clusters of 64 rows) they run as ONE persistent
+ * launch of the group kernel with one weight set per stack; otherwise one stack after the other as fsn_lstm2_forward
+ * would (callers with small stacks do better to put them on one stream each).  Results equal fsn_lstm2_forward's per
+ * stack within fp32 rounding (the kernels differ in their order of accumulation). */
+typedef struct fsn_lstm2_stack {
+    const float* x; /* [T][N][ldx], columns I .. ldx-1 zero */
+    long ldx;
+    const float *w_ih0, *w_hh0, *b_ih0, *b_hh0, *w_ih1, *w_hh1, *b_ih1, *b_hh1;
+    int N, I, H0, H1;
+    float* hseq1; /* [T][N][H1] out */
+} fsn_lstm2_stack;
+int fsn_lstm2_multi_is_persistent(int n, const fsn_lstm2_stack* stacks, int T);
+size_t fsn_lstm2_multi_workspace_bytes(int n, const fsn_lstm2_stack* stacks, int T);
+int fsn_lstm2_forward_multi(int n, const fsn_lstm2_stack* stacks, int T, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
 /* Streaming inference (chunked / frame-by-frame processing with carried state - the real-time use the
  * model is designed for; the reference has no such entry point, nn.LSTM's (h_0, c_0) argument is the
  * analogue).  fsn_lstm_layer_pack re-tiles one layer's weights once; fsn_lstm_layer_forward_state then runs

@@ -150,6 +150,46 @@ def test_sequence_model_inference_and_training_vs_torch(fsn, cell, I, H, O, laye
             assert (g - r).abs().max().item() <= 1e-4 * max(r.abs().max().item(), 1.0), (n, k)
 
 
+@pytest.mark.parametrize("rows", [(640, 800, 192, 128), (630, 790, 170, 100), (1500, 24)])
+def test_several_sequence_models_in_one_persistent_launch_vs_torch(fsn, rows):
+    """sequence_model.multi_forward (fsn_lstm2_forward_multi: one launch of the group kernel, a weight set per model -
+    the band sections of improved_fullsubnet/model.py:402-449 at batch 32) against ATen's nn.LSTM / nn.Linear on the CPU
+    and against each model on its own; row counts that are not multiples of 64 / 16, different input widths."""
+    from fullsubnet_amd.sequence_model import SequenceModel, multi_forward, multi_plan
+    torch.manual_seed(sum(rows))
+    T, H = 9, 384
+    widths = (62, 68, 100, 180)[:len(rows)]
+    outs_n = (2, 8, 40, 120)[:len(rows)]
+    models = [SequenceModel(i, o, H, 2, False, "LSTM", None) for i, o in zip(widths, outs_n)]
+    xs = [torch.randn(n, i, T) for n, i in zip(rows, widths)]
+    refs = []
+    for m, x in zip(models, xs):
+        ref = torch.nn.LSTM(m.input_size, H, 2, batch_first=True)
+        ref.load_state_dict(m.sequence_model.state_dict())
+        with torch.no_grad():
+            o, _ = ref(x.permute(0, 2, 1))
+            refs.append(torch.nn.functional.linear(o, m.fc_output_layer.weight, m.fc_output_layer.bias).permute(0, 2, 1))
+    models = [m.cuda() for m in models]
+    xd = [x.cuda() for x in xs]
+    assert multi_plan(models, [tuple(x.shape) for x in xs]), "these shapes are meant to take the persistent launch"
+    with torch.no_grad():
+        outs = multi_forward(models, xd)
+        single = [m(x) for m, x in zip(models, xd)]
+    from fullsubnet_amd import _lib
+    assert _lib.stream_status(synchronize=True) == (0, 0)
+    for o, r, s1 in zip(outs, refs, single):
+        assert o.shape == r.shape and torch.isfinite(o).all()
+        assert (o.cpu() - r).abs().max().item() <= 2e-5
+        assert (o - s1).abs().max().item() <= 2e-5
+    # too few rows for the persistent launch: the same entry runs stack by stack
+    few = [x[:40].contiguous() for x in xd]
+    assert not multi_plan(models, [tuple(x.shape) for x in few])
+    with torch.no_grad():
+        outs = multi_forward(models, few)
+    for o, r in zip(outs, refs):
+        assert (o.cpu() - r[:40]).abs().max().item() <= 2e-5
+
+
 @pytest.mark.parametrize("n_fft,hop", [(512, 128), (960, 480), (400, 100), (1536, 384)])
 def test_stft_istft_other_transform_shapes(fsn, golden_dir, n_fft, hop):
     """fsn_stft / fsn_istft on the direct-DFT path (every shape but 512 / 256) against the oracle

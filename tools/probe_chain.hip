@@ -6,6 +6,7 @@
 void fsn_set_error(const char*, ...) {}
 bool fsn_persistent_allowed() { return true; }
 bool fsn_grid_fits(const void*, int, unsigned) { return true; }
+void fsn_persist_admit(const void*, int, unsigned) {}
 unsigned long long fsn_spin_ticks() { return 1ull << 31; }
 unsigned* fsn_ctx_sticky() { return nullptr; }
 int fsn_check_launch(const char*) { return hipGetLastError() == hipSuccess ? 0 : -3; }
