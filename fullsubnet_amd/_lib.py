@@ -169,6 +169,7 @@ SIGNATURES = {
     "fsn_stream_status": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_uint), _c.POINTER(_c.c_uint)]),
     "fsn_stream_status_clear": (_c.c_int, [_c.c_void_p]),
     "fsn_debug_hog": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float, _f32p, _c.c_void_p]),
+    "fsn_debug_persist_stats": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "fsn_profile_num_stages": (_c.c_int, []),
     "fsn_profile_stage_name": (_c.c_char_p, [_c.c_int]),
     "fsn_profile_read": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_float), _c.c_int]),
@@ -217,6 +218,13 @@ def stream_status(device=None, synchronize=True, raise_on_timeout=True):
 
 def stream_status_clear(device=None):
     check(lib().fsn_stream_status_clear(stream_ptr(device)))
+
+
+def persist_stats():
+    """(launches, waits, unreported) of the persistent-launch gate (test hook)."""
+    v = [ctypes.c_uint(0) for _ in range(3)]
+    check(lib().fsn_debug_persist_stats(*(ctypes.byref(x) for x in v)))
+    return tuple(x.value for x in v)
 
 
 def set_persistent_mode(mode):

@@ -138,6 +138,7 @@ static bool persist_set_fits(const std::vector<const PersistEntry*>& set) {
 }
 class PersistLaunch;
 static thread_local PersistLaunch* t_persist = nullptr;
+static std::atomic<unsigned> g_persist_launches{0}, g_persist_waits{0}, g_persist_unreported{0};
 class PersistLaunch {
   public:
     explicit PersistLaunch(hipStream_t s) : s_(s), lock_(g_persist_mutex) {
@@ -175,7 +176,13 @@ class PersistLaunch {
         while (set.size() > 1 && !persist_set_fits(set)) {
             (void)hipStreamWaitEvent(s_, set.front()->ev, 0);  // oldest first
             set.erase(set.begin());
+            g_persist_waits.fetch_add(1, std::memory_order_relaxed);
         }
+        g_persist_launches.fetch_add(1, std::memory_order_relaxed);
+        static const bool trace = getenv("FSN_TRACE_GATE") != nullptr;  // diagnostics only
+        if (trace)
+            fprintf(stderr, "libfsn_hip gate: stream %p frac %.3f occ %d admitted beside %zu launch(es) of other streams\n",
+                    (void*)s_, frac, me_.occ, set.size() - 1);
     }
     ~PersistLaunch() {
         t_persist = nullptr;
@@ -197,9 +204,10 @@ class PersistLaunch {
         }
         me_.ev = ev;
         me_.stream = s_;
-        if (!admitted_) {  // a launcher that did not report: treated as filling the chip
+        if (!admitted_) {  // a launcher that did not report (a bug, counted): treated as filling the chip from now on
             me_.frac = 1.0;
             me_.occ = 1;
+            g_persist_unreported.fetch_add(1, std::memory_order_relaxed);
         }
         gate_->live.push_back(me_);
     }
@@ -394,6 +402,12 @@ static int persist_precheck() {
 extern "C" int fsn_set_persistent_mode(int mode) {
     FSN_REQUIRE(mode == FSN_PERSISTENT_AUTO || mode == FSN_PERSISTENT_NEVER, "persistent mode %d unknown", mode);
     g_persist_mode.store(mode, std::memory_order_relaxed);
+    return FSN_OK;
+}
+extern "C" int fsn_debug_persist_stats(unsigned* launches, unsigned* waits, unsigned* unreported) {
+    if (launches) *launches = g_persist_launches.load(std::memory_order_relaxed);
+    if (waits) *waits = g_persist_waits.load(std::memory_order_relaxed);
+    if (unreported) *unreported = g_persist_unreported.load(std::memory_order_relaxed);
     return FSN_OK;
 }
 extern "C" int fsn_set_persistent_timeout_ms(int ms) {

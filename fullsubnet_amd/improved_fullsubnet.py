@@ -17,6 +17,7 @@ from .base_model import _hip_norm
 from .sequence_model import SequenceModel as _SequenceModel
 
 EPSILON = float(torch.finfo(torch.float32).eps)
+_UNFOLD_INDEX = {}  # (band, centre, neighbours, bins, device) -> gather index of SubbandModel._freq_unfold
 
 
 class SequenceModel(_SequenceModel):
@@ -127,10 +128,14 @@ class SubbandModel(BaseModel):
             raise ValueError("an inner band needs num_neighbor_freqs bins above its upper cut-off")
         units = (upper_cutoff_freq - lower_cutoff_freq) // c
         dev = input.device
-        idx = (lower_cutoff_freq - n + c * torch.arange(units, device=dev).reshape(units, 1)
-               + torch.arange(c + 2 * n, device=dev).reshape(1, -1))
-        idx = idx.abs()
-        idx = torch.where(idx > num_freqs - 1, 2 * (num_freqs - 1) - idx, idx)
+        key = (lower_cutoff_freq, upper_cutoff_freq, c, n, num_freqs, str(dev))
+        idx = _UNFOLD_INDEX.get(key)
+        if idx is None:  # built once per band and device (a dozen tiny launches otherwise, per section and call)
+            idx = (lower_cutoff_freq - n + c * torch.arange(units, device=dev).reshape(units, 1)
+                   + torch.arange(c + 2 * n, device=dev).reshape(1, -1))
+            idx = idx.abs()
+            idx = torch.where(idx > num_freqs - 1, 2 * (num_freqs - 1) - idx, idx)
+            _UNFOLD_INDEX[key] = idx
         out = input[:, 0][:, idx, :]  # [B, N, c + 2n, T]
         return out.unsqueeze(2).contiguous()
 
@@ -195,19 +200,35 @@ class SubbandModel(BaseModel):
                 o = outs[live.index(i)].reshape(B, span[i], 2, -1, T).permute(0, 2, 1, 3, 4).contiguous()
                 result.append(o.reshape(B, 2, -1, T))
             return result
-        # otherwise each one is a chain of small dependent launches (B x units rows only): they run concurrently on one
-        # HIP stream each and join on the caller's
+        # otherwise each one is a chain of small dependent launches (B x units rows only): they run concurrently on side
+        # streams and join on the caller's.  Up to 64 rows per section (one or two utterances) every section is ONE
+        # launch of the persistent chain kernel, of which the chip holds two large ones or a large and a small one at
+        # a time (the gate of fsn_api.hip): two streams, large and small sections alternating, and the inputs of all
+        # sections prepared before the first recurrence is issued (the host's launch time would otherwise sit
+        # between the sections' starts)
         main = torch.cuda.current_stream(noisy_input.device)
+        rows = [B * span[i] for i in range(num)]
+        nstreams = 2 if max(rows) <= 64 else num
         if getattr(self, "_streams", None) is None or len(self._streams) != num:
             self._streams = [torch.cuda.Stream(noisy_input.device) for _ in range(num)]
-        subband_output = []
-        for sb_idx, st in enumerate(self._streams):
+        order = sorted(range(num), key=lambda i: -rows[i])
+        stream_of = {i: self._streams[k % nstreams] for k, i in enumerate(order)}
+        for st in self._streams[:nstreams]:
             st.wait_stream(main)
-            with torch.cuda.stream(st):
-                out = self._section(noisy_input, fb_output, sb_idx, units[sb_idx])
+        inputs = {}
+        for i in order:
+            with torch.cuda.stream(stream_of[i]):
+                inputs[i] = self._section_input(noisy_input, fb_output, i, units[i])
+        subband_output = [None] * num
+        for i in order:
+            with torch.cuda.stream(stream_of[i]):
+                if inputs[i] is None:
+                    out = noisy_input.new_zeros((B, 2, 0, T))
+                else:
+                    out = self.sb_models[i](inputs[i])
             out.record_stream(main)
-            subband_output.append(out)
-        for st in self._streams:
+            subband_output[i] = out
+        for st in self._streams[:nstreams]:
             main.wait_stream(st)
         return subband_output
 

@@ -336,7 +336,11 @@ int fsn_clip_adam_step(int n_tensors, float* const* params, float* const* grads,
  * recurrence as ONE launch whose workgroups hand results to each other step by step; they make progress only while
  * their whole grid is resident.  What the library guarantees by itself: such a launch is only chosen when the grid
  * fits an idle device (from the compiled kernel's occupancy on THAT device; other shapes take the per-step paths),
- * and the library's own persistent launches never overlap, whatever streams they come from (one process).  What it
+ * and the library's own persistent launches from different streams (one process) only run side by side when the
+ * whole set is provably placeable in any dispatch order (every launch reports grid and occupancy; a launch waits for
+ * earlier ones, oldest first, until sum_j grid_j / (occ_j CUs) stays below the fill level at which some CU state
+ * could refuse a workgroup of any kernel of the set - e.g. two 192-workgroup chain launches share the chip, two
+ * 448-workgroup group launches take turns).  What it
  * cannot control is bounded instead: a FOREIGN kernel holding CUs (an RCCL collective beside DDP's backward, work
  * of another stream) merely delays the workgroups that found no room until it ends - the resident ones wait for
  * them, by the device's wall clock, up to fsn_set_persistent_timeout_ms (default 20 s).  A wait that runs out means
@@ -366,6 +370,9 @@ int fsn_debug_poison_if(const void* status, float* out, size_t n, void* stream);
 /* Test hook: a foreign kernel - `workgroups` x 256 threads, lds_bytes of LDS each, ~200 registers per lane when
  * heavy != 0 - that holds its CUs for `ms` milliseconds on `stream`.  sink: one device float (never written). */
 int fsn_debug_hog(int workgroups, int lds_bytes, int heavy, float ms, float* sink, void* stream);
+/* Test hook: persistent launches admitted so far (process-wide), stream waits inserted between them, and launches
+ * that did not report their footprint (must stay 0).  Any pointer may be NULL. */
+int fsn_debug_persist_stats(unsigned* launches, unsigned* waits, unsigned* unreported);
 int fsn_profile_num_stages(void);
 const char* fsn_profile_stage_name(int stage);
 int fsn_profile_read(void* stream, float* ms_per_stage, int n);

@@ -258,6 +258,7 @@ def test_persistent_kernels_switched_off(fsn):
         assert (a - b).abs().max().item() <= 2e-4 * max(a.abs().max().item(), 1e-6)
     back = model.enhance(x, return_crm=True)
     assert torch.equal(back[1], ref[1])
+    assert fsn._lib.persist_stats()[2] == 0, "a persistent launch did not report its footprint to the gate"
 
 
 # ---- RCCL itself (world size 1: one rank per GPU is all a one-GPU box allows) -----------------------------------
@@ -305,6 +306,73 @@ def _rccl_worker(rank, world, port):
         assert fsn._lib.stream_status(x.device) == (0, 0)
     finally:
         dist.destroy_process_group()
+
+
+def test_persistent_launches_from_several_streams_share_the_chip_when_provably_placeable(fsn):
+    """The gate of fsn_api.hip on two-layer stacks of 20 - 30 rows (chain kernel with two row tiles: 192 workgroups, two
+    resident per CU - the large band sections of improved_fullsubnet/model.py at batch 1).  Two of them on two streams
+    are admitted side by side (no wait inserted, and they finish sooner than one after the other); a third on a third
+    stream has to wait for the oldest (three would not be placeable in every dispatch order).  Results equal the
+    one-stream run bit for bit, every launch reported its footprint, the streams' status stays clean."""
+    from fullsubnet_amd.sequence_model import SequenceModel
+    torch.manual_seed(5)
+    T = 1000
+    rows = (20, 25, 30)
+    models = [SequenceModel(40 + 8 * i, 2, 384, 2, False, "LSTM", None).cuda() for i in range(3)]
+    xs = [torch.randn(n, 40 + 8 * i, T, device="cuda") for i, n in enumerate(rows)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    main = torch.cuda.current_stream()
+
+    def on_one(n):
+        with torch.no_grad():
+            return [m(x) for m, x in zip(models[:n], xs[:n])]
+
+    def on_streams(n):
+        outs = []
+        for st, m, x in zip(streams[:n], models[:n], xs[:n]):
+            st.wait_stream(main)
+            with torch.cuda.stream(st), torch.no_grad():
+                outs.append(m(x))
+        for st in streams[:n]:
+            main.wait_stream(st)
+        return outs
+
+    ref = on_one(3)
+    torch.cuda.synchronize()  # (those launches are retired from the gate's list when the next one looks)
+
+    def counted(n):
+        before = fsn._lib.persist_stats()
+        outs = on_streams(n)
+        torch.cuda.synchronize()
+        after = fsn._lib.persist_stats()
+        assert after[2] == 0, "a persistent launch did not report its footprint to the gate"
+        for o, r in zip(outs, ref):
+            assert torch.equal(o, r)
+        return after[0] - before[0], after[1] - before[1]
+
+    two, three = counted(2), counted(3)
+    print(f"gate: (launches, waits) two streams {two}, three streams {three}")
+    assert two == (2, 0), "two chain launches of 192 workgroups at two per CU are placeable together"
+    assert three[0] == 3 and three[1] >= 1, "a third one is not: it has to wait"
+    for st in streams:
+        with torch.cuda.stream(st):
+            assert fsn._lib.stream_status(synchronize=True) == (0, 0)
+
+    def timed(fn, n):
+        for _ in range(2):
+            fn(n)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            fn(n)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 3
+
+    t_one, t_two = timed(on_one, 2), timed(on_streams, 2)
+    print(f"two chain stacks of {T} steps: one stream {t_one:.2f} ms, two streams {t_two:.2f} ms")
+    assert t_two < 0.85 * t_one, (t_one, t_two)
 
 
 def test_rccl_world_size_one(fsn):
