@@ -81,12 +81,18 @@ __global__ __launch_bounds__(64) void norm_scan_kernel(const double* __restrict_
         b[t] = vb;
     }
     __syncthreads();
-    if (lane == 0) {
     if (norm_type == FSN_NORM_OFFLINE_LAPLACE || norm_type == FSN_NORM_OFFLINE_GAUSSIAN) {
+        // one statistic per row: every lane adds its frames (t = lane, lane + 64, ...), then a fixed butterfly - the
+        // same order in every run; the whole wave, not lane 0 alone (a serial walk over LDS cost 60 us at batch 1)
         double tot = 0.0, tot2 = 0.0;
-        for (int t = 0; t < T; ++t) {
+        for (int t = lane; t < T; t += 64) {
             tot += a[t];
             if (norm_type == FSN_NORM_OFFLINE_GAUSSIAN) tot2 += b[t];
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            tot += __shfl_xor(tot, m, 64);
+            tot2 += __shfl_xor(tot2, m, 64);
         }
         const double n = (double)Fr * T;
         const float mu = (float)(tot / n);
@@ -100,11 +106,14 @@ __global__ __launch_bounds__(64) void norm_scan_kernel(const double* __restrict_
             s = mu;
             d = (float)sqrt(var) + eps;
         }
-        for (int t = 0; t < T; ++t) {
-            sh[t] = s;
-            dn[t] = d;
+        for (int t = lane; t < T; t += 64) {
+            shift[(long)r * T + t] = s;
+            den[(long)r * T + t] = d;
         }
-    } else if (norm_type == FSN_NORM_CUMULATIVE_LAPLACE || norm_type == FSN_NORM_CUMULATIVE_LAYER) {
+        return;
+    }
+    if (lane == 0) {
+    if (norm_type == FSN_NORM_CUMULATIVE_LAPLACE || norm_type == FSN_NORM_CUMULATIVE_LAYER) {
         double c1 = 0.0, c2 = 0.0;
         for (int t = 0; t < T; ++t) {
             c1 += a[t];
