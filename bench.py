@@ -24,6 +24,8 @@ Prints ONE JSON line (rank 0) with the driver's contract keys plus
                  (config 4) and Improved FullSubNet at 48 kHz, batch 32 (config 5).
 """
 import argparse
+import contextlib
+import gc
 import json
 import os
 import sys
@@ -135,18 +137,35 @@ def cpu_baseline(params, length, budget_s=30.0, all_cores_too=False):
     return out
 
 
+@contextlib.contextmanager
+def collector_paused():
+    """CPython's cyclic collector collected before and held during a timed region: a generation-2 pass over torch's
+    ~10^6 objects is a ~40 ms host pause that otherwise lands in one region or another at random (found with the HIP API
+    trace on the 4.7 ms step of config 5 at one utterance)."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
 def timed_steps(step, fence, steps, read_profile=None):
     """K steps bracketed by fence() on both sides; returns (seconds, summed stage ms)."""
     stage_ms = {}
     fence()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-        if read_profile is not None:
-            for k, v in read_profile().items():  # waits for this step's events only
-                stage_ms[k] = stage_ms.get(k, 0.0) + v
-    fence()
-    return time.perf_counter() - t0, stage_ms
+    with collector_paused():  # a generation-2 pass of the cyclic collector is a ~40 ms host pause (tools/bench_family.py)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+            if read_profile is not None:
+                for k, v in read_profile().items():  # waits for this step's events only
+                    stage_ms[k] = stage_ms.get(k, 0.0) + v
+        fence()
+        dt = time.perf_counter() - t0
+    return dt, stage_ms
 
 
 def training_step_ms(device, steps=5, arith="f32"):
@@ -172,11 +191,12 @@ def training_step_ms(device, steps=5, arith="f32"):
     for _ in range(2):
         train_step(model, opt, noisy, clean, scaler=scaler)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = train_step(model, opt, noisy, clean, scaler=scaler)
-    torch.cuda.synchronize()
-    ms = 1e3 * (time.perf_counter() - t0) / steps
+    with collector_paused():
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = train_step(model, opt, noisy, clean, scaler=scaler)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
     T = 1 + 49152 // HOP
     flops = 3 * 2.0 * 16 * (T + LA) * (MAC_FB + 128 * MAC_SB_PER_BIN)  # ~3x forward, 128 bins kept
     skipped = opt.skipped_steps()

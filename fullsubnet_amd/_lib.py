@@ -148,6 +148,8 @@ SIGNATURES = {
     "fsn_gru_layer_forward": (_c.c_int, [_f32p, _c.c_long, _f32p, _f32p, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_int,
                                          _c.c_int, _f32p, _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t,
                                          _c.c_void_p]),
+    "fsn_gru_layer_forward_state": (_c.c_int, [_f32p, _c.c_long, _f32p, _f32p, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_int,
+                                               _c.c_int, _f32p, _f32p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "fsn_gru_layer_bwd_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "fsn_gru_layer_backward": (_c.c_int, [_f32p, _f32p, _c.c_long, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                           _f32p, _c.c_void_p, _f32p, _c.c_long, _f32p, _f32p, _f32p, _f32p,

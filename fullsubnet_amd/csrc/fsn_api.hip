@@ -2613,6 +2613,49 @@ extern "C" int fsn_gru_layer_forward(const float* x, long ldx, const float* w_ih
     return FSN_OK;
 }
 
+// Streaming form (chunked / frame-by-frame inference with carried state): T more steps from h_state [N][H], which is
+// updated in place (nn.GRU(x, h_0) is the analogue).  Same kernels and workspace as the offline forward.
+extern "C" int fsn_gru_layer_forward_state(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
+                                           const float* b_hh, int T, int N, int I, int H, float* hseq, float* h_state,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+    CallScope scope(stream);
+    FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
+    FSN_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && hseq && h_state && workspace, "NULL pointer argument");
+    if (workspace_bytes < fsn_gru_layer_fwd_workspace_bytes(T, N, I, H)) {
+        fsn_set_error("gru layer forward (state): workspace too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Ipad = fsn_round_up(I, 16), G = 3 * H;
+    Carver cv(workspace);
+    float* wih_p = cv.take<float>((size_t)G * Ipad);
+    float* whh_p = cv.take<float>((size_t)G * H);
+    float* bias = cv.take<float>((size_t)G);
+    float* gx = cv.take<float>((size_t)T * N * G);
+    FSN_TRY(fsn_launch_pack(w_ih, wih_p, G, I, G, Ipad, s));
+    FSN_TRY(fsn_launch_pack(w_hh, whh_p, G, H, G, H, s));
+    FSN_TRY(fsn_launch_bias_sum(b_ih, nullptr, bias, G, G, s));
+    FSN_TRY(fsn_launch_bias_sum(b_ih, b_hh, bias, 2 * H, 2 * H, s));
+    FsnGemmA a{};
+    a.kind = 0;
+    a.p0 = x;
+    a.ld = ldx;
+    FsnGemmC c{};
+    c.kind = 0;
+    c.p0 = gx;
+    c.bias = bias;
+    FSN_TRY(fsn_launch_gemm(a, wih_p, c, T * (N / 16), G / 16, Ipad / 16, s));
+    const size_t step = (size_t)N * H;
+    for (int t = 0; t < T; ++t)
+        FSN_TRY(fsn_launch_gru_step(gx, whh_p, b_hh + 2 * H, t ? hseq + (t - 1) * step : h_state, hseq + t * step, nullptr,
+                                    (long)t * (N / 16), N / 16, H, 0, s));
+    if (hipMemcpyAsync(h_state, hseq + (size_t)(T - 1) * step, step * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        fsn_set_error("gru layer forward (state): state copy failed");
+        return FSN_ERR_LAUNCH;
+    }
+    return FSN_OK;
+}
+
 extern "C" size_t fsn_gru_layer_bwd_workspace_bytes(int T, int N, int I, int H) {
     const int Ipad = fsn_round_up(I, 16), G = 3 * H;
     Carver cv(nullptr);

@@ -56,57 +56,69 @@ __global__ __launch_bounds__(256) void norm_frame_sums_kernel(const float* __res
     }
 }
 
-// one wave per row: (shift, divisor) per frame.  The lanes fetch 64 frames' sums at a time (coalesced, the Fr parts
-// added in index order) into LDS; the recurrence over the frames then runs in lane 0 out of LDS - it is sequential by
+// one workgroup per row: (shift, divisor) per frame.  The threads fetch the frames' sums (coalesced, the Fr parts
+// added in index order) into LDS; the recurrence over the frames then runs in thread 0 out of LDS - it is sequential by
 // nature (a running sum, or the forgetting norm's fp32 recurrence) but no longer pays a memory round trip per frame.
 // The arithmetic after the sums follows the reference's fp32 tensor operations (same operand types, same order) - the
 // sums themselves are exactly-summed fp64 values rounded once.
-__global__ __launch_bounds__(64) void norm_scan_kernel(const double* __restrict__ s1, const double* __restrict__ s2,
-                                                       float* __restrict__ shift, float* __restrict__ den, int R, int Fr,
-                                                       int T, int norm_type, int sample_length, float eps, int parts,
-                                                       int want_sq) {
+__global__ __launch_bounds__(256) void norm_scan_kernel(const double* __restrict__ s1, const double* __restrict__ s2,
+                                                        float* __restrict__ shift, float* __restrict__ den, int R, int Fr,
+                                                        int T, int norm_type, int sample_length, float eps, int parts,
+                                                        int want_sq) {
     extern __shared__ double row[];  // a[T] | b[T] | shift[T] | den[T] (the last two as floats)
-    const int r = blockIdx.x, lane = threadIdx.x;
+    __shared__ float stat[2];
+    const int r = blockIdx.x, lane = threadIdx.x;  // "lane": thread of the workgroup; the recurrences run in thread 0
     double* a = row;
     double* b = row + T;
     float* sh = reinterpret_cast<float*>(row + 2 * T);
     float* dn = sh + T;
-    for (int t = lane; t < T; t += 64) {
+    // the Fr parts of a frame's sums, added in index order; four waves share the frames and eight loads are in flight per
+    // thread (with up to 64 parts and one wave this gather alone was 70 us for a 301-frame row)
+    for (int t = lane; t < T; t += 256) {
         double va = 0.0, vb = 0.0;
+        const double* p1 = s1 + (long)r * T + t;
+        const double* p2 = s2 + (long)r * T + t;
+        const long zs = (long)R * T;
+#pragma unroll 8
         for (int z = 0; z < parts; ++z) {
-            va += s1[((long)z * R + r) * T + t];
-            if (want_sq) vb += s2[((long)z * R + r) * T + t];
+            va += p1[z * zs];
+            if (want_sq) vb += p2[z * zs];
         }
         a[t] = va;
         b[t] = vb;
     }
     __syncthreads();
     if (norm_type == FSN_NORM_OFFLINE_LAPLACE || norm_type == FSN_NORM_OFFLINE_GAUSSIAN) {
-        // one statistic per row: every lane adds its frames (t = lane, lane + 64, ...), then a fixed butterfly - the
-        // same order in every run; the whole wave, not lane 0 alone (a serial walk over LDS cost 60 us at batch 1)
-        double tot = 0.0, tot2 = 0.0;
-        for (int t = lane; t < T; t += 64) {
-            tot += a[t];
-            if (norm_type == FSN_NORM_OFFLINE_GAUSSIAN) tot2 += b[t];
-        }
+        // one statistic per row: the lanes of wave 0 add their frames (t = lane, lane + 64, ...), then a fixed butterfly -
+        // the same order in every run (a serial walk over LDS by one lane cost 60 us at batch 1)
+        if (lane < 64) {
+            double tot = 0.0, tot2 = 0.0;
+            for (int t = lane; t < T; t += 64) {
+                tot += a[t];
+                if (norm_type == FSN_NORM_OFFLINE_GAUSSIAN) tot2 += b[t];
+            }
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            tot += __shfl_xor(tot, m, 64);
-            tot2 += __shfl_xor(tot2, m, 64);
+            for (int m = 32; m >= 1; m >>= 1) {
+                tot += __shfl_xor(tot, m, 64);
+                tot2 += __shfl_xor(tot2, m, 64);
+            }
+            const double n = (double)Fr * T;
+            const float mu = (float)(tot / n);
+            float s = 0.f, d;
+            if (norm_type == FSN_NORM_OFFLINE_LAPLACE) {
+                d = mu + eps;
+            } else {
+                const double m = tot / n;
+                double var = (tot2 - n * m * m) / (n - 1.0);  // torch.std: unbiased
+                var = var > 0.0 ? var : 0.0;
+                s = mu;
+                d = (float)sqrt(var) + eps;
+            }
+            if (lane == 0) stat[0] = s, stat[1] = d;
         }
-        const double n = (double)Fr * T;
-        const float mu = (float)(tot / n);
-        float s = 0.f, d;
-        if (norm_type == FSN_NORM_OFFLINE_LAPLACE) {
-            d = mu + eps;
-        } else {
-            const double m = tot / n;
-            double var = (tot2 - n * m * m) / (n - 1.0);  // torch.std: unbiased
-            var = var > 0.0 ? var : 0.0;
-            s = mu;
-            d = (float)sqrt(var) + eps;
-        }
-        for (int t = lane; t < T; t += 64) {
+        __syncthreads();
+        const float s = stat[0], d = stat[1];
+        for (int t = lane; t < T; t += 256) {
             shift[(long)r * T + t] = s;
             den[(long)r * T + t] = d;
         }
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(64) void norm_scan_kernel(const double* __restrict_
     }
     }
     __syncthreads();
-    for (int t = lane; t < T; t += 64) {
+    for (int t = lane; t < T; t += 256) {
         shift[(long)r * T + t] = sh[t];
         den[(long)r * T + t] = dn[t];
     }
@@ -235,7 +247,7 @@ extern "C" int fsn_norm(const float* x, float* y, int norm_type, int B, int C, i
         eps = (norm_type == FSN_NORM_OFFLINE_LAPLACE || norm_type == FSN_NORM_OFFLINE_GAUSSIAN) ? 1e-5f
               : norm_type == FSN_NORM_FORGETTING                                               ? 1e-10f
                                                                                                : kEpsF32;
-    hipLaunchKernelGGL(norm_scan_kernel, dim3((unsigned)d.R), dim3(64), scan_lds, s, s1,
+    hipLaunchKernelGGL(norm_scan_kernel, dim3((unsigned)d.R), dim3(256), scan_lds, s, s1,
                        s2, shift, den, (int)d.R, d.Fr, T, norm_type, sample_length, eps, d.parts, want_sq);
     FSN_TRY_LAUNCH("norm_scan_kernel");
     const long rows = (long)B * C * F;

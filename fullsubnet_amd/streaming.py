@@ -50,22 +50,32 @@ def _packed_layers(block):
 def _block_forward_state(block, x, state):
     """SequenceModel.forward for k more frames.  x [B, F, k]; state: list of (h, c) [Np, Hp] per layer
     (updated in place).  Returns [B, O, k]."""
-    if block.cell != "LSTM":
-        raise NotImplementedError("streaming is built for the LSTM branch")
     L = _lib.lib()
     B, F, k = x.shape
     H, Hp = block.hidden_size, _round_up(block.hidden_size, 64)
     Np, Ip = _round_up(B, 16), _round_up(F, 16)
-    packed, fc = _packed_layers(block)
     h = torch.zeros((k, Np, Ip), dtype=torch.float32, device=x.device)
     h[:, :B, :F] = x.permute(2, 0, 1)
-    for (buf, I, Hl), (hs, cs) in zip(packed, state):
-        hseq = torch.empty((k, Np, Hl), dtype=torch.float32, device=x.device)
-        ws = _lib.workspace(L.fsn_lstm_layer_state_workspace_bytes(k, Np, Hl), x.device)
-        _lib.check(L.fsn_lstm_layer_forward_state(
-            _lib.dev_ptr(h, "x"), h.shape[2], buf.data_ptr(), k, Np, I, Hl, _lib.dev_ptr(hseq), _lib.dev_ptr(hs),
-            _lib.dev_ptr(cs), ws.data_ptr(), ws.numel(), _lib.stream_ptr(x.device)))
-        h = hseq
+    if block.cell == "GRU":  # sequence_model.py:59-66: the carried state is h alone (fsn_gru_layer_forward_state)
+        layers, fc = block._inference_weights()
+        for (w_ih, w_hh, b_ih, b_hh), (hs, _) in zip(layers, state):
+            I, Hl = w_ih.shape[1], w_hh.shape[1]
+            hseq = torch.empty((k, Np, Hl), dtype=torch.float32, device=x.device)
+            ws = _lib.workspace(L.fsn_gru_layer_fwd_workspace_bytes(k, Np, I, Hl), x.device)
+            _lib.check(L.fsn_gru_layer_forward_state(
+                _lib.dev_ptr(h, "x"), h.shape[2], _lib.dev_ptr(w_ih), _lib.dev_ptr(w_hh), _lib.dev_ptr(b_ih),
+                _lib.dev_ptr(b_hh), k, Np, I, Hl, _lib.dev_ptr(hseq), _lib.dev_ptr(hs), ws.data_ptr(), ws.numel(),
+                _lib.stream_ptr(x.device)))
+            h = hseq
+    else:
+        packed, fc = _packed_layers(block)
+        for (buf, I, Hl), (hs, cs) in zip(packed, state):
+            hseq = torch.empty((k, Np, Hl), dtype=torch.float32, device=x.device)
+            ws = _lib.workspace(L.fsn_lstm_layer_state_workspace_bytes(k, Np, Hl), x.device)
+            _lib.check(L.fsn_lstm_layer_forward_state(
+                _lib.dev_ptr(h, "x"), h.shape[2], buf.data_ptr(), k, Np, I, Hl, _lib.dev_ptr(hseq), _lib.dev_ptr(hs),
+                _lib.dev_ptr(cs), ws.data_ptr(), ws.numel(), _lib.stream_ptr(x.device)))
+            h = hseq
     relu = block.output_activate_function == "ReLU"
     if fc is not None:
         o = linear_infer(h.reshape(k * Np, Hp), fc[0], fc[1], relu).reshape(k, Np, block.output_size)[:, :B]

@@ -281,6 +281,12 @@ size_t fsn_gru_layer_fwd_workspace_bytes(int T, int N, int I, int H);
 int fsn_gru_layer_forward(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
                           const float* b_hh, int T, int N, int I, int H, float* hseq, void* save, size_t save_bytes,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* Streaming form: T more steps from the carried state h_state [N][H] (zero-filled for a new stream), updated in
+ * place - nn.GRU(x, h_0) is the analogue; workspace >= fsn_gru_layer_fwd_workspace_bytes(T, N, I, H).  Chunked calls
+ * give the offline result bit for bit (the same step kernels in the same order). */
+int fsn_gru_layer_forward_state(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
+                                const float* b_hh, int T, int N, int I, int H, float* hseq, float* h_state,
+                                void* workspace, size_t workspace_bytes, void* stream);
 size_t fsn_gru_layer_bwd_workspace_bytes(int T, int N, int I, int H);
 int fsn_gru_layer_backward(const float* dh, const float* x, long ldx, const float* w_ih, const float* w_hh, int T,
                            int N, int I, int H, const float* hseq, const void* save, float* dx, long lddx,

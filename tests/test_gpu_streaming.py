@@ -103,6 +103,26 @@ def test_streaming_composed_configuration(setup):
     assert np.abs(got.cpu().numpy() - want).max() <= 2e-3 * np.abs(want).max()
 
 
+def test_streaming_gru_configuration(setup):
+    """The GRU branch (sequence_model.py:59-66) streams through fsn_gru_layer_forward_state: chunked == offline (the
+    offline GRU model itself is pinned on the reference's var_gru_b2 golden, test_gpu_family.py), whatever the chunking,
+    and a reset stream repeats itself bit for bit."""
+    fsn, _, _ = setup
+    torch.manual_seed(11)
+    kw = dict(MODEL_KW, sequence_model="GRU", fb_model_hidden_size=192, sb_model_hidden_size=128, weight_init=True)
+    m = fsn.Model(norm_type="cumulative_laplace_norm", num_groups_in_drop_band=1, **kw).cuda().eval()
+    assert not m._fused
+    noisy = torch.from_numpy(O.make_noisy(2, 3000, seed=9)).cuda()
+    offline = m.enhance(noisy)
+    assert torch.isfinite(offline).all() and offline.abs().max().item() > 0
+    a, _ = run_stream(fsn, m, noisy, [256, 700, 44, 2000])
+    b, _ = run_stream(fsn, m, noisy, [256] * 11 + [184])
+    for got in (a, b):
+        assert (got - offline).abs().max().item() <= 1e-4 * offline.abs().max().item()
+    again, _ = run_stream(fsn, m, noisy, [256, 700, 44, 2000])
+    assert torch.equal(again, a)
+
+
 @pytest.mark.parametrize("batch", [1, 8, 17])
 def test_enhance_is_capturable_in_a_hip_graph(setup, batch):
     """The C ABI only enqueues on the caller's stream (its auxiliary stream is forked and joined with events), so

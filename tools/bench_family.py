@@ -3,6 +3,8 @@ python tools/bench_family.py [fast|fullband|improved16|improved48|improved769] [
 units=r/w (improved* only): time what rank r of w computes under the frequency-axis shard (its share of every
 section's units; the all-gather is not part of this single-GPU measurement).
 `family_step(which, B)` is also what bench.py's side figures `fast_b256` / `improved48_b32` call."""
+import contextlib
+import gc
 import os
 import sys
 import time
@@ -14,6 +16,22 @@ import fullsubnet_amd  # noqa: E402
 from fullsubnet_amd import decompress_cIRM, istft, stft  # noqa: E402
 from fsn_synthetic import (IMPROVED_16K, IMPROVED_48K, IMPROVED_48K_769, make_fast_params, make_fullband_params,  # noqa: E402
                            make_improved_params, make_noisy)
+
+@contextlib.contextmanager
+def collector_paused():
+    """Timed regions of a few tens of milliseconds: a generation-2 pass of CPython's cyclic collector over torch's
+    ~10^6 objects is a ~40 ms host pause that lands in one of them now and then (measured with the HIP API trace: one
+    utterance of config 5, 4.7 ms per step, read 8.5 - 12.7 ms with one such pause in five steps).  Collected before,
+    held during."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
 
 DEFAULT_BATCH = {"fast": 256, "improved48": 32, "improved769": 32, "improved16": 32}
 
@@ -77,11 +95,12 @@ def family_step(which, B, device="cuda", steps=5, warmup=2, model_pack=None):
     for _ in range(warmup):
         out = enhance(noisy)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        out = enhance(noisy)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    with collector_paused():
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = enhance(noisy)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
     T = 1 + L // hop
     return {"ms_per_step": dt * 1e3, "frames_per_s": B * T / dt, "rtf": B * L / sr / dt,
             "tflops": 2 * mmac * B * (T + la) / dt / 1e12, "mflop_per_frame": 2 * mmac / 1e6, "batch": B,
