@@ -255,6 +255,44 @@ def test_improved_fullsubnet_at_baseline_length_vs_reference(fsn, golden_dir):
     assert np.abs(enh - z["enhanced"]).max() <= 1e-4 * float(z["enhanced_absmax"])
 
 
+def test_improved_fullsubnet_config5_full_size_on_the_persistent_launch(fsn, golden_dir):
+    """BASELINE config 5 at its full size - 32 utterances x 3 s at 48 kHz - where the four band sections run as ONE
+    persistent launch of the group kernel with a weight set per section (fsn_lstm2_forward_multi).  The reference's
+    utterance of improved_48k_long_b1 sits at both ends of the batch: both copies must match the reference model's
+    output; and, a size-independent property (the model has no cross-utterance term), every utterance must equal its
+    result in a batch of 16, which runs on other kernels (wavefronts on one stream per section)."""
+    from oracle import fullsubnet_oracle as O
+    from fullsubnet_amd import _lib
+    from fullsubnet_amd.improved_fullsubnet import Model
+    z, meta = load(golden_dir, "improved_48k_long_b1")
+    cfg = MF.IMPROVED_48K
+    params = MF.make_improved_params(cfg, seed=meta["seed_w"])
+    m = Model(**cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.cuda().eval()
+    assert meta["batch"] == 1
+    gold = O.make_noisy(1, meta["length"], seed=meta["seed_x"])
+    rest = O.make_noisy(30, meta["length"], seed=1234)
+    noisy = torch.from_numpy(np.concatenate([gold, rest, gold], axis=0)).cuda()
+    before = _lib.persist_stats()[0]
+    with torch.no_grad():
+        full = m(noisy.unsqueeze(1))
+    assert _lib.stream_status(synchronize=True) == (0, 0)
+    assert _lib.persist_stats()[0] - before == 2, "full-band chain + ONE launch for the four sections"
+    assert torch.isfinite(full).all()
+    stride, ref, scale = meta["sample_stride"], z["enhanced"], float(z["enhanced_absmax"])
+    for b in (0, 31):
+        got = full[b:b + 1].cpu().numpy()[..., ::stride]
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 1e-4 * scale, b
+    with torch.no_grad():
+        halves = torch.cat([m(noisy[:16].unsqueeze(1)), m(noisy[16:].unsqueeze(1))], dim=0)
+    err = (full - halves).abs().max().item()
+    print(f"config 5, 32 utterances on the persistent launch vs 2 x 16 on wavefronts: max |d| {err:.3g} "
+          f"(output scale {full.abs().max().item():.3g})")
+    assert err <= 5e-6 * full.abs().max().item()  # measured 8.6e-7 of the output scale
+
+
 @pytest.mark.parametrize("world", [3, 8])
 @pytest.mark.parametrize("name,cfg", [("improved_16k_b2", MF.IMPROVED_16K), ("improved_48k_b2", MF.IMPROVED_48K)])
 def test_improved_fullsubnet_unit_shard_vs_reference(fsn, golden_dir, name, cfg, world):
