@@ -357,19 +357,20 @@ __global__ __launch_bounds__(256) void colsum_narrow_kernel(const float* __restr
 
 struct TnPlan {
     int m_blocks, n_blocks, splits, narrow;
-    int square;  // 192 x 192 tiles, every K split's tiles on one XCD (16-bit arithmetic: bandwidth-bound)
+    int square;  // 192 x 192 tiles, every K split's tiles on one XCD (bandwidth-bound under the 16-bit arithmetic)
     long k_per_split;
 };
 // Workgroup tile 256 x 128 (wave tile 8 x 4, waves 2 x 2) or, for narrow outputs (the K = 2nb+2
 // input projection), 512 x 32 (wave tile 8 x 2, waves 4 x 1).  K is split so that the grid is one
 // workgroup per CU (or as close below it as the tile count allows).
-TnPlan tn_plan(int M, int Nc, long K, int arith = FSN_ARITH_F32) {
+TnPlan tn_plan(int M, int Nc, long K, int arith = FSN_ARITH_F32, bool allow_square = true) {
     TnPlan p;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     p.narrow = Nc <= 32;
     p.square = 0;
-    if (arith != FSN_ARITH_F32 && M % 192 == 0 && Nc % 192 == 0 && cus % 8 == 0 && (cus / 8) % ((M / 192) * (Nc / 192)) == 0 &&
+    (void)arith;  // every arithmetic: in fp32 the square plan is worth 0.3 ms of a 42 ms step, under the 16-bit one 1 ms per GEMM
+    if (allow_square && M % 192 == 0 && Nc % 192 == 0 && cus % 8 == 0 && (cus / 8) % ((M / 192) * (Nc / 192)) == 0 &&
         K >= (long)(cus / ((M / 192) * (Nc / 192))) * 128) {
         const long s = cus / ((M / 192) * (Nc / 192));  // whole splits per XCD, one workgroup per CU
         const long kps = ((K + s - 1) / s + 15) / 16 * 16;
@@ -409,9 +410,9 @@ static long colsum_rows_per_block(int cols, long rows) {
 size_t fsn_gemm_tn_workspace_bytes(int M, int Nc, long K) {
     const bool swap = M <= 32 && Nc > 32;
     if ((K & ~15L) <= 0) return (size_t)M * (Nc + 1) * sizeof(float);
-    // sized for the plan with the most splits of any arithmetic (the 16-bit forms may split K further)
-    const TnPlan p = swap ? tn_plan(Nc, M, K & ~15L) : tn_plan(M, Nc, K & ~15L);
-    const TnPlan q = swap ? p : tn_plan(M, Nc, K & ~15L, FSN_ARITH_F16);
+    // sized for the plan with the most splits (the square plan may split K further than the 256 x 128 one)
+    const TnPlan p = swap ? tn_plan(Nc, M, K & ~15L, FSN_ARITH_F32, false) : tn_plan(M, Nc, K & ~15L, FSN_ARITH_F32, false);
+    const TnPlan q = swap ? p : tn_plan(M, Nc, K & ~15L, FSN_ARITH_F32, true);
     const int splits = p.splits > q.splits ? p.splits : q.splits;
     return (size_t)(splits > 0 ? splits : 1) * M * (Nc + 1) * sizeof(float);  // + one column-sum row per split
 }
@@ -438,7 +439,7 @@ int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float
     float* asum_part = nullptr;
     int splits = 0;
     if (K16 > 0) {
-        const TnPlan p = swap ? tn_plan(Nc, M, K16) : tn_plan(M, Nc, K16, arith);
+        const TnPlan p = swap ? tn_plan(Nc, M, K16, arith, false) : tn_plan(M, Nc, K16, arith);
         if (colsum_out) asum_part = part + (size_t)p.splits * M * Nc;
         auto wide = arith == FSN_ARITH_F16    ? gemm_tn_kernel<8, 4, 2, 2, FSN_ARITH_F16>
                     : arith == FSN_ARITH_BF16 ? gemm_tn_kernel<8, 4, 2, 2, FSN_ARITH_BF16>
@@ -459,8 +460,9 @@ int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float
         }
         const dim3 grid((unsigned)(p.m_blocks * p.n_blocks * p.splits));
         if (p.square) {
-            auto square = arith == FSN_ARITH_F16 ? gemm_tn_kernel<6, 6, 2, 2, FSN_ARITH_F16>
-                                                 : gemm_tn_kernel<6, 6, 2, 2, FSN_ARITH_BF16>;
+            auto square = arith == FSN_ARITH_F16    ? gemm_tn_kernel<6, 6, 2, 2, FSN_ARITH_F16>
+                          : arith == FSN_ARITH_BF16 ? gemm_tn_kernel<6, 6, 2, 2, FSN_ARITH_BF16>
+                                                    : gemm_tn_kernel<6, 6, 2, 2, FSN_ARITH_F32>;
             static bool sq_set[4] = {false, false, false, false};
             if (!sq_set[arith]) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(square), hipFuncAttributeMaxDynamicSharedMemorySize,
