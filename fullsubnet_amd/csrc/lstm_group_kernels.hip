@@ -319,16 +319,27 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
                 if (GX && !k.tile_ok) continue;
                 if (ABL & 4) *hp = hv;
                 else store_sc1(hp, hv);
-                if (TRAIN && SAVE) {  // rows of this cluster inside step t's [Nrows][...] slabs
-                    const size_t row = (size_t)k.cluster * GROWS + wave * 16 + 4 * lq + i;
-                    const int unit = (member * GU + u) * 16 + lr;
-                    float* gp = gates_t + row * (4 * GH) + unit;
-                    gp[0] = ig;
-                    gp[GH] = fg;
-                    gp[2 * GH] = gg;
-                    gp[3 * GH] = og;
-                    cseq_t[row * GH + unit] = cn;
+                if (TRAIN && SAVE) {  // kept in place of the pre-activations for save_cell (after the hand-off)
+                    acc[u][0][i] = ig, acc[u][1][i] = fg, acc[u][2][i] = gg, acc[u][3][i] = og;
                 }
+            }
+    };
+    // Training: the activated gates and the cell state of the step, stored AFTER the hand-off - publish() drains the
+    // wave's stores before the flag goes out, and only the 12 h values belong to the hand-off: with the 60 saved values
+    // issued first every step's flag waited for their trip to HBM as well (same values, same addresses: bit-equal)
+    auto save_cell = [&](GrpCl& k, f32x4 (&acc)[GU][4], float* gates_t, float* cseq_t) {
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // rows of this cluster inside step t's [Nrows][...] slabs
+                const size_t row = (size_t)k.cluster * GROWS + wave * 16 + 4 * lq + i;
+                const int unit = (member * GU + u) * 16 + lr;
+                float* gp = gates_t + row * (4 * GH) + unit;
+                gp[0] = acc[u][0][i];
+                gp[GH] = acc[u][1][i];
+                gp[2 * GH] = acc[u][2][i];
+                gp[3 * GH] = acc[u][3][i];
+                cseq_t[row * GH + unit] = k.c[u][i];
             }
     };
 
@@ -392,6 +403,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
             cell(k, acc, reinterpret_cast<float*>(reinterpret_cast<char*>(k.hx0) + slot0(t)),
                  TRAIN ? a.gates0 + (size_t)t * a.Nrows * 4 * GH : nullptr, TRAIN ? a.cseq0 + (size_t)t * a.Nrows * GH : nullptr);
             publish(k.fl0 + member, (unsigned)t + 1);
+            if (TRAIN && SAVE) save_cell(k, acc, a.gates0 + (size_t)t * a.Nrows * 4 * GH, a.cseq0 + (size_t)t * a.Nrows * GH);
         };
         GrpCl ka, kb;
         init(ka, cluster_a);
@@ -465,6 +477,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
                 cell(k, acc, reinterpret_cast<float*>(reinterpret_cast<char*>(k.hx1) + slot1(s)),
                      TRAIN ? a.gates1 + (size_t)s * a.Nrows * 4 * GH : nullptr, TRAIN ? a.cseq1 + (size_t)s * a.Nrows * GH : nullptr);
                 publish(k.fl1 + member, (unsigned)s + 1);
+                if (TRAIN && SAVE) save_cell(k, acc, a.gates1 + (size_t)s * a.Nrows * 4 * GH, a.cseq1 + (size_t)s * a.Nrows * GH);
             }
         };
         GrpCl ka, kb;
