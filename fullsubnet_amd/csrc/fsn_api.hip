@@ -2664,9 +2664,13 @@ extern "C" size_t fsn_gru_layer_bwd_workspace_bytes(int T, int N, int I, int H) 
     cv.take<float>((size_t)T * N * G);  // dgx
     cv.take<float>((size_t)T * N * H);  // dghn
     cv.take<float>((size_t)N * H);      // carry
+    // the scratch of the weight-gradient products: every (M, Nc) that fsn_gru_layer_backward forms (each shape has
+    // its own plan - a narrower product may split K further than the 3H-row one)
     size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
-    const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
-    tn = tn > tn2 ? tn : tn2;
+    for (const int m : {G, 2 * H, H}) {
+        const size_t b = fsn_gemm_tn_workspace_bytes(m, H, (long)T * N);
+        tn = tn > b ? tn : b;
+    }
     const size_t cs = fsn_colsum_workspace_bytes(G, (long)T * N);
     cv.take<char>(tn > cs ? tn : cs);
     return fsn_round_up_sz(cv.off, 256);
@@ -2693,11 +2697,7 @@ extern "C" int fsn_gru_layer_backward(const float* dh, const float* x, long ldx,
     float* dgx = cv.take<float>((size_t)T * N * G);
     float* dghn = cv.take<float>((size_t)T * N * H);
     float* carry = cv.take<float>((size_t)N * H);
-    size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
-    const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
-    tn = tn > tn2 ? tn : tn2;
-    const size_t cs = fsn_colsum_workspace_bytes(G, (long)T * N);
-    void* scratch = cv.take<char>(tn > cs ? tn : cs);
+    void* scratch = cv.take<char>(0);  // the rest of the workspace (sized by fsn_gru_layer_bwd_workspace_bytes)
     const float* sv = static_cast<const float*>(save);
     FSN_TRY(fsn_launch_pack(w_hh, whhT_p, H, G, H, G, s, 1, H));
     FSN_TRY(fsn_launch_pack(w_ih, wihT_p, I, G, Ipad, G, s, 1, I));

@@ -407,14 +407,26 @@ static long colsum_rows_per_block(int cols, long rows) {
 
 }  // namespace
 
-size_t fsn_gemm_tn_workspace_bytes(int M, int Nc, long K) {
+// The most K splits ANY plan of this (M, Nc) can take, whatever K: callers size one scratch buffer for several products
+// of the same shape and slightly different K ((T - 1) N against T N rows), and the two plans split K differently (one
+// workgroup per CU over 256 x 128 tiles, or over 192 x 192 tiles).  fsn_launch_gemm_tn refuses a plan beyond it.
+static long tn_max_splits(int M, int Nc) {
     const bool swap = M <= 32 && Nc > 32;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int m = swap ? Nc : M, n = swap ? M : Nc;
+    const bool narrow = n <= 32;
+    const long tiles = narrow ? (long)((m + 511) / 512) * ((n + 31) / 32) : (long)((m + 255) / 256) * ((n + 127) / 128);
+    long splits = cus / tiles > 1 ? cus / tiles : 1;
+    if (!swap && M % 192 == 0 && Nc % 192 == 0) {
+        const long sq = cus / ((long)(M / 192) * (Nc / 192));
+        splits = sq > splits ? sq : splits;
+    }
+    return splits;
+}
+size_t fsn_gemm_tn_workspace_bytes(int M, int Nc, long K) {
     if ((K & ~15L) <= 0) return (size_t)M * (Nc + 1) * sizeof(float);
-    // sized for the plan with the most splits (the square plan may split K further than the 256 x 128 one)
-    const TnPlan p = swap ? tn_plan(Nc, M, K & ~15L, FSN_ARITH_F32, false) : tn_plan(M, Nc, K & ~15L, FSN_ARITH_F32, false);
-    const TnPlan q = swap ? p : tn_plan(M, Nc, K & ~15L, FSN_ARITH_F32, true);
-    const int splits = p.splits > q.splits ? p.splits : q.splits;
-    return (size_t)(splits > 0 ? splits : 1) * M * (Nc + 1) * sizeof(float);  // + one column-sum row per split
+    return (size_t)tn_max_splits(M, Nc) * M * (Nc + 1) * sizeof(float);  // + one column-sum row per split
 }
 
 // colsum_out (may be NULL): also out[m] = sum_k A[k][m], from the same pass over A (not with a narrow M)
@@ -440,6 +452,10 @@ int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float
     int splits = 0;
     if (K16 > 0) {
         const TnPlan p = swap ? tn_plan(Nc, M, K16, arith, false) : tn_plan(M, Nc, K16, arith);
+        if (p.splits > tn_max_splits(M, Nc)) {  // the scratch buffer is sized by that bound
+            fsn_set_error("gemm_tn: plan of %d splits for %d x %d exceeds the workspace bound", p.splits, M, Nc);
+            return FSN_ERR_WORKSPACE;
+        }
         if (colsum_out) asum_part = part + (size_t)p.splits * M * Nc;
         auto wide = arith == FSN_ARITH_F16    ? gemm_tn_kernel<8, 4, 2, 2, FSN_ARITH_F16>
                     : arith == FSN_ARITH_BF16 ? gemm_tn_kernel<8, 4, 2, 2, FSN_ARITH_BF16>

@@ -171,13 +171,19 @@ class SequenceModel(nn.Module):
         h = torch.zeros((T, Np, Ip), dtype=torch.float32, device=x.device)
         h[:, :B, :F] = x.permute(2, 0, 1)
         layer_infer = lstm_layer_infer if self.cell == "LSTM" else gru_layer_infer
-        if self.cell == "LSTM" and len(layers) == 2 and (
-                Np < WAVEFRONT_BELOW_ROWS or _lib.lib().fsn_lstm2_forward_is_persistent(T, Np, Ip, Ip, Hp, Hp)):
-            # few rows: latency-bound, halve the dependent launches; or a shape with a persistent two-layer kernel
-            h = lstm2_infer(h, layers[0], layers[1])
-        else:
-            for w_ih, w_hh, b_ih, b_hh in layers:
-                h = layer_infer(h, w_ih, w_hh, b_ih, b_hh)
+        k = 0
+        if self.cell == "LSTM":
+            # consecutive layers two by two (fsn_lstm2_forward) where that pays: few rows - latency-bound, half the
+            # dependent launches, or ONE launch of the chain kernel up to 64 rows - or a shape with a persistent
+            # two-layer kernel; a left-over layer (the full-band baseline has three) runs on its own below
+            while k + 1 < len(layers):
+                width = h.shape[2]
+                if not (Np < WAVEFRONT_BELOW_ROWS or _lib.lib().fsn_lstm2_forward_is_persistent(T, Np, width, width, Hp, Hp)):
+                    break
+                h = lstm2_infer(h, layers[k], layers[k + 1])
+                k += 2
+        for w_ih, w_hh, b_ih, b_hh in layers[k:]:
+            h = layer_infer(h, w_ih, w_hh, b_ih, b_hh)
         relu = self.output_activate_function == "ReLU"
         if fc is not None:
             o = linear_infer(h.reshape(T * Np, Hp), fc[0], fc[1], relu).reshape(T, Np, self.output_size)
