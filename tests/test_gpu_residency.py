@@ -340,8 +340,14 @@ def test_persistent_launches_from_several_streams_share_the_chip_when_provably_p
     ref = on_one(3)
     torch.cuda.synchronize()  # (those launches are retired from the gate's list when the next one looks)
 
+    sink = torch.zeros(1, device="cuda")
+
     def counted(n):
         before = fsn._lib.persist_stats()
+        # a small kernel that holds the CALLER's stream for 150 ms first: the side streams wait for it, so none of the
+        # launches below can have finished (or started) by the time the last one is admitted - what the gate decides
+        # does not depend on how fast the host enqueues
+        fsn._lib.check(fsn._lib.lib().fsn_debug_hog(8, 1024, 0, 150.0, fsn._lib.dev_ptr(sink), main.cuda_stream))
         outs = on_streams(n)
         torch.cuda.synchronize()
         after = fsn._lib.persist_stats()
