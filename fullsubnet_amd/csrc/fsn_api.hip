@@ -2759,6 +2759,8 @@ extern "C" int fsn_linear_forward(const float* x, long ldx, const float* w, cons
         return FSN_ERR_WORKSPACE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (fsn_linear_small_out_ok(I, O, ldx))  // a handful of outputs: bandwidth-bound row dot products, no padded GEMM
+        return fsn_launch_linear_small_out(x, ldx, w, b, y, R, I, O, relu, s);
     const int Ip = fsn_round_up(I, 16), Op = fsn_round_up(O, 16);
     Carver cv(workspace);
     float* wp = cv.take<float>((size_t)Op * Ip);
@@ -2801,7 +2803,9 @@ extern "C" int fsn_linear_backward(const float* dy, long lddy, const float* x, l
     size_t tn = fsn_gemm_tn_workspace_bytes(O, I, R);
     const size_t cs = fsn_colsum_workspace_bytes(O, R);
     void* scratch = cv.take<char>(tn > cs ? tn : cs);
-    if (dx) {
+    if (dx && fsn_linear_small_out_ok(I, O, lddx)) {
+        FSN_TRY(fsn_launch_linear_small_dx(dy, lddy, w, dx, lddx, R, I, O, s));
+    } else if (dx) {
         // dX = dY W: "weights" W^T (out = I, k = O) = the stored [O][I] read transposed
         FSN_TRY(fsn_launch_pack(w, wtp, I, O, Ip, Op, s, 1, I));
         FsnGemmA a{};

@@ -225,6 +225,12 @@ struct FsnGemmC {  // C store description
     long ld;       // kind 3: leading dimension of p0
     int rows, cols;  // kind 3: valid extent
 };
+// nn.Linear with O <= 4 outputs and I % 64 == 0 inputs as row dot products / outer products (gemm_kernels.hip)
+bool fsn_linear_small_out_ok(int I, int O, long ldx);
+int fsn_launch_linear_small_out(const float* x, long ldx, const float* w, const float* b, float* y, long R, int I, int O,
+                                int relu, hipStream_t s);
+int fsn_launch_linear_small_dx(const float* dy, long lddy, const float* w, float* dx, long lddx, long R, int I, int O,
+                               hipStream_t s);
 int fsn_launch_gemm(const FsnGemmA& a, const float* w_packed, const FsnGemmC& c, int row_tiles, int col_tiles,
                     int k_chunks, hipStream_t s);
 // W [n_out][k] (transposed = 0) or W^T stored as [k][n_out] (transposed = 1, row stride ldw) -> B fragments

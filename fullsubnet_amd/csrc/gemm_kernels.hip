@@ -385,3 +385,92 @@ int fsn_launch_bias_sum(const float* a, const float* b, float* out, int n, int n
     hipLaunchKernelGGL(bias_sum_kernel, dim3((n_pad + 255) / 256), dim3(256), 0, s, a, b, out, n, n_pad);
     return fsn_check_launch("bias_sum_kernel");
 }
+
+// ---- nn.Linear with a handful of outputs (the sub-band output layer: 384 -> 2, sequence_model.py:82-84) ------------------
+// As a GEMM it is 16 padded columns for 2 real ones and runs at a third of the memory bandwidth it is bound by (0.37 ms
+// for 618 MB at config 3's shape, in each direction).  Forward: one 16-lane group per row, lane p owns the 16-byte groups
+// p, p + 16, ... of the row (one coalesced 256-byte segment per load), fmaf chains in k order, a fixed butterfly.
+// dX = dY W: every thread writes one 16-byte group of a row.
+namespace {
+template <int O>
+__global__ __launch_bounds__(256) void linear_small_out_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                               const float* __restrict__ b, float* __restrict__ y, long R, int I,
+                                                               int relu) {
+    const long r = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int p = threadIdx.x & 15;
+    float acc[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) acc[o] = 0.f;
+    if (r < R) {
+        const float* xr = x + r * ldx;
+        for (int k = 4 * p; k < I; k += 64) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + k);
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (long)o * I + k);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[o] = fmaf(xv[j], wv[j], acc[o]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        acc[o] += __shfl_xor(acc[o], 1, 64);
+        acc[o] += __shfl_xor(acc[o], 2, 64);
+        acc[o] += __shfl_xor(acc[o], 4, 64);
+        acc[o] += __shfl_xor(acc[o], 8, 64);
+    }
+    if (p == 0 && r < R) {
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            const float v = acc[o] + b[o];
+            y[r * O + o] = relu && v < 0.f ? 0.f : v;
+        }
+    }
+}
+template <int O>
+__global__ __launch_bounds__(256) void linear_small_dx_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ w,
+                                                              float* __restrict__ dx, long lddx, long R, int I) {
+    const int groups = I >> 2;  // 16-byte groups per row
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * groups) return;
+    const long r = i / groups;
+    const int k = (int)(i - r * groups) * 4;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        const float d = dy[r * lddy + o];
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (long)o * I + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(d, wv[j], acc[j]);
+    }
+    *reinterpret_cast<f32x4*>(dx + r * lddx + k) = acc;
+}
+}  // namespace
+
+bool fsn_linear_small_out_ok(int I, int O, long ldx) { return O >= 1 && O <= 4 && I % 64 == 0 && ldx % 4 == 0; }
+int fsn_launch_linear_small_out(const float* x, long ldx, const float* w, const float* b, float* y, long R, int I, int O,
+                                int relu, hipStream_t s) {
+    const dim3 grid((unsigned)((R + 15) / 16)), block(256);
+    switch (O) {
+    case 1: hipLaunchKernelGGL(linear_small_out_kernel<1>, grid, block, 0, s, x, ldx, w, b, y, R, I, relu); break;
+    case 2: hipLaunchKernelGGL(linear_small_out_kernel<2>, grid, block, 0, s, x, ldx, w, b, y, R, I, relu); break;
+    case 3: hipLaunchKernelGGL(linear_small_out_kernel<3>, grid, block, 0, s, x, ldx, w, b, y, R, I, relu); break;
+    case 4: hipLaunchKernelGGL(linear_small_out_kernel<4>, grid, block, 0, s, x, ldx, w, b, y, R, I, relu); break;
+    default: fsn_set_error("linear_small_out: O = %d", O); return FSN_ERR_ARG;
+    }
+    return fsn_check_launch("linear_small_out_kernel");
+}
+int fsn_launch_linear_small_dx(const float* dy, long lddy, const float* w, float* dx, long lddx, long R, int I, int O,
+                               hipStream_t s) {
+    const long n = R * (I >> 2);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    switch (O) {
+    case 1: hipLaunchKernelGGL(linear_small_dx_kernel<1>, grid, block, 0, s, dy, lddy, w, dx, lddx, R, I); break;
+    case 2: hipLaunchKernelGGL(linear_small_dx_kernel<2>, grid, block, 0, s, dy, lddy, w, dx, lddx, R, I); break;
+    case 3: hipLaunchKernelGGL(linear_small_dx_kernel<3>, grid, block, 0, s, dy, lddy, w, dx, lddx, R, I); break;
+    case 4: hipLaunchKernelGGL(linear_small_dx_kernel<4>, grid, block, 0, s, dy, lddy, w, dx, lddx, R, I); break;
+    default: fsn_set_error("linear_small_dx: O = %d", O); return FSN_ERR_ARG;
+    }
+    return fsn_check_launch("linear_small_dx_kernel");
+}
