@@ -265,8 +265,8 @@ int fsn_launch_hog(int workgroups, int lds_bytes, int heavy, unsigned long long 
 // ---- residency contract of the persistent kernels whose workgroups wait for each other ----------
 // (fsn_api.hip)  fb_chain_kernel, lstm2_group_kernel, lstm2_group_bptt_kernel and fb_chain_bptt_kernel make progress
 // only when their WHOLE grid is resident.  The library guarantees what it can decide alone - the grid fits an idle
-// device (fsn_grid_fits, from the compiled kernel's occupancy), its own persistent launches never overlap
-// (PersistLaunch) - and bounds what it cannot: a foreign kernel (RCCL, another stream of the process) that holds CUs
+// device (fsn_grid_fits, from the compiled kernel's occupancy), its own persistent launches of different streams
+// share the chip only when the set is provably placeable (PersistLaunch / fsn_persist_admit) - and bounds what it cannot: a foreign kernel (RCCL, another stream of the process) that holds CUs
 // delays the missing workgroups until it ends; the resident ones wait for them, by the CLOCK (fsn_spin_ticks, not by a
 // poll count), and a wait that runs out raises the launch's status word: outputs become NaN and the host learns of it
 // through the stream's sticky status (FSN_ERR_TIMEOUT).
