@@ -134,6 +134,9 @@ SIGNATURES = {
     "fsn_lstm2_fwd_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "fsn_lstm2_forward": (_c.c_int, [_f32p, _c.c_long] + [_f32p] * 8 + [_c.c_int] * 5 + [_f32p, _c.c_void_p, _c.c_size_t,
                                                                                          _c.c_void_p]),
+    "fsn_improved_section_input_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int]),
+    "fsn_improved_section_input": (_c.c_int, [_f32p, _f32p] + [_c.c_int] * 11 + [_c.c_float, _f32p, _c.c_int, _c.c_int,
+                                                                                _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "fsn_lstm2_multi_is_persistent": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_int]),
     "fsn_lstm2_multi_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_void_p, _c.c_int]),
     "fsn_lstm2_forward_multi": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_size_t, _c.c_void_p]),

@@ -2054,6 +2054,39 @@ static LayerPacked layer_packed_layout(int I, int H) {
     p.total = p.bias + fsn_round_up_sz(4 * (size_t)H, 64);
     return p;
 }
+// ---- Improved FullSubNet: the normalised input of one band section, in the LSTM entries' layout ------------------------
+extern "C" size_t fsn_improved_section_input_workspace_bytes(int B, int F) {
+    if (B < 1 || F < 2) return 0;
+    return fsn_round_up_sz(fsn_section_input_workspace_floats(B, F) * sizeof(float), 256);
+}
+extern "C" int fsn_improved_section_input(const float* noisy, const float* fb_out, int B, int F, int T, int lower, int upper,
+                                          int sb_center, int sb_neighbor, int fb_center, int fb_neighbor, int unit_lo,
+                                          int unit_hi, float eps, float* out, int Np, int ldo, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+    CallScope scope(stream);
+    FSN_REQUIRE(noisy && fb_out && out && workspace, "NULL pointer argument");
+    FSN_REQUIRE(B >= 1 && F >= 2 && T >= 1 && 0 <= lower && lower < upper && upper <= F, "section input: bad band [%d, %d) of %d bins",
+                lower, upper, F);
+    FSN_REQUIRE(sb_center >= 1 && fb_center >= 1 && sb_neighbor >= 0 && fb_neighbor >= 0 && (upper - lower) % sb_center == 0 &&
+                    (upper - lower) % fb_center == 0 && (upper - lower) / sb_center == (upper - lower) / fb_center,
+                "section input: the band must hold the same whole number of units for both windows");
+    const int units = (upper - lower) / sb_center, W = sb_center + 2 * sb_neighbor + fb_center + 2 * fb_neighbor;
+    // the reflections of model.py:376-383 are single ones: a window may not reach beyond a mirror image of the spectrum
+    FSN_REQUIRE(sb_neighbor < F && fb_neighbor < F && sb_center + sb_neighbor <= F && fb_center + fb_neighbor <= F,
+                "section input: windows wider than the spectrum");
+    FSN_REQUIRE(0 <= unit_lo && unit_lo < unit_hi && unit_hi <= units, "section input: unit range [%d, %d) of %d", unit_lo, unit_hi,
+                units);
+    FSN_REQUIRE(Np >= B * (unit_hi - unit_lo) && Np <= 65535 && ldo >= W && ldo <= 1024, "section input: out [T][%d][%d] too small",
+                Np, ldo);
+    FSN_REQUIRE(eps > 0.f, "section input: eps must be positive");
+    if (workspace_bytes < fsn_improved_section_input_workspace_bytes(B, F)) {
+        fsn_set_error("section input: workspace too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    return fsn_launch_section_input(noisy, fb_out, B, F, T, lower, units, sb_center, sb_neighbor, fb_center, fb_neighbor, unit_lo,
+                                    unit_hi, eps, out, Np, ldo, workspace, static_cast<hipStream_t>(stream));
+}
+
 // ---- several independent two-layer stacks over the same frames ------------------------------------------------------
 // (improved_fullsubnet/model.py:402-449: the band sections' SequenceModels - B x {20, 25, 6, 4} rows at 48 kHz, input
 // widths 62 .. 180 - all see the same T frames.)  When every stack is H = 384 twice and together they fill most of the

@@ -225,6 +225,11 @@ struct FsnGemmC {  // C store description
     long ld;       // kind 3: leading dimension of p0
     int rows, cols;  // kind 3: valid extent
 };
+// input of one band section of Improved FullSubNet, normalised, in the LSTM entries' layout (section_kernels.hip)
+size_t fsn_section_input_workspace_floats(int B, int F);
+int fsn_launch_section_input(const float* noisy, const float* fb, int B, int F, int T, int lower, int units, int sc, int sn,
+                             int fc, int fn, int u_lo, int u_hi, float eps, float* out, int Np, int ldo, void* workspace,
+                             hipStream_t s);
 // nn.Linear with O <= 4 outputs and I % 64 == 0 inputs as row dot products / outer products (gemm_kernels.hip)
 bool fsn_linear_small_out_ok(int I, int O, long ldx);
 int fsn_launch_linear_small_out(const float* x, long ldx, const float* w, const float* b, float* y, long R, int I, int O,

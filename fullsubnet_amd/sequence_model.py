@@ -165,11 +165,17 @@ class SequenceModel(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return self._forward_train(x)
         B, F, T = x.shape
-        H, Hp = self.hidden_size, _round_up(self.hidden_size, 64)
         Np, Ip = _round_up(B, 16), _round_up(F, 16)
-        layers, fc = self._inference_weights()
         h = torch.zeros((T, Np, Ip), dtype=torch.float32, device=x.device)
         h[:, :B, :F] = x.permute(2, 0, 1)
+        return self.forward_time_major(h, B)
+
+    def forward_time_major(self, h, B):
+        """Inference on an input that is already laid out as the LSTM entries take it: h [T, Np, Ip] time-major, rows
+        beyond B and columns beyond input_size zero (Np, Ip multiples of 16) -> [B, O, T]."""
+        T, Np, _ = h.shape
+        H, Hp = self.hidden_size, _round_up(self.hidden_size, 64)
+        layers, fc = self._inference_weights()
         layer_infer = lstm_layer_infer if self.cell == "LSTM" else gru_layer_infer
         k = 0
         if self.cell == "LSTM":
@@ -228,29 +234,37 @@ def multi_plan(models, shapes):
     return bool(_lib.lib().fsn_lstm2_multi_is_persistent(n, ctypes.byref(stacks), shapes[0][2]))
 
 
-def multi_forward(models, xs):
+def multi_forward(models, xs=None, prepared=None):
     """Several independent two-layer LSTM SequenceModels over the SAME frames (the band sections of Improved FullSubNet,
     improved_fullsubnet/model.py:402-449) through fsn_lstm2_forward_multi: one persistent launch of the group kernel with
     one weight set per model when ``multi_plan`` says so.  models[i](xs[i]) for xs[i] [B_i, F_i, T] -> list of
-    [B_i, O_i, T].  Inference only."""
+    [B_i, O_i, T]; or ``prepared[i] = (h_i [T, Np_i, Ip_i], B_i)``, inputs already in the entries' time-major zero-padded
+    layout.  Inference only."""
     import ctypes
     L = _lib.lib()
     n = len(models)
-    if n < 1 or n > 8 or len(xs) != n:
+    given = prepared if prepared is not None else xs
+    if n < 1 or n > 8 or given is None or len(given) != n:
         raise _lib.FsnError("multi_forward: 1 .. 8 models with one input each")
-    T = xs[0].shape[2]
-    dev = xs[0].device
+    if prepared is None:
+        prepared = []
+        for x in xs:
+            if x.dim() != 3 or not x.is_cuda:
+                raise _lib.FsnError("multi_forward: GPU inputs [B, F, T]")
+            B, F, T = x.shape
+            h = torch.zeros((T, _round_up(B, 16), _round_up(F, 16)), dtype=torch.float32, device=x.device)
+            h[:, :B, :F] = x.permute(2, 0, 1)
+            prepared.append((h, B))
+    T = prepared[0][0].shape[0]
+    dev = prepared[0][0].device
     stacks = (_lib.Lstm2Stack * n)()
     keep, hseqs, meta = [], [], []
-    for i, (m, x) in enumerate(zip(models, xs)):
-        if m.cell != "LSTM" or m.num_layers != 2 or x.dim() != 3 or x.shape[2] != T or not x.is_cuda:
-            raise _lib.FsnError("multi_forward: two-layer LSTM SequenceModels on GPU inputs [B, F, T] with a common T")
-        B, F, _ = x.shape
+    for i, (m, (h, B)) in enumerate(zip(models, prepared)):
+        if m.cell != "LSTM" or m.num_layers != 2 or h.dim() != 3 or h.shape[0] != T or not h.is_cuda:
+            raise _lib.FsnError("multi_forward: two-layer LSTM SequenceModels on GPU inputs with a common T")
         Hp = _round_up(m.hidden_size, 64)
-        Np, Ip = _round_up(B, 16), _round_up(F, 16)
+        Np, Ip = h.shape[1], h.shape[2]
         layers, fc = m._inference_weights()
-        h = torch.zeros((T, Np, Ip), dtype=torch.float32, device=dev)
-        h[:, :B, :F] = x.permute(2, 0, 1)
         hseq = torch.empty((T, Np, Hp), dtype=torch.float32, device=dev)
         q = stacks[i]
         q.x, q.ldx = h.data_ptr(), Ip

@@ -223,6 +223,20 @@ int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, const float*
                       const float* b_hh1, int T, int N, int I, int H0, int H1, float* hseq1, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* improved_fullsubnet/model.py:402-440 (SubbandModel.forward up to the sequence model) for one band section
+ * [lower, upper) of the F-bin inputs noisy / fb_out [B][F][T]: unit u sees the noisy bins lower + u c - n .. (c =
+ * sb_center, n = sb_neighbor; model.py:315-400 `_freq_unfold`, reflected at both ends of the spectrum) and the same
+ * window of the full-band output (fb_center, fb_neighbor), concatenated and divided by (the mean of the WHOLE section's
+ * unfolded input of that utterance + eps): offline_laplace_norm, model.py:124-150 (eps = torch.finfo(float32).eps
+ * there).  The result is written for units [unit_lo, unit_hi) in the layout the LSTM entries take: out [T][Np][ldo],
+ * row b (unit_hi - unit_lo) + (u - unit_lo), columns beyond the window and rows beyond B (unit_hi - unit_lo) zero.
+ * The unfolded tensor is never formed (three launches instead of nine per section). */
+size_t fsn_improved_section_input_workspace_bytes(int B, int F);
+int fsn_improved_section_input(const float* noisy, const float* fb_out, int B, int F, int T, int lower, int upper,
+                               int sb_center, int sb_neighbor, int fb_center, int fb_neighbor, int unit_lo, int unit_hi,
+                               float eps, float* out, int Np, int ldo, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
 /* Up to eight INDEPENDENT two-layer stacks over the same T frames: the band sections of
  * improved_fullsubnet/model.py:402-449, whose SequenceModels have B x {20, 25, 6, 4} rows and input widths 62 .. 180 at
  * 48 kHz.  Per stack the arguments of fsn_lstm2_forward.  When every stack has H0 = H1 = 384 and together they fill

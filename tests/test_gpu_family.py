@@ -255,6 +255,36 @@ def test_improved_fullsubnet_at_baseline_length_vs_reference(fsn, golden_dir):
     assert np.abs(enh - z["enhanced"]).max() <= 1e-4 * float(z["enhanced_absmax"])
 
 
+@pytest.mark.parametrize("cfg", [MF.IMPROVED_16K, MF.IMPROVED_48K])
+def test_improved_section_input_kernel_vs_the_unfolded_tensor(fsn, cfg):
+    """fsn_improved_section_input (gather + offline Laplace norm + time-major layout, the unfolded tensor never formed)
+    against the reference's operation sequence as tensor algebra (model.py:402-440: two `_freq_unfold`s, cat, norm) for
+    every section, whole and on a unit range (the norm statistic is the whole section's either way)."""
+    from fullsubnet_amd.improved_fullsubnet import Model
+    torch.manual_seed(3)
+    m = Model(**cfg).cuda().eval()
+    sb = m.sb_model
+    B, F, T = 3, cfg["num_freqs"] - 1, 77
+    noisy = torch.rand(B, 1, F, T, device="cuda") + 0.05
+    fb = torch.randn(B, 1, F, T, device="cuda")
+    worst = 0.0
+    with torch.no_grad():
+        for i, n_units in enumerate(sb.num_units(F)):
+            for units in (None, (1, n_units), (0, 1)):
+                if units is not None and units[1] > n_units:
+                    continue
+                want = sb._section_input(noisy, fb, i, units)  # [B, n, 1, W, T]
+                h, rows = sb._section_prepared(noisy, fb, i, units)
+                n, W = want.shape[1], want.shape[3]
+                assert rows == B * n and h.shape[0] == T and h.shape[1] % 16 == 0 and h.shape[2] % 16 == 0
+                got = h[:, :rows, :W].permute(1, 2, 0).reshape(B, n, 1, W, T)
+                worst = max(worst, ((got - want).abs().max() / want.abs().max()).item())
+                assert torch.equal(h[:, rows:], torch.zeros_like(h[:, rows:]))
+                assert torch.equal(h[:, :, W:], torch.zeros_like(h[:, :, W:]))
+    print(f"section input kernel vs tensor algebra: max relative difference {worst:.3g}")
+    assert worst <= 5e-7
+
+
 def test_improved_fullsubnet_config5_full_size_on_the_persistent_launch(fsn, golden_dir):
     """BASELINE config 5 at its full size - 32 utterances x 3 s at 48 kHz - where the four band sections run as ONE
     persistent launch of the group kernel with a weight set per section (fsn_lstm2_forward_multi).  The reference's
