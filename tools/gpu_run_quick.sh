@@ -1,5 +1,10 @@
 #!/bin/bash
 # scratch session: edit, run, read (kept as the one ad-hoc runner)
-timeout 900 python -m pytest tests/test_gpu_family.py -m gpu -x -q -rP -k "improved" 2>&1 | grep -E "passed|failed|section input|config 5|^E " | tail -8
-for B in 1 2 4 16 32; do timeout 120 python tools/bench_family.py improved48 $B 2>&1 | tail -1; done
-timeout 120 python tools/bench_family.py improved16 1 2>&1 | tail -1
+set -u
+export TMPDIR=/tmp
+O=gpurun_out/q
+mkdir -p $O
+timeout 300 rocprofv3 --kernel-trace -d $O/trace -- python tools/bench_family.py improved48 1 > $O/fam.txt 2>&1
+grep -a "improved48 B" $O/fam.txt
+python tools/rocprof_tail.py $O/trace 75 > $O/tail.txt
+rm -rf $O/trace
