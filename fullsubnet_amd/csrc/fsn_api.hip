@@ -2704,7 +2704,11 @@ extern "C" size_t fsn_gru_layer_bwd_workspace_bytes(int T, int N, int I, int H) 
         const size_t b = fsn_gemm_tn_workspace_bytes(m, H, (long)T * N);
         tn = tn > b ? tn : b;
     }
-    const size_t cs = fsn_colsum_workspace_bytes(G, (long)T * N);
+    size_t cs = 0;  // the column sums fsn_gru_layer_backward forms: 3H, 2H and H columns (each with its own row blocking)
+    for (const int c : {G, 2 * H, H}) {
+        const size_t b = fsn_colsum_workspace_bytes(c, (long)T * N);
+        cs = cs > b ? cs : b;
+    }
     cv.take<char>(tn > cs ? tn : cs);
     return fsn_round_up_sz(cv.off, 256);
 }
