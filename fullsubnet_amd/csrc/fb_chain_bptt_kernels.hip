@@ -5,12 +5,14 @@
 //   layer 1: dh1_t = dH1_t + dgates1_{t+1} W_hh1 -> cell derivative -> dgates1_t
 //   layer 0: dh0_t = dgates1_t W_ih1 + dgates0_{t+1} W_hh0 -> ... -> dgates0_t
 // As 2 x 193 launches of bptt_step_kernel<1, 1, 16> (7.8 us each) this was 3.0 ms of a 45 ms training step.  Here:
-//   - two stages of H / 16 = 32 workgroups: L1 and L0.  A workgroup owns 16 hidden units = one 16-column MFMA tile of
-//     dh for the 16 rows; K = 2048 gate columns is split over its four waves (fixed-order sum through LDS); its slice of
-//     every W^T it needs (2048 x 16 floats each) is read ONCE into registers;
-//   - dgates1_{t+1} W_ih1 (layer 0's dH of step t + 1) has the same A operand as layer 1's own product: the L1
-//     workgroup forms it from the same A fragments AFTER publishing dgates1_t, while its partners' flags are on their
-//     way, and hands the four partial tiles over (summed by L0's reduction); L0 is left with one product;
+//   - three stages of H / 16 = 32 workgroups: L1, X and L0.  A workgroup owns 16 hidden units = one 16-column MFMA tile
+//     of dh for the 16 rows; K = 2048 gate columns is split over its four waves (fixed-order sum through LDS); its slice
+//     of the ONE W^T it needs (2048 x 16 floats) is read once into registers;
+//   - every stage forms one product per step: L1 dgates1_{t+1} W_hh1, X dgates1_t W_ih1 (layer 0's dH of step t, handed
+//     to L0 workgroup j as four partial tiles that L0's reduction sums), L0 dgates0_{t+1} W_hh0.  Round 2 had L1 form
+//     X's product too, after publishing, from the same A fragments: 1.7 us of MFMAs per step that sat on L1's own chain
+//     (the next step's flags arrived while it was still multiplying) - 9.3 us per step; as a stage of its own X follows
+//     L1 by one step and L0 follows X, and a step is one product long;
 //   - the gate-gradient buffers dgates[t] ([16][2048] per step; the weight-gradient GEMMs read them afterwards) are the
 //     exchange buffers: write-through stores, drain, flag copies; one wave polls; sc1 loads; nothing is reused;
 //   - the saved activations of a step are requested AFTER the A fragments (loads return in order: requested first they
@@ -32,7 +34,7 @@ struct ChainBpttArgs {
     const float *gates0, *cseq0, *gates1, *cseq1;  // saved by the forward pass: [Tp][16][4H], [Tp][16][H]
     float *dg0, *dg1;     // [Tp][16][4H]: gate gradients (outputs and exchange buffers)
     float* dx;            // [Tp][QNW][4 waves][64][4]: partial tiles of dgates1_t W_ih1 (layer 0's dH)
-    unsigned* flags;      // [2][QREP][QNW]: steps published by (L1 | L0, workgroup)
+    unsigned* flags;      // [3][QREP][QNW]: steps published by (L1 | L0 | X, workgroup)
     unsigned* status;
     unsigned long long spin_ticks;  // wait bound (fsn_spin_ticks)
     int Tp;
@@ -54,12 +56,14 @@ __device__ __forceinline__ bool qwait(const unsigned* flags, unsigned epoch, con
 
 __global__ __launch_bounds__(256, 1) void fb_chain_bptt_kernel(const ChainBpttArgs a) {
     __shared__ f32x4 red[3][64];
-    const int l1 = (int)blockIdx.x < QNW ? 1 : 0, j = (int)blockIdx.x % QNW;  // first half of the grid: layer 1
+    const int role = (int)blockIdx.x / QNW, j = (int)blockIdx.x % QNW;  // thirds of the grid: L1, X, L0
+    const int l1 = role == 0 ? 1 : 0;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const int Tp = a.Tp;
     unsigned* fl1 = a.flags;                 // [QREP][QNW]
     unsigned* fl0 = a.flags + QREP * QNW;
+    unsigned* flx = a.flags + 2 * QREP * QNW;
     const int rep = j % QREP;
     const unsigned lane16 = (unsigned)lane * 16u;
 
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void fb_chain_bptt_kernel(const ChainBpttAr
     float dc[4] = {0.f, 0.f, 0.f, 0.f};
 
     f32x4 whh[QCW], ar[QCW];
-    load_w(l1 ? a.whh1T_p : a.whh0T_p, whh);
+    load_w(role == 0 ? a.whh1T_p : role == 1 ? a.wih1T_p : a.whh0T_p, whh);
 
     // cell derivative of rows 4 lq + i, unit 16 j + lr (wave 0) from dh -> dgates_t (write-through)
     auto cell = [&](int t, f32x4 dh, const float (&e_g)[4][4], const float (&e_ct)[4], const float (&e_cp)[4]) {
@@ -155,14 +159,9 @@ __global__ __launch_bounds__(256, 1) void fb_chain_bptt_kernel(const ChainBpttAr
         }
     };
 
-    if (l1) {
-        f32x4 wih[QCW];
-        load_w(a.wih1T_p, wih);
-        // iteration t: dgates1_t (t >= 0) and the partial tiles of dgates1_{t+1} W_ih1 (t < Tp - 1), both from the A
-        // fragments of dgates1_{t+1}; t = -1 only produces dx_0.  Epoch Tp - t is published after dgates1_t is stored
-        // and drained; the dx tile of step t + 1 is stored after that flag and covered by the NEXT drain: complete once
-        // this workgroup has published Tp - t + 1.
-        for (int t = Tp - 1; t >= -1; --t) {
+    if (role == 0) {
+        // ---- L1: dgates1_t from dH1_t + dgates1_{t+1} W_hh1; epoch Tp - t is published once dgates1_t is stored, drained
+        for (int t = Tp - 1; t >= 0; --t) {
             const unsigned done = (unsigned)(Tp - 1 - t);
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
             float e_g[4][4], e_ct[4], e_cp[4], e_dh[4];
@@ -171,28 +170,35 @@ __global__ __launch_bounds__(256, 1) void fb_chain_bptt_kernel(const ChainBpttAr
                 __syncthreads();
                 load_a(ar, a.dg1, t + 1);
             }
-            if (t >= 0) {
-                if (wave == 0) load_saved(t, e_g, e_ct, e_cp, e_dh);
-                if (t < Tp - 1) acc = mac(acc, ar, whh);
-                acc = reduce(acc);
-                if (wave == 0)
-                    cell(t, f32x4{acc[0] + e_dh[0], acc[1] + e_dh[1], acc[2] + e_dh[2], acc[3] + e_dh[3]}, e_g, e_ct, e_cp);
-            }
+            if (wave == 0) load_saved(t, e_g, e_ct, e_cp, e_dh);
+            if (t < Tp - 1) acc = mac(acc, ar, whh);
+            acc = reduce(acc);
+            if (wave == 0)
+                cell(t, f32x4{acc[0] + e_dh[0], acc[1] + e_dh[1], acc[2] + e_dh[2], acc[3] + e_dh[3]}, e_g, e_ct, e_cp);
             publish(fl1, done + 1);
-            if (t < Tp - 1) {
-                const f32x4 accx = mac(f32x4{0.f, 0.f, 0.f, 0.f}, ar, wih);
-                const unsigned so = (unsigned)(t + 1) * dx_step + dx_wave;
-                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1" ::"v"(accx), "v"(lane16), "s"(rdx), "s"(so) : "memory");
-            }
         }
-        publish(fl1, (unsigned)Tp + 2);  // covers dx_0
+        return;
+    }
+    if (role == 1) {
+        // ---- X: the partial tiles of dx_t = dgates1_t W_ih1 (layer 0's dH of step t), one per wave, for L0 workgroup j;
+        // dgates1_t is complete at L1's epoch Tp - t; this workgroup publishes the same epoch once its tile is drained
+        for (int t = Tp - 1; t >= 0; --t) {
+            const unsigned epoch = (unsigned)(Tp - t);
+            if (wave == 0) (void)qwait(fl1 + rep * QNW, epoch, nullptr, 0, a.status, a.spin_ticks);
+            __syncthreads();
+            load_a(ar, a.dg1, t);
+            const f32x4 accx = mac(f32x4{0.f, 0.f, 0.f, 0.f}, ar, whh);
+            const unsigned so = (unsigned)t * dx_step + dx_wave;
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1" ::"v"(accx), "v"(lane16), "s"(rdx), "s"(so) : "memory");
+            publish(flx, epoch);
+        }
         return;
     }
     // ---- L0: dh0_t = dx_t (four partial tiles from L1 workgroup j, one per wave) + dgates0_{t+1} W_hh0 -------------
     for (int t = Tp - 1; t >= 0; --t) {
         const unsigned done = (unsigned)(Tp - 1 - t);
-        // dx_t was stored by L1 workgroup j in its iteration t - 1, complete at its epoch Tp - (t - 1) + 1 = done + 3
-        if (wave == 0) (void)qwait(fl0 + rep * QNW, done, fl1 + rep * QNW + j, done + 3, a.status, a.spin_ticks);
+        // dx_t: stored by X workgroup j, complete at its epoch Tp - t = done + 1
+        if (wave == 0) (void)qwait(fl0 + rep * QNW, done, flx + rep * QNW + j, done + 1, a.status, a.spin_ticks);
         __syncthreads();
         f32x4 acc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdx, lane16, (unsigned)t * dx_step + dx_wave, 16));
         float e_g[4][4], e_ct[4], e_cp[4], e_dh[4];
@@ -209,13 +215,13 @@ __global__ __launch_bounds__(256, 1) void fb_chain_bptt_kernel(const ChainBpttAr
 
 bool fsn_fb_chain_bptt_supported(int H, int N) {
     if (H != QH || N != 16 || !fsn_persistent_allowed()) return false;
-    return fsn_grid_fits((const void*)fb_chain_bptt_kernel, 256, 2 * QNW);  // residency contract
+    return fsn_grid_fits((const void*)fb_chain_bptt_kernel, 256, 3 * QNW);  // residency contract
 }
 // dx is addressed as t * 128 KB through 32-bit byte offsets
 int fsn_fb_chain_bptt_max_steps() { return (int)(0x7fffffffu / ((unsigned)QNW * 4096u)) - 1; }
 size_t fsn_fb_chain_bptt_dx_floats(int Tp) { return (size_t)Tp * QNW * 1024; }
-size_t fsn_fb_chain_bptt_flag_words() { return (size_t)2 * QREP * QNW + 16; }
-size_t fsn_fb_chain_bptt_status_word() { return (size_t)2 * QREP * QNW; }
+size_t fsn_fb_chain_bptt_flag_words() { return (size_t)3 * QREP * QNW + 16; }
+size_t fsn_fb_chain_bptt_status_word() { return (size_t)3 * QREP * QNW; }
 
 // dh1 [Tp][16][H]; W^T matrices packed by fsn_launch_pack(..., transposed = 1); save0 / save1 in
 // fsn_lstm_layer_forward's layout; dg0 / dg1 [Tp][16][4H] out; dx: fsn_fb_chain_bptt_dx_floats(Tp) scratch.
@@ -243,6 +249,6 @@ int fsn_launch_fb_chain_bptt(const float* dh1, const float* whh1T_p, const float
     a.status = flags + fsn_fb_chain_bptt_status_word();
     a.spin_ticks = fsn_spin_ticks();
     a.Tp = Tp;
-    FSN_PERSIST_LAUNCH(fb_chain_bptt_kernel, dim3(2 * QNW), dim3(256), s, a);
+    FSN_PERSIST_LAUNCH(fb_chain_bptt_kernel, dim3(3 * QNW), dim3(256), s, a);
     return fsn_check_launch("fb_chain_bptt_kernel");
 }
