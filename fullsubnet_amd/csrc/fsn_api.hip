@@ -2076,8 +2076,9 @@ extern "C" int fsn_improved_section_input(const float* noisy, const float* fb_ou
                 "section input: windows wider than the spectrum");
     FSN_REQUIRE(0 <= unit_lo && unit_lo < unit_hi && unit_hi <= units, "section input: unit range [%d, %d) of %d", unit_lo, unit_hi,
                 units);
-    FSN_REQUIRE(Np >= B * (unit_hi - unit_lo) && Np <= 65535 && ldo >= W && ldo <= 1024, "section input: out [T][%d][%d] too small",
-                Np, ldo);
+    FSN_REQUIRE(Np >= B * (unit_hi - unit_lo) && Np <= 65535 && ldo >= W && ldo <= 240,
+                "section input: out [T][%d][%d]: rows up to 65535, the window's %d columns up to 240 (a 64-frame tile in LDS)", Np,
+                ldo, W);
     FSN_REQUIRE(eps > 0.f, "section input: eps must be positive");
     if (workspace_bytes < fsn_improved_section_input_workspace_bytes(B, F)) {
         fsn_set_error("section input: workspace too small");

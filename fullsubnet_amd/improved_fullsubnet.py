@@ -194,6 +194,8 @@ class SubbandModel(BaseModel):
         width = sc + 2 * sn + fc + 2 * fn
         rows = B * (hi - lo)
         Np, Ip = _round_up(rows, 16), _round_up(width, 16)
+        if Ip > 240 or Np > 65535:  # beyond the kernel's tile (include/fsn_hip.h): through the unfolded tensor
+            return None
         x = noisy_input.reshape(B, F, T).contiguous()
         f = fb_output.reshape(B, F, T).contiguous()
         h = torch.empty((T, Np, Ip), dtype=torch.float32, device=x.device)

@@ -229,7 +229,8 @@ int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, const float*
  * window of the full-band output (fb_center, fb_neighbor), concatenated and divided by (the mean of the WHOLE section's
  * unfolded input of that utterance + eps): offline_laplace_norm, model.py:124-150 (eps = torch.finfo(float32).eps
  * there).  The result is written for units [unit_lo, unit_hi) in the layout the LSTM entries take: out [T][Np][ldo],
- * row b (unit_hi - unit_lo) + (u - unit_lo), columns beyond the window and rows beyond B (unit_hi - unit_lo) zero.
+ * row b (unit_hi - unit_lo) + (u - unit_lo), columns beyond the window and rows beyond B (unit_hi - unit_lo) zero
+ * (Np <= 65535 rows, ldo <= 240 columns).
  * The unfolded tensor is never formed (three launches instead of nine per section). */
 size_t fsn_improved_section_input_workspace_bytes(int B, int F);
 int fsn_improved_section_input(const float* noisy, const float* fb_out, int B, int F, int T, int lower, int upper,
