@@ -355,6 +355,10 @@ int fsn_launch_gemm(const FsnGemmA& a, const float* wp, const FsnGemmC& c, int r
             return launch<0, 3, 8, 4, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s, 1, kOnePerCu);
         // a one-tile-wide output layer over many rows is HBM-bound on reading its input: many waves in flight
         if (row_tiles >= 2048 && col_tiles == 1) return launch<0, 3, 4, 1, 4, 1>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
+        // two tiles wide over many rows (the sub-band model's input gradient: 402 k rows x 32 columns, K = 1536, 2.5 GB of
+        // gate gradients to read): every wave owns both column tiles of four row tiles - as 2 x 2 waves of 2 x 2 tiles half
+        // of the workgroup had no columns: 1.08 -> 0.63 ms (deeper prefetch or 2 row tiles per wave: no better)
+        if (row_tiles >= 2048 && col_tiles == 2) return launch<0, 3, 4, 2, 4, 1>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
         return launch<0, 3, 2, 2, 2, 2>(a, wp, c, row_tiles, col_tiles, k_chunks, s);
     }
     fsn_set_error("fsn_launch_gemm: unsupported operand kinds A=%d C=%d", a.kind, c.kind);

@@ -4,12 +4,9 @@ set -u
 export TMPDIR=/tmp
 O=gpurun_out/q
 mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_amp.py tests/test_gpu_trainer.py tests/test_gpu_residency.py -m gpu -x -q -rP 2>&1 | grep -E "passed|failed|margins|^E " | tail -6
-for A in f32 f16; do
-  timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_$A -- python tools/bench_train.py 16 $A > $O/train_$A.txt 2>&1
-  DB=$(ls $O/trace_$A/*/*.db 2>/dev/null | head -1)
-  [ -n "$DB" ] && python tools/rocprof_summary.py $DB $O/kernel_stats_train_$A.md "x"
-  grep -a "train step" $O/train_$A.txt
-  grep "fb_chain" $O/kernel_stats_train_$A.md | cut -c1-100
-  rm -rf $O/trace_$A
-done
+timeout 300 rocprofv3 --kernel-trace -d $O/trace -- python tools/bench_train.py 16 f16 > $O/train.txt 2>&1
+grep -a "train step" $O/train.txt
+python tools/rocprof_kernel_calls.py $O/trace "gemm_kernel<0, 3, 2, 2, 4" 2
+python tools/rocprof_kernel_calls.py $O/trace "gemm_kernel<0, 3, 2, 2, 2" 1
+rm -rf $O/trace
+timeout 600 python -m pytest tests/test_gpu_train.py -m gpu -x -q 2>&1 | tail -2
