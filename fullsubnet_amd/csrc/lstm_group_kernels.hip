@@ -30,11 +30,22 @@
 #ifndef FSN_GRP_CPS
 #define FSN_GRP_CPS 2       // K chunks per LDS stage of the weight fragments = per workgroup barrier (probe: 1 -> 11.09 ms, 2 -> 10.88)
 #endif
+#ifndef FSN_GRP_CPS16
+#define FSN_GRP_CPS16 4     // the same under the 16-bit arithmetic: fragments are half as large and a chunk is 8x fewer MFMA cycles
+#endif
+#ifndef FSN_GRP_AD16
+#define FSN_GRP_AD16 8      // a multiple of FSN_GRP_CPS16
+#endif
 #ifndef FSN_GRP_BIAS_LDS
 #define FSN_GRP_BIAS_LDS 1  // biases in LDS also with one cluster per workgroup set (frees 12 registers for the ring)
 #endif
 
 namespace {
+
+template <int AR>
+constexpr int grp_cps() { return AR == FSN_ARITH_F32 ? FSN_GRP_CPS : FSN_GRP_CPS16; }
+template <int AR>
+constexpr int grp_ad() { return AR == FSN_ARITH_F32 ? FSN_GRP_AD : FSN_GRP_AD16; }
 
 constexpr int GH = 384;          // hidden units (both layers)
 constexpr int GKC = GH / 16;     // K chunks of an H-wide operand
@@ -133,7 +144,7 @@ struct GrpCl {
 // training); data movement and everything stored are the same in every mode
 template <int LAYER, int ABL, bool TRAIN, int NCL, bool SAVE, int AR, bool GX = false>
 __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int cluster_b, int member,
-                                           typename FsnWFrag<AR>::type (*bsh)[GU * 4 * FSN_GRP_CPS][64], float (*bias_sh)[16]) {
+                                           typename FsnWFrag<AR>::type (*bsh)[GU * 4 * grp_cps<AR>()][64], float (*bias_sh)[16]) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const int Tp = a.Tp;
@@ -208,7 +219,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
         // first touch after the acquire costs a trip to the Infinity Cache / HBM, several chunks of MFMA time.  They
         // are therefore requested AD chunks ahead (a register ring, indexed statically by unrolling the loop AD-fold);
         // the weight fragments (L2 hits) one chunk ahead, through LDS.
-        constexpr int AD = FSN_GRP_AD;
+        constexpr int AD = grp_ad<AR>();
         f32x4 ar[AD];
         typename FsnWFrag<AR>::type bn[GU];
         auto fetch_a = [&](int k) -> f32x4 {
@@ -234,7 +245,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
         };
 #pragma unroll
         for (int d = 0; d < AD; ++d) ar[d] = fetch_a(d);
-        constexpr int CPS = FSN_GRP_CPS;
+        constexpr int CPS = grp_cps<AR>();
         static_assert(AD % CPS == 0, "the A ring turns in whole stages");
 #pragma unroll
         for (int c = 0; c < CPS; ++c) {
@@ -279,6 +290,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
                 }
             }
         }
+        if (n % CPS) __syncthreads();  // a last, partial stage (layer 0's 2 + 24 chunks at four per stage): close it as well
     };
 
     // Flags are looked at EARLY (before a K loop) and checked after it: in the steady state the early look already
@@ -497,7 +509,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
 template <int ABL, bool TRAIN = false, int NCL = 1, bool SAVE = TRAIN, int AR = FSN_ARITH_F32>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void lstm2_group_kernel(const GrpArgs a) {
     // weight fragments of one K chunk, shared by the four waves: two stages x 12 fragments x 1 KB
-    __shared__ typename FsnWFrag<AR>::type bsh[2][GU * 4 * FSN_GRP_CPS][64];
+    __shared__ typename FsnWFrag<AR>::type bsh[2][GU * 4 * grp_cps<AR>()][64];
     __shared__ float bias_sh[GU * 4][16];
     // The first half of the grid runs layer 0, the second half layer 1: blocks are handed out in order, one per CU
     // before any CU gets its second, so that every CU ends up with one workgroup of each layer (speed only).  Within a
