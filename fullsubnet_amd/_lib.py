@@ -260,11 +260,34 @@ def stream_ptr(device=None):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+_CANARY = 4096     # bytes of guard pattern behind every workspace when FSN_WS_CANARY is set (memory-safety runs)
+_canaries = []      # (guarded tensor, payload bytes) not yet verified
+
+
 def workspace(nbytes, device):
-    """Workspace from PyTorch's caching allocator (the library never allocates)."""
+    """Workspace from PyTorch's caching allocator (the library never allocates).  With FSN_WS_CANARY in the environment
+    (tools/gpu_run_nocache.sh) every workspace is followed by a guard pattern that `check_canaries` verifies: a kernel
+    that writes beyond the size its `*_workspace_bytes` query promised is caught even when the overrun stays inside
+    memory the process owns."""
     if nbytes <= 0:
         raise FsnError(f"workspace query failed: {lib().fsn_last_error().decode()}")
+    if os.environ.get("FSN_WS_CANARY"):
+        buf = torch.empty(nbytes + _CANARY, dtype=torch.uint8, device=device)
+        buf[nbytes:].fill_(0xA5)
+        _canaries.append((buf, nbytes))
+        return buf[:nbytes]
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def check_canaries():
+    """Verify and forget the guard patterns of the workspaces handed out since the last call (synchronises)."""
+    bad = []
+    while _canaries:
+        buf, n = _canaries.pop()
+        if not bool((buf[n:] == 0xA5).all()):
+            bad.append(n)
+    if bad:
+        raise FsnError(f"workspace overrun: the guard behind workspaces of {bad} bytes was overwritten")
 
 
 def profile_enable(on, device=None):

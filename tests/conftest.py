@@ -29,3 +29,13 @@ def _library_present():
         from fullsubnet_amd import build as b
         b.build(force=True)
     yield
+
+
+@pytest.fixture(autouse=True)
+def _workspace_canaries():
+    """Memory-safety runs (FSN_WS_CANARY=1, tools/gpu_run_nocache.sh): after every test, the guard patterns behind the
+    workspaces it handed to the library must be intact."""
+    yield
+    if os.environ.get("FSN_WS_CANARY"):
+        from fullsubnet_amd import _lib
+        _lib.check_canaries()
