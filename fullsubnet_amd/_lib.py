@@ -175,6 +175,8 @@ SIGNATURES = {
     "fsn_stream_status_clear": (_c.c_int, [_c.c_void_p]),
     "fsn_debug_hog": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_float, _f32p, _c.c_void_p]),
     "fsn_debug_persist_stats": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "fsn_debug_persist_set_fits": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p]),
+    "fsn_debug_tn_plan": (_c.c_int, [_c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "fsn_profile_num_stages": (_c.c_int, []),
     "fsn_profile_stage_name": (_c.c_char_p, [_c.c_int]),
     "fsn_profile_read": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_float), _c.c_int]),

@@ -98,7 +98,7 @@ static std::atomic<int> g_persist_timeout_ms{20000};  // fsn_set_persistent_time
 //   for every k of the set.
 // One kernel alone is always admitted (its own grid was checked against occ x CUs at plan time).  Examples on 256 CUs:
 // two chain launches of H = 384 with two row tiles (192 workgroups, 2 per CU each) run side by side, a third waits; two
-// group launches of 28 clusters (448 workgroups, 4 per CU) do not.  Nothing else of the streams is ordered.  Not under
+// group launches of 28 clusters (448 workgroups, 2 per CU) do not.  Nothing else of the streams is ordered.  Not under
 // stream capture: the replays of a graph are ordered by whoever launches them.
 struct PersistEntry {
     hipEvent_t ev;
@@ -403,6 +403,24 @@ extern "C" int fsn_set_persistent_mode(int mode) {
     FSN_REQUIRE(mode == FSN_PERSISTENT_AUTO || mode == FSN_PERSISTENT_NEVER, "persistent mode %d unknown", mode);
     g_persist_mode.store(mode, std::memory_order_relaxed);
     return FSN_OK;
+}
+// Test hooks without a device: the gate's admission rule on a hypothetical set (n launches, fractions of the chip and
+// resident workgroups per CU), and the K-split plan of a weight-gradient product against the bound its scratch is sized by.
+extern "C" int fsn_debug_persist_set_fits(int n, const double* fracs, const int* occs) {
+    if (n < 1 || n > 64 || !fracs || !occs) return -1;
+    std::vector<PersistEntry> e((size_t)n);
+    std::vector<const PersistEntry*> set;
+    for (int i = 0; i < n; ++i) {
+        e[(size_t)i].frac = fracs[i];
+        e[(size_t)i].occ = occs[i] < 1 ? 1 : occs[i] > 8 ? 8 : occs[i];
+        set.push_back(&e[(size_t)i]);
+    }
+    return n == 1 || persist_set_fits(set) ? 1 : 0;
+}
+extern "C" int fsn_debug_tn_plan(int M, int Nc, long K, int arith, int* splits, long* bound) {
+    if (M < 1 || Nc < 1 || K < 1) return -1;
+    fsn_tn_plan_splits(M, Nc, K, arith, splits, bound);
+    return 0;
 }
 extern "C" int fsn_debug_persist_stats(unsigned* launches, unsigned* waits, unsigned* unreported) {
     if (launches) *launches = g_persist_launches.load(std::memory_order_relaxed);

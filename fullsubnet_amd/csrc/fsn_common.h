@@ -230,6 +230,7 @@ size_t fsn_section_input_workspace_floats(int B, int F);
 int fsn_launch_section_input(const float* noisy, const float* fb, int B, int F, int T, int lower, int units, int sc, int sn,
                              int fc, int fn, int u_lo, int u_hi, float eps, float* out, int Np, int ldo, void* workspace,
                              hipStream_t s);
+void fsn_tn_plan_splits(int M, int Nc, long K, int arith, int* splits, long* bound);  // lstm_train_kernels.hip (test hook)
 // nn.Linear with O <= 4 outputs and I % 64 == 0 inputs as row dot products / outer products (gemm_kernels.hip)
 bool fsn_linear_small_out_ok(int I, int O, long ldx);
 int fsn_launch_linear_small_out(const float* x, long ldx, const float* w, const float* b, float* y, long R, int I, int O,

@@ -424,6 +424,15 @@ static long tn_max_splits(int M, int Nc) {
     }
     return splits;
 }
+// test hook (fsn_debug_tn_plan): the K splits fsn_launch_gemm_tn would take for this product and the bound its scratch is
+// sized by
+void fsn_tn_plan_splits(int M, int Nc, long K, int arith, int* splits, long* bound) {
+    const bool swap = M <= 32 && Nc > 32;
+    const long K16 = K & ~15L;
+    const TnPlan p = K16 <= 0 ? TnPlan{} : swap ? tn_plan(Nc, M, K16, arith, false) : tn_plan(M, Nc, K16, arith);
+    if (splits) *splits = K16 <= 0 ? 1 : p.splits;
+    if (bound) *bound = tn_max_splits(M, Nc);
+}
 size_t fsn_gemm_tn_workspace_bytes(int M, int Nc, long K) {
     if ((K & ~15L) <= 0) return (size_t)M * (Nc + 1) * sizeof(float);
     return (size_t)tn_max_splits(M, Nc) * M * (Nc + 1) * sizeof(float);  // + one column-sum row per split

@@ -394,6 +394,12 @@ int fsn_debug_hog(int workgroups, int lds_bytes, int heavy, float ms, float* sin
 /* Test hook: persistent launches admitted so far (process-wide), stream waits inserted between them, and launches
  * that did not report their footprint (must stay 0).  Any pointer may be NULL. */
 int fsn_debug_persist_stats(unsigned* launches, unsigned* waits, unsigned* unreported);
+/* Test hooks that need no device.  fsn_debug_persist_set_fits: 1 when the gate would let n persistent launches with the
+ * given chip fractions (grid / (occ x CUs)) and occupancies run side by side, 0 when the newest has to wait.
+ * fsn_debug_tn_plan: the K splits a weight-gradient product [M x Nc], K rows, would take (*splits) and the bound the
+ * scratch of every caller is sized by (*bound >= *splits must hold for every shape). */
+int fsn_debug_persist_set_fits(int n, const double* fracs, const int* occs);
+int fsn_debug_tn_plan(int M, int Nc, long K, int arith, int* splits, long* bound);
 int fsn_profile_num_stages(void);
 const char* fsn_profile_stage_name(int stage);
 int fsn_profile_read(void* stream, float* ms_per_stage, int n);

@@ -244,3 +244,54 @@ def test_subband_multiplicity_closed_form():
         assert brute(F, nb) == closed(F, nb), (F, nb)
     m = closed(257, 15)
     assert m[0] == m[256] == 16 and m[1] == 32 and m[100] == 31 and sum(m) == 31 * 257
+
+
+def test_gate_admission_rule_of_persistent_launches():
+    """The rule of fsn_api.hip's PersistLaunch on hypothetical sets, no device needed: launches of different
+    streams run side by side only when every workgroup of every kernel is placeable in any dispatch order - the sum of
+    chip fractions stays below the smallest CU fill that could refuse a workgroup of any kernel of the set."""
+    import ctypes
+    from fullsubnet_amd import _lib
+    L = _lib.lib()
+
+    def fits(*launches):  # (workgroups, resident per CU) on 256 CUs
+        n = len(launches)
+        fr = (ctypes.c_double * n)(*[wg / (occ * 256.0) for wg, occ in launches])
+        oc = (ctypes.c_int * n)(*[occ for _, occ in launches])
+        return L.fsn_debug_persist_set_fits(n, fr, oc)
+
+    chain2, chain4, chain1 = (192, 2), (192, 4), (192, 1)  # H = 384 chain kernel: 2 / 1 / 4 row tiles
+    group, group_small = (448, 2), (160, 2)                # group kernel (two resident per CU): 28 and 10 clusters
+    assert fits(chain2) == 1 and fits(group) == 1 and fits((512, 2)) == 1  # alone: always (the plan checked the grid)
+    assert fits(chain2, chain2) == 1          # 384 half-CU workgroups on 512 half-CU slots: no fragmentation possible
+    assert fits(chain2, chain4) == 1
+    assert fits(chain4, chain4) == 1
+    assert fits(chain2, chain2, chain4) == 0  # 0.94 of the chip in two sizes: a state with every CU > 1/2 full exists
+    assert fits(chain2, chain4, chain4) == 0  # 0.75 = the fill that can refuse a half-CU workgroup: refused (conservative)
+    assert fits(chain1, chain4) == 0          # a one-per-CU kernel shares with nothing
+    assert fits(group, group) == 0            # 1.75 chips' worth
+    assert fits((448, 4), (448, 4)) == 1      # the same grids at four per CU: 896 quarter-CU workgroups on 1024 slots
+    assert fits(group_small, group_small) == 1
+    assert fits(group, chain2) == 0
+    # more launches never make a refused set admissible
+    assert fits(chain2, chain2, chain4, chain4) == 0
+
+
+def test_weight_gradient_scratch_bound_covers_every_plan():
+    """fsn_launch_gemm_tn splits K by one of two plans (256 x 128 tiles, or 192 x 192 tiles with every split on one XCD),
+    depending on shape and K; every caller sizes ONE scratch buffer per shape by the bound of
+    fsn_gemm_tn_workspace_bytes.  A plan beyond that bound was a memory overrun in round 3 (the GRU backward's 2H x H and
+    H x H products): the bound must cover the plan for every shape and every K."""
+    import ctypes
+    from fullsubnet_amd import _lib
+    L = _lib.lib()
+    worst = 0.0
+    for M in (64, 192, 257, 384, 512, 768, 1024, 1152, 1536, 2048, 3072):
+        for Nc in (2, 16, 32, 33, 64, 128, 192, 257, 384, 416, 512, 768):
+            for K in (16, 100, 2000, 8192, 9504, 65536, 402480, 3000000):
+                for arith in (_lib.ARITH["f32"], _lib.ARITH["f16"], _lib.ARITH["bf16"]):
+                    splits, bound = ctypes.c_int(0), ctypes.c_long(0)
+                    assert L.fsn_debug_tn_plan(M, Nc, K, arith, ctypes.byref(splits), ctypes.byref(bound)) == 0
+                    assert 1 <= splits.value <= bound.value, (M, Nc, K, arith, splits.value, bound.value)
+                    worst = max(worst, splits.value / bound.value)
+    assert worst == 1.0  # the bound is attained somewhere: it is not a loose over-estimate
