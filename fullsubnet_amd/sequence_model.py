@@ -22,13 +22,13 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
-def pad_lstm_weights(w_ih, w_hh, b_ih, b_hh, in_pad):
+def pad_lstm_weights(w_ih, w_hh, b_ih, b_hh, in_pad, hidden_pad=None):
     """nn.LSTM / nn.GRU layer tensors ([gH, I], [gH, H], [gH], [gH], g = 4 / 3 gates) -> the same layer
-    with H padded to a multiple of 64 and I padded to ``in_pad`` columns (gate blocks stay contiguous).
-    Plain torch ops, so gradients flow back to the unpadded parameters when autograd is recording."""
+    with H padded to a multiple of 64 (or to ``hidden_pad``) and I padded to ``in_pad`` columns (gate blocks stay
+    contiguous).  Plain torch ops, so gradients flow back to the unpadded parameters when autograd is recording."""
     H, I = w_hh.shape[1], w_ih.shape[1]
     g = w_hh.shape[0] // H
-    Hp = _round_up(H, 64)
+    Hp = _round_up(H, 64) if hidden_pad is None else hidden_pad
     if Hp == H and in_pad == I:
         return w_ih, w_hh, b_ih, b_hh
     dev = w_ih.device
@@ -304,15 +304,32 @@ def pair_forward(block0, block1, x):
     B, F, T = x.shape
     Np, Ip = _round_up(B, 16), _round_up(F, 16)
     (layer0,), _ = block0._inference_weights()
-    Hp0 = layer0[1].shape[1]
-    # block1's own padded weights take block0.hidden_size inputs; widen them to block0's padded width
-    w_ih1, w_hh1, b_ih1, b_hh1 = (t.detach() for t in pad_lstm_weights(*block1._layer_tensors(0), Hp0))
-    layer1 = (w_ih1.contiguous(), w_hh1.contiguous(), b_ih1.contiguous(), b_hh1.contiguous())
     _, fc = block1._inference_weights()
+    Hp0, Hp1 = layer0[1].shape[1], _round_up(block1.hidden_size, 64)
+    # Up to 64 rows two EQUAL-width layers of 384 or 512 units are one launch of the chain kernel (fb_chain_kernels.hip)
+    # instead of T + 1 dependent ones: blocks of different widths (Fast FullSubNet's encoder, 384 -> 320) are padded to
+    # the wider one for that - units with zero weights and biases keep h = c = 0, so the padding is exact
+    width = max(Hp0, Hp1)
+    chain = Np <= 64 and width in (384, 512)
+    H0t, H1t = (width, width) if chain else (Hp0, Hp1)
+    key = (block0._padded_key, block1._padded_key, H0t, H1t)
+    cached = getattr(block1, "_pair_cache", None)
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            if H0t != Hp0:
+                layer0 = tuple(t.detach().contiguous() for t in
+                               pad_lstm_weights(*block0._layer_tensors(0), block0.input_size, hidden_pad=H0t))
+            # block1's weights take block0.hidden_size inputs: widened to block0's (padded) width
+            layer1 = tuple(t.detach().contiguous() for t in pad_lstm_weights(*block1._layer_tensors(0), H0t, hidden_pad=H1t))
+        cached = (key, layer0, layer1)
+        block1._pair_cache = cached
+    _, layer0, layer1 = cached
     h = torch.zeros((T, Np, Ip), dtype=torch.float32, device=x.device)
     h[:, :B, :F] = x.permute(2, 0, 1)
     h = lstm2_infer(h, layer0, layer1)
-    Hp1, H1 = h.shape[2], block1.hidden_size
+    if h.shape[2] != Hp1:
+        h = h[:, :, :Hp1].contiguous()
+    H1 = block1.hidden_size
     relu = block1.output_activate_function == "ReLU"
     if fc is not None:
         o = linear_infer(h.reshape(T * Np, Hp1), fc[0], fc[1], relu).reshape(T, Np, block1.output_size)[:, :B]
