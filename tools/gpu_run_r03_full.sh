@@ -22,13 +22,13 @@ for A in f32 f16; do
   grep "train step" $O/train_$A.txt
   rm -rf $O/trace_$A
 done
-for W in "fast 256" "improved48 32"; do
+for W in "fast 256" "improved48 32" "improved48 1"; do
   set -- $W
-  timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_$1 -- python tools/bench_family.py $1 $2 > $O/fam_$1.txt 2>&1
-  DB=$(ls $O/trace_$1/*/*.db 2>/dev/null | head -1)
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_$1_$2 -- python tools/bench_family.py $1 $2 > $O/fam_$1_$2.txt 2>&1
+  DB=$(ls $O/trace_$1_$2/*/*.db 2>/dev/null | head -1)
   [ -n "$DB" ] && python tools/rocprof_summary.py $DB $O/kernel_stats_$1_b$2.md "rocprofv3 --kernel-trace --stats -- python tools/bench_family.py $1 $2"
-  tail -1 $O/fam_$1.txt
-  rm -rf $O/trace_$1
+  tail -1 $O/fam_$1_$2.txt
+  rm -rf $O/trace_$1_$2
 done
 B1="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras"
 i=0
