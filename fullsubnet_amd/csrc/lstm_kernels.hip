@@ -1576,7 +1576,7 @@ FsnRecPlan fsn_lstm_rec_plan(int N, int H) {
         p.left_tiles = left;
         return p;
     }
-    // general case: whole rounds, pick the RT with the smallest makespan (rounds x RT)
+    // general case: whole rounds, pick the RT with the smallest makespan (rounds x RT) ...
     int best = 1;
     long best_cost = -1;
     for (int rt = 1; rt <= rt_max; ++rt) {
@@ -1586,6 +1586,21 @@ FsnRecPlan fsn_lstm_rec_plan(int N, int H) {
         if (best_cost < 0 || cost < best_cost || (cost == best_cost && rt > best)) {
             best = rt;
             best_cost = cost;
+        }
+    }
+    // ... unless FULL rounds of some RT leave only a few tiles for the step kernels: 128 utterances are 2056 tiles = two
+    // full rounds at 4 tiles per workgroup + 8 left over, where whole rounds would take three of RT = 3 (188 ms against
+    // 2 x 84); 96 utterances two rounds of 3 + 6 tiles instead of three
+    for (int rt = rt_max; rt >= 1; --rt) {
+        const long rounds = p.tiles / ((long)cus * rt);
+        if (rounds < 1) continue;
+        const long left2 = p.tiles - rounds * cus * rt;
+        const long cost = rounds * rt * 64 + rounds;
+        if (left2 <= left_max && cost < best_cost) {
+            p.rt = rt;
+            p.main_wgs = (int)(rounds * cus);
+            p.left_tiles = (int)left2;
+            return p;
         }
     }
     p.rt = best;
