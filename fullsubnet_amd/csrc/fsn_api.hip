@@ -1187,6 +1187,45 @@ static int check_bt(int B, int T) {
     return FSN_OK;
 }
 
+// Batches beyond what ONE round of the persistent kernels holds at 4 row tiles per workgroup (64 utterances of 257 bins
+// on 256 CUs) run as whole chunks of that size plus a remainder, one after the other: the model has no cross-utterance
+// term (both norms are per utterance), and a workgroup walks its RT tiles one after the other every step, so a batch
+// that does not fill rounds x RT x CUs tiles pays for the full round - 104 utterances took 171 ms as two rounds of 4,
+// 64 + 40 take 84 + 63.  Returns the chunk size (B itself: no chunking).
+static int core_chunk(const fsn_fullsubnet_cfg* cfg, int B) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus < 1) cus = 256;
+    const long b0 = ((long)cus * 4 + 16) * 16 / cfg->num_freqs;
+    return b0 >= 1 && B > b0 ? (int)b0 : B;
+}
+// the core's scratch behind the per-batch planes: sized for the largest chunk's plan (the chunks reuse it)
+static void core_carve_chunks(Carver& cv, const fsn_fullsubnet_cfg* cfg, int B, int T) {
+    const int chunk = core_chunk(cfg, B);
+    size_t most = 0;
+    for (int b : {chunk, B % chunk}) {
+        if (b < 1) continue;
+        Carver c2(nullptr);
+        core_carve(c2, core_dims(cfg, b, T), cfg->norm_type);
+        most = c2.off > most ? c2.off : most;
+    }
+    cv.take<char>(most);
+}
+// run_core over the chunks; `scratch` = a region of at least core_carve_chunks' size
+static int run_core_chunks(const fsn_fullsubnet_cfg* cfg, const float* pk, const float* magT, int B, int T, void* scratch,
+                           float* crm_r, float* crm_i, hipStream_t s) {
+    const int chunk = core_chunk(cfg, B);
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int b = B - b0 < chunk ? B - b0 : chunk;
+        const CoreDims d = core_dims(cfg, b, T);
+        Carver cv(scratch);
+        const CoreWs w = core_carve(cv, d, cfg->norm_type);
+        FSN_TRY(run_core(cfg, pk, magT + (size_t)b0 * d.Tp * d.FP, d, w, crm_r + (size_t)b0 * d.T * d.FP,
+                         crm_i + (size_t)b0 * d.T * d.FP, s, false));
+    }
+    return FSN_OK;
+}
+
 extern "C" size_t fsn_fullsubnet_workspace_bytes(const fsn_fullsubnet_cfg* cfg, int B, int T) {
     if (check_cfg(cfg) != FSN_OK || check_bt(B, T) != FSN_OK) return 0;
     const CoreDims d = core_dims(cfg, B, T);
@@ -1194,7 +1233,11 @@ extern "C" size_t fsn_fullsubnet_workspace_bytes(const fsn_fullsubnet_cfg* cfg, 
     cv.take<float>((size_t)B * d.Tp * d.FP);     // magT
     cv.take<float>((size_t)B * d.T * d.FP);      // crm_r
     cv.take<float>((size_t)B * d.T * d.FP);      // crm_i
-    core_carve(cv, d, cfg->norm_type);
+    // the whole batch's plan (what the stage-level entries carve) is never smaller than a chunk's; both are checked
+    Carver whole(nullptr), parts(nullptr);
+    core_carve(whole, d, cfg->norm_type);
+    core_carve_chunks(parts, cfg, B, T);
+    cv.take<char>(whole.off > parts.off ? whole.off : parts.off);
     return fsn_round_up_sz(cv.off, 256);
 }
 
@@ -1216,11 +1259,11 @@ extern "C" int fsn_fullsubnet_forward(const fsn_fullsubnet_cfg* cfg, const void*
     float* magT = cv.take<float>((size_t)B * d.Tp * d.FP);
     float* crm_r = cv.take<float>((size_t)B * d.T * d.FP);
     float* crm_i = cv.take<float>((size_t)B * d.T * d.FP);
-    const CoreWs w = core_carve(cv, d, cfg->norm_type);
+    void* scratch = cv.take<char>(0);  // the rest: the core's scratch (fsn_fullsubnet_workspace_bytes)
     prof_reset();
     // [B,1,F,T] -> frame-major [B][Tp][FP]; look-ahead frames (model.py:85) and padded bins are zeros
     FSN_TRY(fsn_launch_transpose(noisy_mag, magT, B, d.FP, d.Tp, T, (long)d.F * T, d.FP, (long)d.Tp * d.FP, d.F, T, s));
-    FSN_TRY(run_core(cfg, static_cast<const float*>(packed), magT, d, w, crm_r, crm_i, s));
+    FSN_TRY(run_core_chunks(cfg, static_cast<const float*>(packed), magT, B, T, scratch, crm_r, crm_i, s));
     // frame-major planes -> [B, 2, F, T] (model.py:129-135)
     FSN_TRY(fsn_launch_transpose(crm_r, crm_out, B, T, d.F, d.FP, (long)T * d.FP, T, 2L * d.F * T, T, d.F, s));
     FSN_TRY(fsn_launch_transpose(crm_i, crm_out + (size_t)d.F * T, B, T, d.F, d.FP, (long)T * d.FP, T, 2L * d.F * T,
@@ -1576,7 +1619,10 @@ extern "C" size_t fsn_enhance_workspace_bytes(const fsn_fullsubnet_cfg* cfg, int
     cv.take<float>((size_t)B * d.T * d.FP);   // crm_r
     cv.take<float>((size_t)B * d.T * d.FP);   // crm_i
     cv.take<float>((size_t)B * d.T * n_fft);  // windowed frames
-    core_carve(cv, d, cfg->norm_type);
+    Carver whole(nullptr), parts(nullptr);
+    core_carve(whole, d, cfg->norm_type);
+    core_carve_chunks(parts, cfg, B, T);
+    cv.take<char>(whole.off > parts.off ? whole.off : parts.off);
     return fsn_round_up_sz(cv.off, 256);
 }
 
@@ -1605,13 +1651,13 @@ extern "C" int fsn_enhance(const fsn_fullsubnet_cfg* cfg, const void* packed, co
     float* crm_r = cv.take<float>((size_t)B * d.T * d.FP);
     float* crm_i = cv.take<float>((size_t)B * d.T * d.FP);
     float* wf = cv.take<float>((size_t)B * d.T * n_fft);
-    const CoreWs w = core_carve(cv, d, cfg->norm_type);
+    void* scratch = cv.take<char>(0);  // the rest: the core's scratch (fsn_enhance_workspace_bytes)
     prof_reset();
     {
         StageTimer st(ST_STFT, s);
         FSN_TRY(fsn_launch_stft(noisy, B, L, window, re, im, magT, d.T, d.Tp, d.F, d.FP, true, s));
     }
-    FSN_TRY(run_core(cfg, static_cast<const float*>(packed), magT, d, w, crm_r, crm_i, s));
+    FSN_TRY(run_core_chunks(cfg, static_cast<const float*>(packed), magT, B, T, scratch, crm_r, crm_i, s));
     {
         StageTimer st(ST_MASK_ISTFT, s);
         FSN_TRY(fsn_launch_mask_irfft(re, im, crm_r, crm_i, B, d.T, d.F, d.FP, true, window, wf, s));
