@@ -1199,14 +1199,69 @@ static int core_chunk(const fsn_fullsubnet_cfg* cfg, int B) {
     const long b0 = ((long)cus * 4 + 16) * 16 / cfg->num_freqs;
     return b0 >= 1 && B > b0 ? (int)b0 : B;
 }
+// Below one round the same holds between the regimes: 40 utterances take as long as 48 (one round of 3 tiles per
+// workgroup), 24 as long as 32, 10 - 13 run at one tile per CU - where 32 + 8, 16 + 8 and 8 + 2 as separate calls are 12 -
+// 18 % faster.  Time of one core call in microseconds per frame step, from the plan it would take (calibrated on
+// config 2's clips: 1 / 2 / 4 / 8 / 16 / 32 / 48 / 64 utterances = 24 / 37 / 60 / 66 / 122 / 229 / 337 / 441 us per step):
+static double core_cost(const fsn_fullsubnet_cfg* cfg, int b) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus < 1) cus = 256;
+    const CoreDims d = core_dims(cfg, b, 64);
+    double c = 6.0;  // the full-band chain and the fixed launches of a call
+    if (d.rec.main_wgs > 0) {
+        const int rounds = (d.rec.main_wgs + cus - 1) / cus;
+        c += rounds * (d.rec.rt == 1 ? 120.0 : 110.0 * d.rec.rt);  // one tile per CU streams all weights for 16 rows
+    } else if (d.grp_clusters > 0) {
+        c += (d.grp_clusters > cus / 8 ? 2 : 1) * 58.0 + (d.rec.left_tiles - 4 * d.grp_clusters > 0 ? 2.0 : 0.0);
+    } else {
+        c += 7.0 + 0.67 * d.rec.left_tiles;  // two-layer wavefront of per-step launches
+    }
+    return c;
+}
+// the chunk sizes of a batch, largest first: whole rounds of core_chunk(), then the cheapest split of the remainder into
+// {itself, 48, 32, 16, 8}-utterance calls by core_cost
+static int core_chunks(const fsn_fullsubnet_cfg* cfg, int B, int* sizes, int max_sizes) {
+    int n = 0;
+    const int full = core_chunk(cfg, B);
+    int rem = B;
+    while (rem > full && n < max_sizes - 8) {
+        sizes[n++] = full;
+        rem -= full;
+    }
+    if (rem > 64 || !fsn_persistent_allowed() || cfg->arith != FSN_ARITH_F32) {  // outside the calibrated range: as one call
+        sizes[n++] = rem;
+        return n;
+    }
+    double best[65];
+    int first[65];
+    best[0] = 0.0;
+    first[0] = 0;
+    for (int b = 1; b <= rem; ++b) {
+        best[b] = core_cost(cfg, b);
+        first[b] = b;
+        for (int c : {48, 32, 16, 8}) {
+            if (c >= b) continue;
+            const double v = core_cost(cfg, c) + best[b - c];
+            if (v < 0.97 * best[b]) {  // a split has to be worth it
+                best[b] = v;
+                first[b] = c;
+            }
+        }
+    }
+    for (int b = rem; b > 0 && n < max_sizes; b -= first[b]) sizes[n++] = first[b];
+    return n;
+}
+constexpr int kMaxChunks = 80;  // 4096 utterances (check_bt) in rounds of >= 64, plus the remainder's few calls
 // the core's scratch behind the per-batch planes: sized for the largest chunk's plan (the chunks reuse it)
 static void core_carve_chunks(Carver& cv, const fsn_fullsubnet_cfg* cfg, int B, int T) {
-    const int chunk = core_chunk(cfg, B);
+    int sizes[kMaxChunks];
+    const int n = core_chunks(cfg, B, sizes, kMaxChunks);
     size_t most = 0;
-    for (int b : {chunk, B % chunk}) {
-        if (b < 1) continue;
+    for (int i = 0; i < n; ++i) {
+        if (i > 0 && sizes[i] == sizes[i - 1]) continue;
         Carver c2(nullptr);
-        core_carve(c2, core_dims(cfg, b, T), cfg->norm_type);
+        core_carve(c2, core_dims(cfg, sizes[i], T), cfg->norm_type);
         most = c2.off > most ? c2.off : most;
     }
     cv.take<char>(most);
@@ -1214,15 +1269,19 @@ static void core_carve_chunks(Carver& cv, const fsn_fullsubnet_cfg* cfg, int B, 
 // run_core over the chunks; `scratch` = a region of at least core_carve_chunks' size
 static int run_core_chunks(const fsn_fullsubnet_cfg* cfg, const float* pk, const float* magT, int B, int T, void* scratch,
                            float* crm_r, float* crm_i, hipStream_t s) {
-    const int chunk = core_chunk(cfg, B);
-    for (int b0 = 0; b0 < B; b0 += chunk) {
-        const int b = B - b0 < chunk ? B - b0 : chunk;
+    int sizes[kMaxChunks];
+    const int n = core_chunks(cfg, B, sizes, kMaxChunks);
+    int b0 = 0;
+    for (int i = 0; i < n; ++i) {
+        const int b = sizes[i];
         const CoreDims d = core_dims(cfg, b, T);
         Carver cv(scratch);
         const CoreWs w = core_carve(cv, d, cfg->norm_type);
         FSN_TRY(run_core(cfg, pk, magT + (size_t)b0 * d.Tp * d.FP, d, w, crm_r + (size_t)b0 * d.T * d.FP,
                          crm_i + (size_t)b0 * d.T * d.FP, s, false));
+        b0 += b;
     }
+    FSN_REQUIRE(b0 == B, "internal: the chunks cover %d of %d utterances", b0, B);
     return FSN_OK;
 }
 

@@ -244,18 +244,21 @@ def test_more_row_tiles_than_cus(fsn, batch):
     assert np.abs(enh.cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("batch", [96, 128])
+@pytest.mark.parametrize("batch", [10, 24, 40, 96, 104, 128])
 def test_full_rounds_plus_leftover_tiles_for_large_batches(fsn, batch):
     """More than five row tiles per CU: the plan takes FULL rounds of the persistent kernels and hands the few tiles that
     remain to the step kernels (96 utterances: 1542 tiles = two rounds of 3 tiles per workgroup + 6; 128: two rounds of 4
     + 8 - where whole rounds only would take three).  The model has no cross-utterance term: every utterance must equal
-    its result in a batch of 32 (another plan: one round of 2 tiles per workgroup, held to the oracle above)."""
+    its result in a batch of 32 (another plan: one round of 2 tiles per workgroup, held to the oracle above).  Likewise
+    the batches BETWEEN the regimes (10, 24, 40: run as 8 + 2, 16 + 8, 32 + 8 by the cost model of run_core_chunks) against
+    batches of 8 (the group kernel, held to the oracle by test_few_rows_on_the_group_kernel)."""
     meta = dict(seed_w=5, gain=2.0, mask_gain=24.0, norm_type="offline_laplace_norm", groups=1)
     model, _ = build_model(fsn, meta)
     noisy = dev(O.make_noisy(batch, 1300, seed=37))
     enh, crm = model.enhance(noisy, return_crm=True)
     assert torch.isfinite(crm).all() and torch.isfinite(enh).all()
-    parts = [model.enhance(noisy[i:i + 32], return_crm=True) for i in range(0, batch, 32)]
+    piece = 32 if batch >= 96 else 8
+    parts = [model.enhance(noisy[i:i + piece], return_crm=True) for i in range(0, batch, piece)]
     enh32, crm32 = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
     assert (crm - crm32).abs().max().item() <= 2e-5
     assert (enh - enh32).abs().max().item() <= 1e-5 * enh32.abs().max().item()
