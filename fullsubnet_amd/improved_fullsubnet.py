@@ -354,6 +354,32 @@ class Model(BaseModel):
                                      sequence_model=sequence_model, activate_function=sb_output_activate_function)
         self.norm = self.norm_wrapper(norm_type)
 
+    def _persistent_chunk(self, B, T):
+        """The largest batch <= B whose band sections run as one persistent launch (sequence_model.multi_plan), or None
+        when B itself does / no batch in reach does."""
+        from .sequence_model import multi_plan
+        key = (B, T)
+        cache = self.__dict__.setdefault("_chunk_cache", {})
+        if key not in cache:
+            sb = self.sb_model
+            F = self.fb_model.input_size
+            n_units = sb.num_units(F)
+            widths = [(sc + 2 * sn) + (fc + 2 * fn) for sc, sn, fc, fn in
+                      zip(sb.sb_num_center_freqs, sb.sb_num_neighbor_freqs, sb.fb_num_center_freqs, sb.fb_num_neighbor_freqs)]
+            models = list(sb.sb_models)
+
+            def fits(b):
+                return multi_plan(models, [(b * n, w, T) for n, w in zip(n_units, widths)])
+
+            best = None
+            if not fits(B):
+                for b in range(min(B - 1, 256), 7, -1):
+                    if fits(b):
+                        best = b
+                        break
+            cache[key] = best
+        return cache[key]
+
     def forward(self, y, unit_group=None):
         """model.py:541-591: y [B, L] or [B, 1, L] -> enhanced [B, 1, L].  ``unit_group``: shard the sub-band units
         over that process group (every rank gets the same ``y`` and returns the same result; for fewer utterances
@@ -363,6 +389,12 @@ class Model(BaseModel):
         if ndim == 3:
             assert y.size(1) == 1, "Input must be 2D (B, T) or 3D tensor (B, 1, T)"
             y = y.squeeze(1)
+        if unit_group is None and y.is_cuda and not torch.is_grad_enabled():
+            # the model has no cross-utterance term: a batch beyond what ONE persistent launch of the band sections holds
+            # (32 utterances at 48 kHz) runs as chunks that do fit - 64 utterances: 55 ms as wavefronts, 2 x 21.5 as chunks
+            c = self._persistent_chunk(y.size(0), 1 + y.size(-1) // self.hop_length)
+            if c and y.size(0) > c:
+                return torch.cat([self.forward(y[i:i + c]) for i in range(0, y.size(0), c)], dim=0)
         mag, _, real, imag = stft(y, self.n_fft, self.hop_length, self.win_length, return_phase=False)  # [B, F, T] each
         noisy_mag = mag.unsqueeze(1) ** self.fdrc
         noisy_mag = noisy_mag[..., :-1, :]  # the last bin is left out (model.py:566) and masked with 0 below

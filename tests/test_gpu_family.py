@@ -323,6 +323,27 @@ def test_improved_fullsubnet_config5_full_size_on_the_persistent_launch(fsn, gol
     assert err <= 5e-6 * full.abs().max().item()  # measured 8.6e-7 of the output scale
 
 
+def test_improved_fullsubnet_batches_beyond_one_persistent_launch_run_as_chunks(fsn):
+    """More utterances than one persistent launch of the band sections holds (32 clusters of 64 rows: 33 utterances at 48
+    kHz): Model.forward runs the batch as chunks that fit plus a remainder.  Every utterance must equal its result in a
+    batch of 12 (wavefronts on one stream per section)."""
+    from oracle import fullsubnet_oracle as O
+    from fullsubnet_amd.improved_fullsubnet import Model
+    cfg = MF.IMPROVED_48K
+    m = Model(**cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in MF.make_improved_params(cfg, seed=2).items()}, strict=True)
+    m = m.cuda().eval()
+    noisy = torch.from_numpy(O.make_noisy(40, 14400, seed=77)).cuda()
+    T = 1 + 14400 // cfg["hop_length"]
+    chunk = m._persistent_chunk(40, T)
+    assert chunk is not None and 28 <= chunk < 40, chunk
+    with torch.no_grad():
+        whole = m(noisy)
+        parts = torch.cat([m(noisy[i:i + 12]) for i in range(0, 40, 12)], dim=0)
+    assert whole.shape == (40, 1, 14400) and torch.isfinite(whole).all()
+    assert (whole - parts).abs().max().item() <= 5e-6 * parts.abs().max().item()
+
+
 @pytest.mark.parametrize("world", [3, 8])
 @pytest.mark.parametrize("name,cfg", [("improved_16k_b2", MF.IMPROVED_16K), ("improved_48k_b2", MF.IMPROVED_48K)])
 def test_improved_fullsubnet_unit_shard_vs_reference(fsn, golden_dir, name, cfg, world):

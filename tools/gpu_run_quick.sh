@@ -1,4 +1,3 @@
 #!/bin/bash
 # scratch session: edit, run, read (kept as the one ad-hoc runner)
-(time timeout 1500 python -m pytest tests -m gpu -q -x) 2>&1 | tail -5
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 600 python -m pytest tests/test_gpu_family.py -m gpu -x -q -k "improved" 2>&1 | tail -2
