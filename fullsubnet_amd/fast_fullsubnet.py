@@ -117,6 +117,13 @@ class Model(BaseModel):
         """mix_mag [B, 1, F, T] -> [B, 2, F, T] (model.py:143-202)."""
         if mix_mag.dim() != 4 or mix_mag.shape[1] != 1:
             raise AssertionError(f"{self.__class__.__name__} takes a magnitude feature as the input ([B, 1, F, T]).")
+        if mix_mag.is_cuda and not torch.is_grad_enabled():
+            # the model has no cross-utterance term: a batch well beyond ONE round of the bottleneck's persistent kernels
+            # (4 row tiles per workgroup: 256 utterances x 64 bands on 256 CUs) runs as whole rounds plus a remainder -
+            # 512 utterances 124 -> 2 x 51 ms (the block pairs' per-step launches and the multi-round launch cost more)
+            chunk = torch.cuda.get_device_properties(mix_mag.device).multi_processor_count * 4 * 16 // self.num_mels
+            if chunk >= 16 and mix_mag.shape[0] >= chunk + chunk // 2:
+                return torch.cat([self.forward(mix_mag[i:i + chunk]) for i in range(0, mix_mag.shape[0], chunk)], dim=0)
         mag = look_ahead_pad(mix_mag, self.look_ahead)
         n_batch, _, n_bins, n_frames = mag.shape
         mel = self.mel_scale(mag)                                                         # [B, 1, M, T]
