@@ -997,10 +997,6 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
             FSN_PERSIST_BEGIN(s);
             FSN_TRY(fsn_launch_lstm2_group(&xin, pk + p.sb_whh0, pk + p.sb_wih1, pk + p.sb_whh1, pk + p.sb_b1,
                                            w.grp_exchange, w.grp_flags, &gfc, d.Tp, d.grp_clusters, d.Hs, s));
-            // a spin bound hit inside it (see fsn_launch_poison_if): the mask planes become NaN instead of garbage
-            const unsigned* st_word = w.grp_flags + fsn_lstm2_group_status_word(d.grp_clusters);
-            FSN_TRY(fsn_launch_poison_if(st_word, crm_r, (size_t)d.B * d.T * d.FP, s));
-            FSN_TRY(fsn_launch_poison_if(st_word, crm_i, (size_t)d.B * d.T * d.FP, s));
         }
         if (aux_tiles > 0) {
             FSN_TRY(fsn_launch_lstm_wavefront2(w.gx_sb, aux_tiles, 0, pk + p.sb_whh0, pk + p.sb_wih1, pk + p.sb_b1_frag,
@@ -1029,6 +1025,12 @@ static int run_core(const fsn_fullsubnet_cfg* cfg, const float* pk, const float*
                 return FSN_ERR_LAUNCH;
             }
         }
+        // a spin bound hit inside the group launch (see fsn_launch_poison_if): the mask planes become NaN instead of
+        // garbage - AFTER the join: the left-over rows' output layer on the auxiliary stream writes into the same planes
+        // (poisoned before it, a launch that gave up early left those rows finite: one run of the residency test in many)
+        const unsigned* st_word = w.grp_flags + fsn_lstm2_group_status_word(d.grp_clusters);
+        FSN_TRY(fsn_launch_poison_if(st_word, crm_r, (size_t)d.B * d.T * d.FP, s));
+        FSN_TRY(fsn_launch_poison_if(st_word, crm_i, (size_t)d.B * d.T * d.FP, s));
         return FSN_OK;
     }
     // sub-band model (model.py:121-128): N = B F sequences, 2 LSTM layers + Linear(2)

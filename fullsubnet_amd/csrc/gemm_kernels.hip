@@ -143,7 +143,10 @@ __device__ __forceinline__ void store_tile(const FsnGemmC& c, f32x4 acc, float b
             const int t = (int)(row / c.Npad), n = (int)(row % c.Npad) + (KIND == 2 ? c.n_off : 0);
             if (KIND == 1) {  // full-band output layer: ReLU(h W^T + b) -> fb_out[b][t][f]
                 if (n < c.B && col < c.FP) {
-                    const float v = col < c.F ? fmaxf(acc[i] + bias, 0.f) : 0.f;
+                    // ReLU as torch.relu: a NaN stays a NaN (fmaxf would turn it into 0 - and with it the poison that
+                    // a full-band chain launch which ran out of time leaves in its output, fsn_launch_poison_if)
+                    const float pre = acc[i] + bias;
+                    const float v = col < c.F ? (pre < 0.f ? 0.f : pre) : 0.f;
                     c.p0[((long)n * c.Tp + t) * c.FP + col] = v;
                 }
             } else {  // sub-band output layer: compressed cIRM planes, look-ahead frames dropped
