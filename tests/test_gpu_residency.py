@@ -320,8 +320,28 @@ def test_persistent_launches_from_several_streams_share_the_chip_when_provably_p
     rows = (20, 25, 30)
     models = [SequenceModel(40 + 8 * i, 2, 384, 2, False, "LSTM", None).cuda() for i in range(3)]
     xs = [torch.randn(n, 40 + 8 * i, T, device="cuda") for i, n in enumerate(rows)]
-    streams = [torch.cuda.Stream() for _ in range(3)]
     main = torch.cuda.current_stream()
+    sink = torch.zeros(1, device="cuda")
+
+    def overlap(a, b):
+        """Do kernels of streams a and b run side by side?  (HIP multiplexes streams onto a few hardware queues; two
+        streams of one queue never overlap - see Hog.)  Two 4 ms kernels of 8 workgroups: ~4 ms together, or ~8."""
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for st in (a, b):
+            st.wait_stream(main)
+            fsn._lib.check(fsn._lib.lib().fsn_debug_hog(8, 1024, 0, 4.0, fsn._lib.dev_ptr(sink), st.cuda_stream))
+        for st in (a, b):
+            main.wait_stream(st)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) < 6.0
+
+    pool = [torch.cuda.Stream() for _ in range(12)]
+    pair = next(((a, b) for i, a in enumerate(pool) for b in pool[i + 1:] if overlap(a, b)), None)
+    assert pair is not None, "no two streams that run concurrently"
+    streams = [pair[0], pair[1], next(st for st in pool if st not in pair)]
 
     def on_one(n):
         with torch.no_grad():
@@ -339,8 +359,6 @@ def test_persistent_launches_from_several_streams_share_the_chip_when_provably_p
 
     ref = on_one(3)
     torch.cuda.synchronize()  # (those launches are retired from the gate's list when the next one looks)
-
-    sink = torch.zeros(1, device="cuda")
 
     def counted(n):
         before = fsn._lib.persist_stats()

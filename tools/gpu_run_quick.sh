@@ -1,4 +1,5 @@
 #!/bin/bash
 # scratch session: edit, run, read (kept as the one ad-hoc runner)
-for i in 1 2 3 4; do timeout 600 python -m pytest tests/test_gpu_residency.py -m gpu -x -q 2>&1 | tail -1; done
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -1
+mkdir -p gpurun_out/q
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/q/pytest_full.log 2>&1
+grep -n "^E  \|FAILED\|passed\|failed" gpurun_out/q/pytest_full.log | head -20
