@@ -177,6 +177,7 @@ SIGNATURES = {
     "fsn_debug_persist_stats": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "fsn_debug_persist_set_fits": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p]),
     "fsn_debug_tn_plan": (_c.c_int, [_c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    "fsn_debug_core_chunks": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int]),
     "fsn_profile_num_stages": (_c.c_int, []),
     "fsn_profile_stage_name": (_c.c_char_p, [_c.c_int]),
     "fsn_profile_read": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_float), _c.c_int]),

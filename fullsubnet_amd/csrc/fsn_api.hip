@@ -1287,6 +1287,12 @@ static int run_core_chunks(const fsn_fullsubnet_cfg* cfg, const float* pk, const
     return FSN_OK;
 }
 
+// test hook: the utterance counts of the core calls a batch of B runs as (sum = B); returns their number
+extern "C" int fsn_debug_core_chunks(const fsn_fullsubnet_cfg* cfg, int B, int* sizes, int max_sizes) {
+    if (check_cfg(cfg) != FSN_OK || B < 1 || B > 4096 || !sizes || max_sizes < kMaxChunks) return -1;
+    return core_chunks(cfg, B, sizes, kMaxChunks);
+}
+
 extern "C" size_t fsn_fullsubnet_workspace_bytes(const fsn_fullsubnet_cfg* cfg, int B, int T) {
     if (check_cfg(cfg) != FSN_OK || check_bt(B, T) != FSN_OK) return 0;
     const CoreDims d = core_dims(cfg, B, T);

@@ -400,6 +400,10 @@ int fsn_debug_persist_stats(unsigned* launches, unsigned* waits, unsigned* unrep
  * scratch of every caller is sized by (*bound >= *splits must hold for every shape). */
 int fsn_debug_persist_set_fits(int n, const double* fracs, const int* occs);
 int fsn_debug_tn_plan(int M, int Nc, long K, int arith, int* splits, long* bound);
+/* Test hook: fsn_enhance / fsn_fullsubnet_forward run a batch of B utterances as one or several calls of the model core
+ * (whole rounds of the persistent kernels, a remainder split by a cost model of the plans - the model has no
+ * cross-utterance term); sizes[0..n) = their utterance counts, n returned (max_sizes >= 80), -1 on bad arguments. */
+int fsn_debug_core_chunks(const fsn_fullsubnet_cfg* cfg, int B, int* sizes, int max_sizes);
 int fsn_profile_num_stages(void);
 const char* fsn_profile_stage_name(int stage);
 int fsn_profile_read(void* stream, float* ms_per_stage, int n);

@@ -295,3 +295,22 @@ def test_weight_gradient_scratch_bound_covers_every_plan():
                     assert 1 <= splits.value <= bound.value, (M, Nc, K, arith, splits.value, bound.value)
                     worst = max(worst, splits.value / bound.value)
     assert worst == 1.0  # the bound is attained somewhere: it is not a loose over-estimate
+
+
+def test_batches_are_covered_exactly_by_the_chunks_they_run_as():
+    """fsn_enhance / fsn_fullsubnet_forward run a batch as one or several calls of the model core (whole rounds of the
+    persistent kernels plus a remainder split by a cost model, include/fsn_hip.h: fsn_debug_core_chunks).  Whatever
+    plans the device at hand offers, the chunks must cover the batch exactly once, largest rounds first, and never be
+    more than the contract allows (80 calls for 4096 utterances)."""
+    import ctypes
+    from fullsubnet_amd import _lib
+    L = _lib.lib()
+    cfg = _lib.Cfg(257, 2, 15, 512, 384, 0, 0)
+    sizes = (ctypes.c_int * 80)()
+    for B in list(range(1, 140)) + [192, 255, 256, 257, 1000, 4096]:
+        n = L.fsn_debug_core_chunks(ctypes.byref(cfg), B, sizes, 80)
+        got = [sizes[i] for i in range(n)]
+        assert 1 <= n <= 80 and all(g >= 1 for g in got) and sum(got) == B, (B, got)
+        assert got == sorted(got, reverse=True), (B, got)
+    assert L.fsn_debug_core_chunks(ctypes.byref(cfg), 0, sizes, 80) == -1
+    assert L.fsn_debug_core_chunks(ctypes.byref(cfg), 8, sizes, 4) == -1
