@@ -129,8 +129,9 @@ def cpu_baseline(params, length, budget_s=30.0, all_cores_too=False):
     noisy = O.make_noisy(2, length, seed=77)
     O.full_band_crm_mask(noisy[:1], params, window=win)
     t0 = time.perf_counter()
-    O.full_band_crm_mask(noisy, params, window=win)
+    ref, inter = O.full_band_crm_mask(noisy, params, window=win, return_intermediates=True)
     dt = time.perf_counter() - t0
+    out["_oracle_outputs"] = (noisy, ref, inter["crm"])  # popped by main(): the checker's side of `parity`
     out["oracle_port"] = {"value": round(2 * frames_per_utt / dt, 2), "unit": "frames/s", "cores": cores,
                           "sample": f"2 x {length / SR:.1f} s, oracle/fullsubnet_oracle.py (numpy {np.__version__} + "
                                     f"torch-CPU matmuls), {dt:.1f} s wall"}
@@ -188,6 +189,7 @@ def training_step_ms(device, steps=5, arith="f32"):
     opt = fullsubnet_amd.ClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
     noisy = torch.from_numpy(make_noisy(16, 49152, seed=41)).to(device)
     clean = torch.from_numpy(0.7 * make_noisy(16, 49152, seed=42)).to(device)
+    check = training_parity(device, arith)
     for _ in range(2):
         train_step(model, opt, noisy, clean, scaler=scaler)
     torch.cuda.synchronize()
@@ -208,9 +210,77 @@ def training_step_ms(device, steps=5, arith="f32"):
                                                      f", use_amp = true: {arith} matrix-core operands with fp32 accumulation "
                                                      f"on the sub-band kernels + torch.amp.GradScaler (scale "
                                                      f"{scaler.get_scale():g}, {skipped} skipped updates)"),
-           "loss": round(float(loss), 6), "tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
+           "loss": round(float(loss), 6), "tflops": round(flops / (ms * 1e-3) / 1e12, 1), **check}
     if arith == "f32":
         out["frac_fp32_mfma_peak"] = round(flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3)
+    return out
+
+
+def path_parity(model, oracle_outputs, batch, length, device):
+    """The margin the timed arithmetic leaves under the north-star bound, in the line itself: the two utterances the
+    numpy oracle just computed (cpu_baseline's `oracle_port` leg) sit at both ends of a batch of the TIMED size, so the
+    plan - the persistent kernels with the hardware-transcendental gate functions (v_exp_f32 / v_rcp_f32,
+    fsn_common.h) - is the timed one; compressed cIRM against the oracle (bound 1e-4) and the enhanced waveform
+    relative to its peak (bound 2e-3: the decompression slope reaches 100 near |m| = 9.9)."""
+    from fsn_synthetic import make_noisy
+    noisy2, ref, crm_ref = oracle_outputs
+    x = make_noisy(max(batch, 2), length, seed=1234)
+    x[0], x[-1] = noisy2[0], noisy2[1]
+    enh, crm = model.enhance(torch.from_numpy(x).to(device), return_crm=True)
+    torch.cuda.synchronize()
+    rows = [0, x.shape[0] - 1]
+    d_crm = float(np.abs(crm[rows].cpu().numpy() - crm_ref).max())
+    d_enh = float(np.abs(enh[rows].cpu().numpy() - ref).max() / np.abs(ref).max())
+    return {"max_abs_err_cirm_vs_oracle": d_crm, "bound_cirm": 1e-4, "mean_abs_err_cirm_vs_oracle":
+            float(np.abs(crm[rows].cpu().numpy() - crm_ref).mean()), "max_rel_err_enhanced_vs_oracle": d_enh,
+            "bound_enhanced": 2e-3, "cirm_range": [round(float(crm_ref.min()), 2), round(float(crm_ref.max()), 2)],
+            "utterances": rows, "of_batch": int(x.shape[0]), "within_bound": bool(d_crm <= 1e-4 and d_enh <= 2e-3),
+            "note": "gate non-linearities are v_exp_f32 / v_rcp_f32 forms by choice (SURVEY 7 advises libm): this is "
+                    "the margin they leave"}
+
+
+def training_parity(device, arith):
+    """The checker leg of the training figures: ONE step of a fresh model at exactly the timed shape on the inputs of
+    tests/golden/fsn_train_c3.npz - the REFERENCE's own step (fullsubnet/trainer.py:41-71, use_amp = false, made by
+    tests/golden/make_golden_train.py --config3) - loss, total gradient norm (what clip_grad_norm_ returns) and the
+    worst parameter tensor's gradient norm, as relative errors.  Under the 16-bit arithmetic the same fp32 golden is the
+    yardstick (tests/test_gpu_amp.py holds it to 3x the margins measured there)."""
+    import ast
+    import fullsubnet_amd
+    from fullsubnet_amd.train import train_step
+    from fsn_synthetic import make_noisy, make_params
+    try:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "fsn_train_c3.npz"))
+    except OSError:
+        return {"parity": None}
+    meta = ast.literal_eval(str(z["meta"]))
+    model = fullsubnet_amd.Model(num_freqs=F, look_ahead=LA, sequence_model="LSTM", fb_num_neighbors=0,
+                                 sb_num_neighbors=NB, fb_output_activate_function="ReLU",
+                                 sb_output_activate_function=False, fb_model_hidden_size=H_FB,
+                                 sb_model_hidden_size=H_SB, norm_type="offline_laplace_norm",
+                                 num_groups_in_drop_band=meta["groups"], weight_init=False)
+    params = make_params(seed=meta["seed_w"])
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    model = model.to(device).train()
+    model.train_arithmetic = arith
+    scaler = torch.amp.GradScaler("cuda", enabled=arith != "f32")
+    opt = fullsubnet_amd.ClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    noisy = torch.from_numpy(make_noisy(meta["batch"], meta["length"], seed=meta["seed_noisy"])).to(device)
+    clean = torch.from_numpy((meta["clean_gain"] * make_noisy(meta["batch"], meta["length"], seed=meta["seed_clean"]))
+                             .astype(np.float32)).to(device)
+    loss = float(train_step(model, opt, noisy, clean, scaler=scaler))
+    # ClipAdam leaves the unscaled, clipped gradients in .grad (what GradScaler.unscale_ + clip_grad_norm_ leave there)
+    worst = max(abs(float(p.grad.norm()) - float(z["gnorm/" + k])) / (float(z["gnorm/" + k]) + 1e-30)
+                for k, p in model.named_parameters())
+    out = {"max_rel_err_vs_reference": round(max(abs(loss - float(z["loss"])) / float(z["loss"]),
+                                                 abs(float(opt.total_norm) - float(z["total_norm"])) / float(z["total_norm"]),
+                                                 worst), 9),
+           "parity": {"against": "tests/golden/fsn_train_c3.npz: one step of the reference at this shape (fp32)",
+                      "rel_err_loss": abs(loss - float(z["loss"])) / float(z["loss"]),
+                      "rel_err_total_grad_norm": abs(float(opt.total_norm) - float(z["total_norm"])) / float(z["total_norm"]),
+                      "worst_rel_err_tensor_grad_norm": worst}}
+    del model, opt
+    torch.cuda.empty_cache()
     return out
 
 
@@ -220,13 +290,49 @@ def family_figure(which, batch, peak_tflops, device):
     8(d)'s MFLOP per frame."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_family as BF
-    m = BF.family_step(which, batch, device=device, steps=5, warmup=2)
+    pack = BF.build(which, device)
+    m = BF.family_step(which, batch, device=device, steps=5, warmup=2, model_pack=pack)
+    check = family_parity(BF, which, batch, pack, device)
+    del pack
     torch.cuda.empty_cache()
-    return {"ms_per_step": round(m["ms_per_step"], 3), "value": round(m["frames_per_s"], 1), "unit": "frames/s",
+    return {**check, "ms_per_step": round(m["ms_per_step"], 3), "value": round(m["frames_per_s"], 1), "unit": "frames/s",
             "rtf_speedup_audio_s_per_s": round(m["rtf"], 1), "batch": batch, "samples": m["samples"],
             "sample_rate": m["sample_rate"], "frames_per_utterance": m["frames_per_utterance"],
             "mflop_per_frame": round(m["mflop_per_frame"], 1), "tflops": round(m["tflops"], 1),
             "frac_fp32_mfma_peak": round(m["tflops"] / peak_tflops, 3), "finite": m["finite"], "dtype": "f32"}
+
+
+def family_parity(BF, which, batch, pack, device):
+    """The checker leg of a side figure: the SAME batch the timed step ran (so the plan - kernels, tiles per workgroup -
+    is the timed one), two of its utterances against the CPU oracle (oracle/model_family_oracle.py, pinned on the
+    reference's goldens).  Fast FullSubNet: max |d| of the compressed mask (north-star bound 1e-4); Improved
+    FullSubNet (waveform out, no compressed mask at its boundary): max |d| of the enhanced waveform relative to its
+    peak.  The oracle is the checker only - nothing timed touches it."""
+    from fsn_synthetic import make_fast_params, make_improved_params, make_noisy, IMPROVED_48K, IMPROVED_48K_769
+    from oracle import fullsubnet_oracle as O
+    from oracle import model_family_oracle as MF
+    model, _, L, hop, sr, la = pack
+    noisy_np = np.tile(make_noisy(min(batch, 8), L, seed=1), ((batch + 7) // 8, 1))[:batch]  # family_step's input
+    rows = [0, batch - 1] if batch > 1 else [0]
+    got = BF.parity_sample(which, model, torch.from_numpy(noisy_np).to(device), rows)
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    t0 = time.perf_counter()
+    if which == "fast":
+        params = make_fast_params(seed=3)
+        params["mel_scale.fb"] = model.mel_scale.fb.cpu().numpy()
+        want = MF.fast_fullsubnet_forward(O.stft(noisy_np[rows])[0][:, None], params)
+        err, scale, what = float(np.abs(got - want).max()), float(np.abs(want).max()), "compressed mask"
+        out = {"max_abs_err_vs_oracle": err}
+    else:
+        cfg = {"improved48": IMPROVED_48K, "improved769": IMPROVED_48K_769}[which]
+        want = MF.improved_fullsubnet_forward(noisy_np[rows], make_improved_params(cfg, seed=3), cfg,
+                                              torch.hann_window(cfg["win_length"]).numpy()).reshape(len(rows), -1)
+        scale, what = float(np.abs(want).max()), "enhanced waveform, relative to its peak"
+        err = float(np.abs(got - want).max()) / scale
+        out = {"max_abs_err_vs_oracle": err}
+    out["parity"] = {"checked": what, "utterances": rows, "of_batch": batch, "output_scale": round(scale, 4),
+                     "bound": 1e-4, "within_bound": bool(err <= 1e-4), "oracle_s": round(time.perf_counter() - t0, 1)}
+    return out
 
 
 def measured_counters():
@@ -469,6 +575,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             torch.cuda.synchronize()
             out["cpu_baseline"] = cpu_baseline(params, length, args.cpu_budget, args.cpu_all_cores)
+            out["parity"] = path_parity(model, out["cpu_baseline"].pop("_oracle_outputs"), args.batch, length, device)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None  # reported at N = 1 only
         print(json.dumps(out), flush=True)

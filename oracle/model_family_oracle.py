@@ -17,7 +17,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import fullsubnet_oracle as O
-from fsn_synthetic import (IMPROVED_16K, IMPROVED_48K, make_fast_params, make_fullband_params,  # noqa: F401
+from fsn_synthetic import (IMPROVED_16K, IMPROVED_48K, IMPROVED_48K_769, make_fast_params, make_fullband_params,  # noqa: F401
                            make_improved_params)
 
 

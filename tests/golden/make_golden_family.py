@@ -130,10 +130,18 @@ def stft_generic_case(name, batch=2, length=5000, seed_x=79):
     print(name, {k: v.shape for k, v in out.items() if k.startswith("re/")})
 
 
+CASES = {
+    "stft_generic": lambda: stft_generic_case("stft_generic"),
+    "improved_16k_b2": lambda: improved_case("improved_16k_b2", MF.IMPROVED_16K, 2, 4000),
+    "improved_48k_b2": lambda: improved_case("improved_48k_b2", MF.IMPROVED_48K, 2, 9600, seed_w=1),
+    # BASELINE config 5's "769 bins" (n_fft 1536 / hop 768): the reference model accepts these hyper-parameters
+    # (improved_fullsubnet/model.py:315-400, 541-591); sections of 32 + 40 + 12 + 6 units, 22 frames
+    "improved_769_b2": lambda: improved_case("improved_769_b2", MF.IMPROVED_48K_769, 2, 16000, seed_w=2, seed_x=81),
+    "fast_b2_even": lambda: fast_case("fast_b2_even", 2, 8192),  # T' = 35: 34 frames after the first -> all blocks full
+    "fast_b3_odd": lambda: fast_case("fast_b3_odd", 3, 8192 - 256, seed_w=1),  # T' = 34: 33 frames -> last block of 1
+    "fullband_b2": lambda: fullband_case("fullband_b2", 2, 8192),
+}
+
 if __name__ == "__main__":
-    stft_generic_case("stft_generic")
-    improved_case("improved_16k_b2", MF.IMPROVED_16K, 2, 4000)
-    improved_case("improved_48k_b2", MF.IMPROVED_48K, 2, 9600, seed_w=1)
-    fast_case("fast_b2_even", 2, 8192)          # T' = 35: 34 frames after the first -> all blocks full
-    fast_case("fast_b3_odd", 3, 8192 - 256, seed_w=1)  # T' = 34: 33 frames -> last block of 1
-    fullband_case("fullband_b2", 2, 8192)
+    for case in (sys.argv[1:] or list(CASES)):  # python tests/golden/make_golden_family.py [case ...]
+        CASES[case]()

@@ -141,7 +141,8 @@ def test_oracle_stft_istft_other_transform_shapes(golden_dir, n_fft, hop):
     assert np.abs(back - z["back/" + k]).max() <= 3e-6 * np.abs(z["back/" + k]).max()
 
 
-@pytest.mark.parametrize("name,cfg", [("improved_16k_b2", MF.IMPROVED_16K), ("improved_48k_b2", MF.IMPROVED_48K)])
+@pytest.mark.parametrize("name,cfg", [("improved_16k_b2", MF.IMPROVED_16K), ("improved_48k_b2", MF.IMPROVED_48K),
+                                      ("improved_769_b2", MF.IMPROVED_48K_769)])
 def test_improved_fullsubnet_oracle_vs_reference(golden_dir, name, cfg):
     z, meta = load(golden_dir, name)
     params = MF.make_improved_params(cfg, seed=meta["seed_w"])

@@ -411,7 +411,7 @@ def test_fused_forward_other_shapes_vs_oracle(fsn, F, la, nb, fbh, B, T, norm):
         crm = m(dev(mag)).cpu().numpy()
     want = O.fullsubnet_forward(mag, params, look_ahead=la, sb_num_neighbors=nb, norm_type=norm)
     assert crm.shape == want.shape == (B, 2, F, T)
-    assert np.abs(crm - want).max() <= 1e-4 * max(1.0, np.abs(want).max() / 10)
+    assert np.abs(crm - want).max() <= 1e-4  # the north-star bound on the compressed mask, unscaled
 
 
 @pytest.mark.parametrize("B,L", [(2, 300), (1, 257), (3, 1024), (2, 4097)])
@@ -500,7 +500,7 @@ def test_fused_forward_random_configurations(fsn):
         with torch.no_grad():
             crm = m(dev(mag)).cpu().numpy()
         want = O.fullsubnet_forward(mag, params, look_ahead=la, sb_num_neighbors=nb, norm_type=norm)
-        lim = 1e-4 * max(1.0, np.abs(want).max() / 10)
+        lim = 1e-4  # the north-star bound on the compressed mask, unscaled
         err = np.abs(crm - want).max()
         assert err <= lim, (F, la, nb, fbh, B, T, norm, err)
         worst = max(worst, err / lim)

@@ -86,6 +86,19 @@ def enhance_fn(which, model):
     return enhance
 
 
+def parity_sample(which, model, noisy, rows):
+    """What the parity checker compares for a family, computed on the WHOLE batch `noisy` (so the kernels are the ones
+    the timed step runs) and returned for the utterances `rows` only: the compressed mask [n, 2, F, T] for the
+    magnitude-in / mask-out models, the enhanced waveform [n, L] for Improved FullSubNet.  No oracle in here: bench.py
+    holds the checker."""
+    with torch.no_grad():
+        if which.startswith("improved"):
+            out = model(noisy)
+            return out.reshape(noisy.shape[0], -1)[rows].cpu().numpy()
+        mag = stft(noisy, 512, 256, 512, return_phase=False)[0]
+        return model(mag.unsqueeze(1))[rows].cpu().numpy()
+
+
 def family_step(which, B, device="cuda", steps=5, warmup=2, model_pack=None):
     """Whole path (stft -> model -> decompress -> mask -> istft; waveform to waveform for Improved FullSubNet) on B x 3 s
     of synthetic audio resident in HBM: dict(ms_per_step, frames_per_s, rtf, tflops, finite)."""
