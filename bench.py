@@ -369,6 +369,10 @@ def main():
                     help="also time the CPU baseline with every host thread (minutes on a 256-thread box)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements (other scaling mode, opt-in arithmetic, training step)")
+    ap.add_argument("--persistent", choices=["auto", "never"], default="auto",
+                    help="never: take the kernels that run a whole recurrence as one launch out of every plan "
+                         "(fsn_set_persistent_mode) - for ranks that SHARE a GPU (the gloo control-flow tests on a "
+                         "one-GPU box), the one situation the residency contract excludes (include/fsn_hip.h)")
     ap.add_argument("--host-io", action="store_true",
                     help="side measurement for DESIGN.md: every step also copies its input from pinned host memory and "
                          "its result back (the PCIe-inclusive rate; never the headline `value`, which is HBM-resident)")
@@ -406,6 +410,7 @@ def main():
     Tp = T + LA
     model, params = build_model(device)
     L = _lib.lib()
+    _lib.set_persistent_mode(args.persistent)
 
     def fence():
         torch.cuda.synchronize()
@@ -536,19 +541,26 @@ def main():
         }
         out.update(extras)
     if not args.no_extras and world == 1 and args.batch % 8 == 0:
-        # One rank's share of the strong-scaled batch at 8 GPUs (batch / 8 utterances), measured on this GPU: the
-        # north-star target (>= 6x at 8 GPUs) is this time against ms_per_step, before the all-gather of the waveforms
-        # (12 MB over xGMI) - a driver-visible prediction for boxes without an 8-GPU node.
+        # One rank's share of the strong-scaled batch at 2 / 4 / 8 GPUs (batch / N utterances), measured on this GPU:
+        # the north-star target (>= 6x at 8 GPUs) is this time against ms_per_step, before the all-gather of the
+        # waveforms (12 MB over xGMI) - a driver-visible PREDICTED curve for boxes without an 8-GPU node.
         keep = args.batch
-        args.batch = keep // 8
-        sh = run_mode("weak", max(5, args.steps), 3, profile=True)
+        shares = {}
+        for n in (2, 4, 8):
+            args.batch = keep // n
+            sh = run_mode("weak", max(5, args.steps), 3, profile=True)
+            sh_ms = 1e3 * sh["dt"] / sh["steps"]
+            shares[str(n)] = {"ranks": n, "utterances_per_rank": keep // n, "ms_per_step": round(sh_ms, 3),
+                              "predicted_speedup": round(ms_per_step / sh_ms, 2),
+                              "predicted_efficiency": round(ms_per_step / sh_ms / n, 3),
+                              "stage_ms": {k: round(v, 3) for k, v in sh["stage_ms"].items()}}
         args.batch = keep
-        sh_ms = 1e3 * sh["dt"] / sh["steps"]
         out["strong_scaling_share"] = {
-            "ranks": 8, "utterances_per_rank": keep // 8, "ms_per_step": round(sh_ms, 3),
-            "predicted_speedup_at_8_gpus": round(ms_per_step / sh_ms, 2),
-            "stage_ms": {k: round(v, 3) for k, v in sh["stage_ms"].items()},
+            **shares["8"], "predicted_speedup_at_8_gpus": shares["8"]["predicted_speedup"],
             "note": "one rank's share measured on ONE GPU (sub-band model on lstm2_group_kernel); excludes the all-gather"}
+        out["strong_scaling_shares"] = {
+            **shares, "note": "PREDICTED strong-scaling curve: one rank's share of the 64-utterance step at N ranks, each "
+                              "measured on this one GPU; excludes the all-gather (12 MB of waveforms per node)"}
     if not args.no_extras and world == 1:
         # the opt-in split-precision kernels (Model.arithmetic -> cfg.arith), reported NEXT TO `value`, never as it
         model.arithmetic = "f16x3"

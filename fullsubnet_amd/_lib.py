@@ -167,8 +167,10 @@ SIGNATURES = {
     "fsn_clip_adam_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.POINTER(_c.c_size_t)]),
     "fsn_clip_adam_step": (_c.c_int, [_c.c_int, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_void_p),
                                       _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
-                                      _c.c_void_p, _f32p, _f32p, _c.c_void_p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+                                      _c.c_void_p, _f32p, _f32p, _f32p, _c.c_void_p, _c.c_void_p, _c.c_size_t,
+                                      _c.c_void_p]),
     "fsn_profile_enable": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "fsn_stream_timeout_policy": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "fsn_set_persistent_mode": (_c.c_int, [_c.c_int]),
     "fsn_set_persistent_timeout_ms": (_c.c_int, [_c.c_int]),
     "fsn_stream_status": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_uint), _c.POINTER(_c.c_uint)]),
@@ -226,6 +228,13 @@ def stream_status(device=None, synchronize=True, raise_on_timeout=True):
 
 def stream_status_clear(device=None):
     check(lib().fsn_stream_status_clear(stream_ptr(device)))
+
+
+def stream_timeout_policy(policy, device=None):
+    """"refuse" (default): a raised timeout record makes later persistent launches on the current stream of `device`
+    fail with FsnTimeout until cleared.  "defer": they run regardless (a training step in flight; the poison is NaN,
+    the fused optimizer skips, the caller reads `stream_status` once per step)."""
+    check(lib().fsn_stream_timeout_policy(stream_ptr(device), {"refuse": 0, "defer": 1}[policy]))
 
 
 def persist_stats():

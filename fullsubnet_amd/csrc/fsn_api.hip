@@ -11,6 +11,7 @@
 
 #include <atomic>
 #include <map>
+#include <string>
 #include <vector>
 #include <mutex>
 #include <utility>
@@ -77,6 +78,9 @@ struct StreamCtx {
     // ({status word of the first launch that ran out of time, number of such launches}); NULL until first needed
     unsigned* sticky_host = nullptr;
     unsigned* sticky_dev = nullptr;
+    // fsn_stream_timeout_policy: a raised record does not refuse later persistent launches on this stream (a training
+    // step in flight: NaN poison + the optimizer's skip contain the damage; the caller looks at the end of the step)
+    bool timeout_defer = false;
 };
 static std::mutex g_ctx_mutex;
 static std::map<std::pair<int, hipStream_t>, StreamCtx*> g_ctx;
@@ -385,7 +389,7 @@ static int persist_precheck() {
     StreamCtx* c = cur_ctx();
     if (c->sticky_host) {
         const unsigned st = __atomic_load_n(&c->sticky_host[0], __ATOMIC_ACQUIRE);
-        if (st != 0) {
+        if (st != 0 && !c->timeout_defer) {
             fsn_set_error("a persistent kernel launched earlier on this stream ran out of time waiting for its partner "
                           "workgroups (status %u, %u such launches): its outputs are NaN; see fsn_stream_status / "
                           "fsn_stream_status_clear", st, __atomic_load_n(&c->sticky_host[1], __ATOMIC_ACQUIRE));
@@ -450,6 +454,12 @@ extern "C" int fsn_stream_status(void* stream, int synchronize, unsigned* status
                       st, ev);
         return FSN_ERR_TIMEOUT;
     }
+    return FSN_OK;
+}
+extern "C" int fsn_stream_timeout_policy(void* stream, int policy) {
+    FSN_REQUIRE(policy == FSN_TIMEOUT_REFUSE || policy == FSN_TIMEOUT_DEFER, "timeout policy %d unknown", policy);
+    CallScope scope(stream);
+    cur_ctx()->timeout_defer = policy == FSN_TIMEOUT_DEFER;
     return FSN_OK;
 }
 extern "C" int fsn_stream_status_clear(void* stream) {
@@ -1223,7 +1233,33 @@ static double core_cost(const fsn_fullsubnet_cfg* cfg, int b) {
 }
 // the chunk sizes of a batch, largest first: whole rounds of core_chunk(), then the cheapest split of the remainder into
 // {itself, 48, 32, 16, 8}-utterance calls by core_cost
+static int core_chunks_search(const fsn_fullsubnet_cfg* cfg, int B, int* sizes, int max_sizes);
+// The search evaluates core_cost / core_dims ~5 x (remainder) times, each with device-attribute and occupancy lookups:
+// ~10^4 host calls at B = 64, three times per fsn_enhance (workspace query, workspace check, run).  The plan depends
+// only on (configuration, B, device, persistent mode): memoised.
 static int core_chunks(const fsn_fullsubnet_cfg* cfg, int B, int* sizes, int max_sizes) {
+    static std::mutex mu;
+    static std::map<std::string, std::vector<int>> memo;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::string key(reinterpret_cast<const char*>(cfg), sizeof(*cfg));
+    const int tail[4] = {B, dev, fsn_persistent_allowed() ? 1 : 0, max_sizes};
+    key.append(reinterpret_cast<const char*>(tail), sizeof(tail));
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = memo.find(key);
+        if (it != memo.end()) {
+            for (size_t i = 0; i < it->second.size(); ++i) sizes[i] = it->second[i];
+            return (int)it->second.size();
+        }
+    }
+    const int n = core_chunks_search(cfg, B, sizes, max_sizes);
+    std::lock_guard<std::mutex> lk(mu);
+    if (memo.size() > 4096) memo.clear();
+    memo[key] = std::vector<int>(sizes, sizes + n);
+    return n;
+}
+static int core_chunks_search(const fsn_fullsubnet_cfg* cfg, int B, int* sizes, int max_sizes) {
     int n = 0;
     const int full = core_chunk(cfg, B);
     int rem = B;

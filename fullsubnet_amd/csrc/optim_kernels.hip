@@ -82,7 +82,8 @@ struct AdamScalars {
 __global__ __launch_bounds__(256) void clip_adam_kernel(TensorTable tt, const double* __restrict__ partial,
                                                         int n_partials, AdamScalars a, float* __restrict__ norm_out,
                                                         unsigned* __restrict__ skipped,
-                                                        const float* __restrict__ grad_scale) {
+                                                        const float* __restrict__ grad_scale,
+                                                        const float* __restrict__ found_inf) {
     __shared__ double sh[4];
     __shared__ float coef_sh, step_size_sh, bc2_sqrt_sh;
     __shared__ int ok_sh;
@@ -93,7 +94,9 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(TensorTable tt, const do
         const float norm = (float)sqrt(t);
         float coef = a.max_norm / (norm + 1e-6f);
         coef_sh = coef < 1.0f ? coef : 1.0f;
-        const bool ok = __builtin_isfinite(norm);
+        // found_inf: GradScaler's verdict over ALL parameter groups of the optimizer - a group whose own gradients
+        // are finite must skip with the others (scaler.step skips the whole optimizer.step, trainer.py:69)
+        const bool ok = __builtin_isfinite(norm) && !(found_inf && *found_inf != 0.f);
         ok_sh = ok ? 1 : 0;
         step_size_sh = a.step_size;
         bc2_sqrt_sh = a.bc2_sqrt;
@@ -187,8 +190,8 @@ extern "C" size_t fsn_clip_adam_workspace_bytes(int n_tensors, const size_t* num
 
 extern "C" int fsn_clip_adam_step(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                                   float* const* exp_avg_sq, const size_t* numel, const fsn_adam_cfg* cfg,
-                                  float* total_norm_out, const float* grad_scale, unsigned* skipped_steps, void* workspace,
-                                  size_t workspace_bytes, void* stream) {
+                                  float* total_norm_out, const float* grad_scale, const float* found_inf,
+                                  unsigned* skipped_steps, void* workspace, size_t workspace_bytes, void* stream) {
     FsnCallScope scope(stream);
     FSN_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel && cfg && workspace, "NULL pointer argument");
     FSN_REQUIRE(n_tensors >= 1 && n_tensors <= kMaxTensors, "clip_adam: 1..%d tensors per call (got %d)", kMaxTensors,
@@ -224,7 +227,7 @@ extern "C" int fsn_clip_adam_step(int n_tensors, float* const* params, float* co
     a.beta2_d = b2;
     a.step = cfg->step;
     hipLaunchKernelGGL(clip_adam_kernel, dim3(chunks), dim3(256), 0, s, tt, partial, chunks, a, total_norm_out,
-                       skipped_steps, grad_scale);
+                       skipped_steps, grad_scale, found_inf);
     return fsn_check_launch("clip_adam_kernel");
 }
 

@@ -41,8 +41,10 @@ class MelScale(nn.Module):
     def forward(self, specgram):
         """[..., F, T] -> [..., n_mels, T]: specgram^T fb, through the in-tree MFMA GEMM (fsn_linear_forward with the
         filterbank as an nn.Linear weight [n_mels, F] and a zero bias) - no vendor BLAS on the path."""
-        if not specgram.is_cuda:
-            raise _lib.FsnError("MelScale: input must live on a ROCm device; this path has no CPU implementation")
+        if not specgram.is_cuda or (torch.is_grad_enabled() and specgram.requires_grad):
+            # host-side callers (CPU unit tests of the glue) and inputs that want a gradient (a learned front end): the
+            # same product as tensor algebra, autograd-tracked - the pattern of base_model._hip_norm
+            return torch.matmul(specgram.transpose(-1, -2), self.fb).transpose(-1, -2)
         F, T = specgram.shape[-2], specgram.shape[-1]
         lead = specgram.shape[:-2]
         key = (self.fb.data_ptr(), self.fb._version, str(self.fb.device))

@@ -102,8 +102,14 @@ class ClipAdam(torch.optim.Optimizer):
             scale = getattr(self, "grad_scale", None)  # set by GradScaler.step for the duration of this call
             if scale is not None:
                 scale = scale.to(device=dev, dtype=torch.float32).reshape(1)
+            # GradScaler's inf flag covers every group of this optimizer: all of them skip together (scaler.step skips
+            # the whole optimizer.step in the reference), not each on its own gradients
+            found = getattr(self, "found_inf", None)
+            if found is not None:
+                found = found.to(device=dev, dtype=torch.float32).reshape(1)
             _lib.check(L.fsn_clip_adam_step(n, P, G, M, V, numel, ctypes.byref(cfg), _lib.dev_ptr(self.total_norm),
                                             _lib.dev_ptr(scale, "grad_scale", allow_none=True),
+                                            _lib.dev_ptr(found, "found_inf", allow_none=True),
                                             ctypes.c_void_p(self._skipped[gi].data_ptr()),
                                             ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_ptr(dev)))
             torch._C._increment_version(ps)  # the raw-pointer update above is invisible to autograd's counters

@@ -75,9 +75,9 @@ class Lstm2Function(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, arith="f32"):
         L = _lib.lib()
-        ctx.arith = _lib.ARITH[arith]
         if arith not in ("f32", "f16", "bf16"):
             raise _lib.FsnError(f"training arithmetic {arith!r}: one of 'f32', 'f16', 'bf16'")
+        ctx.arith = _lib.ARITH[arith]
         T, N, I = x.shape
         H = w_hh0.shape[1]
         Np, Ip = (N + 15) // 16 * 16, (I + 15) // 16 * 16
@@ -402,7 +402,12 @@ def train_step(model, optimizer, noisy, clean, n_fft=512, hop_length=256, win_le
     _, _, clean_real, clean_imag = stft(clean, n_fft, hop_length, win_length, return_phase=False)
     cirm = build_complex_ideal_ratio_mask(noisy_real, noisy_imag, clean_real, clean_imag)  # [B, F, T, 2]
     inner = model.module if hasattr(model, "module") else model
-    cirm = drop_band(cirm.permute(0, 3, 1, 2), inner.num_groups_in_drop_band).permute(0, 2, 3, 1)
+    # fullsubnet/trainer.py:53 drops bands of the target like the model does of its input; the sibling trainers
+    # (fast_fullsubnet/trainer.py:33-76, fullband_baseline/trainer.py) have no band dropping: their models carry no
+    # `num_groups_in_drop_band` and the target stays whole
+    groups = getattr(inner, "num_groups_in_drop_band", None)
+    if groups is not None:
+        cirm = drop_band(cirm.permute(0, 3, 1, 2), groups).permute(0, 2, 3, 1)
     crm = model(noisy_mag.unsqueeze(1)).permute(0, 2, 3, 1)
     loss = loss_function(cirm, crm)
     if scaler is not None and scaler.is_enabled():

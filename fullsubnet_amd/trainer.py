@@ -14,9 +14,9 @@ Checkpoints are the reference's ``latest_model.tar`` / ``best_model.tar`` / ``mo
 reference's keys (epoch, best_score, optimizer, scaler, model), so either side can resume from the other's files
 and ``BaseInferencer._load_model`` (base_inferencer.py:146-160) accepts them.
 
-Arithmetic: fp32 only.  ``meta.use_amp = true`` (every shipped train TOML) is accepted and computed in fp32
-(a precision superset of fp16 autocast); a disabled GradScaler is kept so the checkpoint has the
-reference's ``scaler`` entry.
+Arithmetic: ``meta.use_amp = true`` (every shipped train TOML) is the reference's autocast step - 16-bit matrix-core
+operands with fp32 accumulation on the sub-band kernels (``meta.amp_dtype``: "f16" default, "bf16") under the
+reference's own ``torch.amp.GradScaler`` (same ``scaler`` entry in the checkpoint); ``use_amp = false`` is fp32.
 
 Validation metrics: STOI / WB_PESQ live in third-party packages (pystoi, pesq) that are outside this path and not
 in this image.  ``_validation_epoch`` scores with the metrics registered in ``self.metrics`` (name -> fn(reference,
@@ -93,7 +93,13 @@ class Trainer:
         # own GradScaler scales the loss, skips overflowed steps and adapts the scale.
         self.use_amp = bool(meta.get("use_amp", False))
         self.scaler = torch.amp.GradScaler("cuda", enabled=self.use_amp)
-        self._inner().train_arithmetic = str(meta.get("amp_dtype", "f16")) if self.use_amp else "f32"
+        amp_dtype = str(meta.get("amp_dtype", "f16")).lower()
+        aliases = {"f16": "f16", "fp16": "f16", "float16": "f16", "half": "f16", "torch.float16": "f16",
+                   "bf16": "bf16", "bfloat16": "bf16", "torch.bfloat16": "bf16"}
+        if self.use_amp and amp_dtype not in aliases:
+            raise ValueError(f"meta.amp_dtype = {meta.get('amp_dtype')!r}: the autocast arithmetic is \"f16\" (fp16, the "
+                             f"recipe's) or \"bf16\" (aliases: {sorted(aliases)})")
+        self._inner().train_arithmetic = aliases[amp_dtype] if self.use_amp else "f32"
 
         ac = config["acoustics"]
         self.acoustic_config = ac
@@ -211,6 +217,11 @@ class Trainer:
     def _train_epoch(self, epoch):
         """fullsubnet/trainer.py:33-76."""
         loss_total, n = 0.0, 0
+        # a persistent kernel that runs out of time in the MIDDLE of a step (its record is read at enqueue time by
+        # every later persistent launch) must not raise out of forward / backward - under DistributedDataParallel the
+        # peers would be left waiting in the gradient all-reduce.  The launches go ahead instead (NaN in, NaN out), the
+        # fused optimizer skips the update on the device, and the record is read below, once per step
+        _lib.stream_timeout_policy("defer", self.device)
         for noisy, clean in self.train_dataloader:
             loss = train_step(self.model, self.optimizer, noisy.to(self.device), clean.to(self.device), self.n_fft,
                               self.hop_length, self.win_length, self.clip_grad_norm_value, self.loss_function,
@@ -231,6 +242,7 @@ class Trainer:
                 continue
             loss_total += value
             n += 1
+        _lib.stream_timeout_policy("refuse", self.device)
         self.last_loss = loss_total / max(n, 1)
         self.history["Loss/Train"][epoch] = self.last_loss
         return self.last_loss
@@ -257,8 +269,16 @@ class Trainer:
             noisy_mag, _, noisy_real, noisy_imag = self.torch_stft(noisy)
             _, _, clean_real, clean_imag = self.torch_stft(clean)
             cirm = build_complex_ideal_ratio_mask(noisy_real, noisy_imag, clean_real, clean_imag)  # [B, F, T, 2]
-            crm = model(noisy_mag.unsqueeze(1)).permute(0, 2, 3, 1).contiguous()
-            loss = float(loss_fn(cirm, crm))
+            try:
+                crm = model(noisy_mag.unsqueeze(1)).permute(0, 2, 3, 1).contiguous()
+                loss = float(loss_fn(cirm, crm))  # host sync: the utterance's launches are complete
+                status, _ = _lib.stream_status(self.device, synchronize=False, raise_on_timeout=False)
+            except _lib.FsnTimeout:
+                status = 1
+            if status:  # a persistent kernel ran out of time: NaN outputs, keep the utterance out of loss and score
+                self.persistent_timeouts += 1
+                _lib.stream_status_clear(self.device)
+                continue
             m = decompress_cIRM(crm)
             enhanced_real = m[..., 0] * noisy_real - m[..., 1] * noisy_imag
             enhanced_imag = m[..., 1] * noisy_real + m[..., 0] * noisy_imag

@@ -339,7 +339,9 @@ int fsn_mse_loss(const float* input, const float* target, size_t n, float* loss,
  * advance Adam's step count - the kernel uses step - skipped for the bias corrections.
  * grad_scale (device scalar, may be NULL = 1): the loss scale the gradients carry (GradScaler, trainer.py:63-69):
  * they are divided by it first (GradScaler.unscale_), so total_norm_out, the clipping and the update see unscaled
- * gradients; an overflowed (inf / NaN) gradient makes the norm non-finite and the update is skipped as above. */
+ * gradients; an overflowed (inf / NaN) gradient makes the norm non-finite and the update is skipped as above.
+ * found_inf (device scalar, may be NULL): GradScaler's inf flag over ALL of the optimizer's parameter groups; non-zero
+ * skips this call's update too, so that the groups of one optimizer skip together like scaler.step does. */
 #define FSN_ADAM_MAX_TENSORS 32
 typedef struct fsn_adam_cfg {
     float lr, beta1, beta2, eps;
@@ -349,8 +351,8 @@ typedef struct fsn_adam_cfg {
 size_t fsn_clip_adam_workspace_bytes(int n_tensors, const size_t* numel);
 int fsn_clip_adam_step(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                        float* const* exp_avg_sq, const size_t* numel, const fsn_adam_cfg* cfg,
-                       float* total_norm_out, const float* grad_scale, unsigned* skipped_steps, void* workspace,
-                       size_t workspace_bytes, void* stream);
+                       float* total_norm_out, const float* grad_scale, const float* found_inf,
+                       unsigned* skipped_steps, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- residency contract of the persistent kernels ----------------------------------------------------------
  * Four kernels - the full-band chain (forward, BPTT) and the sub-band group kernel (forward, BPTT) - run a whole
@@ -379,6 +381,16 @@ int fsn_set_persistent_timeout_ms(int ms);   /* process-wide, [1, 3600000] */
  * stream first (the record is written by the device when the launch ends).  Returns FSN_ERR_TIMEOUT when raised. */
 int fsn_stream_status(void* stream, int synchronize, unsigned* status_out, unsigned* events_out);
 int fsn_stream_status_clear(void* stream);
+/* What a RAISED record does to later persistent launches on `stream`.  FSN_TIMEOUT_REFUSE (default): they return
+ * FSN_ERR_TIMEOUT until the record is cleared - an inference caller must never consume NaN silently.
+ * FSN_TIMEOUT_DEFER: they are launched regardless - for a training step in flight (fullsubnet/trainer.py:41-71:
+ * forward, loss, backward are ~10 entry points behind autograd, and under DistributedDataParallel,
+ * audio_zen/trainer/base_trainer.py:32, a rank that raised in the middle of backward would leave its peers waiting in
+ * the gradient all-reduce): the poisoned outputs are NaN, NaN propagates into every gradient, the fused optimizer
+ * skips the update on the device (fsn_clip_adam_step), and the caller reads fsn_stream_status once per step. */
+#define FSN_TIMEOUT_REFUSE 0
+#define FSN_TIMEOUT_DEFER 1
+int fsn_stream_timeout_policy(void* stream, int policy);
 
 /* Per-stage kernel timing of the last fsn_enhance / fsn_fullsubnet_forward call made ON `stream` with
  * profiling enabled for THAT stream (hipEvents on it, kept per (device, stream); forces a sync of them when read).
