@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, "libfsn_hip.so")
 HEADERS = [os.path.join(CSRC, "fsn_common.h"), os.path.join(HERE, "..", "include", "fsn_hip.h")]
 SOURCES = ["fft_kernels.hip", "dft_kernels.hip", "elementwise_kernels.hip", "gemm_kernels.hip",
            "gemm_f16x3_kernels.hip", "lstm_kernels.hip", "lstm_group_kernels.hip",
-           "lstm_group_bptt_kernels.hip", "fb_chain_kernels.hip", "fb_chain_bptt_kernels.hip",
+           "lstm_group_bptt_kernels.hip", "lstm_group16_kernels.hip", "fb_chain_kernels.hip", "fb_chain_bptt_kernels.hip",
            "lstm_f16x3_kernels.hip", "lstm_train_kernels.hip", "gru_kernels.hip", "optim_kernels.hip",
            "norm_kernels.hip", "section_kernels.hip", "fsn_api.hip"]
 # -ffp-contract=off: elementwise code follows the reference's mul/add rounding sequence; fused

@@ -85,6 +85,7 @@ struct StreamCtx {
 static std::mutex g_ctx_mutex;
 static std::map<std::pair<int, hipStream_t>, StreamCtx*> g_ctx;
 static std::atomic<int> g_persist_mode{0};          // fsn_set_persistent_mode: 0 auto, 1 never
+static std::atomic<int> g_g16_off{0};               // fsn_debug_g16_kernels(0): the fp32-era group kernels also under 16-bit arithmetic
 static std::atomic<int> g_persist_timeout_ms{20000};  // fsn_set_persistent_timeout_ms
 
 // Persistent kernels whose workgroups wait for each other (the group kernel, the full-band chain) need ALL their
@@ -425,6 +426,12 @@ extern "C" int fsn_debug_tn_plan(int M, int Nc, long K, int arith, int* splits, 
     if (M < 1 || Nc < 1 || K < 1) return -1;
     fsn_tn_plan_splits(M, Nc, K, arith, splits, bound);
     return 0;
+}
+// Test / measurement hook: 0 = the fp32-era group kernels also under the 16-bit training arithmetic (A/B against
+// lstm_group16_kernels.hip), 1 (default) = the 16-bit arithmetic's own kernels where they apply.
+extern "C" int fsn_debug_g16_kernels(int on) {
+    g_g16_off.store(on ? 0 : 1, std::memory_order_relaxed);
+    return FSN_OK;
 }
 extern "C" int fsn_debug_persist_stats(unsigned* launches, unsigned* waits, unsigned* unreported) {
     if (launches) *launches = g_persist_launches.load(std::memory_order_relaxed);
@@ -1924,6 +1931,16 @@ static Lstm2TrainPlan lstm2_train_plan(int T, int N, int I, int H) {
     return p;
 }
 static int lstm2_train_group_clusters(int T, int N, int I, int H) { return lstm2_train_plan(T, N, I, H).fwd_group; }
+// the 16-bit arithmetic has kernels of its own for the group shapes (lstm_group16_kernels.hip) when they take the same
+// clusters; the flag array is sized for either family
+static bool lstm2_use_g16(int arith, int clusters, int N) {
+    return arith != FSN_ARITH_F32 && clusters > 0 && fsn_lstm2_g16_clusters(N / 16) >= clusters && !g_g16_off.load(std::memory_order_relaxed);
+}
+static size_t lstm2_group_flag_words_any(int clusters) {
+    size_t a = fsn_lstm2_group_flag_words(clusters), b = fsn_lstm2_g16_flag_words(clusters), c = fsn_lstm2_group_bptt_flag_words(clusters);
+    a = a > b ? a : b;
+    return a > c ? a : c;
+}
 extern "C" size_t fsn_lstm2_train_workspace_bytes(int T, int N, int I, int H, int arith) {
     const int Ipad = fsn_round_up(I, 16);
     Carver cv(nullptr);
@@ -1931,7 +1948,7 @@ extern "C" size_t fsn_lstm2_train_workspace_bytes(int T, int N, int I, int H, in
         const size_t left = (size_t)(N / 16 - 4 * clusters) * 16;
         cv.take<float>((size_t)4 * H * Ipad + (size_t)3 * 4 * H * H);
         cv.take<float>((size_t)2 * 4 * H);
-        cv.take<unsigned>(fsn_lstm2_group_flag_words(clusters));
+        cv.take<unsigned>(lstm2_group_flag_words_any(clusters));
         cv.take<float>((size_t)T * left * Ipad);
         cv.take<float>((size_t)T * left * H);
         cv.take<float>((size_t)T * left * 4 * H);
@@ -1980,7 +1997,7 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
         float* whh1_p = wih1_p + (size_t)4 * H * H;
         float* b0 = cv.take<float>((size_t)2 * 4 * H);
         float* b1 = b0 + 4 * H;
-        unsigned* flags = cv.take<unsigned>(fsn_lstm2_group_flag_words(clusters));
+        unsigned* flags = cv.take<unsigned>(lstm2_group_flag_words_any(clusters));
         float* x_left = cv.take<float>((size_t)T * left * Ipad);
         float* h0_left = cv.take<float>((size_t)T * left * H);
         float* gx_left = cv.take<float>((size_t)T * left * 4 * H);
@@ -1992,7 +2009,8 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
         FSN_TRY(fsn_launch_pack(w_hh1, whh1_p, 4 * H, H, 4 * H, H, s));
         FSN_TRY(fsn_launch_bias_sum(b_ih0, b_hh0, b0, 4 * H, 4 * H, s));
         FSN_TRY(fsn_launch_bias_sum(b_ih1, b_hh1, b1, 4 * H, 4 * H, s));
-        if (w16) FSN_TRY(fsn_launch_to16(wih0_p, w16, wfloats, arith, s));  // the group kernel's weight fragments in 16 bits
+        const bool g16 = lstm2_use_g16(arith, clusters, N);
+        if (w16 && !g16) FSN_TRY(fsn_launch_to16(wih0_p, w16, wfloats, arith, s));  // the group kernel's weight fragments in 16 bits
         float* sv0 = static_cast<float*>(save0);
         float* sv1 = static_cast<float*>(save1);
         StreamCtx* cx = cur_ctx();
@@ -2005,9 +2023,15 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
         }
         {
             FSN_PERSIST_BEGIN(s);
-            FSN_TRY(fsn_launch_lstm2_group_train(x, ldx, 32, N, wih0_p, whh0_p, wih1_p, whh1_p, b0, b1, hseq0, hseq1, sv0, sv1,
-                                                 flags, T, clusters, H, s, arith, w16));
-            FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_status_word(clusters), hseq1, (size_t)T * N * H, s));
+            if (g16) {  // the 16-bit arithmetic's own kernels: they pack the raw weights their way into w16
+                FSN_TRY(fsn_launch_lstm2_g16_train(x, I, N, w_ih0, w_hh0, w_ih1, w_hh1, b0, b1, hseq0, hseq1, sv0, sv1, flags, w16,
+                                                   T, clusters, H, s, arith));
+                FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_g16_status_word(clusters), hseq1, (size_t)T * N * H, s));
+            } else {
+                FSN_TRY(fsn_launch_lstm2_group_train(x, ldx, 32, N, wih0_p, whh0_p, wih1_p, whh1_p, b0, b1, hseq0, hseq1, sv0,
+                                                     sv1, flags, T, clusters, H, s, arith, w16));
+                FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_status_word(clusters), hseq1, (size_t)T * N * H, s));
+            }
         }
         if (left > 0) {
             hipStream_t as = cx->aux;
@@ -2545,14 +2569,17 @@ extern "C" size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H, int 
         cv.take<float>((size_t)3 * H * G + (size_t)Ipad * G);  // W_hh1^T, W_ih1^T, W_hh0^T, W_ih0^T fragments
         cv.take<float>((size_t)2 * T * N * G);                 // dgates of both layers
         cv.take<float>((size_t)T * N * H);                     // layer 0's dH (dgates1 W_ih1), produced by the kernel
-        cv.take<unsigned>(fsn_lstm2_group_bptt_flag_words(clusters));
+        cv.take<unsigned>(lstm2_group_flag_words_any(clusters));
         cv.take<float>((size_t)T * left * G);                  // left-over rows: compact dgates1
         cv.take<float>((size_t)T * left * H);                  // ... their dh0
         cv.take<float>((size_t)left * H);                      // ... dc
         size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
         const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
         cv.take<char>(tn > tn2 ? tn : tn2);
-        if (arith != FSN_ARITH_F32) cv.take<unsigned short>((size_t)3 * H * G);  // 16-bit W^T fragments
+        if (arith != FSN_ARITH_F32) {
+            cv.take<unsigned short>((size_t)3 * H * G);  // 16-bit W^T fragments
+            cv.take<float>(fsn_lstm2_g16_partial_floats(clusters));  // lstm_group16_kernels.hip: exchanged partial sums
+        }
         return fsn_round_up_sz(cv.off, 256);
     }
     if (lstm2_train_plan(T, N, I, H).bptt_chain) {
@@ -2661,7 +2688,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     float* dg1 = cv.take<float>((size_t)2 * T * N * G);
     float* dg0 = dg1 + (size_t)T * N * G;
     float* dxbuf = cv.take<float>((size_t)T * N * H);
-    unsigned* flags = cv.take<unsigned>(fsn_lstm2_group_bptt_flag_words(clusters));
+    unsigned* flags = cv.take<unsigned>(lstm2_group_flag_words_any(clusters));
     float* dg1_left = cv.take<float>((size_t)T * left * G);
     float* dh0_left = cv.take<float>((size_t)T * left * H);
     float* dc_left = cv.take<float>((size_t)left * H);
@@ -2669,6 +2696,8 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
     void* scratch = cv.take<char>(tn > tn2 ? tn : tn2);
     unsigned short* w16 = arith != FSN_ARITH_F32 ? cv.take<unsigned short>((size_t)3 * H * G) : nullptr;
+    float* partials = arith != FSN_ARITH_F32 ? cv.take<float>(fsn_lstm2_g16_partial_floats(clusters)) : nullptr;
+    const bool g16 = lstm2_use_g16(arith, clusters, N);
     const float* sv0 = static_cast<const float*>(save0);
     const float* sv1 = static_cast<const float*>(save1);
     // "weights" of dh = dgates W are W^T: out = H columns, k = 4H; nn.LSTM stores exactly that transposed
@@ -2676,7 +2705,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     FSN_TRY(fsn_launch_pack(w_ih1, wih1T_p, H, G, H, G, s, 1, H));
     FSN_TRY(fsn_launch_pack(w_hh0, whh0T_p, H, G, H, G, s, 1, H));
     FSN_TRY(fsn_launch_pack(w_ih0, wih0T_p, I, G, Ipad, G, s, 1, I));
-    if (w16) FSN_TRY(fsn_launch_to16(whh1T_p, w16, (size_t)3 * H * G, arith, s));  // the BPTT kernel's W^T fragments in 16 bits
+    if (w16 && !g16) FSN_TRY(fsn_launch_to16(whh1T_p, w16, (size_t)3 * H * G, arith, s));  // the BPTT kernel's W^T fragments in 16 bits
     StreamCtx* cx = cur_ctx();
     if (left > 0) {
         FSN_TRY(aux_init(cx));
@@ -2687,10 +2716,16 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     }
     {
         FSN_PERSIST_BEGIN(s);
-        FSN_TRY(fsn_launch_lstm2_group_bptt(dh1, whh1T_p, wih1T_p, whh0T_p, sv0, sv1, dg0, dg1, dxbuf, flags, T, N, clusters,
-                                            H, s, arith, w16));
-        // both gate-gradient buffers (dg1 | dg0 are adjacent): every weight gradient and dx derive from them
-        FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_bptt_status_word(clusters), dg1, (size_t)2 * T * N * G, s));
+        if (g16) {  // the 16-bit arithmetic's own kernel (K-split; packs the raw weights its way into w16)
+            FSN_TRY(fsn_launch_lstm2_g16_bptt(dh1, w_hh1, w_ih1, w_hh0, sv0, sv1, dg0, dg1, partials, flags, w16, T, N, clusters,
+                                              H, s, arith));
+            FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_g16_status_word(clusters), dg1, (size_t)2 * T * N * G, s));
+        } else {
+            FSN_TRY(fsn_launch_lstm2_group_bptt(dh1, whh1T_p, wih1T_p, whh0T_p, sv0, sv1, dg0, dg1, dxbuf, flags, T, N, clusters,
+                                                H, s, arith, w16));
+            // both gate-gradient buffers (dg1 | dg0 are adjacent): every weight gradient and dx derive from them
+            FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_group_bptt_status_word(clusters), dg1, (size_t)2 * T * N * G, s));
+        }
     }
     if (left > 0) {
         // the rows that do not fill a cluster: step by step on the auxiliary stream, straight into the same buffers

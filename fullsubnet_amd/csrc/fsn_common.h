@@ -251,6 +251,21 @@ int fsn_launch_lstm2_group_bptt(const float* dh1, const float* whh1T_p, const fl
                                 const float* save0, const float* save1, float* dg0, float* dg1, float* dx, unsigned* flags,
                                 int Tp, int Nrows, int clusters, int H, hipStream_t s, int arith = FSN_ARITH_F32,
                                 const void* w16 = nullptr);
+// lstm_group16_kernels.hip: the same two-layer forward-with-saves / BPTT for the 16-bit training arithmetic (autocast),
+// built for it: transposed products, per-wave weight streams, 16-byte hand-offs, K-split BPTT (see the file)
+int fsn_lstm2_g16_clusters(int tiles);
+size_t fsn_lstm2_g16_flag_words(int clusters);
+size_t fsn_lstm2_g16_status_word(int clusters);
+size_t fsn_lstm2_g16_partial_floats(int clusters);
+size_t fsn_lstm2_g16_fwd_weight_halves(int Ipad);
+size_t fsn_lstm2_g16_bwd_weight_halves();
+int fsn_launch_lstm2_g16_train(const float* x, int I, int Nrows, const float* w_ih0, const float* w_hh0, const float* w_ih1,
+                               const float* w_hh1, const float* bias0, const float* bias1, float* hseq0, float* hseq1,
+                               float* save0, float* save1, unsigned* flags, void* w16, int Tp, int clusters, int H,
+                               hipStream_t s, int arith);
+int fsn_launch_lstm2_g16_bptt(const float* dh1, const float* w_hh1, const float* w_ih1, const float* w_hh0, const float* save0,
+                              const float* save1, float* dg0, float* dg1, float* partials, unsigned* flags, void* w16, int Tp,
+                              int Nrows, int clusters, int H, hipStream_t s, int arith);
 // fb_chain_bptt_kernels.hip: BPTT of the full-band model's two layers (16 rows, H = 512) as one persistent launch
 bool fsn_fb_chain_bptt_supported(int H, int N);
 int fsn_fb_chain_bptt_max_steps();

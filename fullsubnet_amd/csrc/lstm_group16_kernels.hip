@@ -1,0 +1,768 @@
+// The sub-band model's two LSTM layers under the reference's OWN training arithmetic (torch.autocast: 16-bit matrix-core
+// operands, fp32 accumulation; recipes/dns_interspeech_2020/fullsubnet/trainer.py:56-69, fullsubnet/train.toml:5) as
+// persistent launches built for that arithmetic: forward with saves (sequence_model.py:52-58 under autograd) and
+// back-propagation through time.  Same work split as lstm_group_kernels.hip / lstm_group_bptt_kernels.hip - clusters
+// of 64 rows, eight members of 48 hidden units per layer, two workgroups per CU - and the same buffers in and out
+// (hidden sequences, save layout, gate gradients), but a different step:
+//
+// With 16-bit operands the matrix work of a step is 3 - 6 us and the fp32-era kernels spend 30 - 45 us per step in a
+// CHAIN of memory round trips (profiles/r03_bptt_probe_f16.md: weights through L2 / LDS with a barrier per four K
+// chunks ~10 us, the partners' operand ~9, saved activations ~8, dword write-through stores ~11).  Here
+//   * every product is formed TRANSPOSED, D^T[gate column or unit][batch row] = W (A operand) x activations^T (B
+//     operand): a lane's four accumulator values are four CONSECUTIVE hidden units of one batch row, so everything
+//     that touches memory - h, the saves, the gate gradients, the exchanged partial sums - moves as 16-byte accesses
+//     (5 - 6x fewer fabric transactions than dword write-through stores);
+//   * the waves of a workgroup split the WEIGHT dimension: each wave streams its own weight fragments L2 -> registers
+//     through a ring that is filled BEFORE the step's hand-off wait (weights do not depend on it) - no LDS staging of
+//     weights, no barrier inside a K loop; the ACTIVATIONS (what the partners handed over) are staged once per product
+//     into LDS, rounded to 16 bits once on the way in, and shared by the four waves;
+//   * forward: wave g forms gate g of the member's 48 units for all 64 rows; the four gates of a unit meet through one
+//     LDS exchange, after which a thread owns (row, four units): cell update, one 16-byte write-through store of h per
+//     (row, unit quad), the saves as 16-byte stores after the flag;
+//   * BPTT splits K instead of the output: a member keeps the gate gradients of ITS 192 gate columns (it has just
+//     formed them: no exchange to read them) and multiplies them by its 192 ROWS of W_hh / W_ih - a [64 x 192] x
+//     [192 x 384] product whose result is a PARTIAL dh for all 384 units; the eight partials of a cluster are summed
+//     in a fixed order by the member that owns the units.  Per member and step 96 KB written + 96 KB read in
+//     accumulator-fragment order (16-byte, fully coalesced) instead of a 393 KB gather of everyone's gate gradients;
+//     layer 1 also forms dgates1 W_ih1 (layer 0's dH) from the same LDS tile, handed over through a four-deep ring.
+// Arithmetic: operands rounded to fp16 / bf16 (round to nearest even) exactly where fsn_mma_k16 rounds them - weights
+// once when packed, activations when staged - products and sums in fp32, everything stored in fp32.  Results differ
+// from the fp32-era kernels under the same arithmetic only by the order of the fp32 sums (tests/test_gpu_amp.py holds
+// both to the exact emulation).  Flags / bounded waits / status / poison exactly as in lstm_group_kernels.hip.
+#include "fsn_common.h"
+
+namespace {
+
+typedef unsigned q_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int QH = 384;            // hidden units (both layers)
+constexpr int QG = 4 * QH;         // gate columns
+constexpr int QM = 8;              // members per cluster and layer
+constexpr int QU = QH / QM;        // units per member (48)
+constexpr int QROWS = 64;          // rows per cluster
+constexpr int QFS = 32;            // words between flag groups (one 128-byte line each)
+constexpr int QD = 4;              // forward: K blocks (32 k each) of weight fragments in flight per wave
+constexpr int QDB = 2;             // BPTT: K blocks in flight per wave (six fragments each)
+constexpr int QDX = 4;             // BPTT: depth of the layer-1 -> layer-0 ring of dgates1 W_ih1 partials
+constexpr int ACT_STRIDE = QH * 2 + 16;   // bytes per row of a staged [64][384] 16-bit tile (+16: conflict-free b128 reads)
+constexpr int X_STRIDE = 32 * 2 + 16;     // layer-0 input tile [64][32]
+constexpr int GSH_STRIDE = QU * 4 + 16;   // bytes per row of the gate exchange [4][64][48] fp32
+constexpr int DSH_STRIDE = 4 * QU * 2 + 16;  // BPTT: own gate gradients [64][192] 16-bit
+constexpr int ACT_BYTES = QROWS * ACT_STRIDE, GSH_BYTES = 4 * QROWS * GSH_STRIDE;
+constexpr int FWD_LDS = ACT_BYTES > GSH_BYTES ? ACT_BYTES : GSH_BYTES;
+constexpr int PSET = 24 * 4 * 256;  // floats of one member's partial dh^T: 24 unit tiles x 4 row tiles x [64 lanes][4]
+
+template <int AR>
+__device__ __forceinline__ fsn_u32x2 q_round4(const f32x4 v) {
+    return __builtin_bit_cast(fsn_u32x2, fsn_operand<AR>(v));
+}
+template <int AR>
+__device__ __forceinline__ f32x4 q_mma2(const q_u32x4 a, const q_u32x4 b, f32x4 c) {  // one K block (32 k) of one tile
+    c = fsn_mma_k16<AR>(fsn_wfrag_operand<AR>(fsn_u32x2{a[0], a[1]}), fsn_wfrag_operand<AR>(fsn_u32x2{b[0], b[1]}), c);
+    return fsn_mma_k16<AR>(fsn_wfrag_operand<AR>(fsn_u32x2{a[2], a[3]}), fsn_wfrag_operand<AR>(fsn_u32x2{b[2], b[3]}), c);
+}
+__device__ __forceinline__ q_u32x4 q_lds128(const unsigned char* p) { return *reinterpret_cast<const q_u32x4*>(p); }
+
+// One wave polls eight member flags until all have reached `epoch` (bounded by the device clock).
+__device__ __forceinline__ void q_poll(unsigned* flags8, unsigned epoch, unsigned* status, unsigned long long ticks) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long t0 = 0;
+    for (unsigned spins = 0;; ++spins) {
+        unsigned v = epoch;
+        if (lane < QM) v = __hip_atomic_load(flags8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all((int)(v >= epoch))) return;
+        if ((spins & 255u) == 255u && fsn_wait_give_up(status, spins, t0, ticks, 1u + epoch)) return;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void q_wait(unsigned* flags8, unsigned epoch, unsigned* status, unsigned long long ticks) {
+    if ((threadIdx.x >> 6) == 0) q_poll(flags8, epoch, status, ticks);
+    __syncthreads();  // one wave looked for all four
+}
+// the workgroup's write-through stores of this step are in flight: every wave drains, then ONE lane bumps the flag
+__device__ __forceinline__ void q_publish(unsigned* flag, unsigned epoch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x4 q_load_sc1(const __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16));  // aux 16 = sc1: never from this CU's L1
+}
+__device__ __forceinline__ f32x4 q_load(const __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void q_store_sc1(const __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(q_u32x4, v), r, voff, soff, 16);  // write-through
+}
+__device__ __forceinline__ void q_store(const __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(q_u32x4, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t q_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// ---- packing ------------------------------------------------------------------------------------------------------
+// forward: product W [4H][K] (nn.LSTM's layout, K = k_pad columns, zeros beyond k) -> [member 8][gate 4][K/32][unit
+// tile 3][lane 64][8]: lane (lr, lq) of fragment (m, g, kb, j) holds W[g H + 48 m + 16 j + lr][32 kb + 8 lq .. + 7] -
+// the A operand of two 16x16x16 matrix instructions whose B operand is row lr's activations at the same k.
+template <int AR>
+__global__ void q_pack_fwd_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int k, int k_pad) {
+    const int kbn = k_pad / 32;
+    const long n8 = (long)QG * k_pad / 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        long f = i >> 6;
+        const int j = (int)(f % 3);
+        f /= 3;
+        const int kb = (int)(f % kbn);
+        f /= kbn;
+        const int g = (int)(f & 3), m = (int)(f >> 2);
+        const int row = g * QH + QU * m + 16 * j + (lane & 15), k0 = 32 * kb + 8 * (lane >> 4);
+        f32x4 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo[e] = k0 + e < k ? w[(long)row * k + k0 + e] : 0.f;
+            hi[e] = k0 + 4 + e < k ? w[(long)row * k + k0 + 4 + e] : 0.f;
+        }
+        const fsn_u32x2 a = q_round4<AR>(lo), b = q_round4<AR>(hi);
+        reinterpret_cast<q_u32x4*>(out)[i] = q_u32x4{a[0], a[1], b[0], b[1]};
+    }
+}
+// BPTT: product W [4H][H] -> [member 8][wave 4][kb 6][nn 6][lane 64][8]: lane (lr, lq) of fragment (m, w, kb, nn) holds
+// W[gamma(m, 32 kb + 8 lq + e)][16 (6 w + nn) + lr], e = 0..7, with gamma(m, k) = (k / 48) H + 48 m + k % 48 the gate
+// column behind position k of member m's 192 own gate columns (K of its product), 16 (6 w + nn) + lr the output unit.
+template <int AR>
+__global__ void q_pack_bptt_kernel(const float* __restrict__ w, unsigned short* __restrict__ out) {
+    const long n8 = (long)QG * QH / 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        long f = i >> 6;
+        const int nn = (int)(f % 6);
+        f /= 6;
+        const int kb = (int)(f % 6);
+        f /= 6;
+        const int wv = (int)(f & 3), m = (int)(f >> 2);
+        const int unit = 16 * (6 * wv + nn) + (lane & 15), k0 = 32 * kb + 8 * (lane >> 4);
+        f32x4 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kk = k0 + e, col = (kk / QU) * QH + QU * m + kk % QU;
+            const float v = w[(long)col * QH + unit];
+            if (e < 4) lo[e] = v;
+            else hi[e - 4] = v;
+        }
+        const fsn_u32x2 a = q_round4<AR>(lo), b = q_round4<AR>(hi);
+        reinterpret_cast<q_u32x4*>(out)[i] = q_u32x4{a[0], a[1], b[0], b[1]};
+    }
+}
+
+// ---- forward with saves -------------------------------------------------------------------------------------------
+struct G16FwdArgs {
+    const float* x;        // layer-0 input [Tp][x_step][32] (zero-padded columns)
+    long x_step;
+    const unsigned short* w16;
+    unsigned o_ih0, o_hh0, o_ih1, o_hh1;  // byte offsets of the packed products
+    const float *bias0, *bias1;           // b_ih + b_hh [4H]
+    float *hseq0, *hseq1;                 // [Tp][Nrows][H]: outputs AND exchange buffers
+    float *gates0, *cseq0, *gates1, *cseq1;
+    unsigned* flags;                      // [clusters][2][QFS]
+    unsigned* status;
+    unsigned long long spin_ticks;
+    int Tp, Nrows;
+};
+
+// ABL: experiment knob of tools/probe_g16.hip (0 in the library; any bit set gives WRONG results): 1 no flag waits, 2 the
+// partners' tiles not loaded (constants staged), 4 no weight loads (constant fragments), 8 no saves, 16 no h stores
+template <int LAYER, int AR, int ABL>
+__device__ __forceinline__ void g16_fwd_body(const G16FwdArgs& a, int cluster, int member, unsigned char* act, unsigned char* xsm) {
+    float live = 0.f;  // keeps ablated values alive
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int Tp = a.Tp;
+    const size_t N = (size_t)a.Nrows;
+    unsigned* fl0 = a.flags + ((size_t)cluster * 2 + 0) * QFS;
+    unsigned* fl1 = a.flags + ((size_t)cluster * 2 + 1) * QFS;
+    const __amdgpu_buffer_rsrc_t wrsrc = q_rsrc(a.w16, 0x7fffffff);
+    // this wave's weight stream of a product: fragments (kb, j) at wbase + kb * 3072 + j * 1024 + lane * 16
+    auto wbase = [&](unsigned o, int kbn) { return o + (unsigned)((member * 4 + wave) * kbn) * 3072u; };
+    const unsigned w_rec = wbase(LAYER ? a.o_hh1 : a.o_hh0, 12), w_in = LAYER ? wbase(a.o_ih1, 12) : wbase(a.o_ih0, 1);
+    auto wload = [&](unsigned base, int kb, int j) {
+        if constexpr ((ABL & 4) != 0) return q_u32x4{0x3c003c00u + (unsigned)kb, 0x38003800u, 0x34003400u + (unsigned)j, 0x30003000u};
+        else return __builtin_bit_cast(q_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)lane * 16u,
+                                                                                      base + (unsigned)kb * 3072u + (unsigned)j * 1024u, 0));
+    };
+    // the cluster's [64][H] tile of step t of a hidden sequence / cell sequence, its [64][4H] tile of a gate buffer
+    auto tileh = [&](float* p, int t) { return q_rsrc(p + ((size_t)t * N + (size_t)cluster * QROWS) * QH, QROWS * QH * 4); };
+    auto tileg = [&](float* p, int t) { return q_rsrc(p + ((size_t)t * N + (size_t)cluster * QROWS) * QG, QROWS * QG * 4); };
+
+    // bias of this wave's gate for the member's three unit tiles: accumulator row 4 lq + i of tile j = unit 16 j + 4 lq + i
+    f32x4 bias[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        bias[j] = *reinterpret_cast<const f32x4*>((LAYER ? a.bias1 : a.bias0) + wave * QH + QU * member + 16 * j + 4 * lq);
+
+    // stage the cluster's [64][H] fp32 tile behind `src` (written through by the partners: sc1 loads) into `act` as 16-bit
+    // rows: item q = tid + 256 i is (row q / 48, eight consecutive k)
+    auto stage = [&](const __amdgpu_buffer_rsrc_t src) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 v[12];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int q = tid + 256 * (half * 6 + i), row = q / 48, k8 = q % 48;
+                const unsigned go = (unsigned)((row * QH + k8 * 8) * 4);
+                if constexpr ((ABL & 2) != 0) {
+                    v[2 * i] = f32x4{0.01f * (float)row, 0.02f, -0.01f, 0.03f};
+                    v[2 * i + 1] = f32x4{0.02f, -0.03f, 0.01f * (float)k8, 0.f};
+                } else {
+                    v[2 * i] = q_load_sc1(src, go, 0);
+                    v[2 * i + 1] = q_load_sc1(src, go, 16);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int q = tid + 256 * (half * 6 + i), row = q / 48, k8 = q % 48;
+                const fsn_u32x2 lo = q_round4<AR>(v[2 * i]), hi = q_round4<AR>(v[2 * i + 1]);
+                *reinterpret_cast<q_u32x4*>(act + row * ACT_STRIDE + k8 * 16) = q_u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+        }
+    };
+    // acc += W(gate `wave` of the member's 48 units x K) act^T: twelve K blocks, the wave's own weight stream through a
+    // ring of QD blocks whose first turn `ring` was requested by the caller (before the hand-off wait)
+    auto kloop12 = [&](f32x4 (&acc)[3][4], q_u32x4 (&ring)[QD][3], unsigned base) {
+#pragma unroll
+        for (int kb0 = 0; kb0 < 12; kb0 += QD) {
+#pragma unroll
+            for (int d = 0; d < QD; ++d) {
+                const int kb = kb0 + d;
+                q_u32x4 wf[3], af[4];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) wf[j] = ring[d][j];
+                if (kb + QD < 12) {
+                    __builtin_amdgcn_sched_barrier(0);  // the refill goes out before this block's matrix work
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) ring[d][j] = wload(base, kb + QD, j);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) af[r] = q_lds128(act + (16 * r + lr) * ACT_STRIDE + kb * 64 + lq * 16);
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[j][r] = q_mma2<AR>(wf[j], af[r], acc[j][r]);
+            }
+        }
+    };
+    auto ring_start = [&](q_u32x4 (&ring)[QD][3], unsigned base) {
+#pragma unroll
+        for (int d = 0; d < QD; ++d)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) ring[d][j] = wload(base, d, j);
+    };
+
+    // elementwise items of this thread: q = tid + 256 e -> (row q / 12, unit quad q % 12); cell state in registers
+    f32x4 c[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) c[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float* const hseq = LAYER ? a.hseq1 : a.hseq0;
+    float* const gates = LAYER ? a.gates1 : a.gates0;
+    float* const cseq = LAYER ? a.cseq1 : a.cseq0;
+    unsigned* const myflag = (LAYER ? fl1 : fl0) + member;
+
+    for (int t = 0; t < Tp; ++t) {
+        f32x4 acc[3][4];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[j][r] = bias[j];
+        q_u32x4 ring[QD][3];
+        if (LAYER == 0) {
+            // x_t (64 rows x 32 columns, the caller's tensor: plain loads) -> xsm; its three weight fragments
+            q_u32x4 wx[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) wx[j] = wload(w_in, 0, j);
+            if (t > 0) ring_start(ring, w_rec);
+            {
+                const int row = tid >> 2, k8 = tid & 3;
+                const float* xp = a.x + ((size_t)t * a.x_step + (size_t)cluster * QROWS + row) * 32 + k8 * 8;
+                const fsn_u32x2 lo = q_round4<AR>(*reinterpret_cast<const f32x4*>(xp));
+                const fsn_u32x2 hi = q_round4<AR>(*reinterpret_cast<const f32x4*>(xp + 4));
+                *reinterpret_cast<q_u32x4*>(xsm + row * X_STRIDE + k8 * 16) = q_u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+            if (t > 0) {
+                if constexpr ((ABL & 1) != 0) __syncthreads();
+                else q_wait(fl0, (unsigned)t, a.status, a.spin_ticks);  // h0_{t-1} of all members
+                stage(tileh(a.hseq0, t - 1));
+            }
+            __syncthreads();
+            {
+                q_u32x4 af[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) af[r] = q_lds128(xsm + (16 * r + lr) * X_STRIDE + lq * 16);
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[j][r] = q_mma2<AR>(wx[j], af[r], acc[j][r]);
+            }
+            if (t > 0) kloop12(acc, ring, w_rec);
+        } else {
+            // x_t W_ih1^T first: it needs h0_t, which layer 0 published long ago; then h1_{t-1} W_hh1^T
+            ring_start(ring, w_in);
+            if constexpr ((ABL & 1) != 0) __syncthreads();
+            else q_wait(fl0, (unsigned)t + 1, a.status, a.spin_ticks);
+            stage(tileh(a.hseq0, t));
+            __syncthreads();
+            kloop12(acc, ring, w_in);
+            if (t > 0) {
+                ring_start(ring, w_rec);
+                if constexpr ((ABL & 1) != 0) __syncthreads();
+                else q_wait(fl1, (unsigned)t, a.status, a.spin_ticks);  // h1_{t-1} of all members; also: everyone has left `act`
+                stage(tileh(a.hseq1, t - 1));
+                __syncthreads();
+                kloop12(acc, ring, w_rec);
+            }
+        }
+        __syncthreads();  // every wave has left `act`: the gate exchange takes its place
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<f32x4*>(act + (wave * QROWS + 16 * r + lr) * GSH_STRIDE + (16 * j + 4 * lq) * 4) = acc[j][r];
+        __syncthreads();
+        f32x4 sg[3][4];  // activated gates of this thread's items, kept for the saves
+        const __amdgpu_buffer_rsrc_t rh = tileh(hseq, t);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int q = tid + 256 * e, row = q / 12, quad = q % 12;
+            f32x4 pre[4], hv;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[g] = *reinterpret_cast<const f32x4*>(act + (g * QROWS + row) * GSH_STRIDE + quad * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float ig = sigmoid_fast(pre[0][i]), fg = sigmoid_fast(pre[1][i]);
+                const float gg = tanh_fast(pre[2][i]), og = sigmoid_fast(pre[3][i]);
+                const float cn = fg * c[e][i] + ig * gg;
+                c[e][i] = cn;
+                hv[i] = og * tanh_fast(cn);
+                sg[e][0][i] = ig, sg[e][1][i] = fg, sg[e][2][i] = gg, sg[e][3][i] = og;
+            }
+            if constexpr ((ABL & 16) != 0) live += hv[0] + hv[1] + hv[2] + hv[3];
+            else q_store_sc1(rh, (unsigned)((row * QH + QU * member + quad * 4) * 4), 0, hv);
+        }
+        q_publish(myflag, (unsigned)t + 1);  // its barrier also closes the reads of the gate exchange
+        // the saves of the step, AFTER the hand-off (only h belongs to it)
+        const __amdgpu_buffer_rsrc_t rg = tileg(gates, t), rc = tileh(cseq, t);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int q = tid + 256 * e, row = q / 12, quad = q % 12;
+            const unsigned go = (unsigned)((row * QG + QU * member + quad * 4) * 4);
+            if constexpr ((ABL & 8) != 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) live += sg[e][g][0] + sg[e][g][3];
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) q_store(rg, go, (unsigned)(g * QH * 4), sg[e][g]);
+                q_store(rc, (unsigned)((row * QH + QU * member + quad * 4) * 4), 0, c[e]);
+            }
+        }
+    }
+    if (ABL != 0 && live == 123.456f) a.status[1] = 1u;  // never true: the ablated values stay computed
+}
+
+template <int AR, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void lstm2_g16_fwd_kernel(const G16FwdArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char act[FWD_LDS];
+    __shared__ __attribute__((aligned(16))) unsigned char xsm[QROWS * X_STRIDE];
+    // first half of the grid: layer 0, second half: layer 1 - blocks are handed out in order, one per CU before any CU
+    // gets its second, so a CU ends up with one workgroup of each layer; the members of a cluster on one XCD (block b
+    // runs on XCD b % 8, observed) when the cluster count allows it.  Speed only.
+    const int half = gridDim.x >> 1;
+    const int layer = (int)blockIdx.x >= half ? 1 : 0;
+    const int bid = (int)blockIdx.x - layer * half;
+    const int nclusters = half / QM;
+    int cluster, member;
+    if (nclusters % 8 == 0) {
+        const int xcd = bid & 7, j = bid >> 3;
+        cluster = xcd * (nclusters / 8) + j / QM;
+        member = j % QM;
+    } else {
+        cluster = bid / QM;
+        member = bid % QM;
+    }
+    if (layer == 0) g16_fwd_body<0, AR, ABL>(a, cluster, member, act, xsm);
+    else g16_fwd_body<1, AR, ABL>(a, cluster, member, act, xsm);
+}
+
+// ---- back-propagation through time --------------------------------------------------------------------------------
+struct G16BwdArgs {
+    const float* dh1;      // [Tp][N][H]  d loss / d hseq1
+    const unsigned short* w16;
+    unsigned o_hh1, o_ih1, o_hh0;  // byte offsets of the packed products (q_pack_bptt_kernel)
+    const float *gates0, *cseq0, *gates1, *cseq1;
+    float *dg0, *dg1;      // [Tp][N][4H] gate gradients (outputs)
+    float *p_hh1, *p_hh0;  // [clusters][2][8 members][PSET]: partial dh^T of the step before, by producer
+    float* p_ih1;          // [clusters][QDX][8][PSET]: partial dH0^T = dgates1 W_ih1, layer 1 -> layer 0
+    unsigned* flags;       // [clusters][3][QFS]: hh1 sets published (layer 1), ih1 sets (layer 1), steps done (layer 0)
+    unsigned* status;
+    unsigned long long spin_ticks;
+    int Tp, Nrows;
+};
+
+// ABL (tools/probe_g16.hip; 0 in the library, any bit set gives WRONG results): 1 no flag waits, 2 saved activations not
+// loaded, 4 no weight loads, 8 no gate-gradient stores, 16 no partial stores, 32 partials not loaded
+template <int LAYER, int AR, int ABL>
+__device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, int member, unsigned char* dsh) {
+    float live = 0.f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int Tp = a.Tp;
+    const size_t N = (size_t)a.Nrows;
+    unsigned* fl1 = a.flags + ((size_t)cluster * 3 + 0) * QFS;
+    unsigned* flx = a.flags + ((size_t)cluster * 3 + 1) * QFS;
+    unsigned* fl0 = a.flags + ((size_t)cluster * 3 + 2) * QFS;
+    const __amdgpu_buffer_rsrc_t wrsrc = q_rsrc(a.w16, 0x7fffffff);
+    // this wave's weight stream of a product: fragments (kb, nn) at base + kb * 6144 + nn * 1024 + lane * 16
+    auto wbase = [&](unsigned o) { return o + (unsigned)((member * 4 + wave) * 6) * 6144u; };
+    auto wload = [&](unsigned base, int kb, int nn) {
+        if constexpr ((ABL & 4) != 0) return q_u32x4{0x3c003c00u + (unsigned)kb, 0x38003800u, 0x34003400u + (unsigned)nn, 0x30003000u};
+        else return __builtin_bit_cast(q_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)lane * 16u,
+                                                                                      base + (unsigned)kb * 6144u + (unsigned)nn * 1024u, 0));
+    };
+    auto wait = [&](unsigned* f8, unsigned epoch) {
+        if constexpr ((ABL & 1) != 0) __syncthreads();
+        else q_wait(f8, epoch, a.status, a.spin_ticks);
+    };
+    auto sload = [&](const __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        if constexpr ((ABL & 2) != 0) return f32x4{0.4f, 0.3f, 0.2f + 1e-6f * (float)soff, 0.1f};
+        else return q_load(r, voff, soff);
+    };
+    auto tileh = [&](const float* p, int t) { return q_rsrc(p + ((size_t)t * N + (size_t)cluster * QROWS) * QH, QROWS * QH * 4); };
+    auto tileg = [&](const float* p, int t) { return q_rsrc(p + ((size_t)t * N + (size_t)cluster * QROWS) * QG, QROWS * QG * 4); };
+    // elementwise mapping = accumulator layout of the transposed products: wave = row tile, lane (lr, lq) = row 16 w +
+    // lr, for unit tile j = 0..2 of this member the four units 48 m + 16 j + 4 lq .. + 3
+    const unsigned eo_h = (unsigned)((((wave * 16 + lr) * QH) + QU * member + 4 * lq) * 4);  // + j * 64
+    const unsigned eo_g = (unsigned)((((wave * 16 + lr) * QG) + QU * member + 4 * lq) * 4);  // + g * H * 4 + j * 64
+    // a set of partials: [producer 8][unit tile 24][row tile 4][lane][4]; this thread reads tiles (3 m + j, wave) of
+    // every producer and, as a producer, writes tiles (6 wave + nn, r)
+    const __amdgpu_buffer_rsrc_t r_hh = q_rsrc((LAYER ? a.p_hh1 : a.p_hh0) + (size_t)cluster * 2 * QM * PSET, 2u * QM * PSET * 4u);
+    const __amdgpu_buffer_rsrc_t r_ih = q_rsrc(a.p_ih1 + (size_t)cluster * QDX * QM * PSET, (unsigned)QDX * QM * PSET * 4u);
+    const unsigned rd_off = (unsigned)(((3 * member * 4 + wave) * 256 + lane * 4) * 4);   // + (producer * PSET + j * 1024) * 4
+    const unsigned wr_off = (unsigned)((member * PSET + (6 * wave * 4) * 256 + lane * 4) * 4);  // + (nn * 4 + r) * 1024
+
+    // partial^T[unit][row] = W^T(24 unit tiles x own 192 gate columns) dgates^T: this wave's six unit tiles x four row tiles,
+    // K = 192 = six blocks; the first QDB blocks of weight fragments were requested by the caller
+    auto product = [&](f32x4 (&acc)[6][4], q_u32x4 (&ring)[QDB][6], unsigned base) {
+#pragma unroll
+        for (int kb0 = 0; kb0 < 6; kb0 += QDB) {
+#pragma unroll
+            for (int d = 0; d < QDB; ++d) {
+                const int kb = kb0 + d;
+                q_u32x4 wf[6], af[4];
+#pragma unroll
+                for (int nn = 0; nn < 6; ++nn) wf[nn] = ring[d][nn];
+                if (kb + QDB < 6) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nn = 0; nn < 6; ++nn) ring[d][nn] = wload(base, kb + QDB, nn);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) af[r] = q_lds128(dsh + (16 * r + lr) * DSH_STRIDE + kb * 64 + lq * 16);
+#pragma unroll
+                for (int nn = 0; nn < 6; ++nn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[nn][r] = q_mma2<AR>(wf[nn], af[r], acc[nn][r]);
+            }
+        }
+    };
+    auto ring_start = [&](q_u32x4 (&ring)[QDB][6], unsigned base) {
+#pragma unroll
+        for (int d = 0; d < QDB; ++d)
+#pragma unroll
+            for (int nn = 0; nn < 6; ++nn) ring[d][nn] = wload(base, d, nn);
+    };
+    auto zero = [&](f32x4 (&acc)[6][4]) {
+#pragma unroll
+        for (int nn = 0; nn < 6; ++nn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[nn][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto store_set = [&](const __amdgpu_buffer_rsrc_t rs, unsigned slot_bytes, const f32x4 (&acc)[6][4]) {
+#pragma unroll
+        for (int nn = 0; nn < 6; ++nn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr ((ABL & 16) != 0) live += acc[nn][r][0] + acc[nn][r][2];
+                else q_store_sc1(rs, wr_off, slot_bytes + (unsigned)((nn * 4 + r) * 1024), acc[nn][r]);
+            }
+    };
+    // dh[j] += the eight producers' partials of this thread's tiles, producer 0 first (a fixed order: bit-reproducible)
+    auto reduce_set = [&](const __amdgpu_buffer_rsrc_t rs, unsigned slot_bytes, f32x4 (&dh)[3]) {
+        f32x4 v[QM][3];
+#pragma unroll
+        for (int p = 0; p < QM; ++p)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if constexpr ((ABL & 32) != 0) v[p][j] = f32x4{1e-3f * (float)p, 2e-3f, -1e-3f * (float)j, 1e-7f * (float)slot_bytes};
+                else v[p][j] = q_load_sc1(rs, rd_off, slot_bytes + (unsigned)((p * PSET + j * 1024) * 4));
+            }
+#pragma unroll
+        for (int p = 0; p < QM; ++p)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) dh[j] += v[p][j];
+    };
+
+    const float* const gates = LAYER ? a.gates1 : a.gates0;
+    const float* const cseq = LAYER ? a.cseq1 : a.cseq0;
+    float* const dgout = LAYER ? a.dg1 : a.dg0;
+    const unsigned w_hh = wbase(LAYER ? a.o_hh1 : a.o_hh0), w_ih = wbase(a.o_ih1);
+    f32x4 dc[3], c_t[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        const __amdgpu_buffer_rsrc_t rc = tileh(cseq, Tp - 1);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c_t[j] = sload(rc, eo_h, (unsigned)(j * 64));
+    }
+
+    for (int t = Tp - 1; t >= 0; --t) {
+        const unsigned done = (unsigned)(Tp - 1 - t);  // steps every member has completed when step t + 1 is
+        q_u32x4 ring[QDB][6];
+        // saved activations of step t, requested before any hand-off wait: the gates, c_{t-1}, and (layer 1) dH1_t
+        f32x4 sg[3][4], c_p[3], dh[3];
+        {
+            const __amdgpu_buffer_rsrc_t rg = tileg(gates, t), rp = tileh(cseq, t > 0 ? t - 1 : 0), rd = tileh(LAYER ? a.dh1 : cseq, t);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sg[j][g] = sload(rg, eo_g, (unsigned)(g * QH * 4 + j * 64));
+                c_p[j] = t > 0 ? sload(rp, eo_h, (unsigned)(j * 64)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                dh[j] = LAYER ? sload(rd, eo_h, (unsigned)(j * 64)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (LAYER == 0) {
+            // dH0_t = dgates1_t W_ih1: layer 1's members published it as their ih1 set number done + 1
+            wait(flx, done + 1);
+            reduce_set(r_ih, (unsigned)((t % QDX) * QM * PSET * 4), dh);
+        }
+        if (t < Tp - 1) {
+            wait(LAYER ? fl1 : fl0, done);  // the partials of step t + 1 from all members
+            reduce_set(r_hh, (unsigned)(((t + 1) & 1) * QM * PSET * 4), dh);
+        }
+        // the first weight fragments of this step's product: requested now (the reductions' registers are free again),
+        // they arrive under the cell derivative
+        if (t > 0 || LAYER) ring_start(ring, (t > 0) ? w_hh : w_ih);
+        // cell derivative of this thread's 3 x 4 elements -> gate gradients of step t: to memory (the weight-gradient
+        // products read them afterwards) and, rounded to 16 bits, into this member's [64][192] operand tile
+        const __amdgpu_buffer_rsrc_t ro = tileg(dgout, t);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            f32x4 d_i, d_f, d_g, d_o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float ig = sg[j][0][i], fg = sg[j][1][i], gg = sg[j][2][i], og = sg[j][3][i];
+                const float tc = tanhf(c_t[j][i]);
+                const float dhv = dh[j][i];
+                const float dct = dc[j][i] + dhv * og * (1.f - tc * tc);
+                d_i[i] = dct * gg * ig * (1.f - ig);
+                d_f[i] = dct * c_p[j][i] * fg * (1.f - fg);
+                d_g[i] = dct * ig * (1.f - gg * gg);
+                d_o[i] = dhv * tc * og * (1.f - og);
+                dc[j][i] = dct * fg;
+            }
+            if constexpr ((ABL & 8) == 0) {
+                q_store(ro, eo_g, (unsigned)(j * 64), d_i);
+                q_store(ro, eo_g, (unsigned)(QH * 4 + j * 64), d_f);
+                q_store(ro, eo_g, (unsigned)(2 * QH * 4 + j * 64), d_g);
+                q_store(ro, eo_g, (unsigned)(3 * QH * 4 + j * 64), d_o);
+            }
+            unsigned char* dp = dsh + (wave * 16 + lr) * DSH_STRIDE + (16 * j + 4 * lq) * 2;
+            *reinterpret_cast<fsn_u32x2*>(dp) = q_round4<AR>(d_i);
+            *reinterpret_cast<fsn_u32x2*>(dp + QU * 2) = q_round4<AR>(d_f);
+            *reinterpret_cast<fsn_u32x2*>(dp + 2 * QU * 2) = q_round4<AR>(d_g);
+            *reinterpret_cast<fsn_u32x2*>(dp + 3 * QU * 2) = q_round4<AR>(d_o);
+            c_t[j] = c_p[j];  // c_{t-1} is the next iteration's c_t
+        }
+        __syncthreads();
+        f32x4 acc[6][4];
+        if (t > 0) {  // dgates_t W_hh: step t - 1's recurrent term
+            zero(acc);
+            product(acc, ring, w_hh);
+            if (LAYER) ring_start(ring, w_ih);
+            store_set(r_hh, (unsigned)((t & 1) * QM * PSET * 4), acc);
+        }
+        if (LAYER) {
+            if (t > 0) q_publish(fl1 + member, done + 1);
+            // dgates1_t W_ih1 = layer 0's dH_t.  Its ring slot still holds step t + QDX until every layer-0 member has
+            // consumed that step, i.e. completed done - QDX + 1 steps
+            zero(acc);
+            product(acc, ring, w_ih);
+            if (done >= (unsigned)QDX) wait(fl0, done - QDX + 1);
+            store_set(r_ih, (unsigned)((t % QDX) * QM * PSET * 4), acc);
+            q_publish(flx + member, done + 1);
+        } else {
+            q_publish(fl0 + member, done + 1);
+        }
+        // (the barrier inside the last publish also orders this step's reads of `dsh` before the next step's writes)
+    }
+    if (ABL != 0 && live == 123.456f) a.status[1] = 1u;  // never true: the ablated values stay computed
+}
+
+template <int AR, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void lstm2_g16_bwd_kernel(const G16BwdArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char dsh[QROWS * DSH_STRIDE];
+    // first half of the grid: layer 1 (the leading chain), second half: layer 0; cluster members on one XCD when the
+    // cluster count allows it (speed only)
+    const int half = gridDim.x >> 1;
+    const int second = (int)blockIdx.x >= half ? 1 : 0;
+    const int bid = (int)blockIdx.x - second * half;
+    const int nclusters = half / QM;
+    int cluster, member;
+    if (nclusters % 8 == 0) {
+        const int xcd = bid & 7, j = bid >> 3;
+        cluster = xcd * (nclusters / 8) + j / QM;
+        member = j % QM;
+    } else {
+        cluster = bid / QM;
+        member = bid % QM;
+    }
+    if (!second) g16_bwd_body<1, AR, ABL>(a, cluster, member, dsh);
+    else g16_bwd_body<0, AR, ABL>(a, cluster, member, dsh);
+}
+
+}  // namespace
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+// clusters these kernels can take for `tiles` 16-row tiles: whole 64-row clusters, one per eight CUs at most, two
+// workgroups per CU by the compiled kernels' occupancy (residency contract)
+int fsn_lstm2_g16_clusters(int tiles) {
+    int cus = 0, dev = 0;
+    if (!fsn_persistent_allowed() || hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return 0;
+    for (const void* k : {(const void*)lstm2_g16_fwd_kernel<FSN_ARITH_F16>, (const void*)lstm2_g16_fwd_kernel<FSN_ARITH_BF16>,
+                          (const void*)lstm2_g16_bwd_kernel<FSN_ARITH_F16>, (const void*)lstm2_g16_bwd_kernel<FSN_ARITH_BF16>})
+        if (!fsn_grid_fits(k, 256, 2u * (unsigned)cus)) return 0;
+    const int cap = cus / QM, c = tiles / 4;
+    return c < cap ? c : cap;
+}
+size_t fsn_lstm2_g16_flag_words(int clusters) { return (size_t)clusters * 3 * QFS + 16; }
+size_t fsn_lstm2_g16_status_word(int clusters) { return (size_t)clusters * 3 * QFS; }
+size_t fsn_lstm2_g16_partial_floats(int clusters) { return (size_t)clusters * (2 + 2 + QDX) * QM * PSET; }
+size_t fsn_lstm2_g16_fwd_weight_halves(int Ipad) { return (size_t)QG * Ipad + (size_t)3 * QG * QH; }
+size_t fsn_lstm2_g16_bwd_weight_halves() { return (size_t)3 * QG * QH; }
+
+template <int AR>
+static int g16_pack_fwd(const float* w, unsigned short* out, int k, int k_pad, hipStream_t s) {
+    const long n8 = (long)QG * k_pad / 8;
+    hipLaunchKernelGGL(q_pack_fwd_kernel<AR>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, w, out, k, k_pad);
+    return fsn_check_launch("q_pack_fwd_kernel");
+}
+template <int AR>
+static int g16_pack_bptt(const float* w, unsigned short* out, hipStream_t s) {
+    const long n8 = (long)QG * QH / 8;
+    hipLaunchKernelGGL(q_pack_bptt_kernel<AR>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, w, out);
+    return fsn_check_launch("q_pack_bptt_kernel");
+}
+
+// Rows [0, 64 clusters) of two stacked LSTM layers, forward with saves, 16-bit operands.  x [Tp][Nrows][32] (zero-padded
+// columns beyond I); w_* the UNPACKED nn.LSTM tensors; bias0 / bias1 = b_ih + b_hh [4H]; w16: scratch of
+// fsn_lstm2_g16_fwd_weight_halves(32) 16-bit words; flags: fsn_lstm2_g16_flag_words(clusters) words.
+int fsn_launch_lstm2_g16_train(const float* x, int I, int Nrows, const float* w_ih0, const float* w_hh0, const float* w_ih1,
+                               const float* w_hh1, const float* bias0, const float* bias1, float* hseq0, float* hseq1,
+                               float* save0, float* save1, unsigned* flags, void* w16, int Tp, int clusters, int H,
+                               hipStream_t s, int arith) {
+    if (H != QH || I < 1 || I > 32 || clusters < 1 || clusters > fsn_lstm2_g16_clusters(Nrows / 16) ||
+        (arith != FSN_ARITH_F16 && arith != FSN_ARITH_BF16)) {
+        fsn_set_error("lstm2_g16 (forward): H = 384, up to 32 input columns, 16-bit arithmetic, clusters * 64 <= rows, one cluster per eight CUs at most");
+        return FSN_ERR_ARG;
+    }
+    if (fsn_launch_zero_words(flags, fsn_lstm2_g16_flag_words(clusters), s) != FSN_OK) return FSN_ERR_LAUNCH;
+    unsigned short* p = static_cast<unsigned short*>(w16);
+    unsigned short *p_ih0 = p, *p_hh0 = p_ih0 + (size_t)QG * 32, *p_ih1 = p_hh0 + (size_t)QG * QH, *p_hh1 = p_ih1 + (size_t)QG * QH;
+    int rc;
+    if (arith == FSN_ARITH_F16) {
+        if ((rc = g16_pack_fwd<FSN_ARITH_F16>(w_ih0, p_ih0, I, 32, s)) || (rc = g16_pack_fwd<FSN_ARITH_F16>(w_hh0, p_hh0, QH, QH, s)) ||
+            (rc = g16_pack_fwd<FSN_ARITH_F16>(w_ih1, p_ih1, QH, QH, s)) || (rc = g16_pack_fwd<FSN_ARITH_F16>(w_hh1, p_hh1, QH, QH, s)))
+            return rc;
+    } else {
+        if ((rc = g16_pack_fwd<FSN_ARITH_BF16>(w_ih0, p_ih0, I, 32, s)) || (rc = g16_pack_fwd<FSN_ARITH_BF16>(w_hh0, p_hh0, QH, QH, s)) ||
+            (rc = g16_pack_fwd<FSN_ARITH_BF16>(w_ih1, p_ih1, QH, QH, s)) || (rc = g16_pack_fwd<FSN_ARITH_BF16>(w_hh1, p_hh1, QH, QH, s)))
+            return rc;
+    }
+    G16FwdArgs a{};
+    a.x = x;
+    a.x_step = Nrows;
+    a.w16 = p;
+    a.o_ih0 = 0;
+    a.o_hh0 = (unsigned)((p_hh0 - p) * 2);
+    a.o_ih1 = (unsigned)((p_ih1 - p) * 2);
+    a.o_hh1 = (unsigned)((p_hh1 - p) * 2);
+    a.bias0 = bias0;
+    a.bias1 = bias1;
+    a.hseq0 = hseq0;
+    a.hseq1 = hseq1;
+    a.gates0 = save0;
+    a.cseq0 = save0 + (size_t)Tp * Nrows * QG;
+    a.gates1 = save1;
+    a.cseq1 = save1 + (size_t)Tp * Nrows * QG;
+    a.flags = flags;
+    a.status = flags + fsn_lstm2_g16_status_word(clusters);
+    a.spin_ticks = fsn_spin_ticks();
+    a.Tp = Tp;
+    a.Nrows = Nrows;
+    const dim3 grid((unsigned)clusters * QM * 2), block(256);
+    if (arith == FSN_ARITH_F16) FSN_PERSIST_LAUNCH(lstm2_g16_fwd_kernel<FSN_ARITH_F16>, grid, block, s, a);
+    else FSN_PERSIST_LAUNCH(lstm2_g16_fwd_kernel<FSN_ARITH_BF16>, grid, block, s, a);
+    return fsn_check_launch("lstm2_g16_fwd_kernel");
+}
+
+// Rows [0, 64 clusters) of the two layers' back-propagation through time, 16-bit operands.  w_* UNPACKED; save0 / save1
+// in fsn_lstm_layer_forward's layout; dg0 / dg1 [Tp][Nrows][4H] out; partials: fsn_lstm2_g16_partial_floats(clusters)
+// floats of scratch; w16: fsn_lstm2_g16_bwd_weight_halves() 16-bit words of scratch.
+int fsn_launch_lstm2_g16_bptt(const float* dh1, const float* w_hh1, const float* w_ih1, const float* w_hh0, const float* save0,
+                              const float* save1, float* dg0, float* dg1, float* partials, unsigned* flags, void* w16, int Tp,
+                              int Nrows, int clusters, int H, hipStream_t s, int arith) {
+    if (H != QH || clusters < 1 || clusters > fsn_lstm2_g16_clusters(Nrows / 16) ||
+        (arith != FSN_ARITH_F16 && arith != FSN_ARITH_BF16)) {
+        fsn_set_error("lstm2_g16 (bptt): H = 384, 16-bit arithmetic, clusters * 64 <= rows, one cluster per eight CUs at most");
+        return FSN_ERR_ARG;
+    }
+    if (fsn_launch_zero_words(flags, fsn_lstm2_g16_flag_words(clusters), s) != FSN_OK) return FSN_ERR_LAUNCH;
+    unsigned short* p = static_cast<unsigned short*>(w16);
+    unsigned short *p_hh1 = p, *p_ih1 = p + (size_t)QG * QH, *p_hh0 = p + (size_t)2 * QG * QH;
+    int rc;
+    if (arith == FSN_ARITH_F16) {
+        if ((rc = g16_pack_bptt<FSN_ARITH_F16>(w_hh1, p_hh1, s)) || (rc = g16_pack_bptt<FSN_ARITH_F16>(w_ih1, p_ih1, s)) ||
+            (rc = g16_pack_bptt<FSN_ARITH_F16>(w_hh0, p_hh0, s)))
+            return rc;
+    } else {
+        if ((rc = g16_pack_bptt<FSN_ARITH_BF16>(w_hh1, p_hh1, s)) || (rc = g16_pack_bptt<FSN_ARITH_BF16>(w_ih1, p_ih1, s)) ||
+            (rc = g16_pack_bptt<FSN_ARITH_BF16>(w_hh0, p_hh0, s)))
+            return rc;
+    }
+    G16BwdArgs a{};
+    a.dh1 = dh1;
+    a.w16 = p;
+    a.o_hh1 = 0;
+    a.o_ih1 = (unsigned)((size_t)QG * QH * 2);
+    a.o_hh0 = (unsigned)((size_t)2 * QG * QH * 2);
+    a.gates0 = save0;
+    a.cseq0 = save0 + (size_t)Tp * Nrows * QG;
+    a.gates1 = save1;
+    a.cseq1 = save1 + (size_t)Tp * Nrows * QG;
+    a.dg0 = dg0;
+    a.dg1 = dg1;
+    a.p_hh1 = partials;
+    a.p_hh0 = partials + (size_t)clusters * 2 * QM * PSET;
+    a.p_ih1 = partials + (size_t)clusters * 4 * QM * PSET;
+    a.flags = flags;
+    a.status = flags + fsn_lstm2_g16_status_word(clusters);
+    a.spin_ticks = fsn_spin_ticks();
+    a.Tp = Tp;
+    a.Nrows = Nrows;
+    const dim3 grid((unsigned)clusters * QM * 2), block(256);
+    if (arith == FSN_ARITH_F16) FSN_PERSIST_LAUNCH(lstm2_g16_bwd_kernel<FSN_ARITH_F16>, grid, block, s, a);
+    else FSN_PERSIST_LAUNCH(lstm2_g16_bwd_kernel<FSN_ARITH_BF16>, grid, block, s, a);
+    return fsn_check_launch("lstm2_g16_bwd_kernel");
+}

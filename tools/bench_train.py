@@ -1,5 +1,5 @@
 """Time one training step (BASELINE config 3 per-rank shape: 16 x 3.072 s) on one MI355X.
-python tools/bench_train.py [batch] [f32|f16|bf16]   (f16 / bf16: autocast arithmetic + GradScaler)"""
+python tools/bench_train.py [batch] [f32|f16|bf16] [g16=0]   (f16 / bf16: autocast arithmetic + GradScaler)"""
 import os
 import sys
 import time
@@ -20,6 +20,8 @@ model = fullsubnet_amd.Model(num_freqs=257, look_ahead=2, sequence_model="LSTM",
 model.load_state_dict({k: torch.from_numpy(v) for k, v in make_params(seed=3).items()})
 model = model.cuda().train()
 model.train_arithmetic = ARITH
+if "g16=0" in sys.argv:  # A/B: the fp32-era group kernels under the 16-bit arithmetic (lstm_group16_kernels.hip off)
+    fullsubnet_amd._lib.lib().fsn_debug_g16_kernels(0)
 scaler = torch.amp.GradScaler("cuda", enabled=ARITH != "f32")
 opt = fullsubnet_amd.ClipAdam(model.parameters(), lr=1e-3)
 noisy = torch.from_numpy(make_noisy(B, L, seed=1)).cuda()
