@@ -42,15 +42,13 @@ constexpr int QU = QH / QM;        // units per member (48)
 constexpr int QROWS = 64;          // rows per cluster
 constexpr int QFS = 32;            // words between flag groups (one 128-byte line each)
 constexpr int QD = 4;              // forward: K blocks (32 k each) of weight fragments in flight per wave
-constexpr int QDB = 2;             // BPTT: K blocks in flight per wave (six fragments each)
-constexpr int QDX = 4;             // BPTT: depth of the layer-1 -> layer-0 ring of dgates1 W_ih1 partials
+constexpr int QDX = 4;             // BPTT: slots of the exchanged gate-gradient tiles (layer 1 may run QDX - 1 steps ahead of layer 0)
 constexpr int ACT_STRIDE = QH * 2 + 16;   // bytes per row of a staged [64][384] 16-bit tile (+16: conflict-free b128 reads)
 constexpr int X_STRIDE = 32 * 2 + 16;     // layer-0 input tile [64][32]
 constexpr int GSH_STRIDE = QU * 4 + 16;   // bytes per row of the gate exchange [4][64][48] fp32
 constexpr int DSH_STRIDE = 4 * QU * 2 + 16;  // BPTT: own gate gradients [64][192] 16-bit
 constexpr int ACT_BYTES = QROWS * ACT_STRIDE, GSH_BYTES = 4 * QROWS * GSH_STRIDE;
 constexpr int FWD_LDS = ACT_BYTES > GSH_BYTES ? ACT_BYTES : GSH_BYTES;
-constexpr int PSET = 24 * 4 * 256;  // floats of one member's partial dh^T: 24 unit tiles x 4 row tiles x [64 lanes][4]
 
 template <int AR>
 __device__ __forceinline__ fsn_u32x2 q_round4(const f32x4 v) {
@@ -97,6 +95,23 @@ __device__ __forceinline__ void q_store_sc1(const __amdgpu_buffer_rsrc_t r, unsi
 __device__ __forceinline__ void q_store(const __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(q_u32x4, v), r, voff, soff, 0);
 }
+// One 16-byte-per-lane LDS-DMA fragment (1 KB per wave, no registers): lane l's 16 bytes at `g` land at LDS byte address
+// lds_base + 16 l.  As asm: the compiler neither serialises later LDS reads behind it nor counts it in its own vmcnt
+// bookkeeping (an extra OLDER request in the queue can only make its counted waits longer, never too short); the reader
+// states its own wait (s_waitcnt vmcnt(0)) before it touches the landing zone.
+__device__ __forceinline__ void q_lds_dma(const float* g, unsigned lds_base) {
+    unsigned saved;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, off\n\t"
+        "s_nop 0\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(saved)
+        : "s"(lds_base), "v"(g)
+        : "memory");
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t q_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
@@ -128,25 +143,26 @@ __global__ void q_pack_fwd_kernel(const float* __restrict__ w, unsigned short* _
         reinterpret_cast<q_u32x4*>(out)[i] = q_u32x4{a[0], a[1], b[0], b[1]};
     }
 }
-// BPTT: product W [4H][H] -> [member 8][wave 4][kb 6][nn 6][lane 64][8]: lane (lr, lq) of fragment (m, w, kb, nn) holds
-// W[gamma(m, 32 kb + 8 lq + e)][16 (6 w + nn) + lr], e = 0..7, with gamma(m, k) = (k / 48) H + 48 m + k % 48 the gate
-// column behind position k of member m's 192 own gate columns (K of its product), 16 (6 w + nn) + lr the output unit.
+// BPTT: product W [4H][H] -> [member 8][wave 4][kbl 12][j 3][lane 64][8]: lane (lr, lq) of fragment (m, w, kbl, j) holds
+// W[gamma(k')][48 m + 16 j + lr] for k' = 32 (12 w + kbl) + 8 lq + e, e = 0..7, where k' = 192 m' + 48 gate + unit is the K
+// position of the exchanged gate gradients (member m' owns a contiguous run) and gamma(k') = gate H + 48 m' + unit the
+// gate column behind it; 48 m + 16 j + lr is the output unit (a hidden unit of the step before / of the layer below).
 template <int AR>
 __global__ void q_pack_bptt_kernel(const float* __restrict__ w, unsigned short* __restrict__ out) {
     const long n8 = (long)QG * QH / 8;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(i & 63);
         long f = i >> 6;
-        const int nn = (int)(f % 6);
-        f /= 6;
-        const int kb = (int)(f % 6);
-        f /= 6;
+        const int j = (int)(f % 3);
+        f /= 3;
+        const int kbl = (int)(f % 12);
+        f /= 12;
         const int wv = (int)(f & 3), m = (int)(f >> 2);
-        const int unit = 16 * (6 * wv + nn) + (lane & 15), k0 = 32 * kb + 8 * (lane >> 4);
+        const int unit = QU * m + 16 * j + (lane & 15), k0 = 32 * (12 * wv + kbl) + 8 * (lane >> 4);
         f32x4 lo, hi;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int kk = k0 + e, col = (kk / QU) * QH + QU * m + kk % QU;
+            const int kk = k0 + e, mm = kk / (4 * QU), kl = kk % (4 * QU), col = (kl / QU) * QH + QU * mm + kl % QU;
             const float v = w[(long)col * QH + unit];
             if (e < 4) lo[e] = v;
             else hi[e - 4] = v;
@@ -394,39 +410,53 @@ __global__ __launch_bounds__(256, 2) void lstm2_g16_fwd_kernel(const G16FwdArgs 
 }
 
 // ---- back-propagation through time --------------------------------------------------------------------------------
+// Per step t = T-1 .. 0 (formulas: lstm_train_kernels.hip):
+//   layer 1: dh1_t = dH1_t + dgates1_{t+1} W_hh1;   layer 0: dh0_t = dgates1_t W_ih1 + dgates0_{t+1} W_hh0
+// Member m owns the 48 units [48 m, 48 m + 48) of dh for the cluster's 64 rows, transposed: D^T[unit][row] = sum over ALL
+// 1536 gate columns.  The gate gradients travel between members as a 16-BIT copy in matrix-operand FRAGMENT order -
+// X[cluster][slot][K block 48][row tile 4][lane 64][8 values], K position k' = 192 m' + 48 gate + unit: member m' owns
+// blocks 6 m' .. 6 m' + 5 and writes them as six fully coalesced 16-byte write-through stores per thread; rounding to 16
+// bits at the producer or at the consumer's matrix input is the same number - so a consumer wave's operand load is ONE
+// contiguous 1 KB line group, straight into registers: no LDS staging, no conversion, and the eight members of a cluster
+// (one XCD when the grid allows it) share each tile through that XCD's L2 (196 KB per cluster, layer and step through the
+// fabric, where per-member partial sums cost 1.5 MB - measured: profiles/r04_g16_probe_v1.txt).  The four waves split K
+// (twelve blocks each, own weight stream, own operand stream) and meet once per step in a fixed-order LDS reduction.
+// Layer 0 forms dgates1_t W_ih1 itself, from layer 1's tile (published well ahead: off its recurrent chain).
+constexpr int XSLOT = 48 * 4 * 1024;   // bytes of one [64 rows][1536] 16-bit tile in fragment order
+constexpr int QAD = 4;                  // operand blocks in flight per wave (4 fragments each)
+constexpr int QWD = 4;                  // weight blocks in flight per wave (3 fragments each)
+
 struct G16BwdArgs {
     const float* dh1;      // [Tp][N][H]  d loss / d hseq1
     const unsigned short* w16;
     unsigned o_hh1, o_ih1, o_hh0;  // byte offsets of the packed products (q_pack_bptt_kernel)
     const float *gates0, *cseq0, *gates1, *cseq1;
     float *dg0, *dg1;      // [Tp][N][4H] gate gradients (outputs)
-    float *p_hh1, *p_hh0;  // [clusters][2][8 members][PSET]: partial dh^T of the step before, by producer
-    float* p_ih1;          // [clusters][QDX][8][PSET]: partial dH0^T = dgates1 W_ih1, layer 1 -> layer 0
-    unsigned* flags;       // [clusters][3][QFS]: hh1 sets published (layer 1), ih1 sets (layer 1), steps done (layer 0)
+    unsigned short *x1, *x0;  // [clusters][QDX][XSLOT bytes]: 16-bit gate gradients of the last steps, fragment order
+    unsigned* flags;       // [clusters][2][QFS]: steps published by (layer 1 | layer 0, member)
     unsigned* status;
     unsigned long long spin_ticks;
     int Tp, Nrows;
 };
 
 // ABL (tools/probe_g16.hip; 0 in the library, any bit set gives WRONG results): 1 no flag waits, 2 saved activations not
-// loaded, 4 no weight loads, 8 no gate-gradient stores, 16 no partial stores, 32 partials not loaded
+// loaded, 4 no weight loads, 8 no gate-gradient stores, 16 no exchange stores, 32 exchanged operand not loaded
 template <int LAYER, int AR, int ABL>
-__device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, int member, unsigned char* dsh) {
+__device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, int member, unsigned char* red, unsigned char* dsh) {
     float live = 0.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const int Tp = a.Tp;
     const size_t N = (size_t)a.Nrows;
-    unsigned* fl1 = a.flags + ((size_t)cluster * 3 + 0) * QFS;
-    unsigned* flx = a.flags + ((size_t)cluster * 3 + 1) * QFS;
-    unsigned* fl0 = a.flags + ((size_t)cluster * 3 + 2) * QFS;
+    unsigned* fl1 = a.flags + ((size_t)cluster * 2 + 0) * QFS;
+    unsigned* fl0 = a.flags + ((size_t)cluster * 2 + 1) * QFS;
     const __amdgpu_buffer_rsrc_t wrsrc = q_rsrc(a.w16, 0x7fffffff);
-    // this wave's weight stream of a product: fragments (kb, nn) at base + kb * 6144 + nn * 1024 + lane * 16
-    auto wbase = [&](unsigned o) { return o + (unsigned)((member * 4 + wave) * 6) * 6144u; };
-    auto wload = [&](unsigned base, int kb, int nn) {
-        if constexpr ((ABL & 4) != 0) return q_u32x4{0x3c003c00u + (unsigned)kb, 0x38003800u, 0x34003400u + (unsigned)nn, 0x30003000u};
+    // this wave's weight stream of a product: fragments (kbl, j) at base + kbl * 3072 + j * 1024 + lane * 16
+    auto wbase = [&](unsigned o) { return o + (unsigned)((member * 4 + wave) * 12) * 3072u; };
+    auto wload = [&](unsigned base, int kbl, int j) {
+        if constexpr ((ABL & 4) != 0) return q_u32x4{0x3c003c00u + (unsigned)kbl, 0x38003800u, 0x34003400u + (unsigned)j, 0x30003000u};
         else return __builtin_bit_cast(q_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)lane * 16u,
-                                                                                      base + (unsigned)kb * 6144u + (unsigned)nn * 1024u, 0));
+                                                                                      base + (unsigned)kbl * 3072u + (unsigned)j * 1024u, 0));
     };
     auto wait = [&](unsigned* f8, unsigned epoch) {
         if constexpr ((ABL & 1) != 0) __syncthreads();
@@ -438,83 +468,65 @@ __device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, i
     };
     auto tileh = [&](const float* p, int t) { return q_rsrc(p + ((size_t)t * N + (size_t)cluster * QROWS) * QH, QROWS * QH * 4); };
     auto tileg = [&](const float* p, int t) { return q_rsrc(p + ((size_t)t * N + (size_t)cluster * QROWS) * QG, QROWS * QG * 4); };
-    // elementwise mapping = accumulator layout of the transposed products: wave = row tile, lane (lr, lq) = row 16 w +
-    // lr, for unit tile j = 0..2 of this member the four units 48 m + 16 j + 4 lq .. + 3
+    const __amdgpu_buffer_rsrc_t rx1 = q_rsrc(reinterpret_cast<const unsigned char*>(a.x1) + (size_t)cluster * QDX * XSLOT, (unsigned)QDX * XSLOT);
+    const __amdgpu_buffer_rsrc_t rx0 = q_rsrc(reinterpret_cast<const unsigned char*>(a.x0) + (size_t)cluster * QDX * XSLOT, (unsigned)QDX * XSLOT);
+    const __amdgpu_buffer_rsrc_t rxo = LAYER ? rx1 : rx0;
+    // elementwise mapping = accumulator layout of the transposed product after the reduction: wave = row tile, lane (lr, lq)
+    // = row 16 w + lr, for unit tile j = 0..2 of this member the four units 48 m + 16 j + 4 lq .. + 3
     const unsigned eo_h = (unsigned)((((wave * 16 + lr) * QH) + QU * member + 4 * lq) * 4);  // + j * 64
     const unsigned eo_g = (unsigned)((((wave * 16 + lr) * QG) + QU * member + 4 * lq) * 4);  // + g * H * 4 + j * 64
-    // a set of partials: [producer 8][unit tile 24][row tile 4][lane][4]; this thread reads tiles (3 m + j, wave) of
-    // every producer and, as a producer, writes tiles (6 wave + nn, r)
-    const __amdgpu_buffer_rsrc_t r_hh = q_rsrc((LAYER ? a.p_hh1 : a.p_hh0) + (size_t)cluster * 2 * QM * PSET, 2u * QM * PSET * 4u);
-    const __amdgpu_buffer_rsrc_t r_ih = q_rsrc(a.p_ih1 + (size_t)cluster * QDX * QM * PSET, (unsigned)QDX * QM * PSET * 4u);
-    const unsigned rd_off = (unsigned)(((3 * member * 4 + wave) * 256 + lane * 4) * 4);   // + (producer * PSET + j * 1024) * 4
-    const unsigned wr_off = (unsigned)((member * PSET + (6 * wave * 4) * 256 + lane * 4) * 4);  // + (nn * 4 + r) * 1024
 
-    // partial^T[unit][row] = W^T(24 unit tiles x own 192 gate columns) dgates^T: this wave's six unit tiles x four row tiles,
-    // K = 192 = six blocks; the first QDB blocks of weight fragments were requested by the caller
-    auto product = [&](f32x4 (&acc)[6][4], q_u32x4 (&ring)[QDB][6], unsigned base) {
+    // acc += W^T(this member's 48 units x this wave's twelve K blocks) x (the tile behind `rx`, slot offset `xo`)^T.  The
+    // first QWD blocks of weight fragments were requested by the caller (before the hand-off wait); the operand ring
+    // starts here, after it.
+    auto kloop = [&](f32x4 (&acc)[3][4], q_u32x4 (&wring)[QWD][3], unsigned wb, const __amdgpu_buffer_rsrc_t rx, unsigned xo) {
+        auto xload = [&](int kbl, int r) {
+            if constexpr ((ABL & 32) != 0) return q_u32x4{0x2c002c00u + (unsigned)kbl, 0x28002800u, 0x24002400u + (unsigned)r, 0x20002000u};
+            else return __builtin_bit_cast(q_u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                        rx, (unsigned)lane * 16u, xo + (unsigned)(((wave * 12 + kbl) * 4 + r) * 1024), 16));
+        };
+        q_u32x4 aring[QAD][4];
 #pragma unroll
-        for (int kb0 = 0; kb0 < 6; kb0 += QDB) {
+        for (int d = 0; d < QAD; ++d)
 #pragma unroll
-            for (int d = 0; d < QDB; ++d) {
-                const int kb = kb0 + d;
-                q_u32x4 wf[6], af[4];
+            for (int r = 0; r < 4; ++r) aring[d][r] = xload(d, r);
 #pragma unroll
-                for (int nn = 0; nn < 6; ++nn) wf[nn] = ring[d][nn];
-                if (kb + QDB < 6) {
-                    __builtin_amdgcn_sched_barrier(0);
+        for (int kb0 = 0; kb0 < 12; kb0 += QAD) {
 #pragma unroll
-                    for (int nn = 0; nn < 6; ++nn) ring[d][nn] = wload(base, kb + QDB, nn);
+            for (int d = 0; d < QAD; ++d) {
+                const int kbl = kb0 + d;
+                q_u32x4 wf[3], af[4];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) wf[j] = wring[d][j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) af[r] = aring[d][r];
+                if (kbl + QAD < 12) {
+                    __builtin_amdgcn_sched_barrier(0);  // the refills go out before this block's matrix work
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) wring[d][j] = wload(wb, kbl + QWD, j);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) aring[d][r] = xload(kbl + QAD, r);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) af[r] = q_lds128(dsh + (16 * r + lr) * DSH_STRIDE + kb * 64 + lq * 16);
+                for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int nn = 0; nn < 6; ++nn)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[nn][r] = q_mma2<AR>(wf[nn], af[r], acc[nn][r]);
+                    for (int r = 0; r < 4; ++r) acc[j][r] = q_mma2<AR>(wf[j], af[r], acc[j][r]);
             }
         }
     };
-    auto ring_start = [&](q_u32x4 (&ring)[QDB][6], unsigned base) {
+    static_assert(QAD == QWD, "the two rings turn together");
+    auto wring_start = [&](q_u32x4 (&wring)[QWD][3], unsigned wb) {
 #pragma unroll
-        for (int d = 0; d < QDB; ++d)
+        for (int d = 0; d < QWD; ++d)
 #pragma unroll
-            for (int nn = 0; nn < 6; ++nn) ring[d][nn] = wload(base, d, nn);
-    };
-    auto zero = [&](f32x4 (&acc)[6][4]) {
-#pragma unroll
-        for (int nn = 0; nn < 6; ++nn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[nn][r] = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    auto store_set = [&](const __amdgpu_buffer_rsrc_t rs, unsigned slot_bytes, const f32x4 (&acc)[6][4]) {
-#pragma unroll
-        for (int nn = 0; nn < 6; ++nn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if constexpr ((ABL & 16) != 0) live += acc[nn][r][0] + acc[nn][r][2];
-                else q_store_sc1(rs, wr_off, slot_bytes + (unsigned)((nn * 4 + r) * 1024), acc[nn][r]);
-            }
-    };
-    // dh[j] += the eight producers' partials of this thread's tiles, producer 0 first (a fixed order: bit-reproducible)
-    auto reduce_set = [&](const __amdgpu_buffer_rsrc_t rs, unsigned slot_bytes, f32x4 (&dh)[3]) {
-        f32x4 v[QM][3];
-#pragma unroll
-        for (int p = 0; p < QM; ++p)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if constexpr ((ABL & 32) != 0) v[p][j] = f32x4{1e-3f * (float)p, 2e-3f, -1e-3f * (float)j, 1e-7f * (float)slot_bytes};
-                else v[p][j] = q_load_sc1(rs, rd_off, slot_bytes + (unsigned)((p * PSET + j * 1024) * 4));
-            }
-#pragma unroll
-        for (int p = 0; p < QM; ++p)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) dh[j] += v[p][j];
+            for (int j = 0; j < 3; ++j) wring[d][j] = wload(wb, d, j);
     };
 
     const float* const gates = LAYER ? a.gates1 : a.gates0;
     const float* const cseq = LAYER ? a.cseq1 : a.cseq0;
     float* const dgout = LAYER ? a.dg1 : a.dg0;
+    unsigned* const myfl = LAYER ? fl1 : fl0;
     const unsigned w_hh = wbase(LAYER ? a.o_hh1 : a.o_hh0), w_ih = wbase(a.o_ih1);
     f32x4 dc[3], c_t[3];
 #pragma unroll
@@ -527,33 +539,63 @@ __device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, i
 
     for (int t = Tp - 1; t >= 0; --t) {
         const unsigned done = (unsigned)(Tp - 1 - t);  // steps every member has completed when step t + 1 is
-        q_u32x4 ring[QDB][6];
-        // saved activations of step t, requested before any hand-off wait: the gates, c_{t-1}, and (layer 1) dH1_t
+        f32x4 acc[3][4];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[j][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // The saved activations of step t do not depend on any hand-off: requested FIRST.  The gates (12 fragments per
+        // lane) by LDS-DMA into this wave's own 12 KB of `red` - no registers while the K loops run; they are read back
+        // after the loops and before the wave's partial sums take their place - c_{t-1} and (layer 1) dH1_t into registers.
+        const unsigned red_w = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)red + (unsigned)wave * 12u * 1024u;  // LDS byte address of this wave's region
         f32x4 sg[3][4], c_p[3], dh[3];
         {
-            const __amdgpu_buffer_rsrc_t rg = tileg(gates, t), rp = tileh(cseq, t > 0 ? t - 1 : 0), rd = tileh(LAYER ? a.dh1 : cseq, t);
+            const float* gp = gates + ((size_t)t * N + (size_t)cluster * QROWS + wave * 16 + lr) * QG + QU * member + 4 * lq;
+            if constexpr ((ABL & 2) == 0) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) q_lds_dma(gp + g * QH + 16 * j, red_w + (unsigned)((j * 4 + g) * 1024));
+            }
+            const __amdgpu_buffer_rsrc_t rp = tileh(cseq, t > 0 ? t - 1 : 0), rd = tileh(LAYER ? a.dh1 : cseq, t);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) sg[j][g] = sload(rg, eo_g, (unsigned)(g * QH * 4 + j * 64));
                 c_p[j] = t > 0 ? sload(rp, eo_h, (unsigned)(j * 64)) : f32x4{0.f, 0.f, 0.f, 0.f};
                 dh[j] = LAYER ? sload(rd, eo_h, (unsigned)(j * 64)) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        if (LAYER == 0) {
-            // dH0_t = dgates1_t W_ih1: layer 1's members published it as their ih1 set number done + 1
-            wait(flx, done + 1);
-            reduce_set(r_ih, (unsigned)((t % QDX) * QM * PSET * 4), dh);
+        q_u32x4 wring[QWD][3];
+        if (LAYER == 0) {  // dgates1_t W_ih1: layer 1 published step t as its flag value done + 1
+            wring_start(wring, w_ih);
+            wait(fl1, done + 1);
+            kloop(acc, wring, w_ih, rx1, (unsigned)((t % QDX) * XSLOT));
         }
-        if (t < Tp - 1) {
-            wait(LAYER ? fl1 : fl0, done);  // the partials of step t + 1 from all members
-            reduce_set(r_hh, (unsigned)(((t + 1) & 1) * QM * PSET * 4), dh);
+        if (t < Tp - 1) {  // dgates_{t+1} W_hh of the own layer
+            wring_start(wring, w_hh);
+            wait(myfl, done);
+            kloop(acc, wring, w_hh, rxo, (unsigned)(((t + 1) % QDX) * XSLOT));
         }
-        // the first weight fragments of this step's product: requested now (the reductions' registers are free again),
-        // they arrive under the cell derivative
-        if (t > 0 || LAYER) ring_start(ring, (t > 0) ? w_hh : w_ih);
-        // cell derivative of this thread's 3 x 4 elements -> gate gradients of step t: to memory (the weight-gradient
-        // products read them afterwards) and, rounded to 16 bits, into this member's [64][192] operand tile
+        // the gates have landed long ago (the DMA is older than every load the K loops consumed); say so, read them back
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if constexpr ((ABL & 2) != 0) sg[j][g] = f32x4{0.4f, 0.3f, 0.2f + 1e-3f * (float)(j + g), 0.1f};
+                else sg[j][g] = *reinterpret_cast<const f32x4*>(red + (wave * 12 + j * 4 + g) * 1024 + lane * 16);
+            }
+        // the four waves' K quarters meet: wave w' takes row tile w', sums the sources in a fixed order
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(red + ((wave * 12 + j * 4 + r) * 64 + lane) * 16) = acc[j][r];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int src = 0; src < 4; ++src) dh[j] += *reinterpret_cast<const f32x4*>(red + ((src * 12 + j * 4 + wave) * 64 + lane) * 16);
+        // cell derivative of this thread's 3 x 4 elements -> gate gradients of step t: fp32 to memory (the weight-gradient
+        // products read them afterwards) and, rounded to 16 bits, into this member's [64][192] tile for the exchange
         const __amdgpu_buffer_rsrc_t ro = tileg(dgout, t);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -570,12 +612,7 @@ __device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, i
                 d_o[i] = dhv * tc * og * (1.f - og);
                 dc[j][i] = dct * fg;
             }
-            if constexpr ((ABL & 8) == 0) {
-                q_store(ro, eo_g, (unsigned)(j * 64), d_i);
-                q_store(ro, eo_g, (unsigned)(QH * 4 + j * 64), d_f);
-                q_store(ro, eo_g, (unsigned)(2 * QH * 4 + j * 64), d_g);
-                q_store(ro, eo_g, (unsigned)(3 * QH * 4 + j * 64), d_o);
-            }
+            sg[j][0] = d_i, sg[j][1] = d_f, sg[j][2] = d_g, sg[j][3] = d_o;  // kept for the fp32 stores after the hand-off
             unsigned char* dp = dsh + (wave * 16 + lr) * DSH_STRIDE + (16 * j + 4 * lq) * 2;
             *reinterpret_cast<fsn_u32x2*>(dp) = q_round4<AR>(d_i);
             *reinterpret_cast<fsn_u32x2*>(dp + QU * 2) = q_round4<AR>(d_f);
@@ -584,35 +621,35 @@ __device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, i
             c_t[j] = c_p[j];  // c_{t-1} is the next iteration's c_t
         }
         __syncthreads();
-        f32x4 acc[6][4];
-        if (t > 0) {  // dgates_t W_hh: step t - 1's recurrent term
-            zero(acc);
-            product(acc, ring, w_hh);
-            if (LAYER) ring_start(ring, w_ih);
-            store_set(r_hh, (unsigned)((t & 1) * QM * PSET * 4), acc);
+        // exchange: this member's six K blocks x four row tiles of step t's tile, one 1 KB fragment per wave and store.
+        // Layer 1's slot still holds step t + QDX until every layer-0 member has read it, i.e. completed that step
+        if (LAYER && done >= (unsigned)QDX) wait(fl0, done - QDX + 1);
+#pragma unroll
+        for (int kbl = 0; kbl < 6; ++kbl) {
+            const q_u32x4 v = q_lds128(dsh + (wave * 16 + lr) * DSH_STRIDE + kbl * 64 + lq * 16);
+            if constexpr ((ABL & 16) != 0) live += __builtin_bit_cast(float, v[0]);
+            else __builtin_amdgcn_raw_buffer_store_b128(v, rxo, (unsigned)lane * 16u,
+                                                        (unsigned)((t % QDX) * XSLOT + ((6 * member + kbl) * 4 + wave) * 1024), 16);
         }
-        if (LAYER) {
-            if (t > 0) q_publish(fl1 + member, done + 1);
-            // dgates1_t W_ih1 = layer 0's dH_t.  Its ring slot still holds step t + QDX until every layer-0 member has
-            // consumed that step, i.e. completed done - QDX + 1 steps
-            zero(acc);
-            product(acc, ring, w_ih);
-            if (done >= (unsigned)QDX) wait(fl0, done - QDX + 1);
-            store_set(r_ih, (unsigned)((t % QDX) * QM * PSET * 4), acc);
-            q_publish(flx + member, done + 1);
-        } else {
-            q_publish(fl0 + member, done + 1);
+        q_publish(myfl + member, done + 1);  // its barrier also closes this step's use of `red` and `dsh`
+        // the fp32 gate gradients (what the weight-gradient products read afterwards) AFTER the hand-off: only the 16-bit
+        // tile belongs to it
+        if constexpr ((ABL & 8) == 0) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) q_store(ro, eo_g, (unsigned)(g * QH * 4 + j * 64), sg[j][g]);
         }
-        // (the barrier inside the last publish also orders this step's reads of `dsh` before the next step's writes)
     }
     if (ABL != 0 && live == 123.456f) a.status[1] = 1u;  // never true: the ablated values stay computed
 }
 
 template <int AR, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void lstm2_g16_bwd_kernel(const G16BwdArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char red[4 * 12 * 1024];
     __shared__ __attribute__((aligned(16))) unsigned char dsh[QROWS * DSH_STRIDE];
     // first half of the grid: layer 1 (the leading chain), second half: layer 0; cluster members on one XCD when the
-    // cluster count allows it (speed only)
+    // cluster count allows it (speed only: they then share the exchanged tiles through that XCD's L2)
     const int half = gridDim.x >> 1;
     const int second = (int)blockIdx.x >= half ? 1 : 0;
     const int bid = (int)blockIdx.x - second * half;
@@ -626,8 +663,8 @@ __global__ __launch_bounds__(256, 2) void lstm2_g16_bwd_kernel(const G16BwdArgs 
         cluster = bid / QM;
         member = bid % QM;
     }
-    if (!second) g16_bwd_body<1, AR, ABL>(a, cluster, member, dsh);
-    else g16_bwd_body<0, AR, ABL>(a, cluster, member, dsh);
+    if (!second) g16_bwd_body<1, AR, ABL>(a, cluster, member, red, dsh);
+    else g16_bwd_body<0, AR, ABL>(a, cluster, member, red, dsh);
 }
 
 }  // namespace
@@ -648,7 +685,7 @@ int fsn_lstm2_g16_clusters(int tiles) {
 }
 size_t fsn_lstm2_g16_flag_words(int clusters) { return (size_t)clusters * 3 * QFS + 16; }
 size_t fsn_lstm2_g16_status_word(int clusters) { return (size_t)clusters * 3 * QFS; }
-size_t fsn_lstm2_g16_partial_floats(int clusters) { return (size_t)clusters * (2 + 2 + QDX) * QM * PSET; }
+size_t fsn_lstm2_g16_partial_floats(int clusters) { return (size_t)clusters * 2 * QDX * (XSLOT / 4); }  // the two exchange rings
 size_t fsn_lstm2_g16_fwd_weight_halves(int Ipad) { return (size_t)QG * Ipad + (size_t)3 * QG * QH; }
 size_t fsn_lstm2_g16_bwd_weight_halves() { return (size_t)3 * QG * QH; }
 
@@ -753,9 +790,8 @@ int fsn_launch_lstm2_g16_bptt(const float* dh1, const float* w_hh1, const float*
     a.cseq1 = save1 + (size_t)Tp * Nrows * QG;
     a.dg0 = dg0;
     a.dg1 = dg1;
-    a.p_hh1 = partials;
-    a.p_hh0 = partials + (size_t)clusters * 2 * QM * PSET;
-    a.p_ih1 = partials + (size_t)clusters * 4 * QM * PSET;
+    a.x1 = reinterpret_cast<unsigned short*>(partials);
+    a.x0 = reinterpret_cast<unsigned short*>(partials + (size_t)clusters * QDX * (XSLOT / 4));
     a.flags = flags;
     a.status = flags + fsn_lstm2_g16_status_word(clusters);
     a.spin_ticks = fsn_spin_ticks();

@@ -97,7 +97,7 @@ int main(int argc, char** argv) {
         G16BwdArgs b{};
         b.dh1 = dh1; b.w16 = w16; b.o_hh1 = 0; b.o_ih1 = (unsigned)((size_t)QG * QH * 2); b.o_hh0 = (unsigned)((size_t)2 * QG * QH * 2);
         b.gates0 = sv0; b.cseq0 = sv0 + TN * QG; b.gates1 = sv1; b.cseq1 = sv1 + TN * QG; b.dg1 = dg; b.dg0 = dg + TN * QG;
-        b.p_hh1 = part; b.p_hh0 = part + (size_t)clusters * 2 * QM * PSET; b.p_ih1 = part + (size_t)clusters * 4 * QM * PSET;
+        b.x1 = reinterpret_cast<unsigned short*>(part); b.x0 = reinterpret_cast<unsigned short*>(part + (size_t)clusters * QDX * (XSLOT / 4));
         b.flags = flags; b.status = flags + fsn_lstm2_g16_status_word(clusters); b.spin_ticks = 1ull << 31; b.Tp = Tp; b.Nrows = N;
         const float t0 = run_bwd<0>(b);
         unsigned st = 0; hipMemcpy(&st, b.status, 4, hipMemcpyDeviceToHost);
@@ -106,12 +106,11 @@ int main(int argc, char** argv) {
         VB(8, "no gate-gradient stores");
         VB(2, "saved activations not loaded");
         VB(4, "no weight loads");
-        VB(16, "no partial stores");
-        VB(32, "partials not loaded");
+        VB(16, "no exchange stores");
+        VB(32, "exchanged operand not loaded");
         VB(1, "no flag waits");
-        VB(16 + 32, "no partial traffic");
         VB(8 + 2, "no saved loads, no gate-gradient stores");
-        VB(8 + 2 + 16 + 32, "... and no partial traffic");
+        VB(8 + 2 + 16 + 32, "... and no exchange traffic");
         VB(8 + 2 + 16 + 32 + 4, "... and no weight loads");
         VB(8 + 2 + 16 + 32 + 4 + 1, "... and no flag waits (K loops, LDS, barriers, cell derivative)");
         VB(0, "shipped again");
