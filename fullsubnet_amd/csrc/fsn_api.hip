@@ -2576,9 +2576,10 @@ extern "C" size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H, int 
         size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
         const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
         cv.take<char>(tn > tn2 ? tn : tn2);
-        if (arith != FSN_ARITH_F32) {
-            cv.take<unsigned short>((size_t)3 * H * G);  // 16-bit W^T fragments
-            cv.take<float>(fsn_lstm2_g16_partial_floats(clusters));  // lstm_group16_kernels.hip: exchanged partial sums
+        if (arith != FSN_ARITH_F32) cv.take<unsigned short>((size_t)3 * H * G);  // 16-bit W^T fragments
+        if (arith != FSN_ARITH_F32) {  // lstm_group16_kernels.hip: its packed weights and the rings of exchanged gate-gradient tiles
+            cv.take<char>(fsn_lstm2_g16_bwd_weight_bytes());
+            cv.take<float>(fsn_lstm2_g16_partial_floats(clusters));
         }
         return fsn_round_up_sz(cv.off, 256);
     }
@@ -2696,6 +2697,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
     void* scratch = cv.take<char>(tn > tn2 ? tn : tn2);
     unsigned short* w16 = arith != FSN_ARITH_F32 ? cv.take<unsigned short>((size_t)3 * H * G) : nullptr;
+    void* g16_w = arith != FSN_ARITH_F32 ? cv.take<char>(fsn_lstm2_g16_bwd_weight_bytes()) : nullptr;
     float* partials = arith != FSN_ARITH_F32 ? cv.take<float>(fsn_lstm2_g16_partial_floats(clusters)) : nullptr;
     const bool g16 = lstm2_use_g16(arith, clusters, N);
     const float* sv0 = static_cast<const float*>(save0);
@@ -2717,7 +2719,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     {
         FSN_PERSIST_BEGIN(s);
         if (g16) {  // the 16-bit arithmetic's own kernel (K-split; packs the raw weights its way into w16)
-            FSN_TRY(fsn_launch_lstm2_g16_bptt(dh1, w_hh1, w_ih1, w_hh0, sv0, sv1, dg0, dg1, partials, flags, w16, T, N, clusters,
+            FSN_TRY(fsn_launch_lstm2_g16_bptt(dh1, w_hh1, w_ih1, w_hh0, sv0, sv1, dg0, dg1, partials, flags, g16_w, T, N, clusters,
                                               H, s, arith));
             FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_g16_status_word(clusters), dg1, (size_t)2 * T * N * G, s));
         } else {

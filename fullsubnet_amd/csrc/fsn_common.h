@@ -258,13 +258,13 @@ size_t fsn_lstm2_g16_flag_words(int clusters);
 size_t fsn_lstm2_g16_status_word(int clusters);
 size_t fsn_lstm2_g16_partial_floats(int clusters);
 size_t fsn_lstm2_g16_fwd_weight_halves(int Ipad);
-size_t fsn_lstm2_g16_bwd_weight_halves();
+size_t fsn_lstm2_g16_bwd_weight_bytes();
 int fsn_launch_lstm2_g16_train(const float* x, int I, int Nrows, const float* w_ih0, const float* w_hh0, const float* w_ih1,
                                const float* w_hh1, const float* bias0, const float* bias1, float* hseq0, float* hseq1,
                                float* save0, float* save1, unsigned* flags, void* w16, int Tp, int clusters, int H,
                                hipStream_t s, int arith);
 int fsn_launch_lstm2_g16_bptt(const float* dh1, const float* w_hh1, const float* w_ih1, const float* w_hh0, const float* save0,
-                              const float* save1, float* dg0, float* dg1, float* partials, unsigned* flags, void* w16, int Tp,
+                              const float* save1, float* dg0, float* dg1, float* exchange, unsigned* flags, void* wbuf, int Tp,
                               int Nrows, int clusters, int H, hipStream_t s, int arith);
 // fb_chain_bptt_kernels.hip: BPTT of the full-band model's two layers (16 rows, H = 512) as one persistent launch
 bool fsn_fb_chain_bptt_supported(int H, int N);

@@ -50,6 +50,11 @@ constexpr int DSH_STRIDE = 4 * QU * 2 + 16;  // BPTT: own gate gradients [64][19
 constexpr int ACT_BYTES = QROWS * ACT_STRIDE, GSH_BYTES = 4 * QROWS * GSH_STRIDE;
 constexpr int FWD_LDS = ACT_BYTES > GSH_BYTES ? ACT_BYTES : GSH_BYTES;
 
+// geometry of the BPTT kernel's K blocks under arithmetic AR (see there)
+template <int AR> constexpr int q_kbk() { return 32; }                               // k per block (eight 16-bit values per lane)
+template <int AR> constexpr int q_nbw() { return QG / q_kbk<AR>() / 4; }             // blocks of one wave's K quarter: 12
+template <int AR> constexpr int q_nbm() { return 4 * QU / q_kbk<AR>(); }             // blocks a member owns: 6
+template <int AR> constexpr int q_xslot() { return QG / q_kbk<AR>() * 4 * 1024; }    // bytes of one [64 rows][1536] tile in fragment order
 template <int AR>
 __device__ __forceinline__ fsn_u32x2 q_round4(const f32x4 v) {
     return __builtin_bit_cast(fsn_u32x2, fsn_operand<AR>(v));
@@ -148,26 +153,25 @@ __global__ void q_pack_fwd_kernel(const float* __restrict__ w, unsigned short* _
 // position of the exchanged gate gradients (member m' owns a contiguous run) and gamma(k') = gate H + 48 m' + unit the
 // gate column behind it; 48 m + 16 j + lr is the output unit (a hidden unit of the step before / of the layer below).
 template <int AR>
-__global__ void q_pack_bptt_kernel(const float* __restrict__ w, unsigned short* __restrict__ out) {
-    const long n8 = (long)QG * QH / 8;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+__global__ void q_pack_bptt_kernel(const float* __restrict__ w, void* __restrict__ out) {
+    constexpr int NBW = q_nbw<AR>(), KBK = q_kbk<AR>();
+    const long nf = (long)QM * 4 * NBW * 3 * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(i & 63);
         long f = i >> 6;
         const int j = (int)(f % 3);
         f /= 3;
-        const int kbl = (int)(f % 12);
-        f /= 12;
+        const int kbl = (int)(f % NBW);
+        f /= NBW;
         const int wv = (int)(f & 3), m = (int)(f >> 2);
-        const int unit = QU * m + 16 * j + (lane & 15), k0 = 32 * (12 * wv + kbl) + 8 * (lane >> 4);
-        f32x4 lo, hi;
+        const int unit = QU * m + 16 * j + (lane & 15), k0 = KBK * (NBW * wv + kbl) + 8 * (lane >> 4);
+        float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int kk = k0 + e, mm = kk / (4 * QU), kl = kk % (4 * QU), col = (kl / QU) * QH + QU * mm + kl % QU;
-            const float v = w[(long)col * QH + unit];
-            if (e < 4) lo[e] = v;
-            else hi[e - 4] = v;
+            v[e] = w[(long)col * QH + unit];
         }
-        const fsn_u32x2 a = q_round4<AR>(lo), b = q_round4<AR>(hi);
+        const fsn_u32x2 a = q_round4<AR>(f32x4{v[0], v[1], v[2], v[3]}), b = q_round4<AR>(f32x4{v[4], v[5], v[6], v[7]});
         reinterpret_cast<q_u32x4*>(out)[i] = q_u32x4{a[0], a[1], b[0], b[1]};
     }
 }
@@ -422,17 +426,22 @@ __global__ __launch_bounds__(256, 2) void lstm2_g16_fwd_kernel(const G16FwdArgs 
 // fabric, where per-member partial sums cost 1.5 MB - measured: profiles/r04_g16_probe_v1.txt).  The four waves split K
 // (twelve blocks each, own weight stream, own operand stream) and meet once per step in a fixed-order LDS reduction.
 // Layer 0 forms dgates1_t W_ih1 itself, from layer 1's tile (published well ahead: off its recurrent chain).
-constexpr int XSLOT = 48 * 4 * 1024;   // bytes of one [64 rows][1536] 16-bit tile in fragment order
+// (An fp32 instantiation of this kernel - 16 k per block, the tile exchanged in fp32 - was built and measured in round 4:
+// 69 us per step against the fp32-era kernel's 72: with fp32 operands the step is bound by the fabric either way, 0.5 GB
+// of tiles and weight fragments per step that the 4 MB L2s cannot hold, so the fp32 arithmetic stays on
+// lstm_group_bptt_kernels.hip; profiles/r04_g16_probe_bptt_f32.txt.)
 constexpr int QAD = 4;                  // operand blocks in flight per wave (4 fragments each)
 constexpr int QWD = 4;                  // weight blocks in flight per wave (3 fragments each)
+template <int AR>
+__device__ __forceinline__ f32x4 q_mma_blk(const q_u32x4 a, const q_u32x4 b, f32x4 c) { return q_mma2<AR>(a, b, c); }
 
 struct G16BwdArgs {
     const float* dh1;      // [Tp][N][H]  d loss / d hseq1
-    const unsigned short* w16;
+    const void* w16;       // packed 16-bit weights
     unsigned o_hh1, o_ih1, o_hh0;  // byte offsets of the packed products (q_pack_bptt_kernel)
     const float *gates0, *cseq0, *gates1, *cseq1;
     float *dg0, *dg1;      // [Tp][N][4H] gate gradients (outputs)
-    unsigned short *x1, *x0;  // [clusters][QDX][XSLOT bytes]: 16-bit gate gradients of the last steps, fragment order
+    void *x1, *x0;         // [clusters][QDX][q_xslot bytes]: the gate gradients of the last steps, fragment order
     unsigned* flags;       // [clusters][2][QFS]: steps published by (layer 1 | layer 0, member)
     unsigned* status;
     unsigned long long spin_ticks;
@@ -452,7 +461,8 @@ __device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, i
     unsigned* fl0 = a.flags + ((size_t)cluster * 2 + 1) * QFS;
     const __amdgpu_buffer_rsrc_t wrsrc = q_rsrc(a.w16, 0x7fffffff);
     // this wave's weight stream of a product: fragments (kbl, j) at base + kbl * 3072 + j * 1024 + lane * 16
-    auto wbase = [&](unsigned o) { return o + (unsigned)((member * 4 + wave) * 12) * 3072u; };
+    constexpr int NBW = q_nbw<AR>(), NBM = q_nbm<AR>(), XSLOT = q_xslot<AR>();
+    auto wbase = [&](unsigned o) { return o + (unsigned)((member * 4 + wave) * NBW) * 3072u; };
     auto wload = [&](unsigned base, int kbl, int j) {
         if constexpr ((ABL & 4) != 0) return q_u32x4{0x3c003c00u + (unsigned)kbl, 0x38003800u, 0x34003400u + (unsigned)j, 0x30003000u};
         else return __builtin_bit_cast(q_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)lane * 16u,
@@ -483,7 +493,7 @@ __device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, i
         auto xload = [&](int kbl, int r) {
             if constexpr ((ABL & 32) != 0) return q_u32x4{0x2c002c00u + (unsigned)kbl, 0x28002800u, 0x24002400u + (unsigned)r, 0x20002000u};
             else return __builtin_bit_cast(q_u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                        rx, (unsigned)lane * 16u, xo + (unsigned)(((wave * 12 + kbl) * 4 + r) * 1024), 16));
+                                                        rx, (unsigned)lane * 16u, xo + (unsigned)(((wave * NBW + kbl) * 4 + r) * 1024), 16));
         };
         q_u32x4 aring[QAD][4];
 #pragma unroll
@@ -491,7 +501,7 @@ __device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, i
 #pragma unroll
             for (int r = 0; r < 4; ++r) aring[d][r] = xload(d, r);
 #pragma unroll
-        for (int kb0 = 0; kb0 < 12; kb0 += QAD) {
+        for (int kb0 = 0; kb0 < NBW; kb0 += QAD) {
 #pragma unroll
             for (int d = 0; d < QAD; ++d) {
                 const int kbl = kb0 + d;
@@ -500,7 +510,7 @@ __device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, i
                 for (int j = 0; j < 3; ++j) wf[j] = wring[d][j];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) af[r] = aring[d][r];
-                if (kbl + QAD < 12) {
+                if (kbl + QAD < NBW) {
                     __builtin_amdgcn_sched_barrier(0);  // the refills go out before this block's matrix work
 #pragma unroll
                     for (int j = 0; j < 3; ++j) wring[d][j] = wload(wb, kbl + QWD, j);
@@ -511,11 +521,11 @@ __device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, i
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[j][r] = q_mma2<AR>(wf[j], af[r], acc[j][r]);
+                    for (int r = 0; r < 4; ++r) acc[j][r] = q_mma_blk<AR>(wf[j], af[r], acc[j][r]);
             }
         }
     };
-    static_assert(QAD == QWD, "the two rings turn together");
+    static_assert(QAD == QWD && NBW % QAD == 0, "the two rings turn together, in whole turns");
     auto wring_start = [&](q_u32x4 (&wring)[QWD][3], unsigned wb) {
 #pragma unroll
         for (int d = 0; d < QWD; ++d)
@@ -620,16 +630,16 @@ __device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, i
             *reinterpret_cast<fsn_u32x2*>(dp + 3 * QU * 2) = q_round4<AR>(d_o);
             c_t[j] = c_p[j];  // c_{t-1} is the next iteration's c_t
         }
-        __syncthreads();
-        // exchange: this member's six K blocks x four row tiles of step t's tile, one 1 KB fragment per wave and store.
+        // exchange: this member's K blocks x four row tiles of step t's tile, one 1 KB fragment per wave and store.
         // Layer 1's slot still holds step t + QDX until every layer-0 member has read it, i.e. completed that step
+        __syncthreads();
         if (LAYER && done >= (unsigned)QDX) wait(fl0, done - QDX + 1);
 #pragma unroll
-        for (int kbl = 0; kbl < 6; ++kbl) {
+        for (int kbl = 0; kbl < NBM; ++kbl) {
             const q_u32x4 v = q_lds128(dsh + (wave * 16 + lr) * DSH_STRIDE + kbl * 64 + lq * 16);
             if constexpr ((ABL & 16) != 0) live += __builtin_bit_cast(float, v[0]);
             else __builtin_amdgcn_raw_buffer_store_b128(v, rxo, (unsigned)lane * 16u,
-                                                        (unsigned)((t % QDX) * XSLOT + ((6 * member + kbl) * 4 + wave) * 1024), 16);
+                                                        (unsigned)((t % QDX) * XSLOT + ((NBM * member + kbl) * 4 + wave) * 1024), 16);
         }
         q_publish(myfl + member, done + 1);  // its barrier also closes this step's use of `red` and `dsh`
         // the fp32 gate gradients (what the weight-gradient products read afterwards) AFTER the hand-off: only the 16-bit
@@ -685,9 +695,10 @@ int fsn_lstm2_g16_clusters(int tiles) {
 }
 size_t fsn_lstm2_g16_flag_words(int clusters) { return (size_t)clusters * 3 * QFS + 16; }
 size_t fsn_lstm2_g16_status_word(int clusters) { return (size_t)clusters * 3 * QFS; }
-size_t fsn_lstm2_g16_partial_floats(int clusters) { return (size_t)clusters * 2 * QDX * (XSLOT / 4); }  // the two exchange rings
+// the two rings of exchanged gate-gradient tiles (floats of scratch), the packed weights (bytes of scratch)
+size_t fsn_lstm2_g16_partial_floats(int clusters) { return (size_t)clusters * 2 * QDX * (q_xslot<FSN_ARITH_F16>() / 4); }
+size_t fsn_lstm2_g16_bwd_weight_bytes() { return (size_t)3 * QG * QH * 2; }
 size_t fsn_lstm2_g16_fwd_weight_halves(int Ipad) { return (size_t)QG * Ipad + (size_t)3 * QG * QH; }
-size_t fsn_lstm2_g16_bwd_weight_halves() { return (size_t)3 * QG * QH; }
 
 template <int AR>
 static int g16_pack_fwd(const float* w, unsigned short* out, int k, int k_pad, hipStream_t s) {
@@ -696,10 +707,28 @@ static int g16_pack_fwd(const float* w, unsigned short* out, int k, int k_pad, h
     return fsn_check_launch("q_pack_fwd_kernel");
 }
 template <int AR>
-static int g16_pack_bptt(const float* w, unsigned short* out, hipStream_t s) {
-    const long n8 = (long)QG * QH / 8;
-    hipLaunchKernelGGL(q_pack_bptt_kernel<AR>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, w, out);
+static int g16_pack_bptt(const float* w, void* out, hipStream_t s) {
+    const long nf = (long)QM * 4 * q_nbw<AR>() * 3 * 64;
+    hipLaunchKernelGGL(q_pack_bptt_kernel<AR>, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s, w, out);
     return fsn_check_launch("q_pack_bptt_kernel");
+}
+template <int AR>
+static int g16_launch_bptt(G16BwdArgs a, const float* w_hh1, const float* w_ih1, const float* w_hh0, void* wbuf, float* exchange,
+                           int clusters, hipStream_t s) {
+    const size_t wb = (size_t)QG * QH * 2;
+    unsigned char* p = static_cast<unsigned char*>(wbuf);
+    int rc;
+    if ((rc = g16_pack_bptt<AR>(w_hh1, p, s)) || (rc = g16_pack_bptt<AR>(w_ih1, p + wb, s)) || (rc = g16_pack_bptt<AR>(w_hh0, p + 2 * wb, s)))
+        return rc;
+    a.w16 = p;
+    a.o_hh1 = 0;
+    a.o_ih1 = (unsigned)wb;
+    a.o_hh0 = (unsigned)(2 * wb);
+    a.x1 = exchange;
+    a.x0 = reinterpret_cast<unsigned char*>(exchange) + (size_t)clusters * QDX * q_xslot<AR>();
+    const dim3 grid((unsigned)clusters * QM * 2), block(256);
+    FSN_PERSIST_LAUNCH(lstm2_g16_bwd_kernel<AR>, grid, block, s, a);
+    return fsn_check_launch("lstm2_g16_bwd_kernel");
 }
 
 // Rows [0, 64 clusters) of two stacked LSTM layers, forward with saves, 16-bit operands.  x [Tp][Nrows][32] (zero-padded
@@ -754,51 +783,30 @@ int fsn_launch_lstm2_g16_train(const float* x, int I, int Nrows, const float* w_
     return fsn_check_launch("lstm2_g16_fwd_kernel");
 }
 
-// Rows [0, 64 clusters) of the two layers' back-propagation through time, 16-bit operands.  w_* UNPACKED; save0 / save1
-// in fsn_lstm_layer_forward's layout; dg0 / dg1 [Tp][Nrows][4H] out; partials: fsn_lstm2_g16_partial_floats(clusters)
-// floats of scratch; w16: fsn_lstm2_g16_bwd_weight_halves() 16-bit words of scratch.
+// Rows [0, 64 clusters) of the two layers' back-propagation through time, 16-bit operands (FSN_ARITH_F16 / _BF16).  w_*
+// UNPACKED; save0 / save1 in fsn_lstm_layer_forward's layout; dg0 / dg1 [Tp][Nrows][4H] out; exchange:
+// fsn_lstm2_g16_partial_floats(clusters) floats of scratch; wbuf: fsn_lstm2_g16_bwd_weight_bytes() bytes.
 int fsn_launch_lstm2_g16_bptt(const float* dh1, const float* w_hh1, const float* w_ih1, const float* w_hh0, const float* save0,
-                              const float* save1, float* dg0, float* dg1, float* partials, unsigned* flags, void* w16, int Tp,
+                              const float* save1, float* dg0, float* dg1, float* exchange, unsigned* flags, void* wbuf, int Tp,
                               int Nrows, int clusters, int H, hipStream_t s, int arith) {
-    if (H != QH || clusters < 1 || clusters > fsn_lstm2_g16_clusters(Nrows / 16) ||
-        (arith != FSN_ARITH_F16 && arith != FSN_ARITH_BF16)) {
+    if (H != QH || clusters < 1 || clusters > fsn_lstm2_g16_clusters(Nrows / 16) || (arith != FSN_ARITH_F16 && arith != FSN_ARITH_BF16)) {
         fsn_set_error("lstm2_g16 (bptt): H = 384, 16-bit arithmetic, clusters * 64 <= rows, one cluster per eight CUs at most");
         return FSN_ERR_ARG;
     }
     if (fsn_launch_zero_words(flags, fsn_lstm2_g16_flag_words(clusters), s) != FSN_OK) return FSN_ERR_LAUNCH;
-    unsigned short* p = static_cast<unsigned short*>(w16);
-    unsigned short *p_hh1 = p, *p_ih1 = p + (size_t)QG * QH, *p_hh0 = p + (size_t)2 * QG * QH;
-    int rc;
-    if (arith == FSN_ARITH_F16) {
-        if ((rc = g16_pack_bptt<FSN_ARITH_F16>(w_hh1, p_hh1, s)) || (rc = g16_pack_bptt<FSN_ARITH_F16>(w_ih1, p_ih1, s)) ||
-            (rc = g16_pack_bptt<FSN_ARITH_F16>(w_hh0, p_hh0, s)))
-            return rc;
-    } else {
-        if ((rc = g16_pack_bptt<FSN_ARITH_BF16>(w_hh1, p_hh1, s)) || (rc = g16_pack_bptt<FSN_ARITH_BF16>(w_ih1, p_ih1, s)) ||
-            (rc = g16_pack_bptt<FSN_ARITH_BF16>(w_hh0, p_hh0, s)))
-            return rc;
-    }
     G16BwdArgs a{};
     a.dh1 = dh1;
-    a.w16 = p;
-    a.o_hh1 = 0;
-    a.o_ih1 = (unsigned)((size_t)QG * QH * 2);
-    a.o_hh0 = (unsigned)((size_t)2 * QG * QH * 2);
     a.gates0 = save0;
     a.cseq0 = save0 + (size_t)Tp * Nrows * QG;
     a.gates1 = save1;
     a.cseq1 = save1 + (size_t)Tp * Nrows * QG;
     a.dg0 = dg0;
     a.dg1 = dg1;
-    a.x1 = reinterpret_cast<unsigned short*>(partials);
-    a.x0 = reinterpret_cast<unsigned short*>(partials + (size_t)clusters * QDX * (XSLOT / 4));
     a.flags = flags;
     a.status = flags + fsn_lstm2_g16_status_word(clusters);
     a.spin_ticks = fsn_spin_ticks();
     a.Tp = Tp;
     a.Nrows = Nrows;
-    const dim3 grid((unsigned)clusters * QM * 2), block(256);
-    if (arith == FSN_ARITH_F16) FSN_PERSIST_LAUNCH(lstm2_g16_bwd_kernel<FSN_ARITH_F16>, grid, block, s, a);
-    else FSN_PERSIST_LAUNCH(lstm2_g16_bwd_kernel<FSN_ARITH_BF16>, grid, block, s, a);
-    return fsn_check_launch("lstm2_g16_bwd_kernel");
+    if (arith == FSN_ARITH_F16) return g16_launch_bptt<FSN_ARITH_F16>(a, w_hh1, w_ih1, w_hh0, wbuf, exchange, clusters, s);
+    return g16_launch_bptt<FSN_ARITH_BF16>(a, w_hh1, w_ih1, w_hh0, wbuf, exchange, clusters, s);
 }

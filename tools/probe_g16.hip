@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
     hipMalloc(&x, TN * 32 * 4); hipMalloc(&w, (size_t)4 * QG * QH * 4); hipMalloc(&bias, 2 * QG * 4);
     hipMalloc(&h0, TN * QH * 4); hipMalloc(&h1, TN * QH * 4); hipMalloc(&sv0, TN * 5 * QH * 4); hipMalloc(&sv1, TN * 5 * QH * 4);
     hipMalloc(&dg, 2 * TN * QG * 4); hipMalloc(&dh1, TN * QH * 4); hipMalloc(&part, fsn_lstm2_g16_partial_floats(clusters) * 4);
-    hipMalloc(&w16, (size_t)4 * QG * QH * 2); hipMalloc(&flags, fsn_lstm2_g16_flag_words(clusters) * 4);
+    hipMalloc(&w16, (size_t)4 * QG * QH * 4); hipMalloc(&flags, fsn_lstm2_g16_flag_words(clusters) * 4);
     g_flags = flags;
     fill_kernel<<<1024, 256>>>(x, TN * 32, 1, 1.0f, 0.f);
     fill_kernel<<<1024, 256>>>(w, (size_t)4 * QG * QH, 2, 0.05f, 0.f);
@@ -67,6 +67,7 @@ int main(int argc, char** argv) {
     fill_kernel<<<1024, 256>>>(dh1, TN * QH, 6, 0.01f, 0.f);
     hipDeviceSynchronize();
     unsigned short *p_a = w16, *p_b = p_a + (size_t)QG * 32, *p_c = p_b + (size_t)QG * QH, *p_d = p_c + (size_t)QG * QH;
+#if PROBE_AR != 0
     if (which & 1) {
         g16_pack_fwd<PROBE_AR>(w, p_a, 32, 32, 0); g16_pack_fwd<PROBE_AR>(w, p_b, QH, QH, 0);
         g16_pack_fwd<PROBE_AR>(w + (size_t)QG * QH, p_c, QH, QH, 0); g16_pack_fwd<PROBE_AR>(w + (size_t)2 * QG * QH, p_d, QH, QH, 0);
@@ -89,15 +90,18 @@ int main(int argc, char** argv) {
         VF(8 + 4 + 2 + 1 + 16, "... and no h stores (K loops, LDS traffic, barriers, cell)");
         VF(0, "shipped again");
     }
+#endif
     if (which & 2) {
-        g16_pack_bptt<PROBE_AR>(w, p_a, 0); g16_pack_bptt<PROBE_AR>(w + (size_t)QG * QH, p_a + (size_t)QG * QH, 0);
-        g16_pack_bptt<PROBE_AR>(w + (size_t)2 * QG * QH, p_a + (size_t)2 * QG * QH, 0);
+        const size_t wb = (size_t)QG * QH * 2;
+        unsigned char* wp = reinterpret_cast<unsigned char*>(w16);
+        g16_pack_bptt<PROBE_AR>(w, wp, 0); g16_pack_bptt<PROBE_AR>(w + (size_t)QG * QH, wp + wb, 0);
+        g16_pack_bptt<PROBE_AR>(w + (size_t)2 * QG * QH, wp + 2 * wb, 0);
         fill_kernel<<<1024, 256>>>(sv0, TN * 5 * QH, 3, 0.4f, 0.5f);
         fill_kernel<<<1024, 256>>>(sv1, TN * 5 * QH, 4, 0.4f, 0.5f);
         G16BwdArgs b{};
-        b.dh1 = dh1; b.w16 = w16; b.o_hh1 = 0; b.o_ih1 = (unsigned)((size_t)QG * QH * 2); b.o_hh0 = (unsigned)((size_t)2 * QG * QH * 2);
+        b.dh1 = dh1; b.w16 = w16; b.o_hh1 = 0; b.o_ih1 = (unsigned)wb; b.o_hh0 = (unsigned)(2 * wb);
         b.gates0 = sv0; b.cseq0 = sv0 + TN * QG; b.gates1 = sv1; b.cseq1 = sv1 + TN * QG; b.dg1 = dg; b.dg0 = dg + TN * QG;
-        b.x1 = reinterpret_cast<unsigned short*>(part); b.x0 = reinterpret_cast<unsigned short*>(part + (size_t)clusters * QDX * (XSLOT / 4));
+        b.x1 = part; b.x0 = reinterpret_cast<unsigned char*>(part) + (size_t)clusters * QDX * q_xslot<PROBE_AR>();
         b.flags = flags; b.status = flags + fsn_lstm2_g16_status_word(clusters); b.spin_ticks = 1ull << 31; b.Tp = Tp; b.Nrows = N;
         const float t0 = run_bwd<0>(b);
         unsigned st = 0; hipMemcpy(&st, b.status, 4, hipMemcpyDeviceToHost);
