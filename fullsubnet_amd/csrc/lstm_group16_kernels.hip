@@ -177,6 +177,10 @@ __global__ void q_pack_bptt_kernel(const float* __restrict__ w, void* __restrict
 }
 
 // ---- forward with saves -------------------------------------------------------------------------------------------
+// (Tried in round 4 and dropped, profiles/r04_g16_probe_fwd_v2.txt: layer 0 forming layer 1's input projection from its
+// own staged tile + a 16-bit h exchange - balanced workgroups, a third of the hand-off bytes, and no faster: 23.2 us per
+// step against 22.0.  What bounds the step is the weight stream - 454 KB per CU and step from the Infinity Cache, which
+// the 4 MB L2s cannot keep beside the streaming saves - at the bytes a wave can keep in flight in registers.)
 struct G16FwdArgs {
     const float* x;        // layer-0 input [Tp][x_step][32] (zero-padded columns)
     long x_step;
