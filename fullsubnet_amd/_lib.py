@@ -76,6 +76,11 @@ class AdamCfg(ctypes.Structure):
 ADAM_MAX_TENSORS = 32  # FSN_ADAM_MAX_TENSORS
 
 
+class TrainDims(ctypes.Structure):  # fsn_train_dims
+    _fields_ = [("B", ctypes.c_int), ("F", ctypes.c_int), ("T", ctypes.c_int), ("look_ahead", ctypes.c_int),
+                ("nb", ctypes.c_int), ("groups", ctypes.c_int)]
+
+
 class Params(ctypes.Structure):
     _fields_ = [(n, _f32p) for n in PARAM_FIELDS]
 
@@ -169,6 +174,17 @@ SIGNATURES = {
                                       _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_size_t),
                                       _c.c_void_p, _f32p, _f32p, _f32p, _c.c_void_p, _c.c_void_p, _c.c_size_t,
                                       _c.c_void_p]),
+    "fsn_train_rows": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
+    "fsn_train_glue_workspace_bytes": (_c.c_size_t, [_c.c_void_p]),
+    "fsn_train_fb_input": (_c.c_int, [_c.c_void_p, _f32p, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "fsn_train_sb_input": (_c.c_int, [_c.c_void_p, _f32p, _f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _c.c_int, _f32p,
+                                      _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "fsn_train_sb_input_backward": (_c.c_int, [_c.c_void_p, _f32p, _f32p, _c.c_int, _f32p, _f32p, _c.c_long, _c.c_int, _f32p,
+                                               _c.c_long, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "fsn_train_mask_out": (_c.c_int, [_c.c_void_p, _f32p, _c.c_int, _f32p, _c.c_void_p]),
+    "fsn_train_mask_grad": (_c.c_int, [_c.c_void_p, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_void_p]),
+    "fsn_train_cirm_target": (_c.c_int, [_c.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, _c.c_void_p]),
+    "fsn_scale_by_scalar": (_c.c_int, [_f32p, _f32p, _f32p, _c.c_size_t, _c.c_void_p]),
     "fsn_profile_enable": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "fsn_stream_timeout_policy": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "fsn_debug_g16_kernels": (_c.c_int, [_c.c_int]),

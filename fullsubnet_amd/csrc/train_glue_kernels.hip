@@ -1,0 +1,396 @@
+// The glue of the FullSubNet TRAINING graph as hand-written kernels (recipes/dns_interspeech_2020/fullsubnet/model.py:72-136
+// under autograd, fullsubnet/trainer.py:41-71): everything between the transforms, the four LSTM layers, the two output
+// layers and the loss that round 3 still ran as ATen tensor algebra -
+//   * look-ahead pad + offline Laplace norm of the full-band input, written time-major for the LSTM entries
+//     (model.py:85-95, audio_zen/model/base_model.py:204-218);
+//   * the sub-band model's input: freq_unfold (reflect-padded neighbours, base_model.py:14-46) ++ full-band output, the
+//     offline norm over the unfolded tensor with its mean taken analytically from per-bin sums (the 31-fold unfolded
+//     tensor is never formed), restricted to the rows drop_band keeps (audio_zen/acoustics/feature.py:309-345) - forward
+//     and backward (the gradient reaches the full-band output directly and through the mean);
+//   * the mask's reshape / look-ahead slice (model.py:129-135) and its gradient;
+//   * the training target: complex ideal ratio mask, compressed, band-dropped like the prediction
+//     (audio_zen/acoustics/mask.py:7-44, trainer.py:51-53).
+// HBM-bound gathers and reductions (a few MB per step): coalesced along the frequency axis of time-major tensors,
+// statistics in fp64 in a fixed order (bit-reproducible).  Row order of the sub-band tensors: drop_band's - group i holds
+// samples i, i + g, ... at bins i, i + g, ... (< F - F % g), the groups concatenated along the batch axis.
+#include "fsn_common.h"
+
+namespace {
+
+struct TrDims {
+    int B, F, T, la, nb, g;   // g = 1: no band dropping (B == 1 or num_groups <= 1)
+    int Tp, Fd, Fs, R;
+};
+__host__ __device__ inline TrDims tr_dims(const fsn_train_dims* d) {
+    TrDims t;
+    t.B = d->B, t.F = d->F, t.T = d->T, t.la = d->look_ahead, t.nb = d->nb;
+    t.g = (d->B > 1 && d->groups > 1) ? d->groups : 1;
+    t.Tp = t.T + t.la;
+    t.Fd = t.F - t.F % t.g;
+    t.Fs = t.g > 1 ? t.Fd / t.g : t.F;
+    t.R = t.B * t.Fs;
+    return t;
+}
+// row of the band-dropped (b_out, fs) space -> (sample b, bin f)
+__device__ __forceinline__ void tr_row_bf(const TrDims& d, int r, int& b, int& f) {
+    const int bo = r / d.Fs, fs = r % d.Fs;
+    if (d.g == 1) {
+        b = bo, f = fs;
+        return;
+    }
+    int i = 0, off = 0;
+    for (; i < d.g; ++i) {
+        const int n = (d.B - i + d.g - 1) / d.g;
+        if (bo < off + n) break;
+        off += n;
+    }
+    b = i + d.g * (bo - off);
+    f = i + d.g * fs;
+}
+// (sample b, bin f) -> its row, or -1 when drop_band leaves it out
+__device__ __forceinline__ int tr_bf_row(const TrDims& d, int b, int f) {
+    if (d.g == 1) return b * d.Fs + f;
+    const int i = b % d.g;
+    if (f >= d.Fd || f % d.g != i) return -1;
+    int off = 0;
+    for (int k = 0; k < i; ++k) off += (d.B - k + d.g - 1) / d.g;
+    return (off + b / d.g) * d.Fs + f / d.g;
+}
+__device__ __forceinline__ int tr_reflect(int j, int F) {
+    j = j < 0 ? -j : j;
+    return j >= F ? 2 * (F - 1) - j : j;
+}
+__device__ __forceinline__ double tr_block_sum(double v, double* sh) {  // 256 threads, valid in thread 0
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+    __syncthreads();
+    return t;
+}
+
+// rowsum[b F + f] = sum_t mag[b][f][t]  (one wave per row)
+__global__ __launch_bounds__(256) void tr_rowsum_kernel(const float* __restrict__ mag, double* __restrict__ rowsum, int rows, int T) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    double acc = 0.0;
+    for (int t = lane; t < T; t += 64) acc += (double)mag[(size_t)row * T + t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) rowsum[row] = acc;
+}
+// total[b] = sum_f rowsum[b][f]
+__global__ __launch_bounds__(256) void tr_total_kernel(const double* __restrict__ rowsum, double* __restrict__ total, int F) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int f = threadIdx.x; f < F; f += 256) acc += rowsum[(size_t)blockIdx.x * F + f];
+    const double t = tr_block_sum(acc, sh);
+    if (threadIdx.x == 0) total[blockIdx.x] = t;
+}
+// x_tm[t][b][f] = pad(mag)[b][f][t] / (mean_b + 1e-5), mag_tm[t][b][f] = pad(mag)[b][f][t]; zero beyond (B, F); one block
+// per (t, 32-bin slab, b): a 32 x 32 tile through LDS so that both sides are coalesced
+__global__ __launch_bounds__(256) void tr_fb_input_kernel(const float* __restrict__ mag, const double* __restrict__ total,
+                                                         float* __restrict__ x_tm, float* __restrict__ mag_tm, TrDims d, int Bp, int Fp) {
+    __shared__ float tile[32][33];
+    const int t0 = blockIdx.x * 32, f0 = blockIdx.y * 32, b = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {  // rows of the tile = bins, columns = frames (contiguous in mag)
+        const int f = f0 + i, t = t0 + tx;
+        tile[i][tx] = (b < d.B && f < d.F && t < d.T) ? mag[((size_t)b * d.F + f) * d.T + t] : 0.f;
+    }
+    __syncthreads();
+    float den = 1.f;
+    if (b < d.B) den = (float)(total[b] / ((double)d.F * d.Tp)) + 1e-5f;
+    for (int i = ty; i < 32; i += 8) {  // rows = frames, columns = bins (contiguous in the outputs)
+        const int t = t0 + i, f = f0 + tx;
+        if (t < d.Tp && f < Fp) {
+            const float v = tile[tx][i];
+            const size_t o = ((size_t)t * Bp + b) * Fp + f;
+            mag_tm[o] = v;
+            x_tm[o] = (b < d.B && f < d.F) ? v / den : 0.f;
+        }
+    }
+}
+// fbsum[b] = sum over (t, f) of fb_out_tm[t][b][f]: partial per (t, b), then per b (fixed order)
+__global__ __launch_bounds__(256) void tr_fbsum_partial_kernel(const float* __restrict__ fb, long ld, double* __restrict__ partial,
+                                                              TrDims d, int Bp) {
+    __shared__ double sh[4];
+    const int t = blockIdx.x, b = blockIdx.y;
+    double acc = 0.0;
+    for (int f = threadIdx.x; f < d.F; f += 256) acc += (double)fb[((size_t)t * Bp + b) * ld + f];
+    const double s = tr_block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[(size_t)b * d.Tp + t] = s;
+}
+// den[b] = mean of the unfolded sub-band tensor + 1e-5: (sum_j mult[j] rowsum[b][j] + sum fb_out[b]) / (F (2 nb + 2) Tp),
+// mult[j] = number of (unit f, window position) pairs that read bin j (reflection without edge repeat)
+__global__ __launch_bounds__(256) void tr_sb_den_kernel(const double* __restrict__ rowsum, const double* __restrict__ partial,
+                                                       float* __restrict__ den, TrDims d) {
+    __shared__ double sh[4];
+    const int b = blockIdx.x;
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < d.F; j += 256) {
+        int lo = j - d.nb, hi = j + d.nb;
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > d.F - 1 ? d.F - 1 : hi;
+        int m = hi - lo + 1;                                  // units whose window holds j directly
+        if (j > 0 && d.nb - j >= 0) m += d.nb - j + 1;        // ... below bin 0, mirrored onto j: units f <= nb - j
+        const int ju = d.F - 1 - j;
+        if (ju > 0 && d.nb - ju >= 0) m += d.nb - ju + 1;     // ... above bin F - 1
+        acc += (double)m * rowsum[(size_t)b * d.F + j];
+    }
+    for (int t = threadIdx.x; t < d.Tp; t += 256) acc += partial[(size_t)b * d.Tp + t];
+    const double s = tr_block_sum(acc, sh);
+    if (threadIdx.x == 0) den[b] = (float)(s / ((double)d.F * (2 * d.nb + 2) * d.Tp)) + 1e-5f;
+}
+// sb_in[t][r][c] (c < 32 = 2 nb + 2 padded to the LSTM entries' 32 columns; rows beyond R zero): 8 rows x 32 columns per wave-pass
+__global__ __launch_bounds__(256) void tr_sb_input_kernel(const float* __restrict__ mag_tm, const float* __restrict__ fb, long ld_fb,
+                                                         const float* __restrict__ den, float* __restrict__ out, TrDims d, int Bp,
+                                                         int Fp, int Rp) {
+    const int t = blockIdx.y;
+    const int c = threadIdx.x & 31;
+    const int W = 2 * d.nb + 1;
+    for (int r = blockIdx.x * 8 + (threadIdx.x >> 5); r < Rp; r += gridDim.x * 8) {
+        float v = 0.f;
+        if (r < d.R && c <= W) {
+            int b, f;
+            tr_row_bf(d, r, b, f);
+            const float raw = c < W ? mag_tm[((size_t)t * Bp + b) * Fp + tr_reflect(f + c - d.nb, d.F)]
+                                    : fb[((size_t)t * Bp + b) * ld_fb + f];
+            v = raw / den[b];
+        }
+        out[((size_t)t * Rp + r) * 32 + c] = v;
+    }
+}
+// backward, pass 1: partial[bo][t] = sum over the rows of band-dropped sample bo and the columns of dx[t][r][c] sb_in[t][r][c]
+__global__ __launch_bounds__(256) void tr_sb_bwd_partial_kernel(const float* __restrict__ dx, const float* __restrict__ sb_in,
+                                                               double* __restrict__ partial, TrDims d, int Rp) {
+    __shared__ double sh[4];
+    const int t = blockIdx.x, bo = blockIdx.y;
+    const size_t base = ((size_t)t * Rp + (size_t)bo * d.Fs) * 32;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < d.Fs * 32; i += 256) acc += (double)dx[base + i] * (double)sb_in[base + i];
+    const double s = tr_block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[(size_t)bo * d.Tp + t] = s;
+}
+// pass 2: dmu[b] = - (sum_t partial) / den[b]: every element's share of d loss / d mean times its 1 / count
+__global__ __launch_bounds__(256) void tr_sb_bwd_dmu_kernel(const double* __restrict__ partial, const float* __restrict__ den,
+                                                           float* __restrict__ dmu, TrDims d) {
+    __shared__ double sh[4];
+    const int bo = blockIdx.x;
+    double acc = 0.0;
+    for (int t = threadIdx.x; t < d.Tp; t += 256) acc += partial[(size_t)bo * d.Tp + t];
+    const double s = tr_block_sum(acc, sh);
+    if (threadIdx.x == 0) {
+        int b, f;
+        tr_row_bf(d, bo * d.Fs, b, f);
+        dmu[b] = (float)(-s / (double)den[b] / ((double)d.F * (2 * d.nb + 2) * d.Tp));
+    }
+}
+// pass 3: d fb_out[t][b][f] = [row kept] dx[t][r][2 nb + 1] / den[b] + dmu[b], through the ReLU of the full-band output
+// layer (fb_out > 0), as the padded dy of fsn_linear_backward ([Tp Bp][ld_d], zeros beyond (B, F))
+__global__ __launch_bounds__(256) void tr_sb_bwd_dfb_kernel(const float* __restrict__ dx, const float* __restrict__ den,
+                                                           const float* __restrict__ dmu, const float* __restrict__ fb, long ld_fb,
+                                                           float* __restrict__ dfb, long ld_d, TrDims d, int Bp, int Rp) {
+    const int t = blockIdx.y, b = blockIdx.z;
+    for (int f = blockIdx.x * 256 + threadIdx.x; f < ld_d; f += gridDim.x * 256) {
+        float v = 0.f;
+        if (b < d.B && f < d.F && fb[((size_t)t * Bp + b) * ld_fb + f] > 0.f) {
+            v = dmu[b];
+            const int r = tr_bf_row(d, b, f);
+            if (r >= 0) v += dx[((size_t)t * Rp + r) * 32 + 2 * d.nb + 1] / den[b];
+        }
+        dfb[((size_t)t * Bp + b) * ld_d + f] = v;
+    }
+}
+// mask[bo][c][fs][t] = y[t + la][bo Fs + fs][c]  (model.py:129-135): a 32 (rows) x 32 (frames) tile per block
+__global__ __launch_bounds__(256) void tr_mask_out_kernel(const float* __restrict__ y, float* __restrict__ mask, TrDims d, int Rp) {
+    __shared__ float tile[2][32][33];
+    const int r0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {  // 64 floats per frame: 32 rows x 2 outputs, contiguous in y
+        const int tt = i >> 6, rc = i & 63, r = r0 + (rc >> 1), t = t0 + tt;
+        tile[rc & 1][rc >> 1][tt] = (r < d.R && t < d.T) ? y[((size_t)(t + d.la) * Rp + r) * 2 + (rc & 1)] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * 32 * 32; i += 256) {
+        const int tt = i & 31, rr = (i >> 5) & 31, c = i >> 10, r = r0 + rr, t = t0 + tt;
+        if (r < d.R && t < d.T) mask[(((size_t)(r / d.Fs) * 2 + c) * d.Fs + r % d.Fs) * d.T + t] = tile[c][rr][tt];
+    }
+}
+// dy[t][r][c] (ld columns, zero beyond the two outputs, beyond R and for the look-ahead frames) = d mask[bo][c][fs][t - la]
+__global__ __launch_bounds__(256) void tr_mask_grad_kernel(const float* __restrict__ dmask, float* __restrict__ dy, TrDims d, int Rp,
+                                                          int ld) {
+    const int t = blockIdx.y;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)Rp * ld; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / ld), c = (int)(i % ld);
+        float v = 0.f;
+        if (r < d.R && c < 2 && t >= d.la) v = dmask[(((size_t)(r / d.Fs) * 2 + c) * d.Fs + r % d.Fs) * d.T + (t - d.la)];
+        dy[(size_t)t * Rp * ld + i] = v;
+    }
+}
+// target[bo][c][fs][t] = compress(cIRM)[b][f][t][c]  (mask.py:7-44 + drop_band, in the layout of the prediction)
+__device__ __forceinline__ float tr_compress(float m) {  // mask.py:32-44, K = 10, C = 0.1
+    m = m <= -100.0f ? -100.0f : m;
+    const float e = expf(-0.1f * m);
+    return 10.0f * (1.0f - e) / (1.0f + e);
+}
+__global__ __launch_bounds__(256) void tr_target_kernel(const float* __restrict__ nr, const float* __restrict__ ni,
+                                                       const float* __restrict__ cr, const float* __restrict__ ci,
+                                                       float* __restrict__ target, TrDims d) {
+    const float eps = 1.1920928955078125e-07f;  // audio_zen/constant.py:9
+    const int r = blockIdx.y;
+    int b, f;
+    tr_row_bf(d, r, b, f);
+    const size_t src = ((size_t)b * d.F + f) * d.T;
+    const size_t dst = ((size_t)(r / d.Fs) * 2 * d.Fs + r % d.Fs) * d.T;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < d.T; t += gridDim.x * 256) {
+        const float a = nr[src + t], bb = ni[src + t], c = cr[src + t], dd = ci[src + t];
+        const float den = a * a + bb * bb + eps;
+        target[dst + t] = tr_compress((a * c + bb * dd) / den);
+        target[dst + (size_t)d.Fs * d.T + t] = tr_compress((a * dd - bb * c) / den);
+    }
+}
+__global__ void tr_scale_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ y, size_t n) {
+    const float k = *s;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = x[i] * k;
+}
+
+struct TrWs {
+    double *rowsum, *total, *partial;
+    float* dmu;
+};
+static size_t tr_ws_bytes(const TrDims& d) { return ((size_t)d.B * d.F + d.B + (size_t)d.B * d.Tp) * sizeof(double) + (size_t)d.B * sizeof(float) + 256; }
+static TrWs tr_carve(const TrDims& d, void* ws) {
+    TrWs w;
+    w.rowsum = static_cast<double*>(ws);
+    w.total = w.rowsum + (size_t)d.B * d.F;
+    w.partial = w.total + d.B;
+    w.dmu = reinterpret_cast<float*>(w.partial + (size_t)d.B * d.Tp);
+    return w;
+}
+static bool tr_check(const fsn_train_dims* dd) {
+    return dd && dd->B >= 1 && dd->F >= 2 && dd->T >= 1 && dd->look_ahead >= 0 && dd->nb >= 0 && 2 * dd->nb + 2 <= 32 && dd->nb < dd->F &&
+           dd->groups >= 1;
+}
+
+}  // namespace
+
+#define TR_REQUIRE_DIMS(dd) FSN_REQUIRE(tr_check(dd), "train glue: bad dimensions (B, F >= 2, T >= 1, 2 nb + 2 <= 32, nb < F, groups >= 1)")
+
+extern "C" int fsn_train_rows(const fsn_train_dims* dims, int* Fs, int* R) {
+    TR_REQUIRE_DIMS(dims);
+    const TrDims d = tr_dims(dims);
+    if (Fs) *Fs = d.Fs;
+    if (R) *R = d.R;
+    return FSN_OK;
+}
+extern "C" size_t fsn_train_glue_workspace_bytes(const fsn_train_dims* dims) { return tr_check(dims) ? tr_ws_bytes(tr_dims(dims)) : 0; }
+
+extern "C" int fsn_train_fb_input(const fsn_train_dims* dims, const float* mag, float* x_tm, float* mag_tm, int Bp, int Fp,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    FsnCallScope scope(stream);
+    TR_REQUIRE_DIMS(dims);
+    const TrDims d = tr_dims(dims);
+    FSN_REQUIRE(mag && x_tm && mag_tm && workspace && Bp >= d.B && Fp >= d.F, "train fb input: NULL pointer / padded sizes below (B, F)");
+    if (workspace_bytes < tr_ws_bytes(d)) {
+        fsn_set_error("train fb input: workspace too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const TrWs w = tr_carve(d, workspace);
+    hipLaunchKernelGGL(tr_rowsum_kernel, dim3((unsigned)((d.B * d.F + 3) / 4)), dim3(256), 0, s, mag, w.rowsum, d.B * d.F, d.T);
+    FSN_TRY_LAUNCH("tr_rowsum_kernel");
+    hipLaunchKernelGGL(tr_total_kernel, dim3((unsigned)d.B), dim3(256), 0, s, w.rowsum, w.total, d.F);
+    FSN_TRY_LAUNCH("tr_total_kernel");
+    hipLaunchKernelGGL(tr_fb_input_kernel, dim3((unsigned)((d.Tp + 31) / 32), (unsigned)((Fp + 31) / 32), (unsigned)Bp), dim3(256), 0, s,
+                       mag, w.total, x_tm, mag_tm, d, Bp, Fp);
+    return fsn_check_launch("tr_fb_input_kernel");
+}
+
+extern "C" int fsn_train_sb_input(const fsn_train_dims* dims, const float* mag_tm, const float* fb_out_tm, long ld_fb, int Bp, int Fp,
+                                  float* sb_in, int Rp, float* den, void* workspace, size_t workspace_bytes, void* stream) {
+    FsnCallScope scope(stream);
+    TR_REQUIRE_DIMS(dims);
+    const TrDims d = tr_dims(dims);
+    FSN_REQUIRE(mag_tm && fb_out_tm && sb_in && den && workspace && Bp >= d.B && Fp >= d.F && ld_fb >= d.F && Rp >= d.R,
+                "train sb input: NULL pointer / padded sizes below (B, F, rows)");
+    if (workspace_bytes < tr_ws_bytes(d)) {
+        fsn_set_error("train sb input: workspace too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const TrWs w = tr_carve(d, workspace);  // rowsum: left there by fsn_train_fb_input of the same step
+    hipLaunchKernelGGL(tr_fbsum_partial_kernel, dim3((unsigned)d.Tp, (unsigned)d.B), dim3(256), 0, s, fb_out_tm, ld_fb, w.partial, d, Bp);
+    FSN_TRY_LAUNCH("tr_fbsum_partial_kernel");
+    hipLaunchKernelGGL(tr_sb_den_kernel, dim3((unsigned)d.B), dim3(256), 0, s, w.rowsum, w.partial, den, d);
+    FSN_TRY_LAUNCH("tr_sb_den_kernel");
+    const unsigned gx = (unsigned)((Rp + 7) / 8 < 1024 ? (Rp + 7) / 8 : 1024);
+    hipLaunchKernelGGL(tr_sb_input_kernel, dim3(gx, (unsigned)d.Tp), dim3(256), 0, s, mag_tm, fb_out_tm, ld_fb, den, sb_in, d, Bp, Fp, Rp);
+    return fsn_check_launch("tr_sb_input_kernel");
+}
+
+extern "C" int fsn_train_sb_input_backward(const fsn_train_dims* dims, const float* dx, const float* sb_in, int Rp, const float* den,
+                                           const float* fb_out_tm, long ld_fb, int Bp, float* d_fb, long ld_dfb, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+    FsnCallScope scope(stream);
+    TR_REQUIRE_DIMS(dims);
+    const TrDims d = tr_dims(dims);
+    FSN_REQUIRE(dx && sb_in && den && fb_out_tm && d_fb && workspace && Bp >= d.B && ld_fb >= d.F && ld_dfb >= d.F && Rp >= d.R,
+                "train sb input backward: NULL pointer / padded sizes below (B, F, rows)");
+    if (workspace_bytes < tr_ws_bytes(d)) {
+        fsn_set_error("train sb input backward: workspace too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const TrWs w = tr_carve(d, workspace);
+    hipLaunchKernelGGL(tr_sb_bwd_partial_kernel, dim3((unsigned)d.Tp, (unsigned)d.B), dim3(256), 0, s, dx, sb_in, w.partial, d, Rp);
+    FSN_TRY_LAUNCH("tr_sb_bwd_partial_kernel");
+    hipLaunchKernelGGL(tr_sb_bwd_dmu_kernel, dim3((unsigned)d.B), dim3(256), 0, s, w.partial, den, w.dmu, d);
+    FSN_TRY_LAUNCH("tr_sb_bwd_dmu_kernel");
+    hipLaunchKernelGGL(tr_sb_bwd_dfb_kernel, dim3((unsigned)((ld_dfb + 255) / 256), (unsigned)d.Tp, (unsigned)Bp), dim3(256), 0, s, dx, den,
+                       w.dmu, fb_out_tm, ld_fb, d_fb, ld_dfb, d, Bp, Rp);
+    return fsn_check_launch("tr_sb_bwd_dfb_kernel");
+}
+
+extern "C" int fsn_train_mask_out(const fsn_train_dims* dims, const float* y, int Rp, float* mask, void* stream) {
+    FsnCallScope scope(stream);
+    TR_REQUIRE_DIMS(dims);
+    const TrDims d = tr_dims(dims);
+    FSN_REQUIRE(y && mask && Rp >= d.R, "train mask out: NULL pointer / fewer padded rows than rows");
+    hipLaunchKernelGGL(tr_mask_out_kernel, dim3((unsigned)((d.R + 31) / 32), (unsigned)((d.T + 31) / 32)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), y, mask, d, Rp);
+    return fsn_check_launch("tr_mask_out_kernel");
+}
+
+extern "C" int fsn_train_mask_grad(const fsn_train_dims* dims, const float* d_mask, float* dy, int Rp, int ld, void* stream) {
+    FsnCallScope scope(stream);
+    TR_REQUIRE_DIMS(dims);
+    const TrDims d = tr_dims(dims);
+    FSN_REQUIRE(d_mask && dy && Rp >= d.R && ld >= 2, "train mask grad: NULL pointer / bad padded sizes");
+    const size_t n = (size_t)Rp * ld;
+    hipLaunchKernelGGL(tr_mask_grad_kernel, dim3((unsigned)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512), (unsigned)d.Tp), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), d_mask, dy, d, Rp, ld);
+    return fsn_check_launch("tr_mask_grad_kernel");
+}
+
+extern "C" int fsn_train_cirm_target(const fsn_train_dims* dims, const float* noisy_real, const float* noisy_imag,
+                                     const float* clean_real, const float* clean_imag, float* target, void* stream) {
+    FsnCallScope scope(stream);
+    TR_REQUIRE_DIMS(dims);
+    const TrDims d = tr_dims(dims);
+    FSN_REQUIRE(noisy_real && noisy_imag && clean_real && clean_imag && target, "train target: NULL pointer argument");
+    hipLaunchKernelGGL(tr_target_kernel, dim3((unsigned)((d.T + 255) / 256), (unsigned)d.R), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       noisy_real, noisy_imag, clean_real, clean_imag, target, d);
+    return fsn_check_launch("tr_target_kernel");
+}
+
+extern "C" int fsn_scale_by_scalar(const float* x, const float* scale, float* y, size_t n, void* stream) {
+    FsnCallScope scope(stream);
+    FSN_REQUIRE(x && scale && y, "scale: NULL pointer argument");
+    if (n == 0) return FSN_OK;
+    const size_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(tr_scale_kernel, dim3((unsigned)(g < 2048 ? g : 2048)), dim3(256), 0, static_cast<hipStream_t>(stream), x, scale, y, n);
+    return fsn_check_launch("tr_scale_kernel");
+}

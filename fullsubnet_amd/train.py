@@ -3,10 +3,15 @@
 SURVEY §8 row A16: the four LSTM layers (99.9 % of the FLOPs of the step, forward and backward) run
 on libfsn_hip.so through ``LstmLayerFunction`` (forward with saved activations + back-propagation
 through time), the two output layers through ``LinearFunction``, the loss through ``mse_loss`` and
-gradient clipping + Adam through ``optim.ClipAdam``; the thin glue between them (look-ahead pad,
-Laplace norms, sub-band input gather) is autograd-tracked torch tensor algebra, so every gradient of
-the reference's graph is produced.
+gradient clipping + Adam through ``optim.ClipAdam``.  For the shipped configuration (LSTM, offline Laplace norm,
+``fb_num_neighbors = 0``) the glue between them - look-ahead pad, norms, the sub-band input (freq_unfold ++ full-band
+output, normalised, band-dropped) forward and backward, the mask's reshape, the cIRM target - runs on
+hand-written kernels too (``FullSubNetTrainFunction``, csrc/train_glue_kernels.hip): one autograd node for the whole
+model, no tensor-algebra kernel of the host framework in the step.  Other configurations take the same graph with the
+glue as autograd-tracked torch tensor algebra, so every gradient of the reference's graph is produced either way.
 """
+import ctypes
+
 import torch
 import torch.nn.functional as functional
 
@@ -325,13 +330,162 @@ class SubbandInputOffline(torch.autograd.Function):
         return d_x, d_fb, None, None
 
 
+_ONE = {}
+
+
+def _one(device):
+    """A device scalar 1.0 (made once per device: no fill kernel per step)."""
+    key = str(device)
+    if key not in _ONE:
+        _ONE[key] = torch.ones((), dtype=torch.float32, device=device)
+    return _ONE[key]
+
+
+def _dup(t):
+    """A second buffer with the same values through the library (b_ih and b_hh receive the same gradient, and the fused
+    optimizer clips gradients in place: they must not share storage)."""
+    out = torch.empty_like(t)
+    _lib.check(_lib.lib().fsn_scale_by_scalar(_lib.dev_ptr(t), _lib.dev_ptr(_one(t.device)), _lib.dev_ptr(out), t.numel(),
+                                              _lib.stream_ptr(t.device)))
+    return out
+
+
+class FullSubNetTrainFunction(torch.autograd.Function):
+    """fullsubnet/model.py:72-136 as ONE autograd node for the shipped configuration: noisy_mag [B, 1, F, T] ->
+    compressed mask [B, 2, Fs, T] (band-dropped, look-ahead frames removed).  Forward: fsn_train_fb_input ->
+    fsn_lstm2_forward_train + fsn_linear_forward (full-band model, ReLU) -> fsn_train_sb_input -> fsn_lstm2_forward_train +
+    fsn_linear_forward (sub-band model) -> fsn_train_mask_out; backward: the mirror image.  Every tensor in between lives
+    in the time-major, zero-padded layouts the LSTM entries take, written by the kernels themselves (torch.empty only)."""
+
+    @staticmethod
+    def forward(ctx, noisy_mag, look_ahead, nb, groups, arith, *params):
+        L = _lib.lib()
+        if arith not in ("f32", "f16", "bf16"):
+            raise _lib.FsnError(f"training arithmetic {arith!r}: one of 'f32', 'f16', 'bf16'")
+        ar = _lib.ARITH[arith]
+        dev = noisy_mag.device
+        B, _, F, T = noisy_mag.shape
+        Tp = T + look_ahead
+        dims = _lib.TrainDims(B, F, T, look_ahead, nb, groups)
+        dp = ctypes.byref(dims)
+        fs, rows = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(L.fsn_train_rows(dp, ctypes.byref(fs), ctypes.byref(rows)))
+        Fs, R = fs.value, rows.value
+        Bp, Fp, Rp = (B + 15) // 16 * 16, (F + 15) // 16 * 16, (R + 15) // 16 * 16
+        p = [t.detach().contiguous() for t in params]
+        fb, fb_fc, sb, sb_fc = p[0:8], p[8:10], p[10:18], p[18:20]
+        Hf, Hs, Is = fb[1].shape[1], sb[1].shape[1], 2 * nb + 2
+        st = _lib.stream_ptr(dev)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        mag = noisy_mag.detach().reshape(B, F, T)
+        if not mag.is_contiguous():
+            mag = mag.contiguous()
+        gws = _lib.workspace(L.fsn_train_glue_workspace_bytes(dp), dev)
+        x_tm, mag_tm = new(Tp, Bp, Fp), new(Tp, Bp, Fp)
+        _lib.check(L.fsn_train_fb_input(dp, _lib.dev_ptr(mag, "noisy_mag"), _lib.dev_ptr(x_tm), _lib.dev_ptr(mag_tm), Bp, Fp,
+                                        gws.data_ptr(), gws.numel(), st))
+
+        def lstm2(x, ldx, w, N, I, H):
+            h0, h1 = new(Tp, N, H), new(Tp, N, H)
+            nsave = L.fsn_lstm_layer_save_bytes(Tp, N, H)
+            s0, s1 = _lib.workspace(nsave, dev), _lib.workspace(nsave, dev)
+            ws = _lib.workspace(L.fsn_lstm2_train_workspace_bytes(Tp, N, I, H, ar), dev)
+            _lib.check(L.fsn_lstm2_forward_train(_lib.dev_ptr(x), ldx, *[_lib.dev_ptr(t) for t in w], Tp, N, I, H, _lib.dev_ptr(h0),
+                                                 _lib.dev_ptr(h1), s0.data_ptr(), s1.data_ptr(), nsave, ws.data_ptr(), ws.numel(), ar, st))
+            return h0, h1, s0, s1
+
+        def linear(x, ldx, w, b, rows_, I, O, relu):
+            y = new(rows_, O)
+            ws = _lib.workspace(L.fsn_linear_workspace_bytes(rows_, I, O), dev)
+            _lib.check(L.fsn_linear_forward(_lib.dev_ptr(x), ldx, _lib.dev_ptr(w), _lib.dev_ptr(b), rows_, I, O, relu, _lib.dev_ptr(y),
+                                            ws.data_ptr(), ws.numel(), st))
+            return y
+
+        fh0, fh1, fs0, fs1 = lstm2(x_tm, Fp, fb, Bp, F, Hf)
+        fb_out = linear(fh1, Hf, fb_fc[0], fb_fc[1], Tp * Bp, Hf, F, 1)          # [Tp Bp, F], ReLU
+        sb_in, den = new(Tp, Rp, 32), new(B)
+        _lib.check(L.fsn_train_sb_input(dp, _lib.dev_ptr(mag_tm), _lib.dev_ptr(fb_out), F, Bp, Fp, _lib.dev_ptr(sb_in), Rp,
+                                        _lib.dev_ptr(den), gws.data_ptr(), gws.numel(), st))
+        sh0, sh1, ss0, ss1 = lstm2(sb_in, 32, sb, Rp, Is, Hs)
+        y2 = linear(sh1, Hs, sb_fc[0], sb_fc[1], Tp * Rp, Hs, 2, 0)              # [Tp Rp, 2]
+        mask = new(B, 2, Fs, T)
+        _lib.check(L.fsn_train_mask_out(dp, _lib.dev_ptr(y2), Rp, _lib.dev_ptr(mask), st))
+        ctx.save_for_backward(x_tm, fh0, fh1, fs0, fs1, fb_out, sb_in, den, sh0, sh1, ss0, ss1, gws, *p)
+        ctx.meta = (dims, ar, Tp, Bp, Fp, Rp, Hf, Hs, Is, F)
+        return mask
+
+    @staticmethod
+    def backward(ctx, d_mask):
+        L = _lib.lib()
+        x_tm, fh0, fh1, fs0, fs1, fb_out, sb_in, den, sh0, sh1, ss0, ss1, gws = ctx.saved_tensors[:13]
+        p = ctx.saved_tensors[13:]
+        fb, fb_fc, sb, sb_fc = p[0:8], p[8:10], p[10:18], p[18:20]
+        dims, ar, Tp, Bp, Fp, Rp, Hf, Hs, Is, F = ctx.meta
+        dp = ctypes.byref(dims)
+        dev = d_mask.device
+        st = _lib.stream_ptr(dev)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        dm = d_mask if d_mask.is_contiguous() else d_mask.contiguous()
+
+        def linear_bwd(dy, lddy, x, ldx, w, rows_, I, O):
+            dx, dw, db = new(rows_, ldx), torch.empty_like(w), new(O)
+            ws = _lib.workspace(L.fsn_linear_workspace_bytes(rows_, I, O), dev)
+            _lib.check(L.fsn_linear_backward(_lib.dev_ptr(dy), lddy, _lib.dev_ptr(x), ldx, _lib.dev_ptr(w), rows_, I, O, _lib.dev_ptr(dx),
+                                             ldx, _lib.dev_ptr(dw), _lib.dev_ptr(db), ws.data_ptr(), ws.numel(), st))
+            return dx, dw, db
+
+        def lstm2_bwd(dh, x, ldx, w, h0, h1, s0, s1, N, I, H, need_dx):
+            dx = new(Tp, N, ldx) if need_dx else None
+            dw = [torch.empty_like(w[k]) for k in (0, 1, 4, 5)]
+            db0, db1 = new(4 * H), new(4 * H)
+            ws = _lib.workspace(L.fsn_lstm2_bwd_workspace_bytes(Tp, N, I, H, ar), dev)
+            _lib.check(L.fsn_lstm2_backward(
+                _lib.dev_ptr(dh), _lib.dev_ptr(x), ldx, _lib.dev_ptr(w[0]), _lib.dev_ptr(w[1]), _lib.dev_ptr(w[4]), _lib.dev_ptr(w[5]),
+                Tp, N, I, H, _lib.dev_ptr(h0), _lib.dev_ptr(h1), s0.data_ptr(), s1.data_ptr(), _lib.dev_ptr(dx, allow_none=True), ldx,
+                _lib.dev_ptr(dw[0]), _lib.dev_ptr(dw[1]), _lib.dev_ptr(db0), _lib.dev_ptr(dw[2]), _lib.dev_ptr(dw[3]), _lib.dev_ptr(db1),
+                ws.data_ptr(), ws.numel(), ar, st))
+            return dx, [dw[0], dw[1], db0, _dup(db0), dw[2], dw[3], db1, _dup(db1)]
+
+        dy2 = new(Tp * Rp, 16)
+        _lib.check(L.fsn_train_mask_grad(dp, _lib.dev_ptr(dm, "d_mask"), _lib.dev_ptr(dy2), Rp, 16, st))
+        dsh1, d_sfw, d_sfb = linear_bwd(dy2, 16, sh1, Hs, sb_fc[0], Tp * Rp, Hs, 2)
+        dx_sb, g_sb = lstm2_bwd(dsh1, sb_in, 32, sb, sh0, sh1, ss0, ss1, Rp, Is, Hs, True)
+        d_fb = new(Tp * Bp, Fp)
+        _lib.check(L.fsn_train_sb_input_backward(dp, _lib.dev_ptr(dx_sb), _lib.dev_ptr(sb_in), Rp, _lib.dev_ptr(den), _lib.dev_ptr(fb_out),
+                                                 F, Bp, _lib.dev_ptr(d_fb), Fp, gws.data_ptr(), gws.numel(), st))
+        dfh1, d_ffw, d_ffb = linear_bwd(d_fb, Fp, fh1, Hf, fb_fc[0], Tp * Bp, Hf, F)
+        _, g_fb = lstm2_bwd(dfh1, x_tm, Fp, fb, fh0, fh1, fs0, fs1, Bp, F, Hf, False)
+        return (None, None, None, None, None, *g_fb, d_ffw, d_ffb, *g_sb, d_sfw, d_sfb)
+
+
+def fused_train_supported(model, noisy_mag):
+    """The configuration FullSubNetTrainFunction is built for: the shipped FullSubNet TOMLs (LSTM, offline Laplace norm, no
+    full-band neighbours, ReLU / linear output layers), a ROCm input that does not itself need a gradient."""
+    return (getattr(model, "_fused", False) and model.norm_type == "offline_laplace_norm" and noisy_mag.is_cuda
+            and not noisy_mag.requires_grad and 2 * model.sb_num_neighbors + 2 <= 32
+            and model.fb_model.sequence_model.num_layers == 2 and model.sb_model.sequence_model.num_layers == 2
+            and getattr(model, "fused_training_graph", True))
+
+
+def _fused_params(model):
+    out = []
+    for blk in (model.fb_model, model.sb_model):
+        lstm = blk.sequence_model
+        out += [getattr(lstm, f"{n}_l{k}") for k in (0, 1) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        out += [blk.fc_output_layer.weight, blk.fc_output_layer.bias]
+    return out
+
+
 def forward_train(model, noisy_mag):
     """fullsubnet/model.py:72-136 under autograd (drop_band included), LSTMs on the HIP kernels.
     noisy_mag [B, 1, F, T] -> [B, 2, F // g, T]."""
+    arith = getattr(model, "train_arithmetic", "f32")  # "f16" / "bf16": autocast arithmetic (Trainer, use_amp)
+    if fused_train_supported(model, noisy_mag):  # the whole model as one autograd node on the library's kernels
+        return FullSubNetTrainFunction.apply(noisy_mag, model.look_ahead, model.sb_num_neighbors, model.num_groups_in_drop_band,
+                                             arith, *_fused_params(model))
     x = functional.pad(noisy_mag, [0, model.look_ahead])
     B, C, F, Tp = x.shape
     fb_in = _norm(x, model.norm_type).reshape(B, F, Tp)
-    arith = getattr(model, "train_arithmetic", "f32")  # "f16" / "bf16": autocast arithmetic (Trainer, use_amp)
     h = lstm_stack(fb_in.permute(2, 0, 1), model.fb_model.sequence_model, arith)  # [Tp, B, Hf]
     fc = model.fb_model.fc_output_layer
     fb_out = LinearFunction.apply(h, fc.weight, fc.bias, True)  # ReLU(h W^T + b): [Tp, B, F]
@@ -379,6 +533,11 @@ class MseLossFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         (grad,) = ctx.saved_tensors
+        if dloss.is_cuda and dloss.dtype == torch.float32 and dloss.numel() == 1:  # grad * dloss (a device scalar) on the library
+            out = torch.empty_like(grad)
+            _lib.check(_lib.lib().fsn_scale_by_scalar(_lib.dev_ptr(grad), _lib.dev_ptr(dloss.reshape(1).contiguous()), _lib.dev_ptr(out),
+                                                      grad.numel(), _lib.stream_ptr(grad.device)))
+            return out, None
         return grad * dloss, None
 
 
@@ -396,20 +555,35 @@ def train_step(model, optimizer, noisy, clean, n_fft=512, hop_length=256, win_le
     transforms and the cIRM target stay fp32 (outside the autocast context there too, trainer.py:46-54), the LSTM
     products take 16-bit operands, the loss is scaled before backward, and scaler.step / scaler.update skip the
     update and back the scale off when a gradient is not finite."""
-    loss_function = loss_function or (lambda target, pred: mse_loss(pred, target))
     optimizer.zero_grad()
     noisy_mag, _, noisy_real, noisy_imag = stft(noisy, n_fft, hop_length, win_length, return_phase=False)
     _, _, clean_real, clean_imag = stft(clean, n_fft, hop_length, win_length, return_phase=False)
-    cirm = build_complex_ideal_ratio_mask(noisy_real, noisy_imag, clean_real, clean_imag)  # [B, F, T, 2]
     inner = model.module if hasattr(model, "module") else model
     # fullsubnet/trainer.py:53 drops bands of the target like the model does of its input; the sibling trainers
     # (fast_fullsubnet/trainer.py:33-76, fullband_baseline/trainer.py) have no band dropping: their models carry no
     # `num_groups_in_drop_band` and the target stays whole
     groups = getattr(inner, "num_groups_in_drop_band", None)
-    if groups is not None:
-        cirm = drop_band(cirm.permute(0, 3, 1, 2), groups).permute(0, 2, 3, 1)
-    crm = model(noisy_mag.unsqueeze(1)).permute(0, 2, 3, 1)
-    loss = loss_function(cirm, crm)
+    x_in = noisy_mag.unsqueeze(1)
+    if loss_function is None and groups is not None and inner.training and fused_train_supported(inner, x_in):
+        # the target straight into the prediction's layout [B, 2, Fs, T] (mask.py:7-44 + drop_band, one kernel): the mean
+        # squared error does not care about the element order as long as both sides share it
+        B, F, T = noisy_mag.shape
+        assert B > groups, (  # drop_band's own check (feature.py:322-323): the reference's step fails the same way
+            f"Batch size = {B}, num_groups = {groups}. The batch size should larger than the num_groups.")
+        dims = _lib.TrainDims(B, F, T, inner.look_ahead, inner.sb_num_neighbors, groups)
+        crm = model(x_in)
+        cirm = torch.empty_like(crm)
+        _lib.check(_lib.lib().fsn_train_cirm_target(ctypes.byref(dims), *[_lib.dev_ptr(t.contiguous()) for t in
+                                                                       (noisy_real, noisy_imag, clean_real, clean_imag)],
+                                                    _lib.dev_ptr(cirm), _lib.stream_ptr(cirm.device)))
+        loss = mse_loss(crm, cirm)
+    else:
+        loss_function = loss_function or (lambda target, pred: mse_loss(pred, target))
+        cirm = build_complex_ideal_ratio_mask(noisy_real, noisy_imag, clean_real, clean_imag)  # [B, F, T, 2]
+        if groups is not None:
+            cirm = drop_band(cirm.permute(0, 3, 1, 2), groups).permute(0, 2, 3, 1)
+        crm = model(x_in).permute(0, 2, 3, 1)
+        loss = loss_function(cirm, crm)
     if scaler is not None and scaler.is_enabled():
         scaler.scale(loss).backward()
         if isinstance(optimizer, ClipAdam):
@@ -424,7 +598,7 @@ def train_step(model, optimizer, noisy, clean, n_fft=512, hop_length=256, win_le
             scaler.step(optimizer)
         scaler.update()
         return loss.detach()
-    loss.backward()
+    torch.autograd.backward(loss, grad_tensors=_one(loss.device))  # loss.backward() without its ones_like fill kernel
     if isinstance(optimizer, ClipAdam):  # clip + Adam fused (two launches)
         for group in optimizer.param_groups:
             group["clip_grad_norm_value"] = clip_grad_norm_value

@@ -327,6 +327,52 @@ size_t fsn_mse_loss_workspace_bytes(size_t n);
 int fsn_mse_loss(const float* input, const float* target, size_t n, float* loss, float* grad_input,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+
+/* ---- glue of the TRAINING graph (fullsubnet/model.py:72-136 under autograd, fullsubnet/trainer.py:41-71) ----------------
+ * Everything between the transforms, the LSTM / Linear entries above and the loss, as kernels (train_glue_kernels.hip):
+ * no tensor-algebra kernel of the host framework is left in a training step.  Dimensions: B utterances, F bins, T frames,
+ * look_ahead (model.py:13), nb = sb_num_neighbors (model.py:16), groups = num_groups_in_drop_band (model.py:22; band
+ * dropping applies when B > 1 and groups > 1, audio_zen/acoustics/feature.py:309-345).  Row order of the sub-band
+ * tensors = drop_band's: group i holds samples i, i + g, ... at bins i, i + g, ... (< F - F % g), groups concatenated
+ * along the batch axis: row r = b_out Fs + fs.  Time-major tensors: [Tp = T + look_ahead][rows padded][columns padded].
+ *
+ * fsn_train_rows            Fs (bins per band-dropped sample) and R = B Fs (sub-band rows).
+ * fsn_train_fb_input        mag [B][F][T] -> x_tm [Tp][Bp][Fp] = pad(mag) / (mean_b + 1e-5) (model.py:85-95: look-ahead pad,
+ *                           base_model.py:204-218 offline Laplace norm over [1, F, Tp]), zeros beyond (B, F): the input of
+ *                           fsn_lstm2_forward_train (ldx = Fp); mag_tm [Tp][Bp][Fp] = the padded magnitude itself, for
+ *                           fsn_train_sb_input.  Leaves the per-bin sums in `workspace` (same buffer for the whole step).
+ * fsn_train_sb_input        freq_unfold(mag, nb) ++ fb_out, / (mean + 1e-5), rows of drop_band (model.py:98-125;
+ *                           base_model.py:14-46) -> sb_in [Tp][Rp][32] (columns 2 nb + 2 .. 31 and rows beyond R zero);
+ *                           fb_out_tm [Tp][Bp][ld_fb] = the full-band output layer's result (fsn_linear_forward, ReLU);
+ *                           den [B] = the divisor per utterance (kept for the backward).  The mean of the unfolded tensor
+ *                           is taken from per-bin sums and window multiplicities; the unfolded tensor is never formed.
+ * fsn_train_sb_input_backward  dx [Tp][Rp][32] (d loss / d sb_in, from fsn_lstm2_backward) -> d_fb [Tp Bp][ld_dfb]: the
+ *                           gradient of the full-band output layer's PRE-activation (through the ReLU: fb_out > 0), directly
+ *                           (column 2 nb + 1 of the kept rows) and through the mean - the padded dy fsn_linear_backward takes.
+ * fsn_train_mask_out        y [Tp][Rp][2] (fsn_linear_forward of the sub-band output layer) -> mask [B][2][Fs][T], the
+ *                           look-ahead frames dropped (model.py:129-135).   fsn_train_mask_grad: its adjoint, d_mask ->
+ *                           dy [Tp][Rp][ld] (zeros in the look-ahead frames and the padding).
+ * fsn_train_cirm_target     compressed cIRM of (noisy, clean) spectra [B][F][T] (mask.py:7-44), band-dropped like the
+ *                           prediction, in its layout [B][2][Fs][T] (trainer.py:51-53).
+ * fsn_scale_by_scalar       y = x * (*scale), scale a device scalar (the incoming gradient of the loss). */
+typedef struct fsn_train_dims {
+    int B, F, T, look_ahead, nb, groups;
+} fsn_train_dims;
+int fsn_train_rows(const fsn_train_dims* dims, int* Fs, int* R);
+size_t fsn_train_glue_workspace_bytes(const fsn_train_dims* dims);
+int fsn_train_fb_input(const fsn_train_dims* dims, const float* mag, float* x_tm, float* mag_tm, int Bp, int Fp,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int fsn_train_sb_input(const fsn_train_dims* dims, const float* mag_tm, const float* fb_out_tm, long ld_fb, int Bp, int Fp,
+                       float* sb_in, int Rp, float* den, void* workspace, size_t workspace_bytes, void* stream);
+int fsn_train_sb_input_backward(const fsn_train_dims* dims, const float* dx, const float* sb_in, int Rp, const float* den,
+                                const float* fb_out_tm, long ld_fb, int Bp, float* d_fb, long ld_dfb, void* workspace,
+                                size_t workspace_bytes, void* stream);
+int fsn_train_mask_out(const fsn_train_dims* dims, const float* y, int Rp, float* mask, void* stream);
+int fsn_train_mask_grad(const fsn_train_dims* dims, const float* d_mask, float* dy, int Rp, int ld, void* stream);
+int fsn_train_cirm_target(const fsn_train_dims* dims, const float* noisy_real, const float* noisy_imag,
+                          const float* clean_real, const float* clean_imag, float* target, void* stream);
+int fsn_scale_by_scalar(const float* x, const float* scale, float* y, size_t n, void* stream);
+
 /* fullsubnet/trainer.py:65-69: torch.nn.utils.clip_grad_norm_(parameters, max_norm) followed by
  * torch.optim.Adam.step() (train.py:55-59: lr, betas, eps 1e-8, no weight decay / amsgrad), fused into
  * two multi-tensor launches.  The arrays are HOST arrays of n_tensors device pointers / element

@@ -146,6 +146,49 @@ def test_train_step_vs_reference_and_oracle(fsn, golden_dir, name):
         assert loss2.item() < loss.item()
 
 
+@pytest.mark.parametrize("B,groups,T,arith", [(3, 2, 7, "f32"), (5, 3, 6, "f32"), (1, 2, 9, "f32"), (4, 1, 5, "f32")])
+def test_fused_training_graph_vs_the_tensor_algebra_graph(fsn, B, groups, T, arith):
+    """FullSubNetTrainFunction (csrc/train_glue_kernels.hip: look-ahead pad + norm, sub-band input forward / backward, mask
+    reshape and its gradient as kernels, one autograd node for the model) against the same graph with the glue as
+    autograd-tracked tensor algebra (model.fused_training_graph = False; itself held to the reference's goldens): odd batch
+    sizes (uneven drop_band groups), three groups, a single utterance (no band dropping), groups = 1; the band-dropped cIRM
+    target kernel against drop_band(build_complex_ideal_ratio_mask)."""
+    from fullsubnet_amd.train import forward_train, mse_loss
+    params = O.make_params(seed=B * 10 + groups, gain=1.5)
+    rng = np.random.default_rng(T)
+    mag = torch.from_numpy((np.abs(rng.standard_normal((B, 1, 257, T))) + 0.05).astype(np.float32)).cuda()
+    results = []
+    for fused in (True, False):
+        model = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=groups, **MODEL_KW)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        model = model.cuda().train()
+        model.fused_training_graph = fused
+        out = forward_train(model, mag)
+        w = torch.from_numpy(rng.standard_normal(tuple(out.shape)).astype(np.float32)).cuda() if not results else results[0][2]
+        (out * w).sum().backward()
+        results.append((out.detach(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}, w))
+    (y1, g1, _), (y0, g0, _) = results
+    assert y1.shape == y0.shape
+    assert (y1 - y0).abs().max().item() <= 2e-5 * max(y0.abs().max().item(), 1.0)
+    for k in g0:
+        scale = max(g0[k].abs().max().item(), 1e-6)
+        err = (g1[k] - g0[k]).abs().max().item()
+        assert err <= 2e-4 * scale, (k, err, scale)
+    if B <= groups:  # drop_band refuses such a batch (feature.py:322-323), and with it the reference's training step
+        return
+    # the training target in the prediction's layout
+    import ctypes
+    from fullsubnet_amd import _lib
+    spec = [torch.from_numpy(rng.standard_normal((B, 257, T)).astype(np.float32)).cuda() for _ in range(4)]
+    want = fsn.build_complex_ideal_ratio_mask(*spec)                      # [B, F, T, 2]
+    want = fsn.drop_band(want.permute(0, 3, 1, 2), groups)                # [B, 2, Fs, T]
+    got = torch.empty_like(y1)
+    dims = _lib.TrainDims(B, 257, T, 2, 15, groups)
+    _lib.check(_lib.lib().fsn_train_cirm_target(ctypes.byref(dims), *[_lib.dev_ptr(t) for t in spec], _lib.dev_ptr(got),
+                                                _lib.stream_ptr(got.device)))
+    assert got.shape == want.shape and torch.equal(got, want.contiguous())
+
+
 @pytest.mark.parametrize("R,I,O,relu", [(68, 512, 257, True), (33, 384, 2, False), (16, 32, 48, False)])
 def test_linear_forward_backward(fsn, R, I, O, relu):
     from fullsubnet_amd.train import LinearFunction
