@@ -283,6 +283,140 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     }
 }
 
+// The same product under the 16-bit training arithmetic, built for it (round 4).  With 16-bit operands the matrix work of
+// a 192 x 192 tile is 36 instructions of 8 cycles per 16 k, and gemm_tn_kernel feeds them with 48 DWORD loads per lane
+// (a lane's operand is four k of one column: four rows of a K-major matrix) - it ran at 14 % of the 16-bit peak, bound
+// by its load instructions.  Here both operand slabs of a 32-k chunk are fetched as 16-BYTE row pieces (12 per thread
+// instead of 96 dword loads), rounded to 16 bits once on the way into LDS - [k step][column tile][16 k][16 columns], k
+// rows of 32 bytes - and every wave reads its operands with ds_read_b64_tr_b16 (gfx950's transposing LDS read: lane (lr,
+// lq) of a 16-lane group addresses row lr / 4, column quad lr % 4 of a [4 k][16 columns] block and receives column lr of
+// the four rows = the matrix instruction's operand A[m = lr][k = 4 lq + j]; measured, tools/probe_tr16.hip).  Two LDS
+// stages, one barrier per chunk, the next chunk's loads in flight under the current chunk's matrix work.  Same products
+// (operands rounded exactly as fsn_mma_k16 rounds them), same k order, same K splits: bit-identical partial sums.  The
+// column sums of A (the bias gradient) ride on the staging threads' fp32 values.
+typedef short tq_s16x4 __attribute__((ext_vector_type(4)));
+constexpr int TQ_TS = 544;             // bytes per [16 k][16 columns] 16-bit subtile (512 + 32: spreads the staging writes over banks)
+constexpr int TQ_OP = 2 * 12 * TQ_TS;  // one operand of one chunk: 2 k steps x 12 column tiles
+constexpr int TQ_STAGE = 2 * TQ_OP;    // A then B
+constexpr int TQ_LDS = 2 * TQ_STAGE + 4 * 48 * 16;
+constexpr int TQ_PF = 2;               // chunks of operand rows in flight per staging thread
+template <int AR>
+__global__ __launch_bounds__(256) void gemm_tn16_kernel(const float* __restrict__ A, long lda, const float* __restrict__ B,
+                                                        long ldb, float* __restrict__ part, int M, int Nc, long K,
+                                                        long k_per_split, int m_blocks, int n_blocks,
+                                                        float* __restrict__ asum_part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tq_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    // all tiles of a K split on ONE XCD (block b runs on XCD b % 8: observed, speed only), as gemm_tn_kernel's grouped form
+    const int tiles = m_blocks * n_blocks, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int tile = jb % tiles, split = xcd * ((int)(gridDim.x >> 3) / tiles) + jb / tiles;
+    const int mb = tile / n_blocks, nb = tile % n_blocks;
+    const int m0 = mb * 192, n0 = nb * 192;
+    const long k_begin = (long)split * k_per_split;
+    long k_end = k_begin + k_per_split;
+    k_end = k_end < K ? k_end : K;
+    const int chunks = (int)((k_end - k_begin + 31) >> 5);
+
+    // staging: thread t < 192 owns the 16-byte piece q = t % 48 of the 192 columns for the k rows 8 (t / 48) + i, i < 8
+    const bool stager = tid < 192;
+    const int q = tid % 48, kp = (tid / 48) & 3;
+    const float* ap = A + (k_begin + kp * 8) * lda + m0 + 4 * q;
+    const float* bp = B + (k_begin + kp * 8) * ldb + n0 + 4 * q;
+    // TQ_PF chunks of operand rows in flight per staging thread (register sets, statically indexed): the slabs come from
+    // HBM (3 GB per product, each element read once: PMC FETCH_SIZE = 3.4 GB), and a chunk's matrix work is ~0.25 us - one
+    // chunk ahead left the kernel at 2.3 TB/s, latency-bound; two: 2.65.  Three do not fit the 256 architectural
+    // registers a load can target beside the operands (the accumulators live in the other half of the file).
+    f32x4 va[TQ_PF][8], vb[TQ_PF][8], asum = {0.f, 0.f, 0.f, 0.f};
+    auto load = [&](int set, int c) {
+        if (!stager) return;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long k = k_begin + (long)c * 32 + kp * 8 + i;
+            const bool ok = k < k_end;
+            va[set][i] = ok ? *reinterpret_cast<const f32x4*>(ap + ((long)c * 32 + i) * lda) : f32x4{0.f, 0.f, 0.f, 0.f};
+            vb[set][i] = ok ? *reinterpret_cast<const f32x4*>(bp + ((long)c * 32 + i) * ldb) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store = [&](int set, int stage) {
+        if (!stager) return;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int kk = kp * 8 + i;
+            unsigned char* d = tq_lds + stage * TQ_STAGE + ((kk >> 4) * 12 + (q >> 2)) * TQ_TS + (kk & 15) * 32 + (q & 3) * 8;
+            *reinterpret_cast<fsn_u32x2*>(d) = __builtin_bit_cast(fsn_u32x2, fsn_operand<AR>(va[set][i]));
+            *reinterpret_cast<fsn_u32x2*>(d + TQ_OP) = __builtin_bit_cast(fsn_u32x2, fsn_operand<AR>(vb[set][i]));
+            asum += va[set][i];
+        }
+    };
+    f32x4 acc[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int lane_off = (4 * lq + (lr >> 2)) * 32 + (lr & 3) * 8;
+    auto tr = [&](const unsigned char* p) {
+        return __builtin_bit_cast(typename FsnOperand<AR>::type,
+                                  __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tq_s16x4*)p));
+    };
+    auto compute = [&](int stage) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            typename FsnOperand<AR>::type a[6], b[6];
+            const unsigned char* base = tq_lds + stage * TQ_STAGE + ks * 12 * TQ_TS + lane_off;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                a[i] = tr(base + (wm * 6 + i) * TQ_TS);
+                b[i] = tr(base + TQ_OP + (wn * 6 + i) * TQ_TS);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[i][j] = fsn_mma_k16<AR>(a[i], b[j], acc[i][j]);
+        }
+    };
+    // chunk c lives in register set c % TQ_PF and LDS stage c & 1; rows beyond k_end (and whole chunks beyond the last) load zeros
+#pragma unroll
+    for (int d = 0; d < TQ_PF; ++d) load(d, d);
+    store(0, 0);
+    __syncthreads();
+    for (int c0 = 0; c0 < chunks; c0 += 2 * TQ_PF) {  // 2 TQ_PF: both the register set and the LDS stage of a chunk are static
+#pragma unroll
+        for (int d = 0; d < 2 * TQ_PF; ++d) {
+            const int c = c0 + d;
+            if (c < chunks) {  // uniform
+                load(d % TQ_PF, c + TQ_PF);           // set of chunk c (already in LDS) is free: chunk c + TQ_PF takes it
+                compute(d & 1);
+                store((d + 1) % TQ_PF, (d + 1) & 1);  // chunk c + 1 (zeros beyond the end) into the other stage
+                __syncthreads();
+            }
+        }
+    }
+
+    float* out = part + (long)split * M * Nc;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + (wm * 6 + i) * 16 + 4 * lq + r, n = n0 + (wn * 6 + j) * 16 + lr;
+                out[(long)m * Nc + n] = acc[i][j][r];
+            }
+    if (asum_part && nb == 0) {  // the four k phases of a column quad meet in a fixed order
+        f32x4* red = reinterpret_cast<f32x4*>(tq_lds + 2 * TQ_STAGE);
+        if (stager) red[kp * 48 + q] = asum;
+        __syncthreads();
+        if (tid < 48) {
+            f32x4 v = red[tid];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) v += red[k * 48 + tid];
+            *reinterpret_cast<f32x4*>(asum_part + (long)split * M + m0 + 4 * tid) = v;
+        }
+    }
+}
+
 // column sums riding on gemm_tn: sum of the split partials (fixed order) + the K % 16 tail rows
 __global__ void tn_colsum_reduce_kernel(const float* __restrict__ asum_part, float* __restrict__ out, int M, int splits,
                                         const float* __restrict__ A, long lda, long k_tail0, long K) {
@@ -484,7 +618,22 @@ int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float
             attr_set[arith] = true;
         }
         const dim3 grid((unsigned)(p.m_blocks * p.n_blocks * p.splits));
-        if (p.square) {
+        if (p.square && arith != FSN_ARITH_F32 && lda % 4 == 0 && ldb % 4 == 0 && ((size_t)A & 15) == 0 && ((size_t)B & 15) == 0) {
+            // the 16-bit arithmetic's own kernel: 16-byte operand loads, transposing LDS reads
+            auto k16 = arith == FSN_ARITH_F16 ? gemm_tn16_kernel<FSN_ARITH_F16> : gemm_tn16_kernel<FSN_ARITH_BF16>;
+            static bool k16_set[4] = {false, false, false, false};
+            if (!k16_set[arith]) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(k16), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)kTnOnePerCu) != hipSuccess) {
+                    fsn_set_error("gemm_tn: cannot reserve %zu bytes of LDS", kTnOnePerCu);
+                    return FSN_ERR_LAUNCH;
+                }
+                k16_set[arith] = true;
+            }
+            static_assert(TQ_LDS <= (int)kTnOnePerCu, "the reservation that keeps one workgroup per CU holds the stages");
+            hipLaunchKernelGGL(k16, grid, dim3(256), kTnOnePerCu, s, A, lda, B, ldb, part, M, Nc, K16, p.k_per_split, p.m_blocks,
+                               p.n_blocks, asum_part);
+        } else if (p.square) {
             auto square = arith == FSN_ARITH_F16    ? gemm_tn_kernel<6, 6, 2, 2, FSN_ARITH_F16>
                           : arith == FSN_ARITH_BF16 ? gemm_tn_kernel<6, 6, 2, 2, FSN_ARITH_BF16>
                                                     : gemm_tn_kernel<6, 6, 2, 2, FSN_ARITH_F32>;
