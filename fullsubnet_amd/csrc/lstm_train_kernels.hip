@@ -159,14 +159,13 @@ __global__ __launch_bounds__(NW * 64) void bptt_step_kernel(const float* __restr
 // chunk: 16 lanes read 64 contiguous bytes of one k row, the row base is wave-uniform (SGPR) and
 // the lane part a fixed 32-bit offset.  Out-of-range columns are clamped on load and never stored.
 // AR: arithmetic of the products (fsn_mma_k16): the lane's four k of a chunk ARE the 16-bit instruction's operand.
-template <int RTW, int CTW, int WM, int WN, int AR = FSN_ARITH_F32>
+template <int RTW, int CTW, int WM, int WN, int AR = FSN_ARITH_F32, int PF = 2>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, long lda,
                                                       const float* __restrict__ B, long ldb,
                                                       float* __restrict__ part, int M, int Nc, long K, long k_per_split,
                                                       int m_blocks, int n_blocks, float* __restrict__ asum_part,
                                                       int xcd_grouped) {
-    constexpr int PF = 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;  // PF: operand chunks in flight (register ring)
     const int lr = lane & 15, lq = lane >> 4;
     const int wm = wave / WN, wn = wave % WN;
     int tile = blockIdx.x % (m_blocks * n_blocks), split = blockIdx.x / (m_blocks * n_blocks);
@@ -259,7 +258,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (k_main < chunks) consume(0);  // PF == 2: at most one left-over chunk, already in slot 0
+#pragma unroll
+    for (int p = 0; p < PF - 1; ++p)  // the left-over chunks (fewer than PF) are already in slots 0 ..
+        if (k_main + p < chunks) consume(p);
 
     float* out = part + (long)split * M * Nc;
 #pragma unroll
@@ -528,6 +529,9 @@ TnPlan tn_plan(int M, int Nc, long K, int arith = FSN_ARITH_F32, bool allow_squa
     p.splits = (int)((K + p.k_per_split - 1) / p.k_per_split);
     return p;
 }
+#ifndef FSN_TN_PF32
+#define FSN_TN_PF32 3  // operand chunks in flight of the fp32 192 x 192 form (measured r04: 2 -> 3.76 ms, 3 -> ?)
+#endif
 constexpr size_t kTnOnePerCu = 96 * 1024;  // LDS reservation (never touched): one workgroup per CU
 constexpr long kColsumRows = 2048;
 // rows per block of a column-sum launch: 2048, or fewer when that would leave most of the chip idle - the full-band
@@ -636,7 +640,7 @@ int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float
         } else if (p.square) {
             auto square = arith == FSN_ARITH_F16    ? gemm_tn_kernel<6, 6, 2, 2, FSN_ARITH_F16>
                           : arith == FSN_ARITH_BF16 ? gemm_tn_kernel<6, 6, 2, 2, FSN_ARITH_BF16>
-                                                    : gemm_tn_kernel<6, 6, 2, 2, FSN_ARITH_F32>;
+                                                    : gemm_tn_kernel<6, 6, 2, 2, FSN_ARITH_F32, FSN_TN_PF32>;
             static bool sq_set[4] = {false, false, false, false};
             if (!sq_set[arith]) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(square), hipFuncAttributeMaxDynamicSharedMemorySize,
