@@ -530,7 +530,7 @@ TnPlan tn_plan(int M, int Nc, long K, int arith = FSN_ARITH_F32, bool allow_squa
     return p;
 }
 #ifndef FSN_TN_PF32
-#define FSN_TN_PF32 3  // operand chunks in flight of the fp32 192 x 192 form (measured r04: 2 -> 3.76 ms, 3 -> ?)
+#define FSN_TN_PF32 2  // operand chunks in flight of the fp32 192 x 192 form (measured r04: 2 -> 3.76 ms, 3 -> 3.72: not latency-bound)
 #endif
 constexpr size_t kTnOnePerCu = 96 * 1024;  // LDS reservation (never touched): one workgroup per CU
 constexpr long kColsumRows = 2048;
