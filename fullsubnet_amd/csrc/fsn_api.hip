@@ -86,6 +86,7 @@ static std::mutex g_ctx_mutex;
 static std::map<std::pair<int, hipStream_t>, StreamCtx*> g_ctx;
 static std::atomic<int> g_persist_mode{0};          // fsn_set_persistent_mode: 0 auto, 1 never
 static std::atomic<int> g_g16_off{0};               // fsn_debug_g16_kernels(0): the fp32-era group kernels also under 16-bit arithmetic
+static std::atomic<int> g_tn16h_off{0};             // fsn_debug_g16_kernels(2): ... only the weight-gradient products of round 3
 static std::atomic<int> g_persist_timeout_ms{20000};  // fsn_set_persistent_timeout_ms
 
 // Persistent kernels whose workgroups wait for each other (the group kernel, the full-band chain) need ALL their
@@ -430,7 +431,8 @@ extern "C" int fsn_debug_tn_plan(int M, int Nc, long K, int arith, int* splits, 
 // Test / measurement hook: 0 = the fp32-era group kernels also under the 16-bit training arithmetic (A/B against
 // lstm_group16_kernels.hip), 1 (default) = the 16-bit arithmetic's own kernels where they apply.
 extern "C" int fsn_debug_g16_kernels(int on) {
-    g_g16_off.store(on ? 0 : 1, std::memory_order_relaxed);
+    g_g16_off.store(on == 0 ? 1 : 0, std::memory_order_relaxed);
+    g_tn16h_off.store(on == 2 ? 1 : 0, std::memory_order_relaxed);
     return FSN_OK;
 }
 extern "C" int fsn_debug_persist_stats(unsigned* launches, unsigned* waits, unsigned* unreported) {
@@ -2580,6 +2582,9 @@ extern "C" size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H, int 
         if (arith != FSN_ARITH_F32) {  // lstm_group16_kernels.hip: its packed weights and the rings of exchanged gate-gradient tiles
             cv.take<char>(fsn_lstm2_g16_bwd_weight_bytes());
             cv.take<float>(fsn_lstm2_g16_partial_floats(clusters));
+            cv.take<unsigned short>((size_t)2 * T * N * G);  // 16-bit gate gradients: operands of the weight-gradient products
+            cv.take<unsigned short>((size_t)2 * T * N * H);  // 16-bit hidden sequences
+            cv.take<float>((size_t)2 * clusters * G);        // bias-gradient sums per (layer, cluster)
         }
         return fsn_round_up_sz(cv.off, 256);
     }
@@ -2699,7 +2704,12 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     unsigned short* w16 = arith != FSN_ARITH_F32 ? cv.take<unsigned short>((size_t)3 * H * G) : nullptr;
     void* g16_w = arith != FSN_ARITH_F32 ? cv.take<char>(fsn_lstm2_g16_bwd_weight_bytes()) : nullptr;
     float* partials = arith != FSN_ARITH_F32 ? cv.take<float>(fsn_lstm2_g16_partial_floats(clusters)) : nullptr;
+    unsigned short* dg16 = arith != FSN_ARITH_F32 ? cv.take<unsigned short>((size_t)2 * T * N * G) : nullptr;  // layer 0 | layer 1
+    unsigned short* h16 = arith != FSN_ARITH_F32 ? cv.take<unsigned short>((size_t)2 * T * N * H) : nullptr;    // hseq0 | hseq1
+    float* dbp = arith != FSN_ARITH_F32 ? cv.take<float>((size_t)2 * clusters * G) : nullptr;
     const bool g16 = lstm2_use_g16(arith, clusters, N);
+    // the weight-gradient products from 16-bit operands in memory (needs the shapes' one-workgroup-per-CU plan)
+    const bool tn16h = g16 && T > 1 && fsn_gemm_tn16h_supported(G, H, (long)(T - 1) * N) && !g_tn16h_off.load(std::memory_order_relaxed);
     const float* sv0 = static_cast<const float*>(save0);
     const float* sv1 = static_cast<const float*>(save1);
     // "weights" of dh = dgates W are W^T: out = H columns, k = 4H; nn.LSTM stores exactly that transposed
@@ -2719,9 +2729,15 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     {
         FSN_PERSIST_BEGIN(s);
         if (g16) {  // the 16-bit arithmetic's own kernel (K-split; packs the raw weights its way into w16)
+            // (layer 1's fp32 gate gradients of the cluster rows are not stored: the products below take the 16-bit copies)
             FSN_TRY(fsn_launch_lstm2_g16_bptt(dh1, w_hh1, w_ih1, w_hh0, sv0, sv1, dg0, dg1, partials, flags, g16_w, T, N, clusters,
-                                              H, s, arith));
+                                              H, s, arith, dg16, dg16 + (size_t)T * N * G, dbp, tn16h ? 0 : 1));  // dg16 = layer 0 | layer 1
             FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_g16_status_word(clusters), dg1, (size_t)2 * T * N * G, s));
+            // the 16-bit copies and the bias-gradient sums as well (viewed as floats: every second value of a poisoned copy
+            // is NaN - enough for every product to carry NaN into the gradient norm, on which the optimizer skips)
+            FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_g16_status_word(clusters), reinterpret_cast<float*>(dg16),
+                                         (size_t)T * N * G, s));
+            FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_g16_status_word(clusters), dbp, (size_t)2 * clusters * G, s));
         } else {
             FSN_TRY(fsn_launch_lstm2_group_bptt(dh1, whh1T_p, wih1T_p, whh0T_p, sv0, sv1, dg0, dg1, dxbuf, flags, T, N, clusters,
                                                 H, s, arith, w16));
@@ -2783,8 +2799,29 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
         FSN_TRY(fsn_launch_gemm(a, wih0T_p, c, T * (N / 16), Ipad / 16, G / 16, s));
     }
     // dW_ih = dgates^T X (+ db = its column sums: fp32 adds in every arithmetic), dW_hh = dgates_{1..}^T H_{0..T-2}
-    FSN_TRY(fsn_launch_gemm_tn(dg1, G, hseq0, H, dw_ih1, H, G, H, (long)T * N, scratch, s, db1, arith));
-    FSN_TRY(fsn_launch_gemm_tn(dg0, G, x, ldx, dw_ih0, I, G, I, (long)T * N, scratch, s, db0, arith));
+    if (g16) {
+        // bias gradients = the BPTT launch's cluster sums + the step-by-step rows; those rows' 16-bit gate gradients
+        FSN_TRY(fsn_launch_lstm2_g16_finish(dg1, dg0, dg16 + (size_t)T * N * G, dg16, dbp, clusters, T, N, left, db1, db0, s, arith));
+    }
+    if (tn16h) {
+        // the three large products with both operands 16-bit in memory: dg16 = dg0 | dg1 written by the BPTT kernel, the
+        // hidden sequences converted once (half the HBM bytes of the fp32 operands, LDS-DMA staging, no conversion pass)
+        const size_t TNG = (size_t)T * N * G, TNH = (size_t)T * N * H;
+        const unsigned short *dg16_0 = dg16, *dg16_1 = dg16 + TNG;
+        FSN_TRY(fsn_launch_to16(hseq0, h16, TNH, arith, s));
+        FSN_TRY(fsn_launch_to16(hseq1, h16 + TNH, TNH, arith, s));
+        FSN_TRY(fsn_launch_gemm_tn16h(dg16_1, G, h16, H, dw_ih1, H, G, H, (long)T * N, scratch, s, arith));
+        FSN_TRY(fsn_launch_gemm_tn16h(dg16_1 + (size_t)N * G, G, h16 + TNH, H, dw_hh1, H, G, H, (long)(T - 1) * N, scratch, s, arith));
+        FSN_TRY(fsn_launch_gemm_tn16h(dg16_0 + (size_t)N * G, G, h16, H, dw_hh0, H, G, H, (long)(T - 1) * N, scratch, s, arith));
+        return fsn_launch_gemm_tn(dg0, G, x, ldx, dw_ih0, I, G, I, (long)T * N, scratch, s, nullptr, arith);
+    }
+    if (g16) {  // (no plan for the 16-bit-operand products at this shape: the fp32 buffers; layer 1's were stored in that case)
+        FSN_TRY(fsn_launch_gemm_tn(dg1, G, hseq0, H, dw_ih1, H, G, H, (long)T * N, scratch, s, nullptr, arith));
+        FSN_TRY(fsn_launch_gemm_tn(dg0, G, x, ldx, dw_ih0, I, G, I, (long)T * N, scratch, s, nullptr, arith));
+    } else {
+        FSN_TRY(fsn_launch_gemm_tn(dg1, G, hseq0, H, dw_ih1, H, G, H, (long)T * N, scratch, s, db1, arith));
+        FSN_TRY(fsn_launch_gemm_tn(dg0, G, x, ldx, dw_ih0, I, G, I, (long)T * N, scratch, s, db0, arith));
+    }
     if (T > 1) {
         FSN_TRY(fsn_launch_gemm_tn(dg1 + (size_t)N * G, G, hseq1, H, dw_hh1, H, G, H, (long)(T - 1) * N, scratch, s, nullptr,
                                    arith));

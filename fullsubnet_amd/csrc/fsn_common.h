@@ -265,7 +265,10 @@ int fsn_launch_lstm2_g16_train(const float* x, int I, int Nrows, const float* w_
                                hipStream_t s, int arith);
 int fsn_launch_lstm2_g16_bptt(const float* dh1, const float* w_hh1, const float* w_ih1, const float* w_hh0, const float* save0,
                               const float* save1, float* dg0, float* dg1, float* exchange, unsigned* flags, void* wbuf, int Tp,
-                              int Nrows, int clusters, int H, hipStream_t s, int arith);
+                              int Nrows, int clusters, int H, hipStream_t s, int arith, void* dg16_0, void* dg16_1, float* dbp,
+                              int dg1_f32);
+int fsn_launch_lstm2_g16_finish(const float* dg1, const float* dg0, void* dg16_1, void* dg16_0, const float* dbp, int clusters, int Tp,
+                                int Nrows, int left, float* db1, float* db0, hipStream_t s, int arith);
 // fb_chain_bptt_kernels.hip: BPTT of the full-band model's two layers (16 rows, H = 512) as one persistent launch
 bool fsn_fb_chain_bptt_supported(int H, int N);
 int fsn_fb_chain_bptt_max_steps();
@@ -352,6 +355,10 @@ size_t fsn_gemm_tn_workspace_bytes(int M, int Nc, long K);
 int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int Nc, long K,
                        void* workspace, hipStream_t s, float* colsum_out = nullptr, int arith = FSN_ARITH_F32);
 int fsn_launch_colsum(const float* A, long lda, float* out, int cols, long rows, void* workspace, hipStream_t s);
+// the same product with both operands 16-bit in memory (LDS-DMA staging, transposing LDS reads); workspace as above
+bool fsn_gemm_tn16h_supported(int M, int Nc, long K);
+int fsn_launch_gemm_tn16h(const void* A16, long lda, const void* B16, long ldb, float* C, long ldc, int M, int Nc, long K,
+                          void* workspace, hipStream_t s, int arith);
 size_t fsn_colsum_workspace_bytes(int cols, long rows);
 int fsn_launch_bptt_step(const float* dh_out, const float* dgates_next, const float* whhT_p, float* dc,
                          const float* gates, const float* c_t, const float* c_prev, float* dgates, int row_tiles, int H,

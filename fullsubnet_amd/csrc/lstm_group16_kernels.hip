@@ -446,6 +446,9 @@ struct G16BwdArgs {
     const float *gates0, *cseq0, *gates1, *cseq1;
     float *dg0, *dg1;      // [Tp][N][4H] gate gradients (outputs)
     void *x1, *x0;         // [clusters][QDX][q_xslot bytes]: the gate gradients of the last steps, fragment order
+    unsigned short *dg16_0, *dg16_1;  // [Tp][N][4H] 16-bit gate gradients, row-major: operands of the weight-gradient products
+    float* dbp;            // [2 layers][clusters][4H]: column sums of this launch's gate gradients (fp32 values): the bias gradients
+    int dg1_f32;           // 0: layer 1's fp32 gate gradients are not stored (nothing reads them: the products take dg16_1)
     unsigned* flags;       // [clusters][2][QFS]: steps published by (layer 1 | layer 0, member)
     unsigned* status;
     unsigned long long spin_ticks;
@@ -455,7 +458,8 @@ struct G16BwdArgs {
 // ABL (tools/probe_g16.hip; 0 in the library, any bit set gives WRONG results): 1 no flag waits, 2 saved activations not
 // loaded, 4 no weight loads, 8 no gate-gradient stores, 16 no exchange stores, 32 exchanged operand not loaded
 template <int LAYER, int AR, int ABL>
-__device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, int member, unsigned char* red, unsigned char* dsh) {
+__device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, int member, unsigned char* red, unsigned char* dsh,
+                                             float (*dbs)[4 * QU]) {
     float live = 0.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
@@ -542,6 +546,8 @@ __device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, i
     float* const dgout = LAYER ? a.dg1 : a.dg0;
     unsigned* const myfl = LAYER ? fl1 : fl0;
     const unsigned w_hh = wbase(LAYER ? a.o_hh1 : a.o_hh0), w_ih = wbase(a.o_ih1);
+    unsigned short* const dg16 = LAYER ? a.dg16_1 : a.dg16_0;
+    for (int i = threadIdx.x; i < 4 * 4 * QU; i += 256) dbs[0][i] = 0.f;  // [wave][gate 48 + unit]: this member's bias-gradient sums
     f32x4 dc[3], c_t[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) dc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -646,14 +652,42 @@ __device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, i
                                                         (unsigned)((t % QDX) * XSLOT + ((NBM * member + kbl) * 4 + wave) * 1024), 16);
         }
         q_publish(myfl + member, done + 1);  // its barrier also closes this step's use of `red` and `dsh`
-        // the fp32 gate gradients (what the weight-gradient products read afterwards) AFTER the hand-off: only the 16-bit
-        // tile belongs to it
+        // AFTER the hand-off (only the fragment-order tile belongs to it): the gate gradients for the products that follow
+        // the launch - 16-bit row-major copies [t][row][4H] (the weight-gradient products' operand: rounding here or at their
+        // matrix input is the same number), fp32 for layer 0 (its input gradient is an fp32 product) - and their column sums
+        // (the bias gradients, from the fp32 values): the 16 rows of a wave summed by DPP, one lane per unit quad adds to LDS
         if constexpr ((ABL & 8) == 0) {
+            const __amdgpu_buffer_rsrc_t r16 = q_rsrc(dg16 + ((size_t)t * N + (size_t)cluster * QROWS) * QG, QROWS * QG * 2);
+            const unsigned eo_16 = (unsigned)((((wave * 16 + lr) * QG) + QU * member + 4 * lq) * 2);
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) q_store(ro, eo_g, (unsigned)(g * QH * 4 + j * 64), sg[j][g]);
+                for (int g = 0; g < 4; ++g) {
+                    if (LAYER == 0 || a.dg1_f32) q_store(ro, eo_g, (unsigned)(g * QH * 4 + j * 64), sg[j][g]);
+                    __builtin_amdgcn_raw_buffer_store_b64(q_round4<AR>(sg[j][g]), r16, eo_16, (unsigned)((g * QH + j * 16) * 2), 0);
+                    f32x4 v = sg[j][g];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {  // sum over the 16 lanes lr of this lane's group: quad xor 1, xor 2, half mirror, mirror
+                        float x = v[i];
+                        x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+                        x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+                        x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+                        x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));
+                        v[i] = x;
+                    }
+                    if (lr == 0) {
+                        f32x4* d = reinterpret_cast<f32x4*>(&dbs[wave][g * QU + 16 * j + 4 * lq]);
+                        *d += v;
+                    }
+                }
         }
+    }
+    // the member's bias-gradient sums: the four waves' (row tiles') accumulators in a fixed order
+    __syncthreads();
+    if (threadIdx.x < 4 * QU && (ABL & 8) == 0) {
+        const int k = threadIdx.x;
+        const float v = ((dbs[0][k] + dbs[1][k]) + dbs[2][k]) + dbs[3][k];
+        a.dbp[((size_t)LAYER * (gridDim.x / (2 * QM)) + cluster) * QG + (k / QU) * QH + QU * member + k % QU] = v;
     }
     if (ABL != 0 && live == 123.456f) a.status[1] = 1u;  // never true: the ablated values stay computed
 }
@@ -662,6 +696,7 @@ template <int AR, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void lstm2_g16_bwd_kernel(const G16BwdArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char red[4 * 12 * 1024];
     __shared__ __attribute__((aligned(16))) unsigned char dsh[QROWS * DSH_STRIDE];
+    __shared__ __attribute__((aligned(16))) float dbs[4][4 * QU];
     // first half of the grid: layer 1 (the leading chain), second half: layer 0; cluster members on one XCD when the
     // cluster count allows it (speed only: they then share the exchanged tiles through that XCD's L2)
     const int half = gridDim.x >> 1;
@@ -677,8 +712,29 @@ __global__ __launch_bounds__(256, 2) void lstm2_g16_bwd_kernel(const G16BwdArgs 
         cluster = bid / QM;
         member = bid % QM;
     }
-    if (!second) g16_bwd_body<1, AR, ABL>(a, cluster, member, red, dsh);
-    else g16_bwd_body<0, AR, ABL>(a, cluster, member, red, dsh);
+    if (!second) g16_bwd_body<1, AR, ABL>(a, cluster, member, red, dsh, dbs);
+    else g16_bwd_body<0, AR, ABL>(a, cluster, member, red, dsh, dbs);
+}
+
+// After the launch: the rows that did not fill a cluster (computed step by step beside it, fp32) need their 16-bit copies ...
+template <int AR>
+__global__ void g16_left_to16_kernel(const float* __restrict__ dg, unsigned short* __restrict__ dg16, int T, long N, long row0, int left) {
+    const long per_t = (long)left * QG / 4, n4 = (long)T * per_t;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long t = i / per_t, o = ((t * N + row0) * QG) + (i % per_t) * 4;
+        *reinterpret_cast<fsn_u32x2*>(dg16 + o) = q_round4<AR>(*reinterpret_cast<const f32x4*>(dg + o));
+    }
+}
+// ... and the bias gradient is the clusters' sums (fixed order) plus those rows' fp32 gate gradients
+__global__ void g16_db_kernel(const float* __restrict__ dbp, int clusters, const float* __restrict__ dg, int T, long N, long row0,
+                              int left, float* __restrict__ db) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= QG) return;
+    float acc = 0.f;
+    for (int c = 0; c < clusters; ++c) acc += dbp[(size_t)c * QG + col];
+    for (int t = 0; t < T; ++t)
+        for (int r = 0; r < left; ++r) acc += dg[((long)t * N + row0 + r) * QG + col];
+    db[col] = acc;
 }
 
 }  // namespace
@@ -792,7 +848,8 @@ int fsn_launch_lstm2_g16_train(const float* x, int I, int Nrows, const float* w_
 // fsn_lstm2_g16_partial_floats(clusters) floats of scratch; wbuf: fsn_lstm2_g16_bwd_weight_bytes() bytes.
 int fsn_launch_lstm2_g16_bptt(const float* dh1, const float* w_hh1, const float* w_ih1, const float* w_hh0, const float* save0,
                               const float* save1, float* dg0, float* dg1, float* exchange, unsigned* flags, void* wbuf, int Tp,
-                              int Nrows, int clusters, int H, hipStream_t s, int arith) {
+                              int Nrows, int clusters, int H, hipStream_t s, int arith, void* dg16_0, void* dg16_1, float* dbp,
+                              int dg1_f32) {
     if (H != QH || clusters < 1 || clusters > fsn_lstm2_g16_clusters(Nrows / 16) || (arith != FSN_ARITH_F16 && arith != FSN_ARITH_BF16)) {
         fsn_set_error("lstm2_g16 (bptt): H = 384, 16-bit arithmetic, clusters * 64 <= rows, one cluster per eight CUs at most");
         return FSN_ERR_ARG;
@@ -806,6 +863,14 @@ int fsn_launch_lstm2_g16_bptt(const float* dh1, const float* w_hh1, const float*
     a.cseq1 = save1 + (size_t)Tp * Nrows * QG;
     a.dg0 = dg0;
     a.dg1 = dg1;
+    a.dg16_0 = static_cast<unsigned short*>(dg16_0);
+    a.dg16_1 = static_cast<unsigned short*>(dg16_1);
+    a.dbp = dbp;
+    a.dg1_f32 = dg1_f32;
+    if (!dg16_0 || !dg16_1 || !dbp) {
+        fsn_set_error("lstm2_g16 (bptt): NULL 16-bit gate-gradient / bias-gradient buffer");
+        return FSN_ERR_ARG;
+    }
     a.flags = flags;
     a.status = flags + fsn_lstm2_g16_status_word(clusters);
     a.spin_ticks = fsn_spin_ticks();
@@ -813,4 +878,29 @@ int fsn_launch_lstm2_g16_bptt(const float* dh1, const float* w_hh1, const float*
     a.Nrows = Nrows;
     if (arith == FSN_ARITH_F16) return g16_launch_bptt<FSN_ARITH_F16>(a, w_hh1, w_ih1, w_hh0, wbuf, exchange, clusters, s);
     return g16_launch_bptt<FSN_ARITH_BF16>(a, w_hh1, w_ih1, w_hh0, wbuf, exchange, clusters, s);
+}
+
+// After fsn_launch_lstm2_g16_bptt AND the step-by-step rows beside it: 16-bit copies of those rows' gate gradients (rows
+// [row0, row0 + left) of every step, both layers: dg = dg1 | dg0 adjacent, dg16 likewise) and the bias gradients
+// db1 / db0 [4H] = the launch's cluster sums (dbp) + those rows.
+int fsn_launch_lstm2_g16_finish(const float* dg1, const float* dg0, void* dg16_1, void* dg16_0, const float* dbp, int clusters, int Tp,
+                                int Nrows, int left, float* db1, float* db0, hipStream_t s, int arith) {
+    const long row0 = (long)clusters * QROWS;
+    if (left > 0) {
+        const long n4 = (long)Tp * left * QG / 4;
+        const unsigned blocks = (unsigned)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
+        for (int layer = 0; layer < 2; ++layer) {
+            const float* src = layer ? dg1 : dg0;
+            unsigned short* dst = static_cast<unsigned short*>(layer ? dg16_1 : dg16_0);
+            if (arith == FSN_ARITH_F16)
+                hipLaunchKernelGGL(g16_left_to16_kernel<FSN_ARITH_F16>, dim3(blocks), dim3(256), 0, s, src, dst, Tp, (long)Nrows, row0, left);
+            else
+                hipLaunchKernelGGL(g16_left_to16_kernel<FSN_ARITH_BF16>, dim3(blocks), dim3(256), 0, s, src, dst, Tp, (long)Nrows, row0, left);
+            FSN_TRY_LAUNCH("g16_left_to16_kernel");
+        }
+    }
+    hipLaunchKernelGGL(g16_db_kernel, dim3(QG / 256), dim3(256), 0, s, dbp + (size_t)clusters * QG, clusters, dg1, Tp, (long)Nrows, row0, left, db1);
+    FSN_TRY_LAUNCH("g16_db_kernel");
+    hipLaunchKernelGGL(g16_db_kernel, dim3(QG / 256), dim3(256), 0, s, dbp, clusters, dg0, Tp, (long)Nrows, row0, left, db0);
+    return fsn_check_launch("g16_db_kernel");
 }

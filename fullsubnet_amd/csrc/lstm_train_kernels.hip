@@ -418,6 +418,131 @@ __global__ __launch_bounds__(256) void gemm_tn16_kernel(const float* __restrict_
     }
 }
 
+// ... and with the operands ALREADY in 16 bits in memory (the BPTT kernel writes the 16-bit gate gradients it forms for the
+// exchange anyway; the hidden sequences are converted once): half the HBM bytes, and no conversion pass - so the slabs go
+// global -> LDS by LDS-DMA (no registers: four chunks of 24 KB in flight per CU instead of the two that fit the
+// architectural registers), each DMA instruction building two [16 k][16 columns] subtiles of the image
+// ds_read_b64_tr_b16 wants (lane l fetches row (l & 31) >> 1, half l & 1 of subtile l >> 5).  K in chunks of 32 (the
+// caller passes K rounded down to 32; the reduce kernel adds the tail rows from the same 16-bit operands).
+constexpr int TH_STAGE = 2 * 12 * 1024;  // bytes of one chunk: (A, B) x 2 k steps x 6 tile pairs x 1 KB
+constexpr int TH_STAGES = 4;             // (6 stages = 5 chunks in flight measured SLOWER, 0.76 against 0.66 ms: the LDS-DMA path lands ~29 GB/s per CU whatever is in flight)
+__device__ __forceinline__ void th_lds_dma(const unsigned short* g, unsigned lds_base) {
+    unsigned saved;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, off\n\t"
+        "s_nop 0\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(saved)
+        : "s"(lds_base), "v"(g)
+        : "memory");
+}
+template <int AR>
+__global__ __launch_bounds__(256) void gemm_tn16h_kernel(const unsigned short* __restrict__ A, long lda,
+                                                         const unsigned short* __restrict__ B, long ldb,
+                                                         float* __restrict__ part, int M, int Nc, long K, long k_per_split,
+                                                         int m_blocks, int n_blocks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char th_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles = m_blocks * n_blocks, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int tile = jb % tiles, split = xcd * ((int)(gridDim.x >> 3) / tiles) + jb / tiles;
+    const int mb = tile / n_blocks, nb = tile % n_blocks;
+    const int m0 = mb * 192, n0 = nb * 192;
+    const long k_begin = (long)split * k_per_split;
+    long k_end = k_begin + k_per_split;
+    k_end = k_end < K ? k_end : K;
+    const int chunks = (int)((k_end - k_begin) >> 5);  // whole chunks of 32 (K and k_per_split are multiples of 32)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)th_lds;
+
+    // staging: wave w fills operand w >> 1 (0 = A, 1 = B), k step w & 1 of every chunk: six DMA instructions, one per
+    // pair of column tiles; lane l -> row 16 ks + ((l & 31) >> 1), columns 16 (2 p + (l >> 5)) + 8 (l & 1) .. + 7
+    const int s_op = wave >> 1, s_ks = wave & 1;
+    const unsigned short* sp = (s_op ? B + n0 : A + m0) + (k_begin + 16 * s_ks + ((lane & 31) >> 1)) * (s_op ? ldb : lda) +
+                               16 * (lane >> 5) + 8 * (lane & 1);
+    const long s_ld = s_op ? ldb : lda;
+    auto issue = [&](int c) {  // chunk c into stage c % TH_STAGES
+        const unsigned dst = lds0 + (unsigned)((c % TH_STAGES) * TH_STAGE + (s_op * 12 + s_ks * 6) * 1024);
+#pragma unroll
+        for (int p = 0; p < 6; ++p) th_lds_dma(sp + (long)c * 32 * s_ld + 32 * p, dst + (unsigned)(p * 1024));
+    };
+    f32x4 acc[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int lane_off = (4 * lq + (lr >> 2)) * 32 + (lr & 3) * 8;
+    auto tr = [&](const unsigned char* p) {
+        return __builtin_bit_cast(typename FsnOperand<AR>::type,
+                                  __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tq_s16x4*)p));
+    };
+    auto compute = [&](int stage) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            typename FsnOperand<AR>::type a[6], b[6];
+            const unsigned char* base = th_lds + stage * TH_STAGE + ks * 6 * 1024 + lane_off;  // column tile i at + i * 512
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                a[i] = tr(base + (wm * 6 + i) * 512);
+                b[i] = tr(base + 12 * 1024 + (wn * 6 + i) * 512);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[i][j] = fsn_mma_k16<AR>(a[i], b[j], acc[i][j]);
+        }
+    };
+    // TH_STAGES - 1 chunks in flight; the DMAs are invisible to the compiler's counter, so the waits are stated here: a wave
+    // issues 6 per chunk, in order, and nothing else that counts
+#pragma unroll
+    for (int c = 0; c < TH_STAGES - 1; ++c)
+        if (c < chunks) issue(c);
+    for (int c = 0; c < chunks; ++c) {
+        static_assert(TH_STAGES == 4, "the counted wait below: TH_STAGES - 2 younger chunks x 6 DMAs per wave");
+        if (c + TH_STAGES - 1 <= chunks) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // two younger chunks may still be in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // chunk c of every wave has landed; everyone has left stage (c - 1) % TH_STAGES
+        if (c + TH_STAGES - 1 < chunks) issue(c + TH_STAGES - 1);
+        compute(c % TH_STAGES);
+    }
+    float* out = part + (long)split * M * Nc;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + (wm * 6 + i) * 16 + 4 * lq + r, n = n0 + (wn * 6 + j) * 16 + lr;
+                out[(long)m * Nc + n] = acc[i][j][r];
+            }
+}
+// its epilogue: sum of the split partials (fixed order) + the tail rows (K % 32) from the same 16-bit operands
+template <int AR>
+__global__ void tn16h_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, long ldc, int M, int Nc, int splits,
+                                    const unsigned short* __restrict__ A, long lda, const unsigned short* __restrict__ B,
+                                    long ldb, long k_tail0, long K) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)M * Nc) return;
+    const int m = (int)(i / Nc), n = (int)(i % Nc);
+    float acc = 0.f;
+    for (int s = 0; s < splits; ++s) acc += part[(long)s * M * Nc + i];
+    for (long k = k_tail0; k < K; ++k) {
+        float a, b;
+        if constexpr (AR == FSN_ARITH_F16) {
+            a = (float)__builtin_bit_cast(_Float16, A[k * lda + m]);
+            b = (float)__builtin_bit_cast(_Float16, B[k * ldb + n]);
+        } else {
+            a = __builtin_bit_cast(float, (unsigned)A[k * lda + m] << 16);
+            b = __builtin_bit_cast(float, (unsigned)B[k * ldb + n] << 16);
+        }
+        acc = fmaf(a, b, acc);
+    }
+    C[(long)m * ldc + n] = acc;
+}
+
 // column sums riding on gemm_tn: sum of the split partials (fixed order) + the K % 16 tail rows
 __global__ void tn_colsum_reduce_kernel(const float* __restrict__ asum_part, float* __restrict__ out, int M, int splits,
                                         const float* __restrict__ A, long lda, long k_tail0, long K) {
@@ -671,6 +796,55 @@ int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float
         return fsn_check_launch("tn_colsum_reduce_kernel");
     }
     return FSN_OK;
+}
+
+// C [M][Nc] = sum_k A[k][m] B[k][n] with BOTH operands 16-bit in memory (fp16 / bf16 per `arith`), fp32 accumulation:
+// M and Nc multiples of 192, one workgroup per CU over the 192 x 192 tiles with every K split's tiles on one XCD (the
+// plan of fsn_launch_gemm_tn's square form); false when the shape has no such plan.  workspace: fsn_gemm_tn_workspace_bytes.
+bool fsn_gemm_tn16h_supported(int M, int Nc, long K) {
+    const long K32 = K & ~31L;
+    if (K32 <= 0) return false;
+    return tn_plan(M, Nc, K32, FSN_ARITH_F16).square != 0;
+}
+int fsn_launch_gemm_tn16h(const void* A16, long lda, const void* B16, long ldb, float* C, long ldc, int M, int Nc, long K,
+                          void* workspace, hipStream_t s, int arith) {
+    const long K32 = K & ~31L;
+    if ((arith != FSN_ARITH_F16 && arith != FSN_ARITH_BF16) || !fsn_gemm_tn16h_supported(M, Nc, K) || lda % 8 || ldb % 8 ||
+        ((size_t)A16 & 15) || ((size_t)B16 & 15)) {
+        fsn_set_error("gemm_tn16h: 16-bit arithmetic, M and Nc multiples of 192 with a one-workgroup-per-CU plan, 16-byte aligned rows");
+        return FSN_ERR_ARG;
+    }
+    TnPlan p = tn_plan(M, Nc, K32, arith);
+    p.k_per_split = (p.k_per_split + 31) / 32 * 32;  // whole chunks; the last split takes what is left (K32 is a multiple of 32)
+    if ((K32 + p.k_per_split - 1) / p.k_per_split != p.splits || p.splits > tn_max_splits(M, Nc)) {
+        fsn_set_error("gemm_tn16h: no plan for %d x %d, K = %ld", M, Nc, K);
+        return FSN_ERR_ARG;
+    }
+    float* part = static_cast<float*>(workspace);
+    const unsigned short *a = static_cast<const unsigned short*>(A16), *b = static_cast<const unsigned short*>(B16);
+    constexpr size_t kLds = kTnOnePerCu;  // 4 stages of 24 KB = the reservation that keeps one workgroup per CU
+    static_assert(TH_STAGES * TH_STAGE <= (int)kTnOnePerCu, "the stages fit it");
+    const dim3 grid((unsigned)(p.m_blocks * p.n_blocks * p.splits));
+    auto kern = arith == FSN_ARITH_F16 ? gemm_tn16h_kernel<FSN_ARITH_F16> : gemm_tn16h_kernel<FSN_ARITH_BF16>;
+    static bool set[4] = {false, false, false, false};
+    if (!set[arith]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds) !=
+            hipSuccess) {
+            fsn_set_error("gemm_tn16h: cannot reserve %zu bytes of LDS", kLds);
+            return FSN_ERR_LAUNCH;
+        }
+        set[arith] = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), kLds, s, a, lda, b, ldb, part, M, Nc, K32, p.k_per_split, p.m_blocks, p.n_blocks);
+    FSN_TRY_LAUNCH("gemm_tn16h_kernel");
+    const long n = (long)M * Nc;
+    if (arith == FSN_ARITH_F16)
+        hipLaunchKernelGGL(tn16h_reduce_kernel<FSN_ARITH_F16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, C, ldc, M, Nc,
+                           p.splits, a, lda, b, ldb, K32, K);
+    else
+        hipLaunchKernelGGL(tn16h_reduce_kernel<FSN_ARITH_BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, C, ldc, M, Nc,
+                           p.splits, a, lda, b, ldb, K32, K);
+    return fsn_check_launch("tn16h_reduce_kernel");
 }
 
 size_t fsn_colsum_workspace_bytes(int cols, long rows) {

@@ -454,7 +454,8 @@ int fsn_debug_hog(int workgroups, int lds_bytes, int heavy, float ms, float* sin
 int fsn_debug_persist_stats(unsigned* launches, unsigned* waits, unsigned* unreported);
 /* Test / measurement hook: the two-layer training entries (fsn_lstm2_forward_train / fsn_lstm2_backward) under
  * FSN_ARITH_F16 / _BF16 run the 16-bit arithmetic's own persistent kernels (lstm_group16_kernels.hip) where they
- * apply; on = 0 keeps the fp32-era group kernels under that arithmetic (A/B measurements), on = 1 restores the default. */
+ * apply; on = 0 keeps the fp32-era group kernels under that arithmetic (A/B measurements), on = 2 only the round-3 form
+ * of the weight-gradient products (operands converted on the fly), on = 1 restores the default. */
 int fsn_debug_g16_kernels(int on);
 /* Test hooks that need no device.  fsn_debug_persist_set_fits: 1 when the gate would let n persistent launches with the
  * given chip fractions (grid / (occ x CUs)) and occupancies run side by side, 0 when the newest has to wait.

@@ -22,6 +22,8 @@ model = model.cuda().train()
 model.train_arithmetic = ARITH
 if "g16=0" in sys.argv:  # A/B: the fp32-era group kernels under the 16-bit arithmetic (lstm_group16_kernels.hip off)
     fullsubnet_amd._lib.lib().fsn_debug_g16_kernels(0)
+if "g16=2" in sys.argv:  # A/B: weight-gradient products converting their operands on the fly (gemm_tn16_kernel)
+    fullsubnet_amd._lib.lib().fsn_debug_g16_kernels(2)
 scaler = torch.amp.GradScaler("cuda", enabled=ARITH != "f32")
 opt = fullsubnet_amd.ClipAdam(model.parameters(), lr=1e-3)
 noisy = torch.from_numpy(make_noisy(B, L, seed=1)).cuda()

@@ -102,6 +102,8 @@ int main(int argc, char** argv) {
         b.dh1 = dh1; b.w16 = w16; b.o_hh1 = 0; b.o_ih1 = (unsigned)wb; b.o_hh0 = (unsigned)(2 * wb);
         b.gates0 = sv0; b.cseq0 = sv0 + TN * QG; b.gates1 = sv1; b.cseq1 = sv1 + TN * QG; b.dg1 = dg; b.dg0 = dg + TN * QG;
         b.x1 = part; b.x0 = reinterpret_cast<unsigned char*>(part) + (size_t)clusters * QDX * q_xslot<PROBE_AR>();
+        unsigned short* dg16; float* dbp; hipMalloc(&dg16, 2 * TN * QG * 2); hipMalloc(&dbp, (size_t)2 * clusters * QG * 4);
+        b.dg16_0 = dg16; b.dg16_1 = dg16 + TN * QG; b.dbp = dbp; b.dg1_f32 = 0;
         b.flags = flags; b.status = flags + fsn_lstm2_g16_status_word(clusters); b.spin_ticks = 1ull << 31; b.Tp = Tp; b.Nrows = N;
         const float t0 = run_bwd<0>(b);
         unsigned st = 0; hipMemcpy(&st, b.status, 4, hipMemcpyDeviceToHost);
