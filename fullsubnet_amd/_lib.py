@@ -185,6 +185,14 @@ SIGNATURES = {
     "fsn_train_mask_grad": (_c.c_int, [_c.c_void_p, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_void_p]),
     "fsn_train_cirm_target": (_c.c_int, [_c.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, _c.c_void_p]),
     "fsn_scale_by_scalar": (_c.c_int, [_f32p, _f32p, _f32p, _c.c_size_t, _c.c_void_p]),
+    "fsn_fast_low_rate_frames": (_c.c_int, [_c.c_int, _c.c_int]),
+    "fsn_fast_glue_workspace_bytes": (_c.c_size_t, [_c.c_int] * 4),
+    "fsn_fast_spec_rows": (_c.c_int, [_f32p] + [_c.c_int] * 4 + [_f32p, _c.c_int, _c.c_int, _c.c_void_p]),
+    "fsn_fast_norm_rows": (_c.c_int, [_f32p] + [_c.c_int] * 4 + [_f32p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "fsn_fast_bottleneck_input": (_c.c_int, [_f32p, _f32p, _c.c_long] + [_c.c_int] * 7 + [_f32p, _c.c_int, _c.c_int, _c.c_void_p,
+                                             _c.c_size_t, _c.c_void_p]),
+    "fsn_fast_decoder_input": (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _c.c_long] + [_c.c_int] * 5 + [_f32p, _c.c_void_p]),
+    "fsn_fast_mask_out": (_c.c_int, [_f32p, _c.c_long] + [_c.c_int] * 5 + [_f32p, _c.c_void_p]),
     "fsn_profile_enable": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "fsn_stream_timeout_policy": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "fsn_debug_g16_kernels": (_c.c_int, [_c.c_int]),

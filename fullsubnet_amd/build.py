@@ -16,7 +16,8 @@ SOURCES = ["fft_kernels.hip", "dft_kernels.hip", "elementwise_kernels.hip", "gem
            "gemm_f16x3_kernels.hip", "lstm_kernels.hip", "lstm_group_kernels.hip",
            "lstm_group_bptt_kernels.hip", "lstm_group16_kernels.hip", "fb_chain_kernels.hip", "fb_chain_bptt_kernels.hip",
            "lstm_f16x3_kernels.hip", "lstm_train_kernels.hip", "gru_kernels.hip", "optim_kernels.hip",
-           "norm_kernels.hip", "section_kernels.hip", "train_glue_kernels.hip", "fsn_api.hip"]
+           "norm_kernels.hip", "section_kernels.hip", "train_glue_kernels.hip", "fast_glue_kernels.hip",
+           "fsn_api.hip"]
 # -ffp-contract=off: elementwise code follows the reference's mul/add rounding sequence; fused
 # multiply-adds are written explicitly (fma / MFMA) where they are wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-pass-failed",

@@ -1,8 +1,10 @@
 """Drop-in ``Model`` for recipes/dns_interspeech_2020/fast_fullsubnet/model.py:11-202 (BASELINE
 config 4): mel filtering -> F_l2m encoder (2 LSTM blocks) -> sub-band bottleneck S on B * num_mels
 rows at 1/shrink_size of the frame rate -> F_m2l decoder (2 LSTM blocks), every LSTM / Linear block
-on the HIP kernels through ``SequenceModel``; mel matmul, unfold, time down/up-sampling and norms are
-tensor-algebra glue (< 1 % of the FLOPs).
+on the HIP kernels through ``SequenceModel``.  In inference the tensors between the blocks stay time-major and the glue
+(look-ahead pad, norms, unit windows, time down/up-sampling, concatenations, the final reshape) is HIP too
+(``_forward_rows``, csrc/fast_glue_kernels.hip); the tensor-algebra ``forward`` below it is what autograd records in
+training and what host-side unit tests of the glue run.
 
 The reference takes the mel filterbank from torchaudio (``audio.transforms.MelScale(n_mels, 16000,
 f_min=0, f_max=8000, n_stft)``, model.py:57-63), which is not part of the reference tree: ``MelScale``
@@ -16,7 +18,7 @@ import torch.nn as nn
 
 from .base_model import BaseModel, look_ahead_pad
 from . import _lib
-from .sequence_model import SequenceModel, linear_infer, pair_forward
+from .sequence_model import SequenceModel, linear_infer, pair_forward, pair_forward_rows, pair_fusable
 
 
 def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate):
@@ -38,6 +40,15 @@ class MelScale(nn.Module):
         super().__init__()
         self.register_buffer("fb", melscale_fbanks(n_stft, f_min, f_max, n_mels, sample_rate))
 
+    def linear_weights(self):
+        """The filterbank as an nn.Linear weight [n_mels, F] and a zero bias (made once per buffer version)."""
+        key = (self.fb.data_ptr(), self.fb._version, str(self.fb.device))
+        if getattr(self, "_w_key", None) != key:
+            self._w = self.fb.detach().t().contiguous()  # [n_mels, F]
+            self._b = torch.zeros(self._w.shape[0], dtype=torch.float32, device=self._w.device)
+            self._w_key = key
+        return self._w, self._b
+
     def forward(self, specgram):
         """[..., F, T] -> [..., n_mels, T]: specgram^T fb, through the in-tree MFMA GEMM (fsn_linear_forward with the
         filterbank as an nn.Linear weight [n_mels, F] and a zero bias) - no vendor BLAS on the path."""
@@ -47,11 +58,7 @@ class MelScale(nn.Module):
             return torch.matmul(specgram.transpose(-1, -2), self.fb).transpose(-1, -2)
         F, T = specgram.shape[-2], specgram.shape[-1]
         lead = specgram.shape[:-2]
-        key = (self.fb.data_ptr(), self.fb._version, str(self.fb.device))
-        if getattr(self, "_w_key", None) != key:
-            self._w = self.fb.detach().t().contiguous()  # [n_mels, F]
-            self._b = torch.zeros(self._w.shape[0], dtype=torch.float32, device=self._w.device)
-            self._w_key = key
+        self.linear_weights()
         Fp = (F + 15) // 16 * 16
         x2 = torch.zeros((specgram.numel() // (F * T), T, Fp), dtype=torch.float32, device=specgram.device)
         x2[..., :F] = specgram.detach().reshape(-1, F, T).transpose(1, 2)
@@ -115,6 +122,57 @@ class Model(BaseModel):
         b, _, m, t = x.shape
         return self.freq_unfold(x, num_neighbors=neighbors).reshape(b, m, 2 * neighbors + 1, t)
 
+    def _rows_path_ok(self, mix_mag):
+        enc0, enc1 = self.encoder
+        dec0, dec1 = self.decoder_lstm
+        B = mix_mag.shape[0]
+        return (getattr(self, "rows_path", True) and self.norm == self.offline_laplace_norm and self.num_mels % 16 == 0
+                and self.num_mels == enc0.input_size == enc1.output_size and dec0.input_size == 2 * self.num_mels
+                and dec1.output_size == 2 * mix_mag.shape[2] and self.bottleneck.cell == "LSTM"
+                and self.bottleneck.output_size == 1 and pair_fusable(enc0, enc1, B) and pair_fusable(dec0, dec1, B)
+                and mix_mag.shape[3] + self.look_ahead >= 2 and mix_mag.dtype == torch.float32)
+
+    def _forward_rows(self, mix_mag):
+        """The inference forward with every tensor between the blocks time-major and the glue on fast_glue_kernels.hip
+        (model.py:143-202 line by line in the comments)."""
+        L = _lib.lib()
+        dev = mix_mag.device
+        st = _lib.stream_ptr(dev)
+        mag = mix_mag.detach().contiguous()
+        B, _, F, T0 = mag.shape
+        M, s, la = self.num_mels, self.shrink_size, self.look_ahead
+        T = T0 + la
+        Bp, Fp = (B + 15) // 16 * 16, (F + 15) // 16 * 16
+        f32 = dict(dtype=torch.float32, device=dev)
+        ws = _lib.workspace(L.fsn_fast_glue_workspace_bytes(T, B, M, s), dev)
+        # :151-157 pad + mel_scale
+        rows = torch.empty((T, Bp, Fp), **f32)
+        _lib.check(L.fsn_fast_spec_rows(_lib.dev_ptr(mag, "mix_mag"), B, F, T0, la, _lib.dev_ptr(rows), Bp, Fp, st))
+        w, b = self.mel_scale.linear_weights()
+        mel = linear_infer(rows.reshape(T * Bp, Fp), w, b, False)                       # [T Bp, M]
+        # :160 norm -> encoder
+        enc_in = torch.empty((T, Bp, M), **f32)
+        _lib.check(L.fsn_fast_norm_rows(_lib.dev_ptr(mel), T, B, Bp, M, _lib.dev_ptr(enc_in), ws.data_ptr(), ws.numel(), st))
+        enc = pair_forward_rows(*self.encoder, enc_in)                                   # [T, Bp, M]
+        # :163-178 unit windows, down-sampling, norm -> bottleneck
+        n_mel, n_enc = self.noisy_input_num_neighbors, self.enc_output_num_neighbors
+        W = (2 * n_mel + 1) + (2 * n_enc + 1)
+        Wp, N = (W + 15) // 16 * 16, B * M
+        Np, Ts = (N + 15) // 16 * 16, L.fsn_fast_low_rate_frames(T, s)
+        units = torch.empty((Ts, Np, Wp), **f32)
+        _lib.check(L.fsn_fast_bottleneck_input(_lib.dev_ptr(mel), _lib.dev_ptr(enc), enc.stride(1), T, B, Bp, M, n_mel, n_enc, s,
+                                               _lib.dev_ptr(units), Np, Wp, ws.data_ptr(), ws.numel(), st))
+        slow = self.bottleneck.forward_time_major(units, N, rows_out=True)               # [Ts, Np, 1]
+        # :180-190 up-sampling, cat -> decoder
+        dec_in = torch.empty((T, Bp, 2 * M), **f32)
+        _lib.check(L.fsn_fast_decoder_input(_lib.dev_ptr(enc), enc.stride(1), _lib.dev_ptr(slow), slow.stride(0), slow.stride(1),
+                                            T, B, Bp, M, s, _lib.dev_ptr(dec_in), st))
+        out = pair_forward_rows(*self.decoder_lstm, dec_in)                              # [T, Bp, 2 F]
+        # :200-202 reshape + look-ahead slice
+        mask = torch.empty((B, 2, F, T0), **f32)
+        _lib.check(L.fsn_fast_mask_out(_lib.dev_ptr(out), out.stride(1), T, B, Bp, F, la, _lib.dev_ptr(mask), st))
+        return mask
+
     def forward(self, mix_mag):
         """mix_mag [B, 1, F, T] -> [B, 2, F, T] (model.py:143-202)."""
         if mix_mag.dim() != 4 or mix_mag.shape[1] != 1:
@@ -126,6 +184,8 @@ class Model(BaseModel):
             chunk = torch.cuda.get_device_properties(mix_mag.device).multi_processor_count * 4 * 16 // self.num_mels
             if chunk >= 16 and mix_mag.shape[0] >= chunk + chunk // 2:
                 return torch.cat([self.forward(mix_mag[i:i + chunk]) for i in range(0, mix_mag.shape[0], chunk)], dim=0)
+            if self._rows_path_ok(mix_mag):
+                return self._forward_rows(mix_mag)
         mag = look_ahead_pad(mix_mag, self.look_ahead)
         n_batch, _, n_bins, n_frames = mag.shape
         mel = self.mel_scale(mag)                                                         # [B, 1, M, T]

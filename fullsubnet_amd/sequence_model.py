@@ -170,9 +170,10 @@ class SequenceModel(nn.Module):
         h[:, :B, :F] = x.permute(2, 0, 1)
         return self.forward_time_major(h, B)
 
-    def forward_time_major(self, h, B):
+    def forward_time_major(self, h, B, rows_out=False):
         """Inference on an input that is already laid out as the LSTM entries take it: h [T, Np, Ip] time-major, rows
-        beyond B and columns beyond input_size zero (Np, Ip multiples of 16) -> [B, O, T]."""
+        beyond B and columns beyond input_size zero (Np, Ip multiples of 16) -> [B, O, T]; ``rows_out``: the output as it
+        lies, [T, Np, O] (rows beyond B are not meaningful) - what the next block's time-major entry takes."""
         T, Np, _ = h.shape
         H, Hp = self.hidden_size, _round_up(self.hidden_size, 64)
         layers, fc = self._inference_weights()
@@ -193,13 +194,12 @@ class SequenceModel(nn.Module):
         relu = self.output_activate_function == "ReLU"
         if fc is not None:
             o = linear_infer(h.reshape(T * Np, Hp), fc[0], fc[1], relu).reshape(T, Np, self.output_size)
-            o = o[:, :B]
         else:
-            o = h[:, :B, :H]
+            o = h[:, :, :H]
             relu = False
         if self.output_activate_function and not relu:
             o = self.activate_function(o)
-        return o.permute(1, 2, 0)
+        return o if rows_out else o[:, :B].permute(1, 2, 0)
 
     def _forward_train(self, x):
         from .train import GruLayerFunction, LinearFunction, LstmLayerFunction
@@ -290,19 +290,18 @@ def multi_forward(models, xs=None, prepared=None):
     return outs
 
 
-def pair_forward(block0, block1, x):
-    """``block1(block0(x))`` for two consecutive SequenceModel blocks (an ``nn.Sequential`` pair of the sibling
-    models).  In inference, when both are single-layer LSTM blocks, block0 has no output layer / activation and
-    there are few rows, the two recurrences advance as one wavefront (fsn_lstm2_forward); otherwise block by
-    block."""
-    fusable = (not torch.is_grad_enabled() and x.is_cuda and block0.cell == block1.cell == "LSTM"
-               and block0.num_layers == block1.num_layers == 1 and not block0.output_size
-               and not block0.output_activate_function and block1.input_size == block0.hidden_size
-               and _round_up(x.shape[0], 16) < WAVEFRONT_BELOW_ROWS)
-    if not fusable:
-        return block1(block0(x))
-    B, F, T = x.shape
-    Np, Ip = _round_up(B, 16), _round_up(F, 16)
+def pair_fusable(block0, block1, rows):
+    """Whether two consecutive SequenceModel blocks run as ONE two-layer recurrence in inference (``pair_forward``): both
+    single-layer LSTM blocks, block0 without output layer / activation, few rows."""
+    return (block0.cell == block1.cell == "LSTM" and block0.num_layers == block1.num_layers == 1
+            and not block0.output_size and not block0.output_activate_function
+            and block1.input_size == block0.hidden_size and _round_up(rows, 16) < WAVEFRONT_BELOW_ROWS)
+
+
+def pair_forward_rows(block0, block1, h):
+    """``block1(block0(.))`` of a fusable pair on time-major rows: h [T, Np, Ip] (zero beyond the block's input width) ->
+    [T, Np, O] as the output layer writes it (rows beyond the batch are not meaningful)."""
+    T, Np, _ = h.shape
     (layer0,), _ = block0._inference_weights()
     _, fc = block1._inference_weights()
     Hp0, Hp1 = layer0[1].shape[1], _round_up(block1.hidden_size, 64)
@@ -324,17 +323,28 @@ def pair_forward(block0, block1, x):
         cached = (key, layer0, layer1)
         block1._pair_cache = cached
     _, layer0, layer1 = cached
-    h = torch.zeros((T, Np, Ip), dtype=torch.float32, device=x.device)
-    h[:, :B, :F] = x.permute(2, 0, 1)
     h = lstm2_infer(h, layer0, layer1)
     if h.shape[2] != Hp1:
         h = h[:, :, :Hp1].contiguous()
-    H1 = block1.hidden_size
     relu = block1.output_activate_function == "ReLU"
     if fc is not None:
-        o = linear_infer(h.reshape(T * Np, Hp1), fc[0], fc[1], relu).reshape(T, Np, block1.output_size)[:, :B]
+        o = linear_infer(h.reshape(T * Np, Hp1), fc[0], fc[1], relu).reshape(T, Np, block1.output_size)
     else:
-        o, relu = h[:, :B, :H1], False
+        o, relu = h[:, :, :block1.hidden_size], False
     if block1.output_activate_function and not relu:
         o = block1.activate_function(o)
-    return o.permute(1, 2, 0)
+    return o
+
+
+def pair_forward(block0, block1, x):
+    """``block1(block0(x))`` for two consecutive SequenceModel blocks (an ``nn.Sequential`` pair of the sibling
+    models).  In inference, when both are single-layer LSTM blocks, block0 has no output layer / activation and
+    there are few rows, the two recurrences advance as one wavefront (fsn_lstm2_forward); otherwise block by
+    block."""
+    if torch.is_grad_enabled() or not x.is_cuda or not pair_fusable(block0, block1, x.shape[0]):
+        return block1(block0(x))
+    B, F, T = x.shape
+    Np, Ip = _round_up(B, 16), _round_up(F, 16)
+    h = torch.zeros((T, Np, Ip), dtype=torch.float32, device=x.device)
+    h[:, :B, :F] = x.permute(2, 0, 1)
+    return pair_forward_rows(block0, block1, h)[:, :B].permute(1, 2, 0)

@@ -373,6 +373,34 @@ int fsn_train_cirm_target(const fsn_train_dims* dims, const float* noisy_real, c
                           const float* clean_real, const float* clean_imag, float* target, void* stream);
 int fsn_scale_by_scalar(const float* x, const float* scale, float* y, size_t n, void* stream);
 
+/* Fast FullSubNet's tensor glue between its LSTM / Linear blocks (fast_fullsubnet/model.py:108-140 real_time_down /
+ * up-sampling, :143-202 forward), every tensor TIME-MAJOR [frames][rows][columns] - the layout the LSTM entries take and
+ * fsn_linear_forward writes - so that no transposing copy sits between two blocks (fast_glue_kernels.hip):
+ * fsn_fast_spec_rows        mag [B][F][T0] (model.py:151 functional.pad(..., [0, look_ahead]) included) -> rows
+ *                           [T0 + look_ahead][Bp][Fp] of the mel product (model.py:157), zero beyond (T0, B, F).
+ * fsn_fast_norm_rows        offline_laplace_norm (base_model.py:204-218) of x [T][Bp][C]: out = x / (mean over the
+ *                           utterance's T x C values + 1e-5), rows beyond B zero (model.py:160, the encoder's input).
+ *                           workspace: fsn_fast_glue_workspace_bytes.
+ * fsn_fast_bottleneck_input model.py:163-178: unit windows of mel (mel_neighbors) and of the encoder output (enc_neighbors),
+ *                           reflected at the band edges (base_model.py:14-46), concatenated, down-sampled in time (frame 0
+ *                           kept, then means over blocks of `shrink` frames, a shorter last block over what it has),
+ *                           divided by (the utterance's mean of that tensor + 1e-5): out [Ts][Np][Wp], row b num_mels + m,
+ *                           zero padding; Ts = fsn_fast_low_rate_frames(T, shrink).  The unfolded tensor is never formed.
+ * fsn_fast_decoder_input    model.py:131-140 + :188-190: out [T][Bp][2 num_mels] = encoder output | bottleneck output held
+ *                           for `shrink` frames (frame t takes low-rate frame t / shrink; slow[ts ld_slow_frame + row ld_slow_row]).
+ * fsn_fast_mask_out         model.py:200-202: o [T][Bp][ld >= 2F] -> mask [B][2][F][T - look_ahead] (first frames dropped). */
+int fsn_fast_low_rate_frames(int T, int shrink);
+size_t fsn_fast_glue_workspace_bytes(int T, int B, int num_mels, int shrink);
+int fsn_fast_spec_rows(const float* mag, int B, int F, int T0, int look_ahead, float* rows, int Bp, int Fp, void* stream);
+int fsn_fast_norm_rows(const float* x, int T, int B, int Bp, int C, float* out, void* workspace, size_t workspace_bytes,
+                       void* stream);
+int fsn_fast_bottleneck_input(const float* mel, const float* enc, long ld_enc, int T, int B, int Bp, int num_mels,
+                              int mel_neighbors, int enc_neighbors, int shrink, float* out, int Np, int Wp, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int fsn_fast_decoder_input(const float* enc, long ld_enc, const float* slow, long ld_slow_frame, long ld_slow_row, int T, int B,
+                           int Bp, int num_mels, int shrink, float* out, void* stream);
+int fsn_fast_mask_out(const float* o, long ld, int T, int B, int Bp, int F, int look_ahead, float* mask, void* stream);
+
 /* fullsubnet/trainer.py:65-69: torch.nn.utils.clip_grad_norm_(parameters, max_norm) followed by
  * torch.optim.Adam.step() (train.py:55-59: lr, betas, eps 1e-8, no weight decay / amsgrad), fused into
  * two multi-tensor launches.  The arrays are HOST arrays of n_tensors device pointers / element

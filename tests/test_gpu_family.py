@@ -127,6 +127,42 @@ def test_fast_fullsubnet_config4_full_size(fsn, batch):
     assert d_plan.max() <= 5e-5
 
 
+@pytest.mark.parametrize("batch,frames,shrink,nn_noisy,nn_enc", [(3, 21, 2, 5, 0), (5, 22, 2, 5, 0), (2, 20, 3, 2, 1),
+                                                                 (17, 9, 4, 0, 3), (1, 3, 2, 5, 0)])
+def test_fast_fullsubnet_glue_kernels_vs_the_tensor_algebra(fsn, batch, frames, shrink, nn_noisy, nn_enc):
+    """The inference forward with time-major tensors and the glue on fast_glue_kernels.hip (look-ahead pad, norms, unit
+    windows with reflected edges, real_time_down / up-sampling incl. a shorter last block, cats, the final reshape) against
+    the composed forward (the reference's own tensor algebra, model.py:108-140, 143-202) on the same LSTM kernels, and
+    against the numpy oracle: other shrink sizes and neighbour counts than the shipped TOML's, rows that need padding."""
+    from fullsubnet_amd.fast_fullsubnet import Model
+    kw = dict(FAST_KW, shrink_size=shrink, noisy_input_num_neighbors=nn_noisy, encoder_output_num_neighbors=nn_enc)
+    params = MF.make_fast_params(seed=11, nn_noisy=nn_noisy, nn_enc=nn_enc)
+    m = Model(**kw)
+    sd = {k: torch.from_numpy(v) for k, v in params.items()}
+    sd["mel_scale.fb"] = m.mel_scale.fb.clone()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    rng = np.random.default_rng(frames)
+    mag = np.abs(rng.standard_normal((batch, 1, 257, frames))).astype(np.float32)
+    mag *= rng.uniform(0.3, 3.0, (batch, 1, 1, 1)).astype(np.float32)
+    x = torch.from_numpy(mag).cuda()
+    with torch.no_grad():
+        assert m._rows_path_ok(x)
+        got = m(x)
+        m.rows_path = False
+        composed = m(x)
+        m.rows_path = True
+    assert got.shape == composed.shape == (batch, 2, 257, frames)
+    scale = float(composed.abs().max())
+    d = float((got - composed).abs().max())
+    print(f"fast glue B={batch} T={frames} s={shrink}: max|d| vs the composed forward {d:.2e} (mask scale {scale:.2f})")
+    assert d <= 2e-5 * max(1.0, scale)
+    params["mel_scale.fb"] = m.mel_scale.fb.cpu().numpy()
+    want = MF.fast_fullsubnet_forward(mag[[0, batch - 1]], params, look_ahead=kw["look_ahead"], shrink_size=shrink,
+                                      noisy_input_num_neighbors=nn_noisy, encoder_output_num_neighbors=nn_enc)
+    assert np.abs(got.cpu().numpy()[[0, batch - 1]] - want).max() <= 1e-4
+
+
 def test_fullband_baseline_vs_reference(fsn, golden_dir):
     from fullsubnet_amd.fullband_baseline import Model
     z, meta = load(golden_dir, "fullband_b2")
