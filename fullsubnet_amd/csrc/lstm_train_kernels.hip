@@ -159,7 +159,8 @@ __global__ __launch_bounds__(NW * 64) void bptt_step_kernel(const float* __restr
 // chunk: 16 lanes read 64 contiguous bytes of one k row, the row base is wave-uniform (SGPR) and
 // the lane part a fixed 32-bit offset.  Out-of-range columns are clamped on load and never stored.
 // AR: arithmetic of the products (fsn_mma_k16): the lane's four k of a chunk ARE the 16-bit instruction's operand.
-template <int RTW, int CTW, int WM, int WN, int AR = FSN_ARITH_F32, int PF = 2>
+// ABL: experiment knob of tools/probe_tn.hip (0 in the library; a set bit gives WRONG results): 1 operands not loaded
+template <int RTW, int CTW, int WM, int WN, int AR = FSN_ARITH_F32, int PF = 2, int ABL = 0>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, long lda,
                                                       const float* __restrict__ B, long ldb,
                                                       float* __restrict__ part, int M, int Nc, long K, long k_per_split,
@@ -216,9 +217,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
             const float* ar = a0 + ((long)kc * 16 + j) * lda;  // wave-uniform row bases
             const float* br = b0 + ((long)kc * 16 + j) * ldb;
 #pragma unroll
-            for (int i = 0; i < RTW; ++i) abuf[p][i][j] = ar[aoff[i]];
+            for (int i = 0; i < RTW; ++i) abuf[p][i][j] = (ABL & 1) ? 0.25f * (float)kc : ar[aoff[i]];
 #pragma unroll
-            for (int i = 0; i < CTW; ++i) bbuf[p][i][j] = br[boff[i]];
+            for (int i = 0; i < CTW; ++i) bbuf[p][i][j] = (ABL & 1) ? 0.5f : br[boff[i]];
         }
     };
     auto consume = [&](int p) {
@@ -656,6 +657,11 @@ TnPlan tn_plan(int M, int Nc, long K, int arith = FSN_ARITH_F32, bool allow_squa
 }
 #ifndef FSN_TN_PF32
 #define FSN_TN_PF32 2  // operand chunks in flight of the fp32 192 x 192 form (measured r04: 2 -> 3.76 ms, 3 -> 3.72: not latency-bound)
+// (r04, tools/probe_tn.hip, profiles/r04_tn_probe.txt: without its operand loads this kernel's matrix stream runs at 0.98 of
+// the fp32 peak, 3.03 ms, with them at 0.80, 3.67.  Three LDS-staged forms of the same product - 16-byte row pieces through
+// registers with one / two chunks in flight, and by LDS-DMA with software-pipelined ds_read_b32 operands - measured 4.6 /
+// 4.2 / 3.67 ms: the staged form only reaches the register ring's time (its DMA costs 0.3 ms, its LDS reads 0.2, its
+// barrier 0.15), so the ring stays.)
 #endif
 constexpr size_t kTnOnePerCu = 96 * 1024;  // LDS reservation (never touched): one workgroup per CU
 constexpr long kColsumRows = 2048;
