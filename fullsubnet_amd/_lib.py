@@ -132,6 +132,9 @@ SIGNATURES = {
     "fsn_lstm2_backward": (_c.c_int, [_f32p, _f32p, _c.c_long, _f32p, _f32p, _f32p, _f32p] + [_c.c_int] * 4 +
                            [_f32p, _f32p, _c.c_void_p, _c.c_void_p, _f32p, _c.c_long] + [_f32p] * 6 +
                            [_c.c_void_p, _c.c_size_t, _c.c_int, _c.c_void_p]),
+    "fsn_lstm2_backward_phase": (_c.c_int, [_f32p, _f32p, _c.c_long, _f32p, _f32p, _f32p, _f32p] + [_c.c_int] * 4 +
+                                 [_f32p, _f32p, _c.c_void_p, _c.c_void_p, _f32p, _c.c_long] + [_f32p] * 6 +
+                                 [_c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_void_p]),
     "fsn_lstm_layer_backward": (_c.c_int, [_f32p, _f32p, _c.c_long, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_int,
                                            _c.c_int, _f32p, _c.c_void_p, _f32p, _c.c_long, _f32p, _f32p, _f32p,
                                            _c.c_void_p, _c.c_size_t, _c.c_void_p]),

@@ -2602,12 +2602,18 @@ extern "C" size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H, int 
     cv.take<char>(l1 > l0 ? l1 : l0);
     return fsn_round_up_sz(cv.off, 256);
 }
-extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, const float* w_ih0, const float* w_hh0,
-                                  const float* w_ih1, const float* w_hh1, int T, int N, int I, int H, const float* hseq0,
-                                  const float* hseq1, const void* save0, const void* save1, float* dx, long lddx,
-                                  float* dw_ih0, float* dw_hh0, float* db0, float* dw_ih1, float* dw_hh1, float* db1,
-                                  void* workspace, size_t workspace_bytes, int arith, void* stream) {
+// `phase`: which parts run (a sum; 7 = everything) - 1: back-propagation through time, the gate gradients stay in the
+// workspace; 4: dx from them; 2: the weight- and bias-gradient products from them.  Parts 2 and 4 take the same arguments
+// and the same workspace, untouched since part 1; either may be issued on another stream, ordered behind part 1 by the
+// caller.  The persistent shapes only (sub-band group kernels, full-band chain): the layer-by-layer form runs whole in
+// part 1.
+static int lstm2_backward_phases(const float* dh1, const float* x, long ldx, const float* w_ih0, const float* w_hh0,
+                                 const float* w_ih1, const float* w_hh1, int T, int N, int I, int H, const float* hseq0,
+                                 const float* hseq1, const void* save0, const void* save1, float* dx, long lddx,
+                                 float* dw_ih0, float* dw_hh0, float* db0, float* dw_ih1, float* dw_hh1, float* db1,
+                                 void* workspace, size_t workspace_bytes, int arith, void* stream, int phase) {
     CallScope scope(stream);
+    const bool chain_part = (phase & 1) != 0, products_part = (phase & 2) != 0, dx_part = (phase & 4) != 0;
     FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
     FSN_REQUIRE(arith == FSN_ARITH_F32 || arith == FSN_ARITH_F16 || arith == FSN_ARITH_BF16,
                 "lstm2 backward: arithmetic %d unknown (FSN_ARITH_F32 / _F16 / _BF16)", arith);
@@ -2637,18 +2643,18 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
         size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
         const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
         void* scratch = cv.take<char>(tn > tn2 ? tn : tn2);
-        FSN_TRY(fsn_launch_pack(w_hh1, whh1T_p, H, G, H, G, s, 1, H));
-        FSN_TRY(fsn_launch_pack(w_ih1, wih1T_p, H, G, H, G, s, 1, H));
-        FSN_TRY(fsn_launch_pack(w_hh0, whh0T_p, H, G, H, G, s, 1, H));
-        if (dx) FSN_TRY(fsn_launch_pack(w_ih0, wih0T_p, I, G, Ipad, G, s, 1, I));
-        {
+        if (chain_part) {
+            FSN_TRY(fsn_launch_pack(w_hh1, whh1T_p, H, G, H, G, s, 1, H));
+            FSN_TRY(fsn_launch_pack(w_ih1, wih1T_p, H, G, H, G, s, 1, H));
+            FSN_TRY(fsn_launch_pack(w_hh0, whh0T_p, H, G, H, G, s, 1, H));
+            if (dx) FSN_TRY(fsn_launch_pack(w_ih0, wih0T_p, I, G, Ipad, G, s, 1, I));
             FSN_PERSIST_BEGIN(s);
             FSN_TRY(fsn_launch_fb_chain_bptt(dh1, whh1T_p, wih1T_p, whh0T_p, static_cast<const float*>(save0),
                                              static_cast<const float*>(save1), dg0, dg1, dxp, flags, T, N, H, s));
             // both gate-gradient buffers (dg1 | dg0 are adjacent): every weight gradient and dx derive from them
             FSN_TRY(fsn_launch_poison_if(flags + fsn_fb_chain_bptt_status_word(), dg1, (size_t)2 * T * N * G, s));
         }
-        if (dx) {
+        if (dx && dx_part) {
             FsnGemmA a{};
             a.kind = 0;
             a.p0 = dg0;
@@ -2661,6 +2667,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
             c.cols = I;
             FSN_TRY(fsn_launch_gemm(a, wih0T_p, c, T * (N / 16), Ipad / 16, G / 16, s));
         }
+        if (!products_part) return FSN_OK;
         FSN_TRY(fsn_launch_gemm_tn(dg1, G, hseq0, H, dw_ih1, H, G, H, (long)T * N, scratch, s, db1));
         FSN_TRY(fsn_launch_gemm_tn(dg0, G, x, ldx, dw_ih0, I, G, I, (long)T * N, scratch, s, db0));
         if (T > 1) {
@@ -2674,6 +2681,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
         return FSN_OK;
     }
     if (!clusters) {  // layer by layer; layer 1's dx is d loss / d hseq0
+        if (!chain_part) return FSN_OK;  // (this form ran whole in phase 1)
         Carver cv(workspace);
         float* dh0 = cv.take<float>((size_t)T * N * H);
         const size_t l1 = fsn_lstm_layer_bwd_workspace_bytes(T, N, H, H), l0 = fsn_lstm_layer_bwd_workspace_bytes(T, N, I, H);
@@ -2712,6 +2720,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
     const bool tn16h = g16 && T > 1 && fsn_gemm_tn16h_supported(G, H, (long)(T - 1) * N) && !g_tn16h_off.load(std::memory_order_relaxed);
     const float* sv0 = static_cast<const float*>(save0);
     const float* sv1 = static_cast<const float*>(save1);
+    if (chain_part) {
     // "weights" of dh = dgates W are W^T: out = H columns, k = 4H; nn.LSTM stores exactly that transposed
     FSN_TRY(fsn_launch_pack(w_hh1, whh1T_p, H, G, H, G, s, 1, H));
     FSN_TRY(fsn_launch_pack(w_ih1, wih1T_p, H, G, H, G, s, 1, H));
@@ -2785,9 +2794,10 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
             return FSN_ERR_LAUNCH;
         }
     }
-    FsnGemmA a{};
-    FsnGemmC c{};
-    if (dx) {
+    }  // chain_part
+    if (dx && dx_part) {
+        FsnGemmA a{};
+        FsnGemmC c{};
         a.kind = 0;
         a.p0 = dg0;
         a.ld = G;
@@ -2798,6 +2808,7 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
         c.cols = I;
         FSN_TRY(fsn_launch_gemm(a, wih0T_p, c, T * (N / 16), Ipad / 16, G / 16, s));
     }
+    if (!products_part) return FSN_OK;
     // dW_ih = dgates^T X (+ db = its column sums: fp32 adds in every arithmetic), dW_hh = dgates_{1..}^T H_{0..T-2}
     if (g16) {
         // bias gradients = the BPTT launch's cluster sums + the step-by-step rows; those rows' 16-bit gate gradients
@@ -2833,6 +2844,24 @@ extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, co
         return FSN_ERR_LAUNCH;
     }
     return FSN_OK;
+}
+
+extern "C" int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, const float* w_ih0, const float* w_hh0,
+                                  const float* w_ih1, const float* w_hh1, int T, int N, int I, int H, const float* hseq0,
+                                  const float* hseq1, const void* save0, const void* save1, float* dx, long lddx,
+                                  float* dw_ih0, float* dw_hh0, float* db0, float* dw_ih1, float* dw_hh1, float* db1,
+                                  void* workspace, size_t workspace_bytes, int arith, void* stream) {
+    return lstm2_backward_phases(dh1, x, ldx, w_ih0, w_hh0, w_ih1, w_hh1, T, N, I, H, hseq0, hseq1, save0, save1, dx, lddx, dw_ih0,
+                                 dw_hh0, db0, dw_ih1, dw_hh1, db1, workspace, workspace_bytes, arith, stream, 7);
+}
+extern "C" int fsn_lstm2_backward_phase(const float* dh1, const float* x, long ldx, const float* w_ih0, const float* w_hh0,
+                                        const float* w_ih1, const float* w_hh1, int T, int N, int I, int H, const float* hseq0,
+                                        const float* hseq1, const void* save0, const void* save1, float* dx, long lddx,
+                                        float* dw_ih0, float* dw_hh0, float* db0, float* dw_ih1, float* dw_hh1, float* db1,
+                                        void* workspace, size_t workspace_bytes, int arith, int phase, void* stream) {
+    FSN_REQUIRE(phase >= 1 && phase <= 7, "lstm2 backward parts %d: a sum of 1 (through time), 2 (weight-gradient products), 4 (dx)", phase);
+    return lstm2_backward_phases(dh1, x, ldx, w_ih0, w_hh0, w_ih1, w_hh1, T, N, I, H, hseq0, hseq1, save0, save1, dx, lddx, dw_ih0,
+                                 dw_hh0, db0, dw_ih1, dw_hh1, db1, workspace, workspace_bytes, arith, stream, phase);
 }
 
 // ---- nn.GRU layer (sequence_model.py:59-66): forward (inference / training) + BPTT -----------------

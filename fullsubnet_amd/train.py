@@ -330,6 +330,19 @@ class SubbandInputOffline(torch.autograd.Function):
         return d_x, d_fb, None, None
 
 
+# FullSubNetTrainFunction.backward: the sub-band weight-gradient products on a second stream beside the full-band model's
+# backward (False: everything on the caller's stream, in order)
+OVERLAP_WEIGHT_PRODUCTS = True
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device)
+    return _SIDE[key]
+
+
 _ONE = {}
 
 
@@ -341,10 +354,10 @@ def _one(device):
     return _ONE[key]
 
 
-def _dup(t):
+def _dup(t, out=None):
     """A second buffer with the same values through the library (b_ih and b_hh receive the same gradient, and the fused
     optimizer clips gradients in place: they must not share storage)."""
-    out = torch.empty_like(t)
+    out = torch.empty_like(t) if out is None else out
     _lib.check(_lib.lib().fsn_scale_by_scalar(_lib.dev_ptr(t), _lib.dev_ptr(_one(t.device)), _lib.dev_ptr(out), t.numel(),
                                               _lib.stream_ptr(t.device)))
     return out
@@ -434,27 +447,47 @@ class FullSubNetTrainFunction(torch.autograd.Function):
                                              ldx, _lib.dev_ptr(dw), _lib.dev_ptr(db), ws.data_ptr(), ws.numel(), st))
             return dx, dw, db
 
-        def lstm2_bwd(dh, x, ldx, w, h0, h1, s0, s1, N, I, H, need_dx):
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if OVERLAP_WEIGHT_PRODUCTS else None
+        keep = []  # what the side stream still reads: alive until the join below
+
+        def lstm2_bwd(dh, x, ldx, w, h0, h1, s0, s1, N, I, H, need_dx, beside=False):
             dx = new(Tp, N, ldx) if need_dx else None
             dw = [torch.empty_like(w[k]) for k in (0, 1, 4, 5)]
             db0, db1 = new(4 * H), new(4 * H)
             ws = _lib.workspace(L.fsn_lstm2_bwd_workspace_bytes(Tp, N, I, H, ar), dev)
-            _lib.check(L.fsn_lstm2_backward(
-                _lib.dev_ptr(dh), _lib.dev_ptr(x), ldx, _lib.dev_ptr(w[0]), _lib.dev_ptr(w[1]), _lib.dev_ptr(w[4]), _lib.dev_ptr(w[5]),
-                Tp, N, I, H, _lib.dev_ptr(h0), _lib.dev_ptr(h1), s0.data_ptr(), s1.data_ptr(), _lib.dev_ptr(dx, allow_none=True), ldx,
-                _lib.dev_ptr(dw[0]), _lib.dev_ptr(dw[1]), _lib.dev_ptr(db0), _lib.dev_ptr(dw[2]), _lib.dev_ptr(dw[3]), _lib.dev_ptr(db1),
-                ws.data_ptr(), ws.numel(), ar, st))
+            args = (_lib.dev_ptr(dh), _lib.dev_ptr(x), ldx, _lib.dev_ptr(w[0]), _lib.dev_ptr(w[1]), _lib.dev_ptr(w[4]), _lib.dev_ptr(w[5]),
+                    Tp, N, I, H, _lib.dev_ptr(h0), _lib.dev_ptr(h1), s0.data_ptr(), s1.data_ptr(), _lib.dev_ptr(dx, allow_none=True), ldx,
+                    _lib.dev_ptr(dw[0]), _lib.dev_ptr(dw[1]), _lib.dev_ptr(db0), _lib.dev_ptr(dw[2]), _lib.dev_ptr(dw[3]), _lib.dev_ptr(db1),
+                    ws.data_ptr(), ws.numel(), ar)
+            if beside and side is not None:
+                # Only dx is waited for (the full-band model's backward hangs on it): back-propagation through time and dx
+                # here, the weight- and bias-gradient products on a second stream BESIDE dx and what follows - the
+                # full-band chain is a latency-bound launch on 96 CUs that leaves the chip to them (fsn_lstm2_backward_phase)
+                _lib.check(L.fsn_lstm2_backward_phase(*args, 1, st))
+                db0b, db1b = torch.empty_like(db0), torch.empty_like(db1)  # (allocated on the caller's stream, like all outputs)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    _lib.check(L.fsn_lstm2_backward_phase(*args, 2, _lib.stream_ptr(dev)))
+                    _dup(db0, db0b), _dup(db1, db1b)
+                _lib.check(L.fsn_lstm2_backward_phase(*args, 4, st))
+                keep.extend((ws, dh, dx))
+                return dx, [dw[0], dw[1], db0, db0b, dw[2], dw[3], db1, db1b]
+            _lib.check(L.fsn_lstm2_backward(*args, st))
             return dx, [dw[0], dw[1], db0, _dup(db0), dw[2], dw[3], db1, _dup(db1)]
 
         dy2 = new(Tp * Rp, 16)
         _lib.check(L.fsn_train_mask_grad(dp, _lib.dev_ptr(dm, "d_mask"), _lib.dev_ptr(dy2), Rp, 16, st))
         dsh1, d_sfw, d_sfb = linear_bwd(dy2, 16, sh1, Hs, sb_fc[0], Tp * Rp, Hs, 2)
-        dx_sb, g_sb = lstm2_bwd(dsh1, sb_in, 32, sb, sh0, sh1, ss0, ss1, Rp, Is, Hs, True)
+        dx_sb, g_sb = lstm2_bwd(dsh1, sb_in, 32, sb, sh0, sh1, ss0, ss1, Rp, Is, Hs, True, beside=True)
         d_fb = new(Tp * Bp, Fp)
         _lib.check(L.fsn_train_sb_input_backward(dp, _lib.dev_ptr(dx_sb), _lib.dev_ptr(sb_in), Rp, _lib.dev_ptr(den), _lib.dev_ptr(fb_out),
                                                  F, Bp, _lib.dev_ptr(d_fb), Fp, gws.data_ptr(), gws.numel(), st))
         dfh1, d_ffw, d_ffb = linear_bwd(d_fb, Fp, fh1, Hf, fb_fc[0], Tp * Bp, Hf, F)
         _, g_fb = lstm2_bwd(dfh1, x_tm, Fp, fb, fh0, fh1, fs0, fs1, Bp, F, Hf, False)
+        if side is not None:
+            main.wait_stream(side)  # the sub-band weight gradients: everything after this call sees them
+            keep.clear()
         return (None, None, None, None, None, *g_fb, d_ffw, d_ffb, *g_sb, d_sfw, d_sfb)
 
 

@@ -288,6 +288,18 @@ int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, const float* 
                        float* dw_hh0, float* db0, float* dw_ih1, float* dw_hh1, float* db1, void* workspace,
                        size_t workspace_bytes, int arith, void* stream);
 
+/* The same in parts, for callers that have other work waiting on dx (fullsubnet/trainer.py:56-69: the full-band model's
+ * backward only needs the sub-band model's input gradient).  `phase` is a sum of 1 = back-propagation through time (the
+ * gate gradients stay in the workspace), 4 = dx from them, 2 = the weight- and bias-gradient products from them; 7 =
+ * fsn_lstm2_backward.  Parts 2 and 4 take the same arguments and the same workspace as part 1, which nothing else may touch
+ * in between; either may be issued on ANOTHER stream, ordered behind part 1 by the caller (an event), so that the products
+ * run beside whatever follows dx. */
+int fsn_lstm2_backward_phase(const float* dh1, const float* x, long ldx, const float* w_ih0, const float* w_hh0,
+                             const float* w_ih1, const float* w_hh1, int T, int N, int I, int H, const float* hseq0,
+                             const float* hseq1, const void* save0, const void* save1, float* dx, long lddx, float* dw_ih0,
+                             float* dw_hh0, float* db0, float* dw_ih1, float* dw_hh1, float* db1, void* workspace,
+                             size_t workspace_bytes, int arith, int phase, void* stream);
+
 /* nn.GRU branch of SequenceModel (sequence_model.py:59-66), one layer, unidirectional, h0 = 0; same
  * conventions as the LSTM layer above with 3H gate rows (r, z, n).  save == NULL: inference.  The two
  * bias gradients differ in the n block (b_hn sits inside r * (W_hn h + b_hn)), hence two outputs. */

@@ -189,6 +189,44 @@ def test_fused_training_graph_vs_the_tensor_algebra_graph(fsn, B, groups, T, ari
     assert got.shape == want.shape and torch.equal(got, want.contiguous())
 
 
+@pytest.mark.parametrize("arith", ["f32", "f16"])
+def test_weight_gradient_products_beside_the_full_band_backward(fsn, arith):
+    """FullSubNetTrainFunction.backward issues the sub-band model's weight- and bias-gradient products on a second stream
+    (fsn_lstm2_backward_phase parts 1 / 2 / 4: through time, products, dx) beside the full-band model's backward: the
+    gradients must be the very numbers of the in-line order (same kernels, same operands), twice in a row, and a step
+    taken right after the backward must see them (the join is inside the call)."""
+    import fullsubnet_amd.train as TR
+    from fullsubnet_amd.train import forward_train
+    params = O.make_params(seed=21, gain=1.5)
+    rng = np.random.default_rng(5)
+    B, T = 16, 40  # 16 x 128 kept bins = 32 whole clusters: the persistent group kernels; the full-band chain at 16 rows
+    mag = torch.from_numpy((np.abs(rng.standard_normal((B, 1, 257, T))) + 0.05).astype(np.float32)).cuda()
+    w = None
+    grads = {}
+    assert TR.OVERLAP_WEIGHT_PRODUCTS
+    try:
+        for mode in (True, False, True):
+            TR.OVERLAP_WEIGHT_PRODUCTS = mode
+            model = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=2, **MODEL_KW)
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+            model = model.cuda().train()
+            model.train_arithmetic = arith
+            out = forward_train(model, mag)
+            if w is None:
+                w = torch.from_numpy(rng.standard_normal(tuple(out.shape)).astype(np.float32)).cuda() * 64.0
+            (out * w).sum().backward()
+            total = torch.stack([p.grad.double().pow(2).sum() for p in model.parameters()]).sum()  # consumed at once
+            g = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+            assert torch.isfinite(total)
+            grads.setdefault(mode, []).append(g)
+    finally:
+        TR.OVERLAP_WEIGHT_PRODUCTS = True
+    assert fsn._lib.stream_status(synchronize=True) == (0, 0)
+    for k, ref in grads[False][0].items():
+        for g in grads[True]:
+            assert torch.equal(g[k], ref), k
+
+
 @pytest.mark.parametrize("R,I,O,relu", [(68, 512, 257, True), (33, 384, 2, False), (16, 32, 48, False)])
 def test_linear_forward_backward(fsn, R, I, O, relu):
     from fullsubnet_amd.train import LinearFunction

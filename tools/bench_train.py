@@ -1,5 +1,5 @@
 """Time one training step (BASELINE config 3 per-rank shape: 16 x 3.072 s) on one MI355X.
-python tools/bench_train.py [batch] [f32|f16|bf16] [g16=0]   (f16 / bf16: autocast arithmetic + GradScaler)"""
+python tools/bench_train.py [batch] [f32|f16|bf16] [g16=0] [overlap=0]   (f16 / bf16: autocast arithmetic + GradScaler)"""
 import os
 import sys
 import time
@@ -24,6 +24,9 @@ if "g16=0" in sys.argv:  # A/B: the fp32-era group kernels under the 16-bit arit
     fullsubnet_amd._lib.lib().fsn_debug_g16_kernels(0)
 if "g16=2" in sys.argv:  # A/B: weight-gradient products converting their operands on the fly (gemm_tn16_kernel)
     fullsubnet_amd._lib.lib().fsn_debug_g16_kernels(2)
+if "overlap=0" in sys.argv:  # A/B: the sub-band weight-gradient products in line instead of beside the full-band backward
+    import fullsubnet_amd.train as _tr
+    _tr.OVERLAP_WEIGHT_PRODUCTS = False
 scaler = torch.amp.GradScaler("cuda", enabled=ARITH != "f32")
 opt = fullsubnet_amd.ClipAdam(model.parameters(), lr=1e-3)
 noisy = torch.from_numpy(make_noisy(B, L, seed=1)).cuda()
