@@ -88,14 +88,20 @@ __device__ __forceinline__ void q_publish(unsigned* flag, unsigned epoch) {
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// XS: the scope of the exchanged payload.  16 = sc1, device scope: never from this CU's L1, and lines written by a CU of
+// another XCD are fetched through the fabric - valid wherever the workgroups run.  1 = sc0: never from this CU's L1, served
+// by this XCD's L2 - valid only between workgroups of ONE XCD (whose L2 is their point of coherence); the forward kernel
+// takes it when every workgroup of a cluster reports the same XCD at start (HW_REG_XCC_ID), see lstm2_g16_fwd_kernel.
+template <int XS = 16>
 __device__ __forceinline__ f32x4 q_load_sc1(const __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16));  // aux 16 = sc1: never from this CU's L1
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, XS));
 }
 __device__ __forceinline__ f32x4 q_load(const __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+template <int XS = 16>
 __device__ __forceinline__ void q_store_sc1(const __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(q_u32x4, v), r, voff, soff, 16);  // write-through
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(q_u32x4, v), r, voff, soff, XS);  // write-through
 }
 __device__ __forceinline__ void q_store(const __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(q_u32x4, v), r, voff, soff, 0);
@@ -197,7 +203,7 @@ struct G16FwdArgs {
 
 // ABL: experiment knob of tools/probe_g16.hip (0 in the library; any bit set gives WRONG results): 1 no flag waits, 2 the
 // partners' tiles not loaded (constants staged), 4 no weight loads (constant fragments), 8 no saves, 16 no h stores
-template <int LAYER, int AR, int ABL>
+template <int LAYER, int AR, int ABL, int XS>
 __device__ __forceinline__ void g16_fwd_body(const G16FwdArgs& a, int cluster, int member, unsigned char* act, unsigned char* xsm) {
     float live = 0.f;  // keeps ablated values alive
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -239,8 +245,8 @@ __device__ __forceinline__ void g16_fwd_body(const G16FwdArgs& a, int cluster, i
                     v[2 * i] = f32x4{0.01f * (float)row, 0.02f, -0.01f, 0.03f};
                     v[2 * i + 1] = f32x4{0.02f, -0.03f, 0.01f * (float)k8, 0.f};
                 } else {
-                    v[2 * i] = q_load_sc1(src, go, 0);
-                    v[2 * i + 1] = q_load_sc1(src, go, 16);
+                    v[2 * i] = q_load_sc1<XS>(src, go, 0);
+                    v[2 * i + 1] = q_load_sc1<XS>(src, go, 16);
                 }
             }
 #pragma unroll
@@ -371,7 +377,7 @@ __device__ __forceinline__ void g16_fwd_body(const G16FwdArgs& a, int cluster, i
                 sg[e][0][i] = ig, sg[e][1][i] = fg, sg[e][2][i] = gg, sg[e][3][i] = og;
             }
             if constexpr ((ABL & 16) != 0) live += hv[0] + hv[1] + hv[2] + hv[3];
-            else q_store_sc1(rh, (unsigned)((row * QH + QU * member + quad * 4) * 4), 0, hv);
+            else q_store_sc1<XS>(rh, (unsigned)((row * QH + QU * member + quad * 4) * 4), 0, hv);
         }
         q_publish(myflag, (unsigned)t + 1);  // its barrier also closes the reads of the gate exchange
         // the saves of the step, AFTER the hand-off (only h belongs to it)
@@ -413,8 +419,45 @@ __global__ __launch_bounds__(256, 2) void lstm2_g16_fwd_kernel(const G16FwdArgs 
         cluster = bid / QM;
         member = bid % QM;
     }
-    if (layer == 0) g16_fwd_body<0, AR, ABL>(a, cluster, member, act, xsm);
-    else g16_fwd_body<1, AR, ABL>(a, cluster, member, act, xsm);
+    // Placement check: every workgroup reports the XCD it runs on (HW_REG_XCC_ID) and reads its cluster's sixteen reports;
+    // only when all agree is the payload exchanged at XCD scope (XS = 1: 9 % of the launch, the partners' tiles come from
+    // the shared L2 instead of through the fabric).  Any other placement - or a timeout - takes the device-scope path:
+    // results never depend on where the workgroups run.  (ABL & 64: the probe's device-scope run.)
+    bool same_xcd = false;
+    {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc = (xcc & 0xfu) + 1u;
+        unsigned* reports = a.flags + (size_t)nclusters * 2 * QFS + (size_t)cluster * QFS;  // [layer][member], zeroed by the host
+        unsigned* agree = reinterpret_cast<unsigned*>(xsm);
+        if (threadIdx.x == 0) __hip_atomic_store(reports + layer * QM + member, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((threadIdx.x >> 6) == 0) {
+            const int lane = threadIdx.x & 63;
+            unsigned long long t0 = 0;
+            unsigned v = xcc;
+            for (unsigned spins = 0;; ++spins) {
+                if (lane < 2 * QM) v = __hip_atomic_load(reports + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((int)(v != 0u))) break;
+                if ((spins & 255u) == 255u && fsn_wait_give_up(a.status, spins, t0, a.spin_ticks, 0x7000u)) {
+                    v = 0u;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const bool ok = __all((int)(v == xcc));
+            if (lane == 0) *agree = ok ? 1u : 0u;
+        }
+        __syncthreads();
+        same_xcd = *agree != 0u && (ABL & 64) == 0;
+        __syncthreads();  // (xsm is the layer-0 input tile afterwards)
+    }
+    if (same_xcd) {
+        if (layer == 0) g16_fwd_body<0, AR, ABL, 1>(a, cluster, member, act, xsm);
+        else g16_fwd_body<1, AR, ABL, 1>(a, cluster, member, act, xsm);
+    } else {
+        if (layer == 0) g16_fwd_body<0, AR, ABL, 16>(a, cluster, member, act, xsm);
+        else g16_fwd_body<1, AR, ABL, 16>(a, cluster, member, act, xsm);
+    }
 }
 
 // ---- back-propagation through time --------------------------------------------------------------------------------

@@ -80,6 +80,7 @@ int main(int argc, char** argv) {
         unsigned st = 0; hipMemcpy(&st, a.status, 4, hipMemcpyDeviceToHost);
         printf("arithmetic %d: lstm2_g16_fwd_kernel, %d clusters, %d steps: %.3f ms = %.1f us per step, status %u\n", PROBE_AR, clusters, Tp, t0, 1e3 * t0 / Tp, st);
 #define VF(abl, what) { const float t = run_fwd<abl>(a); printf("  %-60s: %.3f ms = %.1f us per step\n", what, t, 1e3 * t / Tp); }
+        VF(64, "payload at device scope (what any other placement takes)");
         VF(8, "no saves");
         VF(4, "no weight loads");
         VF(2, "partners' tiles not loaded (constants staged)");
