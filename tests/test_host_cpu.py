@@ -84,6 +84,29 @@ def test_two_layer_training_entries_size_queries_without_a_gpu():
     assert L.fsn_lstm2_forward_is_persistent(100, 2048, 16, 48, 384, 384) == 0   # x rows wider than two K chunks
 
 
+def test_fast_fullsubnet_glue_queries_without_a_gpu():
+    """fsn_fast_low_rate_frames = the length real_time_downsampling produces (fast_fullsubnet/model.py:108-129: frame 0,
+    then blocks of `shrink` frames, a shorter last block kept) for every (T, shrink); the workspace query covers the two
+    down-sampled sources + one mean per utterance; bad sizes answer 0."""
+    from fullsubnet_amd import _lib
+    from fullsubnet_amd.fast_fullsubnet import Model
+    L = _lib.lib()
+    m = Model.__new__(Model)  # the glue methods only read shrink_size
+    for shrink in (1, 2, 3, 4, 7):
+        m.shrink_size = shrink
+        for T in range(2, 40):
+            want = m.real_time_downsampling(torch.zeros(1, 1, 1, T)).shape[-1]
+            assert L.fsn_fast_low_rate_frames(T, shrink) == want, (T, shrink)
+            up = m.real_time_upsampling(torch.zeros(1, 1, 1, want), target_len=T)
+            assert up.shape[-1] == T  # every frame t finds its low-rate frame t // shrink
+            assert (T - 1) // shrink < want
+    Ts = L.fsn_fast_low_rate_frames(190, 2)
+    assert L.fsn_fast_glue_workspace_bytes(190, 256, 64, 2) >= 2 * Ts * 256 * 64 * 4 + 256 * 4
+    for bad in ((1, 4, 64, 2), (10, 0, 64, 2), (10, 4, 0, 2), (10, 4, 64, 0)):
+        assert L.fsn_fast_glue_workspace_bytes(*bad) == 0
+    assert L.fsn_fast_low_rate_frames(1, 2) == 0 and L.fsn_fast_low_rate_frames(10, 0) == 0
+
+
 def test_model_surface_matches_reference_state_dict():
     from fullsubnet_amd import Model, _lib
     from oracle.fullsubnet_oracle import make_params
