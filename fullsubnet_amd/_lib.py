@@ -132,6 +132,10 @@ SIGNATURES = {
     "fsn_lstm2_backward": (_c.c_int, [_f32p, _f32p, _c.c_long, _f32p, _f32p, _f32p, _f32p] + [_c.c_int] * 4 +
                            [_f32p, _f32p, _c.c_void_p, _c.c_void_p, _f32p, _c.c_long] + [_f32p] * 6 +
                            [_c.c_void_p, _c.c_size_t, _c.c_int, _c.c_void_p]),
+    "fsn_lstm_layer_fc_supported": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_int]),
+    "fsn_lstm_layer_fc_workspace_bytes": (_c.c_size_t, [_c.c_int] * 4),
+    "fsn_lstm_layer_forward_fc": (_c.c_int, [_f32p, _c.c_long, _f32p, _f32p, _f32p, _f32p] + [_c.c_int] * 4 +
+                                  [_f32p, _f32p, _c.c_int, _f32p, _f32p, _c.c_long, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "fsn_lstm2_backward_phase": (_c.c_int, [_f32p, _f32p, _c.c_long, _f32p, _f32p, _f32p, _f32p] + [_c.c_int] * 4 +
                                  [_f32p, _f32p, _c.c_void_p, _c.c_void_p, _f32p, _c.c_long] + [_f32p] * 6 +
                                  [_c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int, _c.c_void_p]),
@@ -194,7 +198,7 @@ SIGNATURES = {
     "fsn_fast_norm_rows": (_c.c_int, [_f32p] + [_c.c_int] * 4 + [_f32p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "fsn_fast_bottleneck_input": (_c.c_int, [_f32p, _f32p, _c.c_long] + [_c.c_int] * 7 + [_f32p, _c.c_int, _c.c_int, _c.c_void_p,
                                              _c.c_size_t, _c.c_void_p]),
-    "fsn_fast_decoder_input": (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _c.c_long] + [_c.c_int] * 5 + [_f32p, _c.c_void_p]),
+    "fsn_fast_decoder_input": (_c.c_int, [_f32p, _c.c_long, _f32p, _c.c_long, _c.c_long] + [_c.c_int] * 6 + [_f32p, _c.c_void_p]),
     "fsn_fast_mask_out": (_c.c_int, [_f32p, _c.c_long] + [_c.c_int] * 5 + [_f32p, _c.c_void_p]),
     "fsn_profile_enable": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "fsn_stream_timeout_policy": (_c.c_int, [_c.c_void_p, _c.c_int]),

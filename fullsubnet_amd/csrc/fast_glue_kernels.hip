@@ -153,14 +153,21 @@ __global__ __launch_bounds__(256) void fast_units_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void fast_decoder_input_kernel(const float* __restrict__ enc, long ld_enc,
                                                                  const float* __restrict__ slow, long ld_slow_t, long ld_slow_r,
                                                                  float* __restrict__ out, int T, int B, int Bp, int M,
-                                                                 int shrink) {
+                                                                 int shrink, int relu) {
     const long per_t = (long)Bp * 2 * M;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const int t = blockIdx.y;
     if (i >= per_t) return;
     const int b = (int)(i / (2 * M)), c = (int)(i % (2 * M));
     float v = 0.f;
-    if (b < B) v = c < M ? enc[((size_t)t * Bp + b) * ld_enc + c] : slow[(size_t)(t / shrink) * ld_slow_t + ((size_t)b * M + (c - M)) * ld_slow_r];
+    if (b < B) {
+        if (c < M) {
+            v = enc[((size_t)t * Bp + b) * ld_enc + c];
+        } else {  // the bottleneck's output, held; `relu`: it arrives as the output layer's pre-activation
+            v = slow[(size_t)(t / shrink) * ld_slow_t + ((size_t)b * M + (c - M)) * ld_slow_r];
+            if (relu) v = fmaxf(v, 0.f);
+        }
+    }
     out[(size_t)t * per_t + i] = v;
 }
 
@@ -258,8 +265,8 @@ extern "C" int fsn_fast_bottleneck_input(const float* mel, const float* enc, lon
     return fsn_check_launch("fast_units_kernel");
 }
 
-extern "C" int fsn_fast_decoder_input(const float* enc, long ld_enc, const float* slow, long ld_slow_frame, long ld_slow_row, int T,
-                                      int B, int Bp, int num_mels, int shrink, float* out, void* stream) {
+extern "C" int fsn_fast_decoder_input(const float* enc, long ld_enc, const float* slow, long ld_slow_frame, long ld_slow_row, int relu,
+                                      int T, int B, int Bp, int num_mels, int shrink, float* out, void* stream) {
     FsnCallScope scope(stream);
     FSN_REQUIRE(enc && slow && out, "NULL pointer argument");
     FSN_REQUIRE(T >= 1 && B >= 1 && Bp >= B && num_mels >= 1 && ld_enc >= num_mels && shrink >= 1 && ld_slow_row >= 1 &&
@@ -267,7 +274,7 @@ extern "C" int fsn_fast_decoder_input(const float* enc, long ld_enc, const float
                 "fast decoder input: need 1 <= T <= 65535, 1 <= B <= Bp, strides not below the sizes");
     const long per_t = (long)Bp * 2 * num_mels;
     hipLaunchKernelGGL(fast_decoder_input_kernel, dim3((unsigned)((per_t + 255) / 256), (unsigned)T), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), enc, ld_enc, slow, ld_slow_frame, ld_slow_row, out, T, B, Bp, num_mels, shrink);
+                       static_cast<hipStream_t>(stream), enc, ld_enc, slow, ld_slow_frame, ld_slow_row, out, T, B, Bp, num_mels, shrink, relu);
     return fsn_check_launch("fast_decoder_input_kernel");
 }
 

@@ -1900,6 +1900,77 @@ extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_i
     return FSN_OK;
 }
 
+// ---- a stacked layer + the output layer that follows it, inference ---------------------------------------------------
+// (sequence_model.py:106-125: `self.fc_output_layer(self.sequence_model(x))` for the LAST layer of a stack with one or two
+// outputs - Fast FullSubNet's bottleneck, fast_fullsubnet/model.py:66-74: 16 384 rows x 384 units -> 1 value per step.)
+// When the persistent kernel that forms the projection itself takes the layer (fsn_lstm_layer_fc_supported), its fused
+// two-row output layer does the nn.Linear as well: the [T][N][H] hidden sequence is neither written nor read back.
+// out0 / out1: [T][ldo] PRE-activation outputs 0 / 1 (time-major; out1 may be NULL when O == 1).
+static bool lstm_layer_fc_plan(int T, int N, int I, long ldx, int H, int O, FsnRecPlan* plan) {
+    if (T < 1 || N < 16 || N % 16 || H != 384 || I != H || ldx != H || O < 1 || O > 2) return false;
+    const FsnRecPlan p = layer_plan(N, H);
+    if (plan) *plan = p;
+    return p.main_wgs > 0 && p.left_tiles == 0 && fsn_lstm_rec_x_supported(H, p.rt);
+}
+extern "C" int fsn_lstm_layer_fc_supported(int T, int N, int I, long ldx, int H, int O) {
+    return lstm_layer_fc_plan(T, N, I, ldx, H, O, nullptr) ? 1 : 0;
+}
+extern "C" size_t fsn_lstm_layer_fc_workspace_bytes(int T, int N, int I, int H) {
+    if (T < 1 || N < 16 || I < 1 || H < 64) return 0;
+    Carver cv(nullptr);
+    cv.take<float>((size_t)4 * H * fsn_round_up(I, 16));
+    cv.take<float>((size_t)4 * H * H);
+    cv.take<float>((size_t)4 * H);
+    cv.take<float>((size_t)16 * H);      // the output layer's two rows as one packed column tile
+    cv.take<float>(16);
+    cv.take<float>((size_t)T * N);       // the unused second output when O == 1
+    return fsn_round_up_sz(cv.off, 256);
+}
+extern "C" int fsn_lstm_layer_forward_fc(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
+                                         const float* b_hh, int T, int N, int I, int H, const float* fc_w, const float* fc_b,
+                                         int O, float* out0, float* out1, long ldo, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+    CallScope scope(stream);
+    FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
+    FSN_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && fc_w && fc_b && out0 && workspace, "NULL pointer argument");
+    FsnRecPlan plan{};
+    FSN_REQUIRE(lstm_layer_fc_plan(T, N, I, ldx, H, O, &plan),
+                "lstm layer + output layer: not a shape of the fused form (H = I = ldx = 384, 1 or 2 outputs, whole rounds of "
+                "2 - 4 row tiles per CU): ask fsn_lstm_layer_fc_supported");
+    FSN_REQUIRE(ldo >= N && (O == 1 || out1), "lstm layer + output layer: ldo %ld < N or the second output is missing", ldo);
+    if (workspace_bytes < fsn_lstm_layer_fc_workspace_bytes(T, N, I, H)) {
+        fsn_set_error("lstm layer + output layer: workspace too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Carver cv(workspace);
+    float* wih_p = cv.take<float>((size_t)4 * H * fsn_round_up(I, 16));
+    float* whh_p = cv.take<float>((size_t)4 * H * H);
+    float* bias = cv.take<float>((size_t)4 * H);
+    float* fcw_p = cv.take<float>((size_t)16 * H);
+    float* fcb_p = cv.take<float>(16);
+    float* spare = cv.take<float>((size_t)T * N);
+    FSN_TRY(fsn_launch_pack(w_ih, wih_p, 4 * H, I, 4 * H, fsn_round_up(I, 16), s));
+    FSN_TRY(fsn_launch_pack(w_hh, whh_p, 4 * H, H, 4 * H, H, s));
+    FSN_TRY(fsn_launch_bias_sum(b_ih, b_hh, bias, 4 * H, 4 * H, s));
+    FSN_TRY(fsn_launch_pack(fc_w, fcw_p, O, H, 16, H, s));
+    FSN_TRY(fsn_launch_bias_sum(fc_b, nullptr, fcb_p, O, 16, s));
+    FsnRecFc fc{};
+    fc.w_p = fcw_p;
+    fc.bias = fcb_p;
+    fc.crm_r = out0;
+    fc.crm_i = O > 1 ? out1 : spare;
+    // the kernel's destination of row n at step t is plane[((n / F) T + t) FP + n % F]: one group of F = N rows, FP = ldo
+    // -> plane[t ldo + n], time-major
+    fc.N = N;
+    fc.F = N;
+    fc.FP = (int)ldo;
+    fc.T = T;
+    fc.la = 0;
+    fc.row0 = 0;
+    return fsn_launch_lstm_rec_x(x, wih_p, whh_p, bias, T, N, H, plan.rt, plan.main_wgs, s, &fc, nullptr);
+}
+
 // ---- training: two stacked nn.LSTM layers of equal width, forward with saved activations ----------------------
 // (sequence_model.py:52-58 with num_layers = 2, under autograd: fullsubnet/trainer.py:56-63).  The result is that of two
 // fsn_lstm_layer_forward calls; what it adds is the persistent kernels: the full-band shape (H = 512, up to 64 rows)

@@ -132,6 +132,30 @@ class Model(BaseModel):
                 and self.bottleneck.output_size == 1 and pair_fusable(enc0, enc1, B) and pair_fusable(dec0, dec1, B)
                 and mix_mag.shape[3] + self.look_ahead >= 2 and mix_mag.dtype == torch.float32)
 
+    def _bottleneck_rows(self, units, N):
+        """The bottleneck block on time-major rows [Ts, Np, Wp] -> ([Ts, Np(, 1)] output, 1 if it is still the output
+        layer's PRE-activation).  A two-layer LSTM stack whose last layer the persistent kernel takes with its fused output
+        layer (fsn_lstm_layer_forward_fc: batch 128+ at 64 bands) never writes that layer's [Ts, Np, 384] hidden sequence;
+        the ReLU then rides on the decoder-input kernel."""
+        from .sequence_model import lstm_layer_infer
+        L = _lib.lib()
+        bn = self.bottleneck
+        Ts, Np, _ = units.shape
+        H = bn.hidden_size
+        if (bn.cell == "LSTM" and bn.num_layers == 2 and bn.output_size == 1 and bn.output_activate_function == "ReLU"
+                and getattr(self, "fused_output_layer", True) and L.fsn_lstm_layer_fc_supported(Ts, Np, H, H, H, 1)):
+            layers, fc = bn._inference_weights()
+            h0 = lstm_layer_infer(units, *layers[0])                                      # [Ts, Np, H]
+            out = torch.empty((Ts, Np), dtype=torch.float32, device=units.device)
+            ws = _lib.workspace(L.fsn_lstm_layer_fc_workspace_bytes(Ts, Np, H, H), units.device)
+            w_ih, w_hh, b_ih, b_hh = layers[1]
+            _lib.check(L.fsn_lstm_layer_forward_fc(
+                _lib.dev_ptr(h0), H, _lib.dev_ptr(w_ih), _lib.dev_ptr(w_hh), _lib.dev_ptr(b_ih), _lib.dev_ptr(b_hh), Ts, Np, H, H,
+                _lib.dev_ptr(fc[0]), _lib.dev_ptr(fc[1]), 1, _lib.dev_ptr(out), None, Np, ws.data_ptr(), ws.numel(),
+                _lib.stream_ptr(units.device)))
+            return out, 1
+        return bn.forward_time_major(units, N, rows_out=True), 0
+
     def _forward_rows(self, mix_mag):
         """The inference forward with every tensor between the blocks time-major and the glue on fast_glue_kernels.hip
         (model.py:143-202 line by line in the comments)."""
@@ -162,11 +186,11 @@ class Model(BaseModel):
         units = torch.empty((Ts, Np, Wp), **f32)
         _lib.check(L.fsn_fast_bottleneck_input(_lib.dev_ptr(mel), _lib.dev_ptr(enc), enc.stride(1), T, B, Bp, M, n_mel, n_enc, s,
                                                _lib.dev_ptr(units), Np, Wp, ws.data_ptr(), ws.numel(), st))
-        slow = self.bottleneck.forward_time_major(units, N, rows_out=True)               # [Ts, Np, 1]
+        slow, relu = self._bottleneck_rows(units, N)                                     # [Ts, Np(, 1)]
         # :180-190 up-sampling, cat -> decoder
         dec_in = torch.empty((T, Bp, 2 * M), **f32)
         _lib.check(L.fsn_fast_decoder_input(_lib.dev_ptr(enc), enc.stride(1), _lib.dev_ptr(slow), slow.stride(0), slow.stride(1),
-                                            T, B, Bp, M, s, _lib.dev_ptr(dec_in), st))
+                                            relu, T, B, Bp, M, s, _lib.dev_ptr(dec_in), st))
         out = pair_forward_rows(*self.decoder_lstm, dec_in)                              # [T, Bp, 2 F]
         # :200-202 reshape + look-ahead slice
         mask = torch.empty((B, 2, F, T0), **f32)

@@ -277,6 +277,19 @@ int fsn_lstm_layer_backward(const float* dh, const float* x, long ldx, const flo
                             float* dw_ih, float* dw_hh, float* db, void* workspace, size_t workspace_bytes,
                             void* stream);
 
+/* The LAST layer of an inference stack together with the nn.Linear(H, O) that follows it (sequence_model.py:106-125:
+ * self.fc_output_layer(self.sequence_model(x)); Fast FullSubNet's bottleneck, fast_fullsubnet/model.py:66-74: 16 384 rows x
+ * 384 units -> one value per step).  Where the persistent kernel that forms the projection itself takes the layer
+ * (fsn_lstm_layer_fc_supported: H = I = ldx = 384, O = 1 or 2, whole rounds of 2 - 4 row tiles per CU) its fused two-row
+ * output layer does the nn.Linear too: the [T][N][H] hidden sequence is neither written nor read back.  out0 / out1:
+ * PRE-activation outputs 0 / 1, time-major [T][ldo] (out1 may be NULL when O == 1); the caller applies the block's
+ * activation.  Any other shape: FSN_ERR_ARG (fsn_lstm_layer_forward + fsn_linear_forward take it). */
+int fsn_lstm_layer_fc_supported(int T, int N, int I, long ldx, int H, int O);
+size_t fsn_lstm_layer_fc_workspace_bytes(int T, int N, int I, int H);
+int fsn_lstm_layer_forward_fc(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
+                              const float* b_hh, int T, int N, int I, int H, const float* fc_w, const float* fc_b, int O,
+                              float* out0, float* out1, long ldo, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Backward of two stacked layers (the counterpart of fsn_lstm2_forward_train): dh1 [T][N][H] = dLoss/dhseq1;
  * outputs as two fsn_lstm_layer_backward calls would give them (dx may be NULL).  The sub-band shape (H = 384, 96+
  * row tiles) runs its back-propagation through time - both layers, all steps, the layer-to-layer dX - as ONE
@@ -399,7 +412,8 @@ int fsn_scale_by_scalar(const float* x, const float* scale, float* y, size_t n, 
  *                           divided by (the utterance's mean of that tensor + 1e-5): out [Ts][Np][Wp], row b num_mels + m,
  *                           zero padding; Ts = fsn_fast_low_rate_frames(T, shrink).  The unfolded tensor is never formed.
  * fsn_fast_decoder_input    model.py:131-140 + :188-190: out [T][Bp][2 num_mels] = encoder output | bottleneck output held
- *                           for `shrink` frames (frame t takes low-rate frame t / shrink; slow[ts ld_slow_frame + row ld_slow_row]).
+ *                           for `shrink` frames (frame t takes low-rate frame t / shrink; slow[ts ld_slow_frame + row ld_slow_row];
+ *                           relu != 0: `slow` is the bottleneck output layer's PRE-activation, fsn_lstm_layer_forward_fc).
  * fsn_fast_mask_out         model.py:200-202: o [T][Bp][ld >= 2F] -> mask [B][2][F][T - look_ahead] (first frames dropped). */
 int fsn_fast_low_rate_frames(int T, int shrink);
 size_t fsn_fast_glue_workspace_bytes(int T, int B, int num_mels, int shrink);
@@ -409,8 +423,8 @@ int fsn_fast_norm_rows(const float* x, int T, int B, int Bp, int C, float* out, 
 int fsn_fast_bottleneck_input(const float* mel, const float* enc, long ld_enc, int T, int B, int Bp, int num_mels,
                               int mel_neighbors, int enc_neighbors, int shrink, float* out, int Np, int Wp, void* workspace,
                               size_t workspace_bytes, void* stream);
-int fsn_fast_decoder_input(const float* enc, long ld_enc, const float* slow, long ld_slow_frame, long ld_slow_row, int T, int B,
-                           int Bp, int num_mels, int shrink, float* out, void* stream);
+int fsn_fast_decoder_input(const float* enc, long ld_enc, const float* slow, long ld_slow_frame, long ld_slow_row, int relu, int T,
+                           int B, int Bp, int num_mels, int shrink, float* out, void* stream);
 int fsn_fast_mask_out(const float* o, long ld, int T, int B, int Bp, int F, int look_ahead, float* mask, void* stream);
 
 /* fullsubnet/trainer.py:65-69: torch.nn.utils.clip_grad_norm_(parameters, max_norm) followed by

@@ -114,6 +114,14 @@ def test_fast_fullsubnet_config4_full_size(fsn, batch):
         crm = m(x).cpu().numpy()
         crm2 = m(x).cpu().numpy()
         small = torch.cat([m(x[i:i + 32]) for i in range(0, batch, 32)], dim=0).cpu().numpy()
+        # the bottleneck's last layer with the kernel's fused output layer (fsn_lstm_layer_forward_fc: no hidden sequence
+        # written) against the layer + fsn_linear_forward form
+        units_rows = batch * 64
+        assert fsn._lib.lib().fsn_lstm_layer_fc_supported(22, units_rows, 384, 384, 384, 1) == 1
+        m.fused_output_layer = False
+        unfused = m(x).cpu().numpy()
+        m.fused_output_layer = True
+    assert np.abs(crm - unfused).max() <= 2e-5
     assert np.isfinite(crm).all() and np.array_equal(crm, crm2)
     d_plan = np.abs(crm - small).reshape(batch, -1).max(axis=1)
     params["mel_scale.fb"] = m.mel_scale.fb.cpu().numpy()
