@@ -3167,7 +3167,8 @@ extern "C" int fsn_linear_backward(const float* dy, long lddy, const float* x, l
                                    int O, float* dx, long lddx, float* dw, float* db, void* workspace,
                                    size_t workspace_bytes, void* stream) {
     CallScope scope(stream);
-    FSN_REQUIRE(dy && x && w && dw && db && workspace, "NULL pointer argument");
+    FSN_REQUIRE(dy && x && w && workspace && (dx || dw) && (dw == nullptr) == (db == nullptr),
+                "linear backward: NULL pointer argument (dx alone, dw + db alone, or all three)");
     FSN_REQUIRE(R >= 1 && I >= 1 && O >= 1 && lddy >= fsn_round_up(O, 16) && lddy % 4 == 0 && ldx >= I,
                 "linear backward: bad shape");
     if (workspace_bytes < fsn_linear_workspace_bytes(R, I, O)) {
@@ -3200,6 +3201,7 @@ extern "C" int fsn_linear_backward(const float* dy, long lddy, const float* x, l
         a.N = R;
         FSN_TRY(fsn_launch_gemm(a, wtp, c, (R + 15) / 16, Ip / 16, Op / 16, s));
     }
+    if (!dw) return FSN_OK;  // the input gradient alone (the parameter gradients by a second call, possibly on another stream)
     FSN_TRY(fsn_launch_gemm_tn(dy, lddy, x, ldx, dw, I, O, I, R, scratch, s));
     return fsn_launch_colsum(dy, lddy, db, O, R, scratch, s);
 }

@@ -336,8 +336,8 @@ OVERLAP_WEIGHT_PRODUCTS = True
 _SIDE = {}
 
 
-def _side_stream(device):
-    key = str(device)
+def _side_stream(device, which=0):
+    key = (str(device), which)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device)
     return _SIDE[key]
@@ -440,16 +440,26 @@ class FullSubNetTrainFunction(torch.autograd.Function):
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         dm = d_mask if d_mask.is_contiguous() else d_mask.contiguous()
 
-        def linear_bwd(dy, lddy, x, ldx, w, rows_, I, O):
-            dx, dw, db = new(rows_, ldx), torch.empty_like(w), new(O)
-            ws = _lib.workspace(L.fsn_linear_workspace_bytes(rows_, I, O), dev)
-            _lib.check(L.fsn_linear_backward(_lib.dev_ptr(dy), lddy, _lib.dev_ptr(x), ldx, _lib.dev_ptr(w), rows_, I, O, _lib.dev_ptr(dx),
-                                             ldx, _lib.dev_ptr(dw), _lib.dev_ptr(db), ws.data_ptr(), ws.numel(), st))
-            return dx, dw, db
-
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if OVERLAP_WEIGHT_PRODUCTS else None
+        third = _side_stream(dev, 1) if OVERLAP_WEIGHT_PRODUCTS else None
         keep = []  # what the side stream still reads: alive until the join below
+
+        def linear_bwd(dy, lddy, x, ldx, w, rows_, I, O, beside=None):
+            dx, dw, db = new(rows_, ldx), torch.empty_like(w), new(O)
+            ws = _lib.workspace(L.fsn_linear_workspace_bytes(rows_, I, O), dev)
+            head = (_lib.dev_ptr(dy), lddy, _lib.dev_ptr(x), ldx, _lib.dev_ptr(w), rows_, I, O)
+            if beside is not None:  # the input gradient here (the chain waits for it), the parameter gradients beside it
+                _lib.check(L.fsn_linear_backward(*head, _lib.dev_ptr(dx), ldx, None, None, ws.data_ptr(), ws.numel(), st))
+                ws2 = _lib.workspace(L.fsn_linear_workspace_bytes(rows_, I, O), dev)
+                beside.wait_stream(main)
+                with torch.cuda.stream(beside):
+                    _lib.check(L.fsn_linear_backward(*head, None, ldx, _lib.dev_ptr(dw), _lib.dev_ptr(db), ws2.data_ptr(), ws2.numel(),
+                                                     _lib.stream_ptr(dev)))
+                keep.extend((ws2, dy))
+                return dx, dw, db
+            _lib.check(L.fsn_linear_backward(*head, _lib.dev_ptr(dx), ldx, _lib.dev_ptr(dw), _lib.dev_ptr(db), ws.data_ptr(), ws.numel(), st))
+            return dx, dw, db
 
         def lstm2_bwd(dh, x, ldx, w, h0, h1, s0, s1, N, I, H, need_dx, beside=False):
             dx = new(Tp, N, ldx) if need_dx else None
@@ -478,15 +488,16 @@ class FullSubNetTrainFunction(torch.autograd.Function):
 
         dy2 = new(Tp * Rp, 16)
         _lib.check(L.fsn_train_mask_grad(dp, _lib.dev_ptr(dm, "d_mask"), _lib.dev_ptr(dy2), Rp, 16, st))
-        dsh1, d_sfw, d_sfb = linear_bwd(dy2, 16, sh1, Hs, sb_fc[0], Tp * Rp, Hs, 2)
+        dsh1, d_sfw, d_sfb = linear_bwd(dy2, 16, sh1, Hs, sb_fc[0], Tp * Rp, Hs, 2)  # (its parameter gradients beside the BPTT launch: measured, slows that launch by more)
         dx_sb, g_sb = lstm2_bwd(dsh1, sb_in, 32, sb, sh0, sh1, ss0, ss1, Rp, Is, Hs, True, beside=True)
         d_fb = new(Tp * Bp, Fp)
         _lib.check(L.fsn_train_sb_input_backward(dp, _lib.dev_ptr(dx_sb), _lib.dev_ptr(sb_in), Rp, _lib.dev_ptr(den), _lib.dev_ptr(fb_out),
                                                  F, Bp, _lib.dev_ptr(d_fb), Fp, gws.data_ptr(), gws.numel(), st))
-        dfh1, d_ffw, d_ffb = linear_bwd(d_fb, Fp, fh1, Hf, fb_fc[0], Tp * Bp, Hf, F)
+        dfh1, d_ffw, d_ffb = linear_bwd(d_fb, Fp, fh1, Hf, fb_fc[0], Tp * Bp, Hf, F, beside=third)  # the chain below only needs dfh1
         _, g_fb = lstm2_bwd(dfh1, x_tm, Fp, fb, fh0, fh1, fs0, fs1, Bp, F, Hf, False)
         if side is not None:
             main.wait_stream(side)  # the sub-band weight gradients: everything after this call sees them
+            main.wait_stream(third)
             keep.clear()
         return (None, None, None, None, None, *g_fb, d_ffw, d_ffb, *g_sb, d_sfw, d_sfb)
 
