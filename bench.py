@@ -19,7 +19,8 @@ Prints ONE JSON line (rank 0) with the driver's contract keys plus
                  launch stream; `traffic` / `mfma_busy_frac` from the committed rocprofv3 PMC passes of this config
   cpu_baseline - the reference's ATen operator sequence (oracle/aten_baseline.py) timed on this box's host cores
                  on a bounded sample of the same workload (rank 0, N = 1 only); the numpy oracle as `oracle_port`
-  split_f16x3, train_step, fast_b256, improved48_b32 - side figures (N = 1): the opt-in split-precision
+  one_utterance (eager / hipGraph replay latency of one utterance), split_f16x3, train_step, fast_b256, improved48_b32 -
+  side figures (N = 1): the opt-in split-precision
                  kernels, one training step at BASELINE config 3's per-rank shape, Fast FullSubNet at batch 256
                  (config 4) and Improved FullSubNet at 48 kHz, batch 32 (config 5).
 """
@@ -335,6 +336,30 @@ def family_parity(BF, which, batch, pack, device):
     return out
 
 
+def one_utterance_figure(model, length, device, reps=20):
+    """Latency of ONE utterance through Model.enhance: eager, and as a hipGraph replay (fullsubnet_amd.GraphedCall; the
+    replay must be bit-identical).  A side figure: the serving end of the path, where the step is a chain of small launches."""
+    from fullsubnet_amd import GraphedCall
+    from fsn_synthetic import make_noisy
+    noisy = torch.from_numpy(make_noisy(1, length, seed=11)).to(device)
+    graphed = GraphedCall(model.enhance)
+    eager = model.enhance(noisy)
+    same = bool(torch.equal(graphed(noisy), eager))
+    res = {}
+    for name, fn in (("eager", model.enhance), ("graph", graphed)):
+        for _ in range(3):
+            fn(noisy)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn(noisy)
+        torch.cuda.synchronize()
+        res[name] = (time.perf_counter() - t0) / reps
+    return {"samples": length, "eager_ms": round(1e3 * res["eager"], 3), "graph_replay_ms": round(1e3 * res["graph"], 3),
+            "replay_bit_identical": same, "rtf_speedup_graph": round(length / 16000.0 / res["graph"], 1),
+            "note": "ONE 3 s utterance, stft -> model -> mask -> istft: host-launched vs hipGraph replay of the same kernels"}
+
+
 def measured_counters():
     """PMC figures of the dominant kernel REPLAYED from the committed rocprofv3 passes (profiles/rNN_pmc.json, produced
     by tools/rocprof_pmc.py from separate --pmc runs of `bench.py` at config 2): HBM bytes per launch (FETCH_SIZE x 2
@@ -588,6 +613,11 @@ def main():
                 out[key] = family_figure(which, b, PEAK_FP32_MFMA_TFLOPS, device)
             except Exception as e:
                 out[key] = {"error": str(e)[:200]}
+        # the launch-bound regime: ONE utterance, eager against a hipGraph replay of the whole call (fullsubnet_amd.GraphedCall)
+        try:
+            out["one_utterance"] = one_utterance_figure(model, length, device)
+        except Exception as e:
+            out["one_utterance"] = {"error": str(e)[:200]}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             torch.cuda.synchronize()

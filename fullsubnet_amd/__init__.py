@@ -7,6 +7,7 @@ from . import _lib  # noqa: F401
 from .acoustics.feature import drop_band, istft, mag_phase, stft  # noqa: F401
 from .acoustics.mask import (build_complex_ideal_ratio_mask, complex_mul, compress_cIRM,  # noqa: F401
                              decompress_cIRM)
+from .graphs import GraphedCall  # noqa: F401
 from .inferencer import Inferencer  # noqa: F401
 from .model import Model  # noqa: F401
 from .optim import ClipAdam  # noqa: F401

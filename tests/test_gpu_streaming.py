@@ -1,5 +1,7 @@
 """Streaming (chunked, stateful) enhancement == the offline path on the same utterance.
 Needs a real MI355X:  python -m pytest tests -m gpu"""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -151,3 +153,34 @@ def test_enhance_is_capturable_in_a_hip_graph(setup, batch):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(static_out, model.enhance(other))
+
+
+@pytest.mark.parametrize("which", ["fullsubnet", "improved16", "fast"])
+def test_graphed_call_replays_the_eager_result(setup, which):
+    """fullsubnet_amd.GraphedCall: one hipGraph per input shape, captured on first use (side streams, persistent launches
+    and all), replayed on new input - bit-identical to the eager call on every replay, for the FullSubNet path and for the
+    sibling models' whole enhancement call; a second shape gets its own graph and the first one keeps working."""
+    fsn, model, _ = setup
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    if which == "fullsubnet":
+        fn, length = model.enhance, 4096
+    else:
+        import bench_family
+        m, _, _, _, _, _ = bench_family.build(which)
+        fn, length = bench_family.enhance_fn(which, m), 8192
+    graphed = fsn.GraphedCall(fn)
+    for batch, seeds in ((1, (31, 32, 31)), (3, (33, 34))):
+        for seed in seeds:
+            noisy = torch.from_numpy(O.make_noisy(batch, length, seed=seed)).cuda()
+            want = fn(noisy)
+            got = graphed(noisy)
+            torch.cuda.synchronize()
+            assert got.shape == want.shape and torch.equal(got, want), (which, batch, seed)
+    assert len(graphed._graphs) == 2
+    noisy = torch.from_numpy(O.make_noisy(1, length, seed=35)).cuda()  # the first shape's graph again
+    assert torch.equal(graphed(noisy), fn(noisy))
+    with pytest.raises(RuntimeError):
+        graphed(torch.zeros(1, length))
