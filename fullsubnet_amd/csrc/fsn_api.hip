@@ -2881,10 +2881,12 @@ static int lstm2_backward_phases(const float* dh1, const float* x, long ldx, con
     }
     if (!products_part) return FSN_OK;
     // dW_ih = dgates^T X (+ db = its column sums: fp32 adds in every arithmetic), dW_hh = dgates_{1..}^T H_{0..T-2}
-    if (g16) {
-        // bias gradients = the BPTT launch's cluster sums + the step-by-step rows; those rows' 16-bit gate gradients
+    // bias gradients = the BPTT launch's cluster sums + the step-by-step rows; those rows' 16-bit gate gradients (operands of
+    // the products below: first when there are such rows; otherwise LAST - six tiny workgroups at the head of this part
+    // queued behind whatever the caller's other stream was running and held the products back by its length)
+    const bool finish_first = left > 0;
+    if (g16 && finish_first)
         FSN_TRY(fsn_launch_lstm2_g16_finish(dg1, dg0, dg16 + (size_t)T * N * G, dg16, dbp, clusters, T, N, left, db1, db0, s, arith));
-    }
     if (tn16h) {
         // the three large products with both operands 16-bit in memory: dg16 = dg0 | dg1 written by the BPTT kernel, the
         // hidden sequences converted once (half the HBM bytes of the fp32 operands, LDS-DMA staging, no conversion pass)
@@ -2895,7 +2897,10 @@ static int lstm2_backward_phases(const float* dh1, const float* x, long ldx, con
         FSN_TRY(fsn_launch_gemm_tn16h(dg16_1, G, h16, H, dw_ih1, H, G, H, (long)T * N, scratch, s, arith));
         FSN_TRY(fsn_launch_gemm_tn16h(dg16_1 + (size_t)N * G, G, h16 + TNH, H, dw_hh1, H, G, H, (long)(T - 1) * N, scratch, s, arith));
         FSN_TRY(fsn_launch_gemm_tn16h(dg16_0 + (size_t)N * G, G, h16, H, dw_hh0, H, G, H, (long)(T - 1) * N, scratch, s, arith));
-        return fsn_launch_gemm_tn(dg0, G, x, ldx, dw_ih0, I, G, I, (long)T * N, scratch, s, nullptr, arith);
+        FSN_TRY(fsn_launch_gemm_tn(dg0, G, x, ldx, dw_ih0, I, G, I, (long)T * N, scratch, s, nullptr, arith));
+        if (!finish_first)
+            FSN_TRY(fsn_launch_lstm2_g16_finish(dg1, dg0, dg16 + (size_t)T * N * G, dg16, dbp, clusters, T, N, left, db1, db0, s, arith));
+        return FSN_OK;
     }
     if (g16) {  // (no plan for the 16-bit-operand products at this shape: the fp32 buffers; layer 1's were stored in that case)
         FSN_TRY(fsn_launch_gemm_tn(dg1, G, hseq0, H, dw_ih1, H, G, H, (long)T * N, scratch, s, nullptr, arith));
@@ -2914,6 +2919,8 @@ static int lstm2_backward_phases(const float* dh1, const float* x, long ldx, con
         fsn_set_error("memset failed");
         return FSN_ERR_LAUNCH;
     }
+    if (g16 && !finish_first)
+        FSN_TRY(fsn_launch_lstm2_g16_finish(dg1, dg0, dg16 + (size_t)T * N * G, dg16, dbp, clusters, T, N, left, db1, db0, s, arith));
     return FSN_OK;
 }
 
