@@ -2674,7 +2674,9 @@ extern "C" size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H, int 
     return fsn_round_up_sz(cv.off, 256);
 }
 // `phase`: which parts run (a sum; 7 = everything) - 1: back-propagation through time, the gate gradients stay in the
-// workspace; 4: dx from them; 2: the weight- and bias-gradient products from them.  Parts 2 and 4 take the same arguments
+// workspace; 4: dx from them; 2: the weight- and bias-gradient products from them; 8: only what the products need BESIDES
+// the gate gradients (the 16-bit copies of the hidden sequences: independent of part 1, so a caller can have them made on
+// another stream while part 1 runs); 16 (with 2): a part-8 call has done that.  Parts 2 and 4 take the same arguments
 // and the same workspace, untouched since part 1; either may be issued on another stream, ordered behind part 1 by the
 // caller.  The persistent shapes only (sub-band group kernels, full-band chain): the layer-by-layer form runs whole in
 // part 1.
@@ -2685,6 +2687,7 @@ static int lstm2_backward_phases(const float* dh1, const float* x, long ldx, con
                                  void* workspace, size_t workspace_bytes, int arith, void* stream, int phase) {
     CallScope scope(stream);
     const bool chain_part = (phase & 1) != 0, products_part = (phase & 2) != 0, dx_part = (phase & 4) != 0;
+    const bool prepare_part = (phase & 8) != 0, prepared = (phase & 16) != 0;
     FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
     FSN_REQUIRE(arith == FSN_ARITH_F32 || arith == FSN_ARITH_F16 || arith == FSN_ARITH_BF16,
                 "lstm2 backward: arithmetic %d unknown (FSN_ARITH_F32 / _F16 / _BF16)", arith);
@@ -2791,6 +2794,13 @@ static int lstm2_backward_phases(const float* dh1, const float* x, long ldx, con
     const bool tn16h = g16 && T > 1 && fsn_gemm_tn16h_supported(G, H, (long)(T - 1) * N) && !g_tn16h_off.load(std::memory_order_relaxed);
     const float* sv0 = static_cast<const float*>(save0);
     const float* sv1 = static_cast<const float*>(save1);
+    if (prepare_part) {
+        if (tn16h) {
+            FSN_TRY(fsn_launch_to16(hseq0, h16, (size_t)T * N * H, arith, s));
+            FSN_TRY(fsn_launch_to16(hseq1, h16 + (size_t)T * N * H, (size_t)T * N * H, arith, s));
+        }
+        if (!chain_part && !products_part && !dx_part) return FSN_OK;
+    }
     if (chain_part) {
     // "weights" of dh = dgates W are W^T: out = H columns, k = 4H; nn.LSTM stores exactly that transposed
     FSN_TRY(fsn_launch_pack(w_hh1, whh1T_p, H, G, H, G, s, 1, H));
@@ -2892,8 +2902,10 @@ static int lstm2_backward_phases(const float* dh1, const float* x, long ldx, con
         // hidden sequences converted once (half the HBM bytes of the fp32 operands, LDS-DMA staging, no conversion pass)
         const size_t TNG = (size_t)T * N * G, TNH = (size_t)T * N * H;
         const unsigned short *dg16_0 = dg16, *dg16_1 = dg16 + TNG;
-        FSN_TRY(fsn_launch_to16(hseq0, h16, TNH, arith, s));
-        FSN_TRY(fsn_launch_to16(hseq1, h16 + TNH, TNH, arith, s));
+        if (!prepared && !prepare_part) {
+            FSN_TRY(fsn_launch_to16(hseq0, h16, TNH, arith, s));
+            FSN_TRY(fsn_launch_to16(hseq1, h16 + TNH, TNH, arith, s));
+        }
         FSN_TRY(fsn_launch_gemm_tn16h(dg16_1, G, h16, H, dw_ih1, H, G, H, (long)T * N, scratch, s, arith));
         FSN_TRY(fsn_launch_gemm_tn16h(dg16_1 + (size_t)N * G, G, h16 + TNH, H, dw_hh1, H, G, H, (long)(T - 1) * N, scratch, s, arith));
         FSN_TRY(fsn_launch_gemm_tn16h(dg16_0 + (size_t)N * G, G, h16, H, dw_hh0, H, G, H, (long)(T - 1) * N, scratch, s, arith));
@@ -2937,7 +2949,9 @@ extern "C" int fsn_lstm2_backward_phase(const float* dh1, const float* x, long l
                                         const float* hseq1, const void* save0, const void* save1, float* dx, long lddx,
                                         float* dw_ih0, float* dw_hh0, float* db0, float* dw_ih1, float* dw_hh1, float* db1,
                                         void* workspace, size_t workspace_bytes, int arith, int phase, void* stream) {
-    FSN_REQUIRE(phase >= 1 && phase <= 7, "lstm2 backward parts %d: a sum of 1 (through time), 2 (weight-gradient products), 4 (dx)", phase);
+    FSN_REQUIRE(phase >= 1 && phase <= 31 && (!(phase & 16) || (phase & 2)),
+                "lstm2 backward parts %d: a sum of 1 (through time), 2 (weight-gradient products), 4 (dx), 8 (operand preparation), "
+                "16 (with 2: prepared by an earlier part-8 call)", phase);
     return lstm2_backward_phases(dh1, x, ldx, w_ih0, w_hh0, w_ih1, w_hh1, T, N, I, H, hseq0, hseq1, save0, save1, dx, lddx, dw_ih0,
                                  dw_hh0, db0, dw_ih1, dw_hh1, db1, workspace, workspace_bytes, arith, stream, phase);
 }

@@ -474,11 +474,14 @@ class FullSubNetTrainFunction(torch.autograd.Function):
                 # Only dx is waited for (the full-band model's backward hangs on it): back-propagation through time and dx
                 # here, the weight- and bias-gradient products on a second stream BESIDE dx and what follows - the
                 # full-band chain is a latency-bound launch on 96 CUs that leaves the chip to them (fsn_lstm2_backward_phase)
-                _lib.check(L.fsn_lstm2_backward_phase(*args, 1, st))
                 db0b, db1b = torch.empty_like(db0), torch.empty_like(db1)  # (allocated on the caller's stream, like all outputs)
                 side.wait_stream(main)
+                with torch.cuda.stream(side):  # what the products need besides the gate gradients: while part 1 runs
+                    _lib.check(L.fsn_lstm2_backward_phase(*args, 8, _lib.stream_ptr(dev)))
+                _lib.check(L.fsn_lstm2_backward_phase(*args, 1, st))
+                side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    _lib.check(L.fsn_lstm2_backward_phase(*args, 2, _lib.stream_ptr(dev)))
+                    _lib.check(L.fsn_lstm2_backward_phase(*args, 2 + 16, _lib.stream_ptr(dev)))
                     _dup(db0, db0b), _dup(db1, db1b)
                 _lib.check(L.fsn_lstm2_backward_phase(*args, 4, st))
                 keep.extend((ws, dh, dx))

@@ -304,7 +304,8 @@ int fsn_lstm2_backward(const float* dh1, const float* x, long ldx, const float* 
 /* The same in parts, for callers that have other work waiting on dx (fullsubnet/trainer.py:56-69: the full-band model's
  * backward only needs the sub-band model's input gradient).  `phase` is a sum of 1 = back-propagation through time (the
  * gate gradients stay in the workspace), 4 = dx from them, 2 = the weight- and bias-gradient products from them; 7 =
- * fsn_lstm2_backward.  Parts 2 and 4 take the same arguments and the same workspace as part 1, which nothing else may touch
+ * fsn_lstm2_backward; 8 = only what the products need besides the gate gradients (16-bit copies of the hidden sequences:
+ * independent of part 1, so it can run on another stream WHILE part 1 runs), 16 (with 2) = a part-8 call has done that.  Parts 2 and 4 take the same arguments and the same workspace as part 1, which nothing else may touch
  * in between; either may be issued on ANOTHER stream, ordered behind part 1 by the caller (an event), so that the products
  * run beside whatever follows dx. */
 int fsn_lstm2_backward_phase(const float* dh1, const float* x, long ldx, const float* w_ih0, const float* w_hh0,
