@@ -20,7 +20,17 @@ def main(outdir, min_us=20.0):
         d = (e - s) / 1e3
         if d >= min_us:
             print(f"{(s - t0) / 1e3:9.1f} .. {(e - t0) / 1e3:9.1f} us  {d:8.1f} us  q{qid}  {n[:70]}")
-    print(f"step: {(rows[hi - 1][2] - t0) / 1e6:.3f} ms")
+    # idle time of the device inside the step: the gaps of the union of all kernel intervals
+    ivs = sorted((s, e) for _, s, e, _ in rows[lo:hi])
+    idle, gaps, end = 0, [], ivs[0][1]
+    for s, e in ivs[1:]:
+        if s > end:
+            idle += s - end
+            gaps.append(((s - end) / 1e3, (end - t0) / 1e3))
+        end = max(end, e)
+    gaps.sort(reverse=True)
+    print(f"step: {(rows[hi - 1][2] - t0) / 1e6:.3f} ms, no kernel running for {idle / 1e6:.3f} ms of it; largest gaps (us @ us): "
+          + ", ".join(f"{g:.0f} @ {at:.0f}" for g, at in gaps[:8]))
 
 
 if __name__ == "__main__":
