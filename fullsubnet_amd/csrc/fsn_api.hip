@@ -430,6 +430,11 @@ extern "C" int fsn_debug_tn_plan(int M, int Nc, long K, int arith, int* splits, 
 }
 // Test / measurement hook: 0 = the fp32-era group kernels also under the 16-bit training arithmetic (A/B against
 // lstm_group16_kernels.hip), 1 (default) = the 16-bit arithmetic's own kernels where they apply.
+void fsn_tn16h_wide(int on);
+extern "C" int fsn_debug_tn16h_wide(int on) {
+    fsn_tn16h_wide(on);
+    return FSN_OK;
+}
 extern "C" int fsn_debug_g16_kernels(int on) {
     g_g16_off.store(on == 0 ? 1 : 0, std::memory_order_relaxed);
     g_tn16h_off.store(on == 2 ? 1 : 0, std::memory_order_relaxed);

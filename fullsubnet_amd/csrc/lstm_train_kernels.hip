@@ -425,8 +425,13 @@ __global__ __launch_bounds__(256) void gemm_tn16_kernel(const float* __restrict_
 // architectural registers), each DMA instruction building two [16 k][16 columns] subtiles of the image
 // ds_read_b64_tr_b16 wants (lane l fetches row (l & 31) >> 1, half l & 1 of subtile l >> 5).  K in chunks of 32 (the
 // caller passes K rounded down to 32; the reduce kernel adds the tail rows from the same 16-bit operands).
-constexpr int TH_STAGE = 2 * 12 * 1024;  // bytes of one chunk: (A, B) x 2 k steps x 6 tile pairs x 1 KB
 constexpr int TH_STAGES = 4;             // (6 stages = 5 chunks in flight measured SLOWER, 0.76 against 0.66 ms: the LDS-DMA path lands ~29 GB/s per CU whatever is in flight)
+// WN: waves along the N side - 2: 192 x 192 tile, four waves (the square plan); 4: 192 x 384 tile, eight waves - a weight
+// gradient's whole 384-column side in one workgroup, so that the [k][1536] gate-gradient rows are fetched once per 192 of
+// their columns instead of twice (the launch is bound by the bytes its DMAs land: 36 KB per chunk for 192 x 384 outputs
+// against 2 x 24 KB)
+template <int WN>
+constexpr int th_stage_bytes() { return 2 * (12 + 6 * WN) * 512; }  // (A 12 + B 6 WN column tiles) x 2 k steps x 512 B
 __device__ __forceinline__ void th_lds_dma(const unsigned short* g, unsigned lds_base) {
     unsigned saved;
     asm volatile(
@@ -440,33 +445,40 @@ __device__ __forceinline__ void th_lds_dma(const unsigned short* g, unsigned lds
         : "s"(lds_base), "v"(g)
         : "memory");
 }
-template <int AR>
-__global__ __launch_bounds__(256) void gemm_tn16h_kernel(const unsigned short* __restrict__ A, long lda,
-                                                         const unsigned short* __restrict__ B, long ldb,
-                                                         float* __restrict__ part, int M, int Nc, long K, long k_per_split,
-                                                         int m_blocks, int n_blocks) {
+template <int AR, int WN>
+__global__ __launch_bounds__(WN * 128) void gemm_tn16h_kernel(const unsigned short* __restrict__ A, long lda,
+                                                              const unsigned short* __restrict__ B, long ldb,
+                                                              float* __restrict__ part, int M, int Nc, long K, long k_per_split,
+                                                              int m_blocks, int n_blocks) {
+    constexpr int TH_STAGE = th_stage_bytes<WN>();
+    constexpr int NTB = 6 * WN;        // B column tiles of the workgroup
+    constexpr int B0 = 12 * 1024;      // byte offset of the B block inside a stage (A: 2 k steps x 6 KB)
     extern __shared__ __attribute__((aligned(16))) unsigned char th_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int tiles = m_blocks * n_blocks, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int tile = jb % tiles, split = xcd * ((int)(gridDim.x >> 3) / tiles) + jb / tiles;
     const int mb = tile / n_blocks, nb = tile % n_blocks;
-    const int m0 = mb * 192, n0 = nb * 192;
+    const int m0 = mb * 192, n0 = nb * (96 * WN);
     const long k_begin = (long)split * k_per_split;
     long k_end = k_begin + k_per_split;
     k_end = k_end < K ? k_end : K;
     const int chunks = (int)((k_end - k_begin) >> 5);  // whole chunks of 32 (K and k_per_split are multiples of 32)
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)th_lds;
 
-    // staging: wave w fills operand w >> 1 (0 = A, 1 = B), k step w & 1 of every chunk: six DMA instructions, one per
-    // pair of column tiles; lane l -> row 16 ks + ((l & 31) >> 1), columns 16 (2 p + (l >> 5)) + 8 (l & 1) .. + 7
-    const int s_op = wave >> 1, s_ks = wave & 1;
-    const unsigned short* sp = (s_op ? B + n0 : A + m0) + (k_begin + 16 * s_ks + ((lane & 31) >> 1)) * (s_op ? ldb : lda) +
-                               16 * (lane >> 5) + 8 * (lane & 1);
+    // staging roles (six DMA instructions per chunk each, one per pair of column tiles): role 0, 1 = A, k step 0 / 1;
+    // role 2 + 2 h + ks = B columns [192 h, 192 h + 192), k step ks.  Wave w takes role w (2 + WN roles: with eight waves the
+    // last two stage nothing).  Lane l -> row 16 ks + ((l & 31) >> 1), columns 16 (2 p + (l >> 5)) + 8 (l & 1) .. + 7
+    const bool loader = wave < 2 + WN;
+    const int s_op = wave >= 2 ? 1 : 0, s_ks = wave & 1, s_half = wave >= 2 ? (wave - 2) >> 1 : 0;
     const long s_ld = s_op ? ldb : lda;
+    const unsigned short* sp = (s_op ? B + n0 + 192 * s_half : A + m0) + (k_begin + 16 * s_ks + ((lane & 31) >> 1)) * s_ld +
+                               16 * (lane >> 5) + 8 * (lane & 1);
+    const unsigned s_dst = s_op ? (unsigned)(B0 + (s_ks * (NTB / 2) + s_half * 6) * 1024) : (unsigned)(s_ks * 6 * 1024);
     auto issue = [&](int c) {  // chunk c into stage c % TH_STAGES
-        const unsigned dst = lds0 + (unsigned)((c % TH_STAGES) * TH_STAGE + (s_op * 12 + s_ks * 6) * 1024);
+        if (!loader) return;
+        const unsigned dst = lds0 + (unsigned)((c % TH_STAGES) * TH_STAGE) + s_dst;
 #pragma unroll
         for (int p = 0; p < 6; ++p) th_lds_dma(sp + (long)c * 32 * s_ld + 32 * p, dst + (unsigned)(p * 1024));
     };
@@ -484,11 +496,11 @@ __global__ __launch_bounds__(256) void gemm_tn16h_kernel(const unsigned short* _
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             typename FsnOperand<AR>::type a[6], b[6];
-            const unsigned char* base = th_lds + stage * TH_STAGE + ks * 6 * 1024 + lane_off;  // column tile i at + i * 512
+            const unsigned char* base = th_lds + stage * TH_STAGE + lane_off;  // column tile i of an operand block at + i * 512
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                a[i] = tr(base + (wm * 6 + i) * 512);
-                b[i] = tr(base + 12 * 1024 + (wn * 6 + i) * 512);
+                a[i] = tr(base + ks * 6 * 1024 + (wm * 6 + i) * 512);
+                b[i] = tr(base + B0 + ks * (NTB / 2) * 1024 + (wn * 6 + i) * 512);
             }
 #pragma unroll
             for (int i = 0; i < 6; ++i)
@@ -496,8 +508,8 @@ __global__ __launch_bounds__(256) void gemm_tn16h_kernel(const unsigned short* _
                 for (int j = 0; j < 6; ++j) acc[i][j] = fsn_mma_k16<AR>(a[i], b[j], acc[i][j]);
         }
     };
-    // TH_STAGES - 1 chunks in flight; the DMAs are invisible to the compiler's counter, so the waits are stated here: a wave
-    // issues 6 per chunk, in order, and nothing else that counts
+    // TH_STAGES - 1 chunks in flight; the DMAs are invisible to the compiler's counter, so the waits are stated here: a
+    // staging wave issues 6 per chunk, in order, and nothing else that counts
 #pragma unroll
     for (int c = 0; c < TH_STAGES - 1; ++c)
         if (c < chunks) issue(c);
@@ -691,6 +703,10 @@ static long tn_max_splits(int M, int Nc) {
         const long sq = cus / ((long)(M / 192) * (Nc / 192));
         splits = sq > splits ? sq : splits;
     }
+    if (!swap && M % 192 == 0 && Nc % 384 == 0) {  // the 192 x 384 form of the 16-bit-operand products: half as many tiles
+        const long wq = cus / ((long)(M / 192) * (Nc / 384));
+        splits = wq > splits ? wq : splits;
+    }
     return splits;
 }
 // test hook (fsn_debug_tn_plan): the K splits fsn_launch_gemm_tn would take for this product and the bound its scratch is
@@ -807,10 +823,32 @@ int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float
 // C [M][Nc] = sum_k A[k][m] B[k][n] with BOTH operands 16-bit in memory (fp16 / bf16 per `arith`), fp32 accumulation:
 // M and Nc multiples of 192, one workgroup per CU over the 192 x 192 tiles with every K split's tiles on one XCD (the
 // plan of fsn_launch_gemm_tn's square form); false when the shape has no such plan.  workspace: fsn_gemm_tn_workspace_bytes.
+static int g_tn16h_wide = 1;  // fsn_tn16h_wide(0): the 192 x 192 tiles also where the 192 x 384 form applies (A/B measurements, tests)
+void fsn_tn16h_wide(int on) { g_tn16h_wide = on; }
+// the 192 x 384 form: Nc a multiple of 384, whole K splits per XCD with one (eight-wave) workgroup per CU
+static bool tn16h_wide_plan(int M, int Nc, long K32, TnPlan* out) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (!g_tn16h_wide || M % 192 || Nc % 384 || cus % 8) return false;
+    const int tiles = (M / 192) * (Nc / 384);
+    if ((cus / 8) % tiles) return false;
+    const long s = cus / tiles;
+    const long kps = ((K32 + s - 1) / s + 31) / 32 * 32;
+    if (kps < 128 || (K32 + kps - 1) / kps != s || s > tn_max_splits(M, Nc)) return false;
+    if (out) {
+        out->square = 1;
+        out->narrow = 0;
+        out->m_blocks = M / 192;
+        out->n_blocks = Nc / 384;
+        out->splits = (int)s;
+        out->k_per_split = kps;
+    }
+    return true;
+}
 bool fsn_gemm_tn16h_supported(int M, int Nc, long K) {
     const long K32 = K & ~31L;
     if (K32 <= 0) return false;
-    return tn_plan(M, Nc, K32, FSN_ARITH_F16).square != 0;
+    return tn16h_wide_plan(M, Nc, K32, nullptr) || tn_plan(M, Nc, K32, FSN_ARITH_F16).square != 0;
 }
 int fsn_launch_gemm_tn16h(const void* A16, long lda, const void* B16, long ldb, float* C, long ldc, int M, int Nc, long K,
                           void* workspace, hipStream_t s, int arith) {
@@ -820,28 +858,47 @@ int fsn_launch_gemm_tn16h(const void* A16, long lda, const void* B16, long ldb, 
         fsn_set_error("gemm_tn16h: 16-bit arithmetic, M and Nc multiples of 192 with a one-workgroup-per-CU plan, 16-byte aligned rows");
         return FSN_ERR_ARG;
     }
-    TnPlan p = tn_plan(M, Nc, K32, arith);
-    p.k_per_split = (p.k_per_split + 31) / 32 * 32;  // whole chunks; the last split takes what is left (K32 is a multiple of 32)
-    if ((K32 + p.k_per_split - 1) / p.k_per_split != p.splits || p.splits > tn_max_splits(M, Nc)) {
-        fsn_set_error("gemm_tn16h: no plan for %d x %d, K = %ld", M, Nc, K);
-        return FSN_ERR_ARG;
+    TnPlan p{};
+    const bool wide = tn16h_wide_plan(M, Nc, K32, &p);
+    if (!wide) {
+        p = tn_plan(M, Nc, K32, arith);
+        p.k_per_split = (p.k_per_split + 31) / 32 * 32;  // whole chunks; the last split takes what is left (K32 is a multiple of 32)
+        if ((K32 + p.k_per_split - 1) / p.k_per_split != p.splits || p.splits > tn_max_splits(M, Nc)) {
+            fsn_set_error("gemm_tn16h: no plan for %d x %d, K = %ld", M, Nc, K);
+            return FSN_ERR_ARG;
+        }
     }
     float* part = static_cast<float*>(workspace);
     const unsigned short *a = static_cast<const unsigned short*>(A16), *b = static_cast<const unsigned short*>(B16);
-    constexpr size_t kLds = kTnOnePerCu;  // 4 stages of 24 KB = the reservation that keeps one workgroup per CU
-    static_assert(TH_STAGES * TH_STAGE <= (int)kTnOnePerCu, "the stages fit it");
     const dim3 grid((unsigned)(p.m_blocks * p.n_blocks * p.splits));
-    auto kern = arith == FSN_ARITH_F16 ? gemm_tn16h_kernel<FSN_ARITH_F16> : gemm_tn16h_kernel<FSN_ARITH_BF16>;
-    static bool set[4] = {false, false, false, false};
-    if (!set[arith]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds) !=
-            hipSuccess) {
-            fsn_set_error("gemm_tn16h: cannot reserve %zu bytes of LDS", kLds);
-            return FSN_ERR_LAUNCH;
+    if (wide) {
+        constexpr size_t kLdsW = (size_t)TH_STAGES * th_stage_bytes<4>();  // 144 KB: one workgroup per CU by itself
+        auto kern = arith == FSN_ARITH_F16 ? gemm_tn16h_kernel<FSN_ARITH_F16, 4> : gemm_tn16h_kernel<FSN_ARITH_BF16, 4>;
+        static bool setw[4] = {false, false, false, false};
+        if (!setw[arith]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsW) !=
+                hipSuccess) {
+                fsn_set_error("gemm_tn16h: cannot reserve %zu bytes of LDS", kLdsW);
+                return FSN_ERR_LAUNCH;
+            }
+            setw[arith] = true;
         }
-        set[arith] = true;
+        hipLaunchKernelGGL(kern, grid, dim3(512), kLdsW, s, a, lda, b, ldb, part, M, Nc, K32, p.k_per_split, p.m_blocks, p.n_blocks);
+    } else {
+        constexpr size_t kLds = kTnOnePerCu;  // 4 stages of 24 KB = the reservation that keeps one workgroup per CU
+        static_assert(TH_STAGES * th_stage_bytes<2>() <= (int)kTnOnePerCu, "the stages fit it");
+        auto kern = arith == FSN_ARITH_F16 ? gemm_tn16h_kernel<FSN_ARITH_F16, 2> : gemm_tn16h_kernel<FSN_ARITH_BF16, 2>;
+        static bool set[4] = {false, false, false, false};
+        if (!set[arith]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds) !=
+                hipSuccess) {
+                fsn_set_error("gemm_tn16h: cannot reserve %zu bytes of LDS", kLds);
+                return FSN_ERR_LAUNCH;
+            }
+            set[arith] = true;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(256), kLds, s, a, lda, b, ldb, part, M, Nc, K32, p.k_per_split, p.m_blocks, p.n_blocks);
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), kLds, s, a, lda, b, ldb, part, M, Nc, K32, p.k_per_split, p.m_blocks, p.n_blocks);
     FSN_TRY_LAUNCH("gemm_tn16h_kernel");
     const long n = (long)M * Nc;
     if (arith == FSN_ARITH_F16)

@@ -512,6 +512,9 @@ int fsn_debug_persist_stats(unsigned* launches, unsigned* waits, unsigned* unrep
  * apply; on = 0 keeps the fp32-era group kernels under that arithmetic (A/B measurements), on = 2 only the round-3 form
  * of the weight-gradient products (operands converted on the fly), on = 1 restores the default. */
 int fsn_debug_g16_kernels(int on);
+/* 0: the 16-bit-operand weight-gradient products on 192 x 192 tiles also where the 192 x 384 eight-wave form applies (both
+ * give bit-identical partial products; the split count differs).  A/B measurements and tests. */
+int fsn_debug_tn16h_wide(int on);
 /* Test hooks that need no device.  fsn_debug_persist_set_fits: 1 when the gate would let n persistent launches with the
  * given chip fractions (grid / (occ x CUs)) and occupancies run side by side, 0 when the newest has to wait.
  * fsn_debug_tn_plan: the K splits a weight-gradient product [M x Nc], K rows, would take (*splits) and the bound the

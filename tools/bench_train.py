@@ -27,6 +27,8 @@ if "g16=2" in sys.argv:  # A/B: weight-gradient products converting their operan
 if "overlap=0" in sys.argv:  # A/B: the sub-band weight-gradient products in line instead of beside the full-band backward
     import fullsubnet_amd.train as _tr
     _tr.OVERLAP_WEIGHT_PRODUCTS = False
+if "wide=0" in sys.argv:  # A/B: the 16-bit-operand products on 192 x 192 tiles instead of 192 x 384
+    fullsubnet_amd._lib.lib().fsn_debug_tn16h_wide(0)
 scaler = torch.amp.GradScaler("cuda", enabled=ARITH != "f32")
 opt = fullsubnet_amd.ClipAdam(model.parameters(), lr=1e-3)
 noisy = torch.from_numpy(make_noisy(B, L, seed=1)).cuda()
