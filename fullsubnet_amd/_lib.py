@@ -78,7 +78,10 @@ ADAM_MAX_TENSORS = 32  # FSN_ADAM_MAX_TENSORS
 
 class TrainDims(ctypes.Structure):  # fsn_train_dims
     _fields_ = [("B", ctypes.c_int), ("F", ctypes.c_int), ("T", ctypes.c_int), ("look_ahead", ctypes.c_int),
-                ("nb", ctypes.c_int), ("groups", ctypes.c_int)]
+                ("nb", ctypes.c_int), ("groups", ctypes.c_int), ("norm", ctypes.c_int)]
+
+
+ABI_VERSION = 110  # FSN_ABI_VERSION of include/fsn_hip.h these signatures were written against
 
 
 class Params(ctypes.Structure):
@@ -183,6 +186,7 @@ SIGNATURES = {
                                       _c.c_void_p]),
     "fsn_train_rows": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
     "fsn_train_glue_workspace_bytes": (_c.c_size_t, [_c.c_void_p]),
+    "fsn_train_den_elems": (_c.c_size_t, [_c.c_void_p, _c.c_int]),
     "fsn_train_fb_input": (_c.c_int, [_c.c_void_p, _f32p, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "fsn_train_sb_input": (_c.c_int, [_c.c_void_p, _f32p, _f32p, _c.c_long, _c.c_int, _c.c_int, _f32p, _c.c_int, _f32p,
                                       _c.c_void_p, _c.c_size_t, _c.c_void_p]),
@@ -228,6 +232,11 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -m fullsubnet_amd.build` (hipcc, gfx950). "
                 "There is no CPU / PyTorch fallback for this path.")
         handle = ctypes.CDLL(LIB_PATH)
+        handle.fsn_version.restype = ctypes.c_int
+        built = handle.fsn_version()
+        if built != ABI_VERSION:  # argument lists differ between revisions: a stale library would misread them silently
+            raise FsnError(f"{LIB_PATH} was built for ABI revision {built}, this package binds revision {ABI_VERSION}: "
+                           "rebuild it with `python -m fullsubnet_amd.build`")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the ABI drifted from include/fsn_hip.h
             fn.restype = res

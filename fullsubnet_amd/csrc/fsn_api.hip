@@ -36,7 +36,7 @@ int fsn_check_launch(const char* what) {
     return FSN_OK;
 }
 extern "C" const char* fsn_last_error(void) { return g_err; }
-extern "C" int fsn_version(void) { return 100; }
+extern "C" int fsn_version(void) { return FSN_ABI_VERSION; }
 
 #define FSN_TRY(x)                \
     do {                          \

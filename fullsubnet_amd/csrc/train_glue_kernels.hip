@@ -1,12 +1,14 @@
 // The glue of the FullSubNet TRAINING graph as hand-written kernels (recipes/dns_interspeech_2020/fullsubnet/model.py:72-136
 // under autograd, fullsubnet/trainer.py:41-71): everything between the transforms, the four LSTM layers, the two output
 // layers and the loss that round 3 still ran as ATen tensor algebra -
-//   * look-ahead pad + offline Laplace norm of the full-band input, written time-major for the LSTM entries
-//     (model.py:85-95, audio_zen/model/base_model.py:204-218);
+//   * look-ahead pad + Laplace norm of the full-band input, written time-major for the LSTM entries
+//     (model.py:85-95; offline: audio_zen/model/base_model.py:204-218, cumulative: :221-251);
 //   * the sub-band model's input: freq_unfold (reflect-padded neighbours, base_model.py:14-46) ++ full-band output, the
-//     offline norm over the unfolded tensor with its mean taken analytically from per-bin sums (the 31-fold unfolded
-//     tensor is never formed), restricted to the rows drop_band keeps (audio_zen/acoustics/feature.py:309-345) - forward
-//     and backward (the gradient reaches the full-band output directly and through the mean);
+//     norm over the unfolded tensor - offline: ONE mean per utterance, taken analytically from per-bin sums (the 31-fold
+//     unfolded tensor is never formed); cumulative (the shipped train_cumulativeLaplaceNorm.toml): every
+//     unit (b, f) is its own "sample" whose 2 nb + 2 rows are the "frequencies", a running mean over the frames so far -
+//     restricted to the rows drop_band keeps (audio_zen/acoustics/feature.py:309-345) - forward and backward (the
+//     gradient reaches the full-band output directly and through the mean / the running means of all later frames);
 //   * the mask's reshape / look-ahead slice (model.py:129-135) and its gradient;
 //   * the training target: complex ideal ratio mask, compressed, band-dropped like the prediction
 //     (audio_zen/acoustics/mask.py:7-44, trainer.py:51-53).
@@ -20,6 +22,7 @@ namespace {
 struct TrDims {
     int B, F, T, la, nb, g;   // g = 1: no band dropping (B == 1 or num_groups <= 1)
     int Tp, Fd, Fs, R;
+    int cum;                  // 1: cumulative_laplace_norm (divisors per frame), 0: offline_laplace_norm (per utterance)
 };
 __host__ __device__ inline TrDims tr_dims(const fsn_train_dims* d) {
     TrDims t;
@@ -29,6 +32,7 @@ __host__ __device__ inline TrDims tr_dims(const fsn_train_dims* d) {
     t.Fd = t.F - t.F % t.g;
     t.Fs = t.g > 1 ? t.Fd / t.g : t.F;
     t.R = t.B * t.Fs;
+    t.cum = d->norm == FSN_NORM_CUMULATIVE_LAPLACE;
     return t;
 }
 // row of the band-dropped (b_out, fs) space -> (sample b, bin f)
@@ -92,8 +96,30 @@ __global__ __launch_bounds__(256) void tr_total_kernel(const double* __restrict_
 }
 // x_tm[t][b][f] = pad(mag)[b][f][t] / (mean_b + 1e-5), mag_tm[t][b][f] = pad(mag)[b][f][t]; zero beyond (B, F); one block
 // per (t, 32-bin slab, b): a 32 x 32 tile through LDS so that both sides are coalesced
+// cumulative_laplace_norm of the padded full-band input (base_model.py:221-251): colsum[b][t] = sum_f mag[b][f][t]
+// (threads along t: coalesced), then cden[b][t] = (sum_{tau <= t} colsum[b][tau]) / (F (t + 1)) + EPSILON; the look-ahead
+// frames are zeros that still count.  One block per utterance; the scan is ~200 additions by one thread.
+__global__ __launch_bounds__(256) void tr_fb_cum_den_kernel(const float* __restrict__ mag, double* __restrict__ colsum,
+                                                           float* __restrict__ cden, TrDims d) {
+    const int b = blockIdx.x;
+    for (int t = threadIdx.x; t < d.Tp; t += 256) {
+        double acc = 0.0;
+        if (t < d.T)
+            for (int f = 0; f < d.F; ++f) acc += (double)mag[((size_t)b * d.F + f) * d.T + t];
+        colsum[(size_t)b * d.Tp + t] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double run = 0.0;
+        for (int t = 0; t < d.Tp; ++t) {
+            run += colsum[(size_t)b * d.Tp + t];
+            cden[(size_t)b * d.Tp + t] = (float)(run / ((double)d.F * (t + 1))) + 1.1920928955078125e-07f;
+        }
+    }
+}
 __global__ __launch_bounds__(256) void tr_fb_input_kernel(const float* __restrict__ mag, const double* __restrict__ total,
-                                                         float* __restrict__ x_tm, float* __restrict__ mag_tm, TrDims d, int Bp, int Fp) {
+                                                         const float* __restrict__ cden, float* __restrict__ x_tm,
+                                                         float* __restrict__ mag_tm, TrDims d, int Bp, int Fp) {
     __shared__ float tile[32][33];
     const int t0 = blockIdx.x * 32, f0 = blockIdx.y * 32, b = blockIdx.z;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -103,11 +129,12 @@ __global__ __launch_bounds__(256) void tr_fb_input_kernel(const float* __restric
     }
     __syncthreads();
     float den = 1.f;
-    if (b < d.B) den = (float)(total[b] / ((double)d.F * d.Tp)) + 1e-5f;
+    if (b < d.B && !d.cum) den = (float)(total[b] / ((double)d.F * d.Tp)) + 1e-5f;
     for (int i = ty; i < 32; i += 8) {  // rows = frames, columns = bins (contiguous in the outputs)
         const int t = t0 + i, f = f0 + tx;
         if (t < d.Tp && f < Fp) {
             const float v = tile[tx][i];
+            if (d.cum && b < d.B) den = cden[(size_t)b * d.Tp + t];
             const size_t o = ((size_t)t * Bp + b) * Fp + f;
             mag_tm[o] = v;
             x_tm[o] = (b < d.B && f < d.F) ? v / den : 0.f;
@@ -146,6 +173,16 @@ __global__ __launch_bounds__(256) void tr_sb_den_kernel(const double* __restrict
     if (threadIdx.x == 0) den[b] = (float)(s / ((double)d.F * (2 * d.nb + 2) * d.Tp)) + 1e-5f;
 }
 // sb_in[t][r][c] (c < 32 = 2 nb + 2 padded to the LSTM entries' 32 columns; rows beyond R zero): 8 rows x 32 columns per wave-pass
+__device__ __forceinline__ float tr_sb_raw(const float* __restrict__ mag_tm, const float* __restrict__ fb, long ld_fb, const TrDims& d,
+                                           int Bp, int Fp, int t, int b, int f, int c) {
+    return c < 2 * d.nb + 1 ? mag_tm[((size_t)t * Bp + b) * Fp + tr_reflect(f + c - d.nb, d.F)] : fb[((size_t)t * Bp + b) * ld_fb + f];
+}
+__device__ __forceinline__ double tr_sum32(double v) {  // over the 32 lanes that share a row (either half of the wave)
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// den: [B] (offline) or [Tp][Rp] (cumulative)
 __global__ __launch_bounds__(256) void tr_sb_input_kernel(const float* __restrict__ mag_tm, const float* __restrict__ fb, long ld_fb,
                                                          const float* __restrict__ den, float* __restrict__ out, TrDims d, int Bp,
                                                          int Fp, int Rp) {
@@ -157,11 +194,65 @@ __global__ __launch_bounds__(256) void tr_sb_input_kernel(const float* __restric
         if (r < d.R && c <= W) {
             int b, f;
             tr_row_bf(d, r, b, f);
-            const float raw = c < W ? mag_tm[((size_t)t * Bp + b) * Fp + tr_reflect(f + c - d.nb, d.F)]
-                                    : fb[((size_t)t * Bp + b) * ld_fb + f];
-            v = raw / den[b];
+            v = tr_sb_raw(mag_tm, fb, ld_fb, d, Bp, Fp, t, b, f, c) / (d.cum ? den[(size_t)t * Rp + r] : den[b]);
         }
         out[((size_t)t * Rp + r) * 32 + c] = v;
+    }
+}
+// cumulative norm of the sub-band tensor, forward: S[t][r] = sum over the 2 nb + 2 columns of the raw row (fp64) ...
+__global__ __launch_bounds__(256) void tr_sb_cum_sum_kernel(const float* __restrict__ mag_tm, const float* __restrict__ fb, long ld_fb,
+                                                           double* __restrict__ S, TrDims d, int Bp, int Fp, int Rp) {
+    const int t = blockIdx.y;
+    const int c = threadIdx.x & 31;
+    for (int r0 = blockIdx.x * 8; r0 < Rp; r0 += gridDim.x * 8) {  // (uniform trip count: the shuffles see whole waves)
+        const int r = r0 + (threadIdx.x >> 5);
+        double v = 0.0;
+        if (r < d.R && c <= 2 * d.nb + 1) {
+            int b, f;
+            tr_row_bf(d, r, b, f);
+            v = (double)tr_sb_raw(mag_tm, fb, ld_fb, d, Bp, Fp, t, b, f, c);
+        }
+        v = tr_sum32(v);
+        if (c == 0 && r < Rp) S[(size_t)t * Rp + r] = v;
+    }
+}
+// ... den[t][r] = (sum_{tau <= t} S[tau][r]) / ((2 nb + 2) (t + 1)) + EPSILON (base_model.py:230-251 with the units as samples:
+// quirk Q4); a thread per row, rows coalesced
+__global__ __launch_bounds__(256) void tr_sb_cum_scan_kernel(const double* __restrict__ S, float* __restrict__ den, TrDims d, int Rp) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= Rp) return;
+    double run = 0.0;
+    const double C = (double)(2 * d.nb + 2);
+    for (int t = 0; t < d.Tp; ++t) {
+        run += S[(size_t)t * Rp + r];
+        den[(size_t)t * Rp + r] = (float)(run / (C * (t + 1))) + 1.1920928955078125e-07f;
+    }
+}
+// backward: y = raw / D, D[t] = (sum_{tau <= t} S[tau]) / (C (t + 1)) + eps  =>  d loss / d S[tau] = sum_{t >= tau} P[t] with
+// P[t] = - (sum_c dy[t][c] y[t][c]) / D[t] / (C (t + 1)); every raw element of frame tau receives that on top of dy / D.
+__global__ __launch_bounds__(256) void tr_sb_cum_bwd_p_kernel(const float* __restrict__ dx, const float* __restrict__ sb_in,
+                                                             const float* __restrict__ den, double* __restrict__ P, TrDims d, int Rp) {
+    const int t = blockIdx.y;
+    const int c = threadIdx.x & 31;
+    const double k = 1.0 / ((double)(2 * d.nb + 2) * (t + 1));
+    for (int r0 = blockIdx.x * 8; r0 < Rp; r0 += gridDim.x * 8) {
+        const int r = r0 + (threadIdx.x >> 5);
+        double v = 0.0;
+        if (r < d.R && c <= 2 * d.nb + 1) {
+            const size_t i = ((size_t)t * Rp + r) * 32 + c;
+            v = (double)dx[i] * (double)sb_in[i];
+        }
+        v = tr_sum32(v);
+        if (c == 0 && r < Rp) P[(size_t)t * Rp + r] = r < d.R ? -v / (double)den[(size_t)t * Rp + r] * k : 0.0;
+    }
+}
+__global__ __launch_bounds__(256) void tr_sb_cum_bwd_scan_kernel(const double* __restrict__ P, float* __restrict__ G, TrDims d, int Rp) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= Rp) return;
+    double run = 0.0;
+    for (int t = d.Tp - 1; t >= 0; --t) {
+        run += P[(size_t)t * Rp + r];
+        G[(size_t)t * Rp + r] = (float)run;
     }
 }
 // backward, pass 1: partial[bo][t] = sum over the rows of band-dropped sample bo and the columns of dx[t][r][c] sb_in[t][r][c]
@@ -171,7 +262,9 @@ __global__ __launch_bounds__(256) void tr_sb_bwd_partial_kernel(const float* __r
     const int t = blockIdx.x, bo = blockIdx.y;
     const size_t base = ((size_t)t * Rp + (size_t)bo * d.Fs) * 32;
     double acc = 0.0;
-    for (int i = threadIdx.x; i < d.Fs * 32; i += 256) acc += (double)dx[base + i] * (double)sb_in[base + i];
+    const int C = 2 * d.nb + 2;  // columns beyond are padding: the dX product does not write them (uninitialised memory)
+    for (int i = threadIdx.x; i < d.Fs * 32; i += 256)
+        if ((i & 31) < C) acc += (double)dx[base + i] * (double)sb_in[base + i];
     const double s = tr_block_sum(acc, sh);
     if (threadIdx.x == 0) partial[(size_t)bo * d.Tp + t] = s;
 }
@@ -191,6 +284,7 @@ __global__ __launch_bounds__(256) void tr_sb_bwd_dmu_kernel(const double* __rest
 }
 // pass 3: d fb_out[t][b][f] = [row kept] dx[t][r][2 nb + 1] / den[b] + dmu[b], through the ReLU of the full-band output
 // layer (fb_out > 0), as the padded dy of fsn_linear_backward ([Tp Bp][ld_d], zeros beyond (B, F))
+// (cumulative norm: a unit's divisors hang on its own rows only, so dropped units receive nothing; dmu = G [Tp][Rp])
 __global__ __launch_bounds__(256) void tr_sb_bwd_dfb_kernel(const float* __restrict__ dx, const float* __restrict__ den,
                                                            const float* __restrict__ dmu, const float* __restrict__ fb, long ld_fb,
                                                            float* __restrict__ dfb, long ld_d, TrDims d, int Bp, int Rp) {
@@ -198,9 +292,13 @@ __global__ __launch_bounds__(256) void tr_sb_bwd_dfb_kernel(const float* __restr
     for (int f = blockIdx.x * 256 + threadIdx.x; f < ld_d; f += gridDim.x * 256) {
         float v = 0.f;
         if (b < d.B && f < d.F && fb[((size_t)t * Bp + b) * ld_fb + f] > 0.f) {
-            v = dmu[b];
             const int r = tr_bf_row(d, b, f);
-            if (r >= 0) v += dx[((size_t)t * Rp + r) * 32 + 2 * d.nb + 1] / den[b];
+            if (d.cum) {
+                if (r >= 0) v = dx[((size_t)t * Rp + r) * 32 + 2 * d.nb + 1] / den[(size_t)t * Rp + r] + dmu[(size_t)t * Rp + r];
+            } else {
+                v = dmu[b];
+                if (r >= 0) v += dx[((size_t)t * Rp + r) * 32 + 2 * d.nb + 1] / den[b];
+            }
         }
         dfb[((size_t)t * Bp + b) * ld_d + f] = v;
     }
@@ -260,24 +358,37 @@ __global__ void tr_scale_kernel(const float* __restrict__ x, const float* __rest
 struct TrWs {
     double *rowsum, *total, *partial;
     float* dmu;
+    // cumulative norm only
+    double* rowframe;  // [Tp][Rcap]: S (forward) / P (backward)
+    float* G;          // [Tp][Rcap]
+    float* cden;       // [B][Tp]
 };
-static size_t tr_ws_bytes(const TrDims& d) { return ((size_t)d.B * d.F + d.B + (size_t)d.B * d.Tp) * sizeof(double) + (size_t)d.B * sizeof(float) + 256; }
+static size_t tr_rcap(const TrDims& d) { return ((size_t)d.R + 63) / 64 * 64; }  // padded row counts up to this fit the workspace
+static size_t tr_ws_bytes(const TrDims& d) {
+    size_t n = ((size_t)d.B * d.F + d.B + (size_t)d.B * d.Tp) * sizeof(double) + (((size_t)d.B + 1) / 2 * 2) * sizeof(float) + 256;
+    if (d.cum) n += (size_t)d.Tp * tr_rcap(d) * (sizeof(double) + sizeof(float)) + (size_t)d.B * d.Tp * sizeof(float);
+    return n;
+}
 static TrWs tr_carve(const TrDims& d, void* ws) {
     TrWs w;
     w.rowsum = static_cast<double*>(ws);
     w.total = w.rowsum + (size_t)d.B * d.F;
     w.partial = w.total + d.B;
     w.dmu = reinterpret_cast<float*>(w.partial + (size_t)d.B * d.Tp);
+    w.rowframe = reinterpret_cast<double*>(w.dmu + ((size_t)d.B + 1) / 2 * 2);
+    w.G = reinterpret_cast<float*>(w.rowframe + (size_t)d.Tp * tr_rcap(d));
+    w.cden = w.G + (size_t)d.Tp * tr_rcap(d);
     return w;
 }
 static bool tr_check(const fsn_train_dims* dd) {
     return dd && dd->B >= 1 && dd->F >= 2 && dd->T >= 1 && dd->look_ahead >= 0 && dd->nb >= 0 && 2 * dd->nb + 2 <= 32 && dd->nb < dd->F &&
-           dd->groups >= 1;
+           dd->groups >= 1 && (dd->norm == FSN_NORM_OFFLINE_LAPLACE || dd->norm == FSN_NORM_CUMULATIVE_LAPLACE);
 }
 
 }  // namespace
 
-#define TR_REQUIRE_DIMS(dd) FSN_REQUIRE(tr_check(dd), "train glue: bad dimensions (B, F >= 2, T >= 1, 2 nb + 2 <= 32, nb < F, groups >= 1)")
+#define TR_REQUIRE_DIMS(dd) \
+    FSN_REQUIRE(tr_check(dd), "train glue: bad dimensions (B, F >= 2, T >= 1, 2 nb + 2 <= 32, nb < F, groups >= 1, norm offline / cumulative Laplace)")
 
 extern "C" int fsn_train_rows(const fsn_train_dims* dims, int* Fs, int* R) {
     TR_REQUIRE_DIMS(dims);
@@ -287,6 +398,11 @@ extern "C" int fsn_train_rows(const fsn_train_dims* dims, int* Fs, int* R) {
     return FSN_OK;
 }
 extern "C" size_t fsn_train_glue_workspace_bytes(const fsn_train_dims* dims) { return tr_check(dims) ? tr_ws_bytes(tr_dims(dims)) : 0; }
+extern "C" size_t fsn_train_den_elems(const fsn_train_dims* dims, int Rp) {
+    if (!tr_check(dims)) return 0;
+    const TrDims d = tr_dims(dims);
+    return d.cum ? (size_t)d.Tp * (size_t)Rp : (size_t)d.B;
+}
 
 extern "C" int fsn_train_fb_input(const fsn_train_dims* dims, const float* mag, float* x_tm, float* mag_tm, int Bp, int Fp,
                                   void* workspace, size_t workspace_bytes, void* stream) {
@@ -300,12 +416,17 @@ extern "C" int fsn_train_fb_input(const fsn_train_dims* dims, const float* mag, 
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const TrWs w = tr_carve(d, workspace);
-    hipLaunchKernelGGL(tr_rowsum_kernel, dim3((unsigned)((d.B * d.F + 3) / 4)), dim3(256), 0, s, mag, w.rowsum, d.B * d.F, d.T);
-    FSN_TRY_LAUNCH("tr_rowsum_kernel");
-    hipLaunchKernelGGL(tr_total_kernel, dim3((unsigned)d.B), dim3(256), 0, s, w.rowsum, w.total, d.F);
-    FSN_TRY_LAUNCH("tr_total_kernel");
+    if (d.cum) {
+        hipLaunchKernelGGL(tr_fb_cum_den_kernel, dim3((unsigned)d.B), dim3(256), 0, s, mag, w.partial, w.cden, d);
+        FSN_TRY_LAUNCH("tr_fb_cum_den_kernel");
+    } else {
+        hipLaunchKernelGGL(tr_rowsum_kernel, dim3((unsigned)((d.B * d.F + 3) / 4)), dim3(256), 0, s, mag, w.rowsum, d.B * d.F, d.T);
+        FSN_TRY_LAUNCH("tr_rowsum_kernel");
+        hipLaunchKernelGGL(tr_total_kernel, dim3((unsigned)d.B), dim3(256), 0, s, w.rowsum, w.total, d.F);
+        FSN_TRY_LAUNCH("tr_total_kernel");
+    }
     hipLaunchKernelGGL(tr_fb_input_kernel, dim3((unsigned)((d.Tp + 31) / 32), (unsigned)((Fp + 31) / 32), (unsigned)Bp), dim3(256), 0, s,
-                       mag, w.total, x_tm, mag_tm, d, Bp, Fp);
+                       mag, w.total, w.cden, x_tm, mag_tm, d, Bp, Fp);
     return fsn_check_launch("tr_fb_input_kernel");
 }
 
@@ -322,11 +443,19 @@ extern "C" int fsn_train_sb_input(const fsn_train_dims* dims, const float* mag_t
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const TrWs w = tr_carve(d, workspace);  // rowsum: left there by fsn_train_fb_input of the same step
-    hipLaunchKernelGGL(tr_fbsum_partial_kernel, dim3((unsigned)d.Tp, (unsigned)d.B), dim3(256), 0, s, fb_out_tm, ld_fb, w.partial, d, Bp);
-    FSN_TRY_LAUNCH("tr_fbsum_partial_kernel");
-    hipLaunchKernelGGL(tr_sb_den_kernel, dim3((unsigned)d.B), dim3(256), 0, s, w.rowsum, w.partial, den, d);
-    FSN_TRY_LAUNCH("tr_sb_den_kernel");
     const unsigned gx = (unsigned)((Rp + 7) / 8 < 1024 ? (Rp + 7) / 8 : 1024);
+    if (d.cum) {
+        FSN_REQUIRE((size_t)Rp <= tr_rcap(d), "train sb input: cumulative norm takes at most the rows rounded up to 64 as padded rows");
+        hipLaunchKernelGGL(tr_sb_cum_sum_kernel, dim3(gx, (unsigned)d.Tp), dim3(256), 0, s, mag_tm, fb_out_tm, ld_fb, w.rowframe, d, Bp, Fp, Rp);
+        FSN_TRY_LAUNCH("tr_sb_cum_sum_kernel");
+        hipLaunchKernelGGL(tr_sb_cum_scan_kernel, dim3((unsigned)((Rp + 255) / 256)), dim3(256), 0, s, w.rowframe, den, d, Rp);
+        FSN_TRY_LAUNCH("tr_sb_cum_scan_kernel");
+    } else {
+        hipLaunchKernelGGL(tr_fbsum_partial_kernel, dim3((unsigned)d.Tp, (unsigned)d.B), dim3(256), 0, s, fb_out_tm, ld_fb, w.partial, d, Bp);
+        FSN_TRY_LAUNCH("tr_fbsum_partial_kernel");
+        hipLaunchKernelGGL(tr_sb_den_kernel, dim3((unsigned)d.B), dim3(256), 0, s, w.rowsum, w.partial, den, d);
+        FSN_TRY_LAUNCH("tr_sb_den_kernel");
+    }
     hipLaunchKernelGGL(tr_sb_input_kernel, dim3(gx, (unsigned)d.Tp), dim3(256), 0, s, mag_tm, fb_out_tm, ld_fb, den, sb_in, d, Bp, Fp, Rp);
     return fsn_check_launch("tr_sb_input_kernel");
 }
@@ -345,12 +474,21 @@ extern "C" int fsn_train_sb_input_backward(const fsn_train_dims* dims, const flo
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const TrWs w = tr_carve(d, workspace);
-    hipLaunchKernelGGL(tr_sb_bwd_partial_kernel, dim3((unsigned)d.Tp, (unsigned)d.B), dim3(256), 0, s, dx, sb_in, w.partial, d, Rp);
-    FSN_TRY_LAUNCH("tr_sb_bwd_partial_kernel");
-    hipLaunchKernelGGL(tr_sb_bwd_dmu_kernel, dim3((unsigned)d.B), dim3(256), 0, s, w.partial, den, w.dmu, d);
-    FSN_TRY_LAUNCH("tr_sb_bwd_dmu_kernel");
+    if (d.cum) {
+        FSN_REQUIRE((size_t)Rp <= tr_rcap(d), "train sb input backward: cumulative norm takes at most the rows rounded up to 64 as padded rows");
+        const unsigned gx = (unsigned)((Rp + 7) / 8 < 1024 ? (Rp + 7) / 8 : 1024);
+        hipLaunchKernelGGL(tr_sb_cum_bwd_p_kernel, dim3(gx, (unsigned)d.Tp), dim3(256), 0, s, dx, sb_in, den, w.rowframe, d, Rp);
+        FSN_TRY_LAUNCH("tr_sb_cum_bwd_p_kernel");
+        hipLaunchKernelGGL(tr_sb_cum_bwd_scan_kernel, dim3((unsigned)((Rp + 255) / 256)), dim3(256), 0, s, w.rowframe, w.G, d, Rp);
+        FSN_TRY_LAUNCH("tr_sb_cum_bwd_scan_kernel");
+    } else {
+        hipLaunchKernelGGL(tr_sb_bwd_partial_kernel, dim3((unsigned)d.Tp, (unsigned)d.B), dim3(256), 0, s, dx, sb_in, w.partial, d, Rp);
+        FSN_TRY_LAUNCH("tr_sb_bwd_partial_kernel");
+        hipLaunchKernelGGL(tr_sb_bwd_dmu_kernel, dim3((unsigned)d.B), dim3(256), 0, s, w.partial, den, w.dmu, d);
+        FSN_TRY_LAUNCH("tr_sb_bwd_dmu_kernel");
+    }
     hipLaunchKernelGGL(tr_sb_bwd_dfb_kernel, dim3((unsigned)((ld_dfb + 255) / 256), (unsigned)d.Tp, (unsigned)Bp), dim3(256), 0, s, dx, den,
-                       w.dmu, fb_out_tm, ld_fb, d_fb, ld_dfb, d, Bp, Rp);
+                       d.cum ? w.G : w.dmu, fb_out_tm, ld_fb, d_fb, ld_dfb, d, Bp, Rp);
     return fsn_check_launch("tr_sb_bwd_dfb_kernel");
 }
 

@@ -371,15 +371,20 @@ class FullSubNetTrainFunction(torch.autograd.Function):
     in the time-major, zero-padded layouts the LSTM entries take, written by the kernels themselves (torch.empty only)."""
 
     @staticmethod
-    def forward(ctx, noisy_mag, look_ahead, nb, groups, arith, *params):
+    def forward(ctx, noisy_mag, look_ahead, nb, groups, arith, norm_type, *params):
         L = _lib.lib()
         if arith not in ("f32", "f16", "bf16"):
             raise _lib.FsnError(f"training arithmetic {arith!r}: one of 'f32', 'f16', 'bf16'")
+        if norm_type not in _lib.NORM_TYPES:
+            raise _lib.FsnError(f"fused training graph: norm_type {norm_type!r}: one of {sorted(_lib.NORM_TYPES)}")
         ar = _lib.ARITH[arith]
         dev = noisy_mag.device
         B, _, F, T = noisy_mag.shape
+        # drop_band's own check (feature.py:317-319), reached for every batch of more than one utterance (model.py:114)
+        assert B == 1 or B > groups, (
+            f"Batch size = {B}, num_groups = {groups}. The batch size should larger than the num_groups.")
         Tp = T + look_ahead
-        dims = _lib.TrainDims(B, F, T, look_ahead, nb, groups)
+        dims = _lib.TrainDims(B, F, T, look_ahead, nb, groups, _lib.NORM_TYPES[norm_type])
         dp = ctypes.byref(dims)
         fs, rows = ctypes.c_int(0), ctypes.c_int(0)
         _lib.check(L.fsn_train_rows(dp, ctypes.byref(fs), ctypes.byref(rows)))
@@ -416,7 +421,7 @@ class FullSubNetTrainFunction(torch.autograd.Function):
 
         fh0, fh1, fs0, fs1 = lstm2(x_tm, Fp, fb, Bp, F, Hf)
         fb_out = linear(fh1, Hf, fb_fc[0], fb_fc[1], Tp * Bp, Hf, F, 1)          # [Tp Bp, F], ReLU
-        sb_in, den = new(Tp, Rp, 32), new(B)
+        sb_in, den = new(Tp, Rp, 32), new(L.fsn_train_den_elems(dp, Rp))  # divisors: per utterance / per unit and frame
         _lib.check(L.fsn_train_sb_input(dp, _lib.dev_ptr(mag_tm), _lib.dev_ptr(fb_out), F, Bp, Fp, _lib.dev_ptr(sb_in), Rp,
                                         _lib.dev_ptr(den), gws.data_ptr(), gws.numel(), st))
         sh0, sh1, ss0, ss1 = lstm2(sb_in, 32, sb, Rp, Is, Hs)
@@ -502,13 +507,14 @@ class FullSubNetTrainFunction(torch.autograd.Function):
             main.wait_stream(side)  # the sub-band weight gradients: everything after this call sees them
             main.wait_stream(third)
             keep.clear()
-        return (None, None, None, None, None, *g_fb, d_ffw, d_ffb, *g_sb, d_sfw, d_sfb)
+        return (None, None, None, None, None, None, *g_fb, d_ffw, d_ffb, *g_sb, d_sfw, d_sfb)
 
 
 def fused_train_supported(model, noisy_mag):
-    """The configuration FullSubNetTrainFunction is built for: the shipped FullSubNet TOMLs (LSTM, offline Laplace norm, no
-    full-band neighbours, ReLU / linear output layers), a ROCm input that does not itself need a gradient."""
-    return (getattr(model, "_fused", False) and model.norm_type == "offline_laplace_norm" and noisy_mag.is_cuda
+    """The configurations FullSubNetTrainFunction is built for: the shipped FullSubNet TOMLs (LSTM, offline or cumulative
+    Laplace norm - fullsubnet/train.toml:82, train_cumulativeLaplaceNorm.toml:82 -, no full-band neighbours, ReLU / linear
+    output layers), a ROCm input that does not itself need a gradient."""
+    return (getattr(model, "_fused", False) and model.norm_type in _lib.NORM_TYPES and noisy_mag.is_cuda
             and not noisy_mag.requires_grad and 2 * model.sb_num_neighbors + 2 <= 32
             and model.fb_model.sequence_model.num_layers == 2 and model.sb_model.sequence_model.num_layers == 2
             and getattr(model, "fused_training_graph", True))
@@ -529,7 +535,7 @@ def forward_train(model, noisy_mag):
     arith = getattr(model, "train_arithmetic", "f32")  # "f16" / "bf16": autocast arithmetic (Trainer, use_amp)
     if fused_train_supported(model, noisy_mag):  # the whole model as one autograd node on the library's kernels
         return FullSubNetTrainFunction.apply(noisy_mag, model.look_ahead, model.sb_num_neighbors, model.num_groups_in_drop_band,
-                                             arith, *_fused_params(model))
+                                             arith, model.norm_type, *_fused_params(model))
     x = functional.pad(noisy_mag, [0, model.look_ahead])
     B, C, F, Tp = x.shape
     fb_in = _norm(x, model.norm_type).reshape(B, F, Tp)
@@ -617,7 +623,7 @@ def train_step(model, optimizer, noisy, clean, n_fft=512, hop_length=256, win_le
         B, F, T = noisy_mag.shape
         assert B > groups, (  # drop_band's own check (feature.py:322-323): the reference's step fails the same way
             f"Batch size = {B}, num_groups = {groups}. The batch size should larger than the num_groups.")
-        dims = _lib.TrainDims(B, F, T, inner.look_ahead, inner.sb_num_neighbors, groups)
+        dims = _lib.TrainDims(B, F, T, inner.look_ahead, inner.sb_num_neighbors, groups, _lib.NORM_TYPES[inner.norm_type])
         crm = model(x_in)
         cirm = torch.empty_like(crm)
         _lib.check(_lib.lib().fsn_train_cirm_target(ctypes.byref(dims), *[_lib.dev_ptr(t.contiguous()) for t in
@@ -651,6 +657,10 @@ def train_step(model, optimizer, noisy, clean, n_fft=512, hop_length=256, win_le
             group["clip_grad_norm_value"] = clip_grad_norm_value
         optimizer.step()
     else:
-        torch.nn.utils.clip_grad_norm_(model.parameters(), clip_grad_norm_value)
-        optimizer.step()
+        # a stock optimizer (the reference's torch.optim.Adam, train.py:55-59) has no skip of its own: a poisoned step - a
+        # persistent kernel that ran out of time under the trainer's "defer" policy turns every gradient into NaN - must not
+        # reach the parameters and moments (one host read of the norm; the reference syncs on loss.item() every step anyway)
+        total_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), clip_grad_norm_value)
+        if bool(torch.isfinite(total_norm)):
+            optimizer.step()
     return loss

@@ -221,7 +221,18 @@ class Trainer:
         # every later persistent launch) must not raise out of forward / backward - under DistributedDataParallel the
         # peers would be left waiting in the gradient all-reduce.  The launches go ahead instead (NaN in, NaN out), the
         # fused optimizer skips the update on the device, and the record is read below, once per step
+        # (every optimizer path of train_step skips the update on a non-finite gradient norm: ClipAdam and GradScaler on the
+        # device, a stock optimizer after a host check of clip_grad_norm_'s result)
         _lib.stream_timeout_policy("defer", self.device)
+        try:
+            loss_total, n = self._train_batches(loss_total, n)
+        finally:  # an exception in the loop must not leave the stream deferring: later inference would yield NaN silently
+            _lib.stream_timeout_policy("refuse", self.device)
+        self.last_loss = loss_total / max(n, 1)
+        self.history["Loss/Train"][epoch] = self.last_loss
+        return self.last_loss
+
+    def _train_batches(self, loss_total, n):
         for noisy, clean in self.train_dataloader:
             loss = train_step(self.model, self.optimizer, noisy.to(self.device), clean.to(self.device), self.n_fft,
                               self.hop_length, self.win_length, self.clip_grad_norm_value, self.loss_function,
@@ -242,10 +253,7 @@ class Trainer:
                 continue
             loss_total += value
             n += 1
-        _lib.stream_timeout_policy("refuse", self.device)
-        self.last_loss = loss_total / max(n, 1)
-        self.history["Loss/Train"][epoch] = self.last_loss
-        return self.last_loss
+        return loss_total, n
 
     @torch.no_grad()
     def _validation_epoch(self, epoch):

@@ -50,6 +50,10 @@ extern "C" {
 #define FSN_ARITH_BF16 3
 
 const char* fsn_last_error(void);
+/* The ABI revision this header describes.  fsn_version() returns the revision the LIBRARY was built with: a caller
+ * compares the two once after loading (fullsubnet_amd/_lib.py raises on a mismatch) - argument lists changed between
+ * revisions (110: fsn_train_dims.norm, fsn_train_den_elems; 100 -> 101 of round 4: fsn_clip_adam_step's found_inf). */
+#define FSN_ABI_VERSION 110
 int fsn_version(void);
 
 /* ---- STFT / iSTFT : audio_zen/acoustics/feature.py ------------------------------------- */
@@ -363,18 +367,25 @@ int fsn_mse_loss(const float* input, const float* target, size_t n, float* loss,
  * along the batch axis: row r = b_out Fs + fs.  Time-major tensors: [Tp = T + look_ahead][rows padded][columns padded].
  *
  * fsn_train_rows            Fs (bins per band-dropped sample) and R = B Fs (sub-band rows).
+ * norm = FSN_NORM_OFFLINE_LAPLACE (train.toml:82) or FSN_NORM_CUMULATIVE_LAPLACE (train_cumulativeLaplaceNorm.toml:82).
  * fsn_train_fb_input        mag [B][F][T] -> x_tm [Tp][Bp][Fp] = pad(mag) / (mean_b + 1e-5) (model.py:85-95: look-ahead pad,
- *                           base_model.py:204-218 offline Laplace norm over [1, F, Tp]), zeros beyond (B, F): the input of
+ *                           base_model.py:204-218 offline Laplace norm over [1, F, Tp]; cumulative: / (running mean over the
+ *                           frames so far + EPSILON, base_model.py:221-251)), zeros beyond (B, F): the input of
  *                           fsn_lstm2_forward_train (ldx = Fp); mag_tm [Tp][Bp][Fp] = the padded magnitude itself, for
  *                           fsn_train_sb_input.  Leaves the per-bin sums in `workspace` (same buffer for the whole step).
  * fsn_train_sb_input        freq_unfold(mag, nb) ++ fb_out, / (mean + 1e-5), rows of drop_band (model.py:98-125;
  *                           base_model.py:14-46) -> sb_in [Tp][Rp][32] (columns 2 nb + 2 .. 31 and rows beyond R zero);
  *                           fb_out_tm [Tp][Bp][ld_fb] = the full-band output layer's result (fsn_linear_forward, ReLU);
- *                           den [B] = the divisor per utterance (kept for the backward).  The mean of the unfolded tensor
- *                           is taken from per-bin sums and window multiplicities; the unfolded tensor is never formed.
+ *                           den [fsn_train_den_elems] = the divisors (kept for the backward): [B], one per utterance
+ *                           (offline; the mean of the unfolded tensor is taken from per-bin sums and window multiplicities) or
+ *                           [Tp][Rp], one per unit and frame (cumulative: base_model.py:230-251 sees the units as samples and
+ *                           a unit's 2 nb + 2 rows as its frequencies; Rp <= rows rounded up to 64).  The unfolded tensor is
+ *                           never formed.
  * fsn_train_sb_input_backward  dx [Tp][Rp][32] (d loss / d sb_in, from fsn_lstm2_backward) -> d_fb [Tp Bp][ld_dfb]: the
  *                           gradient of the full-band output layer's PRE-activation (through the ReLU: fb_out > 0), directly
- *                           (column 2 nb + 1 of the kept rows) and through the mean - the padded dy fsn_linear_backward takes.
+ *                           (column 2 nb + 1 of the kept rows) and through the mean (cumulative: through the running means of
+ *                           this and all later frames of the same unit) - the padded dy fsn_linear_backward takes.  Columns
+ *                           2 nb + 2 .. 31 of dx are never read (the dX product does not write them).
  * fsn_train_mask_out        y [Tp][Rp][2] (fsn_linear_forward of the sub-band output layer) -> mask [B][2][Fs][T], the
  *                           look-ahead frames dropped (model.py:129-135).   fsn_train_mask_grad: its adjoint, d_mask ->
  *                           dy [Tp][Rp][ld] (zeros in the look-ahead frames and the padding).
@@ -383,9 +394,11 @@ int fsn_mse_loss(const float* input, const float* target, size_t n, float* loss,
  * fsn_scale_by_scalar       y = x * (*scale), scale a device scalar (the incoming gradient of the loss). */
 typedef struct fsn_train_dims {
     int B, F, T, look_ahead, nb, groups;
+    int norm; /* FSN_NORM_OFFLINE_LAPLACE / FSN_NORM_CUMULATIVE_LAPLACE (model.py:21 norm_type) */
 } fsn_train_dims;
 int fsn_train_rows(const fsn_train_dims* dims, int* Fs, int* R);
 size_t fsn_train_glue_workspace_bytes(const fsn_train_dims* dims);
+size_t fsn_train_den_elems(const fsn_train_dims* dims, int Rp);
 int fsn_train_fb_input(const fsn_train_dims* dims, const float* mag, float* x_tm, float* mag_tm, int Bp, int Fp,
                        void* workspace, size_t workspace_bytes, void* stream);
 int fsn_train_sb_input(const fsn_train_dims* dims, const float* mag_tm, const float* fb_out_tm, long ld_fb, int Bp, int Fp,

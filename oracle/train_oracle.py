@@ -7,8 +7,8 @@ Restates recipes/dns_interspeech_2020/fullsubnet/trainer.py:41-71 with use_amp =
 The nn.LSTM layers are restated as an explicit loop over time on torch CPU tensors (gate order
 i, f, g, o; sequence_model.py:52-58) so that autograd differentiates the *restated* cell, not ATen's
 fused LSTM; everything else uses the same tensor algebra as the reference.  Pinned against the
-reference's own loss / gradients / updated parameters in tests/golden/fsn_train_b4.npz
-(tests/test_train_oracle.py).
+reference's own loss / gradients / updated parameters in tests/golden/fsn_train_b4.npz and, for the cumulative Laplace
+norm of train_cumulativeLaplaceNorm.toml, fsn_train_cum_b4.npz (tests/test_train_oracle.py).
 """
 import numpy as np
 import torch
@@ -62,6 +62,20 @@ def offline_laplace_norm(x):
     return x / (mu + 1e-5)
 
 
+def cumulative_laplace_norm(x):
+    """base_model.py:221-251: x [B, C, F, T] -> x / (running mean over (F, frames <= t) of every (b, c) + EPSILON).  On the
+    4-D sub-band tensor [B, F, 2 nb + 2, T'] the units f take the place of the channels."""
+    B, C, F, T = x.shape
+    xr = x.reshape(B * C, F, T)
+    cum = torch.cumsum(torch.sum(xr, dim=1), dim=-1)
+    count = torch.arange(F, F * T + 1, F, dtype=x.dtype).reshape(1, T)
+    mean = (cum / count).reshape(B * C, 1, T)
+    return (xr / (mean + EPSILON)).reshape(B, C, F, T)
+
+
+NORMS = {"offline_laplace_norm": offline_laplace_norm, "cumulative_laplace_norm": cumulative_laplace_norm}
+
+
 def drop_band(x, g):
     """feature.py:309-345."""
     B, _, F, _ = x.shape
@@ -73,14 +87,15 @@ def drop_band(x, g):
     return torch.cat([x[i::g][:, :, i:F:g, :] for i in range(g)], dim=0)
 
 
-def model_forward(noisy_mag, p, look_ahead=2, nb=15, groups=2):
+def model_forward(noisy_mag, p, look_ahead=2, nb=15, groups=2, norm_type="offline_laplace_norm"):
     """fullsubnet/model.py:72-136."""
+    norm = NORMS[norm_type]
     x = functional.pad(noisy_mag, [0, look_ahead])
     B, C, F, Tp = x.shape
-    fb_out = sequence_model(offline_laplace_norm(x).reshape(B, F, Tp), p, "fb_model", True).reshape(B, 1, F, Tp)
+    fb_out = sequence_model(norm(x).reshape(B, F, Tp), p, "fb_model", True).reshape(B, 1, F, Tp)
     sb_in = torch.cat([freq_unfold(x, nb).reshape(B, F, 2 * nb + 1, Tp), freq_unfold(fb_out, 0).reshape(B, F, 1, Tp)],
                       dim=2)
-    sb_in = offline_laplace_norm(sb_in)
+    sb_in = norm(sb_in)
     Fs = F
     if B > 1:
         sb_in = drop_band(sb_in.permute(0, 2, 1, 3), groups)
@@ -96,7 +111,7 @@ def compress_cirm(m):
     return 10 * (1 - torch.exp(-0.1 * m)) / (1 + torch.exp(-0.1 * m))
 
 
-def train_step(params, noisy, clean, groups=2, lr=1e-3, clip=10.0):
+def train_step(params, noisy, clean, groups=2, lr=1e-3, clip=10.0, norm_type="offline_laplace_norm"):
     """One iteration; returns dict(loss, grads {name: tensor}, new_params {name: tensor}).
     params: {reference state_dict name: np.ndarray}; noisy / clean: np.ndarray [B, L]."""
     p = {k: torch.tensor(v, dtype=torch.float32, requires_grad=True) for k, v in params.items()}
@@ -107,7 +122,7 @@ def train_step(params, noisy, clean, groups=2, lr=1e-3, clip=10.0):
     cirm = compress_cirm(torch.stack(((sn.real * sc.real + sn.imag * sc.imag) / den,
                                       (sn.real * sc.imag - sn.imag * sc.real) / den), dim=-1))
     cirm = drop_band(cirm.permute(0, 3, 1, 2), groups).permute(0, 2, 3, 1)
-    crm = model_forward(sn.abs().unsqueeze(1), p, groups=groups).permute(0, 2, 3, 1)
+    crm = model_forward(sn.abs().unsqueeze(1), p, groups=groups, norm_type=norm_type).permute(0, 2, 3, 1)
     loss = torch.mean((cirm - crm) ** 2)
     loss.backward()
     names = list(p)

@@ -5,6 +5,8 @@ Follows recipes/dns_interspeech_2020/fullsubnet/trainer.py:41-71 with use_amp = 
 stft / build_complex_ideal_ratio_mask / drop_band / Model (nn.LSTM) / MSELoss / clip_grad_norm_(10)
 / Adam(lr 1e-3).  Stored: the loss, and for every parameter the clipped-gradient norm, a strided
 sample of the gradient and of the updated parameter (the full tensors are 22 MB each).
+Flags: --config3 / --config3x2 (BASELINE config 3 shapes), --amp-bf16 (the step under CPU autocast), --cumulative (the
+shipped train_cumulativeLaplaceNorm.toml's norm).
 """
 import os
 import sys
@@ -29,13 +31,13 @@ from oracle.fullsubnet_oracle import make_noisy, make_params  # noqa: E402
 SAMPLE = 97  # stride of the per-parameter samples
 
 
-def main(batch=4, length=2560, groups=2, name="fsn_train_b4", sample=SAMPLE, autocast=None):
+def main(batch=4, length=2560, groups=2, name="fsn_train_b4", sample=SAMPLE, autocast=None, norm_type="offline_laplace_norm"):
     params = make_params(seed=3)
     noisy = make_noisy(batch, length, seed=41)
     clean = 0.7 * make_noisy(batch, length, seed=42)
     model = Model(num_freqs=257, look_ahead=2, sequence_model="LSTM", fb_num_neighbors=0, sb_num_neighbors=15,
                   fb_output_activate_function="ReLU", sb_output_activate_function=False, fb_model_hidden_size=512,
-                  sb_model_hidden_size=384, norm_type="offline_laplace_norm", num_groups_in_drop_band=groups,
+                  sb_model_hidden_size=384, norm_type=norm_type, num_groups_in_drop_band=groups,
                   weight_init=False).train()
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
@@ -61,7 +63,7 @@ def main(batch=4, length=2560, groups=2, name="fsn_train_b4", sample=SAMPLE, aut
         out["p/" + k] = p.detach().reshape(-1)[::sample].numpy().copy()
     out["meta"] = np.array(repr(dict(batch=batch, length=length, groups=groups, seed_w=3, seed_noisy=41, seed_clean=42,
                                      clean_gain=0.7, sample=sample, torch=torch.__version__,
-                                     autocast=str(autocast))))
+                                     autocast=str(autocast), norm_type=norm_type)))
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"loss {loss.item():.6f} total grad norm {total_norm.item():.4f} -> {os.path.getsize(path) / 1024:.0f} KiB")
@@ -73,6 +75,12 @@ if __name__ == "__main__":
         # the same two steps under torch.autocast("cpu", dtype=torch.bfloat16)
         main(name="fsn_train_b4_bf16", autocast=torch.bfloat16)
         main(batch=16, length=49152, groups=2, name="fsn_train_c3_bf16", sample=397, autocast=torch.bfloat16)
+    elif "--cumulative" in sys.argv:
+        # the other shipped training configuration (fullsubnet/train_cumulativeLaplaceNorm.toml:82): the same two steps with
+        # norm_type = "cumulative_laplace_norm" (audio_zen/model/base_model.py:221-251; on the 4-D sub-band tensor every
+        # unit is its own "sample") - the short batch and BASELINE config 3's per-rank shape
+        main(name="fsn_train_cum_b4", norm_type="cumulative_laplace_norm")
+        main(batch=16, length=49152, groups=2, name="fsn_train_cum_c3", sample=397, norm_type="cumulative_laplace_norm")
     elif "--config3x2" in sys.argv:
         # two ranks of BASELINE config 3 as ONE batch: 32 utterances x 3.072 s (what 2 x 16 under DistributedDataParallel
         # must reproduce: drop_band keeps the sample parity of the global batch when ranks take contiguous halves)

@@ -201,6 +201,37 @@ def test_full_band_crm_mask_end_to_end(fsn, golden_dir, name):
     assert np.abs(one - z["enhanced"][0]).max() <= 2e-3 * scale
 
 
+def test_inferencer_call_writes_the_reference_int16_files(fsn, golden_dir, tmp_path):
+    """BaseInferencer.__call__ (audio_zen/inferencer/base_inferencer.py:163-195): every utterance of the loader through
+    `full_band_crm_mask`, the enhanced waveform peak-normalised to 0.8 of int16 full scale and written as 16-bit PCM
+    (:181-182), the noisy input beside it trimmed to the same length.  The file's samples are the reference's formula
+    applied to the reference's own enhanced waveform (golden `fsn_offline_b2`) to within the one count per 2e-3 of
+    peak the waveform bound allows; they are EXACTLY the formula applied to this path's waveform."""
+    from scipy.io import wavfile
+    z, meta = load(golden_dir, "fsn_offline_b2")
+    model, _ = build_model(fsn, meta)
+    noisy = O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_x"])
+    loader = [(torch.from_numpy(noisy[i:i + 1]), [f"utt{i}"]) for i in range(meta["batch"])]
+    cfg = dict(inferencer=dict(type="full_band_crm_mask", args={}),
+               acoustics=dict(n_fft=512, hop_length=256, win_length=512, sr=16000))
+    inf = fsn.Inferencer(cfg, model=model, dataloader=loader, output_dir=str(tmp_path))
+    inf()
+    amp = np.iinfo(np.int16).max
+    for i in range(meta["batch"]):
+        sr, pcm = wavfile.read(str(inf.enhanced_dir / f"utt{i}.wav"))
+        assert sr == 16000 and pcm.dtype == np.int16 and pcm.shape == (meta["length"],)
+        own = inf.full_band_crm_mask(dev(noisy[i:i + 1]), {})
+        assert np.array_equal(pcm, np.int16(0.8 * amp * own / np.max(np.abs(own))))
+        ref = z["enhanced"][i]
+        want = np.int16(0.8 * amp * ref / np.max(np.abs(ref)))
+        assert np.abs(pcm.astype(np.int32) - want.astype(np.int32)).max() <= 1 + int(2 * 2e-3 * 0.8 * amp)
+        assert abs(int(np.abs(pcm).max()) - int(0.8 * amp)) <= 1
+        sr_n, noisy_file = wavfile.read(str(inf.noisy_dir / f"utt{i}.wav"))
+        assert sr_n == 16000 and np.array_equal(noisy_file, noisy[i])
+    with pytest.raises(AssertionError):  # base_inferencer.py:173: one utterance per loader item
+        fsn.Inferencer(cfg, model=model, dataloader=[(torch.from_numpy(noisy), ["a", "b"])], output_dir=str(tmp_path))()
+
+
 def test_batch_independence_and_determinism(fsn):
     """Every utterance of a batch gets the full mask, independent of its neighbours; two runs are
     bit-identical (no atomics on the path)."""

@@ -184,3 +184,30 @@ def test_graphed_call_replays_the_eager_result(setup, which):
     assert torch.equal(graphed(noisy), fn(noisy))
     with pytest.raises(RuntimeError):
         graphed(torch.zeros(1, length))
+
+
+def test_graphed_call_recaptures_when_the_weights_change(setup):
+    """The graphs hold raw pointers into the re-tiled weight caches of the eager warm-up; a parameter written in place
+    (an optimizer step between two validations) or replaced (load_state_dict) makes the eager code build NEW caches.
+    GraphedCall keys its graphs on a fingerprint of the owning module's parameters: the next call captures again and
+    returns the eager result of the NEW weights (not a replay over stale or freed memory)."""
+    fsn, model, _ = setup
+    graphed = fsn.GraphedCall(model.enhance)
+    assert graphed.modules == [model]
+    noisy = torch.from_numpy(O.make_noisy(1, 4096, seed=51)).cuda()
+    first = graphed(noisy).clone()
+    assert torch.equal(first, model.enhance(noisy))
+    saved = {k: v.clone() for k, v in model.state_dict().items()}
+    try:
+        with torch.no_grad():
+            model.sb_model.fc_output_layer.weight.mul_(1.25)  # in place: same storage, new version
+        second = graphed(noisy).clone()
+        assert torch.equal(second, model.enhance(noisy)) and not torch.equal(second, first)
+        model.load_state_dict(saved, strict=True)  # copies in place as well
+        third = graphed(noisy).clone()
+        assert torch.equal(third, first)
+        assert len(graphed._graphs) == 1
+        graphed.invalidate()
+        assert torch.equal(graphed(noisy), first)
+    finally:
+        model.load_state_dict(saved, strict=True)

@@ -87,23 +87,29 @@ def test_two_layer_lstm_on_the_persistent_kernels(fsn, T, N, I, H):
 # from the margins measured on MI355X (printed by the test), about 3x above them
 # measured r03 (b4 / c3): total norm 2.1e-6 / 3.2e-6, worst tensor norm 1.0e-4 / 6.8e-5, worst sampled element
 # 1.4e-4 / 6.4e-5 (fp32 rounding through ~50 / ~195 recurrent steps each way; r02's bounds were 2e-3 throughout)
-TRAIN_TOL = {"fsn_train_b4": (1e-5, 3e-4, 4e-4), "fsn_train_c3": (1e-5, 2e-4, 2e-4)}
+# fsn_train_cum_*: the same two steps with norm_type = cumulative_laplace_norm (the other shipped training TOML)
+TRAIN_TOL = {"fsn_train_b4": (1e-5, 3e-4, 4e-4), "fsn_train_c3": (1e-5, 2e-4, 2e-4),
+             "fsn_train_cum_b4": (1e-5, 3e-4, 4e-4), "fsn_train_cum_c3": (1e-5, 2e-4, 2e-4)}
 
 
-@pytest.mark.parametrize("name", ["fsn_train_b4", "fsn_train_c3"])
+@pytest.mark.parametrize("name", ["fsn_train_b4", "fsn_train_c3", "fsn_train_cum_b4", "fsn_train_cum_c3"])
 def test_train_step_vs_reference_and_oracle(fsn, golden_dir, name):
     """One step of fullsubnet/trainer.py:41-71 (use_amp = false) against the reference's own loss, clipped gradients
     and Adam-updated parameters: a short batch (4 x 2560 samples) and BASELINE config 3's per-rank shape
-    (fullsubnet/train.toml: 16 utterances x 49 152 samples = 193 frames, drop_band groups 2)."""
+    (fullsubnet/train.toml: 16 utterances x 49 152 samples = 193 frames, drop_band groups 2), with the offline Laplace norm
+    (train.toml:82) and with the cumulative one (train_cumulativeLaplaceNorm.toml:82) - both on the fused training graph
+    (no tensor-algebra kernel of the host framework in the step)."""
     from fullsubnet_amd.train import train_step
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     meta = ast.literal_eval(str(z["meta"]))
     params = O.make_params(seed=meta["seed_w"])
     noisy = O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_noisy"])
     clean = (meta["clean_gain"] * O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_clean"])).astype(np.float32)
-    model = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=meta["groups"], **MODEL_KW)
+    model = fsn.Model(norm_type=meta.get("norm_type", "offline_laplace_norm"), num_groups_in_drop_band=meta["groups"], **MODEL_KW)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
     model = model.cuda().train()
+    from fullsubnet_amd.train import fused_train_supported
+    assert fused_train_supported(model, torch.empty((2, 1, 257, 4), device="cuda"))
     # clip_grad_norm_ + torch.optim.Adam of the reference -> the fused HIP optimizer
     opt = fsn.ClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
     loss = train_step(model, opt, torch.from_numpy(noisy).cuda(), torch.from_numpy(clean).cuda())
@@ -142,30 +148,49 @@ def test_train_step_vs_reference_and_oracle(fsn, golden_dir, name):
     # at config 3's size Adam's first fixed-size step overshoots, in the reference too, so only "changed" is asserted)
     loss2 = train_step(model, opt, torch.from_numpy(noisy).cuda(), torch.from_numpy(clean).cuda())
     assert loss2.item() != loss.item() and np.isfinite(loss2.item())
-    if name == "fsn_train_b4":
+    if name.endswith("_b4"):
         assert loss2.item() < loss.item()
 
 
-@pytest.mark.parametrize("B,groups,T,arith", [(3, 2, 7, "f32"), (5, 3, 6, "f32"), (1, 2, 9, "f32"), (4, 1, 5, "f32")])
-def test_fused_training_graph_vs_the_tensor_algebra_graph(fsn, B, groups, T, arith):
+@pytest.mark.parametrize("norm", ["offline_laplace_norm", "cumulative_laplace_norm"])
+@pytest.mark.parametrize("B,groups,T,nb", [(3, 2, 7, 15), (5, 3, 6, 15), (1, 2, 9, 15), (4, 1, 5, 15), (3, 2, 6, 7), (5, 2, 5, 0)])
+def test_fused_training_graph_vs_the_tensor_algebra_graph(fsn, monkeypatch, B, groups, T, nb, norm):
     """FullSubNetTrainFunction (csrc/train_glue_kernels.hip: look-ahead pad + norm, sub-band input forward / backward, mask
     reshape and its gradient as kernels, one autograd node for the model) against the same graph with the glue as
-    autograd-tracked tensor algebra (model.fused_training_graph = False; itself held to the reference's goldens): odd batch
-    sizes (uneven drop_band groups), three groups, a single utterance (no band dropping), groups = 1; the band-dropped cIRM
-    target kernel against drop_band(build_complex_ideal_ratio_mask)."""
-    from fullsubnet_amd.train import forward_train, mse_loss
-    params = O.make_params(seed=B * 10 + groups, gain=1.5)
+    autograd-tracked tensor algebra (model.fused_training_graph = False; itself held to the reference's goldens), for both
+    Laplace norms: odd batch sizes (uneven drop_band groups), three groups, a single utterance (no band dropping), groups =
+    1, fewer neighbours than the 15 that fill the LSTM entries' 32 input columns (the padding columns of the input
+    gradient are never written: the fused graph runs with NaN-poisoned buffers here); the band-dropped cIRM target kernel
+    against drop_band(build_complex_ideal_ratio_mask)."""
+    from fullsubnet_amd.train import forward_train, fused_train_supported, mse_loss
+    params = O.make_params(seed=B * 10 + groups, gain=1.5, sb_num_neighbors=nb)
     rng = np.random.default_rng(T)
     mag = torch.from_numpy((np.abs(rng.standard_normal((B, 1, 257, T))) + 0.05).astype(np.float32)).cuda()
     results = []
+    real_empty, real_like = torch.empty, torch.empty_like
+
+    def poison(t):
+        if t.is_cuda and t.dtype == torch.float32:
+            t.fill_(float("nan"))
+        return t
+
     for fused in (True, False):
-        model = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=groups, **MODEL_KW)
+        model = fsn.Model(norm_type=norm, num_groups_in_drop_band=groups, **dict(MODEL_KW, sb_num_neighbors=nb))
         model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
         model = model.cuda().train()
         model.fused_training_graph = fused
-        out = forward_train(model, mag)
-        w = torch.from_numpy(rng.standard_normal(tuple(out.shape)).astype(np.float32)).cuda() if not results else results[0][2]
-        (out * w).sum().backward()
+        assert fused_train_supported(model, mag) == fused
+        w = torch.from_numpy(rng.standard_normal((B, 2, 257 // groups if B > 1 else 257, T)).astype(np.float32)).cuda() \
+            if not results else results[0][2]
+        if fused:
+            monkeypatch.setattr(torch, "empty", lambda *a, **k: poison(real_empty(*a, **k)))
+            monkeypatch.setattr(torch, "empty_like", lambda *a, **k: poison(real_like(*a, **k)))
+        try:
+            out = forward_train(model, mag)
+            (out * w).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            monkeypatch.undo()
         results.append((out.detach(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}, w))
     (y1, g1, _), (y0, g0, _) = results
     assert y1.shape == y0.shape
@@ -183,10 +208,26 @@ def test_fused_training_graph_vs_the_tensor_algebra_graph(fsn, B, groups, T, ari
     want = fsn.build_complex_ideal_ratio_mask(*spec)                      # [B, F, T, 2]
     want = fsn.drop_band(want.permute(0, 3, 1, 2), groups)                # [B, 2, Fs, T]
     got = torch.empty_like(y1)
-    dims = _lib.TrainDims(B, 257, T, 2, 15, groups)
+    dims = _lib.TrainDims(B, 257, T, 2, nb, groups, _lib.NORM_TYPES[norm])
     _lib.check(_lib.lib().fsn_train_cirm_target(ctypes.byref(dims), *[_lib.dev_ptr(t) for t in spec], _lib.dev_ptr(got),
                                                 _lib.stream_ptr(got.device)))
     assert got.shape == want.shape and torch.equal(got, want.contiguous())
+
+
+@pytest.mark.parametrize("norm", ["offline_laplace_norm", "cumulative_laplace_norm"])
+def test_training_forward_refuses_the_batches_drop_band_refuses(fsn, norm):
+    """drop_band asserts batch_size > num_groups (feature.py:317-319) and the model calls it for every batch of more than
+    one utterance (model.py:114): the reference's training forward fails for 1 < B <= groups, and so does every entry here
+    (the fused graph checks for itself; the composed graph goes through drop_band)."""
+    model = fsn.Model(norm_type=norm, num_groups_in_drop_band=2, **MODEL_KW).cuda().train()
+    mag = torch.rand(2, 1, 257, 5, device="cuda") + 0.1
+    for fused in (True, False):
+        model.fused_training_graph = fused
+        with pytest.raises(AssertionError, match="should larger than the num_groups"):
+            model(mag)
+    model.fused_training_graph = True
+    assert model(mag[:1]).shape == (1, 2, 257, 5)      # one utterance: no band dropping
+    assert model(torch.cat([mag, mag[:1]])).shape == (3, 2, 128, 5)
 
 
 @pytest.mark.parametrize("arith", ["f32", "f16"])

@@ -4,14 +4,15 @@ import ast
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import fullsubnet_oracle as O
 from oracle import train_oracle as TO
 
 
-def load(golden_dir):
-    z = np.load(os.path.join(golden_dir, "fsn_train_b4.npz"))
+def load(golden_dir, name="fsn_train_b4"):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
     return z, ast.literal_eval(str(z["meta"]))
 
 
@@ -31,12 +32,14 @@ def test_restated_lstm_cell_matches_aten():
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
 
 
-def test_train_step_oracle_vs_reference(golden_dir):
-    z, meta = load(golden_dir)
+@pytest.mark.parametrize("name", ["fsn_train_b4", "fsn_train_cum_b4"])
+def test_train_step_oracle_vs_reference(golden_dir, name):
+    """offline_laplace_norm (fullsubnet/train.toml:82) and cumulative_laplace_norm (train_cumulativeLaplaceNorm.toml:82)."""
+    z, meta = load(golden_dir, name)
     params = O.make_params(seed=meta["seed_w"])
     noisy = O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_noisy"])
     clean = (meta["clean_gain"] * O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_clean"])).astype(np.float32)
-    r = TO.train_step(params, noisy, clean, groups=meta["groups"])
+    r = TO.train_step(params, noisy, clean, groups=meta["groups"], norm_type=meta.get("norm_type", "offline_laplace_norm"))
     assert abs(r["loss"] - float(z["loss"])) <= 1e-5 * float(z["loss"])
     s = meta["sample"]
     for k in params:
