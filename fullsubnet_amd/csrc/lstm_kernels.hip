@@ -229,6 +229,40 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) void lstm_rec_kernel(const fl
     }
 }
 
+// Gate non-linearities on PAIRS of values (round 5): fp32 MFMAs and vector instructions do not overlap on a SIMD
+// (tools/probe_overlap.hip: the times add whoever issues them), so every vector instruction of the persistent kernels is
+// paid in full; v_pk_mul / v_pk_add / v_pk_fma_f32 do two lanes' worth of the multiplies and adds around the
+// transcendentals per issue.  Same IEEE operations as sigmoid_fast / tanh_fast (1 - 2 r == fma(-2, r, 1) exactly).
+__device__ __forceinline__ f32x2 sigmoid_fast2(f32x2 x) {
+    const f32x2 t = x * f32x2{-1.4426950408889634f, -1.4426950408889634f};
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
+    return f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+__device__ __forceinline__ f32x2 tanh_fast2(f32x2 x) {
+    const f32x2 t = x * f32x2{2.8853900817779268f, 2.8853900817779268f};
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
+    const f32x2 r = f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return __builtin_elementwise_fma(r, f32x2{-2.0f, -2.0f}, f32x2{1.0f, 1.0f});
+}
+// ... with the gate's bias added here instead of seeding the accumulators with it (kb = scale * bias): one fma
+__device__ __forceinline__ f32x2 sigmoid_fast2b(f32x2 x, float kb) {
+    const f32x2 t = __builtin_elementwise_fma(x, f32x2{-1.4426950408889634f, -1.4426950408889634f}, f32x2{kb, kb});
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
+    return f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+__device__ __forceinline__ f32x2 tanh_fast2b(f32x2 x, float kb) {
+    const f32x2 t = __builtin_elementwise_fma(x, f32x2{2.8853900817779268f, 2.8853900817779268f}, f32x2{kb, kb});
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
+    const f32x2 r = f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return __builtin_elementwise_fma(r, f32x2{-2.0f, -2.0f}, f32x2{1.0f, 1.0f});
+}
+__device__ __forceinline__ f32x2 lo2(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f32x2 hi2(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
+__device__ __forceinline__ f32x4 cat2(f32x2 a, f32x2 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3); }
+// cell state / staged values of a wave: scalars (the round-2 form) or whole accumulator-shaped vectors (the packed form)
+template <bool PK> struct RecState { typedef float type[4]; };
+template <> struct RecState<true> { typedef f32x4 type; };
+
 // ---------------------------------------------------------------------------------------------
 // Last sub-band layer with its INPUT PROJECTION INSIDE: gates = b + x_t W_ih^T + h_{t-1} W_hh^T with x_t = h_t of the
 // layer below, read from that layer's hidden sequence (4.8 GB at config 2).  The separate K = 384 projection GEMM and
@@ -299,7 +333,7 @@ struct SbStage {
 //   - the two barriers of a step only order LDS traffic;
 //   - the bias of the next pass is requested a pass ahead.
 // W_hh must follow W_ih in one packed buffer (element offset whh_off).  hseq [Tp][Npad][H] receives h_t.
-template <int H, int RT, int UG>
+template <int H, int RT, int UG, int OPT = 0>
 __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgpr(76))) void lstm_rec_in_kernel(
     const FsnSbInput xin, const float* __restrict__ w_p, unsigned whh_off, float* __restrict__ hseq, int Tp, int Npad) {
     constexpr int NW = H / (16 * UG);
@@ -318,7 +352,10 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
     const int sb_b0 = (int)((n0 + xin.row0) / xin.F);  // (b, f) of the workgroup's first row, once
     const int sb_f0 = (int)((n0 + xin.row0) - (long)sb_b0 * xin.F);
 
-    float cst[RT][UG][4], tmp[RT][UG][4];
+    constexpr bool PK = (OPT & 256) != 0;    // gate non-linearities on pairs (v_pk_*_f32), see sigmoid_fast2
+    constexpr bool BEP = PK && (OPT & 512);  // accumulators start from zero, the bias enters in the non-linearity
+    constexpr bool KOPT = (OPT & 4096) != 0 && RT == 4 && KC % 6 == 0;  // see lstm_rec_x_kernel
+    typename RecState<PK>::type cst[RT][UG], tmp[RT][UG];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -361,6 +398,19 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
         }
     };
 
+    auto mma0 = [&](f32x4 (&acc)[RT][UG], const float* a, int a_rt_stride, const f32x4 (&b)[UG]) {  // C = 0: first block of a pass
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(a + rt * a_rt_stride);
+#pragma unroll
+            for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[0], b[u][0], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int jj = 1; jj < 4; ++jj)
+#pragma unroll
+                for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[jj], b[u][jj], acc[rt][u]);
+        }
+    };
+
     for (int t = 0; t < Tp; ++t) {
         // frame t + 1: requested now, written to the other x buffer after the first gate pass (that buffer was last
         // read in step t - 1 and is first read after the two barriers that end this step)
@@ -378,28 +428,71 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
             asm volatile("" : "+s"(gn));
             f32x4 acc[RT][UG];
             unsigned wx[UG], wh[UG], wxn[UG];
+            float kb[UG];
 #pragma unroll
             for (int u = 0; u < UG; ++u) {
                 wx[u] = wxofs(g, u);
                 wh[u] = whofs(g, u);
                 wxn[u] = wxofs(gn, u);
                 const float b = bias_n[u];
+                if (BEP) {
+                    kb[u] = b * (pass == 2 ? 2.8853900817779268f : -1.4426950408889634f);
+                } else {
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][u] = f32x4{b, b, b, b};
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][u] = f32x4{b, b, b, b};
+                }
                 bias_n[u] = xin.bias[(gn * KC + wave * UG + u) * 16 + lr];  // a pass ahead
             }
             // ---- x_t W_ih^T: two chunks -----------------------------------------------------------
 #pragma unroll
             for (int u = 0; u < UG; ++u) b1[u] = wload(wx[u] + 256u);
             __builtin_amdgcn_sched_barrier(0);
-            mma(acc, xa, 16 * XS, b0);
+            if (BEP) mma0(acc, xa, 16 * XS, b0);
+            else mma(acc, xa, 16 * XS, b0);
 #pragma unroll
             for (int u = 0; u < UG; ++u) b0[u] = wload(t > 0 ? wh[u] : wxn[u]);
             __builtin_amdgcn_sched_barrier(0);
             mma(acc, xa + 16, 16 * XS, b1);
             __builtin_amdgcn_sched_barrier(0);
             // ---- h_{t-1} W_hh^T (h_{-1} = 0) -------------------------------------------------------
-            if (t > 0) {
+            if (KOPT && t > 0) {
+                typedef const __attribute__((address_space(3))) float* lds_cptr;
+                unsigned hb01 = (unsigned)(size_t)(lds_cptr)(hl + lr * HS + 4 * lq), hb23 = hb01 + 32u * HS * 4u;
+                asm volatile("" : "+v"(hb01));
+                asm volatile("" : "+v"(hb23));
+                lds_cptr ha01 = (lds_cptr)(size_t)hb01;
+                lds_cptr ha23 = (lds_cptr)(size_t)hb23;
+                auto mmah = [&](int kofs, const f32x4 (&b)[UG]) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const f32x4 av = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((rt < 2 ? ha01 : ha23) + (rt & 1) * 16 * HS + kofs);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                            for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[jj], b[u][jj], acc[rt][u]);
+                    }
+                };
+#pragma unroll 1
+                for (int hs = 0; hs < KC / 6; ++hs) {
+#pragma unroll
+                    for (int kk = 0; kk < 6; kk += 2) {
+                        const int kc = hs * 6 + kk;
+#pragma unroll
+                        for (int u = 0; u < UG; ++u) b1[u] = wload(wh[u] + (unsigned)(kc + 1) * 256u);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mmah(kk * 16, b0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const bool more_h = kc + 2 < KC;
+#pragma unroll
+                        for (int u = 0; u < UG; ++u) b0[u] = wload(more_h ? wh[u] + (unsigned)(kc + 2) * 256u : wxn[u]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mmah((kk + 1) * 16, b1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    ha01 += 6 * 16;
+                    ha23 += 6 * 16;
+                }
+            } else if (t > 0) {
 #pragma unroll 1
                 for (int kc = 0; kc < KC; kc += 2) {
 #pragma unroll
@@ -421,7 +514,27 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
         VAR[rt][u][i] = EXPR;                                                                         \
         asm volatile("" : "+v"(VAR[rt][u][i]));                                                       \
     }
-            if (pass == 0) {
+#define FSN_REC_EPILOGUE2(VAR, EXPR)                                                                  \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                 \
+    _Pragma("unroll") for (int u = 0; u < UG; ++u) {                                                  \
+        const f32x4 A = acc[rt][u], C = cst[rt][u], M = tmp[rt][u];                                   \
+        (void)A, (void)C, (void)M;                                                                    \
+        auto half = [&](f32x2 a, f32x2 c, f32x2 m) { (void)a, (void)c, (void)m; return EXPR; };       \
+        VAR[rt][u] = cat2(half(lo2(A), lo2(C), lo2(M)), half(hi2(A), hi2(C), hi2(M)));                \
+        asm volatile("" : "+v"(VAR[rt][u]));                                                          \
+    }
+            if constexpr (PK) {
+                if (pass == 0) {
+                    if constexpr (BEP) { FSN_REC_EPILOGUE2(cst, sigmoid_fast2b(a, kb[u]) * c) } else { FSN_REC_EPILOGUE2(cst, sigmoid_fast2(a) * c) }
+                    if (more) stage.commit(xin, xl + ((t + 1) & 1) * ROWS * XS, XS, n0);
+                } else if (pass == 1) {
+                    if constexpr (BEP) { FSN_REC_EPILOGUE2(tmp, sigmoid_fast2b(a, kb[u])) } else { FSN_REC_EPILOGUE2(tmp, sigmoid_fast2(a)) }
+                } else if (pass == 2) {
+                    if constexpr (BEP) { FSN_REC_EPILOGUE2(cst, c + m * tanh_fast2b(a, kb[u])) } else { FSN_REC_EPILOGUE2(cst, c + m * tanh_fast2(a)) }
+                } else {
+                    if constexpr (BEP) { FSN_REC_EPILOGUE2(tmp, sigmoid_fast2b(a, kb[u]) * tanh_fast2(c)) } else { FSN_REC_EPILOGUE2(tmp, sigmoid_fast2(a) * tanh_fast2(c)) }
+                }
+            } else if (pass == 0) {
                 FSN_REC_EPILOGUE(cst, sigmoid_fast(acc[rt][u][i]) * cst[rt][u][i])
                 if (more) stage.commit(xin, xl + ((t + 1) & 1) * ROWS * XS, XS, n0);  // tmp's registers are free here
             } else if (pass == 1) {
@@ -432,6 +545,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 FSN_REC_EPILOGUE(tmp, sigmoid_fast(acc[rt][u][i]) * tanh_fast(cst[rt][u][i]))
             }
 #undef FSN_REC_EPILOGUE
+#undef FSN_REC_EPILOGUE2
             __builtin_amdgcn_sched_barrier(0);
         }
         // every wave has finished reading h_{t-1}
@@ -456,7 +570,10 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
         float* dst = hseq + ((long)t * Npad + n0) * H;
         for (int i = threadIdx.x; i < ROWS * (H / 4); i += NW * 64) {
             const int row = i / (H / 4), c4 = i % (H / 4);
-            *reinterpret_cast<f32x4*>(dst + (long)row * H + c4 * 4) = *reinterpret_cast<const f32x4*>(hl + row * HS + c4 * 4);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(hl + row * HS + c4 * 4);
+            // (OPT & 1024: streamed past the L2 - 4.8 GB nobody on this XCD reads back - so that the weights stay in it)
+            if (OPT & 1024) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst + (long)row * H + c4 * 4));
+            else *reinterpret_cast<f32x4*>(dst + (long)row * H + c4 * 4) = v;
         }
     }
 }
@@ -465,25 +582,49 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
 // lds_base + 16 l.  Written as asm so that the compiler neither serialises later LDS reads behind it (it cannot tell
 // the ring stages apart and would wait for vmcnt(0) before every ds_read) nor counts it in its own vmcnt bookkeeping
 // (an extra, OLDER request in the queue can only make its counted waits longer, never too short).
+// POLICY: 0 default, 1 non-temporal (nt: the line is marked for early eviction - x slices are read by one CU only and must
+// not push the weights, which every CU of the XCD streams every step, out of the 4 MB L2), 2 sc1 sc0, 3 nt sc1 sc0.
+template <int POLICY = 0>
 __device__ __forceinline__ void lds_dma_fragment(const float* g, unsigned lds_base) {
     unsigned saved;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, off\n\t"
-        "s_nop 0\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(saved)
-        : "s"(lds_base), "v"(g)
-        : "memory");
+    if constexpr (POLICY == 1) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\ts_nop 0\n\ts_mov_b32 m0, %0"
+                     : "=&s"(saved) : "s"(lds_base), "v"(g) : "memory");
+    } else if constexpr (POLICY == 2) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off sc0 sc1\n\ts_nop 0\n\ts_mov_b32 m0, %0"
+                     : "=&s"(saved) : "s"(lds_base), "v"(g) : "memory");
+    } else if constexpr (POLICY == 3) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off sc0 sc1 nt\n\ts_nop 0\n\ts_mov_b32 m0, %0"
+                     : "=&s"(saved) : "s"(lds_base), "v"(g) : "memory");
+    } else {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %1\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %2, off\n\t"
+            "s_nop 0\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(saved)
+            : "s"(lds_base), "v"(g)
+            : "memory");
+    }
 }
 
 // ABL (experiment knob of tools/probe_rec_x.hip, 0 in the library; results are WRONG with any bit set): leaves out one
 // ingredient at a time to price it - 1 slice barriers, 2 gate non-linearities, 4 output layer, 8 ring fills,
-// 16 the two barriers that end a step.  Measured (tools/probe_rec_x.hip, 52.7 ms shipped): 0.5 / 1.3 / 0.45 / 1.5 /
+// 16 the two barriers that end a step.  Bits 32 / 64 are scheduling experiments with correct results (round 5).  Measured (tools/probe_rec_x.hip, 52.7 ms shipped): 0.5 / 1.3 / 0.45 / 1.5 /
 // 0.4 ms, 49.3 ms without all five, 47.1 ms = the MFMAs alone at the 2.38 GHz the kernel runs at.  (Touching the next
 // step's tile ahead of its fills, so that they hit L2, changes nothing: tried.)
+// The forms the library ships (round 5, tools/probe_rec_x.hip / probe_rec_in.hip on three MI355X boxes, bit-identical
+// results): layer 1 = 64 (pass-opening barrier inside the recurrent product) + 256 (packed gate non-linearities): 52.5 ->
+// 51.8 ms; layer 0 = 4096 (K loop without per-chunk vector instructions) + 256: 28.65 -> 27.85 ms.  4096 does not pay in
+// layer 1 (51.9 - 52.0), 128 / 512 / 1024.. neither (profiles/r05_rec_probes.md).
+#ifndef FSN_REC_X_OPT
+#define FSN_REC_X_OPT (64 | 256)
+#endif
+#ifndef FSN_REC_IN_OPT
+#define FSN_REC_IN_OPT (4096 | 256)
+#endif
 #ifndef FSN_REC_VCAP
 #define FSN_REC_VCAP 76  // x 2 on gfx950's unified register file = 152: three waves per SIMD + room for a step workgroup
 #endif
@@ -516,12 +657,28 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const long n0 = (long)blockIdx.x * ROWS;
+    if (ABL & 32) {  // experiment: static priorities among the three waves of a SIMD (waves w, w + 4, w + 8 share one)
+        if ((wave >> 2) == 0) __builtin_amdgcn_s_setprio(0);
+        else if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(2);
+    }
     if (!HSEQ)
         for (int i = threadIdx.x; i < 2 * H; i += NW * 64) {  // rows 0 / 1 of the packed output weights, un-tiled
             const int c = i / H, k = i % H;
             wl[i] = fc.w_p[(((k >> 4) * 64) + ((k & 15) >> 2) * 16 + c) * 4 + (k & 3)];
         }
-    float cst[RT][UG][4], tmp[RT][UG][4];
+    constexpr bool ROT = (ABL & 128) && NW == 12;  // ring fills by ONE wave of every SIMD per slice, in rotation
+    constexpr int FPOL = (ABL >> 10) & 3;          // cache policy of the ring fills (lds_dma_fragment)
+    // KOPT: the recurrent product's K loop without per-chunk vector instructions.  Vector instructions and fp32 MFMAs share
+    // the SIMD (tools/probe_overlap.hip), and the rolled loop spent 11 of them per 64 MFMAs: the hidden state sits beyond
+    // the 64 KB an LDS read's immediate offset reaches, so every row tile's address was re-derived per chunk (6 v_add), and
+    // the refilled weight fragments landed in fresh registers that were then copied (4 v_mov_b64 behind a vmcnt(0)).  Now:
+    // two base registers (row tiles 0-1 / 2-3) advanced once per 6 chunks, immediates inside, and the refill of a
+    // fragment pinned behind the last MFMA that reads it, so that it returns into the same registers.
+    constexpr bool KOPT = (ABL & 4096) != 0 && RT == 4;
+    constexpr bool PK = (ABL & 256) != 0;          // gate non-linearities on pairs (v_pk_*_f32)
+    constexpr bool BEP = PK && (ABL & 512);        // accumulators start from zero, the bias enters in the non-linearity
+    typename RecState<PK>::type cst[RT][UG], tmp[RT][UG];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -533,15 +690,28 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
     // ring stage `buf` <- slice `sl` of x_t: this wave's share of the NF fragments
     const unsigned xlane = (unsigned)(lr * H + 4 * lq);  // lane part of the source address; the rest is uniform
     const unsigned xs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)xs;  // LDS byte address
-    auto fill = [&](int buf, int t, int sl) {
+    // (ROT: loads return in order per wave, so the weight fragment requested behind a fill waits for the fill's HBM round
+    // trip; with every wave filling, all three waves of a SIMD stall together and the matrix pipe idles - with one wave
+    // group (waves g, g + 4, g + 8 share SIMD g... the groups are wave >> 2) filling per slice, its two siblings keep
+    // the pipe busy meanwhile.  who < 0: every wave, the prologue.)
+    auto fill = [&](int buf, int t, int sl, int who) {
         const float* src = xseq + ((long)t * Npad + n0) * H + sl * (SK * 16);  // wave-uniform
+        if (ROT && who >= 0) {
+            if ((wave >> 2) != who) return;
+            for (int f = wave & 3; f < NF; f += 4) {
+                const int rt = f / SK, kcl = f - rt * SK;
+                lds_dma_fragment<FPOL>(src + (rt * 16 * H + kcl * 16) + xlane,
+                                 __builtin_amdgcn_readfirstlane(xs_lds + (unsigned)((buf * NF + f) * 1024)));
+            }
+            return;
+        }
         for (int f = wave; f < NF; f += NW) {
             const int rt = f / SK, kcl = f - rt * SK;
-            lds_dma_fragment(src + (rt * 16 * H + kcl * 16) + xlane,
+            lds_dma_fragment<FPOL>(src + (rt * 16 * H + kcl * 16) + xlane,
                              __builtin_amdgcn_readfirstlane(xs_lds + (unsigned)((buf * NF + f) * 1024)));
         }
     };
-    fill(0, 0, 0);
+    fill(0, 0, 0, -1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -582,6 +752,20 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
         }
     };
 
+    // the first K block of a pass when the accumulators start from zero (BEP): C = 0 is an inline operand of the first MFMA
+    auto mma0 = [&](f32x4 (&acc)[RT][UG], const float* a, int a_rt_stride, const f32x4 (&b)[UG]) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(a + rt * a_rt_stride);
+#pragma unroll
+            for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[0], b[u][0], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int jj = 1; jj < 4; ++jj)
+#pragma unroll
+                for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[jj], b[u][jj], acc[rt][u]);
+        }
+    };
+
     for (int t = 0; t < Tp; ++t) {
         // gate order of evaluation: f (1), i (0), g (2), o (3)
 #pragma unroll
@@ -593,21 +777,29 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
             asm volatile("" : "+s"(gn));
             f32x4 acc[RT][UG];
             unsigned wx[UG], wh[UG], wxn[UG];  // uniform offsets: W_ih / W_hh of this gate, W_ih of the next one
+            float kb[UG];                      // BEP: this gate's bias times the scale of its exponent
 #pragma unroll
             for (int u = 0; u < UG; ++u) {
                 wx[u] = wofs(g, u);
                 wh[u] = wx[u] + whh_off;
                 wxn[u] = wofs(gn, u);
                 const float b = bias_n[u];
+                if (BEP) {
+                    kb[u] = b * (pass == 2 ? 2.8853900817779268f : -1.4426950408889634f);
+                } else {
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][u] = f32x4{b, b, b, b};
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][u] = f32x4{b, b, b, b};
+                }
                 bias_n[u] = bias[(gn * KC + wave * UG + u) * 16 + lr];
             }
             // ---- x_t W_ih^T, slice by slice ------------------------------------------------------
 #pragma unroll 1
             for (int sl = 0; sl < NSL; ++sl) {
                 const int j = pass * NSL + sl;  // slice counter of the step: ring stage j & 1
-                if (j > 0 && !(ABL & 1)) {
+                // (ABL & 64, experiment: the barrier that opens a pass' first slice is taken in the middle of the previous
+                // pass' recurrent product instead - its fills were issued before that product began - so that no barrier
+                // follows the gate non-linearities)
+                if (j > 0 && !(ABL & 1) && !((ABL & 64) && sl == 0 && t > 0)) {
                     // this wave's fills of stage j & 1 were issued a slice ago, before UG SK weight fragments it has
                     // consumed since; at most the UG prefetched ones are still in flight
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UG) : "memory");
@@ -620,7 +812,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 {
                     const int nsl = sl + 1 < NSL ? sl + 1 : 0;
                     const int nt = (sl + 1 < NSL || pass < 3) ? t : t + 1;
-                    if (nt < Tp && !(ABL & 8)) fill((j + 1) & 1, nt, nsl);
+                    if (nt < Tp && !(ABL & 8)) fill((j + 1) & 1, nt, nsl, (int)((unsigned)j % 3u));
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const float* xa = xs + ((j & 1) * NF) * 256 + lane * 4;
@@ -631,7 +823,9 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                     for (int u = 0; u < UG; ++u)
                         b1[u] = wload(wx[u] + (unsigned)(kc + 1) * 256u);
                     __builtin_amdgcn_sched_barrier(0);  // requests first, pinned: hipcc otherwise sinks them to their use
-                    mma(acc, xa + kk * 256, SK * 256, b0);
+                    if (BEP && kk == 0 && sl == 0) mma0(acc, xa + kk * 256, SK * 256, b0);
+                    else mma(acc, xa + kk * 256, SK * 256, b0);
+                    if (KOPT && !(ABL & 8192)) __builtin_amdgcn_sched_barrier(0);
                     // chunk kc + 2: W_ih, or the first chunk of W_hh, or (h_{-1} = 0: no W_hh product) of the next pass
                     const bool more_x = kc + 2 < KC;
 #pragma unroll
@@ -644,10 +838,61 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 }
             }
             // ---- h_{t-1} W_hh^T (h_{-1} = 0) -------------------------------------------------------
-            if (t > 0) {
+            if (KOPT && t > 0) {
+                // two LDS byte addresses, opaque to the optimiser (it would fold the tile's own offset into the immediates
+                // and overflow them again): row tiles 0-1 / 2-3
+                typedef const __attribute__((address_space(3))) float* lds_cptr;
+                unsigned hb01 = (unsigned)(size_t)(lds_cptr)(hl + lr * HS + 4 * lq), hb23 = hb01 + 32u * HS * 4u;
+                asm volatile("" : "+v"(hb01));
+                asm volatile("" : "+v"(hb23));
+                lds_cptr ha01 = (lds_cptr)(size_t)hb01;
+                lds_cptr ha23 = (lds_cptr)(size_t)hb23;
+                auto mmah = [&](int kofs, const f32x4 (&b)[UG]) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const f32x4 av = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((rt < 2 ? ha01 : ha23) + (rt & 1) * 16 * HS + kofs);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                            for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[jj], b[u][jj], acc[rt][u]);
+                    }
+                };
+#pragma unroll 1
+                for (int hs = 0; hs < NSL; ++hs) {
+                    if ((ABL & 64) && pass < 3 && hs == NSL / 2) {
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UG) : "memory");
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < SK; kk += 2) {
+                        const int kc = hs * SK + kk;
+#pragma unroll
+                        for (int u = 0; u < UG; ++u) b1[u] = wload(wh[u] + (unsigned)(kc + 1) * 256u);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mmah(kk * 16, b0);
+                        __builtin_amdgcn_sched_barrier(0);  // the refill behind the last MFMA that reads b0: same registers
+                        const bool more_h = kc + 2 < KC;
+#pragma unroll
+                        for (int u = 0; u < UG; ++u) b0[u] = wload(more_h ? wh[u] + (unsigned)(kc + 2) * 256u : wxn[u]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mmah((kk + 1) * 16, b1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    ha01 += SK * 16;
+                    ha23 += SK * 16;
+                }
+            } else if (t > 0) {
                 const float* ha = hl + lr * HS + 4 * lq;
 #pragma unroll 1
                 for (int kc = 0; kc < KC; kc += 2) {
+                    if ((ABL & 64) && pass < 3 && kc == KC / 2) {
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UG) : "memory");
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                    }
 #pragma unroll
                     for (int u = 0; u < UG; ++u)
                         b1[u] = wload(wh[u] + (unsigned)(kc + 1) * 256u);
@@ -670,7 +915,39 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
         VAR[rt][u][i] = EXPR;                                                                         \
         asm volatile("" : "+v"(VAR[rt][u][i]));                                                       \
     }
-            if (ABL & 2) {
+#define FSN_REC_EPILOGUE2(VAR, EXPR)                                                                  \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                 \
+    _Pragma("unroll") for (int u = 0; u < UG; ++u) {                                                  \
+        const f32x4 A = acc[rt][u], C = cst[rt][u], M = tmp[rt][u];                                   \
+        (void)A, (void)C, (void)M;                                                                    \
+        auto half = [&](f32x2 a, f32x2 c, f32x2 m) { (void)a, (void)c, (void)m; return EXPR; };       \
+        VAR[rt][u] = cat2(half(lo2(A), lo2(C), lo2(M)), half(hi2(A), hi2(C), hi2(M)));                \
+        asm volatile("" : "+v"(VAR[rt][u]));                                                          \
+    }
+            if constexpr (PK && !(ABL & 2)) {
+                if constexpr (BEP) {
+                    if (pass == 0) {
+                        FSN_REC_EPILOGUE2(cst, sigmoid_fast2b(a, kb[u]) * c)
+                    } else if (pass == 1) {
+                        FSN_REC_EPILOGUE2(tmp, sigmoid_fast2b(a, kb[u]))
+                    } else if (pass == 2) {
+                        FSN_REC_EPILOGUE2(cst, c + m * tanh_fast2b(a, kb[u]))
+                    } else {
+                        FSN_REC_EPILOGUE2(tmp, sigmoid_fast2b(a, kb[u]) * tanh_fast2(c))
+                    }
+                } else {
+                    if (pass == 0) {
+                        FSN_REC_EPILOGUE2(cst, sigmoid_fast2(a) * c)
+                    } else if (pass == 1) {
+                        FSN_REC_EPILOGUE2(tmp, sigmoid_fast2(a))
+                    } else if (pass == 2) {
+                        FSN_REC_EPILOGUE2(cst, c + m * tanh_fast2(a))
+                    } else {
+                        FSN_REC_EPILOGUE2(tmp, sigmoid_fast2(a) * tanh_fast2(c))
+                    }
+                }
+            } else if constexpr (PK) {
+            } else if (ABL & 2) {
                 if (pass == 0 || pass == 2) {
                     FSN_REC_EPILOGUE(cst, acc[rt][u][i] * 0.5f)
                 } else {
@@ -686,6 +963,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 FSN_REC_EPILOGUE(tmp, sigmoid_fast(acc[rt][u][i]) * tanh_fast(cst[rt][u][i]))
             }
 #undef FSN_REC_EPILOGUE
+#undef FSN_REC_EPILOGUE2
             __builtin_amdgcn_sched_barrier(0);
         }
         // every wave has finished reading h_{t-1}; the fill of the next step's first slice stays in flight
@@ -1457,7 +1735,7 @@ int launch_rec_x(const float* xseq, const float* wih_p, const float* whh_p, cons
                  int main_wgs, hipStream_t s, const FsnRecFc* fc, float* hseq_out) {
     constexpr int NW = H / (16 * UG);
     const size_t lds = ((size_t)RT * 16 * (H + 4) + 2 * H + (size_t)2 * RT * 6 * 256) * sizeof(float);
-    auto kern = lstm_rec_x_kernel<H, RT, UG, 0, HSEQ>;
+    auto kern = lstm_rec_x_kernel<H, RT, UG, FSN_REC_X_OPT, HSEQ>;
     if (lds > 160 * 1024 ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
@@ -1480,7 +1758,7 @@ template <int H, int RT, int UG = 2>
 int launch_rec_in(const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad, int main_wgs, hipStream_t s) {
     constexpr int NW = H / (16 * UG);
     const size_t lds = ((size_t)RT * 16 * (H + 4) + (size_t)2 * RT * 16 * 36) * sizeof(float);
-    auto kern = lstm_rec_in_kernel<H, RT, UG>;
+    auto kern = lstm_rec_in_kernel<H, RT, UG, FSN_REC_IN_OPT>;
     if (lds > 160 * 1024 ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {

@@ -533,6 +533,11 @@ def forward_train(model, noisy_mag):
     """fullsubnet/model.py:72-136 under autograd (drop_band included), LSTMs on the HIP kernels.
     noisy_mag [B, 1, F, T] -> [B, 2, F // g, T]."""
     arith = getattr(model, "train_arithmetic", "f32")  # "f16" / "bf16": autocast arithmetic (Trainer, use_amp)
+    # drop_band's own check (feature.py:317-319), reached for every batch of more than one utterance (model.py:114): the
+    # reference's forward fails for 1 < B <= num_groups, and so does every graph here
+    assert noisy_mag.shape[0] == 1 or noisy_mag.shape[0] > model.num_groups_in_drop_band, (
+        f"Batch size = {noisy_mag.shape[0]}, num_groups = {model.num_groups_in_drop_band}. "
+        "The batch size should larger than the num_groups.")
     if fused_train_supported(model, noisy_mag):  # the whole model as one autograd node on the library's kernels
         return FullSubNetTrainFunction.apply(noisy_mag, model.look_ahead, model.sb_num_neighbors, model.num_groups_in_drop_band,
                                              arith, model.norm_type, *_fused_params(model))

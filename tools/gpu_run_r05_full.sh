@@ -1,14 +1,14 @@
 #!/bin/bash
-# Round 3, full session: GPU suite, bench line, kernel traces (bench / training f32 + f16 / sibling models), PMC passes.
+# Round 5, full session: GPU suite, bench line, kernel traces (bench / training f32 + f16 / sibling models), PMC passes.
 set -u
-O=gpurun_out/${1:-r03full}
+O=gpurun_out/${1:-r05full}
 mkdir -p $O
 export TMPDIR=/tmp
-(time timeout 1200 python -m pytest tests -m gpu -q -rP) > $O/pytest.log 2>&1
+(time timeout 1500 python -m pytest tests -m gpu -q -rP) > $O/pytest.log 2>&1
 echo "pytest rc=$?" >> $O/pytest.log
 grep -E "passed|failed|rc=|^E  |FAILED" $O/pytest.log | tail -8
-(time timeout 600 python bench.py --steps 10 --warmup 3) > $O/bench.json 2> $O/bench.err
-tail -c 1500 $O/bench.json; tail -3 $O/bench.err
+(time timeout 900 python bench.py --steps 10 --warmup 3) > $O/bench.json 2> $O/bench.err
+tail -c 600 $O/bench.json; tail -3 $O/bench.err
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -- $B > $O/trace.log 2>&1
 DB=$(ls $O/trace/*/*.db 2>/dev/null | head -1)

@@ -1,0 +1,119 @@
+// Can the gate non-linearities of one wave run under the MFMAs of its sibling waves?  (Round 5: the persistent recurrent
+// kernels pay ~1.3 ms per launch for them, about the serial VALU time of all three waves of a SIMD.)
+// 12 waves per workgroup (3 per SIMD), one workgroup per CU, no memory traffic.  Per iteration a wave issues NM MFMAs on 8
+// accumulator tiles (one gate pass of lstm_rec_x_kernel: 1536) and the sigmoid of 32 values (v_exp_f32 + v_rcp_f32 + 2 VALU).
+//   mode bit 1: MFMAs, bit 2: non-linearities, bit 4: a workgroup barrier after every iteration (lockstep),
+//   bit 8: static wave priorities 0 / 1 / 2 among the three waves of a SIMD, bit 16: the non-linearities of iteration i - 1
+//   interleaved by hand into the MFMA stream of iteration i (second register set), bit 32: barrier BEFORE the non-linearities
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sig(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+
+template <int MODE>
+__global__ __launch_bounds__(768) void overlap_kernel(float* out, int iters, float a0, float b0) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (MODE & 8) {
+        if ((wave >> 2) == 0) __builtin_amdgcn_s_setprio(0);
+        else if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(2);
+    }
+    f32x4 acc[8], prev[8];
+    float st[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0, 0, 0, 0}, prev[i] = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
+#pragma unroll
+    for (int i = 0; i < 32; ++i) st[i] = 0.01f * i + threadIdx.x * 1e-4f;
+    float a = a0 + (threadIdx.x & 63) * 1e-3f, b = b0 + (threadIdx.x & 63) * 5e-4f;
+    for (int it = 0; it < iters; ++it) {
+        if (MODE & 1) {
+            if (MODE & 16) {
+                // 48 chunks x 32 MFMAs; the first 8 chunks each carry the sigmoid of one f32x4 of the previous iteration
+#pragma unroll 1
+                for (int c = 0; c < 40; ++c) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                        if (MODE & 2) st[c * 4 + r] = sig(prev[c][r]) * st[c * 4 + r];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    prev[i] = acc[i] * 1e-3f;
+                    acc[i] = f32x4{0, 0, 0, 0};
+                }
+            } else {
+#pragma unroll 1
+                for (int c = 0; c < 48; ++c) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                }
+            }
+        }
+        if (MODE & 32) __syncthreads();
+        if ((MODE & 2) && !(MODE & 16)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[i * 4 + r] = sig(acc[i][r] * 1e-3f + st[i * 4 + r]) * st[i * 4 + r];
+                    asm volatile("" : "+v"(st[i * 4 + r]));
+                }
+        }
+        if (MODE & 4) __syncthreads();
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += st[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] + prev[i][0];
+    out[(size_t)blockIdx.x * 768 + threadIdx.x] = s;
+}
+
+template <int MODE>
+void run(const char* name, float* out, int iters) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int t = 0; t < 3; ++t) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(overlap_kernel<MODE>, dim3(256), dim3(768), 0, 0, out, iters, 1.0f, 2.0f);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (t > 0 && ms < best) best = ms;
+    }
+    printf("%-78s %8.3f ms\n", name, best);
+}
+
+int main() {
+    float* out;
+    hipMalloc(&out, (size_t)256 * 768 * 4);
+    const int iters = 760;  // 190 steps x 4 gate passes
+    run<1>("MFMAs alone (1536 per wave and iteration, 3 waves per SIMD)", out, iters);
+    run<2>("non-linearities alone (32 sigmoids per wave and iteration)", out, iters);
+    run<3>("both, free running", out, iters);
+    run<3 | 4>("both, barrier after the non-linearities (lockstep)", out, iters);
+    run<3 | 32>("both, barrier before the non-linearities", out, iters);
+    run<3 | 8>("both, free running, wave priorities 0/1/2 per SIMD", out, iters);
+    run<3 | 4 | 8>("both, barrier after the non-linearities, wave priorities", out, iters);
+    run<3 | 32 | 8>("both, barrier before the non-linearities, wave priorities", out, iters);
+    run<1 | 16>("MFMAs, hand-interleaved form without the non-linearities", out, iters);
+    run<3 | 16>("both, previous iteration's non-linearities inside the MFMA stream", out, iters);
+    run<3 | 16 | 4>("the same with a barrier per iteration", out, iters);
+    return 0;
+}

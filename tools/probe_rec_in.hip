@@ -1,0 +1,82 @@
+// Timing probe for lstm_rec_in_kernel (not part of the library): the shipped kernel against the round-5 variants (template
+// parameter OPT: 256 packed gate non-linearities, 512 bias inside the non-linearity), config-2 shape, results compared.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../fullsubnet_amd/csrc/lstm_kernels.hip"
+void fsn_set_error(const char*, ...) {}
+int fsn_check_launch(const char*) { return hipGetLastError() == hipSuccess ? 0 : -3; }
+FsnCallScope::FsnCallScope(void*) : prev(-1), switched(false) {}
+FsnCallScope::~FsnCallScope() {}
+__global__ void fill_kernel(float* p, size_t n, unsigned seed, float scale, float offset) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 747796405u + seed; x ^= x >> 16; x *= 2246822519u; x ^= x >> 13;
+        p[i] = ((x & 0xffff) / 32768.0f - 1.0f) * scale + offset;
+    }
+}
+static std::vector<float> g_ref;
+static float* g_out = nullptr;
+static size_t g_n = 0;
+static double check() {
+    std::vector<float> h(g_n);
+    hipMemcpy(h.data(), g_out, g_n * 4, hipMemcpyDeviceToHost);
+    if (g_ref.empty()) { g_ref = h; return 0.0; }
+    double m = 0.0;
+    for (size_t i = 0; i < g_n; ++i) { const double d = std::fabs((double)h[i] - (double)g_ref[i]); if (!(d <= m)) m = d; }
+    return m;
+}
+template <int OPT>
+float run(const FsnSbInput& xin, const float* w, unsigned whh_off, float* hseq, int Tp, int Npad) {
+    constexpr int H = 384, RT = 4, UG = 2, NW = H / (16 * UG);
+    const size_t lds = ((size_t)RT * 16 * (H + 4) + (size_t)2 * RT * 16 * 36) * sizeof(float);
+    auto kern = lstm_rec_in_kernel<H, RT, UG, OPT>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int it = 0; it < 7; ++it) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(NW * 64), lds, 0, xin, w, whh_off, hseq, Tp, Npad);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (it > 0 && ms < best) best = ms;
+    }
+    return best;
+}
+int main(int argc, char** argv) {
+    const int Tp = argc > 1 ? atoi(argv[1]) : 190;
+    const int H = 384, tiles = 1028, Npad = tiles * 16, F = 257, FP = 272, B = 64;
+    float *mag, *fb, *den, *w, *bias, *hseq;
+    hipMalloc(&mag, (size_t)B * Tp * FP * 4);
+    hipMalloc(&fb, (size_t)B * Tp * FP * 4);
+    hipMalloc(&den, 256);
+    hipMalloc(&w, (size_t)(4 * H * 32 + 4 * H * H) * 4);
+    hipMalloc(&bias, 4 * H * 4);
+    hipMalloc(&hseq, (size_t)Tp * Npad * H * 4);
+    fill_kernel<<<1024, 256>>>(mag, (size_t)B * Tp * FP, 1, 0.5f, 0.6f);
+    fill_kernel<<<1024, 256>>>(fb, (size_t)B * Tp * FP, 5, 0.5f, 0.6f);
+    fill_kernel<<<1, 64>>>(den, 64, 6, 0.1f, 0.7f);
+    fill_kernel<<<256, 256>>>(w, (size_t)(4 * H * 32 + 4 * H * H), 2, 0.05f, 0.f);
+    fill_kernel<<<8, 256>>>(bias, 4 * H, 3, 0.1f, 0.f);
+    hipDeviceSynchronize();
+    FsnSbInput xin{};
+    xin.mag = mag; xin.fb_out = fb; xin.den = den; xin.wih_p = w; xin.bias = bias; xin.den_mode = 0; xin.den_stride = 0;
+    xin.B = B; xin.Tp = Tp; xin.F = F; xin.FP = FP; xin.N = B * F; xin.nb = 15; xin.kin_chunks = 2; xin.x_rows = nullptr; xin.row0 = 0;
+    const unsigned whh_off = 4 * H * 32;
+    g_out = hseq + (size_t)(Tp - 1) * Npad * H; g_n = (size_t)Npad * H;  // the last frame's hidden state
+    const double flops = 2.0 * 256 * 64 * 416.0 * 1536 * Tp;
+    const float t0 = run<0>(xin, w, whh_off, hseq, Tp, Npad);
+    check();
+    printf("lstm_rec_in_kernel<384,4,2> x 256 workgroups: %.3f ms = %.1f TFLOP/s (ideal at 157.3: %.3f ms)\n", t0, flops / t0 / 1e9, flops / 157.3e9);
+#define VARIANT(NAME, BITS)                                                          \
+    {                                                                                \
+        const float ms = run<BITS>(xin, w, whh_off, hseq, Tp, Npad);                 \
+        printf("  %-58s: %.3f ms   max |d| vs shipped %.3e\n", NAME, ms, check());   \
+    }
+    VARIANT("packed non-linearities (256)", 256)
+    VARIANT("packed + bias in the non-linearity (256 + 512)", 768)
+    VARIANT("K loop without per-chunk vector instructions (4096)", 4096)
+    VARIANT("4096 + 256", 4096 + 256)
+    VARIANT("4096 + 256 + 512", 4096 + 256 + 512)
+    VARIANT("shipped once more", 0)
+    return 0;
+}

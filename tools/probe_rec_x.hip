@@ -1,7 +1,9 @@
 // Timing probe for lstm_rec_x_kernel (not part of the library): the shipped kernel and ablations that leave out one
 // ingredient at a time (template parameter ABL, see the kernel) to price it.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include "../fullsubnet_amd/csrc/lstm_kernels.hip"
 void fsn_set_error(const char*, ...) {}
 int fsn_check_launch(const char*) { return hipGetLastError() == hipSuccess ? 0 : -3; }
@@ -25,13 +27,25 @@ float run(const float* xseq, const float* w, const float* bias, int Tp, int Npad
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f;
-    for (int it = 0; it < 3; ++it) {
+    for (int it = 0; it < 7; ++it) {
         hipEventRecord(e0, 0);
         hipLaunchKernelGGL(kern, dim3(256 * 4 / RT), dim3(NW * 64), lds, 0, xseq, w, (unsigned)(4 * H * H), bias, Tp, Npad, fc);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (it > 0 && ms < best) best = ms;
     }
     return best;
+}
+static std::vector<float> g_ref;
+static float* g_out = nullptr;
+static size_t g_n = 0;
+// max |difference| of the output plane against the shipped kernel's (first call: remember it)
+static double check() {
+    std::vector<float> h(g_n);
+    hipMemcpy(h.data(), g_out, g_n * 4, hipMemcpyDeviceToHost);
+    if (g_ref.empty()) { g_ref = h; return 0.0; }
+    double m = 0.0;
+    for (size_t i = 0; i < g_n; ++i) { const double d = std::fabs((double)h[i] - (double)g_ref[i]); if (!(d <= m)) m = d; }
+    return m;
 }
 int main(int argc, char** argv) {
     const int Tp = argc > 1 ? atoi(argv[1]) : 190;
@@ -53,14 +67,29 @@ int main(int argc, char** argv) {
     FsnRecFc fc{};
     fc.w_p = fcw; fc.bias = fcb; fc.crm_r = cr; fc.crm_i = ci; fc.N = 64 * F; fc.F = F; fc.FP = 272; fc.T = T; fc.la = 2; fc.row0 = 0;
     const double flops = 2.0 * 256 * 64 * 768.0 * 1536 * Tp;
+    g_out = cr; g_n = (size_t)64 * T * 272;
+    hipMemset(cr, 0, g_n * 4);
     const float t0 = run<0>(xseq, w, bias, Tp, Npad, fc);
+    check();
     printf("lstm_rec_x_kernel<384,%d,%d> x %d workgroups: %.3f ms = %.1f TFLOP/s (ideal at 157.3: %.3f ms)\n", PROBE_RT, PROBE_UG, 256 * 4 / PROBE_RT, t0, flops / t0 / 1e9, flops / 157.3e9);
-    printf("  without slice barriers      : %.3f ms\n", run<1>(xseq, w, bias, Tp, Npad, fc));
-    printf("  without gate non-linearities: %.3f ms\n", run<2>(xseq, w, bias, Tp, Npad, fc));
-    printf("  without the output layer    : %.3f ms\n", run<4>(xseq, w, bias, Tp, Npad, fc));
-    printf("  without ring fills          : %.3f ms\n", run<8>(xseq, w, bias, Tp, Npad, fc));
-    printf("  without end-of-step barriers: %.3f ms\n", run<16>(xseq, w, bias, Tp, Npad, fc));
-    printf("  without all of them         : %.3f ms\n", run<31>(xseq, w, bias, Tp, Npad, fc));
-    printf("  shipped again               : %.3f ms\n", run<0>(xseq, w, bias, Tp, Npad, fc));
+#define VARIANT(NAME, BITS)                                                            \
+    {                                                                                  \
+        const float ms = run<BITS>(xseq, w, bias, Tp, Npad, fc);                       \
+        printf("  %-58s: %.3f ms   max |d| vs shipped %.3e\n", NAME, ms, check());     \
+    }
+    VARIANT("pass-opening barrier inside the h product (64)", 64)
+    VARIANT("packed non-linearities (256)", 256)
+    VARIANT("64 + 256", 320)
+    VARIANT("K loop without per-chunk vector instructions (4096)", 4096)
+    VARIANT("4096 + 64", 4096 + 64)
+    VARIANT("4096 + 64 + 256", 4096 + 64 + 256)
+    VARIANT("shipped", 0)
+    VARIANT("4096 (h part only) + 64 + 256", 8192 + 4096 + 64 + 256)
+    VARIANT("4096 (h part only) + 64", 8192 + 4096 + 64)
+    VARIANT("64 + 256", 320)
+    VARIANT("4096 + 64 + 256", 4096 + 64 + 256)
+    VARIANT("4096 + 64", 4096 + 64)
+    VARIANT("64", 64)
+    VARIANT("shipped once more", 0)
     return 0;
 }
