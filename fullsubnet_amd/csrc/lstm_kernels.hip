@@ -397,6 +397,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[jj], b[u][jj], acc[rt][u]);
         }
     };
+    constexpr bool JJM = (OPT & 16384) != 0;  // k-step major MFMA order in the recurrent product, see lstm_rec_x_kernel
 
     auto mma0 = [&](f32x4 (&acc)[RT][UG], const float* a, int a_rt_stride, const f32x4 (&b)[UG]) {  // C = 0: first block of a pass
 #pragma unroll
@@ -463,6 +464,19 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 lds_cptr ha01 = (lds_cptr)(size_t)hb01;
                 lds_cptr ha23 = (lds_cptr)(size_t)hb23;
                 auto mmah = [&](int kofs, const f32x4 (&b)[UG]) {
+                    if constexpr (JJM) {
+                        f32x4 av[RT];
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+                            av[rt] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((rt < 2 ? ha01 : ha23) + (rt & 1) * 16 * HS + kofs);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                                for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[rt][jj], b[u][jj], acc[rt][u]);
+                        return;
+                    }
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
                         const f32x4 av = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((rt < 2 ? ha01 : ha23) + (rt & 1) * 16 * HS + kofs);
@@ -742,6 +756,20 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
     }
     // acc[rt][u] += A(16 rows x 16 k) B(16 k x 16 units): a = this lane's A fragment address of row tile 0
     auto mma = [&](f32x4 (&acc)[RT][UG], const float* a, int a_rt_stride, const f32x4 (&b)[UG]) {
+        if constexpr ((ABL & 16384) != 0) {
+            // k-step major: an accumulator is touched again RT UG MFMAs later (a dependent v_mfma_f32_16x16x4_f32 issues 40
+            // cycles after its producer, an independent one 32)
+            f32x4 av[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) av[rt] = *reinterpret_cast<const f32x4*>(a + rt * a_rt_stride);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[rt][jj], b[u][jj], acc[rt][u]);
+            return;
+        }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const f32x4 av = *reinterpret_cast<const f32x4*>(a + rt * a_rt_stride);

@@ -72,11 +72,10 @@ int main(int argc, char** argv) {
         const float ms = run<BITS>(xin, w, whh_off, hseq, Tp, Npad);                 \
         printf("  %-58s: %.3f ms   max |d| vs shipped %.3e\n", NAME, ms, check());   \
     }
-    VARIANT("packed non-linearities (256)", 256)
-    VARIANT("packed + bias in the non-linearity (256 + 512)", 768)
-    VARIANT("K loop without per-chunk vector instructions (4096)", 4096)
+    VARIANT("4096 + 256 (the library's form)", 4096 + 256)
+    VARIANT("4096 + 256 + k-step major MFMA order (16384)", 4096 + 256 + 16384)
     VARIANT("4096 + 256", 4096 + 256)
-    VARIANT("4096 + 256 + 512", 4096 + 256 + 512)
+    VARIANT("4096 + 256 + 16384", 4096 + 256 + 16384)
     VARIANT("shipped once more", 0)
     return 0;
 }

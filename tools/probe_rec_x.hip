@@ -77,19 +77,12 @@ int main(int argc, char** argv) {
         const float ms = run<BITS>(xseq, w, bias, Tp, Npad, fc);                       \
         printf("  %-58s: %.3f ms   max |d| vs shipped %.3e\n", NAME, ms, check());     \
     }
-    VARIANT("pass-opening barrier inside the h product (64)", 64)
-    VARIANT("packed non-linearities (256)", 256)
+    VARIANT("64 + 256 (the library's form)", 320)
+    VARIANT("64 + 256 + k-step major MFMA order (16384)", 320 + 16384)
+    VARIANT("64 + 256 + 4096 + 16384", 320 + 4096 + 16384)
+    VARIANT("shipped r04", 0)
     VARIANT("64 + 256", 320)
-    VARIANT("K loop without per-chunk vector instructions (4096)", 4096)
-    VARIANT("4096 + 64", 4096 + 64)
-    VARIANT("4096 + 64 + 256", 4096 + 64 + 256)
-    VARIANT("shipped", 0)
-    VARIANT("4096 (h part only) + 64 + 256", 8192 + 4096 + 64 + 256)
-    VARIANT("4096 (h part only) + 64", 8192 + 4096 + 64)
-    VARIANT("64 + 256", 320)
-    VARIANT("4096 + 64 + 256", 4096 + 64 + 256)
-    VARIANT("4096 + 64", 4096 + 64)
-    VARIANT("64", 64)
+    VARIANT("64 + 256 + 16384", 320 + 16384)
     VARIANT("shipped once more", 0)
     return 0;
 }
