@@ -75,6 +75,37 @@ def _time_aten(model, length, batch, threads):
     return time.perf_counter() - t0
 
 
+def _all_cores_sample(avail, cap_s=45.0, seconds=0.5):
+    """SURVEY 8(d)'s figure with EVERY host thread the process may use (n = len(os.sched_getaffinity(0)), stated), on a
+    reduced sample so that it fits the default run: ONE utterance of `seconds` of audio through the same ATen operator
+    sequence, in a child process with a hard time limit (oneDNN's LSTM collapses when oversubscribed - r03: 5 frames/s
+    on 4 utterances with 256 threads - and a running ATen call cannot be interrupted from inside).  A run that hits the
+    limit is reported as an upper bound."""
+    import subprocess
+    n = int(round(seconds * SR))
+    code = (
+        "import sys, time, torch; sys.path.insert(0, %r)\n"
+        "from fsn_synthetic import make_noisy, make_params\n"
+        "from oracle import aten_baseline as A\n"
+        "torch.set_num_threads(%d)\n"
+        "m = A.AtenFullSubNet(make_params(seed=0, gain=2.0, mask_gain=24.0)).eval()\n"
+        "x = torch.from_numpy(make_noisy(1, %d, seed=78))\n"
+        "A.full_band_crm_mask(m, x[:, :2048])\n"
+        "t0 = time.perf_counter(); A.full_band_crm_mask(m, x); print(time.perf_counter() - t0)\n" % (ROOT, avail, n))
+    frames = 1 + n // HOP
+    sample = f"1 x {seconds:g} s ({frames} frames), the ATen operator sequence with all {avail} host threads"
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=cap_s)
+        dt = float(r.stdout.strip().splitlines()[-1])
+        return {"value": round(frames / dt, 2), "unit": "frames/s", "cores": avail, "sample": sample + f", {dt:.1f} s wall"}
+    except subprocess.TimeoutExpired:
+        return {"value": round(frames / cap_s, 2), "unit": "frames/s", "cores": avail, "upper_bound": True,
+                "sample": sample + f": not finished after {cap_s:g} s (the figure is an upper bound)"}
+    except Exception as e:  # a side figure must never break the line
+        return {"value": None, "cores": avail, "error": str(e)[:160], "s": round(time.perf_counter() - t0, 1)}
+
+
 def cpu_baseline(params, length, budget_s=30.0, all_cores_too=False):
     """The reference's CPU arithmetic on this box's host cores, on a bounded sample of the same workload.
 
@@ -112,6 +143,8 @@ def cpu_baseline(params, length, budget_s=30.0, all_cores_too=False):
         t_all = _time_aten(model, length, nb, avail)
         all_cores = {"value": round(nb * frames_per_utt / t_all, 2), "unit": "frames/s", "cores": avail,
                      "sample": f"the same {nb}-utterance batch, {t_all:.1f} s wall"}
+    else:
+        all_cores = _all_cores_sample(avail)
     out = {"value": round(nb * frames_per_utt / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
            "sample": f"{nb} x {length / SR:.1f} s utterance(s) in one batch, full path stft -> model -> decompress -> "
                      f"mask -> istft as the ATen operator sequence of the reference (oracle/aten_baseline.py: torch "
@@ -120,9 +153,9 @@ def cpu_baseline(params, length, budget_s=30.0, all_cores_too=False):
            "rtf_speedup": round(nb * length / SR / dt, 3),
            "by_threads": {str(th): round(nb * frames_per_utt / t, 2) for th, t in sorted(cal.items())},
            "all_cores": all_cores,
-           "all_cores_note": (None if all_cores else
-                              f"not timed in this run (--cpu-all-cores): with all {avail} host threads the same batch "
-                              f"measured 66 frames/s in r03 (oneDNN's LSTM oversubscribed; profiles/r03_cpu_threads.md)")}
+           "all_cores_note": f"n = len(os.sched_getaffinity(0)) = {avail}; oneDNN's LSTM slows down when oversubscribed (the whole "
+                             f"64-utterance batch with all 256 threads: 66 frames/s in r03, profiles/r03_cpu_threads.md; "
+                             f"--cpu-all-cores times that batch), which is why `value` is the fastest of 16 / 32 / 64 threads"}
     # the parity checker (numpy + torch-CPU matmuls), for the record: it scales to ~16 threads
     cores = min(16, avail)
     torch.set_num_threads(cores)
@@ -230,14 +263,44 @@ def path_parity(model, oracle_outputs, batch, length, device):
     enh, crm = model.enhance(torch.from_numpy(x).to(device), return_crm=True)
     torch.cuda.synchronize()
     rows = [0, x.shape[0] - 1]
+    stft_ulp = stft_parity(noisy2, device)
     d_crm = float(np.abs(crm[rows].cpu().numpy() - crm_ref).max())
     d_enh = float(np.abs(enh[rows].cpu().numpy() - ref).max() / np.abs(ref).max())
     return {"max_abs_err_cirm_vs_oracle": d_crm, "bound_cirm": 1e-4, "mean_abs_err_cirm_vs_oracle":
             float(np.abs(crm[rows].cpu().numpy() - crm_ref).mean()), "max_rel_err_enhanced_vs_oracle": d_enh,
             "bound_enhanced": 2e-3, "cirm_range": [round(float(crm_ref.min()), 2), round(float(crm_ref.max()), 2)],
             "utterances": rows, "of_batch": int(x.shape[0]), "within_bound": bool(d_crm <= 1e-4 and d_enh <= 2e-3),
+            "stft": stft_ulp,
             "note": "gate non-linearities are v_exp_f32 / v_rcp_f32 forms by choice (SURVEY 7 advises libm): this is "
                     "the margin they leave"}
+
+
+def stft_parity(noisy2, device):
+    """north_star: "STFT bins bit-pattern within 2 ULP".  Measured here on the checker's two utterances, in ULP of each
+    frame's largest component (own-scale ULPs of cancellation bins are unbounded for ANY two FFTs): against the
+    exactly rounded transform (the oracle's fp64 DFT of the fp32 frame x window product: bound 1) and against
+    torch.stft on this box's CPU (MKL: the reference's own arithmetic).  The stated deviation lives here, in the line:
+    MKL's fp32 FFT is itself up to ~3 ULP from the exact transform on long inputs (2.95 measured), so
+    against MKL the tests allow 2 ULP on the short goldens and 3 on the 376-frame one."""
+    import fullsubnet_amd
+    from oracle import fullsubnet_oracle as O
+    _, _, re, im = fullsubnet_amd.stft(torch.from_numpy(noisy2).to(device), N_FFT, HOP, N_FFT, return_phase=False)
+    re, im = re.cpu().numpy(), im.cpu().numpy()
+    win = torch.hann_window(N_FFT)
+    _, _, ore, oim = O.stft(noisy2, window=win.numpy())
+    mkl = torch.stft(torch.from_numpy(noisy2), N_FFT, HOP, N_FFT, window=win, return_complex=True)
+    mre, mim = mkl.real.numpy(), mkl.imag.numpy()
+
+    def ulps(ar, ai, br, bi):
+        fmax = np.maximum(np.abs(br), np.abs(bi)).max(axis=1, keepdims=True)
+        return float((np.maximum(np.abs(ar - br), np.abs(ai - bi)) / np.spacing(fmax.astype(np.float32))).max())
+
+    return {"max_ulp_vs_exact_transform": round(ulps(re, im, ore, oim), 3), "bound_vs_exact": 1.0,
+            "max_ulp_vs_torch_stft_cpu": round(ulps(re, im, mre, mim), 3),
+            "torch_stft_cpu_vs_exact": round(ulps(mre, mim, ore, oim), 3),
+            "bound_vs_torch_stft": {"north_star": 2.0, "tests": "2 on the short goldens, 3 on the 376-frame golden "
+                                                                "(stated deviation: MKL itself is up to ~3 from exact)"},
+            "scale": "ULP of each frame's largest component", "frames": int(re.shape[0] * re.shape[2])}
 
 
 def training_parity(device, arith):
@@ -462,6 +525,7 @@ def main():
         b_max = shard_bounds(b_total, 0, world)[1]
         noisy = torch.from_numpy(noisy_np).to(device)  # resident in HBM before the timed region
         gathered = send = None
+        ag = {"ev": [], "ms": 0.0, "n": 0}  # the collective's own time: events on the launch stream around it
         if world > 1 and not row_sharded:
             gathered = torch.empty((world * b_max, length), dtype=torch.float32, device=device)
             send = torch.zeros((b_max, length), dtype=torch.float32, device=device)
@@ -479,34 +543,70 @@ def main():
             if args.host_io:
                 host_out.copy_(enh, non_blocking=True)
             if world > 1:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 if b_loc == b_max:
                     dist.all_gather_into_tensor(gathered, enh)  # RCCL over xGMI: re-assemble the node batch
                 else:
                     send[:b_loc].copy_(enh)
                     dist.all_gather_into_tensor(gathered, send)
+                e1.record()
+                ag["ev"].append((e0, e1))
                 return gathered
             return enh
+
+        def all_gather_ms():
+            """ms per step the all-gather took on this rank (read after a fence; includes waiting for the slowest peer)."""
+            for e0, e1 in ag["ev"]:
+                ag["ms"] += e0.elapsed_time(e1)
+                ag["n"] += 1
+            ag["ev"].clear()
+            return ag["ms"] / max(ag["n"], 1)
+
+        def reset_all_gather():
+            ag["ev"].clear()
+            ag["ms"], ag["n"] = 0.0, 0
 
         rows_loc = shard_bounds(b_total * F, 0, world)[1] if row_sharded else b_loc * F
         par = (f"row-shard x{world} ({rows_loc} of {b_total * F} sub-band rows per rank) + all-gather of the mask"
                if row_sharded else f"utterance-shard x{world}" + (" + all-gather of the waveforms" if world > 1 else ""))
+        step.all_gather_ms, step.reset_all_gather, step.row_sharded = all_gather_ms, reset_all_gather, row_sharded
         return step, b_total, b_loc, rows_loc, par
 
     def run_mode(scaling, steps, warmup, profile):
         step, b_total, b_loc, rows_loc, par = make_mode(scaling)
         for _ in range(warmup):
             step()
+        fence()
+        step.reset_all_gather()
         if profile:
             _lib.profile_enable(True, device)  # hipEvents on the launch stream around every stage (no host sync inside)
         dt, stage_ms = timed_steps(step, fence, steps, (lambda: _lib.profile_read(device)) if profile else None)
         if profile:
             _lib.profile_enable(False, device)
+        # what this rank's share runs on: the plan of its B utterances (row shard: of the whole batch it holds)
+        plan = _lib.core_plan(model._cfg, max(1, -(-rows_loc // F)) if step.row_sharded else b_loc, T)
+        per_rank = None
         if world > 1:
+            # every rank's own clock, its all-gather time and its plan, for rank 0's line: a slow rank, a slow collective
+            # and an unexpected plan are told apart at a glance the day an 8-GPU node runs this
+            mine = torch.tensor([dt, step.all_gather_ms(), float(b_loc), float(plan["row_tiles_per_workgroup"]),
+                                 float(plan["persistent_workgroups"]), float(plan["left_over_tiles"]),
+                                 float(plan["group_clusters"]), float(plan["chunks"])], dtype=torch.float64, device=device)
+            everyone = torch.empty((world * mine.numel(),), dtype=torch.float64, device=device)  # (flat: gloo insists)
+            dist.all_gather_into_tensor(everyone, mine)
+            everyone = everyone.view(world, mine.numel())
+            per_rank = [{"rank": r, "ms_per_step": round(1e3 * v[0] / steps, 3), "all_gather_ms": round(v[1], 3),
+                         "utterances": int(v[2]), "plan": {"row_tiles_per_workgroup": int(v[3]),
+                                                           "persistent_workgroups": int(v[4]),
+                                                           "left_over_tiles": int(v[5]), "group_clusters": int(v[6]),
+                                                           "chunks": int(v[7])}}
+                        for r, v in enumerate(everyone.cpu().tolist())]
             tmax = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         return dict(dt=dt, stage_ms={k: v / steps for k, v in stage_ms.items()}, b_total=b_total, b_loc=b_loc,
-                    rows_loc=rows_loc, par=par, steps=steps)
+                    rows_loc=rows_loc, par=par, steps=steps, plan=plan, per_rank=per_rank)
 
     scaling = args.scaling if world > 1 else "weak"  # one GPU: the two modes are the same workload
     head = run_mode(scaling, args.steps, args.warmup, profile=True)
@@ -525,7 +625,12 @@ def main():
         ms_per_step = 1e3 * dt / args.steps
         value = b_total * T * args.steps / dt
         # dominant kernel: the persistent sub-band recurrent kernel, launched twice per step (layers 0 and 1)
-        rows_steps = float(rows_loc) * Tp
+        # ... counted on the rows those two launches actually process (config 2: 256 workgroups x 64 rows = 16 384 of the
+        # 16 448; the 64 left-over rows run as per-step launches beside them and are not in `ms` either)
+        plan = head["plan"]
+        rows_rec = plan["persistent_workgroups"] * plan["row_tiles_per_workgroup"] * 16 * plan["chunks"]
+        rows_rec = min(rows_rec, rows_loc) if rows_rec > 0 else rows_loc
+        rows_steps = float(rows_rec) * Tp
         rec_flops = 2.0 * (MAC_REC_L0 + MAC_REC_L1) * rows_steps  # both launches
         rec_ms = stage_ms.get("sb_rec_l0", 0.0) + stage_ms.get("sb_rec_l1", 0.0)
         achieved = rec_flops / (rec_ms * 1e-3) / 1e12 if rec_ms > 0 else 0.0
@@ -557,6 +662,7 @@ def main():
                                             f"at config 2), NOT measured in this run") if pmc_src else None,
                          "mfma_busy_frac_replayed": mfma_busy, "pmc_source": pmc_src,
                          "flops_per_launch": rec_flops / 2, "ms_per_launch": round(rec_ms / 2, 3),
+                         "rows": {"persistent_pair": int(rows_rec), "of": int(rows_loc), "plan": plan},
                          "launches": {"sb_rec_l0": {"flops": 2.0 * MAC_REC_L0 * rows_steps,
                                                     "ms": round(stage_ms.get("sb_rec_l0", 0.0), 3)},
                                       "sb_rec_l1": {"flops": 2.0 * MAC_REC_L1 * rows_steps,
@@ -564,6 +670,8 @@ def main():
                          "whole_path_frac": round(path_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         }
+        if head["per_rank"] is not None:
+            out["per_rank"] = head["per_rank"]
         out.update(extras)
     if not args.no_extras and world == 1 and args.batch % 8 == 0:
         # One rank's share of the strong-scaled batch at 2 / 4 / 8 GPUs (batch / N utterances), measured on this GPU:

@@ -217,6 +217,7 @@ SIGNATURES = {
     "fsn_debug_persist_set_fits": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_void_p]),
     "fsn_debug_tn_plan": (_c.c_int, [_c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "fsn_debug_core_chunks": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int]),
+    "fsn_debug_core_plan": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int]),
     "fsn_profile_num_stages": (_c.c_int, []),
     "fsn_profile_stage_name": (_c.c_char_p, [_c.c_int]),
     "fsn_profile_read": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_float), _c.c_int]),
@@ -353,6 +354,16 @@ def profile_enable(on, device=None):
 def profile_stage_names():
     L = lib()
     return [L.fsn_profile_stage_name(i).decode() for i in range(L.fsn_profile_num_stages())]
+
+
+def core_plan(cfg, B, T):
+    """How the sub-band model of a B-utterance, T-frame call is spread over the device (fsn_debug_core_plan)."""
+    buf = (ctypes.c_int * 8)()
+    if lib().fsn_debug_core_plan(ctypes.byref(cfg), B, T, buf, 8) != 0:
+        raise FsnError("fsn_debug_core_plan: bad arguments")
+    keys = ("rows", "tiles", "row_tiles_per_workgroup", "persistent_workgroups", "left_over_tiles", "group_clusters",
+            "fullband_chain", "chunks")
+    return dict(zip(keys, list(buf)))
 
 
 def profile_read(device=None):

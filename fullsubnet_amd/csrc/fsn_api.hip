@@ -1343,6 +1343,22 @@ extern "C" int fsn_debug_core_chunks(const fsn_fullsubnet_cfg* cfg, int B, int* 
     return core_chunks(cfg, B, sizes, kMaxChunks);
 }
 
+extern "C" int fsn_debug_core_plan(const fsn_fullsubnet_cfg* cfg, int B, int T, int* plan, int n) {
+    if (check_cfg(cfg) != FSN_OK || check_bt(B, T) != FSN_OK || !plan || n < 8) return -1;
+    int sizes[kMaxChunks];
+    const int chunks = core_chunks(cfg, B, sizes, kMaxChunks);
+    const CoreDims d = core_dims(cfg, chunks > 0 ? sizes[0] : B, T);
+    plan[0] = d.N;
+    plan[1] = d.rec.tiles;
+    plan[2] = d.rec.rt;
+    plan[3] = d.rec.main_wgs;
+    plan[4] = d.rec.left_tiles;
+    plan[5] = d.grp_clusters;
+    plan[6] = d.fb_chain ? 1 : 0;
+    plan[7] = chunks;
+    return FSN_OK;
+}
+
 extern "C" size_t fsn_fullsubnet_workspace_bytes(const fsn_fullsubnet_cfg* cfg, int B, int T) {
     if (check_cfg(cfg) != FSN_OK || check_bt(B, T) != FSN_OK) return 0;
     const CoreDims d = core_dims(cfg, B, T);

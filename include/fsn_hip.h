@@ -538,6 +538,12 @@ int fsn_debug_tn_plan(int M, int Nc, long K, int arith, int* splits, long* bound
  * (whole rounds of the persistent kernels, a remainder split by a cost model of the plans - the model has no
  * cross-utterance term); sizes[0..n) = their utterance counts, n returned (max_sizes >= 80), -1 on bad arguments. */
 int fsn_debug_core_chunks(const fsn_fullsubnet_cfg* cfg, int B, int* sizes, int max_sizes);
+/* Diagnostic: how the sub-band model of a B-utterance, T-frame call is spread over the device (of its first chunk when the
+ * batch runs as several).  plan[0..8) = sub-band rows, 16-row tiles, row tiles per workgroup of the persistent pair, its
+ * workgroups (0: the rows run on the group kernel / step launches), left-over tiles beside it, clusters of the group
+ * kernel (0: none), full-band model on the chain kernel (0 / 1), chunks of the batch.  bench.py prints it per rank and
+ * counts the roofline's FLOPs on the rows the persistent launches actually process. */
+int fsn_debug_core_plan(const fsn_fullsubnet_cfg* cfg, int B, int T, int* plan, int n);
 int fsn_profile_num_stages(void);
 const char* fsn_profile_stage_name(int stage);
 int fsn_profile_read(void* stream, float* ms_per_stage, int n);

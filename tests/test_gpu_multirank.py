@@ -70,6 +70,13 @@ def test_bench_two_ranks_as_the_driver_launches_it(fsn, shard, batch, extras):
     rows = shard == "rows" or (shard == "auto" and batch % 2)
     assert ("row-shard x2" in out["config"]["parallelism"]) == bool(rows), out["config"]["parallelism"]
     assert out.get("cpu_baseline") is None  # reported at N = 1 only
+    # the diagnosis block: every rank's own clock (never above the max-over-ranks figure), its all-gather time, its plan
+    pr = out["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1] and all(0 < p["ms_per_step"] <= out["ms_per_step"] * 1.001 for p in pr)
+    assert max(p["ms_per_step"] for p in pr) >= 0.999 * out["ms_per_step"]
+    assert all(p["all_gather_ms"] >= 0 and p["plan"]["persistent_workgroups"] == 0 for p in pr)  # --persistent never
+    assert (sum(p["utterances"] for p in pr) == batch) != bool(rows)  # row shard: every rank holds the whole batch
+    assert out["roofline"]["rows"]["of"] > 0
     if extras:
         assert out["other_scaling"]["scaling"] == "weak" and out["other_scaling"]["batch_total"] == 2 * batch
 

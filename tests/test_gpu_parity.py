@@ -611,6 +611,46 @@ def test_f16x3_promotion_criterion(fsn):
         assert r_max <= 2.0 and r_rms <= 2.0, (name, r_max, r_rms)
 
 
+def test_long_utterance_mask_bound_of_the_fp32_path(fsn):
+    """The gate non-linearities of the forward kernels are hardware-transcendental forms (v_exp_f32 / v_rcp_f32,
+    fsn_common.h; SURVEY 7 advises libm): their ~1 ULP errors feed back through the recurrence, so the 1e-4 bound on the
+    compressed mask is checked where that has had the longest to act - 4000 recurrent steps (64 s of audio, 20x BASELINE's
+    length), a batch of 32 (8224 sub-band rows: the persistent pair lstm_rec_in / lstm_rec_x at two row tiles per
+    workgroup, the kernels the headline is measured on), weights that drive the mask beyond the +-9.9 clamp - against the
+    fp64 oracle of one utterance from the middle of the batch."""
+    steps = 4000
+    params = O.make_params(seed=0, gain=2.0, mask_gain=24.0)
+    m = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=1, **MODEL_KW)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    m = m.cuda().eval()
+    plan = fsn._lib.core_plan(m._cfg, 32, 1 + steps)
+    assert plan["persistent_workgroups"] > 0 and plan["chunks"] == 1, plan
+    x = O.make_noisy(32, steps * 256, seed=6)
+    xd = dev(x)
+    row = 17
+    mag = fsn.stft(xd[row:row + 1], 512, 256, 512)[0].cpu().numpy()
+    # the oracle's pieces in fullsubnet_forward's order (fullsubnet/model.py:85-135), fp64; the sub-band model on 40 of
+    # the 257 independent rows (both edges with their reflected windows, and a spread over the spectrum)
+    f64 = np.float64
+    xp = np.pad(mag[:, None].astype(f64), [(0, 0), (0, 0), (0, 0), (0, 2)])
+    fb_out = O.sequence_model(O.offline_laplace_norm(xp, dtype=f64).reshape(1, 257, -1), params, "fb_model",
+                              activation="ReLU", dtype=f64).reshape(1, 1, 257, -1)
+    sb_in = np.concatenate([O.freq_unfold(xp, 15).reshape(1, 257, 31, -1), O.freq_unfold(fb_out, 0).reshape(1, 257, 1, -1)], axis=2)
+    sb_in = O.offline_laplace_norm(sb_in, dtype=f64)[0]
+    bins = sorted(set(list(range(0, 8)) + list(range(249, 257)) + list(range(8, 249, 10))))
+    want = O.sequence_model(np.ascontiguousarray(sb_in[bins]), params, "sb_model", activation=None, dtype=f64)[:, :, 2:]
+    want = want.transpose(1, 0, 2)[None]  # [1, 2, bins, T]
+    crm = m.enhance(xd, return_crm=True)[1][row:row + 1][:, :, bins].cpu().numpy().astype(np.float64)
+    d = np.abs(crm - want)
+    late = d[..., steps // 2:].max()
+    print(f"{steps} steps, batch 32 (plan {plan}): max |d cIRM| vs the fp64 oracle {d.max():.2e} (second half of the "
+          f"utterance {late:.2e}), rms {np.sqrt((d ** 2).mean()):.2e}, mask {want.min():.1f} .. {want.max():.1f}")
+    assert np.abs(want).max() > 9.9
+    assert d.max() <= 1e-4, d.max()
+    del xd
+    torch.cuda.empty_cache()
+
+
 def test_two_streams_and_two_host_threads_are_independent(fsn):
     """re-entrant across streams.  The library's only state is one record per (device, caller stream)
     (auxiliary stream + fork / join events for the left-over tiles, profiler events): two host threads, each on its

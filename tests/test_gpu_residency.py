@@ -293,6 +293,34 @@ def _rccl_worker(rank, world, port):
         again = model.enhance(x)
         work.wait()
         assert torch.equal(again, fused) and torch.equal(out, big)
+        # ... and issued by the caller on a SIDE stream, several in a row, while the persistent kernels (full-band chain +
+        # group kernel: 8 utterances x 190 steps, ~12 ms) are resident on the compute stream: RCCL's kernels vs the
+        # residency contract (include/fsn_hip.h) - results bit-equal, the two streams really overlapped, no time-out record
+        long_x = wav(8, 48000, 81)
+        want = model.enhance(long_x)
+        side, main = torch.cuda.Stream(), torch.cuda.current_stream()
+        outs = [torch.empty_like(big) for _ in range(6)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        torch.cuda.synchronize()
+        before = fsn._lib.persist_stats()[0]
+        ev[0].record(main)
+        side.wait_stream(main)
+        ev[3].record(main)
+        got = model.enhance(long_x)  # enqueued: ~12 ms of device time ahead of the host
+        ev[4].record(main)
+        with torch.cuda.stream(side):  # the collectives enter while those kernels run
+            ev[1].record(side)
+            for o in outs:
+                dist.all_gather_into_tensor(o, big)
+            ev[2].record(side)
+        main.wait_stream(side)
+        torch.cuda.synchronize()
+        assert fsn._lib.persist_stats()[0] - before >= 2, "the call must have run on the persistent launches"
+        assert torch.equal(got, want) and all(torch.equal(o, big) for o in outs)
+        t = [ev[0].elapsed_time(e) for e in ev]  # ms since ev[0]: collectives [t1, t2], model [t3, t4]
+        print(f"RCCL all-gathers on a side stream {t[1]:.2f} .. {t[2]:.2f} ms, persistent kernels {t[3]:.2f} .. {t[4]:.2f} ms")
+        assert t[1] < t[4] and t[3] < t[2], t  # the intervals intersect
+        assert fsn._lib.stream_status(x.device) == (0, 0)
         # DistributedDataParallel around Model (base_trainer.py:32): bucketed all-reduce hooks fire during backward,
         # beside the persistent BPTT kernels; gradients = the plain model's
         noisy, clean = wav(16, 8192, 5), 0.7 * wav(16, 8192, 6)
