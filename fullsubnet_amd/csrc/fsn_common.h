@@ -131,6 +131,32 @@ __device__ __forceinline__ f32x4 fsn_mma_k16(const typename FsnOperand<AR>::type
     }
 }
 
+// Two K = 16 blocks of the same product at once, as ONE K = 32 instruction of gfx950 (v_mfma_f32_16x16x32_{f16,bf16}: the
+// K = 16 shapes issue at half its rate there).  The matrix instruction sums a_lane(i, q)[j] b_lane(n, q)[j] over the four
+// lane groups q and the lane's elements j: as long as A and B give the same k to the same (q, j), ANY assignment of k to
+// (q, j) is the same contraction - so the eight values of a lane are simply block 0's four followed by block 1's, and the
+// result is fsn_mma_k16(a0, b0, fsn_mma_k16(a1, b1, c)) up to the order of the fp32 sums inside the instruction.
+typedef _Float16 fsn_f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 fsn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned fsn_u32x4 __attribute__((ext_vector_type(4)));
+template <int AR>
+__device__ __forceinline__ f32x4 fsn_mma_k32(const typename FsnOperand<AR>::type a0, const typename FsnOperand<AR>::type a1,
+                                             const typename FsnOperand<AR>::type b0, const typename FsnOperand<AR>::type b1,
+                                             f32x4 c) {
+    if constexpr (AR == FSN_ARITH_F16) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7),
+                                                      __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7), c, 0, 0, 0);
+    } else if constexpr (AR == FSN_ARITH_BF16) {
+        const fsn_u32x2 pa0 = __builtin_bit_cast(fsn_u32x2, a0), pa1 = __builtin_bit_cast(fsn_u32x2, a1);
+        const fsn_u32x2 pb0 = __builtin_bit_cast(fsn_u32x2, b0), pb1 = __builtin_bit_cast(fsn_u32x2, b1);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            __builtin_bit_cast(fsn_bf16x8, fsn_u32x4{pa0[0], pa0[1], pa1[0], pa1[1]}),
+            __builtin_bit_cast(fsn_bf16x8, fsn_u32x4{pb0[0], pb0[1], pb1[0], pb1[1]}), c, 0, 0, 0);
+    } else {
+        return fsn_mma_k16<AR>(a1, b1, fsn_mma_k16<AR>(a0, b0, c));
+    }
+}
+
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // Gate non-linearities of every LSTM forward kernel (persistent, per-step, wavefront) on the hardware transcendentals

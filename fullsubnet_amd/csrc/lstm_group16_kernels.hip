@@ -61,8 +61,10 @@ __device__ __forceinline__ fsn_u32x2 q_round4(const f32x4 v) {
 }
 template <int AR>
 __device__ __forceinline__ f32x4 q_mma2(const q_u32x4 a, const q_u32x4 b, f32x4 c) {  // one K block (32 k) of one tile
-    c = fsn_mma_k16<AR>(fsn_wfrag_operand<AR>(fsn_u32x2{a[0], a[1]}), fsn_wfrag_operand<AR>(fsn_u32x2{b[0], b[1]}), c);
-    return fsn_mma_k16<AR>(fsn_wfrag_operand<AR>(fsn_u32x2{a[2], a[3]}), fsn_wfrag_operand<AR>(fsn_u32x2{b[2], b[3]}), c);
+    // (round 5: ONE v_mfma_f32_16x16x32_{f16,bf16} - the lane's sixteen bytes ARE that instruction's operand - where
+    // rounds 3 - 4 issued two K = 16 instructions, which run at half its rate on gfx950)
+    return fsn_mma_k32<AR>(fsn_wfrag_operand<AR>(fsn_u32x2{a[0], a[1]}), fsn_wfrag_operand<AR>(fsn_u32x2{a[2], a[3]}),
+                           fsn_wfrag_operand<AR>(fsn_u32x2{b[0], b[1]}), fsn_wfrag_operand<AR>(fsn_u32x2{b[2], b[3]}), c);
 }
 __device__ __forceinline__ q_u32x4 q_lds128(const unsigned char* p) { return *reinterpret_cast<const q_u32x4*>(p); }
 
@@ -480,7 +482,19 @@ __global__ __launch_bounds__(256, 2) void lstm2_g16_fwd_kernel(const G16FwdArgs 
 constexpr int QAD = 4;                  // operand blocks in flight per wave (4 fragments each)
 constexpr int QWD = 4;                  // weight blocks in flight per wave (3 fragments each)
 template <int AR>
-__device__ __forceinline__ f32x4 q_mma_blk(const q_u32x4 a, const q_u32x4 b, f32x4 c) { return q_mma2<AR>(a, b, c); }
+// The BPTT kernel stays on the two K = 16 instructions per block (round 5): with fsn_mma_k32 here the same source gives layer-0
+// gate gradients that are 6e-2 off the exact emulation (tests/test_gpu_amp.py; the forward kernel and the weight-gradient
+// products pass with it, and tools/probe_k32.hip shows the instruction itself equal to the pair to 2e-6) - the kernel sits
+// at the 256-register limit with 6 spilled registers (10 with the wider operands), and the cause was not found in the
+// round.  -DFSN_G16_BWD_K32 builds the failing form.
+__device__ __forceinline__ f32x4 q_mma_blk(const q_u32x4 a, const q_u32x4 b, f32x4 c) {
+#ifdef FSN_G16_BWD_K32
+    return q_mma2<AR>(a, b, c);
+#else
+    c = fsn_mma_k16<AR>(fsn_wfrag_operand<AR>(fsn_u32x2{a[0], a[1]}), fsn_wfrag_operand<AR>(fsn_u32x2{b[0], b[1]}), c);
+    return fsn_mma_k16<AR>(fsn_wfrag_operand<AR>(fsn_u32x2{a[2], a[3]}), fsn_wfrag_operand<AR>(fsn_u32x2{b[2], b[3]}), c);
+#endif
+}
 
 struct G16BwdArgs {
     const float* dh1;      // [Tp][N][H]  d loss / d hseq1

@@ -363,20 +363,21 @@ __global__ __launch_bounds__(256) void gemm_tn16_kernel(const float* __restrict_
                                   __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tq_s16x4*)p));
     };
     auto compute = [&](int stage) {
+        // both k steps of the chunk as ONE K = 32 matrix instruction per tile (fsn_mma_k32: round 5)
+        typename FsnOperand<AR>::type a[2][6], b[2][6];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            typename FsnOperand<AR>::type a[6], b[6];
             const unsigned char* base = tq_lds + stage * TQ_STAGE + ks * 12 * TQ_TS + lane_off;
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                a[i] = tr(base + (wm * 6 + i) * TQ_TS);
-                b[i] = tr(base + TQ_OP + (wn * 6 + i) * TQ_TS);
+                a[ks][i] = tr(base + (wm * 6 + i) * TQ_TS);
+                b[ks][i] = tr(base + TQ_OP + (wn * 6 + i) * TQ_TS);
             }
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc[i][j] = fsn_mma_k16<AR>(a[i], b[j], acc[i][j]);
         }
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i][j] = fsn_mma_k32<AR>(a[0][i], a[1][i], b[0][j], b[1][j], acc[i][j]);
     };
     // chunk c lives in register set c % TQ_PF and LDS stage c & 1; rows beyond k_end (and whole chunks beyond the last) load zeros
 #pragma unroll
@@ -493,20 +494,19 @@ __global__ __launch_bounds__(WN * 128) void gemm_tn16h_kernel(const unsigned sho
                                   __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tq_s16x4*)p));
     };
     auto compute = [&](int stage) {
+        typename FsnOperand<AR>::type a[2][6], b[2][6];
+        const unsigned char* base = th_lds + stage * TH_STAGE + lane_off;  // column tile i of an operand block at + i * 512
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            typename FsnOperand<AR>::type a[6], b[6];
-            const unsigned char* base = th_lds + stage * TH_STAGE + lane_off;  // column tile i of an operand block at + i * 512
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                a[i] = tr(base + ks * 6 * 1024 + (wm * 6 + i) * 512);
-                b[i] = tr(base + B0 + ks * (NTB / 2) * 1024 + (wn * 6 + i) * 512);
+                a[ks][i] = tr(base + ks * 6 * 1024 + (wm * 6 + i) * 512);
+                b[ks][i] = tr(base + B0 + ks * (NTB / 2) * 1024 + (wn * 6 + i) * 512);
             }
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) acc[i][j] = fsn_mma_k16<AR>(a[i], b[j], acc[i][j]);
-        }
+            for (int j = 0; j < 6; ++j) acc[i][j] = fsn_mma_k32<AR>(a[0][i], a[1][i], b[0][j], b[1][j], acc[i][j]);
     };
     // TH_STAGES - 1 chunks in flight; the DMAs are invisible to the compiler's counter, so the waits are stated here: a
     // staging wave issues 6 per chunk, in order, and nothing else that counts
