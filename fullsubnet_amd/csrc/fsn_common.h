@@ -157,6 +157,14 @@ __device__ __forceinline__ f32x4 fsn_mma_k32(const typename FsnOperand<AR>::type
     }
 }
 
+// gfx950 / ROCm 7.2 (found in round 5, tools/diag_k32_bwd.py): a 16-byte-per-lane buffer store whose data registers are
+// written again a few issue slots later - hipcc placed a v_pk_add_f32 three slots and a v_mov_b32_dpp five slots behind a
+// buffer_store_dwordx4, more than its own hazard table asks for - stored the NEW values in the lanes whose data is read
+// last (lanes 12 - 15 of every 16), differently from run to run.  Whether the allocator re-uses the registers that early
+// is its own choice (the K = 16 build of the same source did not).  Call this right behind such a store when the value is
+// dead afterwards: the data registers stay allocated, and untouched, for a few more cycles.
+__device__ __forceinline__ void fsn_hold_store_data(const f32x4& v) { asm volatile("s_nop 7\n\ts_nop 7" ::"v"(v) : "memory"); }
+
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // Gate non-linearities of every LSTM forward kernel (persistent, per-step, wavefront) on the hardware transcendentals

@@ -482,19 +482,7 @@ __global__ __launch_bounds__(256, 2) void lstm2_g16_fwd_kernel(const G16FwdArgs 
 constexpr int QAD = 4;                  // operand blocks in flight per wave (4 fragments each)
 constexpr int QWD = 4;                  // weight blocks in flight per wave (3 fragments each)
 template <int AR>
-// The BPTT kernel stays on the two K = 16 instructions per block (round 5): with fsn_mma_k32 here the same source gives layer-0
-// gate gradients that are 6e-2 off the exact emulation (tests/test_gpu_amp.py; the forward kernel and the weight-gradient
-// products pass with it, and tools/probe_k32.hip shows the instruction itself equal to the pair to 2e-6) - the kernel sits
-// at the 256-register limit with 6 spilled registers (10 with the wider operands), and the cause was not found in the
-// round.  -DFSN_G16_BWD_K32 builds the failing form.
-__device__ __forceinline__ f32x4 q_mma_blk(const q_u32x4 a, const q_u32x4 b, f32x4 c) {
-#ifdef FSN_G16_BWD_K32
-    return q_mma2<AR>(a, b, c);
-#else
-    c = fsn_mma_k16<AR>(fsn_wfrag_operand<AR>(fsn_u32x2{a[0], a[1]}), fsn_wfrag_operand<AR>(fsn_u32x2{b[0], b[1]}), c);
-    return fsn_mma_k16<AR>(fsn_wfrag_operand<AR>(fsn_u32x2{a[2], a[3]}), fsn_wfrag_operand<AR>(fsn_u32x2{b[2], b[3]}), c);
-#endif
-}
+__device__ __forceinline__ f32x4 q_mma_blk(const q_u32x4 a, const q_u32x4 b, f32x4 c) { return q_mma2<AR>(a, b, c); }
 
 struct G16BwdArgs {
     const float* dh1;      // [Tp][N][H]  d loss / d hseq1
@@ -722,6 +710,7 @@ __device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, i
                 for (int g = 0; g < 4; ++g) {
                     if (LAYER == 0 || a.dg1_f32) q_store(ro, eo_g, (unsigned)(g * QH * 4 + j * 64), sg[j][g]);
                     __builtin_amdgcn_raw_buffer_store_b64(q_round4<AR>(sg[j][g]), r16, eo_16, (unsigned)((g * QH + j * 16) * 2), 0);
+                    fsn_hold_store_data(sg[j][g]);  // the sums below may be formed in the store's data registers
                     f32x4 v = sg[j][g];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {  // sum over the 16 lanes lr of this lane's group: quad xor 1, xor 2, half mirror, mirror

@@ -242,6 +242,21 @@ def test_built_library_holds_the_same_budget():
     assert 3 * gran(recx["vgpr_count"]) + gran(step["vgpr_count"]) <= 512 and recx["vgpr_spill_count"] <= 8, recx
 
 
+def test_no_early_rewrite_of_store_data_in_the_bptt_kernel():
+    """Round 5 (fsn_common.h: fsn_hold_store_data, tools/check_store_hazard.py): on gfx950 a 16-byte-per-lane store whose data
+    registers a vector instruction rewrites a few issue slots later - hipcc leaves two - stored the new values in some lanes
+    when the kernel's waves all store at once (lstm2_g16_bwd_kernel's burst of 24 stores per wave and step: layer-0 gate
+    gradients 6e-2 off, different from run to run).  The shipped library must not contain that pattern in that kernel."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_store_hazard", os.path.join(ROOT, "tools", "check_store_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(mod.OBJDUMP):
+        pytest.skip("llvm-objdump not available")
+    hits = [h for h in mod.scan(window=8) if "lstm2_g16_bwd_kernel" in h[0] and h[3].startswith("v_")]
+    assert not hits, hits[:4]
+
+
 def test_subband_multiplicity_closed_form():
     """offline_den_kernel (elementwise_kernels.hip) weighs bin f by m[f] = number of (unit, row) pairs of
     freq_unfold that read it; the kernel's closed form against the brute-force count over the reflect map."""
