@@ -427,7 +427,7 @@ def measured_counters():
     """PMC figures of the dominant kernel REPLAYED from the committed rocprofv3 passes (profiles/rNN_pmc.json, produced
     by tools/rocprof_pmc.py from separate --pmc runs of `bench.py` at config 2): HBM bytes per launch (FETCH_SIZE x 2
     on gfx950 + WRITE_SIZE) and the MFMA-busy fraction of the launch.  Not measured in this run - the keys say so."""
-    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_hbm_traffic_end.json"):
+    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_hbm_traffic_end.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)["dominant_kernel"]

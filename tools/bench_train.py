@@ -1,5 +1,6 @@
 """Time one training step (BASELINE config 3 per-rank shape: 16 x 3.072 s) on one MI355X.
-python tools/bench_train.py [batch] [f32|f16|bf16] [g16=0] [overlap=0]   (f16 / bf16: autocast arithmetic + GradScaler)"""
+python tools/bench_train.py [batch] [f32|f16|bf16] [g16=0] [overlap=0] [norm=cumulative]   (f16 / bf16: autocast arithmetic +
+GradScaler; norm=cumulative: the shipped train_cumulativeLaplaceNorm.toml's norm)"""
 import os
 import sys
 import time
@@ -16,7 +17,8 @@ ARITH = sys.argv[2] if len(sys.argv) > 2 else "f32"
 model = fullsubnet_amd.Model(num_freqs=257, look_ahead=2, sequence_model="LSTM", fb_num_neighbors=0,
                              sb_num_neighbors=15, fb_output_activate_function="ReLU",
                              sb_output_activate_function=False, fb_model_hidden_size=512, sb_model_hidden_size=384,
-                             norm_type="offline_laplace_norm", num_groups_in_drop_band=2, weight_init=False)
+                             norm_type="cumulative_laplace_norm" if "norm=cumulative" in sys.argv else "offline_laplace_norm",
+                             num_groups_in_drop_band=2, weight_init=False)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in make_params(seed=3).items()})
 model = model.cuda().train()
 model.train_arithmetic = ARITH

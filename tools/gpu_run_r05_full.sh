@@ -14,13 +14,14 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -- $B > $O/trace.log 2>
 DB=$(ls $O/trace/*/*.db 2>/dev/null | head -1)
 [ -n "$DB" ] && python tools/rocprof_summary.py $DB $O/kernel_stats_bench_b64.md "rocprofv3 --kernel-trace --stats -- $B" && python tools/rocprof_timeline.py $O/trace > $O/timeline.txt 2>&1
 rm -rf $O/trace
-for A in f32 f16; do
+for A in f32 f16 "f32 norm=cumulative"; do
   C="python tools/bench_train.py 16 $A"
-  timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_$A -- $C > $O/train_$A.txt 2>&1
-  DB=$(ls $O/trace_$A/*/*.db 2>/dev/null | head -1)
-  [ -n "$DB" ] && python tools/rocprof_summary.py $DB $O/kernel_stats_train_$A.md "rocprofv3 --kernel-trace --stats -- $C"
-  grep "train step" $O/train_$A.txt
-  rm -rf $O/trace_$A
+  N=$(echo $A | tr ' =' '__')
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_$N -- $C > $O/train_$N.txt 2>&1
+  DB=$(ls $O/trace_$N/*/*.db 2>/dev/null | head -1)
+  [ -n "$DB" ] && python tools/rocprof_summary.py $DB $O/kernel_stats_train_$N.md "rocprofv3 --kernel-trace --stats -- $C"
+  grep "train step" $O/train_$N.txt
+  rm -rf $O/trace_$N
 done
 for W in "fast 256" "improved48 32" "improved48 1"; do
   set -- $W
