@@ -486,6 +486,53 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                             for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[jj], b[u][jj], acc[rt][u]);
                     }
                 };
+                if constexpr ((OPT & 32768) != 0) {
+                    // APF: the first row tile's A fragment of block k + 1 is requested right behind block k's first-tile MFMAs
+                    // (into the registers they have just read) instead of at the head of block k + 1, where the block's first
+                    // MFMA waits for it; tiles 1 - 3 have the MFMAs before them to land
+                    auto lda = [&](int rt, int kofs) {
+                        return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((rt < 2 ? ha01 : ha23) + (rt & 1) * 16 * HS + kofs);
+                    };
+                    f32x4 apre = lda(0, 0);
+                    auto blk = [&](int kofs, const f32x4 (&b)[UG], bool more) {
+                        f32x4 av[RT];
+#pragma unroll
+                        for (int rt = 1; rt < RT; ++rt) av[rt] = lda(rt, kofs);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                            for (int u = 0; u < UG; ++u) acc[0][u] = mfma16(apre[jj], b[u][jj], acc[0][u]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more) apre = lda(0, kofs + 16);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int rt = 1; rt < RT; ++rt)
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                                for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[rt][jj], b[u][jj], acc[rt][u]);
+                    };
+#pragma unroll 1
+                    for (int hs = 0; hs < KC / 6; ++hs) {
+#pragma unroll
+                        for (int kk = 0; kk < 6; kk += 2) {
+                            const int kc = hs * 6 + kk;
+#pragma unroll
+                            for (int u = 0; u < UG; ++u) b1[u] = wload(wh[u] + (unsigned)(kc + 1) * 256u);
+                            __builtin_amdgcn_sched_barrier(0);
+                            blk(kk * 16, b0, true);
+                            __builtin_amdgcn_sched_barrier(0);
+                            const bool more_h = kc + 2 < KC;
+#pragma unroll
+                            for (int u = 0; u < UG; ++u) b0[u] = wload(more_h ? wh[u] + (unsigned)(kc + 2) * 256u : wxn[u]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            blk((kk + 1) * 16, b1, more_h);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        ha01 += 6 * 16;
+                        ha23 += 6 * 16;
+                    }
+                } else
 #pragma unroll 1
                 for (int hs = 0; hs < KC / 6; ++hs) {
 #pragma unroll
@@ -637,7 +684,7 @@ __device__ __forceinline__ void lds_dma_fragment(const float* g, unsigned lds_ba
 #define FSN_REC_X_OPT (64 | 256)
 #endif
 #ifndef FSN_REC_IN_OPT
-#define FSN_REC_IN_OPT (4096 | 256)
+#define FSN_REC_IN_OPT (4096 | 256 | 32768)  // + 32768: the next block's first-tile A fragment requested a block early: 27.78 -> 27.40 ms (nothing in layer 1: 20 spilled registers)
 #endif
 #ifndef FSN_REC_VCAP
 #define FSN_REC_VCAP 76  // x 2 on gfx950's unified register file = 152: three waves per SIMD + room for a step workgroup
@@ -794,6 +841,30 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
         }
     };
 
+    // APF (ABL & 32768): block k's first row tile comes from `apre`, requested a block earlier - right behind block k - 1's
+    // first-tile MFMAs, into the registers they had just read - instead of at the head of block k, where the block's first
+    // MFMA waited for it; tiles 1 - 3 have the MFMAs before them to land (lstm_rec_in_kernel: -0.37 ms)
+    constexpr bool APF = (ABL & 32768) != 0;
+    f32x4 apre = {0.f, 0.f, 0.f, 0.f};
+    auto mma_pf = [&](f32x4 (&acc)[RT][UG], const float* a, int a_rt_stride, const f32x4 (&b)[UG], const float* next) {
+        f32x4 av[RT];
+#pragma unroll
+        for (int rt = 1; rt < RT; ++rt) av[rt] = *reinterpret_cast<const f32x4*>(a + rt * a_rt_stride);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int u = 0; u < UG; ++u) acc[0][u] = mfma16(apre[jj], b[u][jj], acc[0][u]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (next) apre = *reinterpret_cast<const f32x4*>(next);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 1; rt < RT; ++rt)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[rt][jj], b[u][jj], acc[rt][u]);
+    };
+
     for (int t = 0; t < Tp; ++t) {
         // gate order of evaluation: f (1), i (0), g (2), o (3)
 #pragma unroll
@@ -844,6 +915,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const float* xa = xs + ((j & 1) * NF) * 256 + lane * 4;
+                if (APF) apre = *reinterpret_cast<const f32x4*>(xa);  // a slice's first block: its stage has only just been released
 #pragma unroll
                 for (int kk = 0; kk < SK; kk += 2) {
                     const int kc = sl * SK + kk;
@@ -851,7 +923,8 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                     for (int u = 0; u < UG; ++u)
                         b1[u] = wload(wx[u] + (unsigned)(kc + 1) * 256u);
                     __builtin_amdgcn_sched_barrier(0);  // requests first, pinned: hipcc otherwise sinks them to their use
-                    if (BEP && kk == 0 && sl == 0) mma0(acc, xa + kk * 256, SK * 256, b0);
+                    if (APF) mma_pf(acc, xa + kk * 256, SK * 256, b0, xa + (kk + 1) * 256);
+                    else if (BEP && kk == 0 && sl == 0) mma0(acc, xa + kk * 256, SK * 256, b0);
                     else mma(acc, xa + kk * 256, SK * 256, b0);
                     if (KOPT && !(ABL & 8192)) __builtin_amdgcn_sched_barrier(0);
                     // chunk kc + 2: W_ih, or the first chunk of W_hh, or (h_{-1} = 0: no W_hh product) of the next pass
@@ -861,7 +934,15 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                         b0[u] = wload(more_x ? wx[u] + (unsigned)(kc + 2) * 256u : (t > 0 ? wh[u] : wxn[u]));
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    mma(acc, xa + (kk + 1) * 256, SK * 256, b1);
+                    if (APF) {
+                        // next: the slice's next block; behind a slice's last block the next stage is not released yet (its
+                        // barrier comes first) - except behind the LAST slice, where the recurrent product's first block
+                        // follows (the hidden state is stable through the step)
+                        const float* nx = kk + 2 < SK ? xa + (kk + 2) * 256 : ((sl + 1 == NSL && t > 0) ? hl + lr * HS + 4 * lq : nullptr);
+                        mma_pf(acc, xa + (kk + 1) * 256, SK * 256, b1, nx);
+                    } else {
+                        mma(acc, xa + (kk + 1) * 256, SK * 256, b1);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -925,14 +1006,16 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                     for (int u = 0; u < UG; ++u)
                         b1[u] = wload(wh[u] + (unsigned)(kc + 1) * 256u);
                     __builtin_amdgcn_sched_barrier(0);
-                    mma(acc, ha + kc * 16, 16 * HS, b0);
+                    if (APF) mma_pf(acc, ha + kc * 16, 16 * HS, b0, ha + (kc + 1) * 16);
+                    else mma(acc, ha + kc * 16, 16 * HS, b0);
                     const bool more_h = kc + 2 < KC;
 #pragma unroll
                     for (int u = 0; u < UG; ++u) {
                         b0[u] = wload(more_h ? wh[u] + (unsigned)(kc + 2) * 256u : wxn[u]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    mma(acc, ha + (kc + 1) * 16, 16 * HS, b1);
+                    if (APF) mma_pf(acc, ha + (kc + 1) * 16, 16 * HS, b1, more_h ? ha + (kc + 2) * 16 : nullptr);
+                    else mma(acc, ha + (kc + 1) * 16, 16 * HS, b1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }

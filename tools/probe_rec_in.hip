@@ -73,9 +73,9 @@ int main(int argc, char** argv) {
         printf("  %-58s: %.3f ms   max |d| vs shipped %.3e\n", NAME, ms, check());   \
     }
     VARIANT("4096 + 256 (the library's form)", 4096 + 256)
-    VARIANT("4096 + 256 + k-step major MFMA order (16384)", 4096 + 256 + 16384)
+    VARIANT("4096 + 256 + A fragment of the next block's first tile requested early (32768)", 4096 + 256 + 32768)
     VARIANT("4096 + 256", 4096 + 256)
-    VARIANT("4096 + 256 + 16384", 4096 + 256 + 16384)
+    VARIANT("4096 + 256 + 32768", 4096 + 256 + 32768)
     VARIANT("shipped once more", 0)
     return 0;
 }

@@ -78,11 +78,9 @@ int main(int argc, char** argv) {
         printf("  %-58s: %.3f ms   max |d| vs shipped %.3e\n", NAME, ms, check());     \
     }
     VARIANT("64 + 256 (the library's form)", 320)
-    VARIANT("64 + 256 + k-step major MFMA order (16384)", 320 + 16384)
-    VARIANT("64 + 256 + 4096 + 16384", 320 + 4096 + 16384)
-    VARIANT("shipped r04", 0)
+    VARIANT("64 + 256 + first-tile A fragment requested a block early (32768)", 320 + 32768)
     VARIANT("64 + 256", 320)
-    VARIANT("64 + 256 + 16384", 320 + 16384)
+    VARIANT("64 + 256 + 32768", 320 + 32768)
     VARIANT("shipped once more", 0)
     return 0;
 }
