@@ -81,7 +81,12 @@ class TrainDims(ctypes.Structure):  # fsn_train_dims
                 ("nb", ctypes.c_int), ("groups", ctypes.c_int), ("norm", ctypes.c_int)]
 
 
-ABI_VERSION = 110  # FSN_ABI_VERSION of include/fsn_hip.h these signatures were written against
+ABI_VERSION = 111  # FSN_ABI_VERSION of include/fsn_hip.h these signatures were written against
+
+
+class MaskSection(ctypes.Structure):  # fsn_mask_section
+    _fields_ = [("o", ctypes.c_void_p), ("Np", ctypes.c_int), ("ld", ctypes.c_int), ("lower", ctypes.c_int),
+                ("units", ctypes.c_int), ("center", ctypes.c_int)]
 
 
 class Params(ctypes.Structure):
@@ -218,6 +223,11 @@ SIGNATURES = {
     "fsn_debug_tn_plan": (_c.c_int, [_c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "fsn_debug_core_chunks": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int]),
     "fsn_debug_core_plan": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int]),
+    "fsn_improved_front": (_c.c_int, [_f32p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_void_p]),
+    "fsn_bft_to_rows": (_c.c_int, [_f32p, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_int, _c.c_int, _c.c_void_p]),
+    "fsn_rows_to_bft": (_c.c_int, [_f32p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _f32p, _c.c_void_p]),
+    "fsn_improved_mask_apply": (_c.c_int, [_c.c_int, _c.c_void_p, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_int, _f32p, _f32p,
+                                           _c.c_void_p]),
     "fsn_profile_num_stages": (_c.c_int, []),
     "fsn_profile_stage_name": (_c.c_char_p, [_c.c_int]),
     "fsn_profile_read": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_float), _c.c_int]),

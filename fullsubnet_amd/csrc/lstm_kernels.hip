@@ -865,6 +865,37 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[rt][jj], b[u][jj], acc[rt][u]);
     };
 
+    // ROLL (ABL & 65536, RT = 4): TWO fragment registers sets instead of four - tiles 0 / 1 of a block arrive prefetched,
+    // tile 2 is requested into tile 0's registers right behind tile 0's MFMAs, tile 3 into tile 1's, then the next block's
+    // tiles 0 / 1 behind tiles 2 / 3: every A fragment is requested one tile slot (256 matrix cycles) before its first use,
+    // and eight registers are free
+    constexpr bool ROLL = (ABL & 65536) != 0 && RT == 4;
+    f32x4 fa = {0.f, 0.f, 0.f, 0.f}, fb = {0.f, 0.f, 0.f, 0.f};
+    auto mma_roll = [&](f32x4 (&acc)[RT][UG], const float* a, int a_rt_stride, const f32x4 (&b)[UG], const float* next,
+                        int next_rt_stride) {
+        auto tile = [&](int rt, const f32x4 av) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[jj], b[u][jj], acc[rt][u]);
+        };
+        tile(0, fa);
+        __builtin_amdgcn_sched_barrier(0);
+        fa = *reinterpret_cast<const f32x4*>(a + 2 * a_rt_stride);
+        __builtin_amdgcn_sched_barrier(0);
+        tile(1, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        fb = *reinterpret_cast<const f32x4*>(a + 3 * a_rt_stride);
+        __builtin_amdgcn_sched_barrier(0);
+        tile(2, fa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (next) fa = *reinterpret_cast<const f32x4*>(next);
+        __builtin_amdgcn_sched_barrier(0);
+        tile(3, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (next) fb = *reinterpret_cast<const f32x4*>(next + next_rt_stride);
+    };
+
     for (int t = 0; t < Tp; ++t) {
         // gate order of evaluation: f (1), i (0), g (2), o (3)
 #pragma unroll
@@ -916,6 +947,10 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 }
                 const float* xa = xs + ((j & 1) * NF) * 256 + lane * 4;
                 if (APF) apre = *reinterpret_cast<const f32x4*>(xa);  // a slice's first block: its stage has only just been released
+                if (ROLL) {
+                    fa = *reinterpret_cast<const f32x4*>(xa);
+                    fb = *reinterpret_cast<const f32x4*>(xa + SK * 256);
+                }
 #pragma unroll
                 for (int kk = 0; kk < SK; kk += 2) {
                     const int kc = sl * SK + kk;
@@ -923,7 +958,8 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                     for (int u = 0; u < UG; ++u)
                         b1[u] = wload(wx[u] + (unsigned)(kc + 1) * 256u);
                     __builtin_amdgcn_sched_barrier(0);  // requests first, pinned: hipcc otherwise sinks them to their use
-                    if (APF) mma_pf(acc, xa + kk * 256, SK * 256, b0, xa + (kk + 1) * 256);
+                    if (ROLL) mma_roll(acc, xa + kk * 256, SK * 256, b0, xa + (kk + 1) * 256, SK * 256);
+                    else if (APF) mma_pf(acc, xa + kk * 256, SK * 256, b0, xa + (kk + 1) * 256);
                     else if (BEP && kk == 0 && sl == 0) mma0(acc, xa + kk * 256, SK * 256, b0);
                     else mma(acc, xa + kk * 256, SK * 256, b0);
                     if (KOPT && !(ABL & 8192)) __builtin_amdgcn_sched_barrier(0);
@@ -934,7 +970,11 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                         b0[u] = wload(more_x ? wx[u] + (unsigned)(kc + 2) * 256u : (t > 0 ? wh[u] : wxn[u]));
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (APF) {
+                    if (ROLL) {
+                        const bool to_h = sl + 1 == NSL && t > 0;
+                        const float* nx = kk + 2 < SK ? xa + (kk + 2) * 256 : (to_h ? hl + lr * HS + 4 * lq : nullptr);
+                        mma_roll(acc, xa + (kk + 1) * 256, SK * 256, b1, nx, kk + 2 < SK ? SK * 256 : 16 * HS);
+                    } else if (APF) {
                         // next: the slice's next block; behind a slice's last block the next stage is not released yet (its
                         // barrier comes first) - except behind the LAST slice, where the recurrent product's first block
                         // follows (the hidden state is stable through the step)
@@ -1006,7 +1046,8 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                     for (int u = 0; u < UG; ++u)
                         b1[u] = wload(wh[u] + (unsigned)(kc + 1) * 256u);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (APF) mma_pf(acc, ha + kc * 16, 16 * HS, b0, ha + (kc + 1) * 16);
+                    if (ROLL) mma_roll(acc, ha + kc * 16, 16 * HS, b0, ha + (kc + 1) * 16, 16 * HS);
+                    else if (APF) mma_pf(acc, ha + kc * 16, 16 * HS, b0, ha + (kc + 1) * 16);
                     else mma(acc, ha + kc * 16, 16 * HS, b0);
                     const bool more_h = kc + 2 < KC;
 #pragma unroll
@@ -1014,7 +1055,8 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                         b0[u] = wload(more_h ? wh[u] + (unsigned)(kc + 2) * 256u : wxn[u]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (APF) mma_pf(acc, ha + (kc + 1) * 16, 16 * HS, b1, more_h ? ha + (kc + 2) * 16 : nullptr);
+                    if (ROLL) mma_roll(acc, ha + (kc + 1) * 16, 16 * HS, b1, more_h ? ha + (kc + 2) * 16 : nullptr, 16 * HS);
+                    else if (APF) mma_pf(acc, ha + (kc + 1) * 16, 16 * HS, b1, more_h ? ha + (kc + 2) * 16 : nullptr);
                     else mma(acc, ha + (kc + 1) * 16, 16 * HS, b1);
                     __builtin_amdgcn_sched_barrier(0);
                 }

@@ -137,3 +137,155 @@ int fsn_launch_section_input(const float* noisy, const float* fb, int B, int F, 
     hipLaunchKernelGGL(section_gather_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)Np), dim3(256), lds, s, a, den, out, Np, ldo);
     return fsn_check_launch("section_gather_kernel");
 }
+
+// ---- round 5: the glue AROUND the models of the composed families as kernels -------------------------------------------------
+// Improved FullSubNet's forward (improved_fullsubnet/model.py:541-591) still ran 21 tensor-algebra launches of the host
+// framework per call (tools/diag_aten_ops.py): mag ** fdrc, the last-bin slice (a non-contiguous view that every consumer
+// copied: eight times), the [B, F, T] <-> time-major transposes around a SequenceModel, the sections' output re-ordering,
+// cat, F.pad and the two mask products.  Four kernels, all pure data movement + the same IEEE operations (sqrtf, one
+// multiply): bit-identical to the tensor algebra.
+namespace {
+
+// out [B][F - 1][T] = mag[b][f][t] ** fdrc for fdrc = 0.5 (sqrtf: what torch.pow dispatches to for that exponent) or 1
+__global__ __launch_bounds__(256) void improved_front_kernel(const float* __restrict__ mag, float* __restrict__ out, int B, int F, int T,
+                                                            int mode) {
+    const long n = (long)B * (F - 1) * T;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long row = i / T;
+        const int t = (int)(i - row * T);
+        const long b = row / (F - 1), f = row - b * (F - 1);
+        const float v = mag[(b * F + f) * T + t];
+        out[i] = mode ? sqrtf(v) : v;
+    }
+}
+// h [T][Np][Ip] = x[b][f][t] (zero for b >= B, f >= F): 32 x 32 tiles through LDS, both sides coalesced
+__global__ __launch_bounds__(256) void bft_to_rows_kernel(const float* __restrict__ x, float* __restrict__ h, int B, int F, int T, int Np,
+                                                         int Ip) {
+    __shared__ float tile[32][33];
+    const int t0 = blockIdx.x * 32, f0 = blockIdx.y * 32, b = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int f = f0 + i, t = t0 + tx;
+        tile[i][tx] = (b < B && f < F && t < T) ? x[((long)b * F + f) * T + t] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, f = f0 + tx;
+        if (t < T && f < Ip) h[((long)t * Np + b) * Ip + f] = tile[tx][i];
+    }
+}
+// y [B][O][T] = o[t][b][c] (o: [T][Np][ld])
+__global__ __launch_bounds__(256) void rows_to_bft_kernel(const float* __restrict__ o, float* __restrict__ y, int T, int Np, int ld, int B,
+                                                         int O) {
+    __shared__ float tile[32][33];
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32, b = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, c = c0 + tx;
+        tile[i][tx] = (t < T && c < O) ? o[((long)t * Np + b) * ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, t = t0 + tx;
+        if (c < O && t < T) y[((long)b * O + c) * T + t] = tile[tx][i];
+    }
+}
+struct MaskSections {
+    fsn_mask_section s[8];
+    int n;
+};
+// bins no section covers (the last bin: model.py:566, 575 F.pad): zero in both planes
+__global__ __launch_bounds__(256) void mask_zero_uncovered_kernel(const MaskSections ms, float* __restrict__ er, float* __restrict__ ei,
+                                                                 int F, int T) {
+    const int f = blockIdx.x, b = blockIdx.y;
+    for (int i = 0; i < ms.n; ++i)
+        if (f >= ms.s[i].lower && f < ms.s[i].lower + ms.s[i].units * ms.s[i].center) return;
+    const long base = ((long)b * F + f) * T;
+    for (int t = threadIdx.x; t < T; t += 256) er[base + t] = 0.f, ei[base + t] = 0.f;
+}
+// one section: o [T][Np][ld], row b units + u, column comp center + cc  ->  er / ei [B][F][T] at bin lower + u center + cc,
+// times the noisy real / imaginary part (model.py:576-577: no complex product).  A workgroup = 8 rows x 32 frames.
+__global__ __launch_bounds__(256) void mask_apply_kernel(const fsn_mask_section sec, const float* __restrict__ real,
+                                                        const float* __restrict__ imag, float* __restrict__ er, float* __restrict__ ei,
+                                                        int B, int F, int T) {
+    extern __shared__ float tile[];  // [32 frames][R rows * ld + 1], R = rows per workgroup (8 for narrow sections, fewer for wide)
+    if (blockIdx.z != 0) return;
+    const int R = (int)gridDim.z;  // rows per workgroup, carried in gridDim.z (1 .. 8)
+    const int W = 2 * sec.center, pitch = R * sec.ld + 1;
+    const int t0 = blockIdx.x * 32, r0 = blockIdx.y * R;
+    const int rows = B * sec.units;
+    const int nt = T - t0 < 32 ? T - t0 : 32;
+    const float* o = static_cast<const float*>(sec.o);
+    for (int i = threadIdx.x; i < nt * R * sec.ld; i += 256) {  // R rows x ld columns are contiguous for a frame
+        const int tt = i / (R * sec.ld), j = i - tt * (R * sec.ld);
+        tile[tt * pitch + j] = (r0 + j / sec.ld < sec.Np) ? o[((long)(t0 + tt) * sec.Np + r0) * sec.ld + j] : 0.f;
+    }
+    __syncthreads();
+    const int tt = threadIdx.x & 31;
+    for (int p = threadIdx.x >> 5; p < R * W; p += 8) {  // (row, column) pairs, 32 frames each: 128-byte runs in the planes
+        const int rr = p / W, col = p - rr * W, row = r0 + rr;
+        if (row >= rows || tt >= nt) continue;
+        const int b = row / sec.units, u = row - b * sec.units;
+        const int comp = col / sec.center, cc = col - comp * sec.center;
+        const long idx = ((long)b * F + sec.lower + u * sec.center + cc) * T + t0 + tt;
+        const float m = tile[tt * pitch + rr * sec.ld + col];
+        if (comp == 0) er[idx] = m * real[idx];
+        else ei[idx] = m * imag[idx];
+    }
+}
+
+}  // namespace
+
+extern "C" int fsn_improved_front(const float* mag, int B, int F, int T, int sqrt_mode, float* out, void* stream) {
+    FsnCallScope scope(stream);
+    FSN_REQUIRE(mag && out && B >= 1 && F >= 2 && T >= 1 && (sqrt_mode == 0 || sqrt_mode == 1), "improved front: bad arguments");
+    const long n = (long)B * (F - 1) * T;
+    const long g = (n + 255) / 256;
+    hipLaunchKernelGGL(improved_front_kernel, dim3((unsigned)(g < 4096 ? g : 4096)), dim3(256), 0, static_cast<hipStream_t>(stream), mag, out,
+                       B, F, T, sqrt_mode);
+    return fsn_check_launch("improved_front_kernel");
+}
+extern "C" int fsn_bft_to_rows(const float* x, int B, int F, int T, float* h, int Np, int Ip, void* stream) {
+    FsnCallScope scope(stream);
+    FSN_REQUIRE(x && h && B >= 1 && F >= 1 && T >= 1 && Np >= B && Ip >= F && Np <= 65535, "bft_to_rows: bad arguments");
+    hipLaunchKernelGGL(bft_to_rows_kernel, dim3((unsigned)((T + 31) / 32), (unsigned)((Ip + 31) / 32), (unsigned)Np), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, h, B, F, T, Np, Ip);
+    return fsn_check_launch("bft_to_rows_kernel");
+}
+extern "C" int fsn_rows_to_bft(const float* o, int T, int Np, int ld, int B, int O, float* y, void* stream) {
+    FsnCallScope scope(stream);
+    FSN_REQUIRE(o && y && B >= 1 && O >= 1 && T >= 1 && Np >= B && ld >= O && B <= 65535, "rows_to_bft: bad arguments");
+    hipLaunchKernelGGL(rows_to_bft_kernel, dim3((unsigned)((T + 31) / 32), (unsigned)((O + 31) / 32), (unsigned)B), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), o, y, T, Np, ld, B, O);
+    return fsn_check_launch("rows_to_bft_kernel");
+}
+extern "C" int fsn_improved_mask_apply(int n, const fsn_mask_section* sections, const float* real, const float* imag, int B, int F, int T,
+                                       float* er, float* ei, void* stream) {
+    FsnCallScope scope(stream);
+    FSN_REQUIRE(n >= 1 && n <= 8 && sections && real && imag && er && ei && B >= 1 && F >= 1 && T >= 1 && B <= 65535,
+                "improved mask apply: 1 .. 8 sections, non-NULL planes");
+    MaskSections ms{};
+    ms.n = n;
+    for (int i = 0; i < n; ++i) {
+        const fsn_mask_section& q = sections[i];
+        FSN_REQUIRE(q.o && q.center >= 1 && q.units >= 0 && q.lower >= 0 && q.lower + q.units * q.center <= F && q.ld >= 2 * q.center &&
+                        q.ld <= 512 && q.Np >= B * q.units,
+                    "improved mask apply: section %d out of range", i);
+        ms.s[i] = q;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mask_zero_uncovered_kernel, dim3((unsigned)F, (unsigned)B), dim3(256), 0, s, ms, er, ei, F, T);
+    FSN_TRY_LAUNCH("mask_zero_uncovered_kernel");
+    for (int i = 0; i < n; ++i) {
+        const fsn_mask_section& q = ms.s[i];
+        if (q.units == 0) continue;
+        int R = 512 / q.ld;  // rows per workgroup: at most 512 floats per frame in the tile (64 KB of LDS)
+        R = R > 8 ? 8 : (R < 1 ? 1 : R);
+        const size_t lds = (size_t)32 * (R * q.ld + 1) * sizeof(float);
+        // gridDim.z carries R (only blockIdx.z == 0 works: the others return at once)
+        hipLaunchKernelGGL(mask_apply_kernel, dim3((unsigned)((T + 31) / 32), (unsigned)((B * q.units + R - 1) / R), (unsigned)R), dim3(256), lds, s,
+                           q, real, imag, er, ei, B, F, T);
+        FSN_TRY_LAUNCH("mask_apply_kernel");
+    }
+    return FSN_OK;
+}

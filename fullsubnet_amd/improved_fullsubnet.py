@@ -5,8 +5,9 @@ F - 1 bins and *banded* sub-band LSTMs (finer-to-coarser: section i moves over i
 without decompression.
 
 STFT / iSTFT (any n_fft / hop: 512 / 128 at 16 kHz, 960 / 480 at 48 kHz) and every LSTM / Linear block
-run on libfsn_hip.so; power law, strided unfold, concat, norms and the complex product are
-tensor-algebra glue.  Parameter names follow the reference (``fb_model.*``, ``sb_model.sb_models.{i}.*``).
+run on libfsn_hip.so; in inference (``Model._forward_kernels``, round 5) so do power law, last-bin slice, norms, the sections'
+inputs and the mask products - no tensor-algebra launch of the host framework is left in a call; the tensor-algebra forward
+below it is what autograd records in training and what the unit-sharded and odd configurations run.  Parameter names follow the reference (``fb_model.*``, ``sb_model.sb_models.{i}.*``).
 """
 import torch
 import torch.nn as nn
@@ -220,10 +221,13 @@ class SubbandModel(BaseModel):
             return noisy_input.new_zeros((noisy_input.size(0), 2, 0, noisy_input.size(-1)))
         return self.sb_models[sb_idx](sb_model_input)
 
-    def _run_sections(self, noisy_input, fb_output, units):
-        """All sections, ``units[i]`` = None or the unit range of section i -> list of [B, 2, n_i c_i, T]."""
+    def _run_sections(self, noisy_input, fb_output, units, rows_out=False):
+        """All sections, ``units[i]`` = None or the unit range of section i -> list of [B, 2, n_i c_i, T]; ``rows_out``
+        (inference on prepared inputs only): the sections' outputs as their output layers wrote them, [T, Np_i, 2 c_i]
+        time-major - what fsn_improved_mask_apply takes."""
         num = len(self.sb_models)
         if torch.is_grad_enabled() or not noisy_input.is_cuda:
+            assert not rows_out
             return [self._section(noisy_input, fb_output, i, units[i]) for i in range(num)]
         # inference: the sections are independent two-layer stacks over the same frames.  When together they fill the
         # chip's workgroup sets (batches around 32 at 48 kHz) they run as ONE persistent launch of the group kernel with
@@ -245,7 +249,9 @@ class SubbandModel(BaseModel):
                     h[:, :B * span[i], :widths[i]] = x.permute(2, 0, 1)
                     p = (h, B * span[i])
                 prepared.append(p)
-            outs = multi_forward([self.sb_models[i] for i in live], prepared=prepared)
+            outs = multi_forward([self.sb_models[i] for i in live], prepared=prepared, rows_out=rows_out)
+            if rows_out:  # [T, Np, 2 c] as the output layers wrote them, per section (None: no unit of it here)
+                return [outs[live.index(i)] if i in live else None for i in range(num)]
             result = []
             for i in range(num):
                 if i not in live:
@@ -282,7 +288,12 @@ class SubbandModel(BaseModel):
         for i in order:
             with torch.cuda.stream(stream_of[i]):
                 if inputs[i] is None:
+                    if rows_out:
+                        subband_output[i] = None
+                        continue
                     out = noisy_input.new_zeros((B, 2, 0, T))
+                elif isinstance(inputs[i], tuple) and rows_out:
+                    out = self.sb_models[i].forward_time_major(*inputs[i], rows_out=True)
                 elif isinstance(inputs[i], tuple):
                     out = self._wrap_output(self.sb_models[i].forward_time_major(*inputs[i]), B, span[i])
                 else:
@@ -380,6 +391,55 @@ class Model(BaseModel):
             cache[key] = best
         return cache[key]
 
+    def _glue_on_kernels(self, y, unit_group):
+        """Inference on the GPU with the configuration of the shipped use (fdrc 0.5 or 1, offline Laplace norm, LSTM blocks):
+        the forward below without a single tensor-algebra launch of the host framework (round 5)."""
+        sb = self.sb_model
+        return (getattr(self, "glue_kernels", True) and unit_group is None and y.is_cuda and not torch.is_grad_enabled()
+                and y.dtype == torch.float32 and self.fdrc in (0.5, 1.0) and sb.norm_type == "offline_laplace_norm"
+                and self.norm == self.offline_laplace_norm and self.fb_model.cell == "LSTM"
+                and all(m.cell == "LSTM" and m.output_size for m in sb.sb_models)
+                and max(2 * c for c in sb.sb_num_center_freqs) <= 512)
+
+    def _forward_kernels(self, y, mag, real, imag):
+        """model.py:541-591 with every step between the transforms and the LSTM / Linear entries on kernels of the library:
+        fsn_improved_front (mag ** fdrc, last bin left out), fsn_norm, fsn_bft_to_rows / fsn_rows_to_bft around the
+        full-band model, fsn_improved_section_input per section, fsn_improved_mask_apply (the sections' outputs into the
+        two masked planes, last bin zero).  Bit-identical to the tensor-algebra forward (tests/test_gpu_family.py)."""
+        import ctypes
+        from . import _lib
+        from .sequence_model import from_rows, to_rows
+        L = _lib.lib()
+        dev = y.device
+        st = _lib.stream_ptr(dev)
+        B, F, T = mag.shape
+        Fm = F - 1
+        noisy_mag = torch.empty((B, 1, Fm, T), dtype=torch.float32, device=dev)
+        _lib.check(L.fsn_improved_front(_lib.dev_ptr(mag, "mag"), B, F, T, 1 if self.fdrc == 0.5 else 0, _lib.dev_ptr(noisy_mag), st))
+        fb_in = self.norm(noisy_mag).reshape(B, Fm, T)                                  # fsn_norm (contiguous: no copy)
+        fb_rows = self.fb_model.forward_time_major(to_rows(fb_in), B, rows_out=True)     # [T, Np, Fm]
+        fb_output = from_rows(fb_rows, B).reshape(B, 1, Fm, T)
+        sb = self.sb_model
+        outs = sb._run_sections(noisy_mag, fb_output, [None] * len(sb.sb_models), rows_out=True)
+        secs = (_lib.MaskSection * len(outs))()
+        keep, n = [], 0
+        n_units = sb.num_units(Fm)
+        for i, o in enumerate(outs):
+            if o is None:
+                continue
+            if o.dim() != 3 or o.stride(2) != 1 or o.stride(0) != o.shape[1] * o.stride(1):
+                o = o.contiguous()
+            keep.append(o)
+            q = secs[n]
+            q.o, q.Np, q.ld = o.data_ptr(), o.shape[1], o.stride(1)
+            q.lower, q.units, q.center = sb._band(i, Fm)[0], n_units[i], sb.sb_num_center_freqs[i]
+            n += 1
+        er, ei = torch.empty_like(real), torch.empty_like(imag)
+        _lib.check(L.fsn_improved_mask_apply(n, ctypes.byref(secs), _lib.dev_ptr(real, "real"), _lib.dev_ptr(imag, "imag"), B, F, T,
+                                             _lib.dev_ptr(er), _lib.dev_ptr(ei), st))
+        enhanced = istft((er, ei), self.n_fft, self.hop_length, self.win_length, length=y.size(-1), input_type="real_imag")
+        return enhanced.unsqueeze(1)
+
     def forward(self, y, unit_group=None):
         """model.py:541-591: y [B, L] or [B, 1, L] -> enhanced [B, 1, L].  ``unit_group``: shard the sub-band units
         over that process group (every rank gets the same ``y`` and returns the same result; for fewer utterances
@@ -396,6 +456,8 @@ class Model(BaseModel):
             if c and y.size(0) > c:
                 return torch.cat([self.forward(y[i:i + c]) for i in range(0, y.size(0), c)], dim=0)
         mag, _, real, imag = stft(y, self.n_fft, self.hop_length, self.win_length, return_phase=False)  # [B, F, T] each
+        if self._glue_on_kernels(y, unit_group):
+            return self._forward_kernels(y, mag, real, imag)
         noisy_mag = mag.unsqueeze(1) ** self.fdrc
         noisy_mag = noisy_mag[..., :-1, :]  # the last bin is left out (model.py:566) and masked with 0 below
         B, _, Fm, T = noisy_mag.shape

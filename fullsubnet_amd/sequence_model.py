@@ -105,6 +105,33 @@ def linear_infer(x2, w, b, relu):
     return y
 
 
+def to_rows(x):
+    """x [B, F, T] (inference, fp32, on the GPU) -> h [T, Np, Ip] time-major, zero beyond (B, F): the layout every LSTM /
+    Linear entry takes (fsn_bft_to_rows: one transposing kernel instead of a fill and a strided copy of the host framework)."""
+    B, F, T = x.shape
+    Np, Ip = _round_up(B, 16), _round_up(F, 16)
+    x = x if x.is_contiguous() else x.contiguous()
+    h = torch.empty((T, Np, Ip), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().fsn_bft_to_rows(_lib.dev_ptr(x, "x"), B, F, T, _lib.dev_ptr(h), Np, Ip, _lib.stream_ptr(x.device)))
+    return h
+
+
+def from_rows(o, B):
+    """o [T, Np, O] time-major as an entry wrote it (or a column slice of it: row stride o.stride(1)) -> [B, O, T] contiguous
+    (fsn_rows_to_bft)."""
+    T, Np, O = o.shape
+    ld = o.stride(1)
+    if o.stride(2) != 1 or o.stride(0) != Np * ld:
+        o = o.contiguous()
+        ld = O
+    if not o.is_cuda or o.dtype != torch.float32:
+        raise _lib.FsnError("from_rows: fp32 rows on a ROCm device")
+    y = torch.empty((B, O, T), dtype=torch.float32, device=o.device)
+    # (a column slice is not contiguous: its base address and row stride are what the entry takes)
+    _lib.check(_lib.lib().fsn_rows_to_bft(o.data_ptr(), T, Np, ld, B, O, _lib.dev_ptr(y), _lib.stream_ptr(o.device)))
+    return y
+
+
 class SequenceModel(nn.Module):
     def __init__(self, input_size, output_size, hidden_size, num_layers, bidirectional, sequence_model="GRU",
                  output_activate_function="Tanh"):
@@ -164,11 +191,7 @@ class SequenceModel(nn.Module):
             raise _lib.FsnError("SequenceModel: input must live on a ROCm device; this path has no CPU implementation")
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return self._forward_train(x)
-        B, F, T = x.shape
-        Np, Ip = _round_up(B, 16), _round_up(F, 16)
-        h = torch.zeros((T, Np, Ip), dtype=torch.float32, device=x.device)
-        h[:, :B, :F] = x.permute(2, 0, 1)
-        return self.forward_time_major(h, B)
+        return self.forward_time_major(to_rows(x), x.shape[0])
 
     def forward_time_major(self, h, B, rows_out=False):
         """Inference on an input that is already laid out as the LSTM entries take it: h [T, Np, Ip] time-major, rows
@@ -199,7 +222,7 @@ class SequenceModel(nn.Module):
             relu = False
         if self.output_activate_function and not relu:
             o = self.activate_function(o)
-        return o if rows_out else o[:, :B].permute(1, 2, 0)
+        return o if rows_out else from_rows(o, B)
 
     def _forward_train(self, x):
         from .train import GruLayerFunction, LinearFunction, LstmLayerFunction
@@ -234,11 +257,11 @@ def multi_plan(models, shapes):
     return bool(_lib.lib().fsn_lstm2_multi_is_persistent(n, ctypes.byref(stacks), shapes[0][2]))
 
 
-def multi_forward(models, xs=None, prepared=None):
+def multi_forward(models, xs=None, prepared=None, rows_out=False):
     """Several independent two-layer LSTM SequenceModels over the SAME frames (the band sections of Improved FullSubNet,
     improved_fullsubnet/model.py:402-449) through fsn_lstm2_forward_multi: one persistent launch of the group kernel with
     one weight set per model when ``multi_plan`` says so.  models[i](xs[i]) for xs[i] [B_i, F_i, T] -> list of
-    [B_i, O_i, T]; or ``prepared[i] = (h_i [T, Np_i, Ip_i], B_i)``, inputs already in the entries' time-major zero-padded
+    [B_i, O_i, T] (``rows_out``: of [T, Np_i, O_i] time-major, as the output layers wrote them); or ``prepared[i] = (h_i [T, Np_i, Ip_i], B_i)``, inputs already in the entries' time-major zero-padded
     layout.  Inference only."""
     import ctypes
     L = _lib.lib()
@@ -251,10 +274,7 @@ def multi_forward(models, xs=None, prepared=None):
         for x in xs:
             if x.dim() != 3 or not x.is_cuda:
                 raise _lib.FsnError("multi_forward: GPU inputs [B, F, T]")
-            B, F, T = x.shape
-            h = torch.zeros((T, _round_up(B, 16), _round_up(F, 16)), dtype=torch.float32, device=x.device)
-            h[:, :B, :F] = x.permute(2, 0, 1)
-            prepared.append((h, B))
+            prepared.append((to_rows(x), x.shape[0]))
     T = prepared[0][0].shape[0]
     dev = prepared[0][0].device
     stacks = (_lib.Lstm2Stack * n)()
@@ -281,12 +301,12 @@ def multi_forward(models, xs=None, prepared=None):
     for m, hseq, (B, Np, Hp, fc) in zip(models, hseqs, meta):
         relu = m.output_activate_function == "ReLU"
         if fc is not None:
-            o = linear_infer(hseq.reshape(T * Np, Hp), fc[0], fc[1], relu).reshape(T, Np, m.output_size)[:, :B]
+            o = linear_infer(hseq.reshape(T * Np, Hp), fc[0], fc[1], relu).reshape(T, Np, m.output_size)
         else:
-            o, relu = hseq[:, :B, :m.hidden_size], False
+            o, relu = hseq[:, :, :m.hidden_size], False
         if m.output_activate_function and not relu:
             o = m.activate_function(o)
-        outs.append(o.permute(1, 2, 0))
+        outs.append(o if rows_out else from_rows(o, B))  # rows_out: [T, Np, O] as it lies (rows beyond B are not meaningful)
     return outs
 
 
@@ -343,8 +363,4 @@ def pair_forward(block0, block1, x):
     block."""
     if torch.is_grad_enabled() or not x.is_cuda or not pair_fusable(block0, block1, x.shape[0]):
         return block1(block0(x))
-    B, F, T = x.shape
-    Np, Ip = _round_up(B, 16), _round_up(F, 16)
-    h = torch.zeros((T, Np, Ip), dtype=torch.float32, device=x.device)
-    h[:, :B, :F] = x.permute(2, 0, 1)
-    return pair_forward_rows(block0, block1, h)[:, :B].permute(1, 2, 0)
+    return from_rows(pair_forward_rows(block0, block1, to_rows(x)), x.shape[0])

@@ -52,8 +52,8 @@ extern "C" {
 const char* fsn_last_error(void);
 /* The ABI revision this header describes.  fsn_version() returns the revision the LIBRARY was built with: a caller
  * compares the two once after loading (fullsubnet_amd/_lib.py raises on a mismatch) - argument lists changed between
- * revisions (110: fsn_train_dims.norm, fsn_train_den_elems; 100 -> 101 of round 4: fsn_clip_adam_step's found_inf). */
-#define FSN_ABI_VERSION 110
+ * revisions (111: + the composed families' glue entries; 110: fsn_train_dims.norm, fsn_train_den_elems; 100 -> 101 of round 4: fsn_clip_adam_step's found_inf). */
+#define FSN_ABI_VERSION 111
 int fsn_version(void);
 
 /* ---- STFT / iSTFT : audio_zen/acoustics/feature.py ------------------------------------- */
@@ -241,6 +241,28 @@ int fsn_improved_section_input(const float* noisy, const float* fb_out, int B, i
                                int sb_center, int sb_neighbor, int fb_center, int fb_neighbor, int unit_lo, int unit_hi,
                                float eps, float* out, int Np, int ldo, void* workspace, size_t workspace_bytes,
                                void* stream);
+
+/* The tensor glue AROUND the models of the composed families (round 5; section_kernels.hip), all bit-identical to the tensor
+ * algebra it replaces:
+ * fsn_improved_front      improved_fullsubnet/model.py:565-566: mag [B][F][T] -> out [B][F - 1][T] = mag ** fdrc without the
+ *                         last bin, contiguous; sqrt_mode 1: fdrc = 0.5 (sqrtf, what torch.pow computes for that exponent),
+ *                         0: fdrc = 1.
+ * fsn_bft_to_rows         x [B][F][T] -> h [T][Np][Ip], zero beyond (B, F): the layout every LSTM / Linear entry takes
+ *                         (audio_zen/model/module/sequence_model.py:106-125 permutes to [B, T, F] for nn.LSTM).
+ * fsn_rows_to_bft         o [T][Np][ld] -> y [B][O][T]: the way back (sequence_model.py:123).
+ * fsn_improved_mask_apply model.py:438-449 (the sections' outputs re-ordered and concatenated along the bins), :575 F.pad of
+ *                         the last bin and :576-577 (mask x noisy real / imaginary part, no complex product) in one pass:
+ *                         section i's output o [T][Np][ld] (as fsn_linear_forward writes it: row b units + u, column
+ *                         comp center + cc) -> er / ei [B][F][T] at bin lower + u center + cc; bins no section covers: 0. */
+typedef struct fsn_mask_section {
+    const void* o; /* [T][Np][ld] */
+    int Np, ld, lower, units, center;
+} fsn_mask_section;
+int fsn_improved_front(const float* mag, int B, int F, int T, int sqrt_mode, float* out, void* stream);
+int fsn_bft_to_rows(const float* x, int B, int F, int T, float* h, int Np, int Ip, void* stream);
+int fsn_rows_to_bft(const float* o, int T, int Np, int ld, int B, int O, float* y, void* stream);
+int fsn_improved_mask_apply(int n, const fsn_mask_section* sections, const float* real, const float* imag, int B, int F, int T,
+                            float* er, float* ei, void* stream);
 
 /* Up to eight INDEPENDENT two-layer stacks over the same T frames: the band sections of
  * improved_fullsubnet/model.py:402-449, whose SequenceModels have B x {20, 25, 6, 4} rows and input widths 62 .. 180 at

@@ -318,6 +318,41 @@ def test_improved_fullsubnet_vs_reference(fsn, golden_dir, name, cfg):
     assert np.abs(enh - z["enhanced"]).max() <= 1e-4 * np.abs(z["enhanced"]).max()
 
 
+@pytest.mark.parametrize("cfg,batch,length", [(MF.IMPROVED_16K, 3, 5000), (MF.IMPROVED_48K, 2, 24000), (MF.IMPROVED_48K, 32, 9600),
+                                              (MF.IMPROVED_48K_769, 1, 15000)])
+def test_improved_fullsubnet_glue_kernels_vs_the_tensor_algebra(fsn, cfg, batch, length):
+    """Model._forward_kernels (round 5: |X| ** fdrc + last-bin slice, the transposes around the full-band model, the sections'
+    outputs re-ordered / padded / multiplied into the two planes - fsn_improved_front, fsn_bft_to_rows, fsn_rows_to_bft,
+    fsn_improved_mask_apply) against the same forward as tensor algebra of the host framework (`glue_kernels = False`): pure
+    data movement and the same IEEE operations, so BIT-identical - on chain-kernel plans (one to three utterances) and on the
+    persistent multi-section launch (batch 32); SequenceModel.forward's own transposes against a permute; both entries'
+    argument checks."""
+    from oracle import fullsubnet_oracle as O
+    from fullsubnet_amd.improved_fullsubnet import Model
+    from fullsubnet_amd.sequence_model import from_rows, to_rows
+    m = Model(**cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in MF.make_improved_params(cfg, seed=5).items()}, strict=True)
+    m = m.cuda().eval()
+    y = torch.from_numpy(O.make_noisy(batch, length, seed=9)).cuda()
+    with torch.no_grad():
+        assert m._glue_on_kernels(y, None)
+        got = m(y)
+        m.glue_kernels = False
+        assert not m._glue_on_kernels(y, None)
+        want = m(y)
+        m.glue_kernels = True
+    assert got.shape == want.shape == (batch, 1, length) and torch.equal(got, want)
+    assert float(want.abs().max()) > 0
+    x = torch.randn(5, 37, 29, device="cuda")
+    h = to_rows(x)
+    assert h.shape == (29, 16, 48) and torch.equal(h[:, :5, :37], x.permute(2, 0, 1)) and float(h[:, 5:].abs().max()) == 0
+    assert float(h[:, :, 37:].abs().max()) == 0
+    assert torch.equal(from_rows(h, 5)[:, :37], x) and torch.equal(from_rows(h[:, :, :20], 5), x[:, :20])
+    L = fsn._lib.lib()
+    assert L.fsn_bft_to_rows(fsn._lib.dev_ptr(x), 5, 37, 29, fsn._lib.dev_ptr(h), 4, 48, None) != 0  # fewer padded rows than rows
+    assert L.fsn_improved_mask_apply(0, None, None, None, 1, 1, 1, None, None, None) != 0
+
+
 def test_improved_fullsubnet_at_baseline_length_vs_reference(fsn, golden_dir):
     """BASELINE config 5's clip: 3 s at 48 kHz through the reference's own 481-bin example (301 frames) against the
     reference model's output (tests/golden/improved_48k_long_b1.npz, every 8th sample)."""
@@ -449,6 +484,7 @@ def test_improved_fullsubnet_unit_shard_vs_reference(fsn, golden_dir, name, cfg,
         return sb.assemble_units([torch.cat(sec, dim=0) for sec in zip(*per_rank)])
 
     sb.forward = ranks_in_turn
+    m.glue_kernels = False  # (a real unit shard passes `unit_group`, which takes the tensor-algebra forward that calls sb.forward)
     noisy = O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_x"])
     with torch.no_grad():
         enh = m(torch.from_numpy(noisy).cuda().unsqueeze(1)).cpu().numpy()

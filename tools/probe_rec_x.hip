@@ -79,8 +79,9 @@ int main(int argc, char** argv) {
     }
     VARIANT("64 + 256 (the library's form)", 320)
     VARIANT("64 + 256 + first-tile A fragment requested a block early (32768)", 320 + 32768)
+    VARIANT("64 + 256 + two rolling A fragment sets (65536)", 320 + 65536)
     VARIANT("64 + 256", 320)
-    VARIANT("64 + 256 + 32768", 320 + 32768)
+    VARIANT("64 + 256 + 65536", 320 + 65536)
     VARIANT("shipped once more", 0)
     return 0;
 }
