@@ -97,24 +97,33 @@ __global__ __launch_bounds__(256) void tr_total_kernel(const double* __restrict_
 // x_tm[t][b][f] = pad(mag)[b][f][t] / (mean_b + 1e-5), mag_tm[t][b][f] = pad(mag)[b][f][t]; zero beyond (B, F); one block
 // per (t, 32-bin slab, b): a 32 x 32 tile through LDS so that both sides are coalesced
 // cumulative_laplace_norm of the padded full-band input (base_model.py:221-251): colsum[b][t] = sum_f mag[b][f][t]
-// (threads along t: coalesced), then cden[b][t] = (sum_{tau <= t} colsum[b][tau]) / (F (t + 1)) + EPSILON; the look-ahead
-// frames are zeros that still count.  One block per utterance; the scan is ~200 additions by one thread.
-__global__ __launch_bounds__(256) void tr_fb_cum_den_kernel(const float* __restrict__ mag, double* __restrict__ colsum,
-                                                           float* __restrict__ cden, TrDims d) {
-    const int b = blockIdx.x;
-    for (int t = threadIdx.x; t < d.Tp; t += 256) {
-        double acc = 0.0;
-        if (t < d.T)
-            for (int f = 0; f < d.F; ++f) acc += (double)mag[((size_t)b * d.F + f) * d.T + t];
-        colsum[(size_t)b * d.Tp + t] = acc;
-    }
+// (a block = 64 frames x 4 bin groups: threads along t, coalesced; the four partial sums meet in a fixed order), then
+// cden[b][t] = (sum_{tau <= t} colsum[b][tau]) / (F (t + 1)) + EPSILON; the look-ahead frames are zeros that still count.
+__global__ __launch_bounds__(256) void tr_fb_colsum_kernel(const float* __restrict__ mag, double* __restrict__ colsum, TrDims d) {
+    __shared__ double part[4][64];
+    const int b = blockIdx.y, t = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    double acc = 0.0;
+    if (t < d.T)
+        for (int f = q; f < d.F; f += 4) acc += (double)mag[((size_t)b * d.F + f) * d.T + t];
+    part[q][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double run = 0.0;
-        for (int t = 0; t < d.Tp; ++t) {
-            run += colsum[(size_t)b * d.Tp + t];
-            cden[(size_t)b * d.Tp + t] = (float)(run / ((double)d.F * (t + 1))) + 1.1920928955078125e-07f;
+    if (q == 0 && t < d.Tp) colsum[(size_t)b * d.Tp + t] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+}
+// one wave per utterance: a scan over the frames in chunks of 64 (Hillis-Steele inside the chunk, fp64, fixed order)
+__global__ __launch_bounds__(64) void tr_fb_cum_den_kernel(const double* __restrict__ colsum, float* __restrict__ cden, TrDims d) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double carry = 0.0;
+    for (int t0 = 0; t0 < d.Tp; t0 += 64) {
+        const int t = t0 + lane;
+        double v = t < d.Tp ? colsum[(size_t)b * d.Tp + t] : 0.0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double u = __shfl_up(v, o, 64);
+            if (lane >= o) v += u;
         }
+        v += carry;
+        if (t < d.Tp) cden[(size_t)b * d.Tp + t] = (float)(v / ((double)d.F * (t + 1))) + 1.1920928955078125e-07f;
+        carry = __shfl(v, 63, 64);
     }
 }
 __global__ __launch_bounds__(256) void tr_fb_input_kernel(const float* __restrict__ mag, const double* __restrict__ total,
@@ -217,13 +226,23 @@ __global__ __launch_bounds__(256) void tr_sb_cum_sum_kernel(const float* __restr
     }
 }
 // ... den[t][r] = (sum_{tau <= t} S[tau][r]) / ((2 nb + 2) (t + 1)) + EPSILON (base_model.py:230-251 with the units as samples:
-// quirk Q4); a thread per row, rows coalesced
+// quirk Q4).  A block = 32 rows x 8 time segments: every thread sums its segment, the eight segment sums of a row meet in
+// LDS, every thread walks its segment again from its prefix - a serial depth of 2 Tp / 8 instead of Tp; rows coalesced.
+constexpr int TR_SEG = 8;
 __global__ __launch_bounds__(256) void tr_sb_cum_scan_kernel(const double* __restrict__ S, float* __restrict__ den, TrDims d, int Rp) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= Rp) return;
+    __shared__ double seg[TR_SEG][32];
+    const int rl = threadIdx.x & 31, q = threadIdx.x >> 5, r = blockIdx.x * 32 + rl;
+    const int L = (d.Tp + TR_SEG - 1) / TR_SEG, ta = q * L, tb = ta + L < d.Tp ? ta + L : d.Tp;
     double run = 0.0;
+    if (r < Rp)
+        for (int t = ta; t < tb; ++t) run += S[(size_t)t * Rp + r];
+    seg[q][rl] = run;
+    __syncthreads();
+    if (r >= Rp) return;
+    run = 0.0;
+    for (int k = 0; k < q; ++k) run += seg[k][rl];
     const double C = (double)(2 * d.nb + 2);
-    for (int t = 0; t < d.Tp; ++t) {
+    for (int t = ta; t < tb; ++t) {
         run += S[(size_t)t * Rp + r];
         den[(size_t)t * Rp + r] = (float)(run / (C * (t + 1))) + 1.1920928955078125e-07f;
     }
@@ -232,25 +251,35 @@ __global__ __launch_bounds__(256) void tr_sb_cum_scan_kernel(const double* __res
 // P[t] = - (sum_c dy[t][c] y[t][c]) / D[t] / (C (t + 1)); every raw element of frame tau receives that on top of dy / D.
 __global__ __launch_bounds__(256) void tr_sb_cum_bwd_p_kernel(const float* __restrict__ dx, const float* __restrict__ sb_in,
                                                              const float* __restrict__ den, double* __restrict__ P, TrDims d, int Rp) {
-    const int t = blockIdx.y;
-    const int c = threadIdx.x & 31;
-    const double k = 1.0 / ((double)(2 * d.nb + 2) * (t + 1));
-    for (int r0 = blockIdx.x * 8; r0 < Rp; r0 += gridDim.x * 8) {
-        const int r = r0 + (threadIdx.x >> 5);
-        double v = 0.0;
-        if (r < d.R && c <= 2 * d.nb + 1) {
-            const size_t i = ((size_t)t * Rp + r) * 32 + c;
-            v = (double)dx[i] * (double)sb_in[i];
-        }
-        v = tr_sum32(v);
-        if (c == 0 && r < Rp) P[(size_t)t * Rp + r] = r < d.R ? -v / (double)den[(size_t)t * Rp + r] * k : 0.0;
+    // a thread = four columns of a row (16-byte loads: a wave reads 2 x 1 KB runs), eight threads per row, 32 rows per block
+    const int t = blockIdx.y, c4 = (threadIdx.x & 7) * 4, r = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int C = 2 * d.nb + 2;
+    double v = 0.0;
+    if (r < d.R) {
+        const size_t i = ((size_t)t * Rp + r) * 32 + c4;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(dx + i), b = *reinterpret_cast<const f32x4*>(sb_in + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (c4 + k < C) v += (double)a[k] * (double)b[k];  // (the padding columns of dx are never written: not read into the sum)
     }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 7) == 0 && r < Rp)
+        P[(size_t)t * Rp + r] = r < d.R ? -v / (double)den[(size_t)t * Rp + r] / ((double)C * (t + 1)) : 0.0;
 }
 __global__ __launch_bounds__(256) void tr_sb_cum_bwd_scan_kernel(const double* __restrict__ P, float* __restrict__ G, TrDims d, int Rp) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= Rp) return;
+    __shared__ double seg[TR_SEG][32];
+    const int rl = threadIdx.x & 31, q = threadIdx.x >> 5, r = blockIdx.x * 32 + rl;
+    const int L = (d.Tp + TR_SEG - 1) / TR_SEG, ta = q * L, tb = ta + L < d.Tp ? ta + L : d.Tp;
     double run = 0.0;
-    for (int t = d.Tp - 1; t >= 0; --t) {
+    if (r < Rp)
+        for (int t = ta; t < tb; ++t) run += P[(size_t)t * Rp + r];
+    seg[q][rl] = run;
+    __syncthreads();
+    if (r >= Rp) return;
+    run = 0.0;
+    for (int k = TR_SEG - 1; k > q; --k) run += seg[k][rl];  // everything behind this segment
+    for (int t = tb - 1; t >= ta; --t) {
         run += P[(size_t)t * Rp + r];
         G[(size_t)t * Rp + r] = (float)run;
     }
@@ -417,7 +446,9 @@ extern "C" int fsn_train_fb_input(const fsn_train_dims* dims, const float* mag, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const TrWs w = tr_carve(d, workspace);
     if (d.cum) {
-        hipLaunchKernelGGL(tr_fb_cum_den_kernel, dim3((unsigned)d.B), dim3(256), 0, s, mag, w.partial, w.cden, d);
+        hipLaunchKernelGGL(tr_fb_colsum_kernel, dim3((unsigned)((d.Tp + 63) / 64), (unsigned)d.B), dim3(256), 0, s, mag, w.partial, d);
+        FSN_TRY_LAUNCH("tr_fb_colsum_kernel");
+        hipLaunchKernelGGL(tr_fb_cum_den_kernel, dim3((unsigned)d.B), dim3(64), 0, s, w.partial, w.cden, d);
         FSN_TRY_LAUNCH("tr_fb_cum_den_kernel");
     } else {
         hipLaunchKernelGGL(tr_rowsum_kernel, dim3((unsigned)((d.B * d.F + 3) / 4)), dim3(256), 0, s, mag, w.rowsum, d.B * d.F, d.T);
@@ -448,7 +479,7 @@ extern "C" int fsn_train_sb_input(const fsn_train_dims* dims, const float* mag_t
         FSN_REQUIRE((size_t)Rp <= tr_rcap(d), "train sb input: cumulative norm takes at most the rows rounded up to 64 as padded rows");
         hipLaunchKernelGGL(tr_sb_cum_sum_kernel, dim3(gx, (unsigned)d.Tp), dim3(256), 0, s, mag_tm, fb_out_tm, ld_fb, w.rowframe, d, Bp, Fp, Rp);
         FSN_TRY_LAUNCH("tr_sb_cum_sum_kernel");
-        hipLaunchKernelGGL(tr_sb_cum_scan_kernel, dim3((unsigned)((Rp + 255) / 256)), dim3(256), 0, s, w.rowframe, den, d, Rp);
+        hipLaunchKernelGGL(tr_sb_cum_scan_kernel, dim3((unsigned)((Rp + 31) / 32)), dim3(256), 0, s, w.rowframe, den, d, Rp);
         FSN_TRY_LAUNCH("tr_sb_cum_scan_kernel");
     } else {
         hipLaunchKernelGGL(tr_fbsum_partial_kernel, dim3((unsigned)d.Tp, (unsigned)d.B), dim3(256), 0, s, fb_out_tm, ld_fb, w.partial, d, Bp);
@@ -476,10 +507,10 @@ extern "C" int fsn_train_sb_input_backward(const fsn_train_dims* dims, const flo
     const TrWs w = tr_carve(d, workspace);
     if (d.cum) {
         FSN_REQUIRE((size_t)Rp <= tr_rcap(d), "train sb input backward: cumulative norm takes at most the rows rounded up to 64 as padded rows");
-        const unsigned gx = (unsigned)((Rp + 7) / 8 < 1024 ? (Rp + 7) / 8 : 1024);
-        hipLaunchKernelGGL(tr_sb_cum_bwd_p_kernel, dim3(gx, (unsigned)d.Tp), dim3(256), 0, s, dx, sb_in, den, w.rowframe, d, Rp);
+        hipLaunchKernelGGL(tr_sb_cum_bwd_p_kernel, dim3((unsigned)((Rp + 31) / 32), (unsigned)d.Tp), dim3(256), 0, s, dx, sb_in, den, w.rowframe, d,
+                           Rp);
         FSN_TRY_LAUNCH("tr_sb_cum_bwd_p_kernel");
-        hipLaunchKernelGGL(tr_sb_cum_bwd_scan_kernel, dim3((unsigned)((Rp + 255) / 256)), dim3(256), 0, s, w.rowframe, w.G, d, Rp);
+        hipLaunchKernelGGL(tr_sb_cum_bwd_scan_kernel, dim3((unsigned)((Rp + 31) / 32)), dim3(256), 0, s, w.rowframe, w.G, d, Rp);
         FSN_TRY_LAUNCH("tr_sb_cum_bwd_scan_kernel");
     } else {
         hipLaunchKernelGGL(tr_sb_bwd_partial_kernel, dim3((unsigned)d.Tp, (unsigned)d.B), dim3(256), 0, s, dx, sb_in, w.partial, d, Rp);

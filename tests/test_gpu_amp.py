@@ -126,9 +126,9 @@ def test_two_layer_lstm_16bit_operands_vs_an_exact_emulation(fsn, arith):
     print(f"{arith}: worst deviation from the exact emulation {worst[1]:.2e} ({worst[0]})")
 
 
-def build(fsn, arith, seed=3, groups=2):
+def build(fsn, arith, seed=3, groups=2, norm_type="offline_laplace_norm"):
     params = O.make_params(seed=seed)
-    model = fsn.Model(norm_type="offline_laplace_norm", num_groups_in_drop_band=groups, **MODEL_KW)
+    model = fsn.Model(norm_type=norm_type, num_groups_in_drop_band=groups, **MODEL_KW)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
     model = model.cuda().train()
     model.train_arithmetic = arith
@@ -170,6 +170,9 @@ AMP_TOL = {
     ("bf16", "fsn_train_c3"): (1e-5, 5e-3, 6e-3, 2.5e-2, 3e-7),
     ("bf16", "fsn_train_b4_bf16"): (1e-5, 5e-3, 7e-2, 1.0, 2e-4),
     ("bf16", "fsn_train_c3_bf16"): (1e-5, 3e-3, 8e-3, 1.5e-1, 7e-7),
+    # the shipped cumulative-norm TOML under its own use_amp = true (round 5), against the reference's fp32 step with that norm
+    ("f16", "fsn_train_cum_c3"): (2e-6, 2e-5, 3e-4, 6e-3, 1e-8),
+    ("bf16", "fsn_train_cum_c3"): (1e-5, 5e-3, 6e-3, 2.5e-2, 3e-7),
 }
 
 
@@ -180,7 +183,8 @@ def test_amp_train_step_vs_the_reference(fsn, golden_dir, arith, name):
     from fullsubnet_amd.train import train_step
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     meta = ast.literal_eval(str(z["meta"]))
-    model, params = build(fsn, arith, seed=meta["seed_w"], groups=meta["groups"])
+    model, params = build(fsn, arith, seed=meta["seed_w"], groups=meta["groups"],
+                          norm_type=meta.get("norm_type", "offline_laplace_norm"))
     noisy = torch.from_numpy(O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_noisy"])).cuda()
     clean = torch.from_numpy((meta["clean_gain"] * O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_clean"]))
                              .astype(np.float32)).cuda()
