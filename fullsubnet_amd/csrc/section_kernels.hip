@@ -207,10 +207,8 @@ __global__ __launch_bounds__(256) void mask_zero_uncovered_kernel(const MaskSect
 // times the noisy real / imaginary part (model.py:576-577: no complex product).  A workgroup = 8 rows x 32 frames.
 __global__ __launch_bounds__(256) void mask_apply_kernel(const fsn_mask_section sec, const float* __restrict__ real,
                                                         const float* __restrict__ imag, float* __restrict__ er, float* __restrict__ ei,
-                                                        int B, int F, int T) {
+                                                        int B, int F, int T, int R) {
     extern __shared__ float tile[];  // [32 frames][R rows * ld + 1], R = rows per workgroup (8 for narrow sections, fewer for wide)
-    if (blockIdx.z != 0) return;
-    const int R = (int)gridDim.z;  // rows per workgroup, carried in gridDim.z (1 .. 8)
     const int W = 2 * sec.center, pitch = R * sec.ld + 1;
     const int t0 = blockIdx.x * 32, r0 = blockIdx.y * R;
     const int rows = B * sec.units;
@@ -282,9 +280,8 @@ extern "C" int fsn_improved_mask_apply(int n, const fsn_mask_section* sections, 
         int R = 512 / q.ld;  // rows per workgroup: at most 512 floats per frame in the tile (64 KB of LDS)
         R = R > 8 ? 8 : (R < 1 ? 1 : R);
         const size_t lds = (size_t)32 * (R * q.ld + 1) * sizeof(float);
-        // gridDim.z carries R (only blockIdx.z == 0 works: the others return at once)
-        hipLaunchKernelGGL(mask_apply_kernel, dim3((unsigned)((T + 31) / 32), (unsigned)((B * q.units + R - 1) / R), (unsigned)R), dim3(256), lds, s,
-                           q, real, imag, er, ei, B, F, T);
+        hipLaunchKernelGGL(mask_apply_kernel, dim3((unsigned)((T + 31) / 32), (unsigned)((B * q.units + R - 1) / R)), dim3(256), lds, s, q, real,
+                           imag, er, ei, B, F, T, R);
         FSN_TRY_LAUNCH("mask_apply_kernel");
     }
     return FSN_OK;
