@@ -267,7 +267,7 @@ extern "C" int fsn_improved_mask_apply(int n, const fsn_mask_section* sections, 
     for (int i = 0; i < n; ++i) {
         const fsn_mask_section& q = sections[i];
         FSN_REQUIRE(q.o && q.center >= 1 && q.units >= 0 && q.lower >= 0 && q.lower + q.units * q.center <= F && q.ld >= 2 * q.center &&
-                        q.ld <= 512 && q.Np >= B * q.units,
+                        q.ld <= 480 && q.Np >= B * q.units,
                     "improved mask apply: section %d out of range", i);
         ms.s[i] = q;
     }
@@ -277,7 +277,7 @@ extern "C" int fsn_improved_mask_apply(int n, const fsn_mask_section* sections, 
     for (int i = 0; i < n; ++i) {
         const fsn_mask_section& q = ms.s[i];
         if (q.units == 0) continue;
-        int R = 512 / q.ld;  // rows per workgroup: at most 512 floats per frame in the tile (64 KB of LDS)
+        int R = 480 / q.ld;  // rows per workgroup: at most 480 floats per frame in the tile (61.6 KB of LDS: below the 64 KB a launch gets unasked)
         R = R > 8 ? 8 : (R < 1 ? 1 : R);
         const size_t lds = (size_t)32 * (R * q.ld + 1) * sizeof(float);
         hipLaunchKernelGGL(mask_apply_kernel, dim3((unsigned)((T + 31) / 32), (unsigned)((B * q.units + R - 1) / R)), dim3(256), lds, s, q, real,

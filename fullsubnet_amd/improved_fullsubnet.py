@@ -399,7 +399,7 @@ class Model(BaseModel):
                 and y.dtype == torch.float32 and self.fdrc in (0.5, 1.0) and sb.norm_type == "offline_laplace_norm"
                 and self.norm == self.offline_laplace_norm and self.fb_model.cell == "LSTM"
                 and all(m.cell == "LSTM" and m.output_size for m in sb.sb_models)
-                and max(2 * c for c in sb.sb_num_center_freqs) <= 512)
+                and max(2 * c for c in sb.sb_num_center_freqs) <= 480)
 
     def _forward_kernels(self, y, mag, real, imag):
         """model.py:541-591 with every step between the transforms and the LSTM / Linear entries on kernels of the library:
