@@ -415,7 +415,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
     for (int t = 0; t < Tp; ++t) {
         // frame t + 1: requested now, written to the other x buffer after the first gate pass (that buffer was last
         // read in step t - 1 and is first read after the two barriers that end this step)
-        const bool more = t + 1 < Tp;
+        const bool more = t + 1 < Tp && !(OPT & 2);  // (OPT & 2, probe: the price of the input gather)
         if (more) stage.issue(xin, n0, sb_b0, sb_f0, t + 1);
         const float* xa = xl + (t & 1) * ROWS * XS + lr * XS + 4 * lq;
         const float* ha = hl + lr * HS + 4 * lq;
@@ -629,6 +629,10 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         // stream h_t out as whole rows: hseq[t][n0 + row][0..H)
         float* dst = hseq + ((long)t * Npad + n0) * H;
+        // (Round 5, measured and not kept: the gather's step-independent index arithmetic read back from an LDS table, and
+        // these stores from one address pair per step - ~250 fewer vector instructions per wave and step, no change in
+        // time: the step's ends wait on the barriers anyway.  Without the stores 0.1 ms, without the gather 0.2.)
+        if ((OPT & 1) && t + 1 < Tp) continue;  // probe: the price of streaming the hidden sequence out
         for (int i = threadIdx.x; i < ROWS * (H / 4); i += NW * 64) {
             const int row = i / (H / 4), c4 = i % (H / 4);
             const f32x4 v = *reinterpret_cast<const f32x4*>(hl + row * HS + c4 * 4);
@@ -671,6 +675,22 @@ __device__ __forceinline__ void lds_dma_fragment(const float* g, unsigned lds_ba
     }
 }
 
+// The same with the source address as a wave-uniform base (scalar registers) + this lane's byte offset: no per-fragment
+// vector arithmetic at all.
+__device__ __forceinline__ void lds_dma_fragment_s(const float* sbase, unsigned lane_bytes, unsigned lds_base) {
+    unsigned saved;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %3\n\t"
+        "s_nop 0\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(saved)
+        : "s"(lds_base), "v"(lane_bytes), "s"(sbase)
+        : "memory");
+}
+
 // ABL (experiment knob of tools/probe_rec_x.hip, 0 in the library; results are WRONG with any bit set): leaves out one
 // ingredient at a time to price it - 1 slice barriers, 2 gate non-linearities, 4 output layer, 8 ring fills,
 // 16 the two barriers that end a step.  Bits 32 / 64 are scheduling experiments with correct results (round 5).  Measured (tools/probe_rec_x.hip, 52.7 ms shipped): 0.5 / 1.3 / 0.45 / 1.5 /
@@ -681,7 +701,9 @@ __device__ __forceinline__ void lds_dma_fragment(const float* g, unsigned lds_ba
 // 51.8 ms; layer 0 = 4096 (K loop without per-chunk vector instructions) + 256: 28.65 -> 27.85 ms.  4096 does not pay in
 // layer 1 (51.9 - 52.0), 128 / 512 / 1024.. neither (profiles/r05_rec_probes.md).
 #ifndef FSN_REC_X_OPT
-#define FSN_REC_X_OPT (64 | 256)
+// + 131072: a slice's ring fills behind the first row tile of its first block (51.7 -> 51.3 ms); + 524288: their addresses
+// from scalar registers (-> 50.6); + 262144: the output layer's tail without a 64-bit division per step (-> 50.4); + 4096 (-> 50.3)
+#define FSN_REC_X_OPT (64 | 256 | 131072 | 262144 | 524288 | 4096)
 #endif
 #ifndef FSN_REC_IN_OPT
 #define FSN_REC_IN_OPT (4096 | 256 | 32768)  // + 32768: the next block's first-tile A fragment requested a block early: 27.78 -> 27.40 ms (nothing in layer 1: 20 spilled registers)
@@ -728,6 +750,20 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
             const int c = i / H, k = i % H;
             wl[i] = fc.w_p[(((k >> 4) * 64) + ((k & 15) >> 2) * 16 + c) * 4 + (k & 3)];
         }
+    // FCT (ABL & 262144): the output layer's tail without its per-step overhead - (b, f) of the workgroup's first row once
+    // (rows are consecutive; the per-step form divided two 64-bit integers per thread and step), the bias from scalar
+    // registers, the quad sums by DPP instead of ds_bpermute, and the two product chains kept scalar (hipcc paired them
+    // into v_pk_fma_f32 at the price of three v_mov per product).  Same arithmetic, same order.
+    constexpr bool FCT = (ABL & 262144) != 0 && !HSEQ;
+    int fc_b0 = 0, fc_f0 = 0;
+    float fc_bias0 = 0.f, fc_bias1 = 0.f;
+    if (FCT) {
+        const long ng0 = n0 + fc.row0;
+        fc_b0 = (int)(ng0 / fc.F);
+        fc_f0 = (int)(ng0 - (long)fc_b0 * fc.F);
+        fc_bias0 = fc.bias[0];
+        fc_bias1 = fc.bias[1];
+    }
     constexpr bool ROT = (ABL & 128) && NW == 12;  // ring fills by ONE wave of every SIMD per slice, in rotation
     constexpr int FPOL = (ABL >> 10) & 3;          // cache policy of the ring fills (lds_dma_fragment)
     // KOPT: the recurrent product's K loop without per-chunk vector instructions.  Vector instructions and fp32 MFMAs share
@@ -771,6 +807,25 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
             lds_dma_fragment<FPOL>(src + (rt * 16 * H + kcl * 16) + xlane,
                              __builtin_amdgcn_readfirstlane(xs_lds + (unsigned)((buf * NF + f) * 1024)));
         }
+    };
+    // FSA (ABL & 524288): the fills' addresses from scalar registers - a wave's fragments of a stage are the same (row
+    // tile, chunk) pairs all through the kernel, so their offsets are formed once, and the source is base + lane offset
+    // (the loop form spent a 64-bit vector add, a vector add and a v_readfirstlane per fragment, inside a real loop)
+    constexpr bool FSA = (ABL & 524288) != 0 && NF % NW == 0;
+    constexpr int FPW = NF % NW == 0 ? NF / NW : 1;
+    int fsa_src[FPW], fsa_lds[FPW];
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) {
+        const int f = wave + i * NW, rt = f / SK, kcl = f - rt * SK;
+        fsa_src[i] = __builtin_amdgcn_readfirstlane(rt * 16 * H + kcl * 16);
+        fsa_lds[i] = __builtin_amdgcn_readfirstlane((int)xs_lds + f * 1024);
+    }
+    const unsigned xlane_bytes = xlane * 4u;
+    auto fill_s = [&](int buf, int t, int sl) {
+        const float* src = xseq + ((long)t * Npad + n0) * H + sl * (SK * 16);  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < FPW; ++i)
+            lds_dma_fragment_s(src + fsa_src[i], xlane_bytes, (unsigned)(fsa_lds[i] + buf * (NF * 1024)));
     };
     fill(0, 0, 0, -1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -896,6 +951,35 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
         if (next) fb = *reinterpret_cast<const f32x4*>(next + next_rt_stride);
     };
 
+    // FLATE (ABL & 131072): a slice's ring fills are issued BEHIND the first row tile's MFMAs of the slice's first block
+    // instead of ahead of the block.  Loads return in order and the compiler's counted waits do not know the fills: ahead of
+    // the block, the block's own wait for its weight fragment (vmcnt(UG), the fragment requested a block earlier) also
+    // waited for the fills' HBM round trip, in all twelve waves at once; behind the wait they have the block to land.
+    constexpr bool FLATE = (ABL & 131072) != 0;
+    auto mma_fill = [&](f32x4 (&acc)[RT][UG], const float* a, int a_rt_stride, const f32x4 (&b)[UG], int buf, int nt, int nsl,
+                        const float* next) {
+        const f32x4 a0 = APF ? apre : *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + a_rt_stride);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int u = 0; u < UG; ++u) acc[0][u] = mfma16(a0[jj], b[u][jj], acc[0][u]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nt < Tp && !(ABL & 8)) {
+            if (FSA) fill_s(buf, nt, nsl);
+            else fill(buf, nt, nsl, -1);
+        }
+        if (APF) apre = *reinterpret_cast<const f32x4*>(next);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 1; rt < RT; ++rt) {
+            const f32x4 av = rt == 1 ? a1 : *reinterpret_cast<const f32x4*>(a + rt * a_rt_stride);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[jj], b[u][jj], acc[rt][u]);
+        }
+    };
+
     for (int t = 0; t < Tp; ++t) {
         // gate order of evaluation: f (1), i (0), g (2), o (3)
 #pragma unroll
@@ -939,9 +1023,9 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 }
                 // next slice into the other stage (last read in slice j - 1, which every wave has left):
                 // same x_t for the next pass, x_{t+1} after the last pass
-                {
-                    const int nsl = sl + 1 < NSL ? sl + 1 : 0;
-                    const int nt = (sl + 1 < NSL || pass < 3) ? t : t + 1;
+                const int nsl = sl + 1 < NSL ? sl + 1 : 0;
+                const int nt = (sl + 1 < NSL || pass < 3) ? t : t + 1;
+                if (!FLATE) {
                     if (nt < Tp && !(ABL & 8)) fill((j + 1) & 1, nt, nsl, (int)((unsigned)j % 3u));
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -958,7 +1042,8 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                     for (int u = 0; u < UG; ++u)
                         b1[u] = wload(wx[u] + (unsigned)(kc + 1) * 256u);
                     __builtin_amdgcn_sched_barrier(0);  // requests first, pinned: hipcc otherwise sinks them to their use
-                    if (ROLL) mma_roll(acc, xa + kk * 256, SK * 256, b0, xa + (kk + 1) * 256, SK * 256);
+                    if (FLATE && kk == 0) mma_fill(acc, xa, SK * 256, b0, (j + 1) & 1, nt, nsl, xa + 256);
+                    else if (ROLL) mma_roll(acc, xa + kk * 256, SK * 256, b0, xa + (kk + 1) * 256, SK * 256);
                     else if (APF) mma_pf(acc, xa + kk * 256, SK * 256, b0, xa + (kk + 1) * 256);
                     else if (BEP && kk == 0 && sl == 0) mma0(acc, xa + kk * 256, SK * 256, b0);
                     else mma(acc, xa + kk * 256, SK * 256, b0);
@@ -1150,6 +1235,40 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 const int row = i / (H / 4), c4 = i % (H / 4);
                 *reinterpret_cast<f32x4*>(dst + (long)row * H + c4 * 4) =
                     *reinterpret_cast<const f32x4*>(hl + row * HS + c4 * 4);
+            }
+        } else if (FCT && !(ABL & 4)) {
+            const int tid = threadIdx.x;
+            if (tid < ROWS * 8) {
+                const int part = tid & 3, c = (tid >> 2) & 1, row = tid >> 3;
+                const float* hp = hl + row * HS + part * (H / 4);
+                const float* wp = wl + c * H + part * (H / 4);
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll 2
+                for (int k = 0; k < H / 4; k += 8) {
+                    const f32x4 h0 = *reinterpret_cast<const f32x4*>(hp + k), w0 = *reinterpret_cast<const f32x4*>(wp + k);
+                    const f32x4 h1 = *reinterpret_cast<const f32x4*>(hp + k + 4),
+                                w1 = *reinterpret_cast<const f32x4*>(wp + k + 4);
+                    a0 = fmaf(h0[0], w0[0], a0);
+                    a0 = fmaf(h0[1], w0[1], a0);
+                    a0 = fmaf(h0[2], w0[2], a0);
+                    a0 = fmaf(h0[3], w0[3], a0);
+                    asm volatile("" : "+v"(a0));  // not a twin of the other chain any more: no pairing
+                    a1 = fmaf(h1[0], w1[0], a1);
+                    a1 = fmaf(h1[1], w1[1], a1);
+                    a1 = fmaf(h1[2], w1[2], a1);
+                    a1 = fmaf(h1[3], w1[3], a1);
+                }
+                float v = a0 + a1;
+                v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+                v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+                if (part == 0 && t >= fc.la && (int)n0 + row < fc.N) {
+                    int f = fc_f0 + row, b = fc_b0;
+                    while (f >= fc.F) {
+                        f -= fc.F;
+                        ++b;
+                    }
+                    (c ? fc.crm_i : fc.crm_r)[((long)b * fc.T + (t - fc.la)) * fc.FP + f] = v + (c ? fc_bias1 : fc_bias0);
+                }
             }
         } else if (!(ABL & 4)) {
             // output layer on the spot (nn.Linear(H, 2)): 4 threads per (row, output), a quarter of K each
@@ -1635,7 +1754,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(24))) void lstm
                                                          float* __restrict__ h_out, float* __restrict__ c,
                                                          long gx_rt0, int H, int first) {
     // split-K partials meet pairwise (8 KB of LDS instead of 12): next to lstm_rec_x_kernel's 151.5 KB there is
-    // room for exactly one such workgroup per CU, and this chain has ~10 x slack against the kernel it runs beside
+    // room for exactly one such workgroup per CU, and this chain has ~10 x slack against the kernel it runs beside.
+    // (Round 5: a grid of one slot per CU with the step's 96 tasks rotating through the slots, so that no CU pays every
+    // step's matrix work, measured no different: 81.8 / 82.0 against 81.6 / 81.9 ms per batch.)
     __shared__ f32x4 red[2][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lq = lane >> 4;

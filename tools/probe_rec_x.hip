@@ -77,11 +77,12 @@ int main(int argc, char** argv) {
         const float ms = run<BITS>(xseq, w, bias, Tp, Npad, fc);                       \
         printf("  %-58s: %.3f ms   max |d| vs shipped %.3e\n", NAME, ms, check());     \
     }
-    VARIANT("64 + 256 (the library's form)", 320)
-    VARIANT("64 + 256 + first-tile A fragment requested a block early (32768)", 320 + 32768)
-    VARIANT("64 + 256 + two rolling A fragment sets (65536)", 320 + 65536)
-    VARIANT("64 + 256", 320)
-    VARIANT("64 + 256 + 65536", 320 + 65536)
-    VARIANT("shipped once more", 0)
+    VARIANT("64 + 256 + 131072 (the library's form)", 320 + 131072)
+    VARIANT("... + 262144 + 524288", 320 + 131072 + 262144 + 524288)
+    VARIANT("... + K loop of the h part without per-chunk vector instructions (4096 + 8192)", 320 + 131072 + 262144 + 524288 + 4096 + 8192)
+    VARIANT("... + 4096 (x part too)", 320 + 131072 + 262144 + 524288 + 4096)
+    VARIANT("64 + 256 + 131072 + 262144 + 524288", 320 + 131072 + 262144 + 524288)
+    VARIANT("... + 4096 + 8192", 320 + 131072 + 262144 + 524288 + 4096 + 8192)
+    VARIANT("... + 4096", 320 + 131072 + 262144 + 524288 + 4096)
     return 0;
 }
