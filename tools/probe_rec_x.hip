@@ -77,12 +77,12 @@ int main(int argc, char** argv) {
         const float ms = run<BITS>(xseq, w, bias, Tp, Npad, fc);                       \
         printf("  %-58s: %.3f ms   max |d| vs shipped %.3e\n", NAME, ms, check());     \
     }
-    VARIANT("64 + 256 + 131072 (the library's form)", 320 + 131072)
-    VARIANT("... + 262144 + 524288", 320 + 131072 + 262144 + 524288)
-    VARIANT("... + K loop of the h part without per-chunk vector instructions (4096 + 8192)", 320 + 131072 + 262144 + 524288 + 4096 + 8192)
-    VARIANT("... + 4096 (x part too)", 320 + 131072 + 262144 + 524288 + 4096)
-    VARIANT("64 + 256 + 131072 + 262144 + 524288", 320 + 131072 + 262144 + 524288)
-    VARIANT("... + 4096 + 8192", 320 + 131072 + 262144 + 524288 + 4096 + 8192)
-    VARIANT("... + 4096", 320 + 131072 + 262144 + 524288 + 4096)
+    VARIANT("64 + 256 (round 5's first form)", 320)
+    VARIANT("+ 131072: ring fills behind the first row tile of a slice", 320 + 131072)
+    VARIANT("+ 524288: their addresses from scalar registers", 320 + 131072 + 524288)
+    VARIANT("+ 262144: output layer's tail without the 64-bit division", 320 + 131072 + 524288 + 262144)
+    VARIANT("+ 4096 (the library's form)", FSN_REC_X_OPT)
+    VARIANT("the library's form without ring fills (8)", FSN_REC_X_OPT + 8)
+    VARIANT("the library's form", FSN_REC_X_OPT)
     return 0;
 }
