@@ -244,18 +244,6 @@ __device__ __forceinline__ f32x2 tanh_fast2(f32x2 x) {
     const f32x2 r = f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
     return __builtin_elementwise_fma(r, f32x2{-2.0f, -2.0f}, f32x2{1.0f, 1.0f});
 }
-// ... with the gate's bias added here instead of seeding the accumulators with it (kb = scale * bias): one fma
-__device__ __forceinline__ f32x2 sigmoid_fast2b(f32x2 x, float kb) {
-    const f32x2 t = __builtin_elementwise_fma(x, f32x2{-1.4426950408889634f, -1.4426950408889634f}, f32x2{kb, kb});
-    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
-    return f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-}
-__device__ __forceinline__ f32x2 tanh_fast2b(f32x2 x, float kb) {
-    const f32x2 t = __builtin_elementwise_fma(x, f32x2{2.8853900817779268f, 2.8853900817779268f}, f32x2{kb, kb});
-    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
-    const f32x2 r = f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-    return __builtin_elementwise_fma(r, f32x2{-2.0f, -2.0f}, f32x2{1.0f, 1.0f});
-}
 __device__ __forceinline__ f32x2 lo2(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
 __device__ __forceinline__ f32x2 hi2(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
 __device__ __forceinline__ f32x4 cat2(f32x2 a, f32x2 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3); }
@@ -353,7 +341,6 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
     const int sb_f0 = (int)((n0 + xin.row0) - (long)sb_b0 * xin.F);
 
     constexpr bool PK = (OPT & 256) != 0;    // gate non-linearities on pairs (v_pk_*_f32), see sigmoid_fast2
-    constexpr bool BEP = PK && (OPT & 512);  // accumulators start from zero, the bias enters in the non-linearity
     constexpr bool KOPT = (OPT & 4096) != 0 && RT == 4 && KC % 6 == 0;  // see lstm_rec_x_kernel
     typename RecState<PK>::type cst[RT][UG], tmp[RT][UG];
 #pragma unroll
@@ -397,21 +384,6 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[jj], b[u][jj], acc[rt][u]);
         }
     };
-    constexpr bool JJM = (OPT & 16384) != 0;  // k-step major MFMA order in the recurrent product, see lstm_rec_x_kernel
-
-    auto mma0 = [&](f32x4 (&acc)[RT][UG], const float* a, int a_rt_stride, const f32x4 (&b)[UG]) {  // C = 0: first block of a pass
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(a + rt * a_rt_stride);
-#pragma unroll
-            for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[0], b[u][0], f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-            for (int jj = 1; jj < 4; ++jj)
-#pragma unroll
-                for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[jj], b[u][jj], acc[rt][u]);
-        }
-    };
-
     for (int t = 0; t < Tp; ++t) {
         // frame t + 1: requested now, written to the other x buffer after the first gate pass (that buffer was last
         // read in step t - 1 and is first read after the two barriers that end this step)
@@ -429,27 +401,21 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
             asm volatile("" : "+s"(gn));
             f32x4 acc[RT][UG];
             unsigned wx[UG], wh[UG], wxn[UG];
-            float kb[UG];
 #pragma unroll
             for (int u = 0; u < UG; ++u) {
                 wx[u] = wxofs(g, u);
                 wh[u] = whofs(g, u);
                 wxn[u] = wxofs(gn, u);
                 const float b = bias_n[u];
-                if (BEP) {
-                    kb[u] = b * (pass == 2 ? 2.8853900817779268f : -1.4426950408889634f);
-                } else {
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) acc[rt][u] = f32x4{b, b, b, b};
-                }
+                for (int rt = 0; rt < RT; ++rt) acc[rt][u] = f32x4{b, b, b, b};
                 bias_n[u] = xin.bias[(gn * KC + wave * UG + u) * 16 + lr];  // a pass ahead
             }
             // ---- x_t W_ih^T: two chunks -----------------------------------------------------------
 #pragma unroll
             for (int u = 0; u < UG; ++u) b1[u] = wload(wx[u] + 256u);
             __builtin_amdgcn_sched_barrier(0);
-            if (BEP) mma0(acc, xa, 16 * XS, b0);
-            else mma(acc, xa, 16 * XS, b0);
+            mma(acc, xa, 16 * XS, b0);
 #pragma unroll
             for (int u = 0; u < UG; ++u) b0[u] = wload(t > 0 ? wh[u] : wxn[u]);
             __builtin_amdgcn_sched_barrier(0);
@@ -464,19 +430,6 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 lds_cptr ha01 = (lds_cptr)(size_t)hb01;
                 lds_cptr ha23 = (lds_cptr)(size_t)hb23;
                 auto mmah = [&](int kofs, const f32x4 (&b)[UG]) {
-                    if constexpr (JJM) {
-                        f32x4 av[RT];
-#pragma unroll
-                        for (int rt = 0; rt < RT; ++rt)
-                            av[rt] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((rt < 2 ? ha01 : ha23) + (rt & 1) * 16 * HS + kofs);
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                                for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[rt][jj], b[u][jj], acc[rt][u]);
-                        return;
-                    }
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
                         const f32x4 av = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((rt < 2 ? ha01 : ha23) + (rt & 1) * 16 * HS + kofs);
@@ -586,14 +539,14 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
     }
             if constexpr (PK) {
                 if (pass == 0) {
-                    if constexpr (BEP) { FSN_REC_EPILOGUE2(cst, sigmoid_fast2b(a, kb[u]) * c) } else { FSN_REC_EPILOGUE2(cst, sigmoid_fast2(a) * c) }
+                    FSN_REC_EPILOGUE2(cst, sigmoid_fast2(a) * c)
                     if (more) stage.commit(xin, xl + ((t + 1) & 1) * ROWS * XS, XS, n0);
                 } else if (pass == 1) {
-                    if constexpr (BEP) { FSN_REC_EPILOGUE2(tmp, sigmoid_fast2b(a, kb[u])) } else { FSN_REC_EPILOGUE2(tmp, sigmoid_fast2(a)) }
+                    FSN_REC_EPILOGUE2(tmp, sigmoid_fast2(a))
                 } else if (pass == 2) {
-                    if constexpr (BEP) { FSN_REC_EPILOGUE2(cst, c + m * tanh_fast2b(a, kb[u])) } else { FSN_REC_EPILOGUE2(cst, c + m * tanh_fast2(a)) }
+                    FSN_REC_EPILOGUE2(cst, c + m * tanh_fast2(a))
                 } else {
-                    if constexpr (BEP) { FSN_REC_EPILOGUE2(tmp, sigmoid_fast2b(a, kb[u]) * tanh_fast2(c)) } else { FSN_REC_EPILOGUE2(tmp, sigmoid_fast2(a) * tanh_fast2(c)) }
+                    FSN_REC_EPILOGUE2(tmp, sigmoid_fast2(a) * tanh_fast2(c))
                 }
             } else if (pass == 0) {
                 FSN_REC_EPILOGUE(cst, sigmoid_fast(acc[rt][u][i]) * cst[rt][u][i])
@@ -636,9 +589,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
         for (int i = threadIdx.x; i < ROWS * (H / 4); i += NW * 64) {
             const int row = i / (H / 4), c4 = i % (H / 4);
             const f32x4 v = *reinterpret_cast<const f32x4*>(hl + row * HS + c4 * 4);
-            // (OPT & 1024: streamed past the L2 - 4.8 GB nobody on this XCD reads back - so that the weights stay in it)
-            if (OPT & 1024) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst + (long)row * H + c4 * 4));
-            else *reinterpret_cast<f32x4*>(dst + (long)row * H + c4 * 4) = v;
+            *reinterpret_cast<f32x4*>(dst + (long)row * H + c4 * 4) = v;
         }
     }
 }
@@ -647,32 +598,19 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
 // lds_base + 16 l.  Written as asm so that the compiler neither serialises later LDS reads behind it (it cannot tell
 // the ring stages apart and would wait for vmcnt(0) before every ds_read) nor counts it in its own vmcnt bookkeeping
 // (an extra, OLDER request in the queue can only make its counted waits longer, never too short).
-// POLICY: 0 default, 1 non-temporal (nt: the line is marked for early eviction - x slices are read by one CU only and must
-// not push the weights, which every CU of the XCD streams every step, out of the 4 MB L2), 2 sc1 sc0, 3 nt sc1 sc0.
-template <int POLICY = 0>
+// (Non-temporal / sc0 sc1 fills were measured in round 5: +0.4 .. +0.8 ms - the slices are re-read from L2 / Infinity Cache.)
 __device__ __forceinline__ void lds_dma_fragment(const float* g, unsigned lds_base) {
     unsigned saved;
-    if constexpr (POLICY == 1) {
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\ts_nop 0\n\ts_mov_b32 m0, %0"
-                     : "=&s"(saved) : "s"(lds_base), "v"(g) : "memory");
-    } else if constexpr (POLICY == 2) {
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off sc0 sc1\n\ts_nop 0\n\ts_mov_b32 m0, %0"
-                     : "=&s"(saved) : "s"(lds_base), "v"(g) : "memory");
-    } else if constexpr (POLICY == 3) {
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off sc0 sc1 nt\n\ts_nop 0\n\ts_mov_b32 m0, %0"
-                     : "=&s"(saved) : "s"(lds_base), "v"(g) : "memory");
-    } else {
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %1\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %2, off\n\t"
-            "s_nop 0\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(saved)
-            : "s"(lds_base), "v"(g)
-            : "memory");
-    }
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, off\n\t"
+        "s_nop 0\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(saved)
+        : "s"(lds_base), "v"(g)
+        : "memory");
 }
 
 // The same with the source address as a wave-uniform base (scalar registers) + this lane's byte offset: no per-fragment
@@ -691,22 +629,22 @@ __device__ __forceinline__ void lds_dma_fragment_s(const float* sbase, unsigned 
         : "memory");
 }
 
-// ABL (experiment knob of tools/probe_rec_x.hip, 0 in the library; results are WRONG with any bit set): leaves out one
-// ingredient at a time to price it - 1 slice barriers, 2 gate non-linearities, 4 output layer, 8 ring fills,
-// 16 the two barriers that end a step.  Bits 32 / 64 are scheduling experiments with correct results (round 5).  Measured (tools/probe_rec_x.hip, 52.7 ms shipped): 0.5 / 1.3 / 0.45 / 1.5 /
-// 0.4 ms, 49.3 ms without all five, 47.1 ms = the MFMAs alone at the 2.38 GHz the kernel runs at.  (Touching the next
-// step's tile ahead of its fills, so that they hit L2, changes nothing: tried.)
-// The forms the library ships (round 5, tools/probe_rec_x.hip / probe_rec_in.hip on three MI355X boxes, bit-identical
-// results): layer 1 = 64 (pass-opening barrier inside the recurrent product) + 256 (packed gate non-linearities): 52.5 ->
-// 51.8 ms; layer 0 = 4096 (K loop without per-chunk vector instructions) + 256: 28.65 -> 27.85 ms.  4096 does not pay in
-// layer 1 (51.9 - 52.0), 128 / 512 / 1024.. neither (profiles/r05_rec_probes.md).
+// ABL / OPT: the bits of the two persistent kernels' template parameter (tools/probe_rec_x.hip, probe_rec_in.hip).
+//   Pricing bits, results WRONG: 1 no slice barriers, 2 no gate non-linearities, 4 no output layer, 8 no ring fills,
+//   16 no step barriers (lstm_rec_in_kernel: 1 no hidden-sequence stores, 2 no input gather).
+//   Forms with bit-identical results: 64 the barrier that opens a pass' first ring slice taken inside the previous pass'
+//   recurrent product; 256 gate non-linearities on pairs (v_pk_*_f32); 4096 (+ 8192: h part only) the K loop without
+//   per-chunk vector instructions; 32768 (layer 0) the next block's first-tile A fragment requested a block early;
+//   131072 a slice's ring fills behind the first row tile of its first block; 262144 the output layer's tail without a
+//   64-bit division per step; 524288 the fills' addresses from scalar registers.
+// What each is worth, and the variants that were measured and removed from this file again (wave priorities, fills by
+// one wave per SIMD in rotation, non-temporal fills / stores, zero-seeded accumulators, k-step-major MFMA order, two
+// rolling A fragment sets, merged reciprocals, a step without its barriers): profiles/r05_rec_probes.md.
 #ifndef FSN_REC_X_OPT
-// + 131072: a slice's ring fills behind the first row tile of its first block (51.7 -> 51.3 ms); + 524288: their addresses
-// from scalar registers (-> 50.6); + 262144: the output layer's tail without a 64-bit division per step (-> 50.4); + 4096 (-> 50.3)
-#define FSN_REC_X_OPT (64 | 256 | 131072 | 262144 | 524288 | 4096)
+#define FSN_REC_X_OPT (64 | 256 | 4096 | 131072 | 262144 | 524288)  // 52.9 (round 4) -> 50.3 ms stand-alone
 #endif
 #ifndef FSN_REC_IN_OPT
-#define FSN_REC_IN_OPT (4096 | 256 | 32768)  // + 32768: the next block's first-tile A fragment requested a block early: 27.78 -> 27.40 ms (nothing in layer 1: 20 spilled registers)
+#define FSN_REC_IN_OPT (256 | 4096 | 32768)  // 28.65 -> 27.4 ms stand-alone
 #endif
 #ifndef FSN_REC_VCAP
 #define FSN_REC_VCAP 76  // x 2 on gfx950's unified register file = 152: three waves per SIMD + room for a step workgroup
@@ -740,11 +678,6 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const long n0 = (long)blockIdx.x * ROWS;
-    if (ABL & 32) {  // experiment: static priorities among the three waves of a SIMD (waves w, w + 4, w + 8 share one)
-        if ((wave >> 2) == 0) __builtin_amdgcn_s_setprio(0);
-        else if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(2);
-    }
     if (!HSEQ)
         for (int i = threadIdx.x; i < 2 * H; i += NW * 64) {  // rows 0 / 1 of the packed output weights, un-tiled
             const int c = i / H, k = i % H;
@@ -764,8 +697,6 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
         fc_bias0 = fc.bias[0];
         fc_bias1 = fc.bias[1];
     }
-    constexpr bool ROT = (ABL & 128) && NW == 12;  // ring fills by ONE wave of every SIMD per slice, in rotation
-    constexpr int FPOL = (ABL >> 10) & 3;          // cache policy of the ring fills (lds_dma_fragment)
     // KOPT: the recurrent product's K loop without per-chunk vector instructions.  Vector instructions and fp32 MFMAs share
     // the SIMD (tools/probe_overlap.hip), and the rolled loop spent 11 of them per 64 MFMAs: the hidden state sits beyond
     // the 64 KB an LDS read's immediate offset reaches, so every row tile's address was re-derived per chunk (6 v_add), and
@@ -774,7 +705,6 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
     // fragment pinned behind the last MFMA that reads it, so that it returns into the same registers.
     constexpr bool KOPT = (ABL & 4096) != 0 && RT == 4;
     constexpr bool PK = (ABL & 256) != 0;          // gate non-linearities on pairs (v_pk_*_f32)
-    constexpr bool BEP = PK && (ABL & 512);        // accumulators start from zero, the bias enters in the non-linearity
     typename RecState<PK>::type cst[RT][UG], tmp[RT][UG];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -787,24 +717,11 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
     // ring stage `buf` <- slice `sl` of x_t: this wave's share of the NF fragments
     const unsigned xlane = (unsigned)(lr * H + 4 * lq);  // lane part of the source address; the rest is uniform
     const unsigned xs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)xs;  // LDS byte address
-    // (ROT: loads return in order per wave, so the weight fragment requested behind a fill waits for the fill's HBM round
-    // trip; with every wave filling, all three waves of a SIMD stall together and the matrix pipe idles - with one wave
-    // group (waves g, g + 4, g + 8 share SIMD g... the groups are wave >> 2) filling per slice, its two siblings keep
-    // the pipe busy meanwhile.  who < 0: every wave, the prologue.)
-    auto fill = [&](int buf, int t, int sl, int who) {
+    auto fill = [&](int buf, int t, int sl) {
         const float* src = xseq + ((long)t * Npad + n0) * H + sl * (SK * 16);  // wave-uniform
-        if (ROT && who >= 0) {
-            if ((wave >> 2) != who) return;
-            for (int f = wave & 3; f < NF; f += 4) {
-                const int rt = f / SK, kcl = f - rt * SK;
-                lds_dma_fragment<FPOL>(src + (rt * 16 * H + kcl * 16) + xlane,
-                                 __builtin_amdgcn_readfirstlane(xs_lds + (unsigned)((buf * NF + f) * 1024)));
-            }
-            return;
-        }
         for (int f = wave; f < NF; f += NW) {
             const int rt = f / SK, kcl = f - rt * SK;
-            lds_dma_fragment<FPOL>(src + (rt * 16 * H + kcl * 16) + xlane,
+            lds_dma_fragment(src + (rt * 16 * H + kcl * 16) + xlane,
                              __builtin_amdgcn_readfirstlane(xs_lds + (unsigned)((buf * NF + f) * 1024)));
         }
     };
@@ -827,7 +744,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
         for (int i = 0; i < FPW; ++i)
             lds_dma_fragment_s(src + fsa_src[i], xlane_bytes, (unsigned)(fsa_lds[i] + buf * (NF * 1024)));
     };
-    fill(0, 0, 0, -1);
+    fill(0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -858,20 +775,6 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
     }
     // acc[rt][u] += A(16 rows x 16 k) B(16 k x 16 units): a = this lane's A fragment address of row tile 0
     auto mma = [&](f32x4 (&acc)[RT][UG], const float* a, int a_rt_stride, const f32x4 (&b)[UG]) {
-        if constexpr ((ABL & 16384) != 0) {
-            // k-step major: an accumulator is touched again RT UG MFMAs later (a dependent v_mfma_f32_16x16x4_f32 issues 40
-            // cycles after its producer, an independent one 32)
-            f32x4 av[RT];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) av[rt] = *reinterpret_cast<const f32x4*>(a + rt * a_rt_stride);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                    for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[rt][jj], b[u][jj], acc[rt][u]);
-            return;
-        }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const f32x4 av = *reinterpret_cast<const f32x4*>(a + rt * a_rt_stride);
@@ -880,85 +783,15 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
 #pragma unroll
                 for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[jj], b[u][jj], acc[rt][u]);
         }
-    };
-
-    // the first K block of a pass when the accumulators start from zero (BEP): C = 0 is an inline operand of the first MFMA
-    auto mma0 = [&](f32x4 (&acc)[RT][UG], const float* a, int a_rt_stride, const f32x4 (&b)[UG]) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(a + rt * a_rt_stride);
-#pragma unroll
-            for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[0], b[u][0], f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-            for (int jj = 1; jj < 4; ++jj)
-#pragma unroll
-                for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[jj], b[u][jj], acc[rt][u]);
-        }
-    };
-
-    // APF (ABL & 32768): block k's first row tile comes from `apre`, requested a block earlier - right behind block k - 1's
-    // first-tile MFMAs, into the registers they had just read - instead of at the head of block k, where the block's first
-    // MFMA waited for it; tiles 1 - 3 have the MFMAs before them to land (lstm_rec_in_kernel: -0.37 ms)
-    constexpr bool APF = (ABL & 32768) != 0;
-    f32x4 apre = {0.f, 0.f, 0.f, 0.f};
-    auto mma_pf = [&](f32x4 (&acc)[RT][UG], const float* a, int a_rt_stride, const f32x4 (&b)[UG], const float* next) {
-        f32x4 av[RT];
-#pragma unroll
-        for (int rt = 1; rt < RT; ++rt) av[rt] = *reinterpret_cast<const f32x4*>(a + rt * a_rt_stride);
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int u = 0; u < UG; ++u) acc[0][u] = mfma16(apre[jj], b[u][jj], acc[0][u]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (next) apre = *reinterpret_cast<const f32x4*>(next);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int rt = 1; rt < RT; ++rt)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[rt][jj], b[u][jj], acc[rt][u]);
-    };
-
-    // ROLL (ABL & 65536, RT = 4): TWO fragment registers sets instead of four - tiles 0 / 1 of a block arrive prefetched,
-    // tile 2 is requested into tile 0's registers right behind tile 0's MFMAs, tile 3 into tile 1's, then the next block's
-    // tiles 0 / 1 behind tiles 2 / 3: every A fragment is requested one tile slot (256 matrix cycles) before its first use,
-    // and eight registers are free
-    constexpr bool ROLL = (ABL & 65536) != 0 && RT == 4;
-    f32x4 fa = {0.f, 0.f, 0.f, 0.f}, fb = {0.f, 0.f, 0.f, 0.f};
-    auto mma_roll = [&](f32x4 (&acc)[RT][UG], const float* a, int a_rt_stride, const f32x4 (&b)[UG], const float* next,
-                        int next_rt_stride) {
-        auto tile = [&](int rt, const f32x4 av) {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                for (int u = 0; u < UG; ++u) acc[rt][u] = mfma16(av[jj], b[u][jj], acc[rt][u]);
-        };
-        tile(0, fa);
-        __builtin_amdgcn_sched_barrier(0);
-        fa = *reinterpret_cast<const f32x4*>(a + 2 * a_rt_stride);
-        __builtin_amdgcn_sched_barrier(0);
-        tile(1, fb);
-        __builtin_amdgcn_sched_barrier(0);
-        fb = *reinterpret_cast<const f32x4*>(a + 3 * a_rt_stride);
-        __builtin_amdgcn_sched_barrier(0);
-        tile(2, fa);
-        __builtin_amdgcn_sched_barrier(0);
-        if (next) fa = *reinterpret_cast<const f32x4*>(next);
-        __builtin_amdgcn_sched_barrier(0);
-        tile(3, fb);
-        __builtin_amdgcn_sched_barrier(0);
-        if (next) fb = *reinterpret_cast<const f32x4*>(next + next_rt_stride);
     };
 
     // FLATE (ABL & 131072): a slice's ring fills are issued BEHIND the first row tile's MFMAs of the slice's first block
-    // instead of ahead of the block.  Loads return in order and the compiler's counted waits do not know the fills: ahead of
-    // the block, the block's own wait for its weight fragment (vmcnt(UG), the fragment requested a block earlier) also
-    // waited for the fills' HBM round trip, in all twelve waves at once; behind the wait they have the block to land.
+    // instead of ahead of the block: the block that follows a slice barrier - where all twelve waves stand together - opens
+    // with two LDS reads and eight MFMAs, and the fills' instructions run under the other waves' MFMAs (the same gain was
+    // measured with the fills left out: it is the shape of the block, not the fills' latency).
     constexpr bool FLATE = (ABL & 131072) != 0;
-    auto mma_fill = [&](f32x4 (&acc)[RT][UG], const float* a, int a_rt_stride, const f32x4 (&b)[UG], int buf, int nt, int nsl,
-                        const float* next) {
-        const f32x4 a0 = APF ? apre : *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + a_rt_stride);
+    auto mma_fill = [&](f32x4 (&acc)[RT][UG], const float* a, int a_rt_stride, const f32x4 (&b)[UG], int buf, int nt, int nsl) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + a_rt_stride);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -966,9 +799,8 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
         __builtin_amdgcn_sched_barrier(0);
         if (nt < Tp && !(ABL & 8)) {
             if (FSA) fill_s(buf, nt, nsl);
-            else fill(buf, nt, nsl, -1);
+            else fill(buf, nt, nsl);
         }
-        if (APF) apre = *reinterpret_cast<const f32x4*>(next);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int rt = 1; rt < RT; ++rt) {
@@ -991,19 +823,14 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
             asm volatile("" : "+s"(gn));
             f32x4 acc[RT][UG];
             unsigned wx[UG], wh[UG], wxn[UG];  // uniform offsets: W_ih / W_hh of this gate, W_ih of the next one
-            float kb[UG];                      // BEP: this gate's bias times the scale of its exponent
 #pragma unroll
             for (int u = 0; u < UG; ++u) {
                 wx[u] = wofs(g, u);
                 wh[u] = wx[u] + whh_off;
                 wxn[u] = wofs(gn, u);
                 const float b = bias_n[u];
-                if (BEP) {
-                    kb[u] = b * (pass == 2 ? 2.8853900817779268f : -1.4426950408889634f);
-                } else {
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) acc[rt][u] = f32x4{b, b, b, b};
-                }
+                for (int rt = 0; rt < RT; ++rt) acc[rt][u] = f32x4{b, b, b, b};
                 bias_n[u] = bias[(gn * KC + wave * UG + u) * 16 + lr];
             }
             // ---- x_t W_ih^T, slice by slice ------------------------------------------------------
@@ -1026,15 +853,10 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 const int nsl = sl + 1 < NSL ? sl + 1 : 0;
                 const int nt = (sl + 1 < NSL || pass < 3) ? t : t + 1;
                 if (!FLATE) {
-                    if (nt < Tp && !(ABL & 8)) fill((j + 1) & 1, nt, nsl, (int)((unsigned)j % 3u));
+                    if (nt < Tp && !(ABL & 8)) fill((j + 1) & 1, nt, nsl);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const float* xa = xs + ((j & 1) * NF) * 256 + lane * 4;
-                if (APF) apre = *reinterpret_cast<const f32x4*>(xa);  // a slice's first block: its stage has only just been released
-                if (ROLL) {
-                    fa = *reinterpret_cast<const f32x4*>(xa);
-                    fb = *reinterpret_cast<const f32x4*>(xa + SK * 256);
-                }
 #pragma unroll
                 for (int kk = 0; kk < SK; kk += 2) {
                     const int kc = sl * SK + kk;
@@ -1042,10 +864,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                     for (int u = 0; u < UG; ++u)
                         b1[u] = wload(wx[u] + (unsigned)(kc + 1) * 256u);
                     __builtin_amdgcn_sched_barrier(0);  // requests first, pinned: hipcc otherwise sinks them to their use
-                    if (FLATE && kk == 0) mma_fill(acc, xa, SK * 256, b0, (j + 1) & 1, nt, nsl, xa + 256);
-                    else if (ROLL) mma_roll(acc, xa + kk * 256, SK * 256, b0, xa + (kk + 1) * 256, SK * 256);
-                    else if (APF) mma_pf(acc, xa + kk * 256, SK * 256, b0, xa + (kk + 1) * 256);
-                    else if (BEP && kk == 0 && sl == 0) mma0(acc, xa + kk * 256, SK * 256, b0);
+                    if (FLATE && kk == 0) mma_fill(acc, xa, SK * 256, b0, (j + 1) & 1, nt, nsl);
                     else mma(acc, xa + kk * 256, SK * 256, b0);
                     if (KOPT && !(ABL & 8192)) __builtin_amdgcn_sched_barrier(0);
                     // chunk kc + 2: W_ih, or the first chunk of W_hh, or (h_{-1} = 0: no W_hh product) of the next pass
@@ -1055,19 +874,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                         b0[u] = wload(more_x ? wx[u] + (unsigned)(kc + 2) * 256u : (t > 0 ? wh[u] : wxn[u]));
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (ROLL) {
-                        const bool to_h = sl + 1 == NSL && t > 0;
-                        const float* nx = kk + 2 < SK ? xa + (kk + 2) * 256 : (to_h ? hl + lr * HS + 4 * lq : nullptr);
-                        mma_roll(acc, xa + (kk + 1) * 256, SK * 256, b1, nx, kk + 2 < SK ? SK * 256 : 16 * HS);
-                    } else if (APF) {
-                        // next: the slice's next block; behind a slice's last block the next stage is not released yet (its
-                        // barrier comes first) - except behind the LAST slice, where the recurrent product's first block
-                        // follows (the hidden state is stable through the step)
-                        const float* nx = kk + 2 < SK ? xa + (kk + 2) * 256 : ((sl + 1 == NSL && t > 0) ? hl + lr * HS + 4 * lq : nullptr);
-                        mma_pf(acc, xa + (kk + 1) * 256, SK * 256, b1, nx);
-                    } else {
-                        mma(acc, xa + (kk + 1) * 256, SK * 256, b1);
-                    }
+                    mma(acc, xa + (kk + 1) * 256, SK * 256, b1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -1131,18 +938,14 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                     for (int u = 0; u < UG; ++u)
                         b1[u] = wload(wh[u] + (unsigned)(kc + 1) * 256u);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (ROLL) mma_roll(acc, ha + kc * 16, 16 * HS, b0, ha + (kc + 1) * 16, 16 * HS);
-                    else if (APF) mma_pf(acc, ha + kc * 16, 16 * HS, b0, ha + (kc + 1) * 16);
-                    else mma(acc, ha + kc * 16, 16 * HS, b0);
+                    mma(acc, ha + kc * 16, 16 * HS, b0);
                     const bool more_h = kc + 2 < KC;
 #pragma unroll
                     for (int u = 0; u < UG; ++u) {
                         b0[u] = wload(more_h ? wh[u] + (unsigned)(kc + 2) * 256u : wxn[u]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (ROLL) mma_roll(acc, ha + (kc + 1) * 16, 16 * HS, b1, more_h ? ha + (kc + 2) * 16 : nullptr, 16 * HS);
-                    else if (APF) mma_pf(acc, ha + (kc + 1) * 16, 16 * HS, b1, more_h ? ha + (kc + 2) * 16 : nullptr);
-                    else mma(acc, ha + (kc + 1) * 16, 16 * HS, b1);
+                    mma(acc, ha + (kc + 1) * 16, 16 * HS, b1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -1163,26 +966,14 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
         asm volatile("" : "+v"(VAR[rt][u]));                                                          \
     }
             if constexpr (PK && !(ABL & 2)) {
-                if constexpr (BEP) {
-                    if (pass == 0) {
-                        FSN_REC_EPILOGUE2(cst, sigmoid_fast2b(a, kb[u]) * c)
-                    } else if (pass == 1) {
-                        FSN_REC_EPILOGUE2(tmp, sigmoid_fast2b(a, kb[u]))
-                    } else if (pass == 2) {
-                        FSN_REC_EPILOGUE2(cst, c + m * tanh_fast2b(a, kb[u]))
-                    } else {
-                        FSN_REC_EPILOGUE2(tmp, sigmoid_fast2b(a, kb[u]) * tanh_fast2(c))
-                    }
+                if (pass == 0) {
+                    FSN_REC_EPILOGUE2(cst, sigmoid_fast2(a) * c)
+                } else if (pass == 1) {
+                    FSN_REC_EPILOGUE2(tmp, sigmoid_fast2(a))
+                } else if (pass == 2) {
+                    FSN_REC_EPILOGUE2(cst, c + m * tanh_fast2(a))
                 } else {
-                    if (pass == 0) {
-                        FSN_REC_EPILOGUE2(cst, sigmoid_fast2(a) * c)
-                    } else if (pass == 1) {
-                        FSN_REC_EPILOGUE2(tmp, sigmoid_fast2(a))
-                    } else if (pass == 2) {
-                        FSN_REC_EPILOGUE2(cst, c + m * tanh_fast2(a))
-                    } else {
-                        FSN_REC_EPILOGUE2(tmp, sigmoid_fast2(a) * tanh_fast2(c))
-                    }
+                    FSN_REC_EPILOGUE2(tmp, sigmoid_fast2(a) * tanh_fast2(c))
                 }
             } else if constexpr (PK) {
             } else if (ABL & 2) {
