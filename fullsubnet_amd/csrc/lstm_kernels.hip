@@ -272,20 +272,35 @@ template <> struct RecState<true> { typedef f32x4 type; };
 // divides and writes them to the LDS tile a gate pass later.  No 64-bit division per element: the rows of a
 // workgroup are consecutive, so (b, f) of a row follow from (b0, f0) of the workgroup's first row by a carry.
 // Same operands, same IEEE division as fsn_sb_input_value: bit-identical values.
-template <int NTHREADS, int ROWS, int EPT>
+// ROWSIN: the plain row-major form of the layer input (FsnSbInput::x_rows, COLS = 16 or 32 columns, zero padded in
+// memory) - requested the same way, nothing to divide.
+template <int NTHREADS, int ROWS, int EPT, int COLS = 32, bool ROWSIN = false>
 struct SbStage {
-    float raw[EPT], den[EPT];
+    static constexpr int LOGC = COLS == 32 ? 5 : 4;
+    static_assert(COLS == 32 || COLS == 16, "one or two K chunks");
+    float raw[EPT], den[ROWSIN ? 1 : EPT];
     __device__ __forceinline__ void issue(const FsnSbInput& x, long n0, int b0, int f0, int t) {
         // the element indices do not depend on the step; left visible, the optimiser computes them once and keeps
         // a dozen registers live through the whole kernel
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
+        if constexpr (ROWSIN) {
+            const float* frame = x.x_rows + ((long)t * x.x_step + n0) * x.x_ld;  // wave-uniform
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int i = tid + e * NTHREADS;
+                const int row = i >> LOGC, c = i & (COLS - 1);
+                const bool ok = i < ROWS * COLS && n0 + row < x.N;
+                raw[e] = frame[ok ? (long)row * x.x_ld + c : 0];  // branch-free; replaced by zero in commit()
+            }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int i = tid + e * NTHREADS;
-            const int row = i >> 5, c = i & 31;  // 32 input columns (two K chunks)
+            const int row = i >> LOGC, c = i & (COLS - 1);  // 32 input columns (two K chunks)
             const long n = n0 + row;             // local row (validity, per-row divisors); (b, f) are global
-            const bool ok = i < ROWS * 32 && n < x.N && c <= 2 * x.nb + 1;
+            const bool ok = i < ROWS * COLS && n < x.N && c <= 2 * x.nb + 1;
             const unsigned fr = (unsigned)(f0 + row), q = fr / (unsigned)x.F;  // the carry: rows are consecutive
             const int b = b0 + (int)q, f = (int)(fr - q * (unsigned)x.F);
             const long fo = ((long)b * x.Tp + t) * x.FP;
@@ -304,9 +319,13 @@ struct SbStage {
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int i = tid + e * NTHREADS;
-            const int row = i >> 5, c = i & 31;
-            const bool ok = n0 + row < x.N && c <= 2 * x.nb + 1;
-            if (i < ROWS * 32) xl[row * xs + c] = ok ? raw[e] / den[e] : 0.f;
+            const int row = i >> LOGC, c = i & (COLS - 1);
+            if constexpr (ROWSIN) {
+                if (i < ROWS * COLS) xl[row * xs + c] = n0 + row < x.N ? raw[e] : 0.f;
+            } else {
+                const bool ok = n0 + row < x.N && c <= 2 * x.nb + 1;
+                if (i < ROWS * COLS) xl[row * xs + c] = ok ? raw[e] / den[e] : 0.f;
+            }
         }
     }
 };
@@ -321,24 +340,28 @@ struct SbStage {
 //   - the two barriers of a step only order LDS traffic;
 //   - the bias of the next pass is requested a pass ahead.
 // W_hh must follow W_ih in one packed buffer (element offset whh_off).  hseq [Tp][Npad][H] receives h_t.
-template <int H, int RT, int UG, int OPT = 0>
+// KX: K chunks of the layer input (2: the sub-band model's 32 columns; 1 or 2 with ROWSIN, the plain row-major input of
+// any stacked LSTM's first layer - Fast FullSubNet's bottleneck is 16 columns wide: fast_fullsubnet/model.py:66-74).  With
+// ONE x chunk a pass walks an odd number of K chunks, so the two weight-fragment registers sets swap roles from pass to pass
+// (four passes per step: every step starts the same way).
+template <int H, int RT, int UG, int OPT = 0, int KX = 2, bool ROWSIN = false>
 __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgpr(76))) void lstm_rec_in_kernel(
     const FsnSbInput xin, const float* __restrict__ w_p, unsigned whh_off, float* __restrict__ hseq, int Tp, int Npad) {
     constexpr int NW = H / (16 * UG);
     constexpr int KC = H / 16;
-    constexpr int KX = 2;   // x chunks (32 input columns)
+    static_assert(KX == 2 || (KX == 1 && ROWSIN), "the gathered sub-band input is two chunks wide");
     constexpr int HS = H + 4;
-    constexpr int XS = 36;  // row stride of the x tile
+    constexpr int XS = 16 * KX + 4;  // row stride of the x tile
     constexpr int ROWS = RT * 16;
-    constexpr int EPT = (ROWS * 32 + NW * 64 - 1) / (NW * 64);
+    constexpr int EPT = (ROWS * 16 * KX + NW * 64 - 1) / (NW * 64);
     extern __shared__ __attribute__((aligned(16))) float hl[];  // [ROWS][HS] | xl [2][ROWS][XS]
     float* xl = hl + ROWS * HS;
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const long n0 = (long)blockIdx.x * ROWS;
-    const int sb_b0 = (int)((n0 + xin.row0) / xin.F);  // (b, f) of the workgroup's first row, once
-    const int sb_f0 = (int)((n0 + xin.row0) - (long)sb_b0 * xin.F);
+    const int sb_b0 = ROWSIN ? 0 : (int)((n0 + xin.row0) / xin.F);  // (b, f) of the workgroup's first row, once
+    const int sb_f0 = ROWSIN ? 0 : (int)((n0 + xin.row0) - (long)sb_b0 * xin.F);
 
     constexpr bool PK = (OPT & 256) != 0;    // gate non-linearities on pairs (v_pk_*_f32), see sigmoid_fast2
     constexpr bool KOPT = (OPT & 4096) != 0 && RT == 4 && KC % 6 == 0;  // see lstm_rec_x_kernel
@@ -350,7 +373,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
 #pragma unroll
             for (int i = 0; i < 4; ++i) cst[rt][u][i] = 0.f;
     for (int i = threadIdx.x; i < ROWS * HS; i += NW * 64) hl[i] = 0.f;
-    SbStage<NW * 64, ROWS, EPT> stage;
+    SbStage<NW * 64, ROWS, EPT, 16 * KX, ROWSIN> stage;
     stage.issue(xin, n0, sb_b0, sb_f0, 0);
     stage.commit(xin, xl, XS, n0);
     __syncthreads();
@@ -400,6 +423,12 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
             asm volatile("" : "+s"(g));  // opaque: see lstm_rec_kernel
             asm volatile("" : "+s"(gn));
             f32x4 acc[RT][UG];
+            // B0: the fragments this pass starts with, B1: the other set; C0 / C1: the same for the recurrent product
+            const bool SW = KX == 1 && (pass & 1);  // (a constant once the passes are unrolled)
+            f32x4 (&B0)[UG] = SW ? b1 : b0;
+            f32x4 (&B1)[UG] = SW ? b0 : b1;
+            f32x4 (&C0)[UG] = KX == 1 ? B1 : B0;
+            f32x4 (&C1)[UG] = KX == 1 ? B0 : B1;
             unsigned wx[UG], wh[UG], wxn[UG];
 #pragma unroll
             for (int u = 0; u < UG; ++u) {
@@ -411,15 +440,22 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 for (int rt = 0; rt < RT; ++rt) acc[rt][u] = f32x4{b, b, b, b};
                 bias_n[u] = xin.bias[(gn * KC + wave * UG + u) * 16 + lr];  // a pass ahead
             }
-            // ---- x_t W_ih^T: two chunks -----------------------------------------------------------
+            // ---- x_t W_ih^T: two chunks (or one) --------------------------------------------------
+            if constexpr (KX == 2) {
 #pragma unroll
-            for (int u = 0; u < UG; ++u) b1[u] = wload(wx[u] + 256u);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(acc, xa, 16 * XS, b0);
+                for (int u = 0; u < UG; ++u) B1[u] = wload(wx[u] + 256u);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(acc, xa, 16 * XS, B0);
 #pragma unroll
-            for (int u = 0; u < UG; ++u) b0[u] = wload(t > 0 ? wh[u] : wxn[u]);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(acc, xa + 16, 16 * XS, b1);
+                for (int u = 0; u < UG; ++u) B0[u] = wload(t > 0 ? wh[u] : wxn[u]);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(acc, xa + 16, 16 * XS, B1);
+            } else {
+#pragma unroll
+                for (int u = 0; u < UG; ++u) B1[u] = wload(t > 0 ? wh[u] : wxn[u]);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(acc, xa, 16 * XS, B0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             // ---- h_{t-1} W_hh^T (h_{-1} = 0) -------------------------------------------------------
             if (KOPT && t > 0) {
@@ -471,15 +507,15 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                         for (int kk = 0; kk < 6; kk += 2) {
                             const int kc = hs * 6 + kk;
 #pragma unroll
-                            for (int u = 0; u < UG; ++u) b1[u] = wload(wh[u] + (unsigned)(kc + 1) * 256u);
+                            for (int u = 0; u < UG; ++u) C1[u] = wload(wh[u] + (unsigned)(kc + 1) * 256u);
                             __builtin_amdgcn_sched_barrier(0);
-                            blk(kk * 16, b0, true);
+                            blk(kk * 16, C0, true);
                             __builtin_amdgcn_sched_barrier(0);
                             const bool more_h = kc + 2 < KC;
 #pragma unroll
-                            for (int u = 0; u < UG; ++u) b0[u] = wload(more_h ? wh[u] + (unsigned)(kc + 2) * 256u : wxn[u]);
+                            for (int u = 0; u < UG; ++u) C0[u] = wload(more_h ? wh[u] + (unsigned)(kc + 2) * 256u : wxn[u]);
                             __builtin_amdgcn_sched_barrier(0);
-                            blk((kk + 1) * 16, b1, more_h);
+                            blk((kk + 1) * 16, C1, more_h);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                         ha01 += 6 * 16;
@@ -492,15 +528,15 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                     for (int kk = 0; kk < 6; kk += 2) {
                         const int kc = hs * 6 + kk;
 #pragma unroll
-                        for (int u = 0; u < UG; ++u) b1[u] = wload(wh[u] + (unsigned)(kc + 1) * 256u);
+                        for (int u = 0; u < UG; ++u) C1[u] = wload(wh[u] + (unsigned)(kc + 1) * 256u);
                         __builtin_amdgcn_sched_barrier(0);
-                        mmah(kk * 16, b0);
+                        mmah(kk * 16, C0);
                         __builtin_amdgcn_sched_barrier(0);
                         const bool more_h = kc + 2 < KC;
 #pragma unroll
-                        for (int u = 0; u < UG; ++u) b0[u] = wload(more_h ? wh[u] + (unsigned)(kc + 2) * 256u : wxn[u]);
+                        for (int u = 0; u < UG; ++u) C0[u] = wload(more_h ? wh[u] + (unsigned)(kc + 2) * 256u : wxn[u]);
                         __builtin_amdgcn_sched_barrier(0);
-                        mmah((kk + 1) * 16, b1);
+                        mmah((kk + 1) * 16, C1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     ha01 += 6 * 16;
@@ -510,14 +546,14 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
 #pragma unroll 1
                 for (int kc = 0; kc < KC; kc += 2) {
 #pragma unroll
-                    for (int u = 0; u < UG; ++u) b1[u] = wload(wh[u] + (unsigned)(kc + 1) * 256u);
+                    for (int u = 0; u < UG; ++u) C1[u] = wload(wh[u] + (unsigned)(kc + 1) * 256u);
                     __builtin_amdgcn_sched_barrier(0);
-                    mma(acc, ha + kc * 16, 16 * HS, b0);
+                    mma(acc, ha + kc * 16, 16 * HS, C0);
                     const bool more_h = kc + 2 < KC;
 #pragma unroll
-                    for (int u = 0; u < UG; ++u) b0[u] = wload(more_h ? wh[u] + (unsigned)(kc + 2) * 256u : wxn[u]);
+                    for (int u = 0; u < UG; ++u) C0[u] = wload(more_h ? wh[u] + (unsigned)(kc + 2) * 256u : wxn[u]);
                     __builtin_amdgcn_sched_barrier(0);
-                    mma(acc, ha + (kc + 1) * 16, 16 * HS, b1);
+                    mma(acc, ha + (kc + 1) * 16, 16 * HS, C1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -1819,11 +1855,11 @@ int launch_rec_x(const float* xseq, const float* wih_p, const float* whh_p, cons
     return fsn_check_launch("lstm_rec_x_kernel");
 }
 
-template <int H, int RT, int UG = 2>
+template <int H, int RT, int KX = 2, bool ROWSIN = false, int UG = 2>
 int launch_rec_in(const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad, int main_wgs, hipStream_t s) {
     constexpr int NW = H / (16 * UG);
-    const size_t lds = ((size_t)RT * 16 * (H + 4) + (size_t)2 * RT * 16 * 36) * sizeof(float);
-    auto kern = lstm_rec_in_kernel<H, RT, UG, FSN_REC_IN_OPT>;
+    const size_t lds = ((size_t)RT * 16 * (H + 4) + (size_t)2 * RT * 16 * (16 * KX + 4)) * sizeof(float);
+    auto kern = lstm_rec_in_kernel<H, RT, UG, FSN_REC_IN_OPT, KX, ROWSIN>;
     if (lds > 160 * 1024 ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
@@ -1837,11 +1873,13 @@ int launch_rec_in(const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp
 
 }  // namespace
 
-// First sub-band layer on lstm_rec_in_kernel: the 32-column sub-band input (two K chunks), H = 384, 2 - 4 row tiles
-// per workgroup, W_hh packed right behind W_ih.  Anything else stays on lstm_rec_kernel<.., XIN = true>.
+// First layer of a stack on lstm_rec_in_kernel: the 32-column gathered sub-band input (two K chunks) or a plain row-major
+// input of one or two chunks, H = 384, 2 - 4 row tiles per workgroup, W_hh packed right behind W_ih.  Anything else stays
+// on lstm_rec_kernel<.., XIN = true>.
 bool fsn_lstm_rec_in_supported(const FsnSbInput* xin, const float* whh_p, int H, int RT) {
-    return xin && !xin->x_rows && xin->kin_chunks == 2 && H == 384 && RT >= 2 && RT <= 4 && whh_p > xin->wih_p &&
-           whh_p - xin->wih_p < 0x3fffffffL;
+    const bool shape = xin && (xin->x_rows ? (xin->kin_chunks == 1 || xin->kin_chunks == 2) && xin->x_ld >= 16 * xin->kin_chunks
+                                           : xin->kin_chunks == 2);
+    return shape && H == 384 && RT >= 2 && RT <= 4 && whh_p > xin->wih_p && whh_p - xin->wih_p < 0x3fffffffL;
 }
 
 int fsn_launch_lstm_rec_in(const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad, int H, int RT,
@@ -1850,9 +1888,18 @@ int fsn_launch_lstm_rec_in(const FsnSbInput* xin, const float* whh_p, float* hse
         fsn_set_error("lstm_rec_in: unsupported configuration");
         return FSN_ERR_ARG;
     }
-    if (RT == 2) return launch_rec_in<384, 2>(xin, whh_p, hseq, Tp, Npad, main_wgs, s);
-    if (RT == 3) return launch_rec_in<384, 3>(xin, whh_p, hseq, Tp, Npad, main_wgs, s);
-    return launch_rec_in<384, 4>(xin, whh_p, hseq, Tp, Npad, main_wgs, s);
+#define FSN_REC_IN_CASE(R)                                                                                         \
+    if (RT == R) {                                                                                                 \
+        if (!xin->x_rows) return launch_rec_in<384, R>(xin, whh_p, hseq, Tp, Npad, main_wgs, s);                   \
+        if (xin->kin_chunks == 2) return launch_rec_in<384, R, 2, true>(xin, whh_p, hseq, Tp, Npad, main_wgs, s);  \
+        return launch_rec_in<384, R, 1, true>(xin, whh_p, hseq, Tp, Npad, main_wgs, s);                            \
+    }
+    FSN_REC_IN_CASE(2)
+    FSN_REC_IN_CASE(3)
+    FSN_REC_IN_CASE(4)
+#undef FSN_REC_IN_CASE
+    fsn_set_error("lstm_rec_in: unsupported row tiles %d", RT);
+    return FSN_ERR_ARG;
 }
 
 // The last sub-band layer with its input projection inside (lstm_rec_x_kernel): built for H = 384 and 2 - 4 row
