@@ -230,6 +230,28 @@ def test_sequence_model_inference_and_training_vs_torch(fsn, cell, I, H, O, laye
             assert (g - r).abs().max().item() <= 1e-4 * max(r.abs().max().item(), 1.0), (n, k)
 
 
+
+@pytest.mark.parametrize("I,O,B", [(12, 1, 8192), (24, 0, 8192), (28, 1, 12288), (12, 0, 8300)])
+def test_stacked_lstm_on_the_persistent_kernels_vs_torch(fsn, I, O, B):
+    """A two-layer H = 384 stack with a narrow input on enough rows for the persistent kernels (512 / 768 row tiles: two /
+    three per workgroup, nothing left over): layer 0 on lstm_rec_in_kernel's row-major form with one (I <= 16) or two K
+    chunks of input, layer 1 on lstm_rec_x_kernel (hidden sequence out, or the fused output layer); 8300 rows (left-over
+    tiles): the projection GEMM + lstm_rec_kernel.  Against ATen's nn.LSTM / nn.Linear on the CPU (sequence_model.py:52-58)."""
+    from fullsubnet_amd.sequence_model import SequenceModel
+    torch.manual_seed(I + B)
+    T, H = 5, 384
+    m = SequenceModel(I, O, H, 2, False, "LSTM", "ReLU" if O else None)
+    ref = torch.nn.LSTM(I, H, 2, batch_first=True)
+    ref.load_state_dict(m.sequence_model.state_dict())
+    x = torch.randn(B, I, T)
+    with torch.no_grad():
+        want, _ = ref(x.permute(0, 2, 1))
+        if O:
+            want = torch.relu(torch.nn.functional.linear(want, m.fc_output_layer.weight, m.fc_output_layer.bias))
+        got = m.cuda()(x.cuda()).cpu()
+    assert got.shape == (B, O or H, T)
+    assert (got - want.permute(0, 2, 1)).abs().max().item() <= 2e-5
+
 @pytest.mark.parametrize("rows", [(640, 800, 192, 128), (630, 790, 170, 100), (1500, 24)])
 def test_several_sequence_models_in_one_persistent_launch_vs_torch(fsn, rows):
     """sequence_model.multi_forward (fsn_lstm2_forward_multi: one launch of the group kernel, a weight set per model -
