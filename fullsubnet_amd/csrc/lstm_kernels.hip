@@ -764,8 +764,8 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
     // FSA (ABL & 524288): the fills' addresses from scalar registers - a wave's fragments of a stage are the same (row
     // tile, chunk) pairs all through the kernel, so their offsets are formed once, and the source is base + lane offset
     // (the loop form spent a 64-bit vector add, a vector add and a v_readfirstlane per fragment, inside a real loop)
-    constexpr bool FSA = (ABL & 524288) != 0 && NF % NW == 0;
-    constexpr int FPW = NF % NW == 0 ? NF / NW : 1;
+    constexpr bool FSA = (ABL & 524288) != 0;
+    constexpr int FPW = (NF + NW - 1) / NW;  // fragments per wave and stage (the last one only in the first waves if NW does not divide NF)
     int fsa_src[FPW], fsa_lds[FPW];
 #pragma unroll
     for (int i = 0; i < FPW; ++i) {
@@ -778,7 +778,8 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
         const float* src = xseq + ((long)t * Npad + n0) * H + sl * (SK * 16);  // wave-uniform
 #pragma unroll
         for (int i = 0; i < FPW; ++i)
-            lds_dma_fragment_s(src + fsa_src[i], xlane_bytes, (unsigned)(fsa_lds[i] + buf * (NF * 1024)));
+            if (NF % NW == 0 || wave + i * NW < NF)
+                lds_dma_fragment_s(src + fsa_src[i], xlane_bytes, (unsigned)(fsa_lds[i] + buf * (NF * 1024)));
     };
     fill(0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

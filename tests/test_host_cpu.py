@@ -257,6 +257,39 @@ def test_no_early_rewrite_of_store_data_in_the_bptt_kernel():
     assert not hits, hits[:4]
 
 
+def test_ring_fills_of_the_persistent_kernel_take_scalar_addresses():
+    """Round 5: lstm_rec_x_kernel's ring fills cost 0.65 ms per batch while each LDS-DMA fragment formed its
+    address in vector registers inside a loop the compiler could not unroll.  In the shipped library every fill of the time
+    loop must be the scalar-base form (`global_load_lds_dwordx4 v, s[..]`); the one loop-form fill left is the prologue's."""
+    import importlib.util
+    import re
+    import subprocess
+    import tempfile
+    spec = importlib.util.spec_from_file_location("check_store_hazard", os.path.join(ROOT, "tools", "check_store_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(mod.OBJDUMP):
+        pytest.skip("llvm-objdump not available")
+    forms = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for k, blob in enumerate(mod.code_objects(mod.SO)):
+            path = os.path.join(tmp, f"co{k}.elf")
+            with open(path, "wb") as f:
+                f.write(blob)
+            dis = subprocess.run([mod.OBJDUMP, "-d", "--no-show-raw-insn", path], capture_output=True, text=True).stdout
+            kernel = None
+            for line in dis.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+                if m:
+                    kernel = m.group(1)
+                elif kernel and "lstm_rec_x_kernel" in kernel and "global_load_lds_dwordx4" in line:
+                    v = forms.setdefault(kernel, [0, 0])
+                    v[0 if re.search(r"\boff\b", line) else 1] += 1
+    assert len(forms) == 6, sorted(forms)  # 2 - 4 row tiles per workgroup x (fused output layer | hidden sequence out)
+    for kernel, (vector_form, scalar_form) in forms.items():
+        assert vector_form <= 1 and scalar_form >= 4, (kernel, vector_form, scalar_form)
+
+
 def test_subband_multiplicity_closed_form():
     """offline_den_kernel (elementwise_kernels.hip) weighs bin f by m[f] = number of (unit, row) pairs of
     freq_unfold that read it; the kernel's closed form against the brute-force count over the reflect map."""
