@@ -364,7 +364,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
     const int sb_f0 = ROWSIN ? 0 : (int)((n0 + xin.row0) - (long)sb_b0 * xin.F);
 
     constexpr bool PK = (OPT & 256) != 0;    // gate non-linearities on pairs (v_pk_*_f32), see sigmoid_fast2
-    constexpr bool KOPT = (OPT & 4096) != 0 && RT == 4 && KC % 6 == 0;  // see lstm_rec_x_kernel
+    constexpr bool KOPT = (OPT & 4096) != 0 && RT >= 2 && RT <= 4 && KC % 6 == 0;  // see lstm_rec_x_kernel
     typename RecState<PK>::type cst[RT][UG], tmp[RT][UG];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -739,7 +739,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
     // the refilled weight fragments landed in fresh registers that were then copied (4 v_mov_b64 behind a vmcnt(0)).  Now:
     // two base registers (row tiles 0-1 / 2-3) advanced once per 6 chunks, immediates inside, and the refill of a
     // fragment pinned behind the last MFMA that reads it, so that it returns into the same registers.
-    constexpr bool KOPT = (ABL & 4096) != 0 && RT == 4;
+    constexpr bool KOPT = (ABL & 4096) != 0 && RT >= 2 && RT <= 4;
     constexpr bool PK = (ABL & 256) != 0;          // gate non-linearities on pairs (v_pk_*_f32)
     typename RecState<PK>::type cst[RT][UG], tmp[RT][UG];
 #pragma unroll
