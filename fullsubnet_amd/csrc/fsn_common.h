@@ -157,13 +157,26 @@ __device__ __forceinline__ f32x4 fsn_mma_k32(const typename FsnOperand<AR>::type
     }
 }
 
-// gfx950 / ROCm 7.2 (found in round 5, tools/diag_k32_bwd.py): a 16-byte-per-lane buffer store whose data registers are
-// written again a few issue slots later - hipcc placed a v_pk_add_f32 three slots and a v_mov_b32_dpp five slots behind a
-// buffer_store_dwordx4, more than its own hazard table asks for - stored the NEW values in the lanes whose data is read
-// last (lanes 12 - 15 of every 16), differently from run to run.  Whether the allocator re-uses the registers that early
-// is its own choice (the K = 16 build of the same source did not).  Call this right behind such a store when the value is
-// dead afterwards: the data registers stay allocated, and untouched, for a few more cycles.
-__device__ __forceinline__ void fsn_hold_store_data(const f32x4& v) { asm volatile("s_nop 7\n\ts_nop 7" ::"v"(v) : "memory"); }
+// gfx950 store-data hazard (measured: tools/probe_store_hazard.hip, profiles/r06_store_hazard.md).  A 12 / 16-byte-per-lane
+// store reads its data registers lane quad by lane quad over the cycles after issue; a vector instruction that writes them
+// again 1 - 2 issue slots later (global stores, buffer stores with an immediate soffset) or 1 slot later (buffer stores with
+// an SGPR soffset) reaches memory in lanes 8 - 15 / 12 - 15 of every 16.  hipcc (ROCm 7.2) keeps two wait states in the
+// first case and none in the second (its hazard recogniser exempts a register soffset): lstm2_g16_bwd_kernel's layer-0 gate
+// gradients were 6e-2 off in round 5 behind `buffer_store_dwordx4 v[38:41], .., s0 offen ; v_pk_add_f32 v[38:39], ..`.
+// Call this right behind such a store when the value is re-used as an accumulator: the data registers stay allocated and
+// untouched for two more issue slots (the distance that was never wrong is 3).  tests/test_host_cpu.py scans EVERY kernel
+// of the shipped library for vector writes inside the unsafe distance (tools/check_store_hazard.py).
+// FSN_HOLD_MODE (diagnosis builds only, tools/build_variant.py): 1 = nothing (the failing build), 2 = kept allocated, no wait.
+#ifndef FSN_HOLD_MODE
+#define FSN_HOLD_MODE 0
+#endif
+__device__ __forceinline__ void fsn_hold_store_data(const f32x4& v) {
+#if FSN_HOLD_MODE == 0
+    asm volatile("s_nop 1" ::"v"(v) : "memory");
+#elif FSN_HOLD_MODE == 2
+    asm volatile("" ::"v"(v) : "memory");
+#endif
+}
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 

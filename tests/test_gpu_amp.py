@@ -126,6 +126,40 @@ def test_two_layer_lstm_16bit_operands_vs_an_exact_emulation(fsn, arith):
     print(f"{arith}: worst deviation from the exact emulation {worst[1]:.2e} ({worst[0]})")
 
 
+@pytest.mark.parametrize("arith", ["f16", "bf16"])
+def test_bptt_gate_gradient_stores_repeat_and_agree_with_their_16bit_copies(fsn, arith):
+    """gfx950 store-data hazard (fsn_common.h: fsn_hold_store_data; profiles/r06_store_hazard.md): lstm2_g16_bwd_kernel stores
+    layer 0's gate gradients twice - fp32 (the input gradient dx is their product with W_ih0) and rounded to 16 bits (the
+    weight gradients' operand) - and then sums the same registers; a build without the hold put post-sum values into lanes
+    12 - 15 of every 16 of the fp32 copy: dx 6e-2 off and different from run to run while dw_ih0 stayed right.  Five launches:
+    bit-identical, and dx as close to the fp32 mode as the weight gradient formed from the 16-bit copies is."""
+    from fullsubnet_amd.train import Lstm2Function
+    T, N, I, H = 7, 2048, 32, 384
+    g = torch.Generator().manual_seed(12)
+    k = 1.0 / np.sqrt(H)
+    x = torch.randn(T, N, I, generator=g)
+    shapes = ((4 * H, I), (4 * H, H), (4 * H,), (4 * H,), (4 * H, H), (4 * H, H), (4 * H,), (4 * H,))
+    w = [(torch.rand(s_, generator=g) * 2 - 1) * k * 2 for s_ in shapes]
+    dy = torch.randn(T, N, H, generator=g) * 64.0
+
+    def run(a):
+        xd = x.cuda().requires_grad_(True)
+        wd = [t.cuda().requires_grad_(True) for t in w]
+        (Lstm2Function.apply(xd, *wd, a) * dy.cuda()).sum().backward()
+        torch.cuda.synchronize()
+        return xd.grad.cpu(), wd[0].grad.cpu()
+
+    dx32, dw32 = run("f32")
+    first = run(arith)
+    for _ in range(4):
+        again = run(arith)
+        assert torch.equal(first[0], again[0]) and torch.equal(first[1], again[1])
+    e_dx = ((first[0] - dx32).abs().max() / dx32.abs().max()).item()
+    e_dw = ((first[1] - dw32).abs().max() / dw32.abs().max()).item()
+    print(f"{arith}: dx {e_dx:.2e}, dw_ih0 {e_dw:.2e} from the fp32 mode")
+    assert e_dx <= (2e-3 if arith == "f16" else 1.5e-2) and e_dx <= 4 * e_dw + 1e-4, (e_dx, e_dw)
+
+
 def build(fsn, arith, seed=3, groups=2, norm_type="offline_laplace_norm"):
     params = O.make_params(seed=seed)
     model = fsn.Model(norm_type=norm_type, num_groups_in_drop_band=groups, **MODEL_KW)

@@ -242,19 +242,25 @@ def test_built_library_holds_the_same_budget():
     assert 3 * gran(recx["vgpr_count"]) + gran(step["vgpr_count"]) <= 512 and recx["vgpr_spill_count"] <= 8, recx
 
 
-def test_no_early_rewrite_of_store_data_in_the_bptt_kernel():
-    """Round 5 (fsn_common.h: fsn_hold_store_data, tools/check_store_hazard.py): on gfx950 a 16-byte-per-lane store whose data
-    registers a vector instruction rewrites a few issue slots later - hipcc leaves two - stored the new values in some lanes
-    when the kernel's waves all store at once (lstm2_g16_bwd_kernel's burst of 24 stores per wave and step: layer-0 gate
-    gradients 6e-2 off, different from run to run).  The shipped library must not contain that pattern in that kernel."""
+def test_no_kernel_rewrites_store_data_inside_the_measured_unsafe_distance():
+    """gfx950 store-data hazard (tools/probe_store_hazard.hip, profiles/r06_store_hazard.md): a vector instruction that writes
+    the data registers of a 12 / 16-byte-per-lane store 1 - 2 issue slots behind it (1 behind a buffer store with an SGPR
+    soffset - the case hipcc's hazard recogniser exempts, and what corrupted lstm2_g16_bwd_kernel's gate gradients in round 5)
+    puts the new value into memory for the last lane quads.  No kernel of the shipped library may contain such a pair; the
+    stand-alone probe's failing pairs and a build of the BPTT kernel without fsn_hold_store_data must both be caught."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("check_store_hazard", os.path.join(ROOT, "tools", "check_store_hazard.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     if not os.path.exists(mod.OBJDUMP):
         pytest.skip("llvm-objdump not available")
-    hits = [h for h in mod.scan(window=8) if "lstm2_g16_bwd_kernel" in h[0] and h[3].startswith("v_")]
-    assert not hits, hits[:4]
+    hits = mod.scan(window=8)
+    assert hits, "the scan found no store at all: the disassembly step is broken"
+    assert not mod.unsafe(hits), mod.unsafe(hits)[:4]
+    # the rule itself, on hand-made hits: (kernel, store, distance, writer)
+    mk = lambda d, w: ("k", "buffer_store_dwordx4 v[38:41], v134, s[68:71], s0 offen", d, w)
+    assert mod.unsafe([mk(1, "v_pk_add_f32 v[38:39], v[38:39], v[50:51]"), mk(2, "v_mov_b32_dpp v38, v40"), mk(3, "v_mov_b32_e32 v38, v1"),
+                       mk(1, "ds_read_b128 v[38:41], v138")]) == [mk(1, "v_pk_add_f32 v[38:39], v[38:39], v[50:51]"), mk(2, "v_mov_b32_dpp v38, v40")]
 
 
 def test_ring_fills_of_the_persistent_kernel_take_scalar_addresses():

@@ -1,10 +1,20 @@
-"""Static scan of the kernels INSIDE libfsn_hip.so for the store-data hazard found in round 5 (fsn_common.h,
-fsn_hold_store_data): on gfx950 a 16-byte-per-lane store (buffer / global / scratch _store_dwordx4, or dwordx3) whose
-data registers are written again by a vector instruction a few issue slots later stores the NEW values in some lanes.
-hipcc (ROCm 7.2) leaves 1 - 2 slots; the failing code had a write 3 and 5 slots behind the store.
+"""Static scan of the kernels INSIDE libfsn_hip.so for the gfx950 store-data hazard (fsn_common.h: fsn_hold_store_data;
+measured by tools/probe_store_hazard.hip, profiles/r06_store_hazard.md): a 12 / 16-byte-per-lane store reads its data
+registers lane quad by lane quad over the cycles after it issues; a vector instruction that writes them again
 
-usage: check_store_hazard.py [--window N] [so]    lists every store followed, within N instructions of straight-line code
-(default 8; s_nop k counts as k + 1), by a VALU / MFMA / LDS-read / load write into its data registers."""
+  * 1 or 2 issue slots behind a global / flat / scratch store or a buffer store with an IMMEDIATE soffset,
+  * 1 issue slot behind a buffer store whose soffset is an SGPR
+
+puts the NEW value into memory for lanes 8 - 15 / 12 - 15 of every 16.  hipcc (ROCm 7.2) keeps the two wait states of the first
+case and NONE in the second (GCNHazardRecognizer exempts buffer stores with a register soffset - a rule of the first GCN parts
+that gfx950 does not honour): that is what corrupted lstm2_g16_bwd_kernel's gate gradients in round 5.  LDS reads and memory
+loads that land in the data registers were never wrong at any distance (their results return long after the store has read).
+
+The RULE this file enforces (tests/test_host_cpu.py, library-wide): no VALU / MFMA write of a wide store's data registers
+within UNSAFE_SLOTS = 2 issue slots (one slot of margin over the measured failure of the SGPR form).
+
+usage: check_store_hazard.py [--window N] [so]    lists every wide store followed, within N instructions of straight-line code
+(default 8; s_nop k counts as k + 1), by a write into its data registers, and says which of them break the rule."""
 import os
 import re
 import struct
@@ -15,6 +25,7 @@ import tempfile
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(HERE, "fullsubnet_amd", "libfsn_hip.so")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+UNSAFE_SLOTS = 2  # measured: wrong at D = 1 (SGPR soffset) / D <= 2 (immediate soffset, global); never at D >= 3
 STORE = re.compile(r"^(buffer|global|flat|scratch)_store_dwordx[34]\b")
 REG = re.compile(r"v\[(\d+):(\d+)\]|v(\d+)\b")
 
@@ -72,17 +83,6 @@ def scan(so=SO, window=8):
             with open(path, "wb") as f:
                 f.write(blob)
             dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", path], capture_output=True, text=True).stdout
-            kernel, insts = None, []
-            for line in dis.splitlines():
-                m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
-                if m:
-                    kernel, insts = m.group(1), []
-                    continue
-                m = re.match(r"^\s+([a-z_0-9]+)\s*(.*?)\s*(//.*)?$", line)
-                if not m or kernel is None:
-                    continue
-                insts.append((m.group(1), m.group(2), kernel))
-            # (objdump lists kernels back to back; `insts` restarts per symbol, so keep a flat list with the symbol attached)
             flat = []
             kernel = None
             for line in dis.splitlines():
@@ -101,7 +101,7 @@ def scan(so=SO, window=8):
                     continue
                 slots = 0
                 for op2, args2, kern2 in flat[i + 1:i + 1 + 4 * window]:
-                    if kern2 != kern or op2.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_barrier", "s_setpc")):
+                    if kern2 != kern or op2.startswith(("s_branch", "s_endpgm", "s_barrier", "s_setpc")):  # a conditional branch: its fall-through
                         break
                     slots += (int(args2.split()[0]) + 1) if op2 == "s_nop" and args2 else 1
                     if slots > window:
@@ -112,6 +112,11 @@ def scan(so=SO, window=8):
     return hits
 
 
+def unsafe(hits):
+    """The hits that break the rule: a vector-ALU / matrix instruction writing the data registers within UNSAFE_SLOTS."""
+    return [h for h in hits if h[2] <= UNSAFE_SLOTS and h[3].startswith("v_")]
+
+
 if __name__ == "__main__":
     a = [x for x in sys.argv[1:] if not x.startswith("--")]
     window = int(sys.argv[sys.argv.index("--window") + 1]) if "--window" in sys.argv else 8
@@ -120,4 +125,6 @@ if __name__ == "__main__":
     hits = scan(a[0] if a else SO, window)
     for kern, st, d, ow in hits:
         print(f"{kern[-70:]}: `{st}` data written again {d} slot(s) later by `{ow}`")
-    print(f"{len(hits)} store(s) whose data registers are written again within {window} issue slots")
+    print(f"{len(hits)} store(s) whose data registers are written again within {window} issue slots; "
+          f"{len(unsafe(hits))} of them by a vector instruction within {UNSAFE_SLOTS} (the measured unsafe distance)")
+    sys.exit(1 if unsafe(hits) else 0)

@@ -1,5 +1,5 @@
-"""Diagnosis of the BPTT kernel built with -DFSN_G16_BWD_K32 (one K = 32 instruction per block): every gradient of
-tests/test_gpu_amp.py::test_two_layer_lstm_16bit_operands_vs_an_exact_emulation against the fp32 mode, twice (determinism)."""
+"""Diagnosis of the 16-bit BPTT kernel: every gradient of tests/test_gpu_amp.py::test_two_layer_lstm_16bit_operands_vs_an_exact_emulation
+against the fp32 mode, twice (determinism).  usage: diag_k32_bwd.py [T] [--lib tools/bin/<variant>.so] (tools/build_variant.py)."""
 import os
 import sys
 
@@ -8,6 +8,10 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fullsubnet_amd  # noqa: E402
+if "--lib" in sys.argv:
+    i = sys.argv.index("--lib")
+    fullsubnet_amd._lib.LIB_PATH = os.path.abspath(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 from fullsubnet_amd.train import Lstm2Function  # noqa: E402
 
 T, N, I, H = int(sys.argv[1]) if len(sys.argv) > 1 else 5, 2048, 32, 384

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 5: GPU suite (optional) + the bench line.  usage: gpu_run_r05_bench.sh <tag> [pytest args...]
+# GPU suite (optional) + the bench line.  usage: gpu_run_bench.sh <tag> [pytest args...]
 set -u
-O=gpurun_out/${1:-r05bench}
+O=gpurun_out/${1:-bench}
 shift || true
 mkdir -p $O
 export TMPDIR=/tmp

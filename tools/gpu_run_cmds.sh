@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 5: run the commands given as arguments one after the other, logs under gpurun_out/<tag>/ (first argument).
+# Run the commands given as arguments one after the other, logs under gpurun_out/<tag>/ (first argument).
 set -u
-O=gpurun_out/${1:-r05cmds}
+O=gpurun_out/${1:-cmds}
 shift || true
 mkdir -p $O
 export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 5, full session: GPU suite, bench line, kernel traces (bench / training f32 + f16 / sibling models), PMC passes.
+# Full session: GPU suite, bench line, kernel traces (bench / training f32 + f16 / sibling models), PMC passes.
 set -u
-O=gpurun_out/${1:-r05full}
+O=gpurun_out/${1:-full}
 mkdir -p $O
 export TMPDIR=/tmp
 (time timeout 1500 python -m pytest tests -m gpu -q -rP) > $O/pytest.log 2>&1
