@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 SR, N_FFT, HOP = 16000, 512, 256
 F, LA, NB, H_FB, H_SB = 257, 2, 15, 512, 384
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec (6290 GB/s measured copy)
 # MAC per utterance per computed frame
 MAC_FB = 2048 * (257 + 512) + 2048 * (512 + 512) + 512 * 257
 MAC_SB_PER_BIN = 1536 * (32 + 384) + 1536 * (384 + 384) + 384 * 2
@@ -426,15 +427,37 @@ def one_utterance_figure(model, length, device, reps=20):
 def measured_counters():
     """PMC figures of the dominant kernel REPLAYED from the committed rocprofv3 passes (profiles/rNN_pmc.json, produced
     by tools/rocprof_pmc.py from separate --pmc runs of `bench.py` at config 2): HBM bytes per launch (FETCH_SIZE x 2
-    on gfx950 + WRITE_SIZE) and the MFMA-busy fraction of the launch.  Not measured in this run - the keys say so."""
-    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_hbm_traffic_end.json"):
+    on gfx950 + WRITE_SIZE) and the MFMA-busy fraction of the launch.  Not measured in this run - the keys say so, and the
+    stamp of the kernel sources the passes were taken on is compared with this tree's (`stale`: the sources have changed
+    since; files of rounds 1 - 5 carry no stamp)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from rocprof_pmc import source_stamp
+    here = source_stamp(ROOT)
+    for name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_hbm_traffic_end.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                d = json.load(f)["dominant_kernel"]
-            return d.get("hbm_bytes_per_launch"), d.get("mfma_busy_frac"), "profiles/" + name
+                j = json.load(f)
+            d = j["dominant_kernel"]
+            built = j.get("build") or {}
+            stale = None if not built else built.get("csrc_sha256") != here["csrc_sha256"]
+            return {"traffic": d.get("hbm_bytes_per_launch"), "mfma_busy": d.get("mfma_busy_frac"), "src": "profiles/" + name,
+                    "taken_on": built or "unstamped (before round 6)", "stale": stale, "this_tree": here["csrc_sha256"]}
         except (OSError, KeyError, ValueError):
             continue
-    return None, None, None
+    return {"traffic": None, "mfma_busy": None, "src": None, "taken_on": None, "stale": None, "this_tree": here["csrc_sha256"]}
+
+
+def hbm_stage_rooflines(stage_ms, b, length, T):
+    """The two streaming stages against the HBM roofline (SURVEY 8(d)'s algorithmic bytes, fp32): stft = read 4 B L, write
+    re / im / |X| 12 B F T; mask_istft (decompress + complex mask + irfft + overlap-add) = read mask 8 B F T + re / im 8 B F T,
+    write 4 B L.  Durations: the stage's hipEvents on the launch stream."""
+    out = {}
+    for name, nbytes in (("stft", 4.0 * b * length + 12.0 * b * F * T), ("mask_istft", 16.0 * b * F * T + 4.0 * b * length)):
+        ms = stage_ms.get(name, 0.0)
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out[name] = {"bound": "hbm", "algorithmic_bytes": nbytes, "ms": round(ms, 4), "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+                     "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
+    return out
 
 
 def main():
@@ -628,7 +651,7 @@ def main():
         # ... counted on the rows those two launches actually process (config 2: 256 workgroups x 64 rows = 16 384 of the
         # 16 448; the 64 left-over rows run as per-step launches beside them and are not in `ms` either)
         plan = head["plan"]
-        rows_rec = plan["persistent_workgroups"] * plan["row_tiles_per_workgroup"] * 16 * plan["chunks"]
+        rows_rec = plan["persistent_rows_all_chunks"]  # summed over the chunks (a remainder chunk has its own plan)
         rows_rec = min(rows_rec, rows_loc) if rows_rec > 0 else rows_loc
         rows_steps = float(rows_rec) * Tp
         rec_flops = 2.0 * (MAC_REC_L0 + MAC_REC_L1) * rows_steps  # both launches
@@ -636,7 +659,8 @@ def main():
         achieved = rec_flops / (rec_ms * 1e-3) / 1e12 if rec_ms > 0 else 0.0
         path_flops = 2.0 * (MAC_FB * b_loc + MAC_SB_PER_BIN * rows_loc) * Tp
         at_config2 = world == 1 and b_loc == 64 and length == 48000
-        traffic, mfma_busy, pmc_src = measured_counters() if at_config2 else (None, None, None)
+        pmc = measured_counters() if at_config2 else {"traffic": None, "mfma_busy": None, "src": None, "taken_on": None, "stale": None}
+        traffic, mfma_busy, pmc_src = pmc["traffic"], pmc["mfma_busy"], pmc["src"]
         out = {
             "metric": "frames/sec (16 kHz, 512-FFT, hop 256), whole job", "value": round(value, 1),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -660,7 +684,10 @@ def main():
                          "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc)",
                          "traffic_source": (f"replayed from {pmc_src} (separate rocprofv3 --pmc passes of this command "
                                             f"at config 2), NOT measured in this run") if pmc_src else None,
-                         "mfma_busy_frac_replayed": mfma_busy, "pmc_source": pmc_src,
+                         "mfma_busy_frac_replayed": mfma_busy, "pmc_source": pmc_src, "pmc_taken_on": pmc["taken_on"],
+                         "pmc_stale": pmc["stale"],
+                         "pmc_warning": ("the kernel sources have changed since the PMC passes were taken: re-run "
+                                         "tools/gpu_run_full.sh") if pmc["stale"] else None,
                          "flops_per_launch": rec_flops / 2, "ms_per_launch": round(rec_ms / 2, 3),
                          "rows": {"persistent_pair": int(rows_rec), "of": int(rows_loc), "plan": plan},
                          "launches": {"sb_rec_l0": {"flops": 2.0 * MAC_REC_L0 * rows_steps,
@@ -669,6 +696,7 @@ def main():
                                                     "ms": round(stage_ms.get("sb_rec_l1", 0.0), 3)}},
                          "whole_path_frac": round(path_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+            "roofline_hbm": hbm_stage_rooflines(stage_ms, b_loc, length, T),
         }
         if head["per_rank"] is not None:
             out["per_rank"] = head["per_rank"]

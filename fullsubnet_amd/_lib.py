@@ -368,11 +368,11 @@ def profile_stage_names():
 
 def core_plan(cfg, B, T):
     """How the sub-band model of a B-utterance, T-frame call is spread over the device (fsn_debug_core_plan)."""
-    buf = (ctypes.c_int * 8)()
-    if lib().fsn_debug_core_plan(ctypes.byref(cfg), B, T, buf, 8) != 0:
+    buf = (ctypes.c_int * 9)()
+    if lib().fsn_debug_core_plan(ctypes.byref(cfg), B, T, buf, 9) != 0:
         raise FsnError("fsn_debug_core_plan: bad arguments")
     keys = ("rows", "tiles", "row_tiles_per_workgroup", "persistent_workgroups", "left_over_tiles", "group_clusters",
-            "fullband_chain", "chunks")
+            "fullband_chain", "chunks", "persistent_rows_all_chunks")  # the first seven: the FIRST chunk's plan
     return dict(zip(keys, list(buf)))
 
 

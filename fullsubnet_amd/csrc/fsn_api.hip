@@ -1356,6 +1356,14 @@ extern "C" int fsn_debug_core_plan(const fsn_fullsubnet_cfg* cfg, int B, int T, 
     plan[5] = d.grp_clusters;
     plan[6] = d.fb_chain ? 1 : 0;
     plan[7] = chunks;
+    if (n >= 9) {  // rows on the persistent recurrent pair over ALL chunks (whole rounds and a remainder have different plans)
+        long rows = 0;
+        for (int c = 0; c < (chunks > 0 ? chunks : 1); ++c) {
+            const CoreDims dc = core_dims(cfg, chunks > 0 ? sizes[c] : B, T);
+            rows += (long)dc.rec.main_wgs * dc.rec.rt * 16;
+        }
+        plan[8] = (int)rows;
+    }
     return FSN_OK;
 }
 

@@ -160,9 +160,9 @@ __global__ __launch_bounds__(256) void improved_front_kernel(const float* __rest
 }
 // h [T][Np][Ip] = x[b][f][t] (zero for b >= B, f >= F): 32 x 32 tiles through LDS, both sides coalesced
 __global__ __launch_bounds__(256) void bft_to_rows_kernel(const float* __restrict__ x, float* __restrict__ h, int B, int F, int T, int Np,
-                                                         int Ip) {
+                                                         int Ip, int z0) {
     __shared__ float tile[32][33];
-    const int t0 = blockIdx.x * 32, f0 = blockIdx.y * 32, b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, f0 = blockIdx.y * 32, b = z0 + (int)blockIdx.z;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int i = ty; i < 32; i += 8) {
         const int f = f0 + i, t = t0 + tx;
@@ -176,9 +176,9 @@ __global__ __launch_bounds__(256) void bft_to_rows_kernel(const float* __restric
 }
 // y [B][O][T] = o[t][b][c] (o: [T][Np][ld])
 __global__ __launch_bounds__(256) void rows_to_bft_kernel(const float* __restrict__ o, float* __restrict__ y, int T, int Np, int ld, int B,
-                                                         int O) {
+                                                         int O, int z0) {
     __shared__ float tile[32][33];
-    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32, b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32, b = z0 + (int)blockIdx.z;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int i = ty; i < 32; i += 8) {
         const int t = t0 + i, c = c0 + tx;
@@ -207,10 +207,10 @@ __global__ __launch_bounds__(256) void mask_zero_uncovered_kernel(const MaskSect
 // times the noisy real / imaginary part (model.py:576-577: no complex product).  A workgroup = 8 rows x 32 frames.
 __global__ __launch_bounds__(256) void mask_apply_kernel(const fsn_mask_section sec, const float* __restrict__ real,
                                                         const float* __restrict__ imag, float* __restrict__ er, float* __restrict__ ei,
-                                                        int B, int F, int T, int R) {
+                                                        int B, int F, int T, int R, int y0) {
     extern __shared__ float tile[];  // [32 frames][R rows * ld + 1], R = rows per workgroup (8 for narrow sections, fewer for wide)
     const int W = 2 * sec.center, pitch = R * sec.ld + 1;
-    const int t0 = blockIdx.x * 32, r0 = blockIdx.y * R;
+    const int t0 = blockIdx.x * 32, r0 = (y0 + (int)blockIdx.y) * R;
     const int rows = B * sec.units;
     const int nt = T - t0 < 32 ? T - t0 : 32;
     const float* o = static_cast<const float*>(sec.o);
@@ -245,17 +245,25 @@ extern "C" int fsn_improved_front(const float* mag, int B, int F, int T, int sqr
 }
 extern "C" int fsn_bft_to_rows(const float* x, int B, int F, int T, float* h, int Np, int Ip, void* stream) {
     FsnCallScope scope(stream);
-    FSN_REQUIRE(x && h && B >= 1 && F >= 1 && T >= 1 && Np >= B && Ip >= F && Np <= 65535, "bft_to_rows: bad arguments");
-    hipLaunchKernelGGL(bft_to_rows_kernel, dim3((unsigned)((T + 31) / 32), (unsigned)((Ip + 31) / 32), (unsigned)Np), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, h, B, F, T, Np, Ip);
-    return fsn_check_launch("bft_to_rows_kernel");
+    FSN_REQUIRE(x && h && B >= 1 && F >= 1 && T >= 1 && Np >= B && Ip >= F, "bft_to_rows: bad arguments");
+    for (int z0 = 0; z0 < Np; z0 += 65535) {  // the row index is grid.z: at most 65535 per launch
+        const int nz = Np - z0 < 65535 ? Np - z0 : 65535;
+        hipLaunchKernelGGL(bft_to_rows_kernel, dim3((unsigned)((T + 31) / 32), (unsigned)((Ip + 31) / 32), (unsigned)nz), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), x, h, B, F, T, Np, Ip, z0);
+        FSN_TRY_LAUNCH("bft_to_rows_kernel");
+    }
+    return FSN_OK;
 }
 extern "C" int fsn_rows_to_bft(const float* o, int T, int Np, int ld, int B, int O, float* y, void* stream) {
     FsnCallScope scope(stream);
-    FSN_REQUIRE(o && y && B >= 1 && O >= 1 && T >= 1 && Np >= B && ld >= O && B <= 65535, "rows_to_bft: bad arguments");
-    hipLaunchKernelGGL(rows_to_bft_kernel, dim3((unsigned)((T + 31) / 32), (unsigned)((O + 31) / 32), (unsigned)B), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), o, y, T, Np, ld, B, O);
-    return fsn_check_launch("rows_to_bft_kernel");
+    FSN_REQUIRE(o && y && B >= 1 && O >= 1 && T >= 1 && Np >= B && ld >= O, "rows_to_bft: bad arguments");
+    for (int z0 = 0; z0 < B; z0 += 65535) {
+        const int nz = B - z0 < 65535 ? B - z0 : 65535;
+        hipLaunchKernelGGL(rows_to_bft_kernel, dim3((unsigned)((T + 31) / 32), (unsigned)((O + 31) / 32), (unsigned)nz), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), o, y, T, Np, ld, B, O, z0);
+        FSN_TRY_LAUNCH("rows_to_bft_kernel");
+    }
+    return FSN_OK;
 }
 extern "C" int fsn_improved_mask_apply(int n, const fsn_mask_section* sections, const float* real, const float* imag, int B, int F, int T,
                                        float* er, float* ei, void* stream) {
@@ -280,9 +288,13 @@ extern "C" int fsn_improved_mask_apply(int n, const fsn_mask_section* sections, 
         int R = 480 / q.ld;  // rows per workgroup: at most 480 floats per frame in the tile (61.6 KB of LDS: below the 64 KB a launch gets unasked)
         R = R > 8 ? 8 : (R < 1 ? 1 : R);
         const size_t lds = (size_t)32 * (R * q.ld + 1) * sizeof(float);
-        hipLaunchKernelGGL(mask_apply_kernel, dim3((unsigned)((T + 31) / 32), (unsigned)((B * q.units + R - 1) / R)), dim3(256), lds, s, q, real,
-                           imag, er, ei, B, F, T, R);
-        FSN_TRY_LAUNCH("mask_apply_kernel");
+        const long groups = ((long)B * q.units + R - 1) / R;  // grid.y: at most 65535 per launch
+        for (long y0 = 0; y0 < groups; y0 += 65535) {
+            const long ny = groups - y0 < 65535 ? groups - y0 : 65535;
+            hipLaunchKernelGGL(mask_apply_kernel, dim3((unsigned)((T + 31) / 32), (unsigned)ny), dim3(256), lds, s, q, real, imag, er, ei, B,
+                               F, T, R, (int)y0);
+            FSN_TRY_LAUNCH("mask_apply_kernel");
+        }
     }
     return FSN_OK;
 }

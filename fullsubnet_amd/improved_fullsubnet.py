@@ -232,7 +232,7 @@ class SubbandModel(BaseModel):
         # inference: the sections are independent two-layer stacks over the same frames.  When together they fill the
         # chip's workgroup sets (batches around 32 at 48 kHz) they run as ONE persistent launch of the group kernel with
         # a weight set per section (sequence_model.multi_forward -> fsn_lstm2_forward_multi)
-        from .sequence_model import multi_forward, multi_plan
+        from .sequence_model import multi_forward, multi_plan, to_rows
         B, T = noisy_input.size(0), noisy_input.size(-1)
         n_units = self.num_units(noisy_input.size(2))
         span = [n_units[i] if units[i] is None else max(units[i][1] - units[i][0], 0) for i in range(num)]
@@ -282,8 +282,10 @@ class SubbandModel(BaseModel):
                     inputs[i] = None
                     continue
                 inputs[i] = self._section_prepared(noisy_input, fb_output, i, units[i])
-                if inputs[i] is None:
+                if inputs[i] is None:  # wider than fsn_improved_section_input's tile / another norm: through the unfolded tensor
                     inputs[i] = self._section_input(noisy_input, fb_output, i, units[i])
+                    if rows_out:  # ... into the entries' own layout, as the one-launch path above does
+                        inputs[i] = (to_rows(inputs[i].reshape(B * span[i], widths[i], T)), B * span[i])
         subband_output = [None] * num
         for i in order:
             with torch.cuda.stream(stream_of[i]):
@@ -427,7 +429,8 @@ class Model(BaseModel):
         for i, o in enumerate(outs):
             if o is None:
                 continue
-            if o.dim() != 3 or o.stride(2) != 1 or o.stride(0) != o.shape[1] * o.stride(1):
+            assert o.dim() == 3, "the sections hand over [T, Np, 2 c] rows here"
+            if o.stride(2) != 1 or o.stride(0) != o.shape[1] * o.stride(1):
                 o = o.contiguous()
             keep.append(o)
             q = secs[n]

@@ -110,6 +110,7 @@ def to_rows(x):
     Linear entry takes (fsn_bft_to_rows: one transposing kernel instead of a fill and a strided copy of the host framework)."""
     B, F, T = x.shape
     Np, Ip = _round_up(B, 16), _round_up(F, 16)
+    x = x.float()  # (the strided copy this replaced cast on the way; fp32 stays as it is)
     x = x if x.is_contiguous() else x.contiguous()
     h = torch.empty((T, Np, Ip), dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().fsn_bft_to_rows(_lib.dev_ptr(x, "x"), B, F, T, _lib.dev_ptr(h), Np, Ip, _lib.stream_ptr(x.device)))

@@ -563,8 +563,9 @@ int fsn_debug_core_chunks(const fsn_fullsubnet_cfg* cfg, int B, int* sizes, int 
 /* Diagnostic: how the sub-band model of a B-utterance, T-frame call is spread over the device (of its first chunk when the
  * batch runs as several).  plan[0..8) = sub-band rows, 16-row tiles, row tiles per workgroup of the persistent pair, its
  * workgroups (0: the rows run on the group kernel / step launches), left-over tiles beside it, clusters of the group
- * kernel (0: none), full-band model on the chain kernel (0 / 1), chunks of the batch.  bench.py prints it per rank and
- * counts the roofline's FLOPs on the rows the persistent launches actually process. */
+ * kernel (0: none), full-band model on the chain kernel (0 / 1), chunks of the batch; with n >= 9 also plan[8] = the rows
+ * the persistent pair processes summed over ALL chunks (whole rounds and a remainder have different plans).  bench.py
+ * prints it per rank and counts the roofline's FLOPs on the rows the persistent launches actually process. */
 int fsn_debug_core_plan(const fsn_fullsubnet_cfg* cfg, int B, int T, int* plan, int n);
 int fsn_profile_num_stages(void);
 const char* fsn_profile_stage_name(int stage);

@@ -6,7 +6,10 @@ stft / build_complex_ideal_ratio_mask / drop_band / Model (nn.LSTM) / MSELoss / 
 / Adam(lr 1e-3).  Stored: the loss, and for every parameter the clipped-gradient norm, a strided
 sample of the gradient and of the updated parameter (the full tensors are 22 MB each).
 Flags: --config3 / --config3x2 (BASELINE config 3 shapes), --amp-bf16 (the step under CPU autocast), --cumulative (the
-shipped train_cumulativeLaplaceNorm.toml's norm).
+shipped train_cumulativeLaplaceNorm.toml's norm), --amp-fp16 (the shipped use_amp = true arithmetic itself: torch.autocast("cpu",
+float16) + GradScaler exactly as trainer.py:56-69; oneDNN has no fp16 LSTM primitive - "could not create a primitive descriptor
+for the LSTM forward propagation primitive" - so that step runs with torch.backends.mkldnn.flags(enabled=False): ATen's own
+LSTM cell, fp16 tensors, fp32 accumulation inside each product; ~25 min for the config-3 shape on 8 cores).
 """
 import os
 import sys
@@ -31,7 +34,8 @@ from oracle.fullsubnet_oracle import make_noisy, make_params  # noqa: E402
 SAMPLE = 97  # stride of the per-parameter samples
 
 
-def main(batch=4, length=2560, groups=2, name="fsn_train_b4", sample=SAMPLE, autocast=None, norm_type="offline_laplace_norm"):
+def main(batch=4, length=2560, groups=2, name="fsn_train_b4", sample=SAMPLE, autocast=None, norm_type="offline_laplace_norm",
+         scaler=None):
     params = make_params(seed=3)
     noisy = make_noisy(batch, length, seed=41)
     clean = 0.7 * make_noisy(batch, length, seed=42)
@@ -52,11 +56,21 @@ def main(batch=4, length=2560, groups=2, name="fsn_train_b4", sample=SAMPLE, aut
     with torch.autocast("cpu", dtype=autocast, enabled=autocast is not None):
         crm = model(noisy_mag.unsqueeze(1)).permute(0, 2, 3, 1)
         loss = torch.nn.MSELoss()(cirm, crm)
-    loss.backward()
+    if scaler is None:
+        loss.backward()
+    else:  # trainer.py:63-69
+        scaler.scale(loss).backward()
+        scaler.unscale_(opt)
     total_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
     out = dict(loss=np.float64(loss.item()), total_norm=np.float64(total_norm.item()))
     grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
-    opt.step()
+    if scaler is None:
+        opt.step()
+    else:
+        out["scale_before"] = np.float64(scaler.get_scale())
+        scaler.step(opt)
+        scaler.update()
+        out["scale_after"] = np.float64(scaler.get_scale())
     for k, p in model.named_parameters():
         out["gnorm/" + k] = np.float64(grads[k].norm().item())
         out["g/" + k] = grads[k].reshape(-1)[::sample].numpy().copy()
@@ -71,7 +85,13 @@ def main(batch=4, length=2560, groups=2, name="fsn_train_b4", sample=SAMPLE, aut
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    if "--amp-bf16" in sys.argv:
+    if "--amp-fp16" in sys.argv:
+        with torch.backends.mkldnn.flags(enabled=False):
+            main(name="fsn_train_b4_f16", autocast=torch.float16, scaler=torch.amp.GradScaler("cpu"))
+            if "--short" not in sys.argv:
+                main(batch=16, length=49152, groups=2, name="fsn_train_c3_f16", sample=397, autocast=torch.float16,
+                     scaler=torch.amp.GradScaler("cpu"))
+    elif "--amp-bf16" in sys.argv:
         # the same two steps under torch.autocast("cpu", dtype=torch.bfloat16)
         main(name="fsn_train_b4_bf16", autocast=torch.bfloat16)
         main(batch=16, length=49152, groups=2, name="fsn_train_c3_bf16", sample=397, autocast=torch.bfloat16)

@@ -375,6 +375,38 @@ def test_improved_fullsubnet_glue_kernels_vs_the_tensor_algebra(fsn, cfg, batch,
     assert L.fsn_improved_mask_apply(0, None, None, None, 1, 1, 1, None, None, None) != 0
 
 
+@pytest.mark.parametrize("batch", [1, 3])
+def test_improved_fullsubnet_wide_neighbourhood_on_the_kernel_glue(fsn, batch):
+    """A section whose unfolded width (8 + 2 x 60 twice = 256 columns) is beyond fsn_improved_section_input's 240-column tile:
+    `_section_prepared` declines, the section's input goes through the unfolded tensor - and, on the kernel-glue forward, from
+    there into the LSTM entries' own time-major layout (that branch used to hand the wrapped [B, 2, n c, T] tensor
+    to fsn_improved_mask_apply, which refused it).  Bit-identical to the tensor-algebra forward."""
+    from oracle import fullsubnet_oracle as O
+    from fullsubnet_amd.improved_fullsubnet import Model
+    cfg = dict(MF.IMPROVED_16K, sb_num_neighbor_freqs=[15, 15, 60], fb_num_neighbor_freqs=[15, 15, 60])
+    m = Model(**cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in MF.make_improved_params(cfg, seed=6).items()}, strict=True)
+    m = m.cuda().eval()
+    y = torch.from_numpy(O.make_noisy(batch, 4000, seed=10)).cuda()
+    with torch.no_grad():
+        assert m._glue_on_kernels(y, None)
+        got = m(y)
+        m.glue_kernels = False
+        want = m(y)
+    assert got.shape == want.shape == (batch, 1, 4000) and torch.equal(got, want) and float(want.abs().max()) > 0
+
+
+def test_row_transposes_beyond_one_grid_of_rows(fsn):
+    """fsn_bft_to_rows / fsn_rows_to_bft with more than 65535 rows (the row index is grid.z: ADVICE r5 - B F >= 65536 rows of a
+    composed model used to raise): several launches, same result as a permute."""
+    from fullsubnet_amd.sequence_model import from_rows, to_rows
+    x = torch.randn(70000, 3, 5, device="cuda")
+    h = to_rows(x)
+    assert h.shape == (5, 70000, 16) and torch.equal(h[:, :, :3], x.permute(2, 0, 1)) and float(h[:, :, 3:].abs().max()) == 0
+    assert torch.equal(from_rows(h, 70000)[:, :3], x)
+    assert torch.equal(to_rows(x.half()[:100]), to_rows(x.half()[:100].float()))  # other dtypes are cast, as the strided copy did
+
+
 def test_improved_fullsubnet_at_baseline_length_vs_reference(fsn, golden_dir):
     """BASELINE config 5's clip: 3 s at 48 kHz through the reference's own 481-bin example (301 frames) against the
     reference model's output (tests/golden/improved_48k_long_b1.npz, every 8th sample)."""

@@ -1,4 +1,5 @@
-"""world_size-2 (and 3) gloo tests of the sharding / re-assembly logic used by bench.py --gpus N."""
+"""world_size-2 / 3 / 8 gloo tests of the sharding / re-assembly logic used by bench.py --gpus N (8 = the node the north star
+names: config 2's 64 utterances and 16 448 batch x frequency rows, config 5's 55 unequal units)."""
 import os
 import socket
 
@@ -42,7 +43,7 @@ def _worker(rank, world, port, n_items):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_items", [(2, 64), (2, 5), (3, 7)])
+@pytest.mark.parametrize("world,n_items", [(2, 64), (2, 5), (3, 7), (8, 64), (8, 5)])
 def test_sharded_enhance_reassembles_the_batch(world, n_items):
     mp.spawn(_worker, args=(world, _free_port(), n_items), nprocs=world, join=True)
 
@@ -71,6 +72,7 @@ def _subband_model(num_freqs, cutoffs, centres, norm):
 
 
 _UNIT_CASES = [
+    (480, [20, 120, 240], [1, 4, 20, 60], "offline_laplace_norm"),      # BASELINE config 5 (48 kHz): 20 + 25 + 6 + 4 = 55 units
     (256, [20, 80], [1, 4, 8], "offline_laplace_norm"),                 # 16 kHz default: 20 + 15 + 22 units
     (480, [32, 128, 192], [1, 4, 8, 16], "offline_laplace_norm"),       # a four-section layout, uneven over 3 ranks
     (64, [32], [1, 16], "offline_gaussian_norm"),                       # 2 units in the last section: ranks with none
@@ -97,9 +99,16 @@ def _unit_worker(rank, world, port, case):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("case", _UNIT_CASES, ids=["16k", "four_sections", "fewer_units_than_ranks"])
+@pytest.mark.parametrize("case", _UNIT_CASES[1:], ids=["16k", "four_sections", "fewer_units_than_ranks"])
 def test_unit_sharded_subband_model_equals_the_unsharded_one(world, case):
     mp.spawn(_unit_worker, args=(world, _free_port(), case), nprocs=world, join=True)
+
+
+def test_unit_shard_of_config5_over_eight_ranks():
+    """BASELINE config 5 on the node the north star names: 55 units of four unequal sections over 8 ranks (sections of 6 and 4
+    units leave ranks without a unit of theirs), one ragged all-gather."""
+    assert [shard_bounds(n, 7, 8) for n in (20, 25, 6, 4)] == [(18, 20), (22, 25), (6, 6), (4, 4)]
+    mp.spawn(_unit_worker, args=(8, _free_port(), _UNIT_CASES[0]), nprocs=8, join=True)
 
 
 def test_unit_shard_refuses_to_build_an_autograd_graph():
@@ -155,6 +164,7 @@ def _row_worker(rank, world, port, B, F, T):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,B,F", [(2, 3, 257), (3, 1, 257), (3, 2, 5), (3, 1, 2)])  # last: a rank without rows
+# last of the small ones: a rank without rows; (8, 64, 257): config 2 on 8 ranks, 16 448 = 8 x 2056 rows
+@pytest.mark.parametrize("world,B,F", [(2, 3, 257), (3, 1, 257), (3, 2, 5), (3, 1, 2), (8, 64, 257), (8, 9, 257)])
 def test_row_sharded_forward_reassembles_the_mask(world, B, F):
     mp.spawn(_row_worker, args=(world, _free_port(), B, F, 6), nprocs=world, join=True)

@@ -24,6 +24,27 @@ import re
 import sys
 
 CUS, SIMDS, XCDS = 256, 4, 8
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_stamp(root=ROOT):
+    """What the counters were taken on: sha256 over the kernel sources (the GPU box has no .git), and the commit when there is
+    one.  bench.py replays these files' figures and compares the stamp with the tree it runs in."""
+    import hashlib
+    import subprocess
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(root, "fullsubnet_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "fullsubnet_amd", "csrc", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    stamp = {"csrc_sha256": h.hexdigest()[:16], "files": len(files)}
+    try:
+        stamp["commit"] = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                                         timeout=10).stdout.strip() or None
+    except Exception:
+        stamp["commit"] = None
+    return stamp
+
 
 
 def read_pass(d):
@@ -77,7 +98,8 @@ def main(root, out_json, patterns):
             if vals:
                 dom[key] = sum(vals) / len(vals)
         dom["name"] = "persistent sub-band recurrent kernels (mean of the launches per step): " + ", ".join(sorted(rec))
-    json.dump({"note": __doc__.strip().split("\n\n")[0], "kernels": kernels, "dominant_kernel": dom}, open(out_json, "w"), indent=1)
+    json.dump({"note": __doc__.strip().split("\n\n")[0], "build": source_stamp(), "kernels": kernels, "dominant_kernel": dom},
+              open(out_json, "w"), indent=1)
     print(json.dumps({"dominant_kernel": dom, "kernels": {n: {c: v for c, v in k.items() if c != "counters_mean"} for n, k in kernels.items()}}, indent=1))
 
 
