@@ -204,7 +204,37 @@ def timed_steps(step, fence, steps, read_profile=None):
     return dt, stage_ms
 
 
-def training_step_ms(device, steps=5, arith="f32"):
+def amp_step_traffic(saves):
+    """HBM bytes of ONE autocast training step REPLAYED from the committed PMC passes (tools/gpu_run_pmc_train.sh:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of tools/bench_train.py 16 f16, summed over every kernel of a
+    step, FETCH_SIZE x 2 on gfx950 + WRITE_SIZE) with the stamp of the sources they were taken on."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from rocprof_pmc import source_stamp
+    name = "r06_pmc_train_f16.json" if saves == "16" else "r06_pmc_train_f16_saves32.json"
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            j = json.load(f)
+        total = sum(k.get("hbm_bytes_per_launch", 0.0) * k["dispatches"] for k in j["kernels"].values()) / 5.0  # 2 warm-up + 3 timed steps
+        top = sorted(j["kernels"].items(), key=lambda kv: -kv[1].get("hbm_bytes_per_launch", 0.0) * kv[1]["dispatches"])[:2]
+        built = j.get("build") or {}
+        return {"bytes_per_step": total, "src": "profiles/" + name, "taken_on": built,
+                "stale": built.get("csrc_sha256") != source_stamp(ROOT)["csrc_sha256"] if built else None,
+                "largest": {n.split("<")[0]: round(k["hbm_bytes_per_launch"] / 1e9, 2) for n, k in top}}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def amp_step_algorithmic_bytes(saves, rows=2048, steps=195, H=384):
+    """What one autocast step of the sub-band model must move through HBM if every tensor is written once and read once per
+    consuming launch (N rows, T' steps, G = 4H, s = bytes of a saved gate): forward writes both hidden sequences,
+    the gate saves and the cell sequences N T' (8H + 2sG + 8H); BPTT reads the saves, the cell sequences and dH1 and writes
+    the 16-bit gate gradients N T' (2sG + 8H + 4H + 4G); the products read those five times, convert and read the hidden
+    sequences N T' (10G + 18H).  The exchanges between the workgroups of a persistent launch are NOT in it."""
+    G, s = 4 * H, (2 if saves == "16" else 4)
+    return float(rows) * steps * ((4 * s + 14) * G + 46 * H)
+
+
+def training_step_ms(device, steps=5, arith="f32", saves=None):
     """Side figure (BASELINE config 3, per-rank shape): one step of fullsubnet/trainer.py:41-71 - 16 utterances x
     49 152 samples, drop_band groups 2, MSE on the compressed cIRM, clip_grad_norm_(10) + Adam, one GPU.
     arith "f32": use_amp = false.  "f16": the reference's own mode (train.toml:5 use_amp = true): autocast arithmetic
@@ -220,11 +250,13 @@ def training_step_ms(device, steps=5, arith="f32"):
     model.load_state_dict({k: torch.from_numpy(v) for k, v in make_params(seed=3).items()})
     model = model.to(device).train()
     model.train_arithmetic = arith
+    if saves is not None:
+        model.train_saves = saves
     scaler = torch.amp.GradScaler("cuda", enabled=arith != "f32")
     opt = fullsubnet_amd.ClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
     noisy = torch.from_numpy(make_noisy(16, 49152, seed=41)).to(device)
     clean = torch.from_numpy(0.7 * make_noisy(16, 49152, seed=42)).to(device)
-    check = training_parity(device, arith)
+    check = training_parity(device, arith, saves)
     for _ in range(2):
         train_step(model, opt, noisy, clean, scaler=scaler)
     torch.cuda.synchronize()
@@ -248,6 +280,22 @@ def training_step_ms(device, steps=5, arith="f32"):
            "loss": round(float(loss), 6), "tflops": round(flops / (ms * 1e-3) / 1e12, 1), **check}
     if arith == "f32":
         out["frac_fp32_mfma_peak"] = round(flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3)
+    else:
+        from fullsubnet_amd.train import DEFAULT_TRAIN_SAVES
+        mode = saves or DEFAULT_TRAIN_SAVES
+        out["saved_gates"] = f"{mode}-bit" + (" (Model.train_saves default)" if saves is None else f' (Model.train_saves = "{saves}")')
+        tr = amp_step_traffic(mode)
+        alg = amp_step_algorithmic_bytes(mode)
+        if tr:
+            gbs = tr["bytes_per_step"] / (ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": round(gbs / PEAK_HBM_GBS, 4), "frac_of_measured_copy_bandwidth": round(gbs / 6290.0, 4),
+                               "traffic": tr["bytes_per_step"], "traffic_unit": "HBM bytes per step, all kernels (rocprofv3 --pmc)",
+                               "traffic_source": f"replayed from {tr['src']}, NOT measured in this run", "pmc_taken_on": tr["taken_on"],
+                               "pmc_stale": tr["stale"], "largest_launches_gb": tr["largest"],
+                               "algorithmic_bytes": alg, "traffic_over_algorithmic": round(tr["bytes_per_step"] / alg, 2),
+                               "note": "the step is bound by the memory system, not by the 16-bit matrix peak (2.5 PFLOP/s: "
+                                       f"{round(flops / (ms * 1e-3) / 1e12 / 2500.0, 3)} of it)"}
     return out
 
 
@@ -304,7 +352,7 @@ def stft_parity(noisy2, device):
             "scale": "ULP of each frame's largest component", "frames": int(re.shape[0] * re.shape[2])}
 
 
-def training_parity(device, arith):
+def training_parity(device, arith, saves=None):
     """The checker leg of the training figures: ONE step of a fresh model at exactly the timed shape on the inputs of
     tests/golden/fsn_train_c3.npz - the REFERENCE's own step (fullsubnet/trainer.py:41-71, use_amp = false, made by
     tests/golden/make_golden_train.py --config3) - loss, total gradient norm (what clip_grad_norm_ returns) and the
@@ -328,6 +376,8 @@ def training_parity(device, arith):
     model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
     model = model.to(device).train()
     model.train_arithmetic = arith
+    if saves is not None:
+        model.train_saves = saves
     scaler = torch.amp.GradScaler("cuda", enabled=arith != "f32")
     opt = fullsubnet_amd.ClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
     noisy = torch.from_numpy(make_noisy(meta["batch"], meta["length"], seed=meta["seed_noisy"])).to(device)
@@ -487,7 +537,12 @@ def main():
     ap.add_argument("--host-io", action="store_true",
                     help="side measurement for DESIGN.md: every step also copies its input from pinned host memory and "
                          "its result back (the PCIe-inclusive rate; never the headline `value`, which is HBM-resident)")
+    ap.add_argument("--lib", default=None,
+                    help="diagnosis: load this build of libfsn_hip.so (tools/build_variant.py) instead of the shipped one; the line says so")
     args = ap.parse_args()
+    if args.lib:
+        import fullsubnet_amd
+        fullsubnet_amd._lib.LIB_PATH = os.path.abspath(args.lib)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -698,6 +753,8 @@ def main():
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "roofline_hbm": hbm_stage_rooflines(stage_ms, b_loc, length, T),
         }
+        if args.lib:
+            out["library"] = f"DIAGNOSIS BUILD {args.lib} (not the shipped libfsn_hip.so)"
         if head["per_rank"] is not None:
             out["per_rank"] = head["per_rank"]
         out.update(extras)
@@ -738,9 +795,9 @@ def main():
                          "tests/test_gpu_parity.py::test_f16x3_promotion_criterion",
             "note": "opt-in (fp32 operands split into two fp16 halves, three 16-bit MFMAs per product block, fp32 "
                     "accumulation); NOT the arithmetic of `value`"}
-        for key, arith in (("train_step", "f32"), ("train_step_amp", "f16")):
+        for key, arith, saves in (("train_step", "f32", None), ("train_step_amp", "f16", None), ("train_step_amp_saves32", "f16", "32")):
             try:
-                out[key] = training_step_ms(device, arith=arith)
+                out[key] = training_step_ms(device, arith=arith, saves=saves)
             except Exception as e:  # a side figure must never break the benchmark line
                 out[key] = {"error": str(e)[:200]}
         # BASELINE configs 4 and 5 (fast_fullsubnet/model.py:143-202, improved_fullsubnet/model.py:541-591)

@@ -33,6 +33,8 @@ class Cfg(ctypes.Structure):
 # the opt-in split-precision experiment (Model.arithmetic = "f16x3", or FSN_F16X3=1 in the environment of the
 # HOST process - the library itself reads no environment variables).
 ARITH = {"f32": 0, "f16x3": 1, "f16": 2, "bf16": 3}  # "f16" / "bf16": training entries only (autocast arithmetic)
+ARITH_SAVES16 = 0x100  # FSN_ARITH_SAVES16: "f16+s16" / "bf16+s16" - the saved gates in the 16-bit type too
+ARITH.update({"f16+s16": 2 | ARITH_SAVES16, "bf16+s16": 3 | ARITH_SAVES16})
 
 
 def default_arith():
@@ -81,7 +83,7 @@ class TrainDims(ctypes.Structure):  # fsn_train_dims
                 ("nb", ctypes.c_int), ("groups", ctypes.c_int), ("norm", ctypes.c_int)]
 
 
-ABI_VERSION = 111  # FSN_ABI_VERSION of include/fsn_hip.h these signatures were written against
+ABI_VERSION = 112  # FSN_ABI_VERSION of include/fsn_hip.h these signatures were written against
 
 
 class MaskSection(ctypes.Structure):  # fsn_mask_section

@@ -86,6 +86,7 @@ static std::mutex g_ctx_mutex;
 static std::map<std::pair<int, hipStream_t>, StreamCtx*> g_ctx;
 static std::atomic<int> g_persist_mode{0};          // fsn_set_persistent_mode: 0 auto, 1 never
 static std::atomic<int> g_g16_off{0};               // fsn_debug_g16_kernels(0): the fp32-era group kernels also under 16-bit arithmetic
+static std::atomic<int> g_in16_off{0};              // fsn_debug_g16_kernels(3): dx / dW_ih0 from the fp32 gate gradients (round 5's form)
 static std::atomic<int> g_tn16h_off{0};             // fsn_debug_g16_kernels(2): ... only the weight-gradient products of round 3
 static std::atomic<int> g_persist_timeout_ms{20000};  // fsn_set_persistent_timeout_ms
 
@@ -438,6 +439,7 @@ extern "C" int fsn_debug_tn16h_wide(int on) {
 extern "C" int fsn_debug_g16_kernels(int on) {
     g_g16_off.store(on == 0 ? 1 : 0, std::memory_order_relaxed);
     g_tn16h_off.store(on == 2 ? 1 : 0, std::memory_order_relaxed);
+    g_in16_off.store(on == 3 ? 1 : 0, std::memory_order_relaxed);
     return FSN_OK;
 }
 extern "C" int fsn_debug_persist_stats(unsigned* launches, unsigned* waits, unsigned* unreported) {
@@ -2044,6 +2046,7 @@ static size_t lstm2_group_flag_words_any(int clusters) {
     return a > c ? a : c;
 }
 extern "C" size_t fsn_lstm2_train_workspace_bytes(int T, int N, int I, int H, int arith) {
+    arith &= ~FSN_ARITH_SAVES16;
     const int Ipad = fsn_round_up(I, 16);
     Carver cv(nullptr);
     if (const int clusters = lstm2_train_group_clusters(T, N, I, H)) {
@@ -2076,8 +2079,10 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
                                        size_t workspace_bytes, int arith, void* stream) {
     CallScope scope(stream);
     FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
-    FSN_REQUIRE(arith == FSN_ARITH_F32 || arith == FSN_ARITH_F16 || arith == FSN_ARITH_BF16,
-                "lstm2 forward (training): arithmetic %d unknown (FSN_ARITH_F32 / _F16 / _BF16)", arith);
+    const int saves16 = arith & FSN_ARITH_SAVES16;  // only meaningful with a 16-bit arithmetic; passed on to the g16 launch
+    arith &= ~FSN_ARITH_SAVES16;
+    FSN_REQUIRE((arith == FSN_ARITH_F32 && !saves16) || arith == FSN_ARITH_F16 || arith == FSN_ARITH_BF16,
+                "lstm2 forward (training): arithmetic %d unknown (FSN_ARITH_F32 / _F16 / _BF16 [| FSN_ARITH_SAVES16])", arith | saves16);
     FSN_REQUIRE(x && w_ih0 && w_hh0 && b_ih0 && b_hh0 && w_ih1 && w_hh1 && b_ih1 && b_hh1 && hseq0 && hseq1 && save0 &&
                     save1 && workspace,
                 "NULL pointer argument");
@@ -2127,7 +2132,7 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
             FSN_PERSIST_BEGIN(s);
             if (g16) {  // the 16-bit arithmetic's own kernels: they pack the raw weights their way into w16
                 FSN_TRY(fsn_launch_lstm2_g16_train(x, I, N, w_ih0, w_hh0, w_ih1, w_hh1, b0, b1, hseq0, hseq1, sv0, sv1, flags, w16,
-                                                   T, clusters, H, s, arith));
+                                                   T, clusters, H, s, arith | saves16));
                 FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_g16_status_word(clusters), hseq1, (size_t)T * N * H, s));
             } else {
                 FSN_TRY(fsn_launch_lstm2_group_train(x, ldx, 32, N, wih0_p, whh0_p, wih1_p, whh1_p, b0, b1, hseq0, hseq1, sv0,
@@ -2663,6 +2668,7 @@ extern "C" int fsn_lstm_layer_backward(const float* dh, const float* x, long ldx
 // layer-to-layer dX included - as ONE persistent launch (lstm_group_bptt_kernels.hip).
 static int lstm2_bptt_group_clusters(int T, int N, int I, int H) { return lstm2_train_plan(T, N, I, H).bptt_group; }
 extern "C" size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H, int arith) {
+    arith &= ~FSN_ARITH_SAVES16;
     const int Ipad = fsn_round_up(I, 16), G = 4 * H;
     const size_t l1 = fsn_lstm_layer_bwd_workspace_bytes(T, N, H, H), l0 = fsn_lstm_layer_bwd_workspace_bytes(T, N, I, H);
     Carver cv(nullptr);
@@ -2685,6 +2691,7 @@ extern "C" size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H, int 
             cv.take<unsigned short>((size_t)2 * T * N * G);  // 16-bit gate gradients: operands of the weight-gradient products
             cv.take<unsigned short>((size_t)2 * T * N * H);  // 16-bit hidden sequences
             cv.take<float>((size_t)2 * clusters * G);        // bias-gradient sums per (layer, cluster)
+            cv.take<unsigned short>((size_t)T * N * 32 + (size_t)G * 32);  // x in 16 bits | W_ih0 fragments (gemm_tn16n / gemm_dx16)
         }
         return fsn_round_up_sz(cv.off, 256);
     }
@@ -2718,8 +2725,10 @@ static int lstm2_backward_phases(const float* dh1, const float* x, long ldx, con
     const bool chain_part = (phase & 1) != 0, products_part = (phase & 2) != 0, dx_part = (phase & 4) != 0;
     const bool prepare_part = (phase & 8) != 0, prepared = (phase & 16) != 0;
     FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
-    FSN_REQUIRE(arith == FSN_ARITH_F32 || arith == FSN_ARITH_F16 || arith == FSN_ARITH_BF16,
-                "lstm2 backward: arithmetic %d unknown (FSN_ARITH_F32 / _F16 / _BF16)", arith);
+    const int saves16 = arith & FSN_ARITH_SAVES16;  // must be what the forward call of this step was given
+    arith &= ~FSN_ARITH_SAVES16;
+    FSN_REQUIRE((arith == FSN_ARITH_F32 && !saves16) || arith == FSN_ARITH_F16 || arith == FSN_ARITH_BF16,
+                "lstm2 backward: arithmetic %d unknown (FSN_ARITH_F32 / _F16 / _BF16 [| FSN_ARITH_SAVES16])", arith | saves16);
     FSN_REQUIRE(dh1 && x && w_ih0 && w_hh0 && w_ih1 && w_hh1 && hseq0 && hseq1 && save0 && save1 && dw_ih0 && dw_hh0 && db0 &&
                     dw_ih1 && dw_hh1 && db1 && workspace,
                 "NULL pointer argument");
@@ -2821,6 +2830,11 @@ static int lstm2_backward_phases(const float* dh1, const float* x, long ldx, con
     const bool g16 = lstm2_use_g16(arith, clusters, N);
     // the weight-gradient products from 16-bit operands in memory (needs the shapes' one-workgroup-per-CU plan)
     const bool tn16h = g16 && T > 1 && fsn_gemm_tn16h_supported(G, H, (long)(T - 1) * N) && !g_tn16h_off.load(std::memory_order_relaxed);
+    // ... and layer 0's input-side products too (dx, dW_ih0): then the BPTT launch stores no fp32 gate gradients at all
+    const bool in16 = tn16h && fsn_gemm_tn16n_supported(G, I, (long)T * N) && fsn_gemm_dx16_supported((long)T * N, G, I) && ldx == 32 &&
+                      !g_in16_off.load(std::memory_order_relaxed);
+    unsigned short* x16 = arith != FSN_ARITH_F32 ? cv.take<unsigned short>((size_t)T * N * 32 + (size_t)G * 32) : nullptr;  // x in 16 bits | W_ih0 fragments
+    unsigned short* wdx16 = in16 ? x16 + (size_t)T * N * 32 : nullptr;
     const float* sv0 = static_cast<const float*>(save0);
     const float* sv1 = static_cast<const float*>(save1);
     if (prepare_part) {
@@ -2850,7 +2864,8 @@ static int lstm2_backward_phases(const float* dh1, const float* x, long ldx, con
         if (g16) {  // the 16-bit arithmetic's own kernel (K-split; packs the raw weights its way into w16)
             // (layer 1's fp32 gate gradients of the cluster rows are not stored: the products below take the 16-bit copies)
             FSN_TRY(fsn_launch_lstm2_g16_bptt(dh1, w_hh1, w_ih1, w_hh0, sv0, sv1, dg0, dg1, partials, flags, g16_w, T, N, clusters,
-                                              H, s, arith, dg16, dg16 + (size_t)T * N * G, dbp, tn16h ? 0 : 1));  // dg16 = layer 0 | layer 1
+                                              H, s, arith | saves16, dg16, dg16 + (size_t)T * N * G, dbp, tn16h ? 0 : 1,
+                                              in16 ? 0 : 1));  // dg16 = layer 0 | layer 1
             FSN_TRY(fsn_launch_poison_if(flags + fsn_lstm2_g16_status_word(clusters), dg1, (size_t)2 * T * N * G, s));
             // the 16-bit copies and the bias-gradient sums as well (viewed as floats: every second value of a poisoned copy
             // is NaN - enough for every product to carry NaN into the gradient norm, on which the optimizer skips)
@@ -2905,7 +2920,11 @@ static int lstm2_backward_phases(const float* dh1, const float* x, long ldx, con
         }
     }
     }  // chain_part
-    if (dx && dx_part) {
+    if (dx && dx_part && in16) {
+        // (the step-by-step rows' 16-bit copies first: the finish step of the products part may not have run yet)
+        FSN_TRY(fsn_launch_g16_left_to16(dg0, dg16, T, N, row0, left, s, arith));
+        FSN_TRY(fsn_launch_gemm_dx16(dg16, G, w_ih0, wdx16, dx, lddx, (long)T * N, G, I, s, arith));
+    } else if (dx && dx_part) {
         FsnGemmA a{};
         FsnGemmC c{};
         a.kind = 0;
@@ -2938,7 +2957,12 @@ static int lstm2_backward_phases(const float* dh1, const float* x, long ldx, con
         FSN_TRY(fsn_launch_gemm_tn16h(dg16_1, G, h16, H, dw_ih1, H, G, H, (long)T * N, scratch, s, arith));
         FSN_TRY(fsn_launch_gemm_tn16h(dg16_1 + (size_t)N * G, G, h16 + TNH, H, dw_hh1, H, G, H, (long)(T - 1) * N, scratch, s, arith));
         FSN_TRY(fsn_launch_gemm_tn16h(dg16_0 + (size_t)N * G, G, h16, H, dw_hh0, H, G, H, (long)(T - 1) * N, scratch, s, arith));
-        FSN_TRY(fsn_launch_gemm_tn(dg0, G, x, ldx, dw_ih0, I, G, I, (long)T * N, scratch, s, nullptr, arith));
+        if (in16) {  // x rounded once ([T N][32], its padding columns are zero), then the narrow product from 16-bit operands
+            FSN_TRY(fsn_launch_to16(x, x16, (size_t)T * N * 32, arith, s));
+            FSN_TRY(fsn_launch_gemm_tn16n(dg16_0, G, x16, 32, dw_ih0, I, G, I, (long)T * N, scratch, s, arith));
+        } else {
+            FSN_TRY(fsn_launch_gemm_tn(dg0, G, x, ldx, dw_ih0, I, G, I, (long)T * N, scratch, s, nullptr, arith));
+        }
         if (!finish_first)
             FSN_TRY(fsn_launch_lstm2_g16_finish(dg1, dg0, dg16 + (size_t)T * N * G, dg16, dbp, clusters, T, N, left, db1, db0, s, arith));
         return FSN_OK;

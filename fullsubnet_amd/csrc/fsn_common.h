@@ -313,7 +313,8 @@ int fsn_launch_lstm2_g16_train(const float* x, int I, int Nrows, const float* w_
 int fsn_launch_lstm2_g16_bptt(const float* dh1, const float* w_hh1, const float* w_ih1, const float* w_hh0, const float* save0,
                               const float* save1, float* dg0, float* dg1, float* exchange, unsigned* flags, void* wbuf, int Tp,
                               int Nrows, int clusters, int H, hipStream_t s, int arith, void* dg16_0, void* dg16_1, float* dbp,
-                              int dg1_f32);
+                              int dg1_f32, int dg0_f32 = 1);
+int fsn_launch_g16_left_to16(const float* dg, void* dg16, int Tp, int Nrows, long row0, int left, hipStream_t s, int arith);
 int fsn_launch_lstm2_g16_finish(const float* dg1, const float* dg0, void* dg16_1, void* dg16_0, const float* dbp, int clusters, int Tp,
                                 int Nrows, int left, float* db1, float* db0, hipStream_t s, int arith);
 // fb_chain_bptt_kernels.hip: BPTT of the full-band model's two layers (16 rows, H = 512) as one persistent launch
@@ -404,6 +405,12 @@ int fsn_launch_gemm_tn(const float* A, long lda, const float* B, long ldb, float
 int fsn_launch_colsum(const float* A, long lda, float* out, int cols, long rows, void* workspace, hipStream_t s);
 // the same product with both operands 16-bit in memory (LDS-DMA staging, transposing LDS reads); workspace as above
 bool fsn_gemm_tn16h_supported(int M, int Nc, long K);
+bool fsn_gemm_tn16n_supported(int M, int Nc, long K);  // the narrow form (Nc <= 32) and dx from the 16-bit gate gradients
+int fsn_launch_gemm_tn16n(const void* A16, long lda, const void* B16, long ldb, float* C, long ldc, int M, int Nc, long K,
+                          void* workspace, hipStream_t s, int arith);
+bool fsn_gemm_dx16_supported(long rows, int G, int I);
+int fsn_launch_gemm_dx16(const void* dg16, long ld16, const float* w, void* wfrag, float* dx, long lddx, long rows, int G, int I,
+                         hipStream_t s, int arith);
 int fsn_launch_gemm_tn16h(const void* A16, long lda, const void* B16, long ldb, float* C, long ldc, int M, int Nc, long K,
                           void* workspace, hipStream_t s, int arith);
 size_t fsn_colsum_workspace_bytes(int cols, long rows);

@@ -67,6 +67,21 @@ __device__ __forceinline__ f32x4 q_mma2(const q_u32x4 a, const q_u32x4 b, f32x4 
                            fsn_wfrag_operand<AR>(fsn_u32x2{b[0], b[1]}), fsn_wfrag_operand<AR>(fsn_u32x2{b[2], b[3]}), c);
 }
 __device__ __forceinline__ q_u32x4 q_lds128(const unsigned char* p) { return *reinterpret_cast<const q_u32x4*>(p); }
+// four 16-bit values as q_round4 packed them -> fp32 (exact)
+template <int AR>
+__device__ __forceinline__ f32x4 q_unpack4(const unsigned lo, const unsigned hi) {
+    if constexpr (AR == FSN_ARITH_F16) {
+        return __builtin_convertvector(__builtin_bit_cast(fsn_f16x4, fsn_u32x2{lo, hi}), f32x4);
+    } else {
+        return f32x4{__builtin_bit_cast(float, lo << 16), __builtin_bit_cast(float, lo & 0xffff0000u),
+                     __builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+    }
+}
+// Saved gates in 16 bits (SV = 1; fsn_set_train_saves): the activated gates i, f, g, o that BPTT re-reads are kept in the
+// operand type of the arithmetic - what the vendor's autocast LSTM keeps in its reserve space - inside the SAME buffer: row
+// r of step t still owns its 4H x 4 bytes and uses the first half as [unit quad 96][gate 4][4 units] 16-bit, so a thread's
+// (row, unit quad) item is 32 contiguous bytes (two 16-byte stores forward, two LDS-DMA pieces backward) and rows that do
+// not fill a cluster (step kernels beside the launch, fp32 layout) are untouched.  The cell sequence stays fp32.
 
 // One wave polls eight member flags until all have reached `epoch` (bounded by the device clock).
 __device__ __forceinline__ void q_poll(unsigned* flags8, unsigned epoch, unsigned* status, unsigned long long ticks) {
@@ -205,7 +220,7 @@ struct G16FwdArgs {
 
 // ABL: experiment knob of tools/probe_g16.hip (0 in the library; any bit set gives WRONG results): 1 no flag waits, 2 the
 // partners' tiles not loaded (constants staged), 4 no weight loads (constant fragments), 8 no saves, 16 no h stores
-template <int LAYER, int AR, int ABL, int XS>
+template <int LAYER, int AR, int ABL, int XS, int SV>
 __device__ __forceinline__ void g16_fwd_body(const G16FwdArgs& a, int cluster, int member, unsigned char* act, unsigned char* xsm) {
     float live = 0.f;  // keeps ablated values alive
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -392,8 +407,16 @@ __device__ __forceinline__ void g16_fwd_body(const G16FwdArgs& a, int cluster, i
 #pragma unroll
                 for (int g = 0; g < 4; ++g) live += sg[e][g][0] + sg[e][g][3];
             } else {
+                if constexpr (SV != 0) {
+                    const unsigned so = (unsigned)(row * QG * 4 + (12 * member + quad) * 32);
+                    const fsn_u32x2 pi = q_round4<AR>(sg[e][0]), pf = q_round4<AR>(sg[e][1]);
+                    const fsn_u32x2 pg = q_round4<AR>(sg[e][2]), po = q_round4<AR>(sg[e][3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(q_u32x4{pi[0], pi[1], pf[0], pf[1]}, rg, so, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(q_u32x4{pg[0], pg[1], po[0], po[1]}, rg, so, 16, 0);
+                } else {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) q_store(rg, go, (unsigned)(g * QH * 4), sg[e][g]);
+                    for (int g = 0; g < 4; ++g) q_store(rg, go, (unsigned)(g * QH * 4), sg[e][g]);
+                }
                 q_store(rc, (unsigned)((row * QH + QU * member + quad * 4) * 4), 0, c[e]);
             }
         }
@@ -401,7 +424,7 @@ __device__ __forceinline__ void g16_fwd_body(const G16FwdArgs& a, int cluster, i
     if (ABL != 0 && live == 123.456f) a.status[1] = 1u;  // never true: the ablated values stay computed
 }
 
-template <int AR, int ABL = 0>
+template <int AR, int ABL = 0, int SV = 0>
 __global__ __launch_bounds__(256, 2) void lstm2_g16_fwd_kernel(const G16FwdArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char act[FWD_LDS];
     __shared__ __attribute__((aligned(16))) unsigned char xsm[QROWS * X_STRIDE];
@@ -454,11 +477,11 @@ __global__ __launch_bounds__(256, 2) void lstm2_g16_fwd_kernel(const G16FwdArgs 
         __syncthreads();  // (xsm is the layer-0 input tile afterwards)
     }
     if (same_xcd) {
-        if (layer == 0) g16_fwd_body<0, AR, ABL, 1>(a, cluster, member, act, xsm);
-        else g16_fwd_body<1, AR, ABL, 1>(a, cluster, member, act, xsm);
+        if (layer == 0) g16_fwd_body<0, AR, ABL, 1, SV>(a, cluster, member, act, xsm);
+        else g16_fwd_body<1, AR, ABL, 1, SV>(a, cluster, member, act, xsm);
     } else {
-        if (layer == 0) g16_fwd_body<0, AR, ABL, 16>(a, cluster, member, act, xsm);
-        else g16_fwd_body<1, AR, ABL, 16>(a, cluster, member, act, xsm);
+        if (layer == 0) g16_fwd_body<0, AR, ABL, 16, SV>(a, cluster, member, act, xsm);
+        else g16_fwd_body<1, AR, ABL, 16, SV>(a, cluster, member, act, xsm);
     }
 }
 
@@ -494,6 +517,7 @@ struct G16BwdArgs {
     unsigned short *dg16_0, *dg16_1;  // [Tp][N][4H] 16-bit gate gradients, row-major: operands of the weight-gradient products
     float* dbp;            // [2 layers][clusters][4H]: column sums of this launch's gate gradients (fp32 values): the bias gradients
     int dg1_f32;           // 0: layer 1's fp32 gate gradients are not stored (nothing reads them: the products take dg16_1)
+    int dg0_f32;           // 0: nor layer 0's (dx and dW_ih0 take dg16_0 too: gemm_dx16_kernel, gemm_tn16n_kernel)
     unsigned* flags;       // [clusters][2][QFS]: steps published by (layer 1 | layer 0, member)
     unsigned* status;
     unsigned long long spin_ticks;
@@ -502,7 +526,7 @@ struct G16BwdArgs {
 
 // ABL (tools/probe_g16.hip; 0 in the library, any bit set gives WRONG results): 1 no flag waits, 2 saved activations not
 // loaded, 4 no weight loads, 8 no gate-gradient stores, 16 no exchange stores, 32 exchanged operand not loaded
-template <int LAYER, int AR, int ABL>
+template <int LAYER, int AR, int ABL, int SV>
 __device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, int member, unsigned char* red, unsigned char* dsh,
                                              float (*dbs)[4 * QU]) {
     float live = 0.f;
@@ -616,7 +640,15 @@ __device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, i
         f32x4 sg[3][4], c_p[3], dh[3];
         {
             const float* gp = gates + ((size_t)t * N + (size_t)cluster * QROWS + wave * 16 + lr) * QG + QU * member + 4 * lq;
-            if constexpr ((ABL & 2) == 0) {
+            if constexpr ((ABL & 2) == 0 && SV != 0) {  // 16-bit saves: a lane's (row, unit quad) item = 32 bytes = two pieces
+                const unsigned char* gp16 = reinterpret_cast<const unsigned char*>(gates) +
+                                            ((size_t)t * N + (size_t)cluster * QROWS + wave * 16 + lr) * (QG * 4) + (12 * member + lq) * 32;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        q_lds_dma(reinterpret_cast<const float*>(gp16 + j * 128 + p * 16), red_w + (unsigned)((j * 2 + p) * 1024));
+            } else if constexpr ((ABL & 2) == 0) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -642,13 +674,23 @@ __device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, i
         }
         // the gates have landed long ago (the DMA is older than every load the K loops consumed); say so, read them back
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr ((ABL & 2) == 0 && SV != 0) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if constexpr ((ABL & 2) != 0) sg[j][g] = f32x4{0.4f, 0.3f, 0.2f + 1e-3f * (float)(j + g), 0.1f};
-                else sg[j][g] = *reinterpret_cast<const f32x4*>(red + (wave * 12 + j * 4 + g) * 1024 + lane * 16);
+            for (int j = 0; j < 3; ++j) {
+                const q_u32x4 v0 = q_lds128(red + (wave * 12 + j * 2) * 1024 + lane * 16);
+                const q_u32x4 v1 = q_lds128(red + (wave * 12 + j * 2 + 1) * 1024 + lane * 16);
+                sg[j][0] = q_unpack4<AR>(v0[0], v0[1]), sg[j][1] = q_unpack4<AR>(v0[2], v0[3]);
+                sg[j][2] = q_unpack4<AR>(v1[0], v1[1]), sg[j][3] = q_unpack4<AR>(v1[2], v1[3]);
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if constexpr ((ABL & 2) != 0) sg[j][g] = f32x4{0.4f, 0.3f, 0.2f + 1e-3f * (float)(j + g), 0.1f};
+                    else sg[j][g] = *reinterpret_cast<const f32x4*>(red + (wave * 12 + j * 4 + g) * 1024 + lane * 16);
+                }
+        }
         // the four waves' K quarters meet: wave w' takes row tile w', sums the sources in a fixed order
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -708,7 +750,7 @@ __device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, i
             for (int j = 0; j < 3; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    if (LAYER == 0 || a.dg1_f32) q_store(ro, eo_g, (unsigned)(g * QH * 4 + j * 64), sg[j][g]);
+                    if (LAYER ? a.dg1_f32 : a.dg0_f32) q_store(ro, eo_g, (unsigned)(g * QH * 4 + j * 64), sg[j][g]);
                     __builtin_amdgcn_raw_buffer_store_b64(q_round4<AR>(sg[j][g]), r16, eo_16, (unsigned)((g * QH + j * 16) * 2), 0);
                     fsn_hold_store_data(sg[j][g]);  // the sums below may be formed in the store's data registers
                     f32x4 v = sg[j][g];
@@ -738,7 +780,7 @@ __device__ __forceinline__ void g16_bwd_body(const G16BwdArgs& a, int cluster, i
     if (ABL != 0 && live == 123.456f) a.status[1] = 1u;  // never true: the ablated values stay computed
 }
 
-template <int AR, int ABL = 0>
+template <int AR, int ABL = 0, int SV = 0>
 __global__ __launch_bounds__(256, 2) void lstm2_g16_bwd_kernel(const G16BwdArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char red[4 * 12 * 1024];
     __shared__ __attribute__((aligned(16))) unsigned char dsh[QROWS * DSH_STRIDE];
@@ -758,8 +800,8 @@ __global__ __launch_bounds__(256, 2) void lstm2_g16_bwd_kernel(const G16BwdArgs 
         cluster = bid / QM;
         member = bid % QM;
     }
-    if (!second) g16_bwd_body<1, AR, ABL>(a, cluster, member, red, dsh, dbs);
-    else g16_bwd_body<0, AR, ABL>(a, cluster, member, red, dsh, dbs);
+    if (!second) g16_bwd_body<1, AR, ABL, SV>(a, cluster, member, red, dsh, dbs);
+    else g16_bwd_body<0, AR, ABL, SV>(a, cluster, member, red, dsh, dbs);
 }
 
 // After the launch: the rows that did not fill a cluster (computed step by step beside it, fp32) need their 16-bit copies ...
@@ -794,7 +836,9 @@ int fsn_lstm2_g16_clusters(int tiles) {
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return 0;
     for (const void* k : {(const void*)lstm2_g16_fwd_kernel<FSN_ARITH_F16>, (const void*)lstm2_g16_fwd_kernel<FSN_ARITH_BF16>,
-                          (const void*)lstm2_g16_bwd_kernel<FSN_ARITH_F16>, (const void*)lstm2_g16_bwd_kernel<FSN_ARITH_BF16>})
+                          (const void*)lstm2_g16_bwd_kernel<FSN_ARITH_F16>, (const void*)lstm2_g16_bwd_kernel<FSN_ARITH_BF16>,
+                          (const void*)lstm2_g16_fwd_kernel<FSN_ARITH_F16, 0, 1>, (const void*)lstm2_g16_fwd_kernel<FSN_ARITH_BF16, 0, 1>,
+                          (const void*)lstm2_g16_bwd_kernel<FSN_ARITH_F16, 0, 1>, (const void*)lstm2_g16_bwd_kernel<FSN_ARITH_BF16, 0, 1>})
         if (!fsn_grid_fits(k, 256, 2u * (unsigned)cus)) return 0;
     const int cap = cus / QM, c = tiles / 4;
     return c < cap ? c : cap;
@@ -820,7 +864,7 @@ static int g16_pack_bptt(const float* w, void* out, hipStream_t s) {
 }
 template <int AR>
 static int g16_launch_bptt(G16BwdArgs a, const float* w_hh1, const float* w_ih1, const float* w_hh0, void* wbuf, float* exchange,
-                           int clusters, hipStream_t s) {
+                           int clusters, hipStream_t s, bool saves16) {
     const size_t wb = (size_t)QG * QH * 2;
     unsigned char* p = static_cast<unsigned char*>(wbuf);
     int rc;
@@ -833,7 +877,8 @@ static int g16_launch_bptt(G16BwdArgs a, const float* w_hh1, const float* w_ih1,
     a.x1 = exchange;
     a.x0 = reinterpret_cast<unsigned char*>(exchange) + (size_t)clusters * QDX * q_xslot<AR>();
     const dim3 grid((unsigned)clusters * QM * 2), block(256);
-    FSN_PERSIST_LAUNCH(lstm2_g16_bwd_kernel<AR>, grid, block, s, a);
+    if (saves16) FSN_PERSIST_LAUNCH((lstm2_g16_bwd_kernel<AR, 0, 1>), grid, block, s, a);
+    else FSN_PERSIST_LAUNCH(lstm2_g16_bwd_kernel<AR>, grid, block, s, a);
     return fsn_check_launch("lstm2_g16_bwd_kernel");
 }
 
@@ -844,6 +889,8 @@ int fsn_launch_lstm2_g16_train(const float* x, int I, int Nrows, const float* w_
                                const float* w_hh1, const float* bias0, const float* bias1, float* hseq0, float* hseq1,
                                float* save0, float* save1, unsigned* flags, void* w16, int Tp, int clusters, int H,
                                hipStream_t s, int arith) {
+    const bool saves16 = (arith & FSN_ARITH_SAVES16) != 0;  // the activated gates saved in the 16-bit type (include/fsn_hip.h)
+    arith &= ~FSN_ARITH_SAVES16;
     if (H != QH || I < 1 || I > 32 || clusters < 1 || clusters > fsn_lstm2_g16_clusters(Nrows / 16) ||
         (arith != FSN_ARITH_F16 && arith != FSN_ARITH_BF16)) {
         fsn_set_error("lstm2_g16 (forward): H = 384, up to 32 input columns, 16-bit arithmetic, clusters * 64 <= rows, one cluster per eight CUs at most");
@@ -884,8 +931,13 @@ int fsn_launch_lstm2_g16_train(const float* x, int I, int Nrows, const float* w_
     a.Tp = Tp;
     a.Nrows = Nrows;
     const dim3 grid((unsigned)clusters * QM * 2), block(256);
-    if (arith == FSN_ARITH_F16) FSN_PERSIST_LAUNCH(lstm2_g16_fwd_kernel<FSN_ARITH_F16>, grid, block, s, a);
-    else FSN_PERSIST_LAUNCH(lstm2_g16_fwd_kernel<FSN_ARITH_BF16>, grid, block, s, a);
+    if (saves16) {
+        if (arith == FSN_ARITH_F16) FSN_PERSIST_LAUNCH((lstm2_g16_fwd_kernel<FSN_ARITH_F16, 0, 1>), grid, block, s, a);
+        else FSN_PERSIST_LAUNCH((lstm2_g16_fwd_kernel<FSN_ARITH_BF16, 0, 1>), grid, block, s, a);
+    } else {
+        if (arith == FSN_ARITH_F16) FSN_PERSIST_LAUNCH(lstm2_g16_fwd_kernel<FSN_ARITH_F16>, grid, block, s, a);
+        else FSN_PERSIST_LAUNCH(lstm2_g16_fwd_kernel<FSN_ARITH_BF16>, grid, block, s, a);
+    }
     return fsn_check_launch("lstm2_g16_fwd_kernel");
 }
 
@@ -895,7 +947,9 @@ int fsn_launch_lstm2_g16_train(const float* x, int I, int Nrows, const float* w_
 int fsn_launch_lstm2_g16_bptt(const float* dh1, const float* w_hh1, const float* w_ih1, const float* w_hh0, const float* save0,
                               const float* save1, float* dg0, float* dg1, float* exchange, unsigned* flags, void* wbuf, int Tp,
                               int Nrows, int clusters, int H, hipStream_t s, int arith, void* dg16_0, void* dg16_1, float* dbp,
-                              int dg1_f32) {
+                              int dg1_f32, int dg0_f32) {
+    const bool saves16 = (arith & FSN_ARITH_SAVES16) != 0;
+    arith &= ~FSN_ARITH_SAVES16;
     if (H != QH || clusters < 1 || clusters > fsn_lstm2_g16_clusters(Nrows / 16) || (arith != FSN_ARITH_F16 && arith != FSN_ARITH_BF16)) {
         fsn_set_error("lstm2_g16 (bptt): H = 384, 16-bit arithmetic, clusters * 64 <= rows, one cluster per eight CUs at most");
         return FSN_ERR_ARG;
@@ -913,6 +967,7 @@ int fsn_launch_lstm2_g16_bptt(const float* dh1, const float* w_hh1, const float*
     a.dg16_1 = static_cast<unsigned short*>(dg16_1);
     a.dbp = dbp;
     a.dg1_f32 = dg1_f32;
+    a.dg0_f32 = dg0_f32;
     if (!dg16_0 || !dg16_1 || !dbp) {
         fsn_set_error("lstm2_g16 (bptt): NULL 16-bit gate-gradient / bias-gradient buffer");
         return FSN_ERR_ARG;
@@ -922,10 +977,21 @@ int fsn_launch_lstm2_g16_bptt(const float* dh1, const float* w_hh1, const float*
     a.spin_ticks = fsn_spin_ticks();
     a.Tp = Tp;
     a.Nrows = Nrows;
-    if (arith == FSN_ARITH_F16) return g16_launch_bptt<FSN_ARITH_F16>(a, w_hh1, w_ih1, w_hh0, wbuf, exchange, clusters, s);
-    return g16_launch_bptt<FSN_ARITH_BF16>(a, w_hh1, w_ih1, w_hh0, wbuf, exchange, clusters, s);
+    if (arith == FSN_ARITH_F16) return g16_launch_bptt<FSN_ARITH_F16>(a, w_hh1, w_ih1, w_hh0, wbuf, exchange, clusters, s, saves16);
+    return g16_launch_bptt<FSN_ARITH_BF16>(a, w_hh1, w_ih1, w_hh0, wbuf, exchange, clusters, s, saves16);
 }
 
+// 16-bit copies of the step-by-step rows' gate gradients of ONE layer (rows [row0, row0 + left) of every step)
+int fsn_launch_g16_left_to16(const float* dg, void* dg16, int Tp, int Nrows, long row0, int left, hipStream_t s, int arith) {
+    if (left <= 0) return FSN_OK;
+    const long n4 = (long)Tp * left * QG / 4;
+    const unsigned blocks = (unsigned)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
+    if (arith == FSN_ARITH_F16)
+        hipLaunchKernelGGL(g16_left_to16_kernel<FSN_ARITH_F16>, dim3(blocks), dim3(256), 0, s, dg, static_cast<unsigned short*>(dg16), Tp, (long)Nrows, row0, left);
+    else
+        hipLaunchKernelGGL(g16_left_to16_kernel<FSN_ARITH_BF16>, dim3(blocks), dim3(256), 0, s, dg, static_cast<unsigned short*>(dg16), Tp, (long)Nrows, row0, left);
+    return fsn_check_launch("g16_left_to16_kernel");
+}
 // After fsn_launch_lstm2_g16_bptt AND the step-by-step rows beside it: 16-bit copies of those rows' gate gradients (rows
 // [row0, row0 + left) of every step, both layers: dg = dg1 | dg0 adjacent, dg16 likewise) and the bias gradients
 // db1 / db0 [4H] = the launch's cluster sums (dbp) + those rows.

@@ -344,8 +344,11 @@ struct SbStage {
 // any stacked LSTM's first layer - Fast FullSubNet's bottleneck is 16 columns wide: fast_fullsubnet/model.py:66-74).  With
 // ONE x chunk a pass walks an odd number of K chunks, so the two weight-fragment registers sets swap roles from pass to pass
 // (four passes per step: every step starts the same way).
+#ifndef FSN_REC_IN_VCAP
+#define FSN_REC_IN_VCAP 76  // x 2 = 152 registers: three waves per SIMD + a step workgroup beside them (tests/test_host_cpu.py)
+#endif
 template <int H, int RT, int UG, int OPT = 0, int KX = 2, bool ROWSIN = false>
-__global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgpr(76))) void lstm_rec_in_kernel(
+__global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgpr(FSN_REC_IN_VCAP))) void lstm_rec_in_kernel(
     const FsnSbInput xin, const float* __restrict__ w_p, unsigned whh_off, float* __restrict__ hseq, int Tp, int Npad) {
     constexpr int NW = H / (16 * UG);
     constexpr int KC = H / 16;

@@ -675,6 +675,179 @@ TnPlan tn_plan(int M, int Nc, long K, int arith = FSN_ARITH_F32, bool allow_squa
 // 4.2 / 3.67 ms: the staged form only reaches the register ring's time (its DMA costs 0.3 ms, its LDS reads 0.2, its
 // barrier 0.15), so the ring stays.)
 #endif
+
+// ---- layer 0's INPUT-side products from the 16-bit gate gradients (round 6) -------------------------------------------------
+// With these two the BPTT launch of the 16-bit arithmetic stores no fp32 gate gradients at all (2.45 GB less written per
+// step at config 3's shape, 2 x 2.45 GB less read): dW_ih0 = dgates0^T x and dx = dgates0 W_ih0 take the row-major 16-bit
+// copies the launch writes for the large products anyway - both operands of both products rounded to 16 bits, as every other
+// product of the autocast arithmetic (dx used to be an fp32 product of the fp32 gradients: wider than the reference's own).
+//
+// (1) dW_ih0 [M = 4H][<= 32] = A^T B: gemm_tn16h_kernel's staging (LDS-DMA into the image ds_read_b64_tr_b16 wants, four stages)
+// on a 384 x 32 tile: four waves x 96 gate columns, B = the 32 input columns.  A chunk of 32 k: A 2 k steps x 24 column
+// tiles x 512 B, B 2 x 2 x 512 B.  Wave w stages A's k step w & 1, column pairs 6 (w >> 1) .. + 5; waves 0, 1 also B's k step w.
+constexpr int TNN_STAGE = 2 * (24 + 2) * 512;
+template <int AR>
+__global__ __launch_bounds__(256) void gemm_tn16n_kernel(const unsigned short* __restrict__ A, long lda,
+                                                         const unsigned short* __restrict__ B, long ldb, float* __restrict__ part,
+                                                         int M, long K, long k_per_split, int m_blocks) {
+    constexpr int B0 = 2 * 24 * 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char th_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int mb = (int)blockIdx.x % m_blocks, split = (int)blockIdx.x / m_blocks;
+    const int m0 = mb * 384;
+    const long k_begin = (long)split * k_per_split;
+    long k_end = k_begin + k_per_split;
+    k_end = k_end < K ? k_end : K;
+    const int chunks = k_end > k_begin ? (int)((k_end - k_begin) >> 5) : 0;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)th_lds;
+    const int s_ks = wave & 1, s_half = wave >> 1;
+    const long s_row = k_begin + 16 * s_ks + ((lane & 31) >> 1);
+    const int s_col = 16 * (lane >> 5) + 8 * (lane & 1);
+    const unsigned short* spa = A + m0 + 192 * s_half + s_row * lda + s_col;
+    const unsigned short* spb = B + s_row * ldb + s_col;
+    const unsigned dst_a = (unsigned)(s_ks * 24 * 512 + s_half * 6 * 1024), dst_b = (unsigned)(B0 + s_ks * 2 * 512);
+    auto issue = [&](int c) {
+        const unsigned st = lds0 + (unsigned)((c % TH_STAGES) * TNN_STAGE);
+#pragma unroll
+        for (int p = 0; p < 6; ++p) th_lds_dma(spa + (long)c * 32 * lda + 32 * p, st + dst_a + (unsigned)(p * 1024));
+        if (wave < 2) th_lds_dma(spb + (long)c * 32 * ldb, st + dst_b);
+    };
+    f32x4 acc[6][2];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int lane_off = (4 * lq + (lr >> 2)) * 32 + (lr & 3) * 8;
+    auto tr = [&](const unsigned char* p) {
+        return __builtin_bit_cast(typename FsnOperand<AR>::type,
+                                  __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tq_s16x4*)p));
+    };
+#pragma unroll
+    for (int c = 0; c < TH_STAGES - 1; ++c)
+        if (c < chunks) issue(c);
+    for (int c = 0; c < chunks; ++c) {
+        static_assert(TH_STAGES == 4, "the counted waits below: two younger chunks of 7 (waves 0, 1) / 6 DMAs per wave");
+        if (c + TH_STAGES - 1 <= chunks) {
+            if (wave < 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();  // chunk c of every wave has landed; everyone has left stage (c - 1) % TH_STAGES
+        if (c + TH_STAGES - 1 < chunks) issue(c + TH_STAGES - 1);
+        const unsigned char* base = th_lds + (c % TH_STAGES) * TNN_STAGE + lane_off;
+        typename FsnOperand<AR>::type a[2][6], b[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) a[ks][i] = tr(base + ks * 24 * 512 + (wave * 6 + i) * 512);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[ks][j] = tr(base + B0 + ks * 2 * 512 + j * 512);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = fsn_mma_k32<AR>(a[0][i], a[1][i], b[0][j], b[1][j], acc[i][j]);
+    }
+    float* out = part + (long)split * M * 32;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(long)(m0 + (wave * 6 + i) * 16 + 4 * lq + r) * 32 + j * 16 + lr] = acc[i][j][r];
+}
+// its epilogue: the split partials [split][M][32] (fixed order) + the K % 32 tail rows, the first Nc <= 32 columns out
+template <int AR>
+__global__ void tn16n_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, long ldc, int M, int Nc, int splits,
+                                    const unsigned short* __restrict__ A, long lda, const unsigned short* __restrict__ B,
+                                    long ldb, long k_tail0, long K) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)M * Nc) return;
+    const int m = (int)(i / Nc), n = (int)(i % Nc);
+    float acc = 0.f;
+    for (int s = 0; s < splits; ++s) acc += part[((long)s * M + m) * 32 + n];
+    for (long k = k_tail0; k < K; ++k) {
+        float a, b;
+        if constexpr (AR == FSN_ARITH_F16) {
+            a = (float)__builtin_bit_cast(_Float16, A[k * lda + m]);
+            b = (float)__builtin_bit_cast(_Float16, B[k * ldb + n]);
+        } else {
+            a = __builtin_bit_cast(float, (unsigned)A[k * lda + m] << 16);
+            b = __builtin_bit_cast(float, (unsigned)B[k * ldb + n] << 16);
+        }
+        acc = fmaf(a, b, acc);
+    }
+    C[(long)m * ldc + n] = acc;
+}
+
+// (2) dx [rows][I <= 32] = dg16 [rows][G] W [G][I], formed transposed like every product of the 16-bit kernels:
+// D^T[input column][row] = W^T (A operand: fragments packed once, resident in LDS) x dg16^T (B operand: a lane's eight
+// consecutive gate columns of one row = one 16-byte load straight from the row-major copy), so a lane ends up with four
+// consecutive input columns of one row: 16-byte stores.  A wave walks 16-row tiles; its operand loads run twelve K blocks
+// ahead.  HBM-bound: 2 G bytes per row in, 128 out.
+constexpr int DX16_DEPTH = 12;
+template <int AR>
+__global__ void dx16_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int G, int I) {
+    // fragment (kb, j): lane (lr, lq) holds W[32 kb + 8 lq + e][16 j + lr], e = 0..7 (zero beyond I)
+    const long n = (long)(G / 32) * 2 * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63), j = (int)((i >> 6) & 1), kb = (int)(i >> 7);
+        const int col = 16 * j + (lane & 15), k0 = 32 * kb + 8 * (lane >> 4);
+        f32x4 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo[e] = col < I ? w[(long)(k0 + e) * I + col] : 0.f;
+            hi[e] = col < I ? w[(long)(k0 + 4 + e) * I + col] : 0.f;
+        }
+        const fsn_u32x2 a = __builtin_bit_cast(fsn_u32x2, fsn_operand<AR>(lo)), b = __builtin_bit_cast(fsn_u32x2, fsn_operand<AR>(hi));
+        reinterpret_cast<fsn_u32x4*>(out)[i] = fsn_u32x4{a[0], a[1], b[0], b[1]};
+    }
+}
+template <int AR>
+__global__ __launch_bounds__(256) void gemm_dx16_kernel(const unsigned short* __restrict__ dg16, long ld16,
+                                                        const unsigned short* __restrict__ wfrag, float* __restrict__ dx, long lddx,
+                                                        long tiles, int I, int KB) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wl[];  // [KB][2][64 lanes][16 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    for (int i = tid; i < KB * 2 * 64; i += 256) reinterpret_cast<fsn_u32x4*>(wl)[i] = reinterpret_cast<const fsn_u32x4*>(wfrag)[i];
+    __syncthreads();
+    auto opnd = [](const fsn_u32x4 v, int h) {
+        return fsn_wfrag_operand<AR>(fsn_u32x2{v[2 * h], v[2 * h + 1]});
+    };
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < tiles; tile += (long)gridDim.x * 4) {
+        const unsigned short* p = dg16 + (tile * 16 + lr) * ld16 + lq * 8;
+        fsn_u32x4 ring[DX16_DEPTH];
+#pragma unroll
+        for (int d = 0; d < DX16_DEPTH; ++d) ring[d] = *reinterpret_cast<const fsn_u32x4*>(p + d * 32);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int kb0 = 0; kb0 < KB; kb0 += DX16_DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DX16_DEPTH; ++d) {
+                const int kb = kb0 + d;
+                const fsn_u32x4 b = ring[d];
+                if (kb + DX16_DEPTH < KB) ring[d] = *reinterpret_cast<const fsn_u32x4*>(p + (kb + DX16_DEPTH) * 32);
+                const fsn_u32x4 a0 = reinterpret_cast<const fsn_u32x4*>(wl)[(kb * 2 + 0) * 64 + lane];
+                const fsn_u32x4 a1 = reinterpret_cast<const fsn_u32x4*>(wl)[(kb * 2 + 1) * 64 + lane];
+                acc0 = fsn_mma_k32<AR>(opnd(a0, 0), opnd(a0, 1), opnd(b, 0), opnd(b, 1), acc0);
+                acc1 = fsn_mma_k32<AR>(opnd(a1, 0), opnd(a1, 1), opnd(b, 0), opnd(b, 1), acc1);
+            }
+        }
+        float* o = dx + (tile * 16 + lr) * lddx + 4 * lq;
+        if (I == 32) {
+            *reinterpret_cast<f32x4*>(o) = acc0;
+            *reinterpret_cast<f32x4*>(o + 16) = acc1;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (4 * lq + r < I) o[r] = acc0[r];
+                if (16 + 4 * lq + r < I) o[16 + r] = acc1[r];
+            }
+        }
+    }
+}
+
 constexpr size_t kTnOnePerCu = 96 * 1024;  // LDS reservation (never touched): one workgroup per CU
 constexpr long kColsumRows = 2048;
 // rows per block of a column-sum launch: 2048, or fewer when that would leave most of the chip idle - the full-band
@@ -908,6 +1081,101 @@ int fsn_launch_gemm_tn16h(const void* A16, long lda, const void* B16, long ldb, 
         hipLaunchKernelGGL(tn16h_reduce_kernel<FSN_ARITH_BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, C, ldc, M, Nc,
                            p.splits, a, lda, b, ldb, K32, K);
     return fsn_check_launch("tn16h_reduce_kernel");
+}
+
+
+// dW [M][Nc <= 32] = A16^T B16 over K rows, both operands 16-bit row-major in memory (A [K][lda >= M], B [K][ldb >= 32], its
+// columns beyond Nc zero); M a multiple of 384.  workspace: fsn_gemm_tn_workspace_bytes(M, Nc, K).
+bool fsn_gemm_tn16n_supported(int M, int Nc, long K) { return M % 384 == 0 && Nc >= 1 && Nc <= 32 && (K & ~31L) >= 32 * 64; }
+int fsn_launch_gemm_tn16n(const void* A16, long lda, const void* B16, long ldb, float* C, long ldc, int M, int Nc, long K,
+                          void* workspace, hipStream_t s, int arith) {
+    if ((arith != FSN_ARITH_F16 && arith != FSN_ARITH_BF16) || !fsn_gemm_tn16n_supported(M, Nc, K) || lda % 8 || ldb % 8 || ldb < 32 ||
+        ((size_t)A16 & 15) || ((size_t)B16 & 15)) {
+        fsn_set_error("gemm_tn16n: 16-bit arithmetic, M a multiple of 384, Nc <= 32 in rows of >= 32 16-bit columns, 16-byte aligned rows");
+        return FSN_ERR_ARG;
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long K32 = K & ~31L;
+    const int m_blocks = M / 384;
+    long splits = cus / m_blocks > 1 ? cus / m_blocks : 1;
+    const long bound = (long)(fsn_gemm_tn_workspace_bytes(M, Nc, K) / ((size_t)M * 32 * sizeof(float)));
+    splits = splits < bound ? splits : bound;
+    const long kps = ((K32 + splits - 1) / splits + 31) / 32 * 32;
+    splits = (K32 + kps - 1) / kps;
+    constexpr size_t kLds = (size_t)TH_STAGES * TNN_STAGE;  // 104 KB: one workgroup per CU by itself
+    auto kern = arith == FSN_ARITH_F16 ? gemm_tn16n_kernel<FSN_ARITH_F16> : gemm_tn16n_kernel<FSN_ARITH_BF16>;
+    static bool set[4] = {false, false, false, false};
+    if (!set[arith]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds) != hipSuccess) {
+            fsn_set_error("gemm_tn16n: cannot reserve %zu bytes of LDS", kLds);
+            return FSN_ERR_LAUNCH;
+        }
+        set[arith] = true;
+    }
+    float* part = static_cast<float*>(workspace);
+    const unsigned short *a = static_cast<const unsigned short*>(A16), *b = static_cast<const unsigned short*>(B16);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(m_blocks * splits)), dim3(256), kLds, s, a, lda, b, ldb, part, M, K32, kps, m_blocks);
+    FSN_TRY_LAUNCH("gemm_tn16n_kernel");
+    const long n = (long)M * Nc;
+    if (arith == FSN_ARITH_F16)
+        hipLaunchKernelGGL(tn16n_reduce_kernel<FSN_ARITH_F16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, C, ldc, M, Nc,
+                           (int)splits, a, lda, b, ldb, K32, K);
+    else
+        hipLaunchKernelGGL(tn16n_reduce_kernel<FSN_ARITH_BF16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, C, ldc, M, Nc,
+                           (int)splits, a, lda, b, ldb, K32, K);
+    return fsn_check_launch("tn16n_reduce_kernel");
+}
+
+// dx [rows][I <= 32] (row stride lddx) = dg16 [rows][G] W [G][I] with both operands rounded to 16 bits; rows a multiple of 16,
+// G a multiple of 32 up to 2048; wfrag: G * 32 16-bit words of scratch for the packed weight (written here).
+bool fsn_gemm_dx16_supported(long rows, int G, int I) {
+    return rows > 0 && rows % 16 == 0 && G % (32 * DX16_DEPTH) == 0 && G <= 2048 && I >= 1 && I <= 32;
+}
+int fsn_launch_gemm_dx16(const void* dg16, long ld16, const float* w, void* wfrag, float* dx, long lddx, long rows, int G, int I,
+                         hipStream_t s, int arith) {
+    if ((arith != FSN_ARITH_F16 && arith != FSN_ARITH_BF16) || !fsn_gemm_dx16_supported(rows, G, I) || ld16 % 8 || lddx % 4 ||
+        ((size_t)dg16 & 15) || ((size_t)dx & 15) || ((size_t)wfrag & 15)) {
+        fsn_set_error("gemm_dx16: 16-bit arithmetic, rows %% 16 == 0, G %% 384 == 0 (<= 2048), I <= 32, 16-byte aligned rows");
+        return FSN_ERR_ARG;
+    }
+    const int KB = G / 32;
+    const size_t lds = (size_t)KB * 2 * 1024;
+    unsigned short* wf = static_cast<unsigned short*>(wfrag);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long tiles = rows / 16;
+    const unsigned grid = (unsigned)((tiles + 3) / 4 < cus ? (tiles + 3) / 4 : cus);
+    if (arith == FSN_ARITH_F16) {
+        hipLaunchKernelGGL(dx16_pack_kernel<FSN_ARITH_F16>, dim3((unsigned)((KB * 128 + 255) / 256)), dim3(256), 0, s, w, wf, G, I);
+        FSN_TRY_LAUNCH("dx16_pack_kernel");
+        static bool set = false;
+        if (!set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dx16_kernel<FSN_ARITH_F16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    128 * 1024) != hipSuccess) {
+                fsn_set_error("gemm_dx16: cannot reserve LDS");
+                return FSN_ERR_LAUNCH;
+            }
+            set = true;
+        }
+        hipLaunchKernelGGL(gemm_dx16_kernel<FSN_ARITH_F16>, dim3(grid), dim3(256), lds, s, static_cast<const unsigned short*>(dg16), ld16, wf,
+                           dx, lddx, tiles, I, KB);
+    } else {
+        hipLaunchKernelGGL(dx16_pack_kernel<FSN_ARITH_BF16>, dim3((unsigned)((KB * 128 + 255) / 256)), dim3(256), 0, s, w, wf, G, I);
+        FSN_TRY_LAUNCH("dx16_pack_kernel");
+        static bool set = false;
+        if (!set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dx16_kernel<FSN_ARITH_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    128 * 1024) != hipSuccess) {
+                fsn_set_error("gemm_dx16: cannot reserve LDS");
+                return FSN_ERR_LAUNCH;
+            }
+            set = true;
+        }
+        hipLaunchKernelGGL(gemm_dx16_kernel<FSN_ARITH_BF16>, dim3(grid), dim3(256), lds, s, static_cast<const unsigned short*>(dg16), ld16, wf,
+                           dx, lddx, tiles, I, KB);
+    }
+    return fsn_check_launch("gemm_dx16_kernel");
 }
 
 size_t fsn_colsum_workspace_bytes(int cols, long rows) {

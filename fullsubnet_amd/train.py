@@ -69,6 +69,25 @@ class LstmLayerFunction(torch.autograd.Function):
         return (dx[:, :N, :I] if need_dx else None), dw_ih, dw_hh, db, db.clone()
 
 
+# "f16" / "bf16": the arithmetic of torch.autocast (16-bit matrix-core operands, fp32 accumulation, everything stored in fp32);
+# "+s16" (Model.train_saves = "16", _lib.ARITH_SAVES16): the activated gates that BPTT re-reads saved in that 16-bit type too -
+# what the vendor LSTM keeps in its reserve space under autocast - half the save traffic of the two persistent launches
+TRAIN_ARITH = ("f32", "f16", "bf16", "f16+s16", "bf16+s16")
+
+
+def train_arith_of(model):
+    """The `arith` string of a model's training step: Model.train_arithmetic ("f32" | "f16" | "bf16"; Trainer sets it from
+    use_amp) and Model.train_saves ("32" | "16", default "16" under a 16-bit arithmetic: tests/test_gpu_amp.py holds that
+    step to the reference's own fp16-autocast step)."""
+    arith = getattr(model, "train_arithmetic", "f32")
+    if arith in ("f16", "bf16") and str(getattr(model, "train_saves", DEFAULT_TRAIN_SAVES)) == "16":
+        arith += "+s16"
+    return arith
+
+
+DEFAULT_TRAIN_SAVES = "16"
+
+
 class Lstm2Function(torch.autograd.Function):
     """nn.LSTM(num_layers=2) (unidirectional, h0 = c0 = 0, both layers H wide) on time-major x [T, N, I] -> [T, N, H]:
     fsn_lstm2_forward_train (the full-band shape - H = 512, up to 64 rows - and the sub-band shape - H = 384, 96+ row
@@ -80,8 +99,8 @@ class Lstm2Function(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, arith="f32"):
         L = _lib.lib()
-        if arith not in ("f32", "f16", "bf16"):
-            raise _lib.FsnError(f"training arithmetic {arith!r}: one of 'f32', 'f16', 'bf16'")
+        if arith not in TRAIN_ARITH:
+            raise _lib.FsnError(f"training arithmetic {arith!r}: one of {TRAIN_ARITH}")
         ctx.arith = _lib.ARITH[arith]
         T, N, I = x.shape
         H = w_hh0.shape[1]
@@ -373,8 +392,8 @@ class FullSubNetTrainFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, noisy_mag, look_ahead, nb, groups, arith, norm_type, *params):
         L = _lib.lib()
-        if arith not in ("f32", "f16", "bf16"):
-            raise _lib.FsnError(f"training arithmetic {arith!r}: one of 'f32', 'f16', 'bf16'")
+        if arith not in TRAIN_ARITH:
+            raise _lib.FsnError(f"training arithmetic {arith!r}: one of {TRAIN_ARITH}")
         if norm_type not in _lib.NORM_TYPES:
             raise _lib.FsnError(f"fused training graph: norm_type {norm_type!r}: one of {sorted(_lib.NORM_TYPES)}")
         ar = _lib.ARITH[arith]
@@ -532,7 +551,7 @@ def _fused_params(model):
 def forward_train(model, noisy_mag):
     """fullsubnet/model.py:72-136 under autograd (drop_band included), LSTMs on the HIP kernels.
     noisy_mag [B, 1, F, T] -> [B, 2, F // g, T]."""
-    arith = getattr(model, "train_arithmetic", "f32")  # "f16" / "bf16": autocast arithmetic (Trainer, use_amp)
+    arith = train_arith_of(model)
     # drop_band's own check (feature.py:317-319), reached for every batch of more than one utterance (model.py:114): the
     # reference's forward fails for 1 < B <= num_groups, and so does every graph here
     assert noisy_mag.shape[0] == 1 or noisy_mag.shape[0] > model.num_groups_in_drop_band, (

@@ -48,12 +48,19 @@ extern "C" {
  * product are rounded to fp16 / bf16 at the matrix core's input, accumulation and everything stored stay fp32. */
 #define FSN_ARITH_F16 2
 #define FSN_ARITH_BF16 3
+/* Flag for the `arith` argument of fsn_lstm2_forward_train / fsn_lstm2_backward(_phase) / their workspace queries, OR-ed to
+ * FSN_ARITH_F16 / _BF16 (the SAME value must reach the forward and the backward call of a step): the activated gates the
+ * backward pass re-reads are saved in the arithmetic's 16-bit type instead of fp32 - what the vendor LSTM the reference
+ * trains on keeps in its reserve space under autocast (fullsubnet/trainer.py:56) - inside the same save buffers; the cell
+ * sequence, the hidden sequences and every gradient stay fp32.  Takes effect where the 16-bit arithmetic's own kernels run
+ * (lstm_group16_kernels.hip); ignored elsewhere.  Half the save traffic of the two persistent launches. */
+#define FSN_ARITH_SAVES16 0x100
 
 const char* fsn_last_error(void);
 /* The ABI revision this header describes.  fsn_version() returns the revision the LIBRARY was built with: a caller
  * compares the two once after loading (fullsubnet_amd/_lib.py raises on a mismatch) - argument lists changed between
- * revisions (111: + the composed families' glue entries; 110: fsn_train_dims.norm, fsn_train_den_elems; 100 -> 101 of round 4: fsn_clip_adam_step's found_inf). */
-#define FSN_ABI_VERSION 111
+ * revisions (112: + FSN_ARITH_SAVES16; 111: + the composed families' glue entries; 110: fsn_train_dims.norm, fsn_train_den_elems; 100 -> 101 of round 4: fsn_clip_adam_step's found_inf). */
+#define FSN_ABI_VERSION 112
 int fsn_version(void);
 
 /* ---- STFT / iSTFT : audio_zen/acoustics/feature.py ------------------------------------- */
@@ -545,7 +552,8 @@ int fsn_debug_persist_stats(unsigned* launches, unsigned* waits, unsigned* unrep
 /* Test / measurement hook: the two-layer training entries (fsn_lstm2_forward_train / fsn_lstm2_backward) under
  * FSN_ARITH_F16 / _BF16 run the 16-bit arithmetic's own persistent kernels (lstm_group16_kernels.hip) where they
  * apply; on = 0 keeps the fp32-era group kernels under that arithmetic (A/B measurements), on = 2 only the round-3 form
- * of the weight-gradient products (operands converted on the fly), on = 1 restores the default. */
+ * of the weight-gradient products (operands converted on the fly), on = 3 layer 0's input-side products (dx, dW_ih0) from
+ * fp32 gate gradients as in round 5 (the BPTT launch then stores them), on = 1 restores the default. */
 int fsn_debug_g16_kernels(int on);
 /* 0: the 16-bit-operand weight-gradient products on 192 x 192 tiles also where the 192 x 384 eight-wave form applies (both
  * give bit-identical partial products; the split count differs).  A/B measurements and tests. */

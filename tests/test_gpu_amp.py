@@ -39,8 +39,9 @@ def fsn():
 
 class RoundedLinear(torch.autograd.Function):
     """y = r(x) r(w)^T with r = round to `dt`: forward and BOTH backward products take rounded operands, as the kernels'
-    matrix instructions do (dx = r(dy) r(w), dw = r(dy)^T r(x)); round_dx = False leaves dx's product exact (the
-    layer-0 input gradient is a plain fp32 GEMM on the HIP path)."""
+    matrix instructions do (dx = r(dy) r(w), dw = r(dy)^T r(x)); round_dx = False leaves dx's product exact (how the
+    layer-0 input gradient ran until round 5: a plain fp32 GEMM; since round 6 it is a 16-bit-operand product like the rest,
+    gemm_dx16_kernel - what autocast does to every matmul)."""
 
     @staticmethod
     def forward(ctx, x, w, dt, round_dx):
@@ -68,7 +69,7 @@ def emulated_lstm2(x, w, dt):
         c = x.new_zeros((N, H))
         outs = []
         for t in range(T):
-            gates = (RoundedLinear.apply(h_in[t], w_ih, dt, layer > 0) + RoundedLinear.apply(h, w_hh, dt, True)
+            gates = (RoundedLinear.apply(h_in[t], w_ih, dt, True) + RoundedLinear.apply(h, w_hh, dt, True)
                      + (b_ih + b_hh))
             i, f, g, o = gates.split(H, dim=1)
             c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
@@ -246,6 +247,85 @@ def test_amp_train_step_vs_the_reference(fsn, golden_dir, arith, name):
             assert np.abs(pv - z["p/" + k])[firm].max() <= 2.1e-3, k  # a sign flip of a firm gradient would be 2 lr
             moved += int((np.abs(pv - params[k].reshape(-1)[::s]) > 5e-4).sum())
     assert moved > 0
+
+
+@pytest.mark.parametrize("arith", ["f16", "bf16"])
+def test_saved_gates_in_16_bits_kernel_level(fsn, arith):
+    """FSN_ARITH_SAVES16 (include/fsn_hip.h; Model.train_saves = "16"): the activated gates BPTT re-reads are kept in the
+    arithmetic's 16-bit type inside the same save buffers.  The forward result is untouched (bit-equal); every gradient stays
+    within the distance the 16-bit OPERANDS already put between this arithmetic and fp32 (printed: deviation of both save
+    modes from the fp32 mode, and of the 16-bit saves from the fp32 saves)."""
+    from fullsubnet_amd.train import Lstm2Function
+    T, N, I, H = 6, 2048, 32, 384
+    g = torch.Generator().manual_seed(13)
+    k = 1.0 / np.sqrt(H)
+    x = torch.randn(T, N, I, generator=g)
+    shapes = ((4 * H, I), (4 * H, H), (4 * H,), (4 * H,), (4 * H, H), (4 * H, H), (4 * H,), (4 * H,))
+    w = [(torch.rand(s_, generator=g) * 2 - 1) * k * 2 for s_ in shapes]
+    dy = torch.randn(T, N, H, generator=g) * 64.0
+
+    def run(a):
+        xd = x.cuda().requires_grad_(True)
+        wd = [t.cuda().requires_grad_(True) for t in w]
+        y = Lstm2Function.apply(xd, *wd, a)
+        (y * dy.cuda()).sum().backward()
+        torch.cuda.synchronize()
+        return [y.detach().cpu(), xd.grad.cpu()] + [t.grad.cpu() for t in wd]
+
+    f32, s32, s16, again = run("f32"), run(arith), run(arith + "+s16"), run(arith + "+s16")
+    names = ["y", "dx", "dw_ih0", "dw_hh0", "db_ih0", "db_hh0", "dw_ih1", "dw_hh1", "db_ih1", "db_hh1"]
+    assert torch.equal(s32[0], s16[0])  # the forward pass computes the same numbers; only what it SAVES differs
+    worst = 0.0
+    for name, r, a, b, c in zip(names, f32, s32, s16, again):
+        assert torch.equal(b, c), name
+        scale = max(r.abs().max().item(), 1e-3)
+        d32, d16, dd = ((a - r).abs().max().item() / scale, (b - r).abs().max().item() / scale, (b - a).abs().max().item() / scale)
+        print(f"{arith} {name:7s}: from the fp32 mode: fp32 saves {d32:.2e}, 16-bit saves {d16:.2e}; between the two {dd:.2e}")
+        if name != "y":
+            worst = max(worst, dd)
+            # measured r06: f16 <= 5e-4, bf16 <= 4e-3 of each tensor's largest element (a gate rounded to 11 / 8 bits)
+            assert dd <= (1.5e-3 if arith == "f16" else 1.2e-2), (name, dd)
+    assert worst > 0, "the 16-bit saves are indistinguishable from the fp32 saves: is the flag reaching the kernels?"
+
+
+@pytest.mark.parametrize("saves", ["32", "16"])
+def test_fp16_amp_step_vs_the_references_own_fp16_autocast_step(fsn, golden_dir, saves):
+    """The reference-held arbiter of the shipped use_amp = true arithmetic (round 6): tests/golden/fsn_train_c3_f16.npz is ONE
+    step of the reference itself under torch.autocast("cpu", float16) + GradScaler (trainer.py:56-69; ATen's own LSTM cell,
+    oneDNN has no fp16 LSTM primitive), fsn_train_c3.npz the same step in fp32.  Held here: this library's autocast step -
+    with fp32 saves and with the gates saved in 16 bits (Model.train_saves) - is CLOSER to the reference's fp32 step than the
+    reference's own fp16-autocast step is (loss, total gradient norm, every parameter tensor's gradient norm), and within
+    that distance of the fp16-autocast step itself."""
+    from fullsubnet_amd.train import train_step
+    z32 = np.load(os.path.join(golden_dir, "fsn_train_c3.npz"))
+    z16 = np.load(os.path.join(golden_dir, "fsn_train_c3_f16.npz"))
+    meta = ast.literal_eval(str(z16["meta"]))
+    assert meta["autocast"] == "torch.float16" and float(z16["scale_before"]) == 65536.0 == float(z16["scale_after"])
+    ref_loss = abs(float(z16["loss"]) - float(z32["loss"])) / float(z32["loss"])
+    ref_total = abs(float(z16["total_norm"]) - float(z32["total_norm"])) / float(z32["total_norm"])
+    keys = [k[6:] for k in z32.files if k.startswith("gnorm/")]
+    ref_worst = max(abs(float(z16["gnorm/" + k]) - float(z32["gnorm/" + k])) / float(z32["gnorm/" + k]) for k in keys)
+    model, params = build(fsn, "f16", seed=meta["seed_w"], groups=meta["groups"])
+    model.train_saves = saves
+    noisy = torch.from_numpy(O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_noisy"])).cuda()
+    clean = torch.from_numpy((meta["clean_gain"] * O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_clean"]))
+                             .astype(np.float32)).cuda()
+    opt = fsn.ClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    scaler = torch.amp.GradScaler("cuda")
+    loss = train_step(model, opt, noisy, clean, scaler=scaler)
+    out = {}
+    for tag, z in (("fp32 step", z32), ("fp16-autocast step", z16)):
+        rel_total, worst_norm, worst_elem, one_minus_cos = margins(model, opt, z, meta, params)
+        out[tag] = (abs(loss.item() - float(z["loss"])) / float(z["loss"]), rel_total, worst_norm[1])
+        print(f"saves {saves}: vs the reference's {tag}: loss {out[tag][0]:.2e}, total norm {rel_total:.2e}, worst tensor norm "
+              f"{worst_norm[1]:.2e} ({worst_norm[0]}), worst sampled element {worst_elem[1]:.2e}, 1 - cos {one_minus_cos:.2e}")
+    print(f"the reference's own fp16-autocast step vs its fp32 step: loss {ref_loss:.2e}, total norm {ref_total:.2e}, worst tensor "
+          f"norm {ref_worst:.2e}")
+    assert scaler.get_scale() == 65536.0 and opt.skipped_steps() == 0
+    a = out["fp32 step"]
+    assert a[1] <= ref_total and a[2] <= ref_worst, (a, ref_total, ref_worst)          # closer to fp32 than the reference's fp16 step
+    b = out["fp16-autocast step"]
+    assert b[1] <= 2 * ref_total and b[2] <= 2 * ref_worst, (b, ref_total, ref_worst)  # and within that distance of it
 
 
 def test_gradscaler_skips_an_overflowing_step_and_backs_off(fsn):

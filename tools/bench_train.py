@@ -1,5 +1,5 @@
 """Time one training step (BASELINE config 3 per-rank shape: 16 x 3.072 s) on one MI355X.
-python tools/bench_train.py [batch] [f32|f16|bf16] [g16=0] [overlap=0] [norm=cumulative]   (f16 / bf16: autocast arithmetic +
+python tools/bench_train.py [batch] [f32|f16|bf16] [g16=0] [overlap=0] [norm=cumulative] [saves=32]   (f16 / bf16: autocast arithmetic +
 GradScaler; norm=cumulative: the shipped train_cumulativeLaplaceNorm.toml's norm)"""
 import os
 import sys
@@ -22,10 +22,15 @@ model = fullsubnet_amd.Model(num_freqs=257, look_ahead=2, sequence_model="LSTM",
 model.load_state_dict({k: torch.from_numpy(v) for k, v in make_params(seed=3).items()})
 model = model.cuda().train()
 model.train_arithmetic = ARITH
+for a in sys.argv:
+    if a.startswith("saves="):  # saves=32: the gates BPTT re-reads kept in fp32 (default under f16 / bf16: "16", FSN_ARITH_SAVES16)
+        model.train_saves = a[6:]
 if "g16=0" in sys.argv:  # A/B: the fp32-era group kernels under the 16-bit arithmetic (lstm_group16_kernels.hip off)
     fullsubnet_amd._lib.lib().fsn_debug_g16_kernels(0)
 if "g16=2" in sys.argv:  # A/B: weight-gradient products converting their operands on the fly (gemm_tn16_kernel)
     fullsubnet_amd._lib.lib().fsn_debug_g16_kernels(2)
+if "g16=3" in sys.argv:  # A/B: dx / dW_ih0 from fp32 gate gradients (the BPTT launch stores them), round 5's form
+    fullsubnet_amd._lib.lib().fsn_debug_g16_kernels(3)
 if "overlap=0" in sys.argv:  # A/B: the sub-band weight-gradient products in line instead of beside the full-band backward
     import fullsubnet_amd.train as _tr
     _tr.OVERLAP_WEIGHT_PRODUCTS = False
