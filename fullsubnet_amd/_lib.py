@@ -215,7 +215,6 @@ SIGNATURES = {
     "fsn_stream_timeout_policy": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "fsn_debug_g16_kernels": (_c.c_int, [_c.c_int]),
     "fsn_debug_tn16h_wide": (_c.c_int, [_c.c_int]),
-    "fsn_debug_group_duo": (_c.c_int, [_c.c_int]),
     "fsn_set_persistent_mode": (_c.c_int, [_c.c_int]),
     "fsn_set_persistent_timeout_ms": (_c.c_int, [_c.c_int]),
     "fsn_stream_status": (_c.c_int, [_c.c_void_p, _c.c_int, _c.POINTER(_c.c_uint), _c.POINTER(_c.c_uint)]),

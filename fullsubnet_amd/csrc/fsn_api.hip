@@ -436,10 +436,6 @@ extern "C" int fsn_debug_tn16h_wide(int on) {
     fsn_tn16h_wide(on);
     return FSN_OK;
 }
-extern "C" int fsn_debug_group_duo(int on) {
-    fsn_lstm2_group_duo(on);
-    return FSN_OK;
-}
 extern "C" int fsn_debug_g16_kernels(int on) {
     g_g16_off.store(on == 0 ? 1 : 0, std::memory_order_relaxed);
     g_tn16h_off.store(on == 2 ? 1 : 0, std::memory_order_relaxed);

@@ -380,7 +380,6 @@ struct FsnGroupStack {
     float *hseq0, *hseq1;
     int N;
 };
-void fsn_lstm2_group_duo(int on);  // lstm_group_kernels.hip: 0 = the two-workgroups-per-CU form also where lstm2_duo_kernel applies
 int fsn_lstm2_group_multi_cap();
 int fsn_launch_lstm2_group_multi(int n, const FsnGroupStack* st, unsigned* flags, int Tp, int H, hipStream_t s);
 int fsn_launch_lstm2_group_train(const float* x, long x_ld, int x_cols, int Nrows, const float* wih0_p, const float* whh0_p,

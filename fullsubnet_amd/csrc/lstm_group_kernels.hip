@@ -22,14 +22,11 @@
 // The output layer of step s is computed by layer-1 member m for rows 8 m .. 8 m + 7 when h1_s has been gathered for the
 // next step anyway.  Every spin is bounded: on a timeout the workgroup raises `status` and all waits fall through (the
 // results are then garbage, never a hang); flags and status are zeroed by the host before every launch.
+// (Round 6: both layers of a member as ONE instruction stream per CU - lstm2_duo_kernel, commit 1df4f24 - was built, is
+// bit-identical and SLOWER: 73 us per step against 57; its floor with every load, poll and non-linearity removed is 53 us, one
+// wave per SIMD hides none of its own latencies.  profiles/r06_duo_probe.md.)
 #include "fsn_common.h"
 
-#ifndef FSN_DUO_ABL
-#define FSN_DUO_ABL 0  // diagnosis builds (tools/build_variant.py): 2 no polls, 8 no non-linearities, 32 tiles not loaded, 128 weights not loaded
-#endif
-#ifndef FSN_DUO_QD
-#define FSN_DUO_QD 4
-#endif
 #ifndef FSN_GRP_AD
 #define FSN_GRP_AD 6        // A fragments in flight (probe, 32 clusters: 4 -> 11.34 ms, 6 -> 11.2, 8 -> 11.4 with spills)
 #endif
@@ -585,333 +582,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void 
     else group_body<1, ABL, true, 1, false, FSN_ARITH_F32, true>(a, cluster, -1, member, bsh, bias_sh);
 }
 
-
-// ---- both layers of a member as ONE instruction stream (round 6) ---------------------------------------------------------
-// lstm2_group_kernel places a layer-0 and a layer-1 workgroup on every CU so that one's hand-off waits, barriers and cell
-// update run under the other's MFMAs - and pays for it in the matrix pipe: two MFMA-streaming waves per SIMD lose ~9 % of it
-// (profiles/r04_group_phase_probe.txt: 51.9 us per step with EVERYTHING else removed against 47.4 us of matrix work; 58 us
-// shipped).  Here a CU holds ONE workgroup of four waves that owns member m of a cluster for BOTH layers and walks, per
-// iteration t,
-//     S1  h0_{t-1} -> LDS tile          (prefetched into registers under the previous iteration's last K loop)
-//     K1  gates0_t  = b0 + x_t W_ih0 + h0_{t-1} W_hh0          K2  gates1_{t-1} = b1 + h0_{t-1} W_ih1   (same tile)
-//     E0  cell update 0, h0_t -> exchange buffer, flag
-//     S2  h1_{t-2} -> LDS tile          (prefetched under K2)
-//     K3  gates1_{t-1} += h1_{t-2} W_hh1        FC  output layer of step t - 2 from the tile
-//     E1  cell update 1, h1_{t-1} -> exchange buffer, flag
-// in program order: every hand-off a step needs was published a whole K loop (>= 15 us) earlier, so no wait is exposed and
-// the matrix pipe sees one stream per SIMD.  Inside a K loop nothing synchronises: wave g forms gate g of the member's 48
-// units for all 64 rows (12 accumulator tiles per layer), streams its own weight fragments L2 -> registers through a ring
-// that keeps turning through the epilogues, and reads the shared activation tile from LDS; the four gates of a unit meet
-// once per step through LDS (aliasing the tile), after which a thread owns the same (rows, unit) items as in
-// lstm2_group_kernel - same operands, same order of every sum: BIT-identical results, same exchange buffers and flags.
-constexpr int DUO_LD = GH + 4;                       // floats per row of the staged [64][H] tile (conflict-free 16-byte reads)
-constexpr int DUO_TILE_FLOATS = GROWS * DUO_LD;      // 99 328 bytes; the gate exchange [4][4][3][64] x 16 B = 48 KB aliases it
-constexpr int DUO_XLD = 36;                          // layer-0 input tile [64][32 (+ 4)]
-constexpr int DUO_QD = FSN_DUO_QD;                         // K chunks of weight fragments in flight per wave
-constexpr size_t DUO_LDS_BYTES = (size_t)(DUO_TILE_FLOATS + GROWS * DUO_XLD) * 4;
-
-template <int ABL, int NCL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm2_duo_kernel(const GrpArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float duo_lds[];
-    float* const tile = duo_lds;
-    float* const xs = duo_lds + DUO_TILE_FLOATS;
-    f32x4* const gsh = reinterpret_cast<f32x4*>(duo_lds);  // [gate 4][row tile 4][unit tile 3][lane 64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 15, lq = lane >> 4;
-    const int Tp = a.Tp;
-    const FsnSbInput& x = a.xin;
-    const int slots = (int)gridDim.x / GM, bid = (int)blockIdx.x;
-    int slot, member;
-    if (slots % 8 == 0) {  // the eight members of a cluster on one XCD (block b runs on XCD b % 8, observed; speed only)
-        const int xcd = bid & 7, j = bid >> 3;
-        slot = xcd * (slots / 8) + j / GM;
-        member = j % GM;
-    } else {
-        slot = bid / GM;
-        member = bid % GM;
-    }
-    auto slot0 = [&](int t) { return (unsigned)((t % GD0) * GROWS * GH * 4); };
-    auto slot1 = [&](int t) { return (unsigned)((t & 1) * GROWS * GH * 4); };
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wbase), 0, 0x7fffffff, 0x00020000);
-    // this wave's weight stream: fragment (unit tile u, chunk k) of gate `wave` of a packed matrix at element offset o with
-    // cs chunks per column tile
-    auto wload = [&](unsigned o, unsigned cs, int u, int k) {
-        if constexpr ((ABL & 128) != 0) return f32x4{0.01f * (float)u, 0.02f, -0.01f * (float)(k & 3), 0.005f};
-        else return fsn_load_wfrag<FSN_ARITH_F32>(wrsrc, (unsigned)lane, o + ((unsigned)(wave * GKC + member * GU + u) * cs + (unsigned)k) * 256u);
-    };
-    float b0[GU], b1[GU];
-#pragma unroll
-    for (int u = 0; u < GU; ++u) {
-        b0[u] = a.xin.bias[(wave * GKC + member * GU + u) * 16 + lr];
-        b1[u] = a.bias1[(wave * GKC + member * GU + u) * 16 + lr];
-    }
-    // output layer: thread (d = tid >> 4, p = tid & 15) owns 24 of the 384 terms of dot product d (row d >> 1 of this member's
-    // eight rows, output d & 1): lstm2_group_kernel's split, read from the staged tile
-    const int fd = tid >> 4, fp = tid & 15, frow = member * 8 + (fd >> 1), fcc = fd & 1;
-
-    struct Cl {
-        int cluster, row_l, xb, xf;
-        bool row_ok;
-        long ng;
-        unsigned *fl0, *fl1;
-        __amdgpu_buffer_rsrc_t r0, r1;
-        float *hx0, *hx1;
-        float c0[GU][4], c1[GU][4];
-        f32x4 pf[24];  // a tile on its way: requested under a K loop, written to LDS behind it
-    };
-    auto init = [&](Cl& k, int cluster) {
-        k.cluster = cluster;
-        k.hx0 = a.hx0 + (size_t)cluster * GD0 * GROWS * GH;
-        k.hx1 = a.hx1 + (size_t)cluster * 2 * GROWS * GH;
-        k.fl0 = a.flags + ((size_t)cluster * 2 + 0) * GFS;
-        k.fl1 = a.flags + ((size_t)cluster * 2 + 1) * GFS;
-        k.r0 = __builtin_amdgcn_make_buffer_rsrc(k.hx0, 0, 0x7fffffff, 0x00020000);
-        k.r1 = __builtin_amdgcn_make_buffer_rsrc(k.hx1, 0, 0x7fffffff, 0x00020000);
-        // the gather's row of this thread: row tid >> 2, eight columns (tid & 3) * 8 ..
-        k.row_l = cluster * GROWS + (tid >> 2);
-        k.row_ok = k.row_l < x.N;
-        k.ng = k.row_l + x.row0;
-        k.xb = k.row_ok ? (int)(k.ng / x.F) : 0;
-        k.xf = k.row_ok ? (int)(k.ng % x.F) : 0;
-#pragma unroll
-        for (int u = 0; u < GU; ++u)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) k.c0[u][i] = 0.f, k.c1[u][i] = 0.f;
-    };
-    // bounded wait for the eight member flags of a layer, one wave polls for all four
-    auto wait = [&](unsigned* flags8, unsigned epoch) {
-        if (wave == 0 && !(ABL & 2)) (void)grp_poll(flags8, epoch, a.status, a.spin_ticks);
-        __syncthreads();
-    };
-    // request the cluster's [64][H] tile at byte offset `off` of an exchange buffer (write-through data of other CUs: sc1)
-    auto tile_request = [&](Cl& k, const __amdgpu_buffer_rsrc_t r, unsigned off) {
-#pragma unroll
-        for (int i = 0; i < 24; ++i) {
-            if constexpr ((ABL & 32) != 0) k.pf[i] = f32x4{0.1f, -0.1f, 0.05f * (float)i, 0.f};
-            else k.pf[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(tid + 256 * i) * 16u, off, 16));
-        }
-    };
-    auto tile_land = [&](Cl& k) {
-#pragma unroll
-        for (int i = 0; i < 24; ++i) {
-            const int q = tid + 256 * i, row = q / 96, c4 = q % 96;
-            *reinterpret_cast<f32x4*>(tile + row * DUO_LD + c4 * 4) = k.pf[i];
-        }
-    };
-    // acc[u][r] += A(row tile r of `src`, chunks [k_from, k_to) of n; row stride ld floats) x this wave's fragments of matrix (o, cs).
-    // The ring holds chunks k_from .. k_from + QD - 1 on entry (k_from a multiple of QD) and the next QD on exit; the A
-    // fragments of chunk k + 1 are read from LDS before chunk k's matrix work (one wave per SIMD: nothing else hides them).
-    auto kloop = [&](f32x4 (&acc)[GU][4], f32x4 (&ring)[DUO_QD][GU], const float* src, int ld, unsigned o, unsigned cs, int n, int k_from,
-                     int k_to) {
-        f32x4 av[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) av[r] = *reinterpret_cast<const f32x4*>(src + (16 * r + lr) * ld + 16 * k_from + 4 * lq);
-#pragma unroll 1
-        for (int k0 = k_from; k0 < k_to; k0 += DUO_QD) {
-#pragma unroll
-            for (int d = 0; d < DUO_QD; ++d) {
-                const int k = k0 + d;
-                f32x4 bw[GU], an[4];
-#pragma unroll
-                for (int u = 0; u < GU; ++u) bw[u] = ring[d][u];
-                __builtin_amdgcn_sched_barrier(0);  // the refill and the next chunk's A fragments go out before this chunk's matrix work
-                {
-                    const int kn = k + DUO_QD < n ? k + DUO_QD : n - 1;
-#pragma unroll
-                    for (int u = 0; u < GU; ++u) ring[d][u] = wload(o, cs, u, kn);
-                    const int ka = k + 1 < n ? k + 1 : n - 1;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) an[r] = *reinterpret_cast<const f32x4*>(src + (16 * r + lr) * ld + 16 * ka + 4 * lq);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)  // (an accumulator is touched again twelve instructions later; k order per accumulator as in lstm2_group_kernel)
-#pragma unroll
-                    for (int u = 0; u < GU; ++u)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[u][r] = mfma16(av[r][j], bw[u][j], acc[u][r]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) av[r] = an[r];
-            }
-        }
-    };
-    auto ring_start = [&](f32x4 (&ring)[DUO_QD][GU], unsigned o, unsigned cs, int n) {
-#pragma unroll
-        for (int d = 0; d < DUO_QD; ++d)
-#pragma unroll
-            for (int u = 0; u < GU; ++u) ring[d][u] = wload(o, cs, u, d < n ? d : n - 1);
-    };
-    // the four gates of a unit meet: wave g parks gate g of all four row tiles, wave w takes the four gates of row tile w -
-    // a thread then owns rows 16 w + 4 lq + i of unit 16 u + lr, exactly lstm2_group_kernel's items.  Cell update, the h
-    // slice to the exchange buffer (write-through), the flag.
-    auto epilogue = [&](f32x4 (&acc)[GU][4], float (&c)[GU][4], float* hdst) {
-        __syncthreads();  // every wave has left the tile
-#pragma unroll
-        for (int u = 0; u < GU; ++u)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gsh[((wave * 4 + r) * GU + u) * 64 + lane] = acc[u][r];
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            f32x4 pre[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) pre[g] = gsh[((g * 4 + wave) * GU + u) * 64 + lane];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float ig, fg, gg, og;
-                if (ABL & 8) {
-                    ig = pre[0][i], fg = pre[1][i], gg = pre[2][i], og = pre[3][i];
-                } else {
-                    ig = sigmoid_fast(pre[0][i]), fg = sigmoid_fast(pre[1][i]);
-                    gg = tanh_fast(pre[2][i]), og = sigmoid_fast(pre[3][i]);
-                }
-                const float cn = fg * c[u][i] + ig * gg;
-                c[u][i] = cn;
-                float* hp = hdst + (size_t)(wave * 16 + 4 * lq + i) * GH + (member * GU + u) * 16 + lr;
-                const float hv = (ABL & 8) ? og * cn : og * tanh_fast(cn);
-                if (ABL & 4) *hp = hv;
-                else store_sc1(hp, hv);
-            }
-        }
-        __syncthreads();  // closes the reads of the gate exchange (the tile lands there next)
-    };
-    // ... the flag, later: the h slice was stored (write-through) a few K chunks ago - by now the drain costs nothing - every wave
-    // drains, one lane bumps the flag
-    auto publish = [&](unsigned* flag, unsigned epoch) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-
-    auto iteration = [&](int t, Cl& k) {
-        f32x4 acc0[GU][4], acc1[GU][4];
-        f32x4 ring_a[DUO_QD][GU], ring_b[DUO_QD][GU];  // two weight rings: the next product's first turn travels under the current one
-        f32x4 xw[2][GU];
-        const bool l0 = t < Tp, l1 = t >= 1 && t <= Tp;  // layer 0 runs step t, layer 1 step t - 1
-        // ---- the layer-0 input of frame t (fullsubnet/model.py:98-111: reflected neighbours, full-band output, norm) -> xs
-        if (l0) {
-            float raw[8];
-            const float den = k.row_ok ? x.den[x.den_mode ? (long)t * x.den_stride + k.ng : (long)k.xb] : 1.f;
-            const long fo = ((long)k.xb * x.Tp + t) * x.FP;
-            const int c0 = (tid & 3) * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int cc = c0 + e;
-                int jj = k.xf + cc - x.nb;
-                jj = jj < 0 ? -jj : jj;
-                jj = jj >= x.F ? 2 * (x.F - 1) - jj : jj;
-                const bool ok = k.row_ok && cc <= 2 * x.nb + 1;
-                const float* src = cc <= 2 * x.nb ? x.mag + fo + jj : x.fb_out + fo + k.xf;
-                raw[e] = *(ok ? src : x.mag);
-            }
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int u = 0; u < GU; ++u) xw[c][u] = wload(a.o_wih0, 2u, u, c);
-            if (t >= 1) ring_start(ring_a, a.o_whh0, (unsigned)GKC, GKC);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int cc = c0 + e;
-                xs[(tid >> 2) * DUO_XLD + cc] = (k.row_ok && cc <= 2 * x.nb + 1) ? raw[e] / den : 0.f;
-            }
-        }
-        // ---- S1: h0_{t-1}, requested in the middle of the previous iteration's K3 (the compiler's own counted wait: loads return
-        // in order and the K loop behind the request has consumed younger ones)
-        if (t >= 1 && t <= Tp) tile_land(k);
-        __syncthreads();  // xs and the tile are in place
-        if (l1) ring_start(ring_b, a.o_wih1, (unsigned)GKC, GKC);  // K2's first turn travels under K1
-        // ---- K1: layer 0, step t; a third of the way in, the flag of h1_{t-2} (stored by the previous iteration's E1)
-        if (l0) {
-#pragma unroll
-            for (int u = 0; u < GU; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc0[u][r] = f32x4{b0[u], b0[u], b0[u], b0[u]};
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                f32x4 av[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) av[r] = *reinterpret_cast<const f32x4*>(xs + (16 * r + lr) * DUO_XLD + 16 * c + 4 * lq);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int u = 0; u < GU; ++u)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc0[u][r] = mfma16(av[r][j], xw[c][u][j], acc0[u][r]);
-            }
-            if (t >= 1) kloop(acc0, ring_a, tile, DUO_LD, a.o_whh0, (unsigned)GKC, GKC, 0, 8);
-        }
-        if (t >= 2 && t <= Tp + 1) publish(k.fl1 + member, (unsigned)(t - 1));  // h1_{t-2}
-        if (l0 && t >= 1) kloop(acc0, ring_a, tile, DUO_LD, a.o_whh0, (unsigned)GKC, GKC, 8, GKC);
-        // ---- S2's request: h1_{t-2}, whose flags went out a K loop's two thirds ago; lands under K2
-        if (t >= 2) {
-            wait(k.fl1, (unsigned)(t - 1));
-            tile_request(k, k.r1, slot1(t - 2));
-        }
-        if (t >= 2 && t <= Tp) ring_start(ring_a, a.o_whh1, (unsigned)GKC, GKC);  // K3's first turn travels under K2, E0 and S2
-        // ---- K2: layer 1, step t - 1, input half (h0_{t-1}: the same tile)
-        if (l1) {
-#pragma unroll
-            for (int u = 0; u < GU; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc1[u][r] = f32x4{b1[u], b1[u], b1[u], b1[u]};
-            kloop(acc1, ring_b, tile, DUO_LD, a.o_wih1, (unsigned)GKC, GKC, 0, GKC);
-        }
-        // ---- E0: cell update, h0_t on its way (its flag goes out a third into K3)
-        if (l0) epilogue(acc0, k.c0, reinterpret_cast<float*>(reinterpret_cast<char*>(k.hx0) + slot0(t)));
-        else __syncthreads();
-        // ---- S2
-        if (t >= 2) tile_land(k);
-        __syncthreads();
-        // ---- K3: layer 1, step t - 1, recurrent half (h1_{t-2}); inside it h0_t's flag and, later, the request for the next S1
-        if (t >= 2 && t <= Tp) kloop(acc1, ring_a, tile, DUO_LD, a.o_whh1, (unsigned)GKC, GKC, 0, 8);
-        if (l0) publish(k.fl0 + member, (unsigned)t + 1);
-        if (t >= 2 && t <= Tp) kloop(acc1, ring_a, tile, DUO_LD, a.o_whh1, (unsigned)GKC, GKC, 8, 16);
-        if (t + 1 <= Tp) {
-            wait(k.fl0, (unsigned)t + 1);
-            tile_request(k, k.r0, slot0(t));
-        }
-        if (t >= 2 && t <= Tp) kloop(acc1, ring_a, tile, DUO_LD, a.o_whh1, (unsigned)GKC, GKC, 16, GKC);
-        // ---- output layer of step t - 2 from the tile
-        if (t >= 2 && !(ABL & 16)) {
-            const float* hrow = tile + frow * DUO_LD + fp * 24;
-            f32x4 hv[6], fw[6];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const int kk = fp * 24 + 4 * q;
-                hv[q] = *reinterpret_cast<const f32x4*>(hrow + 4 * q);
-                fw[q] = *reinterpret_cast<const f32x4*>(a.fc.w_p + (((kk >> 4) * 64) + ((kk & 15) >> 2) * 16 + fcc) * 4);
-            }
-            float o = 0.f;
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o = fmaf(hv[q][j], fw[q][j], o);
-            o += __shfl_xor(o, 1, 64);
-            o += __shfl_xor(o, 2, 64);
-            o += __shfl_xor(o, 4, 64);
-            o += __shfl_xor(o, 8, 64);
-            const long n = (long)k.cluster * GROWS + frow;
-            const int so = t - 2;
-            if (fp == 0 && so >= a.fc.la && n < a.fc.N) {
-                const long ngl = n + a.fc.row0;
-                const int b = (int)(ngl / a.fc.F), f = (int)(ngl % a.fc.F);
-                (fcc ? a.fc.crm_i : a.fc.crm_r)[((long)b * a.fc.T + (so - a.fc.la)) * a.fc.FP + f] = o + a.fc.bias[fcc];
-            }
-        }
-        // ---- E1: cell update, h1_{t-1} on its way (its flag goes out a third into the next iteration's K1)
-        if (l1) epilogue(acc1, k.c1, reinterpret_cast<float*>(reinterpret_cast<char*>(k.hx1) + slot1(t - 1)));
-        else __syncthreads();
-    };
-    Cl ka, kb;
-    const int cluster_b = (NCL > 1 && slot + slots < a.nclusters) ? slot + slots : -1;
-    init(ka, slot);
-    if (NCL > 1 && cluster_b >= 0) init(kb, cluster_b);
-    for (int t = 0; t <= Tp + 1; ++t) {  // (t = Tp: layer 1's last step; t = Tp + 1: the last step's output layer)
-        iteration(t, ka);
-        if (NCL > 1 && cluster_b >= 0) iteration(t, kb);
-    }
-}
-
 }  // namespace
 
 size_t fsn_lstm2_group_exchange_floats(int clusters) { return (size_t)clusters * (GD0 + 2) * GROWS * GH; }
@@ -950,24 +620,6 @@ int fsn_lstm2_group_clusters(int tiles) {
     return c < cap ? c : cap;
 }
 
-// lstm2_duo_kernel: usable when one workgroup of it per CU is resident (100 KB of LDS, one wave per SIMD)
-static int g_duo = 1;  // fsn_lstm2_group_duo(0): lstm2_group_kernel (two workgroups per CU), for A/B measurements and tests
-void fsn_lstm2_group_duo(int on) { g_duo = on; }
-static bool duo_fits() {
-    static int ok = -1;
-    if (ok < 0) {
-        ok = 0;
-        int cus = 0, dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-            hipFuncSetAttribute((const void*)lstm2_duo_kernel<FSN_DUO_ABL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DUO_LDS_BYTES) == hipSuccess &&
-            hipFuncSetAttribute((const void*)lstm2_duo_kernel<FSN_DUO_ABL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DUO_LDS_BYTES) == hipSuccess &&
-            fsn_grid_fits((const void*)lstm2_duo_kernel<FSN_DUO_ABL, 1>, 256, (unsigned)cus) &&
-            fsn_grid_fits((const void*)lstm2_duo_kernel<FSN_DUO_ABL, 2>, 256, (unsigned)cus))
-            ok = 1;
-        (void)hipGetLastError();
-    }
-    return ok == 1;
-}
 int fsn_launch_lstm2_group(const FsnSbInput* xin, const float* whh0_p, const float* wih1_p, const float* whh1_p,
                            const float* bias1, float* exchange, unsigned* flags, const FsnRecFc* fc, int Tp, int clusters,
                            int H, hipStream_t s) {
@@ -1005,18 +657,6 @@ int fsn_launch_lstm2_group(const FsnSbInput* xin, const float* whh0_p, const flo
     if (cap == 0 || clusters > 2 * cap) {
         fsn_set_error("lstm2_group: %d clusters cannot be co-resident on this device (persistent kernels off, or occupancy)", clusters);
         return FSN_ERR_ARG;
-    }
-    if (g_duo && duo_fits()) {
-        // one workgroup per CU owning a member for both layers (lstm2_duo_kernel): same buffers, flags and results
-        const dim3 grid((unsigned)slots * GM), block(256);
-        if (clusters > slots) {
-            fsn_persist_admit((const void*)lstm2_duo_kernel<FSN_DUO_ABL, 2>, 256, grid.x);
-            hipLaunchKernelGGL((lstm2_duo_kernel<FSN_DUO_ABL, 2>), grid, block, DUO_LDS_BYTES, s, a);
-        } else {
-            fsn_persist_admit((const void*)lstm2_duo_kernel<FSN_DUO_ABL, 1>, 256, grid.x);
-            hipLaunchKernelGGL((lstm2_duo_kernel<FSN_DUO_ABL, 1>), grid, block, DUO_LDS_BYTES, s, a);
-        }
-        return fsn_check_launch("lstm2_duo_kernel");
     }
     if (clusters > slots) FSN_PERSIST_LAUNCH((lstm2_group_kernel<0, false, 2>), dim3((unsigned)slots * GM * 2), dim3(256), s, a);
     else FSN_PERSIST_LAUNCH((lstm2_group_kernel<0, false, 1>), dim3((unsigned)slots * GM * 2), dim3(256), s, a);

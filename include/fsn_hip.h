@@ -558,11 +558,6 @@ int fsn_debug_g16_kernels(int on);
 /* 0: the 16-bit-operand weight-gradient products on 192 x 192 tiles also where the 192 x 384 eight-wave form applies (both
  * give bit-identical partial products; the split count differs).  A/B measurements and tests. */
 int fsn_debug_tn16h_wide(int on);
-/* Test / measurement hook (round 6): the sub-band model's few-rows regime (6 - 16 utterances per call: a rank's share of a
- * strong-scaled batch) runs on lstm2_duo_kernel - one workgroup per CU owning a cluster member for BOTH layers, one
- * matrix-instruction stream per SIMD - where it is resident; on = 0 keeps lstm2_group_kernel (a layer-0 and a layer-1
- * workgroup per CU), the same buffers, flags and bit-identical results; on = 1 restores the default. */
-int fsn_debug_group_duo(int on);
 /* Test hooks that need no device.  fsn_debug_persist_set_fits: 1 when the gate would let n persistent launches with the
  * given chip fractions (grid / (occ x CUs)) and occupancies run side by side, 0 when the newest has to wait.
  * fsn_debug_tn_plan: the K splits a weight-gradient product [M x Nc], K rows, would take (*splits) and the bound the
