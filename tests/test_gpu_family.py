@@ -567,6 +567,58 @@ def test_fullsubnet_constructor_variants_vs_reference(fsn, golden_dir, name):
     assert np.abs(crm - z["crm"]).max() <= 1e-4  # measured 1.0e-5 .. 2.9e-5
 
 
+@pytest.mark.parametrize("name", ["fast_train_b3", "fullband_train_b3"])
+def test_sibling_training_step_vs_the_reference(fsn, golden_dir, name):
+    """ONE training step of the two sibling recipes that ship training TOMLs (fast_fullsubnet/train_shrinkSize2.toml:69-79 +
+    fast_fullsubnet/trainer.py:33-76; fullband_baseline/train.toml:70-78 + its trainer.py:32-71) against the REFERENCE's own
+    step (tests/golden/make_golden_family_train.py, fp32): loss, what clip_grad_norm_ returns, every parameter tensor's clipped
+    gradient (norm and strided samples) and the Adam-updated parameters.  Here the LSTM / Linear blocks run on the library's
+    training entries and the glue between them is autograd-tracked tensor algebra.  Fast FullSubNet's mel
+    filterbank is the restated torchaudio one on both sides (parity unpinned at that boundary only)."""
+    from oracle import fullsubnet_oracle as O
+    from fullsubnet_amd.train import train_step
+    z, meta = load(golden_dir, name)
+    if meta["model"] == "fast_fullsubnet":
+        from fullsubnet_amd.fast_fullsubnet import Model
+        params = MF.make_fast_params(seed=meta["seed_w"], gain=meta["gain"])
+        m = Model(**FAST_KW)
+        sd = {k: torch.from_numpy(v) for k, v in params.items()}
+        sd["mel_scale.fb"] = m.mel_scale.fb.clone()
+    else:
+        from fullsubnet_amd.fullband_baseline import Model
+        params = MF.make_fullband_params(seed=meta["seed_w"], gain=meta["gain"], out_gain=meta["out_gain"])
+        m = Model(num_freqs=257, hidden_size=512, sequence_model="LSTM", output_activate_function=False, look_ahead=2,
+                  norm_type="offline_laplace_norm", weight_init=False)
+        sd = {k: torch.from_numpy(v) for k, v in params.items()}
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    noisy = torch.from_numpy(O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_noisy"])).cuda()
+    clean = torch.from_numpy((meta["clean_gain"] * O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_clean"]))
+                             .astype(np.float32)).cuda()
+    opt = fsn.ClipAdam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    loss = train_step(m, opt, noisy, clean).item()
+    rel_loss = abs(loss - float(z["loss"])) / float(z["loss"])
+    rel_total = abs(float(opt.total_norm) - float(z["total_norm"])) / float(z["total_norm"])
+    s = meta["sample"]
+    worst_norm, worst_elem, moved = ("", 0.0), ("", 0.0), 0
+    for k, p in m.named_parameters():
+        gn = float(z["gnorm/" + k])
+        worst_norm = max(worst_norm, (k, abs(float(p.grad.norm()) - gn) / (gn + 1e-30)), key=lambda kv: kv[1])
+        g = p.grad.detach().reshape(-1)[::s].cpu().numpy()
+        r = z["g/" + k]
+        worst_elem = max(worst_elem, (k, float(np.abs(g - r).max() / max(np.abs(r).max(), 1e-3 * gn, 1e-30))), key=lambda kv: kv[1])
+        pv = p.detach().reshape(-1)[::s].cpu().numpy()
+        firm = np.abs(r) > 1e-5
+        if firm.any():
+            assert np.abs(pv - z["p/" + k])[firm].max() <= 2.1e-3, k  # a sign flip of a firm gradient would be 2 lr
+            moved += int((np.abs(pv - params[k].reshape(-1)[::s]) > 5e-4).sum())
+    print(f"{name}: loss {rel_loss:.2e}, total norm {rel_total:.2e}, worst tensor norm {worst_norm[1]:.2e} ({worst_norm[0]}), "
+          f"worst sampled element {worst_elem[1]:.2e} of the tensor's max ({worst_elem[0]})")
+    # measured r06 (printed); bounds ~3x above
+    assert rel_loss <= 2e-6 and rel_total <= 5e-5 and worst_norm[1] <= 5e-4 and worst_elem[1] <= 2e-3
+    assert moved > 0
+
+
 def test_fullsubnet_gru_training_step_runs_and_learns(fsn):
     """The composed path under autograd: GRU forward-with-saves + BPTT through both blocks."""
     from oracle import fullsubnet_oracle as O
