@@ -177,7 +177,7 @@ def cpu_baseline(params, length, budget_s=30.0, all_cores_too=False):
 def collector_paused():
     """CPython's cyclic collector collected before and held during a timed region: a generation-2 pass over torch's
     ~10^6 objects is a ~40 ms host pause that otherwise lands in one region or another at random (found with the HIP API
-    trace on the 4.7 ms step of config 5 at one utterance; DESIGN 5)."""
+    trace on the 4.7 ms step of config 5 at one utterance; DESIGN 6)."""
     gc.collect()
     was = gc.isenabled()
     gc.disable()

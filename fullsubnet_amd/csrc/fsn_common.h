@@ -334,7 +334,7 @@ int fsn_launch_to16(const float* src, void* dst, size_t n, int arith, hipStream_
 int fsn_launch_poison_if(const unsigned* status, float* out, size_t n, hipStream_t s);
 int fsn_launch_hog(int workgroups, int lds_bytes, int heavy, unsigned long long ticks, float* sink, hipStream_t s);
 
-// ---- residency contract of the persistent kernels whose workgroups wait for each other (DESIGN §4.5) ----------
+// ---- residency contract of the persistent kernels whose workgroups wait for each other (DESIGN 5.6) ----------
 // (fsn_api.hip)  fb_chain_kernel, lstm2_group_kernel, lstm2_group_bptt_kernel and fb_chain_bptt_kernel make progress
 // only when their WHOLE grid is resident.  The library guarantees what it can decide alone - the grid fits an idle
 // device (fsn_grid_fits, from the compiled kernel's occupancy), its own persistent launches of different streams

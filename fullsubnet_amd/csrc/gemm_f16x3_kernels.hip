@@ -6,7 +6,7 @@
 // 269 fp32-equivalent TFLOP/s against 138 for the fp32 MFMA kernel, maximum error against an fp64 reference 6e-7
 // - smaller than a plain fp32 fma chain's 1.3e-6, because the 384-term sum sees 36 instead of 384 roundings.
 // It stays opt-in until it is decided whether "fp32 within 1e-4" (the north star) admits 16-bit matrix
-// instructions; DESIGN.md §10.  Same execution shape as gemm_kernel: one 4-wave workgroup per CU, persistent over an
+// instructions; profiles/HISTORY.md §8 (split precision).  Same execution shape as gemm_kernel: one 4-wave workgroup per CU, persistent over an
 // XCD-partitioned tile list, 4 x 8 wave tile, operands straight from global / L2, refills pinned behind the MFMAs.
 #include "fsn_common.h"
 

@@ -1,6 +1,6 @@
 """Accuracy of a split-precision (fp16 x 3 / bf16 x 3) replacement for the fp32 GEMMs of the path, emulated on
 the CPU: every matmul of the oracle is replaced by a_hi b_hi + a_hi b_lo + a_lo b_hi with 16-bit halves and fp32
-accumulation, and the compressed mask is compared with the reference's golden output.  Evidence for DESIGN §10;
+accumulation, and the compressed mask is compared with the reference's golden output.  Evidence for DESIGN 9 (split precision);
 not part of the product or of the test suite (pytest does not collect it).  Run from the repo root:
 python tests/experiments/emulate_f16x3.py"""
 import ast

@@ -1,4 +1,4 @@
-"""The residency contract of the persistent kernels (include/fsn_hip.h, DESIGN 4.5): fb_chain_kernel,
+"""The residency contract of the persistent kernels (include/fsn_hip.h, DESIGN 5.6): fb_chain_kernel,
 lstm2_group_kernel, lstm2_group_bptt_kernel and fb_chain_bptt_kernel need their whole grid resident, and RCCL's
 kernels (the all-gather of a sharded batch, DDP's bucketed all-reduce during backward - base_trainer.py:32,
 recipes/dns_interspeech_2020/train.py:29) are foreign kernels that may hold CUs beside them.  Here: a foreign "hog"

@@ -180,7 +180,7 @@ def test_subband_input_function_matches_unfold_cat_norm_dropband():
 
 def test_leftover_step_kernel_fits_next_to_persistent_kernel(tmp_path):
     """The left-over sub-band tiles run as lstm_step1_kernel launches CONCURRENTLY with the persistent
-    lstm_rec_kernel (DESIGN §4.3).  That only happens if both fit on a CU together: 12 persistent waves =
+    lstm_rec_kernel (DESIGN 5.3).  That only happens if both fit on a CU together: 12 persistent waves =
     3 per SIMD x their register count, plus one step wave, within the 512-entry register file, and both
     LDS allocations within 160 KB.  A compiler or source change that breaks this costs ~1.4 ms per batch
     silently (the step kernels then queue behind the 32 ms kernel), so the budget is checked on the
@@ -264,7 +264,7 @@ def test_no_kernel_rewrites_store_data_inside_the_measured_unsafe_distance():
 
 
 def test_ring_fills_of_the_persistent_kernel_take_scalar_addresses():
-    """Round 5 (DESIGN 4.3): lstm_rec_x_kernel's ring fills cost 0.65 ms per batch while each LDS-DMA fragment formed its
+    """Round 5 (DESIGN 5.3): lstm_rec_x_kernel's ring fills cost 0.65 ms per batch while each LDS-DMA fragment formed its
     address in vector registers inside a loop the compiler could not unroll.  In the shipped library every fill of the time
     loop must be the scalar-base form (`global_load_lds_dwordx4 v, s[..]`); the one loop-form fill left is the prologue's."""
     import importlib.util
@@ -324,7 +324,7 @@ def test_subband_multiplicity_closed_form():
 
 
 def test_gate_admission_rule_of_persistent_launches():
-    """The rule of fsn_api.hip's PersistLaunch (DESIGN 4.7) on hypothetical sets, no device needed: launches of different
+    """The rule of fsn_api.hip's PersistLaunch (DESIGN 5.6) on hypothetical sets, no device needed: launches of different
     streams run side by side only when every workgroup of every kernel is placeable in any dispatch order - the sum of
     chip fractions stays below the smallest CU fill that could refuse a workgroup of any kernel of the set."""
     import ctypes

@@ -1,4 +1,4 @@
-"""hipGraph replay of the whole enhancement path for small batches (the launch-chain regime, DESIGN 4.3):
+"""hipGraph replay of the whole enhancement path for small batches (the launch-chain regime, DESIGN 9):
 capture Model.enhance once with torch.cuda.CUDAGraph (the library only enqueues on the caller's stream and forks /
 joins its auxiliary stream with events, so the call is capturable), replay it, compare with the eager call.
 usage: python tools/bench_graph.py [batch ...]"""

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Full session: GPU suite, bench line, kernel traces (bench / training f32 + f16 / sibling models), PMC passes.
 set -u
-O=gpurun_out/${1:-full}
+TAG=${1:-full}
+O=gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
 (time timeout 1500 python -m pytest tests -m gpu -q -rP) > $O/pytest.log 2>&1
@@ -14,7 +15,7 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -- $B > $O/trace.log 2>
 DB=$(ls $O/trace/*/*.db 2>/dev/null | head -1)
 [ -n "$DB" ] && python tools/rocprof_summary.py $DB $O/kernel_stats_bench_b64.md "rocprofv3 --kernel-trace --stats -- $B" && python tools/rocprof_timeline.py $O/trace > $O/timeline.txt 2>&1
 rm -rf $O/trace
-for A in f32 f16 "f32 norm=cumulative"; do
+for A in f32 f16 "f16 saves=32" "f32 norm=cumulative"; do
   C="python tools/bench_train.py 16 $A"
   N=$(echo $A | tr ' =' '__')
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_$N -- $C > $O/train_$N.txt 2>&1
@@ -41,3 +42,6 @@ done
 python tools/rocprof_pmc.py $O/pmc $O/pmc.json > $O/pmc_summary.txt 2>&1
 tail -12 $O/pmc_summary.txt
 rm -rf $O/pmc
+# HBM traffic of the autocast step per kernel (both save modes): profiles/rNN_pmc_train_f16*.json
+bash tools/gpu_run_pmc_train.sh $TAG/pmc_train f16 > $O/pmc_train_f16.log 2>&1; tail -1 $O/pmc_train_f16.log
+bash tools/gpu_run_pmc_train.sh $TAG/pmc_train f16 saves=32 > $O/pmc_train_f16_saves32.log 2>&1; tail -1 $O/pmc_train_f16_saves32.log

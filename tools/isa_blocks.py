@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per basic block of one kernel in a `hipcc -S` listing: MFMA, vector, LDS and memory instruction counts and the block's
-loop depth - the view that found lstm_rec_x_kernel's fill loop and the 64-bit division in its tail (DESIGN 4.3, round 5).
+loop depth - the view that found lstm_rec_x_kernel's fill loop and the 64-bit division in its tail (DESIGN 5.3, round 5).
 usage: isa_blocks.py <file.s> <kernel name substring> [min vector instructions to list a block without MFMAs]"""
 import re
 import sys

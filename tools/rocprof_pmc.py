@@ -28,15 +28,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def source_stamp(root=ROOT):
-    """What the counters were taken on: sha256 over the kernel sources (the GPU box has no .git), and the commit when there is
-    one.  bench.py replays these files' figures and compares the stamp with the tree it runs in."""
+    """What the counters were taken on: sha256 over the kernel sources WITHOUT their comments and blank lines (the GPU box has no
+    .git; a reworded comment is not another build), and the commit when there is one.  bench.py replays these files' figures and
+    compares the stamp with the tree it runs in."""
     import hashlib
     import subprocess
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(root, "fullsubnet_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "fullsubnet_amd", "csrc", "*.h")))
     for f in files:
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        text = open(f, encoding="utf-8", errors="replace").read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)            # block comments
+        text = re.sub(r"//[^\n]*", "", text)                          # line comments (no string literal of the sources holds "//")
+        code = "\n".join(ln.rstrip() for ln in text.splitlines() if ln.strip())
+        h.update(code.encode())
     stamp = {"csrc_sha256": h.hexdigest()[:16], "files": len(files)}
     try:
         stamp["commit"] = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,

@@ -1,4 +1,4 @@
-"""Timeline check of the left-over-tile concurrency (DESIGN 4.3) on a rocprofv3 --kernel-trace database:
+"""Timeline check of the left-over-tile concurrency (DESIGN 5.3) on a rocprofv3 --kernel-trace database:
 for every persistent lstm_rec_kernel dispatch, how many lstm_step1_kernel launches ran INSIDE its window and how
 many only started after it (= they did not fit beside it and queued: costs ~1.7 ms per layer).
 usage: rocprof_timeline.py <rocprofv3 output dir>"""
