@@ -2837,8 +2837,14 @@ static int lstm2_backward_phases(const float* dh1, const float* x, long ldx, con
     unsigned short* wdx16 = in16 ? x16 + (size_t)T * N * 32 : nullptr;
     const float* sv0 = static_cast<const float*>(save0);
     const float* sv1 = static_cast<const float*>(save1);
+    // FSN_ARITH_SAVES16: the forward launch left h_t in 16 bits inside the save buffers (second half of a row's gate slot) for
+    // every cluster row - with no step-by-step rows beside the launch the hidden sequences need no conversion pass at all
+    const bool h16_saved = tn16h && saves16 && left == 0;
+    const unsigned short* h16_0 = h16_saved ? reinterpret_cast<const unsigned short*>(sv0) + G : h16;
+    const unsigned short* h16_1 = h16_saved ? reinterpret_cast<const unsigned short*>(sv1) + G : (h16 ? h16 + (size_t)T * N * H : nullptr);
+    const long ldh16 = h16_saved ? 2L * G : H;  // 16-bit elements between rows
     if (prepare_part) {
-        if (tn16h) {
+        if (tn16h && !h16_saved) {
             FSN_TRY(fsn_launch_to16(hseq0, h16, (size_t)T * N * H, arith, s));
             FSN_TRY(fsn_launch_to16(hseq1, h16 + (size_t)T * N * H, (size_t)T * N * H, arith, s));
         }
@@ -2950,13 +2956,14 @@ static int lstm2_backward_phases(const float* dh1, const float* x, long ldx, con
         // hidden sequences converted once (half the HBM bytes of the fp32 operands, LDS-DMA staging, no conversion pass)
         const size_t TNG = (size_t)T * N * G, TNH = (size_t)T * N * H;
         const unsigned short *dg16_0 = dg16, *dg16_1 = dg16 + TNG;
-        if (!prepared && !prepare_part) {
+        if (!prepared && !prepare_part && !h16_saved) {
             FSN_TRY(fsn_launch_to16(hseq0, h16, TNH, arith, s));
             FSN_TRY(fsn_launch_to16(hseq1, h16 + TNH, TNH, arith, s));
         }
-        FSN_TRY(fsn_launch_gemm_tn16h(dg16_1, G, h16, H, dw_ih1, H, G, H, (long)T * N, scratch, s, arith));
-        FSN_TRY(fsn_launch_gemm_tn16h(dg16_1 + (size_t)N * G, G, h16 + TNH, H, dw_hh1, H, G, H, (long)(T - 1) * N, scratch, s, arith));
-        FSN_TRY(fsn_launch_gemm_tn16h(dg16_0 + (size_t)N * G, G, h16, H, dw_hh0, H, G, H, (long)(T - 1) * N, scratch, s, arith));
+        (void)TNH;
+        FSN_TRY(fsn_launch_gemm_tn16h(dg16_1, G, h16_0, ldh16, dw_ih1, H, G, H, (long)T * N, scratch, s, arith));
+        FSN_TRY(fsn_launch_gemm_tn16h(dg16_1 + (size_t)N * G, G, h16_1, ldh16, dw_hh1, H, G, H, (long)(T - 1) * N, scratch, s, arith));
+        FSN_TRY(fsn_launch_gemm_tn16h(dg16_0 + (size_t)N * G, G, h16_0, ldh16, dw_hh0, H, G, H, (long)(T - 1) * N, scratch, s, arith));
         if (in16) {  // x rounded once ([T N][32], its padding columns are zero), then the narrow product from 16-bit operands
             FSN_TRY(fsn_launch_to16(x, x16, (size_t)T * N * 32, arith, s));
             FSN_TRY(fsn_launch_gemm_tn16n(dg16_0, G, x16, 32, dw_ih0, I, G, I, (long)T * N, scratch, s, arith));

@@ -42,6 +42,7 @@ constexpr int QU = QH / QM;        // units per member (48)
 constexpr int QROWS = 64;          // rows per cluster
 constexpr int QFS = 32;            // words between flag groups (one 128-byte line each)
 constexpr int QD = 4;              // forward: K blocks (32 k each) of weight fragments in flight per wave
+constexpr int Q_H16_OFF = QG * 2;  // FSN_ARITH_SAVES16: byte offset of the 16-bit h_t inside a row's save slot (behind the 16-bit gates)
 constexpr int QDX = 4;             // BPTT: slots of the exchanged gate-gradient tiles (layer 1 may run QDX - 1 steps ahead of layer 0)
 constexpr int ACT_STRIDE = QH * 2 + 16;   // bytes per row of a staged [64][384] 16-bit tile (+16: conflict-free b128 reads)
 constexpr int X_STRIDE = 32 * 2 + 16;     // layer-0 input tile [64][32]
@@ -413,6 +414,13 @@ __device__ __forceinline__ void g16_fwd_body(const G16FwdArgs& a, int cluster, i
                     const fsn_u32x2 pg = q_round4<AR>(sg[e][2]), po = q_round4<AR>(sg[e][3]);
                     __builtin_amdgcn_raw_buffer_store_b128(q_u32x4{pi[0], pi[1], pf[0], pf[1]}, rg, so, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(q_u32x4{pg[0], pg[1], po[0], po[1]}, rg, so, 16, 0);
+                    // ... and h_t in 16 bits behind them (second half of the row's slot, [H] values): the B operand of two
+                    // weight-gradient products, which then need no conversion pass over the hidden sequence (recomputed from
+                    // o and c: the same fp32 value the hand-off stored, rounded like fsn_launch_to16 rounds it)
+                    f32x4 hv;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hv[i] = sg[e][3][i] * tanh_fast(c[e][i]);
+                    __builtin_amdgcn_raw_buffer_store_b64(q_round4<AR>(hv), rg, (unsigned)(row * QG * 4 + Q_H16_OFF + (QU * member + quad * 4) * 2), 0, 0);
                 } else {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) q_store(rg, go, (unsigned)(g * QH * 4), sg[e][g]);
