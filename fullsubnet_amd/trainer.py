@@ -100,6 +100,13 @@ class Trainer:
             raise ValueError(f"meta.amp_dtype = {meta.get('amp_dtype')!r}: the autocast arithmetic is \"f16\" (fp16, the "
                              f"recipe's) or \"bf16\" (aliases: {sorted(aliases)})")
         self._inner().train_arithmetic = aliases[amp_dtype] if self.use_amp else "f32"
+        # meta.amp_saves (optional): "16" (default under use_amp) keeps the gates the backward pass re-reads in the 16-bit type, as
+        # the vendor LSTM does under autocast; "32" keeps them fp32 (fullsubnet_amd/train.py:train_arith_of)
+        if "amp_saves" in meta:
+            saves = str(meta["amp_saves"])
+            if saves not in ("16", "32"):
+                raise ValueError(f'meta.amp_saves = {saves!r}: "16" or "32"')
+            self._inner().train_saves = saves
 
         ac = config["acoustics"]
         self.acoustic_config = ac
