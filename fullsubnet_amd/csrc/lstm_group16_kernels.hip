@@ -78,7 +78,10 @@ __device__ __forceinline__ f32x4 q_unpack4(const unsigned lo, const unsigned hi)
                      __builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
     }
 }
-// Saved gates in 16 bits (SV = 1; fsn_set_train_saves): the activated gates i, f, g, o that BPTT re-reads are kept in the
+// (With SV the forward hand-off itself travels in 16 bits: a member's h slice goes write-through into the rows' save slots
+// before its flag, the partners copy the [64][H] 16-bit tile straight into LDS - half the exchanged bytes, no conversion - and
+// the fp32 hidden sequence is stored after the flag, off the hand-off path.)
+// Saved gates in 16 bits (SV = 1; FSN_ARITH_SAVES16): the activated gates i, f, g, o that BPTT re-reads are kept in the
 // operand type of the arithmetic - what the vendor's autocast LSTM keeps in its reserve space - inside the SAME buffer: row
 // r of step t still owns its 4H x 4 bytes and uses the first half as [unit quad 96][gate 4][4 units] 16-bit, so a thread's
 // (row, unit quad) item is 32 contiguous bytes (two 16-byte stores forward, two LDS-DMA pieces backward) and rows that do
@@ -275,6 +278,24 @@ __device__ __forceinline__ void g16_fwd_body(const G16FwdArgs& a, int cluster, i
             }
         }
     };
+    // SV: the hand-off travels in 16 bits - a member writes its h slice through (same scope) into the second half of the rows'
+    // save slots BEFORE its flag; the partners copy [64][H] 16-bit values (half the bytes, no conversion) straight into `act`.
+    // `g` = the layer's gate-save buffer, step t.  (Rounded at the producer or at the consumer's matrix input: the same number.)
+    auto stage16 = [&](float* g, int t) {
+        const __amdgpu_buffer_rsrc_t src = q_rsrc(g + ((size_t)t * N + (size_t)cluster * QROWS) * QG, QROWS * QG * 4);
+        q_u32x4 v[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int q = tid + 256 * i, row = q / 48, k8 = q % 48;
+            if constexpr ((ABL & 2) != 0) v[i] = q_u32x4{0x2c002c00u + (unsigned)row, 0x28002800u, 0x24002400u + (unsigned)k8, 0x20002000u};
+            else v[i] = __builtin_bit_cast(q_u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, (unsigned)(row * QG * 4 + Q_H16_OFF + k8 * 16), 0, XS));
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int q = tid + 256 * i, row = q / 48, k8 = q % 48;
+            *reinterpret_cast<q_u32x4*>(act + row * ACT_STRIDE + k8 * 16) = v[i];
+        }
+    };
     // acc += W(gate `wave` of the member's 48 units x K) act^T: twelve K blocks, the wave's own weight stream through a
     // ring of QD blocks whose first turn `ring` was requested by the caller (before the hand-off wait)
     auto kloop12 = [&](f32x4 (&acc)[3][4], q_u32x4 (&ring)[QD][3], unsigned base) {
@@ -340,7 +361,8 @@ __device__ __forceinline__ void g16_fwd_body(const G16FwdArgs& a, int cluster, i
             if (t > 0) {
                 if constexpr ((ABL & 1) != 0) __syncthreads();
                 else q_wait(fl0, (unsigned)t, a.status, a.spin_ticks);  // h0_{t-1} of all members
-                stage(tileh(a.hseq0, t - 1));
+                if constexpr (SV != 0) stage16(a.gates0, t - 1);
+                else stage(tileh(a.hseq0, t - 1));
             }
             __syncthreads();
             {
@@ -358,14 +380,16 @@ __device__ __forceinline__ void g16_fwd_body(const G16FwdArgs& a, int cluster, i
             ring_start(ring, w_in);
             if constexpr ((ABL & 1) != 0) __syncthreads();
             else q_wait(fl0, (unsigned)t + 1, a.status, a.spin_ticks);
-            stage(tileh(a.hseq0, t));
+            if constexpr (SV != 0) stage16(a.gates0, t);
+            else stage(tileh(a.hseq0, t));
             __syncthreads();
             kloop12(acc, ring, w_in);
             if (t > 0) {
                 ring_start(ring, w_rec);
                 if constexpr ((ABL & 1) != 0) __syncthreads();
                 else q_wait(fl1, (unsigned)t, a.status, a.spin_ticks);  // h1_{t-1} of all members; also: everyone has left `act`
-                stage(tileh(a.hseq1, t - 1));
+                if constexpr (SV != 0) stage16(a.gates1, t - 1);
+                else stage(tileh(a.hseq1, t - 1));
                 __syncthreads();
                 kloop12(acc, ring, w_rec);
             }
@@ -378,7 +402,7 @@ __device__ __forceinline__ void g16_fwd_body(const G16FwdArgs& a, int cluster, i
                 *reinterpret_cast<f32x4*>(act + (wave * QROWS + 16 * r + lr) * GSH_STRIDE + (16 * j + 4 * lq) * 4) = acc[j][r];
         __syncthreads();
         f32x4 sg[3][4];  // activated gates of this thread's items, kept for the saves
-        const __amdgpu_buffer_rsrc_t rh = tileh(hseq, t);
+        const __amdgpu_buffer_rsrc_t rh = tileh(hseq, t), rg = tileg(gates, t);
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
             const int q = tid + 256 * e, row = q / 12, quad = q % 12;
@@ -395,11 +419,13 @@ __device__ __forceinline__ void g16_fwd_body(const G16FwdArgs& a, int cluster, i
                 sg[e][0][i] = ig, sg[e][1][i] = fg, sg[e][2][i] = gg, sg[e][3][i] = og;
             }
             if constexpr ((ABL & 16) != 0) live += hv[0] + hv[1] + hv[2] + hv[3];
+            else if constexpr (SV != 0)
+                __builtin_amdgcn_raw_buffer_store_b64(q_round4<AR>(hv), rg, (unsigned)(row * QG * 4 + Q_H16_OFF + (QU * member + quad * 4) * 2), 0, XS);
             else q_store_sc1<XS>(rh, (unsigned)((row * QH + QU * member + quad * 4) * 4), 0, hv);
         }
         q_publish(myflag, (unsigned)t + 1);  // its barrier also closes the reads of the gate exchange
         // the saves of the step, AFTER the hand-off (only h belongs to it)
-        const __amdgpu_buffer_rsrc_t rg = tileg(gates, t), rc = tileh(cseq, t);
+        const __amdgpu_buffer_rsrc_t rc = tileh(cseq, t);
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
             const int q = tid + 256 * e, row = q / 12, quad = q % 12;
@@ -414,13 +440,13 @@ __device__ __forceinline__ void g16_fwd_body(const G16FwdArgs& a, int cluster, i
                     const fsn_u32x2 pg = q_round4<AR>(sg[e][2]), po = q_round4<AR>(sg[e][3]);
                     __builtin_amdgcn_raw_buffer_store_b128(q_u32x4{pi[0], pi[1], pf[0], pf[1]}, rg, so, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(q_u32x4{pg[0], pg[1], po[0], po[1]}, rg, so, 16, 0);
-                    // ... and h_t in 16 bits behind them (second half of the row's slot, [H] values): the B operand of two
-                    // weight-gradient products, which then need no conversion pass over the hidden sequence (recomputed from
-                    // o and c: the same fp32 value the hand-off stored, rounded like fsn_launch_to16 rounds it)
+                    // (h_t in 16 bits sits behind them, second half of the row's slot, [H] values: the hand-off above - and the B
+                    // operand of two weight-gradient products, which need no conversion pass over the hidden sequence.)  The
+                    // fp32 hidden sequence, off the hand-off path: recomputed from o and c, the very value that was rounded
                     f32x4 hv;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) hv[i] = sg[e][3][i] * tanh_fast(c[e][i]);
-                    __builtin_amdgcn_raw_buffer_store_b64(q_round4<AR>(hv), rg, (unsigned)(row * QG * 4 + Q_H16_OFF + (QU * member + quad * 4) * 2), 0, 0);
+                    q_store(rh, (unsigned)((row * QH + QU * member + quad * 4) * 4), 0, hv);
                 } else {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) q_store(rg, go, (unsigned)(g * QH * 4), sg[e][g]);
