@@ -2110,13 +2110,15 @@ extern "C" int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_
         float* gx_left = cv.take<float>((size_t)T * left * 4 * H);
         const size_t wfloats = (size_t)4 * H * Ipad + (size_t)3 * 4 * H * H;
         unsigned short* w16 = arith != FSN_ARITH_F32 ? cv.take<unsigned short>(wfloats) : nullptr;
-        FSN_TRY(fsn_launch_pack(w_ih0, wih0_p, 4 * H, I, 4 * H, Ipad, s));
-        FSN_TRY(fsn_launch_pack(w_hh0, whh0_p, 4 * H, H, 4 * H, H, s));
-        FSN_TRY(fsn_launch_pack(w_ih1, wih1_p, 4 * H, H, 4 * H, H, s));
-        FSN_TRY(fsn_launch_pack(w_hh1, whh1_p, 4 * H, H, 4 * H, H, s));
+        const bool g16 = lstm2_use_g16(arith, clusters, N);
+        if (!g16 || left > 0) {  // the fp32-fragment weights: the group kernel's and the step-by-step rows' (the 16-bit kernels pack their own)
+            FSN_TRY(fsn_launch_pack(w_ih0, wih0_p, 4 * H, I, 4 * H, Ipad, s));
+            FSN_TRY(fsn_launch_pack(w_hh0, whh0_p, 4 * H, H, 4 * H, H, s));
+            FSN_TRY(fsn_launch_pack(w_ih1, wih1_p, 4 * H, H, 4 * H, H, s));
+            FSN_TRY(fsn_launch_pack(w_hh1, whh1_p, 4 * H, H, 4 * H, H, s));
+        }
         FSN_TRY(fsn_launch_bias_sum(b_ih0, b_hh0, b0, 4 * H, 4 * H, s));
         FSN_TRY(fsn_launch_bias_sum(b_ih1, b_hh1, b1, 4 * H, 4 * H, s));
-        const bool g16 = lstm2_use_g16(arith, clusters, N);
         if (w16 && !g16) FSN_TRY(fsn_launch_to16(wih0_p, w16, wfloats, arith, s));  // the group kernel's weight fragments in 16 bits
         float* sv0 = static_cast<float*>(save0);
         float* sv1 = static_cast<float*>(save1);
@@ -2851,11 +2853,14 @@ static int lstm2_backward_phases(const float* dh1, const float* x, long ldx, con
         if (!chain_part && !products_part && !dx_part) return FSN_OK;
     }
     if (chain_part) {
-    // "weights" of dh = dgates W are W^T: out = H columns, k = 4H; nn.LSTM stores exactly that transposed
-    FSN_TRY(fsn_launch_pack(w_hh1, whh1T_p, H, G, H, G, s, 1, H));
-    FSN_TRY(fsn_launch_pack(w_ih1, wih1T_p, H, G, H, G, s, 1, H));
-    FSN_TRY(fsn_launch_pack(w_hh0, whh0T_p, H, G, H, G, s, 1, H));
-    FSN_TRY(fsn_launch_pack(w_ih0, wih0T_p, I, G, Ipad, G, s, 1, I));
+    // "weights" of dh = dgates W are W^T: out = H columns, k = 4H; nn.LSTM stores exactly that transposed.  (Not needed when the
+    // 16-bit kernels take every row and every product: they pack the raw weights their own way.)
+    if (!(g16 && left == 0 && in16)) {
+        FSN_TRY(fsn_launch_pack(w_hh1, whh1T_p, H, G, H, G, s, 1, H));
+        FSN_TRY(fsn_launch_pack(w_ih1, wih1T_p, H, G, H, G, s, 1, H));
+        FSN_TRY(fsn_launch_pack(w_hh0, whh0T_p, H, G, H, G, s, 1, H));
+        FSN_TRY(fsn_launch_pack(w_ih0, wih0T_p, I, G, Ipad, G, s, 1, I));
+    }
     if (w16 && !g16) FSN_TRY(fsn_launch_to16(whh1T_p, w16, (size_t)3 * H * G, arith, s));  // the BPTT kernel's W^T fragments in 16 bits
     StreamCtx* cx = cur_ctx();
     if (left > 0) {
