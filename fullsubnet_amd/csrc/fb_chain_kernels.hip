@@ -90,8 +90,14 @@ __device__ __forceinline__ float quad_bcast(float v) {
 // the flag store, 32 no flag stores, 64 no layer-1 projection in L0 (L1 does not wait for it)
 // SAVE: the training form - every step also keeps the activated gates, the cell state and layer 0's hidden sequence
 // (fsn_lstm_layer_backward's inputs, the layouts of fsn_lstm_layer_forward)
-template <int CH, int KS, int ABL = 0, bool SAVE = false>
+// CELL: 0 = LSTM (gate tile i | f | g | o); 1 = GRU (audio_zen/model/module/sequence_model.py:59-66) written as a FOUR-gate cell
+// so that every product, hand-off and buffer of the chain stays as it is: tile r | z | nx | nh with
+//   r = sigmoid(W_ir x + b_ir + W_hr h + b_hr), z likewise, nx = W_in x + b_in (no recurrent part), nh = W_hn h + b_hn (no
+//   input part), n = tanh(nx + r nh), h' = n + z (h - n)
+// - the caller expands nn.GRU's [3H] gate rows to [4H] with zero blocks (fsn_gru2_forward); the cell state registers hold h.
+template <int CH, int KS, int ABL = 0, bool SAVE = false, int CELL = 0>
 __global__ __launch_bounds__(256, 1) void fb_chain_kernel(const ChainArgs a) {
+    static_assert(!(SAVE && CELL != 0), "the training form is built for the LSTM cell");
     constexpr int CKC = CH / 16;   // K chunks of an H-wide operand (and column tiles per gate)
     constexpr int CNW = CH / 4;    // workgroups per stage
     static_assert(CKC % 4 == 0 && CNW % 2 == 0 && CNW <= CFS, "hidden size: a multiple of 64, at most 512");
@@ -186,6 +192,20 @@ __global__ __launch_bounds__(256, 1) void fb_chain_kernel(const ChainArgs a) {
     // SAVE: activated gates -> gates_t [Npad][4H] (every lane: its gate, 4 units of row 4 lq + ul), c_t -> cseq_t.
     auto cell = [&](f32x4 acc, float (&c)[4], float* gates_t, float* cseq_t) -> f32x4 {
         float act[4], hq[4];
+        if constexpr (CELL == 1) {  // GRU: lanes g = 0 hold r and gather z, nx, nh of their unit; c[] is h_{t-1} of the unit
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = g < 2 ? sigmoid_f(acc[i]) : acc[i];
+                const float z = __shfl(v, lane + 4, 64);
+                const float nx = __shfl(v, lane + 8, 64);
+                const float nh = __shfl(v, lane + 12, 64);
+                const float n = tanhf(nx + v * nh);
+                const float hn = n + z * (c[i] - n);
+                c[i] = hn;
+                hq[i] = hn;
+            }
+            return quad_transpose(hq);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) act[i] = g == 2 ? tanh_fast(acc[i]) : sigmoid_fast(acc[i]);
         // lanes ul (gate i, g = 0) gather f, g, o of their unit from lanes ul + 4, + 8, + 12 of the same 16-lane row
@@ -312,7 +332,10 @@ bool chain_grid_fits(int RT) {
     if (RT == 1) k = (const void*)fb_chain_kernel<CH, 4, 0, false>, ks = (const void*)fb_chain_kernel<CH, 4, 0, true>;
     else if (RT == 2) k = (const void*)fb_chain_kernel<CH, 2, 0, false>, ks = (const void*)fb_chain_kernel<CH, 2, 0, true>;
     else k = (const void*)fb_chain_kernel<CH, 1, 0, false>, ks = (const void*)fb_chain_kernel<CH, 1, 0, true>;
-    return fsn_grid_fits(k, 256, grid) && fsn_grid_fits(ks, 256, grid);
+    const void* kg = RT == 1   ? (const void*)fb_chain_kernel<CH, 4, 0, false, 1>
+                     : RT == 2 ? (const void*)fb_chain_kernel<CH, 2, 0, false, 1>
+                               : (const void*)fb_chain_kernel<CH, 1, 0, false, 1>;
+    return fsn_grid_fits(k, 256, grid) && fsn_grid_fits(ks, 256, grid) && fsn_grid_fits(kg, 256, grid);
 }
 }  // namespace
 bool fsn_fb_chain_supported(int H, int Npad) {
@@ -330,12 +353,12 @@ size_t fsn_fb_chain_flag_words() { return (size_t)2 * CREP * CFS + 16; }
 size_t fsn_fb_chain_status_word() { return (size_t)2 * CREP * CFS; }
 
 namespace {
-template <int CH, bool SAVE>
+template <int CH, bool SAVE, int CELL = 0>
 void chain_launch(const ChainArgs& a, hipStream_t s) {
     const dim3 grid(2 * (CH / 4)), block(256);
-    if (a.RT == 1) FSN_PERSIST_LAUNCH((fb_chain_kernel<CH, 4, 0, SAVE>), grid, block, s, a);
-    else if (a.RT == 2) FSN_PERSIST_LAUNCH((fb_chain_kernel<CH, 2, 0, SAVE>), grid, block, s, a);
-    else FSN_PERSIST_LAUNCH((fb_chain_kernel<CH, 1, 0, SAVE>), grid, block, s, a);
+    if (a.RT == 1) FSN_PERSIST_LAUNCH((fb_chain_kernel<CH, 4, 0, SAVE, CELL>), grid, block, s, a);
+    else if (a.RT == 2) FSN_PERSIST_LAUNCH((fb_chain_kernel<CH, 2, 0, SAVE, CELL>), grid, block, s, a);
+    else FSN_PERSIST_LAUNCH((fb_chain_kernel<CH, 1, 0, SAVE, CELL>), grid, block, s, a);
 }
 }  // namespace
 
@@ -344,12 +367,16 @@ void chain_launch(const ChainArgs& a, hipStream_t s) {
 // the layout of fsn_lstm_layer_forward).
 int fsn_launch_fb_chain(const float* gx0, const float* whh0_p, const float* wih1_p, const float* whh1_p, const float* b1,
                         float* exchange, unsigned* flags, float* hseq1, int Tp, int Npad, int H, hipStream_t s,
-                        float* hseq0, float* save0, float* save1) {
+                        float* hseq0, float* save0, float* save1, int cell) {
     if (!fsn_fb_chain_supported(H, Npad) || Tp < 1 || Tp > fsn_fb_chain_max_steps()) {
         fsn_set_error("fb_chain: built for H = 384 / 512, at most 64 rows and 4095 steps");
         return FSN_ERR_ARG;
     }
     const bool save = hseq0 || save0 || save1;
+    if (cell != 0 && (cell != 1 || save)) {
+        fsn_set_error("fb_chain: cell 0 (LSTM) or 1 (GRU as a four-gate cell, inference form only)");
+        return FSN_ERR_ARG;
+    }
     if (save && !(hseq0 && save0 && save1)) {
         fsn_set_error("fb_chain: the training form needs hseq0, save0 and save1");
         return FSN_ERR_ARG;
@@ -378,10 +405,12 @@ int fsn_launch_fb_chain(const float* gx0, const float* whh0_p, const float* wih1
     a.RT = Npad / 16;
     a.Npad = Npad;
     if (H == 512) {
-        if (save) chain_launch<512, true>(a, s);
+        if (cell) chain_launch<512, false, 1>(a, s);
+        else if (save) chain_launch<512, true>(a, s);
         else chain_launch<512, false>(a, s);
     } else {
-        if (save) chain_launch<384, true>(a, s);
+        if (cell) chain_launch<384, false, 1>(a, s);
+        else if (save) chain_launch<384, true>(a, s);
         else chain_launch<384, false>(a, s);
     }
     return fsn_check_launch("fb_chain_kernel");

@@ -2339,6 +2339,67 @@ extern "C" int fsn_lstm2_forward(const float* x, long ldx, const float* w_ih0, c
                                        cst + (size_t)N * H0, T, N / 16, H0, H1, s);
 }
 
+// ---- two stacked GRU layers of equal width, few rows: ONE persistent launch of the chain kernel ---------------------------
+// (audio_zen/model/module/sequence_model.py:59-66 with num_layers = 2: the full-band model of a GRU FullSubNet, B <= 64 rows.)
+// nn.GRU's weights are expanded to the four-gate cell r | z | nx | nh (zero blocks where a gate has no input / no recurrent
+// part) and take the LSTM chain's path unchanged: projection GEMM of layer 0, fb_chain_kernel<.., CELL = 1>.
+extern "C" int fsn_gru2_forward_supported(int T, int N, int H) { return T >= 1 && lstm2_on_chain(T, N, H) ? 1 : 0; }
+extern "C" size_t fsn_gru2_fwd_workspace_bytes(int T, int N, int I, int H) {
+    if (T < 1 || N < 16 || N % 16 || I < 1 || H < 64) return 0;
+    const size_t Ipad = fsn_round_up(I, 16), G = 4 * (size_t)H;
+    Carver cv(nullptr);
+    cv.take<float>(2 * (G * Ipad + 3 * G * H));  // the expanded matrices and their fragment-order copies
+    cv.take<float>(2 * G);                       // b4 of both layers
+    cv.take<float>((size_t)T * N * G);           // layer-0 projection
+    cv.take<float>(fsn_fb_chain_exchange_floats(T, N));
+    cv.take<unsigned>(fsn_fb_chain_flag_words());
+    return fsn_round_up_sz(cv.off, 256);
+}
+extern "C" int fsn_gru2_forward(const float* x, long ldx, const float* w_ih0, const float* w_hh0, const float* b_ih0,
+                                const float* b_hh0, const float* w_ih1, const float* w_hh1, const float* b_ih1,
+                                const float* b_hh1, int T, int N, int I, int H, float* hseq1, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    CallScope scope(stream);
+    FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
+    FSN_REQUIRE(x && w_ih0 && w_hh0 && b_ih0 && b_hh0 && w_ih1 && w_hh1 && b_ih1 && b_hh1 && hseq1 && workspace, "NULL pointer argument");
+    FSN_REQUIRE(fsn_gru2_forward_supported(T, N, H), "gru2 forward: built for H = 384 / 512 twice, up to 64 rows and 4095 steps on a "
+                                                     "device that holds the chain's grid (fsn_gru2_forward_supported)");
+    if (workspace_bytes < fsn_gru2_fwd_workspace_bytes(T, N, I, H)) {
+        fsn_set_error("gru2 forward: workspace too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Ipad = fsn_round_up(I, 16), G = 4 * H;
+    Carver cv(workspace);
+    float* e = cv.take<float>(2 * ((size_t)G * Ipad + (size_t)3 * G * H));
+    float *wih0_4 = e, *whh0_4 = wih0_4 + (size_t)G * I, *wih1_4 = whh0_4 + (size_t)G * H, *whh1_4 = wih1_4 + (size_t)G * H;
+    float* pk = e + (size_t)G * Ipad + (size_t)3 * G * H;
+    float *wih0_p = pk, *whh0_p = wih0_p + (size_t)G * Ipad, *wih1_p = whh0_p + (size_t)G * H, *whh1_p = wih1_p + (size_t)G * H;
+    float* b0 = cv.take<float>((size_t)2 * G);
+    float* b1 = b0 + G;
+    float* gx = cv.take<float>((size_t)T * N * G);
+    float* exchange = cv.take<float>(fsn_fb_chain_exchange_floats(T, N));
+    unsigned* flags = cv.take<unsigned>(fsn_fb_chain_flag_words());
+    FSN_TRY(fsn_launch_gru_expand4(w_ih0, w_hh0, b_ih0, b_hh0, wih0_4, whh0_4, b0, I, H, s));
+    FSN_TRY(fsn_launch_gru_expand4(w_ih1, w_hh1, b_ih1, b_hh1, wih1_4, whh1_4, b1, H, H, s));
+    FSN_TRY(fsn_launch_pack(wih0_4, wih0_p, G, I, G, Ipad, s));
+    FSN_TRY(fsn_launch_pack(whh0_4, whh0_p, G, H, G, H, s));
+    FSN_TRY(fsn_launch_pack(wih1_4, wih1_p, G, H, G, H, s));
+    FSN_TRY(fsn_launch_pack(whh1_4, whh1_p, G, H, G, H, s));
+    FsnGemmA a{};
+    a.kind = 0;
+    a.p0 = x;
+    a.ld = ldx;
+    FsnGemmC c{};
+    c.kind = 0;
+    c.p0 = gx;
+    c.bias = b0;
+    FSN_TRY(fsn_launch_gemm(a, wih0_p, c, T * (N / 16), G / 16, Ipad / 16, s));
+    FSN_PERSIST_BEGIN(s);
+    FSN_TRY(fsn_launch_fb_chain(gx, whh0_p, wih1_p, whh1_p, b1, exchange, flags, hseq1, T, N, H, s, nullptr, nullptr, nullptr, 1));
+    return fsn_launch_poison_if(flags + fsn_fb_chain_status_word(), hseq1, (size_t)T * N * H, s);
+}
+
 // Streaming form (frame-by-frame / chunked inference with carried state): T more steps from the state
 // (h, c) [N][H], which is updated in place.  Always on the per-step kernels.  The weights are re-tiled
 // once (fsn_lstm_layer_pack) - a per-frame caller must not pay three pack launches per layer per call.

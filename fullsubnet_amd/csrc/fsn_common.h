@@ -395,7 +395,11 @@ size_t fsn_fb_chain_exchange_floats(int Tp, int Npad);
 size_t fsn_fb_chain_flag_words();
 int fsn_launch_fb_chain(const float* gx0, const float* whh0_p, const float* wih1_p, const float* whh1_p, const float* b1,
                         float* exchange, unsigned* flags, float* hseq1, int Tp, int Npad, int H, hipStream_t s,
-                        float* hseq0 = nullptr, float* save0 = nullptr, float* save1 = nullptr);
+                        float* hseq0 = nullptr, float* save0 = nullptr, float* save1 = nullptr, int cell = 0);
+// gru_kernels.hip: nn.GRU's [3H] gate rows (r, z, n) of one layer as the FOUR-gate cell the chain kernel runs (r | z | nx | nh):
+// w_ih4 [4H][I] = W_ir; W_iz; W_in; 0   w_hh4 [4H][H] = W_hr; W_hz; 0; W_hn   b4 [4H] = b_ir + b_hr; b_iz + b_hz; b_in; b_hn
+int fsn_launch_gru_expand4(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* w_ih4, float* w_hh4,
+                           float* b4, int I, int H, hipStream_t s);
 
 // lstm_train_kernels.hip (training step: BPTT pieces)
 // C [M][Nc] = sum_k A[k][M]^T B[k][Nc]   (both operands row-major over k; split-K, deterministic 2-pass)

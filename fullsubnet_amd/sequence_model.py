@@ -78,6 +78,20 @@ def lstm2_infer(x, layer0, layer1):
     return hseq
 
 
+def gru2_infer(x, layer0, layer1):
+    """Two stacked GRU layers of equal (padded) width with few rows as ONE persistent launch (fsn_gru2_forward: the chain kernel
+    with the GRU as a four-gate cell); the caller asked fsn_gru2_forward_supported.  x [T, N, ldx] -> layer 1's hidden sequence."""
+    L = _lib.lib()
+    T, N, ldx = x.shape
+    I, H = layer0[0].shape[1], layer0[1].shape[1]
+    hseq = torch.empty((T, N, H), dtype=torch.float32, device=x.device)
+    ws = _lib.workspace(L.fsn_gru2_fwd_workspace_bytes(T, N, I, H), x.device)
+    ptrs = [_lib.dev_ptr(t, "weight") for t in (*layer0, *layer1)]
+    _lib.check(L.fsn_gru2_forward(_lib.dev_ptr(x, "x"), ldx, *ptrs, T, N, I, H, _lib.dev_ptr(hseq), ws.data_ptr(), ws.numel(),
+                                  _lib.stream_ptr(x.device)))
+    return hseq
+
+
 def gru_layer_infer(x, w_ih, w_hh, b_ih, b_hh):
     """One GRU layer, inference mode (same conventions as lstm_layer_infer, 3H gate rows r, z, n)."""
     L = _lib.lib()
@@ -212,6 +226,12 @@ class SequenceModel(nn.Module):
                 if not (Np < WAVEFRONT_BELOW_ROWS or _lib.lib().fsn_lstm2_forward_is_persistent(T, Np, width, width, Hp, Hp)):
                     break
                 h = lstm2_infer(h, layers[k], layers[k + 1])
+                k += 2
+        elif self.cell == "GRU":
+            # two GRU layers with few rows (a GRU FullSubNet's full-band model): one persistent launch where the chain kernel applies
+            while k + 1 < len(layers) and layers[k][1].shape[1] == layers[k + 1][1].shape[1] and \
+                    _lib.lib().fsn_gru2_forward_supported(T, Np, layers[k][1].shape[1]):
+                h = gru2_infer(h, layers[k], layers[k + 1])
                 k += 2
         for w_ih, w_hh, b_ih, b_hh in layers[k:]:
             h = layer_infer(h, w_ih, w_hh, b_ih, b_hh)

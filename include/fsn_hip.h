@@ -59,8 +59,8 @@ extern "C" {
 const char* fsn_last_error(void);
 /* The ABI revision this header describes.  fsn_version() returns the revision the LIBRARY was built with: a caller
  * compares the two once after loading (fullsubnet_amd/_lib.py raises on a mismatch) - argument lists changed between
- * revisions (112: + FSN_ARITH_SAVES16; 111: + the composed families' glue entries; 110: fsn_train_dims.norm, fsn_train_den_elems; 100 -> 101 of round 4: fsn_clip_adam_step's found_inf). */
-#define FSN_ABI_VERSION 112
+ * revisions (113: + fsn_gru2_forward; 112: + FSN_ARITH_SAVES16; 111: + the composed families' glue entries; 110: fsn_train_dims.norm, fsn_train_den_elems; 100 -> 101 of round 4: fsn_clip_adam_step's found_inf). */
+#define FSN_ABI_VERSION 113
 int fsn_version(void);
 
 /* ---- STFT / iSTFT : audio_zen/acoustics/feature.py ------------------------------------- */
@@ -270,6 +270,17 @@ int fsn_bft_to_rows(const float* x, int B, int F, int T, float* h, int Np, int I
 int fsn_rows_to_bft(const float* o, int T, int Np, int ld, int B, int O, float* y, void* stream);
 int fsn_improved_mask_apply(int n, const fsn_mask_section* sections, const float* real, const float* imag, int B, int F, int T,
                             float* er, float* ei, void* stream);
+
+/* Two stacked GRU layers of equal width (nn.GRU(num_layers = 2) of a SequenceModel, sequence_model.py:59-66; weights in nn.GRU's
+ * layout: w_ih [3H][I], w_hh [3H][H], biases [3H], gate rows r, z, n) with few rows - the full-band model of a GRU FullSubNet -
+ * as ONE persistent launch (the chain kernel with the GRU written as a four-gate cell) instead of 2 T per-step launches.
+ * fsn_gru2_forward_supported: 1 for H = 384 / 512, N <= 64 rows (a multiple of 16), T <= 4095 on a device that holds the
+ * chain's grid; anything else: fsn_gru_layer_forward layer by layer.  x [T][N][ldx] time-major, hseq1 [T][N][H]. */
+int fsn_gru2_forward_supported(int T, int N, int H);
+size_t fsn_gru2_fwd_workspace_bytes(int T, int N, int I, int H);
+int fsn_gru2_forward(const float* x, long ldx, const float* w_ih0, const float* w_hh0, const float* b_ih0, const float* b_hh0,
+                     const float* w_ih1, const float* w_hh1, const float* b_ih1, const float* b_hh1, int T, int N, int I, int H,
+                     float* hseq1, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Up to eight INDEPENDENT two-layer stacks over the same T frames: the band sections of
  * improved_fullsubnet/model.py:402-449, whose SequenceModels have B x {20, 25, 6, 4} rows and input widths 62 .. 180 at

@@ -619,6 +619,48 @@ def test_sibling_training_step_vs_the_reference(fsn, golden_dir, name):
     assert moved > 0
 
 
+@pytest.mark.parametrize("I,H,B,T", [(257, 512, 3, 23), (257, 512, 64, 9), (40, 384, 33, 12), (70, 320, 5, 8)])
+def test_two_gru_layers_with_few_rows_on_the_chain_kernel(fsn, I, H, B, T):
+    """nn.GRU(num_layers = 2) of a SequenceModel with few rows (sequence_model.py:59-66: the full-band model of a GRU FullSubNet)
+    as ONE persistent launch - fb_chain_kernel with the GRU written as a four-gate cell r | z | nx | nh (fsn_gru2_forward) -
+    against torch's nn.GRU on the CPU and against the library's own layer-by-layer path (gru_step_kernel), which it replaces
+    where fsn_gru2_forward_supported says so (H = 384 / 512, up to 64 rows; H = 320 is no chain shape: layer by layer, never an error)."""
+    from fullsubnet_amd.sequence_model import SequenceModel
+    torch.manual_seed(7)
+    m = SequenceModel(I, 0, H, 2, False, "GRU", None)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(2.0)
+    x = torch.randn(B, I, T)
+    ref = torch.nn.GRU(I, H, 2, batch_first=True)
+    ref.load_state_dict(m.sequence_model.state_dict())
+    with torch.no_grad():
+        want = ref(x.permute(0, 2, 1))[0].permute(0, 2, 1)  # [B, H, T]
+        md = m.cuda().eval()
+        L = fsn._lib.lib()
+        Hp, Np = (H + 63) // 64 * 64, (B + 15) // 16 * 16
+        on_chain = L.fsn_gru2_forward_supported(T, Np, Hp) == 1
+        assert on_chain == (Hp in (384, 512)), "H = 384 / 512 with up to 64 rows: this device should hold the chain's grid"
+        got = md(x.cuda()).cpu()
+        # the layer-by-layer path of the same module
+        from fullsubnet_amd import sequence_model as SM
+        keep = SM.gru2_infer
+        try:
+            SM.gru2_infer = None
+            layers, _ = md._inference_weights()
+            h = SM.to_rows(x.cuda())
+            for w_ih, w_hh, b_ih, b_hh in layers:
+                h = SM.gru_layer_infer(h, w_ih, w_hh, b_ih, b_hh)
+            steps = SM.from_rows(h[:, :, :H], B).cpu()
+        finally:
+            SM.gru2_infer = keep
+    assert got.shape == want.shape == (B, H, T)
+    d_ref, d_steps = (got - want).abs().max().item(), (got - steps).abs().max().item()
+    print(f"GRU x 2, I = {I}, H = {H}, {B} rows, {T} steps: max |d| vs nn.GRU {d_ref:.2e}, vs the per-step kernels {d_steps:.2e}, "
+          f"output range {want.min():.2f} .. {want.max():.2f}")
+    assert float(want.abs().max()) > 0.3 and d_ref <= 2e-5 and d_steps <= 2e-5
+
+
 def test_fullsubnet_gru_training_step_runs_and_learns(fsn):
     """The composed path under autograd: GRU forward-with-saves + BPTT through both blocks."""
     from oracle import fullsubnet_oracle as O
