@@ -39,6 +39,18 @@
 #ifndef FSN_GRP_AD16
 #define FSN_GRP_AD16 8      // a multiple of FSN_GRP_CPS16
 #endif
+#ifndef FSN_GRP_VGPR
+#define FSN_GRP_VGPR 108    // register cap of the two-workgroups-per-CU forms
+#endif
+#ifndef FSN_GRP_BOOST
+#define FSN_GRP_BOOST 12    // experiment (ABL 8192): first chunk of layer 0's K loop at the raised priority
+#endif
+#ifndef FSN_GRP_LEAD
+#define FSN_GRP_LEAD 2      // experiment (ABL 2048)
+#endif
+#ifndef FSN_GRP_D0
+#define FSN_GRP_D0 4
+#endif
 #ifndef FSN_GRP_BIAS_LDS
 #define FSN_GRP_BIAS_LDS 1  // biases in LDS also with one cluster per workgroup set (frees 12 registers for the ring)
 #endif
@@ -55,7 +67,7 @@ constexpr int GKC = GH / 16;     // K chunks of an H-wide operand
 constexpr int GM = 8;            // members per cluster and layer
 constexpr int GU = GH / 16 / GM; // unit groups per member (3)
 constexpr int GROWS = 64;        // rows per cluster
-constexpr int GD0 = 4;           // depth of layer 0's exchange buffer: layer 0 may run GD0 - 2 steps ahead of layer 1
+constexpr int GD0 = FSN_GRP_D0;           // depth of layer 0's exchange buffer: layer 0 may run GD0 - 2 steps ahead of layer 1
 constexpr int GFS = 32;          // words between the flag groups of (cluster, layer): one 128-byte line each
 
 struct GrpArgs {
@@ -83,6 +95,7 @@ struct GrpArgs {
     // cluster's missing 16-row tiles load a valid tile's rows and store nothing)
     const float* gx;
     int gx_tiles;
+    unsigned long long* dbg;  // tools/probe_group.hip's timeline (ABL 4096): [layer][member][Tp + 1][8] clock stamps of cluster 0
 };
 
 // Several weight sets in one launch (GX form): the sections of improved_fullsubnet/model.py:402-449 are independent
@@ -123,7 +136,8 @@ __device__ __forceinline__ bool grp_poll(unsigned* flags8, unsigned epoch, unsig
 
 // ABL: experiment knob of tools/probe_group.hip (0 in the library; any bit set gives WRONG results): 1 no acquire
 // fence, 2 no flag polling, 4 plain instead of write-through stores, 8 no gate non-linearities, 16 no output layer,
-// 32 A fragments not loaded (a constant instead).
+// 32 A fragments not loaded (a constant instead), 128 weight fragments not loaded, 256 no LDS stage of the weight fragments
+// (operands from registers, no K-loop barriers), 512 members (not clusters) share an XCD.
 // What a workgroup keeps per cluster.  A workgroup serves one cluster, or TWO alternately (batches of 9 - 16 utterances:
 // more clusters than the chip holds at once): step t of cluster A, step t of cluster B, step t + 1 of A ... - while it
 // works on one cluster the partners' flags and write-through data of the other are on their way.
@@ -152,6 +166,15 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
     const int lr = lane & 15, lq = lane >> 4;
     const int Tp = a.Tp;
     const FsnSbInput& x = a.xin;
+    auto stamp = [&](int cl, int t, int e) {
+        if constexpr ((ABL & 4096) != 0) {
+            if (cl == 0 && threadIdx.x == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                a.dbg[(((size_t)LAYER * GM + member) * (Tp + 1) + t) * 8 + e] = (unsigned long long)wall_clock64();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
     // byte offset of the tile that holds h0_t / h1_t inside hx0 / hx1
     const unsigned step_bytes = TRAIN ? (unsigned)a.Nrows * GH * 4u : 0u;
     auto slot0 = [&](int t) { return TRAIN ? (unsigned)t * step_bytes : (unsigned)((t % GD0) * GROWS * GH * 4); };
@@ -243,7 +266,8 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
             for (int j = 0; j < GU; ++j) {
                 const int f = wave * GU + j, u = f >> 2, g = f & 3;
                 const unsigned ofs = bb + ((unsigned)(g * GKC + member * GU + u) * cs + (unsigned)kk) * 256u;
-                bn[j] = fsn_load_wfrag<AR>(wrsrc, (unsigned)lane, ofs);
+                if constexpr ((ABL & 128) != 0 && AR == FSN_ARITH_F32) bn[j] = f32x4{0.01f, 0.02f, -0.01f, 0.005f};
+                else bn[j] = fsn_load_wfrag<AR>(wrsrc, (unsigned)lane, ofs);
             }
         };
 #pragma unroll
@@ -254,10 +278,14 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
         for (int c = 0; c < CPS; ++c) {
             fetch_b(c);
 #pragma unroll
-            for (int j = 0; j < GU; ++j) bsh[0][c * GU * 4 + wave * GU + j][lane] = bn[j];
+            for (int j = 0; j < GU; ++j)
+                if (!(ABL & 256)) bsh[0][c * GU * 4 + wave * GU + j][lane] = bn[j];
         }
-        __syncthreads();
+        if (!(ABL & 256)) __syncthreads();
         for (int k0 = 0; k0 < n; k0 += AD) {
+            if constexpr ((ABL & 8192) != 0 && LAYER == 0) {  // experiment: layer 0 issues first in the tail of its K loop
+                if (k0 == FSN_GRP_BOOST) __builtin_amdgcn_s_setprio(3);
+            }
 #pragma unroll
             for (int d = 0; d < AD; ++d) {
                 const int k = k0 + d;
@@ -273,7 +301,10 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
                         for (int u = 0; u < GU; ++u) {
                             f32x4 b[4];
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) b[g] = bsh[buf][c * GU * 4 + u * 4 + g][lane];
+                            for (int g = 0; g < 4; ++g) {
+                                if constexpr ((ABL & 256) != 0) b[g] = bn[(u + g) % GU];
+                                else b[g] = bsh[buf][c * GU * 4 + u * 4 + g][lane];
+                            }
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -288,12 +319,13 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
                                 acc[u][g] = fsn_mma_k16<AR>(ao, fsn_wfrag_operand<AR>(bsh[buf][c * GU * 4 + u * 4 + g][lane]), acc[u][g]);
                     }
 #pragma unroll
-                    for (int j = 0; j < GU; ++j) bsh[buf ^ 1][c * GU * 4 + wave * GU + j][lane] = bn[j];
-                    if (c == CPS - 1) __syncthreads();
+                    for (int j = 0; j < GU; ++j)
+                        if (!(ABL & 256)) bsh[buf ^ 1][c * GU * 4 + wave * GU + j][lane] = bn[j];
+                    if (c == CPS - 1 && !(ABL & 256)) __syncthreads();
                 }
             }
         }
-        if (n % CPS) __syncthreads();  // a last, partial stage (layer 0's 2 + 24 chunks at four per stage): close it as well
+        if (n % CPS && !(ABL & 256)) __syncthreads();  // a last, partial stage (layer 0's 2 + 24 chunks at four per stage): close it as well
     };
 
     // Flags are looked at EARLY (before a K loop) and checked after it: in the steady state the early look already
@@ -364,6 +396,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
             // requested now, divided after the wait below
             float raw[8];
             f32x4 acc[GU][4];
+            stamp(k.cluster, t, 0);
             const float den = (k.row_ok && !TRAIN) ? x.den[x.den_mode ? (long)t * x.den_stride + k.ng : (long)k.xb] : 1.f;
             if (GX) {  // the projection tiles of this wave's rows at frame t (bias included): requested before the wait
                 const int tile = k.cluster * (GROWS / 16) + (k.tile_ok ? wave : 0);
@@ -393,6 +426,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
                 }
             }
             if (t > 0) wait_peeked(peek(k.fl0), k.fl0, (unsigned)t);  // h0_{t-1} of all members (just published: polls)
+            stamp(k.cluster, t, 1);
             f32x4 xa[2];
             if (!GX) {
 #pragma unroll
@@ -410,14 +444,28 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
                     }
             }
             const unsigned ring = t >= GD0 ? peek(k.fl1) : 0xffffffffu;
+            if constexpr ((ABL & 2048) != 0) {  // experiment: layer 0 issues first while it is less than two steps ahead
+                unsigned v = lane < GM ? __hip_atomic_load(k.fl1 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                v = min(v, (unsigned)__shfl_xor((int)v, 1, 64));
+                v = min(v, (unsigned)__shfl_xor((int)v, 2, 64));
+                v = min(v, (unsigned)__shfl_xor((int)v, 4, 64));
+                const int done1 = __builtin_amdgcn_readfirstlane((int)v);  // steps layer 1 has published
+                if (t - done1 < FSN_GRP_LEAD) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(0);
+            }
             if (!GX) kloop(acc, xa, k.xrsrc0, 0, a.o_wih0, 2, 2, k.xrsrc0, t > 0 ? slot0(t - 1) : 0u, a.o_whh0, GKC, t > 0 ? GKC : 0);
             else if (t > 0) kloop(acc, nullptr, k.xrsrc0, 0, 0, 0, 0, k.xrsrc0, slot0(t - 1), a.o_whh0, GKC, GKC);
             // slot t % GD0 still holds h0_{t-GD0}: layer 1 must have finished its step t - GD0 (it reads that slot
             // there) - all eight layer-1 members, i.e. they have published step t - GD0 + 1
+            stamp(k.cluster, t, 2);
             if (t >= GD0) wait_peeked(ring, k.fl1, (unsigned)(t - GD0 + 1));
+            stamp(k.cluster, t, 3);
             cell(k, acc, reinterpret_cast<float*>(reinterpret_cast<char*>(k.hx0) + slot0(t)),
                  TRAIN ? a.gates0 + (size_t)t * a.Nrows * 4 * GH : nullptr, TRAIN ? a.cseq0 + (size_t)t * a.Nrows * GH : nullptr);
+            stamp(k.cluster, t, 4);
             publish(k.fl0 + member, (unsigned)t + 1);
+            if constexpr ((ABL & 8192) != 0) __builtin_amdgcn_s_setprio(0);
+            stamp(k.cluster, t, 5);
             if (TRAIN && SAVE) save_cell(k, acc, a.gates0 + (size_t)t * a.Nrows * 4 * GH, a.cseq0 + (size_t)t * a.Nrows * GH);
         };
         GrpCl ka, kb;
@@ -438,8 +486,10 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
             // iteration s = Tp only computes the output layer of the last step.
             f32x4 acc[GU][4];
             unsigned seen1 = 0xffffffffu;
+            stamp(k.cluster, s, 0);
             if (s < Tp) {
                 wait_peeked(k.seen0, k.fl0, (unsigned)s + 1);
+                stamp(k.cluster, s, 1);
                 seen1 = peek(k.fl1);
 #pragma unroll
                 for (int u = 0; u < GU; ++u)
@@ -452,8 +502,10 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
             } else {
                 seen1 = peek(k.fl1);
             }
+            stamp(k.cluster, s, 2);
             if (s > 0) {
                 wait_peeked(seen1, k.fl1, (unsigned)s);  // h1_{s-1} of all members
+                stamp(k.cluster, s, 3);
                 // Output layer (nn.Linear(384, 2)) of step s - 1 for rows 8 m .. 8 m + 7 of the cluster, from h1_{s-1} as
                 // it has just been gathered: 16 dot products x 16 threads (~1 us, covered by the layer-0 workgroup
                 // that shares the CU)
@@ -485,13 +537,17 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
                 }
             }
             k.seen0 = peek(k.fl0);  // for the next step: layer 0 is ahead, this usually shows s + 2 already
+            stamp(k.cluster, s, 4);
             if (s > 0 && s < Tp)
                 kloop(acc, nullptr, k.xrsrc1, slot1(s - 1), a.o_whh1, GKC, GKC, k.xrsrc1, 0, 0, 0, 0);
+            stamp(k.cluster, s, 5);
             if (s < Tp) {
                 // slot s & 1 held h1_{s-2}: read by every member in step s - 1, which they have left (flag1 >= s above)
                 cell(k, acc, reinterpret_cast<float*>(reinterpret_cast<char*>(k.hx1) + slot1(s)),
                      TRAIN ? a.gates1 + (size_t)s * a.Nrows * 4 * GH : nullptr, TRAIN ? a.cseq1 + (size_t)s * a.Nrows * GH : nullptr);
+                stamp(k.cluster, s, 6);
                 publish(k.fl1 + member, (unsigned)s + 1);
+                stamp(k.cluster, s, 7);
                 if (TRAIN && SAVE) save_cell(k, acc, a.gates1 + (size_t)s * a.Nrows * 4 * GH, a.cseq1 + (size_t)s * a.Nrows * GH);
             }
         };
@@ -510,7 +566,7 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
 }
 
 template <int ABL, bool TRAIN = false, int NCL = 1, bool SAVE = TRAIN, int AR = FSN_ARITH_F32>
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void lstm2_group_kernel(const GrpArgs a) {
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(FSN_GRP_VGPR))) void lstm2_group_kernel(const GrpArgs a) {
     // weight fragments of one K chunk, shared by the four waves: two stages x 12 fragments x 1 KB
     __shared__ typename FsnWFrag<AR>::type bsh[2][GU * 4 * grp_cps<AR>()][64];
     __shared__ float bias_sh[GU * 4][16];
@@ -525,7 +581,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void 
     const int bid = (int)blockIdx.x - layer * half;
     const int slots = half / GM;
     int slot, member;
-    if (slots % 8 == 0) {
+    if ((ABL & 512) && slots % 8 == 0) {
+        member = bid & 7;
+        slot = bid >> 3;
+    } else if (slots % 8 == 0) {
         const int xcd = bid & 7, j = bid >> 3;  // j-th block of that XCD
         slot = xcd * (slots / 8) + j / GM;
         member = j % GM;
@@ -536,7 +595,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void 
     const int cluster = slot, cluster_b = slot + slots < a.nclusters ? slot + slots : -1;
     // Layer 1 is the longer dependent chain (K = 768 per step against 416) and layer 0 is throttled to stay within
     // GD0 - 2 steps of it: layer 1's waves issue first, layer 0's fill the gaps.
-    if (layer == 1 && !(ABL & 64)) __builtin_amdgcn_s_setprio(2);
+    if ((ABL & 1024) && layer == 0) __builtin_amdgcn_s_setprio(2);
+    else if ((ABL & 2048) && layer == 1) __builtin_amdgcn_s_setprio(1);
+    else if (!(ABL & (1024 | 2048)) && layer == 1 && !(ABL & 64)) __builtin_amdgcn_s_setprio(2);
     if (layer == 0) group_body<0, ABL, TRAIN, NCL, SAVE, AR>(a, cluster, cluster_b, member, bsh, bias_sh);
     else group_body<1, ABL, TRAIN, NCL, SAVE, AR>(a, cluster, cluster_b, member, bsh, bias_sh);
 }
@@ -544,7 +605,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void 
 // Several independent two-layer stacks (weight sets) in one launch, GX form: workgroup set `slot` serves cluster `slot`
 // of the launch, which belongs to the set whose cluster range contains it.
 template <int ABL>
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(108))) void lstm2_group_multi_kernel(const GrpArgs a0,
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(FSN_GRP_VGPR))) void lstm2_group_multi_kernel(const GrpArgs a0,
                                                                                                           const GrpSets sets) {
     __shared__ typename FsnWFrag<FSN_ARITH_F32>::type bsh[2][GU * 4 * FSN_GRP_CPS][64];
     __shared__ float bias_sh[GU * 4][16];

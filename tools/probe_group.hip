@@ -2,6 +2,8 @@
 // ABL, see the kernel) on random operands at the shape of an 8-utterance shard (32 clusters, 190 steps).
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
+#include <algorithm>
 #include "../fullsubnet_amd/csrc/lstm_group_kernels.hip"
 void fsn_set_error(const char*, ...) {}
 bool fsn_persistent_allowed() { return true; }
@@ -57,6 +59,55 @@ int main(int argc, char** argv) {
     a.bias1 = bias + 4 * H; a.hx0 = ex; a.hx1 = ex + (size_t)clusters * GD0 * 64 * H; a.flags = flags; a.status = flags + (size_t)clusters * 2 * GFS; a.spin_ticks = 1ull << 31;
     a.fc.w_p = fcw; a.fc.bias = fcb; a.fc.crm_r = cr; a.fc.crm_i = ci; a.fc.N = a.xin.N; a.fc.F = F; a.fc.FP = FP; a.fc.T = T; a.fc.la = 2;
     a.Tp = Tp;
+    if (argc > 3) {  // timeline of cluster 0: clock stamps at the phase boundaries of every step (ABL 4096)
+        const size_t nd = (size_t)2 * GM * (Tp + 1) * 8;
+        hipMalloc(&a.dbg, nd * 8); hipMemset(a.dbg, 0, nd * 8);
+        const float ms = atoi(argv[3]) == 1 ? run<4096 + 8192>(a, clusters, fw) : run<4096>(a, clusters, fw);
+        std::vector<unsigned long long> d(nd);
+        hipMemcpy(d.data(), a.dbg, nd * 8, hipMemcpyDeviceToHost);
+        int rate_khz = 100000; hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, 0);
+        const double us = 1e3 / rate_khz;
+        auto D = [&](int l, int m, int t, int e) { return (double)(long long)(d[(((size_t)l * GM + m) * (Tp + 1) + t) * 8 + e] - d[0]) * us; };
+        printf("timeline run: %.3f ms, clock %d kHz\n", ms, rate_khz);
+        const int t0 = 40, t1 = Tp - 20;
+        const char* n0[] = {"input loads + wait h0[t-1]", "K loop (416)", "ring wait", "cell + stores", "publish (drain + flag)", "to next start"};
+        const char* n1[] = {"wait h0[s]", "K loop 1 (384, x W_ih)", "wait h1[s-1]", "output layer", "K loop 2 (384, h W_hh)", "cell + stores", "publish", "to next start"};
+        for (int l = 0; l < 2; ++l) {
+            const int ne = l ? 8 : 6;
+            printf("layer %d, mean phase durations over steps %d..%d [us], members 0..7 and their mean:\n", l, t0, t1);
+            double tot = 0;
+            for (int e = 0; e < ne; ++e) {
+                double mm = 0;
+                printf("  %-28s", l ? n1[e] : n0[e]);
+                for (int m = 0; m < GM; ++m) {
+                    double acc = 0;
+                    for (int t = t0; t < t1; ++t) acc += (e + 1 < ne ? D(l, m, t, e + 1) : D(l, m, t + 1, 0)) - D(l, m, t, e);
+                    acc /= (t1 - t0); mm += acc / GM;
+                    printf(" %6.2f", acc);
+                }
+                printf("  | %6.2f\n", mm); tot += mm;
+            }
+            printf("  period %.2f us\n", tot);
+        }
+        // hand-off latencies: from the LAST member's publish-done stamp to a consumer's wait-passed stamp
+        double h00 = 0, h01 = 0, h11 = 0, lead = 0;
+        for (int t = t0; t < t1; ++t) {
+            double p0 = -1e30, p0p = -1e30, p1p = -1e30, w0 = 0, w1 = 0, w11 = 0;
+            for (int m = 0; m < GM; ++m) { p0 = std::max(p0, D(0, m, t, 5)); p0p = std::max(p0p, D(0, m, t - 1, 5)); p1p = std::max(p1p, D(1, m, t - 1, 7)); }
+            for (int m = 0; m < GM; ++m) { w0 += D(0, m, t, 1) / GM; w1 += D(1, m, t, 1) / GM; w11 += D(1, m, t, 3) / GM; }
+            h00 += w0 - p0p; h01 += w1 - p0; h11 += w11 - p1p;
+            lead += D(1, 0, t, 0) - D(0, 0, t, 0);
+        }
+        const int n = t1 - t0;
+        printf("mean [us]: L0 wait passed - last publish of h0[t-1]: %.2f; L1 wait passed - last publish of h0[s]: %.2f; L1 wait passed - last publish of h1[s-1]: %.2f; L1 starts step s this long after L0 started step s: %.2f\n", h00 / n, h01 / n, h11 / n, lead / n);
+        printf("steps 100..102 of member 0 (us from step 100's layer-0 start):\n");
+        const double o = D(0, 0, 100, 0);
+        for (int t = 100; t < 103; ++t) {
+            printf("  L0 t=%d:", t); for (int e = 0; e < 6; ++e) printf(" %7.2f", D(0, 0, t, e) - o); printf("\n");
+            printf("  L1 s=%d:", t); for (int e = 0; e < 8; ++e) printf(" %7.2f", D(1, 0, t, e) - o); printf("\n");
+        }
+        return 0;
+    }
     const double mfma_us = 2.0 * 64 * (1536.0 / 8) * (416 + 768) / (64.0 * 4 * 2.4e3);  // per iteration and CU at 2.4 GHz
     const float t0 = run<0>(a, clusters, fw);
     unsigned st = 0; hipMemcpy(&st, a.status, 4, hipMemcpyDeviceToHost);
@@ -69,6 +120,16 @@ int main(int argc, char** argv) {
     printf("  without A-fragment loads     : %.3f ms\n", run<32>(a, clusters, fw));
     printf("  without layer-1 priority     : %.3f ms\n", run<64>(a, clusters, fw));
     printf("  without all of them          : %.3f ms\n", run<63>(a, clusters, fw));
+    printf("  weight fragments not loaded  : %.3f ms\n", run<128>(a, clusters, fw));
+    printf("  no weight loads, no LDS stage: %.3f ms\n", run<384>(a, clusters, fw));
+    printf("  all of them + no weight loads: %.3f ms\n", run<63 + 128>(a, clusters, fw));
+    printf("  all + no loads + no LDS stage: %.3f ms\n", run<63 + 384>(a, clusters, fw));
+    printf("  members share an XCD         : %.3f ms\n", run<512>(a, clusters, fw));
+    printf("  ... + without A loads        : %.3f ms\n", run<512 + 32>(a, clusters, fw));
+    printf("  ... + without all of them    : %.3f ms\n", run<512 + 63>(a, clusters, fw));
+    printf("  layer 0 has the priority     : %.3f ms\n", run<1024>(a, clusters, fw));
+    printf("  dynamic priority of layer 0  : %.3f ms\n", run<2048>(a, clusters, fw));
+    printf("  layer 0 boosted in its tail  : %.3f ms\n", run<8192>(a, clusters, fw));
     printf("  shipped again                : %.3f ms\n", run<0>(a, clusters, fw));
     return 0;
 }
