@@ -70,35 +70,56 @@ __device__ __forceinline__ void fft8(cd* v) {
     v[6] = t3;
 }
 
+// LDS index of point i: one double of padding per eight.  The radix-8 passes store with strides of 8 and 64 doubles
+// (16- and 8-way bank conflicts on 8-byte accesses unpadded); with the padding a half-wave's stores fall on distinct banks.
+__device__ __forceinline__ int lpad(int i) { return i + (i >> 3); }
+constexpr int kLdsPoints = 512 + 64;
+
 // One Stockham radix-8 pass of a 512-point FFT held by one wave (lane j owns butterfly j).
 // v holds in[j + 64 r]; on return the outputs are written to (sre, sim) in the pass's order.
 template <bool INV, int NS>
 __device__ __forceinline__ void pass8(cd* v, double* sre, double* sim, int j) {
     const int k = j % NS;
     if (NS > 1) {
-#pragma unroll
-        for (int r = 1; r < 8; ++r) {
-            double s, c;
-            // angle = -+ 2 pi r k / (8 NS)  ->  sincospi(-+ r k / (4 NS))
-            sincospi((INV ? 1.0 : -1.0) * (double)(r * k) / (double)(4 * NS), &s, &c);
-            v[r] = cmul(v[r], cd{c, s});
-        }
+        // twiddle r = w^r with w = e^{-+ 2 pi i k / (8 NS)}: ONE sincospi per lane and pass, the powers by fp64 products
+        // (a few 1e-16 relative: 2^-29 of an fp32 ULP).  Seven sincospi per pass made these kernels compute-bound on the
+        // fp64 vector pipe (35 us for 49 MB, round 6); the transform is a streaming stage.
+        double s, c;
+        sincospi((INV ? 1.0 : -1.0) * (double)k / (double)(4 * NS), &s, &c);
+        const cd w1{c, s};
+        const cd w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+        const cd w5 = cmul(w4, w1), w6 = cmul(w3, w3), w7 = cmul(w4, w3);
+        v[1] = cmul(v[1], w1);
+        v[2] = cmul(v[2], w2);
+        v[3] = cmul(v[3], w3);
+        v[4] = cmul(v[4], w4);
+        v[5] = cmul(v[5], w5);
+        v[6] = cmul(v[6], w6);
+        v[7] = cmul(v[7], w7);
     }
     fft8<INV>(v);
     const int j0 = (j / NS) * NS * 8 + k;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        sre[j0 + r * NS] = v[r].x;
-        sim[j0 + r * NS] = v[r].y;
+        sre[lpad(j0 + r * NS)] = v[r].x;
+        sim[lpad(j0 + r * NS)] = v[r].y;
     }
 }
 
 __device__ __forceinline__ void load8(cd* v, const double* sre, const double* sim, int j) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = cd{sre[j + 64 * r], sim[j + 64 * r]};
+    for (int r = 0; r < 8; ++r) v[r] = cd{sre[lpad(j + 64 * r)], sim[lpad(j + 64 * r)]};
 }
 
 constexpr int kWavesPerBlock = 4;
+
+// A wave exchanges its points through ITS OWN LDS region: LDS instructions of one wave execute in order, so the passes
+// need no workgroup barrier - only the compiler must keep the order (fences at wavefront scope emit no instruction).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // ---------------------------------------------------------------------------------------------
 // y [B][L] -> re, im [B][T][FP] (frame-major) or [B][F][T] (reference layout); mag likewise, with
@@ -110,7 +131,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ y, 
                                                    float* __restrict__ re, float* __restrict__ im,
                                                    float* __restrict__ mag, int B, int L, int T, int Tp, int F,
                                                    int FP) {
-    __shared__ double lds[kWavesPerBlock][2][512];
+    __shared__ double lds[kWavesPerBlock][2][kLdsPoints];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pairs_per_b = (Tp + 1) >> 1;
     const long p = (long)blockIdx.x * kWavesPerBlock + wave;
@@ -141,15 +162,15 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ y, 
         v[r] = cd{(double)xa, (double)xb};
     }
     pass8<false, 1>(v, sre, sim, lane);
-    __syncthreads();
+    wave_lds_sync();
     load8(v, sre, sim, lane);
-    __syncthreads();
+    wave_lds_sync();
     pass8<false, 8>(v, sre, sim, lane);
-    __syncthreads();
+    wave_lds_sync();
     load8(v, sre, sim, lane);
-    __syncthreads();
+    wave_lds_sync();
     pass8<false, 64>(v, sre, sim, lane);
-    __syncthreads();
+    wave_lds_sync();
 
     if (!live) return;
     // split: X_A[k] = (Z[k] + conj Z[N-k]) / 2 ; X_B[k] = (Z[k] - conj Z[N-k]) / (2i)
@@ -160,7 +181,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ y, 
         float ar = 0.f, ai = 0.f, br = 0.f, bi = 0.f;
         if (k < F) {
             const int kn = (512 - k) & 511;
-            const double zr = sre[k], zi = sim[k], wr = sre[kn], wi = sim[kn];
+            const double zr = sre[lpad(k)], zi = sim[lpad(k)], wr = sre[lpad(kn)], wi = sim[lpad(kn)];
             ar = (float)(0.5 * (zr + wr));
             ai = (float)(0.5 * (zi - wi));
             br = (float)(0.5 * (zi + wi));
@@ -219,7 +240,7 @@ __global__ __launch_bounds__(256) void mask_irfft_kernel(const float* __restrict
                                                          const float* __restrict__ crm_i,
                                                          const float* __restrict__ window,
                                                          float* __restrict__ wframes, int B, int T, int F, int FP) {
-    __shared__ double lds[kWavesPerBlock][2][512];
+    __shared__ double lds[kWavesPerBlock][2][kLdsPoints];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pairs_per_b = (T + 1) >> 1;
     const long p = (long)blockIdx.x * kWavesPerBlock + wave;
@@ -255,34 +276,34 @@ __global__ __launch_bounds__(256) void mask_irfft_kernel(const float* __restrict
             s[1][1] = 0.f;
         }
         const double ar = s[0][0], ai = s[0][1], br = s[1][0], bi = s[1][1];
-        sre[k] = ar - bi;
-        sim[k] = ai + br;
+        sre[lpad(k)] = ar - bi;
+        sim[lpad(k)] = ai + br;
         if (k > 0 && k < 256) {
-            sre[512 - k] = ar + bi;
-            sim[512 - k] = br - ai;
+            sre[lpad(512 - k)] = ar + bi;
+            sim[lpad(512 - k)] = br - ai;
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     cd v[8];
     load8(v, sre, sim, lane);
-    __syncthreads();
+    wave_lds_sync();
     pass8<true, 1>(v, sre, sim, lane);
-    __syncthreads();
+    wave_lds_sync();
     load8(v, sre, sim, lane);
-    __syncthreads();
+    wave_lds_sync();
     pass8<true, 8>(v, sre, sim, lane);
-    __syncthreads();
+    wave_lds_sync();
     load8(v, sre, sim, lane);
-    __syncthreads();
+    wave_lds_sync();
     pass8<true, 64>(v, sre, sim, lane);
-    __syncthreads();
+    wave_lds_sync();
     if (!live) return;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int n = lane + 64 * r;
         const float w = window[n];
-        const float fa = (float)(sre[n] * (1.0 / 512.0));
-        const float fb = (float)(sim[n] * (1.0 / 512.0));
+        const float fa = (float)(sre[lpad(n)] * (1.0 / 512.0));
+        const float fb = (float)(sim[lpad(n)] * (1.0 / 512.0));
         if (tA < T) wframes[((long)b * T + tA) * 512 + n] = fa * w;
         if (tB < T) wframes[((long)b * T + tB) * 512 + n] = fb * w;
     }

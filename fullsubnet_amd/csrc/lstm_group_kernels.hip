@@ -251,6 +251,14 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
         auto fetch_a = [&](int k) -> f32x4 {
             const int kc = k < n ? k : n - 1;
             if (ABL & 32) return f32x4{0.5f, 0.25f, 0.125f, 0.0625f};
+            if constexpr ((ABL & 16384) != 0) {  // experiment (wrong data): a wave's fragment as ONE contiguous 1 KB block of the tile
+                const unsigned fo = (unsigned)lane * 16u, blk = (unsigned)wave * 1024u;
+                if (kc < n1) {
+                    if (xa) return kc == 0 ? xa[0] : xa[1];
+                    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, fo, at1 + (unsigned)kc * 4096u + blk, 16));
+                }
+                return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2, fo, at2 + (unsigned)(kc - n1) * 4096u + blk, 16));
+            }
             if (kc < n1) {
                 if (xa) return kc == 0 ? xa[0] : xa[1];
                 return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, a_off, at1 + (unsigned)kc * 64u, 16));

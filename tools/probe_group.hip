@@ -129,6 +129,7 @@ int main(int argc, char** argv) {
     printf("  ... + without all of them    : %.3f ms\n", run<512 + 63>(a, clusters, fw));
     printf("  layer 0 has the priority     : %.3f ms\n", run<1024>(a, clusters, fw));
     printf("  dynamic priority of layer 0  : %.3f ms\n", run<2048>(a, clusters, fw));
+    printf("  A fragments as 1 KB blocks   : %.3f ms\n", run<16384>(a, clusters, fw));
     printf("  layer 0 boosted in its tail  : %.3f ms\n", run<8192>(a, clusters, fw));
     printf("  shipped again                : %.3f ms\n", run<0>(a, clusters, fw));
     return 0;
