@@ -300,9 +300,15 @@ __device__ __forceinline__ void group_body(const GrpArgs& a, int cluster_a, int 
                 if (k < n) {  // uniform (n is a multiple of CPS)
                     const int c = d % CPS, buf = (k / CPS) & 1;
                     __builtin_amdgcn_sched_barrier(0);  // requests first, pinned under this chunk's MFMAs
-                    fetch_b(k + CPS);                   // the same chunk of the next stage
                     const f32x4 av = ar[d];
-                    ar[d] = fetch_a(k + AD);
+                    if constexpr ((ABL & 32768) != 0) {  // experiment: the A request first (the wait for the weight fragments then covers it)
+                        ar[d] = fetch_a(k + AD);
+                        __builtin_amdgcn_sched_barrier(0);
+                        fetch_b(k + CPS);
+                    } else {
+                        fetch_b(k + CPS);                   // the same chunk of the next stage
+                        ar[d] = fetch_a(k + AD);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (AR == FSN_ARITH_F32) {
 #pragma unroll

@@ -130,6 +130,8 @@ int main(int argc, char** argv) {
     printf("  layer 0 has the priority     : %.3f ms\n", run<1024>(a, clusters, fw));
     printf("  dynamic priority of layer 0  : %.3f ms\n", run<2048>(a, clusters, fw));
     printf("  A fragments as 1 KB blocks   : %.3f ms\n", run<16384>(a, clusters, fw));
+    printf("  A request before the weights : %.3f ms\n", run<32768>(a, clusters, fw));
+    printf("  ... with members per XCD     : %.3f ms\n", run<32768 + 512>(a, clusters, fw));
     printf("  layer 0 boosted in its tail  : %.3f ms\n", run<8192>(a, clusters, fw));
     printf("  shipped again                : %.3f ms\n", run<0>(a, clusters, fw));
     return 0;
