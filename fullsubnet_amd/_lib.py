@@ -83,7 +83,7 @@ class TrainDims(ctypes.Structure):  # fsn_train_dims
                 ("nb", ctypes.c_int), ("groups", ctypes.c_int), ("norm", ctypes.c_int)]
 
 
-ABI_VERSION = 113  # FSN_ABI_VERSION of include/fsn_hip.h these signatures were written against
+ABI_VERSION = 114  # FSN_ABI_VERSION of include/fsn_hip.h these signatures were written against
 
 
 class MaskSection(ctypes.Structure):  # fsn_mask_section
@@ -136,6 +136,7 @@ SIGNATURES = {
                                           _c.c_void_p]),
     "fsn_lstm_layer_bwd_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "fsn_lstm2_train_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "fsn_lstm2_train_is_persistent": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "fsn_lstm2_forward_train": (_c.c_int, [_f32p, _c.c_long] + [_f32p] * 8 + [_c.c_int] * 4 + [_f32p, _f32p, _c.c_void_p,
                                            _c.c_void_p, _c.c_size_t, _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_void_p]),
     "fsn_lstm2_bwd_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),

@@ -2035,6 +2035,11 @@ static Lstm2TrainPlan lstm2_train_plan(int T, int N, int I, int H) {
     return p;
 }
 static int lstm2_train_group_clusters(int T, int N, int I, int H) { return lstm2_train_plan(T, N, I, H).fwd_group; }
+extern "C" int fsn_lstm2_train_is_persistent(int T, int N, int I, int H) {
+    if (T < 1 || N < 16 || N % 16 || I < 1 || H < 1) return 0;
+    const Lstm2TrainPlan p = lstm2_train_plan(T, N, I, H);
+    return ((p.fwd_group > 0 || p.fwd_chain) && (p.bptt_group > 0 || p.bptt_chain)) ? 1 : 0;
+}
 // the 16-bit arithmetic has kernels of its own for the group shapes (lstm_group16_kernels.hip) when they take the same
 // clusters; the flag array is sized for either family
 static bool lstm2_use_g16(int arith, int clusters, int N) {

@@ -210,6 +210,11 @@ class Model(BaseModel):
                 return torch.cat([self.forward(mix_mag[i:i + chunk]) for i in range(0, mix_mag.shape[0], chunk)], dim=0)
             if self._rows_path_ok(mix_mag):
                 return self._forward_rows(mix_mag)
+        if torch.is_grad_enabled():
+            # the trainer's arithmetic (Model.train_arithmetic: "f16" under use_amp = true, train_shrinkSize2.toml:5) reaches
+            # the bottleneck, 90 % of the step's products; the encoder / decoder blocks (72 rows) stay fp32
+            from .train import train_arith_of
+            self.bottleneck.train_arithmetic = train_arith_of(self)
         mag = look_ahead_pad(mix_mag, self.look_ahead)
         n_batch, _, n_bins, n_frames = mag.shape
         mel = self.mel_scale(mag)                                                         # [B, 1, M, T]

@@ -246,13 +246,25 @@ class SequenceModel(nn.Module):
         return o if rows_out else from_rows(o, B)
 
     def _forward_train(self, x):
-        from .train import GruLayerFunction, LinearFunction, LstmLayerFunction
+        from .train import GruLayerFunction, LinearFunction, LstmLayerFunction, lstm2_rows_chunked, lstm2_train_chunks
         H, Hp = self.hidden_size, _round_up(self.hidden_size, 64)
         layer = LstmLayerFunction if self.cell == "LSTM" else GruLayerFunction
         h = x.permute(2, 0, 1)  # [T, B, F]
-        for k in range(self.num_layers):
-            in_pad = self.input_size if k == 0 else Hp
-            h = layer.apply(h, *pad_lstm_weights(*self._layer_tensors(k), in_pad))
+        # ``train_arithmetic`` (set by the owning model from Model.train_arithmetic = the trainer's use_amp): under the 16-bit
+        # autocast arithmetic a two-layer stack of the group kernels' width runs on the persistent training kernels, in
+        # pieces of whole clusters when it has more rows than one launch holds (Fast FullSubNet's bottleneck: 3 x 1536 rows
+        # at the shipped batch of 72); fp32 and every other shape layer by layer as before
+        arith = getattr(self, "train_arithmetic", "f32")
+        chunks = None
+        if self.cell == "LSTM" and self.num_layers == 2 and arith != "f32" and Hp == H:
+            chunks = lstm2_train_chunks(h.shape[0], h.shape[1], h.shape[2], H)
+        if chunks is not None:
+            params = [t for k in (0, 1) for t in self._layer_tensors(k)]
+            h = lstm2_rows_chunked(h, params, arith, *chunks)
+        else:
+            for k in range(self.num_layers):
+                in_pad = self.input_size if k == 0 else Hp
+                h = layer.apply(h, *pad_lstm_weights(*self._layer_tensors(k), in_pad))
         h = h[..., :H]
         relu = self.output_activate_function == "ReLU"
         if self.output_size:

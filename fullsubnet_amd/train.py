@@ -247,6 +247,38 @@ class LinearFunction(torch.autograd.Function):
         return (dx[:, :I].reshape(*lead, I) if need_dx else None), dw, db, None
 
 
+LSTM2_CHUNK_ROWS = 2048  # one persistent launch of the group kernels: 32 clusters of 64 rows (two workgroups per CU)
+
+
+def lstm2_train_chunks(T, N, I, H):
+    """Rows per piece, number of pieces - or None - for a two-layer LSTM stack with MORE rows than one persistent launch of
+    the training kernels holds (fsn_lstm2_forward_train / fsn_lstm2_backward: the group kernels take 96 - 128 row tiles in
+    whole 64-row clusters).  The rows of a stack are independent sequences (sequence_model.py:52-58), so N rows run as
+    equal pieces of whole clusters; the weight gradients of the pieces add up in autograd.  Fast FullSubNet's bottleneck
+    (fast_fullsubnet/model.py:66-74; train_shrinkSize2.toml:52: 72 utterances x 64 bands = 4608 rows) is 3 x 1536."""
+    if I > 32 or N < 1:
+        return None
+    L = _lib.lib()
+    n0 = -(-N // LSTM2_CHUNK_ROWS)
+    for n in (n0, n0 + 1):
+        rows = (-(-N // n) + 63) // 64 * 64
+        if L.fsn_lstm2_train_is_persistent(T, rows, 32, H) == 1:
+            return rows, n
+    return None
+
+
+def lstm2_rows_chunked(x_tn, params, arith, rows, n):
+    """x_tn [T, N, I] (I <= 32) -> [T, N, H] through ``n`` Lstm2Function calls of ``rows`` rows each; the input is zero-padded
+    to 32 columns (the group kernels' two K chunks; W_ih0 gets zero columns) and to n * rows rows."""
+    import torch.nn.functional as F
+    T, N, I = x_tn.shape
+    w_ih0, rest = params[0], params[1:]
+    xp = F.pad(x_tn, (0, 32 - I, 0, n * rows - N))
+    w_ih0p = F.pad(w_ih0, (0, 32 - I))
+    outs = [Lstm2Function.apply(xp[:, k * rows:(k + 1) * rows], w_ih0p, *rest, arith) for k in range(n)]
+    return torch.cat(outs, dim=1)[:, :N]
+
+
 def lstm_stack(x_tn, lstm, arith="f32"):
     """Two stacked layers of an nn.LSTM parameter container on time-major x [T, N, I]."""
     h = x_tn

@@ -59,8 +59,8 @@ extern "C" {
 const char* fsn_last_error(void);
 /* The ABI revision this header describes.  fsn_version() returns the revision the LIBRARY was built with: a caller
  * compares the two once after loading (fullsubnet_amd/_lib.py raises on a mismatch) - argument lists changed between
- * revisions (113: + fsn_gru2_forward; 112: + FSN_ARITH_SAVES16; 111: + the composed families' glue entries; 110: fsn_train_dims.norm, fsn_train_den_elems; 100 -> 101 of round 4: fsn_clip_adam_step's found_inf). */
-#define FSN_ABI_VERSION 113
+ * revisions (114: + fsn_lstm2_train_is_persistent; 113: + fsn_gru2_forward; 112: + FSN_ARITH_SAVES16; 111: + the composed families' glue entries; 110: fsn_train_dims.norm, fsn_train_den_elems; 100 -> 101 of round 4: fsn_clip_adam_step's found_inf). */
+#define FSN_ABI_VERSION 114
 int fsn_version(void);
 
 /* ---- STFT / iSTFT : audio_zen/acoustics/feature.py ------------------------------------- */
@@ -212,6 +212,11 @@ int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_ih, const fl
  * that run on other kernels compute in fp32 (wider than asked for).  Same rule for fsn_lstm2_backward, which then
  * expects dh1 scaled by the caller's loss scale (GradScaler) like any autocast backward. */
 size_t fsn_lstm2_train_workspace_bytes(int T, int N, int I, int H, int arith);
+/* 1 when BOTH directions of this shape run as persistent launches (forward: the group kernel - H = 384, 17 - 32 input
+ * columns, 96+ row tiles in whole 64-row clusters up to 8 left-over tiles - or the chain; backward likewise): the shapes on
+ * which the 16-bit arithmetic has kernels of its own.  Callers with more rows than one launch holds split them into such
+ * pieces (the rows of a stack are independent sequences: sequence_model.py:52-58; fullsubnet_amd.train.lstm2_train_chunks). */
+int fsn_lstm2_train_is_persistent(int T, int N, int I, int H);
 int fsn_lstm2_forward_train(const float* x, long ldx, const float* w_ih0, const float* w_hh0, const float* b_ih0,
                             const float* b_hh0, const float* w_ih1, const float* w_hh1, const float* b_ih1,
                             const float* b_hh1, int T, int N, int I, int H, float* hseq0, float* hseq1, void* save0,

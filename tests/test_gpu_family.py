@@ -619,6 +619,73 @@ def test_sibling_training_step_vs_the_reference(fsn, golden_dir, name):
     assert moved > 0
 
 
+def _fast_train_model(fsn, meta, arith):
+    from fullsubnet_amd.fast_fullsubnet import Model
+    params = MF.make_fast_params(seed=meta["seed_w"], gain=meta["gain"])
+    m = Model(**FAST_KW)
+    sd = {k: torch.from_numpy(v) for k, v in params.items()}
+    sd["mel_scale.fb"] = m.mel_scale.fb.clone()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    m.train_arithmetic = arith
+    return m
+
+
+def _step_distances(model, opt, loss, z, sample):
+    """(loss, total gradient norm, worst parameter tensor's gradient norm) of a step, relative to a golden step's."""
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        gn = float(z["gnorm/" + k])
+        worst = max(worst, (k, abs(float(p.grad.norm()) - gn) / (gn + 1e-30)), key=lambda kv: kv[1])
+    return (abs(loss - float(z["loss"])) / float(z["loss"]),
+            abs(float(opt.total_norm) - float(z["total_norm"])) / float(z["total_norm"]), worst)
+
+
+def test_fast_fullsubnet_amp_step_vs_the_references_own_fp16_autocast_step(fsn, golden_dir):
+    """fast_fullsubnet/train_shrinkSize2.toml:5 trains with use_amp = true.  Under the trainer's 16-bit arithmetic
+    (Model.train_arithmetic = "f16") the bottleneck - two LSTM layers x 384 units on B x 64 rows, 90 % of the step's products -
+    runs on the persistent 16-bit training kernels in pieces of whole clusters (fullsubnet_amd.train.lstm2_train_chunks; here 24
+    utterances = ONE piece of 1536 rows; the shipped batch of 72 = three).  Arbiters, both the reference's own steps at this
+    shape (tests/golden/make_golden_family_train.py --b24): fast_train_b24.npz in fp32 and fast_train_b24_f16.npz under
+    torch.autocast("cpu", float16) + GradScaler (fast_fullsubnet/trainer.py:52-66).  Held: the fp32 step matches the fp32
+    golden like the short sibling golden does; the 16-bit step is closer to the reference's fp32 step than the reference's OWN
+    fp16-autocast step is, and within twice that distance of the fp16-autocast step itself."""
+    from oracle import fullsubnet_oracle as O
+    from fullsubnet_amd.train import lstm2_train_chunks, train_step
+    z32, meta = load(golden_dir, "fast_train_b24")
+    z16, meta16 = load(golden_dir, "fast_train_b24_f16")
+    assert meta16["autocast"] == "torch.float16" and meta16["batch"] == meta["batch"] == 24
+    keys = [k[6:] for k in z32.files if k.startswith("gnorm/")]
+    ref = (abs(float(z16["loss"]) - float(z32["loss"])) / float(z32["loss"]),
+           abs(float(z16["total_norm"]) - float(z32["total_norm"])) / float(z32["total_norm"]),
+           max(abs(float(z16["gnorm/" + k]) - float(z32["gnorm/" + k])) / float(z32["gnorm/" + k]) for k in keys))
+    noisy = torch.from_numpy(O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_noisy"])).cuda()
+    clean = torch.from_numpy((meta["clean_gain"] * O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_clean"]))
+                             .astype(np.float32)).cuda()
+    T = 1 + meta["length"] // 256 + FAST_KW["look_ahead"]
+    Ts = fsn._lib.lib().fsn_fast_low_rate_frames(T, FAST_KW["shrink_size"])
+    assert lstm2_train_chunks(Ts, meta["batch"] * FAST_KW["num_mels"], 12, 384) == (1536, 1)  # the path under test is taken
+    out = {}
+    for arith in ("f32", "f16"):
+        m = _fast_train_model(fsn, meta, arith)
+        opt = fsn.ClipAdam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))
+        scaler = torch.amp.GradScaler("cuda", enabled=arith != "f32")
+        loss = train_step(m, opt, noisy, clean, scaler=scaler).item()
+        assert opt.skipped_steps() == 0
+        for tag, z in (("fp32", z32), ("fp16-autocast", z16)):
+            out[arith, tag] = _step_distances(m, opt, loss, z, meta["sample"])
+            d = out[arith, tag]
+            print(f"{arith} step vs the reference's {tag} step: loss {d[0]:.2e}, total norm {d[1]:.2e}, worst tensor norm "
+                  f"{d[2][1]:.2e} ({d[2][0]})")
+    print(f"the reference's own fp16-autocast step vs its fp32 step: loss {ref[0]:.2e}, total norm {ref[1]:.2e}, worst tensor norm {ref[2]:.2e}")
+    a = out["f32", "fp32"]
+    assert a[0] <= 2e-6 and a[1] <= 5e-5 and a[2][1] <= 5e-4, a          # the bounds of the short sibling golden
+    b = out["f16", "fp32"]
+    assert b[1] <= ref[1] and b[2][1] <= ref[2], (b, ref)                  # closer to fp32 than the reference's fp16 step
+    c = out["f16", "fp16-autocast"]
+    assert c[1] <= 2 * ref[1] and c[2][1] <= 2 * ref[2], (c, ref)          # and within that distance of it
+
+
 @pytest.mark.parametrize("I,H,B,T", [(257, 512, 3, 23), (257, 512, 64, 9), (40, 384, 33, 12), (70, 320, 5, 8)])
 def test_two_gru_layers_with_few_rows_on_the_chain_kernel(fsn, I, H, B, T):
     """nn.GRU(num_layers = 2) of a SequenceModel with few rows (sequence_model.py:59-66: the full-band model of a GRU FullSubNet)
