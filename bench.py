@@ -19,7 +19,7 @@ Prints ONE JSON line (rank 0) with the driver's contract keys plus
                  launch stream; `traffic` / `mfma_busy_frac` from the committed rocprofv3 PMC passes of this config
   cpu_baseline - the reference's ATen operator sequence (oracle/aten_baseline.py) timed on this box's host cores
                  on a bounded sample of the same workload (rank 0, N = 1 only); the numpy oracle as `oracle_port`
-  one_utterance (eager / hipGraph replay latency of one utterance), split_f16x3, train_step, fast_b256, improved48_b32 -
+  one_utterance (eager / hipGraph replay latency of one utterance), split_f16x3, train_step, fast_b256, fast_train_b72_amp, improved48_b32 -
   side figures (N = 1): the opt-in split-precision
                  kernels, one training step at BASELINE config 3's per-rank shape, Fast FullSubNet at batch 256
                  (config 4) and Improved FullSubNet at 48 kHz, batch 32 (config 5).
@@ -408,9 +408,21 @@ def family_figure(which, batch, peak_tflops, device):
     pack = BF.build(which, device)
     m = BF.family_step(which, batch, device=device, steps=5, warmup=2, model_pack=pack)
     check = family_parity(BF, which, batch, pack, device)
+    extra = {}
+    if which == "fast":
+        # BASELINE config 4 names a 1 -> 8 GPU scaling curve: the model has no cross-utterance term, so N ranks take batch / N
+        # utterances each (one all-gather of the waveforms at the end, not in these).  PREDICTED from one rank's share measured
+        # on this one GPU, like `strong_scaling_shares` of config 2.
+        shares = {}
+        for n in (2, 4, 8):
+            ms = BF.family_step(which, batch // n, device=device, steps=5, warmup=2, model_pack=pack)["ms_per_step"]
+            shares[str(n)] = {"utterances_per_rank": batch // n, "ms_per_step": round(ms, 3),
+                              "predicted_speedup": round(m["ms_per_step"] / ms, 2)}
+        extra["strong_scaling_shares"] = {**shares, "note": "PREDICTED: one rank's share of the batch at N ranks, each measured on "
+                                          "this one GPU; excludes the all-gather of the enhanced waveforms"}
     del pack
     torch.cuda.empty_cache()
-    return {**check, "ms_per_step": round(m["ms_per_step"], 3), "value": round(m["frames_per_s"], 1), "unit": "frames/s",
+    return {**check, **extra, "ms_per_step": round(m["ms_per_step"], 3), "value": round(m["frames_per_s"], 1), "unit": "frames/s",
             "rtf_speedup_audio_s_per_s": round(m["rtf"], 1), "batch": batch, "samples": m["samples"],
             "sample_rate": m["sample_rate"], "frames_per_utterance": m["frames_per_utterance"],
             "mflop_per_frame": round(m["mflop_per_frame"], 1), "tflops": round(m["tflops"], 1),
@@ -806,6 +818,20 @@ def main():
                 out[key] = family_figure(which, b, PEAK_FP32_MFMA_TFLOPS, device)
             except Exception as e:
                 out[key] = {"error": str(e)[:200]}
+        # the sibling recipe that ships a training TOML with use_amp = true (fast_fullsubnet/train_shrinkSize2.toml:5,52: batch 72):
+        # its bottleneck on the 16-bit persistent training kernels in pieces of whole clusters
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_family_train as BFT
+            m = BFT.family_train_step("fast", 72, "f16", device=device)
+            out["fast_train_b72_amp"] = {
+                "ms_per_step": round(m["ms_per_step"], 2), "dtype": "f16 operands on the bottleneck (90 % of the products), fp32 elsewhere",
+                "config": "fast_fullsubnet/train_shrinkSize2.toml: 72 x 49152 samples, cIRM MSE + clip_grad_norm_(10) + Adam, GradScaler",
+                "loss": round(m["loss"], 6), "tflops": round(m["tflops"], 1), "skipped_steps": m["skipped_steps"],
+                "parity": "tests/test_gpu_family.py::test_fast_fullsubnet_amp_step_vs_the_references_own_fp16_autocast_step"}
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["fast_train_b72_amp"] = {"error": str(e)[:200]}
         # the launch-bound regime: ONE utterance, eager against a hipGraph replay of the whole call (fullsubnet_amd.GraphedCall)
         try:
             out["one_utterance"] = one_utterance_figure(model, length, device)
