@@ -100,6 +100,8 @@ class Model(nn.Module):
         assert num_channels == 1, f"{self.__class__.__name__} takes the mag feature as inputs."
         assert num_freqs == self.num_freqs
         if not self._fused:
+            if self._composed_rows_ok(noisy_mag):
+                return self._forward_composed_rows(noisy_mag)
             return self._forward_composed(noisy_mag)
         if torch.is_grad_enabled() and (self.training or noisy_mag.requires_grad):
             # training step (fullsubnet/trainer.py:56-63): autograd graph with the LSTM layers
@@ -187,6 +189,55 @@ class Model(nn.Module):
             rows = gather_shards(local, B * F, group=group)
         return rows.view(B, F, 2, T).permute(0, 2, 1, 3).contiguous()
 
+    def _composed_rows_ok(self, noisy_mag):
+        """Whether the composed configuration's INFERENCE forward runs with its glue on the library as well
+        (``_forward_composed_rows``): no full-band neighbours, one of the two shipped norms, a sub-band window of up to 32
+        columns, and a batch drop_band accepts (model.py:114-119; anything else takes the tensor algebra and fails there
+        exactly like the reference)."""
+        B = noisy_mag.shape[0]
+        g = self.num_groups_in_drop_band
+        return (getattr(self, "composed_rows", True) and noisy_mag.is_cuda and noisy_mag.dtype == torch.float32
+                and not (torch.is_grad_enabled() and (noisy_mag.requires_grad or any(p.requires_grad for p in self.parameters())))
+                and self.fb_num_neighbors == 0 and self.norm_type in _lib.NORM_TYPES and 2 * self.sb_num_neighbors + 2 <= 32
+                and (B == 1 or g <= 1 or B > g) and noisy_mag.shape[3] + self.look_ahead >= 1)
+
+    def _forward_composed_rows(self, noisy_mag):
+        """``_forward_composed`` in inference with every tensor between the two SequenceModel blocks in the time-major,
+        zero-padded layout the LSTM / GRU / Linear entries take, written by the library's own glue kernels (the ones of the
+        fused training graph, train_glue_kernels.hip: look-ahead pad + norm -> full-band block -> unfold ++ full-band output,
+        norm, drop_band -> sub-band block -> reshape + look-ahead slice; fullsubnet/model.py:84-135): a GRU FullSubNet, other
+        hidden sizes or output activations run without a tensor-algebra kernel of the host framework between the blocks
+        (an activation other than ReLU is one elementwise launch on the block's output)."""
+        L = _lib.lib()
+        dev = noisy_mag.device
+        B, _, F, T = noisy_mag.shape
+        Tp = T + self.look_ahead
+        dims = _lib.TrainDims(B, F, T, self.look_ahead, self.sb_num_neighbors, self.num_groups_in_drop_band,
+                              _lib.NORM_TYPES[self.norm_type])
+        dp = ctypes.byref(dims)
+        fs, rows = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(L.fsn_train_rows(dp, ctypes.byref(fs), ctypes.byref(rows)))
+        Fs, R = fs.value, rows.value
+        Bp, Fp, Rp = (B + 15) // 16 * 16, (F + 15) // 16 * 16, (R + 15) // 16 * 16
+        st = _lib.stream_ptr(dev)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        mag = noisy_mag.detach().reshape(B, F, T)
+        mag = mag if mag.is_contiguous() else mag.contiguous()
+        gws = _lib.workspace(L.fsn_train_glue_workspace_bytes(dp), dev)
+        x_tm, mag_tm = new(Tp, Bp, Fp), new(Tp, Bp, Fp)
+        _lib.check(L.fsn_train_fb_input(dp, _lib.dev_ptr(mag, "noisy_mag"), _lib.dev_ptr(x_tm), _lib.dev_ptr(mag_tm), Bp, Fp,
+                                        gws.data_ptr(), gws.numel(), st))
+        fb_out = self.fb_model.forward_time_major(x_tm, B, rows_out=True)            # [Tp, Bp, F]
+        fb_out = fb_out if fb_out.is_contiguous() else fb_out.contiguous()
+        sb_in, den = new(Tp, Rp, 32), new(L.fsn_train_den_elems(dp, Rp))
+        _lib.check(L.fsn_train_sb_input(dp, _lib.dev_ptr(mag_tm), _lib.dev_ptr(fb_out), F, Bp, Fp, _lib.dev_ptr(sb_in), Rp,
+                                        _lib.dev_ptr(den), gws.data_ptr(), gws.numel(), st))
+        y2 = self.sb_model.forward_time_major(sb_in, R, rows_out=True)               # [Tp, Rp, 2]
+        y2 = y2 if y2.is_contiguous() else y2.contiguous()
+        mask = new(B, 2, Fs, T)
+        _lib.check(L.fsn_train_mask_out(dp, _lib.dev_ptr(y2), Rp, _lib.dev_ptr(mask), st))
+        return mask
+
     def _forward_composed(self, noisy_mag):
         """fullsubnet/model.py:72-136 operation by operation, for the configurations the fused kernels
         are not specialised for: the two SequenceModel blocks run on the HIP LSTM / GRU / GEMM kernels
@@ -223,7 +274,8 @@ class Model(nn.Module):
             mag, _, re, im = stft(y, n_fft, hop_length, n_fft, return_phase=False)
             groups, self.num_groups_in_drop_band = self.num_groups_in_drop_band, 1
             try:
-                crm = self._forward_composed(mag.unsqueeze(1))
+                x4 = mag.unsqueeze(1)
+                crm = self._forward_composed_rows(x4) if self._composed_rows_ok(x4) else self._forward_composed(x4)
             finally:
                 self.num_groups_in_drop_band = groups
             m = decompress_cIRM(crm.permute(0, 2, 3, 1))

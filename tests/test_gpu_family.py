@@ -567,6 +567,41 @@ def test_fullsubnet_constructor_variants_vs_reference(fsn, golden_dir, name):
     assert np.abs(crm - z["crm"]).max() <= 1e-4  # measured 1.0e-5 .. 2.9e-5
 
 
+@pytest.mark.parametrize("kw,B", [
+    (dict(sequence_model="GRU"), 3),
+    (dict(sequence_model="GRU", norm_type="cumulative_laplace_norm"), 1),
+    (dict(fb_model_hidden_size=256, sb_model_hidden_size=192, fb_output_activate_function="Tanh"), 3),
+    (dict(sb_num_neighbors=7, sb_model_hidden_size=320, norm_type="cumulative_laplace_norm", num_groups_in_drop_band=3), 4),
+    (dict(sb_output_activate_function="Tanh", num_groups_in_drop_band=1), 2),
+])
+def test_composed_variants_with_the_glue_on_the_library(fsn, kw, B):
+    """Constructor variants outside the fused kernels' specialisation (GRU, other hidden sizes, other output activations;
+    fullsubnet/model.py:10-70) in inference: ``_forward_composed_rows`` keeps every tensor between the two SequenceModel blocks
+    time-major and forms it with the library's glue kernels (pad + norm, unfold ++ full-band output + norm + drop_band, reshape
+    + look-ahead slice) - held to ``_forward_composed``, the reference's forward operation by operation as tensor algebra
+    (itself held to the reference's goldens: test_fullsubnet_constructor_variants_vs_reference), incl. the eval-mode band
+    dropping of batches (quirk Q1), both shipped norms, one utterance."""
+    base = dict(num_freqs=257, look_ahead=2, sequence_model="LSTM", fb_num_neighbors=0, sb_num_neighbors=15,
+                fb_output_activate_function="ReLU", sb_output_activate_function=False, fb_model_hidden_size=512,
+                sb_model_hidden_size=384, norm_type="offline_laplace_norm", num_groups_in_drop_band=2, weight_init=False)
+    torch.manual_seed(11)
+    m = fsn.Model(**{**base, **kw})
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(2.0)  # masks of a few units, like the goldens' weights
+    m = m.cuda().eval()
+    assert not m._fused
+    mag = (torch.rand(B, 1, 257, 37, device="cuda") ** 2) * 3.0
+    with torch.no_grad():
+        assert m._composed_rows_ok(mag)
+        rows = m(mag)
+        m.composed_rows = False
+        algebra = m(mag)
+    assert rows.shape == algebra.shape and torch.isfinite(rows).all()
+    assert float(algebra.abs().max()) > 0.05
+    assert (rows - algebra).abs().max().item() <= 2e-5  # measured 1e-6 .. 4e-6
+
+
 @pytest.mark.parametrize("name", ["fast_train_b3", "fullband_train_b3"])
 def test_sibling_training_step_vs_the_reference(fsn, golden_dir, name):
     """ONE training step of the two sibling recipes that ship training TOMLs (fast_fullsubnet/train_shrinkSize2.toml:69-79 +

@@ -1,5 +1,5 @@
 """Time the sibling model families on one MI355X (BASELINE configs 1, 4 and 5):
-python tools/bench_family.py [fast|fullband|improved16|improved48|improved769] [batch] [units=r/w]
+python tools/bench_family.py [fast|fullband|gru|improved16|improved48|improved769] [batch] [units=r/w]
 units=r/w (improved* only): time what rank r of w computes under the frequency-axis shard (its share of every
 section's units; the all-gather is not part of this single-GPU measurement).
 `family_step(which, B)` is also what bench.py's side figures `fast_b256` / `improved48_b32` call."""
@@ -61,6 +61,16 @@ def build(which, device="cuda"):
         sd = {k: torch.from_numpy(v) for k, v in make_fast_params(seed=3).items()}
         sd["mel_scale.fb"] = model.mel_scale.fb.clone()
         mmac = 62.9e6  # MAC / frame / utterance
+    elif which == "gru":
+        # FullSubNet with sequence_model = "GRU" (fullsubnet/model.py:10-70: a constructor option no shipped TOML selects): the
+        # composed configuration - SequenceModel blocks on the GRU kernels, the glue between them on the library's glue kernels
+        from fullsubnet_amd.model import Model
+        torch.manual_seed(3)
+        model = Model(num_freqs=257, look_ahead=2, sequence_model="GRU", fb_num_neighbors=0, sb_num_neighbors=15,
+                      fb_output_activate_function="ReLU", sb_output_activate_function=False, fb_model_hidden_size=512,
+                      sb_model_hidden_size=384, norm_type="offline_laplace_norm", num_groups_in_drop_band=1, weight_init=True)
+        sd = model.state_dict()
+        mmac = 3 * 512 * (257 + 512) + 3 * 512 * 1024 + 512 * 257 + 257 * (3 * 384 * (32 + 384) + 3 * 384 * 768 + 384 * 2)
     else:
         from fullsubnet_amd.fullband_baseline import Model
         model = Model(num_freqs=257, hidden_size=512, sequence_model="LSTM", output_activate_function=None, look_ahead=2,
