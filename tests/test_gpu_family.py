@@ -721,6 +721,28 @@ def test_fast_fullsubnet_amp_step_vs_the_references_own_fp16_autocast_step(fsn, 
     assert c[1] <= 2 * ref[1] and c[2][1] <= 2 * ref[2], (c, ref)          # and within that distance of it
 
 
+def test_trainer_trains_fast_fullsubnet_under_use_amp(fsn):
+    """fast_fullsubnet/train_shrinkSize2.toml:5 (use_amp = true) through the Trainer mirror: the trainer's arithmetic reaches the
+    bottleneck (24 utterances x 64 bands = one piece of 1536 rows on the 16-bit persistent training kernels), the reference's
+    GradScaler stays at its initial scale, no step is skipped, the parameters move."""
+    from oracle import fullsubnet_oracle as O
+    from fullsubnet_amd.trainer import Trainer
+    m = _fast_train_model(fsn, dict(seed_w=5, gain=1.0), "f32")
+    before = [p.detach().clone() for p in m.parameters()]
+    loader = [(torch.from_numpy(O.make_noisy(24, 6144, seed=s)), torch.from_numpy(0.7 * O.make_noisy(24, 6144, seed=s + 9)))
+              for s in (1, 2)]
+    cfg = {"meta": {"use_amp": True}, "acoustics": {"n_fft": 512, "hop_length": 256, "win_length": 512, "sr": 16000},
+           "trainer": {"train": {"epochs": 1, "clip_grad_norm_value": 10}}}
+    opt = fsn.ClipAdam(m.parameters(), lr=1e-3)
+    tr = Trainer(None, 0, cfg, False, False, m, None, opt, loader)
+    assert tr.use_amp and tr.scaler.is_enabled() and tr._inner().train_arithmetic == "f16"
+    tr._set_models_to_train_mode()
+    loss = tr._train_epoch(1)
+    assert np.isfinite(loss) and tr.scaler.get_scale() == 65536.0 and opt.skipped_steps() == 0
+    assert m.bottleneck.train_arithmetic.startswith("f16")
+    assert any(not torch.equal(p.detach(), q) for p, q in zip(m.parameters(), before))
+
+
 @pytest.mark.parametrize("I,H,B,T", [(257, 512, 3, 23), (257, 512, 64, 9), (40, 384, 33, 12), (70, 320, 5, 8)])
 def test_two_gru_layers_with_few_rows_on_the_chain_kernel(fsn, I, H, B, T):
     """nn.GRU(num_layers = 2) of a SequenceModel with few rows (sequence_model.py:59-66: the full-band model of a GRU FullSubNet)
