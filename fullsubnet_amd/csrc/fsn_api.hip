@@ -2016,7 +2016,8 @@ static bool lstm2_on_chain(int T, int N, int H) { return fsn_fb_chain_supported(
 //   fwd_chain  : fb_chain_kernel<.., SAVE> - H = 384 / 512, up to 64 rows, up to 4095 steps (its hand-off offsets);
 //   bptt_group : clusters of lstm2_group_bptt_kernel - H = 384, the same row shape, any input width (dX is a GEMM
 //                afterwards) and any T (one buffer resource per (step, cluster) tile);
-//   bptt_chain : fb_chain_bptt_kernel - H = 512, 16 rows, T below fsn_fb_chain_bptt_max_steps (32-bit dx offsets).
+//   bptt_chain : fb_chain_bptt_kernel - H = 512, 16 .. 80 rows (one chain per row tile), T below fsn_fb_chain_bptt_max_steps
+//                (32-bit dx offsets).
 struct Lstm2TrainPlan {
     int fwd_group, bptt_group;
     bool fwd_chain, bptt_chain;
@@ -2766,7 +2767,7 @@ extern "C" size_t fsn_lstm2_bwd_workspace_bytes(int T, int N, int I, int H, int 
     if (lstm2_train_plan(T, N, I, H).bptt_chain) {
         cv.take<float>((size_t)3 * H * G + (size_t)Ipad * G);  // W_hh1^T, W_ih1^T, W_hh0^T, W_ih0^T fragments
         cv.take<float>((size_t)2 * T * N * G);                 // dgates of both layers
-        cv.take<float>(fsn_fb_chain_bptt_dx_floats(T));
+        cv.take<float>(fsn_fb_chain_bptt_dx_floats(T, N));
         cv.take<unsigned>(fsn_fb_chain_bptt_flag_words());
         size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
         const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);
@@ -2807,7 +2808,7 @@ static int lstm2_backward_phases(const float* dh1, const float* x, long ldx, con
     }
     const int clusters = lstm2_bptt_group_clusters(T, N, I, H);
     if (!clusters && lstm2_train_plan(T, N, I, H).bptt_chain) {
-        // the full-band shape (16 rows, H = 512): both layers' BPTT as one persistent launch (fb_chain_bptt_kernels.hip),
+        // the full-band shape (H = 512, up to 80 rows): both layers' BPTT as one persistent launch (fb_chain_bptt_kernels.hip),
         // then the weight-gradient GEMMs
         hipStream_t s = static_cast<hipStream_t>(stream);
         const int Ipad = fsn_round_up(I, 16), G = 4 * H;
@@ -2818,7 +2819,7 @@ static int lstm2_backward_phases(const float* dh1, const float* x, long ldx, con
         float* wih0T_p = whh0T_p + (size_t)H * G;
         float* dg1 = cv.take<float>((size_t)2 * T * N * G);
         float* dg0 = dg1 + (size_t)T * N * G;
-        float* dxp = cv.take<float>(fsn_fb_chain_bptt_dx_floats(T));
+        float* dxp = cv.take<float>(fsn_fb_chain_bptt_dx_floats(T, N));
         unsigned* flags = cv.take<unsigned>(fsn_fb_chain_bptt_flag_words());
         size_t tn = fsn_gemm_tn_workspace_bytes(G, I, (long)T * N);
         const size_t tn2 = fsn_gemm_tn_workspace_bytes(G, H, (long)T * N);

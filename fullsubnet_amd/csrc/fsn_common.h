@@ -320,7 +320,7 @@ int fsn_launch_lstm2_g16_finish(const float* dg1, const float* dg0, void* dg16_1
 // fb_chain_bptt_kernels.hip: BPTT of the full-band model's two layers (16 rows, H = 512) as one persistent launch
 bool fsn_fb_chain_bptt_supported(int H, int N);
 int fsn_fb_chain_bptt_max_steps();
-size_t fsn_fb_chain_bptt_dx_floats(int Tp);
+size_t fsn_fb_chain_bptt_dx_floats(int Tp, int N);
 size_t fsn_fb_chain_bptt_flag_words();
 size_t fsn_fb_chain_bptt_status_word();
 int fsn_launch_fb_chain_bptt(const float* dh1, const float* whh1T_p, const float* wih1T_p, const float* whh0T_p,

@@ -52,14 +52,16 @@ def test_lstm_layer_forward_and_bptt(fsn, T, N, I, H):
 
 
 @pytest.mark.parametrize("T,N,I,H", [(6, 2064, 32, 384), (5, 1552, 20, 384), (4, 16, 257, 512), (3, 40, 64, 512),
-                                     (4, 48, 32, 384), (3, 4128, 32, 384)])
+                                     (4, 48, 32, 384), (3, 4128, 32, 384), (9, 32, 128, 512), (7, 72, 128, 512),
+                                     (5, 80, 257, 512)])
 def test_two_layer_lstm_on_the_persistent_kernels(fsn, T, N, I, H):
     """Lstm2Function (fsn_lstm2_forward_train + fsn_lstm2_backward) against two stacked LstmLayerFunction calls (the
     per-step kernels, themselves held to the oracle above): the sub-band shape - 129 row tiles = 32 clusters on the
     group kernels (forward with saves, BPTT) + one left-over tile step by step beside them; 97 tiles with a narrower
     input; 258 tiles (32 utterances per rank: the forward with two clusters per workgroup set, the backward layer by
-    layer) - the full-band shape on the chain kernel (one and three row tiles), and a shape that falls back to the
-    layer-by-layer path.  Outputs and every gradient; the persistent path twice, bit-identical."""
+    layer) - the full-band shape on the chain kernels (one, two and three row tiles; 72 and 80 rows: the forward layer by
+    layer, the backward as five chains walked by one launch - Fast FullSubNet's decoder pair at its TOML's batch), and a shape
+    that falls back to the layer-by-layer path.  Outputs and every gradient; the persistent path twice, bit-identical."""
     from fullsubnet_amd.train import Lstm2Function, LstmLayerFunction
     g = torch.Generator().manual_seed(T * 1000 + N)
     k = 1.0 / np.sqrt(H)

@@ -67,6 +67,9 @@ def run(fn, reps=5):
 t_a, a = run(layerwise)
 t_b, b = run(lambda: pieces(True))
 t_c, c = run(lambda: pieces(False))
+t_d, dd = run(lambda: Lstm2Function.apply(x, *params, "f32"))
 d = lambda u, v: float((u - v).abs().max() / (v.abs().max() + 1e-30))
 print(f"rows {N}, I {I}, T {T}: layer by layer {t_a:.2f} ms, 16-row pieces on concurrent streams {t_b:.2f} ms, pieces in line {t_c:.2f} ms")
+print(f"  Lstm2Function on all rows (the BPTT chain walks {(N + 15) // 16} row tiles in one launch): {t_d:.2f} ms; vs layer by layer: h {d(dd[0], a[0]):.1e}, "
+      f"dx {d(dd[1], a[1]):.1e}, worst dW {max(d(u, v) for u, v in zip(dd[2], a[2])):.1e}")
 print(f"  pieces vs layer by layer: h {d(b[0], a[0]):.1e}, dx {d(b[1], a[1]):.1e}, worst dW {max(d(u, v) for u, v in zip(b[2], a[2])):.1e}")
