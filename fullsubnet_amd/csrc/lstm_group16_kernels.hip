@@ -470,7 +470,10 @@ __global__ __launch_bounds__(256, 2) void lstm2_g16_fwd_kernel(const G16FwdArgs 
     const int bid = (int)blockIdx.x - layer * half;
     const int nclusters = half / QM;
     int cluster, member;
-    if (nclusters % 8 == 0) {
+    if ((ABL & 128) != 0 && nclusters % 8 == 0) {  // experiment: MEMBERS (not clusters) share an XCD - its L2 holds 1/8 of the weights
+        member = bid & 7;
+        cluster = bid >> 3;
+    } else if (nclusters % 8 == 0) {
         const int xcd = bid & 7, j = bid >> 3;
         cluster = xcd * (nclusters / 8) + j / QM;
         member = j % QM;
@@ -826,7 +829,10 @@ __global__ __launch_bounds__(256, 2) void lstm2_g16_bwd_kernel(const G16BwdArgs 
     const int bid = (int)blockIdx.x - second * half;
     const int nclusters = half / QM;
     int cluster, member;
-    if (nclusters % 8 == 0) {
+    if ((ABL & 128) != 0 && nclusters % 8 == 0) {  // experiment: MEMBERS (not clusters) share an XCD - its L2 holds 1/8 of the weights
+        member = bid & 7;
+        cluster = bid >> 3;
+    } else if (nclusters % 8 == 0) {
         const int xcd = bid & 7, j = bid >> 3;
         cluster = xcd * (nclusters / 8) + j / QM;
         member = j % QM;

@@ -21,6 +21,9 @@ __global__ void fill_kernel(float* p, size_t n, unsigned seed, float scale, floa
 #ifndef PROBE_AR
 #define PROBE_AR 2
 #endif
+#ifndef PROBE_SV
+#define PROBE_SV 0  // 1: the gates saved / the hand-off in 16 bits (FSN_ARITH_SAVES16, the default under AMP since round 6)
+#endif
 static unsigned* g_flags; static int g_clusters;
 template <int ABL>
 float run_fwd(G16FwdArgs a) {
@@ -29,7 +32,7 @@ float run_fwd(G16FwdArgs a) {
     for (int it = 0; it < 3; ++it) {
         hipMemsetAsync(g_flags, 0, fsn_lstm2_g16_flag_words(g_clusters) * 4, 0);
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((lstm2_g16_fwd_kernel<PROBE_AR, ABL>), dim3(g_clusters * QM * 2), dim3(256), 0, 0, a);
+        hipLaunchKernelGGL((lstm2_g16_fwd_kernel<PROBE_AR, ABL, PROBE_SV>), dim3(g_clusters * QM * 2), dim3(256), 0, 0, a);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (it > 0 && ms < best) best = ms;
     }
@@ -42,7 +45,7 @@ float run_bwd(G16BwdArgs a) {
     for (int it = 0; it < 3; ++it) {
         hipMemsetAsync(g_flags, 0, fsn_lstm2_g16_flag_words(g_clusters) * 4, 0);
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((lstm2_g16_bwd_kernel<PROBE_AR, ABL>), dim3(g_clusters * QM * 2), dim3(256), 0, 0, a);
+        hipLaunchKernelGGL((lstm2_g16_bwd_kernel<PROBE_AR, ABL, PROBE_SV>), dim3(g_clusters * QM * 2), dim3(256), 0, 0, a);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (it > 0 && ms < best) best = ms;
     }
@@ -81,6 +84,8 @@ int main(int argc, char** argv) {
         printf("arithmetic %d: lstm2_g16_fwd_kernel, %d clusters, %d steps: %.3f ms = %.1f us per step, status %u\n", PROBE_AR, clusters, Tp, t0, 1e3 * t0 / Tp, st);
 #define VF(abl, what) { const float t = run_fwd<abl>(a); printf("  %-60s: %.3f ms = %.1f us per step\n", what, t, 1e3 * t / Tp); }
         VF(64, "payload at device scope (what any other placement takes)");
+        VF(128, "members (not clusters) share an XCD");
+        VF(128 + 8, "... no saves");
         VF(8, "no saves");
         VF(4, "no weight loads");
         VF(2, "partners' tiles not loaded (constants staged)");
@@ -110,6 +115,7 @@ int main(int argc, char** argv) {
         unsigned st = 0; hipMemcpy(&st, b.status, 4, hipMemcpyDeviceToHost);
         printf("arithmetic %d: lstm2_g16_bwd_kernel, %d clusters, %d steps: %.3f ms = %.1f us per step, status %u\n", PROBE_AR, clusters, Tp, t0, 1e3 * t0 / Tp, st);
 #define VB(abl, what) { const float t = run_bwd<abl>(b); printf("  %-60s: %.3f ms = %.1f us per step\n", what, t, 1e3 * t / Tp); }
+        VB(128, "members (not clusters) share an XCD");
         VB(8, "no gate-gradient stores");
         VB(2, "saved activations not loaded");
         VB(4, "no weight loads");
