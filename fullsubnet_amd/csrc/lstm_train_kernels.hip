@@ -1300,6 +1300,9 @@ __global__ __launch_bounds__(256) void bptt_step_cu_kernel(const float* __restri
         }
 }
 
+#ifndef FSN_BPTT_SPLIT16_TILES
+#define FSN_BPTT_SPLIT16_TILES 8  // measured (round 6, 5 tiles x 512 units, Fast FullSubNet's decoder at batch 72): see DESIGN 7.4
+#endif
 int fsn_launch_bptt_step(const float* dh_out, const float* dgates_next, const float* whhT_p, float* dc,
                          const float* gates, const float* c_t, const float* c_prev, float* dgates, int row_tiles, int H,
                          int last, int first, hipStream_t s) {
@@ -1318,7 +1321,7 @@ int fsn_launch_bptt_step(const float* dh_out, const float* dgates_next, const fl
     hipLaunchKernelGGL((bptt_step_kernel<R, C>), dim3(H / 16 / C, (row_tiles + R - 1) / R), dim3(256), 0, s, dh_out, \
                        dgates_next, whhT_p, dc, gates, c_t, c_prev, dgates, row_tiles, H, last, first)
     if (cfg == 22) FSN_BPTT_CASE(2, 2);
-    else if (row_tiles <= 4 && (4 * H / 16) % 16 == 0)  // a handful of rows (full-band model): 16-way split-K
+    else if (row_tiles <= FSN_BPTT_SPLIT16_TILES && (4 * H / 16) % 16 == 0)  // a handful of rows (full-band model, the sibling models' blocks): 16-way split-K
         hipLaunchKernelGGL((bptt_step_kernel<1, 1, 16>), dim3(H / 16, row_tiles), dim3(1024), 0, s, dh_out, dgates_next,
                            whhT_p, dc, gates, c_t, c_prev, dgates, row_tiles, H, last, first);
     else FSN_BPTT_CASE(1, 1);
