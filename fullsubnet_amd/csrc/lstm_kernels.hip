@@ -2089,7 +2089,10 @@ int fsn_launch_lstm_step_train(const float* gx, const float* whh_p, const float*
                            h_out, c_prev, c_out, gates_out, gx_rt0, row_tiles, H, first);
         return fsn_check_launch("lstm_step_rows_kernel");
     }
-    const int rts = row_tiles >= 16 ? 2 : 1;  // measured: 2 is the best at 129 tiles, 4 no better
+#ifndef FSN_STEP_RTS2_FROM
+#define FSN_STEP_RTS2_FROM 16
+#endif
+    const int rts = row_tiles >= FSN_STEP_RTS2_FROM ? 2 : 1;  // measured: 2 is the best at 129 tiles, 4 no better
 #define FSN_STEP_CASE(R)                                                                                         \
     hipLaunchKernelGGL(lstm_step_kernel<R>, dim3(H / 16, (row_tiles + R - 1) / R), dim3(256), 0, s, gx, whh_p, h_prev, \
                        h_out, c_prev, c_out, gates_out, gx_rt0, row_tiles, H, first)

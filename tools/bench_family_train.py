@@ -60,6 +60,10 @@ def family_train_step(which="fast", B=72, arith="f32", L=49152, steps=3, warmup=
 
 
 if __name__ == "__main__":
+    for a in sys.argv[1:]:
+        if a.startswith("--lib="):  # a diagnosis build (tools/build_variant.py)
+            fullsubnet_amd._lib.LIB_PATH = a[6:]
+            sys.argv.remove(a)
     which = sys.argv[1] if len(sys.argv) > 1 else "fast"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 72
     arith = sys.argv[3] if len(sys.argv) > 3 else "f32"
