@@ -250,7 +250,7 @@ class LinearFunction(torch.autograd.Function):
 LSTM2_CHUNK_ROWS = 2048  # one persistent launch of the group kernels: 32 clusters of 64 rows (two workgroups per CU)
 
 
-def lstm2_train_chunks(T, N, I, H):
+def lstm2_train_chunks(T, N, I, H, pad_to_32=True):
     """Rows per piece, number of pieces - or None - for a two-layer LSTM stack with MORE rows than one persistent launch of
     the training kernels holds (fsn_lstm2_forward_train / fsn_lstm2_backward: the group kernels take 96 - 128 row tiles in
     whole 64-row clusters).  The rows of a stack are independent sequences (sequence_model.py:52-58), so N rows run as
@@ -262,9 +262,24 @@ def lstm2_train_chunks(T, N, I, H):
     n0 = -(-N // LSTM2_CHUNK_ROWS)
     for n in (n0, n0 + 1):
         rows = (-(-N // n) + 63) // 64 * 64
-        if L.fsn_lstm2_train_is_persistent(T, rows, 32, H) == 1:
+        if L.fsn_lstm2_train_is_persistent(T, rows, 32 if pad_to_32 else I, H) == 1:
             return rows, n
     return None
+
+
+def rows_to_pieces(x, rows, n):
+    """x [T, N, W] time-major -> [n, T, rows, W] contiguous: piece k holds rows [k rows, (k + 1) rows) (zeros beyond N)."""
+    T, N, W = x.shape
+    if n * rows != N:
+        x = functional.pad(x, (0, 0, 0, n * rows - N))
+    return x.view(T, n, rows, W).permute(1, 0, 2, 3).contiguous()
+
+
+def pieces_to_rows(parts, T, rows, N):
+    """The inverse: n tensors [T, rows, W] (or [T rows, W]) -> [T, N, W] contiguous (rows beyond N dropped)."""
+    W = parts[0].shape[-1]
+    p = torch.stack([t.reshape(T, rows, W) for t in parts])               # [n, T, rows, W]
+    return p.permute(1, 0, 2, 3).reshape(T, len(parts) * rows, W)[:, :N].contiguous()
 
 
 def lstm2_rows_chunked(x_tn, params, arith, rows, n):
@@ -475,21 +490,38 @@ class FullSubNetTrainFunction(torch.autograd.Function):
         sb_in, den = new(Tp, Rp, 32), new(L.fsn_train_den_elems(dp, Rp))  # divisors: per utterance / per unit and frame
         _lib.check(L.fsn_train_sb_input(dp, _lib.dev_ptr(mag_tm), _lib.dev_ptr(fb_out), F, Bp, Fp, _lib.dev_ptr(sb_in), Rp,
                                         _lib.dev_ptr(den), gws.data_ptr(), gws.numel(), st))
-        sh0, sh1, ss0, ss1 = lstm2(sb_in, 32, sb, Rp, Is, Hs)
-        y2 = linear(sh1, Hs, sb_fc[0], sb_fc[1], Tp * Rp, Hs, 2, 0)              # [Tp Rp, 2]
+        # The sub-band rows are independent sequences (model.py:121-128).  ONE persistent launch per direction holds 2048 of
+        # them (config 3's per-rank batch of 16; the kernels of the 16-bit arithmetic exist for such launches only): a larger
+        # batch - the shipped TOMLs say 32 and 48 per process (train.toml:52, train_cumulativeLaplaceNorm.toml:52) - runs as
+        # equal pieces of whole clusters, each through the same two entries; the pieces' weight gradients add up below
+        pieces = None
+        if L.fsn_lstm2_train_is_persistent(Tp, Rp, Is, Hs) != 1:
+            pieces = lstm2_train_chunks(Tp, Rp, Is, Hs, pad_to_32=False)
+        if pieces is None:
+            xs = [sb_in]
+        else:
+            xs = list(rows_to_pieces(sb_in, *pieces))                             # n x [Tp, rows, 32]
+        sb_saved, y2_parts = [], []
+        for xk in xs:
+            Nk = xk.shape[1]
+            h0, h1, s0, s1 = lstm2(xk, 32, sb, Nk, Is, Hs)
+            y2_parts.append(linear(h1, Hs, sb_fc[0], sb_fc[1], Tp * Nk, Hs, 2, 0))  # [Tp Nk, 2]
+            sb_saved += [xk, h0, h1, s0, s1]
+        y2 = y2_parts[0] if pieces is None else pieces_to_rows(y2_parts, Tp, pieces[0], Rp)  # [Tp Rp, 2]
         mask = new(B, 2, Fs, T)
         _lib.check(L.fsn_train_mask_out(dp, _lib.dev_ptr(y2), Rp, _lib.dev_ptr(mask), st))
-        ctx.save_for_backward(x_tm, fh0, fh1, fs0, fs1, fb_out, sb_in, den, sh0, sh1, ss0, ss1, gws, *p)
-        ctx.meta = (dims, ar, Tp, Bp, Fp, Rp, Hf, Hs, Is, F)
+        ctx.save_for_backward(x_tm, fh0, fh1, fs0, fs1, fb_out, sb_in, den, gws, *sb_saved, *p)
+        ctx.meta = (dims, ar, Tp, Bp, Fp, Rp, Hf, Hs, Is, F, pieces, len(xs))
         return mask
 
     @staticmethod
     def backward(ctx, d_mask):
         L = _lib.lib()
-        x_tm, fh0, fh1, fs0, fs1, fb_out, sb_in, den, sh0, sh1, ss0, ss1, gws = ctx.saved_tensors[:13]
-        p = ctx.saved_tensors[13:]
+        dims, ar, Tp, Bp, Fp, Rp, Hf, Hs, Is, F, pieces, n_sb = ctx.meta
+        x_tm, fh0, fh1, fs0, fs1, fb_out, sb_in, den, gws = ctx.saved_tensors[:9]
+        sb_saved = ctx.saved_tensors[9:9 + 5 * n_sb]
+        p = ctx.saved_tensors[9 + 5 * n_sb:]
         fb, fb_fc, sb, sb_fc = p[0:8], p[8:10], p[10:18], p[18:20]
-        dims, ar, Tp, Bp, Fp, Rp, Hf, Hs, Is, F = ctx.meta
         dp = ctypes.byref(dims)
         dev = d_mask.device
         st = _lib.stream_ptr(dev)
@@ -547,8 +579,15 @@ class FullSubNetTrainFunction(torch.autograd.Function):
 
         dy2 = new(Tp * Rp, 16)
         _lib.check(L.fsn_train_mask_grad(dp, _lib.dev_ptr(dm, "d_mask"), _lib.dev_ptr(dy2), Rp, 16, st))
-        dsh1, d_sfw, d_sfb = linear_bwd(dy2, 16, sh1, Hs, sb_fc[0], Tp * Rp, Hs, 2)  # (its parameter gradients beside the BPTT launch: measured, slows that launch by more)
-        dx_sb, g_sb = lstm2_bwd(dsh1, sb_in, 32, sb, sh0, sh1, ss0, ss1, Rp, Is, Hs, True, beside=True)
+        dy_parts = [dy2] if pieces is None else list(rows_to_pieces(dy2.view(Tp, Rp, 16), *pieces))
+        dx_parts, g_parts, fc_parts = [], [], []
+        for k in range(n_sb):
+            xk, sh0, sh1, ss0, ss1 = sb_saved[5 * k:5 * k + 5]
+            Nk = xk.shape[1]
+            dsh1, d_sfw_k, d_sfb_k = linear_bwd(dy_parts[k].reshape(Tp * Nk, 16), 16, sh1, Hs, sb_fc[0], Tp * Nk, Hs, 2)  # (its parameter gradients beside the BPTT launch: measured, slows that launch by more)
+            dx_k, g_k = lstm2_bwd(dsh1, xk, 32, sb, sh0, sh1, ss0, ss1, Nk, Is, Hs, True, beside=True)
+            dx_parts.append(dx_k), g_parts.append(g_k), fc_parts.append((d_sfw_k, d_sfb_k))
+        dx_sb = dx_parts[0] if pieces is None else pieces_to_rows(dx_parts, Tp, pieces[0], Rp)
         d_fb = new(Tp * Bp, Fp)
         _lib.check(L.fsn_train_sb_input_backward(dp, _lib.dev_ptr(dx_sb), _lib.dev_ptr(sb_in), Rp, _lib.dev_ptr(den), _lib.dev_ptr(fb_out),
                                                  F, Bp, _lib.dev_ptr(d_fb), Fp, gws.data_ptr(), gws.numel(), st))
@@ -558,6 +597,10 @@ class FullSubNetTrainFunction(torch.autograd.Function):
             main.wait_stream(side)  # the sub-band weight gradients: everything after this call sees them
             main.wait_stream(third)
             keep.clear()
+        g_sb, (d_sfw, d_sfb) = g_parts[0], fc_parts[0]
+        for k in range(1, n_sb):  # the pieces' parameter gradients add up (fixed order)
+            g_sb = [a + b for a, b in zip(g_sb, g_parts[k])]
+            d_sfw, d_sfb = d_sfw + fc_parts[k][0], d_sfb + fc_parts[k][1]
         return (None, None, None, None, None, None, *g_fb, d_ffw, d_ffb, *g_sb, d_sfw, d_sfb)
 
 

@@ -328,6 +328,30 @@ def test_fp16_amp_step_vs_the_references_own_fp16_autocast_step(fsn, golden_dir,
     assert b[1] <= 2 * ref_total and b[2] <= 2 * ref_worst, (b, ref_total, ref_worst)  # and within that distance of it
 
 
+def test_amp_step_at_the_shipped_batch_of_32(fsn, golden_dir):
+    """fullsubnet/train.toml:52 says 32 utterances per process: the sub-band rows (4096) run as two pieces of 2048 through the
+    16-bit persistent launches (train.lstm2_train_chunks).  Against the reference's fp32 step on the same 32 utterances
+    (fsn_train_c3x2.npz) with the margins the 16-utterance AMP step keeps against its fp32 golden."""
+    from fullsubnet_amd.train import lstm2_train_chunks, train_step
+    z = np.load(os.path.join(golden_dir, "fsn_train_c3x2.npz"))
+    meta = ast.literal_eval(str(z["meta"]))
+    assert meta["batch"] == 32 and lstm2_train_chunks(195, 4096, 32, 384, pad_to_32=False) == (2048, 2)
+    model, params = build(fsn, "f16", seed=meta["seed_w"], groups=meta["groups"])
+    noisy = torch.from_numpy(O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_noisy"])).cuda()
+    clean = torch.from_numpy((meta["clean_gain"] * O.make_noisy(meta["batch"], meta["length"], seed=meta["seed_clean"]))
+                             .astype(np.float32)).cuda()
+    opt = fsn.ClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    scaler = torch.amp.GradScaler("cuda")
+    loss = train_step(model, opt, noisy, clean, scaler=scaler)
+    rel_total, worst_norm, worst_elem, one_minus_cos = margins(model, opt, z, meta, params)
+    rel_loss = abs(loss.item() - float(z["loss"])) / float(z["loss"])
+    print(f"f16, 32 utterances vs the reference's fp32 step: loss {rel_loss:.2e}, total norm {rel_total:.2e}, worst tensor norm "
+          f"{worst_norm[1]:.2e} ({worst_norm[0]}), worst sampled element {worst_elem[1]:.2e}, 1 - cos {one_minus_cos:.2e}")
+    tol = AMP_TOL[("f16", "fsn_train_c3")]
+    assert scaler.get_scale() == 65536.0 and opt.skipped_steps() == 0
+    assert rel_loss <= tol[0] and rel_total <= tol[1] and worst_norm[1] <= tol[2] and worst_elem[1] <= 2 * tol[3] and one_minus_cos <= tol[4]
+
+
 def test_gradscaler_skips_an_overflowing_step_and_backs_off(fsn):
     """trainer.py:63-69: a loss scale far too large for fp16 operands overflows the scaled gradients -> the update is
     skipped (parameters and moments untouched, on the device, no host sync) and GradScaler halves the scale; the next

@@ -90,20 +90,22 @@ def test_two_layer_lstm_on_the_persistent_kernels(fsn, T, N, I, H):
 # measured r03 (b4 / c3): total norm 2.1e-6 / 3.2e-6, worst tensor norm 1.0e-4 / 6.8e-5, worst sampled element
 # 1.4e-4 / 6.4e-5 (fp32 rounding through ~50 / ~195 recurrent steps each way; r02's bounds were 2e-3 throughout)
 # fsn_train_cum_*: the same two steps with norm_type = cumulative_laplace_norm (the other shipped training TOML)
-TRAIN_TOL = {"fsn_train_b4": (1e-5, 3e-4, 4e-4), "fsn_train_c3": (1e-5, 2e-4, 2e-4),
+TRAIN_TOL = {"fsn_train_b4": (1e-5, 3e-4, 4e-4), "fsn_train_c3": (1e-5, 2e-4, 2e-4), "fsn_train_c3x2": (1e-5, 2e-4, 2.5e-3),
              "fsn_train_cum_b4": (4e-5, 3e-4, 4e-4), "fsn_train_cum_c3": (1e-5, 2e-4, 2e-4)}
 # measured r05 (cum_b4 / cum_c3): total norm 1.39e-5 / 2.38e-6, worst tensor norm 9.4e-5 / 6.8e-5, worst sampled element
 # 7.7e-5 / 8.1e-5 (the 12-frame batch divides its first frames by running means of a handful of values: the fp64 sums here
 # against the reference's fp32 cumsum show in the total norm)
 
 
-@pytest.mark.parametrize("name", ["fsn_train_b4", "fsn_train_c3", "fsn_train_cum_b4", "fsn_train_cum_c3"])
+@pytest.mark.parametrize("name", ["fsn_train_b4", "fsn_train_c3", "fsn_train_cum_b4", "fsn_train_cum_c3", "fsn_train_c3x2"])
 def test_train_step_vs_reference_and_oracle(fsn, golden_dir, name):
     """One step of fullsubnet/trainer.py:41-71 (use_amp = false) against the reference's own loss, clipped gradients
     and Adam-updated parameters: a short batch (4 x 2560 samples) and BASELINE config 3's per-rank shape
     (fullsubnet/train.toml: 16 utterances x 49 152 samples = 193 frames, drop_band groups 2), with the offline Laplace norm
     (train.toml:82) and with the cumulative one (train_cumulativeLaplaceNorm.toml:82) - both on the fused training graph
-    (no tensor-algebra kernel of the host framework in the step)."""
+    (no tensor-algebra kernel of the host framework in the step) - and the batch the shipped train.toml:52 says, 32 utterances
+    (fsn_train_c3x2: 4096 sub-band rows as two pieces of 2048 through the persistent launches, the full-band model's 32 rows on
+    the chain kernels both ways)."""
     from fullsubnet_amd.train import train_step
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     meta = ast.literal_eval(str(z["meta"]))
