@@ -299,6 +299,47 @@ def training_step_ms(device, steps=5, arith="f32", saves=None):
     return out
 
 
+def training_step_shipped_batches(device, steps=3):
+    """The batch sizes the shipped training TOMLs say (fullsubnet/train.toml:52 batch_size = 32, train_cumulativeLaplaceNorm.toml:52
+    batch_size = 48, both use_amp = true) on one GPU: the sub-band rows as pieces of 2048 through the persistent launches."""
+    import fullsubnet_amd
+    from fullsubnet_amd.train import train_step
+    from fsn_synthetic import make_noisy, make_params
+    out = {}
+    for key, B, norm in (("b32_offline", 32, "offline_laplace_norm"), ("b48_cumulative", 48, "cumulative_laplace_norm")):
+        model = fullsubnet_amd.Model(num_freqs=F, look_ahead=LA, sequence_model="LSTM", fb_num_neighbors=0, sb_num_neighbors=NB,
+                                     fb_output_activate_function="ReLU", sb_output_activate_function=False,
+                                     fb_model_hidden_size=H_FB, sb_model_hidden_size=H_SB, norm_type=norm,
+                                     num_groups_in_drop_band=2, weight_init=False)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in make_params(seed=3).items()})
+        model = model.to(device).train()
+        model.train_arithmetic = "f16"
+        scaler = torch.amp.GradScaler("cuda")
+        opt = fullsubnet_amd.ClipAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
+        noisy = torch.from_numpy(make_noisy(B, 49152, seed=41)).to(device)
+        clean = torch.from_numpy(0.7 * make_noisy(B, 49152, seed=42)).to(device)
+        for _ in range(2):
+            train_step(model, opt, noisy, clean, scaler=scaler)
+        torch.cuda.synchronize()
+        with collector_paused():
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = train_step(model, opt, noisy, clean, scaler=scaler)
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / steps
+        T = 1 + 49152 // HOP
+        flops = 3 * 2.0 * B * (T + LA) * (MAC_FB + 128 * MAC_SB_PER_BIN)
+        out[key] = {"batch": B, "norm_type": norm, "ms_per_step": round(ms, 2), "loss": round(float(loss), 6),
+                    "tflops": round(flops / (ms * 1e-3) / 1e12, 1), "skipped_steps": opt.skipped_steps(),
+                    "utterances_per_s": round(B / (ms * 1e-3), 1)}
+        del model, opt, noisy, clean
+        torch.cuda.empty_cache()
+    out["note"] = ("use_amp = true (f16 operands on the sub-band kernels, GradScaler), 49152 samples per utterance; parity at 32 utterances: "
+                   "tests/test_gpu_train.py::test_train_step_vs_reference_and_oracle[fsn_train_c3x2], tests/test_gpu_amp.py::"
+                   "test_amp_step_at_the_shipped_batch_of_32")
+    return out
+
+
 def path_parity(model, oracle_outputs, batch, length, device):
     """The margin the timed arithmetic leaves under the north-star bound, in the line itself: the two utterances the
     numpy oracle just computed (cpu_baseline's `oracle_port` leg) sit at both ends of a batch of the TIMED size, so the
@@ -812,6 +853,10 @@ def main():
                 out[key] = training_step_ms(device, arith=arith, saves=saves)
             except Exception as e:  # a side figure must never break the benchmark line
                 out[key] = {"error": str(e)[:200]}
+        try:
+            out["train_step_amp_shipped_batches"] = training_step_shipped_batches(device)
+        except Exception as e:
+            out["train_step_amp_shipped_batches"] = {"error": str(e)[:200]}
         # BASELINE configs 4 and 5 (fast_fullsubnet/model.py:143-202, improved_fullsubnet/model.py:541-591)
         for key, which, b in (("fast_b256", "fast", 256), ("improved48_b32", "improved48", 32)):
             try:

@@ -248,9 +248,10 @@ class LinearFunction(torch.autograd.Function):
 
 
 LSTM2_CHUNK_ROWS = 2048  # one persistent launch of the group kernels: 32 clusters of 64 rows (two workgroups per CU)
+LSTM2_MIN_PIECE_ROWS = 1536  # ... and the fewest rows the library plans one for (96 row tiles)
 
 
-def lstm2_train_chunks(T, N, I, H, pad_to_32=True):
+def lstm2_train_chunks(T, N, I, H, pad_to_32=True, pad_small=False):
     """Rows per piece, number of pieces - or None - for a two-layer LSTM stack with MORE rows than one persistent launch of
     the training kernels holds (fsn_lstm2_forward_train / fsn_lstm2_backward: the group kernels take 96 - 128 row tiles in
     whole 64-row clusters).  The rows of a stack are independent sequences (sequence_model.py:52-58), so N rows run as
@@ -262,6 +263,11 @@ def lstm2_train_chunks(T, N, I, H, pad_to_32=True):
     n0 = -(-N // LSTM2_CHUNK_ROWS)
     for n in (n0, n0 + 1):
         rows = (-(-N // n) + 63) // 64 * 64
+        # e.g. 20 utterances x 128 bins = 2560 rows: two pieces of 1536 (the second one 2/3 full); ``pad_small``: fewer rows
+        # than the smallest launch as ONE zero-padded piece - what pays under the 16-bit arithmetic (8 utterances: 32 ms step
+        # by step in fp32 against 11), not in fp32 (a launch of 24 clusters costs what it costs whatever it holds)
+        if N > LSTM2_MIN_PIECE_ROWS or pad_small:
+            rows = max(rows, LSTM2_MIN_PIECE_ROWS)
         if L.fsn_lstm2_train_is_persistent(T, rows, 32 if pad_to_32 else I, H) == 1:
             return rows, n
     return None
@@ -495,8 +501,10 @@ class FullSubNetTrainFunction(torch.autograd.Function):
         # batch - the shipped TOMLs say 32 and 48 per process (train.toml:52, train_cumulativeLaplaceNorm.toml:52) - runs as
         # equal pieces of whole clusters, each through the same two entries; the pieces' weight gradients add up below
         pieces = None
-        if L.fsn_lstm2_train_is_persistent(Tp, Rp, Is, Hs) != 1:
-            pieces = lstm2_train_chunks(Tp, Rp, Is, Hs, pad_to_32=False)
+        if not (L.fsn_lstm2_train_is_persistent(Tp, Rp, Is, Hs) == 1 and Rp % 64 == 0 and Rp <= LSTM2_CHUNK_ROWS):
+            # (a launch with a few left-over row tiles beside it - 17 utterances: 2176 rows - is persistent too, but its
+            # left-over rows advance step by step: 41 ms against 22 as two pieces)
+            pieces = lstm2_train_chunks(Tp, Rp, Is, Hs, pad_to_32=False, pad_small=ar != _lib.ARITH["f32"] and Rp >= 256)
         if pieces is None:
             xs = [sb_in]
         else:

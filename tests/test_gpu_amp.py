@@ -195,13 +195,18 @@ def margins(model, opt, z, meta, params):
 #   bf16 vs fp32 reference, c3                     1.6e-6   1.6e-3   2.0e-3   7.6e-3   9.3e-8
 #   bf16 vs the reference under bf16 autocast, b4  2.6e-6   1.4e-3   2.3e-2   3.1e-1   5.2e-5   (*)
 #   bf16 vs the reference under bf16 autocast, c3  6.2e-7   9.8e-4   2.6e-3   4.6e-2   2.2e-7
-# (*) the b4 shape has too few sub-band rows for the group kernels and computes in fp32 whatever the mode (the ABI's
-# rule: shapes on other kernels are wider than asked for): its bf16 row is the distance between the reference's own
-# fp32 and bf16-autocast steps.  fp16 operands leave the step where fp32 rounding already puts it.
+# (*) measured in round 3, when the b4 shape (512 sub-band rows) had too few rows for the group kernels and computed in fp32
+# whatever the mode.  Since round 6 a batch below one persistent launch runs as ONE zero-padded piece of 1536 rows under a
+# 16-bit arithmetic (train.lstm2_train_chunks, pad_small): b4 really computes in 16 bits now, and its bf16 bounds are config
+# 3's.  fp16 operands leave the step where fp32 rounding already puts it.
 AMP_TOL = {
-    ("f16", "fsn_train_b4"): (2e-6, 1e-5, 3e-4, 5e-4, 1e-8),
+    # b4 in 16 bits (round 6; 512 rows x 12 steps: ~60x fewer terms per gradient than c3, so ~8x its relative rounding noise).
+    # Measured f16: 4.7e-7 / 3.7e-5 / 2.9e-4 / 3.9e-3 / 2.5e-7; the reference's own fp16-autocast step at this shape
+    # (fsn_train_b4_f16 vs fsn_train_b4): total norm 8.7e-6, worst tensor 1.2e-3, element 3.9e-3.  bf16: 2.4e-6 / 7.4e-4 /
+    # 5.2e-3 / 2.6e-2 / 1.4e-5; the reference's own bf16-autocast step: 1.4e-3 / 2.3e-2 / 3.1e-1.
+    ("f16", "fsn_train_b4"): (2e-6, 1.2e-4, 1e-3, 1.2e-2, 1e-6),
     ("f16", "fsn_train_c3"): (2e-6, 2e-5, 3e-4, 6e-3, 1e-8),
-    ("bf16", "fsn_train_b4"): (2e-6, 1e-5, 3e-4, 5e-4, 1e-8),
+    ("bf16", "fsn_train_b4"): (1e-5, 5e-3, 2e-2, 8e-2, 5e-5),
     ("bf16", "fsn_train_c3"): (1e-5, 5e-3, 6e-3, 2.5e-2, 3e-7),
     ("bf16", "fsn_train_b4_bf16"): (1e-5, 5e-3, 7e-2, 1.0, 2e-4),
     ("bf16", "fsn_train_c3_bf16"): (1e-5, 3e-3, 8e-3, 1.5e-1, 7e-7),
