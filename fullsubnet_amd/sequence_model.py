@@ -257,7 +257,7 @@ class SequenceModel(nn.Module):
         arith = getattr(self, "train_arithmetic", "f32")
         chunks = None
         if self.cell == "LSTM" and self.num_layers == 2 and arith != "f32" and Hp == H:
-            chunks = lstm2_train_chunks(h.shape[0], h.shape[1], h.shape[2], H)
+            chunks = lstm2_train_chunks(h.shape[0], h.shape[1], h.shape[2], H, pad_small=h.shape[1] >= 256)
         if chunks is not None:
             params = [t for k in (0, 1) for t in self._layer_tensors(k)]
             h = lstm2_rows_chunked(h, params, arith, *chunks)
