@@ -83,7 +83,7 @@ class TrainDims(ctypes.Structure):  # fsn_train_dims
                 ("nb", ctypes.c_int), ("groups", ctypes.c_int), ("norm", ctypes.c_int)]
 
 
-ABI_VERSION = 114  # FSN_ABI_VERSION of include/fsn_hip.h these signatures were written against
+ABI_VERSION = 115  # FSN_ABI_VERSION of include/fsn_hip.h these signatures were written against
 
 
 class MaskSection(ctypes.Structure):  # fsn_mask_section
@@ -205,6 +205,7 @@ SIGNATURES = {
                                                _c.c_long, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
     "fsn_train_mask_out": (_c.c_int, [_c.c_void_p, _f32p, _c.c_int, _f32p, _c.c_void_p]),
     "fsn_train_mask_grad": (_c.c_int, [_c.c_void_p, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_void_p]),
+    "fsn_train_rows_pieces": (_c.c_int, [_f32p, _f32p, _c.c_int, _c.c_long, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     "fsn_train_cirm_target": (_c.c_int, [_c.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, _c.c_void_p]),
     "fsn_scale_by_scalar": (_c.c_int, [_f32p, _f32p, _f32p, _c.c_size_t, _c.c_void_p]),
     "fsn_fast_low_rate_frames": (_c.c_int, [_c.c_int, _c.c_int]),

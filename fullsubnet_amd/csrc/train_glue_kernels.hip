@@ -379,6 +379,26 @@ __global__ __launch_bounds__(256) void tr_target_kernel(const float* __restrict_
         target[dst + (size_t)d.Fs * d.T + t] = tr_compress((a * dd - bb * c) / den);
     }
 }
+// Time-major rows [T][N][W] <-> `n` pieces [n][T][rows][W] of whole clusters (rows beyond N: zeros going in, dropped coming
+// back): a batch of more sub-band rows than one persistent training launch holds runs piece by piece (train.py:
+// lstm2_train_chunks).  W is a multiple of 2 (float2 moves).  TO_PIECES: rows -> pieces, else pieces -> rows.
+template <bool TO_PIECES>
+__global__ __launch_bounds__(256) void tr_pieces_kernel(const float* __restrict__ src, float* __restrict__ dst, int T, long N, int W2,
+                                                        int rows, int n) {
+    const long per_t = (long)n * rows * W2;  // float2 elements of one step across all pieces
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_t; i += (long)gridDim.x * blockDim.x) {
+        const int t = blockIdx.y;
+        const long r = i / W2;              // padded row index = piece * rows + row
+        const int w = (int)(i - r * W2);
+        const long piece = r / rows, row = r - piece * rows;
+        const long po = ((piece * T + t) * rows + row) * W2 + w, ro = ((long)t * N + r) * W2 + w;
+        const float2* s2 = reinterpret_cast<const float2*>(src);
+        float2* d2 = reinterpret_cast<float2*>(dst);
+        if (TO_PIECES) d2[po] = r < N ? s2[ro] : float2{0.f, 0.f};
+        else if (r < N) d2[ro] = s2[po];
+    }
+}
+
 __global__ void tr_scale_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ y, size_t n) {
     const float k = *s;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = x[i] * k;
@@ -553,6 +573,21 @@ extern "C" int fsn_train_cirm_target(const fsn_train_dims* dims, const float* no
     hipLaunchKernelGGL(tr_target_kernel, dim3((unsigned)((d.T + 255) / 256), (unsigned)d.R), dim3(256), 0, static_cast<hipStream_t>(stream),
                        noisy_real, noisy_imag, clean_real, clean_imag, target, d);
     return fsn_check_launch("tr_target_kernel");
+}
+
+extern "C" int fsn_train_rows_pieces(const float* src, float* dst, int T, long N, int W, int rows, int n, int to_pieces, void* stream) {
+    FsnCallScope scope(stream);
+    FSN_REQUIRE(src && dst && T >= 1 && T <= 65535 && N >= 1 && W >= 2 && W % 2 == 0 && rows >= 1 && n >= 1 && (long)n * rows >= N,
+                "train rows <-> pieces: NULL pointer / bad sizes (W even, n rows >= N, T <= 65535)");
+    const long per_t = (long)n * rows * (W / 2);
+    const unsigned gx = (unsigned)((per_t + 255) / 256 < 2048 ? (per_t + 255) / 256 : 2048);
+    if (to_pieces)
+        hipLaunchKernelGGL(tr_pieces_kernel<true>, dim3(gx, (unsigned)T), dim3(256), 0, static_cast<hipStream_t>(stream), src, dst, T, N,
+                           W / 2, rows, n);
+    else
+        hipLaunchKernelGGL(tr_pieces_kernel<false>, dim3(gx, (unsigned)T), dim3(256), 0, static_cast<hipStream_t>(stream), src, dst, T, N,
+                           W / 2, rows, n);
+    return fsn_check_launch("tr_pieces_kernel");
 }
 
 extern "C" int fsn_scale_by_scalar(const float* x, const float* scale, float* y, size_t n, void* stream) {

@@ -274,18 +274,21 @@ def lstm2_train_chunks(T, N, I, H, pad_to_32=True, pad_small=False):
 
 
 def rows_to_pieces(x, rows, n):
-    """x [T, N, W] time-major -> [n, T, rows, W] contiguous: piece k holds rows [k rows, (k + 1) rows) (zeros beyond N)."""
+    """x [T, N, W] time-major (contiguous, on the GPU) -> [n, T, rows, W]: piece k holds rows [k rows, (k + 1) rows), zeros
+    beyond N (fsn_train_rows_pieces: no kernel of the host framework in the step)."""
     T, N, W = x.shape
-    if n * rows != N:
-        x = functional.pad(x, (0, 0, 0, n * rows - N))
-    return x.view(T, n, rows, W).permute(1, 0, 2, 3).contiguous()
+    out = torch.empty((n, T, rows, W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().fsn_train_rows_pieces(_lib.dev_ptr(x, "rows"), _lib.dev_ptr(out), T, N, W, rows, n, 1, _lib.stream_ptr(x.device)))
+    return out
 
 
-def pieces_to_rows(parts, T, rows, N):
-    """The inverse: n tensors [T, rows, W] (or [T rows, W]) -> [T, N, W] contiguous (rows beyond N dropped)."""
-    W = parts[0].shape[-1]
-    p = torch.stack([t.reshape(T, rows, W) for t in parts])               # [n, T, rows, W]
-    return p.permute(1, 0, 2, 3).reshape(T, len(parts) * rows, W)[:, :N].contiguous()
+def pieces_to_rows(pieces, N):
+    """The inverse: pieces [n, T, rows, W] (ONE contiguous tensor) -> [T, N, W] (rows beyond N dropped)."""
+    n, T, rows, W = pieces.shape
+    out = torch.empty((T, N, W), dtype=torch.float32, device=pieces.device)
+    _lib.check(_lib.lib().fsn_train_rows_pieces(_lib.dev_ptr(pieces, "pieces"), _lib.dev_ptr(out), T, N, W, rows, n, 0,
+                                                _lib.stream_ptr(pieces.device)))
+    return out
 
 
 def lstm2_rows_chunked(x_tn, params, arith, rows, n):
@@ -484,8 +487,8 @@ class FullSubNetTrainFunction(torch.autograd.Function):
                                                  _lib.dev_ptr(h1), s0.data_ptr(), s1.data_ptr(), nsave, ws.data_ptr(), ws.numel(), ar, st))
             return h0, h1, s0, s1
 
-        def linear(x, ldx, w, b, rows_, I, O, relu):
-            y = new(rows_, O)
+        def linear(x, ldx, w, b, rows_, I, O, relu, out=None):
+            y = new(rows_, O) if out is None else out
             ws = _lib.workspace(L.fsn_linear_workspace_bytes(rows_, I, O), dev)
             _lib.check(L.fsn_linear_forward(_lib.dev_ptr(x), ldx, _lib.dev_ptr(w), _lib.dev_ptr(b), rows_, I, O, relu, _lib.dev_ptr(y),
                                             ws.data_ptr(), ws.numel(), st))
@@ -506,16 +509,20 @@ class FullSubNetTrainFunction(torch.autograd.Function):
             # left-over rows advance step by step: 41 ms against 22 as two pieces)
             pieces = lstm2_train_chunks(Tp, Rp, Is, Hs, pad_to_32=False, pad_small=ar != _lib.ARITH["f32"] and Rp >= 256)
         if pieces is None:
-            xs = [sb_in]
+            xs, y2 = [sb_in], new(Tp * Rp, 2)
+            y2_out = [y2]
         else:
             xs = list(rows_to_pieces(sb_in, *pieces))                             # n x [Tp, rows, 32]
-        sb_saved, y2_parts = [], []
-        for xk in xs:
+            y2_pieces = new(pieces[1], Tp, pieces[0], 2)
+            y2_out = [y2_pieces[k].view(Tp * pieces[0], 2) for k in range(pieces[1])]
+        sb_saved = []
+        for xk, yk in zip(xs, y2_out):
             Nk = xk.shape[1]
             h0, h1, s0, s1 = lstm2(xk, 32, sb, Nk, Is, Hs)
-            y2_parts.append(linear(h1, Hs, sb_fc[0], sb_fc[1], Tp * Nk, Hs, 2, 0))  # [Tp Nk, 2]
+            linear(h1, Hs, sb_fc[0], sb_fc[1], Tp * Nk, Hs, 2, 0, out=yk)          # [Tp Nk, 2]
             sb_saved += [xk, h0, h1, s0, s1]
-        y2 = y2_parts[0] if pieces is None else pieces_to_rows(y2_parts, Tp, pieces[0], Rp)  # [Tp Rp, 2]
+        if pieces is not None:
+            y2 = pieces_to_rows(y2_pieces, Rp)                                     # [Tp, Rp, 2]
         mask = new(B, 2, Fs, T)
         _lib.check(L.fsn_train_mask_out(dp, _lib.dev_ptr(y2), Rp, _lib.dev_ptr(mask), st))
         ctx.save_for_backward(x_tm, fh0, fh1, fs0, fs1, fb_out, sb_in, den, gws, *sb_saved, *p)
@@ -557,8 +564,8 @@ class FullSubNetTrainFunction(torch.autograd.Function):
             _lib.check(L.fsn_linear_backward(*head, _lib.dev_ptr(dx), ldx, _lib.dev_ptr(dw), _lib.dev_ptr(db), ws.data_ptr(), ws.numel(), st))
             return dx, dw, db
 
-        def lstm2_bwd(dh, x, ldx, w, h0, h1, s0, s1, N, I, H, need_dx, beside=False):
-            dx = new(Tp, N, ldx) if need_dx else None
+        def lstm2_bwd(dh, x, ldx, w, h0, h1, s0, s1, N, I, H, need_dx, beside=False, dx_out=None):
+            dx = (new(Tp, N, ldx) if dx_out is None else dx_out) if need_dx else None
             dw = [torch.empty_like(w[k]) for k in (0, 1, 4, 5)]
             db0, db1 = new(4 * H), new(4 * H)
             ws = _lib.workspace(L.fsn_lstm2_bwd_workspace_bytes(Tp, N, I, H, ar), dev)
@@ -588,14 +595,17 @@ class FullSubNetTrainFunction(torch.autograd.Function):
         dy2 = new(Tp * Rp, 16)
         _lib.check(L.fsn_train_mask_grad(dp, _lib.dev_ptr(dm, "d_mask"), _lib.dev_ptr(dy2), Rp, 16, st))
         dy_parts = [dy2] if pieces is None else list(rows_to_pieces(dy2.view(Tp, Rp, 16), *pieces))
-        dx_parts, g_parts, fc_parts = [], [], []
+        dx_pieces = None if pieces is None else new(pieces[1], Tp, pieces[0], 32)
+        dx_sb, g_parts, fc_parts = None, [], []
         for k in range(n_sb):
             xk, sh0, sh1, ss0, ss1 = sb_saved[5 * k:5 * k + 5]
             Nk = xk.shape[1]
-            dsh1, d_sfw_k, d_sfb_k = linear_bwd(dy_parts[k].reshape(Tp * Nk, 16), 16, sh1, Hs, sb_fc[0], Tp * Nk, Hs, 2)  # (its parameter gradients beside the BPTT launch: measured, slows that launch by more)
-            dx_k, g_k = lstm2_bwd(dsh1, xk, 32, sb, sh0, sh1, ss0, ss1, Nk, Is, Hs, True, beside=True)
-            dx_parts.append(dx_k), g_parts.append(g_k), fc_parts.append((d_sfw_k, d_sfb_k))
-        dx_sb = dx_parts[0] if pieces is None else pieces_to_rows(dx_parts, Tp, pieces[0], Rp)
+            dsh1, d_sfw_k, d_sfb_k = linear_bwd(dy_parts[k].view(Tp * Nk, 16), 16, sh1, Hs, sb_fc[0], Tp * Nk, Hs, 2)  # (its parameter gradients beside the BPTT launch: measured, slows that launch by more)
+            dx_sb, g_k = lstm2_bwd(dsh1, xk, 32, sb, sh0, sh1, ss0, ss1, Nk, Is, Hs, True, beside=True,
+                                   dx_out=None if pieces is None else dx_pieces[k])
+            g_parts.append(g_k), fc_parts.append((d_sfw_k, d_sfb_k))
+        if pieces is not None:
+            dx_sb = pieces_to_rows(dx_pieces, Rp)
         d_fb = new(Tp * Bp, Fp)
         _lib.check(L.fsn_train_sb_input_backward(dp, _lib.dev_ptr(dx_sb), _lib.dev_ptr(sb_in), Rp, _lib.dev_ptr(den), _lib.dev_ptr(fb_out),
                                                  F, Bp, _lib.dev_ptr(d_fb), Fp, gws.data_ptr(), gws.numel(), st))

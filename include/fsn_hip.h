@@ -59,8 +59,8 @@ extern "C" {
 const char* fsn_last_error(void);
 /* The ABI revision this header describes.  fsn_version() returns the revision the LIBRARY was built with: a caller
  * compares the two once after loading (fullsubnet_amd/_lib.py raises on a mismatch) - argument lists changed between
- * revisions (114: + fsn_lstm2_train_is_persistent; 113: + fsn_gru2_forward; 112: + FSN_ARITH_SAVES16; 111: + the composed families' glue entries; 110: fsn_train_dims.norm, fsn_train_den_elems; 100 -> 101 of round 4: fsn_clip_adam_step's found_inf). */
-#define FSN_ABI_VERSION 114
+ * revisions (115: + fsn_train_rows_pieces; 114: + fsn_lstm2_train_is_persistent; 113: + fsn_gru2_forward; 112: + FSN_ARITH_SAVES16; 111: + the composed families' glue entries; 110: fsn_train_dims.norm, fsn_train_den_elems; 100 -> 101 of round 4: fsn_clip_adam_step's found_inf). */
+#define FSN_ABI_VERSION 115
 int fsn_version(void);
 
 /* ---- STFT / iSTFT : audio_zen/acoustics/feature.py ------------------------------------- */
@@ -453,6 +453,11 @@ int fsn_train_sb_input_backward(const fsn_train_dims* dims, const float* dx, con
                                 size_t workspace_bytes, void* stream);
 int fsn_train_mask_out(const fsn_train_dims* dims, const float* y, int Rp, float* mask, void* stream);
 int fsn_train_mask_grad(const fsn_train_dims* dims, const float* d_mask, float* dy, int Rp, int ld, void* stream);
+/* Time-major rows src [T][N][W] -> dst [n][T][rows][W] (to_pieces = 1; rows beyond N zero) or back (to_pieces = 0: src the
+ * pieces, dst the rows; rows beyond N dropped): a batch with more sub-band rows than one persistent training launch holds
+ * - the shipped TOMLs train 32 / 48 utterances per process, train.toml:52 - runs as n equal pieces of whole clusters
+ * (fullsubnet/model.py:121-128: the rows are independent sequences).  W even, n rows >= N, T <= 65535. */
+int fsn_train_rows_pieces(const float* src, float* dst, int T, long N, int W, int rows, int n, int to_pieces, void* stream);
 int fsn_train_cirm_target(const fsn_train_dims* dims, const float* noisy_real, const float* noisy_imag,
                           const float* clean_real, const float* clean_imag, float* target, void* stream);
 int fsn_scale_by_scalar(const float* x, const float* scale, float* y, size_t n, void* stream);
