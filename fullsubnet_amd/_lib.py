@@ -83,7 +83,7 @@ class TrainDims(ctypes.Structure):  # fsn_train_dims
                 ("nb", ctypes.c_int), ("groups", ctypes.c_int), ("norm", ctypes.c_int)]
 
 
-ABI_VERSION = 115  # FSN_ABI_VERSION of include/fsn_hip.h these signatures were written against
+ABI_VERSION = 116  # FSN_ABI_VERSION of include/fsn_hip.h these signatures were written against
 
 
 class MaskSection(ctypes.Structure):  # fsn_mask_section
@@ -143,6 +143,7 @@ SIGNATURES = {
     "fsn_lstm2_backward": (_c.c_int, [_f32p, _f32p, _c.c_long, _f32p, _f32p, _f32p, _f32p] + [_c.c_int] * 4 +
                            [_f32p, _f32p, _c.c_void_p, _c.c_void_p, _f32p, _c.c_long] + [_f32p] * 6 +
                            [_c.c_void_p, _c.c_size_t, _c.c_int, _c.c_void_p]),
+    "fsn_lstm_layer_plan_rows": (_c.c_int, [_c.c_int, _c.c_int]),
     "fsn_lstm_layer_fc_supported": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_long, _c.c_int, _c.c_int]),
     "fsn_lstm_layer_fc_workspace_bytes": (_c.c_size_t, [_c.c_int] * 4),
     "fsn_lstm_layer_forward_fc": (_c.c_int, [_f32p, _c.c_long, _f32p, _f32p, _f32p, _f32p] + [_c.c_int] * 4 +

@@ -1852,11 +1852,37 @@ static FsnRecPlan layer_plan(int N, int H) {
         p.rt = 1;
         p.main_wgs = p.tiles;
     } else {
+        // whole rounds on all CUs + left-over tiles step by step beside them ...
         p.rt = p.tiles / cus < 5 ? p.tiles / cus : 5;
         p.main_wgs = cus;
         p.left_tiles = p.tiles - cus * p.rt;
+        // ... or FEWER workgroups with one more tile each and nothing left over (the workgroups are independent: a launch
+        // takes its tiles-per-workgroup's time whatever its grid).  Measured on Fast FullSubNet's bottleneck (96 steps, round
+        // 6): ~11 ms per tile of a workgroup, ~0.11 ms per left-over tile - 448 tiles as 256 x 1 + 192 left over 32.2 ms, as
+        // 224 x 2 what 512 tiles take (25.4); 288 tiles stay 256 x 1 + 32 (21.0 against 24.6).
+        const int rt2 = (p.tiles + cus - 1) / cus;
+        if (p.left_tiles > 0 && rt2 <= 4 && p.tiles % rt2 == 0 && 100 * rt2 < 100 * p.rt + p.left_tiles) {
+            p.rt = rt2;
+            p.main_wgs = p.tiles / rt2;
+            p.left_tiles = 0;
+        }
     }
     return p;
+}
+// Rows (a multiple of 16, >= N) a caller that owns the row padding should give a stand-alone layer of N rows: the next count
+// whose plan has no left-over tiles when that is the cheaper plan by the measure above, N itself otherwise.
+extern "C" int fsn_lstm_layer_plan_rows(int N, int H) {
+    if (N < 1) return N;
+    const int n16 = fsn_round_up(N, 16);
+    const FsnRecPlan p = layer_plan(n16, H);
+    if (p.main_wgs <= 0 || p.left_tiles == 0) return n16;
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus < 1) cus = 256;
+    const int rt2 = (p.tiles + cus - 1) / cus;
+    if (rt2 > 4) return n16;
+    const int padded = (p.tiles + rt2 - 1) / rt2 * rt2;
+    return 100 * rt2 < 100 * p.rt + p.left_tiles ? padded * 16 : n16;
 }
 
 extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_ih, const float* w_hh,

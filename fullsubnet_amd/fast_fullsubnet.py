@@ -182,7 +182,9 @@ class Model(BaseModel):
         n_mel, n_enc = self.noisy_input_num_neighbors, self.enc_output_num_neighbors
         W = (2 * n_mel + 1) + (2 * n_enc + 1)
         Wp, N = (W + 15) // 16 * 16, B * M
-        Np, Ts = (N + 15) // 16 * 16, L.fsn_fast_low_rate_frames(T, s)
+        # the bottleneck's rows: padded to a count the persistent kernels take whole where that is the faster plan (e.g. 112
+        # utterances x 64 bands = 448 row tiles: 224 workgroups x 2 tiles instead of 256 x 1 + 192 tiles step by step)
+        Np, Ts = L.fsn_lstm_layer_plan_rows((N + 15) // 16 * 16, self.bottleneck.hidden_size), L.fsn_fast_low_rate_frames(T, s)
         units = torch.empty((Ts, Np, Wp), **f32)
         _lib.check(L.fsn_fast_bottleneck_input(_lib.dev_ptr(mel), _lib.dev_ptr(enc), enc.stride(1), T, B, Bp, M, n_mel, n_enc, s,
                                                _lib.dev_ptr(units), Np, Wp, ws.data_ptr(), ws.numel(), st))

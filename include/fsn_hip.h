@@ -59,8 +59,8 @@ extern "C" {
 const char* fsn_last_error(void);
 /* The ABI revision this header describes.  fsn_version() returns the revision the LIBRARY was built with: a caller
  * compares the two once after loading (fullsubnet_amd/_lib.py raises on a mismatch) - argument lists changed between
- * revisions (115: + fsn_train_rows_pieces; 114: + fsn_lstm2_train_is_persistent; 113: + fsn_gru2_forward; 112: + FSN_ARITH_SAVES16; 111: + the composed families' glue entries; 110: fsn_train_dims.norm, fsn_train_den_elems; 100 -> 101 of round 4: fsn_clip_adam_step's found_inf). */
-#define FSN_ABI_VERSION 115
+ * revisions (116: + fsn_lstm_layer_plan_rows; 115: + fsn_train_rows_pieces; 114: + fsn_lstm2_train_is_persistent; 113: + fsn_gru2_forward; 112: + FSN_ARITH_SAVES16; 111: + the composed families' glue entries; 110: fsn_train_dims.norm, fsn_train_den_elems; 100 -> 101 of round 4: fsn_clip_adam_step's found_inf). */
+#define FSN_ABI_VERSION 116
 int fsn_version(void);
 
 /* ---- STFT / iSTFT : audio_zen/acoustics/feature.py ------------------------------------- */
@@ -333,6 +333,11 @@ int fsn_lstm_layer_backward(const float* dh, const float* x, long ldx, const flo
  * output layer does the nn.Linear too: the [T][N][H] hidden sequence is neither written nor read back.  out0 / out1:
  * PRE-activation outputs 0 / 1, time-major [T][ldo] (out1 may be NULL when O == 1); the caller applies the block's
  * activation.  Any other shape: FSN_ERR_ARG (fsn_lstm_layer_forward + fsn_linear_forward take it). */
+/* Row padding hint for a caller that owns the padding of a stand-alone inference layer's rows: the row count (a multiple of 16,
+ * >= N) to allocate so that the persistent kernels take every row with no left-over tiles, where that is the faster plan (e.g. 448
+ * row tiles: 224 workgroups x 2 tiles instead of 256 x 1 + 192 tiles step by step); N rounded up to 16 otherwise.  Rows beyond N
+ * must be zero-filled inputs (their outputs are not meaningful). */
+int fsn_lstm_layer_plan_rows(int N, int H);
 int fsn_lstm_layer_fc_supported(int T, int N, int I, long ldx, int H, int O);
 size_t fsn_lstm_layer_fc_workspace_bytes(int T, int N, int I, int H);
 int fsn_lstm_layer_forward_fc(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,

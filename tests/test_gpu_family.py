@@ -91,12 +91,14 @@ def test_fast_fullsubnet_many_rows_on_the_persistent_kernels(fsn, batch):
     assert np.abs(crm[[1, batch - 1]] - want).max() <= 1e-4
 
 
-@pytest.mark.parametrize("batch", [128, 192, 256])
+@pytest.mark.parametrize("batch", [112, 128, 176, 192, 256])
 def test_fast_fullsubnet_config4_full_size(fsn, batch):
     """BASELINE config 4's own batch (256 utterances x 64 mel bands = 16 384 bottleneck rows = 1024 row tiles: FOUR tiles
     per workgroup on the persistent recurrent kernels - layer 0 `lstm_rec_kernel<384,4,2,true>` on the generic x_rows
     input, layer 1 `lstm_rec_x_kernel<384,4,2,0,true>` with the hidden sequence streamed out, 81 % of that config's
-    step) and the two neighbouring plans (128 -> RT = 2, 192 -> RT = 3): the oracle on two utterances (1e-4, the
+    step), the two neighbouring plans (128 -> RT = 2, 192 -> RT = 3) and two batches between the plans, whose rows the model
+    pads to a count the persistent kernels take whole (fsn_lstm_layer_plan_rows: 112 utterances = 448 tiles as 224
+    workgroups x 2, 176 = 704 -> 705 tiles as 235 x 3): the oracle on two utterances (1e-4, the
     north-star bound on the compressed mask), and EVERY utterance against its own result inside a batch of 32 (group
     kernel: other instantiations, other summation order).  fast_fullsubnet/model.py:143-202."""
     from fullsubnet_amd.fast_fullsubnet import Model
@@ -116,7 +118,8 @@ def test_fast_fullsubnet_config4_full_size(fsn, batch):
         small = torch.cat([m(x[i:i + 32]) for i in range(0, batch, 32)], dim=0).cpu().numpy()
         # the bottleneck's last layer with the kernel's fused output layer (fsn_lstm_layer_forward_fc: no hidden sequence
         # written) against the layer + fsn_linear_forward form
-        units_rows = batch * 64
+        units_rows = fsn._lib.lib().fsn_lstm_layer_plan_rows(batch * 64, 384)
+        assert units_rows >= batch * 64 and (units_rows > batch * 64) == (batch == 176)
         assert fsn._lib.lib().fsn_lstm_layer_fc_supported(22, units_rows, 384, 384, 384, 1) == 1
         m.fused_output_layer = False
         unfused = m(x).cpu().numpy()
