@@ -105,8 +105,13 @@ static std::atomic<int> g_persist_timeout_ms{20000};  // fsn_set_persistent_time
 //   for every k of the set.
 // One kernel alone is always admitted (its own grid was checked against occ x CUs at plan time).  Examples on 256 CUs:
 // two chain launches of H = 384 with two row tiles (192 workgroups, 2 per CU each) run side by side, a third waits; two
-// group launches of 28 clusters (448 workgroups, 2 per CU) do not.  Nothing else of the streams is ordered.  Not under
-// stream capture: the replays of a graph are ordered by whoever launches them.
+// group launches of 28 clusters (448 workgroups, 2 per CU) do not.  Nothing else of the streams is ordered.
+// Under stream capture (round 6) the same rule orders the persistent launches of ONE capture among themselves, through
+// captured event edges: a graph's replay runs the captured streams' kernels side by side exactly as far as the edges allow, and
+// a call with several persistent launches on side streams (Improved FullSubNet's band sections at a few utterances: chain
+// launches of one workgroup per CU) replayed without them stalled or ran out of time in ~1 % of the replays
+// (tools/diag_stall.py).  Nothing can be retired during a capture: every earlier launch of the capture counts as live.  The
+// replays of DIFFERENT graphs (and eager calls beside them) are ordered by whoever launches them.
 struct PersistEntry {
     hipEvent_t ev;
     hipStream_t stream;
@@ -119,6 +124,7 @@ struct PersistGate {
 };
 static std::mutex g_persist_mutex;
 static std::map<int, PersistGate> g_persist;
+static std::map<std::pair<int, unsigned long long>, PersistGate> g_persist_capture;  // (device, capture id) -> the capture's launches
 // umin(k) in units of 1 / 840 (= lcm(1 .. 8); occupancies above 8 count as 8, which only makes workgroups larger)
 static int persist_umin(const std::vector<int>& occs, int occ_k) {
     bool reach[841] = {};
@@ -150,13 +156,33 @@ class PersistLaunch {
   public:
     explicit PersistLaunch(hipStream_t s) : s_(s), lock_(g_persist_mutex) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        unsigned long long cap_id = 0;
+        if (hipStreamGetCaptureInfo(s, &cap, &cap_id) != hipSuccess) {
             (void)hipGetLastError();
             return;
         }
         int dev = 0;
         (void)hipGetDevice(&dev);
+        if (cap == hipStreamCaptureStatusActive) {
+            // the capture's own gate: its launches, ordered by captured event edges; events come from (and return to) the
+            // device's pool; the gates of finished captures are dropped once a few newer ones exist
+            pool_ = &g_persist[dev].pool;
+            const std::pair<int, unsigned long long> key(dev, cap_id);
+            if (!g_persist_capture.count(key)) {
+                while (g_persist_capture.size() >= 4) {
+                    auto old = g_persist_capture.begin();  // smallest (device, id): an earlier capture
+                    if (old->first.first == dev)
+                        for (PersistEntry& e : old->second.live) g_persist[dev].pool.push_back(e.ev);
+                    g_persist_capture.erase(old);
+                }
+            }
+            gate_ = &g_persist_capture[key];
+            t_persist = this;
+            return;
+        }
+        if (cap != hipStreamCaptureStatusNone) return;  // an invalidated capture: nothing to order
         gate_ = &g_persist[dev];
+        pool_ = &gate_->pool;
         // retire what has completed
         std::vector<PersistEntry>& live = gate_->live;
         for (size_t i = 0; i < live.size();) {
@@ -195,18 +221,19 @@ class PersistLaunch {
         t_persist = nullptr;
         if (!gate_) return;
         hipEvent_t ev = nullptr;
-        if (!gate_->pool.empty()) {
-            ev = gate_->pool.back();
-            gate_->pool.pop_back();
+        const bool capturing = pool_ != &gate_->pool;
+        if (!pool_->empty()) {
+            ev = pool_->back();
+            pool_->pop_back();
         } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
-            (void)hipStreamSynchronize(s_);  // no event to order later launches by: drain instead
+            if (!capturing) (void)hipStreamSynchronize(s_);  // no event to order later launches by: drain instead
             return;
         }
         if (hipEventRecord(ev, s_) != hipSuccess) {
             (void)hipGetLastError();
-            gate_->pool.push_back(ev);
-            (void)hipStreamSynchronize(s_);
+            pool_->push_back(ev);
+            if (!capturing) (void)hipStreamSynchronize(s_);
             return;
         }
         me_.ev = ev;
@@ -226,6 +253,7 @@ class PersistLaunch {
     hipStream_t s_;
     std::unique_lock<std::mutex> lock_;
     PersistGate* gate_ = nullptr;
+    std::vector<hipEvent_t>* pool_ = nullptr;  // where events come from: the device's pool (a capture's gate has none of its own)
     PersistEntry me_{};
     bool admitted_ = false;
 };

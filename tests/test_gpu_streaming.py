@@ -155,6 +155,35 @@ def test_enhance_is_capturable_in_a_hip_graph(setup, batch):
     assert torch.equal(static_out, model.enhance(other))
 
 
+def test_graph_replays_with_several_persistent_launches_never_stall(setup):
+    """A captured call with persistent launches on several side streams (Improved FullSubNet's band sections at three
+    utterances: chain launches of one workgroup per CU that cannot share the chip): the admission rule of the eager path
+     orders them inside the capture as well, through captured event edges.  Without them ~1 % of the replays stalled
+    for seconds or ran into the 20 s wait bound and came back poisoned (round 6, tools/diag_stall.py: 6 of 600).  400 replays:
+    every one finite and within a small multiple of the median."""
+    import time
+    fsn, _, _ = setup
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    import bench_family
+    m = bench_family.build("improved16")[0]
+    graphed = fsn.GraphedCall(bench_family.enhance_fn("improved16", m))
+    x = torch.from_numpy(O.make_noisy(3, 8192, seed=33)).cuda()
+    want = graphed(x).clone()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(400):
+        t0 = time.perf_counter()
+        y = graphed(x)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        assert torch.equal(y, want)
+    med = sorted(times)[len(times) // 2]
+    assert max(times) < max(50 * med, 0.25), (med, max(times))
+
+
 @pytest.mark.parametrize("which", ["fullsubnet", "improved16", "fast"])
 def test_graphed_call_replays_the_eager_result(setup, which):
     """fullsubnet_amd.GraphedCall: one hipGraph per input shape, captured on first use (side streams, persistent launches
