@@ -16,8 +16,17 @@ which = sys.argv[1] if len(sys.argv) > 1 else "improved16"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 L = int(sys.argv[4]) if len(sys.argv) > 4 else 8192
-m = bench_family.build(which)[0]
-fn = bench_family.enhance_fn(which, m)
+if which == "fullsubnet":
+    from fsn_synthetic import make_params
+    m = fsn.Model(num_freqs=257, look_ahead=2, sequence_model="LSTM", fb_num_neighbors=0, sb_num_neighbors=15,
+                  fb_output_activate_function="ReLU", sb_output_activate_function=False, fb_model_hidden_size=512,
+                  sb_model_hidden_size=384, norm_type="offline_laplace_norm", num_groups_in_drop_band=1, weight_init=False)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in make_params(seed=3).items()})
+    m = m.cuda().eval()
+    fn = m.enhance
+else:
+    m = bench_family.build(which)[0]
+    fn = bench_family.enhance_fn(which, m)
 x = torch.from_numpy(make_noisy(B, L, seed=33)).cuda()
 for mode in ("eager", "graph"):
     call = fn if mode == "eager" else fsn.GraphedCall(fn)
