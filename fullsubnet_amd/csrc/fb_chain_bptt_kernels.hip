@@ -65,7 +65,8 @@ __device__ __forceinline__ bool qwait(const unsigned* flags, unsigned epoch, con
 }
 
 __global__ __launch_bounds__(256, 1) void fb_chain_bptt_kernel(const ChainBpttArgs a) {
-    __shared__ f32x4 red[4][QMAXT][64];      // partial sums of (wave, tile)
+    extern __shared__ f32x4 red[];           // partial sums of (wave, tile): [4][nt][64] (4 KB per row tile: the launch beside the
+                                             // weight-gradient products' 144 KB workgroups needs the CU's last 16 KB)
     const int role = (int)blockIdx.x / QNW, j = (int)blockIdx.x % QNW;  // thirds of the grid: L1, X, L0
     const int l1 = role == 0 ? 1 : 0;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -183,17 +184,17 @@ __global__ __launch_bounds__(256, 1) void fb_chain_bptt_kernel(const ChainBpttAr
                       unsigned* flags, unsigned epoch) {
 #pragma unroll
         for (int k = 0; k < QMAXT; ++k)
-            if (k < nt) red[wave][k][lane] = acc[k];
+            if (k < nt) red[(wave * nt + k) * 64 + lane] = acc[k];
         __syncthreads();
 #pragma unroll
         for (int o = 0; o < QOWN; ++o) {
             const int tile = wave + 4 * o;
             if (tile < nt) {
                 if (o > 0) load_saved(t, tile, e_g, e_ct, e_cp, e_dh);
-                f32x4 v = red[0][tile][lane];
+                f32x4 v = red[tile * 64 + lane];
 #pragma unroll
                 for (int p = 1; p < 4; ++p) {
-                    const f32x4 r = red[p][tile][lane];
+                    const f32x4 r = red[(p * nt + tile) * 64 + lane];
                     v = f32x4{v[0] + r[0], v[1] + r[1], v[2] + r[2], v[3] + r[3]};
                 }
                 cell(t, tile, dc[o], f32x4{v[0] + e_dh[0], v[1] + e_dh[1], v[2] + e_dh[2], v[3] + e_dh[3]}, e_g, e_ct, e_cp);
@@ -304,6 +305,7 @@ int fsn_launch_fb_chain_bptt(const float* dh1, const float* whh1T_p, const float
     a.spin_ticks = fsn_spin_ticks();
     a.Tp = Tp;
     a.N = N;
-    FSN_PERSIST_LAUNCH(fb_chain_bptt_kernel, dim3(3 * QNW), dim3(256), s, a);
+    fsn_persist_admit((const void*)fb_chain_bptt_kernel, 256, 3u * QNW);
+    hipLaunchKernelGGL(fb_chain_bptt_kernel, dim3(3 * QNW), dim3(256), (size_t)(N / 16) * 4 * 64 * sizeof(f32x4), s, a);
     return fsn_check_launch("fb_chain_bptt_kernel");
 }
