@@ -160,15 +160,18 @@ def test_train_step_vs_reference_and_oracle(fsn, golden_dir, name):
 
 
 @pytest.mark.parametrize("norm", ["offline_laplace_norm", "cumulative_laplace_norm"])
-@pytest.mark.parametrize("B,groups,T,nb", [(3, 2, 7, 15), (5, 3, 6, 15), (1, 2, 9, 15), (4, 1, 5, 15), (3, 2, 6, 7), (5, 2, 5, 0)])
+@pytest.mark.parametrize("B,groups,T,nb", [(3, 2, 7, 15), (5, 3, 6, 15), (1, 2, 9, 15), (4, 1, 5, 15), (3, 2, 6, 7), (5, 2, 5, 0),
+                                           (26, 2, 4, 15), (13, 1, 3, 15)])
 def test_fused_training_graph_vs_the_tensor_algebra_graph(fsn, monkeypatch, B, groups, T, nb, norm):
     """FullSubNetTrainFunction (csrc/train_glue_kernels.hip: look-ahead pad + norm, sub-band input forward / backward, mask
     reshape and its gradient as kernels, one autograd node for the model) against the same graph with the glue as
     autograd-tracked tensor algebra (model.fused_training_graph = False; itself held to the reference's goldens), for both
     Laplace norms: odd batch sizes (uneven drop_band groups), three groups, a single utterance (no band dropping), groups =
     1, fewer neighbours than the 15 that fill the LSTM entries' 32 input columns (the padding columns of the input
-    gradient are never written: the fused graph runs with NaN-poisoned buffers here); the band-dropped cIRM target kernel
-    against drop_band(build_complex_ideal_ratio_mask)."""
+    gradient are never written: the fused graph runs with NaN-poisoned buffers here), batches with more sub-band rows than one
+    persistent launch holds (26 utterances x 128 bins = 3328 rows as two pieces of 1664; 13 x 257 = 3341 rows, Rp = 3344, as
+    two of 1728 - the last piece's zero rows behind poisoned buffers); the band-dropped cIRM target kernel against
+    drop_band(build_complex_ideal_ratio_mask)."""
     from fullsubnet_amd.train import forward_train, fused_train_supported, mse_loss
     params = O.make_params(seed=B * 10 + groups, gain=1.5, sb_num_neighbors=nb)
     rng = np.random.default_rng(T)
