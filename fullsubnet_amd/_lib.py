@@ -83,7 +83,7 @@ class TrainDims(ctypes.Structure):  # fsn_train_dims
                 ("nb", ctypes.c_int), ("groups", ctypes.c_int), ("norm", ctypes.c_int)]
 
 
-ABI_VERSION = 116  # FSN_ABI_VERSION of include/fsn_hip.h these signatures were written against
+ABI_VERSION = 117  # FSN_ABI_VERSION of include/fsn_hip.h these signatures were written against
 
 
 class MaskSection(ctypes.Structure):  # fsn_mask_section
@@ -173,6 +173,7 @@ SIGNATURES = {
     "fsn_gru2_forward_supported": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int]),
     "fsn_gru2_fwd_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "fsn_gru2_forward": (_c.c_int, [_f32p, _c.c_long] + [_f32p] * 8 + [_c.c_int] * 4 + [_f32p, _c.c_void_p, _c.c_size_t, _c.c_void_p]),
+    "fsn_gru_layer_is_persistent": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_long, _c.c_int]),
     "fsn_gru_layer_save_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int]),
     "fsn_gru_layer_fwd_workspace_bytes": (_c.c_size_t, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "fsn_gru_layer_forward": (_c.c_int, [_f32p, _c.c_long, _f32p, _f32p, _f32p, _f32p, _c.c_int, _c.c_int, _c.c_int,

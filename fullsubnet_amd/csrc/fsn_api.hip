@@ -3146,7 +3146,43 @@ extern "C" int fsn_lstm2_backward_phase(const float* dh1, const float* x, long l
 extern "C" size_t fsn_gru_layer_save_bytes(int T, int N, int H) {
     return fsn_round_up_sz((size_t)T * N * 4 * H * sizeof(float), 256);  // r | z | n | hn
 }
-extern "C" size_t fsn_gru_layer_fwd_workspace_bytes(int T, int N, int I, int H) {
+// Many rows in inference (the sub-band model of a GRU FullSubNet: B F rows, audio_zen/model/module/sequence_model.py:59-66
+// under fullsubnet/model.py:121-128): the layer runs on the LSTM's persistent kernels with the GRU written as a four-gate
+// cell (FSN_REC_GRU, lstm_kernels.hip) - lstm_rec_in_kernel for a narrow row-major input (<= 32 columns: the projection is
+// formed inside), lstm_rec_x_kernel for the layer above an equally wide one (input = its hidden sequence, no projection
+// GEMM, no gx round trip).  Whole rounds of 2 - 4 row tiles per workgroup; the few left-over tiles advance step by step
+// on the auxiliary stream beside the persistent launch, on compact copies of their rows.
+struct GruPlan {
+    int rt, main_wgs, left_tiles;
+};
+static GruPlan gru_layer_plan(int N, int I, long ldx, int H) {
+    GruPlan p{0, 0, N / 16};
+    const int Ipad = fsn_round_up(I, 16);
+    if (H != 384 || !((Ipad <= 32 && (ldx <= 0 || ldx >= Ipad)) || (I == H && (ldx <= 0 || ldx == H)))) return p;
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus < 1) cus = 256;
+    const int tiles = N / 16;
+    if (tiles < cus) return p;  // fewer than 16 rows per CU: the step launches spread a step over more workgroups
+    long best = -1;
+    for (int rt = 4; rt >= 2; --rt) {
+        // whole rounds of rt tiles on every CU, or ONE round of fewer workgroups; a left-over tile costs about a
+        // hundredth of a tile of a resident workgroup (layer_plan's measure)
+        int wgs = 0;
+        const int rounds = tiles / (cus * rt);
+        if (rounds >= 1) wgs = rounds * cus;
+        else if (tiles / rt <= cus) wgs = tiles / rt;
+        if (wgs < 1) continue;
+        const int left = tiles - wgs * rt;
+        const long cost = (long)((wgs + cus - 1) / cus) * rt * 100 + left;
+        if (best < 0 || cost < best) {
+            best = cost;
+            p = GruPlan{rt, wgs, left};
+        }
+    }
+    return p;
+}
+static size_t gru_layer_step_workspace_bytes(int T, int N, int I, int H) {
     Carver cv(nullptr);
     cv.take<float>((size_t)3 * H * fsn_round_up(I, 16));
     cv.take<float>((size_t)3 * H * H);
@@ -3154,19 +3190,28 @@ extern "C" size_t fsn_gru_layer_fwd_workspace_bytes(int T, int N, int I, int H) 
     cv.take<float>((size_t)T * N * 3 * H);
     return fsn_round_up_sz(cv.off, 256);
 }
-
-extern "C" int fsn_gru_layer_forward(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
-                                     const float* b_hh, int T, int N, int I, int H, float* hseq, void* save,
-                                     size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream) {
-    CallScope scope(stream);
-    FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
-    FSN_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && hseq && workspace, "NULL pointer argument");
-    if ((save && save_bytes < fsn_gru_layer_save_bytes(T, N, H)) ||
-        workspace_bytes < fsn_gru_layer_fwd_workspace_bytes(T, N, I, H)) {
-        fsn_set_error("gru layer forward: save / workspace buffer too small");
-        return FSN_ERR_WORKSPACE;
+extern "C" size_t fsn_gru_layer_fwd_workspace_bytes(int T, int N, int I, int H) {
+    if (T < 1 || N < 16 || I < 1 || H < 64) return 0;
+    const size_t Ipad = fsn_round_up(I, 16), G4 = 4 * (size_t)H;
+    const GruPlan p = gru_layer_plan(N, I, 0, H);
+    Carver cv(nullptr);
+    if (p.main_wgs > 0) {  // the persistent form's own buffers first, the step form's region (left-over rows) behind them
+        cv.take<float>(G4 * Ipad + G4 * H);  // the four-gate matrices as expanded ...
+        cv.take<float>(G4 * Ipad + G4 * H);  // ... and in fragment order, W_hh right behind W_ih
+        cv.take<float>(G4);
+        cv.take<float>((size_t)T * p.left_tiles * 16 * Ipad);
+        cv.take<float>((size_t)T * p.left_tiles * 16 * H);
     }
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    cv.take<char>(gru_layer_step_workspace_bytes(T, N, I, H));
+    return fsn_round_up_sz(cv.off, 256);
+}
+extern "C" int fsn_gru_layer_is_persistent(int T, int N, int I, long ldx, int H) {
+    return T >= 1 && N >= 16 && N % 16 == 0 && I >= 1 && gru_layer_plan(N, I, ldx, H).main_wgs > 0 ? 1 : 0;
+}
+
+static int gru_layer_forward_steps(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
+                                   const float* b_hh, int T, int N, int I, int H, float* hseq, float* sv, void* workspace,
+                                   hipStream_t s) {
     const int Ipad = fsn_round_up(I, 16), G = 3 * H;
     Carver cv(workspace);
     float* wih_p = cv.take<float>((size_t)G * Ipad);
@@ -3188,11 +3233,100 @@ extern "C" int fsn_gru_layer_forward(const float* x, long ldx, const float* w_ih
     c.bias = bias;
     FSN_TRY(fsn_launch_gemm(a, wih_p, c, T * (N / 16), G / 16, Ipad / 16, s));
     const size_t step = (size_t)N * H;
-    float* sv = static_cast<float*>(save);
     for (int t = 0; t < T; ++t)
         FSN_TRY(fsn_launch_gru_step(gx, whh_p, b_hh + 2 * H, t ? hseq + (t - 1) * step : hseq, hseq + t * step,
                                     sv ? sv + (size_t)t * N * 4 * H : nullptr, (long)t * (N / 16), N / 16, H, t == 0, s));
     return FSN_OK;
+}
+
+static int gru_layer_forward_persistent(const GruPlan& p, const float* x, long ldx, const float* w_ih, const float* w_hh,
+                                        const float* b_ih, const float* b_hh, int T, int N, int I, int H, float* hseq,
+                                        void* workspace, hipStream_t s) {
+    const int Ipad = fsn_round_up(I, 16), G4 = 4 * H;
+    const int left = p.left_tiles * 16, main_rows = N - left;
+    Carver cv(workspace);
+    float* w4 = cv.take<float>((size_t)G4 * Ipad + (size_t)G4 * H);
+    float* w4p = cv.take<float>((size_t)G4 * Ipad + (size_t)G4 * H);
+    float* b4 = cv.take<float>((size_t)G4);
+    float* x_left = cv.take<float>((size_t)T * left * Ipad);
+    float* h_left = cv.take<float>((size_t)T * left * H);
+    void* step_ws = cv.take<char>(0);
+    float *wih4 = w4, *whh4 = w4 + (size_t)G4 * I, *wih4_p = w4p, *whh4_p = w4p + (size_t)G4 * Ipad;
+    FSN_TRY(fsn_launch_gru_expand4(w_ih, w_hh, b_ih, b_hh, wih4, whh4, b4, I, H, s, 1));
+    FSN_TRY(fsn_launch_pack(wih4, wih4_p, G4, I, G4, Ipad, s));
+    FSN_TRY(fsn_launch_pack(whh4, whh4_p, G4, H, G4, H, s));
+    hipStream_t ls = s;
+    StreamCtx* cx = nullptr;
+    if (left > 0) {
+        cx = cur_ctx();
+        FSN_TRY(aux_init(cx));
+        if (hipEventRecord(cx->ev_fork, s) != hipSuccess || hipStreamWaitEvent(cx->aux, cx->ev_fork, 0) != hipSuccess) {
+            fsn_set_error("aux stream fork failed");
+            return FSN_ERR_LAUNCH;
+        }
+        ls = cx->aux;
+    }
+    if (Ipad <= 32) {
+        FsnSbInput xin{};
+        xin.x_rows = x;
+        xin.x_ld = ldx;
+        xin.x_step = N;
+        xin.N = main_rows;
+        xin.kin_chunks = Ipad / 16;
+        xin.wih_p = wih4_p;
+        xin.bias = b4;
+        FSN_TRY(fsn_launch_lstm_rec_in(&xin, whh4_p, hseq, T, N, H, p.rt, p.main_wgs, s, 1));
+    } else {
+        FSN_TRY(fsn_launch_lstm_rec_x(x, wih4_p, whh4_p, b4, T, N, H, p.rt, p.main_wgs, s, nullptr, hseq, 1));
+    }
+    if (left > 0) {
+        // rows [main_rows, N) of every step as compact [T][left] matrices: in, step launches, out
+        // (columns [0, Ipad) of a row; one 2-D copy when the rows are exactly that wide, one per step otherwise)
+        bool ok = true;
+        if (ldx == Ipad)
+            ok = hipMemcpy2DAsync(x_left, (size_t)left * Ipad * sizeof(float), x + (size_t)main_rows * ldx,
+                                  (size_t)N * ldx * sizeof(float), (size_t)left * Ipad * sizeof(float), (size_t)T,
+                                  hipMemcpyDeviceToDevice, ls) == hipSuccess;
+        else
+            for (int t = 0; t < T && ok; ++t)
+                ok = hipMemcpy2DAsync(x_left + (size_t)t * left * Ipad, (size_t)Ipad * sizeof(float),
+                                      x + ((size_t)t * N + main_rows) * ldx, (size_t)ldx * sizeof(float),
+                                      (size_t)Ipad * sizeof(float), (size_t)left, hipMemcpyDeviceToDevice, ls) == hipSuccess;
+        if (!ok) {
+            fsn_set_error("gru layer forward: copy of the left-over rows failed");
+            return FSN_ERR_LAUNCH;
+        }
+        FSN_TRY(gru_layer_forward_steps(x_left, Ipad, w_ih, w_hh, b_ih, b_hh, T, left, I, H, h_left, nullptr, step_ws, ls));
+        if (hipMemcpy2DAsync(hseq + (size_t)main_rows * H, (size_t)N * H * sizeof(float), h_left, (size_t)left * H * sizeof(float),
+                             (size_t)left * H * sizeof(float), (size_t)T, hipMemcpyDeviceToDevice, ls) != hipSuccess) {
+            fsn_set_error("gru layer forward: copy of the left-over rows failed");
+            return FSN_ERR_LAUNCH;
+        }
+        if (hipEventRecord(cx->ev_join, cx->aux) != hipSuccess || hipStreamWaitEvent(s, cx->ev_join, 0) != hipSuccess) {
+            fsn_set_error("aux stream join failed");
+            return FSN_ERR_LAUNCH;
+        }
+    }
+    return FSN_OK;
+}
+
+extern "C" int fsn_gru_layer_forward(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
+                                     const float* b_hh, int T, int N, int I, int H, float* hseq, void* save,
+                                     size_t save_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+    CallScope scope(stream);
+    FSN_TRY(check_lstm_layer(T, N, I, H, ldx));
+    FSN_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && hseq && workspace, "NULL pointer argument");
+    if ((save && save_bytes < fsn_gru_layer_save_bytes(T, N, H)) ||
+        workspace_bytes < fsn_gru_layer_fwd_workspace_bytes(T, N, I, H)) {
+        fsn_set_error("gru layer forward: save / workspace buffer too small");
+        return FSN_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!save) {
+        const GruPlan p = gru_layer_plan(N, I, ldx, H);
+        if (p.main_wgs > 0) return gru_layer_forward_persistent(p, x, ldx, w_ih, w_hh, b_ih, b_hh, T, N, I, H, hseq, workspace, s);
+    }
+    return gru_layer_forward_steps(x, ldx, w_ih, w_hh, b_ih, b_hh, T, N, I, H, hseq, static_cast<float*>(save), workspace, s);
 }
 
 // Streaming form (chunked / frame-by-frame inference with carried state): T more steps from h_state [N][H], which is

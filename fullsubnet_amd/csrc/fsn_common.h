@@ -398,8 +398,9 @@ int fsn_launch_fb_chain(const float* gx0, const float* whh0_p, const float* wih1
                         float* hseq0 = nullptr, float* save0 = nullptr, float* save1 = nullptr, int cell = 0);
 // gru_kernels.hip: nn.GRU's [3H] gate rows (r, z, n) of one layer as the FOUR-gate cell the chain kernel runs (r | z | nx | nh):
 // w_ih4 [4H][I] = W_ir; W_iz; W_in; 0   w_hh4 [4H][H] = W_hr; W_hz; 0; W_hn   b4 [4H] = b_ir + b_hr; b_iz + b_hz; b_in; b_hn
+// order 1: the gate slots of the many-row persistent kernels (lstm_kernels.hip, FSN_REC_GRU): nh | r | nx | z
 int fsn_launch_gru_expand4(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* w_ih4, float* w_hh4,
-                           float* b4, int I, int H, hipStream_t s);
+                           float* b4, int I, int H, hipStream_t s, int order = 0);
 
 // lstm_train_kernels.hip (training step: BPTT pieces)
 // C [M][Nc] = sum_k A[k][M]^T B[k][Nc]   (both operands row-major over k; split-K, deterministic 2-pass)
@@ -508,13 +509,13 @@ bool fsn_lstm_rec_can_fuse_fc(int RT, bool xin);
 // first sub-band layer on the persistent kernel with the weight ring / deferred input staging (see the kernel)
 bool fsn_lstm_rec_in_supported(const FsnSbInput* xin, const float* whh_p, int H, int RT);
 int fsn_launch_lstm_rec_in(const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad, int H, int RT,
-                           int main_wgs, hipStream_t s);
+                           int main_wgs, hipStream_t s, int cell = 0);
 // a layer with its input projection inside: xseq [Tp][Npad][H] is the hidden sequence of the layer below,
 // wih_p / whh_p the packed weights, bias = b_ih + b_hh [4H]; either the output layer (fc) is fused and nothing else is
 // stored (the last layer of the sub-band model), or hseq_out [Tp][Npad][H] receives h_t (a layer inside a stack)
 bool fsn_lstm_rec_x_supported(int H, int RT);
 int fsn_launch_lstm_rec_x(const float* xseq, const float* wih_p, const float* whh_p, const float* bias, int Tp, int Npad,
-                          int H, int RT, int main_wgs, hipStream_t s, const FsnRecFc* fc, float* hseq_out = nullptr);
+                          int H, int RT, int main_wgs, hipStream_t s, const FsnRecFc* fc, float* hseq_out = nullptr, int cell = 0);
 // state_h0 / state_h1 (may be NULL): streaming continuation - the hidden states before this call ([rows][H],
 // updated to the last step's on return); c0 / c1 then hold the carried cell states.
 int fsn_launch_lstm_wavefront2(const float* gx0, long gx_stride, long gx_off, const float* whh0_p, const float* wih1_p,

@@ -216,31 +216,34 @@ int fsn_launch_gru_bptt_step(const float* dh_out, const float* dgx_next, const f
     return fsn_check_launch("gru_bptt_step_kernel");
 }
 
-// nn.GRU's gate rows as a four-gate cell (fb_chain_kernel<.., CELL = 1>, fsn_gru2_forward)
+// nn.GRU's gate rows as a four-gate cell (fb_chain_kernel<.., CELL = 1>, fsn_gru2_forward: slots r | z | nx | nh; the many-row
+// persistent kernels, FSN_REC_GRU in lstm_kernels.hip: slots nh | r | nx | z - `order` 1)
 namespace {
 __global__ void gru_expand4_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh, const float* __restrict__ b_ih,
                                    const float* __restrict__ b_hh, float* __restrict__ w_ih4, float* __restrict__ w_hh4,
-                                   float* __restrict__ b4, int I, int H) {
+                                   float* __restrict__ b4, int I, int H, int order) {
     const long ni = (long)4 * H * I, nh = (long)4 * H * H, n = ni + nh + 4 * H;
+    // kind of the gate in slot s: 0 = r, 1 = z, 2 = nx (input part of n), 3 = nh (recurrent part of n)
+    const int kinds = order ? (3 | 0 << 2 | 2 << 4 | 1 << 6) : (0 | 1 << 2 | 2 << 4 | 3 << 6);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         if (i < ni) {
-            const int row = (int)(i / I), col = (int)(i % I), gate = row / H;
-            w_ih4[i] = gate < 3 ? w_ih[(long)row * I + col] : 0.f;
+            const int row = (int)(i / I), col = (int)(i % I), kind = (kinds >> (2 * (row / H))) & 3, u = row % H;
+            w_ih4[i] = kind < 3 ? w_ih[(long)(kind * H + u) * I + col] : 0.f;
         } else if (i < ni + nh) {
             const long k = i - ni;
-            const int row = (int)(k / H), col = (int)(k % H), gate = row / H, u = row % H;
-            w_hh4[k] = gate < 2 ? w_hh[(long)row * H + col] : gate == 2 ? 0.f : w_hh[(long)(2 * H + u) * H + col];
+            const int row = (int)(k / H), col = (int)(k % H), kind = (kinds >> (2 * (row / H))) & 3, u = row % H;
+            w_hh4[k] = kind < 2 ? w_hh[(long)(kind * H + u) * H + col] : kind == 2 ? 0.f : w_hh[(long)(2 * H + u) * H + col];
         } else {
-            const int row = (int)(i - ni - nh), gate = row / H, u = row % H;
-            b4[row] = gate < 2 ? b_ih[row] + b_hh[row] : gate == 2 ? b_ih[2 * H + u] : b_hh[2 * H + u];
+            const int row = (int)(i - ni - nh), kind = (kinds >> (2 * (row / H))) & 3, u = row % H;
+            b4[row] = kind < 2 ? b_ih[kind * H + u] + b_hh[kind * H + u] : kind == 2 ? b_ih[2 * H + u] : b_hh[2 * H + u];
         }
     }
 }
 }  // namespace
 int fsn_launch_gru_expand4(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* w_ih4, float* w_hh4,
-                           float* b4, int I, int H, hipStream_t s) {
+                           float* b4, int I, int H, hipStream_t s, int order) {
     const long n = (long)4 * H * (I + H + 1);
     hipLaunchKernelGGL(gru_expand4_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, s, w_ih, w_hh,
-                       b_ih, b_hh, w_ih4, w_hh4, b4, I, H);
+                       b_ih, b_hh, w_ih4, w_hh4, b4, I, H, order);
     return fsn_check_launch("gru_expand4_kernel");
 }

@@ -251,6 +251,15 @@ __device__ __forceinline__ f32x4 cat2(f32x2 a, f32x2 b) { return __builtin_shuff
 template <bool PK> struct RecState { typedef float type[4]; };
 template <> struct RecState<true> { typedef f32x4 type; };
 
+// FSN_REC_GRU (a bit of the two persistent kernels' OPT / ABL parameter): nn.GRU (audio_zen/model/module/sequence_model.py:
+// 59-66) on the same kernels, written as a FOUR-gate cell whose gate slots follow the kernels' order of evaluation
+// (slot 1, 0, 2, 3):  slot 1 = r (W_ir x + W_hr h + b_ir + b_hr), slot 0 = nh (W_hn h + b_hn: zero input block),
+// slot 2 = nx (W_in x + b_in: zero recurrent block), slot 3 = z (fsn_launch_gru_expand4, order 1).  Passes:
+//   r:  tmp = sig(a)      nh: tmp = tmp a      nx: tmp = tanh(a + tmp) = n      z: h = n + sig(a) (h_{t-1} - n)
+// (= (1 - z) n + z h_{t-1}); `cst` holds h in fp32 where the LSTM holds c.  The products of the two zero blocks are
+// skipped (nx: no recurrent K loop; nh: no input slices from step 1 on): 3/4 of the LSTM's matrix work.
+#define FSN_REC_GRU (1 << 20)
+
 // ---------------------------------------------------------------------------------------------
 // Last sub-band layer with its INPUT PROJECTION INSIDE: gates = b + x_t W_ih^T + h_{t-1} W_hh^T with x_t = h_t of the
 // layer below, read from that layer's hidden sequence (4.8 GB at config 2).  The separate K = 384 projection GEMM and
@@ -367,6 +376,8 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
     const int sb_f0 = ROWSIN ? 0 : (int)((n0 + xin.row0) - (long)sb_b0 * xin.F);
 
     constexpr bool PK = (OPT & 256) != 0;    // gate non-linearities on pairs (v_pk_*_f32), see sigmoid_fast2
+    constexpr bool GRU = (OPT & FSN_REC_GRU) != 0;  // the GRU as a four-gate cell (see FSN_REC_GRU below lstm_rec_x_kernel's bits)
+    static_assert(!GRU || PK, "the GRU cell is written on the packed epilogue");
     constexpr bool KOPT = (OPT & 4096) != 0 && RT >= 2 && RT <= 4 && KC % 6 == 0;  // see lstm_rec_x_kernel
     typename RecState<PK>::type cst[RT][UG], tmp[RT][UG];
 #pragma unroll
@@ -425,6 +436,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
             int gn = pass == 0 ? 0 : (pass == 1 ? 2 : (pass == 2 ? 3 : 1));  // the gate after this one
             asm volatile("" : "+s"(g));  // opaque: see lstm_rec_kernel
             asm volatile("" : "+s"(gn));
+            const bool hpart = t > 0 && !(GRU && pass == 2);  // h_{-1} = 0; the GRU's nx gate has no recurrent part
             f32x4 acc[RT][UG];
             // B0: the fragments this pass starts with, B1: the other set; C0 / C1: the same for the recurrent product
             const bool SW = KX == 1 && (pass & 1);  // (a constant once the passes are unrolled)
@@ -450,18 +462,18 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 __builtin_amdgcn_sched_barrier(0);
                 mma(acc, xa, 16 * XS, B0);
 #pragma unroll
-                for (int u = 0; u < UG; ++u) B0[u] = wload(t > 0 ? wh[u] : wxn[u]);
+                for (int u = 0; u < UG; ++u) B0[u] = wload(hpart ? wh[u] : wxn[u]);
                 __builtin_amdgcn_sched_barrier(0);
                 mma(acc, xa + 16, 16 * XS, B1);
             } else {
 #pragma unroll
-                for (int u = 0; u < UG; ++u) B1[u] = wload(t > 0 ? wh[u] : wxn[u]);
+                for (int u = 0; u < UG; ++u) B1[u] = wload(hpart ? wh[u] : wxn[u]);
                 __builtin_amdgcn_sched_barrier(0);
                 mma(acc, xa, 16 * XS, B0);
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- h_{t-1} W_hh^T (h_{-1} = 0) -------------------------------------------------------
-            if (KOPT && t > 0) {
+            if (KOPT && hpart) {
                 typedef const __attribute__((address_space(3))) float* lds_cptr;
                 unsigned hb01 = (unsigned)(size_t)(lds_cptr)(hl + lr * HS + 4 * lq), hb23 = hb01 + 32u * HS * 4u;
                 asm volatile("" : "+v"(hb01));
@@ -545,7 +557,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                     ha01 += 6 * 16;
                     ha23 += 6 * 16;
                 }
-            } else if (t > 0) {
+            } else if (hpart) {
 #pragma unroll 1
                 for (int kc = 0; kc < KC; kc += 2) {
 #pragma unroll
@@ -576,7 +588,18 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
         VAR[rt][u] = cat2(half(lo2(A), lo2(C), lo2(M)), half(hi2(A), hi2(C), hi2(M)));                \
         asm volatile("" : "+v"(VAR[rt][u]));                                                          \
     }
-            if constexpr (PK) {
+            if constexpr (GRU) {  // cst = h_{t-1} (and h_t after the z pass); tmp: r, r * (W_hn h + b_hn), n
+                if (pass == 0) {
+                    FSN_REC_EPILOGUE2(tmp, sigmoid_fast2(a))
+                    if (more) stage.commit(xin, xl + ((t + 1) & 1) * ROWS * XS, XS, n0);
+                } else if (pass == 1) {
+                    FSN_REC_EPILOGUE2(tmp, m * a)
+                } else if (pass == 2) {
+                    FSN_REC_EPILOGUE2(tmp, tanh_fast2(a + m))
+                } else {
+                    FSN_REC_EPILOGUE2(cst, m + sigmoid_fast2(a) * (c - m))
+                }
+            } else if constexpr (PK) {
                 if (pass == 0) {
                     FSN_REC_EPILOGUE2(cst, sigmoid_fast2(a) * c)
                     if (more) stage.commit(xin, xl + ((t + 1) & 1) * ROWS * XS, XS, n0);
@@ -614,7 +637,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
 #pragma unroll
                 for (int u = 0; u < UG; ++u)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) hw[(rt * 16 + i) * HS + u * 16] = tmp[rt][u][i];
+                    for (int i = 0; i < 4; ++i) hw[(rt * 16 + i) * HS + u * 16] = GRU ? cst[rt][u][i] : tmp[rt][u][i];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         __builtin_amdgcn_s_barrier();  // h_t complete in LDS
@@ -744,6 +767,8 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
     // fragment pinned behind the last MFMA that reads it, so that it returns into the same registers.
     constexpr bool KOPT = (ABL & 4096) != 0 && RT >= 2 && RT <= 4;
     constexpr bool PK = (ABL & 256) != 0;          // gate non-linearities on pairs (v_pk_*_f32)
+    constexpr bool GRU = (ABL & FSN_REC_GRU) != 0;  // the GRU as a four-gate cell (FSN_REC_GRU)
+    static_assert(!GRU || (PK && (ABL & 64) && !(ABL & 2)), "the GRU cell is written on the shipped form");
     typename RecState<PK>::type cst[RT][UG], tmp[RT][UG];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -861,13 +886,18 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
             int gn = pass == 0 ? 0 : (pass == 1 ? 2 : (pass == 2 ? 3 : 1));  // the gate after this one
             asm volatile("" : "+s"(g));  // opaque: see lstm_rec_kernel
             asm volatile("" : "+s"(gn));
+            // GRU: the nx gate (pass 2) has no recurrent part, the nh gate (pass 1) no input part - its x slices are
+            // skipped from step 1 on (at step 0 nothing else runs in that pass and the zero block keeps the ring's order)
+            const bool hpart = t > 0 && !(GRU && pass == 2);
+            const bool xpart = !(GRU && pass == 1 && t > 0);
+            const bool prev_h = t > 0 && !(GRU && pass == 3);  // the pass before this one had a recurrent product
             f32x4 acc[RT][UG];
-            unsigned wx[UG], wh[UG], wxn[UG];  // uniform offsets: W_ih / W_hh of this gate, W_ih of the next one
+            unsigned wx[UG], wh[UG], wxn[UG];  // uniform offsets: W_ih / W_hh of this gate, the next pass' first fragment
 #pragma unroll
             for (int u = 0; u < UG; ++u) {
                 wx[u] = wofs(g, u);
                 wh[u] = wx[u] + whh_off;
-                wxn[u] = wofs(gn, u);
+                wxn[u] = wofs(gn, u) + ((GRU && pass == 0 && t > 0) ? whh_off : 0u);
                 const float b = bias_n[u];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) acc[rt][u] = f32x4{b, b, b, b};
@@ -875,12 +905,12 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
             }
             // ---- x_t W_ih^T, slice by slice ------------------------------------------------------
 #pragma unroll 1
-            for (int sl = 0; sl < NSL; ++sl) {
+            for (int sl = 0; sl < (xpart ? NSL : 0); ++sl) {
                 const int j = pass * NSL + sl;  // slice counter of the step: ring stage j & 1
                 // (ABL & 64, experiment: the barrier that opens a pass' first slice is taken in the middle of the previous
                 // pass' recurrent product instead - its fills were issued before that product began - so that no barrier
                 // follows the gate non-linearities)
-                if (j > 0 && !(ABL & 1) && !((ABL & 64) && sl == 0 && t > 0)) {
+                if (j > 0 && !(ABL & 1) && !((ABL & 64) && sl == 0 && prev_h)) {
                     // this wave's fills of stage j & 1 were issued a slice ago, before UG SK weight fragments it has
                     // consumed since; at most the UG prefetched ones are still in flight
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UG) : "memory");
@@ -911,7 +941,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                     const bool more_x = kc + 2 < KC;
 #pragma unroll
                     for (int u = 0; u < UG; ++u) {
-                        b0[u] = wload(more_x ? wx[u] + (unsigned)(kc + 2) * 256u : (t > 0 ? wh[u] : wxn[u]));
+                        b0[u] = wload(more_x ? wx[u] + (unsigned)(kc + 2) * 256u : (hpart ? wh[u] : wxn[u]));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     mma(acc, xa + (kk + 1) * 256, SK * 256, b1);
@@ -919,7 +949,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 }
             }
             // ---- h_{t-1} W_hh^T (h_{-1} = 0) -------------------------------------------------------
-            if (KOPT && t > 0) {
+            if (KOPT && hpart) {
                 // two LDS byte addresses, opaque to the optimiser (it would fold the tile's own offset into the immediates
                 // and overflow them again): row tiles 0-1 / 2-3
                 typedef const __attribute__((address_space(3))) float* lds_cptr;
@@ -964,7 +994,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                     ha01 += SK * 16;
                     ha23 += SK * 16;
                 }
-            } else if (t > 0) {
+            } else if (hpart) {
                 const float* ha = hl + lr * HS + 4 * lq;
 #pragma unroll 1
                 for (int kc = 0; kc < KC; kc += 2) {
@@ -1005,7 +1035,17 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
         VAR[rt][u] = cat2(half(lo2(A), lo2(C), lo2(M)), half(hi2(A), hi2(C), hi2(M)));                \
         asm volatile("" : "+v"(VAR[rt][u]));                                                          \
     }
-            if constexpr (PK && !(ABL & 2)) {
+            if constexpr (GRU) {  // cst = h_{t-1} (h_t after the z pass); tmp: r, r * (W_hn h + b_hn), n
+                if (pass == 0) {
+                    FSN_REC_EPILOGUE2(tmp, sigmoid_fast2(a))
+                } else if (pass == 1) {
+                    FSN_REC_EPILOGUE2(tmp, m * a)
+                } else if (pass == 2) {
+                    FSN_REC_EPILOGUE2(tmp, tanh_fast2(a + m))
+                } else {
+                    FSN_REC_EPILOGUE2(cst, m + sigmoid_fast2(a) * (c - m))
+                }
+            } else if constexpr (PK && !(ABL & 2)) {
                 if (pass == 0) {
                     FSN_REC_EPILOGUE2(cst, sigmoid_fast2(a) * c)
                 } else if (pass == 1) {
@@ -1052,7 +1092,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
 #pragma unroll
                 for (int u = 0; u < UG; ++u)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) hw[(rt * 16 + i) * HS + u * 16] = tmp[rt][u][i];
+                    for (int i = 0; i < 4; ++i) hw[(rt * 16 + i) * HS + u * 16] = GRU ? cst[rt][u][i] : tmp[rt][u][i];
         }
         if (!(ABL & 16)) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -1835,12 +1875,12 @@ int launch_rec(const float* gx, const FsnSbInput* xin, const float* whh_p, float
     return fsn_check_launch("lstm_rec_kernel");
 }
 
-template <int H, int RT, bool HSEQ, int UG = 2>
+template <int H, int RT, bool HSEQ, int CELL = 0, int UG = 2>
 int launch_rec_x(const float* xseq, const float* wih_p, const float* whh_p, const float* bias, int Tp, int Npad,
                  int main_wgs, hipStream_t s, const FsnRecFc* fc, float* hseq_out) {
     constexpr int NW = H / (16 * UG);
     const size_t lds = ((size_t)RT * 16 * (H + 4) + 2 * H + (size_t)2 * RT * 6 * 256) * sizeof(float);
-    auto kern = lstm_rec_x_kernel<H, RT, UG, FSN_REC_X_OPT, HSEQ>;
+    auto kern = lstm_rec_x_kernel<H, RT, UG, FSN_REC_X_OPT | (CELL ? FSN_REC_GRU : 0), HSEQ>;
     if (lds > 160 * 1024 ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
@@ -1859,11 +1899,11 @@ int launch_rec_x(const float* xseq, const float* wih_p, const float* whh_p, cons
     return fsn_check_launch("lstm_rec_x_kernel");
 }
 
-template <int H, int RT, int KX = 2, bool ROWSIN = false, int UG = 2>
+template <int H, int RT, int KX = 2, bool ROWSIN = false, int CELL = 0, int UG = 2>
 int launch_rec_in(const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad, int main_wgs, hipStream_t s) {
     constexpr int NW = H / (16 * UG);
     const size_t lds = ((size_t)RT * 16 * (H + 4) + (size_t)2 * RT * 16 * (16 * KX + 4)) * sizeof(float);
-    auto kern = lstm_rec_in_kernel<H, RT, UG, FSN_REC_IN_OPT, KX, ROWSIN>;
+    auto kern = lstm_rec_in_kernel<H, RT, UG, FSN_REC_IN_OPT | (CELL ? FSN_REC_GRU : 0), KX, ROWSIN>;
     if (lds > 160 * 1024 ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
@@ -1887,10 +1927,20 @@ bool fsn_lstm_rec_in_supported(const FsnSbInput* xin, const float* whh_p, int H,
 }
 
 int fsn_launch_lstm_rec_in(const FsnSbInput* xin, const float* whh_p, float* hseq, int Tp, int Npad, int H, int RT,
-                           int main_wgs, hipStream_t s) {
-    if (!fsn_lstm_rec_in_supported(xin, whh_p, H, RT)) {
+                           int main_wgs, hipStream_t s, int cell) {
+    if (!fsn_lstm_rec_in_supported(xin, whh_p, H, RT) || (cell && !xin->x_rows)) {
         fsn_set_error("lstm_rec_in: unsupported configuration");
         return FSN_ERR_ARG;
+    }
+    if (cell) {  // GRU (FSN_REC_GRU): the row-major input forms, weights expanded by fsn_launch_gru_expand4(.., order 1)
+#define FSN_REC_IN_GRU(R)                                                                                             \
+    if (RT == R)                                                                                                      \
+        return xin->kin_chunks == 2 ? launch_rec_in<384, R, 2, true, 1>(xin, whh_p, hseq, Tp, Npad, main_wgs, s)      \
+                                    : launch_rec_in<384, R, 1, true, 1>(xin, whh_p, hseq, Tp, Npad, main_wgs, s);
+        FSN_REC_IN_GRU(2)
+        FSN_REC_IN_GRU(3)
+        FSN_REC_IN_GRU(4)
+#undef FSN_REC_IN_GRU
     }
 #define FSN_REC_IN_CASE(R)                                                                                         \
     if (RT == R) {                                                                                                 \
@@ -1912,11 +1962,21 @@ int fsn_launch_lstm_rec_in(const FsnSbInput* xin, const float* whh_p, float* hse
 bool fsn_lstm_rec_x_supported(int H, int RT) { return H == 384 && RT >= 2 && RT <= 4; }
 
 int fsn_launch_lstm_rec_x(const float* xseq, const float* wih_p, const float* whh_p, const float* bias, int Tp, int Npad,
-                          int H, int RT, int main_wgs, hipStream_t s, const FsnRecFc* fc, float* hseq_out) {
+                          int H, int RT, int main_wgs, hipStream_t s, const FsnRecFc* fc, float* hseq_out, int cell) {
     if (((!fc || !fc->w_p) && !hseq_out) || !fsn_lstm_rec_x_supported(H, RT)) {
         fsn_set_error("lstm_rec_x: needs the fused output layer or a hidden-sequence buffer, H = 384 and 2 - 4 row tiles "
                       "(got H %d, RT %d)", H, RT);
         return FSN_ERR_ARG;
+    }
+    if (cell) {  // GRU (FSN_REC_GRU)
+        if (hseq_out) {
+            if (RT == 2) return launch_rec_x<384, 2, true, 1>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, nullptr, hseq_out);
+            if (RT == 3) return launch_rec_x<384, 3, true, 1>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, nullptr, hseq_out);
+            return launch_rec_x<384, 4, true, 1>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, nullptr, hseq_out);
+        }
+        if (RT == 2) return launch_rec_x<384, 2, false, 1>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, fc, nullptr);
+        if (RT == 3) return launch_rec_x<384, 3, false, 1>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, fc, nullptr);
+        return launch_rec_x<384, 4, false, 1>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, fc, nullptr);
     }
     if (hseq_out) {  // a layer inside a stack: h_t stored, no output layer
         if (RT == 2) return launch_rec_x<384, 2, true>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, nullptr, hseq_out);

@@ -60,7 +60,7 @@ const char* fsn_last_error(void);
 /* The ABI revision this header describes.  fsn_version() returns the revision the LIBRARY was built with: a caller
  * compares the two once after loading (fullsubnet_amd/_lib.py raises on a mismatch) - argument lists changed between
  * revisions (116: + fsn_lstm_layer_plan_rows; 115: + fsn_train_rows_pieces; 114: + fsn_lstm2_train_is_persistent; 113: + fsn_gru2_forward; 112: + FSN_ARITH_SAVES16; 111: + the composed families' glue entries; 110: fsn_train_dims.norm, fsn_train_den_elems; 100 -> 101 of round 4: fsn_clip_adam_step's found_inf). */
-#define FSN_ABI_VERSION 116
+#define FSN_ABI_VERSION 117
 int fsn_version(void);
 
 /* ---- STFT / iSTFT : audio_zen/acoustics/feature.py ------------------------------------- */
@@ -370,7 +370,13 @@ int fsn_lstm2_backward_phase(const float* dh1, const float* x, long ldx, const f
 
 /* nn.GRU branch of SequenceModel (sequence_model.py:59-66), one layer, unidirectional, h0 = 0; same
  * conventions as the LSTM layer above with 3H gate rows (r, z, n).  save == NULL: inference.  The two
- * bias gradients differ in the n block (b_hn sits inside r * (W_hn h + b_hn)), hence two outputs. */
+ * bias gradients differ in the n block (b_hn sits inside r * (W_hn h + b_hn)), hence two outputs.
+ * Inference with MANY rows (ABI 117; the sub-band model of a GRU FullSubNet, fullsubnet/model.py:121-128 with
+ * sequence_model = "GRU"): H = 384, N >= 16 rows per CU and either I <= 32 (a narrow row-major input) or I = H = ldx (the
+ * layer above an equally wide one) run on the LSTM's persistent many-row kernels with the GRU written as a four-gate cell
+ * (3/4 of the LSTM's matrix work: the two zero blocks are skipped) - fsn_gru_layer_is_persistent says whether; left-over
+ * row tiles advance step by step beside the launch.  Results equal the step form's within fp32 rounding. */
+int fsn_gru_layer_is_persistent(int T, int N, int I, long ldx, int H);
 size_t fsn_gru_layer_save_bytes(int T, int N, int H);
 size_t fsn_gru_layer_fwd_workspace_bytes(int T, int N, int I, int H);
 int fsn_gru_layer_forward(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
@@ -378,7 +384,8 @@ int fsn_gru_layer_forward(const float* x, long ldx, const float* w_ih, const flo
                           void* workspace, size_t workspace_bytes, void* stream);
 /* Streaming form: T more steps from the carried state h_state [N][H] (zero-filled for a new stream), updated in
  * place - nn.GRU(x, h_0) is the analogue; workspace >= fsn_gru_layer_fwd_workspace_bytes(T, N, I, H).  Chunked calls
- * give the offline result bit for bit (the same step kernels in the same order). */
+ * give the offline result bit for bit (the same step kernels in the same order) wherever the offline call runs step by
+ * step (fsn_gru_layer_is_persistent == 0), within fp32 rounding otherwise. */
 int fsn_gru_layer_forward_state(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
                                 const float* b_hh, int T, int N, int I, int H, float* hseq, float* h_state,
                                 void* workspace, size_t workspace_bytes, void* stream);
