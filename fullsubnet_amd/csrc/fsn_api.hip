@@ -3209,9 +3209,13 @@ extern "C" int fsn_gru_layer_is_persistent(int T, int N, int I, long ldx, int H)
     return T >= 1 && N >= 16 && N % 16 == 0 && I >= 1 && gru_layer_plan(N, I, ldx, H).main_wgs > 0 ? 1 : 0;
 }
 
-static int gru_layer_forward_steps(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
-                                   const float* b_hh, int T, int N, int I, int H, float* hseq, float* sv, void* workspace,
-                                   hipStream_t s) {
+// The step form in two halves: weights re-tiled + input projection of all steps (one GEMM), then the T dependent step launches
+// (gru_step_kernel: 32 registers, 12 KB of LDS - it fits beside a resident workgroup of the persistent kernels).
+struct GruStepBufs {
+    float *whh_p, *gx;
+};
+static int gru_layer_steps_prepare(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
+                                   const float* b_hh, int T, int N, int I, int H, void* workspace, hipStream_t s, GruStepBufs* out) {
     const int Ipad = fsn_round_up(I, 16), G = 3 * H;
     Carver cv(workspace);
     float* wih_p = cv.take<float>((size_t)G * Ipad);
@@ -3232,11 +3236,25 @@ static int gru_layer_forward_steps(const float* x, long ldx, const float* w_ih, 
     c.p0 = gx;
     c.bias = bias;
     FSN_TRY(fsn_launch_gemm(a, wih_p, c, T * (N / 16), G / 16, Ipad / 16, s));
+    out->whh_p = whh_p;
+    out->gx = gx;
+    return FSN_OK;
+}
+static int gru_layer_steps_run(const GruStepBufs& b, const float* b_hh, int T, int N, int H, float* hseq, float* sv, hipStream_t s,
+                               int beside_persistent = 0) {
     const size_t step = (size_t)N * H;
     for (int t = 0; t < T; ++t)
-        FSN_TRY(fsn_launch_gru_step(gx, whh_p, b_hh + 2 * H, t ? hseq + (t - 1) * step : hseq, hseq + t * step,
-                                    sv ? sv + (size_t)t * N * 4 * H : nullptr, (long)t * (N / 16), N / 16, H, t == 0, s));
+        FSN_TRY(fsn_launch_gru_step(b.gx, b.whh_p, b_hh + 2 * H, t ? hseq + (t - 1) * step : hseq, hseq + t * step,
+                                    sv ? sv + (size_t)t * N * 4 * H : nullptr, (long)t * (N / 16), N / 16, H, t == 0, s,
+                                    beside_persistent));
     return FSN_OK;
+}
+static int gru_layer_forward_steps(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
+                                   const float* b_hh, int T, int N, int I, int H, float* hseq, float* sv, void* workspace,
+                                   hipStream_t s) {
+    GruStepBufs b{};
+    FSN_TRY(gru_layer_steps_prepare(x, ldx, w_ih, w_hh, b_ih, b_hh, T, N, I, H, workspace, s, &b));
+    return gru_layer_steps_run(b, b_hh, T, N, H, hseq, sv, s);
 }
 
 static int gru_layer_forward_persistent(const GruPlan& p, const float* x, long ldx, const float* w_ih, const float* w_hh,
@@ -3257,7 +3275,27 @@ static int gru_layer_forward_persistent(const GruPlan& p, const float* x, long l
     FSN_TRY(fsn_launch_pack(whh4, whh4_p, G4, H, G4, H, s));
     hipStream_t ls = s;
     StreamCtx* cx = nullptr;
+    GruStepBufs sb{};
     if (left > 0) {
+        // rows [main_rows, N) of every step as compact [T][left] matrices (columns [0, Ipad) of a row; one 2-D copy when the
+        // rows are exactly that wide, one per step otherwise) and their input projection - on `s`, AHEAD of the persistent
+        // launch: the projection GEMM's workgroups (160 registers, 96 KB of LDS) do not fit beside a resident workgroup of it
+        // and would wait for the whole launch (measured: the step launches then ran after it, +2.7 ms per batch of 64)
+        bool ok = true;
+        if (ldx == Ipad)
+            ok = hipMemcpy2DAsync(x_left, (size_t)left * Ipad * sizeof(float), x + (size_t)main_rows * ldx,
+                                  (size_t)N * ldx * sizeof(float), (size_t)left * Ipad * sizeof(float), (size_t)T,
+                                  hipMemcpyDeviceToDevice, s) == hipSuccess;
+        else
+            for (int t = 0; t < T && ok; ++t)
+                ok = hipMemcpy2DAsync(x_left + (size_t)t * left * Ipad, (size_t)Ipad * sizeof(float),
+                                      x + ((size_t)t * N + main_rows) * ldx, (size_t)ldx * sizeof(float),
+                                      (size_t)Ipad * sizeof(float), (size_t)left, hipMemcpyDeviceToDevice, s) == hipSuccess;
+        if (!ok) {
+            fsn_set_error("gru layer forward: copy of the left-over rows failed");
+            return FSN_ERR_LAUNCH;
+        }
+        FSN_TRY(gru_layer_steps_prepare(x_left, Ipad, w_ih, w_hh, b_ih, b_hh, T, left, I, H, step_ws, s, &sb));
         cx = cur_ctx();
         FSN_TRY(aux_init(cx));
         if (hipEventRecord(cx->ev_fork, s) != hipSuccess || hipStreamWaitEvent(cx->aux, cx->ev_fork, 0) != hipSuccess) {
@@ -3280,23 +3318,8 @@ static int gru_layer_forward_persistent(const GruPlan& p, const float* x, long l
         FSN_TRY(fsn_launch_lstm_rec_x(x, wih4_p, whh4_p, b4, T, N, H, p.rt, p.main_wgs, s, nullptr, hseq, 1));
     }
     if (left > 0) {
-        // rows [main_rows, N) of every step as compact [T][left] matrices: in, step launches, out
-        // (columns [0, Ipad) of a row; one 2-D copy when the rows are exactly that wide, one per step otherwise)
-        bool ok = true;
-        if (ldx == Ipad)
-            ok = hipMemcpy2DAsync(x_left, (size_t)left * Ipad * sizeof(float), x + (size_t)main_rows * ldx,
-                                  (size_t)N * ldx * sizeof(float), (size_t)left * Ipad * sizeof(float), (size_t)T,
-                                  hipMemcpyDeviceToDevice, ls) == hipSuccess;
-        else
-            for (int t = 0; t < T && ok; ++t)
-                ok = hipMemcpy2DAsync(x_left + (size_t)t * left * Ipad, (size_t)Ipad * sizeof(float),
-                                      x + ((size_t)t * N + main_rows) * ldx, (size_t)ldx * sizeof(float),
-                                      (size_t)Ipad * sizeof(float), (size_t)left, hipMemcpyDeviceToDevice, ls) == hipSuccess;
-        if (!ok) {
-            fsn_set_error("gru layer forward: copy of the left-over rows failed");
-            return FSN_ERR_LAUNCH;
-        }
-        FSN_TRY(gru_layer_forward_steps(x_left, Ipad, w_ih, w_hh, b_ih, b_hh, T, left, I, H, h_left, nullptr, step_ws, ls));
+        // the left-over rows' T step launches beside the persistent launch, then back into rows [main_rows, N) of hseq
+        FSN_TRY(gru_layer_steps_run(sb, b_hh, T, left, H, h_left, nullptr, ls, 1));
         if (hipMemcpy2DAsync(hseq + (size_t)main_rows * H, (size_t)N * H * sizeof(float), h_left, (size_t)left * H * sizeof(float),
                              (size_t)left * H * sizeof(float), (size_t)T, hipMemcpyDeviceToDevice, ls) != hipSuccess) {
             fsn_set_error("gru layer forward: copy of the left-over rows failed");

@@ -427,7 +427,7 @@ int fsn_launch_bptt_elem(const float* dh_out, const float* dh_rec, float* dc, co
 
 // gru_kernels.hip
 int fsn_launch_gru_step(const float* gx, const float* whh_p, const float* b_hn, const float* h_prev, float* h_out,
-                        float* save, long gx_rt0, int row_tiles, int H, int first, hipStream_t s);
+                        float* save, long gx_rt0, int row_tiles, int H, int first, hipStream_t s, int beside_persistent = 0);
 int fsn_launch_gru_bptt_step(const float* dh_out, const float* dgx_next, const float* dghn_next, const float* whhT_p,
                              float* carry, const float* save, const float* h_prev, float* dgx, float* dghn,
                              int row_tiles, int H, int last, int first, hipStream_t s);

@@ -97,6 +97,83 @@ __global__ __launch_bounds__(256) void gru_step_kernel(const float* __restrict__
     }
 }
 
+// The same step for the left-over row tiles BESIDE a resident workgroup of the persistent many-row kernels (lstm_kernels.hip,
+// FSN_REC_GRU: 3 x 152 of a SIMD's 512 registers and up to 148 KB of a CU's 160 KB of LDS are taken): one row tile per
+// workgroup, at most 48 registers, 6 KB of LDS - the split-K partial sums travel in two rounds (gates r and z, then the n gate's
+// recurrent part) through one small buffer.  Same operations in the same order as gru_step_kernel<1>: bit-identical results.
+// (gru_step_kernel<1> itself takes 64 registers and 12 KB: its launches waited for the persistent launch to END - measured, a
+// GRU FullSubNet at batch 64: 190 launches per layer behind each of the two persistent launches, +2.9 ms of 65.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(24))) void gru_step1_kernel(
+    const float* __restrict__ gx, const float* __restrict__ whh_p, const float* __restrict__ b_hn,
+    const float* __restrict__ h_prev, float* __restrict__ h_out, long gx_rt0, int row_tiles, int H, int first) {
+    __shared__ f32x4 red[3][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int ug = blockIdx.x, rtile = blockIdx.y;
+    const int KC = H >> 4, CT = 3 * KC;
+    f32x4 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!first) {
+        const int kc0 = wave * (KC >> 2), kc1 = kc0 + (KC >> 2);
+        const float* ap = h_prev + ((long)rtile * 16 + lr) * H + 4 * lq;
+#pragma unroll 1
+        for (int kc = kc0; kc < kc1; ++kc) {
+            f32x4 b[3];
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kc * 16);
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                b[g] = *reinterpret_cast<const f32x4*>(whh_p + (((long)(g * KC + ug) * KC + kc) * 64 + lane) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] = mfma16(a[j], b[g][j], acc[g]);
+        }
+        // ((wave 0 + wave 1) + wave 2) + wave 3, gate by gate: gru_step_kernel's order
+        if (wave > 0) {
+            red[wave - 1][0][lane] = acc[0];
+            red[wave - 1][1][lane] = acc[1];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    const f32x4 r = red[w][g][lane];
+                    acc[g] = f32x4{acc[g][0] + r[0], acc[g][1] + r[1], acc[g][2] + r[2], acc[g][3] + r[3]};
+                }
+        }
+        __syncthreads();
+        if (wave > 0) red[wave - 1][0][lane] = acc[2];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                const f32x4 r = red[w][0][lane];
+                acc[2] = f32x4{acc[2][0] + r[0], acc[2][1] + r[1], acc[2][2] + r[2], acc[2][3] + r[3]};
+            }
+        }
+    }
+    if (wave != 0 || rtile >= row_tiles) return;
+    f32x4 xg[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+        xg[g] = *reinterpret_cast<const f32x4*>(gx + (((gx_rt0 + rtile) * CT + g * KC + ug) * 64 + lane) * 4);
+    const int u = ug * 16 + lr;
+    const float bn = b_hn[u];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long idx = ((long)rtile * 16 + 4 * lq + i) * H + u;
+        const float hp = first ? 0.f : h_prev[idx];
+        const float r = sigmoid_f(xg[0][i] + acc[0][i]);
+        const float z = sigmoid_f(xg[1][i] + acc[1][i]);
+        const float hn = acc[2][i] + bn;
+        const float n = tanhf(xg[2][i] + r * hn);
+        h_out[idx] = n + z * (hp - n);
+    }
+}
+
 // One BPTT step: rec = [dgx_{t+1}[:, :2H] | dghn_{t+1}] W_hh (K = 3H) for RTS x CTS blocks, then
 //   dh = dh_out_t + rec + carry;  dn = dh (1 - z);  dz = dh (h_{t-1} - n);  carry' = dh z
 //   dn_pre = dn (1 - n^2);  dr_pre = dn_pre hn r (1 - r);  dz_pre = dz z (1 - z)
@@ -190,10 +267,15 @@ __global__ __launch_bounds__(256) void gru_bptt_step_kernel(
 }  // namespace
 
 int fsn_launch_gru_step(const float* gx, const float* whh_p, const float* b_hn, const float* h_prev, float* h_out,
-                        float* save, long gx_rt0, int row_tiles, int H, int first, hipStream_t s) {
+                        float* save, long gx_rt0, int row_tiles, int H, int first, hipStream_t s, int beside_persistent) {
     if (H % 64 != 0) {
         fsn_set_error("gru_step: hidden size %d must be a multiple of 64", H);
         return FSN_ERR_ARG;
+    }
+    if (beside_persistent && !save) {  // must fit next to a resident persistent workgroup, see gru_step1_kernel
+        hipLaunchKernelGGL(gru_step1_kernel, dim3(H / 16, row_tiles), dim3(256), 0, s, gx, whh_p, b_hn, h_prev, h_out, gx_rt0,
+                           row_tiles, H, first);
+        return fsn_check_launch("gru_step1_kernel");
     }
     if (row_tiles >= 16)
         hipLaunchKernelGGL(gru_step_kernel<2>, dim3(H / 16, (row_tiles + 1) / 2), dim3(256), 0, s, gx, whh_p, b_hn, h_prev,

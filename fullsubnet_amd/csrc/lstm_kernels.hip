@@ -1974,9 +1974,8 @@ int fsn_launch_lstm_rec_x(const float* xseq, const float* wih_p, const float* wh
             if (RT == 3) return launch_rec_x<384, 3, true, 1>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, nullptr, hseq_out);
             return launch_rec_x<384, 4, true, 1>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, nullptr, hseq_out);
         }
-        if (RT == 2) return launch_rec_x<384, 2, false, 1>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, fc, nullptr);
-        if (RT == 3) return launch_rec_x<384, 3, false, 1>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, fc, nullptr);
-        return launch_rec_x<384, 4, false, 1>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, fc, nullptr);
+        fsn_set_error("lstm_rec_x: the GRU cell is instantiated for the hidden-sequence form (its output layer is a separate launch)");
+        return FSN_ERR_ARG;
     }
     if (hseq_out) {  // a layer inside a stack: h_t stored, no output layer
         if (RT == 2) return launch_rec_x<384, 2, true>(xseq, wih_p, whh_p, bias, Tp, Npad, main_wgs, s, nullptr, hseq_out);

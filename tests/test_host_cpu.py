@@ -240,6 +240,15 @@ def test_built_library_holds_the_same_budget():
         assert 3 * gran(rec["vgpr_count"]) + gran(step["vgpr_count"]) <= 512, (name, rec, step)
     recx = next(v for k, v in ks.items() if "lstm_rec_x_kernelILi384ELi4ELi2E" in k)
     assert 3 * gran(recx["vgpr_count"]) + gran(step["vgpr_count"]) <= 512 and recx["vgpr_spill_count"] <= 8, recx
+    # the GRU's left-over tiles beside the same kernels run as a four-gate cell (FSN_REC_GRU = 1 << 20 in their OPT / ABL
+    # parameter; gru_step1_kernel): every such instantiation x the step workgroup inside a SIMD's registers and a CU's LDS
+    gstep = next(v for k, v in ks.items() if "gru_step1_kernel" in k)
+    assert gstep["vgpr_spill_count"] == 0 and gstep["group_segment_fixed_size"] <= 8 * 1024, gstep
+    gru = {k: v for k, v in ks.items() if re.search(r"lstm_rec_(in|x)_kernelILi384ELi\dELi2ELi(\d+)E", k)
+           and int(re.search(r"lstm_rec_(?:in|x)_kernelILi384ELi\dELi2ELi(\d+)E", k).group(1)) & (1 << 20)}
+    assert len(gru) == 9, sorted(gru)  # rec_in: 2 - 4 row tiles x one / two input chunks; rec_x: 2 - 4 row tiles (hseq out)
+    for name, rec in gru.items():
+        assert 3 * gran(rec["vgpr_count"]) + gran(gstep["vgpr_count"]) <= 512 and rec["vgpr_spill_count"] <= 8, (name, rec, gstep)
 
 
 def test_no_kernel_rewrites_store_data_inside_the_measured_unsafe_distance():
@@ -291,7 +300,8 @@ def test_ring_fills_of_the_persistent_kernel_take_scalar_addresses():
                 elif kernel and "lstm_rec_x_kernel" in kernel and "global_load_lds_dwordx4" in line:
                     v = forms.setdefault(kernel, [0, 0])
                     v[0 if re.search(r"\boff\b", line) else 1] += 1
-    assert len(forms) == 6, sorted(forms)  # 2 - 4 row tiles per workgroup x (fused output layer | hidden sequence out)
+    # 2 - 4 row tiles per workgroup x (fused output layer | hidden sequence out), + the GRU as a four-gate cell (hidden sequence out)
+    assert len(forms) == 9, sorted(forms)
     for kernel, (vector_form, scalar_form) in forms.items():
         assert vector_form <= 1 and scalar_form >= 4, (kernel, vector_form, scalar_form)
 
