@@ -491,6 +491,13 @@ def family_parity(BF, which, batch, pack, device):
         want = MF.fast_fullsubnet_forward(O.stft(noisy_np[rows])[0][:, None], params)
         err, scale, what = float(np.abs(got - want).max()), float(np.abs(want).max()), "compressed mask"
         out = {"max_abs_err_vs_oracle": err}
+    elif which == "gru":
+        # FullSubNet with sequence_model = "GRU" (fullsubnet/model.py:10-70; the oracle's GRU cell is pinned on the reference's
+        # var_gru_b2 golden): the model's own random weights, two utterances (the offline norm takes its mean per utterance)
+        params = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+        want = O.fullsubnet_forward(O.stft(noisy_np[rows])[0][:, None], params, cell="GRU", num_groups_in_drop_band=1)
+        err, scale, what = float(np.abs(got - want).max()), float(np.abs(want).max()), "compressed mask"
+        out = {"max_abs_err_vs_oracle": err}
     else:
         cfg = {"improved48": IMPROVED_48K, "improved769": IMPROVED_48K_769}[which]
         want = MF.improved_fullsubnet_forward(noisy_np[rows], make_improved_params(cfg, seed=3), cfg,
@@ -858,7 +865,9 @@ def main():
         except Exception as e:
             out["train_step_amp_shipped_batches"] = {"error": str(e)[:200]}
         # BASELINE configs 4 and 5 (fast_fullsubnet/model.py:143-202, improved_fullsubnet/model.py:541-591)
-        for key, which, b in (("fast_b256", "fast", 256), ("improved48_b32", "improved48", 32)):
+        # + FullSubNet with sequence_model = "GRU" at config 2's shape (a constructor option of fullsubnet/model.py:10-70 no shipped
+        # TOML selects): its sub-band rows on the persistent many-row kernels with the GRU as a four-gate cell
+        for key, which, b in (("fast_b256", "fast", 256), ("improved48_b32", "improved48", 32), ("gru_b64", "gru", 64)):
             try:
                 out[key] = family_figure(which, b, PEAK_FP32_MFMA_TFLOPS, device)
             except Exception as e:

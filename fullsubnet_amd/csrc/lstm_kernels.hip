@@ -257,7 +257,7 @@ template <> struct RecState<true> { typedef f32x4 type; };
 // slot 2 = nx (W_in x + b_in: zero recurrent block), slot 3 = z (fsn_launch_gru_expand4, order 1).  Passes:
 //   r:  tmp = sig(a)      nh: tmp = tmp a      nx: tmp = tanh(a + tmp) = n      z: h = n + sig(a) (h_{t-1} - n)
 // (= (1 - z) n + z h_{t-1}); `cst` holds h in fp32 where the LSTM holds c.  The products of the two zero blocks are
-// skipped (nx: no recurrent K loop; nh: no input slices from step 1 on): 3/4 of the LSTM's matrix work.
+// skipped (nx: no recurrent K loop; nh: no input chunks / slices from step 1 on): 3/4 of the LSTM's matrix work.
 #define FSN_REC_GRU (1 << 20)
 
 // ---------------------------------------------------------------------------------------------
@@ -437,6 +437,10 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
             asm volatile("" : "+s"(g));  // opaque: see lstm_rec_kernel
             asm volatile("" : "+s"(gn));
             const bool hpart = t > 0 && !(GRU && pass == 2);  // h_{-1} = 0; the GRU's nx gate has no recurrent part
+            // ... and its nh gate no input part: skipped from step 1 on in the two-chunk form (with ONE x chunk the skipped pass
+            // would change the parity of the fragment sets' roles; the zero block is multiplied there)
+            const bool xpart = !(GRU && KX == 2 && pass == 1 && t > 0);
+            const bool next_h_first = GRU && KX == 2 && pass == 0 && t > 0;  // the next pass opens with its recurrent product
             f32x4 acc[RT][UG];
             // B0: the fragments this pass starts with, B1: the other set; C0 / C1: the same for the recurrent product
             const bool SW = KX == 1 && (pass & 1);  // (a constant once the passes are unrolled)
@@ -449,7 +453,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
             for (int u = 0; u < UG; ++u) {
                 wx[u] = wxofs(g, u);
                 wh[u] = whofs(g, u);
-                wxn[u] = wxofs(gn, u);
+                wxn[u] = next_h_first ? whofs(gn, u) : wxofs(gn, u);
                 const float b = bias_n[u];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) acc[rt][u] = f32x4{b, b, b, b};
@@ -457,6 +461,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
             }
             // ---- x_t W_ih^T: two chunks (or one) --------------------------------------------------
             if constexpr (KX == 2) {
+              if (xpart) {
 #pragma unroll
                 for (int u = 0; u < UG; ++u) B1[u] = wload(wx[u] + 256u);
                 __builtin_amdgcn_sched_barrier(0);
@@ -465,6 +470,7 @@ __global__ __launch_bounds__((H / (16 * UG)) * 64) __attribute__((amdgpu_num_vgp
                 for (int u = 0; u < UG; ++u) B0[u] = wload(hpart ? wh[u] : wxn[u]);
                 __builtin_amdgcn_sched_barrier(0);
                 mma(acc, xa + 16, 16 * XS, B1);
+              }
             } else {
 #pragma unroll
                 for (int u = 0; u < UG; ++u) B1[u] = wload(hpart ? wh[u] : wxn[u]);

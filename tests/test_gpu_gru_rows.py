@@ -133,3 +133,30 @@ def test_gru_fullsubnet_batch_on_the_persistent_kernels(fsn):
     print(f"GRU FullSubNet, {B} utterances ({rows_p} sub-band rows), {T} frames: max |d| persistent vs per-step {d:.2e}, "
           f"mask range {rows.min():.2f} .. {rows.max():.2f}")
     assert torch.isfinite(rows).all() and float(rows.abs().max()) > 0.05 and d <= 2e-5
+
+
+def test_gru_fullsubnet_at_config2_size_vs_the_oracle(fsn):
+    """BASELINE config 2's shape (64 utterances x 3 s: 16 448 sub-band rows = 4 row tiles on every CU + 4 left-over tiles)
+    with sequence_model = "GRU": the compressed mask of two utterances of the batch against the CPU oracle
+    (oracle/fullsubnet_oracle.py with cell = "GRU", pinned on the reference's var_gru_b2 golden); bound 1e-4 (north star)."""
+    from fsn_synthetic import make_noisy
+    from oracle import fullsubnet_oracle as O
+    from fullsubnet_amd.acoustics.feature import stft
+    kw = dict(num_freqs=257, look_ahead=2, sequence_model="GRU", fb_num_neighbors=0, sb_num_neighbors=15,
+              fb_output_activate_function="ReLU", sb_output_activate_function=False, fb_model_hidden_size=512,
+              sb_model_hidden_size=384, norm_type="offline_laplace_norm", num_groups_in_drop_band=1, weight_init=True)
+    torch.manual_seed(3)
+    m = fsn.Model(**kw)
+    params = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    m = m.cuda().eval()
+    B, L = 64, 48000
+    noisy_np = np.tile(make_noisy(8, L, seed=1), (B // 8, 1))
+    rows = [0, B - 1]
+    with torch.no_grad():
+        mag = stft(torch.from_numpy(noisy_np).cuda(), 512, 256, 512, return_phase=False)[0]
+        assert fsn._lib.lib().fsn_gru_layer_is_persistent(mag.shape[2] + 2, (B * 257 + 15) // 16 * 16, 32, 32, 384) == 1
+        got = m(mag.unsqueeze(1))[rows].cpu().numpy()
+    want = O.fullsubnet_forward(O.stft(noisy_np[rows])[0][:, None], params, cell="GRU", num_groups_in_drop_band=1)
+    err = float(np.abs(got - want).max())
+    print(f"GRU FullSubNet, 64 x 3 s: max |d| of the compressed mask vs the oracle {err:.2e} (mask range {want.min():.2f} .. {want.max():.2f})")
+    assert got.shape == want.shape and np.isfinite(got).all() and float(np.abs(want).max()) > 0.05 and err <= 1e-4
