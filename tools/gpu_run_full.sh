@@ -24,7 +24,7 @@ for A in f32 f16 "f16 saves=32" "f32 norm=cumulative"; do
   grep "train step" $O/train_$N.txt
   rm -rf $O/trace_$N
 done
-for W in "fast 256" "improved48 32" "improved48 1"; do
+for W in "fast 256" "improved48 32" "improved48 1" "gru 64"; do
   set -- $W
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_$1_$2 -- python tools/bench_family.py $1 $2 > $O/fam_$1_$2.txt 2>&1
   DB=$(ls $O/trace_$1_$2/*/*.db 2>/dev/null | head -1)
