@@ -3163,7 +3163,10 @@ static GruPlan gru_layer_plan(int N, int I, long ldx, int H) {
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (cus < 1) cus = 256;
     const int tiles = N / 16;
-    if (tiles < cus) return p;  // fewer than 16 rows per CU: the step launches spread a step over more workgroups
+    // Few rows per CU: the step launches spread a step over more workgroups.  The persistent kernels take 2 - 4 row tiles per
+    // workgroup, so up to 2 x CUs tiles they leave CUs idle and cost what 2 x CUs tiles cost (GRU FullSubNet, 190 frames:
+    // 31.5 - 32.9 ms from 16 to 32 utterances; step by step 1.77 ms per utterance: 26.5 ms at 15, ~30 at 17): from 9/8 x CUs on
+    if (tiles < cus + cus / 8) return p;
     long best = -1;
     for (int rt = 4; rt >= 2; --rt) {
         // whole rounds of rt tiles on every CU, or ONE round of fewer workgroups; a left-over tile costs about a

@@ -372,7 +372,7 @@ int fsn_lstm2_backward_phase(const float* dh1, const float* x, long ldx, const f
  * conventions as the LSTM layer above with 3H gate rows (r, z, n).  save == NULL: inference.  The two
  * bias gradients differ in the n block (b_hn sits inside r * (W_hn h + b_hn)), hence two outputs.
  * Inference with MANY rows (ABI 117; the sub-band model of a GRU FullSubNet, fullsubnet/model.py:121-128 with
- * sequence_model = "GRU"): H = 384, N >= 16 rows per CU and either I <= 32 (a narrow row-major input) or I = H = ldx (the
+ * sequence_model = "GRU"): H = 384, N >= 18 rows per CU and either I <= 32 (a narrow row-major input) or I = H = ldx (the
  * layer above an equally wide one) run on the LSTM's persistent many-row kernels with the GRU written as a four-gate cell
  * (3/4 of the LSTM's matrix work: the two zero blocks are skipped) - fsn_gru_layer_is_persistent says whether; left-over
  * row tiles advance step by step beside the launch.  Results equal the step form's within fp32 rounding. */

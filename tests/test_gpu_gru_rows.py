@@ -47,7 +47,7 @@ def _params(I, H, seed):
 # form (I = H = ldx), with left-over tiles (they advance step by step beside the launch) and without
 CASES = [
     (32, 32, 2, 3),     # rt 2 whole round + 3 left-over tiles, two x chunks
-    (20, 32, 1, 4),     # fewer workgroups than CUs (tiles / 2), I padded to 32
+    (20, 32, 1, 36),    # fewer workgroups than CUs (tiles / 2), I padded to 32
     (12, 16, 3, 0),     # rt 3, ONE x chunk (Fast FullSubNet's bottleneck width)
     (12, 48, 2, 2),     # rows wider than the padded input: the left-over rows' copy goes step by step
     (32, 32, 4, 4),     # rt 4 + left-over: config 2's plan (1028 tiles on 256 CUs)
@@ -65,7 +65,7 @@ def test_gru_layer_many_rows_on_the_persistent_kernels(fsn, I, ldx, per_cu, extr
     tiles = _cus() * per_cu + extra
     N = tiles * 16
     assert L.fsn_gru_layer_is_persistent(T, N, I, ldx, H) == 1
-    assert L.fsn_gru_layer_is_persistent(T, 16 * (_cus() - 1), I, ldx, H) == 0  # few rows: step by step
+    assert L.fsn_gru_layer_is_persistent(T, 16 * (_cus() + _cus() // 8 - 1), I, ldx, H) == 0  # few rows per CU: step by step
     assert L.fsn_gru_layer_is_persistent(T, N, I, ldx, 320) == 0               # built for 384 units
     torch.manual_seed(I + per_cu)
     params = _params(I, H, seed=3 * I + per_cu)
