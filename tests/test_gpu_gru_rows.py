@@ -160,3 +160,22 @@ def test_gru_fullsubnet_at_config2_size_vs_the_oracle(fsn):
     err = float(np.abs(got - want).max())
     print(f"GRU FullSubNet, 64 x 3 s: max |d| of the compressed mask vs the oracle {err:.2e} (mask range {want.min():.2f} .. {want.max():.2f})")
     assert got.shape == want.shape and np.isfinite(got).all() and float(np.abs(want).max()) > 0.05 and err <= 1e-4
+
+
+def test_gru_fullsubnet_call_as_a_hip_graph(fsn):
+    """fullsubnet_amd.GraphedCall on a GRU FullSubNet whose sub-band rows take the persistent kernels with left-over tiles (the fork
+    to the auxiliary stream, the left-over rows' 2-D copies and step launches, the join - all inside the capture): replays are
+    bit-identical to the eager call."""
+    kw = dict(num_freqs=257, look_ahead=2, sequence_model="GRU", fb_num_neighbors=0, sb_num_neighbors=15,
+              fb_output_activate_function="ReLU", sb_output_activate_function=False, fb_model_hidden_size=512,
+              sb_model_hidden_size=384, norm_type="offline_laplace_norm", num_groups_in_drop_band=1, weight_init=True)
+    torch.manual_seed(5)
+    m = fsn.Model(**kw).cuda().eval()
+    B, T = 2 * _cus() * 16 // 257 + 2, 17
+    mag = (torch.rand(B, 1, 257, T, device="cuda") ** 2) * 3.0
+    with torch.no_grad():
+        eager = m(mag).clone()
+    graphed = fsn.GraphedCall(m)
+    first = graphed(mag).clone()
+    again = graphed(mag).clone()
+    assert torch.isfinite(eager).all() and torch.equal(first, eager) and torch.equal(again, eager)
