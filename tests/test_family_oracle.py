@@ -189,7 +189,7 @@ def test_improved_state_dict_keys():
             assert tuple(sd[k].shape) == v.shape, k
 
 
-VARIANTS = ["var_gru_b2", "var_gaussian_b2", "var_cln_b2", "var_forgetting_b2", "var_fbnn2_tanh_b3"]
+VARIANTS = ["var_gru_b2", "var_gaussian_b2", "var_cln_b2", "var_forgetting_b2", "var_fbnn2_tanh_b3", "var_gru_b33"]
 
 
 def variant_inputs(z, meta):

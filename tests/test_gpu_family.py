@@ -552,7 +552,7 @@ def test_improved_fullsubnet_unit_shard_vs_reference(fsn, golden_dir, name, cfg,
 
 
 @pytest.mark.parametrize("name", ["var_gru_b2", "var_gaussian_b2", "var_cln_b2", "var_forgetting_b2",
-                                  "var_fbnn2_tanh_b3"])
+                                  "var_fbnn2_tanh_b3", "var_gru_b33"])
 def test_fullsubnet_constructor_variants_vs_reference(fsn, golden_dir, name):
     """FullSubNet with the constructor options outside the shipped TOMLs (GRU, extra norms, fb neighbours,
     other activations): composed from SequenceModel blocks on the HIP kernels, against the reference model."""
@@ -567,6 +567,10 @@ def test_fullsubnet_constructor_variants_vs_reference(fsn, golden_dir, name):
     with torch.no_grad():
         crm = m(torch.from_numpy(z["mag"]).cuda().unsqueeze(1)).cpu().numpy()
     assert crm.shape == z["crm"].shape
+    if name == "var_gru_b33":  # the reference's own GRU model at a batch whose sub-band rows take the persistent many-row kernels
+        L = fsn._lib.lib()
+        assert L.fsn_gru_layer_is_persistent(z["mag"].shape[2] + 2, (33 * 257 + 15) // 16 * 16, 32, 32, 384) == 1
+        print(f"var_gru_b33: max |d| {np.abs(crm - z['crm']).max():.2e} of a mask range {np.abs(z['crm']).max():.1f}")
     assert np.abs(crm - z["crm"]).max() <= 1e-4  # measured 1.0e-5 .. 2.9e-5
 
 
