@@ -5,9 +5,22 @@
 //   mode bit 1: MFMAs, bit 2: non-linearities, bit 4: a workgroup barrier after every iteration (lockstep),
 //   bit 8: static wave priorities 0 / 1 / 2 among the three waves of a SIMD, bit 16: the non-linearities of iteration i - 1
 //   interleaved by hand into the MFMA stream of iteration i (second register set), bit 32: barrier BEFORE the non-linearities
+// -DPROBE_F16 (round 6, the question the fp32 answer left open for the 16-bit training kernels): the same experiment with
+// v_mfma_f32_16x16x32_f16 (gfx950's K = 32 instruction; 8 cycles of the pipe for 16 x the fp32 instruction's work) - do vector
+// instructions hide under 16-BIT MFMAs?
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifdef PROBE_F16
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define PROBE_OPERAND(x) f16x8{(_Float16)(x), (_Float16)(x), (_Float16)(x), (_Float16)(x), (_Float16)(x), (_Float16)(x), (_Float16)(x), (_Float16)(x)}
+#define PROBE_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+typedef f16x8 probe_op;
+#else
+#define PROBE_OPERAND(x) (x)
+#define PROBE_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+typedef float probe_op;
+#endif
 
 __device__ __forceinline__ float sig(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
@@ -25,7 +38,7 @@ __global__ __launch_bounds__(768) void overlap_kernel(float* out, int iters, flo
     for (int i = 0; i < 8; ++i) acc[i] = f32x4{0, 0, 0, 0}, prev[i] = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
 #pragma unroll
     for (int i = 0; i < 32; ++i) st[i] = 0.01f * i + threadIdx.x * 1e-4f;
-    float a = a0 + (threadIdx.x & 63) * 1e-3f, b = b0 + (threadIdx.x & 63) * 5e-4f;
+    const probe_op a = PROBE_OPERAND(a0 + (threadIdx.x & 63) * 1e-3f), b = PROBE_OPERAND(b0 + (threadIdx.x & 63) * 5e-4f);
     for (int it = 0; it < iters; ++it) {
         if (MODE & 1) {
             if (MODE & 16) {
@@ -35,14 +48,14 @@ __global__ __launch_bounds__(768) void overlap_kernel(float* out, int iters, flo
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                        for (int i = 0; i < 8; ++i) acc[i] = PROBE_MFMA(a, b, acc[i]);
                 }
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                        for (int i = 0; i < 8; ++i) acc[i] = PROBE_MFMA(a, b, acc[i]);
                         if (MODE & 2) st[c * 4 + r] = sig(prev[c][r]) * st[c * 4 + r];
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -58,7 +71,7 @@ __global__ __launch_bounds__(768) void overlap_kernel(float* out, int iters, flo
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                        for (int i = 0; i < 8; ++i) acc[i] = PROBE_MFMA(a, b, acc[i]);
                 }
             }
         }
@@ -104,6 +117,9 @@ int main() {
     float* out;
     hipMalloc(&out, (size_t)256 * 768 * 4);
     const int iters = 760;  // 190 steps x 4 gate passes
+#ifdef PROBE_F16
+    printf("v_mfma_f32_16x16x32_f16 (1536 per wave and iteration = 16 x the fp32 probe's matrix work)\n");
+#endif
     run<1>("MFMAs alone (1536 per wave and iteration, 3 waves per SIMD)", out, iters);
     run<2>("non-linearities alone (32 sigmoids per wave and iteration)", out, iters);
     run<3>("both, free running", out, iters);
