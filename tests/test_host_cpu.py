@@ -84,6 +84,30 @@ def test_two_layer_training_entries_size_queries_without_a_gpu():
     assert L.fsn_lstm2_forward_is_persistent(100, 2048, 16, 48, 384, 384) == 0   # x rows wider than two K chunks
 
 
+def test_gru_many_row_plan_and_workspace_without_a_gpu():
+    """fsn_gru_layer_is_persistent / fsn_gru_layer_fwd_workspace_bytes (ABI 117) answer without a device (256 CUs assumed): the
+    GRU takes the persistent many-row kernels for H = 384, at least 9/8 x CUs row tiles and a narrow row-major input or the layer
+    above an equally wide one; the workspace then holds the four-gate matrices and the left-over rows' compact copies on top of
+    the step form's buffers, and never less than the step form needs."""
+    from fullsubnet_amd import _lib
+    L = _lib.lib()
+    T, H = 190, 384
+    per = lambda N, I, ldx, Hh=H: L.fsn_gru_layer_is_persistent(T, N, I, ldx, Hh)
+    assert per(16448, 32, 32) == 1 and per(16448, 384, 384) == 1 and per(16448, 12, 16) == 1 and per(16448, 20, 48) == 1
+    assert per(16448, 40, 48) == 0        # more than 32 input columns and not the stacked form
+    assert per(16448, 384, 400) == 0      # the stacked form reads the hidden sequence as it lies (ldx = H)
+    assert per(16448, 32, 32, 320) == 0 and per(16448, 32, 32, 512) == 0
+    assert per(16 * 287, 32, 32) == 0 and per(16 * 288, 32, 32) == 1   # from 9/8 x 256 row tiles on
+    assert per(16448 + 8, 32, 32) == 0    # rows in whole 16-row tiles
+    step = lambda N, I: 4 * (3 * H * ((I + 15) // 16 * 16) + 3 * H * H + 3 * H + T * N * 3 * H)
+    for N, I in [(16448, 32), (16448, 384), (4608, 12), (272, 32), (16, 257)]:
+        ws = L.fsn_gru_layer_fwd_workspace_bytes(T, N, I, H)
+        assert ws >= step(N, I), (N, I, ws)
+        if per(N, I, (I + 15) // 16 * 16):
+            assert ws >= step(N, I) + 4 * 2 * (4 * H * ((I + 15) // 16 * 16) + 4 * H * H), (N, I, ws)
+    assert L.fsn_gru_layer_fwd_workspace_bytes(0, 16, 32, H) == 0
+
+
 def test_fast_fullsubnet_glue_queries_without_a_gpu():
     """fsn_fast_low_rate_frames = the length real_time_downsampling produces (fast_fullsubnet/model.py:108-129: frame 0,
     then blocks of `shrink` frames, a shorter last block kept) for every (T, shrink); the workspace query covers the two
