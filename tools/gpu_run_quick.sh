@@ -1,28 +1,15 @@
 #!/bin/bash
 # scratch session: edit, run, read (kept as the one ad-hoc runner)
 export TMPDIR=/tmp
-O=gpurun_out/quick
+O=gpurun_out/gru_pmc
 mkdir -p $O
-for i in 1 2 3 4 5; do
-  timeout 900 python -m pytest tests/test_gpu_gru_rows.py -m gpu -q -x 2>&1 | grep -E "passed|failed" | tee -a $O/gru_soak.txt
+B1="python tools/bench_family.py gru 64"
+i=0
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc/pass$i -- $B1 > $O/pmc_pass$i.log 2>&1
+  echo "pmc pass $i ($C) rc=$?"
 done
-python - <<'PY' 2>&1 | tee -a gpurun_out/quick/gru_soak.txt
-import sys, time, torch
-sys.path.insert(0, "tools")
-import bench_family as BF
-pack = BF.build("gru")
-model = pack[0]
-enh = BF.enhance_fn("gru", model)
-from fsn_synthetic import make_noisy
-y = torch.from_numpy(make_noisy(8, 48000, seed=1)).cuda().repeat(8, 1).contiguous()
-ref = enh(y).clone()
-ts = []
-for i in range(300):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    out = enh(y)
-    torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
-    if not torch.equal(out, ref):
-        print("MISMATCH at call", i); break
-ts = sorted(ts)
-print(f"GRU FullSubNet 64 x 3 s, 300 calls: bit-identical to the first = {torch.equal(out, ref)}; ms median {ts[150]:.2f}, min {ts[0]:.2f}, max {ts[-1]:.2f}")
-PY
+python tools/rocprof_pmc.py $O/pmc $O/pmc_gru.json "lstm_rec_in_kernel" "lstm_rec_x_kernel" "gru_step1_kernel" "linear_small_out" "fb_chain_kernel" > $O/pmc_summary.txt 2>&1
+tail -60 $O/pmc_summary.txt
+rm -rf $O/pmc
