@@ -846,7 +846,8 @@ static int run_recurrence(const float* gx, const FsnSbInput* xin, const float* g
     }
     if (r.main_wgs > 0) {
         if (x_main)
-            FSN_TRY(fsn_launch_lstm_rec_x(x_main, wih_main, whh, bias_main, Tp, Npad, H, r.rt, r.main_wgs, s, fc));
+            FSN_TRY(fsn_launch_lstm_rec_x(x_main, wih_main, whh, bias_main, Tp, Npad, H, r.rt, r.main_wgs, s, fc,
+                                          fc ? nullptr : hseq));  // no output layer: a layer inside a stack, h_t stored
         else if (xin && !fc && !whh_f16x3 && fsn_lstm_rec_in_supported(xin, whh, H, r.rt))
             FSN_TRY(fsn_launch_lstm_rec_in(xin, whh, hseq, Tp, Npad, H, r.rt, r.main_wgs, s));
         else if (whh_f16x3 && fc && !xin && r.rt >= 2)  // experimental split-precision persistent kernel (FSN_F16X3=1)
@@ -1953,6 +1954,56 @@ extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_i
             xin.wih_p = wih_p;
             xin.bias = bias;
             return run_recurrence(nullptr, &xin, nullptr, 0, 0, whh_p, hseq, c_state, T, N, H, plan, s);
+        }
+        // The same two forms with LEFT-OVER row tiles (whole rounds of 2 - 4 tiles per workgroup + a few tiles more: 64 x 257
+        // rows are 256 x 4 tiles + 4): the persistent kernel takes the whole rounds, the left-over rows advance step by step
+        // beside it (run_recurrence) from their own small projection - compact copies of their input rows, one GEMM, formed AHEAD
+        // of the persistent launch (the GEMM's workgroups do not fit beside it) inside the region the full projection would
+        // have taken.  Before: the full [T][N][4H] projection was written and read back for every row (a composed LSTM
+        // FullSubNet at 64 x 3 s: 92 ms per model call against 80 at 62 utterances, whose tiles divide evenly).
+        const bool narrow = Ipad <= 32 && ldx >= Ipad, stacked = I == H && ldx == H && fsn_lstm_rec_x_supported(H, plan.rt);
+        if (plan.main_wgs > 0 && plan.left_tiles > 0 && plan.rt >= 2 && plan.rt <= 4 && (narrow || stacked) && whh_p > wih_p &&
+            (size_t)plan.left_tiles * 16 * ((size_t)4 * H + Ipad) <= (size_t)N * 4 * H) {
+            const int left = plan.left_tiles * 16, main_rows = N - left;
+            float* gx_left = gx;                                  // [T][left / 16 tiles] fragment order
+            float* x_left = gx + (size_t)T * left * 4 * H;        // [T][left][Ipad]
+            bool ok = true;
+            if (ldx == Ipad)
+                ok = hipMemcpy2DAsync(x_left, (size_t)left * Ipad * sizeof(float), x + (size_t)main_rows * ldx,
+                                      (size_t)N * ldx * sizeof(float), (size_t)left * Ipad * sizeof(float), (size_t)T,
+                                      hipMemcpyDeviceToDevice, s) == hipSuccess;
+            else
+                for (int t = 0; t < T && ok; ++t)
+                    ok = hipMemcpy2DAsync(x_left + (size_t)t * left * Ipad, (size_t)Ipad * sizeof(float),
+                                          x + ((size_t)t * N + main_rows) * ldx, (size_t)ldx * sizeof(float),
+                                          (size_t)Ipad * sizeof(float), (size_t)left, hipMemcpyDeviceToDevice, s) == hipSuccess;
+            if (!ok) {
+                fsn_set_error("lstm layer forward: copy of the left-over rows failed");
+                return FSN_ERR_LAUNCH;
+            }
+            FsnGemmA al{};
+            al.kind = 0;
+            al.p0 = x_left;
+            al.ld = Ipad;
+            FsnGemmC cl{};
+            cl.kind = 0;
+            cl.p0 = gx_left;
+            cl.bias = bias;
+            FSN_TRY(fsn_launch_gemm(al, wih_p, cl, T * (left / 16), 4 * H / 16, Ipad / 16, s));
+            float* c_left = c_state + (size_t)main_rows * H;
+            if (narrow) {
+                FsnSbInput xin{};
+                xin.x_rows = x;
+                xin.x_ld = ldx;
+                xin.x_step = N;
+                xin.N = main_rows;
+                xin.kin_chunks = Ipad / 16;
+                xin.wih_p = wih_p;
+                xin.bias = bias;
+                return run_recurrence(nullptr, &xin, gx_left, left / 16, 0, whh_p, hseq, c_left, T, N, H, plan, s);
+            }
+            return run_recurrence(nullptr, nullptr, gx_left, left / 16, 0, whh_p, hseq, c_left, T, N, H, plan, s, nullptr, -1, nullptr,
+                                  nullptr, x, wih_p, bias);
         }
         // a layer of a stack on the persistent kernel (input = the hidden sequence of an equally wide layer below, e.g.
         // the second bottleneck layer of Fast FullSubNet, fast_fullsubnet/model.py:66-74): the K = H projection is
