@@ -1898,6 +1898,33 @@ static FsnRecPlan layer_plan(int N, int H) {
     }
     return p;
 }
+// The same split with SEVERAL whole rounds (more than four row tiles per CU: layer_plan stops at one round of five and hands
+// everything beyond to the step kernels - 96 / 128 utterances of a composed FullSubNet were 518 / 776 left-over tiles, 151 / 216 ms
+// per model call): rounds of 2 - 4 tiles per workgroup on every CU, as many as fit, the rest (fewer than one round) left over.
+static FsnRecPlan layer_plan_rounds(int N, int H) {
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus < 1) cus = 256;
+    const int tiles = N / 16;
+    if (H != 384 || tiles < 2 * cus) return layer_plan(N, H);
+    FsnRecPlan p{};
+    p.tiles = tiles;
+    p.npad = N;
+    long best = -1;
+    for (int rt = 4; rt >= 2; --rt) {
+        const int rounds = tiles / (cus * rt);
+        if (rounds < 1) continue;
+        const int left = tiles - rounds * cus * rt;
+        const long cost = (long)rounds * rt * 100 + left;  // a left-over tile: about a hundredth of a tile of a resident workgroup
+        if (best < 0 || cost < best) {
+            best = cost;
+            p.rt = rt;
+            p.main_wgs = rounds * cus;
+            p.left_tiles = left;
+        }
+    }
+    return p;
+}
 // Rows (a multiple of 16, >= N) a caller that owns the row padding should give a stand-alone layer of N rows: the next count
 // whose plan has no left-over tiles when that is the cheaper plan by the measure above, N itself otherwise.
 extern "C" int fsn_lstm_layer_plan_rows(int N, int H) {
@@ -1943,7 +1970,9 @@ extern "C" int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_i
         // inference with a narrow input on the persistent kernel (e.g. Fast FullSubNet's bottleneck: 12 inputs,
         // 16 384 rows): the K <= 32 projection is formed inside the recurrent kernel from a staged LDS tile,
         // like the sub-band model's layer 0, instead of writing and re-reading a [T][N][4H] projection
-        const FsnRecPlan plan = layer_plan(N, H);
+        FsnRecPlan plan = layer_plan(N, H);
+        if (plan.main_wgs > 0 && (plan.rt > 4 || plan.left_tiles > 16) && (Ipad <= 32 || (I == H && ldx == H)))
+            plan = layer_plan_rounds(N, H);  // more than one round's worth of rows (the two forms below take any grid)
         if (plan.main_wgs > 0 && plan.left_tiles == 0 && Ipad <= 32) {
             FsnSbInput xin{};
             xin.x_rows = x;

@@ -235,14 +235,15 @@ def test_sequence_model_inference_and_training_vs_torch(fsn, cell, I, H, O, laye
 
 
 @pytest.mark.parametrize("I,O,B", [(12, 1, 8192), (24, 0, 8192), (28, 1, 12288), (12, 0, 8300), (24, 1, 8300), (28, 0, 12400),
-                                   (32, 1, 16448)])
+                                   (32, 1, 16448), (24, 1, 24688)])
 def test_stacked_lstm_on_the_persistent_kernels_vs_torch(fsn, I, O, B):
     """A two-layer H = 384 stack with a narrow input on enough rows for the persistent kernels (512 / 768 row tiles: two /
     three per workgroup, nothing left over): layer 0 on lstm_rec_in_kernel's row-major form with one (I <= 16) or two K
     chunks of input, layer 1 on lstm_rec_x_kernel (hidden sequence out, or the fused output layer); 8300 / 12400 / 16448 rows
     (whole rounds of two / three / four tiles per workgroup + 7 / 7 / 4 left-over tiles): the same two kernels on the whole
     rounds, the left-over rows step by step beside them from their own small projection (round 6; before: the full projection
-    GEMM + lstm_rec_kernel).  Against ATen's nn.LSTM / nn.Linear on the CPU (sequence_model.py:52-58)."""
+    GEMM + lstm_rec_kernel); 24688 rows = 1543 tiles: two rounds of three tiles per workgroup + 7 left over (before: one round of
+    five and 263 tiles step by step).  Against ATen's nn.LSTM / nn.Linear on the CPU (sequence_model.py:52-58)."""
     from fullsubnet_amd.sequence_model import SequenceModel
     torch.manual_seed(I + B)
     T, H = 5, 384
