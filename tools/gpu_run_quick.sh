@@ -1,9 +1,10 @@
 #!/bin/bash
 # scratch session: edit, run, read (kept as the one ad-hoc runner)
 export TMPDIR=/tmp
-O=gpurun_out/quick
+O=gpurun_out/r06s18
 mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_family.py -m gpu -q -x -k "stacked_lstm_on_the_persistent or composed_variants or sequence_model_inference or fast" 2>&1 | grep -v "^$" | tail -8 | tee $O/tests_lstm_rounds.txt
-for B in 128 96 80 64; do timeout 300 python tools/bench_composed_lstm.py $B 2>&1 | tail -1 | tee -a $O/composed_lstm3.txt; done
-timeout 300 python tools/bench_family.py fast 512 2>&1 | tail -1 | tee -a $O/composed_lstm3.txt
-timeout 300 python tools/bench_family.py fast 256 2>&1 | tail -1 | tee -a $O/composed_lstm3.txt
+# the driver's own sequence on the final tree: smoke, the GPU suite, the default bench line; then the 10-step bench line
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee $O/smoke.txt
+(time timeout 1500 python -m pytest tests -x -q -m gpu) > $O/pytest1.log 2>&1; echo "rc=$?" >> $O/pytest1.log; grep -E "passed|failed|rc=" $O/pytest1.log | tail -2
+(time timeout 900 python bench.py) > $O/bench_default.json 2> $O/bench_default.err; grep real $O/bench_default.err
+(time timeout 900 python bench.py --steps 10 --warmup 3) > $O/bench.json 2> $O/bench.err; grep real $O/bench.err
