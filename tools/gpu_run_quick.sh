@@ -1,3 +1,7 @@
 #!/bin/bash
 # scratch session: edit, run, read (kept as the one ad-hoc runner)
-bash tools/gpu_run_nocache.sh nocache_final 2>&1 | tee gpurun_out/nocache_final.txt
+export TMPDIR=/tmp
+O=gpurun_out/quick
+mkdir -p $O
+rm -f $O/fast_sweep.txt
+for B in 72 80 100 144 200 208 240; do timeout 300 python tools/bench_family.py fast $B 2>&1 | tail -1 | tee -a $O/fast_sweep.txt; done
