@@ -3,5 +3,9 @@
 export TMPDIR=/tmp
 O=gpurun_out/quick
 mkdir -p $O
-rm -f $O/fast_sweep.txt
-for B in 72 80 100 144 200 208 240; do timeout 300 python tools/bench_family.py fast $B 2>&1 | tail -1 | tee -a $O/fast_sweep.txt; done
+for B in 64 72; do
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace$B -- python tools/bench_family.py fast $B > $O/fam_fast_$B.txt 2>&1
+DB=$(ls $O/trace$B/*/*.db 2>/dev/null | head -1)
+[ -n "$DB" ] && python tools/rocprof_summary.py $DB $O/kernel_stats_fast_b$B.md "rocprofv3 --kernel-trace --stats -- python tools/bench_family.py fast $B"
+rm -rf $O/trace$B
+done
