@@ -870,3 +870,24 @@ def test_improved_fullsubnet_offline_norm_of_a_five_dimensional_tensor(fsn):
     want = IB.offline_laplace_norm(x.double()).float()
     got = IB.offline_laplace_norm(x.cuda())
     assert (got.cpu() - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("I,ldx,rows", [(12, 48, 8304), (20, 32, 8304), (384, 384, 8304), (12, 16, 24688)])
+def test_lstm_layer_with_left_over_tiles_on_the_persistent_kernels_vs_torch(fsn, I, ldx, rows):
+    """fsn_lstm_layer_forward (inference) on row counts whose 16-row tiles do not divide into whole rounds (519 = 256 x 2 + 7,
+    1543 = 512 x 3 + 7): the persistent kernels on the whole rounds, the left-over rows step by step beside them from their own
+    small projection - input rows wider than the padded input (their compact copy goes step by step), a padded input width, the
+    stacked form (I = H = ldx), several rounds.  Against ATen's nn.LSTM on the CPU (sequence_model.py:52-58), last rows included."""
+    from fullsubnet_amd import sequence_model as SM
+    torch.manual_seed(I + rows)
+    T, H = 6, 384
+    ref = torch.nn.LSTM(I, H, 1)
+    x = torch.zeros(T, rows, ldx)
+    x[:, :, :I] = torch.randn(T, rows, I)
+    with torch.no_grad():
+        want = ref(x[:, :, :I].contiguous())[0]
+        p = [getattr(ref, n + "_l0").detach().cuda().contiguous() for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        got = SM.lstm_layer_infer(x.cuda(), *p).cpu()
+    d = (got - want).abs()
+    print(f"LSTM layer I = {I} (ldx {ldx}), {rows} rows: max |d| {d.max():.2e}, last 7 tiles {d[:, -112:].max():.2e}")
+    assert got.shape == want.shape and d.max().item() <= 2e-5
