@@ -3,4 +3,4 @@
 export TMPDIR=/tmp
 O=gpurun_out/quick
 mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_family.py -m gpu -q -x -s -k "left_over_tiles_on_the_persistent" 2>&1 | grep -v "^$" | tail -8 | tee $O/tests_lstm_left2.txt
+(time timeout 1500 python -m pytest tests -x -q -m gpu) > $O/pytest_final.log 2>&1; echo "rc=$?" >> $O/pytest_final.log; grep -E "passed|failed|rc=" $O/pytest_final.log | tail -2
