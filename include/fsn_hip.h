@@ -195,7 +195,10 @@ int fsn_fullsubnet_stream_step(const fsn_fullsubnet_cfg* cfg, const void* packed
  * with all-zero weights and biases stay at h = c = 0, exactly).  `save` keeps the activated gates and
  * the cell sequence for the backward pass; save == NULL is inference mode (SequenceModel.forward under
  * no_grad, sequence_model.py:106-125): nothing but hseq is kept and, for H = 384, the rows run on the
- * persistent recurrent kernel of the sub-band model. */
+ * persistent recurrent kernels of the sub-band model - with a narrow input (I <= 32) or as the layer above an
+ * equally wide one (I = H = ldx) on the forms that build their input projection themselves, in whole rounds of
+ * 2 - 4 row tiles per workgroup (several rounds beyond four tiles per CU); row tiles left over advance step by step
+ * beside the launch from their own small projection (round 6). */
 size_t fsn_lstm_layer_save_bytes(int T, int N, int H);
 size_t fsn_lstm_layer_fwd_workspace_bytes(int T, int N, int I, int H);
 int fsn_lstm_layer_forward(const float* x, long ldx, const float* w_ih, const float* w_hh, const float* b_ih,
